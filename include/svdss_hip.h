@@ -1,0 +1,112 @@
+/*
+ * svdss_hip.h -- C ABI of the MI355X-native SVDSS hot path (libsvdss_hip.so).
+ *
+ * Drop-in boundary B2 of SURVEY.md section 8(b): the reference (Parsoa/SVDSS
+ * v2.1.1) has no plugin layer; the seam is where its stage drivers call into
+ * per-item kernels and third-party C functions.  Each entry point below cites
+ * the reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions: plain-old-data in and out, caller-owned buffers, int status
+ * return (0 = ok; the host turns non-zero into a stderr message + exit(1)
+ * like ping_pong.cpp:62-63), no exceptions across the ABI, no torch types.
+ * Symbols use ropebwt3's nt6 alphabet: $=0 A=1 C=2 G=3 T=4 N/other=5.
+ */
+#ifndef SVDSS_HIP_H
+#define SVDSS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVDSS_OK 0
+#define SVDSS_EINVAL 1    /* bad argument */
+#define SVDSS_ENOMEM 2    /* host or device allocation failed */
+#define SVDSS_EIO 3       /* file could not be read/written or has a bad format */
+#define SVDSS_EHIP 4      /* a HIP runtime call failed (no GPU, launch error, ...) */
+#define SVDSS_ENODEV 5    /* index is not resident on a device */
+#define SVDSS_ERANGE 6    /* input exceeds a layout limit (per-symbol count >= 2^32, read >= 2^31) */
+
+const char* svdss_strerror(int code);
+/* Last HIP error string seen by this library on the calling thread ("" if none). */
+const char* svdss_last_hip_error(void);
+
+/* ---- a1: base -> nt6 ----------------------------------------------------
+ * Replaces seq_nt6_table (ping_pong.hpp:46-52) as applied at
+ * ping_pong.cpp:90-94 (BAM path) and rb3_char2nt6 at ping_pong.cpp:158. */
+int svdss_nt6_encode(const char* seq, int64_t n, uint8_t* out);
+
+/* ---- a5: FM-index -------------------------------------------------------
+ * svdss_index_build replaces `ropebwt3 build` re-exported as `SVDSS index`
+ * (main.cpp:15-17,34-37); svdss_index_load replaces rb3_fmi_restore
+ * (ping_pong.cpp:245).  contigs = concatenated nt6 symbols of all records,
+ * lens[i] symbols each.  The index covers every record and its reverse
+ * complement, each '$'-terminated. */
+typedef struct svdss_index svdss_index_t;
+
+int svdss_index_build(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
+                      int32_t threads, svdss_index_t** out);
+int svdss_index_save(const svdss_index_t* ix, const char* path);
+int svdss_index_load(const char* path, svdss_index_t** out);
+void svdss_index_free(svdss_index_t* ix);
+/* number of BWT symbols, = sum_i 2*(lens[i]+1) */
+int64_t svdss_index_size(const svdss_index_t* ix);
+/* acc[c] = number of symbols < c (rb3_fmi_t::acc, used by rb3_fmd_set_intv) */
+int svdss_index_acc(const svdss_index_t* ix, int64_t acc[7]);
+/* decode the BWT as nt6 bytes (svdss_index_size() of them) */
+int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out);
+/* bytes the index occupies in HBM once resident */
+int64_t svdss_index_device_bytes(const svdss_index_t* ix);
+/* copy the index into the HBM of `device` (replicated per GPU) */
+int svdss_index_to_device(svdss_index_t* ix, int32_t device);
+
+/* Size of the interval of a pattern (occurrences in contigs + revcomps) via
+ * the host copy of the index; rb3_fmd_set_intv + repeated rb3_fmd_extend(...,1)
+ * as in ping_pong.cpp:12-22.  For tests/diagnostics; not a hot path. */
+int64_t svdss_index_count(const svdss_index_t* ix, const uint8_t* pattern_nt6, int64_t len);
+
+/* ---- a2+a3+a4 (+a8): batched ping-pong SFS search -----------------------
+ * Replaces PingPong::ping_pong_search (ping_pong.hpp:84-85, ping_pong.cpp:4-49)
+ * called per read from PingPong::process_batch (ping_pong.cpp:176-209), i.e.
+ * the rb3_fmd_set_intv / rb3_fmd_extend loops, for a whole batch at once.
+ *
+ * reads    : concatenated nt6 symbols; read i = reads[offsets[i] .. offsets[i+1])
+ *            (no terminator byte needed; the P[l]=0 of ping_pong.cpp:94 is implied)
+ * flags    : SVDSS_SFS_ASSEMBLE applies Assembler::assemble (assembler.cpp:34-56)
+ *            per read as ping_pong.cpp:219-222 does unless --noassemble.
+ * Results per read i: counts[i] records (qs,len); without ASSEMBLE in the
+ * order ping_pong.cpp:41 pushes them (descending qs), with ASSEMBLE ascending
+ * qs (assembler.cpp:36).  n_ext[i] = number of rb3_fmd_extend calls the
+ * reference would have made for that read (ping_pong.cpp:20,35).
+ * overlap is fixed at -1 (config.hpp:87; the option is never declared,
+ * config.cpp:30-55,74). */
+#define SVDSS_SFS_ASSEMBLE 1
+
+typedef struct svdss_sfs_batch svdss_sfs_batch_t;
+
+/* Host-buffer entry point: uploads, searches on the index's device, leaves
+ * results in *out (created if *out == NULL, otherwise its buffers are reused). */
+int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* reads, const int64_t* offsets,
+                           int64_t n_reads, int32_t flags, svdss_sfs_batch_t** out);
+/* Device-buffer entry point: d_reads/d_offsets already resident in HBM on the
+ * index's device; work is enqueued on `stream` (a hipStream_t, NULL = default
+ * stream) and is complete when this returns. */
+int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint8_t* d_reads,
+                                  const int64_t* d_offsets, int64_t n_reads, int64_t total_syms,
+                                  int32_t flags, void* stream, svdss_sfs_batch_t** out);
+int64_t svdss_sfs_batch_nreads(const svdss_sfs_batch_t* b);
+int64_t svdss_sfs_batch_total(const svdss_sfs_batch_t* b);       /* sum of counts */
+int64_t svdss_sfs_batch_total_ext(const svdss_sfs_batch_t* b);   /* sum of n_ext */
+/* duration of the search kernel of the last call, from HIP events on its stream */
+double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b);
+/* copy results to host; any pointer may be NULL to skip it.
+ * counts,n_ext: n_reads entries; qs,len: svdss_sfs_batch_total() entries. */
+int svdss_sfs_batch_fetch(const svdss_sfs_batch_t* b, int64_t* counts, int32_t* qs, int32_t* len,
+                          int64_t* n_ext);
+void svdss_sfs_batch_free(svdss_sfs_batch_t* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVDSS_HIP_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of libsvdss_hip.so (the C-ABI declared in include/svdss_hip.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared
+object is missing this module raises at import time; if no GPU is present the
+compute entry points return SVDSS_EHIP and the wrappers raise SvdssError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvdss_hip.so")
+
+SVDSS_OK = 0
+SVDSS_SFS_ASSEMBLE = 1
+
+
+class SvdssError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib.svdss_strerror(code).decode()
+        hip = lib.svdss_last_hip_error().decode()
+        super().__init__(f"{where}: {msg} (code {code})" + (f" [{hip}]" if hip else ""))
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C svdss_amd/csrc` (hipcc, gfx950). There is no CPU fallback."
+        )
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_pi64 = C.POINTER(C.c_int64)
+_pi32 = C.POINTER(C.c_int32)
+_pu8 = C.POINTER(C.c_uint8)
+
+# every symbol declared in include/svdss_hip.h: (restype, argtypes)
+SIGNATURES = {
+    "svdss_strerror": (C.c_char_p, [C.c_int]),
+    "svdss_last_hip_error": (C.c_char_p, []),
+    "svdss_nt6_encode": (C.c_int, [C.c_char_p, _i64, _p]),
+    "svdss_index_build": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
+    "svdss_index_save": (C.c_int, [_p, C.c_char_p]),
+    "svdss_index_load": (C.c_int, [C.c_char_p, C.POINTER(_p)]),
+    "svdss_index_free": (None, [_p]),
+    "svdss_index_size": (_i64, [_p]),
+    "svdss_index_acc": (C.c_int, [_p, _p]),
+    "svdss_index_bwt": (C.c_int, [_p, _p]),
+    "svdss_index_device_bytes": (_i64, [_p]),
+    "svdss_index_to_device": (C.c_int, [_p, _i32]),
+    "svdss_index_count": (_i64, [_p, _p, _i64]),
+    "svdss_sfs_search_batch": (C.c_int, [_p, _p, _p, _i64, _i32, C.POINTER(_p)]),
+    "svdss_sfs_search_batch_device": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, C.POINTER(_p)]),
+    "svdss_sfs_batch_nreads": (_i64, [_p]),
+    "svdss_sfs_batch_total": (_i64, [_p]),
+    "svdss_sfs_batch_total_ext": (_i64, [_p]),
+    "svdss_sfs_batch_kernel_ms": (C.c_double, [_p]),
+    "svdss_sfs_batch_fetch": (C.c_int, [_p, _p, _p, _p, _p]),
+    "svdss_sfs_batch_free": (None, [_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == symbol missing from the .so
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(code, where):
+    if code != SVDSS_OK:
+        raise SvdssError(code, where)

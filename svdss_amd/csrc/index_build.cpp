@@ -1,0 +1,274 @@
+// index_build.cpp -- host-side construction of the HBM FM-index layout.
+//
+// Stands where `SVDSS index` = ropebwt3 `main_build` stands in the reference
+// (/root/reference/main.cpp:15-17,34-37): it turns the FASTA records into the
+// index that `SVDSS search` restores (ping_pong.cpp:245).  The on-disk format
+// is this repo's own (fmd_layout.h); rld0 import/export is SURVEY 8(f) item 1.
+//
+// Suffix sorting: one parallel sort on 63-bit keys (first 21 symbols, 3 bits
+// each) followed by prefix doubling restricted to the still-tied groups
+// (Larsson-Sadakane style, Jacobi updates so groups can be refined in
+// parallel).  On near-random DNA almost every suffix is a singleton after the
+// key sort, so the doubling rounds touch only repeats.
+#include <omp.h>
+#include <parallel/algorithm>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "../../include/svdss_hip.h"
+#include "index_host.h"
+
+namespace {
+
+constexpr int KEY_SYMS = 21;
+
+template <class I>
+struct KeyPos {
+  uint64_t k;
+  I p;
+};
+
+template <class I>
+void suffix_array(const uint8_t* t, int64_t n, std::vector<I>& sa, int threads) {
+  sa.resize((size_t)n);
+  if (n == 0) return;
+  std::vector<I> rank((size_t)n);
+  std::vector<std::pair<int64_t, int64_t>> groups;  // [start,end) with size > 1
+  {
+    std::vector<KeyPos<I>> kp((size_t)n);
+    const int64_t chunk = 1 << 20;
+    const int64_t nchunks = (n + chunk - 1) / chunk;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (int64_t c = 0; c < nchunks; ++c) {
+      const int64_t s = c * chunk, e = std::min(n, s + chunk);
+      uint64_t k = 0;
+      for (int64_t i = std::min(n, e + KEY_SYMS) - 1; i >= s; --i) {
+        k = (k >> 3) | ((uint64_t)t[i] << 60);
+        if (i < e) { kp[(size_t)i].k = k; kp[(size_t)i].p = (I)i; }
+      }
+    }
+    // the recurrence above starts mid-text for all chunks but the last: bits of
+    // symbols beyond i+20 are shifted out, so keys are exact.
+    omp_set_num_threads(threads);
+    __gnu_parallel::sort(kp.begin(), kp.end(),
+                         [](const KeyPos<I>& a, const KeyPos<I>& b) { return a.k < b.k; });
+    int64_t i = 0;
+    while (i < n) {
+      int64_t j = i + 1;
+      while (j < n && kp[(size_t)j].k == kp[(size_t)i].k) ++j;
+      if (j - i > 1) groups.emplace_back(i, j);
+      i = j;
+    }
+    // ranks = start index of the group (serial boundary scan above, parallel fill here)
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t x = 0; x < n; ++x) {
+      sa[(size_t)x] = kp[(size_t)x].p;
+      rank[(size_t)kp[(size_t)x].p] = (I)x;  // singleton default
+    }
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 256)
+    for (int64_t g = 0; g < (int64_t)groups.size(); ++g)
+      for (int64_t x = groups[(size_t)g].first; x < groups[(size_t)g].second; ++x)
+        rank[(size_t)sa[(size_t)x]] = (I)groups[(size_t)g].first;
+  }
+
+  std::vector<I> nr((size_t)n);
+  int64_t h = KEY_SYMS;
+  while (!groups.empty()) {
+    const int64_t ng = (int64_t)groups.size();
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> next((size_t)threads);
+#pragma omp parallel num_threads(threads)
+    {
+      std::vector<std::pair<int64_t, I>> buf;  // (rank of suffix p+h, p)
+      auto& mine = next[(size_t)omp_get_thread_num()];
+#pragma omp for schedule(dynamic, 64)
+      for (int64_t g = 0; g < ng; ++g) {
+        const int64_t s = groups[(size_t)g].first, e = groups[(size_t)g].second;
+        buf.resize((size_t)(e - s));
+        for (int64_t x = s; x < e; ++x) {
+          const int64_t p = (int64_t)sa[(size_t)x];
+          const int64_t q = p + h;
+          buf[(size_t)(x - s)] = {q < n ? (int64_t)rank[(size_t)q] : -1, (I)p};
+        }
+        std::sort(buf.begin(), buf.end());
+        int64_t sub = s;
+        for (int64_t x = s; x < e; ++x) {
+          if (x > s && buf[(size_t)(x - s)].first != buf[(size_t)(x - s - 1)].first) {
+            if (x - sub > 1) mine.emplace_back(sub, x);
+            sub = x;
+          }
+          sa[(size_t)x] = buf[(size_t)(x - s)].second;
+          nr[(size_t)x] = (I)sub;
+        }
+        if (e - sub > 1) mine.emplace_back(sub, e);
+      }
+#pragma omp barrier
+      // Jacobi update: ranks change only after every group was sorted with the old ranks
+#pragma omp for schedule(dynamic, 64)
+      for (int64_t g = 0; g < ng; ++g)
+        for (int64_t x = groups[(size_t)g].first; x < groups[(size_t)g].second; ++x)
+          rank[(size_t)sa[(size_t)x]] = nr[(size_t)x];
+    }
+    groups.clear();
+    for (auto& v : next) groups.insert(groups.end(), v.begin(), v.end());
+    h *= 2;
+  }
+}
+
+}  // namespace
+
+int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
+                           int32_t threads, svdss_index* ix) {
+  if (!contigs || !lens || n_contigs <= 0 || !ix) return SVDSS_EINVAL;
+  if (threads < 1) threads = 1;
+  int64_t n = 0;
+  for (int i = 0; i < n_contigs; ++i) {
+    if (lens[i] < 0) return SVDSS_EINVAL;
+    n += 2 * (lens[i] + 1);
+  }
+  std::vector<uint8_t> t;
+  try { t.resize((size_t)n); } catch (...) { return SVDSS_ENOMEM; }
+  {
+    int64_t o = 0, src = 0;
+    for (int i = 0; i < n_contigs; ++i) {
+      const int64_t l = lens[i];
+      for (int64_t j = 0; j < l; ++j) {
+        const uint8_t c = contigs[src + j];
+        if (c < 1 || c > 5) return SVDSS_EINVAL;  // '$' cannot appear inside a record
+        t[(size_t)(o + j)] = c;
+      }
+      o += l;
+      t[(size_t)o++] = 0;
+      for (int64_t j = l - 1; j >= 0; --j) t[(size_t)o++] = (uint8_t)svdss_comp(contigs[src + j]);
+      t[(size_t)o++] = 0;
+      src += l;
+    }
+  }
+  std::vector<uint8_t> bwt;
+  try {
+    bwt.resize((size_t)n);
+    if (n < (int64_t)0x7fffffff) {
+      std::vector<int32_t> sa;
+      suffix_array<int32_t>(t.data(), n, sa, threads);
+#pragma omp parallel for num_threads(threads) schedule(static)
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t p = sa[(size_t)i];
+        bwt[(size_t)i] = t[(size_t)(p == 0 ? n - 1 : p - 1)];
+      }
+    } else {
+      std::vector<int64_t> sa;
+      suffix_array<int64_t>(t.data(), n, sa, threads);
+#pragma omp parallel for num_threads(threads) schedule(static)
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t p = sa[(size_t)i];
+        bwt[(size_t)i] = t[(size_t)(p == 0 ? n - 1 : p - 1)];
+      }
+    }
+  } catch (...) { return SVDSS_ENOMEM; }
+  std::vector<uint8_t>().swap(t);
+
+  ix->n = n;
+  ix->n_contigs = n_contigs;
+  const int64_t nb = n / SVDSS_BLOCK_SYMS + 1;
+  try { ix->blocks.assign((size_t)(4 * nb), svdss_u4{0, 0, 0, 0}); } catch (...) { return SVDSS_ENOMEM; }
+  // per-block symbol counts, then exclusive prefix over blocks
+  std::vector<int64_t> bc((size_t)(nb * 6), 0);
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t s = b * SVDSS_BLOCK_SYMS, e = std::min(n, s + SVDSS_BLOCK_SYMS);
+    int64_t* c = &bc[(size_t)(b * 6)];
+    svdss_u4* q = &ix->blocks[(size_t)(4 * b)];
+    for (int64_t i = s; i < e; ++i) {
+      const uint8_t sym = bwt[(size_t)i];
+      c[sym]++;
+      const int j = (int)((i - s) >> 5), bit = (int)((i - s) & 31);
+      if (sym >= 1 && sym <= 4) {
+        const uint32_t code = sym - 1u;
+        q[j].y |= (code & 1u) << bit;
+        q[j].z |= ((code >> 1) & 1u) << bit;
+      } else {
+        q[j].w |= 1u << bit;
+        if (sym == 5) q[j].y |= 1u << bit;
+      }
+    }
+  }
+  int64_t run[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t b = 0; b < nb; ++b) {
+    for (int c = 1; c <= 4; ++c) {
+      if (run[c] > (int64_t)0xffffffffLL) return SVDSS_ERANGE;
+      ix->blocks[(size_t)(4 * b + (c - 1))].x = (uint32_t)run[c];
+    }
+    for (int c = 0; c < 6; ++c) run[c] += bc[(size_t)(b * 6 + c)];
+  }
+  ix->acc[0] = 0;
+  for (int c = 0; c < 6; ++c) ix->acc[c + 1] = ix->acc[c] + run[c];
+  ix->dollar.clear();
+  for (int64_t i = 0; i < n; ++i)
+    if (bwt[(size_t)i] == 0) ix->dollar.push_back(i);
+  return SVDSS_OK;
+}
+
+void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt) {
+  for (int64_t i = 0; i < ix->n; ++i) {
+    const svdss_u4& q = ix->blocks[(size_t)(4 * (i >> SVDSS_BLOCK_SHIFT) + ((i >> 5) & 3))];
+    const int bit = (int)(i & 31);
+    const uint32_t p0 = (q.y >> bit) & 1u, p1 = (q.z >> bit) & 1u, p2 = (q.w >> bit) & 1u;
+    bwt[i] = p2 ? (p0 ? 5 : 0) : (uint8_t)(1u + (p1 << 1 | p0));
+  }
+}
+
+namespace {
+struct FileHeader {
+  char magic[8];  // "SVDSSFM1"
+  int64_t n;
+  int64_t acc[7];
+  int64_t n_blocks;
+  int64_t n_dollar;
+  int32_t n_contigs;
+  int32_t block_syms;
+};
+}  // namespace
+
+int svdss_index_save_host(const svdss_index* ix, const char* path) {
+  FILE* f = fopen(path, "wb");
+  if (!f) return SVDSS_EIO;
+  FileHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "SVDSSFM1", 8);
+  h.n = ix->n;
+  memcpy(h.acc, ix->acc, sizeof h.acc);
+  h.n_blocks = (int64_t)ix->blocks.size() / 4;
+  h.n_dollar = (int64_t)ix->dollar.size();
+  h.n_contigs = ix->n_contigs;
+  h.block_syms = SVDSS_BLOCK_SYMS;
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  ok = ok && fwrite(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
+  ok = ok && fwrite(ix->dollar.data(), sizeof(int64_t), ix->dollar.size(), f) == ix->dollar.size();
+  ok = (fclose(f) == 0) && ok;
+  return ok ? SVDSS_OK : SVDSS_EIO;
+}
+
+int svdss_index_load_host(const char* path, svdss_index* ix) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return SVDSS_EIO;
+  FileHeader h;
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SVDSSFM1", 8) != 0 ||
+      h.block_syms != SVDSS_BLOCK_SYMS || h.n < 0 || h.n_blocks != h.n / SVDSS_BLOCK_SYMS + 1 ||
+      h.n_dollar < 0) {
+    fclose(f);
+    return SVDSS_EIO;
+  }
+  ix->n = h.n;
+  memcpy(ix->acc, h.acc, sizeof h.acc);
+  ix->n_contigs = h.n_contigs;
+  try {
+    ix->blocks.resize((size_t)(4 * h.n_blocks));
+    ix->dollar.resize((size_t)h.n_dollar);
+  } catch (...) { fclose(f); return SVDSS_ENOMEM; }
+  bool ok = fread(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
+  ok = ok && fread(ix->dollar.data(), sizeof(int64_t), ix->dollar.size(), f) == ix->dollar.size();
+  fclose(f);
+  return ok ? SVDSS_OK : SVDSS_EIO;
+}

@@ -1,0 +1,26 @@
+// index_host.h -- host-side index object behind the opaque svdss_index_t.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "fmd_layout.h"
+
+struct svdss_index {
+  int64_t n = 0;              // BWT length = sum over contigs of 2*(len+1)
+  int64_t acc[7] = {0};
+  int32_t n_contigs = 0;
+  std::vector<svdss_u4> blocks;   // 4 * (n/128 + 1) quarters
+  std::vector<int64_t> dollar;    // sorted BWT positions of '$'
+  // device residency (filled by svdss_index_to_device)
+  int device = -1;
+  void* d_blocks = nullptr;
+  void* d_dollar = nullptr;
+};
+
+// Builds text (contig $ revcomp $ ...), suffix array, BWT and the block layout.
+// Returns 0 or a SVDSS_E* code.
+int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
+                           int32_t threads, svdss_index* out);
+int svdss_index_save_host(const svdss_index* ix, const char* path);
+int svdss_index_load_host(const char* path, svdss_index* ix);
+void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt);

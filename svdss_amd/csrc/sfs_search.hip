@@ -1,0 +1,516 @@
+// sfs_search.hip -- gfx950 kernels and C-ABI for the SFS-extraction hot path.
+//
+// Replaces PingPong::ping_pong_search + the rb3_fmd_* calls under it
+// (/root/reference/ping_pong.cpp:4-49) and the per-read Assembler::assemble
+// (/root/reference/assembler.cpp:34-56) for a whole batch of reads
+// (PingPong::process_batch, ping_pong.cpp:176-209).
+//
+// Mapping: one read per lane, persistent lanes that pull the next read from a
+// global counter when they finish (reads differ up to 2x in the number of
+// extensions they need).  Every loop iteration performs exactly one LF step
+// per active lane = one (two while the interval still spans blocks) 64-byte
+// BWT block fetch; see sfs_core.h for the flattened state machine.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/svdss_hip.h"
+#include "fmd_layout.h"
+#include "index_host.h"
+#include "sfs_core.h"
+#include "sym_window.h"
+
+// ------------------------------------------------------------------ errors
+
+static thread_local std::string g_hip_err;
+
+#define HIPCHK(expr)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+      return (e_ == hipErrorOutOfMemory) ? SVDSS_ENOMEM : SVDSS_EHIP;             \
+    }                                                                             \
+  } while (0)
+
+extern "C" const char* svdss_strerror(int code) {
+  switch (code) {
+    case SVDSS_OK: return "ok";
+    case SVDSS_EINVAL: return "invalid argument";
+    case SVDSS_ENOMEM: return "out of memory";
+    case SVDSS_EIO: return "i/o error or bad index file";
+    case SVDSS_EHIP: return "HIP runtime error (is a GPU present?)";
+    case SVDSS_ENODEV: return "index is not resident on a device";
+    case SVDSS_ERANGE: return "input exceeds a layout limit";
+    default: return "unknown error";
+  }
+}
+
+extern "C" const char* svdss_last_hip_error(void) { return g_hip_err.c_str(); }
+
+// --------------------------------------------------------------------- a1
+
+extern "C" int svdss_nt6_encode(const char* seq, int64_t n, uint8_t* out) {
+  if ((!seq || !out) && n > 0) return SVDSS_EINVAL;
+  // seq_nt6_table, ping_pong.hpp:46-52: A/a=1 C/c=2 G/g=3 T/t=4, NUL=0, rest 5
+  for (int64_t i = 0; i < n; ++i) {
+    const unsigned char ch = (unsigned char)seq[i];
+    uint8_t v = 5;
+    switch (ch) {
+      case 0: v = 0; break;
+      case 'A': case 'a': v = 1; break;
+      case 'C': case 'c': v = 2; break;
+      case 'G': case 'g': v = 3; break;
+      case 'T': case 't': v = 4; break;
+      default: break;
+    }
+    out[i] = v;
+  }
+  return SVDSS_OK;
+}
+
+// ------------------------------------------------------------------ index
+
+extern "C" int svdss_index_build(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
+                                 int32_t threads, svdss_index_t** out) {
+  if (!out) return SVDSS_EINVAL;
+  svdss_index* ix = new (std::nothrow) svdss_index();
+  if (!ix) return SVDSS_ENOMEM;
+  int rc = svdss_index_build_host(contigs, lens, n_contigs, threads, ix);
+  if (rc != SVDSS_OK) { delete ix; return rc; }
+  *out = ix;
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_index_save(const svdss_index_t* ix, const char* path) {
+  if (!ix || !path) return SVDSS_EINVAL;
+  return svdss_index_save_host(ix, path);
+}
+
+extern "C" int svdss_index_load(const char* path, svdss_index_t** out) {
+  if (!path || !out) return SVDSS_EINVAL;
+  svdss_index* ix = new (std::nothrow) svdss_index();
+  if (!ix) return SVDSS_ENOMEM;
+  int rc = svdss_index_load_host(path, ix);
+  if (rc != SVDSS_OK) { delete ix; return rc; }
+  *out = ix;
+  return SVDSS_OK;
+}
+
+extern "C" void svdss_index_free(svdss_index_t* ix) {
+  if (!ix) return;
+  if (ix->device >= 0) {
+    (void)hipSetDevice(ix->device);
+    if (ix->d_blocks) (void)hipFree(ix->d_blocks);
+    if (ix->d_dollar) (void)hipFree(ix->d_dollar);
+  }
+  delete ix;
+}
+
+extern "C" int64_t svdss_index_size(const svdss_index_t* ix) { return ix ? ix->n : -1; }
+
+extern "C" int svdss_index_acc(const svdss_index_t* ix, int64_t acc[7]) {
+  if (!ix || !acc) return SVDSS_EINVAL;
+  memcpy(acc, ix->acc, sizeof ix->acc);
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out) {
+  if (!ix || !bwt_out) return SVDSS_EINVAL;
+  svdss_index_decode_bwt(ix, bwt_out);
+  return SVDSS_OK;
+}
+
+extern "C" int64_t svdss_index_device_bytes(const svdss_index_t* ix) {
+  if (!ix) return -1;
+  return (int64_t)(ix->blocks.size() * sizeof(svdss_u4) + ix->dollar.size() * sizeof(int64_t));
+}
+
+extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
+  if (!ix || device < 0) return SVDSS_EINVAL;
+  HIPCHK(hipSetDevice(device));
+  if (ix->device >= 0) {
+    if (ix->d_blocks) (void)hipFree(ix->d_blocks);
+    if (ix->d_dollar) (void)hipFree(ix->d_dollar);
+    ix->d_blocks = ix->d_dollar = nullptr;
+    ix->device = -1;
+  }
+  const size_t bb = ix->blocks.size() * sizeof(svdss_u4);
+  const size_t db = (ix->dollar.size() + 1) * sizeof(int64_t);
+  HIPCHK(hipMalloc(&ix->d_blocks, bb));
+  HIPCHK(hipMalloc(&ix->d_dollar, db));
+  HIPCHK(hipMemcpy(ix->d_blocks, ix->blocks.data(), bb, hipMemcpyHostToDevice));
+  if (!ix->dollar.empty())
+    HIPCHK(hipMemcpy(ix->d_dollar, ix->dollar.data(), ix->dollar.size() * sizeof(int64_t),
+                     hipMemcpyHostToDevice));
+  ix->device = device;
+  return SVDSS_OK;
+}
+
+static SvdssDevIndex host_view(const svdss_index* ix) {
+  SvdssDevIndex v;
+  v.blocks = ix->blocks.data();
+  v.dollar = ix->dollar.data();
+  v.n = ix->n;
+  v.n_dollar = (int32_t)ix->dollar.size();
+  v.pad = 0;
+  memcpy(v.acc, ix->acc, sizeof v.acc);
+  return v;
+}
+
+extern "C" int64_t svdss_index_count(const svdss_index_t* ix, const uint8_t* pat, int64_t len) {
+  if (!ix || !pat || len <= 0) return -1;
+  const SvdssDevIndex v = host_view(ix);
+  int c = pat[len - 1];
+  if (c > 5) return -1;
+  int64_t lo = v.acc[c], hi = v.acc[c + 1];
+  for (int64_t i = len - 2; i >= 0 && hi > lo; --i) {
+    c = pat[i];
+    if (c > 5) return -1;
+    const int64_t a = v.acc[c];
+    lo = a + svdss_rank_in_block(v, v.blocks + 4 * (lo >> SVDSS_BLOCK_SHIFT), c, lo);
+    hi = a + svdss_rank_in_block(v, v.blocks + 4 * (hi >> SVDSS_BLOCK_SHIFT), c, hi);
+  }
+  return hi - lo;
+}
+
+// ---------------------------------------------------------------- kernels
+
+struct SfsParams {
+  SvdssDevIndex ix;
+  const svdss_u4* chunks;   // reads viewed as 16-byte chunks
+  int64_t max_chunk;
+  const int64_t* offsets;   // n_reads + 1
+  int64_t n_reads;
+  uint2* rec;               // per-read record regions
+  const int64_t* rec_base;  // explicit region starts (rerun pass) or nullptr
+  const int64_t* rec_cap;   // explicit capacities (rerun pass) or nullptr
+  int64_t* counts;          // n_reads + 1 (last stays 0)
+  int64_t* n_ext;           // n_reads
+  unsigned long long* next_read;
+  int32_t assemble;
+};
+
+// default per-read record region: (len/8 + 8) records starting at off/8 + 8 r
+__host__ __device__ inline int64_t rec_region_base(int64_t off, int64_t r) { return (off >> 3) + 8 * r; }
+__host__ __device__ inline int64_t rec_region_cap(int64_t len) { return (len >> 3) + 8; }
+
+__global__ void __launch_bounds__(256) sfs_search_kernel(SfsParams p) {
+  SvdssLane st;
+  SvdssSymWindow win;
+  SvdssReadView rv;
+  rv.chunks = p.chunks;
+  rv.max_chunk = p.max_chunk;
+  rv.off = 0;
+  int64_t r = 0, base = 0, cap = 0;
+  bool active = false;
+  const bool assemble = p.assemble != 0;
+
+  auto sym = [&](int32_t pos) -> int { return svdss_window_sym(win, rv, pos, st.dir); };
+  auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
+    if (idx < cap) p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
+  };
+
+  for (;;) {
+    if (!active) {
+      const unsigned long long t = atomicAdd(p.next_read, 1ULL);
+      if (t >= (unsigned long long)p.n_reads) break;
+      r = (int64_t)t;
+      const int64_t off = p.offsets[r];
+      const int64_t len = p.offsets[r + 1] - off;
+      rv.off = off;
+      svdss_window_reset(win);
+      base = p.rec_base ? p.rec_base[r] : rec_region_base(off, r);
+      cap = p.rec_cap ? p.rec_cap[r] : rec_region_cap(len);
+      st.dir = 0;
+      svdss_lane_init(st, p.ix, sym, (int32_t)len);
+      active = true;
+    }
+    if (!svdss_lane_resolve(st, p.ix, sym, assemble, emit)) {
+      svdss_lane_flush(st, assemble, emit);
+      p.counts[r] = st.n_sfs;
+      p.n_ext[r] = st.n_ext;
+      active = false;
+      continue;
+    }
+    // overlap the (possible) next read-chunk fetch with the BWT block fetches
+    const int32_t np = st.dir ? st.pos + 1 : st.pos - 1;
+    if (np >= 0 && np < st.len) svdss_window_prefetch(win, rv, np);
+
+    const int64_t blo = st.lo >> SVDSS_BLOCK_SHIFT, bhi = st.hi >> SVDSS_BLOCK_SHIFT;
+    svdss_u4 ql[4], qh[4];
+    const svdss_u4* Bl = p.ix.blocks + 4 * blo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ql[j] = Bl[j];
+    if (bhi != blo) {
+      const svdss_u4* Bh = p.ix.blocks + 4 * bhi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qh[j] = Bh[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qh[j] = ql[j];
+    }
+    svdss_lane_step(st, p.ix, ql, qh);
+  }
+}
+
+// One wavefront per read: copy its records from the region to the compact
+// output (reversed when assembled: the lanes produce chains in descending qs,
+// Assembler::assemble returns ascending, assembler.cpp:36).
+__global__ void __launch_bounds__(256) sfs_gather_kernel(SfsParams p, const int64_t* out_off,
+                                                         int32_t* out_qs, int32_t* out_len,
+                                                         unsigned long long* n_overflow) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < p.n_reads; r += nwaves) {
+    const int64_t off = p.offsets[r];
+    const int64_t len = p.offsets[r + 1] - off;
+    const int64_t base = p.rec_base ? p.rec_base[r] : rec_region_base(off, r);
+    const int64_t cap = p.rec_cap ? p.rec_cap[r] : rec_region_cap(len);
+    const int64_t cnt = p.counts[r];
+    if (cnt > cap) {
+      if (lane == 0) atomicAdd(n_overflow, 1ULL);
+      continue;
+    }
+    const int64_t o = out_off[r];
+    for (int64_t i = lane; i < cnt; i += 64) {
+      const uint2 v = p.rec[base + (p.assemble ? cnt - 1 - i : i)];
+      out_qs[o + i] = (int32_t)v.x;
+      out_len[o + i] = (int32_t)v.y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ batch
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct svdss_sfs_batch {
+  int device = -1;
+  int64_t n_reads = 0;
+  int64_t total = 0;
+  int64_t total_ext = 0;
+  double kernel_ms = 0.0;
+  DevBuf rec, counts, n_ext, out_off, out_qs, out_len, tmp, misc, reads, offsets, base2, sum;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int ensure(DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return SVDSS_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  size_t want = bytes + (bytes >> 3) + 256;
+  HIPCHK(hipMalloc(&b.p, want));
+  b.cap = want;
+  return SVDSS_OK;
+}
+
+static void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+extern "C" void svdss_sfs_batch_free(svdss_sfs_batch_t* b) {
+  if (!b) return;
+  if (b->device >= 0) (void)hipSetDevice(b->device);
+  for (DevBuf* d : {&b->rec, &b->counts, &b->n_ext, &b->out_off, &b->out_qs, &b->out_len, &b->tmp,
+                    &b->misc, &b->reads, &b->offsets, &b->base2, &b->sum})
+    release(*d);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+}
+
+extern "C" int64_t svdss_sfs_batch_nreads(const svdss_sfs_batch_t* b) { return b ? b->n_reads : -1; }
+extern "C" int64_t svdss_sfs_batch_total(const svdss_sfs_batch_t* b) { return b ? b->total : -1; }
+extern "C" int64_t svdss_sfs_batch_total_ext(const svdss_sfs_batch_t* b) { return b ? b->total_ext : -1; }
+extern "C" double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b) { return b ? b->kernel_ms : -1.0; }
+
+static int launch_grid(int device, int* blocks_out) {
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  *blocks_out = prop.multiProcessorCount * 8;  // 8 x 256 threads = 32 waves per CU
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint8_t* d_reads,
+                                             const int64_t* d_offsets, int64_t n_reads,
+                                             int64_t total_syms, int32_t flags, void* stream_,
+                                             svdss_sfs_batch_t** out) {
+  if (!ix || !out || n_reads < 0 || total_syms < 0) return SVDSS_EINVAL;
+  if (n_reads > 0 && (!d_reads || !d_offsets)) return SVDSS_EINVAL;
+  if (((uintptr_t)d_reads & 15u) != 0) return SVDSS_EINVAL;
+  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;
+  hipStream_t stream = (hipStream_t)stream_;
+  HIPCHK(hipSetDevice(ix->device));
+  svdss_sfs_batch* b = *out;
+  if (!b) {
+    b = new (std::nothrow) svdss_sfs_batch();
+    if (!b) return SVDSS_ENOMEM;
+    b->device = ix->device;
+    *out = b;
+  }
+  if (b->device != ix->device) return SVDSS_EINVAL;
+  if (!b->ev0) HIPCHK(hipEventCreate(&b->ev0));
+  if (!b->ev1) HIPCHK(hipEventCreate(&b->ev1));
+  b->n_reads = n_reads;
+  b->total = 0;
+  b->total_ext = 0;
+  b->kernel_ms = 0.0;
+  if (n_reads == 0) return SVDSS_OK;
+
+  int rc;
+  const int64_t rec_total = (total_syms >> 3) + 8 * n_reads + 16;
+  if ((rc = ensure(b->rec, (size_t)rec_total * sizeof(uint2)))) return rc;
+  if ((rc = ensure(b->counts, (size_t)(n_reads + 1) * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(b->n_ext, (size_t)n_reads * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(b->out_off, (size_t)(n_reads + 1) * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(b->misc, 64))) return rc;
+  if ((rc = ensure(b->sum, 64))) return rc;
+
+  SfsParams p;
+  p.ix.blocks = (const svdss_u4*)ix->d_blocks;
+  p.ix.dollar = (const int64_t*)ix->d_dollar;
+  p.ix.n = ix->n;
+  p.ix.n_dollar = (int32_t)ix->dollar.size();
+  p.ix.pad = 0;
+  memcpy(p.ix.acc, ix->acc, sizeof p.ix.acc);
+  p.chunks = (const svdss_u4*)d_reads;
+  p.max_chunk = total_syms > 0 ? ((total_syms + 15) >> 4) - 1 : 0;
+  p.offsets = d_offsets;
+  p.n_reads = n_reads;
+  p.rec = (uint2*)b->rec.p;
+  p.rec_base = nullptr;
+  p.rec_cap = nullptr;
+  p.counts = (int64_t*)b->counts.p;
+  p.n_ext = (int64_t*)b->n_ext.p;
+  p.next_read = (unsigned long long*)b->misc.p;
+  p.assemble = (flags & SVDSS_SFS_ASSEMBLE) ? 1 : 0;
+  unsigned long long* d_overflow = (unsigned long long*)b->misc.p + 1;
+
+  int max_blocks = 0;
+  if ((rc = launch_grid(ix->device, &max_blocks))) return rc;
+  const int64_t want_blocks = (n_reads + 255) / 256;
+  const int sblocks = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
+  const int64_t gw = (n_reads + 3) / 4;  // 4 waves per block, one read per wave iteration
+  const int gblocks = (int)(gw < 4 * (int64_t)max_blocks ? (gw > 0 ? gw : 1) : 4 * (int64_t)max_blocks);
+
+  size_t tmp_bytes = 0, tmp2 = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, p.counts, (int64_t*)b->out_off.p,
+                                          (int)(n_reads + 1), stream));
+  HIPCHK(hipcub::DeviceReduce::Sum(nullptr, tmp2, p.n_ext, (int64_t*)b->sum.p, (int)n_reads, stream));
+  if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
+  if ((rc = ensure(b->tmp, tmp_bytes))) return rc;
+
+  for (int pass = 0; pass < 2; ++pass) {
+    HIPCHK(hipMemsetAsync(b->misc.p, 0, 16, stream));
+    HIPCHK(hipMemsetAsync((int64_t*)b->counts.p + n_reads, 0, sizeof(int64_t), stream));
+    HIPCHK(hipEventRecord(b->ev0, stream));
+    hipLaunchKernelGGL(sfs_search_kernel, dim3(sblocks), dim3(256), 0, stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->ev1, stream));
+    size_t tb = b->tmp.cap;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->tmp.p, tb, p.counts, (int64_t*)b->out_off.p,
+                                            (int)(n_reads + 1), stream));
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, (int64_t*)b->out_off.p + n_reads, sizeof(int64_t),
+                          hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if ((rc = ensure(b->out_qs, (size_t)(total + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(b->out_len, (size_t)(total + 1) * sizeof(int32_t)))) return rc;
+    hipLaunchKernelGGL(sfs_gather_kernel, dim3(gblocks), dim3(256), 0, stream, p,
+                       (const int64_t*)b->out_off.p, (int32_t*)b->out_qs.p, (int32_t*)b->out_len.p,
+                       d_overflow);
+    HIPCHK(hipGetLastError());
+    tb = b->tmp.cap;
+    HIPCHK(hipcub::DeviceReduce::Sum(b->tmp.p, tb, p.n_ext, (int64_t*)b->sum.p, (int)n_reads, stream));
+    unsigned long long n_over = 0;
+    int64_t total_ext = 0;
+    HIPCHK(hipMemcpyAsync(&n_over, d_overflow, sizeof n_over, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(&total_ext, b->sum.p, sizeof total_ext, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->kernel_ms += ms;
+    b->total = total;
+    b->total_ext = total_ext;
+    if (n_over == 0) break;
+    if (pass == 1) return SVDSS_ERANGE;  // cannot happen: capacities were exact
+    // Some read produced more SFS than its default region holds (e.g. a read
+    // of N against an N-free reference gives one SFS per base).  The counts
+    // are exact, so rerun with regions sized from them.
+    if ((rc = ensure(b->rec, (size_t)(total + 1) * sizeof(uint2)))) return rc;
+    if ((rc = ensure(b->base2, (size_t)(2 * (n_reads + 1)) * sizeof(int64_t)))) return rc;
+    int64_t* base2 = (int64_t*)b->base2.p;
+    int64_t* cap2 = base2 + (n_reads + 1);
+    HIPCHK(hipMemcpyAsync(base2, b->out_off.p, (size_t)(n_reads + 1) * sizeof(int64_t),
+                          hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(cap2, b->counts.p, (size_t)(n_reads + 1) * sizeof(int64_t),
+                          hipMemcpyDeviceToDevice, stream));
+    p.rec = (uint2*)b->rec.p;
+    p.rec_base = base2;
+    p.rec_cap = cap2;
+  }
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* reads,
+                                      const int64_t* offsets, int64_t n_reads, int32_t flags,
+                                      svdss_sfs_batch_t** out) {
+  if (!ix || !out || n_reads < 0) return SVDSS_EINVAL;
+  if (n_reads > 0 && (!reads || !offsets)) return SVDSS_EINVAL;
+  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;
+  HIPCHK(hipSetDevice(ix->device));
+  svdss_sfs_batch* b = *out;
+  if (!b) {
+    b = new (std::nothrow) svdss_sfs_batch();
+    if (!b) return SVDSS_ENOMEM;
+    b->device = ix->device;
+    *out = b;
+  }
+  if (n_reads == 0) {
+    b->n_reads = 0; b->total = 0; b->total_ext = 0; b->kernel_ms = 0.0;
+    return SVDSS_OK;
+  }
+  if (offsets[0] != 0) return SVDSS_EINVAL;
+  for (int64_t i = 0; i < n_reads; ++i) {
+    const int64_t l = offsets[i + 1] - offsets[i];
+    if (l < 0) return SVDSS_EINVAL;
+    if (l >= (int64_t)0x7fffffff) return SVDSS_ERANGE;
+  }
+  const int64_t total = offsets[n_reads];
+  int rc;
+  const size_t padded = (size_t)((total + 15) & ~(int64_t)15) + 16;
+  if ((rc = ensure(b->reads, padded))) return rc;
+  if ((rc = ensure(b->offsets, (size_t)(n_reads + 1) * sizeof(int64_t)))) return rc;
+  HIPCHK(hipMemset(b->reads.p, 0, padded));
+  if (total > 0) HIPCHK(hipMemcpy(b->reads.p, reads, (size_t)total, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->offsets.p, offsets, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  return svdss_sfs_search_batch_device(ix, (const uint8_t*)b->reads.p, (const int64_t*)b->offsets.p,
+                                       n_reads, total, flags, nullptr, out);
+}
+
+extern "C" int svdss_sfs_batch_fetch(const svdss_sfs_batch_t* b, int64_t* counts, int32_t* qs,
+                                     int32_t* len, int64_t* n_ext) {
+  if (!b) return SVDSS_EINVAL;
+  if (b->n_reads == 0) return SVDSS_OK;
+  HIPCHK(hipSetDevice(b->device));
+  if (counts)
+    HIPCHK(hipMemcpy(counts, b->counts.p, (size_t)b->n_reads * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (n_ext)
+    HIPCHK(hipMemcpy(n_ext, b->n_ext.p, (size_t)b->n_reads * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (qs && b->total > 0)
+    HIPCHK(hipMemcpy(qs, b->out_qs.p, (size_t)b->total * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (len && b->total > 0)
+    HIPCHK(hipMemcpy(len, b->out_len.p, (size_t)b->total * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return SVDSS_OK;
+}

@@ -1,0 +1,169 @@
+"""ctypes wrapper of oracle/libsvdss_oracle.so (test infrastructure only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = C.CDLL(os.path.join(ROOT, "oracle", "libsvdss_oracle.so"))
+
+_p, _i64 = C.c_void_p, C.c_int64
+_lib.orc_fmd_build.restype = _p
+_lib.orc_fmd_build.argtypes = [_p, _p, C.c_int]
+_lib.orc_fmd_from_bwt.restype = _p
+_lib.orc_fmd_from_bwt.argtypes = [_p, _i64]
+_lib.orc_fmd_free.argtypes = [_p]
+_lib.orc_fmd_n.restype = _i64
+_lib.orc_fmd_n.argtypes = [_p]
+_lib.orc_fmd_acc.argtypes = [_p, _p]
+_lib.orc_fmd_bwt.restype = _p
+_lib.orc_fmd_bwt.argtypes = [_p]
+_lib.orc_build_text.restype = _p
+_lib.orc_build_text.argtypes = [_p, _p, C.c_int, _p]
+_lib.orc_ping_pong_search.restype = _i64
+_lib.orc_ping_pong_search.argtypes = [_p, _p, C.c_int, C.c_int, _p, _p, _i64, _p]
+_lib.orc_ping_pong_bruteforce.restype = _i64
+_lib.orc_ping_pong_bruteforce.argtypes = [_p, _i64, _p, C.c_int, C.c_int, _p, _p, _i64, _p]
+_lib.orc_assemble.restype = _i64
+_lib.orc_assemble.argtypes = [_p, _p, _i64, _p, _p]
+_lib.orc_search_batch.restype = _i64
+_lib.orc_search_batch.argtypes = [_p, _p, _p, _i64, C.c_int, C.c_int, _p, _p, C.POINTER(_p), C.POINTER(_p)]
+_lib.orc_free.argtypes = [_p]
+_lib.orc_nt6_encode.argtypes = [C.c_char_p, _i64, _p]
+_lib.orc_max_threads.restype = C.c_int
+_lib.orc_fmd_set_intv.argtypes = [_p, C.c_int, _p]
+_lib.orc_fmd_extend.argtypes = [_p, _p, _p, C.c_int]
+
+
+def nt6_encode(s: bytes) -> np.ndarray:
+    out = np.empty(len(s), dtype=np.uint8)
+    _lib.orc_nt6_encode(s, len(s), out.ctypes.data)
+    return out
+
+
+def _flat(contigs):
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    flat = np.ascontiguousarray(np.concatenate(contigs), dtype=np.uint8)
+    return flat, lens
+
+
+def build_text(contigs) -> np.ndarray:
+    flat, lens = _flat(contigs)
+    n = _i64()
+    p = _lib.orc_build_text(flat.ctypes.data, lens.ctypes.data, len(contigs), C.byref(n))
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+    _lib.orc_free(p)
+    return out
+
+
+class OracleFMD:
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def build(cls, contigs):
+        flat, lens = _flat(contigs)
+        return cls(_lib.orc_fmd_build(flat.ctypes.data, lens.ctypes.data, len(contigs)))
+
+    @classmethod
+    def from_bwt(cls, bwt: np.ndarray):
+        bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+        return cls(_lib.orc_fmd_from_bwt(bwt.ctypes.data, len(bwt)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib.orc_fmd_free(self.h)
+            self.h = None
+
+    @property
+    def n(self):
+        return _lib.orc_fmd_n(self.h)
+
+    @property
+    def acc(self):
+        a = np.zeros(7, dtype=np.int64)
+        _lib.orc_fmd_acc(self.h, a.ctypes.data)
+        return a
+
+    def bwt(self):
+        p = _lib.orc_fmd_bwt(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.n,)).copy()
+
+    def count(self, pattern: np.ndarray) -> int:
+        """interval size after set_intv + backward extends (ping_pong.cpp:12-22 without the stop)."""
+        ik = (_i64 * 4)()
+        ok = (_i64 * 24)()
+        _lib.orc_fmd_set_intv(self.h, int(pattern[-1]), ik)
+        for c in pattern[-2::-1]:
+            if ik[2] == 0:
+                break
+            _lib.orc_fmd_extend(self.h, ik, ok, 1)
+            for j in range(4):
+                ik[j] = ok[4 * int(c) + j]
+        return ik[2]
+
+    def ping_pong_search(self, read: np.ndarray, overlap: int = -1):
+        """orc_ping_pong_search on one read -> ([(qs,l)...] in push order, n_ext)."""
+        l = len(read)
+        P = np.zeros(l + 1, dtype=np.uint8)
+        P[:l] = read
+        cap = l + 1
+        qs = np.zeros(cap, dtype=np.int32)
+        ln = np.zeros(cap, dtype=np.int32)
+        ext = _i64()
+        n = _lib.orc_ping_pong_search(self.h, P.ctypes.data, l, overlap, qs.ctypes.data, ln.ctypes.data,
+                                      cap, C.byref(ext))
+        assert n >= 0
+        return list(zip(qs[:n].tolist(), ln[:n].tolist())), ext.value
+
+    def search_batch(self, flat: np.ndarray, offsets: np.ndarray, assemble: bool, threads: int = 0):
+        """orc_search_batch: reads WITHOUT terminators in, (counts, qs, len, n_ext) out."""
+        n = len(offsets) - 1
+        # the restated loop reads P[l] == 0 in principle (ping_pong.cpp:94): add terminators
+        lens = np.diff(offsets)
+        toff = offsets + np.arange(n + 1, dtype=np.int64)
+        tflat = np.zeros(int(toff[-1]), dtype=np.uint8)
+        if n:
+            idx = np.arange(int(offsets[-1]), dtype=np.int64) + np.repeat(np.arange(n, dtype=np.int64), lens)
+            tflat[idx] = flat
+        counts = np.zeros(n, dtype=np.int64)
+        n_ext = np.zeros(n, dtype=np.int64)
+        pq, pl = _p(), _p()
+        if threads <= 0:
+            threads = _lib.orc_max_threads()
+        total = _lib.orc_search_batch(self.h, tflat.ctypes.data, toff.ctypes.data, n, int(assemble), threads,
+                                      counts.ctypes.data, n_ext.ctypes.data, C.byref(pq), C.byref(pl))
+        qs = np.ctypeslib.as_array(C.cast(pq, C.POINTER(C.c_int32)), shape=(max(total, 1),))[:total].copy()
+        ln = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_int32)), shape=(max(total, 1),))[:total].copy()
+        _lib.orc_free(pq)
+        _lib.orc_free(pl)
+        return counts, qs, ln, n_ext
+
+
+def ping_pong_bruteforce(text: np.ndarray, read: np.ndarray, overlap: int = -1):
+    l = len(read)
+    P = np.zeros(l + 1, dtype=np.uint8)
+    P[:l] = read
+    cap = l + 1
+    qs = np.zeros(cap, dtype=np.int32)
+    ln = np.zeros(cap, dtype=np.int32)
+    ext = _i64()
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    n = _lib.orc_ping_pong_bruteforce(text.ctypes.data, len(text), P.ctypes.data, l, overlap,
+                                      qs.ctypes.data, ln.ctypes.data, cap, C.byref(ext))
+    assert n >= 0
+    return list(zip(qs[:n].tolist(), ln[:n].tolist())), ext.value
+
+
+def assemble(sfs):
+    n = len(sfs)
+    qs = np.array([s[0] for s in sfs], dtype=np.int32)
+    ln = np.array([s[1] for s in sfs], dtype=np.int32)
+    oq = np.zeros(max(n, 1), dtype=np.int32)
+    ol = np.zeros(max(n, 1), dtype=np.int32)
+    m = _lib.orc_assemble(qs.ctypes.data, ln.ctypes.data, n, oq.ctypes.data, ol.ctypes.data)
+    return list(zip(oq[:m].tolist(), ol[:m].tolist()))
+
+
+def max_threads():
+    return _lib.orc_max_threads()
