@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s through the SFS-search hot path on MI355X.
+
+A "step" = one pass of the hot path (svdss_sfs_search_batch_device: ping-pong
+search kernel + fused per-read assembly + compaction) over one batch of
+synthetic HiFi-shape reads that is already resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: reads shard across ranks (weak scaling: every rank gets its own
+batch of the same size), the index is replicated in every GPU's HBM, and the
+only exchange is the gather of the assembled SFS records on rank 0 each step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def simulate_reads_gpu(ref_t, n_reads, L, err, seed, device, chunk=2048):
+    """Seeded HiFi-shape reads on the GPU (torch ops; data plumbing, not the hot path):
+    uniform start, random strand, errors sub:ins:del = 2:1.5:1.5 (svdss_amd/synth.py semantics)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    comp = torch.tensor([0, 4, 3, 2, 1, 5], dtype=torch.uint8, device=device)
+    span = L + L // 20 + 64
+    n_ref = ref_t.numel()
+    total = n_reads * L
+    out = torch.zeros(((total + 15) // 16) * 16 + 16, dtype=torch.uint8, device=device)
+    p_sub, p_ins, p_del = err * 0.4, err * 0.3, err * 0.3
+    ar_span = torch.arange(span, device=device)
+    ar_L = torch.arange(L, device=device)
+    for s in range(0, n_reads, chunk):
+        B = min(chunk, n_reads - s)
+        start = torch.randint(0, n_ref - span, (B,), generator=g, device=device)
+        src = ref_t[start[:, None] + ar_span[None, :]]
+        u = torch.rand((B, span), generator=g, device=device)
+        is_sub = u < p_sub
+        is_ins = (u >= p_sub) & (u < p_sub + p_ins)
+        is_del = (u >= p_sub + p_ins) & (u < p_sub + p_ins + p_del)
+        reps = torch.ones((B, span), dtype=torch.int32, device=device)
+        reps[is_ins] = 2
+        reps[is_del] = 0
+        c = torch.cumsum(reps, dim=1)
+        j = ar_L[None, :].expand(B, L).contiguous().to(torch.int32)
+        sidx = torch.searchsorted(c, j, right=True).clamp_(max=span - 1)
+        base = torch.gather(src, 1, sidx)
+        c_excl = torch.gather(c - reps, 1, sidx)
+        first = j == c_excl
+        shift = torch.randint(1, 4, (B, L), generator=g, device=device, dtype=torch.uint8)
+        subbed = ((base - 1 + shift) % 4) + 1
+        acgt = (base >= 1) & (base <= 4)
+        base = torch.where(torch.gather(is_sub, 1, sidx) & first & acgt, subbed, base)
+        rnd = torch.randint(1, 5, (B, L), generator=g, device=device, dtype=torch.uint8)
+        base = torch.where(first, base, rnd)
+        strand = torch.rand((B,), generator=g, device=device) < 0.5
+        rc = comp[base.flip(1).long()]
+        base = torch.where(strand[:, None], rc, base)
+        out[s * L:(s + B) * L] = base.reshape(-1)
+    offsets = torch.arange(n_reads + 1, dtype=torch.int64, device=device) * L
+    return out, offsets
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ref-len", type=int, default=64_444_167, help="reference bases (chr20 length)")
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--read-len", type=int, default=15000)
+    ap.add_argument("--err", type=float, default=0.005)
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: coverage*ref/read_len)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import svdss_amd
+    from svdss_amd import multi, synth
+
+    n_reads = args.reads or int(round(args.coverage * args.ref_len / args.read_len))
+    L = args.read_len
+
+    # ---- index: built once (rank 0), replicated into every GPU's HBM -------
+    t0 = time.time()
+    ref = synth.make_reference([args.ref_len], seed=11)
+    idx_path = f"/tmp/svdss_bench_{args.ref_len}.fmd"
+    if rank == 0:
+        ix = svdss_amd.FMDIndex.build(ref)
+        if world > 1:
+            ix.save(idx_path)
+    if world > 1:
+        dist.barrier()
+        if rank != 0:
+            ix = svdss_amd.FMDIndex.load(idx_path)
+    ix.to_device(local_rank)
+    t_index = time.time() - t0
+
+    # ---- reads: generated on the GPU, one independent shard per rank -------
+    ref_t = torch.from_numpy(ref[0]).to(device)
+    d_reads, d_offs = simulate_reads_gpu(ref_t, n_reads, L, args.err, seed=13 + 1000 * rank, device=device)
+    total_syms = n_reads * L
+    del ref_t
+    torch.cuda.synchronize()
+
+    pp = svdss_amd.PingPong(ix, assemble=True)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
+                                   stream=stream.cuda_stream, fetch=False)
+        if world > 1:
+            counts, qs, ln = pp.device_results()
+            multi.gather_sfs(counts, qs, ln)
+
+    # raw (unassembled) SFS count: the N_sfs of the algorithmic-bytes formula
+    pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
+                               stream=stream.cuda_stream, assemble=False, fetch=False)
+    n_sfs_raw = pp.last_total
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(pp.last_kernel_ms)   # HIP events recorded on `stream` around the search kernel
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_ext = pp.last_total_ext
+    n_sfs_asm = pp.last_total
+    # algorithmic bytes per read = N_ext*64 + L + 16*N_sfs
+    alg_bytes = n_ext * 64 + total_syms + 16 * n_sfs_raw
+    k_ms = float(np.mean(kernel_ms))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "reads/sec through SFS search (ping-pong FMD search + assemble), HiFi 15 kb reads",
+            "value": world * n_reads * args.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"synthetic {args.ref_len} bp reference (chr20 length, iid ACGT + 3% diverged "
+                             f"repeats, both strands indexed: {ix.size} BWT symbols), {n_reads} reads/GPU x "
+                             f"{L} bp ({n_reads * L / args.ref_len:.1f}x), {args.err * 100:.2f}% errors, "
+                             "search with fused assemble, all reads searched (--noputative semantics)"),
+                "reads_per_gpu": n_reads, "read_len": L, "index_bytes": ix.device_bytes,
+                "parallelism": f"reads sharded over {world} GPU(s), index replicated, SFS gathered on rank 0",
+                "ext_per_read": n_ext / n_reads, "raw_sfs_per_read": n_sfs_raw / n_reads,
+                "assembled_sfs_per_read": n_sfs_asm / n_reads, "index_build_s": round(t_index, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "sfs_search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ix, d_reads, L, n_reads, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ix, d_reads, L, n_reads, target_s):
+    """The oracle (CPU restatement of ping_pong.cpp:4-49 + assembler.cpp:34-56, OpenMP over reads
+    like ping_pong.cpp:329) timed on this box's cores on a bounded sample of the same reads."""
+    from tests import oracle_lib as O
+    fm = O.OracleFMD.from_bwt(ix.bwt())
+    threads = O.max_threads()
+
+    def run(k):
+        flat = d_reads[:k * L].cpu().numpy()
+        offs = np.arange(k + 1, dtype=np.int64) * L
+        t0 = time.perf_counter()
+        fm.search_batch(flat, offs, True, threads)
+        return time.perf_counter() - t0
+
+    k = min(n_reads, 4 * threads)
+    t = run(k)
+    k2 = int(min(n_reads, max(k, k * target_s / max(t, 1e-3))))
+    t2 = run(k2)
+    return {"value": k2 / t2, "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": f"first {k2} reads of the rank-0 batch, {t2:.1f} s, oracle/svdss_oracle.c "
+                      f"orc_search_batch with {threads} OpenMP threads (plain sampled-Occ FMD, faster than "
+                      "ropebwt3's rld0: the GPU/CPU ratio is conservative)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,11 @@ double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b);
  * counts,n_ext: n_reads entries; qs,len: svdss_sfs_batch_total() entries. */
 int svdss_sfs_batch_fetch(const svdss_sfs_batch_t* b, int64_t* counts, int32_t* qs, int32_t* len,
                           int64_t* n_ext);
+/* device addresses of the result arrays (valid until the next search on this batch
+ * object or svdss_sfs_batch_free): counts int64[n_reads], qs/len int32[total],
+ * n_ext int64[n_reads].  Lets a caller hand results to RCCL without a host hop. */
+int svdss_sfs_batch_device_ptrs(const svdss_sfs_batch_t* b, void** counts, void** qs, void** len,
+                                void** n_ext);
 void svdss_sfs_batch_free(svdss_sfs_batch_t* b);
 
 #ifdef __cplusplus

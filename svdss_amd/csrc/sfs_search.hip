@@ -499,6 +499,16 @@ extern "C" int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* re
                                        n_reads, total, flags, nullptr, out);
 }
 
+extern "C" int svdss_sfs_batch_device_ptrs(const svdss_sfs_batch_t* b, void** counts, void** qs,
+                                           void** len, void** n_ext) {
+  if (!b) return SVDSS_EINVAL;
+  if (counts) *counts = b->counts.p;
+  if (qs) *qs = b->out_qs.p;
+  if (len) *len = b->out_len.p;
+  if (n_ext) *n_ext = b->n_ext.p;
+  return SVDSS_OK;
+}
+
 extern "C" int svdss_sfs_batch_fetch(const svdss_sfs_batch_t* b, int64_t* counts, int32_t* qs,
                                      int32_t* len, int64_t* n_ext) {
   if (!b) return SVDSS_EINVAL;

@@ -191,6 +191,27 @@ class PingPong:
               "svdss_sfs_search_batch_device")
         return self._fetch() if fetch else None
 
+    def device_results(self):
+        """Last results as torch tensors aliasing the library's HBM buffers (counts, qs, len)."""
+        import torch
+        pc, pq, pl, pe = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.svdss_sfs_batch_device_ptrs(self._batch, C.byref(pc), C.byref(pq), C.byref(pl),
+                                              C.byref(pe)), "svdss_sfs_batch_device_ptrs")
+        n, total = lib.svdss_sfs_batch_nreads(self._batch), lib.svdss_sfs_batch_total(self._batch)
+
+        class _Alias:
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": (shape,), "typestr": typestr,
+                                                 "data": (ptr or 0, False), "version": 2}
+
+        def wrap(ptr, count, typestr, dtype):
+            if count == 0 or not ptr.value:
+                return torch.zeros(0, dtype=dtype, device="cuda")
+            return torch.as_tensor(_Alias(ptr.value, count, typestr), device="cuda")
+
+        return (wrap(pc, n, "<i8", torch.int64), wrap(pq, total, "<i4", torch.int32),
+                wrap(pl, total, "<i4", torch.int32))
+
     @property
     def last_total(self) -> int:
         return lib.svdss_sfs_batch_total(self._batch)

@@ -71,7 +71,7 @@ class OracleFMD:
         return cls(_lib.orc_fmd_from_bwt(bwt.ctypes.data, len(bwt)))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _lib is not None:
             _lib.orc_fmd_free(self.h)
             self.h = None
 

@@ -1,0 +1,81 @@
+"""The oracle against its pins: the FMD restatement must equal the index-free
+brute-force model (the mathematical pin of SURVEY 8(c)-1) and the committed
+golden vectors; assemble and nt6 follow the reference tables."""
+import numpy as np
+import pytest
+
+from svdss_amd import synth
+from tests import oracle_lib as O
+from tests.common import from_ascii, load_golden, small_workload
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fmd_restatement_equals_bruteforce(seed):
+    ref = synth.make_reference([30000, 12000], seed=seed, repeat_frac=0.08, n_runs=(30,))
+    hap, _ = synth.implant_svs(ref, 4, seed=seed + 10, min_len=30, max_len=150)
+    flat, offs, _ = synth.simulate_reads(hap, 10, 500, 0.01, seed=seed + 20, ragged=True)
+    fm = O.OracleFMD.build(ref)
+    text = O.build_text(ref)
+    for i in range(10):
+        r = flat[offs[i]:offs[i + 1]]
+        assert fm.ping_pong_search(r) == O.ping_pong_bruteforce(text, r)
+
+
+def test_golden_vectors():
+    for case in load_golden():
+        contigs = [from_ascii(c) for c in case["contigs"]]
+        fm = O.OracleFMD.build(contigs)
+        for rd in case["reads"]:
+            r = from_ascii(rd["read"])
+            sfs, n_ext = fm.ping_pong_search(r)
+            assert [list(x) for x in sfs] == rd["sfs"], case["name"]
+            assert n_ext == rd["n_ext"]
+            assert [list(x) for x in O.assemble(sfs)] == rd["assembled"]
+
+
+def test_fmd_symmetry_and_counts():
+    ref = synth.make_reference([20000], seed=9)
+    fm = O.OracleFMD.build(ref)
+    text = O.build_text(ref)
+    acc = fm.acc
+    assert acc[1] == 2 and acc[6] == fm.n == 2 * (20000 + 1)
+    assert acc[2] - acc[1] == acc[5] - acc[4]  # #A == #T over both strands
+    rng = np.random.default_rng(0)
+    tb = text.tobytes()
+    for _ in range(50):
+        s = int(rng.integers(0, 19900))
+        l = int(rng.integers(1, 40))
+        w = ref[0][s:s + l]
+        want = sum(1 for i in range(len(tb) - l + 1) if tb[i:i + l] == w.tobytes())
+        assert fm.count(w) == want
+        assert fm.count(synth.revcomp(w)) == want
+
+
+def test_assemble_semantics():
+    # assembler.cpp:34-56: chained on consecutive overlap, touching intervals do not merge
+    assert O.assemble([(30, 5), (10, 10), (15, 10), (25, 5)]) == [(10, 15), (25, 5), (30, 5)]
+    assert O.assemble([(5, 3)]) == [(5, 3)]
+    assert O.assemble([]) == []
+    # end of a chain is the END OF ITS LAST member, not the max end (assembler.cpp:42)
+    assert O.assemble([(0, 100), (10, 5), (50, 5)]) == [(0, 15), (50, 5)]
+
+
+def test_nt6_table():
+    # ping_pong.hpp:46-52
+    got = O.nt6_encode(b"ACGTacgtNnXRY-*")
+    assert got.tolist() == [1, 2, 3, 4, 1, 2, 3, 4, 5, 5, 5, 5, 5, 5, 5]
+
+
+def test_batch_matches_single_and_threads():
+    ref, hap, svs, flat, offs = small_workload(n_reads=24, read_len=800, ref_lens=(60000,))
+    fm = O.OracleFMD.build(ref)
+    c1, q1, l1, e1 = fm.search_batch(flat, offs, assemble=False, threads=1)
+    c4, q4, l4, e4 = fm.search_batch(flat, offs, assemble=False, threads=4)
+    assert (c1 == c4).all() and (q1 == q4).all() and (l1 == l4).all() and (e1 == e4).all()
+    o = 0
+    for i in range(len(offs) - 1):
+        sfs, n_ext = fm.ping_pong_search(flat[offs[i]:offs[i + 1]])
+        assert sfs == list(zip(q1[o:o + c1[i]].tolist(), l1[o:o + c1[i]].tolist()))
+        assert n_ext == e1[i]
+        o += c1[i]
+    assert c1.sum() > 0

@@ -1,0 +1,188 @@
+"""Parity tests proper: the HIP kernels, called through the C-ABI, against the
+oracle, the golden vectors and size-independent properties.  Integer work:
+every comparison is bit-exact."""
+import numpy as np
+import pytest
+
+import svdss_amd
+from svdss_amd import synth
+from tests import oracle_lib as O
+from tests.common import from_ascii, load_golden, small_workload, split
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(ix, flat, offs, assemble):
+    pp = svdss_amd.PingPong(ix, assemble=assemble)
+    b = pp.ping_pong_search(flat, offs)
+    pp.close()
+    return b
+
+
+def test_library_is_the_hip_build():
+    import torch
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def test_golden_vectors_on_gpu():
+    for case in load_golden():
+        contigs = [from_ascii(c) for c in case["contigs"]]
+        ix = svdss_amd.FMDIndex.build(contigs, threads=2).to_device(0)
+        reads = [from_ascii(r["read"]) for r in case["reads"]]
+        flat, offs = svdss_amd.pack_reads(reads)
+        raw = _search(ix, flat, offs, False)
+        for got, rd, ne in zip(raw.per_read(), case["reads"], raw.n_ext.tolist()):
+            assert [list(x) for x in got] == rd["sfs"], case["name"]
+            assert ne == rd["n_ext"]
+        asm = _search(ix, flat, offs, True)
+        for got, rd in zip(asm.per_read(), case["reads"]):
+            assert [list(x) for x in got] == rd["assembled"], case["name"]
+
+
+@pytest.mark.parametrize("assemble", [False, True])
+@pytest.mark.parametrize("seed", [31, 32])
+def test_random_reads_match_oracle(assemble, seed):
+    ref, hap, svs, flat, offs = small_workload(seed=seed, n_reads=300, read_len=2000)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    got = _search(ix, flat, offs, assemble)
+    c, q, l, e = fm.search_batch(flat, offs, assemble)
+    assert (got.counts == c).all() and (got.n_ext == e).all()
+    assert (got.qs == q).all() and (got.len == l).all()
+    assert c.sum() > 0
+
+
+def test_empty_ragged_and_unaligned():
+    ref, hap, svs, flat, offs = small_workload(seed=41, n_reads=10, read_len=300, ref_lens=(40000,))
+    reads = [flat[offs[i]:offs[i + 1]] for i in range(10)]
+    reads.insert(3, np.zeros(0, np.uint8))
+    reads.append(np.zeros(0, np.uint8))
+    reads.insert(0, ref[0][5:6])
+    flat2, offs2 = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    for assemble in (False, True):
+        got = _search(ix, flat2, offs2, assemble)
+        c, q, l, e = fm.search_batch(flat2, offs2, assemble)
+        assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
+    # empty batch
+    got = _search(ix, np.zeros(0, np.uint8), np.zeros(1, np.int64), True)
+    assert len(got.counts) == 0 and len(got.qs) == 0
+
+
+def test_record_region_overflow_is_rerun_exactly():
+    # an all-N read against an N-free reference yields one SFS per base: far more than the
+    # default len/8+8 records per read; the library must rerun with exact capacities
+    ref = synth.make_reference([30000], seed=7)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    reads = [np.full(500, 5, np.uint8), ref[0][100:900].copy(), np.full(64, 5, np.uint8),
+             synth.revcomp(ref[0][2000:2600])]
+    reads[1][400] = 5
+    flat, offs = svdss_amd.pack_reads(reads)
+    for assemble in (False, True):
+        got = _search(ix, flat, offs, assemble)
+        c, q, l, e = fm.search_batch(flat, offs, assemble)
+        assert got.counts.tolist() == c.tolist() and c[0] == 500
+        assert (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
+
+
+def test_device_buffers_and_stream():
+    import torch
+    ref, hap, svs, flat, offs = small_workload(seed=51, n_reads=200, read_len=1500)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    total = int(offs[-1])
+    d_reads = torch.zeros(((total + 15) // 16) * 16 + 16, dtype=torch.uint8, device="cuda:0")
+    d_reads[:total] = torch.from_numpy(flat).cuda()
+    d_offs = torch.from_numpy(offs).cuda()
+    pp = svdss_amd.PingPong(ix, assemble=True)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        got = pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), len(offs) - 1, total,
+                                         stream=s.cuda_stream)
+    c, q, l, e = fm.search_batch(flat, offs, True)
+    assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all()
+    assert pp.last_total == c.sum() and pp.last_total_ext == e.sum()
+    assert pp.last_kernel_ms > 0
+    # idempotence: same call, same buffers reused, same answer
+    got2 = pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), len(offs) - 1, total)
+    assert (got2.counts == got.counts).all() and (got2.qs == got.qs).all() and (got2.len == got.len).all()
+
+
+def test_process_batch_putative_filter_and_text():
+    # ping_pong.cpp:196-204: XF != 0 reads are skipped when putative; HP is carried as htag
+    ref, hap, svs, flat, offs = small_workload(seed=61, n_reads=6, read_len=500, ref_lens=(30000,))
+    reads = [flat[offs[i]:offs[i + 1]] for i in range(6)]
+    names = [f"r{i}" for i in range(6)]
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    pp = svdss_amd.PingPong(ix)
+    sols = pp.process_batch(names, reads, xf=[0, 1, 0, 2, 0, 3], hp=[0, 0, 1, 0, 2, 0])
+    assert [s[0] for s in sols] == ["r0", "r2", "r4"] and [s[1] for s in sols] == [0, 1, 2]
+    fm = O.OracleFMD.build(ref)
+    for (name, hp, sfs), i in zip(sols, (0, 2, 4)):
+        raw, _ = fm.ping_pong_search(reads[i])
+        assert sfs == O.assemble(raw)
+    txt = svdss_amd.output_batch(sols)
+    parsed = svdss_amd.parse_sfsfile(txt)
+    for name, hp, sfs in sols:
+        if sfs:
+            assert parsed[name] == [(q, l, hp) for q, l in sfs]
+    pp2 = svdss_amd.PingPong(ix, putative=False)
+    assert len(pp2.process_batch(names, reads, xf=[0, 1, 0, 2, 0, 3])) == 6
+
+
+def test_full_size_properties():
+    """BASELINE-shape reads (15 kb, 0.5 % errors) at a size the oracle cannot check in
+    seconds: size-independent properties of the SFS set."""
+    L = 15000
+    ref = synth.make_reference([8_000_000], seed=71)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    hap, svs = synth.implant_svs(ref, 40, seed=72)
+    flat, offs, truth = synth.simulate_reads(hap, 1500, L, 0.005, seed=73)
+    # reads copied verbatim from either strand of the reference: no SFS, exactly L-1 extensions
+    rng = np.random.default_rng(74)
+    exact = []
+    for k in range(64):
+        s = int(rng.integers(0, 8_000_000 - L))
+        w = ref[0][s:s + L]
+        exact.append(synth.revcomp(w) if k % 2 else w.copy())
+    eflat, eoffs = svdss_amd.pack_reads(exact)
+    got = _search(ix, eflat, eoffs, False)
+    assert got.counts.sum() == 0 and (got.n_ext == L - 1).all()
+
+    raw = _search(ix, flat, offs, False)
+    asm = _search(ix, flat, offs, True)
+    raw2 = _search(ix, flat, offs, False)
+    assert (raw.counts == raw2.counts).all() and (raw.qs == raw2.qs).all() and (raw.len == raw2.len).all()
+    assert raw.counts.sum() > 1500 * 50
+    # extension count == positions consumed by the two loops of ping_pong.cpp:15-22,31-37
+    rr, aa = raw.per_read(), asm.per_read()
+    for i in range(0, 1500, 7):
+        sfs = rr[i]
+        qs = [q for q, _ in sfs]
+        ends = [q + l for q, l in sfs]
+        assert all(a > b for a, b in zip(qs, qs[1:]))        # strictly descending starts
+        assert all(a > b for a, b in zip(ends, ends[1:]))    # and ends
+        assert aa[i] == O.assemble(sfs)
+        a = aa[i]
+        assert all(x[0] + x[1] <= y[0] for x, y in zip(a, a[1:]))
+    # defining property of an SFS: absent from the reference, both maximal proper substrings present
+    chk = 0
+    for i in range(0, 1500, 50):
+        r = flat[offs[i]:offs[i + 1]]
+        for q, l in rr[i][:8]:
+            assert ix.count(r[q:q + l]) == 0
+            if l > 1:
+                assert ix.count(r[q + 1:q + l]) > 0 and ix.count(r[q:q + l - 1]) > 0
+            chk += 1
+    assert chk > 100
+    # a sample against the oracle itself (index contents handed over as a BWT)
+    fm = O.OracleFMD.from_bwt(ix.bwt())
+    sub = list(range(0, 1500, 100))
+    sflat, soffs = svdss_amd.pack_reads([flat[offs[i]:offs[i + 1]] for i in sub])
+    c, q, l, e = fm.search_batch(sflat, soffs, False)
+    for k, i in enumerate(sub):
+        assert raw.counts[i] == c[k] and raw.n_ext[i] == e[k]
+    assert split(c, q, l) == [rr[i] for i in sub]
