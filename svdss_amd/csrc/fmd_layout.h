@@ -36,13 +36,28 @@
 
 struct __attribute__((aligned(16))) svdss_u4 { uint32_t x, y, z, w; };  // == uint4 on device
 
+// k-mer table entry (16 B): the state of a phase of ping_pong_search after its
+// first K symbols, for every ACGT K-mer W (key = sum W[i] << 2i, text order).
+//   info >> 62 == SVDSS_TAB_EMPTY  : W absent; info & 0xff = d = number of symbols
+//                                    (taken from the END of W) that still occur
+//   info >> 62 == SVDSS_TAB_UNIQUE : one occurrence; lo = SA index, info & MASK = text position
+//   info >> 62 == SVDSS_TAB_MULTI  : lo = SA index of the interval, info & MASK = size (>= 2)
+struct __attribute__((aligned(16))) SvdssTabEntry { uint64_t lo, info; };
+#define SVDSS_TAB_EMPTY 0ull
+#define SVDSS_TAB_UNIQUE 1ull
+#define SVDSS_TAB_MULTI 2ull
+#define SVDSS_TAB_MASK ((1ull << 62) - 1)
+
 struct SvdssDevIndex {
   const svdss_u4* blocks;   // 4 quarters per block, (n/128 + 1) blocks
   const int64_t* dollar;    // sorted BWT positions holding '$'
   int64_t n;                // BWT length
   int32_t n_dollar;
-  int32_t pad;
+  int32_t k;                // K of the k-mer table (0: no table)
   int64_t acc[7];           // acc[c] = #symbols < c
+  const uint8_t* text;      // nt6 text; text[-64 .. n+64) is readable ('$' padding)
+  const void* sa;           // suffix array: uint32[n] (n < 2^32) or uint64[n]
+  const SvdssTabEntry* table;  // 4^k entries or nullptr
 };
 
 // acc[c] through a select chain: a dynamically indexed kernel-argument array

@@ -152,22 +152,28 @@ int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t 
     if (n < (int64_t)0x7fffffff) {
       std::vector<int32_t> sa;
       suffix_array<int32_t>(t.data(), n, sa, threads);
+      ix->sa32.resize((size_t)n);
+      ix->sa64.clear();
 #pragma omp parallel for num_threads(threads) schedule(static)
       for (int64_t i = 0; i < n; ++i) {
         const int64_t p = sa[(size_t)i];
+        ix->sa32[(size_t)i] = (uint32_t)p;
         bwt[(size_t)i] = t[(size_t)(p == 0 ? n - 1 : p - 1)];
       }
     } else {
       std::vector<int64_t> sa;
       suffix_array<int64_t>(t.data(), n, sa, threads);
+      ix->sa64.resize((size_t)n);
+      ix->sa32.clear();
 #pragma omp parallel for num_threads(threads) schedule(static)
       for (int64_t i = 0; i < n; ++i) {
         const int64_t p = sa[(size_t)i];
+        ix->sa64[(size_t)i] = (uint64_t)p;
         bwt[(size_t)i] = t[(size_t)(p == 0 ? n - 1 : p - 1)];
       }
     }
   } catch (...) { return SVDSS_ENOMEM; }
-  std::vector<uint8_t>().swap(t);
+  ix->text.swap(t);
 
   ix->n = n;
   ix->n_contigs = n_contigs;
@@ -221,7 +227,7 @@ void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt) {
 
 namespace {
 struct FileHeader {
-  char magic[8];  // "SVDSSFM1"
+  char magic[8];  // "SVDSSFM2"
   int64_t n;
   int64_t acc[7];
   int64_t n_blocks;
@@ -236,7 +242,7 @@ int svdss_index_save_host(const svdss_index* ix, const char* path) {
   if (!f) return SVDSS_EIO;
   FileHeader h;
   memset(&h, 0, sizeof h);
-  memcpy(h.magic, "SVDSSFM1", 8);
+  memcpy(h.magic, "SVDSSFM2", 8);
   h.n = ix->n;
   memcpy(h.acc, ix->acc, sizeof h.acc);
   h.n_blocks = (int64_t)ix->blocks.size() / 4;
@@ -246,6 +252,11 @@ int svdss_index_save_host(const svdss_index* ix, const char* path) {
   bool ok = fwrite(&h, sizeof h, 1, f) == 1;
   ok = ok && fwrite(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
   ok = ok && fwrite(ix->dollar.data(), sizeof(int64_t), ix->dollar.size(), f) == ix->dollar.size();
+  ok = ok && fwrite(ix->text.data(), 1, ix->text.size(), f) == ix->text.size();
+  if (!ix->sa64.empty())
+    ok = ok && fwrite(ix->sa64.data(), sizeof(uint64_t), ix->sa64.size(), f) == ix->sa64.size();
+  else
+    ok = ok && fwrite(ix->sa32.data(), sizeof(uint32_t), ix->sa32.size(), f) == ix->sa32.size();
   ok = (fclose(f) == 0) && ok;
   return ok ? SVDSS_OK : SVDSS_EIO;
 }
@@ -254,7 +265,7 @@ int svdss_index_load_host(const char* path, svdss_index* ix) {
   FILE* f = fopen(path, "rb");
   if (!f) return SVDSS_EIO;
   FileHeader h;
-  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SVDSSFM1", 8) != 0 ||
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SVDSSFM2", 8) != 0 ||
       h.block_syms != SVDSS_BLOCK_SYMS || h.n < 0 || h.n_blocks != h.n / SVDSS_BLOCK_SYMS + 1 ||
       h.n_dollar < 0) {
     fclose(f);
@@ -266,9 +277,16 @@ int svdss_index_load_host(const char* path, svdss_index* ix) {
   try {
     ix->blocks.resize((size_t)(4 * h.n_blocks));
     ix->dollar.resize((size_t)h.n_dollar);
+    ix->text.resize((size_t)h.n);
+    if (h.n < (int64_t)0x7fffffff) ix->sa32.resize((size_t)h.n); else ix->sa64.resize((size_t)h.n);
   } catch (...) { fclose(f); return SVDSS_ENOMEM; }
   bool ok = fread(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
   ok = ok && fread(ix->dollar.data(), sizeof(int64_t), ix->dollar.size(), f) == ix->dollar.size();
+  ok = ok && fread(ix->text.data(), 1, ix->text.size(), f) == ix->text.size();
+  if (!ix->sa64.empty())
+    ok = ok && fread(ix->sa64.data(), sizeof(uint64_t), ix->sa64.size(), f) == ix->sa64.size();
+  else
+    ok = ok && fread(ix->sa32.data(), sizeof(uint32_t), ix->sa32.size(), f) == ix->sa32.size();
   fclose(f);
   return ok ? SVDSS_OK : SVDSS_EIO;
 }

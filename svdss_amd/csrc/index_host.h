@@ -11,10 +11,17 @@ struct svdss_index {
   int32_t n_contigs = 0;
   std::vector<svdss_u4> blocks;   // 4 * (n/128 + 1) quarters
   std::vector<int64_t> dollar;    // sorted BWT positions of '$'
+  std::vector<uint8_t> text;      // nt6 text (contig $ revcomp $ ...), n symbols
+  std::vector<uint32_t> sa32;     // suffix array when n < 2^32 ...
+  std::vector<uint64_t> sa64;     // ... else 64-bit
   // device residency (filled by svdss_index_to_device)
   int device = -1;
   void* d_blocks = nullptr;
   void* d_dollar = nullptr;
+  void* d_text = nullptr;         // allocation start; text begins 64 bytes in
+  void* d_sa = nullptr;
+  void* d_table = nullptr;
+  int32_t table_k = 0;
 };
 
 // Builds text (contig $ revcomp $ ...), suffix array, BWT and the block layout.

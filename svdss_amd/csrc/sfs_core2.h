@@ -1,0 +1,424 @@
+// sfs_core2.h -- per-read state machine of the v2 search kernel, shared by the
+// HIP kernel (one instance per lane) and tests/lane_emulator.cpp.
+//
+// Same observable behaviour as PingPong::ping_pong_search
+// (/root/reference/ping_pong.cpp:4-49): identical SFS (start, length, order)
+// and identical count of rb3_fmd_extend calls -- but the interval-size
+// predicate "does this substring occur" is evaluated three ways, whichever is
+// cheapest for the state the read is in:
+//   TABLE  the first K symbols of a phase (backward :12-22 or forward :30-37)
+//          are resolved by ONE lookup in a 4^K table holding, for every K-mer,
+//          either its SA interval or the depth at which it stops occurring;
+//   LF     one backward rank step on the BWT block layout (fmd_layout.h), as in v1;
+//   TEXT   once a backward phase has narrowed to a single occurrence (size 1),
+//          "prepend c succeeds" <=> "the text byte before the occurrence is c",
+//          so up to 64 read symbols per iteration are compared directly with the
+//          reference text (located through the full suffix array) -- no BWT walk.
+// Every iteration of the kernel issues the loads of exactly one of these
+// operations per lane, waits once, and applies the result.
+#pragma once
+#include "fmd_layout.h"
+
+enum { SV_OP_DONE = 0, SV_OP_LF = 1, SV_OP_TABLE = 2, SV_OP_SA = 3, SV_OP_TEXT = 4, SV_OP_FILL = 5,
+       SV_OP_TEXT_SLOW = 6 };
+
+#define SV_M_DIR 1     // 0 backward (ping_pong.cpp:15-22), 1 forward (:31-37)
+#define SV_M_START 2   // at a phase start: no interval yet (before :12 / :30)
+#define SV_M_TEXT 4    // unique-occurrence text-compare mode (backward only)
+#define SV_M_CHAIN 8   // streaming assembler has an open chain
+#define SV_NO_WINDOW (-0x40000000)
+
+// Per-lane window of 64 read symbols staged in LDS (device) or a local array
+// (emulator): dword row r lives at base[r * stride]; the byte of absolute read
+// buffer position a is byte (a & 3) of row ((a & 63) >> 2).
+struct SvRing {
+  uint32_t* base;
+  int stride;
+};
+
+template <class P>
+struct SvLane {
+  P lo, hi;          // LF mode: SA interval [lo,hi) of W (backward) / revcomp(W) (forward)
+  int64_t tdelta;    // TEXT mode: text index of read position p is tdelta + p
+  int32_t pos;       // read position of the last consumed symbol
+  int32_t begin;     // start of the SFS being closed (forward phase)
+  int32_t len;
+  int32_t mode;
+  int32_t c;         // symbol of the pending LF step / start of the pending table lookup
+  int32_t wrel;      // ring holds read positions [wrel, wrel+64)
+  int32_t n_sfs;
+  int32_t n_ext;
+  int32_t chain_lo, chain_end;
+};
+
+struct SvOp {
+  int op;
+  int64_t a;  // LF: unused; TABLE: key; SA: SA index; TEXT: unused; FILL: first chunk index
+};
+
+SVDSS_HD uint32_t sv_ring_row(const SvRing& g, int r) { return g.base[(r & 15) * g.stride]; }
+
+SVDSS_HD int sv_ring_sym(const SvRing& g, int64_t a) {
+  return (int)((sv_ring_row(g, (int)((a & 63) >> 2)) >> ((a & 3) * 8)) & 0xffu);
+}
+
+SVDSS_HD void sv_ring_fill(const SvRing& g, int64_t first_chunk, const svdss_u4 b[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (int)(((first_chunk + j) & 3) * 4);
+    g.base[(r + 0) * g.stride] = b[j].x;
+    g.base[(r + 1) * g.stride] = b[j].y;
+    g.base[(r + 2) * g.stride] = b[j].z;
+    g.base[(r + 3) * g.stride] = b[j].w;
+  }
+}
+
+// 2-bit key (text order, first symbol in the low bits) of the K symbols at
+// absolute positions [a0, a0+K); returns false if any of them is not A/C/G/T.
+SVDSS_HD bool sv_ring_kmer(const SvRing& g, int64_t a0, int K, uint32_t& key) {
+  const int r0 = (int)((a0 & 63) >> 2);
+  const int sh = (int)(a0 & 3) * 8;
+  uint32_t row[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) row[i] = sv_ring_row(g, r0 + i);
+  uint32_t k = 0, bad = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t w = (uint32_t)(((((uint64_t)row[i + 1]) << 32) | row[i]) >> sh);
+    const uint32_t t = w - 0x01010101u;             // A,C,G,T -> 0..3; '$' -> 0xff; N -> 4
+    const int nb = K - 4 * i;                       // bytes of this dword that belong to the K-mer
+    const uint32_t m = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+    bad |= t & 0xfcfcfcfcu & m;
+    k |= (((t & 0x03030303u) * 0x01041040u) >> 24) << (8 * i);
+  }
+  key = K >= 16 ? k : (k & ((1u << (2 * K)) - 1u));
+  return bad == 0;
+}
+
+// key of revcomp(W) from the key of W (K symbols)
+SVDSS_HD uint32_t sv_key_revcomp(uint32_t key, int K) {
+#if defined(__HIPCC__)
+  uint32_t z = __builtin_bitreverse32(key);
+#else
+  uint32_t z = key;
+  z = ((z >> 1) & 0x55555555u) | ((z & 0x55555555u) << 1);
+  z = ((z >> 2) & 0x33333333u) | ((z & 0x33333333u) << 2);
+  z = ((z >> 4) & 0x0f0f0f0fu) | ((z & 0x0f0f0f0fu) << 4);
+  z = __builtin_bswap32(z);
+#endif
+  z = ((z >> 1) & 0x55555555u) | ((z & 0x55555555u) << 1);
+  z >>= (32 - 2 * K);
+  return z ^ (K >= 16 ? 0xffffffffu : ((1u << (2 * K)) - 1u));
+}
+
+template <class P>
+SVDSS_HD void sv_lane_init(SvLane<P>& s, int len) {
+  s.lo = 0; s.hi = 0; s.tdelta = 0;
+  s.len = len;
+  s.pos = len - 1;
+  s.begin = 0;
+  s.mode = SV_M_START;  // backward phase about to start at pos = len-1 (ping_pong.cpp:8-12)
+  s.c = 0;
+  s.wrel = SV_NO_WINDOW;
+  s.n_sfs = 0; s.n_ext = 0;
+  s.chain_lo = 0; s.chain_end = 0;
+}
+
+template <class P>
+SVDSS_HD bool sv_in_window(const SvLane<P>& s, int p) { return p >= s.wrel && p < s.wrel + 64; }
+
+// Streaming Assembler::assemble (/root/reference/assembler.cpp:34-56), see sfs_core.h.
+template <class P, class Emit>
+SVDSS_HD void sv_emit(SvLane<P>& s, int qs, int l, bool assemble, Emit&& emit) {
+  if (!assemble) { emit(s.n_sfs++, qs, l); return; }
+  if (s.mode & SV_M_CHAIN) {
+    if (qs + l > s.chain_lo) { s.chain_lo = qs; return; }
+    emit(s.n_sfs++, s.chain_lo, s.chain_end - s.chain_lo);
+  }
+  s.mode |= SV_M_CHAIN;
+  s.chain_lo = qs;
+  s.chain_end = qs + l;
+}
+
+template <class P, class Emit>
+SVDSS_HD void sv_flush(SvLane<P>& s, bool assemble, Emit&& emit) {
+  if (assemble && (s.mode & SV_M_CHAIN)) {
+    emit(s.n_sfs++, s.chain_lo, s.chain_end - s.chain_lo);
+    s.mode &= ~SV_M_CHAIN;
+  }
+}
+
+// Decide the one memory operation of this iteration.  `off` = absolute buffer
+// position of the read's first symbol.  ALU + ring (LDS) reads only.
+template <class P, class Emit>
+SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, int64_t off,
+                        bool assemble, Emit&& emit) {
+  SvOp o;
+  o.op = SV_OP_DONE;
+  o.a = 0;
+  if (s.len <= 0) return o;
+  for (;;) {
+    if (s.mode & SV_M_TEXT) {
+      o.op = (off + s.pos >= 64) ? SV_OP_TEXT : SV_OP_TEXT_SLOW;
+      return o;
+    }
+    const int dir = s.mode & SV_M_DIR;
+    if (s.mode & SV_M_START) {
+      const int K = ix.k;
+      const int st = s.pos;
+      const int first = dir ? st : st - K + 1;  // lowest read position of the K-mer
+      if (K > 0 && first >= 0 && first + K <= s.len) {
+        if (first < s.wrel || first + K > s.wrel + 64) {    // the K symbols must be resident
+          o.op = SV_OP_FILL;
+          o.a = ((off + first - 20) >> 4);
+          return o;
+        }
+        uint32_t key;
+        if (sv_ring_kmer(g, off + first, K, key)) {
+          o.op = SV_OP_TABLE;
+          o.a = dir ? sv_key_revcomp(key, K) : key;
+          return o;
+        }
+      }
+      // fewer than K symbols left in this direction, or an N among them: start
+      // from the single symbol like the reference does (rb3_fmd_set_intv, :12 / :30)
+      if (!sv_in_window(s, st)) {
+        o.op = SV_OP_FILL;
+        o.a = ((off + st - 24) >> 4);
+        return o;
+      }
+      int c = sv_ring_sym(g, off + st);
+      if (dir) c = svdss_comp(c);
+      s.lo = (P)svdss_acc(ix, c);
+      s.hi = (P)svdss_acc(ix, c + 1);
+      s.mode &= ~SV_M_START;
+    }
+    const bool nonempty = s.hi > s.lo;
+    if (!dir) {
+      if (nonempty && s.pos > 0) {                    // ping_pong.cpp:15
+        if (s.hi - s.lo == 1 && ix.sa != nullptr) {   // single occurrence: switch to TEXT
+          o.op = SV_OP_SA;
+          o.a = (int64_t)s.lo;
+          return o;
+        }
+        const int np = s.pos - 1;
+        if (!sv_in_window(s, np)) {
+          o.op = SV_OP_FILL;
+          o.a = ((off + np - 40) >> 4);
+          return o;
+        }
+        s.pos = np;
+        s.c = sv_ring_sym(g, off + np);               // :21
+        o.op = SV_OP_LF;
+        return o;
+      }
+      if (s.pos == 0 && nonempty) return o;           // :24 -> DONE
+      s.begin = s.pos;                                // :28
+      s.mode |= SV_M_DIR | SV_M_START;
+    } else {
+      if (nonempty) {                                 // :31
+        const int np = s.pos + 1;
+        if (np < s.len && !sv_in_window(s, np)) {
+          o.op = SV_OP_FILL;
+          o.a = ((off + np - 24) >> 4);
+          return o;
+        }
+        s.pos = np;
+        s.c = svdss_comp(np < s.len ? sv_ring_sym(g, off + np) : 0);  // :36, P[l] == 0
+        o.op = SV_OP_LF;
+        return o;
+      }
+      sv_emit(s, s.begin, s.pos - s.begin + 1, assemble, emit);  // :38-41
+      if (s.begin == 0) return o;                     // :42 -> DONE
+      s.pos = s.pos - 1;                              // :47
+      s.mode = (s.mode & ~SV_M_DIR) | SV_M_START;
+    }
+  }
+}
+
+// ---- apply: the result of the iteration's memory operation -----------------
+
+template <class P>
+SVDSS_HD void sv_apply_lf(SvLane<P>& s, const SvdssDevIndex& ix, const svdss_u4 qa[4],
+                          const svdss_u4 qb[4], bool same_block) {
+  const int c = s.c;
+  const int64_t a = svdss_acc(ix, c);
+  if (c >= 1 && c <= 4) {
+    const uint32_t code = (uint32_t)(c - 1);
+    const uint32_t m0 = (code & 1u) ? 0u : 0xffffffffu;
+    const uint32_t m1 = (code & 2u) ? 0u : 0xffffffffu;
+    const int rl = (int)(s.lo & (SVDSS_BLOCK_SYMS - 1)), rh = (int)(s.hi & (SVDSS_BLOCK_SYMS - 1));
+    uint32_t cl = code == 0 ? qa[0].x : code == 1 ? qa[1].x : code == 2 ? qa[2].x : qa[3].x;
+    uint32_t cb = code == 0 ? qb[0].x : code == 1 ? qb[1].x : code == 2 ? qb[2].x : qb[3].x;
+    uint32_t ch = same_block ? cl : cb;
+    int sl = 0, sh = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t ma = (qa[j].y ^ m0) & (qa[j].z ^ m1) & ~qa[j].w;
+      const uint32_t mb = (qb[j].y ^ m0) & (qb[j].z ^ m1) & ~qb[j].w;
+      const uint32_t mh = same_block ? ma : mb;
+      sl += svdss_popc(ma & svdss_lowmask(rl - 32 * j));
+      sh += svdss_popc(mh & svdss_lowmask(rh - 32 * j));
+    }
+    s.lo = (P)(a + cl + sl);
+    s.hi = (P)(a + ch + sh);
+  } else {
+    s.lo = (P)(a + svdss_rank_in_block(ix, qa, c, (int64_t)s.lo));
+    s.hi = (P)(a + svdss_rank_in_block(ix, same_block ? qa : qb, c, (int64_t)s.hi));
+  }
+  ++s.n_ext;
+}
+
+template <class P>
+SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_lo, uint64_t e_info) {
+  const int K = ix.k;
+  const int dir = s.mode & SV_M_DIR;
+  const uint64_t type = e_info >> 62;
+  const uint64_t val = e_info & SVDSS_TAB_MASK;
+  s.mode &= ~SV_M_START;
+  if (type == SVDSS_TAB_EMPTY) {
+    const int d = (int)(val & 0xff);      // symbols consumed with a non-empty interval
+    // the reference consumed 1 (set_intv) + d extends, the last one emptied the interval
+    s.pos = dir ? s.pos + d : s.pos - d;
+    s.n_ext += d;
+    s.lo = 0;
+    s.hi = 0;
+    return;
+  }
+  s.pos = dir ? s.pos + (K - 1) : s.pos - (K - 1);
+  s.n_ext += K - 1;
+  s.lo = (P)e_lo;
+  if (type == SVDSS_TAB_UNIQUE) {
+    s.hi = (P)(e_lo + 1);
+    if (!dir && s.pos > 0) {              // go straight to TEXT mode: no SA lookup needed
+      s.tdelta = (int64_t)val - s.pos;
+      s.mode |= SV_M_TEXT;
+    }
+  } else {
+    s.hi = (P)(e_lo + val);
+  }
+}
+
+template <class P>
+SVDSS_HD void sv_apply_sa(SvLane<P>& s, int64_t text_pos) {
+  s.tdelta = text_pos - s.pos;
+  s.mode |= SV_M_TEXT;
+}
+
+// TEXT: ta[] = text bytes, rb[] = read bytes, both for read positions
+// [pos-64, pos) (byte 0 of ta[0]/rb[0] <-> position pos-64).  The lane consumes
+// symbols pos-1, pos-2, ... while they agree (one rb3_fmd_extend each,
+// ping_pong.cpp:15-22 with a size-1 interval), stops at the read start.
+template <class P>
+SVDSS_HD void sv_apply_text(SvLane<P>& s, const svdss_u4 ta[4], const svdss_u4 rb[4]) {
+  uint32_t x[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    x[4 * j + 0] = ta[j].x ^ rb[j].x;
+    x[4 * j + 1] = ta[j].y ^ rb[j].y;
+    x[4 * j + 2] = ta[j].z ^ rb[j].z;
+    x[4 * j + 3] = ta[j].w ^ rb[j].w;
+  }
+  // highest differing byte of the 64: binary selection, upper half first
+  int idx = 0;
+  uint32_t v8[8], v4[4], v2[2], v1;
+  {
+    const bool up = (x[8] | x[9] | x[10] | x[11] | x[12] | x[13] | x[14] | x[15]) != 0;
+    idx = up ? 8 : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v8[i] = up ? x[8 + i] : x[i];
+  }
+  {
+    const bool up = (v8[4] | v8[5] | v8[6] | v8[7]) != 0;
+    idx += up ? 4 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v4[i] = up ? v8[4 + i] : v8[i];
+  }
+  {
+    const bool up = (v4[2] | v4[3]) != 0;
+    idx += up ? 2 : 0;
+    v2[0] = up ? v4[2] : v4[0];
+    v2[1] = up ? v4[3] : v4[1];
+  }
+  {
+    const bool up = v2[1] != 0;
+    idx += up ? 1 : 0;
+    v1 = up ? v2[1] : v2[0];
+  }
+  // number of matching symbols counted down from pos-1
+  int matched;
+  if (v1 == 0) matched = 64;
+  else matched = 63 - (4 * idx + ((31 - __builtin_clz(v1)) >> 3));
+  const int avail = s.pos < 64 ? s.pos : 64;     // symbols left before the read start
+  if (matched >= avail) {
+    // every remaining symbol of this window agrees
+    s.pos -= avail;
+    s.n_ext += avail;
+    if (s.pos == 0) {                            // ping_pong.cpp:24: prefix matched, size != 0
+      s.mode &= ~SV_M_TEXT;
+      s.lo = 0;
+      s.hi = 1;
+    }
+  } else {
+    // symbol pos-1-matched disagrees: that extend empties the interval (:15 fails next)
+    s.pos -= matched + 1;
+    s.n_ext += matched + 1;
+    s.mode &= ~SV_M_TEXT;
+    s.lo = 0;
+    s.hi = 0;
+  }
+}
+
+// byte-wise variant for the first 64 bytes of the whole read buffer (where a
+// 64-byte window ending at pos would start before the buffer)
+template <class P>
+SVDSS_HD void sv_apply_text_slow(SvLane<P>& s, const uint8_t* text, const uint8_t* reads, int64_t off) {
+  while (s.pos > 0) {
+    const int np = s.pos - 1;
+    ++s.n_ext;
+    s.pos = np;
+    if (text[s.tdelta + np] != reads[off + np]) {
+      s.mode &= ~SV_M_TEXT;
+      s.lo = 0;
+      s.hi = 0;
+      return;
+    }
+  }
+  s.mode &= ~SV_M_TEXT;
+  s.lo = 0;
+  s.hi = 1;
+}
+
+// ---- k-mer table construction (one entry per key; device kernel and emulator) ----
+
+template <class P>
+SVDSS_HD void sv_table_entry(const SvdssDevIndex& ix, uint32_t key, int K, uint64_t& e_lo, uint64_t& e_info) {
+  // W[i] = ((key >> 2i) & 3) + 1; symbols are consumed from W[K-1] down to W[0]
+  int c = (int)((key >> (2 * (K - 1))) & 3u) + 1;
+  int64_t lo = svdss_acc(ix, c), hi = svdss_acc(ix, c + 1);
+  int d = 0;  // symbols consumed that left a non-empty interval
+  if (hi > lo) {
+    d = 1;
+    for (int i = K - 2; i >= 0; --i) {
+      c = (int)((key >> (2 * i)) & 3u) + 1;
+      const int64_t a = svdss_acc(ix, c);
+      const int64_t nlo = a + svdss_rank_in_block(ix, ix.blocks + 4 * (lo >> SVDSS_BLOCK_SHIFT), c, lo);
+      const int64_t nhi = a + svdss_rank_in_block(ix, ix.blocks + 4 * (hi >> SVDSS_BLOCK_SHIFT), c, hi);
+      lo = nlo;
+      hi = nhi;
+      if (hi <= lo) break;
+      ++d;
+    }
+  }
+  if (d == K) {
+    const uint64_t size = (uint64_t)(hi - lo);
+    e_lo = (uint64_t)lo;
+    if (size == 1 && ix.sa != nullptr)
+      e_info = (SVDSS_TAB_UNIQUE << 62) | (uint64_t)((const P*)ix.sa)[lo];
+    else
+      e_info = (SVDSS_TAB_MULTI << 62) | size;
+  } else {
+    e_lo = 0;
+    e_info = (SVDSS_TAB_EMPTY << 62) | (uint64_t)d;
+  }
+}

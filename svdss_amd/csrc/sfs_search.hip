@@ -14,6 +14,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,7 @@
 #include "fmd_layout.h"
 #include "index_host.h"
 #include "sfs_core.h"
+#include "sfs_core2.h"
 #include "sym_window.h"
 
 // ------------------------------------------------------------------ errors
@@ -102,13 +104,20 @@ extern "C" int svdss_index_load(const char* path, svdss_index_t** out) {
   return SVDSS_OK;
 }
 
+static void free_device_side(svdss_index* ix) {
+  if (ix->device < 0) return;
+  (void)hipSetDevice(ix->device);
+  for (void** p : {&ix->d_blocks, &ix->d_dollar, &ix->d_text, &ix->d_sa, &ix->d_table}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  ix->table_k = 0;
+  ix->device = -1;
+}
+
 extern "C" void svdss_index_free(svdss_index_t* ix) {
   if (!ix) return;
-  if (ix->device >= 0) {
-    (void)hipSetDevice(ix->device);
-    if (ix->d_blocks) (void)hipFree(ix->d_blocks);
-    if (ix->d_dollar) (void)hipFree(ix->d_dollar);
-  }
+  free_device_side(ix);
   delete ix;
 }
 
@@ -126,20 +135,56 @@ extern "C" int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out) {
   return SVDSS_OK;
 }
 
+static int auto_kmer(int64_t n) {
+  // K ~ log4(n): beyond that most K-mers of the text are unique, so a table hit usually
+  // resolves a phase start in one lookup.  4^K * 16 B: K=13 -> 1 GiB, K=16 -> 64 GiB of 288.
+  int k = 1;
+  while (k < 16 && ((int64_t)1 << (2 * (k + 1))) <= n) ++k;
+  if (const char* e = getenv("SVDSS_KMER")) k = atoi(e);
+  if (k < 0) k = 0;
+  if (k > 16) k = 16;
+  return k;
+}
+
 extern "C" int64_t svdss_index_device_bytes(const svdss_index_t* ix) {
   if (!ix) return -1;
-  return (int64_t)(ix->blocks.size() * sizeof(svdss_u4) + ix->dollar.size() * sizeof(int64_t));
+  const int k = ix->table_k > 0 ? ix->table_k : auto_kmer(ix->n);
+  const int64_t sa_bytes = ix->sa64.empty() ? 4 * ix->n : 8 * ix->n;
+  return (int64_t)(ix->blocks.size() * sizeof(svdss_u4) + ix->dollar.size() * sizeof(int64_t)) +
+         ix->n + 144 + sa_bytes + (k > 0 ? ((int64_t)16 << (2 * k)) : 0);
+}
+
+static SvdssDevIndex device_view(const svdss_index* ix) {
+  SvdssDevIndex v;
+  v.blocks = (const svdss_u4*)ix->d_blocks;
+  v.dollar = (const int64_t*)ix->d_dollar;
+  v.n = ix->n;
+  v.n_dollar = (int32_t)ix->dollar.size();
+  v.k = ix->table_k;
+  memcpy(v.acc, ix->acc, sizeof v.acc);
+  v.text = ix->d_text ? (const uint8_t*)ix->d_text + 64 : nullptr;
+  v.sa = ix->d_sa;
+  v.table = (const SvdssTabEntry*)ix->d_table;
+  return v;
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) build_table_kernel(SvdssDevIndex ix, SvdssTabEntry* tab, int K) {
+  const uint64_t nkeys = (uint64_t)1 << (2 * K);
+  for (uint64_t key = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; key < nkeys;
+       key += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t lo, info;
+    sv_table_entry<P>(ix, (uint32_t)key, K, lo, info);
+    tab[key].lo = lo;
+    tab[key].info = info;
+  }
 }
 
 extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
   if (!ix || device < 0) return SVDSS_EINVAL;
   HIPCHK(hipSetDevice(device));
-  if (ix->device >= 0) {
-    if (ix->d_blocks) (void)hipFree(ix->d_blocks);
-    if (ix->d_dollar) (void)hipFree(ix->d_dollar);
-    ix->d_blocks = ix->d_dollar = nullptr;
-    ix->device = -1;
-  }
+  free_device_side(ix);
+  ix->device = device;  // so that a failure below still frees what was allocated
   const size_t bb = ix->blocks.size() * sizeof(svdss_u4);
   const size_t db = (ix->dollar.size() + 1) * sizeof(int64_t);
   HIPCHK(hipMalloc(&ix->d_blocks, bb));
@@ -148,7 +193,36 @@ extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
   if (!ix->dollar.empty())
     HIPCHK(hipMemcpy(ix->d_dollar, ix->dollar.data(), ix->dollar.size() * sizeof(int64_t),
                      hipMemcpyHostToDevice));
-  ix->device = device;
+  // text with 64 bytes of '$' padding on both sides (the TEXT windows may start before /
+  // end after the text); suffix array with 16 bytes of slack for the 16-byte entry loads
+  const bool wide = !ix->sa64.empty();
+  if ((int64_t)ix->text.size() == ix->n && (wide || (int64_t)ix->sa32.size() == ix->n)) {
+    const size_t tb = (size_t)ix->n + 128 + 16;
+    HIPCHK(hipMalloc(&ix->d_text, tb));
+    HIPCHK(hipMemset(ix->d_text, 0, tb));
+    HIPCHK(hipMemcpy((uint8_t*)ix->d_text + 64, ix->text.data(), (size_t)ix->n, hipMemcpyHostToDevice));
+    const size_t sb = (size_t)ix->n * (wide ? 8 : 4);
+    HIPCHK(hipMalloc(&ix->d_sa, sb + 16));
+    HIPCHK(hipMemcpy(ix->d_sa, wide ? (const void*)ix->sa64.data() : (const void*)ix->sa32.data(), sb,
+                     hipMemcpyHostToDevice));
+  }
+  const int k = auto_kmer(ix->n);
+  if (k > 0) {
+    const size_t tbytes = (size_t)16 << (2 * k);
+    HIPCHK(hipMalloc(&ix->d_table, tbytes));
+    SvdssDevIndex v = device_view(ix);
+    const uint64_t nkeys = (uint64_t)1 << (2 * k);
+    const int blocks = (int)((nkeys + 255) / 256 < 65536 ? (nkeys + 255) / 256 : 65536);
+    if (wide)
+      hipLaunchKernelGGL(build_table_kernel<uint64_t>, dim3(blocks), dim3(256), 0, 0, v,
+                         (SvdssTabEntry*)ix->d_table, k);
+    else
+      hipLaunchKernelGGL(build_table_kernel<uint32_t>, dim3(blocks), dim3(256), 0, 0, v,
+                         (SvdssTabEntry*)ix->d_table, k);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    ix->table_k = k;
+  }
   return SVDSS_OK;
 }
 
@@ -158,7 +232,7 @@ static SvdssDevIndex host_view(const svdss_index* ix) {
   v.dollar = ix->dollar.data();
   v.n = ix->n;
   v.n_dollar = (int32_t)ix->dollar.size();
-  v.pad = 0;
+  v.k = 0; v.text = nullptr; v.sa = nullptr; v.table = nullptr;
   memcpy(v.acc, ix->acc, sizeof v.acc);
   return v;
 }
@@ -256,6 +330,115 @@ __global__ void __launch_bounds__(256) sfs_search_kernel(SfsParams p) {
       for (int j = 0; j < 4; ++j) qh[j] = ql[j];
     }
     svdss_lane_step(st, p.ix, ql, qh);
+  }
+}
+
+// ---- v2: k-mer table + LF + unique-match TEXT mode (sfs_core2.h) -------------
+struct __attribute__((packed, aligned(1))) SvU4u { uint32_t x, y, z, w; };  // 16 bytes, any alignment
+
+__device__ __forceinline__ svdss_u4 sv_load16(const uint8_t* p) {
+  const SvU4u v = *(const SvU4u*)p;
+  svdss_u4 r;
+  r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+  return r;
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
+  __shared__ uint32_t ring_lds[16 * 256];   // 64 read symbols per lane: row r of lane t at [r*256 + t]
+  SvRing g;
+  g.base = &ring_lds[threadIdx.x];
+  g.stride = 256;
+  SvLane<P> st;
+  int64_t r = 0, off = 0, base = 0, cap = 0;
+  bool active = false;
+  const bool assemble = p.assemble != 0;
+  const uint8_t* reads = (const uint8_t*)p.chunks;
+  const uint8_t* blocks = (const uint8_t*)p.ix.blocks;
+
+  auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
+    if (idx < cap) p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
+  };
+
+  for (;;) {
+    if (!active) {
+      const unsigned long long t = atomicAdd(p.next_read, 1ULL);
+      if (t >= (unsigned long long)p.n_reads) break;
+      r = (int64_t)t;
+      off = p.offsets[r];
+      const int64_t len = p.offsets[r + 1] - off;
+      base = p.rec_base ? p.rec_base[r] : rec_region_base(off, r);
+      cap = p.rec_cap ? p.rec_cap[r] : rec_region_cap(len);
+      sv_lane_init(st, (int32_t)len);
+      active = true;
+    }
+    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit);
+    if (o.op == SV_OP_DONE) {
+      sv_flush(st, assemble, emit);
+      p.counts[r] = st.n_sfs;
+      p.n_ext[r] = st.n_ext;
+      active = false;
+      continue;
+    }
+    if (o.op == SV_OP_TEXT_SLOW) {   // only the first 64 bytes of the whole batch
+      sv_apply_text_slow(st, p.ix.text, reads, off);
+      continue;
+    }
+    // one memory operation per lane: up to 4 x 16 B from pa and 4 x 16 B from pb
+    const uint8_t* pa = blocks;
+    const uint8_t* pb = blocks;
+    bool wide_a = false, need_b = false;
+    int64_t c0 = 0;
+    if (o.op == SV_OP_LF) {
+      const int64_t blo = (int64_t)st.lo >> SVDSS_BLOCK_SHIFT, bhi = (int64_t)st.hi >> SVDSS_BLOCK_SHIFT;
+      pa = blocks + blo * SVDSS_BLOCK_BYTES;
+      pb = blocks + bhi * SVDSS_BLOCK_BYTES;
+      wide_a = true;
+      need_b = bhi != blo;
+    } else if (o.op == SV_OP_TABLE) {
+      pa = (const uint8_t*)(p.ix.table + o.a);
+    } else if (o.op == SV_OP_SA) {
+      pa = (const uint8_t*)p.ix.sa + o.a * (int64_t)sizeof(P);
+    } else if (o.op == SV_OP_TEXT) {
+      pa = p.ix.text + st.tdelta + st.pos - 64;
+      pb = reads + off + st.pos - 64;
+      wide_a = true;
+      need_b = true;
+    } else {  // SV_OP_FILL
+      c0 = o.a;
+      if (c0 > p.max_chunk - 3) c0 = p.max_chunk - 3;
+      if (c0 < 0) c0 = 0;
+      pb = reads + 16 * c0;
+      need_b = true;
+    }
+    svdss_u4 A[4], B[4];
+    if (o.op != SV_OP_FILL) A[0] = sv_load16(pa);
+    if (wide_a) {
+      A[1] = sv_load16(pa + 16);
+      A[2] = sv_load16(pa + 32);
+      A[3] = sv_load16(pa + 48);
+    }
+    if (need_b) {
+      B[0] = sv_load16(pb);
+      B[1] = sv_load16(pb + 16);
+      B[2] = sv_load16(pb + 32);
+      B[3] = sv_load16(pb + 48);
+    }
+    if (o.op == SV_OP_LF) {
+      sv_apply_lf(st, p.ix, A, B, !need_b);
+    } else if (o.op == SV_OP_TABLE) {
+      sv_apply_table(st, p.ix, (uint64_t)A[0].x | ((uint64_t)A[0].y << 32),
+                     (uint64_t)A[0].z | ((uint64_t)A[0].w << 32));
+    } else if (o.op == SV_OP_SA) {
+      const int64_t tp = sizeof(P) == 4 ? (int64_t)A[0].x
+                                        : (int64_t)((uint64_t)A[0].x | ((uint64_t)A[0].y << 32));
+      sv_apply_sa(st, tp);
+    } else if (o.op == SV_OP_TEXT) {
+      sv_apply_text(st, A, B);
+    } else {
+      sv_ring_fill(g, c0, B);
+      st.wrel = (int32_t)(16 * c0 - off);
+    }
   }
 }
 
@@ -378,12 +561,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   if ((rc = ensure(b->sum, 64))) return rc;
 
   SfsParams p;
-  p.ix.blocks = (const svdss_u4*)ix->d_blocks;
-  p.ix.dollar = (const int64_t*)ix->d_dollar;
-  p.ix.n = ix->n;
-  p.ix.n_dollar = (int32_t)ix->dollar.size();
-  p.ix.pad = 0;
-  memcpy(p.ix.acc, ix->acc, sizeof p.ix.acc);
+  p.ix = device_view(ix);
   p.chunks = (const svdss_u4*)d_reads;
   p.max_chunk = total_syms > 0 ? ((total_syms + 15) >> 4) - 1 : 0;
   p.offsets = d_offsets;
@@ -397,6 +575,9 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.assemble = (flags & SVDSS_SFS_ASSEMBLE) ? 1 : 0;
   unsigned long long* d_overflow = (unsigned long long*)b->misc.p + 1;
 
+  // SVDSS_KERNEL=1 selects the v1 kernel (plain LF walk) for A/B measurements
+  const char* kv = getenv("SVDSS_KERNEL");
+  const bool use_v1 = (kv && atoi(kv) == 1) || total_syms < 64;
   int max_blocks = 0;
   if ((rc = launch_grid(ix->device, &max_blocks))) return rc;
   const int64_t want_blocks = (n_reads + 255) / 256;
@@ -415,7 +596,12 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     HIPCHK(hipMemsetAsync(b->misc.p, 0, 16, stream));
     HIPCHK(hipMemsetAsync((int64_t*)b->counts.p + n_reads, 0, sizeof(int64_t), stream));
     HIPCHK(hipEventRecord(b->ev0, stream));
-    hipLaunchKernelGGL(sfs_search_kernel, dim3(sblocks), dim3(256), 0, stream, p);
+    if (use_v1)
+      hipLaunchKernelGGL(sfs_search_kernel, dim3(sblocks), dim3(256), 0, stream, p);
+    else if (ix->sa64.empty())
+      hipLaunchKernelGGL(sfs_search2_kernel<uint32_t>, dim3(sblocks), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL(sfs_search2_kernel<uint64_t>, dim3(sblocks), dim3(256), 0, stream, p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1, stream));
     size_t tb = b->tmp.cap;

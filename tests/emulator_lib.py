@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "_lane_emulator.so")
 SRC = os.path.join(HERE, "lane_emulator.cpp")
 _deps = [SRC] + [os.path.join(HERE, "..", "svdss_amd", "csrc", f)
-                 for f in ("sfs_core.h", "sym_window.h", "fmd_layout.h", "index_host.h")]
+                 for f in ("sfs_core.h", "sfs_core2.h", "sym_window.h", "fmd_layout.h", "index_host.h")]
 if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in _deps):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                            "-o", SO, SRC])
@@ -35,3 +35,29 @@ def search(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool):
                         counts.ctypes.data, qs.ctypes.data, ln.ctypes.data, cap, n_ext.ctypes.data)
     assert t >= 0
     return counts, qs[:t].copy(), ln[:t].copy(), n_ext
+
+
+_lib.emu_search2.restype = _i64
+_lib.emu_search2.argtypes = [_p, _p, _p, _i64, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _p, _p]
+OP_NAMES = ["DONE", "LF", "TABLE", "SA", "TEXT", "FILL", "TEXT_SLOW"]
+
+
+def search2(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool, K: int = 6, use_text: bool = True):
+    """v2 lane code (k-mer table of order K, LF, TEXT).  Returns (counts, qs, len, n_ext, op_counts)."""
+    n = len(offsets) - 1
+    total_syms = int(offsets[-1])
+    padded = np.zeros(max(((total_syms + 15) // 16) * 16 + 16, 80), dtype=np.uint8)
+    padded[:total_syms] = flat
+    alloc_syms = len(padded) - 16
+    cap = total_syms + n + 1
+    counts = np.zeros(n, dtype=np.int64)
+    n_ext = np.zeros(n, dtype=np.int64)
+    ops = np.zeros(8, dtype=np.int64)
+    qs = np.zeros(cap, dtype=np.int32)
+    ln = np.zeros(cap, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    t = _lib.emu_search2(index._h, padded.ctypes.data, offsets.ctypes.data, n, alloc_syms, int(assemble), K,
+                         int(use_text), counts.ctypes.data, qs.ctypes.data, ln.ctypes.data, cap,
+                         n_ext.ctypes.data, ops.ctypes.data)
+    assert t >= 0
+    return counts, qs[:t].copy(), ln[:t].copy(), n_ext, dict(zip(OP_NAMES, ops.tolist()))

@@ -54,3 +54,69 @@ def test_unaligned_offsets_and_empty_reads():
         c2, q2, l2, e2 = fm.search_batch(flat2, offs2, assemble)
         assert (c == c2).all() and (q == q2).all() and (l == l2).all() and (e == e2).all()
     assert c[4] == 0 and c[-1] == 0
+
+
+# ---- v2 state machine (sfs_core2.h): k-mer table + LF + unique-match TEXT mode ----
+
+V2_CONFIGS = [(0, False), (0, True), (5, False), (7, True), (10, True)]
+
+
+def test_v2_golden_through_lane_code():
+    for case in load_golden():
+        contigs = [from_ascii(c) for c in case["contigs"]]
+        ix = svdss_amd.FMDIndex.build(contigs, threads=2)
+        reads = [from_ascii(r["read"]) for r in case["reads"]]
+        flat, offs = svdss_amd.pack_reads(reads)
+        for K, use_text in V2_CONFIGS:
+            c, q, l, e, ops = E.search2(ix, flat, offs, False, K, use_text)
+            for got, rd, ne in zip(split(c, q, l), case["reads"], e.tolist()):
+                assert [list(x) for x in got] == rd["sfs"], (case["name"], K, use_text)
+                assert ne == rd["n_ext"]
+            c, q, l, e, ops = E.search2(ix, flat, offs, True, K, use_text)
+            for got, rd in zip(split(c, q, l), case["reads"]):
+                assert [list(x) for x in got] == rd["assembled"]
+
+
+@pytest.mark.parametrize("assemble", [False, True])
+def test_v2_random_reads_match_oracle(assemble):
+    ref, hap, svs, flat, offs = small_workload(seed=33, n_reads=40, read_len=1500)
+    reads = [flat[offs[i]:offs[i + 1]] for i in range(40)]
+    # a short first read (TEXT windows would start before the buffer), N reads, empty read, 1-mers
+    reads = [ref[0][3:40].copy()] + reads + [np.full(70, 5, np.uint8), np.zeros(0, np.uint8), ref[1][:1].copy(),
+                                              ref[0][0:900].copy(), hap[0][:700].copy()]
+    reads[-2][450] = 5
+    flat, offs = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(ref, threads=4)
+    fm = O.OracleFMD.build(ref)
+    c2, q2, l2, e2 = fm.search_batch(flat, offs, assemble)
+    for K, use_text in V2_CONFIGS:
+        c, q, l, e, ops = E.search2(ix, flat, offs, assemble, K, use_text)
+        assert (c == c2).all() and (e == e2).all(), (K, use_text)
+        assert (q == q2).all() and (l == l2).all()
+        if K:
+            assert ops["TABLE"] > 0
+        if use_text:
+            assert ops["TEXT"] > 0
+    # the point of v2: an order of magnitude fewer memory operations than extensions
+    assert sum(ops[k] for k in ("LF", "TABLE", "SA", "TEXT", "FILL")) * 4 < e2.sum()
+
+
+def test_v2_repeats_and_long_unique_stretches():
+    # diverged repeats keep intervals > 1 for long (LF mode), exact reads exercise multi-window TEXT runs
+    from svdss_amd import synth
+    ref = synth.make_reference([90000], seed=77, repeat_frac=0.4, divergence=0.002)
+    ix = svdss_amd.FMDIndex.build(ref, threads=4)
+    fm = O.OracleFMD.build(ref)
+    rng = np.random.default_rng(5)
+    reads = []
+    for k in range(12):
+        s = int(rng.integers(0, 80000))
+        w = ref[0][s:s + 3000].copy()
+        if k % 3 == 0:
+            w[int(rng.integers(0, 3000))] = 5
+        reads.append(synth.revcomp(w) if k % 2 else w)
+    flat, offs = svdss_amd.pack_reads(reads)
+    c2, q2, l2, e2 = fm.search_batch(flat, offs, False)
+    for K, use_text in [(8, True), (0, True)]:
+        c, q, l, e, ops = E.search2(ix, flat, offs, False, K, use_text)
+        assert (c == c2).all() and (e == e2).all() and (q == q2).all() and (l == l2).all()
