@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+GRCH38_PRIMARY = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+                  138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+                  83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+
 
 def simulate_reads_gpu(ref_t, n_reads, L, err, seed, device, chunk=2048):
     """Seeded HiFi-shape reads on the GPU (torch ops; data plumbing, not the hot path):
@@ -78,7 +82,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--ref-len", type=int, default=64_444_167, help="reference bases (chr20 length)")
+    ap.add_argument("--workload", choices=["chr20", "wg"], default="chr20",
+                    help="chr20: one 64,444,167 bp contig, 30x; wg: 24 contigs with GRCh38 primary lengths "
+                         "(3,088,269,832 bp), 1,048,576 reads per step (a 30x set is 6.2 M reads = 6 steps)")
+    ap.add_argument("--ref-len", type=int, default=0, help="override: single contig of this many bases")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--read-len", type=int, default=15000)
     ap.add_argument("--err", type=float, default=0.005)
@@ -103,13 +110,25 @@ def main():
     import svdss_amd
     from svdss_amd import multi, synth
 
-    n_reads = args.reads or int(round(args.coverage * args.ref_len / args.read_len))
+    if args.ref_len:
+        contig_lens = [args.ref_len]
+    elif args.workload == "wg":
+        contig_lens = GRCH38_PRIMARY
+    else:
+        contig_lens = [64_444_167]
+    ref_total = sum(contig_lens)
+    if args.reads:
+        n_reads = args.reads
+    elif args.workload == "wg" and not args.ref_len:
+        n_reads = 1 << 20
+    else:
+        n_reads = int(round(args.coverage * ref_total / args.read_len))
     L = args.read_len
 
     # ---- index: built once (rank 0), replicated into every GPU's HBM -------
     t0 = time.time()
-    ref = synth.make_reference([args.ref_len], seed=11)
-    idx_path = f"/tmp/svdss_bench_{args.ref_len}.fmd"
+    ref = synth.make_reference(contig_lens, seed=11)
+    idx_path = f"/tmp/svdss_bench_{ref_total}.fmd"
     if rank == 0:
         ix = svdss_amd.FMDIndex.build(ref)
         if world > 1:
@@ -122,7 +141,8 @@ def main():
     t_index = time.time() - t0
 
     # ---- reads: generated on the GPU, one independent shard per rank -------
-    ref_t = torch.from_numpy(ref[0]).to(device)
+    ref_t = torch.from_numpy(ref[0] if len(ref) == 1 else np.concatenate(ref)).to(device)
+    del ref
     d_reads, d_offs = simulate_reads_gpu(ref_t, n_reads, L, args.err, seed=13 + 1000 * rank, device=device)
     total_syms = n_reads * L
     del ref_t
@@ -185,14 +205,17 @@ def main():
             "dtype": "int64",
             "data": "synthetic",
             "config": {
-                "workload": (f"synthetic {args.ref_len} bp reference (chr20 length, iid ACGT + 3% diverged "
-                             f"repeats, both strands indexed: {ix.size} BWT symbols), {n_reads} reads/GPU x "
-                             f"{L} bp ({n_reads * L / args.ref_len:.1f}x), {args.err * 100:.2f}% errors, "
-                             "search with fused assemble, all reads searched (--noputative semantics)"),
+                "workload": (f"synthetic {ref_total} bp reference in {len(contig_lens)} contig(s) "
+                             f"({'GRCh38 primary lengths' if len(contig_lens) == 24 else 'chr20 length' if ref_total == 64_444_167 else 'custom'}"
+                             f", iid ACGT + 3% diverged repeats, both strands indexed: {ix.size} BWT symbols), "
+                             f"{n_reads} reads/GPU/step x {L} bp ({n_reads * L / ref_total:.2f}x per step), "
+                             f"{args.err * 100:.2f}% errors, search with fused assemble, all reads searched "
+                             "(--noputative semantics)"),
                 "reads_per_gpu": n_reads, "read_len": L, "index_bytes": ix.device_bytes,
                 "parallelism": f"reads sharded over {world} GPU(s), index replicated, SFS gathered on rank 0",
                 "ext_per_read": n_ext / n_reads, "raw_sfs_per_read": n_sfs_raw / n_reads,
                 "assembled_sfs_per_read": n_sfs_asm / n_reads, "index_build_s": round(t_index, 1),
+                "kmer_table_k": ix.kmer_k,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "sfs_search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

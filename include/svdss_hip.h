@@ -58,7 +58,10 @@ int svdss_index_acc(const svdss_index_t* ix, int64_t acc[7]);
 int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out);
 /* bytes the index occupies in HBM once resident */
 int64_t svdss_index_device_bytes(const svdss_index_t* ix);
-/* copy the index into the HBM of `device` (replicated per GPU) */
+/* order K of the k-mer table built by svdss_index_to_device (0 before / without it) */
+int32_t svdss_index_kmer(const svdss_index_t* ix);
+/* copy the index into the HBM of `device` (replicated per GPU): BWT blocks,
+ * text, suffix array, and the 4^K k-mer table (K = floor(log4 n)+1, env SVDSS_KMER overrides) */
 int svdss_index_to_device(svdss_index_t* ix, int32_t device);
 
 /* Size of the interval of a pattern (occurrences in contigs + revcomps) via

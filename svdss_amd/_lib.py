@@ -53,6 +53,7 @@ SIGNATURES = {
     "svdss_index_acc": (C.c_int, [_p, _p]),
     "svdss_index_bwt": (C.c_int, [_p, _p]),
     "svdss_index_device_bytes": (_i64, [_p]),
+    "svdss_index_kmer": (_i32, [_p]),
     "svdss_index_to_device": (C.c_int, [_p, _i32]),
     "svdss_index_count": (_i64, [_p, _p, _i64]),
     "svdss_sfs_search_batch": (C.c_int, [_p, _p, _p, _i64, _i32, C.POINTER(_p)]),

@@ -14,6 +14,7 @@
 #include <parallel/algorithm>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -149,7 +150,8 @@ int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t 
   std::vector<uint8_t> bwt;
   try {
     bwt.resize((size_t)n);
-    if (n < (int64_t)0x7fffffff) {
+    const bool force64 = getenv("SVDSS_FORCE_SA64") != nullptr;  // test hook for the 64-bit path
+    if (n < (int64_t)0x7fffffff && !force64) {
       std::vector<int32_t> sa;
       suffix_array<int32_t>(t.data(), n, sa, threads);
       ix->sa32.resize((size_t)n);
@@ -234,6 +236,8 @@ struct FileHeader {
   int64_t n_dollar;
   int32_t n_contigs;
   int32_t block_syms;
+  int32_t sa_wide;   // 1: 64-bit suffix array entries
+  int32_t reserved;
 };
 }  // namespace
 
@@ -249,6 +253,7 @@ int svdss_index_save_host(const svdss_index* ix, const char* path) {
   h.n_dollar = (int64_t)ix->dollar.size();
   h.n_contigs = ix->n_contigs;
   h.block_syms = SVDSS_BLOCK_SYMS;
+  h.sa_wide = ix->sa64.empty() ? 0 : 1;
   bool ok = fwrite(&h, sizeof h, 1, f) == 1;
   ok = ok && fwrite(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
   ok = ok && fwrite(ix->dollar.data(), sizeof(int64_t), ix->dollar.size(), f) == ix->dollar.size();
@@ -278,7 +283,7 @@ int svdss_index_load_host(const char* path, svdss_index* ix) {
     ix->blocks.resize((size_t)(4 * h.n_blocks));
     ix->dollar.resize((size_t)h.n_dollar);
     ix->text.resize((size_t)h.n);
-    if (h.n < (int64_t)0x7fffffff) ix->sa32.resize((size_t)h.n); else ix->sa64.resize((size_t)h.n);
+    if (h.sa_wide) ix->sa64.resize((size_t)h.n); else ix->sa32.resize((size_t)h.n);
   } catch (...) { fclose(f); return SVDSS_ENOMEM; }
   bool ok = fread(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
   ok = ok && fread(ix->dollar.data(), sizeof(int64_t), ix->dollar.size(), f) == ix->dollar.size();

@@ -136,10 +136,11 @@ extern "C" int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out) {
 }
 
 static int auto_kmer(int64_t n) {
-  // K ~ log4(n): beyond that most K-mers of the text are unique, so a table hit usually
-  // resolves a phase start in one lookup.  4^K * 16 B: K=13 -> 1 GiB, K=16 -> 64 GiB of 288.
+  // K = floor(log4 n) + 1: most K-mers of the text are then unique and most random K-mers
+  // absent, so one lookup resolves a phase start (unique -> TEXT mode, absent -> fail depth).
+  // 4^K * 16 B: K=14 -> 4 GiB (chr20), K=16 -> 64 GiB (GRCh38) of the 288 GB of HBM.
   int k = 1;
-  while (k < 16 && ((int64_t)1 << (2 * (k + 1))) <= n) ++k;
+  while (k < 16 && ((int64_t)1 << (2 * k)) <= n) ++k;   // floor(log4 n) + 1
   if (const char* e = getenv("SVDSS_KMER")) k = atoi(e);
   if (k < 0) k = 0;
   if (k > 16) k = 16;
@@ -153,6 +154,8 @@ extern "C" int64_t svdss_index_device_bytes(const svdss_index_t* ix) {
   return (int64_t)(ix->blocks.size() * sizeof(svdss_u4) + ix->dollar.size() * sizeof(int64_t)) +
          ix->n + 144 + sa_bytes + (k > 0 ? ((int64_t)16 << (2 * k)) : 0);
 }
+
+extern "C" int32_t svdss_index_kmer(const svdss_index_t* ix) { return ix ? ix->table_k : -1; }
 
 static SvdssDevIndex device_view(const svdss_index* ix) {
   SvdssDevIndex v;

@@ -106,6 +106,10 @@ class FMDIndex:
     def device_bytes(self) -> int:
         return lib.svdss_index_device_bytes(self._h)
 
+    @property
+    def kmer_k(self) -> int:
+        return lib.svdss_index_kmer(self._h)
+
     def bwt(self) -> np.ndarray:
         b = np.empty(self.size, dtype=np.uint8)
         check(lib.svdss_index_bwt(self._h, b.ctypes.data), "svdss_index_bwt")

@@ -186,3 +186,42 @@ def test_full_size_properties():
     for k, i in enumerate(sub):
         assert raw.counts[i] == c[k] and raw.n_ext[i] == e[k]
     assert split(c, q, l) == [rr[i] for i in sub]
+
+
+def test_wide_suffix_array_path(monkeypatch):
+    """Genomes with >= 2^31 BWT symbols use 64-bit SA entries / intervals (kernel template
+    instantiation <uint64_t>); SVDSS_FORCE_SA64 builds that layout for a small input."""
+    monkeypatch.setenv("SVDSS_FORCE_SA64", "1")
+    ref, hap, svs, flat, offs = small_workload(seed=35, n_reads=150, read_len=1500)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    monkeypatch.delenv("SVDSS_FORCE_SA64")
+    fm = O.OracleFMD.build(ref)
+    for assemble in (False, True):
+        got = _search(ix, flat, offs, assemble)
+        c, q, l, e = fm.search_batch(flat, offs, assemble)
+        assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
+
+
+@pytest.mark.parametrize("kmer", ["0", "6", "12"])
+def test_kmer_table_orders(monkeypatch, kmer):
+    """Any table order K (0 = no table) must give the same SFS; K > log4(n) makes most entries
+    'absent with fail depth', K small makes them multi-occurrence intervals."""
+    monkeypatch.setenv("SVDSS_KMER", kmer)
+    ref, hap, svs, flat, offs = small_workload(seed=36, n_reads=150, read_len=1500)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    assert ix.kmer_k == int(kmer)
+    fm = O.OracleFMD.build(ref)
+    got = _search(ix, flat, offs, True)
+    c, q, l, e = fm.search_batch(flat, offs, True)
+    assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
+
+
+def test_v1_kernel_still_agrees(monkeypatch):
+    """SVDSS_KERNEL=1 selects the plain LF-walk kernel kept for A/B measurements."""
+    monkeypatch.setenv("SVDSS_KERNEL", "1")
+    ref, hap, svs, flat, offs = small_workload(seed=37, n_reads=100, read_len=1200)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    got = _search(ix, flat, offs, False)
+    c, q, l, e = fm.search_batch(flat, offs, False)
+    assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
