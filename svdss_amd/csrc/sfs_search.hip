@@ -136,11 +136,16 @@ extern "C" int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out) {
 }
 
 static int auto_kmer(int64_t n) {
-  // K = floor(log4 n) + 1: most K-mers of the text are then unique and most random K-mers
-  // absent, so one lookup resolves a phase start (unique -> TEXT mode, absent -> fail depth).
-  // 4^K * 16 B: K=14 -> 4 GiB (chr20), K=16 -> 64 GiB (GRCh38) of the 288 GB of HBM.
+  // K = floor(log4 n) + 3, at most 16: nearly every K-mer of the text is then unique and
+  // nearly every other K-mer absent, so ONE lookup resolves a phase start (unique -> TEXT
+  // mode, absent -> fail depth).  The table costs 4^K * 16 B (K=16: 64 GiB of the 288 GB
+  // of HBM); it is shrunk until it fits in a third of the free device memory.
   int k = 1;
   while (k < 16 && ((int64_t)1 << (2 * k)) <= n) ++k;   // floor(log4 n) + 1
+  k = k + 2 > 16 ? 16 : k + 2;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+    while (k > 4 && ((size_t)16 << (2 * k)) > free_b / 3) --k;
   if (const char* e = getenv("SVDSS_KMER")) k = atoi(e);
   if (k < 0) k = 0;
   if (k > 16) k = 16;
@@ -149,7 +154,7 @@ static int auto_kmer(int64_t n) {
 
 extern "C" int64_t svdss_index_device_bytes(const svdss_index_t* ix) {
   if (!ix) return -1;
-  const int k = ix->table_k > 0 ? ix->table_k : auto_kmer(ix->n);
+  const int k = ix->table_k;   // known once the index is resident
   const int64_t sa_bytes = ix->sa64.empty() ? 4 * ix->n : 8 * ix->n;
   return (int64_t)(ix->blocks.size() * sizeof(svdss_u4) + ix->dollar.size() * sizeof(int64_t)) +
          ix->n + 144 + sa_bytes + (k > 0 ? ((int64_t)16 << (2 * k)) : 0);
