@@ -114,6 +114,37 @@ int svdss_sfs_batch_device_ptrs(const svdss_sfs_batch_t* b, void** counts, void*
                                 void** n_ext);
 void svdss_sfs_batch_free(svdss_sfs_batch_t* b);
 
+/* ---- a15: global dual-affine realignment of consensus to reference --------
+ * Replaces ksw_extd2_sse(km=0, qlen, query, tlen, target, m, mat, q, e, q2, e2,
+ * w=-1, zdrop=-1, end_bonus=-1, flag=0, &ez) as called at caller.cpp:348-349
+ * (ksw2 @HEAD), for a batch of (query = POA consensus, target = reference
+ * window) pairs.  Symbols are 0..m-1 (caller.hpp:25-37 _char26_table: ACGT ->
+ * 0-3, other -> 4); mat is the m x m substitution matrix (caller.cpp:336-337).
+ * Per pair: score = ez.score (VCF `AS`, caller.cpp:351) and the CIGAR as ksw2
+ * packs it, len<<4 | op with op 0=M 1=I 2=D (caller.cpp:353-355), gaps
+ * left-aligned, from a backtrack at (tlen-1, qlen-1).  Empty query or target:
+ * score 0, no CIGAR (ksw2 returns before touching ez). */
+typedef struct svdss_aln_batch svdss_aln_batch_t;
+
+int svdss_align_global_batch(const uint8_t* queries, const int64_t* q_off, const uint8_t* targets,
+                             const int64_t* t_off, int64_t n_pairs, int32_t m, const int8_t* mat,
+                             int32_t gapo, int32_t gape, int32_t gapo2, int32_t gape2, int32_t device,
+                             svdss_aln_batch_t** out);
+int64_t svdss_aln_batch_npairs(const svdss_aln_batch_t* b);
+int64_t svdss_aln_batch_total_cigar(const svdss_aln_batch_t* b);   /* sum of n_cigar */
+int64_t svdss_aln_batch_cells(const svdss_aln_batch_t* b);         /* sum of tlen*qlen */
+double svdss_aln_batch_kernel_ms(const svdss_aln_batch_t* b);
+/* scores int32[n_pairs], n_cigar int64[n_pairs], cigar uint32[total_cigar] (pairs concatenated) */
+int svdss_aln_batch_fetch(const svdss_aln_batch_t* b, int32_t* scores, int64_t* n_cigar, uint32_t* cigar);
+void svdss_aln_batch_free(svdss_aln_batch_t* b);
+
+/* ---- a17: rapidfuzz::fuzz::ratio(a, b) (rapidfuzz-cpp v1.10.4) -----------
+ * as called at caller.cpp:456,458 on the REF/ALT alleles of adjacent SVs:
+ * 100 * (1 - (|a|+|b| - 2 LCS(a,b)) / (|a|+|b|)), 100 for two empty strings.
+ * a/b: concatenated byte strings with offsets[n_pairs+1].  lcs_out may be NULL. */
+int svdss_indel_ratio_batch(const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off,
+                            int64_t n_pairs, int32_t device, double* ratio_out, int64_t* lcs_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,13 +29,13 @@
 
 // ------------------------------------------------------------------ errors
 
-static thread_local std::string g_hip_err;
+thread_local std::string g_svdss_hip_err;   // shared with call_dp.hip
 
 #define HIPCHK(expr)                                                              \
   do {                                                                            \
     hipError_t e_ = (expr);                                                       \
     if (e_ != hipSuccess) {                                                       \
-      g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+      g_svdss_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
       return (e_ == hipErrorOutOfMemory) ? SVDSS_ENOMEM : SVDSS_EHIP;             \
     }                                                                             \
   } while (0)
@@ -53,7 +53,7 @@ extern "C" const char* svdss_strerror(int code) {
   }
 }
 
-extern "C" const char* svdss_last_hip_error(void) { return g_hip_err.c_str(); }
+extern "C" const char* svdss_last_hip_error(void) { return g_svdss_hip_err.c_str(); }
 
 // --------------------------------------------------------------------- a1
 

@@ -167,3 +167,64 @@ def assemble(sfs):
 
 def max_threads():
     return _lib.orc_max_threads()
+
+
+# ---- call-side DP (oracle/svdss_oracle_call.c) -----------------------------
+_i32 = C.c_int32
+_lib.orc_ksw_extd2_global.restype = _i64
+_lib.orc_ksw_extd2_global.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      _p, _p, _i64]
+_lib.orc_global_score_general.restype = _i32
+_lib.orc_global_score_general.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int]
+_lib.orc_cigar_score.restype = _i32
+_lib.orc_cigar_score.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _i64]
+_lib.orc_lcs.restype = _i64
+_lib.orc_lcs.argtypes = [_p, _i64, _p, _i64]
+_lib.orc_fuzz_ratio.restype = C.c_double
+_lib.orc_fuzz_ratio.argtypes = [_p, _i64, _p, _i64]
+
+
+def ksw_extd2_global(query, target, mat, q=16, e=2, q2=41, e2=1):
+    """-> (score, cigar ops uint32 array)."""
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    mat = np.ascontiguousarray(mat, dtype=np.int8)
+    m = int(round(len(mat) ** 0.5))
+    cap = len(query) + len(target) + 2
+    cg = np.zeros(cap, dtype=np.uint32)
+    sc = _i32()
+    n = _lib.orc_ksw_extd2_global(query.ctypes.data, len(query), target.ctypes.data, len(target), m,
+                                  mat.ctypes.data, q, e, q2, e2, C.byref(sc), cg.ctypes.data, cap)
+    assert n >= 0
+    return sc.value, cg[:n].copy()
+
+
+def global_score_general(query, target, mat, q=16, e=2, q2=41, e2=1):
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    mat = np.ascontiguousarray(mat, dtype=np.int8)
+    m = int(round(len(mat) ** 0.5))
+    return _lib.orc_global_score_general(query.ctypes.data, len(query), target.ctypes.data, len(target), m,
+                                         mat.ctypes.data, q, e, q2, e2)
+
+
+def cigar_score(query, target, mat, cigar, q=16, e=2, q2=41, e2=1):
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    mat = np.ascontiguousarray(mat, dtype=np.int8)
+    cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+    m = int(round(len(mat) ** 0.5))
+    return _lib.orc_cigar_score(query.ctypes.data, len(query), target.ctypes.data, len(target), m,
+                                mat.ctypes.data, q, e, q2, e2, cigar.ctypes.data, len(cigar))
+
+
+def lcs(a: bytes, b: bytes) -> int:
+    a = np.frombuffer(a, dtype=np.uint8)
+    b = np.frombuffer(b, dtype=np.uint8)
+    return _lib.orc_lcs(a.ctypes.data, len(a), b.ctypes.data, len(b))
+
+
+def fuzz_ratio(a: bytes, b: bytes) -> float:
+    a = np.frombuffer(a, dtype=np.uint8)
+    b = np.frombuffer(b, dtype=np.uint8)
+    return _lib.orc_fuzz_ratio(a.ctypes.data, len(a), b.ctypes.data, len(b))
