@@ -1,0 +1,191 @@
+// bam_reader.h -- minimal sequential BGZF/BAM record reader for the host CLI (zlib only).
+// Stands where htslib's hts_open / sam_hdr_read / sam_read1 / bam_aux_get stand in
+// /root/reference/ping_pong.cpp:58,247-249,196-201.  Only what `search` consumes is
+// decoded: flag, refID, l_seq, read name, 4-bit SEQ, integer aux tags (XF, HP).
+#pragma once
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct BamRecord {
+  int32_t tid = -1, pos = 0, l_seq = 0;
+  uint16_t flag = 0;
+  uint8_t mapq = 0;
+  std::string qname;
+  std::vector<uint8_t> seq4;   // packed 4-bit bases, (l_seq+1)/2 bytes
+  std::vector<uint8_t> aux;    // raw aux block
+};
+
+class BamReader {
+ public:
+  explicit BamReader(const std::string& path) : f_(fopen(path.c_str(), "rb")) {}
+  ~BamReader() { if (f_) fclose(f_); }
+  bool ok() const { return f_ != nullptr; }
+  const std::string& error() const { return err_; }
+  const std::vector<std::string>& ref_names() const { return refs_; }
+
+  bool read_header() {
+    char magic[4];
+    if (!read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { err_ = "not a BAM file"; return false; }
+    int32_t l_text, n_ref;
+    if (!read(&l_text, 4)) return fail("truncated header");
+    std::string text((size_t)l_text, '\0');
+    if (l_text && !read(&text[0], (size_t)l_text)) return fail("truncated header");
+    if (!read(&n_ref, 4)) return fail("truncated header");
+    for (int i = 0; i < n_ref; ++i) {
+      int32_t l_name, l_ref;
+      if (!read(&l_name, 4)) return fail("truncated header");
+      std::string name((size_t)l_name, '\0');
+      if (!read(&name[0], (size_t)l_name) || !read(&l_ref, 4)) return fail("truncated header");
+      if (!name.empty() && name.back() == '\0') name.pop_back();
+      refs_.push_back(name);
+    }
+    return true;
+  }
+
+  // 1 = record read, 0 = clean end of file, -1 = error
+  int next(BamRecord& r) {
+    int32_t block_size;
+    size_t got = read_some(&block_size, 4);
+    if (got == 0) return 0;
+    if (got != 4 || block_size < 32) { err_ = "truncated record"; return -1; }
+    buf_.resize((size_t)block_size);
+    if (!read(buf_.data(), (size_t)block_size)) { err_ = "truncated record"; return -1; }
+    const uint8_t* p = buf_.data();
+    int32_t refID, pos, l_seq;
+    uint8_t l_read_name, mapq;
+    uint16_t n_cigar, flag;
+    memcpy(&refID, p, 4);
+    memcpy(&pos, p + 4, 4);
+    l_read_name = p[8];
+    mapq = p[9];
+    memcpy(&n_cigar, p + 12, 2);
+    memcpy(&flag, p + 14, 2);
+    memcpy(&l_seq, p + 16, 4);
+    size_t o = 32;
+    if (o + l_read_name + 4u * n_cigar + (size_t)(l_seq + 1) / 2 + (size_t)l_seq > (size_t)block_size) {
+      err_ = "corrupt record";
+      return -1;
+    }
+    r.tid = refID; r.pos = pos; r.l_seq = l_seq; r.flag = flag; r.mapq = mapq;
+    r.qname.assign((const char*)p + o, l_read_name ? l_read_name - 1 : 0);
+    o += l_read_name + 4u * n_cigar;
+    r.seq4.assign(p + o, p + o + (size_t)(l_seq + 1) / 2);
+    o += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+    r.aux.assign(p + o, p + block_size);
+    return 1;
+  }
+
+  // integer aux tag (bam_aux_get + bam_aux2i); returns false if absent or not an integer
+  static bool aux_int(const BamRecord& r, const char tag[2], int64_t& out) {
+    const uint8_t* p = r.aux.data();
+    const uint8_t* e = p + r.aux.size();
+    while (p + 3 <= e) {
+      const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
+      p += 3;
+      size_t sz = 0;
+      switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': { const uint8_t* z = p; while (z < e && *z) ++z; sz = (size_t)(z - p) + 1; break; }
+        case 'B': {
+          if (p + 5 > e) return false;
+          const char st = (char)p[0];
+          int32_t cnt; memcpy(&cnt, p + 1, 4);
+          const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+          sz = 5 + es * (size_t)cnt;
+          break;
+        }
+        default: return false;
+      }
+      if (p + sz > e) return false;
+      if (t0 == tag[0] && t1 == tag[1]) {
+        switch (ty) {
+          case 'c': out = (int8_t)p[0]; return true;
+          case 'C': out = p[0]; return true;
+          case 's': { int16_t v; memcpy(&v, p, 2); out = v; return true; }
+          case 'S': { uint16_t v; memcpy(&v, p, 2); out = v; return true; }
+          case 'i': { int32_t v; memcpy(&v, p, 4); out = v; return true; }
+          case 'I': { uint32_t v; memcpy(&v, p, 4); out = v; return true; }
+          default: return false;
+        }
+      }
+      p += sz;
+    }
+    return false;
+  }
+
+ private:
+  bool fail(const char* m) { err_ = m; return false; }
+  bool read(void* dst, size_t n) { return read_some(dst, n) == n; }
+
+  // reads up to n uncompressed bytes, refilling from BGZF blocks
+  size_t read_some(void* dst, size_t n) {
+    size_t done = 0;
+    while (done < n) {
+      if (upos_ == ublock_.size()) {
+        if (!next_block()) break;
+        if (ublock_.empty()) continue;   // empty block (EOF marker) -- keep going
+      }
+      const size_t take = std::min(n - done, ublock_.size() - upos_);
+      memcpy((uint8_t*)dst + done, ublock_.data() + upos_, take);
+      upos_ += take;
+      done += take;
+    }
+    return done;
+  }
+
+  bool next_block() {
+    uint8_t h[18];
+    const size_t g = fread(h, 1, 18, f_);
+    if (g == 0) return false;
+    if (g != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err_ = "bad BGZF block"; return false; }
+    uint16_t xlen;
+    memcpy(&xlen, h + 10, 2);
+    // find the BC subfield (normally the only one, right at h[12..17])
+    std::vector<uint8_t> extra(xlen);
+    memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
+    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6u, f_) != xlen - 6u) { err_ = "bad BGZF block"; return false; }
+    int bsize = -1;
+    for (size_t o = 0; o + 4 <= extra.size();) {
+      uint16_t slen;
+      memcpy(&slen, &extra[o + 2], 2);
+      if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) {
+        uint16_t v; memcpy(&v, &extra[o + 4], 2); bsize = v; break;
+      }
+      o += 4u + slen;
+    }
+    if (bsize < 0) { err_ = "BGZF block without BC field"; return false; }
+    const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
+    cbuf_.resize(cdata + 8);
+    if (fread(cbuf_.data(), 1, cdata + 8, f_) != cdata + 8) { err_ = "truncated BGZF block"; return false; }
+    uint32_t isize;
+    memcpy(&isize, cbuf_.data() + cdata + 4, 4);
+    ublock_.resize(isize);
+    upos_ = 0;
+    if (isize == 0) return true;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { err_ = "zlib init failed"; return false; }
+    zs.next_in = cbuf_.data();
+    zs.avail_in = (uInt)cdata;
+    zs.next_out = ublock_.data();
+    zs.avail_out = isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) { err_ = "BGZF inflate failed"; return false; }
+    return true;
+  }
+
+  FILE* f_;
+  std::string err_;
+  std::vector<std::string> refs_;
+  std::vector<uint8_t> cbuf_, ublock_, buf_;
+  size_t upos_ = 0;
+};

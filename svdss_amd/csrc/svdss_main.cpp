@@ -1,0 +1,311 @@
+// svdss_main.cpp -- `SVDSS` host CLI on top of libsvdss_hip.so.
+//
+// Keeps the process boundary B1 of SURVEY.md 8(b) for the path built so far:
+//   SVDSS index  -d ref.fa -o ref.fa.fmd [-t T]        (/root/reference/main.cpp:34-37, run_svdss:142)
+//   SVDSS search --index F --bam B | --fastx Q [--threads T] [--bsize N] [--noputative]
+//                [--noassemble] [--omax N] [--verbose]  (config.cpp:30-55, main.cpp:62-68)
+//   SVDSS --version                                     (main.cpp:45-47)
+// SFS text goes to stdout exactly as PingPong::output_batch prints it
+// (ping_pong.cpp:213-236), logs to stderr, fatal conditions exit(1).
+// `smooth` and `call` are not part of this build yet.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/svdss_hip.h"
+#include "bam_reader.h"
+#include "fastx_reader.h"
+
+static const char* VERSION = "v2.1.1";  // main.cpp:19
+
+static const char* MAIN_USAGE =
+    "Usage: SVDSS <index|smooth|search|call> --help\n"
+    "  index   build the FM-index of a reference (FASTA, gz ok):  SVDSS index -d ref.fa -o ref.fa.fmd [-t T]\n"
+    "  search  extract sample-specific strings: SVDSS search --index ref.fa.fmd --bam reads.bam > specifics.txt\n"
+    "  smooth, call: not available in this build\n";
+
+static const char* SEARCH_USAGE =
+    "Usage: SVDSS search --index <FMD> --bam <BAM> | --fastx <FASTA/FASTQ>\n"
+    "      --threads <int>   kept for output-order compatibility (default: 4)\n"
+    "      --bsize <int>     batch size (default: 10000)\n"
+    "      --noputative      search all reads, not only XF == 0\n"
+    "      --noassemble      do not merge overlapping specific strings\n";
+
+static void logmsg(const char* lvl, const std::string& m) {
+  time_t t = time(nullptr);
+  char ts[32];
+  strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", localtime(&t));
+  fprintf(stderr, "[%s] [stderr] [%s] %s\n", ts, lvl, m.c_str());
+}
+
+[[noreturn]] static void die(const std::string& m) {
+  logmsg("critical", m);
+  exit(EXIT_FAILURE);
+}
+
+static void check(int rc, const char* what) {
+  if (rc != SVDSS_OK) die(std::string(what) + ": " + svdss_strerror(rc) + " " + svdss_last_hip_error());
+}
+
+// seq_nt16_str of htslib, then seq_nt6_table (ping_pong.cpp:90-94)
+static const char NT16[] = "=ACMGRSVTWYHKDBN";
+
+struct Options {
+  std::string index, bam, fastx;
+  int threads = 4, bsize = 10000, omax = 100000;  // config.hpp:68-69,88
+  bool putative = true, assemble = true, verbose = false, version = false, help = false;
+};
+
+static bool take(int argc, char** argv, int& i, const char* name, std::string& val) {
+  const size_t n = strlen(name);
+  if (strncmp(argv[i], name, n) != 0) return false;
+  if (argv[i][n] == '=') { val = argv[i] + n + 1; return true; }
+  if (argv[i][n] != '\0') return false;
+  if (i + 1 >= argc) die(std::string("option ") + name + " needs a value");
+  val = argv[++i];
+  return true;
+}
+
+static Options parse(int argc, char** argv) {
+  Options o;
+  std::string v;
+  for (int i = 2; i < argc; ++i) {
+    if (take(argc, argv, i, "--index", v)) o.index = v;
+    else if (take(argc, argv, i, "--bam", v)) o.bam = v;
+    else if (take(argc, argv, i, "--fastx", v)) o.fastx = v;
+    else if (take(argc, argv, i, "--threads", v)) o.threads = atoi(v.c_str());
+    else if (take(argc, argv, i, "--bsize", v)) o.bsize = atoi(v.c_str());
+    else if (take(argc, argv, i, "--omax", v)) o.omax = atoi(v.c_str());
+    else if (!strcmp(argv[i], "--noputative")) o.putative = false;
+    else if (!strcmp(argv[i], "--noassemble")) o.assemble = false;
+    else if (!strcmp(argv[i], "--verbose")) o.verbose = true;
+    else if (!strcmp(argv[i], "--version")) o.version = true;
+    else if (!strcmp(argv[i], "--help") || !strcmp(argv[i], "-h")) o.help = true;
+    else die(std::string("Option '") + argv[i] + "' does not exist");  // cxxopts throws here
+  }
+  if (o.threads < 1) o.threads = 1;
+  o.bsize = (o.bsize / o.threads) * o.threads;  // config.cpp:106
+  return o;
+}
+
+// ---------------------------------------------------------------- index
+
+static int main_index(int argc, char** argv) {
+  // ropebwt3 `build` flags as run_svdss:142 passes them: -t T -d <fasta> -o <out>
+  std::string fasta, out;
+  int threads = 4;
+  for (int i = 2; i < argc; ++i) {
+    if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]);
+    else if (!strncmp(argv[i], "-t", 2) && argv[i][2]) threads = atoi(argv[i] + 2);
+    else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
+    else if (!strcmp(argv[i], "-d") || !strcmp(argv[i], "-b")) continue;  // output-format switches of ropebwt3
+    else if (argv[i][0] == '-' && argv[i][1] == 'd' && argv[i][2]) continue;
+    else if (argv[i][0] != '-') fasta = argv[i];
+  }
+  if (fasta.empty() || out.empty()) {
+    fprintf(stderr, "Usage: SVDSS index [-t threads] -d <reference.fa[.gz]> -o <reference.fmd>\n");
+    return EXIT_FAILURE;
+  }
+  FastxReader fx(fasta);
+  if (!fx.ok()) die("cannot open " + fasta);
+  std::vector<uint8_t> cat;
+  std::vector<int64_t> lens;
+  std::string name, seq;
+  while (fx.next(name, seq)) {
+    const size_t o = cat.size();
+    cat.resize(o + seq.size());
+    check(svdss_nt6_encode(seq.data(), (int64_t)seq.size(), cat.data() + o), "svdss_nt6_encode");
+    lens.push_back((int64_t)seq.size());
+  }
+  if (lens.empty()) die("no sequence in " + fasta);
+  logmsg("info", "Indexing " + std::to_string(lens.size()) + " record(s), " + std::to_string(cat.size()) + " bases..");
+  svdss_index_t* ix = nullptr;
+  check(svdss_index_build(cat.data(), lens.data(), (int32_t)lens.size(), threads, &ix), "svdss_index_build");
+  check(svdss_index_save(ix, out.c_str()), "svdss_index_save");
+  svdss_index_free(ix);
+  return 0;
+}
+
+// --------------------------------------------------------------- search
+
+struct Read {
+  std::string name;
+  int hp = 0;
+  int64_t off = 0, len = 0;   // into the batch buffer
+  int64_t first = 0, count = 0;  // into the result arrays (-1: not searched)
+};
+
+int main_search(const Options& o) {
+  logmsg("info", "Restoring index..");
+  svdss_index_t* ix = nullptr;
+  check(svdss_index_load(o.index.c_str(), &ix), "svdss_index_load");
+  check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
+  const bool bam_mode = !o.bam.empty();
+  BamReader* bam = nullptr;
+  FastxReader* fx = nullptr;
+  if (bam_mode) {
+    bam = new BamReader(o.bam);
+    if (!bam->ok() || !bam->read_header()) die("cannot read " + o.bam + ": " + bam->error());
+  } else {
+    logmsg("warning", "FASTX mode is not optimized (higher running times and larger SFSs set).");
+    fx = new FastxReader(o.fastx);
+    if (!fx->ok()) die("cannot open " + o.fastx);
+  }
+  if (o.bsize <= 0) die("batch size smaller than the number of threads");
+  logmsg("info", "Extracting SFS strings on the GPU (output order as with " + std::to_string(o.threads) + " threads)..");
+  // One GPU launch covers many reference-sized batches; the text is still emitted batch by
+  // batch, thread slice by thread slice, read names in std::map order (ping_pong.cpp:215-217).
+  const int64_t super = std::max<int64_t>(o.bsize, 262144 / o.bsize * (int64_t)o.bsize);
+  svdss_sfs_batch_t* res = nullptr;
+  std::vector<uint8_t> buf;
+  std::vector<int64_t> offsets;
+  std::vector<Read> reads;
+  std::string out;
+  uint64_t total_sfs = 0, n_seen = 0;
+  bool eof = false;
+  uint8_t nt16_to_nt6[16];
+  check(svdss_nt6_encode(NT16, 16, nt16_to_nt6), "svdss_nt6_encode");
+  while (!eof) {
+    buf.clear();
+    offsets.assign(1, 0);
+    reads.clear();
+    while ((int64_t)reads.size() < super) {
+      Read r;
+      bool search = true;
+      if (bam_mode) {
+        BamRecord rec;
+        const int rc = bam->next(rec);
+        if (rc == 0) { eof = true; break; }
+        if (rc < 0) die("error reading " + o.bam + ": " + bam->error());
+        ++n_seen;
+        if (rec.flag & (4 | 2048 | 256)) continue;                     // ping_pong.cpp:66-69
+        if (rec.l_seq < 100) {                                         // :70-75
+          logmsg("warning", "Alignment filtered due to l_qseq. Why are we here? Please check");
+          continue;
+        }
+        if (rec.tid < 0) die("core.tid < 0. Why are we here? Please check");  // :76-79
+        int64_t xf = 0, hp = 0;
+        BamReader::aux_int(rec, "XF", xf);                             // :196-201, missing => 0
+        BamReader::aux_int(rec, "HP", hp);
+        r.name = rec.qname;
+        r.hp = (int)hp;
+        r.len = rec.l_seq;
+        r.off = (int64_t)buf.size();
+        buf.resize(buf.size() + (size_t)rec.l_seq);
+        for (int k = 0; k < rec.l_seq; ++k) {
+          const int code = (rec.seq4[(size_t)k >> 1] >> ((~k & 1) << 2)) & 0xf;
+          buf[(size_t)r.off + (size_t)k] = nt16_to_nt6[code];
+        }
+        search = !(o.putative && xf != 0);                             // :202-203
+      } else {
+        std::string seq;
+        if (!fx->next(r.name, seq)) { eof = true; break; }
+        ++n_seen;
+        r.len = (int64_t)seq.size();
+        r.off = (int64_t)buf.size();
+        buf.resize(buf.size() + seq.size());
+        svdss_nt6_encode(seq.data(), (int64_t)seq.size(), buf.data() + r.off);
+      }
+      if (!search) { buf.resize((size_t)r.off); r.count = -1; r.len = 0; }
+      reads.push_back(r);
+    }
+    if (reads.empty()) break;
+    // searched reads only go to the GPU
+    std::vector<uint8_t> gbuf;
+    std::vector<int64_t> goff(1, 0);
+    std::vector<size_t> gidx;
+    gbuf.reserve(buf.size());
+    for (size_t i = 0; i < reads.size(); ++i) {
+      if (reads[i].count < 0) continue;
+      gbuf.insert(gbuf.end(), buf.begin() + reads[i].off, buf.begin() + reads[i].off + reads[i].len);
+      goff.push_back((int64_t)gbuf.size());
+      gidx.push_back(i);
+    }
+    std::vector<int64_t> counts(gidx.size());
+    std::vector<int32_t> qs, ln;
+    if (!gidx.empty()) {
+      check(svdss_sfs_search_batch(ix, gbuf.data(), goff.data(), (int64_t)gidx.size(),
+                                   o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch");
+      qs.resize((size_t)svdss_sfs_batch_total(res));
+      ln.resize(qs.size());
+      check(svdss_sfs_batch_fetch(res, counts.data(), qs.data(), ln.data(), nullptr), "svdss_sfs_batch_fetch");
+      int64_t acc = 0;
+      for (size_t k = 0; k < gidx.size(); ++k) {
+        reads[gidx[k]].first = acc;
+        reads[gidx[k]].count = counts[k];
+        acc += counts[k];
+      }
+    }
+    // output_batch order: reference batches of bsize reads -> thread t takes reads n with
+    // n % T == t (ping_pong.cpp:59,101-104) -> std::map<qname, vector<SFS>> order (:217)
+    for (size_t b0 = 0; b0 < reads.size(); b0 += (size_t)o.bsize) {
+      const size_t b1 = std::min(reads.size(), b0 + (size_t)o.bsize);
+      for (int t = 0; t < o.threads; ++t) {
+        std::map<std::string, std::vector<size_t>> by_name;
+        for (size_t n = b0 + (size_t)t; n < b1; n += (size_t)o.threads)
+          if (reads[n].count >= 0) by_name[reads[n].name].push_back(n);
+        for (const auto& kv : by_name) {
+          bool first = true;
+          for (size_t n : kv.second) {
+            const Read& r = reads[n];
+            for (int64_t k = 0; k < r.count; ++k) {
+              out += first ? r.name : std::string("*");
+              out += '\t';
+              out += std::to_string(qs[(size_t)(r.first + k)]);
+              out += '\t';
+              out += std::to_string(ln[(size_t)(r.first + k)]);
+              out += '\t';
+              out += std::to_string(r.hp);
+              out += "\t\n";
+              first = false;
+              ++total_sfs;
+            }
+          }
+        }
+      }
+      if (out.size() > (1u << 20)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
+    }
+  }
+  fwrite(out.data(), 1, out.size(), stdout);
+  fflush(stdout);
+  if (o.verbose) logmsg("debug", std::to_string(n_seen) + " records read, " + std::to_string(total_sfs) + " SFS written");
+  svdss_sfs_batch_free(res);
+  svdss_index_free(ix);
+  delete bam;
+  delete fx;
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const time_t t0 = time(nullptr);
+  if (argc == 1) {
+    fputs(MAIN_USAGE, stderr);
+    return EXIT_FAILURE;
+  }
+  if (!strcmp(argv[1], "index")) {
+    logmsg("info", "FM-index construction (stands for 'ropebwt3 build')");
+    const int rc = main_index(argc, argv);
+    if (rc) return rc;
+  } else {
+    for (int i = 1; i < argc; ++i)
+      if (!strcmp(argv[i], "--version")) { printf("SVDSS, %s\n", VERSION); return EXIT_SUCCESS; }
+    const Options o = parse(argc, argv);
+    if (o.help) { fputs(!strcmp(argv[1], "search") ? SEARCH_USAGE : MAIN_USAGE, stderr); return EXIT_SUCCESS; }
+    if (!strcmp(argv[1], "search")) {
+      if (o.index.empty() || (o.fastx.empty() && o.bam.empty())) { fputs(SEARCH_USAGE, stderr); return EXIT_FAILURE; }
+      main_search(o);
+    } else if (!strcmp(argv[1], "call") || !strcmp(argv[1], "smooth")) {
+      die(std::string("'") + argv[1] + "' is not part of this build (SFS search path only)");
+    } else {
+      fputs(MAIN_USAGE, stderr);
+      return EXIT_FAILURE;
+    }
+  }
+  logmsg("info", "All done! Runtime: " + std::to_string((long)(time(nullptr) - t0)) + " seconds");
+  return 0;
+}

@@ -1,0 +1,134 @@
+"""`SVDSS` host CLI: process boundary of SURVEY 8(b) B1 (flags, exit codes, stdout text)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import svdss_amd
+from svdss_amd import synth
+from tests import bam_writer, oracle_lib as O
+from tests.common import ROOT, small_workload
+
+BIN = os.path.join(ROOT, "svdss_amd", "SVDSS")
+
+
+def run(*args, **kw):
+    return subprocess.run([BIN, *args], capture_output=True, text=True, timeout=600, **kw)
+
+
+def test_version_usage_and_errors():
+    r = run("--version")
+    assert r.returncode == 0 and r.stdout == "SVDSS, v2.1.1\n"          # main.cpp:45-47
+    r = run()
+    assert r.returncode == 1 and "Usage" in r.stderr and r.stdout == ""  # main.cpp:27-31
+    r = run("frobnicate")
+    assert r.returncode == 1                                             # main.cpp:78-80
+    r = run("search", "--index", "x.fmd")
+    assert r.returncode == 1 and "Usage: SVDSS search" in r.stderr       # main.cpp:63-66
+    r = run("search", "--index", "/nonexistent.fmd", "--fastx", "/nonexistent.fq")
+    assert r.returncode == 1 and "critical" in r.stderr                  # message + exit(1)
+    r = run("call", "--reference", "a", "--bam", "b", "--sfs", "c")
+    assert r.returncode == 1
+
+
+def test_index_subcommand_roundtrip(tmp_path):
+    ref = synth.make_reference([30000, 8000], seed=5, n_runs=(25,))
+    fa = tmp_path / "ref.fa.gz"
+    with gzip.open(fa, "wt") as fh:
+        for i, c in enumerate(ref):
+            s = synth.to_ascii(c)
+            fh.write(f">chr{i} some description\n")
+            for k in range(0, len(s), 70):
+                fh.write(s[k:k + 70].lower() if i else s[k:k + 70])
+                fh.write("\n")
+    out = tmp_path / "ref.fa.fmd"
+    r = run("index", "-t", "2", "-d", str(fa), "-o", str(out))             # run_svdss:142
+    assert r.returncode == 0, r.stderr
+    ix = svdss_amd.FMDIndex.load(str(out))
+    jx = svdss_amd.FMDIndex.build(ref, threads=2)
+    assert ix.size == jx.size and (ix.acc == jx.acc).all()
+    w = ref[1][100:160]
+    assert ix.count(w) == jx.count(w) >= 1
+
+
+def _expected_text(names, reads, hps, searched, fm, assemble, T, bsize):
+    """ping_pong.cpp:213-236 order: batches of bsize -> thread t = n % T -> std::map name order."""
+    lines = []
+    n = len(names)
+    for b0 in range(0, n, bsize):
+        for t in range(T):
+            group = {}
+            for k in range(b0 + t, min(n, b0 + bsize), T):
+                if searched[k]:
+                    group.setdefault(names[k], []).append(k)
+            for name in sorted(group):
+                first = True
+                for k in group[name]:
+                    raw, _ = fm.ping_pong_search(reads[k])
+                    sfs = O.assemble(raw) if assemble else raw
+                    for q, l in sfs:
+                        lines.append(f"{name if first else '*'}\t{q}\t{l}\t{hps[k]}\t\n")
+                        first = False
+    return "".join(lines)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("assemble", [True, False])
+def test_search_fastx_and_bam_text(tmp_path, assemble):
+    ref, hap, svs, flat, offs = small_workload(seed=81, n_reads=60, read_len=900, ref_lens=(90000,))
+    fm = O.OracleFMD.build(ref)
+    ix = svdss_amd.FMDIndex.build(ref)
+    fmd = tmp_path / "ref.fmd"
+    ix.save(str(fmd))
+    reads = [flat[offs[i]:offs[i + 1]] for i in range(60)]
+    reads[7] = reads[7].copy(); reads[7][40] = 5
+    names = [f"m64/{(i * 37) % 60}/ccs" for i in range(60)]
+    # ---- FASTQ (multi-line sequence, lower case, '@' in quality)
+    fq = tmp_path / "reads.fq"
+    with open(fq, "w") as fh:
+        for nm, r in zip(names, reads):
+            s = synth.to_ascii(r)
+            fh.write(f"@{nm} extra\n{s[:300]}\n{s[300:].lower()}\n+\n{'@' * 300}\n{'I' * (len(s) - 300)}\n")
+    extra = [] if assemble else ["--noassemble"]
+    r = run("search", "--index", str(fmd), "--fastx", str(fq), "--threads", "3", "--bsize", "20", *extra)
+    assert r.returncode == 0, r.stderr
+    exp = _expected_text(names, reads, [0] * 60, [True] * 60, fm, assemble, 3, 18)   # bsize rounded to 18
+    assert r.stdout == exp and len(exp) > 0
+    # ---- BAM: XF/HP tags, filtered flags, short read
+    recs, keep_names, keep_reads, hps, searched = [], [], [], [], []
+    for i, (nm, rd) in enumerate(zip(names, reads)):
+        flag = 0
+        if i % 11 == 3:
+            flag = 256      # secondary: dropped (ping_pong.cpp:66-69)
+        if i % 13 == 5:
+            flag = 2048     # supplementary: dropped
+        if i == 20:
+            flag = 4        # unmapped: dropped
+        xf = 1 if i % 5 == 0 else 0
+        hp = i % 3
+        tags = [("NM", "i", 3)]
+        if i % 2:
+            tags.append(("XF", "C", xf))
+        elif xf:
+            tags.append(("XF", "i", xf))
+        if hp:
+            tags.append(("HP", "s", hp))
+        tags.append(("RG", "Z", "grp"))
+        recs.append(bam_writer.record(nm, flag, 0, 100 + i, 60, [("M", len(rd))], synth.to_ascii(rd), tags))
+        if flag == 0:
+            keep_names.append(nm); keep_reads.append(rd); hps.append(hp); searched.append(xf == 0)
+    recs.insert(4, bam_writer.record("short", 0, 0, 50, 60, [("M", 50)], "ACGT" * 12 + "AC"))  # l_qseq < 100: dropped
+    bam = tmp_path / "reads.bam"
+    bam.write_bytes(bam_writer.bam([("chr1", 90000)], recs))
+    r = run("search", "--index", str(fmd), "--bam", str(bam), "--threads", "4", "--bsize", "16", *extra)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == _expected_text(keep_names, keep_reads, hps, searched, fm, assemble, 4, 16)
+    r2 = run("search", "--index", str(fmd), "--bam", str(bam), "--noputative", "--threads", "4", "--bsize", "16", *extra)
+    assert r2.returncode == 0
+    assert r2.stdout == _expected_text(keep_names, keep_reads, hps, [True] * len(keep_names), fm, assemble, 4, 16)
+    assert len(r2.stdout) > len(r.stdout)
+    # the text parses back (sfs.cpp:5-30)
+    parsed = svdss_amd.parse_sfsfile(r2.stdout)
+    assert set(parsed) <= set(keep_names)
