@@ -218,8 +218,9 @@ def main():
                 "kmer_table_k": ix.kmer_k,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "sfs_search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bound": "hbm", "kernel": "sfs_search2_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(ref_total, n_reads, L, ix.kmer_k),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
             },
         }
@@ -229,6 +230,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(ref_total, n_reads, L, k):
+    """HBM-side bytes per launch of the search kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE + WRITE_SIZE, profiles/traffic.json), for exactly this workload; None if that
+    configuration has not been profiled.  Counters cannot be read from inside the timed run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            table = json.load(fh)
+    except OSError:
+        return None
+    return table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}")
 
 
 def cpu_baseline(ix, d_reads, L, n_reads, target_s):

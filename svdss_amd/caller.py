@@ -85,3 +85,193 @@ def fuzz_ratio(a_list: Sequence, b_list: Sequence, device: int = 0) -> Tuple[np.
     check(lib.svdss_indel_ratio_batch(a.ctypes.data, ao.ctypes.data, b.ctypes.data, bo.ctypes.data, n, device,
                                       ratio.ctypes.data, lcs.ctypes.data), "svdss_indel_ratio_batch")
     return ratio, lcs
+
+
+# ---------------------------------------------------------------------------
+# Host logic of Caller::pcall after run_poa, clean_dups, filter_sv_chains and the VCF writer
+# (/root/reference/caller.cpp:326-475, sv.cpp, caller.cpp:477-550).  The DP inside
+# (ksw_extd2_sse, fuzz::ratio) runs on the GPU through the functions above; everything else
+# is the reference's own integer/string bookkeeping.
+
+class SV:
+    """sv.hpp:14-59 / sv.cpp:7-27."""
+
+    def __init__(self, type_, chrom, s, refall, altall, w, cov, ngaps, score, imprecise=False, l=0, cigar="."):
+        self.type, self.chrom, self.s = type_, chrom, int(s)
+        self.refall, self.altall = refall, altall
+        self.e = self.s + len(refall) - 1                       # sv.cpp:15
+        self.w, self.l, self.cov = int(w), int(l), int(cov)
+        self.cov0 = self.cov1 = self.cov2 = 0
+        self.ngaps, self.score, self.imprecise, self.cigar = int(ngaps), int(score), bool(imprecise), cigar
+        self.idx = f"{type_}_{chrom}:{self.s}-{self.e}_{abs(self.l)}"   # sv.cpp:23-24
+        self.gt, self.gtq = "./.", 0
+        self.rvec, self.reads = "", ""
+
+    def add_reads(self, names):                                  # sv.cpp:29-33
+        self.reads = ",".join(names)
+
+    def set_cov(self, cov, cov0, cov1, cov2):                    # sv.cpp:35-40
+        self.cov, self.cov0, self.cov1, self.cov2 = cov, cov0, cov1, cov2
+
+    def set_rvec(self, reads):                                   # sv.cpp:42-46
+        self.rvec = "-".join(f"{a}:{b}" for a, b in reads)
+
+    def set_gt(self, gt, gtq):                                   # sv.cpp:48-51
+        self.gt, self.gtq = gt, gtq
+
+    def key(self):                                               # sv.hpp:47-55 operator<
+        return (self.chrom, self.s)
+
+    def vcf_line(self) -> str:                                   # sv.cpp:53-80
+        svlen = -self.l if self.type == "DEL" else self.l
+        return (f"{self.chrom}\t{self.s}\t{self.idx}\t{self.refall}\t{self.altall}\t.\tPASS\t"
+                f"VARTYPE=SV;SVTYPE={self.type};SVLEN={svlen};END={self.e};WEIGHT={self.w};COV={self.cov};"
+                f"COV0={self.cov0};COV1={self.cov1};COV2={self.cov2};AS={self.score};NV={self.ngaps};"
+                f"CIGAR={self.cigar};RVEC={self.rvec};READS={self.reads}"
+                + (";IMPRECISE\t" if self.imprecise else "\t") + f"GT:GQ\t{self.gt}:{self.gtq}")
+
+
+def extract_svs(chrom, chrom_seq: str, cl_s: int, consensus: str, cigar_ops, score: int, min_sv_length: int,
+                cl_size: int, cov, names, rvec_reads):
+    """caller.cpp:357-401: walk the consensus->reference CIGAR, one SV per I/D >= min_sv_length.
+    cov = (cov, cov0, cov1, cov2) of the sub-cluster; rvec_reads = parent cluster's (has_sfs, hp) list."""
+    cig = cigar_string(cigar_ops)
+    rpos, cpos, nv = int(cl_s), 0, 0
+    out = []
+    for c in cigar_ops:
+        l, op = int(c) >> 4, "MID"[int(c) & 0xf]
+        if op == "M":
+            rpos += l
+            cpos += l
+        elif op == "I":
+            if l >= min_sv_length:
+                anchor = chrom_seq[rpos - 1]
+                sv = SV("INS", chrom, rpos, anchor, anchor + consensus[cpos:cpos + l], cl_size, cov[0], nv, score,
+                        False, l, cig)
+                sv.add_reads(names)
+                out.append(sv)
+                nv += 1
+            cpos += l
+        else:
+            if l >= min_sv_length:
+                sv = SV("DEL", chrom, rpos, chrom_seq[rpos - 1:rpos + l], chrom_seq[rpos - 1], cl_size, cov[0], nv,
+                        score, False, l, cig)
+                sv.add_reads(names)
+                out.append(sv)
+                nv += 1
+            rpos += l
+    for sv in out:
+        sv.ngaps = nv
+        sv.set_gt("0/1", 100)
+        sv.set_cov(*cov)
+        sv.set_rvec(rvec_reads)
+    return out
+
+
+def pcall_tail(subclusters, chromosomes: dict, min_sv_length: int = 25, threads: int = 4, device: int = 0):
+    """Caller::pcall from the consensus on (caller.cpp:326-405) for a list of sub-clusters, each a
+    dict(chrom, s, e, consensus, size, names, cov=(cov,cov0,cov1,cov2), rvec, cluster_index).
+    All realignments go to the GPU in one batch.  Returns SVs in the order Caller::run leaves them
+    before its sort (caller.cpp:18-22: per-thread vectors, cluster i on thread i % T, each inserted
+    at the FRONT)."""
+    refs = [chromosomes[sc["chrom"]][sc["s"]:sc["e"] + 1] for sc in subclusters]   # caller.cpp:329
+    cons = [sc["consensus"] for sc in subclusters]
+    scores, cigars, stats = ksw_extd2_global(cons, refs, device=device)
+    per_thread = [[] for _ in range(threads)]
+    for sc, score, cg in zip(subclusters, scores.tolist(), cigars):
+        svs = extract_svs(sc["chrom"], chromosomes[sc["chrom"]], sc["s"], sc["consensus"], cg, score,
+                          min_sv_length, sc["size"], sc["cov"], sc["names"], sc["rvec"])
+        per_thread[sc.get("cluster_index", 0) % threads].extend(svs)
+    out = []
+    for t in range(threads):
+        out = per_thread[t] + out
+    return out, stats
+
+
+def clean_dups(svs):
+    """caller.cpp:409-426: drop an SV equal (chrom, s, refall, altall) to the one right before it."""
+    out, last = [], ("", -1, "", "")
+    for sv in svs:
+        cur = (sv.chrom, sv.s, sv.refall, sv.altall)
+        if cur != last:
+            out.append(sv)
+        last = cur
+    return out
+
+
+def filter_sv_chains(svs, min_ratio: float = 0.97, device: int = 0):
+    """caller.cpp:429-475.  `prev` is always the element right before `sv`, so every
+    rapidfuzz::fuzz::ratio call is on an adjacent pair: all candidate pairs are scored in ONE
+    GPU batch, then the sequential keep/merge logic replays on those ratios."""
+    if len(svs) < 2:
+        return list(svs)
+    min_ratio = float(np.float32(min_ratio))     # config.hpp:91: float, compared with a double
+    cand = []
+    for i in range(1, len(svs)):
+        prev, sv = svs[i - 1], svs[i]
+        if sv.chrom == prev.chrom and sv.s - prev.e < 2 * sv.l and prev.type == sv.type:
+            w_r = min(float(sv.w), float(prev.w)) / max(float(sv.w), float(prev.w))
+            l_r = min(float(sv.l), float(prev.l)) / max(float(sv.l), float(prev.l))
+            if sv.s - prev.s < 100 and w_r >= 0.9 and l_r >= min_ratio:
+                cand.append(i)
+    sims = {}
+    if cand:
+        a = [(svs[i].refall if svs[i].type == "DEL" else svs[i].altall) for i in cand]
+        b = [(svs[i - 1].refall if svs[i].type == "DEL" else svs[i - 1].altall) for i in cand]
+        ratio, _ = fuzz_ratio(a, b, device=device)
+        sims = dict(zip(cand, ratio.tolist()))
+    out, prev, reset = [], svs[0], False
+    for i in range(1, len(svs)):
+        if reset:
+            reset = False
+            prev = svs[i]
+            continue
+        sv = svs[i]
+        if i in sims and sims[i] > 70:
+            out.append(sv if sv.w > prev.w else prev)
+            reset = True
+            continue
+        out.append(prev)
+        prev = sv
+    out.append(prev)          # caller.cpp:472 (also when a reset is pending: end-of-list artefact)
+    return out
+
+
+def vcf_header(contigs) -> str:
+    """caller.cpp:477-550; contigs = [(name, length), ...] in FASTA order."""
+    lines = ["##fileformat=VCFv4.2",
+             "##reference=ftp://ftp.1000genomes.ebi.ac.uk/vol1/ftp/data_collections/HGSVC2/technical/reference/"
+             "20200513_hg38_NoALT/hg38.no_alt.fa.gz"]
+    lines += [f"##contig=<ID={n},length={l}>" for n, l in contigs]
+    lines += ['##FILTER=<ID=PASS,Description="All filters passed">']
+    info = [("VARTYPE", "A", "String", "Variant class"), ("SVTYPE", "1", "String", "Variant type"),
+            ("SVLEN", "1", "Integer", "Difference in length between REF and ALT alleles"),
+            ("END", "1", "Integer", "End position of the variant described in this record"),
+            ("WEIGHT", "1", "Integer", "Number of alignments supporting this record"),
+            ("COV", "1", "Integer", "Total number of alignments covering this locus"),
+            ("COV0", "1", "Integer", "Total number of alignments covering this locus (no HP)"),
+            ("COV1", "1", "Integer", "Total number of alignments covering this locus (HP=1)"),
+            ("COV2", "1", "Integer", "Total number of alignments covering this locus (HP=2)"),
+            ("AS", "1", "Integer", "Alignment score"), ("NV", "1", "Integer", "Number of variations on same consensus"),
+            ("IMPRECISE", "0", "Flag", "Imprecise structural variation"),
+            ("CIGAR", "A", "String", "CIGAR of consensus"),
+            ("READS", ".", "String", "Reads identifiers supporting the call"),
+            ("RVEC", ".", "String", "Reads vector used by genotyper")]
+    lines += [f'##INFO=<ID={i},Number={n},Type={t},Description="{d}">' for i, n, t, d in info]
+    lines += ['##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+              '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype quality">',
+              "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tDEFAULT"]
+    return "\n".join(lines) + "\n"
+
+
+def call_tail(subclusters, chromosomes: dict, contigs, min_sv_length: int = 25, threads: int = 4,
+              min_ratio: float = 0.97, device: int = 0) -> str:
+    """Caller::run from pcall's realignment to the VCF text (caller.cpp:17-29): realign, extract,
+    sort, clean_dups, filter_sv_chains, sort, write.  std::sort's order among SVs with equal
+    (chrom, POS) is unspecified in the reference (SURVEY App. A#8); a stable sort is used here."""
+    svs, _ = pcall_tail(subclusters, chromosomes, min_sv_length, threads, device)
+    svs.sort(key=SV.key)
+    svs = clean_dups(svs)
+    svs = filter_sv_chains(svs, min_ratio, device)
+    svs.sort(key=SV.key)
+    return vcf_header(contigs) + "".join(sv.vcf_line() + "\n" for sv in svs)

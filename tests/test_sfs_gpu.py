@@ -225,3 +225,31 @@ def test_v1_kernel_still_agrees(monkeypatch):
     got = _search(ix, flat, offs, False)
     c, q, l, e = fm.search_batch(flat, offs, False)
     assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
+
+
+def test_device_results_alias_and_single_rank_gather():
+    """bench.py --gpus N hands the library's HBM result buffers to torch.distributed without a
+    host hop; check the aliasing tensors and run the gather with a 1-rank NCCL(RCCL) group."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from svdss_amd import multi
+    ref, hap, svs, flat, offs = small_workload(seed=52, n_reads=120, read_len=1500)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    pp = svdss_amd.PingPong(ix, assemble=True)
+    got = pp.ping_pong_search(flat, offs)
+    counts, qs, ln = pp.device_results()
+    assert counts.is_cuda and counts.dtype == torch.int64 and qs.dtype == torch.int32
+    assert (counts.cpu().numpy() == got.counts).all()
+    assert (qs.cpu().numpy() == got.qs).all() and (ln.cpu().numpy() == got.len).all()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29617")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c2, q2, l2 = multi.gather_sfs(counts, qs, ln)
+        torch.cuda.synchronize()
+        assert (c2.cpu().numpy() == got.counts).all()
+        assert (q2.cpu().numpy() == got.qs).all() and (l2.cpu().numpy() == got.len).all()
+    finally:
+        dist.destroy_process_group()
