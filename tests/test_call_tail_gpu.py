@@ -77,24 +77,24 @@ def test_clean_dups_and_chain_filter():
     def ins(s, alt, w, l=None):
         return SV("INS", "chr1", s, "A", "A" + alt, w, 10, 0, 100, False, l or len(alt), "x")
 
-    a, b, c, d = ins(1000, allele, 5), ins(1000, allele, 5), ins(1040, near, 6), ins(1300, far, 5)
+    a, b, c, d = ins(1000, allele, 10), ins(1000, allele, 10), ins(1040, near, 11), ins(1300, far, 10)
     assert [v.s for v in caller.clean_dups([a, b, c, d])] == [1000, 1040, 1300]   # adjacent exact duplicate
     out = caller.filter_sv_chains([a, c, d])
-    assert [v.s for v in out] == [1040, 1300]                     # a/c merged, heavier (w=6) kept, d untouched
+    assert [v.s for v in out] == [1040, 1300]                     # a/c merged (w ratio 10/11 >= 0.9), heavier kept
     # weight ratio below 0.9 blocks the merge (caller.cpp:447-450)
-    c2 = ins(1040, near, 9)
+    c2 = ins(1040, near, 20)
     assert [v.s for v in caller.filter_sv_chains([a, c2, d])] == [1000, 1040, 1300]
     # distance >= 100 blocks it too
-    c3 = ins(1100, near, 6)
+    c3 = ins(1100, near, 11)
     assert [v.s for v in caller.filter_sv_chains([a, c3])] == [1000, 1100]
     # dissimilar alleles are both kept
-    d2 = ins(1030, far, 5)
+    d2 = ins(1030, far, 10)
     ratio, _ = caller.fuzz_ratio([far], [allele])
     assert ratio[0] <= 70
     assert [v.s for v in caller.filter_sv_chains([a, d2])] == [1000, 1030]
     # after a merge the NEXT element becomes prev without being compared, and at the end of the
     # list a pending reset still pushes prev (caller.cpp:437-441,472): 3 similar SVs -> 2 rows
-    e3 = ins(1060, near, 6)
+    e3 = ins(1060, near, 11)
     out = caller.filter_sv_chains([a, c, e3])
     assert [v.s for v in out] == [1040, 1060]
     out = caller.filter_sv_chains([a, c])                         # merge on the last pair: artefact keeps svs[0]
