@@ -101,7 +101,12 @@ int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint8_t* d_read
 int64_t svdss_sfs_batch_nreads(const svdss_sfs_batch_t* b);
 int64_t svdss_sfs_batch_total(const svdss_sfs_batch_t* b);       /* sum of counts */
 int64_t svdss_sfs_batch_total_ext(const svdss_sfs_batch_t* b);   /* sum of n_ext */
-/* duration of the search kernel of the last call, from HIP events on its stream */
+/* Small batches are searched with several lanes per read (segments stitched exactly, see
+ * DESIGN.md); these report the segment count the last call used (1 = one lane per read) and
+ * how many reads had to be redone unsegmented because their chains could not be stitched. */
+int32_t svdss_sfs_batch_segments(const svdss_sfs_batch_t* b);
+int64_t svdss_sfs_batch_fallbacks(const svdss_sfs_batch_t* b);
+/* duration of the search kernel(s) of the last call, from HIP events on its stream */
 double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b);
 /* copy results to host; any pointer may be NULL to skip it.
  * counts,n_ext: n_reads entries; qs,len: svdss_sfs_batch_total() entries. */

@@ -49,7 +49,14 @@ struct SvLane {
   int32_t n_sfs;
   int32_t n_ext;
   int32_t chain_lo, chain_end;
+  int32_t stop_lo;   // segmented search: this lane owns read positions >= stop_lo (0: whole read)
+  int32_t n_below;   // SFS produced with start < stop_lo (overrun into the next segment)
 };
+
+// A segment's chain keeps going this many SFS past its lower boundary so that the stitcher can
+// find the SFS start it shares with the next segment's chain (see sv_stitch).
+#define SV_OVERRUN 8
+#define SV_M_PARTIAL 16   // the lane stopped after its overrun, not at the start of the read
 
 struct SvOp {
   int op;
@@ -112,11 +119,13 @@ SVDSS_HD uint32_t sv_key_revcomp(uint32_t key, int K) {
 }
 
 template <class P>
-SVDSS_HD void sv_lane_init(SvLane<P>& s, int len) {
+SVDSS_HD void sv_lane_init(SvLane<P>& s, int len, int start_pos = -1, int stop_lo = 0) {
   s.lo = 0; s.hi = 0; s.tdelta = 0;
   s.len = len;
-  s.pos = len - 1;
+  s.pos = start_pos >= 0 ? start_pos : len - 1;
   s.begin = 0;
+  s.stop_lo = stop_lo;
+  s.n_below = 0;
   s.mode = SV_M_START;  // backward phase about to start at pos = len-1 (ping_pong.cpp:8-12)
   s.c = 0;
   s.wrel = SV_NO_WINDOW;
@@ -230,6 +239,10 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
       }
       sv_emit(s, s.begin, s.pos - s.begin + 1, assemble, emit);  // :38-41
       if (s.begin == 0) return o;                     // :42 -> DONE
+      if (s.begin < s.stop_lo && ++s.n_below >= SV_OVERRUN) {
+        s.mode |= SV_M_PARTIAL;                       // segment finished; the stitcher takes over
+        return o;
+      }
       s.pos = s.pos - 1;                              // :47
       s.mode = (s.mode & ~SV_M_DIR) | SV_M_START;
     }
@@ -421,4 +434,71 @@ SVDSS_HD void sv_table_entry(const SvdssDevIndex& ix, uint32_t key, int K, uint6
     e_lo = 0;
     e_info = (SVDSS_TAB_EMPTY << 62) | (uint64_t)d;
   }
+}
+
+// ---- segmented search: stitching the per-segment chains of one read -------------------
+//
+// A read is cut into C segments; the lane of segment j starts a FRESH backward phase at the
+// segment's last position (exactly what ping_pong_search does at l-1, ping_pong.cpp:8-12)
+// and runs the unmodified algorithm over the whole read, stopping SV_OVERRUN SFS past its
+// lower boundary.  The state of ping_pong_search at the start of a forward phase is fully
+// determined by `begin` (ping_pong.cpp:28-30 resets the interval), so as soon as the chain
+// coming from the right (the true one) starts a forward phase at a position where the fresh
+// chain of the next segment also started one, the two are identical from there on.  The
+// stitcher looks for that shared SFS start; if the overrun was too short to contain it the
+// read is searched again unsegmented (exactness never depends on the heuristic).
+//
+// rec[] per segment: {qs, len, ext_at_begin, -} in production order (descending qs), where
+// ext_at_begin = extensions counted when the forward phase of that SFS started.
+struct SvSegInfo {
+  int32_t n_rec;     // records produced (may exceed cap -> overflow)
+  int32_t cap;
+  int32_t ext_total;
+  int32_t complete;  // 1: reached the start of the read, 0: stopped after the overrun
+};
+
+// Returns false if the read must be redone unsegmented.  On success take_lo/take_hi give the
+// record range of every segment that belongs to the read's chain (empty range = superseded)
+// and *n_ext the reference's extension count for the whole read.
+template <class GetRec>
+SVDSS_HD bool sv_stitch(int n_seg, const SvSegInfo* info, const int32_t* seg_lo, GetRec&& rec_qs_ext,
+                        int32_t* take_lo, int32_t* take_hi, int64_t* n_ext) {
+  for (int j = 0; j < n_seg; ++j) {
+    take_lo[j] = take_hi[j] = 0;
+    if (info[j].n_rec > info[j].cap) return false;
+  }
+  int a = n_seg - 1;           // current segment (the true chain lives in it)
+  int32_t lo = 0;              // first record of segment a that belongs to the chain
+  int64_t ext = 0;
+  int32_t ext_base = 0;        // ext_at_begin of record lo of segment a (0 for the rightmost)
+  for (;;) {
+    if (info[a].complete || a == 0) {
+      if (!info[a].complete) return false;   // segment 0 always runs to the start of the read
+      take_lo[a] = lo;
+      take_hi[a] = info[a].n_rec;
+      ext += info[a].ext_total - ext_base;
+      break;
+    }
+    const int b = a - 1;
+    const int32_t x = seg_lo[a];             // positions < x belong to segment b
+    int32_t ia = lo, ib = 0;
+    int32_t qa, ea, qb, eb;
+    bool found = false;
+    while (ia < info[a].n_rec && ib < info[b].n_rec) {
+      rec_qs_ext(a, ia, qa, ea);
+      if (qa >= x) { ++ia; continue; }       // still in a's own territory
+      rec_qs_ext(b, ib, qb, eb);
+      if (qa == qb) { found = true; break; }
+      if (qa > qb) ++ia; else ++ib;
+    }
+    if (!found) return false;
+    take_lo[a] = lo;
+    take_hi[a] = ia;
+    ext += ea - ext_base;
+    a = b;
+    lo = ib;
+    ext_base = eb;
+  }
+  *n_ext = ext;
+  return true;
 }

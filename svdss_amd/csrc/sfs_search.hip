@@ -276,7 +276,25 @@ struct SfsParams {
   int64_t* n_ext;           // n_reads
   unsigned long long* next_read;
   int32_t assemble;
+  // segmented search (small batches): every read is cut into n_seg segments, one lane each
+  int32_t n_seg;            // 1: one lane per read
+  uint4* seg_rec;           // per-item raw records {qs, len, ext_at_begin, 0}
+  SvSegInfo* seg_info;      // per item
+  const int64_t* read_ids;  // fallback pass: the reads to search (nullptr: all)
+  int64_t n_items;          // work items of this launch
+  unsigned long long* n_fallback;   // stitch kernel: number of reads to redo unsegmented
+  int64_t* fallback_ids;
 };
+
+// segmented layout: item (r, j), j < seg_count(len): records at seg_region_base + j * seg_region_cap
+__host__ __device__ inline int seg_count(int64_t len, int n_seg) {
+  const int64_t c = len / 256;
+  return (int)(c < 1 ? 1 : (c < n_seg ? c : n_seg));
+}
+__host__ __device__ inline int64_t seg_region_base(int64_t off, int64_t r, int n_seg) {
+  return (off >> 3) + (8 + 24 * (int64_t)n_seg) * r;
+}
+__host__ __device__ inline int64_t seg_region_cap(int64_t len, int cr) { return (len >> 3) / cr + 24; }
 
 // default per-read record region: (len/8 + 8) records starting at off/8 + 8 r
 __host__ __device__ inline int64_t rec_region_base(int64_t off, int64_t r) { return (off >> 3) + 8 * r; }
@@ -351,40 +369,69 @@ __device__ __forceinline__ svdss_u4 sv_load16(const uint8_t* p) {
   return r;
 }
 
-template <class P>
+template <class P, bool SEG>
 __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
   __shared__ uint32_t ring_lds[16 * 256];   // 64 read symbols per lane: row r of lane t at [r*256 + t]
   SvRing g;
   g.base = &ring_lds[threadIdx.x];
   g.stride = 256;
   SvLane<P> st;
-  int64_t r = 0, off = 0, base = 0, cap = 0;
+  int64_t r = 0, off = 0, base = 0, cap = 0, item = 0;
   bool active = false;
-  const bool assemble = p.assemble != 0;
+  const bool assemble = SEG ? false : p.assemble != 0;   // segments produce raw SFS; the stitcher assembles
   const uint8_t* reads = (const uint8_t*)p.chunks;
   const uint8_t* blocks = (const uint8_t*)p.ix.blocks;
 
   auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
-    if (idx < cap) p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
+    if (idx < cap) {
+      if (SEG)   // ext_at_begin: the forward phase of this SFS made pos - begin of the extensions
+        p.seg_rec[base + idx] = make_uint4((uint32_t)qs, (uint32_t)l, (uint32_t)(st.n_ext - (st.pos - st.begin)), 0u);
+      else
+        p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
+    }
   };
 
   for (;;) {
     if (!active) {
       const unsigned long long t = atomicAdd(p.next_read, 1ULL);
-      if (t >= (unsigned long long)p.n_reads) break;
-      r = (int64_t)t;
-      off = p.offsets[r];
-      const int64_t len = p.offsets[r + 1] - off;
-      base = p.rec_base ? p.rec_base[r] : rec_region_base(off, r);
-      cap = p.rec_cap ? p.rec_cap[r] : rec_region_cap(len);
-      sv_lane_init(st, (int32_t)len);
+      if (t >= (unsigned long long)p.n_items) break;
+      item = (int64_t)t;
+      if (SEG) {
+        r = item / p.n_seg;
+        const int j = (int)(item - r * p.n_seg);
+        off = p.offsets[r];
+        const int64_t len = p.offsets[r + 1] - off;
+        const int cr = seg_count(len, p.n_seg);
+        if (j >= cr) {                       // short read: fewer segments than lanes reserved for it
+          SvSegInfo z; z.n_rec = 0; z.cap = 0; z.ext_total = 0; z.complete = 0;
+          p.seg_info[item] = z;
+          continue;
+        }
+        cap = seg_region_cap(len, cr);
+        base = seg_region_base(off, r, p.n_seg) + j * cap;
+        sv_lane_init(st, (int32_t)len, (int)(len * (j + 1) / cr - 1), (int)(len * j / cr));
+      } else {
+        r = p.read_ids ? p.read_ids[item] : item;
+        off = p.offsets[r];
+        const int64_t len = p.offsets[r + 1] - off;
+        base = p.rec_base ? p.rec_base[r] : rec_region_base(off, r);
+        cap = p.rec_cap ? p.rec_cap[r] : rec_region_cap(len);
+        sv_lane_init(st, (int32_t)len);
+      }
       active = true;
     }
     const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit);
     if (o.op == SV_OP_DONE) {
-      sv_flush(st, assemble, emit);
-      p.counts[r] = st.n_sfs;
-      p.n_ext[r] = st.n_ext;
+      if (SEG) {
+        SvSegInfo z;
+        z.n_rec = st.n_sfs; z.cap = (int32_t)cap; z.ext_total = st.n_ext;
+        z.complete = (st.mode & SV_M_PARTIAL) ? 0 : 1;
+        p.seg_info[item] = z;
+      } else {
+        sv_flush(st, assemble, emit);
+        p.counts[r] = st.n_sfs;
+        p.n_ext[r] = st.n_ext;
+      }
       active = false;
       continue;
     }
@@ -450,6 +497,55 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
   }
 }
 
+// One lane per read: stitch the chains of its segments (sv_stitch), run the streaming
+// assembler over the stitched chain and leave the records in the read's default region, exactly
+// what the unsegmented kernel would have written.  Reads whose overrun did not reach the shared
+// SFS start are queued for an unsegmented search.
+__global__ void __launch_bounds__(256) sfs_stitch_kernel(SfsParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.n_reads) return;
+  const int64_t off = p.offsets[r];
+  const int64_t len = p.offsets[r + 1] - off;
+  const int cr = seg_count(len, p.n_seg);
+  const int64_t icap = seg_region_cap(len, cr);
+  const int64_t ibase = seg_region_base(off, r, p.n_seg);
+  SvSegInfo info[16];
+  int32_t seg_lo[16], tlo[16], thi[16];
+  for (int j = 0; j < cr; ++j) {
+    info[j] = p.seg_info[r * p.n_seg + j];
+    seg_lo[j] = (int32_t)(len * j / cr);
+  }
+  auto get = [&](int sg, int32_t i, int32_t& q, int32_t& e) {
+    const uint4 v = p.seg_rec[ibase + sg * icap + i];
+    q = (int32_t)v.x;
+    e = (int32_t)v.z;
+  };
+  int64_t ext = 0;
+  if (!sv_stitch(cr, info, seg_lo, get, tlo, thi, &ext)) {
+    const unsigned long long k = atomicAdd(p.n_fallback, 1ULL);
+    p.fallback_ids[k] = r;
+    p.counts[r] = 0;
+    p.n_ext[r] = 0;
+    return;
+  }
+  const int64_t base = rec_region_base(off, r);
+  const int64_t cap = rec_region_cap(len);
+  const bool assemble = p.assemble != 0;
+  SvLane<uint32_t> as;   // assembler state only
+  sv_lane_init(as, 0);
+  auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
+    if (idx < cap) p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
+  };
+  for (int j = cr - 1; j >= 0; --j)
+    for (int32_t i = tlo[j]; i < thi[j]; ++i) {
+      const uint4 v = p.seg_rec[ibase + j * icap + i];
+      sv_emit(as, (int)v.x, (int)v.y, assemble, emit);
+    }
+  sv_flush(as, assemble, emit);
+  p.counts[r] = as.n_sfs;
+  p.n_ext[r] = ext;
+}
+
 // One wavefront per read: copy its records from the region to the compact
 // output (reversed when assembled: the lanes produce chains in descending qs,
 // Assembler::assemble returns ascending, assembler.cpp:36).
@@ -492,6 +588,9 @@ struct svdss_sfs_batch {
   int64_t total_ext = 0;
   double kernel_ms = 0.0;
   DevBuf rec, counts, n_ext, out_off, out_qs, out_len, tmp, misc, reads, offsets, base2, sum;
+  DevBuf seg_rec, seg_info, fallback;
+  int64_t n_fallback = 0;   // reads of the last call that were redone unsegmented
+  int32_t n_seg = 1;        // segments per read used by the last call
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -514,7 +613,8 @@ extern "C" void svdss_sfs_batch_free(svdss_sfs_batch_t* b) {
   if (!b) return;
   if (b->device >= 0) (void)hipSetDevice(b->device);
   for (DevBuf* d : {&b->rec, &b->counts, &b->n_ext, &b->out_off, &b->out_qs, &b->out_len, &b->tmp,
-                    &b->misc, &b->reads, &b->offsets, &b->base2, &b->sum})
+                    &b->misc, &b->reads, &b->offsets, &b->base2, &b->sum, &b->seg_rec, &b->seg_info,
+                    &b->fallback})
     release(*d);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -525,6 +625,8 @@ extern "C" int64_t svdss_sfs_batch_nreads(const svdss_sfs_batch_t* b) { return b
 extern "C" int64_t svdss_sfs_batch_total(const svdss_sfs_batch_t* b) { return b ? b->total : -1; }
 extern "C" int64_t svdss_sfs_batch_total_ext(const svdss_sfs_batch_t* b) { return b ? b->total_ext : -1; }
 extern "C" double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b) { return b ? b->kernel_ms : -1.0; }
+extern "C" int32_t svdss_sfs_batch_segments(const svdss_sfs_batch_t* b) { return b ? b->n_seg : -1; }
+extern "C" int64_t svdss_sfs_batch_fallbacks(const svdss_sfs_batch_t* b) { return b ? b->n_fallback : -1; }
 
 static int launch_grid(int device, int* blocks_out) {
   hipDeviceProp_t prop;
@@ -582,14 +684,46 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.next_read = (unsigned long long*)b->misc.p;
   p.assemble = (flags & SVDSS_SFS_ASSEMBLE) ? 1 : 0;
   unsigned long long* d_overflow = (unsigned long long*)b->misc.p + 1;
+  p.n_seg = 1;
+  p.seg_rec = nullptr;
+  p.seg_info = nullptr;
+  p.read_ids = nullptr;
+  p.n_items = n_reads;
+  p.n_fallback = (unsigned long long*)b->misc.p + 2;
+  p.fallback_ids = nullptr;
 
   // SVDSS_KERNEL=1 selects the v1 kernel (plain LF walk) for A/B measurements
   const char* kv = getenv("SVDSS_KERNEL");
   const bool use_v1 = (kv && atoi(kv) == 1) || total_syms < 64;
   int max_blocks = 0;
   if ((rc = launch_grid(ix->device, &max_blocks))) return rc;
-  const int64_t want_blocks = (n_reads + 255) / 256;
-  const int sblocks = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
+  // Small batches cannot fill the GPU with one lane per read (256 CUs x 16 waves x 64 lanes):
+  // cut every read into n_seg segments searched by separate lanes and stitch the chains.
+  int n_seg = 1;
+  {
+    const int64_t lanes = (int64_t)max_blocks * 256 / 2;   // 4 waves per SIMD resident
+    const int64_t want = 2 * lanes / (n_reads > 0 ? n_reads : 1);
+    n_seg = (int)(want < 2 ? 1 : (want > 16 ? 16 : want));
+    if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
+    if (n_seg < 1) n_seg = 1;
+    if (n_seg > 16) n_seg = 16;
+    if (use_v1 || total_syms / (n_reads > 0 ? n_reads : 1) < 1024) n_seg = 1;
+  }
+  if (n_seg > 1) {
+    const int64_t seg_total = (total_syms >> 3) + (8 + 24 * (int64_t)n_seg) * n_reads + 64;
+    if ((rc = ensure(b->seg_rec, (size_t)seg_total * sizeof(uint4)))) return rc;
+    if ((rc = ensure(b->seg_info, (size_t)(n_reads * n_seg) * sizeof(SvSegInfo)))) return rc;
+    if ((rc = ensure(b->fallback, (size_t)n_reads * sizeof(int64_t)))) return rc;
+    p.seg_rec = (uint4*)b->seg_rec.p;
+    p.seg_info = (SvSegInfo*)b->seg_info.p;
+    p.fallback_ids = (int64_t*)b->fallback.p;
+  }
+  b->n_seg = n_seg;
+  b->n_fallback = 0;
+  auto blocks_for = [&](int64_t items) {
+    const int64_t w = (items + 255) / 256;
+    return (int)(w < 1 ? 1 : (w < max_blocks ? w : max_blocks));
+  };
   const int64_t gw = (n_reads + 3) / 4;  // 4 waves per block, one read per wave iteration
   const int gblocks = (int)(gw < 4 * (int64_t)max_blocks ? (gw > 0 ? gw : 1) : 4 * (int64_t)max_blocks);
 
@@ -601,15 +735,40 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   if ((rc = ensure(b->tmp, tmp_bytes))) return rc;
 
   for (int pass = 0; pass < 2; ++pass) {
-    HIPCHK(hipMemsetAsync(b->misc.p, 0, 16, stream));
+    HIPCHK(hipMemsetAsync(b->misc.p, 0, 32, stream));
     HIPCHK(hipMemsetAsync((int64_t*)b->counts.p + n_reads, 0, sizeof(int64_t), stream));
+    const bool wide = !ix->sa64.empty();
+    const bool seg = n_seg > 1 && pass == 0;   // the exact-capacity rerun is always unsegmented
     HIPCHK(hipEventRecord(b->ev0, stream));
-    if (use_v1)
-      hipLaunchKernelGGL(sfs_search_kernel, dim3(sblocks), dim3(256), 0, stream, p);
-    else if (ix->sa64.empty())
-      hipLaunchKernelGGL(sfs_search2_kernel<uint32_t>, dim3(sblocks), dim3(256), 0, stream, p);
-    else
-      hipLaunchKernelGGL(sfs_search2_kernel<uint64_t>, dim3(sblocks), dim3(256), 0, stream, p);
+    if (use_v1) {
+      hipLaunchKernelGGL(sfs_search_kernel, dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+    } else if (seg) {
+      p.n_seg = n_seg;
+      p.n_items = n_reads * n_seg;
+      if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true>), dim3(blocks_for(p.n_items)), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true>), dim3(blocks_for(p.n_items)), dim3(256), 0, stream, p);
+      HIPCHK(hipGetLastError());
+      hipLaunchKernelGGL(sfs_stitch_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, p);
+      HIPCHK(hipGetLastError());
+      unsigned long long n_fb = 0;
+      HIPCHK(hipMemcpyAsync(&n_fb, p.n_fallback, sizeof n_fb, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      b->n_fallback = (int64_t)n_fb;
+      if (n_fb > 0) {   // reads whose chains could not be stitched: one lane per read
+        SfsParams q = p;
+        q.n_seg = 1;
+        q.read_ids = p.fallback_ids;
+        q.n_items = (int64_t)n_fb;
+        HIPCHK(hipMemsetAsync(b->misc.p, 0, 8, stream));
+        if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+      }
+    } else {
+      p.n_seg = 1;
+      p.n_items = n_reads;
+      if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1, stream));
     size_t tb = b->tmp.cap;

@@ -225,6 +225,14 @@ class PingPong:
         return lib.svdss_sfs_batch_total_ext(self._batch)
 
     @property
+    def last_segments(self) -> int:
+        return lib.svdss_sfs_batch_segments(self._batch)
+
+    @property
+    def last_fallbacks(self) -> int:
+        return lib.svdss_sfs_batch_fallbacks(self._batch)
+
+    @property
     def last_kernel_ms(self) -> float:
         return lib.svdss_sfs_batch_kernel_ms(self._batch)
 

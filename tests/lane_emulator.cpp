@@ -74,7 +74,7 @@ template <class P>
 int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64_t* offsets,
                  int64_t n_reads, int64_t total_syms, int assemble, int K, int use_text,
                  int64_t* counts, int32_t* qs, int32_t* len, int64_t cap_total, int64_t* n_ext,
-                 int64_t* op_counts) {
+                 int64_t* op_counts, int n_seg, int64_t* seg_stats) {
   SvdssDevIndex v;
   v.blocks = ix->blocks.data();
   v.dollar = ix->dollar.data();
@@ -95,26 +95,23 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
   v.table = K > 0 ? table.data() : nullptr;
   const int64_t max_chunk = ((total_syms + 15) >> 4) - 1;
   int64_t total = 0;
-  for (int64_t r = 0; r < n_reads; ++r) {
+  struct Rec { int32_t qs, len, ext; };
+  // one lane: the chain that starts with a fresh backward phase at start_pos
+  auto run_lane = [&](int64_t off, int64_t l, int start_pos, int stop_lo, bool asm_, std::vector<Rec>& recs,
+                      int32_t& ext_total, bool& complete) {
     uint32_t ring_mem[16];
     memset(ring_mem, 0xee, sizeof ring_mem);
     SvRing g{ring_mem, 1};
     SvLane<P> st;
-    const int64_t off = offsets[r];
-    const int64_t l = offsets[r + 1] - off;
-    std::vector<std::pair<int32_t, int32_t>> recs;
     auto emit = [&](int32_t idx, int32_t q, int32_t ln) {
       if ((int64_t)recs.size() != idx) __builtin_trap();
-      recs.emplace_back(q, ln);
+      recs.push_back({q, ln, st.n_ext - (st.pos - st.begin)});
     };
-    sv_lane_init(st, (int32_t)l);
+    sv_lane_init(st, (int32_t)l, start_pos, stop_lo);
     for (int64_t guard = 0;; ++guard) {
-      if (guard > 8 * l + 1000) { fprintf(stderr, "emu2: no termination read %ld op=%d pos=%d mode=%d lo=%ld hi=%ld wrel=%d\n", (long)r, -1, st.pos, st.mode, (long)st.lo, (long)st.hi, st.wrel); abort(); }
-      SvOp o = sv_decide(st, v, g, off, assemble != 0, emit);
+      if (guard > 400 * l + 10000) { fprintf(stderr, "emu2: no termination off=%ld l=%ld start=%d stop=%d pos=%d begin=%d mode=%d lo=%ld hi=%ld wrel=%d nsfs=%d\n", (long)off, (long)l, start_pos, stop_lo, st.pos, st.begin, st.mode, (long)st.lo, (long)st.hi, st.wrel, st.n_sfs); abort(); }
+      SvOp o = sv_decide(st, v, g, off, asm_, emit);
       if (op_counts) op_counts[o.op]++;
-      if (getenv("EMU_TRACE") && guard < 80)
-        fprintf(stderr, "r%ld it%ld op=%d a=%ld pos=%d begin=%d mode=%d lo=%ld hi=%ld wrel=%d ext=%d\n", (long)r,
-                (long)guard, o.op, (long)o.a, st.pos, st.begin, st.mode, (long)st.lo, (long)st.hi, st.wrel, st.n_ext);
       if (o.op == SV_OP_DONE) break;
       if (o.op == SV_OP_TEXT_SLOW) { sv_apply_text_slow(st, v.text, reads_padded, off); continue; }
       svdss_u4 A[4], B[4];
@@ -142,12 +139,55 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
         st.wrel = (int32_t)(16 * c0 - off);
       }
     }
-    sv_flush(st, assemble != 0, emit);
+    sv_flush(st, asm_, emit);
+    ext_total = st.n_ext;
+    complete = !(st.mode & SV_M_PARTIAL);
+  };
+  for (int64_t r = 0; r < n_reads; ++r) {
+    const int64_t off = offsets[r];
+    const int64_t l = offsets[r + 1] - off;
+    std::vector<std::pair<int32_t, int32_t>> recs;
+    int64_t ext_read = 0;
+    int C = n_seg > 1 ? (int)std::min<int64_t>(n_seg, std::max<int64_t>(1, l / 256)) : 1;
+    bool stitched = false;
+    if (C > 1) {
+      // segmented: raw chains per segment, stitch, then (optionally) the streaming assembler
+      std::vector<std::vector<Rec>> seg((size_t)C);
+      std::vector<SvSegInfo> info((size_t)C);
+      std::vector<int32_t> seg_lo((size_t)C), tlo((size_t)C), thi((size_t)C);
+      for (int j = 0; j < C; ++j) {
+        seg_lo[(size_t)j] = (int32_t)(l * j / C);
+        const int start = (int)(l * (j + 1) / C - 1);
+        int32_t et; bool comp;
+        run_lane(off, l, start, seg_lo[(size_t)j], false, seg[(size_t)j], et, comp);
+        info[(size_t)j] = {(int32_t)seg[(size_t)j].size(), 1 << 30, et, comp ? 1 : 0};
+      }
+      auto get = [&](int sg, int32_t i, int32_t& q, int32_t& e) { q = seg[(size_t)sg][(size_t)i].qs; e = seg[(size_t)sg][(size_t)i].ext; };
+      if (sv_stitch(C, info.data(), seg_lo.data(), get, tlo.data(), thi.data(), &ext_read)) {
+        stitched = true;
+        if (seg_stats) seg_stats[0]++;
+        SvLane<P> as;     // only the assembler fields are used
+        sv_lane_init(as, 0);
+        auto emit2 = [&](int32_t, int32_t q, int32_t ln) { recs.emplace_back(q, ln); };
+        for (int j = C - 1; j >= 0; --j)
+          for (int32_t i = tlo[(size_t)j]; i < thi[(size_t)j]; ++i)
+            sv_emit(as, seg[(size_t)j][(size_t)i].qs, seg[(size_t)j][(size_t)i].len, assemble != 0, emit2);
+        sv_flush(as, assemble != 0, emit2);
+      } else if (seg_stats) seg_stats[1]++;
+    }
+    if (!stitched) {
+      std::vector<Rec> one;
+      int32_t et; bool comp;
+      run_lane(off, l, -1, 0, assemble != 0, one, et, comp);
+      if (!comp) __builtin_trap();
+      for (auto& x : one) recs.emplace_back(x.qs, x.len);
+      ext_read = et;
+    }
     if (assemble) std::reverse(recs.begin(), recs.end());
     if (total + (int64_t)recs.size() > cap_total) return -1;
     for (auto& rc : recs) { qs[total] = rc.first; len[total] = rc.second; ++total; }
     counts[r] = (int64_t)recs.size();
-    n_ext[r] = st.n_ext;
+    n_ext[r] = ext_read;
   }
   return total;
 }
@@ -156,10 +196,11 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
 extern "C" int64_t emu_search2(const svdss_index* ix, const uint8_t* reads_padded,
                                const int64_t* offsets, int64_t n_reads, int64_t total_syms,
                                int assemble, int K, int use_text, int64_t* counts, int32_t* qs,
-                               int32_t* len, int64_t cap_total, int64_t* n_ext, int64_t* op_counts) {
+                               int32_t* len, int64_t cap_total, int64_t* n_ext, int64_t* op_counts,
+                               int n_seg, int64_t* seg_stats) {
   if (ix->sa64.empty())
     return emu2_run<uint32_t>(ix, reads_padded, offsets, n_reads, total_syms, assemble, K, use_text,
-                              counts, qs, len, cap_total, n_ext, op_counts);
+                              counts, qs, len, cap_total, n_ext, op_counts, n_seg, seg_stats);
   return emu2_run<uint64_t>(ix, reads_padded, offsets, n_reads, total_syms, assemble, K, use_text,
-                            counts, qs, len, cap_total, n_ext, op_counts);
+                            counts, qs, len, cap_total, n_ext, op_counts, n_seg, seg_stats);
 }

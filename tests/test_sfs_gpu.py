@@ -253,3 +253,26 @@ def test_device_results_alias_and_single_rank_gather():
         assert (q2.cpu().numpy() == got.qs).all() and (l2.cpu().numpy() == got.len).all()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("segments", ["1", "2", "5", "16"])
+def test_segmented_search_is_exact(monkeypatch, segments):
+    """Small batches use several lanes per read; the stitched chains must equal the one-lane result
+    (SFS, order, assembled form, extension counts), including reads that fall back."""
+    monkeypatch.setenv("SVDSS_SEGMENTS", segments)
+    ref, hap, svs, flat, offs = small_workload(seed=38, n_reads=200, read_len=6000, ref_lens=(400000,))
+    reads = [flat[offs[i]:offs[i + 1]] for i in range(200)]
+    reads += [np.full(1500, 5, np.uint8), ref[0][:5000].copy(), np.zeros(0, np.uint8), ref[0][7:300].copy()]
+    flat, offs = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    for assemble in (False, True):
+        pp = svdss_amd.PingPong(ix, assemble=assemble)
+        got = pp.ping_pong_search(flat, offs)
+        assert pp.last_segments == int(segments)
+        if segments != "1":
+            assert 0 < pp.last_fallbacks < 20     # the all-N read cannot be stitched within the overrun
+        c, q, l, e = fm.search_batch(flat, offs, assemble)
+        assert (got.counts == c).all() and (got.n_ext == e).all()
+        assert (got.qs == q).all() and (got.len == l).all()
+        pp.close()
