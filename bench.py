@@ -215,7 +215,8 @@ def main():
                 "parallelism": f"reads sharded over {world} GPU(s), index replicated, SFS gathered on rank 0",
                 "ext_per_read": n_ext / n_reads, "raw_sfs_per_read": n_sfs_raw / n_reads,
                 "assembled_sfs_per_read": n_sfs_asm / n_reads, "index_build_s": round(t_index, 1),
-                "kmer_table_k": ix.kmer_k,
+                "kmer_table_k": ix.kmer_k, "segments_per_read": pp.last_segments,
+                "reads_redone_unsegmented": pp.last_fallbacks,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "sfs_search2_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

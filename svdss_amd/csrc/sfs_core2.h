@@ -53,9 +53,10 @@ struct SvLane {
   int32_t n_below;   // SFS produced with start < stop_lo (overrun into the next segment)
 };
 
-// A segment's chain keeps going this many SFS past its lower boundary so that the stitcher can
-// find the SFS start it shares with the next segment's chain (see sv_stitch).
-#define SV_OVERRUN 8
+// A segment's chain keeps going past its lower boundary until it sees (peek) that the next
+// segment's chain started a forward phase at the same position, at most this many SFS, so that
+// the stitcher can find the SFS start the two chains share (see sv_stitch).
+#define SV_OVERRUN 48
 #define SV_M_PARTIAL 16   // the lane stopped after its overrun, not at the start of the read
 
 struct SvOp {
@@ -159,9 +160,14 @@ SVDSS_HD void sv_flush(SvLane<P>& s, bool assemble, Emit&& emit) {
 
 // Decide the one memory operation of this iteration.  `off` = absolute buffer
 // position of the read's first symbol.  ALU + ring (LDS) reads only.
-template <class P, class Emit>
+struct SvNoPeek { SVDSS_HD bool operator()(int32_t) const { return false; } };
+
+// peek(begin): segmented search only -- true if the chain of the segment to the left is already
+// known to have started a forward phase at `begin` (then the two chains are identical from here
+// on and this lane can stop; a wrong answer only costs a redo, sv_stitch verifies everything).
+template <class P, class Emit, class Peek = SvNoPeek>
 SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, int64_t off,
-                        bool assemble, Emit&& emit) {
+                        bool assemble, Emit&& emit, Peek&& peek = SvNoPeek()) {
   SvOp o;
   o.op = SV_OP_DONE;
   o.a = 0;
@@ -239,7 +245,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
       }
       sv_emit(s, s.begin, s.pos - s.begin + 1, assemble, emit);  // :38-41
       if (s.begin == 0) return o;                     // :42 -> DONE
-      if (s.begin < s.stop_lo && ++s.n_below >= SV_OVERRUN) {
+      if (s.begin < s.stop_lo && (peek(s.begin) || ++s.n_below >= SV_OVERRUN)) {
         s.mode |= SV_M_PARTIAL;                       // segment finished; the stitcher takes over
         return o;
       }

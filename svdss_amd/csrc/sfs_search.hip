@@ -284,6 +284,7 @@ struct SfsParams {
   int64_t n_items;          // work items of this launch
   unsigned long long* n_fallback;   // stitch kernel: number of reads to redo unsegmented
   int64_t* fallback_ids;
+  uint32_t epoch;           // tag of the records written by this launch (see peek)
 };
 
 // segmented layout: item (r, j), j < seg_count(len): records at seg_region_base + j * seg_region_cap
@@ -377,6 +378,10 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
   g.stride = 256;
   SvLane<P> st;
   int64_t r = 0, off = 0, base = 0, cap = 0, item = 0;
+  int32_t nb_cur = 0;       // SEG: cursor into the left neighbour's records
+  bool has_left = false;
+  const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
+  int64_t next_item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // SEG: static round-robin
   bool active = false;
   const bool assemble = SEG ? false : p.assemble != 0;   // segments produce raw SFS; the stitcher assembles
   const uint8_t* reads = (const uint8_t*)p.chunks;
@@ -385,17 +390,42 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
   auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
     if (idx < cap) {
       if (SEG)   // ext_at_begin: the forward phase of this SFS made pos - begin of the extensions
-        p.seg_rec[base + idx] = make_uint4((uint32_t)qs, (uint32_t)l, (uint32_t)(st.n_ext - (st.pos - st.begin)), 0u);
+        p.seg_rec[base + idx] = make_uint4((uint32_t)qs, (uint32_t)l, (uint32_t)(st.n_ext - (st.pos - st.begin)),
+                                           p.epoch);
       else
         p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
     }
   };
 
+  // Has the chain of the segment to the left (records right below this lane's region, tagged
+  // with this launch's epoch as they are produced) started a forward phase at `begin`?  The
+  // segments of a read sit in adjacent lanes, so the neighbour is normally far ahead; a stale
+  // or missing answer only lengthens the overrun.
+  auto peek = [&](int32_t begin) -> bool {
+    if (!SEG || !has_left) return false;
+    for (int it = 0; it < 32 && nb_cur < cap; ++it) {
+      const uint4* rp = p.seg_rec + (base - cap + nb_cur);
+      const uint32_t tag = __hip_atomic_load(&rp->w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tag != p.epoch) return false;
+      const int32_t q = (int32_t)__hip_atomic_load(&rp->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q == begin) return true;
+      if (q < begin) return false;
+      ++nb_cur;
+    }
+    return false;
+  };
+
   for (;;) {
     if (!active) {
-      const unsigned long long t = atomicAdd(p.next_read, 1ULL);
-      if (t >= (unsigned long long)p.n_items) break;
-      item = (int64_t)t;
+      if (SEG) {
+        if (next_item >= p.n_items) break;
+        item = next_item;
+        next_item += n_threads;
+      } else {
+        const unsigned long long t = atomicAdd(p.next_read, 1ULL);
+        if (t >= (unsigned long long)p.n_items) break;
+        item = (int64_t)t;
+      }
       if (SEG) {
         r = item / p.n_seg;
         const int j = (int)(item - r * p.n_seg);
@@ -409,6 +439,8 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
         }
         cap = seg_region_cap(len, cr);
         base = seg_region_base(off, r, p.n_seg) + j * cap;
+        has_left = j > 0;
+        nb_cur = 0;
         sv_lane_init(st, (int32_t)len, (int)(len * (j + 1) / cr - 1), (int)(len * j / cr));
       } else {
         r = p.read_ids ? p.read_ids[item] : item;
@@ -420,7 +452,7 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
       }
       active = true;
     }
-    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit);
+    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, peek);
     if (o.op == SV_OP_DONE) {
       if (SEG) {
         SvSegInfo z;
@@ -591,6 +623,7 @@ struct svdss_sfs_batch {
   DevBuf seg_rec, seg_info, fallback;
   int64_t n_fallback = 0;   // reads of the last call that were redone unsegmented
   int32_t n_seg = 1;        // segments per read used by the last call
+  uint32_t epoch = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -691,6 +724,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.n_items = n_reads;
   p.n_fallback = (unsigned long long*)b->misc.p + 2;
   p.fallback_ids = nullptr;
+  p.epoch = ++b->epoch ? b->epoch : ++b->epoch;
 
   // SVDSS_KERNEL=1 selects the v1 kernel (plain LF walk) for A/B measurements
   const char* kv = getenv("SVDSS_KERNEL");
@@ -707,6 +741,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
     if (n_seg < 1) n_seg = 1;
     if (n_seg > 16) n_seg = 16;
+    while (n_seg & (n_seg - 1)) n_seg &= n_seg - 1;   // power of two: a read's segments share a wave
     if (use_v1 || total_syms / (n_reads > 0 ? n_reads : 1) < 1024) n_seg = 1;
   }
   if (n_seg > 1) {
@@ -754,6 +789,17 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       HIPCHK(hipMemcpyAsync(&n_fb, p.n_fallback, sizeof n_fb, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
       b->n_fallback = (int64_t)n_fb;
+      if (getenv("SVDSS_DEBUG")) {
+        hipEvent_t e2;
+        (void)hipEventCreate(&e2);
+        (void)hipEventRecord(e2, stream);
+        (void)hipEventSynchronize(e2);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, b->ev0, e2);
+        fprintf(stderr, "[svdss] segmented search + stitch: %.3f ms, %llu of %lld reads to redo\n", t, n_fb,
+                (long long)n_reads);
+        (void)hipEventDestroy(e2);
+      }
       if (n_fb > 0) {   // reads whose chains could not be stitched: one lane per read
         SfsParams q = p;
         q.n_seg = 1;

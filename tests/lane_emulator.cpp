@@ -98,7 +98,18 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
   struct Rec { int32_t qs, len, ext; };
   // one lane: the chain that starts with a fresh backward phase at start_pos
   auto run_lane = [&](int64_t off, int64_t l, int start_pos, int stop_lo, bool asm_, std::vector<Rec>& recs,
-                      int32_t& ext_total, bool& complete) {
+                      int32_t& ext_total, bool& complete, const std::vector<Rec>* left = nullptr) {
+    size_t nb_cur = 0;
+    auto peek = [&](int32_t begin) -> bool {
+      if (!left) return false;
+      while (nb_cur < left->size()) {
+        const int32_t q = (*left)[nb_cur].qs;
+        if (q == begin) return true;
+        if (q < begin) return false;
+        ++nb_cur;
+      }
+      return false;
+    };
     uint32_t ring_mem[16];
     memset(ring_mem, 0xee, sizeof ring_mem);
     SvRing g{ring_mem, 1};
@@ -110,7 +121,7 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
     sv_lane_init(st, (int32_t)l, start_pos, stop_lo);
     for (int64_t guard = 0;; ++guard) {
       if (guard > 400 * l + 10000) { fprintf(stderr, "emu2: no termination off=%ld l=%ld start=%d stop=%d pos=%d begin=%d mode=%d lo=%ld hi=%ld wrel=%d nsfs=%d\n", (long)off, (long)l, start_pos, stop_lo, st.pos, st.begin, st.mode, (long)st.lo, (long)st.hi, st.wrel, st.n_sfs); abort(); }
-      SvOp o = sv_decide(st, v, g, off, asm_, emit);
+      SvOp o = sv_decide(st, v, g, off, asm_, emit, peek);
       if (op_counts) op_counts[o.op]++;
       if (o.op == SV_OP_DONE) break;
       if (o.op == SV_OP_TEXT_SLOW) { sv_apply_text_slow(st, v.text, reads_padded, off); continue; }
@@ -159,7 +170,8 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
         seg_lo[(size_t)j] = (int32_t)(l * j / C);
         const int start = (int)(l * (j + 1) / C - 1);
         int32_t et; bool comp;
-        run_lane(off, l, start, seg_lo[(size_t)j], false, seg[(size_t)j], et, comp);
+        run_lane(off, l, start, seg_lo[(size_t)j], false, seg[(size_t)j], et, comp,
+                 j > 0 ? &seg[(size_t)(j - 1)] : nullptr);
         info[(size_t)j] = {(int32_t)seg[(size_t)j].size(), 1 << 30, et, comp ? 1 : 0};
       }
       auto get = [&](int sg, int32_t i, int32_t& q, int32_t& e) { q = seg[(size_t)sg][(size_t)i].qs; e = seg[(size_t)sg][(size_t)i].ext; };
