@@ -285,6 +285,7 @@ struct SfsParams {
   unsigned long long* n_fallback;   // stitch kernel: number of reads to redo unsegmented
   int64_t* fallback_ids;
   uint32_t epoch;           // tag of the records written by this launch (see peek)
+  unsigned long long* stats;   // SVDSS_DEBUG: [0] lane iterations [1] overrun SFS [2] stops by peek [3] by cap
 };
 
 // segmented layout: item (r, j), j < seg_count(len): records at seg_region_base + j * seg_region_cap
@@ -379,9 +380,8 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
   SvLane<P> st;
   int64_t r = 0, off = 0, base = 0, cap = 0, item = 0;
   int32_t nb_cur = 0;       // SEG: cursor into the left neighbour's records
+  unsigned long long n_iter = 0;
   bool has_left = false;
-  const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
-  int64_t next_item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // SEG: static round-robin
   bool active = false;
   const bool assemble = SEG ? false : p.assemble != 0;   // segments produce raw SFS; the stitcher assembles
   const uint8_t* reads = (const uint8_t*)p.chunks;
@@ -390,8 +390,15 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
   auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
     if (idx < cap) {
       if (SEG)   // ext_at_begin: the forward phase of this SFS made pos - begin of the extensions
-        p.seg_rec[base + idx] = make_uint4((uint32_t)qs, (uint32_t)l, (uint32_t)(st.n_ext - (st.pos - st.begin)),
-                                           p.epoch);
+      {
+        // two 8-byte agent-scope (write-through, sc1) stores: lanes on other XCDs peek at these
+        unsigned long long* rp = (unsigned long long*)(p.seg_rec + (base + idx));
+        __hip_atomic_store(rp, (unsigned long long)(uint32_t)qs | ((unsigned long long)(uint32_t)l << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rp + 1, (unsigned long long)(uint32_t)(st.n_ext - (st.pos - st.begin)) |
+                                       ((unsigned long long)p.epoch << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       else
         p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
     }
@@ -399,15 +406,15 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
 
   // Has the chain of the segment to the left (records right below this lane's region, tagged
   // with this launch's epoch as they are produced) started a forward phase at `begin`?  The
-  // segments of a read sit in adjacent lanes, so the neighbour is normally far ahead; a stale
-  // or missing answer only lengthens the overrun.
+  // segments of a read are fetched back to back, so the neighbour is normally far ahead; a
+  // stale or missing answer only lengthens the overrun.
   auto peek = [&](int32_t begin) -> bool {
     if (!SEG || !has_left) return false;
     for (int it = 0; it < 32 && nb_cur < cap; ++it) {
-      const uint4* rp = p.seg_rec + (base - cap + nb_cur);
-      const uint32_t tag = __hip_atomic_load(&rp->w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tag != p.epoch) return false;
-      const int32_t q = (int32_t)__hip_atomic_load(&rp->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long* rp = (const unsigned long long*)(p.seg_rec + (base - cap + nb_cur));
+      const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(hi >> 32) != p.epoch) return false;
+      const int32_t q = (int32_t)(uint32_t)__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (q == begin) return true;
       if (q < begin) return false;
       ++nb_cur;
@@ -417,15 +424,9 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
 
   for (;;) {
     if (!active) {
-      if (SEG) {
-        if (next_item >= p.n_items) break;
-        item = next_item;
-        next_item += n_threads;
-      } else {
-        const unsigned long long t = atomicAdd(p.next_read, 1ULL);
-        if (t >= (unsigned long long)p.n_items) break;
-        item = (int64_t)t;
-      }
+      const unsigned long long t = atomicAdd(p.next_read, 1ULL);
+      if (t >= (unsigned long long)p.n_items) break;
+      item = (int64_t)t;   // consecutive items = the segments of one read, left to right
       if (SEG) {
         r = item / p.n_seg;
         const int j = (int)(item - r * p.n_seg);
@@ -453,7 +454,14 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
       active = true;
     }
     const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, peek);
+    ++n_iter;
     if (o.op == SV_OP_DONE) {
+      if (p.stats) {
+        atomicAdd(p.stats + 0, n_iter);
+        atomicAdd(p.stats + 1, (unsigned long long)st.n_below);
+        if (st.mode & SV_M_PARTIAL) atomicAdd(p.stats + (st.n_below >= SV_OVERRUN ? 3 : 2), 1ULL);
+        n_iter = 0;
+      }
       if (SEG) {
         SvSegInfo z;
         z.n_rec = st.n_sfs; z.cap = (int32_t)cap; z.ext_total = st.n_ext;
@@ -725,6 +733,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.n_fallback = (unsigned long long*)b->misc.p + 2;
   p.fallback_ids = nullptr;
   p.epoch = ++b->epoch ? b->epoch : ++b->epoch;
+  p.stats = getenv("SVDSS_DEBUG") ? (unsigned long long*)b->misc.p + 4 : nullptr;
 
   // SVDSS_KERNEL=1 selects the v1 kernel (plain LF walk) for A/B measurements
   const char* kv = getenv("SVDSS_KERNEL");
@@ -737,11 +746,10 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   {
     const int64_t lanes = (int64_t)max_blocks * 256 / 2;   // 4 waves per SIMD resident
     const int64_t want = 2 * lanes / (n_reads > 0 ? n_reads : 1);
-    n_seg = (int)(want < 2 ? 1 : (want > 16 ? 16 : want));
+    n_seg = (int)(want < 2 ? 1 : (want > 8 ? 8 : want));   // beyond 8 the odd unstitchable read costs more than it saves
     if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
     if (n_seg < 1) n_seg = 1;
     if (n_seg > 16) n_seg = 16;
-    while (n_seg & (n_seg - 1)) n_seg &= n_seg - 1;   // power of two: a read's segments share a wave
     if (use_v1 || total_syms / (n_reads > 0 ? n_reads : 1) < 1024) n_seg = 1;
   }
   if (n_seg > 1) {
@@ -770,7 +778,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   if ((rc = ensure(b->tmp, tmp_bytes))) return rc;
 
   for (int pass = 0; pass < 2; ++pass) {
-    HIPCHK(hipMemsetAsync(b->misc.p, 0, 32, stream));
+    HIPCHK(hipMemsetAsync(b->misc.p, 0, 64, stream));
     HIPCHK(hipMemsetAsync((int64_t*)b->counts.p + n_reads, 0, sizeof(int64_t), stream));
     const bool wide = !ix->sa64.empty();
     const bool seg = n_seg > 1 && pass == 0;   // the exact-capacity rerun is always unsegmented
@@ -796,8 +804,11 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
         (void)hipEventSynchronize(e2);
         float t = 0.f;
         (void)hipEventElapsedTime(&t, b->ev0, e2);
-        fprintf(stderr, "[svdss] segmented search + stitch: %.3f ms, %llu of %lld reads to redo\n", t, n_fb,
-                (long long)n_reads);
+        unsigned long long st4[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(st4, (unsigned long long*)b->misc.p + 4, sizeof st4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[svdss] segmented search + stitch: %.3f ms, %llu of %lld reads to redo; lane iterations %llu, "
+                "overrun SFS %llu, stops by peek %llu, by cap %llu\n", t, n_fb, (long long)n_reads, st4[0], st4[1],
+                st4[2], st4[3]);
         (void)hipEventDestroy(e2);
       }
       if (n_fb > 0) {   // reads whose chains could not be stitched: one lane per read
