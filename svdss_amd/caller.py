@@ -275,3 +275,162 @@ def call_tail(subclusters, chromosomes: dict, contigs, min_sv_length: int = 25, 
     svs = filter_sv_chains(svs, min_ratio, device)
     svs.sort(key=SV.key)
     return vcf_header(contigs) + "".join(sv.vcf_line() + "\n" for sv in svs)
+
+
+# ---------------------------------------------------------------------------
+# a13: Caller::split_cluster_by_len / split_cluster (caller.cpp:78-255) on the structs of
+# clusterer.hpp:24-139.  float = IEEE binary32 as in the reference (np.float32 arithmetic).
+
+class SubRead:                                       # clusterer.hpp:24-36
+    def __init__(self, name, seq, htag):
+        self.name, self.seq, self.htag = name, seq, int(htag)
+
+    def size(self):
+        return len(self.seq)
+
+
+class Cluster:                                       # clusterer.hpp:38-139
+    def __init__(self, chrom="", s=0, e=0, cov=0, cov0=0, cov1=0, cov2=0):
+        self.chrom, self.s, self.e = chrom, int(s), int(e)
+        self.cov, self.cov0, self.cov1, self.cov2 = cov, cov0, cov1, cov2
+        self.subreads, self.reads, self.SFSs = [], [], []
+
+    def copy_cleared(self):
+        """Cluster c = cluster; c.clear(): the copy constructor drops `reads` (clusterer.hpp:49-59)."""
+        c = Cluster(self.chrom, self.s, self.e, self.cov, self.cov0, self.cov1, self.cov2)
+        return c
+
+    def add_subread(self, sr):
+        self.subreads.append(sr)
+
+    def size(self):
+        return len(self.subreads)
+
+    def get_len(self):                               # integer mean (clusterer.hpp:103-111)
+        return sum(sr.size() for sr in self.subreads) // len(self.subreads)
+
+    def get_names(self):
+        return [sr.name for sr in self.subreads]
+
+    def get_seqs(self):
+        return [sr.seq for sr in self.subreads]
+
+
+_F = np.float32
+
+
+def _len_ratio(cl, sl):
+    cl, sl = _F(cl), _F(sl)
+    return min(cl, sl) / max(cl, sl)
+
+
+def split_cluster_by_len(cluster: Cluster, min_ratio=0.97):
+    """caller.cpp:78-97: greedy first fit by length ratio against the bucket's integer mean length."""
+    mr = _F(min_ratio)
+    subs = []
+    for sr in cluster.subreads:
+        for sc in subs:
+            if _len_ratio(sc.get_len(), sr.size()) >= mr:
+                break
+        else:
+            sc = Cluster(cluster.chrom, cluster.s, cluster.e, cluster.cov, cluster.cov0, cluster.cov1, cluster.cov2)
+            subs.append(sc)
+        sc.add_subread(sr)
+    return subs
+
+
+def _largest(subs):
+    """first bucket of maximal size (strict > scan, caller.cpp:222-229)."""
+    v_max, i_max = 0, -1
+    for i, sc in enumerate(subs):
+        if sc.size() > v_max:
+            v_max, i_max = sc.size(), i
+    return i_max
+
+
+def split_cluster(cluster: Cluster, useht=True, min_ratio=0.97):
+    """caller.cpp:100-255, including the int-typed best_ratio quirk (SURVEY App. A#9)."""
+    mr = _F(min_ratio)
+    c0, c1, c2 = cluster.copy_cleared(), cluster.copy_cleared(), cluster.copy_cleared()
+    for sr in cluster.subreads:
+        if useht and sr.htag == 1:
+            c1.add_subread(sr)
+        elif useht and sr.htag == 2:
+            c2.add_subread(sr)
+        else:
+            c0.add_subread(sr)
+    c0.cov1 = c0.cov2 = -1
+    c1.cov0 = c1.cov2 = -1
+    c2.cov0 = c2.cov1 = -1
+    out = []
+    if c1.size() == 0 and c2.size() == 0:
+        subs = split_cluster_by_len(c0, min_ratio)
+        i1 = i2 = -1
+        v1 = v2 = 0
+        for i, sc in enumerate(subs):               # top-2 by size (caller.cpp:134-145)
+            if sc.size() > v1:
+                v2, i2 = v1, i1
+                v1, i1 = sc.size(), i
+            elif sc.size() > v2:
+                v2, i2 = sc.size(), i
+        if i1 != -1:
+            out.append(subs[i1])
+        if i2 != -1:
+            out.append(subs[i2])
+        return out
+    both = (1 if c1.size() > 0 else 0) + (2 if c2.size() > 0 else 0)
+    subs1 = split_cluster_by_len(c1, min_ratio)
+    subs2 = split_cluster_by_len(c2, min_ratio)
+    new_cluster = Cluster(cluster.chrom, cluster.s, cluster.e, cluster.cov, cluster.cov0, -1, -1)
+
+    def best_of(subs, sl):
+        best, best_ratio = -1, 0 - 1                 # `int best_ratio = -1`
+        for i, sc in enumerate(subs):
+            r = _len_ratio(sc.get_len(), sl)
+            if r >= mr and r > _F(best_ratio):
+                best, best_ratio = i, int(r)         # truncation: 0 unless r == 1.0
+        return best, best_ratio
+
+    for sr in c0.subreads:
+        b1, r1 = best_of(subs1, sr.size())
+        b2, r2 = best_of(subs2, sr.size())
+        if both == 1:
+            if b1 == -1:
+                new_cluster.add_subread(sr)
+            else:
+                subs1[b1].add_subread(sr)
+                subs1[b1].cov1 += 1
+                new_cluster.cov0 -= 1
+        elif both == 2:
+            if b2 == -1:
+                new_cluster.add_subread(sr)
+            else:
+                subs2[b2].add_subread(sr)
+                subs2[b2].cov2 += 1
+                new_cluster.cov0 -= 1
+        else:
+            if b1 != -1 and r1 > r2:
+                subs1[b1].add_subread(sr)
+                subs1[b1].cov1 += 1
+                new_cluster.cov0 -= 1
+            elif b2 != -1 and r2 > r1:
+                subs2[b2].add_subread(sr)
+                subs2[b2].cov2 += 1
+                new_cluster.cov0 -= 1
+            # else: the untagged sub-read is dropped (caller.cpp:211-212)
+    i = _largest(subs1)
+    if i != -1:
+        out.append(subs1[i])
+    i = _largest(subs2)
+    if i != -1:
+        out.append(subs2[i])
+    if both != 3:
+        news = split_cluster_by_len(new_cluster, min_ratio) if new_cluster.size() else []
+        i = _largest(news)
+        if i != -1:
+            if both == 1:
+                news[i].cov1 = -1
+            else:
+                news[i].cov2 = -1
+            out.append(news[i])
+    return out
