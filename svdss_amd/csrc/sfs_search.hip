@@ -277,7 +277,8 @@ struct SfsParams {
   unsigned long long* next_read;
   int32_t assemble;
   // segmented search (small batches): every read is cut into n_seg segments, one lane each
-  int32_t n_seg;            // 1: one lane per read
+  int32_t n_seg;            // 1: one lane per read; a power of two
+  int32_t seg_shift;        // log2(n_seg)
   uint4* seg_rec;           // per-item raw records {qs, len, ext_at_begin, 0}
   SvSegInfo* seg_info;      // per item
   const int64_t* read_ids;  // fallback pass: the reads to search (nullptr: all)
@@ -285,13 +286,17 @@ struct SfsParams {
   unsigned long long* n_fallback;   // stitch kernel: number of reads to redo unsegmented
   int64_t* fallback_ids;
   uint32_t epoch;           // tag of the records written by this launch (see peek)
-  unsigned long long* stats;   // SVDSS_DEBUG: [0] lane iterations [1] overrun SFS [2] stops by peek [3] by cap
 };
 
 // segmented layout: item (r, j), j < seg_count(len): records at seg_region_base + j * seg_region_cap
 __host__ __device__ inline int seg_count(int64_t len, int n_seg) {
-  const int64_t c = len / 256;
+  const int64_t c = len >> 8;
   return (int)(c < 1 ? 1 : (c < n_seg ? c : n_seg));
+}
+// segment j of cr covers read positions [j*sl, (j+1)*sl), the last one up to len; sl = len / cr
+__host__ __device__ inline int32_t seg_lo_pos(int32_t sl, int j) { return j * sl; }
+__host__ __device__ inline int32_t seg_start_pos(int32_t len, int32_t sl, int j, int cr) {
+  return j == cr - 1 ? len - 1 : (j + 1) * sl - 1;
 }
 __host__ __device__ inline int64_t seg_region_base(int64_t off, int64_t r, int n_seg) {
   return (off >> 3) + (8 + 24 * (int64_t)n_seg) * r;
@@ -372,7 +377,7 @@ __device__ __forceinline__ svdss_u4 sv_load16(const uint8_t* p) {
 }
 
 template <class P, bool SEG>
-__global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
+__global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
   __shared__ uint32_t ring_lds[16 * 256];   // 64 read symbols per lane: row r of lane t at [r*256 + t]
   SvRing g;
   g.base = &ring_lds[threadIdx.x];
@@ -380,7 +385,6 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
   SvLane<P> st;
   int64_t r = 0, off = 0, base = 0, cap = 0, item = 0;
   int32_t nb_cur = 0;       // SEG: cursor into the left neighbour's records
-  unsigned long long n_iter = 0;
   bool has_left = false;
   bool active = false;
   const bool assemble = SEG ? false : p.assemble != 0;   // segments produce raw SFS; the stitcher assembles
@@ -410,6 +414,7 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
   // stale or missing answer only lengthens the overrun.
   auto peek = [&](int32_t begin) -> bool {
     if (!SEG || !has_left) return false;
+#pragma unroll 1
     for (int it = 0; it < 32 && nb_cur < cap; ++it) {
       const unsigned long long* rp = (const unsigned long long*)(p.seg_rec + (base - cap + nb_cur));
       const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -428,8 +433,8 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
       if (t >= (unsigned long long)p.n_items) break;
       item = (int64_t)t;   // consecutive items = the segments of one read, left to right
       if (SEG) {
-        r = item / p.n_seg;
-        const int j = (int)(item - r * p.n_seg);
+        r = item >> p.seg_shift;
+        const int j = (int)(item & (p.n_seg - 1));
         off = p.offsets[r];
         const int64_t len = p.offsets[r + 1] - off;
         const int cr = seg_count(len, p.n_seg);
@@ -442,7 +447,8 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
         base = seg_region_base(off, r, p.n_seg) + j * cap;
         has_left = j > 0;
         nb_cur = 0;
-        sv_lane_init(st, (int32_t)len, (int)(len * (j + 1) / cr - 1), (int)(len * j / cr));
+        const int32_t sl = (int32_t)((uint32_t)len / (uint32_t)cr);
+        sv_lane_init(st, (int32_t)len, seg_start_pos((int32_t)len, sl, j, cr), seg_lo_pos(sl, j));
       } else {
         r = p.read_ids ? p.read_ids[item] : item;
         off = p.offsets[r];
@@ -454,14 +460,7 @@ __global__ void __launch_bounds__(256) sfs_search2_kernel(SfsParams p) {
       active = true;
     }
     const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, peek);
-    ++n_iter;
     if (o.op == SV_OP_DONE) {
-      if (p.stats) {
-        atomicAdd(p.stats + 0, n_iter);
-        atomicAdd(p.stats + 1, (unsigned long long)st.n_below);
-        if (st.mode & SV_M_PARTIAL) atomicAdd(p.stats + (st.n_below >= SV_OVERRUN ? 3 : 2), 1ULL);
-        n_iter = 0;
-      }
       if (SEG) {
         SvSegInfo z;
         z.n_rec = st.n_sfs; z.cap = (int32_t)cap; z.ext_total = st.n_ext;
@@ -551,9 +550,10 @@ __global__ void __launch_bounds__(256) sfs_stitch_kernel(SfsParams p) {
   const int64_t ibase = seg_region_base(off, r, p.n_seg);
   SvSegInfo info[16];
   int32_t seg_lo[16], tlo[16], thi[16];
+  const int32_t sl = (int32_t)((uint32_t)len / (uint32_t)cr);
   for (int j = 0; j < cr; ++j) {
     info[j] = p.seg_info[r * p.n_seg + j];
-    seg_lo[j] = (int32_t)(len * j / cr);
+    seg_lo[j] = seg_lo_pos(sl, j);
   }
   auto get = [&](int sg, int32_t i, int32_t& q, int32_t& e) {
     const uint4 v = p.seg_rec[ibase + sg * icap + i];
@@ -726,6 +726,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.assemble = (flags & SVDSS_SFS_ASSEMBLE) ? 1 : 0;
   unsigned long long* d_overflow = (unsigned long long*)b->misc.p + 1;
   p.n_seg = 1;
+  p.seg_shift = 0;
   p.seg_rec = nullptr;
   p.seg_info = nullptr;
   p.read_ids = nullptr;
@@ -733,7 +734,6 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.n_fallback = (unsigned long long*)b->misc.p + 2;
   p.fallback_ids = nullptr;
   p.epoch = ++b->epoch ? b->epoch : ++b->epoch;
-  p.stats = getenv("SVDSS_DEBUG") ? (unsigned long long*)b->misc.p + 4 : nullptr;
 
   // SVDSS_KERNEL=1 selects the v1 kernel (plain LF walk) for A/B measurements
   const char* kv = getenv("SVDSS_KERNEL");
@@ -750,6 +750,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
     if (n_seg < 1) n_seg = 1;
     if (n_seg > 16) n_seg = 16;
+    while (n_seg & (n_seg - 1)) n_seg &= n_seg - 1;   // power of two: item -> (read, segment) by shift
     if (use_v1 || total_syms / (n_reads > 0 ? n_reads : 1) < 1024) n_seg = 1;
   }
   if (n_seg > 1) {
@@ -787,6 +788,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       hipLaunchKernelGGL(sfs_search_kernel, dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
     } else if (seg) {
       p.n_seg = n_seg;
+      p.seg_shift = __builtin_ctz((unsigned)n_seg);
       p.n_items = n_reads * n_seg;
       if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true>), dim3(blocks_for(p.n_items)), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true>), dim3(blocks_for(p.n_items)), dim3(256), 0, stream, p);
@@ -804,11 +806,8 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
         (void)hipEventSynchronize(e2);
         float t = 0.f;
         (void)hipEventElapsedTime(&t, b->ev0, e2);
-        unsigned long long st4[4] = {0, 0, 0, 0};
-        (void)hipMemcpy(st4, (unsigned long long*)b->misc.p + 4, sizeof st4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[svdss] segmented search + stitch: %.3f ms, %llu of %lld reads to redo; lane iterations %llu, "
-                "overrun SFS %llu, stops by peek %llu, by cap %llu\n", t, n_fb, (long long)n_reads, st4[0], st4[1],
-                st4[2], st4[3]);
+        fprintf(stderr, "[svdss] segmented search + stitch: %.3f ms, %llu of %lld reads to redo\n", t, n_fb,
+                (long long)n_reads);
         (void)hipEventDestroy(e2);
       }
       if (n_fb > 0) {   // reads whose chains could not be stitched: one lane per read

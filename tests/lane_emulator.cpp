@@ -159,7 +159,7 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
     const int64_t l = offsets[r + 1] - off;
     std::vector<std::pair<int32_t, int32_t>> recs;
     int64_t ext_read = 0;
-    int C = n_seg > 1 ? (int)std::min<int64_t>(n_seg, std::max<int64_t>(1, l / 256)) : 1;
+    int C = n_seg > 1 ? (int)std::min<int64_t>(n_seg, std::max<int64_t>(1, l >> 8)) : 1;
     bool stitched = false;
     if (C > 1) {
       // segmented: raw chains per segment, stitch, then (optionally) the streaming assembler
@@ -167,8 +167,9 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
       std::vector<SvSegInfo> info((size_t)C);
       std::vector<int32_t> seg_lo((size_t)C), tlo((size_t)C), thi((size_t)C);
       for (int j = 0; j < C; ++j) {
-        seg_lo[(size_t)j] = (int32_t)(l * j / C);
-        const int start = (int)(l * (j + 1) / C - 1);
+        const int32_t sl = (int32_t)(l / C);
+        seg_lo[(size_t)j] = j * sl;
+        const int start = j == C - 1 ? (int)l - 1 : (j + 1) * sl - 1;
         int32_t et; bool comp;
         run_lane(off, l, start, seg_lo[(size_t)j], false, seg[(size_t)j], et, comp,
                  j > 0 ? &seg[(size_t)(j - 1)] : nullptr);
