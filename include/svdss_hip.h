@@ -143,6 +143,26 @@ double svdss_aln_batch_kernel_ms(const svdss_aln_batch_t* b);
 int svdss_aln_batch_fetch(const svdss_aln_batch_t* b, int32_t* scores, int64_t* n_cigar, uint32_t* cigar);
 void svdss_aln_batch_free(svdss_aln_batch_t* b);
 
+/* ---- a14: partial-order-alignment consensus --------------------------------
+ * Replaces Caller::run_poa's abpoa_msa + consensus read-out (caller.cpp:257-308; abPOA
+ * v1.5.3: global, convex gap 4/2/24/1, match 2, mismatch 4, no seeding, input order, one
+ * heaviest-bundle consensus) for a batch of sub-clusters.  abPOA's source is not available;
+ * the algorithm is specified in oracle/svdss_oracle_poa.c (tolerance vs abPOA: DESIGN.md).
+ * seqs: symbols 0..4 (caller.hpp:25-37) of all reads concatenated, seq_off[n_seqs+1];
+ * cluster c owns reads cluster_off[c] .. cluster_off[c+1]-1, aligned in that order.
+ * Result per cluster: consensus symbols 0..4 ("ACGTN"[b], caller.cpp:297); empty for a
+ * cluster without reads. */
+typedef struct svdss_poa_batch svdss_poa_batch_t;
+
+int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq_off, const int64_t* cluster_off,
+                              int64_t n_clusters, int32_t device, svdss_poa_batch_t** out);
+int64_t svdss_poa_batch_nclusters(const svdss_poa_batch_t* b);
+int64_t svdss_poa_batch_total(const svdss_poa_batch_t* b);     /* sum of consensus lengths */
+int64_t svdss_poa_batch_cells(const svdss_poa_batch_t* b);     /* DP cells computed */
+double svdss_poa_batch_kernel_ms(const svdss_poa_batch_t* b);
+int svdss_poa_batch_fetch(const svdss_poa_batch_t* b, int64_t* cons_len, uint8_t* cons);
+void svdss_poa_batch_free(svdss_poa_batch_t* b);
+
 /* ---- a17: rapidfuzz::fuzz::ratio(a, b) (rapidfuzz-cpp v1.10.4) -----------
  * as called at caller.cpp:456,458 on the REF/ALT alleles of adjacent SVs:
  * 100 * (1 - (|a|+|b| - 2 LCS(a,b)) / (|a|+|b|)), 100 for two empty strings.

@@ -434,3 +434,30 @@ def split_cluster(cluster: Cluster, useht=True, min_ratio=0.97):
                 news[i].cov2 = -1
             out.append(news[i])
     return out
+
+
+def run_poa(clusters: Sequence[Sequence], device: int = 0):
+    """Caller::run_poa (caller.cpp:257-308) for a batch of sub-clusters: clusters[c] = list of reads
+    (str/bytes, or uint8 arrays already in 0..4 code) in BAM iteration order.  Returns
+    ([consensus str over ACGTN per cluster], stats)."""
+    seqs = [encode26(s) for cl in clusters for s in cl]
+    flat, seq_off = pack_reads(seqs)
+    cluster_off = np.zeros(len(clusters) + 1, dtype=np.int64)
+    cluster_off[1:] = np.cumsum([len(cl) for cl in clusters])
+    h = C.c_void_p()
+    try:
+        check(lib.svdss_poa_consensus_batch(flat.ctypes.data, seq_off.ctypes.data, cluster_off.ctypes.data,
+                                            len(clusters), device, C.byref(h)), "svdss_poa_consensus_batch")
+        lens = np.zeros(len(clusters), dtype=np.int64)
+        cons = np.zeros(lib.svdss_poa_batch_total(h), dtype=np.uint8)
+        check(lib.svdss_poa_batch_fetch(h, lens.ctypes.data, cons.ctypes.data), "svdss_poa_batch_fetch")
+        stats = {"cells": lib.svdss_poa_batch_cells(h), "kernel_ms": lib.svdss_poa_batch_kernel_ms(h)}
+    finally:
+        if h:
+            lib.svdss_poa_batch_free(h)
+    out, o = [], 0
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for l in lens.tolist():
+        out.append(bytes(letters[cons[o:o + l]]).decode())   # caller.cpp:297
+        o += l
+    return out, stats

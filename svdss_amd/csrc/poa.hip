@@ -1,0 +1,545 @@
+// poa.hip -- gfx950 kernel + C-ABI for the partial-order-alignment consensus of `SVDSS call`.
+//
+// Replaces Caller::run_poa's abpoa_msa + consensus (/root/reference/caller.cpp:257-308, abPOA
+// v1.5.3) for a batch of sub-clusters.  abPOA itself is not available (git-fetched), so the
+// algorithm is the published one (POA with adaptive band, convex gap, heaviest-bundle consensus)
+// under the deterministic specification written out in oracle/svdss_oracle_poa.c, which this
+// kernel must reproduce bit for bit.
+//
+// Mapping: one wavefront per sub-cluster.  The reads of a cluster are aligned to the growing
+// graph one after the other (inherently sequential); inside one alignment the rows (graph nodes
+// in topological order) depend on their predecessors, but the columns of a row -- the band of
+// ~2w+1 read positions -- are independent once the horizontal-gap state F is written as a
+// prefix maximum, F(j) = max_{k<j}(H'(k) + k e) - o - j e, which is a wave-level scan.  So the 64
+// lanes sweep the band; graph bookkeeping (topological sort, traceback, graph update, heaviest
+// bundle) runs on lane 0.  Banded DP matrices, the graph and the traceback live in HBM.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/svdss_hip.h"
+
+extern thread_local std::string g_svdss_hip_err;
+
+#define HIPCHK3(expr)                                                             \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      g_svdss_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);        \
+      return (e_ == hipErrorOutOfMemory) ? SVDSS_ENOMEM : SVDSS_EHIP;             \
+    }                                                                             \
+  } while (0)
+
+#define PNEG (-0x20000000)
+#define P_O1 4
+#define P_E1 2
+#define P_O2 24
+#define P_E2 1
+#define P_MATCH 2
+#define P_MISMATCH 4
+
+struct PoaTask {
+  int64_t seq_first, n_seqs;   // reads of this cluster: seq_off[seq_first .. seq_first+n_seqs]
+  int32_t cap_nodes, cap_edges, max_len;
+  int64_t pool_cap;            // int32 cells per DP array
+  // workspace offsets (elements of the respective typed pools)
+  int64_t node_off;            // per-node int32 arrays (stride cap_nodes): out_head,out_tail,in_head,in_tail,order,index,deg,best,row_beg,row_end,mpl,mpr + aln[5]
+  int64_t edge_off;            // per-edge int32 arrays (stride cap_edges): from,to,w,next_out,next_in
+  int64_t dp_off;              // 6 arrays of pool_cap int32
+  int64_t op_off;              // 2 arrays of (cap_nodes + max_len + 4) int32
+  int64_t row_off64;           // per-node int64: row offset into the DP arrays; then score[cap_nodes]
+  int64_t base_off;            // per-node uint8 base
+  int64_t cons_off;            // output consensus (uint8), capacity cap_nodes
+};
+
+struct PoaGraph {
+  int n_nodes, n_edges, cap_nodes, cap_edges;
+  uint8_t* base;
+  int *out_head, *out_tail, *in_head, *in_tail, *order, *index, *deg, *best, *row_beg, *row_end, *mpl, *mpr, *aln;
+  int *e_from, *e_to, *e_w, *e_next_out, *e_next_in;
+  int64_t *row_off, *score;
+};
+
+__device__ __forceinline__ int p_score(int a, int b) { return (a >= 4 || b >= 4) ? 0 : (a == b ? P_MATCH : -P_MISMATCH); }
+
+__device__ int g_new_node(PoaGraph& g, int base) {
+  const int v = g.n_nodes++;
+  g.base[v] = (uint8_t)base;
+  g.out_head[v] = g.out_tail[v] = g.in_head[v] = g.in_tail[v] = -1;
+  for (int b = 0; b < 5; ++b) g.aln[5 * v + b] = -1;
+  return v;
+}
+
+__device__ void g_add_edge(PoaGraph& g, int u, int v) {
+  for (int e = g.out_head[u]; e >= 0; e = g.e_next_out[e])
+    if (g.e_to[e] == v) { g.e_w[e]++; return; }
+  const int e = g.n_edges++;
+  g.e_from[e] = u; g.e_to[e] = v; g.e_w[e] = 1;
+  g.e_next_out[e] = -1; g.e_next_in[e] = -1;
+  if (g.out_tail[u] < 0) g.out_head[u] = e; else g.e_next_out[g.out_tail[u]] = e;
+  g.out_tail[u] = e;
+  if (g.in_tail[v] < 0) g.in_head[v] = e; else g.e_next_in[g.in_tail[v]] = e;
+  g.in_tail[v] = e;
+}
+
+__device__ void g_toposort(PoaGraph& g) {   // lane 0
+  for (int v = 0; v < g.n_nodes; ++v) g.deg[v] = 0;
+  for (int e = 0; e < g.n_edges; ++e) g.deg[g.e_to[e]]++;
+  int qh = 0, qt = 0;
+  g.order[qt++] = 0;
+  while (qh < qt) {
+    const int u = g.order[qh];
+    g.index[u] = qh++;
+    for (int e = g.out_head[u]; e >= 0; e = g.e_next_out[e])
+      if (--g.deg[g.e_to[e]] == 0) g.order[qt++] = g.e_to[e];
+  }
+}
+
+struct PoaDp { int32_t *H, *Hp, *E1, *E2, *F1, *F2; };
+
+__device__ __forceinline__ int32_t dp_at(const int32_t* arr, const PoaGraph& g, int r, int j) {
+  return (j < g.row_beg[r] || j > g.row_end[r]) ? PNEG : arr[g.row_off[r] + (j - g.row_beg[r])];
+}
+
+// wave-wide inclusive prefix maximum over the 64 lanes
+__device__ __forceinline__ int32_t wave_scan_max(int32_t x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int32_t y = __shfl_up(x, d, 64);
+    if (lane >= d && y > x) x = y;
+  }
+  return x;
+}
+
+// Forward DP of one read against the graph (all 64 lanes).  Returns false if the DP arrays would
+// overflow pool_cap.  *cells accumulates the number of DP cells.
+__device__ bool poa_forward(PoaGraph& g, const PoaDp& dp, const uint8_t* q, int L, int w, int64_t pool_cap,
+                            unsigned long long& cells) {
+  const int lane = threadIdx.x & 63;
+  const int n = g.n_nodes;
+  int64_t used = 0;
+  for (int r = 0; r < n; ++r) {
+    const int v = g.order[r];
+    if (v == 1) {
+      if (lane == 0) { g.row_beg[r] = 0; g.row_end[r] = -1; g.row_off[r] = used; g.mpl[r] = 0; g.mpr[r] = 0; }
+      __syncthreads();
+      continue;
+    }
+    int beg, end;
+    if (r == 0) { beg = 0; end = w < L ? w : L; }
+    else {
+      int lo = 1 << 30, hi = -1;
+      for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
+        const int ur = g.index[g.e_from[e]];
+        const int a = g.mpl[ur], b = g.mpr[ur];
+        if (a < lo) lo = a;
+        if (b > hi) hi = b;
+      }
+      beg = lo + 1 - w; if (beg < 0) beg = 0;
+      end = hi + 1 + w; if (end > L) end = L;
+      if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
+    }
+    const int width = end - beg + 1;
+    if (used + width > pool_cap) return false;   // uniform across lanes
+    if (lane == 0) { g.row_beg[r] = beg; g.row_end[r] = end; g.row_off[r] = used; }
+    const int64_t off = used;
+    used += width;
+    int32_t best = PNEG; int mpl = beg, mpr = beg;
+    int32_t g1 = PNEG, g2 = PNEG;   // running prefix maxima of H'(k) + k e over finished chunks
+    for (int j0 = beg; j0 <= end; j0 += 64) {
+      const int j = j0 + lane;
+      const bool in = j <= end;
+      int32_t m = PNEG, e1 = PNEG, e2 = PNEG;
+      if (in) {
+        if (r == 0) m = (j == 0) ? 0 : PNEG;
+        else {
+          const int bv = g.base[v];
+          for (int e = g.in_head[v]; e >= 0; e = g.e_next_in[e]) {
+            const int ur = g.index[g.e_from[e]];
+            if (j >= 1) {
+              const int32_t h = dp_at(dp.H, g, ur, j - 1);
+              if (h > PNEG / 2) { const int32_t x = h + p_score(bv, q[j - 1]); if (x > m) m = x; }
+            }
+            const int32_t h = dp_at(dp.H, g, ur, j);
+            {
+              const int32_t x = dp_at(dp.E1, g, ur, j);
+              const int32_t a = h > PNEG / 2 ? h - P_O1 : PNEG, b = x > PNEG / 2 ? x : PNEG;
+              int32_t c = a > b ? a : b;
+              if (c > PNEG / 2) { c -= P_E1; if (c > e1) e1 = c; }
+            }
+            {
+              const int32_t x = dp_at(dp.E2, g, ur, j);
+              const int32_t a = h > PNEG / 2 ? h - P_O2 : PNEG, b = x > PNEG / 2 ? x : PNEG;
+              int32_t c = a > b ? a : b;
+              if (c > PNEG / 2) { c -= P_E2; if (c > e2) e2 = c; }
+            }
+          }
+        }
+      }
+      int32_t hp = m; if (e1 > hp) hp = e1; if (e2 > hp) hp = e2;
+      // F(j) = max_{k<j}(H'(k) + k e) - o - j e: exclusive prefix max = scan of the left neighbour
+      const int32_t t1 = (in && hp > PNEG / 2) ? hp + j * P_E1 : PNEG;
+      const int32_t t2 = (in && hp > PNEG / 2) ? hp + j * P_E2 : PNEG;
+      const int32_t s1 = wave_scan_max(t1, lane), s2 = wave_scan_max(t2, lane);
+      int32_t x1 = __shfl_up(s1, 1, 64), x2 = __shfl_up(s2, 1, 64);
+      if (lane == 0) { x1 = PNEG; x2 = PNEG; }
+      if (g1 > x1) x1 = g1;
+      if (g2 > x2) x2 = g2;
+      const int32_t f1 = x1 > PNEG / 2 ? x1 - P_O1 - j * P_E1 : PNEG;
+      const int32_t f2 = x2 > PNEG / 2 ? x2 - P_O2 - j * P_E2 : PNEG;
+      int32_t h = hp; if (f1 > h) h = f1; if (f2 > h) h = f2;
+      if (in) {
+        const int64_t o = off + (j - beg);
+        dp.Hp[o] = hp; dp.E1[o] = e1; dp.E2[o] = e2; dp.F1[o] = f1; dp.F2[o] = f2; dp.H[o] = h;
+      }
+      // carry the chunk's maxima
+      const int32_t c1 = __shfl(s1, 63, 64), c2 = __shfl(s2, 63, 64);
+      if (c1 > g1) g1 = c1;
+      if (c2 > g2) g2 = c2;
+      // row maximum with its leftmost / rightmost column
+      int32_t hm = in ? h : PNEG;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { const int32_t y = __shfl_xor(hm, d, 64); if (y > hm) hm = y; }
+      const unsigned long long eq = __ballot(in && h == hm);
+      if (eq) {
+        const int l = j0 + __builtin_ctzll(eq), rr = j0 + 63 - __builtin_clzll(eq);
+        if (hm > best) { best = hm; mpl = l; mpr = rr; }
+        else if (hm == best) mpr = rr;
+      }
+    }
+    if (lane == 0) { g.mpl[r] = mpl; g.mpr[r] = mpr; }
+    cells += (unsigned long long)width;
+    __syncthreads();   // the row (and its geometry) is visible to every lane before its successors
+  }
+  return true;
+}
+
+// Traceback (lane 0): ops from the sink backwards, (node or -1, qpos or -1).  -1: sink unreachable.
+__device__ int poa_traceback(const PoaGraph& g, const PoaDp& dp, const uint8_t* q, int L, int* op_node, int* op_q) {
+  int bu = -1; int32_t bs = PNEG;
+  for (int e = g.in_head[1]; e >= 0; e = g.e_next_in[e]) {
+    const int32_t h = dp_at(dp.H, g, g.index[g.e_from[e]], L);
+    if (h > bs) { bs = h; bu = g.e_from[e]; }
+  }
+  if (bu < 0 || bs <= PNEG / 2) return -1;
+  int nops = 0, v = bu, j = L, state = 0;   // 0 H, 1 E1, 2 E2, 3 F1, 4 F2, 5 H' (no F)
+  while (v != 0 || j > 0) {
+    const int r = g.index[v];
+    if (v == 0) { op_node[nops] = -1; op_q[nops] = j - 1; ++nops; --j; continue; }
+    if (state == 0 || state == 5) {
+      const int32_t h = state == 0 ? dp_at(dp.H, g, r, j) : dp_at(dp.Hp, g, r, j);
+      bool moved = false;
+      if (j >= 1) {
+        for (int e = g.in_head[v]; e >= 0 && !moved; e = g.e_next_in[e]) {
+          const int u = g.e_from[e];
+          const int32_t x = dp_at(dp.H, g, g.index[u], j - 1);
+          if (x > PNEG / 2 && x + p_score(g.base[v], q[j - 1]) == h) {
+            op_node[nops] = v; op_q[nops] = j - 1; ++nops; v = u; --j; state = 0; moved = true;
+          }
+        }
+      }
+      if (moved) continue;
+      if (dp_at(dp.E1, g, r, j) == h) { state = 1; continue; }
+      if (dp_at(dp.E2, g, r, j) == h) { state = 2; continue; }
+      if (state == 0 && dp_at(dp.F1, g, r, j) == h) { state = 3; continue; }
+      if (state == 0 && dp_at(dp.F2, g, r, j) == h) { state = 4; continue; }
+      return -1;
+    } else if (state == 1 || state == 2) {
+      const int32_t* E = state == 1 ? dp.E1 : dp.E2;
+      const int o = state == 1 ? P_O1 : P_O2, ee = state == 1 ? P_E1 : P_E2;
+      const int32_t x = dp_at(E, g, r, j);
+      bool moved = false;
+      for (int e = g.in_head[v]; e >= 0 && !moved; e = g.e_next_in[e]) {
+        const int u = g.e_from[e];
+        const int32_t h = dp_at(dp.H, g, g.index[u], j);
+        if (h > PNEG / 2 && h - o - ee == x) { op_node[nops] = v; op_q[nops] = -1; ++nops; v = u; state = 0; moved = true; }
+      }
+      for (int e = g.in_head[v]; e >= 0 && !moved; e = g.e_next_in[e]) {
+        const int u = g.e_from[e];
+        const int32_t y = dp_at(E, g, g.index[u], j);
+        if (y > PNEG / 2 && y - ee == x) { op_node[nops] = v; op_q[nops] = -1; ++nops; v = u; moved = true; }
+      }
+      if (!moved) return -1;
+    } else {
+      const int32_t* F = state == 3 ? dp.F1 : dp.F2;
+      const int o = state == 3 ? P_O1 : P_O2, ee = state == 3 ? P_E1 : P_E2;
+      const int32_t x = dp_at(F, g, r, j);
+      op_node[nops] = -1; op_q[nops] = j - 1; ++nops;
+      const int32_t hp = dp_at(dp.Hp, g, r, j - 1);
+      if (hp > PNEG / 2 && hp - o - ee == x) state = 5;
+      --j;
+    }
+  }
+  return nops;
+}
+
+// status per cluster: 0 ok, 1 workspace too small (host retries with a larger DP pool)
+__global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaTask* tasks, const uint8_t* seqs, const int64_t* seq_off,
+                                                          int32_t* ws32, int64_t* ws64, uint8_t* ws8,
+                                                          int32_t* cons_len, int32_t* status, unsigned long long* cells) {
+  const PoaTask T = tasks[blockIdx.x];
+  const int lane = threadIdx.x;
+  __shared__ int sh_flag;
+  PoaGraph g;
+  g.cap_nodes = T.cap_nodes; g.cap_edges = T.cap_edges; g.n_nodes = 0; g.n_edges = 0;
+  int32_t* nb = ws32 + T.node_off;
+  const int64_t cn = T.cap_nodes, ce = T.cap_edges;
+  g.out_head = nb; g.out_tail = nb + cn; g.in_head = nb + 2 * cn; g.in_tail = nb + 3 * cn;
+  g.order = nb + 4 * cn; g.index = nb + 5 * cn; g.deg = nb + 6 * cn; g.best = nb + 7 * cn;
+  g.row_beg = nb + 8 * cn; g.row_end = nb + 9 * cn; g.mpl = nb + 10 * cn; g.mpr = nb + 11 * cn; g.aln = nb + 12 * cn;
+  int32_t* eb = ws32 + T.edge_off;
+  g.e_from = eb; g.e_to = eb + ce; g.e_w = eb + 2 * ce; g.e_next_out = eb + 3 * ce; g.e_next_in = eb + 4 * ce;
+  g.row_off = ws64 + T.row_off64; g.score = ws64 + T.row_off64 + cn;
+  g.base = ws8 + T.base_off;
+  PoaDp dp;
+  int32_t* db = ws32 + T.dp_off;
+  dp.H = db; dp.Hp = db + T.pool_cap; dp.E1 = db + 2 * T.pool_cap; dp.E2 = db + 3 * T.pool_cap;
+  dp.F1 = db + 4 * T.pool_cap; dp.F2 = db + 5 * T.pool_cap;
+  int* op_node = ws32 + T.op_off;
+  int* op_q = op_node + (T.cap_nodes + T.max_len + 4);
+  uint8_t* cons = ws8 + T.cons_off;
+  const int n = (int)T.n_seqs;
+  if (n <= 0) { if (lane == 0) { cons_len[blockIdx.x] = 0; status[blockIdx.x] = 0; } return; }
+  // all lanes track n_nodes / n_edges (they are needed for uniform control flow): lane 0 mutates
+  // the graph in memory, then broadcasts the counters through LDS
+  __shared__ int sh_nodes, sh_edges;
+  unsigned long long my_cells = 0;
+  if (lane == 0) {
+    g_new_node(g, 4); g_new_node(g, 4);
+    const uint8_t* q = seqs + seq_off[T.seq_first];
+    const int L = (int)(seq_off[T.seq_first + 1] - seq_off[T.seq_first]);
+    int last = 0;
+    for (int j = 0; j < L; ++j) { const int v = g_new_node(g, q[j]); g.aln[5 * v + q[j]] = v; g_add_edge(g, last, v); last = v; }
+    g_add_edge(g, last, 1);
+    sh_nodes = g.n_nodes; sh_edges = g.n_edges;
+  }
+  __syncthreads();
+  g.n_nodes = sh_nodes; g.n_edges = sh_edges;
+  for (int i = 1; i < n; ++i) {
+    const uint8_t* q = seqs + seq_off[T.seq_first + i];
+    const int L = (int)(seq_off[T.seq_first + i + 1] - seq_off[T.seq_first + i]);
+    if (lane == 0) g_toposort(g);
+    __syncthreads();
+    int w = 10 + (int)(0.01 * L);
+    int nops = -1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      const bool fit = poa_forward(g, dp, q, L, w, T.pool_cap, my_cells);
+      if (!fit) { if (lane == 0) status[blockIdx.x] = 1; return; }
+      if (lane == 0) sh_flag = poa_traceback(g, dp, q, L, op_node, op_q);
+      __syncthreads();
+      nops = sh_flag;
+      __syncthreads();
+      if (nops >= 0) break;
+      w = L;   // the band lost the sink: full matrix
+    }
+    if (nops < 0) { if (lane == 0) status[blockIdx.x] = 2; return; }
+    if (lane == 0) {
+      int last = 0;
+      for (int k = nops - 1; k >= 0; --k) {
+        const int v = op_node[k], j = op_q[k];
+        if (v >= 0 && j >= 0) {
+          int use;
+          if (g.base[v] == q[j]) use = v;
+          else if (g.aln[5 * v + q[j]] >= 0) use = g.aln[5 * v + q[j]];
+          else {
+            use = g_new_node(g, q[j]);
+            for (int b = 0; b < 5; ++b) {
+              const int sib = g.aln[5 * v + b];
+              g.aln[5 * use + b] = sib;
+              if (sib >= 0) g.aln[5 * sib + q[j]] = use;
+            }
+            g.aln[5 * use + q[j]] = use;
+          }
+          g_add_edge(g, last, use); last = use;
+        } else if (v < 0) {
+          const int use = g_new_node(g, q[j]);
+          g.aln[5 * use + q[j]] = use;
+          g_add_edge(g, last, use); last = use;
+        }
+      }
+      g_add_edge(g, last, 1);
+      sh_nodes = g.n_nodes; sh_edges = g.n_edges;
+    }
+    __syncthreads();
+    g.n_nodes = sh_nodes; g.n_edges = sh_edges;
+  }
+  if (lane == 0) {
+    g_toposort(g);
+    for (int r = g.n_nodes - 1; r >= 0; --r) {
+      const int v = g.order[r];
+      int bst = -1, bw = -1; int64_t bsc = -1;
+      for (int e = g.out_head[v]; e >= 0; e = g.e_next_out[e]) {
+        const int x = g.e_to[e];
+        if (g.e_w[e] > bw || (g.e_w[e] == bw && g.score[x] > bsc)) { bw = g.e_w[e]; bsc = g.score[x]; bst = x; }
+      }
+      g.best[v] = bst;
+      g.score[v] = bst >= 0 ? bw + bsc : 0;
+    }
+    int len = 0;
+    for (int v = g.best[0]; v >= 0 && v != 1; v = g.best[v]) cons[len++] = g.base[v];
+    cons_len[blockIdx.x] = len;
+    status[blockIdx.x] = 0;
+    atomicAdd(cells, my_cells);
+  }
+}
+
+// ------------------------------------------------------------------- ABI
+
+struct svdss_poa_batch {
+  int64_t n_clusters = 0;
+  int64_t cells = 0;
+  double kernel_ms = 0.0;
+  std::vector<int64_t> cons_len;
+  std::vector<uint8_t> cons;   // concatenated, symbols 0..4
+};
+
+namespace {
+struct DevMem3 {
+  void* p = nullptr;
+  ~DevMem3() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { HIPCHK3(hipMalloc(&p, bytes ? bytes : 16)); return SVDSS_OK; }
+};
+}  // namespace
+
+extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq_off, const int64_t* cluster_off,
+                                         int64_t n_clusters, int32_t device, svdss_poa_batch_t** out) {
+  if (!out || n_clusters < 0 || device < 0) return SVDSS_EINVAL;
+  if (n_clusters > 0 && (!seq_off || !cluster_off)) return SVDSS_EINVAL;
+  HIPCHK3(hipSetDevice(device));
+  svdss_poa_batch* b = *out ? *out : new (std::nothrow) svdss_poa_batch();
+  if (!b) return SVDSS_ENOMEM;
+  *out = b;
+  b->n_clusters = n_clusters;
+  b->cells = 0;
+  b->kernel_ms = 0.0;
+  b->cons_len.assign((size_t)n_clusters, 0);
+  b->cons.clear();
+  if (n_clusters == 0) return SVDSS_OK;
+  const int64_t n_seqs_total = cluster_off[n_clusters];
+  const int64_t total_syms = seq_off[n_seqs_total];
+  for (int64_t i = 0; i < n_seqs_total; ++i) {
+    const int64_t l = seq_off[i + 1] - seq_off[i];
+    if (l < 0) return SVDSS_EINVAL;
+    if (l >= (1 << 24)) return SVDSS_ERANGE;
+  }
+  if (total_syms > 0 && !seqs) return SVDSS_EINVAL;
+  DevMem3 d_seqs, d_off, d_cells;
+  int rc;
+  if ((rc = d_seqs.alloc((size_t)total_syms)) || (rc = d_off.alloc(sizeof(int64_t) * (size_t)(n_seqs_total + 1))) ||
+      (rc = d_cells.alloc(8)))
+    return rc;
+  if (total_syms) HIPCHK3(hipMemcpy(d_seqs.p, seqs, (size_t)total_syms, hipMemcpyHostToDevice));
+  HIPCHK3(hipMemcpy(d_off.p, seq_off, sizeof(int64_t) * (size_t)(n_seqs_total + 1), hipMemcpyHostToDevice));
+  HIPCHK3(hipMemset(d_cells.p, 0, 8));
+  hipEvent_t ev0, ev1;
+  HIPCHK3(hipEventCreate(&ev0));
+  HIPCHK3(hipEventCreate(&ev1));
+  std::vector<std::vector<uint8_t>> results((size_t)n_clusters);
+  // pass 0: banded workspace for every cluster; pass 1: clusters whose full-matrix fallback did
+  // not fit get a full-size DP pool, a few at a time
+  std::vector<int64_t> todo((size_t)n_clusters);
+  for (int64_t c = 0; c < n_clusters; ++c) todo[(size_t)c] = c;
+  for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
+    std::vector<int64_t> next;
+    size_t pos = 0;
+    while (pos < todo.size()) {
+      std::vector<PoaTask> tasks;
+      std::vector<int64_t> ids;
+      int64_t w32 = 0, w64 = 0, w8 = 0;
+      const int64_t budget32 = (int64_t)3 << 30;   // 12 GiB of int32 workspace per launch
+      while (pos < todo.size()) {
+        const int64_t c = todo[pos];
+        PoaTask t;
+        memset(&t, 0, sizeof t);
+        t.seq_first = cluster_off[c];
+        t.n_seqs = cluster_off[c + 1] - cluster_off[c];
+        int64_t tot = 0, maxl = 0;
+        for (int64_t s = t.seq_first; s < t.seq_first + t.n_seqs; ++s) {
+          const int64_t l = seq_off[s + 1] - seq_off[s];
+          tot += l;
+          if (l > maxl) maxl = l;
+        }
+        t.cap_nodes = (int32_t)(tot + 2);
+        t.cap_edges = (int32_t)(tot + t.n_seqs + 2);
+        t.max_len = (int32_t)maxl;
+        const int64_t wband = 2 * (10 + (int64_t)(0.01 * (double)maxl)) + 129;
+        t.pool_cap = pass == 0 ? (int64_t)t.cap_nodes * (wband < maxl + 1 ? wband : maxl + 1)
+                               : (int64_t)t.cap_nodes * (maxl + 1);
+        const int64_t need32 = 17 * (int64_t)t.cap_nodes + 5 * (int64_t)t.cap_edges + 6 * t.pool_cap +
+                               2 * ((int64_t)t.cap_nodes + maxl + 4);
+        if (!tasks.empty() && w32 + need32 > budget32) break;
+        t.node_off = w32; w32 += 17 * (int64_t)t.cap_nodes;
+        t.edge_off = w32; w32 += 5 * (int64_t)t.cap_edges;
+        t.dp_off = w32; w32 += 6 * t.pool_cap;
+        t.op_off = w32; w32 += 2 * ((int64_t)t.cap_nodes + maxl + 4);
+        t.row_off64 = w64; w64 += 2 * (int64_t)t.cap_nodes;
+        t.base_off = w8; w8 += t.cap_nodes;
+        t.cons_off = w8; w8 += t.cap_nodes;
+        tasks.push_back(t);
+        ids.push_back(c);
+        ++pos;
+      }
+      const int64_t nt = (int64_t)tasks.size();
+      DevMem3 d_tasks, d32, d64, d8, d_len, d_st;
+      if ((rc = d_tasks.alloc(sizeof(PoaTask) * (size_t)nt)) || (rc = d32.alloc(sizeof(int32_t) * (size_t)w32)) ||
+          (rc = d64.alloc(sizeof(int64_t) * (size_t)w64)) || (rc = d8.alloc((size_t)w8)) ||
+          (rc = d_len.alloc(sizeof(int32_t) * (size_t)nt)) || (rc = d_st.alloc(sizeof(int32_t) * (size_t)nt)))
+        return rc;
+      HIPCHK3(hipMemcpy(d_tasks.p, tasks.data(), sizeof(PoaTask) * (size_t)nt, hipMemcpyHostToDevice));
+      HIPCHK3(hipMemset(d_st.p, 0xff, sizeof(int32_t) * (size_t)nt));
+      HIPCHK3(hipEventRecord(ev0, 0));
+      hipLaunchKernelGGL(poa_consensus_kernel, dim3((unsigned)nt), dim3(64), 0, 0, (const PoaTask*)d_tasks.p,
+                         (const uint8_t*)d_seqs.p, (const int64_t*)d_off.p, (int32_t*)d32.p, (int64_t*)d64.p,
+                         (uint8_t*)d8.p, (int32_t*)d_len.p, (int32_t*)d_st.p, (unsigned long long*)d_cells.p);
+      HIPCHK3(hipGetLastError());
+      HIPCHK3(hipEventRecord(ev1, 0));
+      HIPCHK3(hipDeviceSynchronize());
+      float ms = 0.f;
+      HIPCHK3(hipEventElapsedTime(&ms, ev0, ev1));
+      b->kernel_ms += ms;
+      std::vector<int32_t> lens((size_t)nt), st((size_t)nt);
+      std::vector<uint8_t> h8((size_t)w8);
+      HIPCHK3(hipMemcpy(lens.data(), d_len.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+      HIPCHK3(hipMemcpy(st.data(), d_st.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+      if (w8) HIPCHK3(hipMemcpy(h8.data(), d8.p, (size_t)w8, hipMemcpyDeviceToHost));
+      for (int64_t k = 0; k < nt; ++k) {
+        if (st[(size_t)k] == 0) {
+          const uint8_t* src = h8.data() + tasks[(size_t)k].cons_off;
+          results[(size_t)ids[(size_t)k]].assign(src, src + lens[(size_t)k]);
+        } else if (st[(size_t)k] == 1 && pass == 0) {
+          next.push_back(ids[(size_t)k]);
+        } else {
+          (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+          return SVDSS_ERANGE;   // internal inconsistency
+        }
+      }
+    }
+    todo.swap(next);
+  }
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  unsigned long long cells = 0;
+  HIPCHK3(hipMemcpy(&cells, d_cells.p, 8, hipMemcpyDeviceToHost));
+  b->cells = (int64_t)cells;
+  for (int64_t c = 0; c < n_clusters; ++c) {
+    b->cons_len[(size_t)c] = (int64_t)results[(size_t)c].size();
+    b->cons.insert(b->cons.end(), results[(size_t)c].begin(), results[(size_t)c].end());
+  }
+  return SVDSS_OK;
+}
+
+extern "C" int64_t svdss_poa_batch_nclusters(const svdss_poa_batch_t* b) { return b ? b->n_clusters : -1; }
+extern "C" int64_t svdss_poa_batch_total(const svdss_poa_batch_t* b) { return b ? (int64_t)b->cons.size() : -1; }
+extern "C" int64_t svdss_poa_batch_cells(const svdss_poa_batch_t* b) { return b ? b->cells : -1; }
+extern "C" double svdss_poa_batch_kernel_ms(const svdss_poa_batch_t* b) { return b ? b->kernel_ms : -1.0; }
+extern "C" int svdss_poa_batch_fetch(const svdss_poa_batch_t* b, int64_t* cons_len, uint8_t* cons) {
+  if (!b) return SVDSS_EINVAL;
+  if (cons_len) memcpy(cons_len, b->cons_len.data(), sizeof(int64_t) * b->cons_len.size());
+  if (cons) memcpy(cons, b->cons.data(), b->cons.size());
+  return SVDSS_OK;
+}
+extern "C" void svdss_poa_batch_free(svdss_poa_batch_t* b) { delete b; }

@@ -228,3 +228,21 @@ def fuzz_ratio(a: bytes, b: bytes) -> float:
     a = np.frombuffer(a, dtype=np.uint8)
     b = np.frombuffer(b, dtype=np.uint8)
     return _lib.orc_fuzz_ratio(a.ctypes.data, len(a), b.ctypes.data, len(b))
+
+
+# ---- POA consensus (oracle/svdss_oracle_poa.c) ------------------------------
+_lib.orc_poa_consensus.restype = _i64
+_lib.orc_poa_consensus.argtypes = [_p, _p, C.c_int, _p, _i64]
+
+
+def poa_consensus(seqs) -> np.ndarray:
+    """seqs: list of uint8 arrays over 0..4 (ACGTN).  Returns the consensus symbols."""
+    n = len(seqs)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    flat = np.ascontiguousarray(np.concatenate(seqs) if n and offs[-1] else np.zeros(0, np.uint8), dtype=np.uint8)
+    cap = int(offs[-1]) + 8
+    out = np.zeros(cap, dtype=np.uint8)
+    m = _lib.orc_poa_consensus(flat.ctypes.data, offs.ctypes.data, n, out.ctypes.data, cap)
+    assert m >= 0
+    return out[:m].copy()

@@ -1,0 +1,61 @@
+"""POA consensus kernel against its specification (oracle/svdss_oracle_poa.c): bit-exact consensus,
+plus the invariants and the stated tolerance vs the truth at SURVEY 2.3 K3 sizes."""
+import numpy as np
+import pytest
+
+from svdss_amd import caller
+from tests import oracle_lib as O
+from tests.test_oracle_poa import edit_distance, mutate
+
+pytestmark = pytest.mark.gpu
+LET = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+def _to_str(a):
+    return bytes(LET[a]).decode()
+
+
+def test_clusters_match_oracle_bit_exact():
+    rng = np.random.default_rng(11)
+    clusters = []
+    for k in range(60):
+        length = int(rng.integers(150, 1200))
+        t = rng.integers(0, 4, size=length).astype(np.uint8)
+        if k % 6 == 0:                                    # a haplotype-specific indel in part of the reads
+            alt = np.concatenate([t[:length // 2], rng.integers(0, 4, size=int(rng.integers(30, 200))).astype(np.uint8),
+                                  t[length // 2:]])
+        else:
+            alt = t
+        n = int(rng.integers(2, 30))
+        reads = [mutate(rng, alt if (i % 3 == 0) else t, float(rng.choice([0.005, 0.02, 0.05]))) for i in range(n)]
+        if k % 10 == 3:
+            reads[1][5] = 4                               # an N
+        clusters.append(reads)
+    clusters += [[], [np.array([0, 1, 2, 3], np.uint8)], [np.zeros(0, np.uint8), np.array([1, 1], np.uint8)]]
+    got, stats = caller.run_poa(clusters)
+    for reads, g in zip(clusters, got):
+        assert g == _to_str(O.poa_consensus(reads))
+    assert stats["cells"] > 0 and stats["kernel_ms"] > 0
+
+
+def test_invariants_and_tolerance():
+    rng = np.random.default_rng(12)
+    t = rng.integers(0, 4, size=3000).astype(np.uint8)
+    b = t.copy(); b[1500] = (b[1500] + 1) % 4
+    ins = np.concatenate([t[:1000], rng.integers(0, 4, size=300).astype(np.uint8), t[1000:]])
+    dl = np.concatenate([t[:1200], t[1700:]])            # 500-bp deletion: band must be abandoned / followed
+    noisy = [mutate(rng, t, 0.01) for _ in range(20)]
+    got, _ = caller.run_poa([[t, t, t], [t, b, b], [t, ins, ins, ins, t], [t, dl, dl], noisy, [t]])
+    assert got[0] == _to_str(t) and got[1] == _to_str(b) and got[2] == _to_str(ins) and got[3] == _to_str(dl)
+    assert edit_distance(list(got[4].encode()), list(_to_str(t).encode())) <= max(2, int(0.005 * 3000))
+    assert got[5] == _to_str(t)
+
+
+def test_strings_and_large_cluster():
+    rng = np.random.default_rng(13)
+    t = rng.integers(0, 4, size=6000).astype(np.uint8)
+    reads = [mutate(rng, t, 0.005) for _ in range(12)]
+    got, stats = caller.run_poa([[_to_str(r) for r in reads], ["ACGTACGTAC", "ACGTTCGTAC", "ACGTTCGTAC"]])
+    assert got[0] == _to_str(O.poa_consensus(reads))
+    assert edit_distance(list(got[0].encode()), list(_to_str(t).encode())) <= 30
+    assert got[1] == "ACGTTCGTAC"
