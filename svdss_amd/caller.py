@@ -461,3 +461,32 @@ def run_poa(clusters: Sequence[Sequence], device: int = 0):
         out.append(bytes(letters[cons[o:o + l]]).decode())   # caller.cpp:297
         o += l
     return out, stats
+
+
+def call(alignments, sfs_text: str, chromosomes: dict, contigs, ref_names, threads: int = 4,
+         min_cluster_weight: int = 2, min_sv_length: int = 25, min_mapq: int = 20, useht: bool = True,
+         min_ratio: float = 0.97, device: int = 0):
+    """Caller::run (caller.cpp:3-57) without --poa/--clipped side outputs: SFS file + alignments +
+    reference -> VCF text.  Host bookkeeping as in the reference; POA, realignment and the chain
+    filter's ratio run on the GPU in three batched calls.  Returns (vcf_text, info dict)."""
+    from .clusterer import Clusterer
+    from .pingpong import parse_sfsfile
+    sfs = parse_sfsfile(sfs_text)
+    min_sv_length = max(25, min_sv_length)                      # config.cpp:87
+    C_ = Clusterer(sfs, chromosomes, ref_names, threads=threads, min_mapq=min_mapq,
+                   min_cluster_weight=min_cluster_weight)
+    clusters = C_.run(alignments)
+    subs = []
+    for i, cluster in enumerate(clusters):
+        if cluster.size() < min_cluster_weight:                 # caller.cpp:316-317
+            continue
+        for cl in split_cluster(cluster, useht, min_ratio):
+            subs.append((i, cl, cluster))
+    consensus, poa_stats = run_poa([cl.get_seqs() for _, cl, _ in subs], device=device) if subs else ([], {})
+    entries = [dict(chrom=cl.chrom, s=cl.s, e=cl.e, consensus=cons, size=cl.size(), names=cl.get_names(),
+                    cov=(cl.cov, cl.cov0, cl.cov1, cl.cov2), rvec=parent.reads, cluster_index=i)
+               for (i, cl, parent), cons in zip(subs, consensus)]
+    vcf = call_tail(entries, chromosomes, contigs, min_sv_length, threads, min_ratio, device)
+    info = {"clusters": len(clusters), "subclusters": len(subs), "extended_sfs": len(C_.extended_SFSs),
+            "unplaced": (C_.unplaced, C_.s_unplaced, C_.e_unplaced), "poa": poa_stats}
+    return vcf, info

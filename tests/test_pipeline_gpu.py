@@ -1,0 +1,60 @@
+"""End to end on synthetic data (SURVEY 8(d) config 1 shape, scaled down): FASTA -> `SVDSS index`
+-> smoothed-style BAM -> `SVDSS search` (HIP) -> call (clusterer host logic + POA, realignment and
+ratio kernels) -> VCF.  The VCF must recover the implanted SVs and nothing else."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from svdss_amd import bamio, caller, synth
+from tests import bam_writer
+from tests.common import ROOT
+from tests.pipeline_sim import simulate
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "svdss_amd", "SVDSS")
+
+
+@pytest.mark.parametrize("het", [0.0, 0.45])
+def test_index_search_call_recovers_implanted_svs(tmp_path, het):
+    ref, svs, reads = simulate(seed=5 if het == 0.0 else 6, het_fraction=het)
+    names = ["chrA", "chrB"]
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as fh:
+        for n, c in zip(names, ref):
+            fh.write(f">{n}\n{synth.to_ascii(c)}\n")
+    fmd = tmp_path / "ref.fa.fmd"
+    r = subprocess.run([BIN, "index", "-t", "8", "-d", str(fa), "-o", str(fmd)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    recs = [bam_writer.record(n, 0, tid, pos, 60, cig, seq, [("XF", "C", 0)]) for n, tid, pos, cig, seq, hp in reads]
+    bam = tmp_path / "smoothed.bam"
+    bam.write_bytes(bam_writer.bam([(n, len(c)) for n, c in zip(names, ref)], recs))
+    r = subprocess.run([BIN, "search", "--index", str(fmd), "--bam", str(bam), "--threads", "4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sfs_text = r.stdout
+    assert len(sfs_text) > 0
+    ref_names, ref_lens, alns = bamio.read_bam(str(bam))
+    assert ref_names == names and len(alns) == len(reads)
+    chromosomes = {n: synth.to_ascii(c) for n, c in zip(names, ref)}
+    vcf, info = caller.call(alns, sfs_text, chromosomes, list(zip(names, ref_lens)), ref_names, threads=4,
+                            min_sv_length=50)
+    body = [l.split("\t") for l in vcf.splitlines() if not l.startswith("#")]
+    called = []
+    for f in body:
+        kv = dict(x.split("=", 1) for x in f[7].split(";") if "=" in x)
+        called.append((f[0], int(f[1]), kv["SVTYPE"], abs(int(kv["SVLEN"])), f))
+    truth = [(names[s.contig], s.pos, s.kind, s.length) for s in svs]
+    assert len(truth) == 8
+    for chrom, pos, kind, length in truth:
+        hits = [c for c in called if c[0] == chrom and c[2] == kind and c[3] == length and abs(c[1] - pos) <= 12]
+        assert len(hits) == 1, (chrom, pos, kind, length, [(c[0], c[1], c[2], c[3]) for c in called])
+        f = hits[0][4]
+        # REF/ALT carry the anchor base; a deletion's REF is the deleted reference sequence
+        if kind == "DEL":
+            assert len(f[3]) == length + 1 and len(f[4]) == 1 and f[3] == chromosomes[chrom][hits[0][1] - 1:hits[0][1] + length]
+        else:
+            assert len(f[4]) == length + 1 and len(f[3]) == 1 and f[3] == chromosomes[chrom][hits[0][1] - 1]
+    assert len(called) == len(truth)                      # no spurious calls
+    assert info["subclusters"] >= len(truth)
