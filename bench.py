@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: coverage*ref/read_len)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-call-dp", action="store_true", help="skip the call-side DP kernel measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -227,6 +228,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ix, d_reads, L, n_reads, args.cpu_seconds)
+        if world == 1 and not args.no_call_dp:
+            out["config"]["call_dp"] = call_dp_throughput(local_rank)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -243,6 +246,41 @@ def measured_traffic(ref_total, n_reads, L, k):
     except OSError:
         return None
     return table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}")
+
+
+def call_dp_throughput(device):
+    """Side measurement (not part of `value`): the call-stage DP kernels on synthetic sub-clusters of the
+    SURVEY 2.3 shapes -- 1024 sub-clusters x 12 reads x ~1 kb with 1% errors and one 150-bp insertion in
+    half of them: POA consensus, consensus->reference realignment (full matrix + traceback), and the
+    chain filter's ratio on the resulting alleles.  Integer DP: reported in cell updates per second."""
+    from svdss_amd import caller
+    rng = np.random.default_rng(99)
+    clusters, refs = [], []
+    for c in range(1024):
+        ln = int(rng.integers(600, 1400))
+        t = rng.integers(0, 4, size=ln).astype(np.uint8)
+        alt = np.concatenate([t[:ln // 2], rng.integers(0, 4, size=150).astype(np.uint8), t[ln // 2:]]) if c % 2 else t
+        reads = []
+        for _ in range(12):
+            r = alt.copy()
+            e = rng.random(len(r)) < 0.01
+            r[e] = rng.integers(0, 4, size=int(e.sum()), dtype=np.uint8)
+            reads.append(r)
+        clusters.append(reads)
+        refs.append(t)
+    cons, poa = caller.run_poa(clusters, device=device)
+    scores, cigars, aln = caller.ksw_extd2_global(cons, refs, device=device)
+    t0 = time.perf_counter()
+    ratio, _ = caller.fuzz_ratio(cons[:-1], cons[1:], device=device)
+    t_ratio = time.perf_counter() - t0
+    n_ins = sum(1 for cg in cigars if any((int(x) & 0xf) == 1 and (int(x) >> 4) >= 100 for x in cg))
+    return {"subclusters": len(clusters), "reads_per_subcluster": 12,
+            "poa_cells": poa["cells"], "poa_kernel_ms": round(poa["kernel_ms"], 3),
+            "poa_gcups": poa["cells"] / (poa["kernel_ms"] * 1e-3) / 1e9,
+            "realign_cells": aln["cells"], "realign_kernel_ms": round(aln["kernel_ms"], 3),
+            "realign_gcups": aln["cells"] / (aln["kernel_ms"] * 1e-3) / 1e9,
+            "ratio_pairs": len(ratio), "ratio_wall_ms": round(t_ratio * 1e3, 3),
+            "insertions_recovered": n_ins}
 
 
 def cpu_baseline(ix, d_reads, L, n_reads, target_s):
