@@ -19,6 +19,27 @@ struct BamRecord {
   std::string qname;
   std::vector<uint8_t> seq4;   // packed 4-bit bases, (l_seq+1)/2 bytes
   std::vector<uint8_t> aux;    // raw aux block
+  std::vector<uint32_t> cigar; // raw BAM cigar words (len << 4 | op)
+  std::vector<uint8_t> qual;   // l_seq bytes
+  uint16_t bin = 0;
+  int32_t mtid = -1, mpos = -1, isize = 0;
+
+  // seq_nt16_str decoding of the 4-bit bases
+  std::string seq_string() const {
+    static const char NT16[] = "=ACMGRSVTWYHKDBN";
+    std::string s((size_t)l_seq, 'N');
+    for (int i = 0; i < l_seq; ++i) s[(size_t)i] = NT16[(seq4[(size_t)i >> 1] >> ((~i & 1) << 2)) & 0xf];
+    return s;
+  }
+  // bam_endpos: position after the last reference base covered
+  int32_t endpos() const {
+    int32_t r = 0;
+    for (uint32_t c : cigar) {
+      const uint32_t op = c & 0xf;
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r += (int32_t)(c >> 4);
+    }
+    return pos + (r ? r : 1);
+  }
 };
 
 class BamReader {
@@ -74,9 +95,18 @@ class BamReader {
     }
     r.tid = refID; r.pos = pos; r.l_seq = l_seq; r.flag = flag; r.mapq = mapq;
     r.qname.assign((const char*)p + o, l_read_name ? l_read_name - 1 : 0);
-    o += l_read_name + 4u * n_cigar;
+    o += l_read_name;
+    r.cigar.resize(n_cigar);
+    if (n_cigar) memcpy(r.cigar.data(), p + o, 4u * n_cigar);
+    o += 4u * n_cigar;
+    memcpy(&r.bin, p + 10, 2);
+    memcpy(&r.mtid, p + 20, 4);
+    memcpy(&r.mpos, p + 24, 4);
+    memcpy(&r.isize, p + 28, 4);
     r.seq4.assign(p + o, p + o + (size_t)(l_seq + 1) / 2);
-    o += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+    o += (size_t)(l_seq + 1) / 2;
+    r.qual.assign(p + o, p + o + (size_t)l_seq);
+    o += (size_t)l_seq;
     r.aux.assign(p + o, p + block_size);
     return 1;
   }

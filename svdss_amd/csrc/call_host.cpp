@@ -1,0 +1,652 @@
+// call_host.cpp -- host side of `SVDSS call` (/root/reference/caller.cpp, clusterer.cpp, sv.cpp).
+//
+// Integer/interval bookkeeping restated from the reference;
+// the three DP seams go to the GPU through the C-ABI in three batched calls:
+//   svdss_poa_consensus_batch (abPOA, caller.cpp:291), svdss_align_global_batch (ksw_extd2_sse,
+//   caller.cpp:348), svdss_indel_ratio_batch (rapidfuzz::fuzz::ratio, caller.cpp:456,458).
+// Thread-count dependent orderings of the reference are replayed with T = --threads.
+// BAM access: the reference streams the BAM once (placement) and then issues one BAI region query
+// per cluster; here the second phase is a second sequential pass that hands every alignment to
+// the clusters it overlaps -- same alignments per cluster, same (file) order, no index needed.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/svdss_hip.h"
+#include "bam_reader.h"
+#include "call_host.h"
+#include "fastx_reader.h"
+
+namespace {
+
+void logmsg(const char* lvl, const std::string& m) { fprintf(stderr, "[call] [%s] %s\n", lvl, m.c_str()); }
+[[noreturn]] void die(const std::string& m) { logmsg("critical", m); exit(EXIT_FAILURE); }
+void check(int rc, const char* what) {
+  if (rc != SVDSS_OK) die(std::string(what) + ": " + svdss_strerror(rc) + " " + svdss_last_hip_error());
+}
+
+struct RawSFS { int qs, l, htag; };
+
+struct ESFS {   // SFS after placement (sfs.hpp:52-62)
+  std::string chrom, qname;
+  int rs, re, qs, qe, htag;
+  bool operator<(const ESFS& c) const { return chrom == c.chrom ? rs < c.rs : chrom < c.chrom; }  // sfs.hpp:66-73
+};
+
+struct SubRead { std::string name, seq; int htag; };
+
+struct Cluster {   // clusterer.hpp:38-139
+  std::string chrom;
+  int s = 0, e = 0, cov = 0, cov0 = 0, cov1 = 0, cov2 = 0;
+  std::vector<ESFS> sfss;
+  std::vector<std::pair<int, int>> reads;
+  std::vector<SubRead> subreads;
+  Cluster() {}
+  Cluster(const std::string& c, int s_, int e_, int cov_, int c0, int c1, int c2)
+      : chrom(c), s(s_), e(e_), cov(cov_), cov0(c0), cov1(c1), cov2(c2) {}
+  size_t size() const { return subreads.size(); }
+  int get_len() const {
+    unsigned l = 0, n = 0;
+    for (const auto& sr : subreads) { ++n; l += (unsigned)sr.seq.size(); }
+    return (int)(l / n);
+  }
+  Cluster cleared_copy() const { return Cluster(chrom, s, e, cov, cov0, cov1, cov2); }  // copy ctor drops `reads`
+};
+
+typedef std::vector<std::pair<int, int>> Pairs;
+
+// bam.cpp:92-134
+Pairs get_aligned_pairs(const BamRecord& a) {
+  Pairs res;
+  int ref_pos = a.pos, read_pos = 0;
+  for (uint32_t c : a.cigar) {
+    const int l = (int)(c >> 4), op = (int)(c & 0xf);
+    if (op == 0 || op == 7 || op == 8) {
+      for (int i = 0; i < l; ++i) res.emplace_back(read_pos + i, ref_pos + i);
+      read_pos += l; ref_pos += l;
+    } else if (op == 1 || op == 4) {
+      for (int i = 0; i < l; ++i) res.emplace_back(read_pos + i, -1);
+      read_pos += l;
+    } else if (op == 2 || op == 3) {
+      for (int i = 0; i < l; ++i) res.emplace_back(-1, ref_pos + i);
+      ref_pos += l;
+    }
+  }
+  return res;
+}
+
+// clusterer.cpp:351-405
+std::pair<int, int> get_unique_kmers(const Pairs& al, size_t k, bool from_end, const std::string& cseq) {
+  if (al.size() < k) return {-1, -1};
+  std::map<std::string, int> kmers;
+  size_t i = 0;
+  while (i < al.size() - k + 1) {
+    bool skip = false;
+    for (size_t j = i; j < i + k; ++j)
+      if (al[j].first == -1 || al[j].second == -1) { skip = true; i = j + 1; break; }
+    if (skip) continue;
+    ++kmers[cseq.substr((size_t)al[i].second, k)];
+    ++i;
+  }
+  std::pair<int, int> last(-1, -1);
+  i = 0;
+  while (i < al.size() - k + 1) {
+    size_t offset = from_end ? al.size() - k - i : i;
+    bool skip = false;
+    for (size_t j = offset; j < offset + k; ++j)
+      if (al[j].first == -1 || al[j].second == -1) { skip = true; i += (j - offset); break; }
+    if (skip) { ++i; continue; }
+    last = al[offset];
+    if (kmers[cseq.substr((size_t)al[offset].second, k)] == 1) break;
+    ++i;
+  }
+  return last;
+}
+
+struct Ctx {
+  CallOptions o;
+  std::vector<std::string> chrom_names;
+  std::unordered_map<std::string, std::string> chrom_seqs;
+  std::unordered_map<std::string, std::vector<RawSFS>> sfs;
+  long unplaced = 0, s_unplaced = 0, e_unplaced = 0, unknown = 0, unextended = 0, small = 0, small2 = 0;
+};
+
+// clusterer.cpp:159-346 (without the --clipped bookkeeping)
+void extend_alignment(Ctx& C, const BamRecord& aln, const std::string& chrom, std::vector<ESFS>& out) {
+  auto cs = C.chrom_seqs.find(chrom);
+  if (cs == C.chrom_seqs.end()) return;
+  const std::string& cseq = cs->second;
+  const Pairs al = get_aligned_pairs(aln);
+  const int k = 7, flank = 100;   // config.hpp:89-90, not settable
+  size_t last_pos = 0;
+  std::vector<ESFS> local;
+  for (const RawSFS& sfs : C.sfs.at(aln.qname)) {
+    const int s = sfs.qs, e = sfs.qs + sfs.l - 1;
+    int aln_start = -1, aln_end = -1, refs = -1, refe = -1;
+    for (size_t i = last_pos; i < al.size(); ++i) {
+      const int q = al[i].first, r = al[i].second;
+      if (q == -1 || r == -1) continue;
+      else if (q < s) { last_pos = i; refs = r; aln_start = (int)i; }
+      else if (q > e) { refe = r; aln_end = (int)i; break; }
+    }
+    if (refs == -1 && refe == -1) { ++C.unplaced; continue; }
+    else if (refs == -1) { ++C.s_unplaced; continue; }
+    else if (refe == -1) { ++C.e_unplaced; continue; }
+    Pairs loc;
+    int last_r = refs - 1;
+    for (int i = aln_start; i <= aln_end; ++i) {
+      const int q = al[(size_t)i].first, r = al[(size_t)i].second;
+      if (r == -1) { if (refs <= last_r && last_r <= refe) loc.emplace_back(q, r); }
+      else { last_r = r; if (refs <= r && r <= refe) loc.emplace_back(q, r); }
+      if (q != -1 && r != -1 && r >= refe) break;
+    }
+    Pairs pre, post;
+    for (int i = aln_start - 1; i >= 0; --i) { pre.push_back(al[(size_t)i]); if ((int)pre.size() == flank) break; }
+    std::reverse(pre.begin(), pre.end());
+    for (size_t i = (size_t)aln_end + 1; i < al.size(); ++i) { post.push_back(al[i]); if ((int)post.size() == flank) break; }
+    std::pair<int, int> prek = get_unique_kmers(pre, (size_t)k, true, cseq);
+    std::pair<int, int> postk = get_unique_kmers(post, (size_t)k, false, cseq);
+    if (prek.first == -1 || prek.second == -1) prek = loc.front();
+    if (postk.first == -1 || postk.second == -1) postk = loc.back();
+    if (prek.first == -1 || prek.second == -1 || postk.first == -1 || postk.second == -1) { ++C.unknown; continue; }
+    if ((unsigned)prek.second > (unsigned)(postk.second + k)) continue;   // warning only (:301-303)
+    local.push_back(ESFS{chrom, aln.qname, prek.second, postk.second + k, prek.first, postk.first + k, sfs.htag});
+  }
+  std::vector<ESFS> merged;   // :314-336
+  for (const ESFS& x : local) {
+    size_t j;
+    for (j = 0; j < merged.size(); ++j)
+      if ((x.rs <= merged[j].rs && merged[j].rs <= x.re) || (merged[j].rs <= x.rs && x.rs <= merged[j].re)) break;
+    if (j < merged.size()) {
+      merged[j].rs = std::min(merged[j].rs, x.rs); merged[j].re = std::max(merged[j].re, x.re);
+      merged[j].qs = std::min(merged[j].qs, x.qs); merged[j].qe = std::max(merged[j].qe, x.qe);
+    } else merged.push_back(x);
+  }
+  out.insert(out.end(), merged.begin(), merged.end());
+}
+
+bool primary_ok(const BamRecord& r, int min_mapq) {
+  if (r.flag & (4 | 2048 | 256)) return false;
+  return (int)r.mapq >= min_mapq;
+}
+
+float len_ratio(float cl, float sl) { return std::min(cl, sl) / std::max(cl, sl); }
+
+// caller.cpp:78-97
+std::vector<Cluster> split_by_len(const Cluster& c, float min_ratio) {
+  std::vector<Cluster> subs;
+  for (const SubRead& sr : c.subreads) {
+    size_t i;
+    for (i = 0; i < subs.size(); ++i)
+      if (len_ratio((float)subs[i].get_len(), (float)(unsigned)sr.seq.size()) >= min_ratio) break;
+    if (i == subs.size()) subs.push_back(c.cleared_copy());
+    subs[i].subreads.push_back(sr);
+  }
+  return subs;
+}
+
+int largest(const std::vector<Cluster>& v) {
+  unsigned vmax = 0; int imax = -1;
+  for (size_t i = 0; i < v.size(); ++i) if (v[i].size() > vmax) { vmax = (unsigned)v[i].size(); imax = (int)i; }
+  return imax;
+}
+
+// caller.cpp:100-255 (int-typed best_ratio included)
+std::vector<Cluster> split_cluster(const Cluster& cluster, bool useht, float min_ratio) {
+  Cluster c0 = cluster.cleared_copy(), c1 = cluster.cleared_copy(), c2 = cluster.cleared_copy();
+  for (const SubRead& sr : cluster.subreads) {
+    if (useht && sr.htag == 1) c1.subreads.push_back(sr);
+    else if (useht && sr.htag == 2) c2.subreads.push_back(sr);
+    else c0.subreads.push_back(sr);
+  }
+  c0.cov1 = c0.cov2 = -1; c1.cov0 = c1.cov2 = -1; c2.cov0 = c2.cov1 = -1;
+  std::vector<Cluster> out;
+  if (c1.size() == 0 && c2.size() == 0) {
+    std::vector<Cluster> subs = split_by_len(c0, min_ratio);
+    int i1 = -1, i2 = -1; unsigned v1 = 0, v2 = 0;
+    for (unsigned i = 0; i < subs.size(); ++i) {
+      if (subs[i].size() > v1) { v2 = v1; i2 = i1; v1 = (unsigned)subs[i].size(); i1 = (int)i; }
+      else if (subs[i].size() > v2) { v2 = (unsigned)subs[i].size(); i2 = (int)i; }
+    }
+    if (i1 != -1) out.push_back(subs[(size_t)i1]);
+    if (i2 != -1) out.push_back(subs[(size_t)i2]);
+    return out;
+  }
+  const int both = (c1.size() > 0 ? 1 : 0) + (c2.size() > 0 ? 2 : 0);
+  std::vector<Cluster> s1 = split_by_len(c1, min_ratio), s2 = split_by_len(c2, min_ratio);
+  Cluster nc(cluster.chrom, cluster.s, cluster.e, cluster.cov, cluster.cov0, -1, -1);
+  for (const SubRead& sr : c0.subreads) {
+    const float sl = (float)(unsigned)sr.seq.size();
+    int best_1 = -1, best_ratio_1 = -1, best_2 = -1, best_ratio_2 = -1;
+    for (unsigned i = 0; i < s1.size(); ++i) {
+      const float r = len_ratio((float)s1[i].get_len(), sl);
+      if (r >= min_ratio && r > best_ratio_1) { best_1 = (int)i; best_ratio_1 = (int)r; }
+    }
+    for (unsigned i = 0; i < s2.size(); ++i) {
+      const float r = len_ratio((float)s2[i].get_len(), sl);
+      if (r >= min_ratio && r > best_ratio_2) { best_2 = (int)i; best_ratio_2 = (int)r; }
+    }
+    if (both == 1) {
+      if (best_1 == -1) nc.subreads.push_back(sr);
+      else { s1[(size_t)best_1].subreads.push_back(sr); ++s1[(size_t)best_1].cov1; --nc.cov0; }
+    } else if (both == 2) {
+      if (best_2 == -1) nc.subreads.push_back(sr);
+      else { s2[(size_t)best_2].subreads.push_back(sr); ++s2[(size_t)best_2].cov2; --nc.cov0; }
+    } else {
+      if (best_1 != -1 && best_ratio_1 > best_ratio_2) { s1[(size_t)best_1].subreads.push_back(sr); ++s1[(size_t)best_1].cov1; --nc.cov0; }
+      else if (best_2 != -1 && best_ratio_2 > best_ratio_1) { s2[(size_t)best_2].subreads.push_back(sr); ++s2[(size_t)best_2].cov2; --nc.cov0; }
+    }
+  }
+  int i = largest(s1);
+  if (i != -1) out.push_back(s1[(size_t)i]);
+  i = largest(s2);
+  if (i != -1) out.push_back(s2[(size_t)i]);
+  if (both != 3 && nc.size() > 0) {
+    std::vector<Cluster> ns = split_by_len(nc, min_ratio);
+    i = largest(ns);
+    if (i != -1) {
+      if (both == 1) ns[(size_t)i].cov1 = -1; else ns[(size_t)i].cov2 = -1;
+      out.push_back(ns[(size_t)i]);
+    }
+  }
+  return out;
+}
+
+struct SV {   // sv.hpp / sv.cpp
+  std::string type, chrom, idx, refall, altall, gt = "./.", cigar, reads, rvec;
+  int s = 0, e = 0, cov = 0, cov0 = 0, cov1 = 0, cov2 = 0, l = 0, ngaps = 0, score = 0, gtq = 0;
+  unsigned w = 0;
+  bool imprecise = false;
+  bool operator<(const SV& c) const { return chrom < c.chrom ? true : (chrom > c.chrom ? false : s < c.s); }
+  std::string line() const {   // sv.cpp:53-80
+    std::string o = chrom + "\t" + std::to_string(s) + "\t" + idx + "\t" + refall + "\t" + altall + "\t.\tPASS\t";
+    o += "VARTYPE=SV;SVTYPE=" + type + ";SVLEN=" + std::to_string(type == "DEL" ? -l : l) + ";END=" + std::to_string(e);
+    o += ";WEIGHT=" + std::to_string(w) + ";COV=" + std::to_string(cov) + ";COV0=" + std::to_string(cov0);
+    o += ";COV1=" + std::to_string(cov1) + ";COV2=" + std::to_string(cov2) + ";AS=" + std::to_string(score);
+    o += ";NV=" + std::to_string(ngaps) + ";CIGAR=" + cigar + ";RVEC=" + rvec + ";READS=" + reads;
+    o += imprecise ? ";IMPRECISE\t" : "\t";
+    o += "GT:GQ\t" + gt + ":" + std::to_string(gtq);
+    return o;
+  }
+};
+
+SV make_sv(const std::string& type, const std::string& chrom, int s, const std::string& refall,
+           const std::string& altall, unsigned w, int cov, int ngaps, int score, int l, const std::string& cigar) {
+  SV v;
+  v.type = type; v.chrom = chrom; v.s = s; v.refall = refall; v.altall = altall;
+  v.e = s + (int)refall.size() - 1;
+  v.w = w; v.l = l; v.cov = cov; v.ngaps = ngaps; v.score = score; v.cigar = cigar;
+  v.idx = type + "_" + chrom + ":" + std::to_string(s) + "-" + std::to_string(v.e) + "_" + std::to_string(std::abs(l));
+  return v;
+}
+
+const char* VCF_INFO[][4] = {
+    {"VARTYPE", "A", "String", "Variant class"}, {"SVTYPE", "1", "String", "Variant type"},
+    {"SVLEN", "1", "Integer", "Difference in length between REF and ALT alleles"},
+    {"END", "1", "Integer", "End position of the variant described in this record"},
+    {"WEIGHT", "1", "Integer", "Number of alignments supporting this record"},
+    {"COV", "1", "Integer", "Total number of alignments covering this locus"},
+    {"COV0", "1", "Integer", "Total number of alignments covering this locus (no HP)"},
+    {"COV1", "1", "Integer", "Total number of alignments covering this locus (HP=1)"},
+    {"COV2", "1", "Integer", "Total number of alignments covering this locus (HP=2)"},
+    {"AS", "1", "Integer", "Alignment score"}, {"NV", "1", "Integer", "Number of variations on same consensus"},
+    {"IMPRECISE", "0", "Flag", "Imprecise structural variation"}, {"CIGAR", "A", "String", "CIGAR of consensus"},
+    {"READS", ".", "String", "Reads identifiers supporting the call"},
+    {"RVEC", ".", "String", "Reads vector used by genotyper"}};
+
+uint8_t enc26(char c) {   // caller.hpp:25-37
+  switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+               case 'T': case 't': return 3; default: return 4; }
+}
+
+}  // namespace
+
+int main_call(const CallOptions& o) {
+  Ctx C;
+  C.o = o;
+  const int T = std::max(1, o.threads);
+  // ---- load_chromosomes (chromosomes.cpp:9-27): upper-cased, FASTA order
+  {
+    FastxReader fx(o.reference);
+    if (!fx.ok()) die("cannot open " + o.reference);
+    std::string name, seq;
+    while (fx.next(name, seq)) {
+      for (char& ch : seq) ch = (char)toupper((unsigned char)ch);
+      C.chrom_names.push_back(name);
+      C.chrom_seqs[name] = seq;
+    }
+  }
+  // ---- parse_sfsfile (sfs.cpp:5-30)
+  {
+    FILE* f = fopen(o.sfs.c_str(), "r");
+    if (f) {
+      char nm[4096]; int qs, l, ht; std::string cur;
+      char line[8192];
+      while (fgets(line, sizeof line, f)) {
+        if (sscanf(line, "%4095s %d %d %d", nm, &qs, &l, &ht) != 4) continue;
+        if (strcmp(nm, "*") != 0) { cur = nm; C.sfs[cur] = std::vector<RawSFS>(); }
+        C.sfs[cur].push_back(RawSFS{qs, l, ht});
+      }
+      fclose(f);
+    }
+  }
+  logmsg("info", "Placing SFSs on reference genome");
+  // ---- align_and_extend (clusterer.cpp:56-156): pass 1 over the BAM
+  std::vector<std::string> ref_names;
+  std::vector<ESFS> extended;
+  {
+    BamReader bam(o.bam);
+    if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
+    ref_names = bam.ref_names();
+    const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
+    std::vector<std::vector<ESFS>> per_thread((size_t)T);
+    std::vector<BamRecord> batch;
+    bool eof = false;
+    while (!eof) {
+      batch.clear();
+      while ((int)batch.size() < bsize) {
+        BamRecord r;
+        const int rc = bam.next(r);
+        if (rc == 0) { eof = true; break; }
+        if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
+        if (r.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
+        if ((int)r.mapq < o.min_mapq) continue;
+        if (C.sfs.find(r.qname) == C.sfs.end()) continue;
+        batch.push_back(std::move(r));
+      }
+      for (int t = 0; t < T; ++t)
+        for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
+          const BamRecord& r = batch[n];
+          if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
+          extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t]);
+        }
+    }
+    for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
+  }
+  // ---- cluster_by_proximity (clusterer.cpp:407-474)
+  std::vector<Cluster> clusters;
+  if (!extended.empty()) {
+    std::sort(extended.begin(), extended.end());
+    int maxlen = 0;
+    for (const ESFS& s : extended) maxlen = std::max(maxlen, s.re - s.rs);
+    const int dist = (int)(maxlen * 1.1);
+    std::vector<std::pair<int, int>> intervals;
+    int prev_i = 0, prev_e = extended[0].re;
+    std::string prev_chrom = extended[0].chrom;
+    for (size_t i = 1; i < extended.size(); ++i) {
+      const ESFS& s = extended[i];
+      if (s.chrom != prev_chrom) {
+        prev_chrom = s.chrom; intervals.emplace_back(prev_i, (int)i - 1); prev_i = (int)i; prev_e = s.re; continue;
+      }
+      if (s.rs - prev_e > dist) { intervals.emplace_back(prev_i, (int)i - 1); prev_e = s.re; prev_i = (int)i; }
+    }
+    intervals.emplace_back(prev_i, (int)extended.size() - 1);
+    std::vector<std::map<std::pair<int, int>, std::vector<ESFS>>> per_thread((size_t)T);
+    for (size_t i = 0; i < intervals.size(); ++i) {
+      auto& mp = per_thread[i % (size_t)T];   // schedule(static, 1)
+      int j = intervals[i].first, low = extended[(size_t)j].rs, high = extended[(size_t)j].re, last_j = j;
+      ++j;
+      for (; j <= intervals[i].second; ++j) {
+        const ESFS& s = extended[(size_t)j];
+        if (s.rs <= high) { low = std::min(low, s.rs); high = std::max(high, s.re); }
+        else {
+          for (int k = last_j; k < j; ++k) mp[{low, high}].push_back(extended[(size_t)k]);
+          low = s.rs; high = s.re; last_j = j;
+        }
+      }
+      for (int k = last_j; k <= intervals[i].second; ++k) mp[{low, high}].push_back(extended[(size_t)k]);
+    }
+    for (int t = 0; t < T; ++t)
+      for (auto& kv : per_thread[(size_t)t]) {
+        Cluster c;
+        c.sfss = kv.second;
+        c.chrom = c.sfss[0].chrom;
+        clusters.push_back(std::move(c));
+      }
+  }
+  // ---- fill_clusters (clusterer.cpp:477-610): pass 2 over the BAM
+  {
+    std::vector<std::set<std::string>> reads(clusters.size());
+    std::vector<int> min_s(clusters.size()), max_e(clusters.size());
+    std::vector<char> live(clusters.size(), 0);
+    std::vector<std::vector<int>> cov(clusters.size(), std::vector<int>(3, 0));
+    std::map<std::string, std::vector<size_t>> by_chrom;   // cluster indices per chrom, sorted by region start
+    for (size_t i = 0; i < clusters.size(); ++i) {
+      int mn = std::numeric_limits<int>::max(), mx = 0;
+      for (const ESFS& s : clusters[i].sfss) { mn = std::min(mn, s.rs); mx = std::max(mx, s.re); reads[i].insert(s.qname); }
+      min_s[i] = mn; max_e[i] = mx;
+      if ((int)reads[i].size() < o.min_cluster_weight) { ++C.small; continue; }
+      clusters[i].s = mn; clusters[i].e = mx;
+      live[i] = 1;
+      by_chrom[clusters[i].chrom].push_back(i);
+    }
+    for (auto& kv : by_chrom)
+      std::sort(kv.second.begin(), kv.second.end(), [&](size_t a, size_t b) { return min_s[a] < min_s[b]; });
+    BamReader bam(o.bam);
+    if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
+    BamRecord r;
+    int rc;
+    while ((rc = bam.next(r)) > 0) {
+      if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
+      auto it = by_chrom.find(ref_names[(size_t)r.tid]);
+      if (it == by_chrom.end()) continue;
+      const int a_beg = r.pos, a_end = r.endpos();
+      Pairs al;
+      std::string seq;
+      for (size_t ci : it->second) {
+        // region "chrom:min_s-max_e" = 0-based half-open [min_s-1, max_e)
+        const int beg0 = std::max(min_s[ci] - 1, 0), end0 = max_e[ci];
+        if (beg0 >= a_end) break;   // clusters are sorted by start
+        if (!(a_beg < end0 && a_end > beg0)) continue;
+        if (r.flag & (4 | 2048 | 256)) continue;
+        if ((int)r.mapq < o.min_mapq) continue;
+        int64_t hp = 0;
+        BamReader::aux_int(r, "HP", hp);
+        if (hp >= 0 && hp < 3) ++cov[ci][(size_t)hp];
+        clusters[ci].reads.emplace_back(0, hp == 0 ? 3 : (int)hp);
+        if (reads[ci].find(r.qname) == reads[ci].end()) continue;
+        clusters[ci].reads.back().first = 1;
+        if (al.empty()) { al = get_aligned_pairs(r); seq = r.seq_string(); }
+        int qs = -1, qe = -1;
+        for (int i = (int)al.size() - 1; i >= 0; --i) {
+          if (al[(size_t)i].first == -1 || al[(size_t)i].second == -1) continue;
+          if (al[(size_t)i].second <= min_s[ci]) { qs = al[(size_t)i].first; break; }
+        }
+        for (size_t i = 0; i < al.size(); ++i) {
+          if (al[i].first == -1 || al[i].second == -1) continue;
+          if (al[i].second >= max_e[ci]) { qe = al[i].first; break; }
+        }
+        if (qs == -1 || qe == -1) ++C.unextended;
+        else clusters[ci].subreads.push_back(SubRead{r.qname, seq.substr((size_t)qs, (size_t)(qe - qs + 1)), (int)hp});
+      }
+    }
+    if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
+    for (size_t i = 0; i < clusters.size(); ++i) {
+      if (!live[i]) { clusters[i].reads.clear(); clusters[i].subreads.clear(); continue; }
+      if ((int)clusters[i].size() >= o.min_cluster_weight) {
+        clusters[i].cov0 = cov[i][0]; clusters[i].cov1 = cov[i][1]; clusters[i].cov2 = cov[i][2];
+        clusters[i].cov = cov[i][0] + cov[i][1] + cov[i][2];
+      } else ++C.small2;
+    }
+  }
+  logmsg("info", "Calling SVs from " + std::to_string(clusters.size()) + " clusters..");
+  // ---- pcall (caller.cpp:311-406): split, then the three GPU batches
+  struct Sub { size_t parent; Cluster cl; };
+  std::vector<Sub> subs;
+  for (size_t i = 0; i < clusters.size(); ++i) {
+    if ((int)clusters[i].size() < o.min_cluster_weight) continue;
+    for (Cluster& cl : split_cluster(clusters[i], o.useht, o.min_ratio)) subs.push_back(Sub{i, std::move(cl)});
+  }
+  std::vector<std::string> consensus(subs.size());
+  if (!subs.empty()) {
+    std::vector<uint8_t> flat;
+    std::vector<int64_t> seq_off(1, 0), cl_off(1, 0);
+    for (const Sub& s : subs) {
+      for (const SubRead& sr : s.cl.subreads) {
+        for (char ch : sr.seq) flat.push_back(enc26(ch));
+        seq_off.push_back((int64_t)flat.size());
+      }
+      cl_off.push_back((int64_t)seq_off.size() - 1);
+    }
+    svdss_poa_batch_t* pb = nullptr;
+    check(svdss_poa_consensus_batch(flat.data(), seq_off.data(), cl_off.data(), (int64_t)subs.size(), 0, &pb),
+          "svdss_poa_consensus_batch");
+    std::vector<int64_t> lens(subs.size());
+    std::vector<uint8_t> cons((size_t)svdss_poa_batch_total(pb));
+    check(svdss_poa_batch_fetch(pb, lens.data(), cons.data()), "svdss_poa_batch_fetch");
+    svdss_poa_batch_free(pb);
+    size_t p = 0;
+    for (size_t i = 0; i < subs.size(); ++i) {
+      consensus[i].resize((size_t)lens[i]);
+      for (int64_t k = 0; k < lens[i]; ++k) consensus[i][(size_t)k] = "ACGTN"[cons[p++]];   // caller.cpp:297
+    }
+  }
+  std::vector<SV> svs;
+  if (!subs.empty()) {
+    const int8_t a = 1, b = -9;   // caller.cpp:333-337
+    const int8_t mat[25] = {a, b, b, b, 0, b, a, b, b, 0, b, b, a, b, 0, b, b, b, a, 0, 0, 0, 0, 0, 0};
+    std::vector<uint8_t> q, t;
+    std::vector<int64_t> qo(1, 0), to(1, 0);
+    for (size_t i = 0; i < subs.size(); ++i) {
+      const Cluster& cl = subs[i].cl;
+      const std::string& cs = C.chrom_seqs[cl.chrom];
+      for (char ch : consensus[i]) q.push_back(enc26(ch));
+      qo.push_back((int64_t)q.size());
+      for (int p = cl.s; p <= cl.e && p < (int)cs.size(); ++p) t.push_back(enc26(cs[(size_t)p]));   // caller.cpp:329
+      to.push_back((int64_t)t.size());
+    }
+    svdss_aln_batch_t* ab = nullptr;
+    check(svdss_align_global_batch(q.data(), qo.data(), t.data(), to.data(), (int64_t)subs.size(), 5, mat, 16, 2, 41, 1,
+                                   0, &ab), "svdss_align_global_batch");
+    std::vector<int32_t> scores(subs.size());
+    std::vector<int64_t> ncig(subs.size());
+    std::vector<uint32_t> cig((size_t)svdss_aln_batch_total_cigar(ab));
+    check(svdss_aln_batch_fetch(ab, scores.data(), ncig.data(), cig.data()), "svdss_aln_batch_fetch");
+    svdss_aln_batch_free(ab);
+    std::vector<std::vector<SV>> per_thread((size_t)T);
+    size_t cp = 0;
+    for (size_t i = 0; i < subs.size(); ++i) {
+      const Cluster& cl = subs[i].cl;
+      const Cluster& parent = clusters[subs[i].parent];
+      const std::string& cs = C.chrom_seqs[cl.chrom];
+      std::string cigar_str;
+      for (int64_t k = 0; k < ncig[i]; ++k) cigar_str += std::to_string(cig[cp + (size_t)k] >> 4) + "MID"[cig[cp + (size_t)k] & 0xf];
+      std::string names;
+      for (const SubRead& sr : cl.subreads) names += sr.name + ",";
+      if (!names.empty()) names.pop_back();
+      std::string rvec;
+      for (const auto& rd : parent.reads) rvec += std::to_string(rd.first) + ":" + std::to_string(rd.second) + "-";
+      if (!rvec.empty()) rvec.pop_back();
+      std::vector<SV> local;
+      unsigned rpos = (unsigned)cl.s, cpos = 0;
+      int nv = 0;
+      for (int64_t k = 0; k < ncig[i]; ++k) {
+        const unsigned l = cig[cp + (size_t)k] >> 4;
+        const char op = "MID"[cig[cp + (size_t)k] & 0xf];
+        if (op == 'M') { rpos += l; cpos += l; }
+        else if (op == 'I') {
+          if (l >= (unsigned)o.min_sv_length) {
+            const std::string anchor(1, cs[rpos - 1]);
+            SV v = make_sv("INS", cl.chrom, (int)rpos, anchor, anchor + consensus[i].substr(cpos, l), (unsigned)cl.size(),
+                           cl.cov, nv, scores[i], (int)l, cigar_str);
+            v.reads = names;
+            local.push_back(v);
+            ++nv;
+          }
+          cpos += l;
+        } else {
+          if (l >= (unsigned)o.min_sv_length) {
+            SV v = make_sv("DEL", cl.chrom, (int)rpos, cs.substr(rpos - 1, l + 1), std::string(1, cs[rpos - 1]),
+                           (unsigned)cl.size(), cl.cov, nv, scores[i], (int)l, cigar_str);
+            v.reads = names;
+            local.push_back(v);
+            ++nv;
+          }
+          rpos += l;
+        }
+      }
+      cp += (size_t)ncig[i];
+      for (SV& v : local) {
+        v.ngaps = nv; v.gt = "0/1"; v.gtq = 100;
+        v.cov = cl.cov; v.cov0 = cl.cov0; v.cov1 = cl.cov1; v.cov2 = cl.cov2;
+        v.rvec = rvec;
+        per_thread[subs[i].parent % (size_t)T].push_back(v);
+      }
+    }
+    for (int t = 0; t < T; ++t) svs.insert(svs.begin(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());   // caller.cpp:18-22
+  }
+  std::sort(svs.begin(), svs.end());   // same libstdc++ std::sort as the reference (caller.cpp:23)
+  {   // clean_dups (caller.cpp:409-426)
+    std::vector<SV> kept;
+    std::string lc, lr, la; int lp = -1;
+    for (const SV& v : svs) {
+      if (lc != v.chrom || lp != v.s || lr != v.refall || la != v.altall) kept.push_back(v);
+      lc = v.chrom; lp = v.s; lr = v.refall; la = v.altall;
+    }
+    svs.swap(kept);
+  }
+  if (svs.size() >= 2) {   // filter_sv_chains (caller.cpp:429-475): ratios of adjacent candidates in one batch
+    std::vector<size_t> cand;
+    std::vector<uint8_t> A, B;
+    std::vector<int64_t> ao(1, 0), bo(1, 0);
+    for (size_t i = 1; i < svs.size(); ++i) {
+      const SV &prev = svs[i - 1], &sv = svs[i];
+      if (sv.chrom == prev.chrom && sv.s - prev.e < 2 * sv.l && prev.type == sv.type) {
+        const double w_r = std::min((double)sv.w, (double)prev.w) / std::max((double)sv.w, (double)prev.w);
+        const double l_r = std::min((double)sv.l, (double)prev.l) / std::max((double)sv.l, (double)prev.l);
+        const int d = sv.s - prev.s;
+        if (d < 100 && w_r >= 0.9 && l_r >= o.min_ratio) {
+          const std::string& x = sv.type == "DEL" ? sv.refall : sv.altall;
+          const std::string& y = sv.type == "DEL" ? prev.refall : prev.altall;
+          A.insert(A.end(), x.begin(), x.end()); ao.push_back((int64_t)A.size());
+          B.insert(B.end(), y.begin(), y.end()); bo.push_back((int64_t)B.size());
+          cand.push_back(i);
+        }
+      }
+    }
+    std::map<size_t, double> sim;
+    if (!cand.empty()) {
+      std::vector<double> ratio(cand.size());
+      uint8_t dummy = 0;
+      check(svdss_indel_ratio_batch(A.empty() ? &dummy : A.data(), ao.data(), B.empty() ? &dummy : B.data(), bo.data(),
+                                    (int64_t)cand.size(), 0, ratio.data(), nullptr), "svdss_indel_ratio_batch");
+      for (size_t k = 0; k < cand.size(); ++k) sim[cand[k]] = ratio[k];
+    }
+    std::vector<SV> kept;
+    SV prev = svs[0];
+    bool reset = false;
+    for (size_t i = 1; i < svs.size(); ++i) {
+      if (reset) { reset = false; prev = svs[i]; continue; }
+      const SV& sv = svs[i];
+      auto it = sim.find(i);
+      if (it != sim.end() && it->second > 70) { kept.push_back(sv.w > prev.w ? sv : prev); reset = true; continue; }
+      kept.push_back(prev);
+      prev = sv;
+    }
+    kept.push_back(prev);
+    svs.swap(kept);
+  }
+  std::sort(svs.begin(), svs.end());
+  // ---- write_vcf (caller.cpp:59-63, 477-550)
+  std::string out = "##fileformat=VCFv4.2\n##reference=ftp://ftp.1000genomes.ebi.ac.uk/vol1/ftp/data_collections/HGSVC2/"
+                    "technical/reference/20200513_hg38_NoALT/hg38.no_alt.fa.gz\n";
+  for (const std::string& n : C.chrom_names) out += "##contig=<ID=" + n + ",length=" + std::to_string(C.chrom_seqs[n].size()) + ">\n";
+  out += "##FILTER=<ID=PASS,Description=\"All filters passed\">\n";
+  for (const auto& f : VCF_INFO) out += std::string("##INFO=<ID=") + f[0] + ",Number=" + f[1] + ",Type=" + f[2] + ",Description=\"" + f[3] + "\">\n";
+  out += "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n";
+  out += "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype quality\">\n";
+  out += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tDEFAULT\n";
+  for (const SV& v : svs) out += v.line() + "\n";
+  fwrite(out.data(), 1, out.size(), stdout);
+  fflush(stdout);
+  logmsg("info", "Writing " + std::to_string(svs.size()) + " SVs.");
+  return 0;
+}

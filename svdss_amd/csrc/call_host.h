@@ -1,0 +1,17 @@
+// call_host.h -- options of the `call` and `smooth` sub-commands (config.hpp:68-103 defaults).
+#pragma once
+#include <string>
+
+struct CallOptions {
+  std::string reference, bam, sfs;
+  int threads = 4;
+  int min_cluster_weight = 2;
+  int min_sv_length = 25;
+  int min_mapq = 20;
+  bool useht = true;
+  float min_ratio = 0.97f;
+  float accp = 0.98f;          // smooth only
+};
+
+int main_call(const CallOptions& o);
+int main_smooth(const CallOptions& o);

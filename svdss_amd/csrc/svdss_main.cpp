@@ -19,6 +19,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
+#include "call_host.h"
 #include "fastx_reader.h"
 
 static const char* VERSION = "v2.1.1";  // main.cpp:19
@@ -27,7 +28,16 @@ static const char* MAIN_USAGE =
     "Usage: SVDSS <index|smooth|search|call> --help\n"
     "  index   build the FM-index of a reference (FASTA, gz ok):  SVDSS index -d ref.fa -o ref.fa.fmd [-t T]\n"
     "  search  extract sample-specific strings: SVDSS search --index ref.fa.fmd --bam reads.bam > specifics.txt\n"
-    "  smooth, call: not available in this build\n";
+    "  call    call SVs from the specific strings:    SVDSS call --reference ref.fa --bam reads.bam --sfs specifics.txt\n"
+    "  smooth: not available in this build\n";
+
+static const char* CALL_USAGE =
+    "Usage: SVDSS call --reference <FASTA> --bam <BAM> --sfs <SFS>\n"
+    "      --threads <int>             kept for output-order compatibility (default: 4)\n"
+    "      --min-cluster-weight <int>  minimum number of supporting superstrings for a call (default: 2)\n"
+    "      --min-sv-length <int>       minimum length of reported SVs (default: 25, values < 25 ignored)\n"
+    "      --min-mapq <int>            minimum mapping quality (default: 20)\n"
+    "      --noht                      ignore the HP tag\n";
 
 static const char* SEARCH_USAGE =
     "Usage: SVDSS search --index <FMD> --bam <BAM> | --fastx <FASTA/FASTQ>\n"
@@ -56,7 +66,10 @@ static void check(int rc, const char* what) {
 static const char NT16[] = "=ACMGRSVTWYHKDBN";
 
 struct Options {
-  std::string index, bam, fastx;
+  std::string index, bam, fastx, reference, sfs;
+  int min_sv_length = 25, min_mapq = 20, min_cluster_weight = 2;   // config.hpp:92-96
+  float accp = 0.98f, min_ratio = 0.97f;
+  bool useht = true;
   int threads = 4, bsize = 10000, omax = 100000;  // config.hpp:68-69,88
   bool putative = true, assemble = true, verbose = false, version = false, help = false;
 };
@@ -81,6 +94,14 @@ static Options parse(int argc, char** argv) {
     else if (take(argc, argv, i, "--threads", v)) o.threads = atoi(v.c_str());
     else if (take(argc, argv, i, "--bsize", v)) o.bsize = atoi(v.c_str());
     else if (take(argc, argv, i, "--omax", v)) o.omax = atoi(v.c_str());
+    else if (take(argc, argv, i, "--reference", v)) o.reference = v;
+    else if (take(argc, argv, i, "--sfs", v)) o.sfs = v;
+    else if (take(argc, argv, i, "--min-sv-length", v)) o.min_sv_length = std::max(25, atoi(v.c_str()));  // config.cpp:87
+    else if (take(argc, argv, i, "--min-cluster-weight", v)) o.min_cluster_weight = atoi(v.c_str());
+    else if (take(argc, argv, i, "--min-mapq", v)) o.min_mapq = atoi(v.c_str());
+    else if (take(argc, argv, i, "--accp", v)) o.accp = (float)atof(v.c_str());
+    else if (take(argc, argv, i, "-l", v)) o.min_ratio = (float)atof(v.c_str());
+    else if (!strcmp(argv[i], "--noht")) o.useht = false;
     else if (!strcmp(argv[i], "--noputative")) o.putative = false;
     else if (!strcmp(argv[i], "--noassemble")) o.assemble = false;
     else if (!strcmp(argv[i], "--verbose")) o.verbose = true;
@@ -299,8 +320,15 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[1], "search")) {
       if (o.index.empty() || (o.fastx.empty() && o.bam.empty())) { fputs(SEARCH_USAGE, stderr); return EXIT_FAILURE; }
       main_search(o);
-    } else if (!strcmp(argv[1], "call") || !strcmp(argv[1], "smooth")) {
-      die(std::string("'") + argv[1] + "' is not part of this build (SFS search path only)");
+    } else if (!strcmp(argv[1], "call")) {
+      if (o.reference.empty() || o.bam.empty() || o.sfs.empty()) { fputs(CALL_USAGE, stderr); return EXIT_FAILURE; }  // main.cpp:56-59
+      CallOptions c;
+      c.reference = o.reference; c.bam = o.bam; c.sfs = o.sfs; c.threads = o.threads;
+      c.min_cluster_weight = o.min_cluster_weight; c.min_sv_length = o.min_sv_length; c.min_mapq = o.min_mapq;
+      c.useht = o.useht; c.min_ratio = o.min_ratio;
+      main_call(c);
+    } else if (!strcmp(argv[1], "smooth")) {
+      die("'smooth' is not part of this build yet");
     } else {
       fputs(MAIN_USAGE, stderr);
       return EXIT_FAILURE;

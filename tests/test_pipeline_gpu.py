@@ -58,3 +58,10 @@ def test_index_search_call_recovers_implanted_svs(tmp_path, het):
             assert len(f[4]) == length + 1 and len(f[3]) == 1 and f[3] == chromosomes[chrom][hits[0][1] - 1]
     assert len(called) == len(truth)                      # no spurious calls
     assert info["subclusters"] >= len(truth)
+    # the C++ CLI (`SVDSS call`, csrc/call_host.cpp) and the Python mirror give the same VCF bytes
+    sfs_path = tmp_path / "specifics.txt"
+    sfs_path.write_text(sfs_text)
+    r = subprocess.run([BIN, "call", "--reference", str(fa), "--bam", str(bam), "--sfs", str(sfs_path), "--threads", "4",
+                        "--min-sv-length", "50"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == vcf
