@@ -46,7 +46,9 @@ def read_bam(path: str) -> Tuple[List[str], List[int], List[Alignment]]:
         p += 4 * n_cig
         packed = rec[p:p + (l_seq + 1) // 2]
         seq = "".join(SEQ16[(packed[i >> 1] >> (4 if i % 2 == 0 else 0)) & 0xf] for i in range(l_seq))
-        p += (l_seq + 1) // 2 + l_seq
+        p += (l_seq + 1) // 2
+        qual = bytes(rec[p:p + l_seq])
+        p += l_seq
         tags = {}
         while p + 3 <= len(rec):
             tag, ty = rec[p:p + 2].decode(), chr(rec[p + 2])
@@ -69,5 +71,5 @@ def read_bam(path: str) -> Tuple[List[str], List[int], List[Alignment]]:
                 p += 5 + cnt * (1 if st in "cC" else 2 if st in "sS" else 4)
             else:
                 break
-        alns.append(Alignment(qname, flag, tid, pos, mapq, cigar, seq, tags))
+        alns.append(Alignment(qname, flag, tid, pos, mapq, cigar, seq, tags, qual))
     return names, lens, alns

@@ -24,6 +24,7 @@ class Alignment:
     cigar: List[Tuple[int, int]]      # (length, op code) like decode_cigar (bam.cpp:25-35)
     seq: str
     tags: Dict[str, int] = field(default_factory=dict)
+    qual: bytes = b""
 
     def endpos(self) -> int:          # bam_endpos
         ref = sum(l for l, op in self.cigar if op in (BAM_CMATCH, BAM_CDEL, BAM_CREF_SKIP, BAM_CEQUAL, BAM_CDIFF))

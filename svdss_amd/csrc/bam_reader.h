@@ -49,6 +49,8 @@ class BamReader {
   bool ok() const { return f_ != nullptr; }
   const std::string& error() const { return err_; }
   const std::vector<std::string>& ref_names() const { return refs_; }
+  const std::vector<int32_t>& ref_lens() const { return ref_lens_; }
+  const std::string& header_text() const { return text_; }
 
   bool read_header() {
     char magic[4];
@@ -57,6 +59,7 @@ class BamReader {
     if (!read(&l_text, 4)) return fail("truncated header");
     std::string text((size_t)l_text, '\0');
     if (l_text && !read(&text[0], (size_t)l_text)) return fail("truncated header");
+    text_ = text;
     if (!read(&n_ref, 4)) return fail("truncated header");
     for (int i = 0; i < n_ref; ++i) {
       int32_t l_name, l_ref;
@@ -65,6 +68,7 @@ class BamReader {
       if (!read(&name[0], (size_t)l_name) || !read(&l_ref, 4)) return fail("truncated header");
       if (!name.empty() && name.back() == '\0') name.pop_back();
       refs_.push_back(name);
+      ref_lens_.push_back(l_ref);
     }
     return true;
   }
@@ -216,6 +220,8 @@ class BamReader {
   FILE* f_;
   std::string err_;
   std::vector<std::string> refs_;
+  std::vector<int32_t> ref_lens_;
+  std::string text_;
   std::vector<uint8_t> cbuf_, ublock_, buf_;
   size_t upos_ = 0;
 };

@@ -1,0 +1,202 @@
+// smooth_host.cpp -- `SVDSS smooth` (/root/reference/smoother.cpp): every primary, mapq-ok
+// alignment is rewritten to equal the reference except at long (> 20 bp) indels and soft clips
+// and tagged XF (0 smoothed & interesting, 1 too many mismatches, 2 nothing interesting); all
+// other records are dropped; output order == input order; BAM on stdout.  A CIGAR walk with
+// copies from the reference -- the reference has no alignment DP here.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "bam_reader.h"
+#include "bam_writer.h"
+#include "call_host.h"
+#include "fastx_reader.h"
+
+namespace {
+[[noreturn]] void die(const std::string& m) { fprintf(stderr, "[smooth] [critical] %s\n", m.c_str()); exit(EXIT_FAILURE); }
+
+const int MIN_INDEL = 20;   // config.hpp:95
+
+bool is_m(uint32_t op) { return op == 0 || op == 7 || op == 8; }
+
+void mismatch_counts(const BamRecord& r, const std::string& seq, const std::string& ref, double& nm, double& nx) {
+  size_t ref_off = (size_t)r.pos, q_off = 0;
+  nm = nx = 0;
+  for (uint32_t c : r.cigar) {
+    const uint32_t l = c >> 4, op = c & 0xf;
+    if (is_m(op)) {
+      for (uint32_t j = 0; j < l; ++j) (ref[ref_off + j] == seq[q_off + j]) ? ++nm : ++nx;
+      ref_off += l; q_off += l;
+    } else if (op == 1 || op == 4) q_off += l;
+    else if (op == 2) ref_off += l;
+    else break;
+  }
+}
+
+// bam_aux_update_int(aln, "XF", v): overwrite an existing integer XF, else append XF:C
+void set_xf(std::vector<uint8_t>& aux, int v) {
+  size_t p = 0;
+  while (p + 3 <= aux.size()) {
+    const char t0 = (char)aux[p], t1 = (char)aux[p + 1], ty = (char)aux[p + 2];
+    size_t sz = 0;
+    switch (ty) {
+      case 'A': case 'c': case 'C': sz = 1; break;
+      case 's': case 'S': sz = 2; break;
+      case 'i': case 'I': case 'f': sz = 4; break;
+      case 'Z': case 'H': { size_t z = p + 3; while (z < aux.size() && aux[z]) ++z; sz = z - (p + 3) + 1; break; }
+      case 'B': {
+        if (p + 8 > aux.size()) return;
+        const char st = (char)aux[p + 3];
+        int32_t cnt; memcpy(&cnt, &aux[p + 4], 4);
+        sz = 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4);
+        break;
+      }
+      default: return;
+    }
+    if (t0 == 'X' && t1 == 'F' && strchr("cCsSiI", ty)) {
+      memset(&aux[p + 3], 0, sz);
+      aux[p + 3] = (uint8_t)v;
+      return;
+    }
+    p += 3 + sz;
+  }
+  aux.push_back('X'); aux.push_back('F'); aux.push_back('C'); aux.push_back((uint8_t)v);
+}
+
+void write_record(BgzfWriter& w, const BamRecord& r, const std::vector<uint32_t>& cigar, const std::string& seq,
+                  const std::vector<uint8_t>& qual, const std::vector<uint8_t>& aux) {
+  static const int8_t code[256] = {0};
+  (void)code;
+  const int32_t l_seq = (int32_t)seq.size();
+  std::vector<uint8_t> packed((size_t)(l_seq + 1) / 2, 0);
+  static uint8_t lut[256];
+  static bool init = false;
+  if (!init) {
+    memset(lut, 15, sizeof lut);
+    const char* nt16 = "=ACMGRSVTWYHKDBN";
+    for (int i = 0; i < 16; ++i) { lut[(uint8_t)nt16[i]] = (uint8_t)i; lut[(uint8_t)tolower(nt16[i])] = (uint8_t)i; }
+    init = true;
+  }
+  for (int32_t i = 0; i < l_seq; ++i) packed[(size_t)i >> 1] |= (uint8_t)(lut[(uint8_t)seq[(size_t)i]] << ((~i & 1) << 2));
+  const uint8_t l_name = (uint8_t)(r.qname.size() + 1);
+  const uint16_t n_cig = (uint16_t)cigar.size();
+  const int32_t block = 32 + l_name + 4 * n_cig + (int32_t)packed.size() + l_seq + (int32_t)aux.size();
+  uint8_t core[36];
+  memcpy(core, &block, 4);
+  memcpy(core + 4, &r.tid, 4);
+  memcpy(core + 8, &r.pos, 4);
+  core[12] = l_name; core[13] = r.mapq;
+  memcpy(core + 14, &r.bin, 2);
+  memcpy(core + 16, &n_cig, 2);
+  memcpy(core + 18, &r.flag, 2);
+  memcpy(core + 20, &l_seq, 4);
+  memcpy(core + 24, &r.mtid, 4);
+  memcpy(core + 28, &r.mpos, 4);
+  memcpy(core + 32, &r.isize, 4);
+  w.write(core, 36);
+  w.write(r.qname.c_str(), l_name);
+  if (n_cig) w.write(cigar.data(), 4u * n_cig);
+  w.write(packed.data(), packed.size());
+  w.write(qual.data(), (size_t)l_seq);
+  w.write(aux.data(), aux.size());
+}
+}  // namespace
+
+int main_smooth(const CallOptions& o) {
+  std::unordered_map<std::string, std::string> chrom;
+  {
+    FastxReader fx(o.reference);
+    if (!fx.ok()) die("cannot open " + o.reference);
+    std::string name, seq;
+    while (fx.next(name, seq)) {
+      for (char& c : seq) c = (char)toupper((unsigned char)c);
+      chrom[name] = seq;
+    }
+  }
+  auto eligible = [&](const BamRecord& r, const std::vector<std::string>& names) {
+    if (r.flag & (4 | 2048 | 256)) return false;
+    if ((int)r.mapq < o.min_mapq || r.l_seq < 2) return false;
+    if (r.tid < 0) die("core.tid < 0. Why are we here? Please check");
+    return r.tid < (int)names.size() && chrom.count(names[(size_t)r.tid]) > 0;
+  };
+  // compute_maxaccuracy (smoother.cpp:259-346)
+  double al_accuracy;
+  {
+    BamReader bam(o.bam);
+    if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
+    std::vector<double> acc;
+    BamRecord r;
+    while (acc.size() < 10000 && bam.next(r) > 0) {
+      if (!eligible(r, bam.ref_names())) continue;
+      double nm, nx;
+      mismatch_counts(r, r.seq_string(), chrom[bam.ref_names()[(size_t)r.tid]], nm, nx);
+      acc.push_back(nx / nm);
+    }
+    if (acc.empty()) al_accuracy = 0.0;
+    else {
+      std::sort(acc.begin(), acc.end());
+      const double id = (double)(acc.size() - 1) * (double)o.accp;   // percentile(), smoother.cpp:246-255
+      const double lo = floor(id), hi = ceil(id), h = id - lo;
+      al_accuracy = (1.0 - h) * acc[(size_t)lo] + h * acc[(size_t)hi];
+    }
+  }
+  BamReader bam(o.bam);
+  if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
+  BgzfWriter w(stdout);
+  bam_write_header(w, bam.header_text(), bam.ref_names(), bam.ref_lens());
+  BamRecord r;
+  int rc;
+  while ((rc = bam.next(r)) > 0) {
+    if (!eligible(r, bam.ref_names())) continue;   // dropped from the output (smoother.cpp:509-537)
+    const std::string& ref = chrom[bam.ref_names()[(size_t)r.tid]];
+    const std::string seq = r.seq_string();
+    // smooth_read (smoother.cpp:84-232)
+    std::string nseq;
+    std::vector<uint8_t> nqual;
+    std::vector<uint32_t> ncig;
+    double nm = 0, nx = 0;
+    size_t ref_off = (size_t)r.pos, q_off = 0;
+    uint32_t m_diff = 0;
+    bool ignore = true;
+    auto qcopy = [&](size_t start, size_t len) {   // may run past the read end like the reference's memcpy
+      for (size_t i = 0; i < len; ++i) nqual.push_back(start + i < r.qual.size() ? r.qual[start + i] : 255);
+    };
+    for (uint32_t c : r.cigar) {
+      const uint32_t l = c >> 4, op = c & 0xf;
+      if (is_m(op)) {
+        nseq.append(ref, ref_off, l);
+        qcopy(q_off, l);
+        for (uint32_t j = 0; j < l; ++j) (ref[ref_off + j] == seq[q_off + j]) ? ++nm : ++nx;
+        ref_off += l; q_off += l;
+        if (!ncig.empty() && (ncig.back() & 0xf) == 0) ncig.back() += (l + m_diff) << 4;
+        else ncig.push_back(((l + m_diff) << 4) | 0);
+        m_diff = 0;
+      } else if (op == 1) {
+        if ((int)l > MIN_INDEL) { ignore = false; nseq.append(seq, q_off, l); qcopy(q_off, l); ncig.push_back(c); }
+        q_off += l;
+      } else if (op == 2) {
+        if ((int)l <= MIN_INDEL) { nseq.append(ref, ref_off, l); qcopy(q_off, l); m_diff += l; }
+        else { ignore = false; ncig.push_back(c); }
+        ref_off += l;
+      } else if (op == 4) {
+        ignore = false;
+        nseq.append(seq, q_off, l);
+        qcopy(q_off, l);
+        q_off += l;
+        ncig.push_back(c);
+      } else break;
+    }
+    std::vector<uint8_t> aux = r.aux;
+    if (nx / nm > al_accuracy) { set_xf(aux, 1); write_record(w, r, r.cigar, seq, r.qual, aux); }
+    else if (ignore) { set_xf(aux, 2); write_record(w, r, r.cigar, seq, r.qual, aux); }
+    else { set_xf(aux, 0); write_record(w, r, ncig, nseq, nqual, aux); }
+  }
+  if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
+  if (!w.finish()) die("error writing the BAM to stdout");
+  return 0;
+}

@@ -29,7 +29,12 @@ static const char* MAIN_USAGE =
     "  index   build the FM-index of a reference (FASTA, gz ok):  SVDSS index -d ref.fa -o ref.fa.fmd [-t T]\n"
     "  search  extract sample-specific strings: SVDSS search --index ref.fa.fmd --bam reads.bam > specifics.txt\n"
     "  call    call SVs from the specific strings:    SVDSS call --reference ref.fa --bam reads.bam --sfs specifics.txt\n"
-    "  smooth: not available in this build\n";
+    "  smooth  smooth a BAM (reads equal the reference except at long indels): SVDSS smooth --reference ref.fa --bam in.bam > out.bam\n";
+
+static const char* SMOOTH_USAGE =
+    "Usage: SVDSS smooth --reference <FASTA> --bam <BAM> > smoothed.bam\n"
+    "      --min-mapq <int>   minimum mapping quality (default: 20)\n"
+    "      --accp <float>     accuracy percentile (default: 0.98)\n";
 
 static const char* CALL_USAGE =
     "Usage: SVDSS call --reference <FASTA> --bam <BAM> --sfs <SFS>\n"
@@ -328,7 +333,10 @@ int main(int argc, char** argv) {
       c.useht = o.useht; c.min_ratio = o.min_ratio;
       main_call(c);
     } else if (!strcmp(argv[1], "smooth")) {
-      die("'smooth' is not part of this build yet");
+      if (o.reference.empty() || o.bam.empty()) { fputs(SMOOTH_USAGE, stderr); return EXIT_FAILURE; }   // main.cpp:73-76
+      CallOptions c;
+      c.reference = o.reference; c.bam = o.bam; c.threads = o.threads; c.min_mapq = o.min_mapq; c.accp = o.accp;
+      main_smooth(c);
     } else {
       fputs(MAIN_USAGE, stderr);
       return EXIT_FAILURE;

@@ -19,7 +19,7 @@ def bgzf(data: bytes, block=60000) -> bytes:
     return b"".join(out)
 
 
-def record(qname: str, flag: int, tid: int, pos: int, mapq: int, cigar, seq: str, tags=()) -> bytes:
+def record(qname: str, flag: int, tid: int, pos: int, mapq: int, cigar, seq: str, tags=(), qual: bytes = None) -> bytes:
     """cigar: list of (op_char, len); tags: list of (tag, type_char, value) with integer types cCsSiI or Z."""
     name = qname.encode() + b"\0"
     cig = b"".join(struct.pack("<I", (l << 4) | "MIDNSHP=X".index(op)) for op, l in cigar)
@@ -27,7 +27,7 @@ def record(qname: str, flag: int, tid: int, pos: int, mapq: int, cigar, seq: str
     packed = bytearray((l_seq + 1) // 2)
     for i, ch in enumerate(seq):
         packed[i >> 1] |= SEQ16.get(ch.upper(), 15) << (4 if i % 2 == 0 else 0)
-    qual = b"\xff" * l_seq
+    qual = b"\xff" * l_seq if qual is None else qual
     aux = b""
     for tag, ty, val in tags:
         aux += tag.encode() + ty.encode()

@@ -79,3 +79,46 @@ def simulate(ref_lens=(250000, 120000), n_svs=8, coverage=24, read_len=6000, see
             k += 1
     reads.sort(key=lambda r: (r[1], r[2]))
     return ref, svs, reads
+
+
+def add_errors(seq: str, cigar, rng, err: float):
+    """HiFi-like errors on an error-free read, CIGAR kept truthful: inside M segments a base is
+    substituted, followed by a 1-base insertion, or deleted (sub:ins:del = 2:1.5:1.5)."""
+    out, new = [], []
+    p = 0
+
+    def push(op, l):
+        if l <= 0:
+            return
+        if new and new[-1][0] == op:
+            new[-1] = (op, new[-1][1] + l)
+        else:
+            new.append((op, l))
+
+    for op, l in cigar:
+        if op in ("I", "S"):
+            out.append(seq[p:p + l])
+            p += l
+            push(op, l)
+        elif op == "D":
+            push(op, l)
+        else:
+            for i in range(l):
+                b = seq[p + i]
+                u = rng.random()
+                first_or_last = i == 0 or i == l - 1     # keep segment borders clean (valid CIGAR shape)
+                if u < err * 0.4:
+                    out.append("ACGT"[("ACGT".index(b) + int(rng.integers(1, 4))) % 4])
+                    push("M", 1)
+                elif u < err * 0.7 and not first_or_last:
+                    out.append(b)
+                    out.append("ACGT"[int(rng.integers(0, 4))])
+                    push("M", 1)
+                    push("I", 1)
+                elif u < err and not first_or_last:
+                    push("D", 1)
+                else:
+                    out.append(b)
+                    push("M", 1)
+            p += l
+    return "".join(out), new

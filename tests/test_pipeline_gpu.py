@@ -65,3 +65,52 @@ def test_index_search_call_recovers_implanted_svs(tmp_path, het):
                         "--min-sv-length", "50"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout == vcf
+
+
+def test_run_svdss_chain_with_raw_reads(tmp_path):
+    """The chain run_svdss executes (/root/reference/run_svdss:136-178): index -> smooth -> search -> call,
+    all four through the `SVDSS` binary, on reads WITH sequencing errors (0.5 %, truthful CIGARs)."""
+    from tests.pipeline_sim import add_errors
+    ref, svs, reads = simulate(seed=9, coverage=30)
+    rng = np.random.default_rng(4)
+    names = ["chrA", "chrB"]
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as fh:
+        for n, c in zip(names, ref):
+            fh.write(f">{n}\n{synth.to_ascii(c)}\n")
+    recs = []
+    for n, tid, pos, cig, seq, hp in reads:
+        s2, c2 = add_errors(seq, cig, rng, 0.005)
+        recs.append(bam_writer.record(n, 0, tid, pos, 60, c2, s2))
+    bam = tmp_path / "reads.bam"
+    bam.write_bytes(bam_writer.bam([(n, len(c)) for n, c in zip(names, ref)], recs))
+    fmd = tmp_path / "ref.fa.fmd"
+    assert subprocess.run([BIN, "index", "-t", "8", "-d", str(fa), "-o", str(fmd)], capture_output=True).returncode == 0
+    smoothed = tmp_path / "smoothed.bam"
+    with open(smoothed, "wb") as fh:
+        r = subprocess.run([BIN, "smooth", "--threads", "4", "--min-mapq", "20", "--accp", "0.98", "--reference", str(fa),
+                            "--bam", str(bam)], stdout=fh, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run([BIN, "search", "--threads", "4", "--index", str(fmd), "--bam", str(smoothed)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sfs = tmp_path / "specifics.txt"
+    sfs.write_text(r.stdout)
+    # reads that carry no long indel are tagged XF=2 by smooth and skipped by search (putative filter)
+    n_reads_with_sfs = len([l for l in r.stdout.splitlines() if not l.startswith("*")])
+    assert 0 < n_reads_with_sfs < len(reads)
+    r = subprocess.run([BIN, "call", "--threads", "4", "--min-cluster-weight", "2", "--min-sv-length", "50", "--min-mapq", "20",
+                        "--reference", str(fa), "--bam", str(smoothed), "--sfs", str(sfs)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    called = []
+    for line in r.stdout.splitlines():
+        if line.startswith("#"):
+            continue
+        f = line.split("\t")
+        kv = dict(x.split("=", 1) for x in f[7].split(";") if "=" in x)
+        called.append((f[0], int(f[1]), kv["SVTYPE"], abs(int(kv["SVLEN"]))))
+    truth = [(names[s.contig], s.pos, s.kind, s.length) for s in svs]
+    for chrom, pos, kind, length in truth:
+        hits = [c for c in called if c[0] == chrom and c[2] == kind and abs(c[3] - length) <= 2 and abs(c[1] - pos) <= 15]
+        assert len(hits) == 1, (chrom, pos, kind, length, called)
+    assert len(called) == len(truth)
