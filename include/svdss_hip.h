@@ -160,6 +160,9 @@ int64_t svdss_poa_batch_nclusters(const svdss_poa_batch_t* b);
 int64_t svdss_poa_batch_total(const svdss_poa_batch_t* b);     /* sum of consensus lengths */
 int64_t svdss_poa_batch_cells(const svdss_poa_batch_t* b);     /* DP cells computed */
 double svdss_poa_batch_kernel_ms(const svdss_poa_batch_t* b);
+/* sub-clusters the LDS-resident kernel handed to the HBM kernel (graph too large for LDS, a node with
+ * more than 8 predecessors, or the full-matrix fallback of the band) */
+int64_t svdss_poa_batch_hbm(const svdss_poa_batch_t* b);
 int svdss_poa_batch_fetch(const svdss_poa_batch_t* b, int64_t* cons_len, uint8_t* cons);
 void svdss_poa_batch_free(svdss_poa_batch_t* b);
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "svdss_poa_batch_total": (_i64, [_p]),
     "svdss_poa_batch_cells": (_i64, [_p]),
     "svdss_poa_batch_kernel_ms": (C.c_double, [_p]),
+    "svdss_poa_batch_hbm": (_i64, [_p]),
     "svdss_poa_batch_fetch": (C.c_int, [_p, _p, _p]),
     "svdss_poa_batch_free": (None, [_p]),
     "svdss_indel_ratio_batch": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),

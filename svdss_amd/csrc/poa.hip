@@ -15,13 +15,17 @@
 // bundle) runs on lane 0.  Banded DP matrices, the graph and the traceback live in HBM.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/svdss_hip.h"
+#include "poa_lds.h"
 
 extern thread_local std::string g_svdss_hip_err;
 
@@ -391,6 +395,7 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaTask* tasks,
 
 struct svdss_poa_batch {
   int64_t n_clusters = 0;
+  int64_t n_hbm = 0;   // clusters the LDS kernel handed to the HBM kernel
   int64_t cells = 0;
   double kernel_ms = 0.0;
   std::vector<int64_t> cons_len;
@@ -415,6 +420,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   *out = b;
   b->n_clusters = n_clusters;
   b->cells = 0;
+  b->n_hbm = 0;
   b->kernel_ms = 0.0;
   b->cons_len.assign((size_t)n_clusters, 0);
   b->cons.clear();
@@ -439,10 +445,124 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   HIPCHK3(hipEventCreate(&ev0));
   HIPCHK3(hipEventCreate(&ev1));
   std::vector<std::vector<uint8_t>> results((size_t)n_clusters);
-  // pass 0: banded workspace for every cluster; pass 1: clusters whose full-matrix fallback did
-  // not fit get a full-size DP pool, a few at a time
-  std::vector<int64_t> todo((size_t)n_clusters);
-  for (int64_t c = 0; c < n_clusters; ++c) todo[(size_t)c] = c;
+  // fast path: the LDS-resident kernel, sized for the common case (banded rows, a graph ~1.5 x the longest
+  // read); clusters that outgrow that (band lost -> full matrix, more nodes) get a second, roomier LDS
+  // round when that still fits; what is left (status 3) falls through to the HBM kernel:
+  // pass 0 with a banded workspace, pass 1 with a full-size DP pool
+  std::vector<int64_t> todo;
+  const bool use_lds = getenv("SVDSS_POA_HBM") == nullptr;
+  std::vector<int64_t> cur((size_t)n_clusters), retry;
+  for (int64_t c = 0; c < n_clusters; ++c) cur[(size_t)c] = c;
+  for (int round = 0; round < 2 && !cur.empty(); ++round) {
+    struct Cand { int64_t c; size_t lds; PoaLdsTask t; };
+    std::vector<Cand> cands;
+    const size_t LDS_MAX = 160 * 1024 - 512;
+    for (int64_t c : cur) {
+      PoaLdsTask t;
+      memset(&t, 0, sizeof t);
+      t.seq_first = cluster_off[c];
+      t.n_seqs = cluster_off[c + 1] - cluster_off[c];
+      int64_t tot = 0, maxl = 0;
+      for (int64_t s = t.seq_first; s < t.seq_first + t.n_seqs; ++s) {
+        const int64_t l = seq_off[s + 1] - seq_off[s];
+        tot += l;
+        if (l > maxl) maxl = l;
+      }
+      // the graph rarely grows beyond ~1.5 x the longest read; cap the LDS graph there (a cluster that
+      // outgrows it is redone in HBM).  SVDSS_POA_NC scales the estimate (percent).
+      const int nc_pct = round ? 300 : getenv("SVDSS_POA_NC") ? std::max(atoi(getenv("SVDSS_POA_NC")), 100) : 150;
+      int64_t nc = std::min<int64_t>(tot + 2, maxl * nc_pct / 100 + 8 * t.n_seqs + 64);
+      if (nc > 65000) nc = 65000;
+      const int64_t ecap = std::min<int64_t>(nc + nc / (round ? 2 : 4) + t.n_seqs + 64, 65000);
+      const int64_t wcap = round ? maxl + 1 : std::min<int64_t>(2 * (10 + (int64_t)(0.01 * (double)maxl)) + 129, maxl + 1);
+      int64_t ws = 64;
+      while (ws < wcap) ws <<= 1;
+      int64_t ring = round ? 4 : 8;
+      t.nc = (int32_t)nc; t.ec = (int32_t)ecap; t.max_len = (int32_t)maxl; t.ws = (int32_t)ws;
+      size_t lds = poa_lds_bytes(t.nc, t.ec, t.max_len, t.ws, (int)ring);
+      // two clusters per CU when four ring rows instead of eight make that possible
+      if (lds > LDS_MAX / 2 && 3 * 6 * ws >= nc && poa_lds_bytes(t.nc, t.ec, t.max_len, t.ws, 4) <= LDS_MAX / 2) {
+        ring = 4;
+        lds = poa_lds_bytes(t.nc, t.ec, t.max_len, t.ws, 4);
+      }
+      t.ring = (int32_t)ring;
+      if (3 * (ring + 2) * ws < nc || ws > 1024) lds = LDS_MAX + 1;   // column scratch must hold one int per node
+      if (!use_lds || lds > LDS_MAX || t.n_seqs <= 0) { todo.push_back(c); if (t.n_seqs > 0) ++b->n_hbm; continue; }
+      cands.push_back(Cand{c, lds, t});
+    }
+    // size classes so that small clusters are not charged the LDS of the largest one
+    const size_t classes[4] = {LDS_MAX / 4, LDS_MAX / 3, LDS_MAX / 2, LDS_MAX};
+    for (int cls = 0; cls < 4; ++cls) {
+      std::vector<Cand*> grp;
+      for (Cand& cd : cands)
+        if (cd.lds <= classes[cls] && (cls == 0 || cd.lds > classes[cls - 1])) grp.push_back(&cd);
+      size_t pos = 0;
+      while (pos < grp.size()) {
+        std::vector<PoaLdsTask> tasks;
+        std::vector<int64_t> ids;
+        int64_t w32 = 0, w8 = 0;
+        size_t lds = 0;
+        const int64_t budget32 = (int64_t)3 << 30;
+        while (pos < grp.size()) {
+          PoaLdsTask t = grp[pos]->t;
+          const int64_t dp = 4 * (int64_t)t.nc * t.ws, opc = (int64_t)t.nc + t.max_len + 4;
+          const int64_t need = 12 * (int64_t)t.nc + dp + 4 * opc;
+          if (!tasks.empty() && w32 + need > budget32) break;
+          t.row_off = w32; w32 += 7 * (int64_t)t.nc;
+          t.dp_off = w32; w32 += dp;
+          t.aln_off = w32; w32 += 5 * (int64_t)t.nc;
+          t.op_off = w32; w32 += 4 * opc;
+          t.cons_off = w8; w8 += t.nc;
+          lds = std::max(lds, grp[pos]->lds);
+          tasks.push_back(t);
+          ids.push_back(grp[pos]->c);
+          ++pos;
+        }
+        const int64_t nt = (int64_t)tasks.size();
+        int why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        DevMem3 d_tasks, d32, d8, d_len, d_st;
+        if ((rc = d_tasks.alloc(sizeof(PoaLdsTask) * (size_t)nt)) || (rc = d32.alloc(sizeof(int32_t) * (size_t)w32)) ||
+            (rc = d8.alloc((size_t)w8)) || (rc = d_len.alloc(sizeof(int32_t) * (size_t)nt)) ||
+            (rc = d_st.alloc(sizeof(int32_t) * (size_t)nt)))
+          return rc;
+        HIPCHK3(hipMemcpy(d_tasks.p, tasks.data(), sizeof(PoaLdsTask) * (size_t)nt, hipMemcpyHostToDevice));
+        HIPCHK3(hipMemset(d_st.p, 0xff, sizeof(int32_t) * (size_t)nt));
+        HIPCHK3(hipEventRecord(ev0, 0));
+        HIPCHK3(poa_lds_launch((const PoaLdsTask*)d_tasks.p, (int)nt, lds, (const uint8_t*)d_seqs.p, (const int64_t*)d_off.p,
+                               (int32_t*)d32.p, (uint8_t*)d8.p, (int32_t*)d_len.p, (int32_t*)d_st.p,
+                               (unsigned long long*)d_cells.p));
+        HIPCHK3(hipEventRecord(ev1, 0));
+        HIPCHK3(hipDeviceSynchronize());
+        float ms = 0.f;
+        HIPCHK3(hipEventElapsedTime(&ms, ev0, ev1));
+        b->kernel_ms += ms;
+        std::vector<int32_t> lens((size_t)nt), st((size_t)nt);
+        std::vector<uint8_t> h8((size_t)w8);
+        HIPCHK3(hipMemcpy(lens.data(), d_len.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+        HIPCHK3(hipMemcpy(st.data(), d_st.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+        if (w8) HIPCHK3(hipMemcpy(h8.data(), d8.p, (size_t)w8, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < nt; ++k) {
+          if (st[(size_t)k] == 0) {
+            const uint8_t* src = h8.data() + tasks[(size_t)k].cons_off;
+            results[(size_t)ids[(size_t)k]].assign(src, src + lens[(size_t)k]);
+          } else {
+            const int reason = (st[(size_t)k] >> 8) & 7;
+            if (round == 0 && (reason == 3 || reason == 4 || reason == 5)) retry.push_back(ids[(size_t)k]);
+            else { todo.push_back(ids[(size_t)k]); ++b->n_hbm; }
+            ++why[reason];
+            if (getenv("SVDSS_DEBUG") && why[5] <= 3 && ((st[(size_t)k] >> 8) & 7) == 5)
+              fprintf(stderr, "[poa]   capacity: nc %d ec %d ws %d ring %d max_len %d n %lld -> %d\n", tasks[(size_t)k].nc, tasks[(size_t)k].ec, tasks[(size_t)k].ws, tasks[(size_t)k].ring, tasks[(size_t)k].max_len, (long long)tasks[(size_t)k].n_seqs, lens[(size_t)k]);
+          }
+        }
+        if (getenv("SVDSS_DEBUG"))
+          fprintf(stderr, "[poa] lds round %d: %lld clusters, lds %zu B, not done: first-read %d preds %d width %d band %d capacity %d other %d\n",
+                  round, (long long)nt, lds, why[1], why[2], why[3], why[4], why[5], why[0] + why[6] + why[7]);
+      }
+    }
+    cur.swap(retry);
+    retry.clear();
+  }
+  std::sort(todo.begin(), todo.end());
   for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
     std::vector<int64_t> next;
     size_t pos = 0;
@@ -536,6 +656,7 @@ extern "C" int64_t svdss_poa_batch_nclusters(const svdss_poa_batch_t* b) { retur
 extern "C" int64_t svdss_poa_batch_total(const svdss_poa_batch_t* b) { return b ? (int64_t)b->cons.size() : -1; }
 extern "C" int64_t svdss_poa_batch_cells(const svdss_poa_batch_t* b) { return b ? b->cells : -1; }
 extern "C" double svdss_poa_batch_kernel_ms(const svdss_poa_batch_t* b) { return b ? b->kernel_ms : -1.0; }
+extern "C" int64_t svdss_poa_batch_hbm(const svdss_poa_batch_t* b) { return b ? b->n_hbm : -1; }
 extern "C" int svdss_poa_batch_fetch(const svdss_poa_batch_t* b, int64_t* cons_len, uint8_t* cons) {
   if (!b) return SVDSS_EINVAL;
   if (cons_len) memcpy(cons_len, b->cons_len.data(), sizeof(int64_t) * b->cons_len.size());

@@ -59,3 +59,49 @@ def test_strings_and_large_cluster():
     assert got[0] == _to_str(O.poa_consensus(reads))
     assert edit_distance(list(got[0].encode()), list(_to_str(t).encode())) <= 30
     assert got[1] == "ACGTTCGTAC"
+
+
+def _mixed_clusters(seed, n_clusters):
+    rng = np.random.default_rng(seed)
+    clusters = []
+    for k in range(n_clusters):
+        length = int(rng.integers(200, 900))
+        t = rng.integers(0, 4, size=length).astype(np.uint8)
+        if k % 3 == 0:      # some reads skip a stretch: a long deletion edge whose source row leaves the LDS ring
+            cut = int(rng.integers(20, 120))
+            alt = np.concatenate([t[:length // 3], t[length // 3 + cut:]])
+        elif k % 3 == 1:    # some reads carry an insertion
+            alt = np.concatenate([t[:length // 2], rng.integers(0, 4, size=int(rng.integers(20, 150))).astype(np.uint8),
+                                  t[length // 2:]])
+        else:
+            alt = t
+        n = int(rng.integers(3, 16))
+        clusters.append([mutate(rng, alt if (i % 2) else t, float(rng.choice([0.002, 0.01, 0.03]))) for i in range(n)])
+    return clusters
+
+
+def test_lds_and_hbm_kernels_agree_with_the_oracle(monkeypatch):
+    """The LDS-resident kernel is the fast path, the HBM kernel its fallback: both must be the specification."""
+    clusters = _mixed_clusters(21, 40)
+    want = [_to_str(O.poa_consensus(reads)) for reads in clusters]
+    got, stats = caller.run_poa(clusters)
+    assert got == want
+    assert stats["hbm"] <= len(clusters) // 4          # the fast path is the one that ran
+    monkeypatch.setenv("SVDSS_POA_HBM", "1")
+    got, stats = caller.run_poa(clusters)
+    assert got == want and stats["hbm"] == len(clusters)
+    monkeypatch.delenv("SVDSS_POA_HBM")
+    monkeypatch.setenv("SVDSS_POA_NC", "100")           # LDS graphs sized for the longest read only: most outgrow
+    got, stats = caller.run_poa(clusters)               # it and are redone in the roomier second LDS round
+    assert got == want
+
+
+def test_node_with_many_predecessors_falls_back():
+    rng = np.random.default_rng(22)
+    t = rng.integers(0, 4, size=300).astype(np.uint8)
+    reads = [t]
+    for i in range(12):     # twelve different insertions at one place: the node after it gets 13 predecessors
+        reads.append(np.concatenate([t[:150], rng.integers(0, 4, size=10 + i).astype(np.uint8), t[150:]]))
+    got, stats = caller.run_poa([reads, [t, t]])
+    assert got[0] == _to_str(O.poa_consensus(reads)) and got[1] == _to_str(t)
+    assert stats["hbm"] >= 1
