@@ -1,4 +1,5 @@
-// bam_reader.h -- minimal sequential BGZF/BAM record reader for the host CLI (zlib only).
+// bam_reader.h -- BGZF/BAM record reader for the host CLI (zlib only; blocks inflated in parallel, one
+// chunk ahead of the parser).
 // Stands where htslib's hts_open / sam_hdr_read / sam_read1 / bam_aux_get stand in
 // /root/reference/ping_pong.cpp:58,247-249,196-201.  Only what `search` consumes is
 // decoded: flag, refID, l_seq, read name, 4-bit SEQ, integer aux tags (XF, HP).
@@ -9,7 +10,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct BamRecord {
@@ -44,8 +47,16 @@ struct BamRecord {
 
 class BamReader {
  public:
-  explicit BamReader(const std::string& path) : f_(fopen(path.c_str(), "rb")) {}
-  ~BamReader() { if (f_) fclose(f_); }
+  explicit BamReader(const std::string& path, int threads = 0) : f_(fopen(path.c_str(), "rb")) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+  }
+  ~BamReader() {
+    if (pending_.valid()) pending_.wait();
+    if (f_) fclose(f_);
+  }
+  BamReader(const BamReader&) = delete;
+  BamReader& operator=(const BamReader&) = delete;
   bool ok() const { return f_ != nullptr; }
   const std::string& error() const { return err_; }
   const std::vector<std::string>& ref_names() const { return refs_; }
@@ -74,7 +85,8 @@ class BamReader {
   }
 
   // 1 = record read, 0 = clean end of file, -1 = error
-  int next(BamRecord& r) {
+  // (want_qual = false leaves r.qual empty: `search` never looks at qualities)
+  int next(BamRecord& r, bool want_qual = true) {
     int32_t block_size;
     size_t got = read_some(&block_size, 4);
     if (got == 0) return 0;
@@ -109,7 +121,7 @@ class BamReader {
     memcpy(&r.isize, p + 28, 4);
     r.seq4.assign(p + o, p + o + (size_t)(l_seq + 1) / 2);
     o += (size_t)(l_seq + 1) / 2;
-    r.qual.assign(p + o, p + o + (size_t)l_seq);
+    if (want_qual) r.qual.assign(p + o, p + o + (size_t)l_seq); else r.qual.clear();
     o += (size_t)l_seq;
     r.aux.assign(p + o, p + block_size);
     return 1;
@@ -159,13 +171,13 @@ class BamReader {
   bool fail(const char* m) { err_ = m; return false; }
   bool read(void* dst, size_t n) { return read_some(dst, n) == n; }
 
-  // reads up to n uncompressed bytes, refilling from BGZF blocks
+  // reads up to n uncompressed bytes, refilling from inflated chunks of BGZF blocks
   size_t read_some(void* dst, size_t n) {
     size_t done = 0;
     while (done < n) {
       if (upos_ == ublock_.size()) {
-        if (!next_block()) break;
-        if (ublock_.empty()) continue;   // empty block (EOF marker) -- keep going
+        if (!next_chunk()) break;
+        if (ublock_.empty()) continue;   // only empty blocks (EOF markers) -- keep going
       }
       const size_t take = std::min(n - done, ublock_.size() - upos_);
       memcpy((uint8_t*)dst + done, ublock_.data() + upos_, take);
@@ -175,53 +187,106 @@ class BamReader {
     return done;
   }
 
-  bool next_block() {
-    uint8_t h[18];
-    const size_t g = fread(h, 1, 18, f_);
-    if (g == 0) return false;
-    if (g != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err_ = "bad BGZF block"; return false; }
-    uint16_t xlen;
-    memcpy(&xlen, h + 10, 2);
-    // find the BC subfield (normally the only one, right at h[12..17])
-    std::vector<uint8_t> extra(xlen);
-    memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
-    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6u, f_) != xlen - 6u) { err_ = "bad BGZF block"; return false; }
-    int bsize = -1;
-    for (size_t o = 0; o + 4 <= extra.size();) {
-      uint16_t slen;
-      memcpy(&slen, &extra[o + 2], 2);
-      if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) {
-        uint16_t v; memcpy(&v, &extra[o + 4], 2); bsize = v; break;
-      }
-      o += 4u + slen;
-    }
-    if (bsize < 0) { err_ = "BGZF block without BC field"; return false; }
-    const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
-    cbuf_.resize(cdata + 8);
-    if (fread(cbuf_.data(), 1, cdata + 8, f_) != cdata + 8) { err_ = "truncated BGZF block"; return false; }
-    uint32_t isize;
-    memcpy(&isize, cbuf_.data() + cdata + 4, 4);
-    ublock_.resize(isize);
+  // BGZF blocks are independent deflate streams (<= 64 KiB each): a chunk of kChunkBlocks blocks is read
+  // sequentially, inflated by `threads_` workers, and the next chunk is prepared in the background while the
+  // caller parses the current one (htslib's hts_set_threads plays this role for the reference).
+  struct Chunk {
+    std::vector<uint8_t> data;
+    bool eof = false;
+    std::string err;
+  };
+  struct BlockRef { size_t coff, clen, uoff; uint32_t isize, crc; };
+  static constexpr size_t kChunkBlocks = 512;
+
+  bool next_chunk() {
+    if (eof_seen_) return false;   // the final chunk was already handed out
+    if (!pending_.valid()) pending_ = std::async(std::launch::async, [this] { return load_chunk(); });
+    Chunk c = pending_.get();
+    if (!c.err.empty()) { err_ = c.err; eof_seen_ = true; return false; }
+    if (c.eof) eof_seen_ = true;
+    else pending_ = std::async(std::launch::async, [this] { return load_chunk(); });
+    ublock_.swap(c.data);
     upos_ = 0;
-    if (isize == 0) return true;
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { err_ = "zlib init failed"; return false; }
-    zs.next_in = cbuf_.data();
-    zs.avail_in = (uInt)cdata;
-    zs.next_out = ublock_.data();
-    zs.avail_out = isize;
-    const int rc = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
-    if (rc != Z_STREAM_END) { err_ = "BGZF inflate failed"; return false; }
-    return true;
+    return !(c.eof && ublock_.empty());
+  }
+
+  // runs on a background thread; the only code that touches f_ after construction
+  Chunk load_chunk() {
+    Chunk c;
+    std::vector<uint8_t> comp;
+    std::vector<BlockRef> blocks;
+    size_t total = 0;
+    while (blocks.size() < kChunkBlocks) {
+      uint8_t h[18];
+      const size_t g = fread(h, 1, 18, f_);
+      if (g == 0) { c.eof = true; break; }
+      if (g != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { c.err = "bad BGZF block"; return c; }
+      uint16_t xlen;
+      memcpy(&xlen, h + 10, 2);
+      // find the BC subfield (normally the only one, right at h[12..17])
+      std::vector<uint8_t> extra(xlen);
+      memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
+      if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6u, f_) != xlen - 6u) { c.err = "bad BGZF block"; return c; }
+      int bsize = -1;
+      for (size_t o = 0; o + 4 <= extra.size();) {
+        uint16_t slen;
+        memcpy(&slen, &extra[o + 2], 2);
+        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) {
+          uint16_t v; memcpy(&v, &extra[o + 4], 2); bsize = v; break;
+        }
+        o += 4u + slen;
+      }
+      if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) { c.err = "BGZF block without BC field"; return c; }
+      const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
+      const size_t at = comp.size();
+      comp.resize(at + cdata + 8);
+      if (fread(comp.data() + at, 1, cdata + 8, f_) != cdata + 8) { c.err = "truncated BGZF block"; return c; }
+      BlockRef b;
+      b.coff = at; b.clen = cdata; b.uoff = total;
+      memcpy(&b.crc, comp.data() + at + cdata, 4);
+      memcpy(&b.isize, comp.data() + at + cdata + 4, 4);
+      total += b.isize;
+      blocks.push_back(b);
+    }
+    c.data.resize(total);
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, blocks.size()));
+    std::vector<std::string> errs((size_t)nt);
+    auto work = [&](int t) {
+      for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)nt) {
+        const BlockRef& b = blocks[i];
+        if (b.isize == 0) continue;
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { errs[(size_t)t] = "zlib init failed"; return; }
+        zs.next_in = comp.data() + b.coff;
+        zs.avail_in = (uInt)b.clen;
+        zs.next_out = c.data.data() + b.uoff;
+        zs.avail_out = b.isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END) { errs[(size_t)t] = "BGZF inflate failed"; return; }
+        if ((uint32_t)crc32(0L, c.data.data() + b.uoff, b.isize) != b.crc) { errs[(size_t)t] = "BGZF block CRC mismatch"; return; }
+      }
+    };
+    if (nt == 1) work(0);
+    else {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+      work(0);
+      for (std::thread& th : pool) th.join();
+    }
+    for (const std::string& e : errs) if (!e.empty()) { c.err = e; break; }
+    return c;
   }
 
   FILE* f_;
+  int threads_ = 1;
+  std::future<Chunk> pending_;
+  bool eof_seen_ = false;
   std::string err_;
   std::vector<std::string> refs_;
   std::vector<int32_t> ref_lens_;
   std::string text_;
-  std::vector<uint8_t> cbuf_, ublock_, buf_;
+  std::vector<uint8_t> ublock_, buf_;
   size_t upos_ = 0;
 };

@@ -9,12 +9,18 @@
 // (ping_pong.cpp:213-236), logs to stderr, fatal conditions exit(1).
 // `smooth` and `call` are not part of this build yet.
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <deque>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/svdss_hip.h"
@@ -76,6 +82,7 @@ struct Options {
   float accp = 0.98f, min_ratio = 0.97f;
   bool useht = true;
   int threads = 4, bsize = 10000, omax = 100000;  // config.hpp:68-69,88
+  int io_threads = 0;                              // BGZF inflate workers (0: up to 16)
   bool putative = true, assemble = true, verbose = false, version = false, help = false;
 };
 
@@ -97,6 +104,7 @@ static Options parse(int argc, char** argv) {
     else if (take(argc, argv, i, "--bam", v)) o.bam = v;
     else if (take(argc, argv, i, "--fastx", v)) o.fastx = v;
     else if (take(argc, argv, i, "--threads", v)) o.threads = atoi(v.c_str());
+    else if (take(argc, argv, i, "--io-threads", v)) o.io_threads = atoi(v.c_str());
     else if (take(argc, argv, i, "--bsize", v)) o.bsize = atoi(v.c_str());
     else if (take(argc, argv, i, "--omax", v)) o.omax = atoi(v.c_str());
     else if (take(argc, argv, i, "--reference", v)) o.reference = v;
@@ -158,24 +166,75 @@ static int main_index(int argc, char** argv) {
 }
 
 // --------------------------------------------------------------- search
+//
+// Three stages run concurrently, connected by bounded queues: (1) BGZF inflate + record parsing + nt6
+// encoding into GPU-ready batches, (2) the GPU search of one batch, (3) formatting and writing the text of
+// the previous batch.  The reference interleaves the same work inside one OpenMP loop
+// (ping_pong.cpp:329-376: thread 0 loads and prints while the others search).
 
 struct Read {
   std::string name;
   int hp = 0;
-  int64_t off = 0, len = 0;   // into the batch buffer
+  int64_t len = 0;
   int64_t first = 0, count = 0;  // into the result arrays (-1: not searched)
+};
+
+struct SearchBatch {
+  std::vector<Read> reads;
+  std::vector<uint8_t> gbuf;     // nt6 bases of the searched reads, back to back
+  std::vector<int64_t> goff;
+  std::vector<size_t> gidx;      // searched read -> index into reads
+  std::vector<int32_t> qs, ln;   // results
+};
+
+template <class T>
+class BoundedQueue {
+ public:
+  explicit BoundedQueue(size_t cap) : cap_(cap) {}
+  void push(std::unique_ptr<T> v) {
+    std::unique_lock<std::mutex> lk(m_);
+    not_full_.wait(lk, [&] { return q_.size() < cap_; });
+    q_.push_back(std::move(v));
+    not_empty_.notify_one();
+  }
+  // nullptr = the producer closed the queue and it is drained
+  std::unique_ptr<T> pop() {
+    std::unique_lock<std::mutex> lk(m_);
+    not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return nullptr;
+    std::unique_ptr<T> v = std::move(q_.front());
+    q_.pop_front();
+    not_full_.notify_one();
+    return v;
+  }
+  void close() {
+    std::lock_guard<std::mutex> lk(m_);
+    closed_ = true;
+    not_empty_.notify_all();
+  }
+
+ private:
+  size_t cap_;
+  std::deque<std::unique_ptr<T>> q_;
+  std::mutex m_;
+  std::condition_variable not_full_, not_empty_;
+  bool closed_ = false;
 };
 
 int main_search(const Options& o) {
   logmsg("info", "Restoring index..");
   svdss_index_t* ix = nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&] { return std::to_string(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
   check(svdss_index_load(o.index.c_str(), &ix), "svdss_index_load");
+  if (o.verbose) logmsg("debug", "index file read at +" + since() + " s");
   check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
+  if (o.verbose) logmsg("debug", "index and k-mer table on the device at +" + since() + " s");
   const bool bam_mode = !o.bam.empty();
   BamReader* bam = nullptr;
   FastxReader* fx = nullptr;
   if (bam_mode) {
-    bam = new BamReader(o.bam);
+    bam = new BamReader(o.bam, o.io_threads);
     if (!bam->ok() || !bam->read_header()) die("cannot read " + o.bam + ": " + bam->error());
   } else {
     logmsg("warning", "FASTX mode is not optimized (higher running times and larger SFSs set).");
@@ -187,119 +246,131 @@ int main_search(const Options& o) {
   // One GPU launch covers many reference-sized batches; the text is still emitted batch by
   // batch, thread slice by thread slice, read names in std::map order (ping_pong.cpp:215-217).
   const int64_t super = std::max<int64_t>(o.bsize, 262144 / o.bsize * (int64_t)o.bsize);
-  svdss_sfs_batch_t* res = nullptr;
-  std::vector<uint8_t> buf;
-  std::vector<int64_t> offsets;
-  std::vector<Read> reads;
-  std::string out;
-  uint64_t total_sfs = 0, n_seen = 0;
-  bool eof = false;
+  // a packed pair of 4-bit BAM bases -> two nt6 codes
   uint8_t nt16_to_nt6[16];
   check(svdss_nt6_encode(NT16, 16, nt16_to_nt6), "svdss_nt6_encode");
-  while (!eof) {
-    buf.clear();
-    offsets.assign(1, 0);
-    reads.clear();
-    while ((int64_t)reads.size() < super) {
-      Read r;
-      bool search = true;
-      if (bam_mode) {
-        BamRecord rec;
-        const int rc = bam->next(rec);
-        if (rc == 0) { eof = true; break; }
-        if (rc < 0) die("error reading " + o.bam + ": " + bam->error());
-        ++n_seen;
-        if (rec.flag & (4 | 2048 | 256)) continue;                     // ping_pong.cpp:66-69
-        if (rec.l_seq < 100) {                                         // :70-75
-          logmsg("warning", "Alignment filtered due to l_qseq. Why are we here? Please check");
-          continue;
+  uint16_t pair_to_nt6[256];
+  for (int v = 0; v < 256; ++v) pair_to_nt6[v] = (uint16_t)(nt16_to_nt6[v >> 4] | (nt16_to_nt6[v & 15] << 8));
+
+  BoundedQueue<SearchBatch> parsed(2), searched(2);
+  uint64_t n_seen = 0, total_sfs = 0;
+
+  std::thread producer([&] {
+    bool eof = false;
+    BamRecord rec;   // reused: its buffers keep their capacity
+    while (!eof) {
+      std::unique_ptr<SearchBatch> bt(new SearchBatch);
+      bt->goff.assign(1, 0);
+      while ((int64_t)bt->reads.size() < super) {
+        Read r;
+        bool search = true;
+        if (bam_mode) {
+          const int rc = bam->next(rec, false);
+          if (rc == 0) { eof = true; break; }
+          if (rc < 0) die("error reading " + o.bam + ": " + bam->error());
+          ++n_seen;
+          if (rec.flag & (4 | 2048 | 256)) continue;                     // ping_pong.cpp:66-69
+          if (rec.l_seq < 100) {                                         // :70-75
+            logmsg("warning", "Alignment filtered due to l_qseq. Why are we here? Please check");
+            continue;
+          }
+          if (rec.tid < 0) die("core.tid < 0. Why are we here? Please check");  // :76-79
+          int64_t xf = 0, hp = 0;
+          BamReader::aux_int(rec, "XF", xf);                             // :196-201, missing => 0
+          BamReader::aux_int(rec, "HP", hp);
+          r.name = rec.qname;
+          r.hp = (int)hp;
+          search = !(o.putative && xf != 0);                             // :202-203
+          if (search) {
+            r.len = rec.l_seq;
+            const size_t at = bt->gbuf.size();
+            bt->gbuf.resize(at + (size_t)rec.l_seq + 1);
+            uint8_t* dst = bt->gbuf.data() + at;
+            const size_t pairs = ((size_t)rec.l_seq + 1) / 2;
+            for (size_t k = 0; k < pairs; ++k) memcpy(dst + 2 * k, &pair_to_nt6[rec.seq4[k]], 2);
+            bt->gbuf.resize(at + (size_t)rec.l_seq);
+          }
+        } else {
+          std::string seq;
+          if (!fx->next(r.name, seq)) { eof = true; break; }
+          ++n_seen;
+          r.len = (int64_t)seq.size();
+          const size_t at = bt->gbuf.size();
+          bt->gbuf.resize(at + seq.size());
+          svdss_nt6_encode(seq.data(), (int64_t)seq.size(), bt->gbuf.data() + at);
         }
-        if (rec.tid < 0) die("core.tid < 0. Why are we here? Please check");  // :76-79
-        int64_t xf = 0, hp = 0;
-        BamReader::aux_int(rec, "XF", xf);                             // :196-201, missing => 0
-        BamReader::aux_int(rec, "HP", hp);
-        r.name = rec.qname;
-        r.hp = (int)hp;
-        r.len = rec.l_seq;
-        r.off = (int64_t)buf.size();
-        buf.resize(buf.size() + (size_t)rec.l_seq);
-        for (int k = 0; k < rec.l_seq; ++k) {
-          const int code = (rec.seq4[(size_t)k >> 1] >> ((~k & 1) << 2)) & 0xf;
-          buf[(size_t)r.off + (size_t)k] = nt16_to_nt6[code];
+        if (search) {
+          bt->goff.push_back((int64_t)bt->gbuf.size());
+          bt->gidx.push_back(bt->reads.size());
+        } else {
+          r.count = -1;
+          r.len = 0;
         }
-        search = !(o.putative && xf != 0);                             // :202-203
-      } else {
-        std::string seq;
-        if (!fx->next(r.name, seq)) { eof = true; break; }
-        ++n_seen;
-        r.len = (int64_t)seq.size();
-        r.off = (int64_t)buf.size();
-        buf.resize(buf.size() + seq.size());
-        svdss_nt6_encode(seq.data(), (int64_t)seq.size(), buf.data() + r.off);
+        bt->reads.push_back(std::move(r));
       }
-      if (!search) { buf.resize((size_t)r.off); r.count = -1; r.len = 0; }
-      reads.push_back(r);
+      if (!bt->reads.empty()) parsed.push(std::move(bt));
     }
-    if (reads.empty()) break;
-    // searched reads only go to the GPU
-    std::vector<uint8_t> gbuf;
-    std::vector<int64_t> goff(1, 0);
-    std::vector<size_t> gidx;
-    gbuf.reserve(buf.size());
-    for (size_t i = 0; i < reads.size(); ++i) {
-      if (reads[i].count < 0) continue;
-      gbuf.insert(gbuf.end(), buf.begin() + reads[i].off, buf.begin() + reads[i].off + reads[i].len);
-      goff.push_back((int64_t)gbuf.size());
-      gidx.push_back(i);
-    }
-    std::vector<int64_t> counts(gidx.size());
-    std::vector<int32_t> qs, ln;
-    if (!gidx.empty()) {
-      check(svdss_sfs_search_batch(ix, gbuf.data(), goff.data(), (int64_t)gidx.size(),
-                                   o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch");
-      qs.resize((size_t)svdss_sfs_batch_total(res));
-      ln.resize(qs.size());
-      check(svdss_sfs_batch_fetch(res, counts.data(), qs.data(), ln.data(), nullptr), "svdss_sfs_batch_fetch");
-      int64_t acc = 0;
-      for (size_t k = 0; k < gidx.size(); ++k) {
-        reads[gidx[k]].first = acc;
-        reads[gidx[k]].count = counts[k];
-        acc += counts[k];
-      }
-    }
-    // output_batch order: reference batches of bsize reads -> thread t takes reads n with
-    // n % T == t (ping_pong.cpp:59,101-104) -> std::map<qname, vector<SFS>> order (:217)
-    for (size_t b0 = 0; b0 < reads.size(); b0 += (size_t)o.bsize) {
-      const size_t b1 = std::min(reads.size(), b0 + (size_t)o.bsize);
-      for (int t = 0; t < o.threads; ++t) {
-        std::map<std::string, std::vector<size_t>> by_name;
-        for (size_t n = b0 + (size_t)t; n < b1; n += (size_t)o.threads)
-          if (reads[n].count >= 0) by_name[reads[n].name].push_back(n);
-        for (const auto& kv : by_name) {
-          bool first = true;
-          for (size_t n : kv.second) {
-            const Read& r = reads[n];
-            for (int64_t k = 0; k < r.count; ++k) {
-              out += first ? r.name : std::string("*");
-              out += '\t';
-              out += std::to_string(qs[(size_t)(r.first + k)]);
-              out += '\t';
-              out += std::to_string(ln[(size_t)(r.first + k)]);
-              out += '\t';
-              out += std::to_string(r.hp);
-              out += "\t\n";
-              first = false;
-              ++total_sfs;
+    parsed.close();
+  });
+
+  std::thread writer([&] {
+    std::string out;
+    while (std::unique_ptr<SearchBatch> bt = searched.pop()) {
+      const std::vector<Read>& reads = bt->reads;
+      // output_batch order: reference batches of bsize reads -> thread t takes reads n with
+      // n % T == t (ping_pong.cpp:59,101-104) -> std::map<qname, vector<SFS>> order (:217)
+      char num[64];
+      for (size_t b0 = 0; b0 < reads.size(); b0 += (size_t)o.bsize) {
+        const size_t b1 = std::min(reads.size(), b0 + (size_t)o.bsize);
+        for (int t = 0; t < o.threads; ++t) {
+          std::map<std::string, std::vector<size_t>> by_name;
+          for (size_t n = b0 + (size_t)t; n < b1; n += (size_t)o.threads)
+            if (reads[n].count >= 0) by_name[reads[n].name].push_back(n);
+          for (const auto& kv : by_name) {
+            bool first = true;
+            for (size_t n : kv.second) {
+              const Read& r = reads[n];
+              for (int64_t k = 0; k < r.count; ++k) {
+                if (first) out += r.name; else out += '*';
+                const int m = snprintf(num, sizeof num, "\t%d\t%d\t%d\t\n", bt->qs[(size_t)(r.first + k)],
+                                       bt->ln[(size_t)(r.first + k)], r.hp);
+                out.append(num, (size_t)m);
+                first = false;
+                ++total_sfs;
+              }
             }
           }
         }
+        if (out.size() > (1u << 20)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
       }
-      if (out.size() > (1u << 20)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
     }
+    fwrite(out.data(), 1, out.size(), stdout);
+    fflush(stdout);
+  });
+
+  svdss_sfs_batch_t* res = nullptr;
+  while (std::unique_ptr<SearchBatch> bt = parsed.pop()) {
+    if (!bt->gidx.empty()) {
+      std::vector<int64_t> counts(bt->gidx.size());
+      check(svdss_sfs_search_batch(ix, bt->gbuf.data(), bt->goff.data(), (int64_t)bt->gidx.size(),
+                                   o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch");
+      bt->qs.resize((size_t)svdss_sfs_batch_total(res));
+      bt->ln.resize(bt->qs.size());
+      check(svdss_sfs_batch_fetch(res, counts.data(), bt->qs.data(), bt->ln.data(), nullptr), "svdss_sfs_batch_fetch");
+      int64_t acc = 0;
+      for (size_t k = 0; k < bt->gidx.size(); ++k) {
+        bt->reads[bt->gidx[k]].first = acc;
+        bt->reads[bt->gidx[k]].count = counts[k];
+        acc += counts[k];
+      }
+    }
+    std::vector<uint8_t>().swap(bt->gbuf);
+    searched.push(std::move(bt));
   }
-  fwrite(out.data(), 1, out.size(), stdout);
-  fflush(stdout);
-  if (o.verbose) logmsg("debug", std::to_string(n_seen) + " records read, " + std::to_string(total_sfs) + " SFS written");
+  searched.close();
+  producer.join();
+  writer.join();
+  if (o.verbose) logmsg("debug", std::to_string(n_seen) + " records read, " + std::to_string(total_sfs) + " SFS written at +" + since() + " s");
   svdss_sfs_batch_free(res);
   svdss_index_free(ix);
   delete bam;
