@@ -16,16 +16,18 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/svdss_hip.h"
-#include "poa_lds.h"
+#include "poa_wave.h"
 
 extern thread_local std::string g_svdss_hip_err;
 
@@ -454,11 +456,11 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   std::vector<int64_t> cur((size_t)n_clusters), retry;
   for (int64_t c = 0; c < n_clusters; ++c) cur[(size_t)c] = c;
   for (int round = 0; round < 2 && !cur.empty(); ++round) {
-    struct Cand { int64_t c; size_t lds; PoaLdsTask t; };
+    struct Cand { int64_t c; size_t lds; int cols; PoaWaveTask t; };
     std::vector<Cand> cands;
     const size_t LDS_MAX = 160 * 1024 - 512;
     for (int64_t c : cur) {
-      PoaLdsTask t;
+      PoaWaveTask t;
       memset(&t, 0, sizeof t);
       t.seq_first = cluster_off[c];
       t.n_seqs = cluster_off[c + 1] - cluster_off[c];
@@ -468,96 +470,128 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         tot += l;
         if (l > maxl) maxl = l;
       }
-      // the graph rarely grows beyond ~1.5 x the longest read; cap the LDS graph there (a cluster that
-      // outgrows it is redone in HBM).  SVDSS_POA_NC scales the estimate (percent).
+      // the graph rarely grows beyond ~1.5 x the longest read (round 1: 3 x); a cluster that outgrows its
+      // allocation is redone.  SVDSS_POA_NC scales the first estimate (percent).
       const int nc_pct = round ? 300 : getenv("SVDSS_POA_NC") ? std::max(atoi(getenv("SVDSS_POA_NC")), 100) : 150;
       int64_t nc = std::min<int64_t>(tot + 2, maxl * nc_pct / 100 + 8 * t.n_seqs + 64);
       if (nc > 65000) nc = 65000;
-      const int64_t ecap = std::min<int64_t>(nc + nc / (round ? 2 : 4) + t.n_seqs + 64, 65000);
+      const int64_t ecap = std::min<int64_t>(nc + nc / (round ? 2 : 4) + t.n_seqs + 64, 100000);
+      // widest row: the band (round 0) or the full matrix (round 1, after a band fallback did not fit)
       const int64_t wcap = round ? maxl + 1 : std::min<int64_t>(2 * (10 + (int64_t)(0.01 * (double)maxl)) + 129, maxl + 1);
       int64_t ws = 64;
       while (ws < wcap) ws <<= 1;
-      int64_t ring = round ? 4 : 8;
-      t.nc = (int32_t)nc; t.ec = (int32_t)ecap; t.max_len = (int32_t)maxl; t.ws = (int32_t)ws;
-      size_t lds = poa_lds_bytes(t.nc, t.ec, t.max_len, t.ws, (int)ring);
-      // two clusters per CU when four ring rows instead of eight make that possible
-      if (lds > LDS_MAX / 2 && 3 * 6 * ws >= nc && poa_lds_bytes(t.nc, t.ec, t.max_len, t.ws, 4) <= LDS_MAX / 2) {
-        ring = 4;
-        lds = poa_lds_bytes(t.nc, t.ec, t.max_len, t.ws, 4);
-      }
+      const int64_t rs = (wcap + 3) & ~(int64_t)3;
+      const int cols = wcap <= 64 ? 1 : wcap <= 192 ? 3 : 5;
+      const int64_t ring = 4;
+      t.nc = (int32_t)nc; t.ec = (int32_t)ecap; t.max_len = (int32_t)maxl; t.ws = (int32_t)ws; t.rs = (int32_t)rs;
       t.ring = (int32_t)ring;
-      if (3 * (ring + 2) * ws < nc || ws > 1024) lds = LDS_MAX + 1;   // column scratch must hold one int per node
-      if (!use_lds || lds > LDS_MAX || t.n_seqs <= 0) { todo.push_back(c); if (t.n_seqs > 0) ++b->n_hbm; continue; }
-      cands.push_back(Cand{c, lds, t});
+      const size_t lds = poa_wave_lds_bytes(t.nc, t.max_len, t.rs, t.ring);
+      if (!use_lds || lds > LDS_MAX || ws > 4096 || t.n_seqs <= 0 || t.n_seqs > 8191) {
+        todo.push_back(c);
+        if (t.n_seqs > 0) ++b->n_hbm;
+        continue;
+      }
+      cands.push_back(Cand{c, lds, cols, t});
     }
-    // size classes so that small clusters are not charged the LDS of the largest one
-    const size_t classes[4] = {LDS_MAX / 4, LDS_MAX / 3, LDS_MAX / 2, LDS_MAX};
-    for (int cls = 0; cls < 4; ++cls) {
-      std::vector<Cand*> grp;
-      for (Cand& cd : cands)
-        if (cd.lds <= classes[cls] && (cls == 0 || cd.lds > classes[cls - 1])) grp.push_back(&cd);
-      size_t pos = 0;
-      while (pos < grp.size()) {
-        std::vector<PoaLdsTask> tasks;
-        std::vector<int64_t> ids;
-        int64_t w32 = 0, w8 = 0;
-        size_t lds = 0;
-        const int64_t budget32 = (int64_t)3 << 30;
-        while (pos < grp.size()) {
-          PoaLdsTask t = grp[pos]->t;
-          const int64_t dp = 4 * (int64_t)t.nc * t.ws, opc = (int64_t)t.nc + t.max_len + 4;
-          const int64_t need = 12 * (int64_t)t.nc + dp + 4 * opc;
-          if (!tasks.empty() && w32 + need > budget32) break;
-          t.row_off = w32; w32 += 7 * (int64_t)t.nc;
-          t.dp_off = w32; w32 += dp;
-          t.aln_off = w32; w32 += 5 * (int64_t)t.nc;
-          t.op_off = w32; w32 += 4 * opc;
-          t.cons_off = w8; w8 += t.nc;
-          lds = std::max(lds, grp[pos]->lds);
-          tasks.push_back(t);
-          ids.push_back(grp[pos]->c);
-          ++pos;
+    // launches are grouped by instantiation and by LDS size class, so that small clusters are not charged the
+    // LDS of the largest one (LDS decides how many sub-clusters a CU keeps in flight); the groups run
+    // concurrently on their own streams (one sub-cluster is a chain of dependent steps: the machine is
+    // filled by running many of them, whichever launch they came from)
+    struct Group {
+      int cols = 0;
+      size_t lds = 0;
+      std::vector<PoaWaveTask> tasks;
+      std::vector<int64_t> ids;
+      int64_t w32 = 0, w8 = 0;
+      DevMem3 d_tasks, d32, d8, d_len, d_st;
+      hipStream_t stream = nullptr;
+      ~Group() { if (stream) (void)hipStreamDestroy(stream); }
+    };
+    std::vector<std::unique_ptr<Group>> groups;
+    int n_cus = 256;
+    {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+    }
+    const int64_t group_budget32 = (int64_t)2 << 30;    // ints of workspace per launch
+    std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.lds > y.lds; });
+    for (int ci = 0; ci < 3; ++ci) {
+      Group* g = nullptr;
+      size_t fill = 0;   // sub-clusters that fill the machine at the group's LDS size
+      for (Cand& cd : cands) {
+        if (cd.cols != kPoaWaveCols[ci]) continue;
+        PoaWaveTask t = cd.t;
+        const int64_t need = poa_wave_ws_ints(t.nc, t.ec, t.max_len, t.ws);
+        // a new launch (with the smaller LDS of the clusters that follow) only once the current one fills all CUs
+        if (!g || g->w32 + need > group_budget32 || g->tasks.size() >= fill) {
+          groups.emplace_back(new Group);
+          g = groups.back().get();
+          g->cols = kPoaWaveCols[ci];
+          g->lds = cd.lds;
+          fill = (size_t)n_cus * std::max<size_t>(1, LDS_MAX / cd.lds);
         }
-        const int64_t nt = (int64_t)tasks.size();
-        int why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        DevMem3 d_tasks, d32, d8, d_len, d_st;
-        if ((rc = d_tasks.alloc(sizeof(PoaLdsTask) * (size_t)nt)) || (rc = d32.alloc(sizeof(int32_t) * (size_t)w32)) ||
-            (rc = d8.alloc((size_t)w8)) || (rc = d_len.alloc(sizeof(int32_t) * (size_t)nt)) ||
-            (rc = d_st.alloc(sizeof(int32_t) * (size_t)nt)))
+        t.ws_off = g->w32; g->w32 += need;
+        t.cons_off = g->w8; g->w8 += t.nc;
+        g->tasks.push_back(t);
+        g->ids.push_back(cd.c);
+      }
+    }
+    // run the groups in waves of at most ~32 GB of workspace
+    size_t gpos = 0;
+    while (gpos < groups.size()) {
+      size_t gend = gpos;
+      int64_t tot32 = 0;
+      while (gend < groups.size() && (gend == gpos || tot32 + groups[gend]->w32 <= ((int64_t)8 << 30))) tot32 += groups[gend++]->w32;
+      for (size_t gi = gpos; gi < gend; ++gi) {
+        Group& g = *groups[gi];
+        const size_t nt = g.tasks.size();
+        if ((rc = g.d_tasks.alloc(sizeof(PoaWaveTask) * nt)) || (rc = g.d32.alloc(sizeof(int32_t) * (size_t)g.w32)) ||
+            (rc = g.d8.alloc((size_t)g.w8)) || (rc = g.d_len.alloc(sizeof(int32_t) * nt)) || (rc = g.d_st.alloc(sizeof(int32_t) * nt)))
           return rc;
-        HIPCHK3(hipMemcpy(d_tasks.p, tasks.data(), sizeof(PoaLdsTask) * (size_t)nt, hipMemcpyHostToDevice));
-        HIPCHK3(hipMemset(d_st.p, 0xff, sizeof(int32_t) * (size_t)nt));
-        HIPCHK3(hipEventRecord(ev0, 0));
-        HIPCHK3(poa_lds_launch((const PoaLdsTask*)d_tasks.p, (int)nt, lds, (const uint8_t*)d_seqs.p, (const int64_t*)d_off.p,
-                               (int32_t*)d32.p, (uint8_t*)d8.p, (int32_t*)d_len.p, (int32_t*)d_st.p,
-                               (unsigned long long*)d_cells.p));
-        HIPCHK3(hipEventRecord(ev1, 0));
-        HIPCHK3(hipDeviceSynchronize());
-        float ms = 0.f;
-        HIPCHK3(hipEventElapsedTime(&ms, ev0, ev1));
-        b->kernel_ms += ms;
+        HIPCHK3(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+        HIPCHK3(hipMemcpy(g.d_tasks.p, g.tasks.data(), sizeof(PoaWaveTask) * nt, hipMemcpyHostToDevice));
+        HIPCHK3(hipMemset(g.d_st.p, 0xff, sizeof(int32_t) * nt));
+      }
+      HIPCHK3(hipDeviceSynchronize());
+      const auto t0 = std::chrono::steady_clock::now();
+      for (size_t gi = gpos; gi < gend; ++gi) {
+        Group& g = *groups[gi];
+        HIPCHK3(poa_wave_launch(g.cols, (const PoaWaveTask*)g.d_tasks.p, (int)g.tasks.size(), g.lds, (const uint8_t*)d_seqs.p,
+                                (const int64_t*)d_off.p, (int32_t*)g.d32.p, (uint8_t*)g.d8.p, (int32_t*)g.d_len.p,
+                                (int32_t*)g.d_st.p, (unsigned long long*)d_cells.p, g.stream));
+      }
+      HIPCHK3(hipDeviceSynchronize());
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      b->kernel_ms += ms;   // wall time of the concurrent launches
+      int why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int64_t n_run = 0;
+      for (size_t gi = gpos; gi < gend; ++gi) {
+        Group& g = *groups[gi];
+        const int64_t nt = (int64_t)g.tasks.size();
+        n_run += nt;
         std::vector<int32_t> lens((size_t)nt), st((size_t)nt);
-        std::vector<uint8_t> h8((size_t)w8);
-        HIPCHK3(hipMemcpy(lens.data(), d_len.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-        HIPCHK3(hipMemcpy(st.data(), d_st.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-        if (w8) HIPCHK3(hipMemcpy(h8.data(), d8.p, (size_t)w8, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> h8((size_t)g.w8);
+        HIPCHK3(hipMemcpy(lens.data(), g.d_len.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+        HIPCHK3(hipMemcpy(st.data(), g.d_st.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+        if (g.w8) HIPCHK3(hipMemcpy(h8.data(), g.d8.p, (size_t)g.w8, hipMemcpyDeviceToHost));
         for (int64_t k = 0; k < nt; ++k) {
           if (st[(size_t)k] == 0) {
-            const uint8_t* src = h8.data() + tasks[(size_t)k].cons_off;
-            results[(size_t)ids[(size_t)k]].assign(src, src + lens[(size_t)k]);
+            const uint8_t* src = h8.data() + g.tasks[(size_t)k].cons_off;
+            results[(size_t)g.ids[(size_t)k]].assign(src, src + lens[(size_t)k]);
           } else {
             const int reason = (st[(size_t)k] >> 8) & 7;
-            if (round == 0 && (reason == 3 || reason == 4 || reason == 5)) retry.push_back(ids[(size_t)k]);
-            else { todo.push_back(ids[(size_t)k]); ++b->n_hbm; }
+            if (round == 0 && (reason == 3 || reason == 4 || reason == 5)) retry.push_back(g.ids[(size_t)k]);
+            else { todo.push_back(g.ids[(size_t)k]); ++b->n_hbm; }
             ++why[reason];
-            if (getenv("SVDSS_DEBUG") && why[5] <= 3 && ((st[(size_t)k] >> 8) & 7) == 5)
-              fprintf(stderr, "[poa]   capacity: nc %d ec %d ws %d ring %d max_len %d n %lld -> %d\n", tasks[(size_t)k].nc, tasks[(size_t)k].ec, tasks[(size_t)k].ws, tasks[(size_t)k].ring, tasks[(size_t)k].max_len, (long long)tasks[(size_t)k].n_seqs, lens[(size_t)k]);
           }
         }
-        if (getenv("SVDSS_DEBUG"))
-          fprintf(stderr, "[poa] lds round %d: %lld clusters, lds %zu B, not done: first-read %d preds %d width %d band %d capacity %d other %d\n",
-                  round, (long long)nt, lds, why[1], why[2], why[3], why[4], why[5], why[0] + why[6] + why[7]);
+        groups[gi].reset();   // frees the workspace
       }
+      if (getenv("SVDSS_DEBUG")) poa_wave_debug_report();
+      if (getenv("SVDSS_DEBUG"))
+        fprintf(stderr, "[poa] wave round %d: %lld clusters in %zu launches, %.3f ms, not done: first-read %d preds %d width %d band %d capacity %d other %d\n",
+                round, (long long)n_run, gend - gpos, ms, why[1], why[2], why[3], why[4], why[5], why[0] + why[6] + why[7]);
+      gpos = gend;
     }
     cur.swap(retry);
     retry.clear();

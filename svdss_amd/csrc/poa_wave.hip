@@ -1,0 +1,849 @@
+// poa_wave.hip -- POA consensus, one wavefront per sub-cluster (fast path of svdss_poa_consensus_batch).
+//
+// Same specification as poa.hip / oracle/svdss_oracle_poa.c, bit for bit.  POA over a dozen ~1 kb reads is
+// a chain of ~10^4 short dependent steps per sub-cluster (graph rows, traceback steps); what bounds it on
+// this machine is the latency of each step and how many sub-clusters a CU can keep in flight, not bandwidth.
+// So the kernel keeps in LDS only what the row loop touches -- ~25 KB per sub-cluster, six per CU:
+//   * one 32-bit descriptor per graph row (base, up to two predecessor-row deltas, flags), rebuilt in
+//     parallel before each read is aligned, so the row loop never chases graph pointers;
+//   * the read being aligned;
+//   * a ring of the last `ring` DP rows (H, E1, E2) plus two staging rows.
+// The graph itself (int32 arrays) lives in HBM: it is touched by the parallel phases only.
+//
+//   forward    one wavefront computes a DP row per step, C consecutive band columns per lane (C = 1, 3, 5:
+//              odd strides are LDS-bank-conflict free).  The horizontal gap states are prefix maxima
+//              F(j) = max_{k<j}(H'(k)+k*e) - o - j*e: a serial pass over the lane's C columns and one DPP
+//              max-scan over the lane totals; no barrier anywhere.  HBM receives write-once streams: a
+//              32-bit *direction word* per cell that encodes every decision the traceback can take there
+//              (so the traceback never compares scores), the predecessor-row deltas of each row, and --
+//              only for rows flagged as the source of a long deletion edge -- a copy of H/E1/E2 that is
+//              read back into a staging row when its successor comes up.
+//   traceback  a register window holds the direction words of 64 rows x 4 columns along the current
+//              diagonal (one HBM latency per ~30-60 steps); the walk itself is scalar.
+//   update     parallel over the alignment: wave scans number the surviving path elements and the new
+//              nodes; every path edge touches edge lists no other edge touches, so edges are added
+//              concurrently.
+//   order      any topological order gives the same DP values, traceback (predecessor slots are edge
+//              order) and consensus.  Instead of Kahn's serial queue the kernel keeps a column rank per
+//              node (aligned nodes share a column, a read's path is column-monotone, inserted bases open
+//              new columns right after their anchor's) and rebuilds the order with scans and a counting
+//              sort by column.
+//   consensus  heaviest bundle over a per-row successor table staged in LDS.
+// Clusters that do not fit (graph beyond its allocation, > 8 predecessors or > 2 far predecessors on a
+// node, rows wider than the LDS ring rows) report status 3 and are redone by the HBM kernel of poa.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "poa_wave.h"
+
+#define PNEG (-0x20000000)
+#define P_O1 4
+#define P_E1 2
+#define P_O2 24
+#define P_E2 1
+#define P_MATCH 2
+#define P_MISMATCH 4
+#define COL_SINK 0x7FFFFFFE
+#define COL_NEW 0x7FFFFFFF
+#define RI_SLOW 15u
+
+struct WsLayout {
+  int64_t out_head, in_head, order, index, col, base;
+  int64_t row_beg, row_end, hl, prow0, prow1, row_mpl, row_mpr;
+  int64_t aln, scr;
+  int64_t e_from, e_to, e_w, e_next_out, e_next_in;
+  int64_t op_node, op_q, path_use, path_aux;
+  int64_t gdir, gH, gE1, gE2;
+  int64_t total;
+};
+
+__host__ __device__ inline WsLayout ws_layout(int nc, int ec, int max_len, int ws) {
+  WsLayout w;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { const int64_t at = o; o += n; return at; };
+  w.out_head = take(nc); w.in_head = take(nc); w.order = take(nc); w.index = take(nc); w.col = take(nc); w.base = take(nc);
+  w.row_beg = take(nc); w.row_end = take(nc); w.hl = take(nc); w.prow0 = take(nc); w.prow1 = take(nc);
+  w.row_mpl = take(nc); w.row_mpr = take(nc);
+  w.aln = take(5 * (int64_t)nc);
+  w.scr = take((int64_t)nc + 64);
+  w.e_from = take(ec); w.e_to = take(ec); w.e_w = take(ec); w.e_next_out = take(ec); w.e_next_in = take(ec);
+  const int64_t opcap = (int64_t)nc + max_len + 4;
+  w.op_node = take(opcap); w.op_q = take(opcap); w.path_use = take(opcap); w.path_aux = take(opcap);
+  const int64_t pool = (int64_t)nc * ws;
+  w.gdir = take(pool); w.gH = take(pool); w.gE1 = take(pool); w.gE2 = take(pool);
+  w.total = o;
+  return w;
+}
+
+__device__ __forceinline__ int pl_score(int a, int b) { return (a >= 4 || b >= 4) ? 0 : (a == b ? P_MATCH : -P_MISMATCH); }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+template <int CTRL, int RMASK>
+__device__ __forceinline__ int dppi(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, RMASK, 0xf, false);
+}
+
+// inclusive scans over the 64 lanes of a wave: four row_shr steps, then row_bcast15 / row_bcast31
+__device__ __forceinline__ int wave_scan_max(int x, int ident) {
+  x = imax(x, dppi<0x111, 0xf>(ident, x));
+  x = imax(x, dppi<0x112, 0xf>(ident, x));
+  x = imax(x, dppi<0x114, 0xf>(ident, x));
+  x = imax(x, dppi<0x118, 0xf>(ident, x));
+  x = imax(x, dppi<0x142, 0xa>(ident, x));
+  x = imax(x, dppi<0x143, 0xc>(ident, x));
+  return x;
+}
+
+__device__ __forceinline__ int wave_scan_min(int x, int ident) {
+  x = imin(x, dppi<0x111, 0xf>(ident, x));
+  x = imin(x, dppi<0x112, 0xf>(ident, x));
+  x = imin(x, dppi<0x114, 0xf>(ident, x));
+  x = imin(x, dppi<0x118, 0xf>(ident, x));
+  x = imin(x, dppi<0x142, 0xa>(ident, x));
+  x = imin(x, dppi<0x143, 0xc>(ident, x));
+  return x;
+}
+
+__device__ __forceinline__ int wave_scan_add(int x) {
+  x += dppi<0x111, 0xf>(0, x);
+  x += dppi<0x112, 0xf>(0, x);
+  x += dppi<0x114, 0xf>(0, x);
+  x += dppi<0x118, 0xf>(0, x);
+  x += dppi<0x142, 0xa>(0, x);
+  x += dppi<0x143, 0xc>(0, x);
+  return x;
+}
+
+// value of the lane below (lane 0 receives `fill`)
+__device__ __forceinline__ int wave_shr1(int x, int fill) { return dppi<0x138, 0xf>(fill, x); }
+
+// direction word layout
+//  bits 0-3  source of H : 0-7 match through predecessor slot k, 8 E1, 9 E2, 10 F1, 11 F2
+//  bits 4-7  source of H': 0-7 match through slot k, 8 E1, 9 E2
+//  bits 8-11 E1: 0-7 opened from H of slot k, 8-15 extended from E1 of slot k-8;  bits 12-15 E2 likewise
+//  bit 16    F1 opened from H'(v, j-1) (else extended);  bit 17 F2 likewise
+//
+// row descriptor layout (rowinfo[r], one per topological position)
+//  bits 0-2 base, bits 3-6 number of predecessors (0-2, or RI_SLOW: look at the graph), bits 7-18 and 19-30
+//  the row deltas of predecessor 0 / 1, bit 31: some later row reads this row after it left the ring
+
+__device__ unsigned long long g_poaw_prof[8];   // SVDSS_DEBUG: time in prepare, forward, traceback, update, bundle
+#define PROF_T() (prof_t = wall_clock64())
+#define PROF_ADD(k) do { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - prof_t; prof_t = t_; } while (0)
+
+template <int C>
+__global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, const uint8_t* seqs, const int64_t* seq_off,
+                                                     int32_t* ws32, uint8_t* ws8, int32_t* cons_len, int32_t* status,
+                                                     unsigned long long* cells) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const PoaWaveTask T = tasks[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int nc = T.nc, ec = T.ec, WS = T.ws, wm = WS - 1, RS = T.rs, RING = T.ring, rm = RING - 1, NS = RING + 2;
+  constexpr int G = 4;            // -inf guard cells on each side of a ring row
+  const int RST = RS + 2 * G;     // LDS stride of a ring row
+  // ---- LDS
+  uint32_t* rowinfo = (uint32_t*)smem;
+  int32_t* rH = (int32_t*)(rowinfo + nc);
+  int32_t* rE1 = rH + NS * RST;
+  int32_t* rE2 = rE1 + NS * RST;
+  int32_t* rbeg = rE2 + NS * RST;
+  int32_t* rend = rbeg + NS;
+  int32_t* rmpl = rend + NS;
+  int32_t* rmpr = rmpl + NS;
+  int32_t* sh = rmpr + NS;          // 0 nodes, 1 edges, 2 columns, 3 nops; 8..15 predecessor slots of a slow row
+  uint8_t* q = (uint8_t*)(sh + 16);
+  // ---- HBM
+  const WsLayout wl = ws_layout(nc, ec, T.max_len, WS);
+  int32_t* W = ws32 + T.ws_off;
+  int32_t *out_head = W + wl.out_head, *in_head = W + wl.in_head, *order = W + wl.order, *index = W + wl.index;
+  int32_t *col = W + wl.col, *base = W + wl.base;
+  int32_t *row_beg = W + wl.row_beg, *row_end = W + wl.row_end, *hl = W + wl.hl;
+  uint32_t *prow0 = (uint32_t*)(W + wl.prow0), *prow1 = (uint32_t*)(W + wl.prow1);
+  int32_t *row_mpl = W + wl.row_mpl, *row_mpr = W + wl.row_mpr;
+  int32_t *aln = W + wl.aln, *scr = W + wl.scr;
+  int32_t *e_from = W + wl.e_from, *e_to = W + wl.e_to, *e_w = W + wl.e_w, *e_next_out = W + wl.e_next_out,
+          *e_next_in = W + wl.e_next_in;
+  int32_t *op_node = W + wl.op_node, *op_q = W + wl.op_q, *path_use = W + wl.path_use;
+  uint32_t* path_aux = (uint32_t*)(W + wl.path_aux);
+  uint32_t* gdir = (uint32_t*)(W + wl.gdir);
+  int32_t *gH = W + wl.gH, *gE1 = W + wl.gE1, *gE2 = W + wl.gE2;
+  const int opcap = nc + T.max_len + 4;
+  uint8_t* cons = ws8 + T.cons_off;
+  const int n = (int)T.n_seqs;
+  unsigned long long my_cells = 0;
+  unsigned long long prof[5] = {0, 0, 0, 0, 0}, prof_t;
+#ifdef POA_FINE_PROF
+  long long fp[6] = {0, 0, 0, 0, 0, 0}, ft = 0;
+#define FP(k) do { const long long t_ = clock64(); fp[k] += t_ - ft; ft = t_; } while (0)
+#else
+#define FP(k)
+#endif
+  if (n <= 0) { if (lane == 0) { cons_len[blockIdx.x] = 0; status[blockIdx.x] = 0; } return; }
+#define FAIL(code) do { if (lane == 0) status[blockIdx.x] = (code); return; } while (0)
+  // ------------------------------------------------------------------ graph of the first read
+  {
+    const uint8_t* q0 = seqs + seq_off[T.seq_first];
+    const int L0 = (int)(seq_off[T.seq_first + 1] - seq_off[T.seq_first]);
+    if (L0 + 2 > nc || L0 + 1 > ec) FAIL(3 | (1 << 8));
+    for (int v = lane; v < L0 + 2; v += 64) {
+      const int b = v < 2 ? 4 : q0[v - 2];
+      base[v] = b;
+      out_head[v] = v == 1 ? -1 : (v == 0 ? 0 : v - 1);      // edge e: (e == 0 ? source : node e+1) -> ...
+      in_head[v] = v == 0 ? -1 : (v == 1 ? L0 : v - 2);
+      for (int x = 0; x < 5; ++x) aln[5 * v + x] = -1;
+      if (v >= 2) aln[5 * v + b] = v;
+      const int idx = v == 0 ? 0 : v == 1 ? L0 + 1 : v - 1;
+      col[v] = v == 1 ? COL_SINK : idx;
+      index[v] = idx;
+      order[idx] = v;
+    }
+    for (int e = lane; e <= L0; e += 64) {
+      e_from[e] = e == 0 ? 0 : e + 1;
+      e_to[e] = e == L0 ? 1 : e + 2;
+      e_w[e] = 1;
+      e_next_out[e] = -1; e_next_in[e] = -1;
+    }
+    if (lane == 0) { sh[0] = L0 + 2; sh[1] = L0 + 1; sh[2] = L0 + 1; }
+    __syncthreads();
+  }
+  for (int i = 1; i < n; ++i) {
+    const uint8_t* qg = seqs + seq_off[T.seq_first + i];
+    const int L = (int)(seq_off[T.seq_first + i + 1] - seq_off[T.seq_first + i]);
+    const int N = sh[0];
+    if (L > T.max_len) FAIL(3 | (6 << 8));
+    PROF_T();
+    for (int j = lane; j < L; j += 64) q[j] = qg[j];
+    // ---------------------------------------------------------- row descriptors
+    for (int r = lane; r < N; r += 64) {
+      const int v = order[r];
+      uint32_t ri = (uint32_t)base[v] & 7u;
+      int np = 0, d0 = 0, d1 = 0;
+      for (int e = in_head[v]; e >= 0; e = e_next_in[e]) {
+        const int d = r - index[e_from[e]];
+        if (np == 0) d0 = d; else if (np == 1) d1 = d;
+        ++np;
+      }
+      if (np > 2 || d0 > 4095 || d1 > 4095) ri |= RI_SLOW << 3;
+      else ri |= ((uint32_t)np << 3) | ((uint32_t)d0 << 7) | ((uint32_t)d1 << 19);
+      rowinfo[r] = ri;
+    }
+    __syncthreads();
+    for (int r = lane; r < N - 1; r += 64) {   // flag the rows that are read back after they left the ring
+      const uint32_t ri = rowinfo[r];
+      const uint32_t np = (ri >> 3) & 15u;
+      if (np == RI_SLOW) {
+        for (int e = in_head[order[r]]; e >= 0; e = e_next_in[e]) {
+          const int d = r - index[e_from[e]];
+          if (d >= RING) atomicOr(&rowinfo[r - d], 0x80000000u);
+        }
+      } else {
+        const int d0 = (int)((ri >> 7) & 4095u), d1 = (int)((ri >> 19) & 4095u);
+        if (np >= 1 && d0 >= RING) atomicOr(&rowinfo[r - d0], 0x80000000u);
+        if (np >= 2 && d1 >= RING) atomicOr(&rowinfo[r - d1], 0x80000000u);
+      }
+    }
+    __syncthreads();
+    PROF_ADD(0);
+    int nops = -1;
+    // banded first; if the band loses the sink the read is aligned again with the full matrix (w = L)
+    for (int attempt = 0; attempt < 2 && nops < 0; ++attempt) {
+      const int w = attempt ? L : 10 + (int)(0.01 * L);
+      int last_r = -1, last_mpl = 0, last_mpr = 0;
+      // a row that left the ring comes back from HBM into staging slot s (its stores may still be in flight)
+      auto stage = [&](int ur, int s) {
+        __syncthreads();
+        const int pb = row_beg[ur], pe = row_end[ur];
+        const int64_t po = (int64_t)ur * WS;
+        for (int x = lane; x <= pe - pb; x += 64) {
+          const int64_t o = po + ((pb + x) & wm);
+          rH[s * RST + G + x] = gH[o]; rE1[s * RST + G + x] = gE1[o]; rE2[s * RST + G + x] = gE2[o];
+        }
+        if (lane < G) {
+          const int o1 = s * RST + lane, o2 = s * RST + G + (pe - pb + 1) + lane;
+          rH[o1] = PNEG; rE1[o1] = PNEG; rE2[o1] = PNEG;
+          rH[o2] = PNEG; rE1[o2] = PNEG; rE2[o2] = PNEG;
+        }
+        if (lane == 0) { rbeg[s] = pb; rend[s] = pe; rmpl[s] = row_mpl[ur]; rmpr[s] = row_mpr[ur]; }
+        __syncthreads();
+      };
+      uint32_t ri_n = rowinfo[0];
+      // ------------------------------------------------------------ forward (the sink is order[N-1])
+      for (int r = 0; r < N - 1; ++r) {
+        FP(5);
+        const uint32_t ri = __builtin_amdgcn_readfirstlane(ri_n);
+        ri_n = rowinfo[r + 1];
+        const int slot = r & rm;
+        const int bv = (int)(ri & 7u);
+        int np = (int)((ri >> 3) & 15u);
+        const bool keep = (ri >> 31) != 0;
+        const bool slow = np == (int)RI_SLOW;
+        int ps0 = 0, ps1 = 0;
+        int lo = 1 << 30, hi = -1;
+        uint32_t pd0 = 0, pd1 = 0;
+        if (!slow) {
+          int nfar = 0;
+          if (np >= 1) {
+            const int d = (int)((ri >> 7) & 4095u), ur = r - d;
+            pd0 = (uint32_t)imin(d, 255);
+            if (d < RING) ps0 = ur & rm; else { ps0 = RING + nfar++; stage(ur, ps0); }
+            const int a = ur == last_r ? last_mpl : rmpl[ps0], b = ur == last_r ? last_mpr : rmpr[ps0];
+            lo = imin(lo, a); hi = imax(hi, b);
+          }
+          if (np >= 2) {
+            const int d = (int)((ri >> 19) & 4095u), ur = r - d;
+            pd0 |= (uint32_t)imin(d, 255) << 8;
+            if (d < RING) ps1 = ur & rm; else { ps1 = RING + nfar++; stage(ur, ps1); }
+            const int a = ur == last_r ? last_mpl : rmpl[ps1], b = ur == last_r ? last_mpr : rmpr[ps1];
+            lo = imin(lo, a); hi = imax(hi, b);
+          }
+        } else {
+          int nfar = 0;
+          np = 0;
+          for (int e = in_head[order[r]]; e >= 0; e = e_next_in[e]) {
+            const int ur = index[e_from[e]];
+            if (np < 8) {
+              const uint32_t dl = (uint32_t)imin(r - ur, 255);
+              if (np < 4) pd0 |= dl << (8 * np); else pd1 |= dl << (8 * (np - 4));
+              int s;
+              if (r - ur < RING) s = ur & rm;
+              else {
+                if (nfar >= 2) FAIL(3 | (2 << 8));
+                s = RING + nfar++;
+                stage(ur, s);
+              }
+              sh[8 + np] = s;
+              const int a = ur == last_r ? last_mpl : rmpl[s], b = ur == last_r ? last_mpr : rmpr[s];
+              lo = imin(lo, a); hi = imax(hi, b);
+            }
+            ++np;
+          }
+          if (np > 8) FAIL(3 | (2 << 8));
+        }
+        int beg, end;
+        if (r == 0) { beg = 0; end = w < L ? w : L; }
+        else {
+          beg = lo + 1 - w; if (beg < 0) beg = 0;
+          end = hi + 1 + w; if (end > L) end = L;
+          if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
+        }
+        const int width = end - beg + 1;
+        if (width > RS || width > WS) FAIL(3 | (3 << 8));
+        my_cells += (unsigned long long)width;
+        if (lane == 0) {
+          rbeg[slot] = beg; rend[slot] = end;
+          prow0[r] = pd0; prow1[r] = pd1;
+          if (end < L) hl[r] = PNEG;
+          if (keep) { row_beg[r] = beg; row_end[r] = end; }
+        }
+        FP(0);
+        const int64_t rowo = (int64_t)r * WS;
+        const int sb = slot * RST + G;
+        if (lane < G) {   // -inf guard cells on both sides of the row: successors read them unchecked
+          const int o1 = slot * RST + lane, o2 = sb + width + lane;
+          rH[o1] = PNEG; rE1[o1] = PNEG; rE2[o1] = PNEG;
+          rH[o2] = PNEG; rE1[o2] = PNEG; rE2[o2] = PNEG;
+        }
+        // fast rows: one or two predecessors whose stored band (plus guards) covers every column this row reads
+        int pb0 = 0, pb1 = 0;
+        bool fast = !slow && np >= 1;
+        if (fast) {
+          pb0 = rbeg[ps0];
+          fast = beg - 1 >= pb0 - G && end <= rend[ps0] + G;
+          if (np == 2) {
+            pb1 = rbeg[ps1];
+            fast = fast && beg - 1 >= pb1 - G && end <= rend[ps1] + G;
+          }
+        }
+        // leftmost / rightmost column of the row maximum, per lane (cells in increasing column order)
+        int32_t lbest = -0x7fffffff - 1; int ll = -1, lr = -1;
+        int32_t g1 = PNEG, g2 = PNEG, hpc = PNEG;   // carries between chunks of 64*C columns
+        for (int j0 = beg; j0 <= end; j0 += 64 * C) {
+          const int jb = j0 + lane * C;
+          int32_t m[C], e1[C], e2[C];
+          int km[C];
+          uint32_t dE1[C], dE2[C];
+          int sc[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int j = jb + c;
+            sc[c] = (j >= 1 && j <= end) ? pl_score(bv, q[j - 1]) : 0;
+          }
+          if (fast) {
+            // values below -inf/2 are "no path": they are never clamped here, only kept far below any score
+            int32_t hv0[C + 1], xa0[C], xb0[C];
+            const int bi0 = ps0 * RST + G + (jb - 1 - pb0);
+#pragma unroll
+            for (int t = 0; t <= C; ++t) hv0[t] = rH[bi0 + t];
+#pragma unroll
+            for (int t = 0; t < C; ++t) { xa0[t] = rE1[bi0 + 1 + t]; xb0[t] = rE2[bi0 + 1 + t]; }
+            if (np == 1) {
+#pragma unroll
+              for (int c = 0; c < C; ++c) {
+                m[c] = hv0[c] + sc[c]; km[c] = 0;
+                const int32_t a1 = hv0[c + 1] - P_O1 - P_E1, b1 = xa0[c] - P_E1;
+                e1[c] = imax(a1, b1); dE1[c] = a1 == e1[c] ? 0u : 8u;
+                const int32_t a2 = hv0[c + 1] - P_O2 - P_E2, b2 = xb0[c] - P_E2;
+                e2[c] = imax(a2, b2); dE2[c] = a2 == e2[c] ? 0u : 8u;
+              }
+            } else {
+              int32_t hv1[C + 1], xa1[C], xb1[C];
+              const int bi1 = ps1 * RST + G + (jb - 1 - pb1);
+#pragma unroll
+              for (int t = 0; t <= C; ++t) hv1[t] = rH[bi1 + t];
+#pragma unroll
+              for (int t = 0; t < C; ++t) { xa1[t] = rE1[bi1 + 1 + t]; xb1[t] = rE2[bi1 + 1 + t]; }
+#pragma unroll
+              for (int c = 0; c < C; ++c) {
+                const int32_t m0 = hv0[c] + sc[c], m1 = hv1[c] + sc[c];
+                m[c] = imax(m0, m1); km[c] = m1 > m0 ? 1 : 0;
+                {
+                  const int32_t a0 = hv0[c + 1] - P_O1 - P_E1, b0 = xa0[c] - P_E1, a1 = hv1[c + 1] - P_O1 - P_E1, b1 = xa1[c] - P_E1;
+                  const int32_t e = imax(imax(a0, b0), imax(a1, b1));
+                  e1[c] = e; dE1[c] = a0 == e ? 0u : a1 == e ? 1u : b0 == e ? 8u : 9u;
+                }
+                {
+                  const int32_t a0 = hv0[c + 1] - P_O2 - P_E2, b0 = xb0[c] - P_E2, a1 = hv1[c + 1] - P_O2 - P_E2, b1 = xb1[c] - P_E2;
+                  const int32_t e = imax(imax(a0, b0), imax(a1, b1));
+                  e2[c] = e; dE2[c] = a0 == e ? 0u : a1 == e ? 1u : b0 == e ? 8u : 9u;
+                }
+              }
+            }
+          } else {
+            int ko1[C], kx1[C], ko2[C], kx2[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              m[c] = PNEG; e1[c] = PNEG; e2[c] = PNEG;
+              km[c] = 15; ko1[c] = 15; kx1[c] = 15; ko2[c] = 15; kx2[c] = 15;
+            }
+            auto accum = [&](int k, int sl) {
+              const int pb = rbeg[sl], pe = rend[sl];
+              const int so = sl * RST + G;
+              int32_t hv[C + 1], x1v[C], x2v[C];
+#pragma unroll
+              for (int t = 0; t <= C; ++t) {
+                const int jj = jb - 1 + t;
+                const bool ok = jj >= pb && jj <= pe && jj <= end;
+                const int32_t val = rH[so + (ok ? jj - pb : 0)];
+                hv[t] = ok ? val : PNEG;
+              }
+#pragma unroll
+              for (int t = 0; t < C; ++t) {
+                const int jj = jb + t;
+                const bool ok = jj >= pb && jj <= pe && jj <= end;
+                const int32_t v1 = rE1[so + (ok ? jj - pb : 0)], v2 = rE2[so + (ok ? jj - pb : 0)];
+                x1v[t] = ok ? v1 : PNEG;
+                x2v[t] = ok ? v2 : PNEG;
+              }
+#pragma unroll
+              for (int c = 0; c < C; ++c) {
+                const int32_t hm1 = hv[c], h = hv[c + 1];
+                if (hm1 > PNEG / 2) { const int32_t x = hm1 + sc[c]; if (x > m[c]) { m[c] = x; km[c] = k; } }
+                {
+                  const int32_t a = h > PNEG / 2 ? h - P_O1 - P_E1 : PNEG, b = x1v[c] > PNEG / 2 ? x1v[c] - P_E1 : PNEG;
+                  const int32_t cc = a > b ? a : b;
+                  if (cc > PNEG / 2) {
+                    if (cc > e1[c]) { e1[c] = cc; ko1[c] = 15; kx1[c] = 15; }
+                    if (cc == e1[c]) { if (a == cc && ko1[c] == 15) ko1[c] = k; if (b == cc && kx1[c] == 15) kx1[c] = k; }
+                  }
+                }
+                {
+                  const int32_t a = h > PNEG / 2 ? h - P_O2 - P_E2 : PNEG, b = x2v[c] > PNEG / 2 ? x2v[c] - P_E2 : PNEG;
+                  const int32_t cc = a > b ? a : b;
+                  if (cc > PNEG / 2) {
+                    if (cc > e2[c]) { e2[c] = cc; ko2[c] = 15; kx2[c] = 15; }
+                    if (cc == e2[c]) { if (a == cc && ko2[c] == 15) ko2[c] = k; if (b == cc && kx2[c] == 15) kx2[c] = k; }
+                  }
+                }
+              }
+            };
+            if (r == 0) {
+#pragma unroll
+              for (int c = 0; c < C; ++c) if (jb + c == 0) m[c] = 0;
+            } else if (!slow) {
+              if (np >= 1) accum(0, ps0);
+              if (np >= 2) accum(1, ps1);
+            } else {
+#pragma unroll 1
+              for (int k = 0; k < np; ++k) accum(k, sh[8 + k]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              dE1[c] = ko1[c] != 15 ? (uint32_t)ko1[c] : (uint32_t)(8 + (kx1[c] & 7));
+              dE2[c] = ko2[c] != 15 ? (uint32_t)ko2[c] : (uint32_t)(8 + (kx2[c] & 7));
+            }
+          }
+          FP(1);
+          // H' and the lane-serial half of the F prefix maxima
+          int32_t hp[C], p1[C], p2[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int j = jb + c;
+            int32_t x = imax(m[c], imax(e1[c], e2[c]));
+            if (j > end) x = PNEG;
+            hp[c] = x;
+            const int32_t t1 = x + j * P_E1, t2 = x + j * P_E2;
+            p1[c] = c ? imax(p1[c - 1], t1) : t1;
+            p2[c] = c ? imax(p2[c - 1], t2) : t2;
+          }
+          const int32_t s1 = wave_scan_max(p1[C - 1], PNEG), s2 = wave_scan_max(p2[C - 1], PNEG);
+          const int32_t X1 = imax(wave_shr1(s1, PNEG), g1), X2 = imax(wave_shr1(s2, PNEG), g2);
+          g1 = imax(g1, __builtin_amdgcn_readlane(s1, 63));
+          g2 = imax(g2, __builtin_amdgcn_readlane(s2, 63));
+          FP(2);
+          int32_t hp_prev = wave_shr1(hp[C - 1], PNEG);
+          if (lane == 0) hp_prev = hpc;
+          hpc = __builtin_amdgcn_readlane(hp[C - 1], 63);
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int j = jb + c;
+            const int32_t x1 = c ? imax(X1, p1[c - 1]) : X1, x2 = c ? imax(X2, p2[c - 1]) : X2;
+            const int32_t f1 = x1 - P_O1 - j * P_E1, f2 = x2 - P_O2 - j * P_E2;
+            const int32_t h = imax(hp[c], imax(f1, f2));
+            const int32_t hp_left = c ? hp[c - 1] : hp_prev;
+            if (j <= end) {
+              // the traceback's decisions, in the order the specification tries them
+              const bool mk = km[c] != 15;
+              const uint32_t dH = (m[c] == h && mk) ? (uint32_t)km[c] : e1[c] == h ? 8u : e2[c] == h ? 9u : f1 == h ? 10u : 11u;
+              const uint32_t dHp = (m[c] == hp[c] && mk) ? (uint32_t)km[c] : e1[c] == hp[c] ? 8u : 9u;
+              const uint32_t o1 = hp_left - P_O1 - P_E1 == f1 ? 1u : 0u;
+              const uint32_t o2 = hp_left - P_O2 - P_E2 == f2 ? 1u : 0u;
+              const int64_t o = rowo + (j & wm);
+              gdir[o] = dH | (dHp << 4) | (dE1[c] << 8) | (dE2[c] << 12) | (o1 << 16) | (o2 << 17);
+              if (keep) { gH[o] = h; gE1[o] = e1[c]; gE2[o] = e2[c]; }
+              rH[sb + (j - beg)] = h; rE1[sb + (j - beg)] = e1[c]; rE2[sb + (j - beg)] = e2[c];
+              if (j == L) hl[r] = h;
+              if (h > lbest) { lbest = h; ll = j; lr = j; }
+              else if (h == lbest) lr = j;
+            }
+          }
+        }
+        FP(3);
+        {
+          // row maximum: leftmost / rightmost column over the lanes that own cells.  (No valid cell at all: the
+          // specification leaves mpl at the first column and moves mpr to the last.)
+          const bool own = ll >= 0;
+          const int32_t wmx = __builtin_amdgcn_readlane(wave_scan_max(own ? lbest : -0x7fffffff - 1, -0x7fffffff - 1), 63);
+          const bool eq = own && lbest == wmx;
+          int l, rr;
+          if (width <= 64 * C) {   // lane order = column order
+            const unsigned long long em = __ballot(eq);
+            l = __builtin_amdgcn_readlane(ll, (int)__builtin_ctzll(em));
+            rr = __builtin_amdgcn_readlane(lr, 63 - (int)__builtin_clzll(em));
+          } else {
+            l = __builtin_amdgcn_readlane(wave_scan_min(eq ? ll : 0x7fffffff, 0x7fffffff), 63);
+            rr = __builtin_amdgcn_readlane(wave_scan_max(eq ? lr : -1, -1), 63);
+          }
+          if (wmx <= PNEG / 2) { l = beg; rr = end; }
+          last_r = r; last_mpl = l; last_mpr = rr;
+          if (lane == 0) {
+            rmpl[slot] = l; rmpr[slot] = rr;
+            if (keep) { row_mpl[r] = l; row_mpr[r] = rr; }
+          }
+        }
+        FP(4);
+      }
+      __syncthreads();   // direction words, deltas and end cells are in HBM
+      PROF_ADD(1);
+      // --------------------------------------------------------- traceback
+      {
+        int bu = -1; int32_t bsc = PNEG;
+        for (int e = in_head[1]; e >= 0; e = e_next_in[e]) {
+          const int ur = index[e_from[e]];
+          const int32_t h = hl[ur];
+          if (h > bsc) { bsc = h; bu = ur; }
+        }
+        nops = -1;
+        if (bu >= 0 && bsc > PNEG / 2) {
+          nops = 0;
+          int r = __builtin_amdgcn_readfirstlane(bu), j = L, st = 0;   // 0 H, 1 E1, 2 E2, 3 F1, 4 F2, 5 H'
+          int r0 = -(1 << 28), j0 = 0;
+          uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0, P0 = 0, P1 = 0;
+          while (r != 0 || j > 0) {
+            if (nops + j + 2 > opcap) { nops = -1; break; }   // cannot happen on a valid path
+            if (r == 0) {   // only inserted bases remain
+              for (int t = lane; t < j; t += 64) { op_node[nops + t] = -1; op_q[nops + t] = j - 1 - t; }
+              nops += j; j = 0;
+              break;
+            }
+            int k = r0 - r, d = k - (j0 - j);
+            if (k < 0 || k > 63 || d < 0 || d > 3) {
+              r0 = r; j0 = j; k = 0; d = 0;
+              const int rr = r0 - lane;
+              if (rr >= 0) {
+                const uint32_t* bp = gdir + (int64_t)rr * WS;
+                const int c = j0 - lane;
+                W0 = bp[c & wm]; W1 = bp[(c + 1) & wm]; W2 = bp[(c + 2) & wm]; W3 = bp[(c + 3) & wm];
+                P0 = prow0[rr]; P1 = prow1[rr];
+              }
+              // wait for the window here, not at the join below (where the wait would also cover the op
+              // stores of every step: vmcnt is in-order)
+              asm volatile("" : "+v"(W0), "+v"(W1), "+v"(W2), "+v"(W3), "+v"(P0), "+v"(P1));
+            }
+            const uint32_t wsel = d == 0 ? W0 : d == 1 ? W1 : d == 2 ? W2 : W3;
+            const uint32_t dw = __builtin_amdgcn_readlane(wsel, k);
+            const uint32_t p0 = __builtin_amdgcn_readlane(P0, k), p1 = __builtin_amdgcn_readlane(P1, k);
+            int s = -1;   // predecessor slot to follow
+            if (st == 0 || st == 5) {
+              const uint32_t dd = st == 0 ? (dw & 15u) : ((dw >> 4) & 15u);
+              if (dd < 8) {
+                if (lane == 0) { op_node[nops] = r; op_q[nops] = j - 1; }
+                ++nops; --j; st = 0; s = (int)dd;
+              } else st = (int)dd - 7;   // 8 -> E1, 9 -> E2, 10 -> F1, 11 -> F2
+            } else if (st == 1 || st == 2) {
+              const uint32_t dd = st == 1 ? ((dw >> 8) & 15u) : ((dw >> 12) & 15u);
+              if (lane == 0) { op_node[nops] = r; op_q[nops] = -1; }
+              ++nops; s = (int)(dd & 7u);
+              if (dd < 8) st = 0;
+            } else {
+              const uint32_t open = st == 3 ? ((dw >> 16) & 1u) : ((dw >> 17) & 1u);
+              if (lane == 0) { op_node[nops] = -1; op_q[nops] = j - 1; }
+              ++nops;
+              if (open) st = 5;
+              --j;
+            }
+            if (s >= 0) {
+              const uint32_t dl = ((s < 4 ? p0 : p1) >> (8 * (s & 3))) & 255u;
+              if (dl != 255u) r -= (int)dl;
+              else {
+                int e = in_head[order[r]];
+                for (int t = 0; t < s; ++t) e = e_next_in[e];
+                r = __builtin_amdgcn_readfirstlane(index[e_from[e]]);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      PROF_ADD(2);
+    }
+    if (nops < 0) FAIL(3 | (4 << 8));
+    if (nops > 32000) FAIL(3 | (5 << 8));   // (path positions are packed into 15 bits of a scan key)
+    // ------------------------------------------------------- graph update
+    const int ncols = sh[2], n_old = N;
+    for (int c = lane; c < ncols; c += 64) scr[c] = 0;
+    __syncthreads();
+    int carry_c = 0, carry_n = 0, carry_key = 0;
+    for (int p0 = 0; p0 < nops; p0 += 64) {
+      const int p = p0 + lane;
+      const bool valid = p < nops;
+      int row = -1, j = -1;
+      if (valid) { row = op_node[nops - 1 - p]; j = op_q[nops - 1 - p]; }
+      const bool ali = valid && row >= 0 && j >= 0, ins = valid && row < 0;
+      const int v = ali ? order[row] : -1;
+      const int qb = (ali || ins) ? (int)q[j] : 0;
+      int use = -1;
+      bool isnew = ins;
+      if (ali) {
+        if (base[v] == qb) use = v;
+        else { const int a = aln[5 * v + qb]; if (a >= 0) use = a; else isnew = true; }
+      }
+      const int inc_c = wave_scan_add((ali || ins) ? 1 : 0), inc_n = wave_scan_add(isnew ? 1 : 0);
+      const int cidx = carry_c + inc_c - ((ali || ins) ? 1 : 0);
+      const int nrank = carry_n + inc_n - (isnew ? 1 : 0);
+      const int key = ali ? (((cidx + 1) << 16) | col[v]) : 0;     // (columns and path positions < 65536)
+      const int inc_k = wave_scan_max(key, 0);
+      const int ikey = imax(carry_key, inc_k);
+      carry_c += __builtin_amdgcn_readlane(inc_c, 63);
+      carry_n += __builtin_amdgcn_readlane(inc_n, 63);
+      carry_key = imax(carry_key, __builtin_amdgcn_readlane(inc_k, 63));
+      uint32_t aux = 0xFFFFFFFFu;
+      if (isnew && n_old + nrank < nc) {   // (capacity is checked after the loop)
+        const int nid = n_old + nrank;
+        use = nid;
+        base[nid] = qb;
+        out_head[nid] = -1; in_head[nid] = -1;
+        if (ali) {   // a new base at the column of v: joins v's aligned group
+          for (int b = 0; b < 5; ++b) {
+            const int sib = aln[5 * v + b];
+            aln[5 * nid + b] = sib;
+            if (sib >= 0) aln[5 * sib + qb] = nid;
+          }
+          aln[5 * nid + qb] = nid;
+          col[nid] = col[v];
+        } else {     // an inserted base: a new column, the t-th after its anchor's
+          for (int b = 0; b < 5; ++b) aln[5 * nid + b] = b == qb ? nid : -1;
+          col[nid] = COL_NEW;
+          const int ac = ikey & 0xffff, t = (cidx + 1) - (ikey >> 16);
+          atomicMax(&scr[ac], t);
+          aux = (uint32_t)ac | ((uint32_t)t << 16);
+        }
+      }
+      if (ali || ins) { path_use[cidx] = use; path_aux[cidx] = aux; }
+    }
+    const int PC = carry_c, n_new = n_old + carry_n;
+    // the graph outgrew its allocation: redo this cluster with the HBM kernel
+    if (n_new > nc || ncols + carry_n > nc || ncols + carry_n > 65000 || PC > 65000) FAIL(3 | (5 << 8));
+    __syncthreads();
+    // one edge per path step; no other lane touches the out-list of u or the in-list of v
+    for (int t = lane; t <= PC; t += 64) {
+      const int u = t == 0 ? 0 : path_use[t - 1], v = t == PC ? 1 : path_use[t];
+      int tail = -1, e = out_head[u];
+      bool found = false;
+      for (; e >= 0; e = e_next_out[e]) {
+        if (e_to[e] == v) { e_w[e]++; found = true; break; }
+        tail = e;
+      }
+      if (found) continue;
+      const int ne = atomicAdd(&sh[1], 1);
+      if (ne >= ec) continue;   // out of edge slots: sh[1] > ec below gives the cluster up
+      e_from[ne] = u; e_to[ne] = v; e_w[ne] = 1;
+      e_next_out[ne] = -1; e_next_in[ne] = -1;
+      if (tail < 0) out_head[u] = ne; else e_next_out[tail] = ne;
+      int ie = in_head[v];
+      if (ie < 0) in_head[v] = ne;
+      else {
+        while (e_next_in[ie] >= 0) ie = e_next_in[ie];
+        e_next_in[ie] = ne;
+      }
+    }
+    __syncthreads();
+    if (sh[1] > ec) FAIL(3 | (5 << 8));
+    // column ranks: every column moves right by the number of columns inserted before it
+    int carry = 0;
+    for (int c0 = 0; c0 < ncols; c0 += 64) {
+      const int c = c0 + lane;
+      const int x = c < ncols ? scr[c] : 0;
+      const int inc = wave_scan_add(x);
+      if (c < ncols) scr[c] = carry + inc - x;
+      carry += __builtin_amdgcn_readlane(inc, 63);
+    }
+    __syncthreads();
+    for (int v = lane; v < n_new; v += 64) {
+      const int cv = col[v];
+      if (cv < COL_SINK) col[v] = cv + scr[cv];
+    }
+    __syncthreads();
+    for (int t = lane; t < PC; t += 64) {
+      const uint32_t aux = path_aux[t];
+      if (aux != 0xFFFFFFFFu) { const int ac = (int)(aux & 0xffffu); col[path_use[t]] = ac + scr[ac] + (int)(aux >> 16); }
+    }
+    const int ncols_new = ncols + carry;
+    __syncthreads();
+    // counting sort of the nodes by column = a topological order; the sink goes last
+    for (int c = lane; c < ncols_new; c += 64) scr[c] = 0;
+    __syncthreads();
+    for (int v = lane; v < n_new; v += 64) if (v != 1) atomicAdd(&scr[col[v]], 1);
+    __syncthreads();
+    carry = 0;
+    for (int c0 = 0; c0 < ncols_new; c0 += 64) {
+      const int c = c0 + lane;
+      const int x = c < ncols_new ? scr[c] : 0;
+      const int inc = wave_scan_add(x);
+      if (c < ncols_new) scr[c] = carry + inc - x;
+      carry += __builtin_amdgcn_readlane(inc, 63);
+    }
+    __syncthreads();
+    for (int v = lane; v < n_new; v += 64) if (v != 1) {
+      const int pos = atomicAdd(&scr[col[v]], 1);
+      order[pos] = v; index[v] = pos;
+    }
+    if (lane == 0) { order[n_new - 1] = 1; index[1] = n_new - 1; sh[0] = n_new; sh[2] = ncols_new; }
+    __syncthreads();
+    PROF_ADD(3);
+  }
+  // ----------------------------------------------------------- heaviest bundle
+  PROF_T();
+  {
+    const int N = sh[0];
+    // per row: up to two successors (row, weight) and the base, staged in LDS; rows with more go to the graph
+    uint32_t* succ0 = (uint32_t*)smem;
+    uint32_t* succ1 = succ0 + nc;
+    int32_t* score = (int32_t*)(succ1 + nc);
+    __syncthreads();
+    if (n > 8191) FAIL(3 | (7 << 8));
+    for (int r = lane; r < N; r += 64) {
+      const int v = order[r];
+      uint32_t s0 = 0xFFFFu, s1 = 0xFFFFu;   // row 0xFFFF: none; weight 0x1FFF in s1: more than two, walk the list
+      int k = 0;
+      for (int e = out_head[v]; e >= 0; e = e_next_out[e]) {
+        const uint32_t ent = (uint32_t)index[e_to[e]] | ((uint32_t)e_w[e] << 16);
+        if (k == 0) s0 = ent; else if (k == 1) s1 = ent;
+        ++k;
+      }
+      if (k > 2) s1 = 0xFFFFu | (0x1FFFu << 16);
+      succ0[r] = s0 | ((uint32_t)base[v] << 29);
+      succ1[r] = s1;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int r = N - 1; r >= 0; --r) {
+        const uint32_t s0 = succ0[r], s1 = succ1[r];
+        int bst = -1, bw = -1; int32_t bsc = -1;
+        if ((s1 & 0xFFFFu) == 0xFFFFu && ((s1 >> 16) & 0x1FFFu) == 0x1FFFu) {
+          for (int e = out_head[order[r]]; e >= 0; e = e_next_out[e]) {
+            const int x = index[e_to[e]], wgt = e_w[e];
+            const int32_t sx = score[x];
+            if (wgt > bw || (wgt == bw && sx > bsc)) { bw = wgt; bsc = sx; bst = x; }
+          }
+        } else {
+          if ((s0 & 0xFFFFu) != 0xFFFFu) { bst = (int)(s0 & 0xFFFFu); bw = (int)((s0 >> 16) & 0x1FFFu); bsc = score[bst]; }
+          if ((s1 & 0xFFFFu) != 0xFFFFu) {
+            const int x = (int)(s1 & 0xFFFFu), wgt = (int)((s1 >> 16) & 0x1FFFu);
+            const int32_t sx = score[x];
+            if (wgt > bw || (wgt == bw && sx > bsc)) { bw = wgt; bsc = sx; bst = x; }
+          }
+        }
+        succ1[r] = (uint32_t)bst;
+        score[r] = bst >= 0 ? bw + bsc : 0;
+      }
+      int len = 0;
+      const int sink_row = N - 1;
+      for (int r = (int)succ1[0]; r >= 0 && r != sink_row; r = (int)succ1[r]) cons[len++] = (uint8_t)(succ0[r] >> 29);
+      cons_len[blockIdx.x] = len;
+      status[blockIdx.x] = 0;
+      atomicAdd(cells, my_cells);
+      PROF_ADD(4);
+      for (int k = 0; k < 5; ++k) atomicAdd(&g_poaw_prof[k], prof[k]);
+#ifdef POA_FINE_PROF
+      for (int k = 0; k < 6; ++k) printf("fp%d %lld\n", k, fp[k]);
+#endif
+    }
+  }
+#undef FAIL
+}
+
+size_t poa_wave_lds_bytes(int nc, int max_len, int rs, int ring) {
+  const size_t ns = (size_t)ring + 2;
+  const size_t fwd = 4 * (size_t)nc + 12 * ns * ((size_t)rs + 8) + 16 * ns + 64 + (((size_t)max_len + 15) & ~(size_t)15);
+  const size_t bundle = 12 * (size_t)nc;
+  return (fwd > bundle ? fwd : bundle) + 64;
+}
+
+int64_t poa_wave_ws_ints(int nc, int ec, int max_len, int ws) { return ws_layout(nc, ec, max_len, ws).total; }
+
+template <int C>
+static hipError_t launch_c(const PoaWaveTask* d_tasks, int n_tasks, size_t lds_bytes, const uint8_t* d_seqs,
+                           const int64_t* d_seq_off, int32_t* ws32, uint8_t* ws8, int32_t* d_len, int32_t* d_status,
+                           unsigned long long* d_cells, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute((const void*)poa_wave_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(poa_wave_kernel<C>, dim3((unsigned)n_tasks), dim3(64), lds_bytes, stream, d_tasks, d_seqs, d_seq_off, ws32, ws8,
+                     d_len, d_status, d_cells);
+  return hipGetLastError();
+}
+
+hipError_t poa_wave_launch(int cols, const PoaWaveTask* d_tasks, int n_tasks, size_t lds_bytes, const uint8_t* d_seqs,
+                           const int64_t* d_seq_off, int32_t* ws32, uint8_t* ws8, int32_t* d_len, int32_t* d_status,
+                           unsigned long long* d_cells, hipStream_t stream) {
+  hipError_t e;
+  if (cols == 1) e = launch_c<1>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
+  else if (cols == 3) e = launch_c<3>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
+  else if (cols == 5) e = launch_c<5>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
+  else return hipErrorInvalidValue;
+  return e;
+}
+
+// SVDSS_DEBUG: in-kernel phase timers summed over the sub-clusters run since the last call
+void poa_wave_debug_report() {
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_poaw_prof), sizeof h) != hipSuccess) return;
+  fprintf(stderr, "[poa_wave] 100MHz ticks (sum over clusters): prepare %llu forward %llu traceback %llu update %llu bundle %llu\n",
+          h[0], h[1], h[2], h[3], h[4]);
+  memset(h, 0, sizeof h);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_poaw_prof), h, sizeof h);
+}
