@@ -9,8 +9,11 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <future>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -49,10 +52,10 @@ class BamReader {
  public:
   explicit BamReader(const std::string& path, int threads = 0) : f_(fopen(path.c_str(), "rb")) {
     const unsigned hw = std::thread::hardware_concurrency();
-    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(32u, hw ? hw : 1u));
   }
   ~BamReader() {
-    if (pending_.valid()) pending_.wait();
+    drain();
     if (f_) fclose(f_);
   }
   BamReader(const BamReader&) = delete;
@@ -127,10 +130,55 @@ class BamReader {
     return 1;
   }
 
+  // A record sliced but not decoded: core fields + where name / cigar / packed bases / aux tags sit in an
+  // arena the caller owns (qualities are skipped).  Slicing is sequential and runs at memcpy speed; the
+  // caller decodes many records in parallel.
+  struct RawRec {
+    size_t off = 0;                 // arena offset of: name (l_name bytes, NUL-terminated), cigar, seq4, aux
+    uint32_t l_name = 0, n_cigar = 0, l_aux = 0;
+    int32_t tid = -1, pos = 0, l_seq = 0;
+    uint16_t flag = 0;
+    uint8_t mapq = 0;
+    size_t name_off() const { return off; }
+    size_t seq_off() const { return off + l_name + 4u * n_cigar; }
+    size_t aux_off() const { return seq_off() + (size_t)(l_seq + 1) / 2; }
+  };
+
+  // 1 = record appended to arena, 0 = clean end of file, -1 = error
+  int next_raw(std::vector<uint8_t>& arena, RawRec& rr) {
+    int32_t block_size;
+    const size_t got = read_some(&block_size, 4);
+    if (got == 0) return 0;
+    uint8_t core[32];
+    if (got != 4 || block_size < 32 || !read(core, 32)) { err_ = "truncated record"; return -1; }
+    uint16_t n_cigar;
+    memcpy(&rr.tid, core, 4);
+    memcpy(&rr.pos, core + 4, 4);
+    rr.l_name = core[8];
+    rr.mapq = core[9];
+    memcpy(&n_cigar, core + 12, 2);
+    rr.n_cigar = n_cigar;
+    memcpy(&rr.flag, core + 14, 2);
+    memcpy(&rr.l_seq, core + 16, 4);
+    if (rr.l_seq < 0) { err_ = "corrupt record"; return -1; }
+    const size_t head = (size_t)rr.l_name + 4u * rr.n_cigar + (size_t)(rr.l_seq + 1) / 2;
+    if (32 + head + (size_t)rr.l_seq > (size_t)block_size) { err_ = "corrupt record"; return -1; }
+    rr.l_aux = (uint32_t)((size_t)block_size - 32 - head - (size_t)rr.l_seq);
+    rr.off = arena.size();
+    arena.resize(rr.off + head + rr.l_aux);
+    if (!read(arena.data() + rr.off, head) || !skip((size_t)rr.l_seq) || !read(arena.data() + rr.off + head, rr.l_aux)) {
+      err_ = "truncated record";
+      return -1;
+    }
+    return 1;
+  }
+
   // integer aux tag (bam_aux_get + bam_aux2i); returns false if absent or not an integer
   static bool aux_int(const BamRecord& r, const char tag[2], int64_t& out) {
-    const uint8_t* p = r.aux.data();
-    const uint8_t* e = p + r.aux.size();
+    return aux_int(r.aux.data(), r.aux.size(), tag, out);
+  }
+  static bool aux_int(const uint8_t* p, size_t n, const char tag[2], int64_t& out) {
+    const uint8_t* e = p + n;
     while (p + 3 <= e) {
       const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
       p += 3;
@@ -171,6 +219,19 @@ class BamReader {
   bool fail(const char* m) { err_ = m; return false; }
   bool read(void* dst, size_t n) { return read_some(dst, n) == n; }
 
+  bool skip(size_t n) {
+    while (n) {
+      if (upos_ == ublock_.size()) {
+        if (!next_chunk()) return false;
+        continue;
+      }
+      const size_t take = std::min(n, ublock_.size() - upos_);
+      upos_ += take;
+      n -= take;
+    }
+    return true;
+  }
+
   // reads up to n uncompressed bytes, refilling from inflated chunks of BGZF blocks
   size_t read_some(void* dst, size_t n) {
     size_t done = 0;
@@ -200,33 +261,51 @@ class BamReader {
 
   bool next_chunk() {
     if (eof_seen_) return false;   // the final chunk was already handed out
-    if (!pending_.valid()) pending_ = std::async(std::launch::async, [this] { return load_chunk(); });
-    Chunk c = pending_.get();
-    if (!c.err.empty()) { err_ = c.err; eof_seen_ = true; return false; }
-    if (c.eof) eof_seen_ = true;
-    else pending_ = std::async(std::launch::async, [this] { return load_chunk(); });
+    while (pending_.size() < kAhead && !launched_eof_) {
+      const uint64_t ticket = n_launched_++;
+      pending_.push_back(std::async(std::launch::async, [this, ticket] { return load_chunk(ticket); }));
+    }
+    if (pending_.empty()) { eof_seen_ = true; return false; }
+    Chunk c = pending_.front().get();
+    pending_.pop_front();
+    if (!c.err.empty()) { err_ = c.err; eof_seen_ = true; drain(); return false; }
+    if (c.eof) { eof_seen_ = true; drain(); }
     ublock_.swap(c.data);
     upos_ = 0;
     return !(c.eof && ublock_.empty());
   }
 
-  // runs on a background thread; the only code that touches f_ after construction
-  Chunk load_chunk() {
+  void drain() {
+    for (auto& f : pending_) if (f.valid()) f.wait();
+    pending_.clear();
+  }
+
+  // runs on background threads.  File reads happen in ticket order (one loader at a time); the inflate of a
+  // chunk overlaps the file read of the next one.
+  Chunk load_chunk(uint64_t ticket) {
     Chunk c;
     std::vector<uint8_t> comp;
     std::vector<BlockRef> blocks;
     size_t total = 0;
+    std::unique_lock<std::mutex> file_lock(file_m_);
+    file_cv_.wait(file_lock, [&] { return next_ticket_ == ticket; });
+    struct Release {   // hand the file to the next loader on every exit path
+      BamReader* r; std::unique_lock<std::mutex>* lk; bool done = false;
+      void operator()() { if (!done) { done = true; ++r->next_ticket_; lk->unlock(); r->file_cv_.notify_all(); } }
+      ~Release() { (*this)(); }
+    } release{this, &file_lock};
+    if (file_eof_) { c.eof = true; return c; }
     while (blocks.size() < kChunkBlocks) {
       uint8_t h[18];
       const size_t g = fread(h, 1, 18, f_);
-      if (g == 0) { c.eof = true; break; }
-      if (g != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { c.err = "bad BGZF block"; return c; }
+      if (g == 0) { c.eof = true; file_eof_ = true; break; }
+      if (g != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { c.err = "bad BGZF block"; file_eof_ = true; return c; }
       uint16_t xlen;
       memcpy(&xlen, h + 10, 2);
       // find the BC subfield (normally the only one, right at h[12..17])
       std::vector<uint8_t> extra(xlen);
       memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
-      if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6u, f_) != xlen - 6u) { c.err = "bad BGZF block"; return c; }
+      if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6u, f_) != xlen - 6u) { c.err = "bad BGZF block"; file_eof_ = true; return c; }
       int bsize = -1;
       for (size_t o = 0; o + 4 <= extra.size();) {
         uint16_t slen;
@@ -236,11 +315,11 @@ class BamReader {
         }
         o += 4u + slen;
       }
-      if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) { c.err = "BGZF block without BC field"; return c; }
+      if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) { c.err = "BGZF block without BC field"; file_eof_ = true; return c; }
       const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
       const size_t at = comp.size();
       comp.resize(at + cdata + 8);
-      if (fread(comp.data() + at, 1, cdata + 8, f_) != cdata + 8) { c.err = "truncated BGZF block"; return c; }
+      if (fread(comp.data() + at, 1, cdata + 8, f_) != cdata + 8) { c.err = "truncated BGZF block"; file_eof_ = true; return c; }
       BlockRef b;
       b.coff = at; b.clen = cdata; b.uoff = total;
       memcpy(&b.crc, comp.data() + at + cdata, 4);
@@ -248,6 +327,7 @@ class BamReader {
       total += b.isize;
       blocks.push_back(b);
     }
+    release();
     c.data.resize(total);
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, blocks.size()));
     std::vector<std::string> errs((size_t)nt);
@@ -281,7 +361,13 @@ class BamReader {
 
   FILE* f_;
   int threads_ = 1;
-  std::future<Chunk> pending_;
+  static constexpr size_t kAhead = 3;
+  std::deque<std::future<Chunk>> pending_;
+  std::mutex file_m_;
+  std::condition_variable file_cv_;
+  uint64_t next_ticket_ = 0, n_launched_ = 0;
+  bool file_eof_ = false;          // (guarded by file_m_)
+  bool launched_eof_ = false;
   bool eof_seen_ = false;
   std::string err_;
   std::vector<std::string> refs_;

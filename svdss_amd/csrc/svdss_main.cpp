@@ -16,6 +16,7 @@
 #include <cstring>
 #include <ctime>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -245,7 +246,8 @@ int main_search(const Options& o) {
   logmsg("info", "Extracting SFS strings on the GPU (output order as with " + std::to_string(o.threads) + " threads)..");
   // One GPU launch covers many reference-sized batches; the text is still emitted batch by
   // batch, thread slice by thread slice, read names in std::map order (ping_pong.cpp:215-217).
-  const int64_t super = std::max<int64_t>(o.bsize, 262144 / o.bsize * (int64_t)o.bsize);
+  // (32 k reads keep the GPU efficient and let parsing, search and output of successive batches overlap)
+  const int64_t super = std::max<int64_t>(o.bsize, 32768 / o.bsize * (int64_t)o.bsize);
   // a packed pair of 4-bit BAM bases -> two nt6 codes
   uint8_t nt16_to_nt6[16];
   check(svdss_nt6_encode(NT16, 16, nt16_to_nt6), "svdss_nt6_encode");
@@ -254,43 +256,86 @@ int main_search(const Options& o) {
 
   BoundedQueue<SearchBatch> parsed(2), searched(2);
   uint64_t n_seen = 0, total_sfs = 0;
+  double t_slice = 0, t_decode = 0, t_gpu = 0, t_write = 0;   // busy seconds of the stages (--verbose)
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+
+  const int n_workers = o.io_threads > 0 ? o.io_threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  // items [0, n) over the worker threads, contiguous slices
+  auto parallel_for = [&](size_t n, const std::function<void(size_t, size_t)>& body) {
+    const size_t nt = std::min<size_t>((size_t)n_workers, std::max<size_t>(1, n / 64));
+    if (nt <= 1) { body(0, n); return; }
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(body, n * t / nt, n * (t + 1) / nt);
+    body(0, n / nt);
+    for (std::thread& th : pool) th.join();
+  };
 
   std::thread producer([&] {
     bool eof = false;
-    BamRecord rec;   // reused: its buffers keep their capacity
+    std::vector<uint8_t> arena;
+    std::vector<BamReader::RawRec> recs;
     while (!eof) {
       std::unique_ptr<SearchBatch> bt(new SearchBatch);
       bt->goff.assign(1, 0);
-      while ((int64_t)bt->reads.size() < super) {
-        Read r;
-        bool search = true;
-        if (bam_mode) {
-          const int rc = bam->next(rec, false);
+      if (bam_mode) {
+        // slice the records of one batch out of the stream (sequential), then decode them in parallel
+        arena.clear();
+        recs.clear();
+        const auto ts0 = now();
+        while ((int64_t)recs.size() < super) {
+          BamReader::RawRec rr;
+          const int rc = bam->next_raw(arena, rr);
           if (rc == 0) { eof = true; break; }
           if (rc < 0) die("error reading " + o.bam + ": " + bam->error());
           ++n_seen;
-          if (rec.flag & (4 | 2048 | 256)) continue;                     // ping_pong.cpp:66-69
-          if (rec.l_seq < 100) {                                         // :70-75
+          bool keep = !(rr.flag & (4 | 2048 | 256));                     // ping_pong.cpp:66-69
+          if (keep && rr.l_seq < 100) {                                  // :70-75
             logmsg("warning", "Alignment filtered due to l_qseq. Why are we here? Please check");
-            continue;
+            keep = false;
           }
-          if (rec.tid < 0) die("core.tid < 0. Why are we here? Please check");  // :76-79
-          int64_t xf = 0, hp = 0;
-          BamReader::aux_int(rec, "XF", xf);                             // :196-201, missing => 0
-          BamReader::aux_int(rec, "HP", hp);
-          r.name = rec.qname;
-          r.hp = (int)hp;
-          search = !(o.putative && xf != 0);                             // :202-203
-          if (search) {
-            r.len = rec.l_seq;
-            const size_t at = bt->gbuf.size();
-            bt->gbuf.resize(at + (size_t)rec.l_seq + 1);
-            uint8_t* dst = bt->gbuf.data() + at;
-            const size_t pairs = ((size_t)rec.l_seq + 1) / 2;
-            for (size_t k = 0; k < pairs; ++k) memcpy(dst + 2 * k, &pair_to_nt6[rec.seq4[k]], 2);
-            bt->gbuf.resize(at + (size_t)rec.l_seq);
+          if (keep && rr.tid < 0) die("core.tid < 0. Why are we here? Please check");  // :76-79
+          if (!keep) { arena.resize(rr.off); continue; }
+          recs.push_back(rr);
+        }
+        const auto ts1 = now();
+        t_slice += secs(ts0, ts1);
+        const size_t n = recs.size();
+        bt->reads.resize(n);
+        parallel_for(n, [&](size_t lo, size_t hi) {
+          for (size_t i = lo; i < hi; ++i) {
+            const BamReader::RawRec& rr = recs[i];
+            Read& r = bt->reads[i];
+            r.name.assign((const char*)arena.data() + rr.name_off(), rr.l_name ? rr.l_name - 1 : 0);
+            int64_t xf = 0, hp = 0;
+            BamReader::aux_int(arena.data() + rr.aux_off(), rr.l_aux, "XF", xf);   // :196-201, missing => 0
+            BamReader::aux_int(arena.data() + rr.aux_off(), rr.l_aux, "HP", hp);
+            r.hp = (int)hp;
+            if (o.putative && xf != 0) { r.count = -1; r.len = 0; }                 // :202-203
+            else r.len = rr.l_seq;
           }
-        } else {
+        });
+        for (size_t i = 0; i < n; ++i) {
+          if (bt->reads[i].count < 0) continue;
+          bt->gidx.push_back(i);
+          bt->goff.push_back(bt->goff.back() + bt->reads[i].len);
+        }
+        bt->gbuf.resize((size_t)bt->goff.back() + 1);
+        parallel_for(bt->gidx.size(), [&](size_t lo, size_t hi) {
+          for (size_t k = lo; k < hi; ++k) {
+            const BamReader::RawRec& rr = recs[bt->gidx[k]];
+            const uint8_t* seq4 = arena.data() + rr.seq_off();
+            uint8_t* dst = bt->gbuf.data() + bt->goff[k];
+            const size_t full = (size_t)rr.l_seq / 2;
+            for (size_t x = 0; x < full; ++x) memcpy(dst + 2 * x, &pair_to_nt6[seq4[x]], 2);
+            if (rr.l_seq & 1) dst[rr.l_seq - 1] = nt16_to_nt6[seq4[full] >> 4];
+          }
+        });
+        bt->gbuf.resize((size_t)bt->goff.back());
+        t_decode += secs(ts1, now());
+      } else {
+        while ((int64_t)bt->reads.size() < super) {
+          Read r;
           std::string seq;
           if (!fx->next(r.name, seq)) { eof = true; break; }
           ++n_seen;
@@ -298,15 +343,10 @@ int main_search(const Options& o) {
           const size_t at = bt->gbuf.size();
           bt->gbuf.resize(at + seq.size());
           svdss_nt6_encode(seq.data(), (int64_t)seq.size(), bt->gbuf.data() + at);
-        }
-        if (search) {
           bt->goff.push_back((int64_t)bt->gbuf.size());
           bt->gidx.push_back(bt->reads.size());
-        } else {
-          r.count = -1;
-          r.len = 0;
+          bt->reads.push_back(std::move(r));
         }
-        bt->reads.push_back(std::move(r));
       }
       if (!bt->reads.empty()) parsed.push(std::move(bt));
     }
@@ -316,6 +356,7 @@ int main_search(const Options& o) {
   std::thread writer([&] {
     std::string out;
     while (std::unique_ptr<SearchBatch> bt = searched.pop()) {
+      const auto tw0 = now();
       const std::vector<Read>& reads = bt->reads;
       // output_batch order: reference batches of bsize reads -> thread t takes reads n with
       // n % T == t (ping_pong.cpp:59,101-104) -> std::map<qname, vector<SFS>> order (:217)
@@ -343,6 +384,7 @@ int main_search(const Options& o) {
         }
         if (out.size() > (1u << 20)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
       }
+      t_write += secs(tw0, now());
     }
     fwrite(out.data(), 1, out.size(), stdout);
     fflush(stdout);
@@ -350,6 +392,7 @@ int main_search(const Options& o) {
 
   svdss_sfs_batch_t* res = nullptr;
   while (std::unique_ptr<SearchBatch> bt = parsed.pop()) {
+    const auto tg0 = now();
     if (!bt->gidx.empty()) {
       std::vector<int64_t> counts(bt->gidx.size());
       check(svdss_sfs_search_batch(ix, bt->gbuf.data(), bt->goff.data(), (int64_t)bt->gidx.size(),
@@ -365,12 +408,17 @@ int main_search(const Options& o) {
       }
     }
     std::vector<uint8_t>().swap(bt->gbuf);
+    t_gpu += secs(tg0, now());
     searched.push(std::move(bt));
   }
   searched.close();
   producer.join();
   writer.join();
-  if (o.verbose) logmsg("debug", std::to_string(n_seen) + " records read, " + std::to_string(total_sfs) + " SFS written at +" + since() + " s");
+  if (o.verbose) {
+    logmsg("debug", std::to_string(n_seen) + " records read, " + std::to_string(total_sfs) + " SFS written at +" + since() + " s");
+    logmsg("debug", "stage busy seconds: inflate+slice " + std::to_string(t_slice) + ", decode " + std::to_string(t_decode) +
+                        ", GPU search + copies " + std::to_string(t_gpu) + ", format+write " + std::to_string(t_write));
+  }
   svdss_sfs_batch_free(res);
   svdss_index_free(ix);
   delete bam;
