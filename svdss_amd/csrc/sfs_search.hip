@@ -285,6 +285,7 @@ struct SfsParams {
   int64_t n_items;          // work items of this launch
   unsigned long long* n_fallback;   // stitch kernel: number of reads to redo unsegmented
   int64_t* fallback_ids;
+  int32_t* seg_take;       // per read and segment: [lo, hi) of the records that belong to the read's chain (-1: redo)
   uint32_t epoch;           // tag of the records written by this launch (see peek)
 };
 
@@ -376,6 +377,10 @@ __device__ __forceinline__ svdss_u4 sv_load16(const uint8_t* p) {
   return r;
 }
 
+#ifdef SV_COUNT_ITERS
+__device__ unsigned long long g_sfs_iters[16];   // [0] wave iterations, [1] lane ops, [2+op] lane ops by type
+#endif
+
 template <class P, bool SEG>
 __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
   __shared__ uint32_t ring_lds[16 * 256];   // 64 read symbols per lane: row r of lane t at [r*256 + t]
@@ -460,6 +465,10 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       active = true;
     }
     const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, peek);
+#ifdef SV_COUNT_ITERS
+    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(&g_sfs_iters[0], 1ULL);
+    atomicAdd(&g_sfs_iters[2 + o.op], 1ULL);
+#endif
     if (o.op == SV_OP_DONE) {
       if (SEG) {
         SvSegInfo z;
@@ -541,6 +550,8 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
 // what the unsegmented kernel would have written.  Reads whose overrun did not reach the shared
 // SFS start are queued for an unsegmented search.
 __global__ void __launch_bounds__(256) sfs_stitch_kernel(SfsParams p) {
+  // phase 1, one thread per read: find the shared SFS starts (a short walk over the records next to each
+  // segment boundary) and leave the record range taken from every segment in seg_take
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= p.n_reads) return;
   const int64_t off = p.offsets[r];
@@ -561,29 +572,100 @@ __global__ void __launch_bounds__(256) sfs_stitch_kernel(SfsParams p) {
     e = (int32_t)v.z;
   };
   int64_t ext = 0;
+  int32_t* take = p.seg_take + 2 * r * p.n_seg;
   if (!sv_stitch(cr, info, seg_lo, get, tlo, thi, &ext)) {
     const unsigned long long k = atomicAdd(p.n_fallback, 1ULL);
     p.fallback_ids[k] = r;
     p.counts[r] = 0;
     p.n_ext[r] = 0;
+    take[0] = -1;
     return;
   }
+  for (int j = 0; j < cr; ++j) { take[2 * j] = tlo[j]; take[2 * j + 1] = thi[j]; }
+  p.n_ext[r] = ext;
+}
+
+__global__ void __launch_bounds__(256) sfs_assemble_kernel(SfsParams p) {
+  // phase 2, one wavefront per read: run the assembler over the stitched chain and leave the records in the
+  // read's default region, exactly what the unsegmented kernel would have written.
+  // The chain in production order: the taken records of segment cr-1, then cr-2, ... (descending qs).
+  // Streaming Assembler::assemble (sv_emit) opens a new assembled SFS at record i iff
+  // qs_i + l_i <= qs_(i-1), and an assembled SFS is (qs of its last record, end of its first record):
+  // both are functions of adjacent records, so 64 records are assembled per step.
+  __shared__ int32_t s_cum[4][17], s_lo[4][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= p.n_reads) return;
+  const int32_t* take = p.seg_take + 2 * r * p.n_seg;
+  if (take[0] < 0) return;   // queued for an unsegmented search
+  const int64_t off = p.offsets[r];
+  const int64_t len = p.offsets[r + 1] - off;
+  const int cr = seg_count(len, p.n_seg);
+  const int64_t icap = seg_region_cap(len, cr);
+  const int64_t ibase = seg_region_base(off, r, p.n_seg);
   const int64_t base = rec_region_base(off, r);
   const int64_t cap = rec_region_cap(len);
-  const bool assemble = p.assemble != 0;
-  SvLane<uint32_t> as;   // assembler state only
-  sv_lane_init(as, 0);
-  auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
-    if (idx < cap) p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
-  };
-  for (int j = cr - 1; j >= 0; --j)
-    for (int32_t i = tlo[j]; i < thi[j]; ++i) {
-      const uint4 v = p.seg_rec[ibase + j * icap + i];
-      sv_emit(as, (int)v.x, (int)v.y, assemble, emit);
+  int32_t* cum = s_cum[wv];
+  int32_t* tlo = s_lo[wv];
+  if (lane == 0) {
+    int32_t c = 0;
+    cum[0] = 0;
+    for (int k = 0; k < cr; ++k) {   // k-th segment of the chain = segment cr-1-k
+      const int sg = cr - 1 - k;
+      tlo[k] = take[2 * sg];
+      c += take[2 * sg + 1] - take[2 * sg];
+      cum[k + 1] = c;
     }
-  sv_flush(as, assemble, emit);
-  p.counts[r] = as.n_sfs;
-  p.n_ext[r] = ext;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int32_t M = cum[cr];
+  auto load = [&](int32_t g, int32_t& q, int32_t& l) {
+    int k = 0;
+    while (k + 1 < cr && g >= cum[k + 1]) ++k;
+    const uint4 v = p.seg_rec[ibase + (int64_t)(cr - 1 - k) * icap + tlo[k] + (g - cum[k])];
+    q = (int32_t)v.x;
+    l = (int32_t)v.y;
+  };
+  if (!p.assemble) {
+    for (int32_t g = lane; g < M; g += 64) {
+      int32_t q, l;
+      load(g, q, l);
+      if (g < cap) p.rec[base + g] = make_uint2((uint32_t)q, (uint32_t)l);
+    }
+    if (lane == 0) p.counts[r] = M;
+    return;
+  }
+  int32_t runs = 0;        // assembled SFS opened so far
+  int32_t open_end = 0;    // end of the first record of the open one
+  int32_t prev_q = 0;      // qs of the last record of the previous step
+  for (int32_t g0 = 0; g0 < M; g0 += 64) {
+    const int32_t g = g0 + lane;
+    const bool in = g < M;
+    int32_t q = 0, l = 0;
+    if (in) load(g, q, l);
+    const bool has_next = g + 1 < M;
+    int32_t qn = __shfl_down(q, 1, 64), ln = __shfl_down(l, 1, 64);
+    if (lane == 63 && has_next) load(g + 1, qn, ln);
+    int32_t qp = __shfl_up(q, 1, 64);
+    if (lane == 0) qp = prev_q;
+    const bool flag = in && (g == 0 || q + l <= qp);
+    const bool last = in && (!has_next || qn + ln <= q);
+    const unsigned long long fm = __ballot(flag);
+    const unsigned long long le = lane == 63 ? ~0ULL : ((1ULL << (lane + 1)) - 1ULL);
+    const unsigned long long mine = fm & le;
+    const int32_t run_id = runs + __builtin_popcountll(mine) - 1;
+    const int start_lane = mine ? 63 - __builtin_clzll(mine) : -1;
+    const int32_t e_start = __shfl(q + l, start_lane < 0 ? 0 : start_lane, 64);
+    const int32_t e_first = start_lane < 0 ? open_end : e_start;
+    if (last && run_id < cap) p.rec[base + run_id] = make_uint2((uint32_t)q, (uint32_t)(e_first - q));
+    if (fm) open_end = __shfl(q + l, 63 - __builtin_clzll(fm), 64);
+    runs += __builtin_popcountll(fm);
+    const int nin = M - g0 < 64 ? M - g0 : 64;
+    prev_q = __shfl(q, nin - 1, 64);
+  }
+  if (lane == 0) p.counts[r] = runs;
 }
 
 // One wavefront per read: copy its records from the region to the compact
@@ -628,7 +710,7 @@ struct svdss_sfs_batch {
   int64_t total_ext = 0;
   double kernel_ms = 0.0;
   DevBuf rec, counts, n_ext, out_off, out_qs, out_len, tmp, misc, reads, offsets, base2, sum;
-  DevBuf seg_rec, seg_info, fallback;
+  DevBuf seg_rec, seg_info, fallback, seg_take;
   int64_t n_fallback = 0;   // reads of the last call that were redone unsegmented
   int32_t n_seg = 1;        // segments per read used by the last call
   uint32_t epoch = 0;
@@ -655,7 +737,7 @@ extern "C" void svdss_sfs_batch_free(svdss_sfs_batch_t* b) {
   if (b->device >= 0) (void)hipSetDevice(b->device);
   for (DevBuf* d : {&b->rec, &b->counts, &b->n_ext, &b->out_off, &b->out_qs, &b->out_len, &b->tmp,
                     &b->misc, &b->reads, &b->offsets, &b->base2, &b->sum, &b->seg_rec, &b->seg_info,
-                    &b->fallback})
+                    &b->fallback, &b->seg_take})
     release(*d);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -745,7 +827,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   int n_seg = 1;
   {
     const int64_t lanes = (int64_t)max_blocks * 256 / 2;   // 4 waves per SIMD resident
-    const int64_t want = 2 * lanes / (n_reads > 0 ? n_reads : 1);
+    const int64_t want = 4 * lanes / (n_reads > 0 ? n_reads : 1);   // ~4 items per resident lane: dynamic fetch evens out the segments
     n_seg = (int)(want < 2 ? 1 : (want > 8 ? 8 : want));   // beyond 8 the odd unstitchable read costs more than it saves
     if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
     if (n_seg < 1) n_seg = 1;
@@ -758,15 +840,19 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     if ((rc = ensure(b->seg_rec, (size_t)seg_total * sizeof(uint4)))) return rc;
     if ((rc = ensure(b->seg_info, (size_t)(n_reads * n_seg) * sizeof(SvSegInfo)))) return rc;
     if ((rc = ensure(b->fallback, (size_t)n_reads * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(b->seg_take, (size_t)(2 * n_reads * n_seg) * sizeof(int32_t)))) return rc;
     p.seg_rec = (uint4*)b->seg_rec.p;
     p.seg_info = (SvSegInfo*)b->seg_info.p;
     p.fallback_ids = (int64_t*)b->fallback.p;
+    p.seg_take = (int32_t*)b->seg_take.p;
   }
   b->n_seg = n_seg;
   b->n_fallback = 0;
+  int cap_blocks = max_blocks;
+  if (const char* e = getenv("SVDSS_BLOCKS")) cap_blocks = atoi(e) > 0 ? atoi(e) : max_blocks;
   auto blocks_for = [&](int64_t items) {
     const int64_t w = (items + 255) / 256;
-    return (int)(w < 1 ? 1 : (w < max_blocks ? w : max_blocks));
+    return (int)(w < 1 ? 1 : (w < cap_blocks ? w : cap_blocks));
   };
   const int64_t gw = (n_reads + 3) / 4;  // 4 waves per block, one read per wave iteration
   const int gblocks = (int)(gw < 4 * (int64_t)max_blocks ? (gw > 0 ? gw : 1) : 4 * (int64_t)max_blocks);
@@ -795,6 +881,8 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       HIPCHK(hipGetLastError());
       hipLaunchKernelGGL(sfs_stitch_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, p);
       HIPCHK(hipGetLastError());
+      hipLaunchKernelGGL(sfs_assemble_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, stream, p);
+      HIPCHK(hipGetLastError());
       unsigned long long n_fb = 0;
       HIPCHK(hipMemcpyAsync(&n_fb, p.n_fallback, sizeof n_fb, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
@@ -808,6 +896,14 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
         (void)hipEventElapsedTime(&t, b->ev0, e2);
         fprintf(stderr, "[svdss] segmented search + stitch: %.3f ms, %llu of %lld reads to redo\n", t, n_fb,
                 (long long)n_reads);
+#ifdef SV_COUNT_ITERS
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess)
+          fprintf(stderr, "[svdss] wave-iterations %llu; lane ops: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu\n",
+                  h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+        memset(h, 0, sizeof h);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sfs_iters), h, sizeof h);
+#endif
         (void)hipEventDestroy(e2);
       }
       if (n_fb > 0) {   // reads whose chains could not be stitched: one lane per read
