@@ -20,7 +20,7 @@
 #include "fmd_layout.h"
 
 enum { SV_OP_DONE = 0, SV_OP_LF = 1, SV_OP_TABLE = 2, SV_OP_SA = 3, SV_OP_TEXT = 4, SV_OP_FILL = 5,
-       SV_OP_TEXT_SLOW = 6 };
+       SV_OP_TEXT_SLOW = 6, SV_OP_PEEK = 7 };
 
 #define SV_M_DIR 1     // 0 backward (ping_pong.cpp:15-22), 1 forward (:31-37)
 #define SV_M_START 2   // at a phase start: no interval yet (before :12 / :30)
@@ -58,6 +58,9 @@ struct SvLane {
 // the stitcher can find the SFS start the two chains share (see sv_stitch).
 #define SV_OVERRUN 48
 #define SV_M_PARTIAL 16   // the lane stopped after its overrun, not at the start of the read
+#define SV_M_PEEK 32      // waiting for the left neighbour's records (segmented search, see sv_apply_peek)
+#define SV_PEEK_RECS 4    // neighbour records examined per PEEK operation
+#define SV_PEEK_OPS 8     // PEEK operations per SFS before giving up (the overrun goes on)
 
 struct SvOp {
   int op;
@@ -160,18 +163,21 @@ SVDSS_HD void sv_flush(SvLane<P>& s, bool assemble, Emit&& emit) {
 
 // Decide the one memory operation of this iteration.  `off` = absolute buffer
 // position of the read's first symbol.  ALU + ring (LDS) reads only.
-struct SvNoPeek { SVDSS_HD bool operator()(int32_t) const { return false; } };
-
-// peek(begin): segmented search only -- true if the chain of the segment to the left is already
-// known to have started a forward phase at `begin` (then the two chains are identical from here
-// on and this lane can stop; a wrong answer only costs a redo, sv_stitch verifies everything).
-template <class P, class Emit, class Peek = SvNoPeek>
+//
+// can_peek: segmented search only -- the lane has a left neighbour.  After every SFS that starts below the
+// segment's lower boundary the lane looks (SV_OP_PEEK, like any other memory operation of an iteration)
+// whether the neighbour's chain is already known to have started a forward phase at the same `begin`:
+// then the two chains are identical from here on and this lane can stop.  A wrong or missing answer only
+// lengthens the overrun; sv_stitch verifies everything.
+template <class P, class Emit>
 SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, int64_t off,
-                        bool assemble, Emit&& emit, Peek&& peek = SvNoPeek()) {
+                        bool assemble, Emit&& emit, bool can_peek = false) {
   SvOp o;
   o.op = SV_OP_DONE;
   o.a = 0;
   if (s.len <= 0) return o;
+  if (s.mode & SV_M_PARTIAL) return o;
+  if (s.mode & SV_M_PEEK) { o.op = SV_OP_PEEK; return o; }
   for (;;) {
     if (s.mode & SV_M_TEXT) {
       o.op = (off + s.pos >= 64) ? SV_OP_TEXT : SV_OP_TEXT_SLOW;
@@ -245,9 +251,17 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
       }
       sv_emit(s, s.begin, s.pos - s.begin + 1, assemble, emit);  // :38-41
       if (s.begin == 0) return o;                     // :42 -> DONE
-      if (s.begin < s.stop_lo && (peek(s.begin) || ++s.n_below >= SV_OVERRUN)) {
-        s.mode |= SV_M_PARTIAL;                       // segment finished; the stitcher takes over
-        return o;
+      if (s.begin < s.stop_lo) {
+        if (can_peek) {                               // ask the neighbour before going on
+          s.mode |= SV_M_PEEK;
+          s.c = 0;
+          o.op = SV_OP_PEEK;
+          return o;
+        }
+        if (++s.n_below >= SV_OVERRUN) {
+          s.mode |= SV_M_PARTIAL;                     // segment finished; the stitcher takes over
+          return o;
+        }
       }
       s.pos = s.pos - 1;                              // :47
       s.mode = (s.mode & ~SV_M_DIR) | SV_M_START;
@@ -322,6 +336,32 @@ template <class P>
 SVDSS_HD void sv_apply_sa(SvLane<P>& s, int64_t text_pos) {
   s.tdelta = text_pos - s.pos;
   s.mode |= SV_M_TEXT;
+}
+
+// PEEK: q[i] / written[i] = SFS start and "already produced" of the neighbour's records nb_cur, nb_cur+1, ...
+// (production order = descending start).  Decides whether the neighbour started a forward phase at s.begin.
+template <class P>
+SVDSS_HD void sv_apply_peek(SvLane<P>& s, const int32_t q[SV_PEEK_RECS], const bool written[SV_PEEK_RECS],
+                            int32_t& nb_cur, int32_t nb_cap) {
+  bool decided = false, found = false;
+  int adv = 0;
+#pragma unroll
+  for (int i = 0; i < SV_PEEK_RECS; ++i) {
+    if (decided) continue;
+    if (nb_cur + i >= nb_cap || !written[i]) { decided = true; continue; }
+    if (q[i] == s.begin) { decided = true; found = true; continue; }
+    if (q[i] < s.begin) { decided = true; continue; }
+    ++adv;
+  }
+  nb_cur += adv;
+  if (!decided && ++s.c < SV_PEEK_OPS) return;       // look at the next records
+  s.mode &= ~SV_M_PEEK;
+  if (found || ++s.n_below >= SV_OVERRUN) {
+    s.mode |= SV_M_PARTIAL;                           // segment finished; the stitcher takes over
+    return;
+  }
+  s.pos = s.pos - 1;                                  // ping_pong.cpp:47
+  s.mode = (s.mode & ~SV_M_DIR) | SV_M_START;
 }
 
 // TEXT: ta[] = text bytes, rb[] = read bytes, both for read positions

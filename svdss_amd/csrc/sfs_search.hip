@@ -377,8 +377,45 @@ __device__ __forceinline__ svdss_u4 sv_load16(const uint8_t* p) {
   return r;
 }
 
+// Longest-processing-time-first scheduling.  Lanes fetch items dynamically, so the launch ends when the last
+// item that was started ends: the items that take 5-10 x the median (reads in repeats: every backward phase
+// walks the BWT one symbol at a time until a single copy is left) must start first, not last.  One wavefront
+// per read samples 128 pairs of adjacent K-mers in the table; reads where at least two pairs occur more than
+// once in the reference go to the front of the order, the rest to the back.  The order only decides when a
+// read is searched, never what is found.
+__global__ void __launch_bounds__(256) sfs_order_kernel(SfsParams p, int64_t* order, unsigned long long* cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= p.n_reads) return;
+  const int64_t off = p.offsets[r];
+  const int64_t len = p.offsets[r + 1] - off;
+  const int K = p.ix.k;
+  const uint8_t* reads = (const uint8_t*)p.chunks;
+  int hits = 0;
+  if (K >= 8 && p.ix.table != nullptr && len >= 8 * K) {
+    const int64_t span = len - 2 * K;
+    for (int i = lane; i < 128; i += 64) {
+      const int64_t pos = off + (span * (2 * i + 1)) / 256;
+      uint32_t k1 = 0, k2 = 0;
+      bool ok = true;
+      for (int t = 0; t < K; ++t) {
+        const uint32_t a = (uint32_t)reads[pos + t] - 1u, b = (uint32_t)reads[pos + K + t] - 1u;
+        ok = ok && a < 4u && b < 4u;
+        k1 |= (a & 3u) << (2 * t);
+        k2 |= (b & 3u) << (2 * t);
+      }
+      if (ok && (p.ix.table[k1].info >> 62) == SVDSS_TAB_MULTI && (p.ix.table[k2].info >> 62) == SVDSS_TAB_MULTI) ++hits;
+    }
+  }
+  const int heavy = __builtin_popcountll(__ballot(hits > 0)) + __builtin_popcountll(__ballot(hits > 1));
+  if (lane == 0) {
+    if (heavy >= 2) order[atomicAdd(&cnt[0], 1ULL)] = r;
+    else order[p.n_reads - 1 - (int64_t)atomicAdd(&cnt[1], 1ULL)] = r;
+  }
+}
+
 #ifdef SV_COUNT_ITERS
-__device__ unsigned long long g_sfs_iters[16];   // [0] wave iterations, [1] lane ops, [2+op] lane ops by type
+__device__ unsigned long long g_sfs_iters[48];   // [0] wave iterations, [1] lane ops, [2+op] lane ops by type
 #endif
 
 template <class P, bool SEG>
@@ -413,39 +450,43 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
     }
   };
 
-  // Has the chain of the segment to the left (records right below this lane's region, tagged
-  // with this launch's epoch as they are produced) started a forward phase at `begin`?  The
-  // segments of a read are fetched back to back, so the neighbour is normally far ahead; a
-  // stale or missing answer only lengthens the overrun.
-  auto peek = [&](int32_t begin) -> bool {
-    if (!SEG || !has_left) return false;
-#pragma unroll 1
-    for (int it = 0; it < 32 && nb_cur < cap; ++it) {
-      const unsigned long long* rp = (const unsigned long long*)(p.seg_rec + (base - cap + nb_cur));
-      const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)(hi >> 32) != p.epoch) return false;
-      const int32_t q = (int32_t)(uint32_t)__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (q == begin) return true;
-      if (q < begin) return false;
-      ++nb_cur;
-    }
-    return false;
+  // The next item is fetched while the current one is being finished (ticket, read id, offsets: three
+  // dependent loads that ride along with the lane's memory operation of three iterations) -- fetched
+  // inline they stall the whole wavefront every time one of its 64 lanes starts an item.
+  // The prefetched read id / offset / length wait in LDS (the kernel has no VGPR to spare).
+  __shared__ uint32_t pf_lds[4 * 256];
+  uint32_t* pfl = &pf_lds[threadIdx.x];   // rows: read id, offset lo, offset hi, length
+#ifdef SV_COUNT_ITERS
+  uint32_t item_ops = 0;
+#endif
+  int pf = 0;                       // 0 nothing, 1 ticket, 2 + read id, 3 + offsets
+  uint32_t nt = 0;                  // ticket (n_items < 2^31: checked by the host)
+  auto pf_read_id = [&]() {
+    const uint32_t slot = SEG ? nt >> p.seg_shift : nt;
+    pfl[0] = p.read_ids ? (uint32_t)p.read_ids[slot] : slot;
   };
-
+  auto pf_offsets = [&]() {
+    const int64_t rr = (int64_t)pfl[0];
+    const int64_t o0 = p.offsets[rr], o1 = p.offsets[rr + 1];
+    pfl[256] = (uint32_t)o0; pfl[512] = (uint32_t)((uint64_t)o0 >> 32); pfl[768] = (uint32_t)(o1 - o0);
+  };
   for (;;) {
     if (!active) {
-      const unsigned long long t = atomicAdd(p.next_read, 1ULL);
-      if (t >= (unsigned long long)p.n_items) break;
-      item = (int64_t)t;   // consecutive items = the segments of one read, left to right
+      if (pf == 0) nt = (uint32_t)atomicAdd(p.next_read, 1ULL);
+      if (nt >= (uint32_t)p.n_items) break;
+      if (pf < 2) pf_read_id();
+      if (pf < 3) pf_offsets();
+      pf = 0;
+      item = (int64_t)nt;   // consecutive items = the segments of one read, left to right
+      r = (int64_t)pfl[0];
+      off = (int64_t)((uint64_t)pfl[256] | ((uint64_t)pfl[512] << 32));
+      const int64_t len = (int64_t)pfl[768];
       if (SEG) {
-        r = item >> p.seg_shift;
         const int j = (int)(item & (p.n_seg - 1));
-        off = p.offsets[r];
-        const int64_t len = p.offsets[r + 1] - off;
         const int cr = seg_count(len, p.n_seg);
         if (j >= cr) {                       // short read: fewer segments than lanes reserved for it
           SvSegInfo z; z.n_rec = 0; z.cap = 0; z.ext_total = 0; z.complete = 0;
-          p.seg_info[item] = z;
+          p.seg_info[(r << p.seg_shift) + j] = z;
           continue;
         }
         cap = seg_region_cap(len, cr);
@@ -455,26 +496,25 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
         const int32_t sl = (int32_t)((uint32_t)len / (uint32_t)cr);
         sv_lane_init(st, (int32_t)len, seg_start_pos((int32_t)len, sl, j, cr), seg_lo_pos(sl, j));
       } else {
-        r = p.read_ids ? p.read_ids[item] : item;
-        off = p.offsets[r];
-        const int64_t len = p.offsets[r + 1] - off;
         base = p.rec_base ? p.rec_base[r] : rec_region_base(off, r);
         cap = p.rec_cap ? p.rec_cap[r] : rec_region_cap(len);
         sv_lane_init(st, (int32_t)len);
       }
       active = true;
     }
-    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, peek);
+    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, SEG && has_left);
 #ifdef SV_COUNT_ITERS
     if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(&g_sfs_iters[0], 1ULL);
     atomicAdd(&g_sfs_iters[2 + o.op], 1ULL);
+    ++item_ops;
+    if (o.op == SV_OP_DONE) { atomicAdd(&g_sfs_iters[16 + (31 - __builtin_clz(item_ops | 1))], 1ULL); item_ops = 0; }
 #endif
     if (o.op == SV_OP_DONE) {
       if (SEG) {
         SvSegInfo z;
         z.n_rec = st.n_sfs; z.cap = (int32_t)cap; z.ext_total = st.n_ext;
         z.complete = (st.mode & SV_M_PARTIAL) ? 0 : 1;
-        p.seg_info[item] = z;
+        p.seg_info[(r << p.seg_shift) + (item & (p.n_seg - 1))] = z;
       } else {
         sv_flush(st, assemble, emit);
         p.counts[r] = st.n_sfs;
@@ -486,6 +526,13 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
     if (o.op == SV_OP_TEXT_SLOW) {   // only the first 64 bytes of the whole batch
       sv_apply_text_slow(st, p.ix.text, reads, off);
       continue;
+    }
+    if (pf < 3 && st.pos - st.stop_lo < 256) {   // close to the end of this item: get the next one under way
+      if (pf == 0) nt = (uint32_t)atomicAdd(p.next_read, 1ULL);
+      else if (nt < (uint32_t)p.n_items) {
+        if (pf == 1) pf_read_id(); else pf_offsets();
+      }
+      ++pf;
     }
     // one memory operation per lane: up to 4 x 16 B from pa and 4 x 16 B from pb
     const uint8_t* pa = blocks;
@@ -507,6 +554,14 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       pb = reads + off + st.pos - 64;
       wide_a = true;
       need_b = true;
+    } else if (o.op == SV_OP_PEEK) {
+      // the left neighbour's records sit right below this lane's region, tagged with this launch's epoch as
+      // they are produced; the segments of a read are fetched back to back, so the neighbour is normally far ahead
+      int32_t i0 = nb_cur;
+      if (i0 > (int32_t)cap - SV_PEEK_RECS) i0 = (int32_t)cap - SV_PEEK_RECS;   // stay inside its region
+      if (i0 < 0) i0 = 0;
+      pa = (const uint8_t*)(p.seg_rec + (base - cap + i0));
+      c0 = i0;
     } else {  // SV_OP_FILL
       c0 = o.a;
       if (c0 > p.max_chunk - 3) c0 = p.max_chunk - 3;
@@ -515,7 +570,16 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       need_b = true;
     }
     svdss_u4 A[4], B[4];
-    if (o.op != SV_OP_FILL) A[0] = sv_load16(pa);
+    if (o.op == SV_OP_PEEK) {
+      // agent-scope loads: the records were stored (write-through) by lanes that may sit on another XCD
+#pragma unroll
+      for (int i = 0; i < SV_PEEK_RECS; ++i) {
+        const unsigned long long* rp = (const unsigned long long*)pa + 2 * i;
+        const unsigned long long lo = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        A[i].x = (uint32_t)lo; A[i].y = (uint32_t)(lo >> 32); A[i].z = (uint32_t)hi; A[i].w = (uint32_t)(hi >> 32);
+      }
+    } else if (o.op != SV_OP_FILL) A[0] = sv_load16(pa);
     if (wide_a) {
       A[1] = sv_load16(pa + 16);
       A[2] = sv_load16(pa + 32);
@@ -538,6 +602,19 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       sv_apply_sa(st, tp);
     } else if (o.op == SV_OP_TEXT) {
       sv_apply_text(st, A, B);
+    } else if (o.op == SV_OP_PEEK) {
+      int32_t q[SV_PEEK_RECS];
+      bool written[SV_PEEK_RECS];
+      const int32_t sh = nb_cur - (int32_t)c0;   // records of the window already skipped (window clamped to the region)
+#pragma unroll
+      for (int i = 0; i < SV_PEEK_RECS; ++i) {
+        const int k = i + sh;
+        const uint32_t qq = k == 0 ? A[0].x : k == 1 ? A[1].x : k == 2 ? A[2].x : A[3].x;
+        const uint32_t ee = k == 0 ? A[0].w : k == 1 ? A[1].w : k == 2 ? A[2].w : A[3].w;
+        q[i] = (int32_t)qq;
+        written[i] = k < SV_PEEK_RECS && ee == p.epoch;
+      }
+      sv_apply_peek(st, q, written, nb_cur, (int32_t)cap);
     } else {
       sv_ring_fill(g, c0, B);
       st.wrel = (int32_t)(16 * c0 - off);
@@ -710,7 +787,7 @@ struct svdss_sfs_batch {
   int64_t total_ext = 0;
   double kernel_ms = 0.0;
   DevBuf rec, counts, n_ext, out_off, out_qs, out_len, tmp, misc, reads, offsets, base2, sum;
-  DevBuf seg_rec, seg_info, fallback, seg_take;
+  DevBuf seg_rec, seg_info, fallback, seg_take, order, order_cnt;
   int64_t n_fallback = 0;   // reads of the last call that were redone unsegmented
   int32_t n_seg = 1;        // segments per read used by the last call
   uint32_t epoch = 0;
@@ -737,7 +814,7 @@ extern "C" void svdss_sfs_batch_free(svdss_sfs_batch_t* b) {
   if (b->device >= 0) (void)hipSetDevice(b->device);
   for (DevBuf* d : {&b->rec, &b->counts, &b->n_ext, &b->out_off, &b->out_qs, &b->out_len, &b->tmp,
                     &b->misc, &b->reads, &b->offsets, &b->base2, &b->sum, &b->seg_rec, &b->seg_info,
-                    &b->fallback, &b->seg_take})
+                    &b->fallback, &b->seg_take, &b->order, &b->order_cnt})
     release(*d);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -834,6 +911,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     if (n_seg > 16) n_seg = 16;
     while (n_seg & (n_seg - 1)) n_seg &= n_seg - 1;   // power of two: item -> (read, segment) by shift
     if (use_v1 || total_syms / (n_reads > 0 ? n_reads : 1) < 1024) n_seg = 1;
+    if (n_reads * (int64_t)n_seg >= ((int64_t)1 << 31)) n_seg = 1;   // item tickets are 32-bit in the kernel
   }
   if (n_seg > 1) {
     const int64_t seg_total = (total_syms >> 3) + (8 + 24 * (int64_t)n_seg) * n_reads + 64;
@@ -864,12 +942,26 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
   if ((rc = ensure(b->tmp, tmp_bytes))) return rc;
 
+  // heavy reads first (see sfs_order_kernel); SVDSS_ORDER=0 keeps the input order
+  const char* ord_env = getenv("SVDSS_ORDER");
+  const bool use_order = !use_v1 && n_reads >= 1024 && p.ix.k >= 8 && !(ord_env && atoi(ord_env) == 0);
+  if (use_order) {
+    if ((rc = ensure(b->order, (size_t)n_reads * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(b->order_cnt, 16))) return rc;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     HIPCHK(hipMemsetAsync(b->misc.p, 0, 64, stream));
     HIPCHK(hipMemsetAsync((int64_t*)b->counts.p + n_reads, 0, sizeof(int64_t), stream));
     const bool wide = !ix->sa64.empty();
     const bool seg = n_seg > 1 && pass == 0;   // the exact-capacity rerun is always unsegmented
     HIPCHK(hipEventRecord(b->ev0, stream));
+    if (use_order && pass == 0) {
+      HIPCHK(hipMemsetAsync(b->order_cnt.p, 0, 16, stream));
+      hipLaunchKernelGGL(sfs_order_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, stream, p, (int64_t*)b->order.p,
+                         (unsigned long long*)b->order_cnt.p);
+      HIPCHK(hipGetLastError());
+      p.read_ids = (const int64_t*)b->order.p;
+    }
     if (use_v1) {
       hipLaunchKernelGGL(sfs_search_kernel, dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
     } else if (seg) {
@@ -897,10 +989,13 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
         fprintf(stderr, "[svdss] segmented search + stitch: %.3f ms, %llu of %lld reads to redo\n", t, n_fb,
                 (long long)n_reads);
 #ifdef SV_COUNT_ITERS
-        unsigned long long h[16];
+        unsigned long long h[48];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess)
           fprintf(stderr, "[svdss] wave-iterations %llu; lane ops: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu\n",
                   h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+        fprintf(stderr, "[svdss] items by ops (2^k .. 2^(k+1)-1, k=4..15):");
+        for (int k = 4; k < 16; ++k) fprintf(stderr, " %llu", h[16 + k]);
+        fprintf(stderr, "\n");
         memset(h, 0, sizeof h);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sfs_iters), h, sizeof h);
 #endif

@@ -99,17 +99,7 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
   // one lane: the chain that starts with a fresh backward phase at start_pos
   auto run_lane = [&](int64_t off, int64_t l, int start_pos, int stop_lo, bool asm_, std::vector<Rec>& recs,
                       int32_t& ext_total, bool& complete, const std::vector<Rec>* left = nullptr) {
-    size_t nb_cur = 0;
-    auto peek = [&](int32_t begin) -> bool {
-      if (!left) return false;
-      while (nb_cur < left->size()) {
-        const int32_t q = (*left)[nb_cur].qs;
-        if (q == begin) return true;
-        if (q < begin) return false;
-        ++nb_cur;
-      }
-      return false;
-    };
+    int32_t nb_cur = 0;
     uint32_t ring_mem[16];
     memset(ring_mem, 0xee, sizeof ring_mem);
     SvRing g{ring_mem, 1};
@@ -121,10 +111,20 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
     sv_lane_init(st, (int32_t)l, start_pos, stop_lo);
     for (int64_t guard = 0;; ++guard) {
       if (guard > 400 * l + 10000) { fprintf(stderr, "emu2: no termination off=%ld l=%ld start=%d stop=%d pos=%d begin=%d mode=%d lo=%ld hi=%ld wrel=%d nsfs=%d\n", (long)off, (long)l, start_pos, stop_lo, st.pos, st.begin, st.mode, (long)st.lo, (long)st.hi, st.wrel, st.n_sfs); abort(); }
-      SvOp o = sv_decide(st, v, g, off, asm_, emit, peek);
+      SvOp o = sv_decide(st, v, g, off, asm_, emit, left != nullptr);
       if (op_counts) op_counts[o.op]++;
       if (o.op == SV_OP_DONE) break;
       if (o.op == SV_OP_TEXT_SLOW) { sv_apply_text_slow(st, v.text, reads_padded, off); continue; }
+      if (o.op == SV_OP_PEEK) {   // the neighbour's chain is complete here (segments run left to right)
+        int32_t q[SV_PEEK_RECS];
+        bool written[SV_PEEK_RECS];
+        for (int i = 0; i < SV_PEEK_RECS; ++i) {
+          written[i] = (size_t)(nb_cur + i) < left->size();
+          q[i] = written[i] ? (*left)[(size_t)(nb_cur + i)].qs : 0;
+        }
+        sv_apply_peek(st, q, written, nb_cur, 1 << 30);
+        continue;
+      }
       svdss_u4 A[4], B[4];
       if (o.op == SV_OP_LF) {
         const int64_t blo = (int64_t)st.lo >> SVDSS_BLOCK_SHIFT, bhi = (int64_t)st.hi >> SVDSS_BLOCK_SHIFT;
