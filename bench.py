@@ -169,11 +169,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
+    kernel_ms, pipeline_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(pp.last_kernel_ms)   # HIP events recorded on `stream` around the search kernel
+        kernel_ms.append(pp.last_search_kernel_ms)   # HIP events recorded on `stream` around the search kernel alone
+        pipeline_ms.append(pp.last_kernel_ms)        # ... and around order + search + stitch + assemble
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -224,6 +225,11 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(ref_total, n_reads, L, ix.kmer_k),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+                "all_kernels_ms": float(np.mean(pipeline_ms)),
+                # the kernel's memory operations are dependent random reads (one per lane per iteration): the
+                # measured ceiling of that access pattern on this GPU (tools/random_read_probe.hip) next to the
+                # rate at which the kernel's measured traffic arrives, both in 64-B lines per second
+                "random_access": random_access_info(measured_traffic(ref_total, n_reads, L, ix.kmer_k), k_ms),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -234,6 +240,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def random_access_info(traffic_bytes, k_ms):
+    try:
+        with open(os.path.join(ROOT, "profiles", "random_access.json")) as fh:
+            probe = json.load(fh)
+    except OSError:
+        return None
+    out = {"ceiling_dependent_lines_per_s": probe["dependent_random_lines_per_s"],
+           "ceiling_independent_lines_per_s": probe["independent_random_lines_per_s"], "source": probe["source"]}
+    if traffic_bytes:
+        rate = traffic_bytes / 64 / (k_ms * 1e-3)
+        out["achieved_lines_per_s"] = rate
+        out["frac_of_dependent_ceiling"] = rate / probe["dependent_random_lines_per_s"]
+    return out
 
 
 def measured_traffic(ref_total, n_reads, L, k):

@@ -108,6 +108,8 @@ int32_t svdss_sfs_batch_segments(const svdss_sfs_batch_t* b);
 int64_t svdss_sfs_batch_fallbacks(const svdss_sfs_batch_t* b);
 /* duration of the search kernel(s) of the last call, from HIP events on its stream */
 double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b);
+/* HIP-event time of the search kernel alone (first pass; without ordering, stitching, assembling, gather) */
+double svdss_sfs_batch_search_kernel_ms(const svdss_sfs_batch_t* b);
 /* copy results to host; any pointer may be NULL to skip it.
  * counts,n_ext: n_reads entries; qs,len: svdss_sfs_batch_total() entries. */
 int svdss_sfs_batch_fetch(const svdss_sfs_batch_t* b, int64_t* counts, int32_t* qs, int32_t* len,

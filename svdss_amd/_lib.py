@@ -62,6 +62,7 @@ SIGNATURES = {
     "svdss_sfs_batch_total": (_i64, [_p]),
     "svdss_sfs_batch_total_ext": (_i64, [_p]),
     "svdss_sfs_batch_kernel_ms": (C.c_double, [_p]),
+    "svdss_sfs_batch_search_kernel_ms": (C.c_double, [_p]),
     "svdss_sfs_batch_segments": (_i32, [_p]),
     "svdss_sfs_batch_fallbacks": (_i64, [_p]),
     "svdss_sfs_batch_fetch": (C.c_int, [_p, _p, _p, _p, _p]),

@@ -380,10 +380,10 @@ __device__ __forceinline__ svdss_u4 sv_load16(const uint8_t* p) {
 // Longest-processing-time-first scheduling.  Lanes fetch items dynamically, so the launch ends when the last
 // item that was started ends: the items that take 5-10 x the median (reads in repeats: every backward phase
 // walks the BWT one symbol at a time until a single copy is left) must start first, not last.  One wavefront
-// per read samples 128 pairs of adjacent K-mers in the table; reads where at least two pairs occur more than
+// per read samples 64 pairs of adjacent K-mers in the table; reads where at least two pairs occur more than
 // once in the reference go to the front of the order, the rest to the back.  The order only decides when a
 // read is searched, never what is found.
-__global__ void __launch_bounds__(256) sfs_order_kernel(SfsParams p, int64_t* order, unsigned long long* cnt) {
+__global__ void __launch_bounds__(256) sfs_order_kernel(SfsParams p, int64_t* heavy) {
   const int lane = threadIdx.x & 63;
   const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (r >= p.n_reads) return;
@@ -391,27 +391,32 @@ __global__ void __launch_bounds__(256) sfs_order_kernel(SfsParams p, int64_t* or
   const int64_t len = p.offsets[r + 1] - off;
   const int K = p.ix.k;
   const uint8_t* reads = (const uint8_t*)p.chunks;
-  int hits = 0;
-  if (K >= 8 && p.ix.table != nullptr && len >= 8 * K) {
-    const int64_t span = len - 2 * K;
-    for (int i = lane; i < 128; i += 64) {
-      const int64_t pos = off + (span * (2 * i + 1)) / 256;
-      uint32_t k1 = 0, k2 = 0;
-      bool ok = true;
-      for (int t = 0; t < K; ++t) {
-        const uint32_t a = (uint32_t)reads[pos + t] - 1u, b = (uint32_t)reads[pos + K + t] - 1u;
-        ok = ok && a < 4u && b < 4u;
-        k1 |= (a & 3u) << (2 * t);
-        k2 |= (b & 3u) << (2 * t);
-      }
-      if (ok && (p.ix.table[k1].info >> 62) == SVDSS_TAB_MULTI && (p.ix.table[k2].info >> 62) == SVDSS_TAB_MULTI) ++hits;
+  bool hit = false;
+  if (K >= 8 && K <= 16 && p.ix.table != nullptr && len >= 8 * K) {
+    // one sample per lane: the 2K symbols at an even spacing along the read (two 16-byte loads)
+    const int64_t pos = off + ((len - 32) * (2 * lane + 1)) / 128;
+    const svdss_u4 w0 = sv_load16(reads + pos), w1 = sv_load16(reads + pos + K);
+    const uint32_t wa[4] = {w0.x, w0.y, w0.z, w0.w}, wb[4] = {w1.x, w1.y, w1.z, w1.w};
+    uint32_t k1 = 0, k2 = 0, bad = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const uint32_t a = ((wa[t >> 2] >> (8 * (t & 3))) & 0xffu) - 1u;
+      const uint32_t c = ((wb[t >> 2] >> (8 * (t & 3))) & 0xffu) - 1u;
+      if (t < K) { bad |= (a | c) & ~3u; k1 |= (a & 3u) << (2 * t); k2 |= (c & 3u) << (2 * t); }
     }
+    if (!bad) hit = (p.ix.table[k1].info >> 62) == SVDSS_TAB_MULTI && (p.ix.table[k2].info >> 62) == SVDSS_TAB_MULTI;
   }
-  const int heavy = __builtin_popcountll(__ballot(hits > 0)) + __builtin_popcountll(__ballot(hits > 1));
-  if (lane == 0) {
-    if (heavy >= 2) order[atomicAdd(&cnt[0], 1ULL)] = r;
-    else order[p.n_reads - 1 - (int64_t)atomicAdd(&cnt[1], 1ULL)] = r;
-  }
+  const int hits = __builtin_popcountll(__ballot(hit));
+  if (lane == 0) heavy[r] = hits >= 2 ? 1 : 0;
+}
+
+// stable partition by the flags: heavy reads first (scan = exclusive prefix sum of heavy, n_reads + 1 entries)
+__global__ void __launch_bounds__(256) sfs_order_scatter_kernel(int64_t n_reads, const int64_t* heavy, const int64_t* scan,
+                                                                int64_t* order) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const int64_t before = scan[r], n_heavy = scan[n_reads];
+  order[heavy[r] ? before : n_heavy + (r - before)] = r;
 }
 
 #ifdef SV_COUNT_ITERS
@@ -786,12 +791,13 @@ struct svdss_sfs_batch {
   int64_t total = 0;
   int64_t total_ext = 0;
   double kernel_ms = 0.0;
+  double search_ms = 0.0;   // the segmented / one-lane-per-read search kernel of pass 0 alone
   DevBuf rec, counts, n_ext, out_off, out_qs, out_len, tmp, misc, reads, offsets, base2, sum;
   DevBuf seg_rec, seg_info, fallback, seg_take, order, order_cnt;
   int64_t n_fallback = 0;   // reads of the last call that were redone unsegmented
   int32_t n_seg = 1;        // segments per read used by the last call
   uint32_t epoch = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ek0 = nullptr, ek1 = nullptr;
 };
 
 static int ensure(DevBuf& b, size_t bytes) {
@@ -818,6 +824,8 @@ extern "C" void svdss_sfs_batch_free(svdss_sfs_batch_t* b) {
     release(*d);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->ek0) (void)hipEventDestroy(b->ek0);
+  if (b->ek1) (void)hipEventDestroy(b->ek1);
   delete b;
 }
 
@@ -825,6 +833,7 @@ extern "C" int64_t svdss_sfs_batch_nreads(const svdss_sfs_batch_t* b) { return b
 extern "C" int64_t svdss_sfs_batch_total(const svdss_sfs_batch_t* b) { return b ? b->total : -1; }
 extern "C" int64_t svdss_sfs_batch_total_ext(const svdss_sfs_batch_t* b) { return b ? b->total_ext : -1; }
 extern "C" double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b) { return b ? b->kernel_ms : -1.0; }
+extern "C" double svdss_sfs_batch_search_kernel_ms(const svdss_sfs_batch_t* b) { return b ? b->search_ms : -1.0; }
 extern "C" int32_t svdss_sfs_batch_segments(const svdss_sfs_batch_t* b) { return b ? b->n_seg : -1; }
 extern "C" int64_t svdss_sfs_batch_fallbacks(const svdss_sfs_batch_t* b) { return b ? b->n_fallback : -1; }
 
@@ -855,10 +864,13 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   if (b->device != ix->device) return SVDSS_EINVAL;
   if (!b->ev0) HIPCHK(hipEventCreate(&b->ev0));
   if (!b->ev1) HIPCHK(hipEventCreate(&b->ev1));
+  if (!b->ek0) HIPCHK(hipEventCreate(&b->ek0));
+  if (!b->ek1) HIPCHK(hipEventCreate(&b->ek1));
   b->n_reads = n_reads;
   b->total = 0;
   b->total_ext = 0;
   b->kernel_ms = 0.0;
+  b->search_ms = 0.0;
   if (n_reads == 0) return SVDSS_OK;
 
   int rc;
@@ -904,7 +916,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   int n_seg = 1;
   {
     const int64_t lanes = (int64_t)max_blocks * 256 / 2;   // 4 waves per SIMD resident
-    const int64_t want = 4 * lanes / (n_reads > 0 ? n_reads : 1);   // ~4 items per resident lane: dynamic fetch evens out the segments
+    const int64_t want = 2 * lanes / (n_reads > 0 ? n_reads : 1);   // ~2 items per resident lane
     n_seg = (int)(want < 2 ? 1 : (want > 8 ? 8 : want));   // beyond 8 the odd unstitchable read costs more than it saves
     if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
     if (n_seg < 1) n_seg = 1;
@@ -947,7 +959,11 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   const bool use_order = !use_v1 && n_reads >= 1024 && p.ix.k >= 8 && !(ord_env && atoi(ord_env) == 0);
   if (use_order) {
     if ((rc = ensure(b->order, (size_t)n_reads * sizeof(int64_t)))) return rc;
-    if ((rc = ensure(b->order_cnt, 16))) return rc;
+    if ((rc = ensure(b->order_cnt, (size_t)(2 * n_reads + 2) * sizeof(int64_t)))) return rc;   // flags, their scan
+    size_t t3 = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, t3, (int64_t*)b->order_cnt.p, (int64_t*)b->order_cnt.p + n_reads + 1,
+                                            (int)(n_reads + 1), stream));
+    if (t3 > b->tmp.cap && (rc = ensure(b->tmp, t3))) return rc;
   }
   for (int pass = 0; pass < 2; ++pass) {
     HIPCHK(hipMemsetAsync(b->misc.p, 0, 64, stream));
@@ -956,9 +972,15 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     const bool seg = n_seg > 1 && pass == 0;   // the exact-capacity rerun is always unsegmented
     HIPCHK(hipEventRecord(b->ev0, stream));
     if (use_order && pass == 0) {
-      HIPCHK(hipMemsetAsync(b->order_cnt.p, 0, 16, stream));
-      hipLaunchKernelGGL(sfs_order_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, stream, p, (int64_t*)b->order.p,
-                         (unsigned long long*)b->order_cnt.p);
+      int64_t* heavy = (int64_t*)b->order_cnt.p;
+      int64_t* hscan = heavy + n_reads + 1;
+      HIPCHK(hipMemsetAsync(heavy + n_reads, 0, sizeof(int64_t), stream));
+      hipLaunchKernelGGL(sfs_order_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, stream, p, heavy);
+      HIPCHK(hipGetLastError());
+      size_t t3 = b->tmp.cap;
+      HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->tmp.p, t3, heavy, hscan, (int)(n_reads + 1), stream));
+      hipLaunchKernelGGL(sfs_order_scatter_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, n_reads, heavy,
+                         hscan, (int64_t*)b->order.p);
       HIPCHK(hipGetLastError());
       p.read_ids = (const int64_t*)b->order.p;
     }
@@ -968,9 +990,11 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       p.n_seg = n_seg;
       p.seg_shift = __builtin_ctz((unsigned)n_seg);
       p.n_items = n_reads * n_seg;
+      HIPCHK(hipEventRecord(b->ek0, stream));
       if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true>), dim3(blocks_for(p.n_items)), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true>), dim3(blocks_for(p.n_items)), dim3(256), 0, stream, p);
       HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(b->ek1, stream));
       hipLaunchKernelGGL(sfs_stitch_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, p);
       HIPCHK(hipGetLastError());
       hipLaunchKernelGGL(sfs_assemble_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, stream, p);
@@ -1013,8 +1037,10 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     } else {
       p.n_seg = 1;
       p.n_items = n_reads;
+      if (pass == 0) HIPCHK(hipEventRecord(b->ek0, stream));
       if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+      if (pass == 0) HIPCHK(hipEventRecord(b->ek1, stream));
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1, stream));
@@ -1041,6 +1067,11 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     b->kernel_ms += ms;
+    if (pass == 0 && !use_v1) {
+      float ks = 0.f;
+      HIPCHK(hipEventElapsedTime(&ks, b->ek0, b->ek1));
+      b->search_ms = ks;
+    }
     b->total = total;
     b->total_ext = total_ext;
     if (n_over == 0) break;
@@ -1078,7 +1109,7 @@ extern "C" int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* re
     *out = b;
   }
   if (n_reads == 0) {
-    b->n_reads = 0; b->total = 0; b->total_ext = 0; b->kernel_ms = 0.0;
+    b->n_reads = 0; b->total = 0; b->total_ext = 0; b->kernel_ms = 0.0; b->search_ms = 0.0;
     return SVDSS_OK;
   }
   if (offsets[0] != 0) return SVDSS_EINVAL;

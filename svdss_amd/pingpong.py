@@ -236,6 +236,11 @@ class PingPong:
     def last_kernel_ms(self) -> float:
         return lib.svdss_sfs_batch_kernel_ms(self._batch)
 
+    @property
+    def last_search_kernel_ms(self) -> float:
+        """HIP-event time of the search kernel alone (no ordering / stitching / assembling / gather)."""
+        return lib.svdss_sfs_batch_search_kernel_ms(self._batch)
+
     def process_batch(self, names: Sequence[str], reads: Sequence, xf: Optional[Sequence[int]] = None,
                       hp: Optional[Sequence[int]] = None):
         """ping_pong.cpp:176-209: putative filter on XF (:202-203), HP carried as htag.
