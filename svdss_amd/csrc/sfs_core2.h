@@ -61,6 +61,7 @@ struct SvLane {
 #define SV_M_PEEK 32      // waiting for the left neighbour's records (segmented search, see sv_apply_peek)
 #define SV_PEEK_RECS 4    // neighbour records examined per PEEK operation
 #define SV_PEEK_OPS 8     // PEEK operations per SFS before giving up (the overrun goes on)
+#define SV_PEEK_VISIBLE 16 // records per segment stored so that a concurrently running neighbour can see them
 
 struct SvOp {
   int op;

@@ -442,13 +442,20 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
     if (idx < cap) {
       if (SEG)   // ext_at_begin: the forward phase of this SFS made pos - begin of the extensions
       {
-        // two 8-byte agent-scope (write-through, sc1) stores: lanes on other XCDs peek at these
-        unsigned long long* rp = (unsigned long long*)(p.seg_rec + (base + idx));
-        __hip_atomic_store(rp, (unsigned long long)(uint32_t)qs | ((unsigned long long)(uint32_t)l << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rp + 1, (unsigned long long)(uint32_t)(st.n_ext - (st.pos - st.begin)) |
-                                       ((unsigned long long)p.epoch << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t ext_at_begin = (uint32_t)(st.n_ext - (st.pos - st.begin));
+        if (idx < SV_PEEK_VISIBLE) {
+          // the first records of a segment are the ones its right neighbour peeks at (it synchronises on the first
+          // SFS below the boundary): two 8-byte agent-scope (write-through) stores, visible to lanes on other XCDs
+          unsigned long long* rp = (unsigned long long*)(p.seg_rec + (base + idx));
+          __hip_atomic_store(rp, (unsigned long long)(uint32_t)qs | ((unsigned long long)(uint32_t)l << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(rp + 1, (unsigned long long)ext_at_begin | ((unsigned long long)p.epoch << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          // the rest is only read after the launch (stitch / assemble): plain stores, merged into full lines by L2
+          // instead of one 32-byte memory transaction per 8 bytes
+          p.seg_rec[base + idx] = make_uint4((uint32_t)qs, (uint32_t)l, ext_at_begin, p.epoch);
+        }
       }
       else
         p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
