@@ -229,7 +229,7 @@ def main():
                 # the kernel's memory operations are dependent random reads (one per lane per iteration): the
                 # measured ceiling of that access pattern on this GPU (tools/random_read_probe.hip) next to the
                 # rate at which the kernel's measured traffic arrives, both in 64-B lines per second
-                "random_access": random_access_info(measured_traffic(ref_total, n_reads, L, ix.kmer_k), k_ms),
+                "random_access": random_access_info(measured_traffic(ref_total, n_reads, L, ix.kmer_k, "_transactions"), k_ms),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -242,7 +242,7 @@ def main():
         dist.destroy_process_group()
 
 
-def random_access_info(traffic_bytes, k_ms):
+def random_access_info(transactions, k_ms):
     try:
         with open(os.path.join(ROOT, "profiles", "random_access.json")) as fh:
             probe = json.load(fh)
@@ -250,14 +250,15 @@ def random_access_info(traffic_bytes, k_ms):
         return None
     out = {"ceiling_dependent_lines_per_s": probe["dependent_random_lines_per_s"],
            "ceiling_independent_lines_per_s": probe["independent_random_lines_per_s"], "source": probe["source"]}
-    if traffic_bytes:
-        rate = traffic_bytes / 64 / (k_ms * 1e-3)
-        out["achieved_lines_per_s"] = rate
+    if transactions:   # TCC_EA0_RDREQ + TCC_EA0_WRREQ of one launch (profiles/r01_final_pmc.csv)
+        rate = transactions / (k_ms * 1e-3)
+        out["achieved_transactions_per_s"] = rate
         out["frac_of_dependent_ceiling"] = rate / probe["dependent_random_lines_per_s"]
+        out["frac_of_independent_ceiling"] = rate / probe["independent_random_lines_per_s"]
     return out
 
 
-def measured_traffic(ref_total, n_reads, L, k):
+def measured_traffic(ref_total, n_reads, L, k, suffix=""):
     """HBM-side bytes per launch of the search kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE + WRITE_SIZE, profiles/traffic.json), for exactly this workload; None if that
     configuration has not been profiled.  Counters cannot be read from inside the timed run."""
@@ -266,7 +267,7 @@ def measured_traffic(ref_total, n_reads, L, k):
             table = json.load(fh)
     except OSError:
         return None
-    return table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}")
+    return table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}{suffix}")
 
 
 def call_dp_throughput(device):
