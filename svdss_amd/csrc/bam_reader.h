@@ -10,10 +10,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <future>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -144,8 +147,32 @@ class BamReader {
     size_t aux_off() const { return seq_off() + (size_t)(l_seq + 1) / 2; }
   };
 
+  // growable byte buffer without the zero-fill of std::vector::resize (the arena is written exactly once)
+  struct Arena {
+    uint8_t* p = nullptr;
+    size_t size = 0, cap = 0;
+    Arena() = default;
+    Arena(const Arena&) = delete;
+    Arena& operator=(const Arena&) = delete;
+    ~Arena() { free(p); }
+    uint8_t* data() { return p; }
+    const uint8_t* data() const { return p; }
+    void clear() { size = 0; }
+    void resize(size_t n) {
+      if (n > cap) {
+        size_t c = cap ? cap : (1u << 20);
+        while (c < n) c += c / 2;
+        uint8_t* q = (uint8_t*)realloc(p, c);
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = c;
+      }
+      size = n;
+    }
+  };
+
   // 1 = record appended to arena, 0 = clean end of file, -1 = error
-  int next_raw(std::vector<uint8_t>& arena, RawRec& rr) {
+  int next_raw(Arena& arena, RawRec& rr) {
     int32_t block_size;
     const size_t got = read_some(&block_size, 4);
     if (got == 0) return 0;
@@ -164,7 +191,7 @@ class BamReader {
     const size_t head = (size_t)rr.l_name + 4u * rr.n_cigar + (size_t)(rr.l_seq + 1) / 2;
     if (32 + head + (size_t)rr.l_seq > (size_t)block_size) { err_ = "corrupt record"; return -1; }
     rr.l_aux = (uint32_t)((size_t)block_size - 32 - head - (size_t)rr.l_seq);
-    rr.off = arena.size();
+    rr.off = arena.size;
     arena.resize(rr.off + head + rr.l_aux);
     if (!read(arena.data() + rr.off, head) || !skip((size_t)rr.l_seq) || !read(arena.data() + rr.off + head, rr.l_aux)) {
       err_ = "truncated record";
@@ -251,8 +278,17 @@ class BamReader {
   // BGZF blocks are independent deflate streams (<= 64 KiB each): a chunk of kChunkBlocks blocks is read
   // sequentially, inflated by `threads_` workers, and the next chunk is prepared in the background while the
   // caller parses the current one (htslib's hts_set_threads plays this role for the reference).
+  struct Bytes {   // uninitialised buffer (std::vector would zero-fill what inflate overwrites anyway)
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    void alloc(size_t k) { p.reset(new uint8_t[k ? k : 1]); n = k; }
+    uint8_t* data() { return p.get(); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void swap(Bytes& o) { p.swap(o.p); std::swap(n, o.n); }
+  };
   struct Chunk {
-    std::vector<uint8_t> data;
+    Bytes data;
     bool eof = false;
     std::string err;
   };
@@ -328,7 +364,7 @@ class BamReader {
       blocks.push_back(b);
     }
     release();
-    c.data.resize(total);
+    c.data.alloc(total);
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, blocks.size()));
     std::vector<std::string> errs((size_t)nt);
     auto work = [&](int t) {
@@ -373,6 +409,7 @@ class BamReader {
   std::vector<std::string> refs_;
   std::vector<int32_t> ref_lens_;
   std::string text_;
-  std::vector<uint8_t> ublock_, buf_;
+  Bytes ublock_;
+  std::vector<uint8_t> buf_;
   size_t upos_ = 0;
 };

@@ -182,7 +182,9 @@ struct Read {
 
 struct SearchBatch {
   std::vector<Read> reads;
-  std::vector<uint8_t> gbuf;     // nt6 bases of the searched reads, back to back
+  std::vector<uint8_t> gbuf;     // nt6 bases of the searched reads, back to back (FASTX mode)
+  std::unique_ptr<uint8_t[]> graw; // ... or this uninitialised buffer (BAM mode: filled by the decode workers)
+  const uint8_t* bases() const { return graw ? graw.get() : gbuf.data(); }
   std::vector<int64_t> goff;
   std::vector<size_t> gidx;      // searched read -> index into reads
   std::vector<int32_t> qs, ln;   // results
@@ -273,7 +275,7 @@ int main_search(const Options& o) {
 
   std::thread producer([&] {
     bool eof = false;
-    std::vector<uint8_t> arena;
+    BamReader::Arena arena;
     std::vector<BamReader::RawRec> recs;
     while (!eof) {
       std::unique_ptr<SearchBatch> bt(new SearchBatch);
@@ -320,18 +322,17 @@ int main_search(const Options& o) {
           bt->gidx.push_back(i);
           bt->goff.push_back(bt->goff.back() + bt->reads[i].len);
         }
-        bt->gbuf.resize((size_t)bt->goff.back() + 1);
+        bt->graw.reset(new uint8_t[(size_t)bt->goff.back() + 16]);
         parallel_for(bt->gidx.size(), [&](size_t lo, size_t hi) {
           for (size_t k = lo; k < hi; ++k) {
             const BamReader::RawRec& rr = recs[bt->gidx[k]];
             const uint8_t* seq4 = arena.data() + rr.seq_off();
-            uint8_t* dst = bt->gbuf.data() + bt->goff[k];
+            uint8_t* dst = bt->graw.get() + bt->goff[k];
             const size_t full = (size_t)rr.l_seq / 2;
             for (size_t x = 0; x < full; ++x) memcpy(dst + 2 * x, &pair_to_nt6[seq4[x]], 2);
             if (rr.l_seq & 1) dst[rr.l_seq - 1] = nt16_to_nt6[seq4[full] >> 4];
           }
         });
-        bt->gbuf.resize((size_t)bt->goff.back());
         t_decode += secs(ts1, now());
       } else {
         while ((int64_t)bt->reads.size() < super) {
@@ -395,7 +396,7 @@ int main_search(const Options& o) {
     const auto tg0 = now();
     if (!bt->gidx.empty()) {
       std::vector<int64_t> counts(bt->gidx.size());
-      check(svdss_sfs_search_batch(ix, bt->gbuf.data(), bt->goff.data(), (int64_t)bt->gidx.size(),
+      check(svdss_sfs_search_batch(ix, bt->bases(), bt->goff.data(), (int64_t)bt->gidx.size(),
                                    o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch");
       bt->qs.resize((size_t)svdss_sfs_batch_total(res));
       bt->ln.resize(bt->qs.size());
@@ -408,6 +409,7 @@ int main_search(const Options& o) {
       }
     }
     std::vector<uint8_t>().swap(bt->gbuf);
+    bt->graw.reset();
     t_gpu += secs(tg0, now());
     searched.push(std::move(bt));
   }
