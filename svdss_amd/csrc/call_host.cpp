@@ -9,6 +9,7 @@
 // per cluster; here the second phase is a second sequential pass that hands every alignment to
 // the clusters it overlaps -- same alignments per cluster, same (file) order, no index needed.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -116,7 +118,8 @@ struct Ctx {
   std::vector<std::string> chrom_names;
   std::unordered_map<std::string, std::string> chrom_seqs;
   std::unordered_map<std::string, std::vector<RawSFS>> sfs;
-  long unplaced = 0, s_unplaced = 0, e_unplaced = 0, unknown = 0, unextended = 0, small = 0, small2 = 0;
+  // statistics (bumped from the worker threads of pass 1)
+  std::atomic<long> unplaced{0}, s_unplaced{0}, e_unplaced{0}, unknown{0}, unextended{0}, small{0}, small2{0};
 };
 
 // clusterer.cpp:159-346 (without the --clipped bookkeeping)
@@ -354,7 +357,7 @@ int main_call(const CallOptions& o) {
       batch.clear();
       while ((int)batch.size() < bsize) {
         BamRecord r;
-        const int rc = bam.next(r);
+        const int rc = bam.next(r, false);   // (qualities are not used by `call`)
         if (rc == 0) { eof = true; break; }
         if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
         if (r.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
@@ -362,12 +365,22 @@ int main_call(const CallOptions& o) {
         if (C.sfs.find(r.qname) == C.sfs.end()) continue;
         batch.push_back(std::move(r));
       }
-      for (int t = 0; t < T; ++t)
+      // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
+      // the same order per slice
+      auto slice = [&](int t) {
         for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
           const BamRecord& r = batch[n];
           if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
           extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t]);
         }
+      };
+      if (T == 1 || batch.size() < 64) { for (int t = 0; t < T; ++t) slice(t); }
+      else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(slice, t);
+        slice(0);
+        for (std::thread& th : pool) th.join();
+      }
     }
     for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
   }
@@ -428,20 +441,29 @@ int main_call(const CallOptions& o) {
       live[i] = 1;
       by_chrom[clusters[i].chrom].push_back(i);
     }
-    for (auto& kv : by_chrom)
+    std::map<std::string, std::vector<int>> run_max_end;   // per chrom: running maximum of the region ends, same order
+    for (auto& kv : by_chrom) {
       std::sort(kv.second.begin(), kv.second.end(), [&](size_t a, size_t b) { return min_s[a] < min_s[b]; });
+      std::vector<int>& rm = run_max_end[kv.first];
+      int m = 0;
+      for (size_t ci : kv.second) { m = std::max(m, max_e[ci]); rm.push_back(m); }
+    }
     BamReader bam(o.bam);
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
     BamRecord r;
     int rc;
-    while ((rc = bam.next(r)) > 0) {
+    while ((rc = bam.next(r, false)) > 0) {
       if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
       auto it = by_chrom.find(ref_names[(size_t)r.tid]);
       if (it == by_chrom.end()) continue;
       const int a_beg = r.pos, a_end = r.endpos();
       Pairs al;
       std::string seq;
-      for (size_t ci : it->second) {
+      // clusters before `first` end at or before the alignment's start: none of them can overlap it
+      const std::vector<int>& rm = run_max_end[it->first];
+      const size_t first = (size_t)(std::upper_bound(rm.begin(), rm.end(), a_beg) - rm.begin());
+      for (size_t k = first; k < it->second.size(); ++k) {
+        const size_t ci = it->second[k];
         // region "chrom:min_s-max_e" = 0-based half-open [min_s-1, max_e)
         const int beg0 = std::max(min_s[ci] - 1, 0), end0 = max_e[ci];
         if (beg0 >= a_end) break;   // clusters are sorted by start
