@@ -1,4 +1,4 @@
-// bam_writer.h -- minimal BGZF/BAM writer (zlib only) for `SVDSS smooth`, which prints a BAM to
+// bam_writer.h -- BGZF/BAM writer (zlib only, blocks deflated in parallel) for `SVDSS smooth`, which prints a BAM to
 // stdout (/root/reference/smoother.cpp:441, sam_write1).
 #pragma once
 #include <zlib.h>
@@ -6,39 +6,42 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
+// Blocks are independent deflate streams: the writer collects kBatch blocks of input and compresses them with
+// `threads` workers, then writes them in order (htslib's bgzf_mt plays this role for the reference).  The
+// output bytes do not depend on the number of threads.
 class BgzfWriter {
  public:
-  explicit BgzfWriter(FILE* f) : f_(f) { buf_.reserve(BLOCK); }
+  explicit BgzfWriter(FILE* f, int threads = 1) : f_(f), threads_(threads < 1 ? 1 : threads) { buf_.reserve(BLOCK * kBatch); }
   void write(const void* p, size_t n) {
     const uint8_t* s = (const uint8_t*)p;
-    while (n) {
-      const size_t take = std::min(n, BLOCK - buf_.size());
-      buf_.insert(buf_.end(), s, s + take);
-      s += take;
-      n -= take;
-      if (buf_.size() == BLOCK) flush_block();
-    }
+    buf_.insert(buf_.end(), s, s + n);
+    if (buf_.size() >= BLOCK * kBatch) flush_full_blocks();
   }
   bool finish() {   // flush + the 28-byte EOF marker block
-    if (!buf_.empty()) flush_block();
-    flush_block();
+    flush_full_blocks();
+    if (!buf_.empty()) { emit(buf_.data(), buf_.size(), 1); buf_.clear(); }
+    emit(nullptr, 0, 1);
     return fflush(f_) == 0 && ok_;
   }
 
  private:
   static constexpr size_t BLOCK = 0xff00;
-  void flush_block() {
-    uint8_t out[0x10000 + 64];
+  static constexpr size_t kBatch = 256;
+  static constexpr size_t OUT = 0x10000 + 64;
+
+  static size_t deflate_block(const uint8_t* in, size_t n, uint8_t* out) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
-    zs.next_in = buf_.data();
-    zs.avail_in = (uInt)buf_.size();
+    zs.next_in = const_cast<uint8_t*>(in);
+    zs.avail_in = (uInt)n;
     zs.next_out = out + 18;
-    zs.avail_out = sizeof out - 18 - 8;
+    zs.avail_out = (uInt)(OUT - 18 - 8);
     deflate(&zs, Z_FINISH);
     const size_t clen = zs.total_out;
     deflateEnd(&zs);
@@ -47,14 +50,45 @@ class BgzfWriter {
     out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
     const uint16_t bsize = (uint16_t)(clen + 25);
     memcpy(out + 16, &bsize, 2);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size());
-    const uint32_t isize = (uint32_t)buf_.size();
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n);
+    const uint32_t isize = (uint32_t)n;
     memcpy(out + 18 + clen, &crc, 4);
     memcpy(out + 18 + clen + 4, &isize, 4);
-    if (fwrite(out, 1, clen + 26, f_) != clen + 26) ok_ = false;
-    buf_.clear();
+    return clen + 26;
   }
+
+  // compresses `nblocks` consecutive blocks of `data` (the last one may be short) and writes them in order
+  void emit(const uint8_t* data, size_t bytes, size_t nblocks) {
+    std::vector<uint8_t> out(nblocks * OUT);
+    std::vector<size_t> len(nblocks);
+    auto work = [&](size_t t, size_t nt) {
+      for (size_t i = t; i < nblocks; i += nt) {
+        const size_t off = i * BLOCK;
+        const size_t n = bytes > off ? std::min(BLOCK, bytes - off) : 0;
+        len[i] = deflate_block(data ? data + off : nullptr, n, out.data() + i * OUT);
+      }
+    };
+    const size_t nt = std::min<size_t>((size_t)threads_, nblocks);
+    if (nt <= 1) work(0, 1);
+    else {
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t, nt);
+      work(0, nt);
+      for (std::thread& th : pool) th.join();
+    }
+    for (size_t i = 0; i < nblocks; ++i)
+      if (fwrite(out.data() + i * OUT, 1, len[i], f_) != len[i]) ok_ = false;
+  }
+
+  void flush_full_blocks() {
+    const size_t nfull = buf_.size() / BLOCK;
+    if (!nfull) return;
+    emit(buf_.data(), nfull * BLOCK, nfull);
+    buf_.erase(buf_.begin(), buf_.begin() + (ptrdiff_t)(nfull * BLOCK));
+  }
+
   FILE* f_;
+  int threads_;
   std::vector<uint8_t> buf_;
   bool ok_ = true;
 };

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -68,20 +69,26 @@ void set_xf(std::vector<uint8_t>& aux, int v) {
   aux.push_back('X'); aux.push_back('F'); aux.push_back('C'); aux.push_back((uint8_t)v);
 }
 
-void write_record(BgzfWriter& w, const BamRecord& r, const std::vector<uint32_t>& cigar, const std::string& seq,
+struct ByteSink {
+  std::vector<uint8_t> v;
+  void write(const void* p, size_t n) { v.insert(v.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
+};
+
+void write_record(ByteSink& w, const BamRecord& r, const std::vector<uint32_t>& cigar, const std::string& seq,
                   const std::vector<uint8_t>& qual, const std::vector<uint8_t>& aux) {
   static const int8_t code[256] = {0};
   (void)code;
   const int32_t l_seq = (int32_t)seq.size();
   std::vector<uint8_t> packed((size_t)(l_seq + 1) / 2, 0);
-  static uint8_t lut[256];
-  static bool init = false;
-  if (!init) {
-    memset(lut, 15, sizeof lut);
-    const char* nt16 = "=ACMGRSVTWYHKDBN";
-    for (int i = 0; i < 16; ++i) { lut[(uint8_t)nt16[i]] = (uint8_t)i; lut[(uint8_t)tolower(nt16[i])] = (uint8_t)i; }
-    init = true;
-  }
+  static const struct Lut {   // (initialised once, before any worker thread runs: function-local static)
+    uint8_t t[256];
+    Lut() {
+      memset(t, 15, sizeof t);
+      const char* nt16 = "=ACMGRSVTWYHKDBN";
+      for (int i = 0; i < 16; ++i) { t[(uint8_t)nt16[i]] = (uint8_t)i; t[(uint8_t)tolower(nt16[i])] = (uint8_t)i; }
+    }
+  } lut_obj;
+  const uint8_t* lut = lut_obj.t;
   for (int32_t i = 0; i < l_seq; ++i) packed[(size_t)i >> 1] |= (uint8_t)(lut[(uint8_t)seq[(size_t)i]] << ((~i & 1) << 2));
   const uint8_t l_name = (uint8_t)(r.qname.size() + 1);
   const uint16_t n_cig = (uint16_t)cigar.size();
@@ -147,15 +154,13 @@ int main_smooth(const CallOptions& o) {
   }
   BamReader bam(o.bam);
   if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
-  BgzfWriter w(stdout);
+  const int T = std::max(1, o.threads);
+  BgzfWriter w(stdout, T);
   bam_write_header(w, bam.header_text(), bam.ref_names(), bam.ref_lens());
-  BamRecord r;
-  int rc;
-  while ((rc = bam.next(r)) > 0) {
-    if (!eligible(r, bam.ref_names())) continue;   // dropped from the output (smoother.cpp:509-537)
-    const std::string& ref = chrom[bam.ref_names()[(size_t)r.tid]];
+  // smooth_read (smoother.cpp:84-232) of one record into its serialised BAM bytes
+  auto smooth_one = [&](const BamRecord& r, ByteSink& sink) {
+    const std::string& ref = chrom.at(bam.ref_names()[(size_t)r.tid]);
     const std::string seq = r.seq_string();
-    // smooth_read (smoother.cpp:84-232)
     std::string nseq;
     std::vector<uint8_t> nqual;
     std::vector<uint32_t> ncig;
@@ -192,9 +197,36 @@ int main_smooth(const CallOptions& o) {
       } else break;
     }
     std::vector<uint8_t> aux = r.aux;
-    if (nx / nm > al_accuracy) { set_xf(aux, 1); write_record(w, r, r.cigar, seq, r.qual, aux); }
-    else if (ignore) { set_xf(aux, 2); write_record(w, r, r.cigar, seq, r.qual, aux); }
-    else { set_xf(aux, 0); write_record(w, r, ncig, nseq, nqual, aux); }
+    if (nx / nm > al_accuracy) { set_xf(aux, 1); write_record(sink, r, r.cigar, seq, r.qual, aux); }
+    else if (ignore) { set_xf(aux, 2); write_record(sink, r, r.cigar, seq, r.qual, aux); }
+    else { set_xf(aux, 0); write_record(sink, r, ncig, nseq, nqual, aux); }
+  };
+  // batches of eligible records: read in order, smoothed by T workers, written in order (the reference's
+  // batch loop, smoother.cpp:441-537)
+  const size_t batch_size = 4096;
+  std::vector<BamRecord> batch;
+  std::vector<ByteSink> outs;
+  int rc = 1;
+  while (rc > 0) {
+    batch.clear();
+    while (batch.size() < batch_size) {
+      BamRecord r;
+      rc = bam.next(r);
+      if (rc <= 0) break;
+      if (!eligible(r, bam.ref_names())) continue;   // dropped from the output (smoother.cpp:509-537)
+      batch.push_back(std::move(r));
+    }
+    outs.assign(batch.size(), ByteSink());
+    auto work = [&](size_t t, size_t nt) { for (size_t i = t; i < batch.size(); i += nt) smooth_one(batch[i], outs[i]); };
+    const size_t nt = std::min<size_t>((size_t)T, batch.size());
+    if (nt <= 1) work(0, 1);
+    else {
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t, nt);
+      work(0, nt);
+      for (std::thread& th : pool) th.join();
+    }
+    for (const ByteSink& sk : outs) w.write(sk.v.data(), sk.v.size());
   }
   if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
   if (!w.finish()) die("error writing the BAM to stdout");
