@@ -285,6 +285,9 @@ struct SfsParams {
   int64_t n_items;          // work items of this launch
   unsigned long long* n_fallback;   // stitch kernel: number of reads to redo unsegmented
   int64_t* fallback_ids;
+  int32_t ticket_chunk;    // work-item tickets a wavefront takes from next_read at a time
+  const int64_t* sub_ids;  // stitch / assemble kernels: the reads to process (nullptr: all n_reads)
+  int64_t n_sub;
   int32_t* seg_take;       // per read and segment: [lo, hi) of the records that belong to the read's chain (-1: redo)
   uint32_t epoch;           // tag of the records written by this launch (see peek)
 };
@@ -482,9 +485,35 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
     const int64_t o0 = p.offsets[rr], o1 = p.offsets[rr + 1];
     pfl[256] = (uint32_t)o0; pfl[512] = (uint32_t)((uint64_t)o0 >> 32); pfl[768] = (uint32_t)(o1 - o0);
   };
+  // Tickets come from a per-wavefront pool refilled ticket_chunk at a time: one atomic on the global counter per
+  // chunk instead of one per item (2 M items serialise on that one address for ~20 ms otherwise).
+  uint32_t pool_next = 0, pool_end = 0;   // wave-uniform
   for (;;) {
+    {
+      const int lane = threadIdx.x & 63;
+      const bool want = pf == 0 && (!active || st.pos - st.stop_lo < 256);   // idle, or close to the end of its item
+      const unsigned long long wm = __ballot(want);
+      if (wm) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(wm);
+        const uint32_t rank = (uint32_t)__builtin_popcountll(wm & ((1ULL << lane) - 1ULL));
+        const uint32_t avail = pool_end - pool_next;
+        if (c > avail) {
+          const uint32_t take = c - avail > (uint32_t)p.ticket_chunk ? c - avail : (uint32_t)p.ticket_chunk;
+          const int leader = (int)__builtin_ctzll(wm);
+          uint32_t nb = 0;
+          if (lane == leader) nb = (uint32_t)atomicAdd(p.next_read, (unsigned long long)take);
+          nb = (uint32_t)__shfl((int)nb, leader, 64);
+          if (want) nt = rank < avail ? pool_next + rank : nb + (rank - avail);
+          pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nb + (c - avail)));   // (kept in SGPRs)
+          pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nb + take));
+        } else {
+          if (want) nt = pool_next + rank;
+          pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pool_next + c));
+        }
+        if (want) pf = 1;
+      }
+    }
     if (!active) {
-      if (pf == 0) nt = (uint32_t)atomicAdd(p.next_read, 1ULL);
       if (nt >= (uint32_t)p.n_items) break;
       if (pf < 2) pf_read_id();
       if (pf < 3) pf_offsets();
@@ -539,9 +568,8 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       sv_apply_text_slow(st, p.ix.text, reads, off);
       continue;
     }
-    if (pf < 3 && st.pos - st.stop_lo < 256) {   // close to the end of this item: get the next one under way
-      if (pf == 0) nt = (uint32_t)atomicAdd(p.next_read, 1ULL);
-      else if (nt < (uint32_t)p.n_items) {
+    if (pf >= 1 && pf < 3) {   // the next item's ticket is here: get its read id, then its offsets, under way
+      if (nt < (uint32_t)p.n_items) {
         if (pf == 1) pf_read_id(); else pf_offsets();
       }
       ++pf;
@@ -641,8 +669,9 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
 __global__ void __launch_bounds__(256) sfs_stitch_kernel(SfsParams p) {
   // phase 1, one thread per read: find the shared SFS starts (a short walk over the records next to each
   // segment boundary) and leave the record range taken from every segment in seg_take
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= p.n_reads) return;
+  const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ti >= (p.sub_ids ? p.n_sub : p.n_reads)) return;
+  const int64_t r = p.sub_ids ? p.sub_ids[ti] : ti;
   const int64_t off = p.offsets[r];
   const int64_t len = p.offsets[r + 1] - off;
   const int cr = seg_count(len, p.n_seg);
@@ -683,8 +712,9 @@ __global__ void __launch_bounds__(256) sfs_assemble_kernel(SfsParams p) {
   // both are functions of adjacent records, so 64 records are assembled per step.
   __shared__ int32_t s_cum[4][17], s_lo[4][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (r >= p.n_reads) return;
+  const int64_t wi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wi >= (p.sub_ids ? p.n_sub : p.n_reads)) return;
+  const int64_t r = p.sub_ids ? p.sub_ids[wi] : wi;
   const int32_t* take = p.seg_take + 2 * r * p.n_seg;
   if (take[0] < 0) return;   // queued for an unsegmented search
   const int64_t off = p.offsets[r];
@@ -800,7 +830,7 @@ struct svdss_sfs_batch {
   double kernel_ms = 0.0;
   double search_ms = 0.0;   // the segmented / one-lane-per-read search kernel of pass 0 alone
   DevBuf rec, counts, n_ext, out_off, out_qs, out_len, tmp, misc, reads, offsets, base2, sum;
-  DevBuf seg_rec, seg_info, fallback, seg_take, order, order_cnt;
+  DevBuf seg_rec, seg_info, fallback, fallback2, seg_take, order, order_cnt;
   int64_t n_fallback = 0;   // reads of the last call that were redone unsegmented
   int32_t n_seg = 1;        // segments per read used by the last call
   uint32_t epoch = 0;
@@ -827,7 +857,7 @@ extern "C" void svdss_sfs_batch_free(svdss_sfs_batch_t* b) {
   if (b->device >= 0) (void)hipSetDevice(b->device);
   for (DevBuf* d : {&b->rec, &b->counts, &b->n_ext, &b->out_off, &b->out_qs, &b->out_len, &b->tmp,
                     &b->misc, &b->reads, &b->offsets, &b->base2, &b->sum, &b->seg_rec, &b->seg_info,
-                    &b->fallback, &b->seg_take, &b->order, &b->order_cnt})
+                    &b->fallback, &b->fallback2, &b->seg_take, &b->order, &b->order_cnt})
     release(*d);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -908,6 +938,10 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.seg_rec = nullptr;
   p.seg_info = nullptr;
   p.read_ids = nullptr;
+  p.sub_ids = nullptr;
+  p.n_sub = 0;
+  p.ticket_chunk = 8;
+  if (const char* e = getenv("SVDSS_TICKETS")) p.ticket_chunk = atoi(e) > 0 ? atoi(e) : 8;
   p.n_items = n_reads;
   p.n_fallback = (unsigned long long*)b->misc.p + 2;
   p.fallback_ids = nullptr;
@@ -923,7 +957,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   int n_seg = 1;
   {
     const int64_t lanes = (int64_t)max_blocks * 256 / 2;   // 4 waves per SIMD resident
-    const int64_t want = 2 * lanes / (n_reads > 0 ? n_reads : 1);   // ~2 items per resident lane
+    const int64_t want = 4 * lanes / (n_reads > 0 ? n_reads : 1);   // ~4 items per resident lane: short items bound the tail
     n_seg = (int)(want < 2 ? 1 : (want > 8 ? 8 : want));   // beyond 8 the odd unstitchable read costs more than it saves
     if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
     if (n_seg < 1) n_seg = 1;
@@ -1032,14 +1066,40 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
 #endif
         (void)hipEventDestroy(e2);
       }
-      if (n_fb > 0) {   // reads whose chains could not be stitched: one lane per read
+      // reads whose chains could not be stitched are searched again with a quarter of the segments (their
+      // boundaries fall elsewhere), at the end one lane per read
+      int lvl_seg = n_seg;
+      while (n_fb > 0) {
+        lvl_seg = lvl_seg / 4 < 1 ? 1 : lvl_seg / 4;
+        if ((rc = ensure(b->fallback2, (size_t)n_fb * sizeof(int64_t)))) return rc;
+        HIPCHK(hipMemcpyAsync(b->fallback2.p, p.fallback_ids, (size_t)n_fb * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
         SfsParams q = p;
-        q.n_seg = 1;
-        q.read_ids = p.fallback_ids;
-        q.n_items = (int64_t)n_fb;
-        HIPCHK(hipMemsetAsync(b->misc.p, 0, 8, stream));
-        if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
-        else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        q.read_ids = (const int64_t*)b->fallback2.p;
+        HIPCHK(hipMemsetAsync(b->misc.p, 0, 8, stream));                    // next_read
+        if (lvl_seg == 1) {
+          q.n_seg = 1;
+          q.n_items = (int64_t)n_fb;
+          if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+          else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+          HIPCHK(hipGetLastError());
+          break;
+        }
+        HIPCHK(hipMemsetAsync(p.n_fallback, 0, 8, stream));
+        q.n_seg = lvl_seg;
+        q.seg_shift = __builtin_ctz((unsigned)lvl_seg);
+        q.n_items = (int64_t)n_fb * lvl_seg;
+        q.sub_ids = q.read_ids;
+        q.n_sub = (int64_t)n_fb;
+        q.epoch = ++b->epoch;
+        if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(sfs_stitch_kernel, dim3((unsigned)((n_fb + 255) / 256)), dim3(256), 0, stream, q);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(sfs_assemble_kernel, dim3((unsigned)((n_fb + 3) / 4)), dim3(256), 0, stream, q);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&n_fb, p.n_fallback, sizeof n_fb, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
       }
     } else {
       p.n_seg = 1;
