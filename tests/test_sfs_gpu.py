@@ -276,3 +276,36 @@ def test_segmented_search_is_exact(monkeypatch, segments):
         assert (got.counts == c).all() and (got.n_ext == e).all()
         assert (got.qs == q).all() and (got.len == l).all()
         pp.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"SVDSS_ORDER": "0"},
+    {"SVDSS_ORDER": "1", "SVDSS_TICKETS": "1"},
+    {"SVDSS_ORDER": "1", "SVDSS_TICKETS": "64", "SVDSS_BLOCKS": "8"},
+    {"SVDSS_SEGMENTS": "4", "SVDSS_BLOCKS": "16", "SVDSS_TICKETS": "3"},
+    {"SVDSS_SEGMENTS": "1", "SVDSS_BLOCKS": "4"},
+])
+def test_scheduling_knobs_never_change_results(monkeypatch, env):
+    """Heavy-reads-first order, per-wavefront ticket pools, resident blocks and segment counts decide when and where a
+    read is searched, never what is found: every combination must equal the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ref = synth.make_reference([300000], seed=71, repeat_frac=0.2, divergence=0.01)   # plenty of 2-copy repeats
+    rng = np.random.default_rng(72)
+    reads = []
+    for i in range(1400):
+        ln = int(rng.integers(300, 2600))
+        a = int(rng.integers(0, len(ref[0]) - ln))
+        r = ref[0][a:a + ln].copy()
+        e = rng.random(ln) < 0.005
+        r[e] = (r[e] - 1 + rng.integers(1, 4, size=int(e.sum()))) % 4 + 1
+        reads.append(r.astype(np.uint8))
+    flat, offs = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    pp = svdss_amd.PingPong(ix, assemble=True)
+    got = pp.ping_pong_search(flat, offs)
+    c, q, l, e = fm.search_batch(flat, offs, True)
+    assert (got.counts == c).all() and (got.n_ext == e).all()
+    assert (got.qs == q).all() and (got.len == l).all()
+    pp.close()
