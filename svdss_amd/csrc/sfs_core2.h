@@ -14,13 +14,17 @@
 //          "prepend c succeeds" <=> "the text byte before the occurrence is c",
 //          so up to 64 read symbols per iteration are compared directly with the
 //          reference text (located through the full suffix array) -- no BWT walk.
+//   SET    the same with 2-4 occurrences left (reads in low-copy repeats, where LF would spend one
+//          iteration per symbol until the copies diverge): their text positions are kept, 16 read symbols
+//          per iteration are compared with every surviving copy; the interval size is the number of
+//          survivors, which is all the algorithm ever looks at.
 // Every iteration of the kernel issues the loads of exactly one of these
 // operations per lane, waits once, and applies the result.
 #pragma once
 #include "fmd_layout.h"
 
 enum { SV_OP_DONE = 0, SV_OP_LF = 1, SV_OP_TABLE = 2, SV_OP_SA = 3, SV_OP_TEXT = 4, SV_OP_FILL = 5,
-       SV_OP_TEXT_SLOW = 6, SV_OP_PEEK = 7 };
+       SV_OP_TEXT_SLOW = 6, SV_OP_PEEK = 7, SV_OP_SA_SET = 8, SV_OP_SET = 9 };
 
 #define SV_M_DIR 1     // 0 backward (ping_pong.cpp:15-22), 1 forward (:31-37)
 #define SV_M_START 2   // at a phase start: no interval yet (before :12 / :30)
@@ -33,6 +37,12 @@ enum { SV_OP_DONE = 0, SV_OP_LF = 1, SV_OP_TABLE = 2, SV_OP_SA = 3, SV_OP_TEXT =
 // buffer position a is byte (a & 3) of row ((a & 63) >> 2).
 struct SvRing {
   uint32_t* base;
+  int stride;
+};
+
+// text index deltas of the occurrences of SET mode: slot i of this lane at base[i * stride]
+struct SvSet {
+  int64_t* base;
   int stride;
 };
 
@@ -61,6 +71,10 @@ struct SvLane {
 #define SV_M_PEEK 32      // waiting for the left neighbour's records (segmented search, see sv_apply_peek)
 #define SV_PEEK_RECS 4    // neighbour records examined per PEEK operation
 #define SV_PEEK_OPS 8     // PEEK operations per SFS before giving up (the overrun goes on)
+#define SV_M_SET 64       // 2-4 occurrences followed in the text, 16 symbols per operation (backward only)
+#define SV_SET_MAX 4
+#define SV_SET_SHIFT 8    // mode bits 8-11: which of the occurrences are still alive
+#define SV_SET_WIN 16
 #define SV_PEEK_VISIBLE 16 // records per segment stored so that a concurrently running neighbour can see them
 
 struct SvOp {
@@ -172,7 +186,7 @@ SVDSS_HD void sv_flush(SvLane<P>& s, bool assemble, Emit&& emit) {
 // lengthens the overrun; sv_stitch verifies everything.
 template <class P, class Emit>
 SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, int64_t off,
-                        bool assemble, Emit&& emit, bool can_peek = false) {
+                        bool assemble, Emit&& emit, bool can_peek = false, bool use_set = false) {
   SvOp o;
   o.op = SV_OP_DONE;
   o.a = 0;
@@ -180,6 +194,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
   if (s.mode & SV_M_PARTIAL) return o;
   if (s.mode & SV_M_PEEK) { o.op = SV_OP_PEEK; return o; }
   for (;;) {
+    if (s.mode & SV_M_SET) { o.op = SV_OP_SET; return o; }
     if (s.mode & SV_M_TEXT) {
       o.op = (off + s.pos >= 64) ? SV_OP_TEXT : SV_OP_TEXT_SLOW;
       return o;
@@ -220,6 +235,11 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
       if (nonempty && s.pos > 0) {                    // ping_pong.cpp:15
         if (s.hi - s.lo == 1 && ix.sa != nullptr) {   // single occurrence: switch to TEXT
           o.op = SV_OP_SA;
+          o.a = (int64_t)s.lo;
+          return o;
+        }
+        if (use_set && s.hi - s.lo <= SV_SET_MAX && ix.sa != nullptr && off >= 64) {   // a few: follow them all
+          o.op = SV_OP_SA_SET;
           o.a = (int64_t)s.lo;
           return o;
         }
@@ -337,6 +357,65 @@ template <class P>
 SVDSS_HD void sv_apply_sa(SvLane<P>& s, int64_t text_pos) {
   s.tdelta = text_pos - s.pos;
   s.mode |= SV_M_TEXT;
+}
+
+// SA_SET: text positions of the hi - lo <= SV_SET_MAX occurrences (suffix array entries lo, lo+1, ...)
+template <class P>
+SVDSS_HD void sv_apply_sa_set(SvLane<P>& s, const SvSet& ts, const int64_t text_pos[SV_SET_MAX]) {
+  const int n = (int)(s.hi - s.lo);
+#pragma unroll
+  for (int i = 0; i < SV_SET_MAX; ++i)
+    if (i < n) ts.base[i * ts.stride] = text_pos[i] - s.pos;
+  s.mode |= SV_M_SET | (((1 << n) - 1) << SV_SET_SHIFT);
+}
+
+// SET: tw[i] = the 16 text bytes of occurrence i for read positions [pos-16, pos), rb = the read's.  Every
+// extension keeps the copies whose next text byte equals the read symbol (what rb3_fmd_extend does to the
+// interval, ping_pong.cpp:15-22); the phase goes on while at least one is left.
+template <class P>
+SVDSS_HD void sv_apply_set(SvLane<P>& s, const SvSet& ts, const svdss_u4 tw[SV_SET_MAX], const svdss_u4& rb) {
+  const int alive = (s.mode >> SV_SET_SHIFT) & ((1 << SV_SET_MAX) - 1);
+  int m[SV_SET_MAX];
+  int best = -1;
+#pragma unroll
+  for (int i = 0; i < SV_SET_MAX; ++i) {
+    const uint32_t x3 = tw[i].w ^ rb.w, x2 = tw[i].z ^ rb.z, x1 = tw[i].y ^ rb.y, x0 = tw[i].x ^ rb.x;
+    // matching symbols counted down from pos-1 (byte 15 of the window)
+    int k;
+    if (x3) k = 3 - ((31 - __builtin_clz(x3)) >> 3);
+    else if (x2) k = 7 - ((31 - __builtin_clz(x2)) >> 3);
+    else if (x1) k = 11 - ((31 - __builtin_clz(x1)) >> 3);
+    else if (x0) k = 15 - ((31 - __builtin_clz(x0)) >> 3);
+    else k = SV_SET_WIN;
+    m[i] = ((alive >> i) & 1) ? k : -1;
+    if (m[i] > best) best = m[i];
+  }
+  const int avail = s.pos < SV_SET_WIN ? s.pos : SV_SET_WIN;   // symbols left before the read start
+  if (best >= avail) {
+    // at least one copy agrees with every remaining symbol of this window
+    int keep = 0;
+#pragma unroll
+    for (int i = 0; i < SV_SET_MAX; ++i) if (m[i] >= avail) keep |= 1 << i;
+    s.pos -= avail;
+    s.n_ext += avail;
+    s.mode = (s.mode & ~(((1 << SV_SET_MAX) - 1) << SV_SET_SHIFT)) | (keep << SV_SET_SHIFT);
+    if (s.pos == 0) {                              // ping_pong.cpp:24: prefix matched, size != 0
+      s.mode &= ~(SV_M_SET | (((1 << SV_SET_MAX) - 1) << SV_SET_SHIFT));
+      s.lo = 0;
+      s.hi = 1;
+    } else if ((keep & (keep - 1)) == 0) {         // one copy left: the 64-symbol TEXT mode takes over
+      const int i = keep == 1 ? 0 : keep == 2 ? 1 : keep == 4 ? 2 : 3;
+      s.tdelta = ts.base[i * ts.stride];
+      s.mode = (s.mode & ~(SV_M_SET | (((1 << SV_SET_MAX) - 1) << SV_SET_SHIFT))) | SV_M_TEXT;
+    }
+  } else {
+    // after `best` agreeing symbols the next one disagrees with every copy: that extend empties the interval
+    s.pos -= best + 1;
+    s.n_ext += best + 1;
+    s.mode &= ~(SV_M_SET | (((1 << SV_SET_MAX) - 1) << SV_SET_SHIFT));
+    s.lo = 0;
+    s.hi = 0;
+  }
 }
 
 // PEEK: q[i] / written[i] = SFS start and "already produced" of the neighbour's records nb_cur, nb_cur+1, ...

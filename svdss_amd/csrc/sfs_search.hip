@@ -286,6 +286,7 @@ struct SfsParams {
   unsigned long long* n_fallback;   // stitch kernel: number of reads to redo unsegmented
   int64_t* fallback_ids;
   int32_t ticket_chunk;    // work-item tickets a wavefront takes from next_read at a time
+  int32_t use_set;         // follow 2-4 occurrences in the text instead of walking the BWT (SV_OP_SET)
   const int64_t* sub_ids;  // stitch / assemble kernels: the reads to process (nullptr: all n_reads)
   int64_t n_sub;
   int32_t* seg_take;       // per read and segment: [lo, hi) of the records that belong to the read's chain (-1: redo)
@@ -469,6 +470,8 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
   // dependent loads that ride along with the lane's memory operation of three iterations) -- fetched
   // inline they stall the whole wavefront every time one of its 64 lanes starts an item.
   // The prefetched read id / offset / length wait in LDS (the kernel has no VGPR to spare).
+  __shared__ int64_t set_lds[SV_SET_MAX * 256];   // SET mode: text index deltas of up to 4 occurrences per lane
+  const SvSet ts{&set_lds[threadIdx.x], 256};
   __shared__ uint32_t pf_lds[4 * 256];
   uint32_t* pfl = &pf_lds[threadIdx.x];   // rows: read id, offset lo, offset hi, length
 #ifdef SV_COUNT_ITERS
@@ -543,7 +546,7 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       }
       active = true;
     }
-    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, SEG && has_left);
+    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, SEG && has_left, p.use_set != 0);
 #ifdef SV_COUNT_ITERS
     if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(&g_sfs_iters[0], 1ULL);
     atomicAdd(&g_sfs_iters[2 + o.op], 1ULL);
@@ -602,6 +605,8 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       if (i0 < 0) i0 = 0;
       pa = (const uint8_t*)(p.seg_rec + (base - cap + i0));
       c0 = i0;
+    } else if (o.op == SV_OP_SET || o.op == SV_OP_SA_SET) {
+      // (their loads are issued below, next to the others)
     } else {  // SV_OP_FILL
       c0 = o.a;
       if (c0 > p.max_chunk - 3) c0 = p.max_chunk - 3;
@@ -618,6 +623,22 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
         const unsigned long long lo = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         A[i].x = (uint32_t)lo; A[i].y = (uint32_t)(lo >> 32); A[i].z = (uint32_t)hi; A[i].w = (uint32_t)(hi >> 32);
+      }
+    } else if (o.op == SV_OP_SET) {
+      const int alive = (st.mode >> SV_SET_SHIFT) & ((1 << SV_SET_MAX) - 1);
+#pragma unroll
+      for (int i = 0; i < SV_SET_MAX; ++i) {
+        A[i].x = A[i].y = A[i].z = A[i].w = 0;
+        if ((alive >> i) & 1) A[i] = sv_load16(p.ix.text + ts.base[i * ts.stride] + st.pos - SV_SET_WIN);
+      }
+      B[0] = sv_load16(reads + off + st.pos - SV_SET_WIN);
+    } else if (o.op == SV_OP_SA_SET) {
+      const int n_occ = (int)(st.hi - st.lo);
+#pragma unroll
+      for (int i = 0; i < SV_SET_MAX; ++i) {   // (entries past the interval are not used: read the first one again)
+        const P v = ((const P*)p.ix.sa)[(int64_t)st.lo + (i < n_occ ? i : 0)];
+        A[i].x = (uint32_t)v;
+        A[i].y = (uint32_t)((uint64_t)v >> 32);
       }
     } else if (o.op != SV_OP_FILL) A[0] = sv_load16(pa);
     if (wide_a) {
@@ -642,6 +663,13 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       sv_apply_sa(st, tp);
     } else if (o.op == SV_OP_TEXT) {
       sv_apply_text(st, A, B);
+    } else if (o.op == SV_OP_SET) {
+      sv_apply_set(st, ts, A, B[0]);
+    } else if (o.op == SV_OP_SA_SET) {
+      int64_t tp[SV_SET_MAX];
+#pragma unroll
+      for (int i = 0; i < SV_SET_MAX; ++i) tp[i] = (int64_t)((uint64_t)A[i].x | ((uint64_t)A[i].y << 32));
+      sv_apply_sa_set(st, ts, tp);
     } else if (o.op == SV_OP_PEEK) {
       int32_t q[SV_PEEK_RECS];
       bool written[SV_PEEK_RECS];
@@ -940,6 +968,8 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.read_ids = nullptr;
   p.sub_ids = nullptr;
   p.n_sub = 0;
+  p.use_set = 1;
+  if (const char* e = getenv("SVDSS_SET")) p.use_set = atoi(e) != 0;
   p.ticket_chunk = 8;
   if (const char* e = getenv("SVDSS_TICKETS")) p.ticket_chunk = atoi(e) > 0 ? atoi(e) : 8;
   p.n_items = n_reads;
@@ -958,7 +988,8 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   {
     const int64_t lanes = (int64_t)max_blocks * 256 / 2;   // 4 waves per SIMD resident
     const int64_t want = 4 * lanes / (n_reads > 0 ? n_reads : 1);   // ~4 items per resident lane: short items bound the tail
-    n_seg = (int)(want < 2 ? 1 : (want > 8 ? 8 : want));   // beyond 8 the odd unstitchable read costs more than it saves
+    n_seg = (int)(want < 4 ? 1 : (want > 8 ? 8 : want));   // large batches fill the GPU with one lane per read; beyond 8
+                                                              // the odd unstitchable read costs more than it saves
     if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
     if (n_seg < 1) n_seg = 1;
     if (n_seg > 16) n_seg = 16;

@@ -39,11 +39,11 @@ def search(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool):
 
 _lib.emu_search2.restype = _i64
 _lib.emu_search2.argtypes = [_p, _p, _p, _i64, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _p, _p, C.c_int, _p]
-OP_NAMES = ["DONE", "LF", "TABLE", "SA", "TEXT", "FILL", "TEXT_SLOW"]
+OP_NAMES = ["DONE", "LF", "TABLE", "SA", "TEXT", "FILL", "TEXT_SLOW", "PEEK", "SA_SET", "SET"]
 
 
 def search2(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool, K: int = 6, use_text: bool = True,
-            n_seg: int = 1):
+            n_seg: int = 1, use_set: bool = True):
     """v2 lane code (k-mer table of order K, LF, TEXT).  Returns (counts, qs, len, n_ext, op_counts)."""
     n = len(offsets) - 1
     total_syms = int(offsets[-1])
@@ -53,13 +53,13 @@ def search2(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool, K: int
     cap = total_syms + n + 1
     counts = np.zeros(n, dtype=np.int64)
     n_ext = np.zeros(n, dtype=np.int64)
-    ops = np.zeros(8, dtype=np.int64)
+    ops = np.zeros(16, dtype=np.int64)
     seg_stats = np.zeros(2, dtype=np.int64)
     qs = np.zeros(cap, dtype=np.int32)
     ln = np.zeros(cap, dtype=np.int32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     t = _lib.emu_search2(index._h, padded.ctypes.data, offsets.ctypes.data, n, alloc_syms, int(assemble), K,
-                         int(use_text), counts.ctypes.data, qs.ctypes.data, ln.ctypes.data, cap,
+                         int(use_text) | (2 if (use_set and use_text) else 0), counts.ctypes.data, qs.ctypes.data, ln.ctypes.data, cap,
                          n_ext.ctypes.data, ops.ctypes.data, n_seg, seg_stats.ctypes.data)
     assert t >= 0
     d = dict(zip(OP_NAMES, ops.tolist()))

@@ -85,7 +85,8 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
   std::vector<uint8_t> text((size_t)ix->n + 128 + 16, 0);
   memcpy(text.data() + 64, ix->text.data(), (size_t)ix->n);
   v.text = text.data() + 64;
-  v.sa = use_text ? (ix->sa64.empty() ? (const void*)ix->sa32.data() : (const void*)ix->sa64.data()) : nullptr;
+  v.sa = (use_text & 1) ? (ix->sa64.empty() ? (const void*)ix->sa32.data() : (const void*)ix->sa64.data()) : nullptr;
+  const bool use_set = (use_text & 2) != 0;   // bit 1: SET mode (2-4 occurrences followed in the text)
   std::vector<SvdssTabEntry> table;
   if (K > 0) {
     table.resize((size_t)1 << (2 * K));
@@ -100,6 +101,8 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
   auto run_lane = [&](int64_t off, int64_t l, int start_pos, int stop_lo, bool asm_, std::vector<Rec>& recs,
                       int32_t& ext_total, bool& complete, const std::vector<Rec>* left = nullptr) {
     int32_t nb_cur = 0;
+    int64_t set_mem[SV_SET_MAX];
+    const SvSet ts{set_mem, 1};
     uint32_t ring_mem[16];
     memset(ring_mem, 0xee, sizeof ring_mem);
     SvRing g{ring_mem, 1};
@@ -111,10 +114,27 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
     sv_lane_init(st, (int32_t)l, start_pos, stop_lo);
     for (int64_t guard = 0;; ++guard) {
       if (guard > 400 * l + 10000) { fprintf(stderr, "emu2: no termination off=%ld l=%ld start=%d stop=%d pos=%d begin=%d mode=%d lo=%ld hi=%ld wrel=%d nsfs=%d\n", (long)off, (long)l, start_pos, stop_lo, st.pos, st.begin, st.mode, (long)st.lo, (long)st.hi, st.wrel, st.n_sfs); abort(); }
-      SvOp o = sv_decide(st, v, g, off, asm_, emit, left != nullptr);
+      SvOp o = sv_decide(st, v, g, off, asm_, emit, left != nullptr, use_set);
       if (op_counts) op_counts[o.op]++;
       if (o.op == SV_OP_DONE) break;
       if (o.op == SV_OP_TEXT_SLOW) { sv_apply_text_slow(st, v.text, reads_padded, off); continue; }
+      if (o.op == SV_OP_SA_SET) {
+        int64_t tp[SV_SET_MAX];
+        const int n_occ = (int)(st.hi - st.lo);
+        for (int i = 0; i < SV_SET_MAX; ++i) tp[i] = (int64_t)((const P*)v.sa)[(int64_t)st.lo + (i < n_occ ? i : 0)];
+        sv_apply_sa_set(st, ts, tp);
+        continue;
+      }
+      if (o.op == SV_OP_SET) {
+        svdss_u4 tw[SV_SET_MAX], rb;
+        const int alive = (st.mode >> SV_SET_SHIFT) & ((1 << SV_SET_MAX) - 1);
+        memset(tw, 0, sizeof tw);
+        for (int i = 0; i < SV_SET_MAX; ++i)
+          if ((alive >> i) & 1) memcpy(&tw[i], v.text + set_mem[i] + st.pos - SV_SET_WIN, 16);
+        memcpy(&rb, reads_padded + off + st.pos - SV_SET_WIN, 16);
+        sv_apply_set(st, ts, tw, rb);
+        continue;
+      }
       if (o.op == SV_OP_PEEK) {   // the neighbour's chain is complete here (segments run left to right)
         int32_t q[SV_PEEK_RECS];
         bool written[SV_PEEK_RECS];
