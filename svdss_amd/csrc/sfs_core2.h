@@ -610,9 +610,17 @@ SVDSS_HD bool sv_stitch(int n_seg, const SvSegInfo* info, const int32_t* seg_lo,
     int32_t ia = lo, ib = 0;
     int32_t qa, ea, qb, eb;
     bool found = false;
+    {
+      // skip a's own territory: records are in descending start order, find the first one below x
+      int32_t hi_ = info[a].n_rec;
+      while (ia < hi_) {
+        const int32_t mid = ia + ((hi_ - ia) >> 1);
+        rec_qs_ext(a, mid, qa, ea);
+        if (qa >= x) ia = mid + 1; else hi_ = mid;
+      }
+    }
     while (ia < info[a].n_rec && ib < info[b].n_rec) {
       rec_qs_ext(a, ia, qa, ea);
-      if (qa >= x) { ++ia; continue; }       // still in a's own territory
       rec_qs_ext(b, ib, qb, eb);
       if (qa == qb) { found = true; break; }
       if (qa > qb) ++ia; else ++ib;

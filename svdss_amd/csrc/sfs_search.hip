@@ -382,36 +382,40 @@ __device__ __forceinline__ svdss_u4 sv_load16(const uint8_t* p) {
 }
 
 // Longest-processing-time-first scheduling.  Lanes fetch items dynamically, so the launch ends when the last
-// item that was started ends: the items that take 5-10 x the median (reads in repeats: every backward phase
-// walks the BWT one symbol at a time until a single copy is left) must start first, not last.  One wavefront
-// per read samples 64 pairs of adjacent K-mers in the table; reads where at least two pairs occur more than
+// item that was started ends: the items that take 5-10 x the median (reads in repeats) must start first, not
+// last.  Sixteen
+// lanes per read sample 16 pairs of adjacent K-mers in the table; reads where at least two pairs occur more than
 // once in the reference go to the front of the order, the rest to the back.  The order only decides when a
 // read is searched, never what is found.
 __global__ void __launch_bounds__(256) sfs_order_kernel(SfsParams p, int64_t* heavy) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (r >= p.n_reads) return;
-  const int64_t off = p.offsets[r];
-  const int64_t len = p.offsets[r + 1] - off;
+  // 16 lanes per read, one sample each
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+  const int64_t r = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + grp;
+  const bool live = r < p.n_reads;
   const int K = p.ix.k;
   const uint8_t* reads = (const uint8_t*)p.chunks;
   bool hit = false;
-  if (K >= 8 && K <= 16 && p.ix.table != nullptr && len >= 8 * K) {
-    // one sample per lane: the 2K symbols at an even spacing along the read (two 16-byte loads)
-    const int64_t pos = off + ((len - 32) * (2 * lane + 1)) / 128;
-    const svdss_u4 w0 = sv_load16(reads + pos), w1 = sv_load16(reads + pos + K);
-    const uint32_t wa[4] = {w0.x, w0.y, w0.z, w0.w}, wb[4] = {w1.x, w1.y, w1.z, w1.w};
-    uint32_t k1 = 0, k2 = 0, bad = 0;
+  if (live) {
+    const int64_t off = p.offsets[r];
+    const int64_t len = p.offsets[r + 1] - off;
+    if (K >= 8 && K <= 16 && p.ix.table != nullptr && len >= 8 * K) {
+      // the 2K symbols at an even spacing along the read (two 16-byte loads)
+      const int64_t pos = off + ((len - 32) * (2 * sub + 1)) / 32;
+      const svdss_u4 w0 = sv_load16(reads + pos), w1 = sv_load16(reads + pos + K);
+      const uint32_t wa[4] = {w0.x, w0.y, w0.z, w0.w}, wb[4] = {w1.x, w1.y, w1.z, w1.w};
+      uint32_t k1 = 0, k2 = 0, bad = 0;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const uint32_t a = ((wa[t >> 2] >> (8 * (t & 3))) & 0xffu) - 1u;
-      const uint32_t c = ((wb[t >> 2] >> (8 * (t & 3))) & 0xffu) - 1u;
-      if (t < K) { bad |= (a | c) & ~3u; k1 |= (a & 3u) << (2 * t); k2 |= (c & 3u) << (2 * t); }
+      for (int t = 0; t < 16; ++t) {
+        const uint32_t a = ((wa[t >> 2] >> (8 * (t & 3))) & 0xffu) - 1u;
+        const uint32_t c = ((wb[t >> 2] >> (8 * (t & 3))) & 0xffu) - 1u;
+        if (t < K) { bad |= (a | c) & ~3u; k1 |= (a & 3u) << (2 * t); k2 |= (c & 3u) << (2 * t); }
+      }
+      if (!bad) hit = (p.ix.table[k1].info >> 62) == SVDSS_TAB_MULTI && (p.ix.table[k2].info >> 62) == SVDSS_TAB_MULTI;
     }
-    if (!bad) hit = (p.ix.table[k1].info >> 62) == SVDSS_TAB_MULTI && (p.ix.table[k2].info >> 62) == SVDSS_TAB_MULTI;
   }
-  const int hits = __builtin_popcountll(__ballot(hit));
-  if (lane == 0) heavy[r] = hits >= 2 ? 1 : 0;
+  const unsigned long long hm = __ballot(hit);
+  const int hits = __builtin_popcountll((hm >> (16 * grp)) & 0xffffULL);
+  if (live && sub == 0) heavy[r] = hits >= 2 ? 1 : 0;
 }
 
 // stable partition by the flags: heavy reads first (scan = exclusive prefix sum of heavy, n_reads + 1 entries)
@@ -787,14 +791,20 @@ __global__ void __launch_bounds__(256) sfs_assemble_kernel(SfsParams p) {
   int32_t runs = 0;        // assembled SFS opened so far
   int32_t open_end = 0;    // end of the first record of the open one
   int32_t prev_q = 0;      // qs of the last record of the previous step
+  int32_t q_pre = 0, l_pre = 0;   // the records of the next step are loaded while this one is assembled
+  if (lane < M) load(lane, q_pre, l_pre);
   for (int32_t g0 = 0; g0 < M; g0 += 64) {
     const int32_t g = g0 + lane;
     const bool in = g < M;
-    int32_t q = 0, l = 0;
-    if (in) load(g, q, l);
+    const int32_t q = q_pre, l = l_pre;
+    q_pre = 0; l_pre = 0;
+    if (g + 64 < M) load(g + 64, q_pre, l_pre);
     const bool has_next = g + 1 < M;
     int32_t qn = __shfl_down(q, 1, 64), ln = __shfl_down(l, 1, 64);
-    if (lane == 63 && has_next) load(g + 1, qn, ln);
+    {   // lane 63's successor is lane 0 of the next step
+      const int32_t q0 = __shfl(q_pre, 0, 64), l0 = __shfl(l_pre, 0, 64);
+      if (lane == 63) { qn = q0; ln = l0; }
+    }
     int32_t qp = __shfl_up(q, 1, 64);
     if (lane == 0) qp = prev_q;
     const bool flag = in && (g == 0 || q + l <= qp);
@@ -1047,7 +1057,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       int64_t* heavy = (int64_t*)b->order_cnt.p;
       int64_t* hscan = heavy + n_reads + 1;
       HIPCHK(hipMemsetAsync(heavy + n_reads, 0, sizeof(int64_t), stream));
-      hipLaunchKernelGGL(sfs_order_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, stream, p, heavy);
+      hipLaunchKernelGGL(sfs_order_kernel, dim3((unsigned)((n_reads + 15) / 16)), dim3(256), 0, stream, p, heavy);
       HIPCHK(hipGetLastError());
       size_t t3 = b->tmp.cap;
       HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->tmp.p, t3, heavy, hscan, (int)(n_reads + 1), stream));
