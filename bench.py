@@ -229,7 +229,8 @@ def main():
                 # the kernel's memory operations are dependent random reads (one per lane per iteration): the
                 # measured ceiling of that access pattern on this GPU (tools/random_read_probe.hip) next to the
                 # rate at which the kernel's measured traffic arrives, both in 64-B lines per second
-                "random_access": random_access_info(measured_traffic(ref_total, n_reads, L, ix.kmer_k, "_transactions"), k_ms),
+                "random_access": random_access_info(measured_traffic(ref_total, n_reads, L, ix.kmer_k, "_transactions"),
+                                                    measured_traffic(ref_total, n_reads, L, ix.kmer_k, "_read_transactions"), k_ms),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -242,7 +243,7 @@ def main():
         dist.destroy_process_group()
 
 
-def random_access_info(transactions, k_ms):
+def random_access_info(transactions, read_transactions, k_ms):
     try:
         with open(os.path.join(ROOT, "profiles", "random_access.json")) as fh:
             probe = json.load(fh)
@@ -253,8 +254,11 @@ def random_access_info(transactions, k_ms):
     if transactions:   # TCC_EA0_RDREQ + TCC_EA0_WRREQ of one launch (profiles/r01_final_pmc.csv)
         rate = transactions / (k_ms * 1e-3)
         out["achieved_transactions_per_s"] = rate
-        out["frac_of_dependent_ceiling"] = rate / probe["dependent_random_lines_per_s"]
-        out["frac_of_independent_ceiling"] = rate / probe["independent_random_lines_per_s"]
+    if read_transactions:   # the probe measures reads: compare reads with reads
+        rrate = read_transactions / (k_ms * 1e-3)
+        out["achieved_read_transactions_per_s"] = rrate
+        out["read_frac_of_dependent_ceiling"] = rrate / probe["dependent_random_lines_per_s"]
+        out["read_frac_of_independent_ceiling"] = rrate / probe["independent_random_lines_per_s"]
     return out
 
 
