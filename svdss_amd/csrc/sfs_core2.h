@@ -75,6 +75,9 @@ struct SvLane {
 #define SV_SET_MAX 4
 #define SV_SET_SHIFT 8    // mode bits 8-11: which of the occurrences are still alive
 #define SV_SET_WIN 16
+#define SV_LFC_SHIFT 12   // mode bits 12-13: LF steps taken on an interval of 2-4 since the phase started
+#define SV_LFC_MASK (3 << SV_LFC_SHIFT)
+#define SV_SET_AFTER 2    // ... chance matches of a K-mer die within a symbol or two; real copies do not
 #define SV_PEEK_VISIBLE 16 // records per segment stored so that a concurrently running neighbour can see them
 
 struct SvOp {
@@ -238,10 +241,14 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
           o.a = (int64_t)s.lo;
           return o;
         }
-        if (use_set && s.hi - s.lo <= SV_SET_MAX && ix.sa != nullptr && off >= 64) {   // a few: follow them all
-          o.op = SV_OP_SA_SET;
-          o.a = (int64_t)s.lo;
-          return o;
+        if (use_set && s.hi - s.lo <= SV_SET_MAX && ix.sa != nullptr && off >= 64) {
+          // a few left: if they survived SV_SET_AFTER more symbols they are copies, follow them all in the text
+          if (((s.mode & SV_LFC_MASK) >> SV_LFC_SHIFT) >= SV_SET_AFTER) {
+            o.op = SV_OP_SA_SET;
+            o.a = (int64_t)s.lo;
+            return o;
+          }
+          s.mode += 1 << SV_LFC_SHIFT;
         }
         const int np = s.pos - 1;
         if (!sv_in_window(s, np)) {
@@ -256,7 +263,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
       }
       if (s.pos == 0 && nonempty) return o;           // :24 -> DONE
       s.begin = s.pos;                                // :28
-      s.mode |= SV_M_DIR | SV_M_START;
+      s.mode = (s.mode & ~SV_LFC_MASK) | SV_M_DIR | SV_M_START;
     } else {
       if (nonempty) {                                 // :31
         const int np = s.pos + 1;
@@ -285,7 +292,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
         }
       }
       s.pos = s.pos - 1;                              // :47
-      s.mode = (s.mode & ~SV_M_DIR) | SV_M_START;
+      s.mode = (s.mode & ~(SV_M_DIR | SV_LFC_MASK)) | SV_M_START;
     }
   }
 }
@@ -441,7 +448,7 @@ SVDSS_HD void sv_apply_peek(SvLane<P>& s, const int32_t q[SV_PEEK_RECS], const b
     return;
   }
   s.pos = s.pos - 1;                                  // ping_pong.cpp:47
-  s.mode = (s.mode & ~SV_M_DIR) | SV_M_START;
+  s.mode = (s.mode & ~(SV_M_DIR | SV_LFC_MASK)) | SV_M_START;
 }
 
 // TEXT: ta[] = text bytes, rb[] = read bytes, both for read positions
