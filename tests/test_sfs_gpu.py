@@ -309,3 +309,35 @@ def test_scheduling_knobs_never_change_results(monkeypatch, env):
     assert (got.counts == c).all() and (got.n_ext == e).all()
     assert (got.qs == q).all() and (got.len == l).all()
     pp.close()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_low_copy_repeats_with_n_runs(monkeypatch, wide):
+    """SET mode (2-4 occurrences followed in the text) on a reference made mostly of overlapping copies, with N runs in
+    the reference and N in the reads, on both suffix-array widths; and the same with SET mode off."""
+    if wide:
+        monkeypatch.setenv("SVDSS_FORCE_SA64", "1")
+    ref = synth.make_reference([120000, 60000], seed=91, repeat_frac=0.6, divergence=0.004, n_runs=(300, 40))
+    rng = np.random.default_rng(92)
+    reads = []
+    for i in range(1200):
+        c = ref[int(rng.integers(0, 2))]
+        ln = int(rng.integers(200, 3000))
+        a = int(rng.integers(0, len(c) - ln))
+        r = c[a:a + ln].copy()
+        e = rng.random(ln) < 0.004
+        r[e] = (r[e] - 1 + rng.integers(1, 4, size=int(e.sum()))) % 4 + 1
+        if i % 17 == 0:
+            r[int(rng.integers(0, ln))] = 5
+        reads.append(r.astype(np.uint8))
+    flat, offs = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    c, q, l, e = fm.search_batch(flat, offs, True)
+    for set_mode in ("1", "0"):
+        monkeypatch.setenv("SVDSS_SET", set_mode)
+        pp = svdss_amd.PingPong(ix, assemble=True)
+        got = pp.ping_pong_search(flat, offs)
+        assert (got.counts == c).all() and (got.n_ext == e).all()
+        assert (got.qs == q).all() and (got.len == l).all()
+        pp.close()
