@@ -120,3 +120,34 @@ def test_v2_repeats_and_long_unique_stretches():
     for K, use_text in [(8, True), (0, True)]:
         c, q, l, e, ops = E.search2(ix, flat, offs, False, K, use_text)
         assert (c == c2).all() and (e == e2).all() and (q == q2).all() and (l == l2).all()
+
+
+@pytest.mark.parametrize("n_seg", [1, 4])
+def test_v2_set_mode_in_low_copy_repeats(n_seg):
+    """SET mode (2-4 occurrences followed in the text, 16 symbols per operation) must leave SFS and extension counts
+    untouched while replacing most LF steps of reads in low-copy repeats."""
+    from svdss_amd import synth
+    ref = synth.make_reference([400000], seed=3, repeat_frac=0.3, divergence=0.006, n_runs=(60,))
+    rng = np.random.default_rng(5)
+    reads = []
+    for i in range(40):
+        ln = int(rng.integers(1500, 5000))
+        a = int(rng.integers(0, len(ref[0]) - ln))
+        r = ref[0][a:a + ln].copy()
+        e = rng.random(ln) < 0.005
+        r[e] = (r[e] - 1 + rng.integers(1, 4, size=int(e.sum()))) % 4 + 1
+        if i % 7 == 0:
+            r[int(rng.integers(0, ln))] = 5
+        reads.append(r.astype(np.uint8))
+    flat, offs = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(ref)
+    fm = O.OracleFMD.build(ref)
+    c, q, l, e = fm.search_batch(flat, offs, True)
+    ops = {}
+    for use_set in (False, True):
+        got = E.search2(ix, flat, offs, assemble=True, K=9, n_seg=n_seg, use_set=use_set)
+        assert (got[0] == c).all() and (got[3] == e).all()
+        assert (got[1] == q).all() and (got[2] == l).all()
+        ops[use_set] = got[4]
+    assert ops[False]["SET"] == 0 and ops[True]["SET"] > 0 and ops[True]["SA_SET"] > 0
+    assert ops[True]["LF"] < ops[False]["LF"] // 2
