@@ -41,17 +41,29 @@ __device__ __forceinline__ int dp_gap(int l, const GapModel& g) {
 struct AlnPair {
   int64_t q_off, t_off;   // into the concatenated query / target symbol buffers
   int64_t ws_off;         // int32 workspace: 11 arrays of (tl + 1)
-  int64_t dir_off;        // tl*ql direction bytes
+  int64_t dir_off;        // (tl+ql)*tl direction bytes, diagonal-major: cell (i, j) at (i+j)*tl + i
   int64_t cig_off;        // uint32 ops in backtrack order, capacity tl + ql + 2
   int32_t ql, tl;
 };
 
+// barrier that orders LDS traffic only (the direction bytes stream out to HBM on every diagonal; waiting for them
+// at each of the ~2000 barriers of a pair would cost more than the diagonal itself)
+__device__ __forceinline__ void dp_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // One workgroup per pair.  Cell (i, j): i indexes the target, j the query, r = i + j.
 // Recurrences and tie rules are those of ksw2's extd2 (left-aligned), see the oracle
 // (oracle/svdss_oracle_call.c, orc_ksw_extd2_global) which this kernel must match bit for bit.
+// The rotating diagonals (H of r-1 and r-2, the four gap states of r-1: 11 arrays of tl+1) live in LDS when
+// they fit (LDS = true, 44 bytes per target symbol), else in the HBM workspace.
+template <bool LDS>
 __global__ void __launch_bounds__(DP_THREADS) align_global_kernel(
     const AlnPair* pairs, const uint8_t* qsyms, const uint8_t* tsyms, int m, const int8_t* mat_g,
     GapModel gm, int32_t* ws, uint8_t* dirs, uint32_t* cigars, int32_t* scores, int32_t* n_cigar) {
+  extern __shared__ int32_t dp_lds[];
   __shared__ int8_t mat[64];
   const AlnPair P = pairs[blockIdx.x];
   const int ql = P.ql, tl = P.tl;
@@ -60,24 +72,33 @@ __global__ void __launch_bounds__(DP_THREADS) align_global_kernel(
     if (threadIdx.x == 0) { scores[blockIdx.x] = 0; n_cigar[blockIdx.x] = 0; }
     return;
   }
+  const int stride = tl + 1;
+  int32_t* buf = LDS ? dp_lds : ws + P.ws_off;
+  // the two sequences sit behind the diagonals in LDS (a global byte load per cell would put ~1 us of latency on
+  // every diagonal)
   const uint8_t* q = qsyms + P.q_off;
   const uint8_t* t = tsyms + P.t_off;
-  const int64_t stride = tl + 1;
-  int32_t* base = ws + P.ws_off;
-  // rotating diagonals: H needs r-1 and r-2, the gap states r-1
-  int32_t* Hb[3] = {base, base + stride, base + 2 * stride};
-  int32_t* Eb[2] = {base + 3 * stride, base + 4 * stride};
-  int32_t* Fb[2] = {base + 5 * stride, base + 6 * stride};
-  int32_t* E2b[2] = {base + 7 * stride, base + 8 * stride};
-  int32_t* F2b[2] = {base + 9 * stride, base + 10 * stride};
+  if (LDS) {
+    uint8_t* sq = (uint8_t*)(dp_lds + 11 * stride);
+    uint8_t* st_ = sq + ql;
+    for (int x = threadIdx.x; x < ql; x += DP_THREADS) sq[x] = q[x];
+    for (int x = threadIdx.x; x < tl; x += DP_THREADS) st_[x] = t[x];
+    q = sq;
+    t = st_;
+  }
+  // array k of the 11 at buf + k * stride: H x3 (rotating: needs r-1 and r-2), then E, F, E2, F2 x2 (r-1)
   uint8_t* dir = dirs + P.dir_off;
   __syncthreads();
   const int n_diag = tl + ql - 1;
   for (int r = 0; r < n_diag; ++r) {
-    const int32_t* Hm1 = Hb[(r + 2) % 3];
-    const int32_t* Hm2 = Hb[(r + 1) % 3];
-    int32_t* Hc = Hb[r % 3];
+    const int32_t* Hm1 = buf + ((r + 2) % 3) * stride;
+    const int32_t* Hm2 = buf + ((r + 1) % 3) * stride;
+    int32_t* Hc = buf + (r % 3) * stride;
     const int cur = r & 1, prv = cur ^ 1;
+    const int32_t *Ep_ = buf + (3 + prv) * stride, *Fp_ = buf + (5 + prv) * stride;
+    const int32_t *E2p_ = buf + (7 + prv) * stride, *F2p_ = buf + (9 + prv) * stride;
+    int32_t *Ec = buf + (3 + cur) * stride, *Fc = buf + (5 + cur) * stride;
+    int32_t *E2c = buf + (7 + cur) * stride, *F2c = buf + (9 + cur) * stride;
     const int ilo = r - (ql - 1) > 0 ? r - (ql - 1) : 0;
     const int ihi = r < tl - 1 ? r : tl - 1;
     for (int i = ilo + (int)threadIdx.x; i <= ihi; i += DP_THREADS) {
@@ -86,9 +107,9 @@ __global__ void __launch_bounds__(DP_THREADS) align_global_kernel(
       if (i > 0 && j > 0) hdiag = Hm2[i - 1];
       else if (i == 0) hdiag = j == 0 ? 0 : -dp_gap(j, gm);
       else hdiag = -dp_gap(i, gm);
-      if (i > 0) { hup = Hm1[i - 1]; Ep = Eb[prv][i - 1]; E2p = E2b[prv][i - 1]; }
+      if (i > 0) { hup = Hm1[i - 1]; Ep = Ep_[i - 1]; E2p = E2p_[i - 1]; }
       else { hup = -dp_gap(j + 1, gm); Ep = DP_NEG; E2p = DP_NEG; }
-      if (j > 0) { hleft = Hm1[i]; Fp = Fb[prv][i]; F2p = F2b[prv][i]; }
+      if (j > 0) { hleft = Hm1[i]; Fp = Fp_[i]; F2p = F2p_[i]; }
       else { hleft = -dp_gap(i + 1, gm); Fp = DP_NEG; F2p = DP_NEG; }
       const int32_t Ein = (hup - gm.q > Ep ? hup - gm.q : Ep) - gm.e;
       const int32_t E2in = (hup - gm.q2 > E2p ? hup - gm.q2 : E2p) - gm.e2;
@@ -104,24 +125,47 @@ __global__ void __launch_bounds__(DP_THREADS) align_global_kernel(
       if (Fin > z - gm.q) d |= 0x10;
       if (E2in > z - gm.q2) d |= 0x20;
       if (F2in > z - gm.q2) d |= 0x40;
-      dir[(int64_t)i * ql + j] = (uint8_t)d;
+      dir[(int64_t)r * tl + i] = (uint8_t)d;   // diagonal-major: the lanes of a diagonal write consecutive bytes
       Hc[i] = z;
-      Eb[cur][i] = Ein; E2b[cur][i] = E2in;
-      Fb[cur][i] = Fin; F2b[cur][i] = F2in;
+      Ec[i] = Ein; E2c[i] = E2in;
+      Fc[i] = Fin; F2c[i] = F2in;
     }
-    __syncthreads();
+    if (LDS) dp_lds_barrier(); else __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    scores[blockIdx.x] = Hb[(n_diag - 1) % 3][tl - 1];
-    // ksw_backtrack from (tl-1, ql-1); ops are left in backtrack order, the host reverses them
+  __syncthreads();   // the direction bytes are in HBM
+  if (threadIdx.x < 64) {
+    // ksw_backtrack from (tl-1, ql-1) by the first wavefront; ops are left in backtrack order, the host reverses
+    // them.  A register window holds the direction bytes of 64 rows x 4 columns along the current diagonal (one HBM
+    // latency per ~60 steps of a mostly diagonal path instead of one per step); runs are merged in registers.
+    const int lane = threadIdx.x;
+    if (lane == 0) scores[blockIdx.x] = buf[((n_diag - 1) % 3) * stride + tl - 1];
     uint32_t* cg = cigars + P.cig_off;
     int n = 0, i = tl - 1, j = ql - 1, state = 0;
+    uint32_t cur_op = 0xffffffffu, cur_len = 0;
     auto push = [&](uint32_t op, uint32_t len) {
-      if (n > 0 && (cg[n - 1] & 0xfu) == op) cg[n - 1] += len << 4;
-      else cg[n++] = (len << 4) | op;
+      if (op == cur_op) { cur_len += len; return; }
+      if (cur_op != 0xffffffffu) { if (lane == 0) cg[n] = (cur_len << 4) | cur_op; ++n; }
+      cur_op = op; cur_len = len;
     };
+    int i0 = -(1 << 28), j0 = 0;
+    uint32_t win = 0;
     while (i >= 0 && j >= 0) {
-      const uint32_t tmp = dir[(int64_t)i * ql + j];
+      int k = i0 - i, d = j - (j0 - k);
+      if (k < 0 || k > 63 || d < 0 || d > 3) {
+        i0 = i; j0 = j - 1; k = 0; d = 1;       // columns j0-k .. j0-k+3 of row i0-k (room for two D and one I moves)
+        const int ii = i0 - lane;
+        const int64_t jj = (int64_t)j0 - lane;
+        win = 0;
+        if (ii >= 0) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int64_t c = jj + x;
+            if (c >= 0 && c < ql) win |= (uint32_t)dir[(int64_t)(ii + c) * tl + ii] << (8 * x);
+          }
+        }
+        asm volatile("" : "+v"(win));   // wait for the window here, not at the join below
+      }
+      const uint32_t tmp = ((uint32_t)__builtin_amdgcn_readlane((int)win, k) >> (8 * d)) & 0xffu;
       if (state == 0) state = tmp & 7;
       else if (!((tmp >> (state + 2)) & 1)) state = 0;
       if (state == 0) state = tmp & 7;
@@ -131,7 +175,8 @@ __global__ void __launch_bounds__(DP_THREADS) align_global_kernel(
     }
     if (i >= 0) push(2, (uint32_t)(i + 1));
     if (j >= 0) push(1, (uint32_t)(j + 1));
-    n_cigar[blockIdx.x] = n;
+    if (cur_op != 0xffffffffu) { if (lane == 0) cg[n] = (cur_len << 4) | cur_op; ++n; }
+    if (lane == 0) n_cigar[blockIdx.x] = n;
   }
 }
 
@@ -243,10 +288,10 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
   int64_t start = 0;
   while (start < n_pairs) {
     std::vector<AlnPair> hp;
-    int64_t ws = 0, dirb = 0, cig = 0, end = start;
+    int64_t ws = 0, dirb = 0, cig = 0, end = start, tl_max = 0, ql_max = 0;
     while (end < n_pairs) {
       const int64_t ql = q_off[end + 1] - q_off[end], tl = t_off[end + 1] - t_off[end];
-      const int64_t need = ql * tl;
+      const int64_t need = (ql + tl) * tl;   // direction bytes, one row of tl per anti-diagonal
       if (end > start && dirb + need > dir_budget) break;
       AlnPair a;
       a.q_off = q_off[end] - q_off[0];
@@ -258,9 +303,11 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
       a.tl = (int32_t)tl;
       hp.push_back(a);
       ws += 11 * (tl + 1);
+      if (tl > tl_max) tl_max = tl;
+      if (ql > ql_max) ql_max = ql;
       dirb += need;
       cig += ql + tl + 2;
-      b->cells += need;
+      b->cells += ql * tl;
       ++end;
     }
     const int64_t np = end - start;
@@ -271,10 +318,19 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
       return rc;
     HIPCHK2(hipMemcpy(d_pairs.p, hp.data(), sizeof(AlnPair) * (size_t)np, hipMemcpyHostToDevice));
     HIPCHK2(hipEventRecord(ev0, 0));
-    hipLaunchKernelGGL(align_global_kernel, dim3((unsigned)np), dim3(DP_THREADS), 0, 0,
-                       (const AlnPair*)d_pairs.p, (const uint8_t*)d_q.p, (const uint8_t*)d_t.p, (int)m,
-                       (const int8_t*)d_mat.p, gm, (int32_t*)d_ws.p, (uint8_t*)d_dir.p, (uint32_t*)d_cig.p,
-                       (int32_t*)d_sc.p, (int32_t*)d_nc.p);
+    const size_t lds_need = sizeof(int32_t) * 11 * (size_t)(tl_max + 1) + (size_t)ql_max + (size_t)tl_max + 16;
+    if (lds_need <= 150 * 1024) {
+      HIPCHK2(hipFuncSetAttribute((const void*)align_global_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+      hipLaunchKernelGGL(align_global_kernel<true>, dim3((unsigned)np), dim3(DP_THREADS), lds_need, 0,
+                         (const AlnPair*)d_pairs.p, (const uint8_t*)d_q.p, (const uint8_t*)d_t.p, (int)m,
+                         (const int8_t*)d_mat.p, gm, (int32_t*)d_ws.p, (uint8_t*)d_dir.p, (uint32_t*)d_cig.p,
+                         (int32_t*)d_sc.p, (int32_t*)d_nc.p);
+    } else {
+      hipLaunchKernelGGL(align_global_kernel<false>, dim3((unsigned)np), dim3(DP_THREADS), 0, 0,
+                         (const AlnPair*)d_pairs.p, (const uint8_t*)d_q.p, (const uint8_t*)d_t.p, (int)m,
+                         (const int8_t*)d_mat.p, gm, (int32_t*)d_ws.p, (uint8_t*)d_dir.p, (uint32_t*)d_cig.p,
+                         (int32_t*)d_sc.p, (int32_t*)d_nc.p);
+    }
     HIPCHK2(hipGetLastError());
     HIPCHK2(hipEventRecord(ev1, 0));
     HIPCHK2(hipDeviceSynchronize());
