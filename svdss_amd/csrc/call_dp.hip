@@ -186,22 +186,34 @@ struct LcsPair {
 };
 
 // LCS length by anti-diagonals, then rapidfuzz::fuzz::ratio's arithmetic.
+// (LDS = true: the three rotating diagonals and both strings live in LDS)
+template <bool LDS>
 __global__ void __launch_bounds__(DP_THREADS) lcs_ratio_kernel(const LcsPair* pairs, const uint8_t* as,
                                                               const uint8_t* bs, int32_t* ws,
                                                               int64_t* lcs_out, double* ratio_out) {
+  extern __shared__ int32_t dp_lds[];
   const LcsPair P = pairs[blockIdx.x];
   const int la = P.la, lb = P.lb;
   int64_t lcs = 0;
   if (la > 0 && lb > 0) {
     const uint8_t* a = as + P.a_off;
     const uint8_t* b = bs + P.b_off;
-    const int64_t stride = la + 1;
-    int32_t* Lb[3] = {ws + P.ws_off, ws + P.ws_off + stride, ws + P.ws_off + 2 * stride};
+    const int stride = la + 1;
+    int32_t* buf = LDS ? dp_lds : ws + P.ws_off;
+    if (LDS) {
+      uint8_t* sa = (uint8_t*)(dp_lds + 3 * stride);
+      uint8_t* sb = sa + la;
+      for (int x = threadIdx.x; x < la; x += DP_THREADS) sa[x] = a[x];
+      for (int x = threadIdx.x; x < lb; x += DP_THREADS) sb[x] = b[x];
+      a = sa;
+      b = sb;
+      __syncthreads();
+    }
     const int n_diag = la + lb - 1;
     for (int r = 0; r < n_diag; ++r) {
-      const int32_t* Lm1 = Lb[(r + 2) % 3];
-      const int32_t* Lm2 = Lb[(r + 1) % 3];
-      int32_t* Lc = Lb[r % 3];
+      const int32_t* Lm1 = buf + ((r + 2) % 3) * stride;
+      const int32_t* Lm2 = buf + ((r + 1) % 3) * stride;
+      int32_t* Lc = buf + (r % 3) * stride;
       const int ilo = r - (lb - 1) > 0 ? r - (lb - 1) : 0;
       const int ihi = r < la - 1 ? r : la - 1;
       for (int i = ilo + (int)threadIdx.x; i <= ihi; i += DP_THREADS) {
@@ -211,9 +223,9 @@ __global__ void __launch_bounds__(DP_THREADS) lcs_ratio_kernel(const LcsPair* pa
         const int32_t left = j > 0 ? Lm1[i] : 0;
         Lc[i] = a[i] == b[j] ? diag + 1 : (up > left ? up : left);
       }
-      __syncthreads();
+      if (LDS) dp_lds_barrier(); else __syncthreads();
     }
-    lcs = Lb[(n_diag - 1) % 3][la - 1];
+    lcs = buf[((n_diag - 1) % 3) * stride + la - 1];
   }
   if (threadIdx.x == 0) {
     const int64_t maximum = (int64_t)la + lb;
@@ -379,7 +391,7 @@ extern "C" int svdss_indel_ratio_batch(const uint8_t* a, const int64_t* a_off, c
   if (!a || !a_off || !bsy || !b_off || !ratio_out) return SVDSS_EINVAL;
   HIPCHK2(hipSetDevice(device));
   std::vector<LcsPair> hp((size_t)n_pairs);
-  int64_t ws = 0;
+  int64_t ws = 0, la_max = 0, lb_max = 0;
   for (int64_t i = 0; i < n_pairs; ++i) {
     const int64_t la = a_off[i + 1] - a_off[i], lb = b_off[i + 1] - b_off[i];
     if (la < 0 || lb < 0) return SVDSS_EINVAL;
@@ -390,6 +402,8 @@ extern "C" int svdss_indel_ratio_batch(const uint8_t* a, const int64_t* a_off, c
     hp[(size_t)i].la = (int32_t)la;
     hp[(size_t)i].lb = (int32_t)lb;
     ws += 3 * (la + 1);
+    if (la > la_max) la_max = la;
+    if (lb > lb_max) lb_max = lb;
   }
   const int64_t atot = a_off[n_pairs] - a_off[0], btot = b_off[n_pairs] - b_off[0];
   DevMem d_a, d_b, d_pairs, d_ws, d_lcs, d_ratio;
@@ -401,9 +415,17 @@ extern "C" int svdss_indel_ratio_batch(const uint8_t* a, const int64_t* a_off, c
   if (atot) HIPCHK2(hipMemcpy(d_a.p, a + a_off[0], (size_t)atot, hipMemcpyHostToDevice));
   if (btot) HIPCHK2(hipMemcpy(d_b.p, bsy + b_off[0], (size_t)btot, hipMemcpyHostToDevice));
   HIPCHK2(hipMemcpy(d_pairs.p, hp.data(), sizeof(LcsPair) * (size_t)n_pairs, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(lcs_ratio_kernel, dim3((unsigned)n_pairs), dim3(DP_THREADS), 0, 0,
-                     (const LcsPair*)d_pairs.p, (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (int32_t*)d_ws.p,
-                     (int64_t*)d_lcs.p, (double*)d_ratio.p);
+  const size_t lds_need = sizeof(int32_t) * 3 * (size_t)(la_max + 1) + (size_t)la_max + (size_t)lb_max + 16;
+  if (lds_need <= 150 * 1024) {
+    HIPCHK2(hipFuncSetAttribute((const void*)lcs_ratio_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    hipLaunchKernelGGL(lcs_ratio_kernel<true>, dim3((unsigned)n_pairs), dim3(DP_THREADS), lds_need, 0,
+                       (const LcsPair*)d_pairs.p, (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (int32_t*)d_ws.p,
+                       (int64_t*)d_lcs.p, (double*)d_ratio.p);
+  } else {
+    hipLaunchKernelGGL(lcs_ratio_kernel<false>, dim3((unsigned)n_pairs), dim3(DP_THREADS), 0, 0,
+                       (const LcsPair*)d_pairs.p, (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (int32_t*)d_ws.p,
+                       (int64_t*)d_lcs.p, (double*)d_ratio.p);
+  }
   HIPCHK2(hipGetLastError());
   HIPCHK2(hipDeviceSynchronize());
   HIPCHK2(hipMemcpy(ratio_out, d_ratio.p, sizeof(double) * (size_t)n_pairs, hipMemcpyDeviceToHost));
