@@ -72,3 +72,56 @@ def test_smooth_cli_matches_mirror(tmp_path):
             assert g.seq == a.seq and g.qual == a.qual and g.cigar == a.cigar
         xfs.append(xf)
     assert xfs.count(0) > 5 and xfs.count(1) >= 1 and xfs.count(2) > 5
+
+
+def test_smooth_output_does_not_depend_on_threads_and_spans_many_bgzf_chunks(tmp_path):
+    """The parallel BGZF reader (512-block chunks, read ahead) and writer (256-block batches) must give the same
+    bytes whatever the thread count, on a BAM large enough to span several chunks."""
+    import struct
+    import zlib
+
+    rng = np.random.default_rng(7)
+    ref = rng.integers(1, 5, size=300000).astype(np.uint8)
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">c1\n" + synth.to_ascii(ref) + "\n")
+    code = np.array([0, 1, 2, 4, 8, 15], dtype=np.uint8)            # nt6 -> BAM 4-bit
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c1\tLN:%d\n" % len(ref)
+    data = [b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1)
+            + struct.pack("<i", 3) + b"c1\0" + struct.pack("<i", len(ref))]
+    n_reads, ln = 9000, 4000
+    starts = np.sort(rng.integers(0, len(ref) - ln, size=n_reads))
+    for i, st in enumerate(starts):
+        seq = ref[st:st + ln].copy()
+        e = rng.random(ln) < 0.004
+        seq[e] = (seq[e] - 1 + rng.integers(1, 4, size=int(e.sum()))) % 4 + 1
+        c = code[seq]
+        packed = ((c[0::2] << 4) | c[1::2]).tobytes()
+        name = ("r%06d" % i).encode() + b"\0"
+        core = struct.pack("<iiBBHHHiiii", 0, int(st), len(name), 60, 4680, 1, 0, ln, -1, -1, 0)
+        body = core + name + struct.pack("<I", ln << 4) + packed + rng.integers(20, 60, size=ln, dtype=np.uint8).tobytes()
+        data.append(struct.pack("<i", len(body)) + body)
+    raw = b"".join(data)
+    assert len(raw) > 600 * 65280                                   # more than one 512-block chunk
+
+    def block(d):
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        cd = co.compress(d) + co.flush()
+        return (struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(cd) + 25) + cd
+                + struct.pack("<II", zlib.crc32(d) & 0xFFFFFFFF, len(d)))
+
+    bam = tmp_path / "in.bam"
+    with open(bam, "wb") as fh:
+        for k in range(0, len(raw), 65280):
+            fh.write(block(raw[k:k + 65280]))
+        fh.write(block(b""))
+    outs = []
+    for threads in ("1", "6"):
+        out = tmp_path / f"out{threads}.bam"
+        with open(out, "wb") as fh:
+            r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam), "--threads", threads], stdout=fh,
+                               stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] and len(outs[0]) > 0
+    names, lens, alns = bamio.read_bam(str(tmp_path / "out6.bam"))
+    assert len(alns) == n_reads and names == ["c1"]
