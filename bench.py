@@ -225,6 +225,10 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(ref_total, n_reads, L, ix.kmer_k),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+                "note": ("achieved = SURVEY 8(d) algorithmic bytes (one 64-B BWT block per rb3_fmd_extend the reference "
+                         "would make) / search-kernel time; the k-mer table, text-compare and SET operations answer "
+                         "most of those extensions without fetching their blocks, so frac exceeds 1 -- `traffic` "
+                         "is what really crosses the fabric and `random_access` the limit that binds"),
                 "all_kernels_ms": float(np.mean(pipeline_ms)),
                 # the kernel's memory operations are dependent random reads (one per lane per iteration): the
                 # measured ceiling of that access pattern on this GPU (tools/random_read_probe.hip) next to the
