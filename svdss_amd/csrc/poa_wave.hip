@@ -49,7 +49,7 @@
 #define P_MISMATCH 4
 #define COL_SINK 0x7FFFFFFE
 #define COL_NEW 0x7FFFFFFF
-#define RI_SLOW 15u
+#define RI_SLOW 3u
 
 struct WsLayout {
   int64_t out_head, in_head, order, index, col, base;
@@ -129,8 +129,8 @@ __device__ __forceinline__ int wave_shr1(int x, int fill) { return dppi<0x138, 0
 //  bit 16    F1 opened from H'(v, j-1) (else extended);  bit 17 F2 likewise
 //
 // row descriptor layout (rowinfo[r], one per topological position)
-//  bits 0-2 base, bits 3-6 number of predecessors (0-2, or RI_SLOW: look at the graph), bits 7-18 and 19-30
-//  the row deltas of predecessor 0 / 1, bit 31: some later row reads this row after it left the ring
+//  16 bits: bits 0-2 base, bits 3-4 number of predecessors (0-2, or RI_SLOW: look at the graph), bits 5-9 and
+//  10-14 the row deltas (< 32) of predecessor 0 / 1, bit 15: some later row reads this row after it left the ring
 
 __device__ unsigned long long g_poaw_prof[8];   // SVDSS_DEBUG: time in prepare, forward, traceback, update, bundle
 #define PROF_T() (prof_t = wall_clock64())
@@ -147,8 +147,8 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   constexpr int G = 4;            // -inf guard cells on each side of a ring row
   const int RST = RS + 2 * G;     // LDS stride of a ring row
   // ---- LDS
-  uint32_t* rowinfo = (uint32_t*)smem;
-  int32_t* rH = (int32_t*)(rowinfo + nc);
+  uint16_t* rowinfo = (uint16_t*)smem;
+  int32_t* rH = (int32_t*)(smem + ((2 * (size_t)nc + 15) & ~(size_t)15));
   int32_t* rE1 = rH + NS * RST;
   int32_t* rE2 = rE1 + NS * RST;
   int32_t* rbeg = rE2 + NS * RST;
@@ -228,23 +228,25 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         if (np == 0) d0 = d; else if (np == 1) d1 = d;
         ++np;
       }
-      if (np > 2 || d0 > 4095 || d1 > 4095) ri |= RI_SLOW << 3;
-      else ri |= ((uint32_t)np << 3) | ((uint32_t)d0 << 7) | ((uint32_t)d1 << 19);
-      rowinfo[r] = ri;
+      if (np > 2 || d0 > 31 || d1 > 31) ri |= RI_SLOW << 3;
+      else ri |= ((uint32_t)np << 3) | ((uint32_t)d0 << 5) | ((uint32_t)d1 << 10);
+      rowinfo[r] = (uint16_t)ri;
     }
     __syncthreads();
-    for (int r = lane; r < N - 1; r += 64) {   // flag the rows that are read back after they left the ring
+    // flag the rows that are read back after they left the ring (32-bit LDS atomics on the word that holds the flag)
+    auto flag_row = [&](int rr) { atomicOr((uint32_t*)rowinfo + (rr >> 1), 0x8000u << (16 * (rr & 1))); };
+    for (int r = lane; r < N - 1; r += 64) {
       const uint32_t ri = rowinfo[r];
-      const uint32_t np = (ri >> 3) & 15u;
+      const uint32_t np = (ri >> 3) & 3u;
       if (np == RI_SLOW) {
         for (int e = in_head[order[r]]; e >= 0; e = e_next_in[e]) {
           const int d = r - index[e_from[e]];
-          if (d >= RING) atomicOr(&rowinfo[r - d], 0x80000000u);
+          if (d >= RING) flag_row(r - d);
         }
       } else {
-        const int d0 = (int)((ri >> 7) & 4095u), d1 = (int)((ri >> 19) & 4095u);
-        if (np >= 1 && d0 >= RING) atomicOr(&rowinfo[r - d0], 0x80000000u);
-        if (np >= 2 && d1 >= RING) atomicOr(&rowinfo[r - d1], 0x80000000u);
+        const int d0 = (int)((ri >> 5) & 31u), d1 = (int)((ri >> 10) & 31u);
+        if (np >= 1 && d0 >= RING) flag_row(r - d0);
+        if (np >= 2 && d1 >= RING) flag_row(r - d1);
       }
     }
     __syncthreads();
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         if (lane == 0) { rbeg[s] = pb; rend[s] = pe; rmpl[s] = row_mpl[ur]; rmpr[s] = row_mpr[ur]; }
         __syncthreads();
       };
-      uint32_t ri_n = rowinfo[0];
+      uint32_t ri_n = rowinfo[0];   // (row N-1, the sink, has a descriptor too: r + 1 below stays in range)
       // ------------------------------------------------------------ forward (the sink is order[N-1])
       for (int r = 0; r < N - 1; ++r) {
         FP(5);
@@ -279,8 +281,8 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         ri_n = rowinfo[r + 1];
         const int slot = r & rm;
         const int bv = (int)(ri & 7u);
-        int np = (int)((ri >> 3) & 15u);
-        const bool keep = (ri >> 31) != 0;
+        int np = (int)((ri >> 3) & 3u);
+        const bool keep = ((ri >> 15) & 1u) != 0;
         const bool slow = np == (int)RI_SLOW;
         int ps0 = 0, ps1 = 0;
         int lo = 1 << 30, hi = -1;
@@ -288,14 +290,14 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         if (!slow) {
           int nfar = 0;
           if (np >= 1) {
-            const int d = (int)((ri >> 7) & 4095u), ur = r - d;
+            const int d = (int)((ri >> 5) & 31u), ur = r - d;
             pd0 = (uint32_t)imin(d, 255);
             if (d < RING) ps0 = ur & rm; else { ps0 = RING + nfar++; stage(ur, ps0); }
             const int a = ur == last_r ? last_mpl : rmpl[ps0], b = ur == last_r ? last_mpr : rmpr[ps0];
             lo = imin(lo, a); hi = imax(hi, b);
           }
           if (np >= 2) {
-            const int d = (int)((ri >> 19) & 4095u), ur = r - d;
+            const int d = (int)((ri >> 10) & 31u), ur = r - d;
             pd0 |= (uint32_t)imin(d, 255) << 8;
             if (d < RING) ps1 = ur & rm; else { ps1 = RING + nfar++; stage(ur, ps1); }
             const int a = ur == last_r ? last_mpl : rmpl[ps1], b = ur == last_r ? last_mpr : rmpr[ps1];
@@ -809,7 +811,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
 
 size_t poa_wave_lds_bytes(int nc, int max_len, int rs, int ring) {
   const size_t ns = (size_t)ring + 2;
-  const size_t fwd = 4 * (size_t)nc + 12 * ns * ((size_t)rs + 8) + 16 * ns + 64 + (((size_t)max_len + 15) & ~(size_t)15);
+  const size_t fwd = ((2 * (size_t)nc + 15) & ~(size_t)15) + 12 * ns * ((size_t)rs + 8) + 16 * ns + 64 + (((size_t)max_len + 15) & ~(size_t)15);
   const size_t bundle = 12 * (size_t)nc;
   return (fwd > bundle ? fwd : bundle) + 64;
 }
