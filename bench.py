@@ -10,8 +10,10 @@ synthetic HiFi-shape reads that is already resident in HBM.
 
 Multi-GPU: reads shard across ranks (weak scaling: every rank gets its own
 batch of the same size), the index is replicated in every GPU's HBM, and the
-only exchange is the gather of the assembled SFS records on rank 0 each step.
-Rank 0 prints ONE JSON line.
+path has no exchange step: every rank keeps the SFS of its shard (as N
+`SVDSS search` processes would each write their part of the .sfs file).
+`--gather` adds a gather of the assembled SFS on rank 0 (svdss_amd/multi.py,
+RCCL send/recv over xGMI) to every step.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -93,6 +95,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-call-dp", action="store_true", help="skip the call-side DP kernel measurement")
+    ap.add_argument("--gather", action="store_true", help="multi-GPU: gather the SFS on rank 0 inside every timed step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -155,7 +158,7 @@ def main():
     def step():
         pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
                                    stream=stream.cuda_stream, fetch=False)
-        if world > 1:
+        if world > 1 and args.gather:
             counts, qs, ln = pp.device_results()
             multi.gather_sfs(counts, qs, ln)
 
@@ -214,7 +217,8 @@ def main():
                              f"{args.err * 100:.2f}% errors, search with fused assemble, all reads searched "
                              "(--noputative semantics)"),
                 "reads_per_gpu": n_reads, "read_len": L, "index_bytes": ix.device_bytes,
-                "parallelism": f"reads sharded over {world} GPU(s), index replicated, SFS gathered on rank 0",
+                "parallelism": (f"reads sharded over {world} GPU(s), index replicated, no data-path collective"
+                                + (", SFS gathered on rank 0 every step" if (world > 1 and args.gather) else "")),
                 "ext_per_read": n_ext / n_reads, "raw_sfs_per_read": n_sfs_raw / n_reads,
                 "assembled_sfs_per_read": n_sfs_asm / n_reads, "index_build_s": round(t_index, 1),
                 "kmer_table_k": ix.kmer_k, "segments_per_read": pp.last_segments,
