@@ -200,6 +200,24 @@ class BamReader {
     return 1;
   }
 
+  // a sliced record turned into a BamRecord (without qualities; the packed bases only if want_seq)
+  static void materialize(const Arena& arena, const RawRec& rr, BamRecord& r, bool want_seq = true) {
+    const uint8_t* p = arena.data() + rr.off;
+    r.tid = rr.tid; r.pos = rr.pos; r.l_seq = rr.l_seq; r.flag = rr.flag; r.mapq = rr.mapq;
+    r.qname.assign((const char*)p, rr.l_name ? rr.l_name - 1 : 0);
+    r.cigar.resize(rr.n_cigar);
+    if (rr.n_cigar) memcpy(r.cigar.data(), p + rr.l_name, 4u * rr.n_cigar);
+    const uint8_t* sq = arena.data() + rr.seq_off();
+    if (want_seq) r.seq4.assign(sq, sq + (size_t)(rr.l_seq + 1) / 2); else r.seq4.clear();
+    r.qual.clear();
+    const uint8_t* ax = arena.data() + rr.aux_off();
+    r.aux.assign(ax, ax + rr.l_aux);
+  }
+  static void materialize_seq(const Arena& arena, const RawRec& rr, BamRecord& r) {
+    const uint8_t* sq = arena.data() + rr.seq_off();
+    r.seq4.assign(sq, sq + (size_t)(rr.l_seq + 1) / 2);
+  }
+
   // integer aux tag (bam_aux_get + bam_aux2i); returns false if absent or not an integer
   static bool aux_int(const BamRecord& r, const char tag[2], int64_t& out) {
     return aux_int(r.aux.data(), r.aux.size(), tag, out);

@@ -352,17 +352,24 @@ int main_call(const CallOptions& o) {
     const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
     std::vector<std::vector<ESFS>> per_thread((size_t)T);
     std::vector<BamRecord> batch;
+    BamReader::Arena arena;
+    std::string qname;
     bool eof = false;
     while (!eof) {
       batch.clear();
       while ((int)batch.size() < bsize) {
-        BamRecord r;
-        const int rc = bam.next(r, false);   // (qualities are not used by `call`)
+        // records are sliced out of the stream and only decoded if the read has SFS at all
+        arena.clear();
+        BamReader::RawRec rr;
+        const int rc = bam.next_raw(arena, rr);
         if (rc == 0) { eof = true; break; }
         if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
-        if (r.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
-        if ((int)r.mapq < o.min_mapq) continue;
-        if (C.sfs.find(r.qname) == C.sfs.end()) continue;
+        if (rr.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
+        if ((int)rr.mapq < o.min_mapq) continue;
+        qname.assign((const char*)arena.data() + rr.name_off(), rr.l_name ? rr.l_name - 1 : 0);
+        if (C.sfs.find(qname) == C.sfs.end()) continue;
+        BamRecord r;
+        BamReader::materialize(arena, rr, r);
         batch.push_back(std::move(r));
       }
       // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
@@ -451,11 +458,14 @@ int main_call(const CallOptions& o) {
     BamReader bam(o.bam);
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
     BamRecord r;
+    BamReader::Arena arena;
+    BamReader::RawRec rr;
     int rc;
-    while ((rc = bam.next(r, false)) > 0) {
-      if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
-      auto it = by_chrom.find(ref_names[(size_t)r.tid]);
+    while (arena.clear(), (rc = bam.next_raw(arena, rr)) > 0) {
+      if (rr.tid < 0 || rr.tid >= (int)ref_names.size()) continue;
+      auto it = by_chrom.find(ref_names[(size_t)rr.tid]);
       if (it == by_chrom.end()) continue;
+      BamReader::materialize(arena, rr, r, false);   // (the bases are decoded only for reads that join a cluster)
       const int a_beg = r.pos, a_end = r.endpos();
       Pairs al;
       std::string seq;
@@ -476,7 +486,7 @@ int main_call(const CallOptions& o) {
         clusters[ci].reads.emplace_back(0, hp == 0 ? 3 : (int)hp);
         if (reads[ci].find(r.qname) == reads[ci].end()) continue;
         clusters[ci].reads.back().first = 1;
-        if (al.empty()) { al = get_aligned_pairs(r); seq = r.seq_string(); }
+        if (al.empty()) { al = get_aligned_pairs(r); BamReader::materialize_seq(arena, rr, r); seq = r.seq_string(); }
         int qs = -1, qe = -1;
         for (int i = (int)al.size() - 1; i >= 0; --i) {
           if (al[(size_t)i].first == -1 || al[(size_t)i].second == -1) continue;
