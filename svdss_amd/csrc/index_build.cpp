@@ -22,6 +22,8 @@
 #include "../../include/svdss_hip.h"
 #include "index_host.h"
 
+extern "C" int svdss_sa32_gpu(const uint8_t* t, int64_t n, int32_t* sa_out);   // index_gpu.hip
+
 namespace {
 
 constexpr int KEY_SYMS = 21;
@@ -153,7 +155,13 @@ int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t 
     const bool force64 = getenv("SVDSS_FORCE_SA64") != nullptr;  // test hook for the 64-bit path
     if (n < (int64_t)0x7fffffff && !force64) {
       std::vector<int32_t> sa;
-      suffix_array<int32_t>(t.data(), n, sa, threads);
+      // the GPU sorter when there is one (index_gpu.hip; SVDSS_INDEX_CPU=1 keeps the host builder), same result
+      bool done = false;
+      if (!getenv("SVDSS_INDEX_CPU")) {
+        sa.resize((size_t)n);
+        done = svdss_sa32_gpu(t.data(), n, sa.data()) == 0;
+      }
+      if (!done) suffix_array<int32_t>(t.data(), n, sa, threads);
       ix->sa32.resize((size_t)n);
       ix->sa64.clear();
 #pragma omp parallel for num_threads(threads) schedule(static)

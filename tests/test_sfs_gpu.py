@@ -341,3 +341,17 @@ def test_low_copy_repeats_with_n_runs(monkeypatch, wide):
         assert (got.counts == c).all() and (got.n_ext == e).all()
         assert (got.qs == q).all() and (got.len == l).all()
         pp.close()
+
+
+def test_gpu_suffix_sorter_builds_the_same_index(monkeypatch, tmp_path):
+    """`SVDSS index` sorts suffixes on the GPU when there is one (csrc/index_gpu.hip); the index file must be the one
+    the host builder writes (the suffix array of a text is unique), including long repeats, N runs and several contigs."""
+    ref = synth.make_reference([180000, 90000, 700], seed=33, repeat_frac=0.5, divergence=0.0005, n_runs=(500, 30))
+    ref.append(np.tile(np.array([1, 2, 3, 4], np.uint8), 3000))       # a tandem repeat: many doubling rounds
+    a = svdss_amd.FMDIndex.build(ref)
+    a.save(str(tmp_path / "gpu.fmd"))
+    monkeypatch.setenv("SVDSS_INDEX_CPU", "1")
+    b = svdss_amd.FMDIndex.build(ref)
+    b.save(str(tmp_path / "cpu.fmd"))
+    assert (a.bwt() == b.bwt()).all()
+    assert (tmp_path / "gpu.fmd").read_bytes() == (tmp_path / "cpu.fmd").read_bytes()
