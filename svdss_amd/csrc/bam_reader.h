@@ -133,6 +133,16 @@ class BamReader {
     return 1;
   }
 
+  struct Bytes {   // uninitialised buffer (std::vector would zero-fill what inflate overwrites anyway)
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    void alloc(size_t k) { p.reset(new uint8_t[k ? k : 1]); n = k; }
+    uint8_t* data() { return p.get(); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void swap(Bytes& o) { p.swap(o.p); std::swap(n, o.n); }
+  };
+
   // A record sliced but not decoded: core fields + where name / cigar / packed bases / aux tags sit in an
   // arena the caller owns (qualities are skipped).  Slicing is sequential and runs at memcpy speed; the
   // caller decodes many records in parallel.
@@ -197,6 +207,55 @@ class BamReader {
       err_ = "truncated record";
       return -1;
     }
+    return 1;
+  }
+
+  // Zero-copy variant of next_raw: the record body stays where it was inflated.  `p` points at the 32-byte core block
+  // (inside the current chunk, or inside `own` when the record straddles two chunks); the caller keeps the buffers
+  // alive by holding chunk() (whenever chunk_id() changes) and `own`.
+  struct RawView {
+    const uint8_t* p = nullptr;
+    std::shared_ptr<uint8_t> own;   // only for straddling records
+    uint32_t l_name = 0, n_cigar = 0, l_aux = 0;
+    int32_t tid = -1, pos = 0, l_seq = 0;
+    uint16_t flag = 0;
+    uint8_t mapq = 0;
+    const uint8_t* name() const { return p + 32; }
+    const uint8_t* seq4() const { return p + 32 + l_name + 4u * n_cigar; }
+    const uint8_t* aux() const { return seq4() + (size_t)(l_seq + 1) / 2 + (size_t)l_seq; }
+  };
+  std::shared_ptr<Bytes> chunk() const { return chunk_; }
+  uint64_t chunk_id() const { return chunk_id_; }
+
+  // 1 = record, 0 = clean end of file, -1 = error
+  int next_view(RawView& v) {
+    int32_t block_size;
+    const size_t got = read_some(&block_size, 4);
+    if (got == 0) return 0;
+    if (got != 4 || block_size < 32) { err_ = "truncated record"; return -1; }
+    v.own.reset();
+    if (chunk_->size() - upos_ >= (size_t)block_size) {   // whole record inside the current chunk
+      v.p = chunk_->data() + upos_;
+      upos_ += (size_t)block_size;
+    } else {
+      v.own = std::shared_ptr<uint8_t>(new uint8_t[(size_t)block_size], std::default_delete<uint8_t[]>());
+      if (!read(v.own.get(), (size_t)block_size)) { err_ = "truncated record"; return -1; }
+      v.p = v.own.get();
+    }
+    const uint8_t* core = v.p;
+    uint16_t n_cigar;
+    memcpy(&v.tid, core, 4);
+    memcpy(&v.pos, core + 4, 4);
+    v.l_name = core[8];
+    v.mapq = core[9];
+    memcpy(&n_cigar, core + 12, 2);
+    v.n_cigar = n_cigar;
+    memcpy(&v.flag, core + 14, 2);
+    memcpy(&v.l_seq, core + 16, 4);
+    if (v.l_seq < 0) { err_ = "corrupt record"; return -1; }
+    const size_t head = 32 + (size_t)v.l_name + 4u * v.n_cigar + (size_t)(v.l_seq + 1) / 2 + (size_t)v.l_seq;
+    if (head > (size_t)block_size) { err_ = "corrupt record"; return -1; }
+    v.l_aux = (uint32_t)((size_t)block_size - head);
     return 1;
   }
 
@@ -266,11 +325,11 @@ class BamReader {
 
   bool skip(size_t n) {
     while (n) {
-      if (upos_ == ublock_.size()) {
+      if (upos_ == chunk_->size()) {
         if (!next_chunk()) return false;
         continue;
       }
-      const size_t take = std::min(n, ublock_.size() - upos_);
+      const size_t take = std::min(n, chunk_->size() - upos_);
       upos_ += take;
       n -= take;
     }
@@ -281,37 +340,28 @@ class BamReader {
   size_t read_some(void* dst, size_t n) {
     size_t done = 0;
     while (done < n) {
-      if (upos_ == ublock_.size()) {
+      if (upos_ == chunk_->size()) {
         if (!next_chunk()) break;
-        if (ublock_.empty()) continue;   // only empty blocks (EOF markers) -- keep going
+        if (chunk_->empty()) continue;   // only empty blocks (EOF markers) -- keep going
       }
-      const size_t take = std::min(n - done, ublock_.size() - upos_);
-      memcpy((uint8_t*)dst + done, ublock_.data() + upos_, take);
+      const size_t take = std::min(n - done, chunk_->size() - upos_);
+      memcpy((uint8_t*)dst + done, chunk_->data() + upos_, take);
       upos_ += take;
       done += take;
     }
     return done;
   }
 
-  // BGZF blocks are independent deflate streams (<= 64 KiB each): a chunk of kChunkBlocks blocks is read
+  // BGZF blocks are independent deflate streams (<= 64 KiB each): a chunk of ~512 blocks (one 32 MB read) is located
   // sequentially, inflated by `threads_` workers, and the next chunk is prepared in the background while the
   // caller parses the current one (htslib's hts_set_threads plays this role for the reference).
-  struct Bytes {   // uninitialised buffer (std::vector would zero-fill what inflate overwrites anyway)
-    std::unique_ptr<uint8_t[]> p;
-    size_t n = 0;
-    void alloc(size_t k) { p.reset(new uint8_t[k ? k : 1]); n = k; }
-    uint8_t* data() { return p.get(); }
-    size_t size() const { return n; }
-    bool empty() const { return n == 0; }
-    void swap(Bytes& o) { p.swap(o.p); std::swap(n, o.n); }
-  };
   struct Chunk {
     Bytes data;
     bool eof = false;
     std::string err;
   };
   struct BlockRef { size_t coff, clen, uoff; uint32_t isize, crc; };
-  static constexpr size_t kChunkBlocks = 512;
+  static constexpr size_t kSlabBytes = (size_t)32 << 20;   // compressed bytes read per chunk (~512 blocks)
 
   bool next_chunk() {
     if (eof_seen_) return false;   // the final chunk was already handed out
@@ -324,9 +374,11 @@ class BamReader {
     pending_.pop_front();
     if (!c.err.empty()) { err_ = c.err; eof_seen_ = true; drain(); return false; }
     if (c.eof) { eof_seen_ = true; drain(); }
-    ublock_.swap(c.data);
+    chunk_ = std::make_shared<Bytes>();
+    chunk_->swap(c.data);
+    ++chunk_id_;
     upos_ = 0;
-    return !(c.eof && ublock_.empty());
+    return !(c.eof && chunk_->empty());
   }
 
   void drain() {
@@ -338,7 +390,6 @@ class BamReader {
   // chunk overlaps the file read of the next one.
   Chunk load_chunk(uint64_t ticket) {
     Chunk c;
-    std::vector<uint8_t> comp;
     std::vector<BlockRef> blocks;
     size_t total = 0;
     std::unique_lock<std::mutex> file_lock(file_m_);
@@ -349,37 +400,44 @@ class BamReader {
       ~Release() { (*this)(); }
     } release{this, &file_lock};
     if (file_eof_) { c.eof = true; return c; }
-    while (blocks.size() < kChunkBlocks) {
-      uint8_t h[18];
-      const size_t g = fread(h, 1, 18, f_);
-      if (g == 0) { c.eof = true; file_eof_ = true; break; }
-      if (g != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { c.err = "bad BGZF block"; file_eof_ = true; return c; }
+    // one large read per chunk (plus the partial block the previous chunk left over), blocks located in memory
+    Bytes comp;
+    comp.alloc(carry_.size() + kSlabBytes);
+    if (!carry_.empty()) memcpy(comp.data(), carry_.data(), carry_.size());
+    const size_t got = fread(comp.data() + carry_.size(), 1, kSlabBytes, f_);
+    const size_t avail = carry_.size() + got;
+    size_t pos = 0;
+    while (pos + 18 <= avail) {
+      const uint8_t* h = comp.data() + pos;
+      if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { c.err = "bad BGZF block"; file_eof_ = true; return c; }
       uint16_t xlen;
       memcpy(&xlen, h + 10, 2);
+      if (pos + 12 + xlen > avail) break;          // header extends past what was read: next chunk
       // find the BC subfield (normally the only one, right at h[12..17])
-      std::vector<uint8_t> extra(xlen);
-      memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
-      if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6u, f_) != xlen - 6u) { c.err = "bad BGZF block"; file_eof_ = true; return c; }
       int bsize = -1;
-      for (size_t o = 0; o + 4 <= extra.size();) {
+      for (size_t o = 0; o + 4 <= xlen;) {
+        const uint8_t* x = h + 12 + o;
         uint16_t slen;
-        memcpy(&slen, &extra[o + 2], 2);
-        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) {
-          uint16_t v; memcpy(&v, &extra[o + 4], 2); bsize = v; break;
-        }
+        memcpy(&slen, x + 2, 2);
+        if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) { uint16_t v; memcpy(&v, x + 4, 2); bsize = v; break; }
         o += 4u + slen;
       }
       if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) { c.err = "BGZF block without BC field"; file_eof_ = true; return c; }
+      if (pos + (size_t)bsize + 1 > avail) break;  // partial block: next chunk
       const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
-      const size_t at = comp.size();
-      comp.resize(at + cdata + 8);
-      if (fread(comp.data() + at, 1, cdata + 8, f_) != cdata + 8) { c.err = "truncated BGZF block"; file_eof_ = true; return c; }
       BlockRef b;
-      b.coff = at; b.clen = cdata; b.uoff = total;
-      memcpy(&b.crc, comp.data() + at + cdata, 4);
-      memcpy(&b.isize, comp.data() + at + cdata + 4, 4);
+      b.coff = pos + 12 + xlen; b.clen = cdata; b.uoff = total;
+      memcpy(&b.crc, comp.data() + b.coff + cdata, 4);
+      memcpy(&b.isize, comp.data() + b.coff + cdata + 4, 4);
       total += b.isize;
       blocks.push_back(b);
+      pos += (size_t)bsize + 1;
+    }
+    carry_.assign(comp.data() + pos, comp.data() + avail);
+    if (got == 0) {
+      c.eof = true;
+      file_eof_ = true;
+      if (!carry_.empty()) { c.err = "truncated BGZF block"; return c; }
     }
     release();
     c.data.alloc(total);
@@ -421,13 +479,15 @@ class BamReader {
   std::condition_variable file_cv_;
   uint64_t next_ticket_ = 0, n_launched_ = 0;
   bool file_eof_ = false;          // (guarded by file_m_)
+  std::vector<uint8_t> carry_;     // partial block at the end of the previous read (guarded by file_m_)
   bool launched_eof_ = false;
   bool eof_seen_ = false;
   std::string err_;
   std::vector<std::string> refs_;
   std::vector<int32_t> ref_lens_;
   std::string text_;
-  Bytes ublock_;
+  std::shared_ptr<Bytes> chunk_ = std::make_shared<Bytes>();   // the inflated chunk being parsed
+  uint64_t chunk_id_ = 0;
   std::vector<uint8_t> buf_;
   size_t upos_ = 0;
 };

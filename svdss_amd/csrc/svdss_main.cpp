@@ -275,21 +275,24 @@ int main_search(const Options& o) {
 
   std::thread producer([&] {
     bool eof = false;
-    BamReader::Arena arena;
-    std::vector<BamReader::RawRec> recs;
+    std::vector<BamReader::RawView> recs;
+    std::vector<std::shared_ptr<BamReader::Bytes>> keep_chunks;
     while (!eof) {
       std::unique_ptr<SearchBatch> bt(new SearchBatch);
       bt->goff.assign(1, 0);
       if (bam_mode) {
-        // slice the records of one batch out of the stream (sequential), then decode them in parallel
-        arena.clear();
+        // locate the records of one batch in the inflated chunks (sequential, no copies: the chunks are kept
+        // alive until the batch is decoded), then decode them in parallel
         recs.clear();
+        keep_chunks.clear();
+        uint64_t seen_chunk = ~0ull;
         const auto ts0 = now();
         while ((int64_t)recs.size() < super) {
-          BamReader::RawRec rr;
-          const int rc = bam->next_raw(arena, rr);
+          BamReader::RawView rr;
+          const int rc = bam->next_view(rr);
           if (rc == 0) { eof = true; break; }
           if (rc < 0) die("error reading " + o.bam + ": " + bam->error());
+          if (bam->chunk_id() != seen_chunk) { seen_chunk = bam->chunk_id(); keep_chunks.push_back(bam->chunk()); }
           ++n_seen;
           bool keep = !(rr.flag & (4 | 2048 | 256));                     // ping_pong.cpp:66-69
           if (keep && rr.l_seq < 100) {                                  // :70-75
@@ -297,8 +300,8 @@ int main_search(const Options& o) {
             keep = false;
           }
           if (keep && rr.tid < 0) die("core.tid < 0. Why are we here? Please check");  // :76-79
-          if (!keep) { arena.resize(rr.off); continue; }
-          recs.push_back(rr);
+          if (!keep) continue;
+          recs.push_back(std::move(rr));
         }
         const auto ts1 = now();
         t_slice += secs(ts0, ts1);
@@ -306,12 +309,12 @@ int main_search(const Options& o) {
         bt->reads.resize(n);
         parallel_for(n, [&](size_t lo, size_t hi) {
           for (size_t i = lo; i < hi; ++i) {
-            const BamReader::RawRec& rr = recs[i];
+            const BamReader::RawView& rr = recs[i];
             Read& r = bt->reads[i];
-            r.name.assign((const char*)arena.data() + rr.name_off(), rr.l_name ? rr.l_name - 1 : 0);
+            r.name.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
             int64_t xf = 0, hp = 0;
-            BamReader::aux_int(arena.data() + rr.aux_off(), rr.l_aux, "XF", xf);   // :196-201, missing => 0
-            BamReader::aux_int(arena.data() + rr.aux_off(), rr.l_aux, "HP", hp);
+            BamReader::aux_int(rr.aux(), rr.l_aux, "XF", xf);   // :196-201, missing => 0
+            BamReader::aux_int(rr.aux(), rr.l_aux, "HP", hp);
             r.hp = (int)hp;
             if (o.putative && xf != 0) { r.count = -1; r.len = 0; }                 // :202-203
             else r.len = rr.l_seq;
@@ -325,8 +328,8 @@ int main_search(const Options& o) {
         bt->graw.reset(new uint8_t[(size_t)bt->goff.back() + 16]);
         parallel_for(bt->gidx.size(), [&](size_t lo, size_t hi) {
           for (size_t k = lo; k < hi; ++k) {
-            const BamReader::RawRec& rr = recs[bt->gidx[k]];
-            const uint8_t* seq4 = arena.data() + rr.seq_off();
+            const BamReader::RawView& rr = recs[bt->gidx[k]];
+            const uint8_t* seq4 = rr.seq4();
             uint8_t* dst = bt->graw.get() + bt->goff[k];
             const size_t full = (size_t)rr.l_seq / 2;
             for (size_t x = 0; x < full; ++x) memcpy(dst + 2 * x, &pair_to_nt6[seq4[x]], 2);
