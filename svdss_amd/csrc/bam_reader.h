@@ -4,6 +4,8 @@
 // /root/reference/ping_pong.cpp:58,247-249,196-201.  Only what `search` consumes is
 // decoded: flag, refID, l_seq, read name, 4-bit SEQ, integer aux tags (XF, HP).
 #pragma once
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -54,11 +56,19 @@ struct BamRecord {
 class BamReader {
  public:
   explicit BamReader(const std::string& path, int threads = 0) : f_(fopen(path.c_str(), "rb")) {
+    if (f_) {   // regular files are mapped: blocks are inflated straight from the page cache, no read() copies
+      struct stat st;
+      if (fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f_), 0);
+        if (m != MAP_FAILED) { map_ = (const uint8_t*)m; map_size_ = (size_t)st.st_size; (void)madvise(m, map_size_, MADV_SEQUENTIAL); }
+      }
+    }
     const unsigned hw = std::thread::hardware_concurrency();
     threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(32u, hw ? hw : 1u));
   }
   ~BamReader() {
     drain();
+    if (map_) munmap((void*)map_, map_size_);
     if (f_) fclose(f_);
   }
   BamReader(const BamReader&) = delete;
@@ -400,15 +410,26 @@ class BamReader {
       ~Release() { (*this)(); }
     } release{this, &file_lock};
     if (file_eof_) { c.eof = true; return c; }
-    // one large read per chunk (plus the partial block the previous chunk left over), blocks located in memory
+    // mapped file: the blocks of this chunk are located in the mapping; otherwise one large read per chunk (plus the
+    // partial block the previous chunk left over)
     Bytes comp;
-    comp.alloc(carry_.size() + kSlabBytes);
-    if (!carry_.empty()) memcpy(comp.data(), carry_.data(), carry_.size());
-    const size_t got = fread(comp.data() + carry_.size(), 1, kSlabBytes, f_);
-    const size_t avail = carry_.size() + got;
+    const uint8_t* src;
+    size_t avail, got;
+    if (map_) {
+      src = map_ + map_pos_;
+      got = std::min(kSlabBytes, map_size_ - map_pos_);
+      avail = map_size_ - map_pos_;          // a block may end past the slab: the mapping has it
+    } else {
+      comp.alloc(carry_.size() + kSlabBytes);
+      if (!carry_.empty()) memcpy(comp.data(), carry_.data(), carry_.size());
+      got = fread(comp.data() + carry_.size(), 1, kSlabBytes, f_);
+      avail = carry_.size() + got;
+      src = comp.data();
+    }
+    const size_t scan_end = map_ ? got : avail;   // where to stop starting new blocks
     size_t pos = 0;
-    while (pos + 18 <= avail) {
-      const uint8_t* h = comp.data() + pos;
+    while (pos + 18 <= avail && pos < scan_end) {
+      const uint8_t* h = src + pos;
       if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { c.err = "bad BGZF block"; file_eof_ = true; return c; }
       uint16_t xlen;
       memcpy(&xlen, h + 10, 2);
@@ -427,17 +448,26 @@ class BamReader {
       const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
       BlockRef b;
       b.coff = pos + 12 + xlen; b.clen = cdata; b.uoff = total;
-      memcpy(&b.crc, comp.data() + b.coff + cdata, 4);
-      memcpy(&b.isize, comp.data() + b.coff + cdata + 4, 4);
+      memcpy(&b.crc, src + b.coff + cdata, 4);
+      memcpy(&b.isize, src + b.coff + cdata + 4, 4);
       total += b.isize;
       blocks.push_back(b);
       pos += (size_t)bsize + 1;
     }
-    carry_.assign(comp.data() + pos, comp.data() + avail);
-    if (got == 0) {
-      c.eof = true;
-      file_eof_ = true;
-      if (!carry_.empty()) { c.err = "truncated BGZF block"; return c; }
+    if (map_) {
+      map_pos_ += pos;
+      if (pos == 0) {                       // nothing complete left: end of file (or a truncated last block)
+        c.eof = true;
+        file_eof_ = true;
+        if (map_pos_ < map_size_) { c.err = "truncated BGZF block"; return c; }
+      }
+    } else {
+      carry_.assign(src + pos, src + avail);
+      if (got == 0) {
+        c.eof = true;
+        file_eof_ = true;
+        if (!carry_.empty()) { c.err = "truncated BGZF block"; return c; }
+      }
     }
     release();
     c.data.alloc(total);
@@ -450,7 +480,7 @@ class BamReader {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) { errs[(size_t)t] = "zlib init failed"; return; }
-        zs.next_in = comp.data() + b.coff;
+        zs.next_in = const_cast<uint8_t*>(src + b.coff);
         zs.avail_in = (uInt)b.clen;
         zs.next_out = c.data.data() + b.uoff;
         zs.avail_out = b.isize;
@@ -480,6 +510,8 @@ class BamReader {
   uint64_t next_ticket_ = 0, n_launched_ = 0;
   bool file_eof_ = false;          // (guarded by file_m_)
   std::vector<uint8_t> carry_;     // partial block at the end of the previous read (guarded by file_m_)
+  const uint8_t* map_ = nullptr;   // the whole file, when it could be mapped
+  size_t map_size_ = 0, map_pos_ = 0;
   bool launched_eof_ = false;
   bool eof_seen_ = false;
   std::string err_;
