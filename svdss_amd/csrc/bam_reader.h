@@ -58,7 +58,7 @@ class BamReader {
   explicit BamReader(const std::string& path, int threads = 0) : f_(fopen(path.c_str(), "rb")) {
     if (f_) {   // regular files are mapped: blocks are inflated straight from the page cache, no read() copies
       struct stat st;
-      if (fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      if (!getenv("SVDSS_NO_MMAP") && fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
         void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f_), 0);
         if (m != MAP_FAILED) { map_ = (const uint8_t*)m; map_size_ = (size_t)st.st_size; (void)madvise(m, map_size_, MADV_SEQUENTIAL); }
       }

@@ -123,5 +123,12 @@ def test_smooth_output_does_not_depend_on_threads_and_spans_many_bgzf_chunks(tmp
         assert r.returncode == 0, r.stderr
         outs.append(out.read_bytes())
     assert outs[0] == outs[1] and len(outs[0]) > 0
+    # the read() path of the BGZF loader (pipes, or SVDSS_NO_MMAP) gives the same stream as the mapped file
+    out = tmp_path / "out_nommap.bam"
+    with open(out, "wb") as fh:
+        r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam), "--threads", "4"], stdout=fh,
+                           stderr=subprocess.PIPE, env=dict(os.environ, SVDSS_NO_MMAP="1"))
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == outs[0]
     names, lens, alns = bamio.read_bam(str(tmp_path / "out6.bam"))
     assert len(alns) == n_reads and names == ["c1"]
