@@ -229,10 +229,16 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(ref_total, n_reads, L, ix.kmer_k),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+                # measured HBM-side rate of the same kernel (traffic / kernel time) next to the spec peak
+                "traffic_gbs": (measured_traffic(ref_total, n_reads, L, ix.kmer_k) or 0) / (k_ms * 1e-3) / 1e9 or None,
+                "traffic_frac_of_peak": ((measured_traffic(ref_total, n_reads, L, ix.kmer_k) or 0) / (k_ms * 1e-3) / 1e9
+                                         / HBM_PEAK_GBS) or None,
                 "note": ("achieved = SURVEY 8(d) algorithmic bytes (one 64-B BWT block per rb3_fmd_extend the reference "
                          "would make) / search-kernel time; the k-mer table, text-compare and SET operations answer "
                          "most of those extensions without fetching their blocks, so frac exceeds 1 -- `traffic` "
-                         "is what really crosses the fabric and `random_access` the limit that binds"),
+                         "(TCC_EA0_RDREQ_128B x 128 B + writes: every random 16-B read moves a 128-B line) is what really "
+                         "crosses the fabric, `traffic_frac_of_peak` its share of the 8 TB/s peak, and `random_access` "
+                         "the limit that binds"),
                 "all_kernels_ms": float(np.mean(pipeline_ms)),
                 # the kernel's memory operations are dependent random reads (one per lane per iteration): the
                 # measured ceiling of that access pattern on this GPU (tools/random_read_probe.hip) next to the
