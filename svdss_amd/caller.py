@@ -168,23 +168,40 @@ def extract_svs(chrom, chrom_seq: str, cl_s: int, consensus: str, cigar_ops, sco
     return out
 
 
-def pcall_tail(subclusters, chromosomes: dict, min_sv_length: int = 25, threads: int = 4, device: int = 0):
+def consensus_sam_row(chrom: str, s: int, e: int, cigar: str, seq: str) -> str:
+    """operator<< of Consensus (caller.hpp:56-69): one SAM row of the --poa output."""
+    return f"{chrom}:{s + 1}-{e + 1}\t0\t{chrom}\t{s + 1}\t60\t{cigar}\t*\t0\t0\t{seq}\t*"
+
+
+def sam_text(contigs, rows) -> str:
+    """Caller::write_sam (caller.cpp:65-75)."""
+    return "@HD\tVN:1.4\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in contigs) + "".join(r + "\n" for r in rows)
+
+
+def pcall_tail(subclusters, chromosomes: dict, min_sv_length: int = 25, threads: int = 4, device: int = 0,
+               sam_rows: list = None):
     """Caller::pcall from the consensus on (caller.cpp:326-405) for a list of sub-clusters, each a
     dict(chrom, s, e, consensus, size, names, cov=(cov,cov0,cov1,cov2), rvec, cluster_index).
     All realignments go to the GPU in one batch.  Returns SVs in the order Caller::run leaves them
     before its sort (caller.cpp:18-22: per-thread vectors, cluster i on thread i % T, each inserted
-    at the FRONT)."""
+    at the FRONT).  sam_rows, if given, receives the --poa rows (caller.cpp:356-357) in that same order."""
     refs = [chromosomes[sc["chrom"]][sc["s"]:sc["e"] + 1] for sc in subclusters]   # caller.cpp:329
     cons = [sc["consensus"] for sc in subclusters]
     scores, cigars, stats = ksw_extd2_global(cons, refs, device=device)
     per_thread = [[] for _ in range(threads)]
+    per_thread_sam = [[] for _ in range(threads)]
     for sc, score, cg in zip(subclusters, scores.tolist(), cigars):
+        per_thread_sam[sc.get("cluster_index", 0) % threads].append(
+            consensus_sam_row(sc["chrom"], sc["s"], sc["e"], cigar_string(cg), sc["consensus"]))
         svs = extract_svs(sc["chrom"], chromosomes[sc["chrom"]], sc["s"], sc["consensus"], cg, score,
                           min_sv_length, sc["size"], sc["cov"], sc["names"], sc["rvec"])
         per_thread[sc.get("cluster_index", 0) % threads].extend(svs)
     out = []
     for t in range(threads):
         out = per_thread[t] + out
+    if sam_rows is not None:
+        for t in reversed(range(threads)):
+            sam_rows.extend(per_thread_sam[t])
     return out, stats
 
 
@@ -265,11 +282,11 @@ def vcf_header(contigs) -> str:
 
 
 def call_tail(subclusters, chromosomes: dict, contigs, min_sv_length: int = 25, threads: int = 4,
-              min_ratio: float = 0.97, device: int = 0) -> str:
+              min_ratio: float = 0.97, device: int = 0, sam_rows: list = None) -> str:
     """Caller::run from pcall's realignment to the VCF text (caller.cpp:17-29): realign, extract,
     sort, clean_dups, filter_sv_chains, sort, write.  std::sort's order among SVs with equal
     (chrom, POS) is unspecified in the reference (SURVEY App. A#8); a stable sort is used here."""
-    svs, _ = pcall_tail(subclusters, chromosomes, min_sv_length, threads, device)
+    svs, _ = pcall_tail(subclusters, chromosomes, min_sv_length, threads, device, sam_rows)
     svs.sort(key=SV.key)
     svs = clean_dups(svs)
     svs = filter_sv_chains(svs, min_ratio, device)
@@ -467,8 +484,8 @@ def run_poa(clusters: Sequence[Sequence], device: int = 0):
 def call(alignments, sfs_text: str, chromosomes: dict, contigs, ref_names, threads: int = 4,
          min_cluster_weight: int = 2, min_sv_length: int = 25, min_mapq: int = 20, useht: bool = True,
          min_ratio: float = 0.97, device: int = 0):
-    """Caller::run (caller.cpp:3-57) without --poa/--clipped side outputs: SFS file + alignments +
-    reference -> VCF text.  Host bookkeeping as in the reference; POA, realignment and the chain
+    """Caller::run (caller.cpp:3-57) without --clipped: SFS file + alignments + reference -> VCF text; the
+    --poa (SAM) and --clusters side outputs are returned as info["sam"] / info["clusters_text"].  Host bookkeeping as in the reference; POA, realignment and the chain
     filter's ratio run on the GPU in three batched calls.  Returns (vcf_text, info dict)."""
     from .clusterer import Clusterer
     from .pingpong import parse_sfsfile
@@ -487,7 +504,13 @@ def call(alignments, sfs_text: str, chromosomes: dict, contigs, ref_names, threa
     entries = [dict(chrom=cl.chrom, s=cl.s, e=cl.e, consensus=cons, size=cl.size(), names=cl.get_names(),
                     cov=(cl.cov, cl.cov0, cl.cov1, cl.cov2), rvec=parent.reads, cluster_index=i)
                for (i, cl, parent), cons in zip(subs, consensus)]
-    vcf = call_tail(entries, chromosomes, contigs, min_sv_length, threads, min_ratio, device)
-    info = {"clusters": len(clusters), "subclusters": len(subs), "extended_sfs": len(C_.extended_SFSs),
+    sam_rows = []
+    vcf = call_tail(entries, chromosomes, contigs, min_sv_length, threads, min_ratio, device, sam_rows)
+    # Clusterer::store_clusters (clusterer.cpp:613-626)
+    clusters_text = "".join(
+        f"{c.chrom}:{c.s + 1}-{c.e + 1}\t{c.size()}" + "".join(f"\t{sr.name}:{sr.seq}" for sr in c.subreads) + "\n"
+        for c in clusters)
+    info = {"sam": sam_text(contigs, sam_rows), "clusters_text": clusters_text,
+            "clusters": len(clusters), "subclusters": len(subs), "extended_sfs": len(C_.extended_SFSs),
             "unplaced": (C_.unplaced, C_.s_unplaced, C_.e_unplaced), "poa": poa_stats}
     return vcf, info

@@ -509,6 +509,21 @@ int main_call(const CallOptions& o) {
       } else ++C.small2;
     }
   }
+  // ---- store_clusters (clusterer.cpp:613-626): every cluster, also the filtered ones (their coordinates are
+  // uninitialised in the reference; 0 here)
+  if (!o.clusters.empty()) {
+    logmsg("info", "Storing clusters to " + o.clusters);
+    FILE* f = fopen(o.clusters.c_str(), "w");
+    if (!f) die("cannot write " + o.clusters);
+    std::string line;
+    for (const Cluster& c : clusters) {
+      line = c.chrom + ":" + std::to_string(c.s + 1) + "-" + std::to_string(c.e + 1) + "\t" + std::to_string(c.size());
+      for (const SubRead& sr : c.subreads) { line += "\t"; line += sr.name; line += ":"; line += sr.seq; }
+      line += "\n";
+      fwrite(line.data(), 1, line.size(), f);
+    }
+    fclose(f);
+  }
   logmsg("info", "Calling SVs from " + std::to_string(clusters.size()) + " clusters..");
   // ---- pcall (caller.cpp:311-406): split, then the three GPU batches
   struct Sub { size_t parent; Cluster cl; };
@@ -542,6 +557,7 @@ int main_call(const CallOptions& o) {
     }
   }
   std::vector<SV> svs;
+  std::vector<std::vector<std::string>> sam_rows;   // per reference thread, --poa only
   if (!subs.empty()) {
     const int8_t a = 1, b = -9;   // caller.cpp:333-337
     const int8_t mat[25] = {a, b, b, b, 0, b, a, b, b, 0, b, b, a, b, 0, b, b, b, a, 0, 0, 0, 0, 0, 0};
@@ -564,6 +580,7 @@ int main_call(const CallOptions& o) {
     check(svdss_aln_batch_fetch(ab, scores.data(), ncig.data(), cig.data()), "svdss_aln_batch_fetch");
     svdss_aln_batch_free(ab);
     std::vector<std::vector<SV>> per_thread((size_t)T);
+    sam_rows.resize((size_t)T);
     size_t cp = 0;
     for (size_t i = 0; i < subs.size(); ++i) {
       const Cluster& cl = subs[i].cl;
@@ -571,6 +588,11 @@ int main_call(const CallOptions& o) {
       const std::string& cs = C.chrom_seqs[cl.chrom];
       std::string cigar_str;
       for (int64_t k = 0; k < ncig[i]; ++k) cigar_str += std::to_string(cig[cp + (size_t)k] >> 4) + "MID"[cig[cp + (size_t)k] & 0xf];
+      if (!o.poa.empty()) {   // Consensus, caller.hpp:56-69 / caller.cpp:356-357
+        const std::string p1 = std::to_string(cl.s + 1);
+        sam_rows[subs[i].parent % (size_t)T].push_back(cl.chrom + ":" + p1 + "-" + std::to_string(cl.e + 1) + "\t0\t" + cl.chrom +
+                                                       "\t" + p1 + "\t60\t" + cigar_str + "\t*\t0\t0\t" + consensus[i] + "\t*");
+      }
       std::string names;
       for (const SubRead& sr : cl.subreads) names += sr.name + ",";
       if (!names.empty()) names.pop_back();
@@ -680,5 +702,18 @@ int main_call(const CallOptions& o) {
   fwrite(out.data(), 1, out.size(), stdout);
   fflush(stdout);
   logmsg("info", "Writing " + std::to_string(svs.size()) + " SVs.");
+  // ---- write_sam (caller.cpp:65-75): rows in the order of the reference's per-thread lists, each inserted at the
+  // front of the global one (caller.cpp:18-22)
+  if (!o.poa.empty()) {
+    logmsg("info", "Writing POA alignments to " + o.poa + "..");
+    FILE* f = fopen(o.poa.c_str(), "w");
+    if (!f) die("cannot write " + o.poa);
+    std::string hdr = "@HD\tVN:1.4\n";
+    for (const std::string& n : C.chrom_names) hdr += "@SQ\tSN:" + n + "\tLN:" + std::to_string(C.chrom_seqs[n].size()) + "\n";
+    fwrite(hdr.data(), 1, hdr.size(), f);
+    for (size_t t = sam_rows.size(); t-- > 0;)
+      for (const std::string& row : sam_rows[t]) { fwrite(row.data(), 1, row.size(), f); fputc('\n', f); }
+    fclose(f);
+  }
   return 0;
 }

@@ -11,6 +11,8 @@ struct CallOptions {
   bool useht = true;
   float min_ratio = 0.97f;
   float accp = 0.98f;          // smooth only
+  std::string poa;             // --poa <FILE>: consensus alignments as SAM (caller.cpp:65-75)
+  std::string clusters;        // --clusters <FILE>: the filled clusters (clusterer.cpp:613-626)
 };
 
 int main_call(const CallOptions& o);

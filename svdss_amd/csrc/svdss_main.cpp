@@ -49,6 +49,9 @@ static const char* CALL_USAGE =
     "      --min-cluster-weight <int>  minimum number of supporting superstrings for a call (default: 2)\n"
     "      --min-sv-length <int>       minimum length of reported SVs (default: 25, values < 25 ignored)\n"
     "      --min-mapq <int>            minimum mapping quality (default: 20)\n"
+    "      --poa <FILE>                store POA consensus alignments in .sam format to this file\n"
+    "      --clusters <FILE>           store clusters to this file\n"
+    "      -l <float>                  minimum length ratio for sub-clusters and chain merging (default: 0.97)\n"
     "      --noht                      ignore the HP tag\n";
 
 static const char* SEARCH_USAGE =
@@ -78,7 +81,7 @@ static void check(int rc, const char* what) {
 static const char NT16[] = "=ACMGRSVTWYHKDBN";
 
 struct Options {
-  std::string index, bam, fastx, reference, sfs;
+  std::string index, bam, fastx, reference, sfs, poa, clusters;
   int min_sv_length = 25, min_mapq = 20, min_cluster_weight = 2;   // config.hpp:92-96
   float accp = 0.98f, min_ratio = 0.97f;
   bool useht = true;
@@ -110,6 +113,8 @@ static Options parse(int argc, char** argv) {
     else if (take(argc, argv, i, "--omax", v)) o.omax = atoi(v.c_str());
     else if (take(argc, argv, i, "--reference", v)) o.reference = v;
     else if (take(argc, argv, i, "--sfs", v)) o.sfs = v;
+    else if (take(argc, argv, i, "--poa", v)) o.poa = v;            // config.cpp:65-68
+    else if (take(argc, argv, i, "--clusters", v)) o.clusters = v;
     else if (take(argc, argv, i, "--min-sv-length", v)) o.min_sv_length = std::max(25, atoi(v.c_str()));  // config.cpp:87
     else if (take(argc, argv, i, "--min-cluster-weight", v)) o.min_cluster_weight = atoi(v.c_str());
     else if (take(argc, argv, i, "--min-mapq", v)) o.min_mapq = atoi(v.c_str());
@@ -467,7 +472,7 @@ int main(int argc, char** argv) {
       CallOptions c;
       c.reference = o.reference; c.bam = o.bam; c.sfs = o.sfs; c.threads = o.threads;
       c.min_cluster_weight = o.min_cluster_weight; c.min_sv_length = o.min_sv_length; c.min_mapq = o.min_mapq;
-      c.useht = o.useht; c.min_ratio = o.min_ratio;
+      c.useht = o.useht; c.min_ratio = o.min_ratio; c.poa = o.poa; c.clusters = o.clusters;
       main_call(c);
     } else if (!strcmp(argv[1], "smooth")) {
       if (o.reference.empty() || o.bam.empty()) { fputs(SMOOTH_USAGE, stderr); return EXIT_FAILURE; }   // main.cpp:73-76

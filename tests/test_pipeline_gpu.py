@@ -62,9 +62,20 @@ def test_index_search_call_recovers_implanted_svs(tmp_path, het):
     sfs_path = tmp_path / "specifics.txt"
     sfs_path.write_text(sfs_text)
     r = subprocess.run([BIN, "call", "--reference", str(fa), "--bam", str(bam), "--sfs", str(sfs_path), "--threads", "4",
-                        "--min-sv-length", "50"], capture_output=True, text=True)
+                        "--min-sv-length", "50", "--poa", str(tmp_path / "poa.sam"), "--clusters", str(tmp_path / "clusters.txt")],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout == vcf
+    # side outputs (caller.cpp:65-75, clusterer.cpp:613-626)
+    sam = (tmp_path / "poa.sam").read_text()
+    assert sam == info["sam"]
+    rows = [l.split("\t") for l in sam.splitlines() if not l.startswith("@")]
+    assert len(rows) == info["subclusters"] and all(len(f) == 11 and f[1] == "0" and f[4] == "60" for f in rows)
+    for f in rows:   # the CIGAR consumes the whole consensus
+        import re
+        assert sum(int(n) for n, op in re.findall(r"(\d+)([MID])", f[5]) if op in "MI") == len(f[9])
+    cl_text = (tmp_path / "clusters.txt").read_text()
+    assert cl_text == info["clusters_text"] and len(cl_text.splitlines()) == info["clusters"]
 
 
 def test_run_svdss_chain_with_raw_reads(tmp_path):
