@@ -427,6 +427,8 @@ __global__ void __launch_bounds__(256) sfs_order_scatter_kernel(int64_t n_reads,
   order[heavy[r] ? before : n_heavy + (r - before)] = r;
 }
 
+typedef uint32_t sv_u32x4 __attribute__((ext_vector_type(4)));
+
 #ifdef SV_COUNT_ITERS
 __device__ unsigned long long g_sfs_iters[48];   // [0] wave iterations, [1] lane ops, [2+op] lane ops by type
 #endif
@@ -446,6 +448,8 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
   const uint8_t* reads = (const uint8_t*)p.chunks;
   const uint8_t* blocks = (const uint8_t*)p.ix.blocks;
 
+  __shared__ uint32_t stash_lds[SEG ? 3 * 256 : 1];   // SEG: a record waiting for its pair (qs, l, ext_at_begin)
+  uint32_t* stash = &stash_lds[SEG ? threadIdx.x : 0];
   auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
     if (idx < cap) {
       if (SEG)   // ext_at_begin: the forward phase of this SFS made pos - begin of the extensions
@@ -453,15 +457,18 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
         const uint32_t ext_at_begin = (uint32_t)(st.n_ext - (st.pos - st.begin));
         if (idx < SV_PEEK_VISIBLE) {
           // the first records of a segment are the ones its right neighbour peeks at (it synchronises on the first
-          // SFS below the boundary): two 8-byte agent-scope (write-through) stores, visible to lanes on other XCDs
-          unsigned long long* rp = (unsigned long long*)(p.seg_rec + (base + idx));
-          __hip_atomic_store(rp, (unsigned long long)(uint32_t)qs | ((unsigned long long)(uint32_t)l << 32),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(rp + 1, (unsigned long long)ext_at_begin | ((unsigned long long)p.epoch << 32),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // SFS below the boundary): one 16-byte agent-scope (write-through) store, visible to lanes on other XCDs
+          // (a torn or late view only lengthens the neighbour's overrun or sends the read to the exact fallback)
+          const sv_u32x4 v = {(uint32_t)qs, (uint32_t)l, ext_at_begin, p.epoch};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p.seg_rec + (base + idx)), "v"(v) : "memory");
+        } else if ((((base + idx) & 1) == 0)) {
+          // the rest is only read after the launch (stitch / assemble).  A 16-byte record written on its own is one
+          // 32-byte memory transaction (the line leaves L2 long before the lane's next record): records wait in LDS
+          // for their odd neighbour and the pair is stored back to back
+          stash[0] = (uint32_t)qs; stash[256] = (uint32_t)l; stash[512] = ext_at_begin;
         } else {
-          // the rest is only read after the launch (stitch / assemble): plain stores, merged into full lines by L2
-          // instead of one 32-byte memory transaction per 8 bytes
+          if (idx > SV_PEEK_VISIBLE)
+            p.seg_rec[base + idx - 1] = make_uint4(stash[0], stash[256], stash[512], p.epoch);
           p.seg_rec[base + idx] = make_uint4((uint32_t)qs, (uint32_t)l, ext_at_begin, p.epoch);
         }
       }
@@ -559,6 +566,11 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
 #endif
     if (o.op == SV_OP_DONE) {
       if (SEG) {
+        {   // a record still waiting for its pair
+          const int32_t last = (st.n_sfs < (int32_t)cap ? st.n_sfs : (int32_t)cap) - 1;
+          if (last >= SV_PEEK_VISIBLE && ((base + last) & 1) == 0)
+            p.seg_rec[base + last] = make_uint4(stash[0], stash[256], stash[512], p.epoch);
+        }
         SvSegInfo z;
         z.n_rec = st.n_sfs; z.cap = (int32_t)cap; z.ext_total = st.n_ext;
         z.complete = (st.mode & SV_M_PARTIAL) ? 0 : 1;
