@@ -105,11 +105,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # SVDSS_BENCH_BACKEND=gloo: developer check of the N>1 code path on a box with fewer GPUs than ranks (the ranks
+    # then share GPUs; RCCL refuses that).  The driver's runs use the default, RCCL, one rank per GPU.
+    backend = os.environ.get("SVDSS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import svdss_amd
     from svdss_amd import multi, synth
@@ -242,7 +250,7 @@ def main():
                 "all_kernels_ms": float(np.mean(pipeline_ms)),
                 # the kernel's memory operations are dependent random reads (one per lane per iteration): the
                 # measured ceiling of that access pattern on this GPU (tools/random_read_probe.hip) next to the
-                # rate at which the kernel's measured traffic arrives, both in 64-B lines per second
+                # rate at which the kernel's measured traffic arrives, both in memory requests (128-B lines) per second
                 "random_access": random_access_info(measured_traffic(ref_total, n_reads, L, ix.kmer_k, "_transactions"),
                                                     measured_traffic(ref_total, n_reads, L, ix.kmer_k, "_read_transactions"), k_ms),
             },
