@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -316,6 +317,13 @@ int main_call(const CallOptions& o) {
   Ctx C;
   C.o = o;
   const int T = std::max(1, o.threads);
+  auto t_last = std::chrono::steady_clock::now();
+  auto stage = [&](const char* what) {   // --verbose: seconds since the previous stage mark
+    if (!o.verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[call] [time] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   // ---- load_chromosomes (chromosomes.cpp:9-27): upper-cased, FASTA order
   {
     FastxReader fx(o.reference);
@@ -341,6 +349,7 @@ int main_call(const CallOptions& o) {
       fclose(f);
     }
   }
+  stage("reference + sfs file");
   logmsg("info", "Placing SFSs on reference genome");
   // ---- align_and_extend (clusterer.cpp:56-156): pass 1 over the BAM
   std::vector<std::string> ref_names;
@@ -391,6 +400,7 @@ int main_call(const CallOptions& o) {
     }
     for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
   }
+  stage("pass 1: placement");
   // ---- cluster_by_proximity (clusterer.cpp:407-474)
   std::vector<Cluster> clusters;
   if (!extended.empty()) {
@@ -432,6 +442,7 @@ int main_call(const CallOptions& o) {
         clusters.push_back(std::move(c));
       }
   }
+  stage("cluster_by_proximity");
   // ---- fill_clusters (clusterer.cpp:477-610): pass 2 over the BAM
   {
     std::vector<std::set<std::string>> reads(clusters.size());
@@ -457,47 +468,80 @@ int main_call(const CallOptions& o) {
     }
     BamReader bam(o.bam);
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
-    BamRecord r;
     BamReader::Arena arena;
     BamReader::RawRec rr;
     int rc;
-    while (arena.clear(), (rc = bam.next_raw(arena, rr)) > 0) {
-      if (rr.tid < 0 || rr.tid >= (int)ref_names.size()) continue;
-      auto it = by_chrom.find(ref_names[(size_t)rr.tid]);
+    // per reference id: the clusters of that chromosome (sorted by start) and the running maximum of their ends
+    std::vector<const std::vector<size_t>*> tid_clusters(ref_names.size(), nullptr);
+    std::vector<const std::vector<int>*> tid_run_max(ref_names.size(), nullptr);
+    for (size_t t = 0; t < ref_names.size(); ++t) {
+      auto it = by_chrom.find(ref_names[t]);
       if (it == by_chrom.end()) continue;
-      BamReader::materialize(arena, rr, r, false);   // (the bases are decoded only for reads that join a cluster)
-      const int a_beg = r.pos, a_end = r.endpos();
-      Pairs al;
-      std::string seq;
+      tid_clusters[t] = &it->second;
+      tid_run_max[t] = &run_max_end[it->first];
+    }
+    static const char NT16[] = "=ACMGRSVTWYHKDBN";
+    std::string qname;
+    // Records stay in their raw form: the end position and the two query positions the reference reads off the
+    // aligned-pairs vector (bam.cpp:92-134, clusterer.cpp:555-580) are functions of the CIGAR blocks alone, and only
+    // the bases of the extracted sub-read are decoded.
+    while (arena.clear(), (rc = bam.next_raw(arena, rr)) > 0) {
+      if (rr.tid < 0 || rr.tid >= (int)ref_names.size() || !tid_clusters[(size_t)rr.tid]) continue;
+      if (rr.flag & (4 | 2048 | 256)) continue;      // clusterer.cpp:535-540: such a record touches no cluster
+      if ((int)rr.mapq < o.min_mapq) continue;
+      const uint8_t* cg = arena.data() + rr.off + rr.l_name;
+      auto cig = [&](uint32_t i) { uint32_t c; memcpy(&c, cg + 4u * i, 4); return c; };
+      int32_t ref_len = 0;
+      for (uint32_t i = 0; i < rr.n_cigar; ++i) {
+        const uint32_t c = cig(i), op = c & 0xf;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += (int32_t)(c >> 4);
+      }
+      const int a_beg = rr.pos, a_end = rr.pos + (ref_len ? ref_len : 1);   // bam_endpos
+      const std::vector<size_t>& cl_ids = *tid_clusters[(size_t)rr.tid];
       // clusters before `first` end at or before the alignment's start: none of them can overlap it
-      const std::vector<int>& rm = run_max_end[it->first];
+      const std::vector<int>& rm = *tid_run_max[(size_t)rr.tid];
       const size_t first = (size_t)(std::upper_bound(rm.begin(), rm.end(), a_beg) - rm.begin());
-      for (size_t k = first; k < it->second.size(); ++k) {
-        const size_t ci = it->second[k];
+      bool have_tags = false;
+      int64_t hp = 0;
+      for (size_t k = first; k < cl_ids.size(); ++k) {
+        const size_t ci = cl_ids[k];
         // region "chrom:min_s-max_e" = 0-based half-open [min_s-1, max_e)
         const int beg0 = std::max(min_s[ci] - 1, 0), end0 = max_e[ci];
         if (beg0 >= a_end) break;   // clusters are sorted by start
         if (!(a_beg < end0 && a_end > beg0)) continue;
-        if (r.flag & (4 | 2048 | 256)) continue;
-        if ((int)r.mapq < o.min_mapq) continue;
-        int64_t hp = 0;
-        BamReader::aux_int(r, "HP", hp);
+        if (!have_tags) {
+          have_tags = true;
+          BamReader::aux_int(arena.data() + rr.aux_off(), rr.l_aux, "HP", hp);
+          qname.assign((const char*)arena.data() + rr.name_off(), rr.l_name ? rr.l_name - 1 : 0);
+        }
         if (hp >= 0 && hp < 3) ++cov[ci][(size_t)hp];
         clusters[ci].reads.emplace_back(0, hp == 0 ? 3 : (int)hp);
-        if (reads[ci].find(r.qname) == reads[ci].end()) continue;
+        if (reads[ci].find(qname) == reads[ci].end()) continue;
         clusters[ci].reads.back().first = 1;
-        if (al.empty()) { al = get_aligned_pairs(r); BamReader::materialize_seq(arena, rr, r); seq = r.seq_string(); }
-        int qs = -1, qe = -1;
-        for (int i = (int)al.size() - 1; i >= 0; --i) {
-          if (al[(size_t)i].first == -1 || al[(size_t)i].second == -1) continue;
-          if (al[(size_t)i].second <= min_s[ci]) { qs = al[(size_t)i].first; break; }
-        }
-        for (size_t i = 0; i < al.size(); ++i) {
-          if (al[i].first == -1 || al[i].second == -1) continue;
-          if (al[i].second >= max_e[ci]) { qe = al[i].first; break; }
+        // qs: query position of the last aligned (M/=/X) pair with reference position <= min_s;
+        // qe: of the first one with reference position >= max_e
+        int qs = -1, qe = -1, ref_pos = rr.pos, read_pos = 0;
+        for (uint32_t i = 0; i < rr.n_cigar; ++i) {
+          const uint32_t c = cig(i), op = c & 0xf;
+          const int l = (int)(c >> 4);
+          if (op == 0 || op == 7 || op == 8) {
+            if (l > 0) {
+              if (ref_pos <= min_s[ci]) qs = read_pos + (std::min(min_s[ci], ref_pos + l - 1) - ref_pos);
+              if (qe == -1 && ref_pos + l - 1 >= max_e[ci]) qe = read_pos + (std::max(max_e[ci], ref_pos) - ref_pos);
+            }
+            read_pos += l; ref_pos += l;
+          } else if (op == 1 || op == 4) read_pos += l;
+          else if (op == 2 || op == 3) ref_pos += l;
         }
         if (qs == -1 || qe == -1) ++C.unextended;
-        else clusters[ci].subreads.push_back(SubRead{r.qname, seq.substr((size_t)qs, (size_t)(qe - qs + 1)), (int)hp});
+        else {
+          if (qs > rr.l_seq) throw std::out_of_range("sub-read start past the end of the read");   // std::string::substr
+          const int n = std::max(0, std::min(qe - qs + 1, rr.l_seq - qs));
+          const uint8_t* sq = arena.data() + rr.seq_off();
+          std::string sub((size_t)n, 'N');
+          for (int i = 0; i < n; ++i) { const int q = qs + i; sub[(size_t)i] = NT16[(sq[q >> 1] >> ((~q & 1) << 2)) & 0xf]; }
+          clusters[ci].subreads.push_back(SubRead{qname, std::move(sub), (int)hp});
+        }
       }
     }
     if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
@@ -509,6 +553,7 @@ int main_call(const CallOptions& o) {
       } else ++C.small2;
     }
   }
+  stage("pass 2: fill_clusters");
   // ---- store_clusters (clusterer.cpp:613-626): every cluster, also the filtered ones (their coordinates are
   // uninitialised in the reference; 0 here)
   if (!o.clusters.empty()) {
@@ -532,6 +577,7 @@ int main_call(const CallOptions& o) {
     if ((int)clusters[i].size() < o.min_cluster_weight) continue;
     for (Cluster& cl : split_cluster(clusters[i], o.useht, o.min_ratio)) subs.push_back(Sub{i, std::move(cl)});
   }
+  stage("split_cluster");
   std::vector<std::string> consensus(subs.size());
   if (!subs.empty()) {
     std::vector<uint8_t> flat;
@@ -556,6 +602,7 @@ int main_call(const CallOptions& o) {
       for (int64_t k = 0; k < lens[i]; ++k) consensus[i][(size_t)k] = "ACGTN"[cons[p++]];   // caller.cpp:297
     }
   }
+  stage("POA");
   std::vector<SV> svs;
   std::vector<std::vector<std::string>> sam_rows;   // per reference thread, --poa only
   if (!subs.empty()) {
@@ -637,6 +684,7 @@ int main_call(const CallOptions& o) {
     }
     for (int t = 0; t < T; ++t) svs.insert(svs.begin(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());   // caller.cpp:18-22
   }
+  stage("realign + SV extraction");
   std::sort(svs.begin(), svs.end());   // same libstdc++ std::sort as the reference (caller.cpp:23)
   {   // clean_dups (caller.cpp:409-426)
     std::vector<SV> kept;
@@ -689,6 +737,7 @@ int main_call(const CallOptions& o) {
     svs.swap(kept);
   }
   std::sort(svs.begin(), svs.end());
+  stage("dups + chain filter");
   // ---- write_vcf (caller.cpp:59-63, 477-550)
   std::string out = "##fileformat=VCFv4.2\n##reference=ftp://ftp.1000genomes.ebi.ac.uk/vol1/ftp/data_collections/HGSVC2/"
                     "technical/reference/20200513_hg38_NoALT/hg38.no_alt.fa.gz\n";
@@ -702,6 +751,7 @@ int main_call(const CallOptions& o) {
   fwrite(out.data(), 1, out.size(), stdout);
   fflush(stdout);
   logmsg("info", "Writing " + std::to_string(svs.size()) + " SVs.");
+  stage("vcf");
   // ---- write_sam (caller.cpp:65-75): rows in the order of the reference's per-thread lists, each inserted at the
   // front of the global one (caller.cpp:18-22)
   if (!o.poa.empty()) {

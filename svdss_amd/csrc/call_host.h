@@ -11,6 +11,7 @@ struct CallOptions {
   bool useht = true;
   float min_ratio = 0.97f;
   float accp = 0.98f;          // smooth only
+  bool verbose = false;         // stage timings on stderr
   std::string poa;             // --poa <FILE>: consensus alignments as SAM (caller.cpp:65-75)
   std::string clusters;        // --clusters <FILE>: the filled clusters (clusterer.cpp:613-626)
 };

@@ -472,7 +472,7 @@ int main(int argc, char** argv) {
       CallOptions c;
       c.reference = o.reference; c.bam = o.bam; c.sfs = o.sfs; c.threads = o.threads;
       c.min_cluster_weight = o.min_cluster_weight; c.min_sv_length = o.min_sv_length; c.min_mapq = o.min_mapq;
-      c.useht = o.useht; c.min_ratio = o.min_ratio; c.poa = o.poa; c.clusters = o.clusters;
+      c.useht = o.useht; c.min_ratio = o.min_ratio; c.poa = o.poa; c.clusters = o.clusters; c.verbose = o.verbose;
       main_call(c);
     } else if (!strcmp(argv[1], "smooth")) {
       if (o.reference.empty() || o.bam.empty()) { fputs(SMOOTH_USAGE, stderr); return EXIT_FAILURE; }   // main.cpp:73-76
