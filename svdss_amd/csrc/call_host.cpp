@@ -360,11 +360,15 @@ int main_call(const CallOptions& o) {
     ref_names = bam.ref_names();
     const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
     std::vector<std::vector<ESFS>> per_thread((size_t)T);
-    std::vector<BamRecord> batch;
+    // two batches: the next one is read (inflate + slicing, this thread) while the T slices of the previous one run
+    std::vector<BamRecord> batches[2];
+    std::thread worker;
+    int cur = 0;
     BamReader::Arena arena;
     std::string qname;
     bool eof = false;
     while (!eof) {
+      std::vector<BamRecord>& batch = batches[cur];
       batch.clear();
       while ((int)batch.size() < bsize) {
         // records are sliced out of the stream and only decoded if the read has SFS at all
@@ -372,7 +376,7 @@ int main_call(const CallOptions& o) {
         BamReader::RawRec rr;
         const int rc = bam.next_raw(arena, rr);
         if (rc == 0) { eof = true; break; }
-        if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
+        if (rc < 0) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": " + bam.error()); }
         if (rr.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
         if ((int)rr.mapq < o.min_mapq) continue;
         qname.assign((const char*)arena.data() + rr.name_off(), rr.l_name ? rr.l_name - 1 : 0);
@@ -381,23 +385,28 @@ int main_call(const CallOptions& o) {
         BamReader::materialize(arena, rr, r);
         batch.push_back(std::move(r));
       }
+      if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
       // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
       // the same order per slice
-      auto slice = [&](int t) {
-        for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
-          const BamRecord& r = batch[n];
-          if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
-          extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t]);
+      worker = std::thread([&C, &ref_names, &per_thread, &batch, T]() {
+        auto slice = [&](int t) {
+          for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
+            const BamRecord& r = batch[n];
+            if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
+            extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t]);
+          }
+        };
+        if (T == 1 || batch.size() < 64) { for (int t = 0; t < T; ++t) slice(t); }
+        else {
+          std::vector<std::thread> pool;
+          for (int t = 1; t < T; ++t) pool.emplace_back(slice, t);
+          slice(0);
+          for (std::thread& th : pool) th.join();
         }
-      };
-      if (T == 1 || batch.size() < 64) { for (int t = 0; t < T; ++t) slice(t); }
-      else {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < T; ++t) pool.emplace_back(slice, t);
-        slice(0);
-        for (std::thread& th : pool) th.join();
-      }
+      });
+      cur ^= 1;
     }
+    if (worker.joinable()) worker.join();
     for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
   }
   stage("pass 1: placement");
@@ -468,8 +477,7 @@ int main_call(const CallOptions& o) {
     }
     BamReader bam(o.bam);
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
-    BamReader::Arena arena;
-    BamReader::RawRec rr;
+    BamReader::RawView rr;   // zero-copy: the record is used where it was inflated, within this iteration only
     int rc;
     // per reference id: the clusters of that chromosome (sorted by start) and the running maximum of their ends
     std::vector<const std::vector<size_t>*> tid_clusters(ref_names.size(), nullptr);
@@ -485,11 +493,11 @@ int main_call(const CallOptions& o) {
     // Records stay in their raw form: the end position and the two query positions the reference reads off the
     // aligned-pairs vector (bam.cpp:92-134, clusterer.cpp:555-580) are functions of the CIGAR blocks alone, and only
     // the bases of the extracted sub-read are decoded.
-    while (arena.clear(), (rc = bam.next_raw(arena, rr)) > 0) {
+    while ((rc = bam.next_view(rr)) > 0) {
       if (rr.tid < 0 || rr.tid >= (int)ref_names.size() || !tid_clusters[(size_t)rr.tid]) continue;
       if (rr.flag & (4 | 2048 | 256)) continue;      // clusterer.cpp:535-540: such a record touches no cluster
       if ((int)rr.mapq < o.min_mapq) continue;
-      const uint8_t* cg = arena.data() + rr.off + rr.l_name;
+      const uint8_t* cg = rr.name() + rr.l_name;
       auto cig = [&](uint32_t i) { uint32_t c; memcpy(&c, cg + 4u * i, 4); return c; };
       int32_t ref_len = 0;
       for (uint32_t i = 0; i < rr.n_cigar; ++i) {
@@ -511,8 +519,8 @@ int main_call(const CallOptions& o) {
         if (!(a_beg < end0 && a_end > beg0)) continue;
         if (!have_tags) {
           have_tags = true;
-          BamReader::aux_int(arena.data() + rr.aux_off(), rr.l_aux, "HP", hp);
-          qname.assign((const char*)arena.data() + rr.name_off(), rr.l_name ? rr.l_name - 1 : 0);
+          BamReader::aux_int(rr.aux(), rr.l_aux, "HP", hp);
+          qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
         }
         if (hp >= 0 && hp < 3) ++cov[ci][(size_t)hp];
         clusters[ci].reads.emplace_back(0, hp == 0 ? 3 : (int)hp);
@@ -537,7 +545,7 @@ int main_call(const CallOptions& o) {
         else {
           if (qs > rr.l_seq) throw std::out_of_range("sub-read start past the end of the read");   // std::string::substr
           const int n = std::max(0, std::min(qe - qs + 1, rr.l_seq - qs));
-          const uint8_t* sq = arena.data() + rr.seq_off();
+          const uint8_t* sq = rr.seq4();
           std::string sub((size_t)n, 'N');
           for (int i = 0; i < n; ++i) { const int q = qs + i; sub[(size_t)i] = NT16[(sq[q >> 1] >> ((~q & 1) << 2)) & 0xf]; }
           clusters[ci].subreads.push_back(SubRead{qname, std::move(sub), (int)hp});
