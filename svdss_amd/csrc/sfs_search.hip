@@ -1109,8 +1109,8 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
 #ifdef SV_COUNT_ITERS
         unsigned long long h[48];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess)
-          fprintf(stderr, "[svdss] wave-iterations %llu; lane ops: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu\n",
-                  h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+          fprintf(stderr, "[svdss] wave-iterations %llu; lane ops: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu "
+                  "PEEK %llu SA_SET %llu SET %llu\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
         fprintf(stderr, "[svdss] items by ops (2^k .. 2^(k+1)-1, k=4..15):");
         for (int k = 4; k < 16; ++k) fprintf(stderr, " %llu", h[16 + k]);
         fprintf(stderr, "\n");
