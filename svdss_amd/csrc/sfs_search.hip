@@ -1085,8 +1085,11 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       p.seg_shift = __builtin_ctz((unsigned)n_seg);
       p.n_items = n_reads * n_seg;
       HIPCHK(hipEventRecord(b->ek0, stream));
-      if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true>), dim3(blocks_for(p.n_items)), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true>), dim3(blocks_for(p.n_items)), dim3(256), 0, stream, p);
+      // SVDSS_EXTRA_LDS (developer knob): unused dynamic LDS per block, to study the kernel at lower occupancy
+      const char* xl = getenv("SVDSS_EXTRA_LDS");
+      const size_t extra_lds = xl ? (size_t)atol(xl) : 0;
+      if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
+      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(b->ek1, stream));
       hipLaunchKernelGGL(sfs_stitch_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, p);
