@@ -39,7 +39,9 @@ struct __attribute__((aligned(16))) svdss_u4 { uint32_t x, y, z, w; };  // == ui
 // k-mer table entry (16 B): the state of a phase of ping_pong_search after its
 // first K symbols, for every ACGT K-mer W (key = sum W[i] << 2i, text order).
 //   info >> 62 == SVDSS_TAB_EMPTY  : W absent; info & 0xff = d = number of symbols
-//                                    (taken from the END of W) that still occur
+//                                    (taken from the END of W) that still occur; (info >> 8) & 0xff = df =
+//                                    how many leading symbols of the d + 1 that do not occur together still
+//                                    do (outcome of the forward phase that follows, 0 = not recorded)
 //   info >> 62 == SVDSS_TAB_UNIQUE : one occurrence; lo = SA index, info & MASK = text position
 //   info >> 62 == SVDSS_TAB_MULTI  : lo = SA index of the interval, info & MASK = size (>= 2)
 struct __attribute__((aligned(16))) SvdssTabEntry { uint64_t lo, info; };

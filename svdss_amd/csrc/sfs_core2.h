@@ -344,6 +344,16 @@ SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_l
     s.n_ext += d;
     s.lo = 0;
     s.hi = 0;
+    const int df = (int)((val >> 8) & 0xff);
+    if (!dir && df > 0) {
+      // The forward phase that follows (ping_pong.cpp:28-37) starts at the symbol that emptied the interval and
+      // cannot get past the d + 1 symbols that just failed to occur together -- all of them inside this K-mer:
+      // its outcome (df leading symbols occur) was computed with the entry, no second lookup.
+      s.begin = s.pos;                    // :28
+      s.pos = s.begin + df;               // set_intv + df extends, the last one emptied the interval
+      s.n_ext += df;
+      s.mode = (s.mode & ~SV_LFC_MASK) | SV_M_DIR;
+    }
     return;
   }
   s.pos = dir ? s.pos + (K - 1) : s.pos - (K - 1);
@@ -564,8 +574,29 @@ SVDSS_HD void sv_table_entry(const SvdssDevIndex& ix, uint32_t key, int K, uint6
     else
       e_info = (SVDSS_TAB_MULTI << 62) | size;
   } else {
+    // W[K-1-d .. K-1] (d + 1 symbols) does not occur: how many of its leading symbols do -- the forward phase the
+    // reference starts at W[K-1-d] (interval of revcomp, extended with complemented symbols, ping_pong.cpp:30-37)
+    int df = 0;
+    if (d >= 1) {
+      int cc = svdss_comp((int)((key >> (2 * (K - 1 - d))) & 3u) + 1);
+      int64_t flo = svdss_acc(ix, cc), fhi = svdss_acc(ix, cc + 1);
+      if (fhi > flo) {
+        df = 1;
+        for (int i = K - d; i <= K - 1; ++i) {
+          cc = svdss_comp((int)((key >> (2 * i)) & 3u) + 1);
+          const int64_t a = svdss_acc(ix, cc);
+          const int64_t nlo = a + svdss_rank_in_block(ix, ix.blocks + 4 * (flo >> SVDSS_BLOCK_SHIFT), cc, flo);
+          const int64_t nhi = a + svdss_rank_in_block(ix, ix.blocks + 4 * (fhi >> SVDSS_BLOCK_SHIFT), cc, fhi);
+          flo = nlo;
+          fhi = nhi;
+          if (fhi <= flo) break;
+          ++df;
+        }
+      }
+    }
+    if (df > d) df = 0;   // (cannot happen with both strands indexed; no shortcut then)
     e_lo = 0;
-    e_info = (SVDSS_TAB_EMPTY << 62) | (uint64_t)d;
+    e_info = (SVDSS_TAB_EMPTY << 62) | (uint64_t)d | ((uint64_t)df << 8);
   }
 }
 
