@@ -39,6 +39,18 @@ def search(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool):
 
 _lib.emu_search2.restype = _i64
 _lib.emu_search2.argtypes = [_p, _p, _p, _i64, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _p, _p, C.c_int, _p]
+_lib.emu_table.restype = C.c_int
+_lib.emu_table.argtypes = [_p, C.c_int, _p, _p]
+
+
+def kmer_table(index, K: int):
+    """(lo, info) arrays of the 4^K entries the kernel's table builder (sv_table_entry) produces."""
+    lo = np.zeros(1 << (2 * K), dtype=np.uint64)
+    info = np.zeros(1 << (2 * K), dtype=np.uint64)
+    assert _lib.emu_table(index._h, K, lo.ctypes.data, info.ctypes.data) == 0
+    return lo, info
+
+
 OP_NAMES = ["DONE", "LF", "TABLE", "SA", "TEXT", "FILL", "TEXT_SLOW", "PEEK", "SA_SET", "SET"]
 
 

@@ -226,6 +226,26 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
 }
 }  // namespace
 
+// the k-mer table of order K as the kernel builds it (sv_table_entry), for tests of its fields
+extern "C" int emu_table(const svdss_index* ix, int K, uint64_t* out_lo, uint64_t* out_info) {
+  SvdssDevIndex v;
+  v.blocks = ix->blocks.data();
+  v.dollar = ix->dollar.data();
+  v.n = ix->n;
+  v.n_dollar = (int32_t)ix->dollar.size();
+  v.k = K;
+  memcpy(v.acc, ix->acc, sizeof v.acc);
+  v.text = ix->text.data();
+  v.sa = ix->sa64.empty() ? (const void*)ix->sa32.data() : (const void*)ix->sa64.data();
+  v.table = nullptr;
+  const uint64_t n = (uint64_t)1 << (2 * K);
+  for (uint64_t key = 0; key < n; ++key) {
+    if (ix->sa64.empty()) sv_table_entry<uint32_t>(v, (uint32_t)key, K, out_lo[key], out_info[key]);
+    else sv_table_entry<uint64_t>(v, (uint32_t)key, K, out_lo[key], out_info[key]);
+  }
+  return 0;
+}
+
 extern "C" int64_t emu_search2(const svdss_index* ix, const uint8_t* reads_padded,
                                const int64_t* offsets, int64_t n_reads, int64_t total_syms,
                                int assemble, int K, int use_text, int64_t* counts, int32_t* qs,

@@ -151,3 +151,47 @@ def test_v2_set_mode_in_low_copy_repeats(n_seg):
         ops[use_set] = got[4]
     assert ops[False]["SET"] == 0 and ops[True]["SET"] > 0 and ops[True]["SA_SET"] > 0
     assert ops[True]["LF"] < ops[False]["LF"] // 2
+
+
+def test_kmer_table_entries_against_plain_substring_search():
+    """Every entry of the k-mer table (sv_table_entry): d = how many trailing symbols of the K-mer occur, and for an
+    absent K-mer df = how many leading symbols of the d + 1 that fail together still occur -- the outcome of the
+    forward phase the reference starts there (ping_pong.cpp:28-37), which the kernel takes from the entry instead of
+    a second lookup.  Checked against substring search in the contigs and their reverse complements."""
+    rng = np.random.default_rng(12)
+    contigs = [rng.integers(1, 5, size=n).astype(np.uint8) for n in (700, 450)]
+    ix = svdss_amd.FMDIndex.build(contigs, threads=2)
+    letters = "$ACGTN"
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    strands = []
+    for c in contigs:
+        fw = "".join(letters[x] for x in c)
+        strands += [fw, "".join(comp[ch] for ch in reversed(fw))]
+    occurs = lambda x: any(x in t for t in strands)
+    K = 6
+    lo, info = E.kmer_table(ix, K)
+    n_empty = n_df = 0
+    for key in range(1 << (2 * K)):
+        w = "".join("ACGT"[(key >> (2 * i)) & 3] for i in range(K))     # first symbol in the low bits
+        d = 0
+        while d < K and occurs(w[K - 1 - d:]):
+            d += 1
+        typ = int(info[key]) >> 62
+        if d == K:
+            assert typ in (1, 2), (w, typ)
+            size = sum(t.count(w) if len(set(w)) > 1 else sum(1 for i in range(len(t) - K + 1) if t[i:i + K] == w) for t in strands)
+            if typ == 1:
+                assert size == 1
+            continue
+        n_empty += 1
+        assert typ == 0 and (int(info[key]) & 0xff) == d, (w, d, int(info[key]) & 0xff)
+        if d == 0:
+            continue
+        f = w[K - 1 - d:]                      # d + 1 symbols that do not occur together
+        df = 0
+        while df < len(f) and occurs(f[:df + 1]):
+            df += 1
+        assert df <= d
+        assert ((int(info[key]) >> 8) & 0xff) == df, (w, f, df, (int(info[key]) >> 8) & 0xff)
+        n_df += 1
+    assert n_empty > 500 and n_df > 500
