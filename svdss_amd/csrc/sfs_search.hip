@@ -177,12 +177,13 @@ static SvdssDevIndex device_view(const svdss_index* ix) {
 }
 
 template <class P>
-__global__ void __launch_bounds__(256) build_table_kernel(SvdssDevIndex ix, SvdssTabEntry* tab, int K) {
+__global__ void __launch_bounds__(256) build_table_kernel(SvdssDevIndex ix, SvdssTabEntry* tab, int K, int forward) {
   const uint64_t nkeys = (uint64_t)1 << (2 * K);
   for (uint64_t key = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; key < nkeys;
        key += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t lo, info;
     sv_table_entry<P>(ix, (uint32_t)key, K, lo, info);
+    if (!forward && (info >> 62) == SVDSS_TAB_EMPTY) info &= ~0xff00ull;   // SVDSS_TABLE_FORWARD=0 (A/B measurements)
     tab[key].lo = lo;
     tab[key].info = info;
   }
@@ -221,12 +222,14 @@ extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
     SvdssDevIndex v = device_view(ix);
     const uint64_t nkeys = (uint64_t)1 << (2 * k);
     const int blocks = (int)((nkeys + 255) / 256 < 65536 ? (nkeys + 255) / 256 : 65536);
+    const char* fw = getenv("SVDSS_TABLE_FORWARD");
+    const int forward = (fw && atoi(fw) == 0) ? 0 : 1;   // 0: entries without the forward-phase outcome
     if (wide)
       hipLaunchKernelGGL(build_table_kernel<uint64_t>, dim3(blocks), dim3(256), 0, 0, v,
-                         (SvdssTabEntry*)ix->d_table, k);
+                         (SvdssTabEntry*)ix->d_table, k, forward);
     else
       hipLaunchKernelGGL(build_table_kernel<uint32_t>, dim3(blocks), dim3(256), 0, 0, v,
-                         (SvdssTabEntry*)ix->d_table, k);
+                         (SvdssTabEntry*)ix->d_table, k, forward);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     ix->table_k = k;
