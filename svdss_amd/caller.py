@@ -179,15 +179,19 @@ def sam_text(contigs, rows) -> str:
 
 
 def pcall_tail(subclusters, chromosomes: dict, min_sv_length: int = 25, threads: int = 4, device: int = 0,
-               sam_rows: list = None):
+               sam_rows: list = None, alignments=None):
     """Caller::pcall from the consensus on (caller.cpp:326-405) for a list of sub-clusters, each a
     dict(chrom, s, e, consensus, size, names, cov=(cov,cov0,cov1,cov2), rvec, cluster_index).
     All realignments go to the GPU in one batch.  Returns SVs in the order Caller::run leaves them
     before its sort (caller.cpp:18-22: per-thread vectors, cluster i on thread i % T, each inserted
-    at the FRONT).  sam_rows, if given, receives the --poa rows (caller.cpp:356-357) in that same order."""
-    refs = [chromosomes[sc["chrom"]][sc["s"]:sc["e"] + 1] for sc in subclusters]   # caller.cpp:329
-    cons = [sc["consensus"] for sc in subclusters]
-    scores, cigars, stats = ksw_extd2_global(cons, refs, device=device)
+    at the FRONT).  alignments = (scores, cigars) skips the realignment batch.  sam_rows, if given, receives the --poa rows (caller.cpp:356-357) in that same order."""
+    if alignments is not None:     # (scores, cigars) already computed, e.g. by the ranks of a sharded call
+        scores, cigars = alignments
+        scores, stats = np.asarray(scores), {}
+    else:
+        refs = [chromosomes[sc["chrom"]][sc["s"]:sc["e"] + 1] for sc in subclusters]   # caller.cpp:329
+        cons = [sc["consensus"] for sc in subclusters]
+        scores, cigars, stats = ksw_extd2_global(cons, refs, device=device)
     per_thread = [[] for _ in range(threads)]
     per_thread_sam = [[] for _ in range(threads)]
     for sc, score, cg in zip(subclusters, scores.tolist(), cigars):
@@ -216,7 +220,7 @@ def clean_dups(svs):
     return out
 
 
-def filter_sv_chains(svs, min_ratio: float = 0.97, device: int = 0):
+def filter_sv_chains(svs, min_ratio: float = 0.97, device: int = 0, ratio_fn=None):
     """caller.cpp:429-475.  `prev` is always the element right before `sv`, so every
     rapidfuzz::fuzz::ratio call is on an adjacent pair: all candidate pairs are scored in ONE
     GPU batch, then the sequential keep/merge logic replays on those ratios."""
@@ -235,7 +239,7 @@ def filter_sv_chains(svs, min_ratio: float = 0.97, device: int = 0):
     if cand:
         a = [(svs[i].refall if svs[i].type == "DEL" else svs[i].altall) for i in cand]
         b = [(svs[i - 1].refall if svs[i].type == "DEL" else svs[i - 1].altall) for i in cand]
-        ratio, _ = fuzz_ratio(a, b, device=device)
+        ratio, _ = (ratio_fn or fuzz_ratio)(a, b, device=device)
         sims = dict(zip(cand, ratio.tolist()))
     out, prev, reset = [], svs[0], False
     for i in range(1, len(svs)):
@@ -282,14 +286,14 @@ def vcf_header(contigs) -> str:
 
 
 def call_tail(subclusters, chromosomes: dict, contigs, min_sv_length: int = 25, threads: int = 4,
-              min_ratio: float = 0.97, device: int = 0, sam_rows: list = None) -> str:
+              min_ratio: float = 0.97, device: int = 0, sam_rows: list = None, alignments=None, ratio_fn=None) -> str:
     """Caller::run from pcall's realignment to the VCF text (caller.cpp:17-29): realign, extract,
     sort, clean_dups, filter_sv_chains, sort, write.  std::sort's order among SVs with equal
     (chrom, POS) is unspecified in the reference (SURVEY App. A#8); a stable sort is used here."""
-    svs, _ = pcall_tail(subclusters, chromosomes, min_sv_length, threads, device, sam_rows)
+    svs, _ = pcall_tail(subclusters, chromosomes, min_sv_length, threads, device, sam_rows, alignments)
     svs.sort(key=SV.key)
     svs = clean_dups(svs)
-    svs = filter_sv_chains(svs, min_ratio, device)
+    svs = filter_sv_chains(svs, min_ratio, device, ratio_fn)
     svs.sort(key=SV.key)
     return vcf_header(contigs) + "".join(sv.vcf_line() + "\n" for sv in svs)
 
@@ -483,10 +487,18 @@ def run_poa(clusters: Sequence[Sequence], device: int = 0):
 
 def call(alignments, sfs_text: str, chromosomes: dict, contigs, ref_names, threads: int = 4,
          min_cluster_weight: int = 2, min_sv_length: int = 25, min_mapq: int = 20, useht: bool = True,
-         min_ratio: float = 0.97, device: int = 0):
+         min_ratio: float = 0.97, device: int = 0, shard=None, poa_fn=None, align_fn=None, ratio_fn=None):
     """Caller::run (caller.cpp:3-57) without --clipped: SFS file + alignments + reference -> VCF text; the
     --poa (SAM) and --clusters side outputs are returned as info["sam"] / info["clusters_text"].  Host bookkeeping as in the reference; POA, realignment and the chain
-    filter's ratio run on the GPU in three batched calls.  Returns (vcf_text, info dict)."""
+    filter's ratio run on the GPU in three batched calls.  Returns (vcf_text, info dict).
+
+    shard = (rank, world, all_gather) splits the DP work over the ranks of one node (POA / realignment
+    batches shard by sub-cluster index with no exchange; sort -> clean_dups -> filter_sv_chains -> sort runs once on the
+    gathered rows): every rank runs the host bookkeeping on the whole input (it is deterministic), takes the
+    sub-clusters k with k % world == rank through POA and realignment on its GPU, all_gather(list) returns the list of
+    every rank's (k, consensus, score, cigar) rows, and every rank finishes the call on the merged rows -- the VCF is
+    byte-identical to the single-GPU one.  svdss_amd.multi.call_sharded wraps this for torch.distributed.
+    poa_fn / align_fn / ratio_fn replace run_poa / ksw_extd2_global / fuzz_ratio (tests of the sharding on CPU)."""
     from .clusterer import Clusterer
     from .pingpong import parse_sfsfile
     sfs = parse_sfsfile(sfs_text)
@@ -500,12 +512,25 @@ def call(alignments, sfs_text: str, chromosomes: dict, contigs, ref_names, threa
             continue
         for cl in split_cluster(cluster, useht, min_ratio):
             subs.append((i, cl, cluster))
-    consensus, poa_stats = run_poa([cl.get_seqs() for _, cl, _ in subs], device=device) if subs else ([], {})
+    rank, world, all_gather = shard if shard is not None else (0, 1, None)
+    mine = list(range(rank, len(subs), world))
+    consensus, poa_stats = (poa_fn or run_poa)([subs[k][1].get_seqs() for k in mine], device=device) if mine else ([], {})
+    alignments = None
+    if world > 1 or align_fn is not None:
+        if all_gather is None:
+            all_gather = lambda rows: [rows]
+        refs = [chromosomes[subs[k][1].chrom][subs[k][1].s:subs[k][1].e + 1] for k in mine]   # caller.cpp:329
+        sc_, cg_, _ = (align_fn or ksw_extd2_global)(consensus, refs, device=device) if mine else ([], [], {})
+        rows = [(k, c, int(x), [int(w) for w in g]) for k, c, x, g in zip(mine, consensus, sc_, cg_)]
+        merged = sorted(r for part in all_gather(rows) for r in part)
+        assert [r[0] for r in merged] == list(range(len(subs)))
+        consensus = [r[1] for r in merged]
+        alignments = ([r[2] for r in merged], [np.asarray(r[3], dtype=np.uint32) for r in merged])
     entries = [dict(chrom=cl.chrom, s=cl.s, e=cl.e, consensus=cons, size=cl.size(), names=cl.get_names(),
                     cov=(cl.cov, cl.cov0, cl.cov1, cl.cov2), rvec=parent.reads, cluster_index=i)
                for (i, cl, parent), cons in zip(subs, consensus)]
     sam_rows = []
-    vcf = call_tail(entries, chromosomes, contigs, min_sv_length, threads, min_ratio, device, sam_rows)
+    vcf = call_tail(entries, chromosomes, contigs, min_sv_length, threads, min_ratio, device, sam_rows, alignments, ratio_fn)
     # Clusterer::store_clusters (clusterer.cpp:613-626)
     clusters_text = "".join(
         f"{c.chrom}:{c.s + 1}-{c.e + 1}\t{c.size()}" + "".join(f"\t{sr.name}:{sr.seq}" for sr in c.subreads) + "\n"

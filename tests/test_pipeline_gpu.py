@@ -125,3 +125,43 @@ def test_run_svdss_chain_with_raw_reads(tmp_path):
         hits = [c for c in called if c[0] == chrom and c[2] == kind and abs(c[3] - length) <= 2 and abs(c[1] - pos) <= 15]
         assert len(hits) == 1, (chrom, pos, kind, length, called)
     assert len(called) == len(truth)
+
+
+def _sharded_hip_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from svdss_amd import multi
+    from tests.test_multi_cpu import _call_inputs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # (the ranks share the one GPU of the test box)
+    alns, sfs_text, chromosomes, contigs, ref_names, _ = _call_inputs()
+    vcf, info = multi.call_sharded(alns, sfs_text, chromosomes, contigs, ref_names, threads=4, min_sv_length=50, device=0)
+    q.put((rank, vcf, info["sam"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_call_sharded_over_two_ranks_with_the_hip_kernels():
+    """SURVEY 8(e) for `call`: POA / realignment batches sharded by sub-cluster index over two ranks (gloo, both on
+    this box's GPU), rows gathered, tail run once per rank -- byte-identical to the single-rank call."""
+    import socket
+    import torch.multiprocessing as mp
+    from tests.test_multi_cpu import _call_inputs
+    alns, sfs_text, chromosomes, contigs, ref_names, n_truth = _call_inputs()
+    vcf0, info0 = caller.call(alns, sfs_text, chromosomes, contigs, ref_names, threads=4, min_sv_length=50)
+    assert len([l for l in vcf0.splitlines() if not l.startswith("#")]) == n_truth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_hip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _, vcf, sam in got:
+        assert vcf == vcf0 and sam == info0["sam"]
