@@ -543,7 +543,7 @@ int main_call(const CallOptions& o) {
         }
         if (qs == -1 || qe == -1) ++C.unextended;
         else {
-          if (qs > rr.l_seq) throw std::out_of_range("sub-read start past the end of the read");   // std::string::substr
+          if (qs > rr.l_seq) die("corrupt alignment: sub-read start past the end of read " + qname);   // (std::string::substr throws in the reference)
           const int n = std::max(0, std::min(qe - qs + 1, rr.l_seq - qs));
           const uint8_t* sq = rr.seq4();
           std::string sub((size_t)n, 'N');
