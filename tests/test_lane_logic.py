@@ -195,3 +195,37 @@ def test_kmer_table_entries_against_plain_substring_search():
         assert ((int(info[key]) >> 8) & 0xff) == df, (w, f, df, (int(info[key]) >> 8) & 0xff)
         n_df += 1
     assert n_empty > 500 and n_df > 500
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def test_v2_randomised_configurations(seed):
+    """Random small genomes (some tiny, so that most K-mers are absent and the table's forward-phase outcome is used on
+    nearly every SFS), error rates, N content, table orders and segment counts: SFS and extension counts of the lane
+    code equal the oracle's in every configuration."""
+    from svdss_amd import synth
+    rng = np.random.default_rng(seed)
+    ref_len = int(rng.choice([600, 3000, 20000, 120000]))
+    ref = synth.make_reference([ref_len, max(300, ref_len // 3)], seed=seed, repeat_frac=float(rng.choice([0.0, 0.2])),
+                               n_runs=(int(rng.integers(0, 3)),))
+    err = float(rng.choice([0.0, 0.005, 0.03]))
+    reads = []
+    for i in range(16):
+        c = ref[int(rng.integers(0, 2))]
+        ln = int(rng.integers(20, min(len(c), 2500)))
+        a = int(rng.integers(0, len(c) - ln + 1))
+        r = c[a:a + ln].copy()
+        e = rng.random(ln) < err
+        r[e] = (r[e] - 1 + rng.integers(1, 4, size=int(e.sum()))) % 4 + 1
+        if i % 5 == 0:
+            r[int(rng.integers(0, ln))] = 5
+        reads.append(synth.revcomp(r) if i % 2 else r)
+    flat, offs = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(ref, threads=2)
+    fm = O.OracleFMD.build(ref)
+    for assemble in (False, True):
+        c2, q2, l2, e2 = fm.search_batch(flat, offs, assemble)
+        for K in (0, 4, 7, 9, 11):
+            for n_seg in (1, 4):
+                c, q, l, e, ops = E.search2(ix, flat, offs, assemble, K, True, n_seg=n_seg)
+                assert (c == c2).all() and (e == e2).all(), (seed, K, n_seg, assemble)
+                assert (q == q2).all() and (l == l2).all(), (seed, K, n_seg, assemble)
