@@ -1,10 +1,12 @@
-"""Multi-GPU sharding of the `search` path.
+"""Multi-GPU sharding of the `search` and `call` paths.
 
 Reads are independent (PingPong::process_batch, /root/reference/ping_pong.cpp:176-209,
 gives each OpenMP worker a disjoint slice), so the path shards with NO data-path
 collective: the index is replicated in every GPU's HBM, each rank searches its
 slice of the reads.  The only exchange is the final gather of the (assembled)
 SFS records to rank 0, which writes the .sfs text (ping_pong.cpp:213-236).
+`call` shards its DP batches (POA, realignment) by sub-cluster index and gathers the
+per-sub-cluster rows before the global sort / dedup / chain filter (call_sharded).
 """
 from typing import Optional, Tuple
 
