@@ -13,7 +13,7 @@ cp $(ls $R/gpurun_out/final_stats/*/*kernel_stats.csv | head -1) $R/gpurun_out/f
 i=0
 for c in "FETCH_SIZE WRITE_SIZE" "TCC_EA0_RDREQ TCC_EA0_RDREQ_128B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B" "TCC_HIT TCC_MISS TCC_REQ" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $c --kernel-trace --kernel-include-regex sfs_ --output-format csv -d $R/gpurun_out/final_pmc_$i -- $PMC_CMD > /dev/null 2>&1
+  timeout 150 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex sfs_ --output-format csv -d $R/gpurun_out/final_pmc_$i -- $PMC_CMD > /dev/null 2>&1
 done
 python - <<PY
 import csv, glob
