@@ -282,6 +282,16 @@ class BamReader {
     const uint8_t* ax = arena.data() + rr.aux_off();
     r.aux.assign(ax, ax + rr.l_aux);
   }
+  // the same from a zero-copy view
+  static void materialize(const RawView& v, BamRecord& r, bool want_seq = true) {
+    r.tid = v.tid; r.pos = v.pos; r.l_seq = v.l_seq; r.flag = v.flag; r.mapq = v.mapq;
+    r.qname.assign((const char*)v.name(), v.l_name ? v.l_name - 1 : 0);
+    r.cigar.resize(v.n_cigar);
+    if (v.n_cigar) memcpy(r.cigar.data(), v.name() + v.l_name, 4u * v.n_cigar);
+    if (want_seq) r.seq4.assign(v.seq4(), v.seq4() + (size_t)(v.l_seq + 1) / 2); else r.seq4.clear();
+    r.qual.clear();
+    r.aux.assign(v.aux(), v.aux() + v.l_aux);
+  }
   static void materialize_seq(const Arena& arena, const RawRec& rr, BamRecord& r) {
     const uint8_t* sq = arena.data() + rr.seq_off();
     r.seq4.assign(sq, sq + (size_t)(rr.l_seq + 1) / 2);

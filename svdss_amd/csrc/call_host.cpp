@@ -354,6 +354,30 @@ int main_call(const CallOptions& o) {
   // ---- align_and_extend (clusterer.cpp:56-156): pass 1 over the BAM
   std::vector<std::string> ref_names;
   std::vector<ESFS> extended;
+  // The inflated records of pass 1 are kept for pass 2 when they fit in memory (a second inflate of the whole file
+  // otherwise): SVDSS_CALL_CACHE_GB, default 40 % of MemAvailable, at most 64 GiB.
+  std::vector<BamReader::RawView> cache_views;
+  std::vector<std::shared_ptr<BamReader::Bytes>> cache_chunks;
+  size_t cache_bytes = 0, cache_limit = 0;
+  bool cache_ok = true;
+  std::thread cache_release;
+  {
+    double gb = 0;
+    if (const char* e = getenv("SVDSS_CALL_CACHE_GB")) gb = atof(e);
+    else {
+      if (FILE* f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+          long long kb;
+          if (sscanf(line, "MemAvailable: %lld kB", &kb) == 1) { gb = 0.4 * (double)kb / (1024.0 * 1024.0); break; }
+        }
+        fclose(f);
+      }
+      if (gb > 64) gb = 64;
+    }
+    cache_limit = gb > 0 ? (size_t)(gb * 1024.0 * 1024.0 * 1024.0) : 0;
+    if (cache_limit == 0) cache_ok = false;
+  }
   {
     BamReader bam(o.bam);
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
@@ -364,25 +388,38 @@ int main_call(const CallOptions& o) {
     std::vector<BamRecord> batches[2];
     std::thread worker;
     int cur = 0;
-    BamReader::Arena arena;
     std::string qname;
     bool eof = false;
+    uint64_t seen_chunk = ~0ull;
+    std::shared_ptr<BamReader::Bytes> cur_chunk;
     while (!eof) {
       std::vector<BamRecord>& batch = batches[cur];
       batch.clear();
       while ((int)batch.size() < bsize) {
-        // records are sliced out of the stream and only decoded if the read has SFS at all
-        arena.clear();
-        BamReader::RawRec rr;
-        const int rc = bam.next_raw(arena, rr);
+        // records are located in the inflated chunks and only decoded if the read has SFS at all
+        BamReader::RawView rr;
+        const int rc = bam.next_view(rr);
         if (rc == 0) { eof = true; break; }
         if (rc < 0) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": " + bam.error()); }
+        if (bam.chunk_id() != seen_chunk) {
+          seen_chunk = bam.chunk_id();
+          cur_chunk = bam.chunk();
+          if (cache_ok) {
+            cache_bytes += cur_chunk->size();
+            if (cache_bytes > cache_limit) {   // too big to keep: pass 2 reads the file again
+              cache_ok = false;
+              cache_views.clear(); cache_views.shrink_to_fit();
+              cache_chunks.clear(); cache_chunks.shrink_to_fit();
+            } else cache_chunks.push_back(cur_chunk);
+          }
+        }
         if (rr.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
         if ((int)rr.mapq < o.min_mapq) continue;
-        qname.assign((const char*)arena.data() + rr.name_off(), rr.l_name ? rr.l_name - 1 : 0);
+        if (cache_ok) cache_views.push_back(rr);    // every record pass 2 looks at (same filters, clusterer.cpp:535-540)
+        qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
         if (C.sfs.find(qname) == C.sfs.end()) continue;
         BamRecord r;
-        BamReader::materialize(arena, rr, r);
+        BamReader::materialize(rr, r);
         batch.push_back(std::move(r));
       }
       if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
@@ -475,10 +512,6 @@ int main_call(const CallOptions& o) {
       int m = 0;
       for (size_t ci : kv.second) { m = std::max(m, max_e[ci]); rm.push_back(m); }
     }
-    BamReader bam(o.bam);
-    if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
-    BamReader::RawView rr;   // zero-copy: the record is used where it was inflated, within this iteration only
-    int rc;
     // per reference id: the clusters of that chromosome (sorted by start) and the running maximum of their ends
     std::vector<const std::vector<size_t>*> tid_clusters(ref_names.size(), nullptr);
     std::vector<const std::vector<int>*> tid_run_max(ref_names.size(), nullptr);
@@ -493,10 +526,20 @@ int main_call(const CallOptions& o) {
     // Records stay in their raw form: the end position and the two query positions the reference reads off the
     // aligned-pairs vector (bam.cpp:92-134, clusterer.cpp:555-580) are functions of the CIGAR blocks alone, and only
     // the bases of the extracted sub-read are decoded.
-    while ((rc = bam.next_view(rr)) > 0) {
-      if (rr.tid < 0 || rr.tid >= (int)ref_names.size() || !tid_clusters[(size_t)rr.tid]) continue;
-      if (rr.flag & (4 | 2048 | 256)) continue;      // clusterer.cpp:535-540: such a record touches no cluster
-      if ((int)rr.mapq < o.min_mapq) continue;
+    // what one alignment does to one cluster it overlaps; applied in BAM order (sequentially, or collected by worker
+    // threads over contiguous record ranges and applied range after range)
+    struct Ev { size_t ci; int hp; bool in_reads, unext; std::string name, sub; };
+    auto apply = [&](Ev& e) {
+      if (e.hp >= 0 && e.hp < 3) ++cov[e.ci][(size_t)e.hp];
+      clusters[e.ci].reads.emplace_back(e.in_reads ? 1 : 0, e.hp == 0 ? 3 : e.hp);
+      if (!e.in_reads) return;
+      if (e.unext) ++C.unextended;
+      else clusters[e.ci].subreads.push_back(SubRead{std::move(e.name), std::move(e.sub), e.hp});
+    };
+    auto process = [&](const BamReader::RawView& rr, std::string& qname, auto&& sink) {
+      if (rr.tid < 0 || rr.tid >= (int)ref_names.size() || !tid_clusters[(size_t)rr.tid]) return;
+      if (rr.flag & (4 | 2048 | 256)) return;        // clusterer.cpp:535-540: such a record touches no cluster
+      if ((int)rr.mapq < o.min_mapq) return;
       const uint8_t* cg = rr.name() + rr.l_name;
       auto cig = [&](uint32_t i) { uint32_t c; memcpy(&c, cg + 4u * i, 4); return c; };
       int32_t ref_len = 0;
@@ -522,10 +565,9 @@ int main_call(const CallOptions& o) {
           BamReader::aux_int(rr.aux(), rr.l_aux, "HP", hp);
           qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
         }
-        if (hp >= 0 && hp < 3) ++cov[ci][(size_t)hp];
-        clusters[ci].reads.emplace_back(0, hp == 0 ? 3 : (int)hp);
-        if (reads[ci].find(qname) == reads[ci].end()) continue;
-        clusters[ci].reads.back().first = 1;
+        Ev ev{ci, (int)hp, false, false, std::string(), std::string()};
+        if (reads[ci].find(qname) == reads[ci].end()) { sink(ev); continue; }
+        ev.in_reads = true;
         // qs: query position of the last aligned (M/=/X) pair with reference position <= min_s;
         // qe: of the first one with reference position >= max_e
         int qs = -1, qe = -1, ref_pos = rr.pos, read_pos = 0;
@@ -541,18 +583,47 @@ int main_call(const CallOptions& o) {
           } else if (op == 1 || op == 4) read_pos += l;
           else if (op == 2 || op == 3) ref_pos += l;
         }
-        if (qs == -1 || qe == -1) ++C.unextended;
+        if (qs == -1 || qe == -1) ev.unext = true;
         else {
           if (qs > rr.l_seq) die("corrupt alignment: sub-read start past the end of read " + qname);   // (std::string::substr throws in the reference)
           const int n = std::max(0, std::min(qe - qs + 1, rr.l_seq - qs));
           const uint8_t* sq = rr.seq4();
           std::string sub((size_t)n, 'N');
           for (int i = 0; i < n; ++i) { const int q = qs + i; sub[(size_t)i] = NT16[(sq[q >> 1] >> ((~q & 1) << 2)) & 0xf]; }
-          clusters[ci].subreads.push_back(SubRead{qname, std::move(sub), (int)hp});
+          ev.name = qname;
+          ev.sub = std::move(sub);
         }
+        sink(ev);
       }
+    };
+    if (cache_ok) {
+      stage("pass 2: setup");
+      const size_t n = cache_views.size();
+      const size_t W = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, n / 4096 + 1}));
+      std::vector<std::vector<Ev>> evs(W);
+      auto range = [&](size_t w) {
+        std::string nm;
+        auto sink = [&](Ev& e) { evs[w].push_back(std::move(e)); };
+        for (size_t i = n * w / W; i < n * (w + 1) / W; ++i) process(cache_views[i], nm, sink);
+      };
+      std::vector<std::thread> pool;
+      for (size_t w = 1; w < W; ++w) pool.emplace_back(range, w);
+      range(0);
+      for (std::thread& th : pool) th.join();
+      stage("pass 2: scan");
+      for (size_t w = 0; w < W; ++w)
+        for (Ev& e : evs[w]) apply(e);
+      stage("pass 2: apply");
+      // (gigabytes of inflated records: released while the DP batches run)
+      cache_release = std::thread([v = std::move(cache_views), c = std::move(cache_chunks)]() mutable { v.clear(); c.clear(); });
+    } else {
+      BamReader bam(o.bam);
+      if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
+      BamReader::RawView rr;   // zero-copy: the record is used where it was inflated, within this iteration only
+      int rc;
+      while ((rc = bam.next_view(rr)) > 0) process(rr, qname, apply);
+      if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
     }
-    if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
     for (size_t i = 0; i < clusters.size(); ++i) {
       if (!live[i]) { clusters[i].reads.clear(); clusters[i].subreads.clear(); continue; }
       if ((int)clusters[i].size() >= o.min_cluster_weight) {
@@ -760,6 +831,7 @@ int main_call(const CallOptions& o) {
   fflush(stdout);
   logmsg("info", "Writing " + std::to_string(svs.size()) + " SVs.");
   stage("vcf");
+  if (cache_release.joinable()) cache_release.join();
   // ---- write_sam (caller.cpp:65-75): rows in the order of the reference's per-thread lists, each inserted at the
   // front of the global one (caller.cpp:18-22)
   if (!o.poa.empty()) {

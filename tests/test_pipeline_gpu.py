@@ -76,6 +76,10 @@ def test_index_search_call_recovers_implanted_svs(tmp_path, het):
         assert sum(int(n) for n, op in re.findall(r"(\d+)([MID])", f[5]) if op in "MI") == len(f[9])
     cl_text = (tmp_path / "clusters.txt").read_text()
     assert cl_text == info["clusters_text"] and len(cl_text.splitlines()) == info["clusters"]
+    # pass 2 from the records kept in memory (default) or from a second read of the BAM: the same bytes
+    r2 = subprocess.run([BIN, "call", "--reference", str(fa), "--bam", str(bam), "--sfs", str(sfs_path), "--threads", "4",
+                         "--min-sv-length", "50"], capture_output=True, text=True, env=dict(os.environ, SVDSS_CALL_CACHE_GB="0"))
+    assert r2.returncode == 0 and r2.stdout == vcf
 
 
 def test_run_svdss_chain_with_raw_reads(tmp_path):
