@@ -177,11 +177,6 @@ void extend_alignment(Ctx& C, const BamRecord& aln, const std::string& chrom, st
   out.insert(out.end(), merged.begin(), merged.end());
 }
 
-bool primary_ok(const BamRecord& r, int min_mapq) {
-  if (r.flag & (4 | 2048 | 256)) return false;
-  return (int)r.mapq >= min_mapq;
-}
-
 float len_ratio(float cl, float sl) { return std::min(cl, sl) / std::max(cl, sl); }
 
 // caller.cpp:78-97
