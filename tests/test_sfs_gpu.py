@@ -284,6 +284,9 @@ def test_segmented_search_is_exact(monkeypatch, segments):
     {"SVDSS_ORDER": "1", "SVDSS_TICKETS": "64", "SVDSS_BLOCKS": "8"},
     {"SVDSS_SEGMENTS": "4", "SVDSS_BLOCKS": "16", "SVDSS_TICKETS": "3"},
     {"SVDSS_SEGMENTS": "1", "SVDSS_BLOCKS": "4"},
+    {"SVDSS_TABLE_FORWARD": "0", "SVDSS_SEGMENTS": "4"},     # k-mer table without the forward-phase outcome
+    {"SVDSS_TABLE_FORWARD": "0", "SVDSS_KMER": "9"},
+    {"SVDSS_KMER": "9", "SVDSS_SEGMENTS": "2"},              # 4^9 << text: nearly every 9-mer occurs
 ])
 def test_scheduling_knobs_never_change_results(monkeypatch, env):
     """Heavy-reads-first order, per-wavefront ticket pools, resident blocks and segment counts decide when and where a
