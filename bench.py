@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- reads/s through the SFS-search hot path on MI355X.
+"""bench.py -- reads/s through search+call on MI355X (BASELINE.json's metric, on its configuration).
 
-A "step" = one pass of the hot path (svdss_sfs_search_batch_device: ping-pong
-search kernel + fused per-read assembly + compaction) over one batch of
-synthetic HiFi-shape reads that is already resident in HBM.
+Default workload (config 4 of BASELINE.json / SURVEY 8(d)): 24 contigs with the GRCh38 primary lengths
+(3,088,269,832 bp; both strands indexed: 6.18e9 BWT symbols), HiFi-shape reads of 15 kb with 0.5 % errors.
+A "step" = one pass of the hot path over one batch of 1,048,576 reads per GPU (a 30x read set is 6,176,540 reads =
+5.9 steps), i.e.
+  search  svdss_sfs_search_batch_device: ping-pong search kernel + fused per-read assembly + compaction, reads
+          already resident in HBM (ping_pong.cpp:4-49, assembler.cpp:34-56);
+  call    the DP kernels of `SVDSS call` for the sub-clusters that many reads imply (config 4: ~20,000 SVs per 30x
+          read set => 3,395 clusters of 30 sub-reads per step, het ones split in two by split_cluster):
+          svdss_poa_consensus_batch (caller.cpp:257-308), svdss_align_global_batch of every consensus against its
+          reference window (caller.cpp:332-355), svdss_indel_ratio_batch on adjacent alleles (caller.cpp:456-458).
+          The sub-reads are handed over as host buffers (~120 MB per step), as `pcall` hands them to abPOA.
+value = reads / wall time of the steps.  In the same run the first reads of the batch are searched by the CPU oracle
+(cpu_baseline) and the GPU's counts / starts / lengths / extension counts for those reads are compared with it:
+`verified_reads`; the bench fails on a mismatch.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: reads shard across ranks (weak scaling: every rank gets its own
-batch of the same size), the index is replicated in every GPU's HBM, and the
-path has no exchange step: every rank keeps the SFS of its shard (as N
-`SVDSS search` processes would each write their part of the .sfs file).
-`--gather` adds a gather of the assembled SFS on rank 0 (svdss_amd/multi.py,
-RCCL send/recv over xGMI) to every step.  Rank 0 prints ONE JSON line.
+Multi-GPU (config 5): the index is replicated (every rank builds its own replica in its HBM, svdss_index_build_device),
+the contigs are dealt to the ranks by LPT bin packing and every rank searches reads drawn from ITS contigs (weak
+scaling: 1,048,576 reads per rank per step) and calls its share of the clusters; the only collective is the gather of
+the assembled SFS on rank 0 (svdss_amd/multi.py: RCCL send/recv over xGMI straight from the library's HBM buffers),
+inside every timed step.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -28,21 +39,38 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: int32 lane-operations per second (same guide)
 
 GRCH38_PRIMARY = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
                   138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
                   83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+READS_30X_WG = 6_176_540       # 30 x 3,088,269,832 / 15,000
+SVS_30X_WG = 20_000
 
 
-def simulate_reads_gpu(ref_t, n_reads, L, err, seed, device, chunk=2048):
-    """Seeded HiFi-shape reads on the GPU (torch ops; data plumbing, not the hot path):
-    uniform start, random strand, errors sub:ins:del = 2:1.5:1.5 (svdss_amd/synth.py semantics)."""
+def lpt_partition(lens, world):
+    """Longest-processing-time bin packing of the contigs onto the ranks (config 5)."""
+    load = [0] * world
+    owner = [0] * len(lens)
+    for i in sorted(range(len(lens)), key=lambda i: -lens[i]):
+        r = min(range(world), key=lambda r: load[r])
+        owner[i] = r
+        load[r] += lens[i]
+    return owner
+
+
+def simulate_reads_gpu(ref_t, contig_ranges, n_reads, L, err, seed, device, chunk=2048):
+    """Seeded HiFi-shape reads on the GPU (torch ops; data plumbing, not the hot path): uniform start inside one of the
+    given contigs [(start, length) in ref_t], random strand, errors sub:ins:del = 2:1.5:1.5 (svdss_amd/synth.py)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     comp = torch.tensor([0, 4, 3, 2, 1, 5], dtype=torch.uint8, device=device)
     span = L + L // 20 + 64
-    n_ref = ref_t.numel()
+    starts0 = torch.tensor([s for s, l in contig_ranges if l > span], dtype=torch.int64, device=device)
+    room = torch.tensor([l - span for s, l in contig_ranges if l > span], dtype=torch.int64, device=device)
+    cum = torch.cumsum(room, 0)
+    total_room = int(cum[-1])
     total = n_reads * L
     out = torch.zeros(((total + 15) // 16) * 16 + 16, dtype=torch.uint8, device=device)
     p_sub, p_ins, p_del = err * 0.4, err * 0.3, err * 0.3
@@ -50,7 +78,10 @@ def simulate_reads_gpu(ref_t, n_reads, L, err, seed, device, chunk=2048):
     ar_L = torch.arange(L, device=device)
     for s in range(0, n_reads, chunk):
         B = min(chunk, n_reads - s)
-        start = torch.randint(0, n_ref - span, (B,), generator=g, device=device)
+        u0 = (torch.rand((B,), generator=g, device=device, dtype=torch.float64) * total_room).to(torch.int64)
+        u0.clamp_(max=total_room - 1)
+        ci = torch.searchsorted(cum, u0, right=True)
+        start = starts0[ci] + (u0 - (cum[ci] - room[ci]))
         src = ref_t[start[:, None] + ar_span[None, :]]
         u = torch.rand((B, span), generator=g, device=device)
         is_sub = u < p_sub
@@ -79,23 +110,121 @@ def simulate_reads_gpu(ref_t, n_reads, L, err, seed, device, chunk=2048):
     return out, offsets
 
 
+class CallWorkload:
+    """The call-side DP work one step's reads imply: n_clusters SVs (INS/DEL alternating, length
+    U[50, 2000], 300-bp flanks on both sides as the k-mer extension of the SFS leaves them, clusterer.cpp:159-346), 30
+    sub-reads per cluster with 0.5 % errors; every other cluster is heterozygous and leaves split_cluster
+    (caller.cpp:100-255) as two sub-clusters of 15 (alt / ref allele), the others as one of 30.  Packed once on the
+    host in the layout the C-ABI takes; symbols 0..3 (caller.hpp:25-37)."""
+
+    def __init__(self, n_clusters, seed, coverage=30, err=0.005, flank=300):
+        rng = np.random.default_rng(seed)
+        seqs, sub_sizes, refs, kinds = [], [], [], []
+        for c in range(n_clusters):
+            ln = int(rng.integers(50, 2001))
+            left = rng.integers(0, 4, size=flank).astype(np.uint8)
+            right = rng.integers(0, 4, size=flank).astype(np.uint8)
+            seg = rng.integers(0, 4, size=ln).astype(np.uint8)
+            ins = c % 2 == 0
+            ref_w = np.concatenate([left, right]) if ins else np.concatenate([left, seg, right])
+            alt = np.concatenate([left, seg, right]) if ins else np.concatenate([left, right])
+            het = (c // 2) % 2 == 0
+            groups = [(alt, coverage // 2), (ref_w, coverage - coverage // 2)] if het else [(alt, coverage)]
+            for tmpl, k in groups:
+                for _ in range(k):
+                    r = tmpl.copy()
+                    e = rng.random(len(r)) < err
+                    r[e] = (r[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+                    seqs.append(r)
+                sub_sizes.append(k)
+                refs.append(ref_w)
+                kinds.append((ins, tmpl is alt, ln))
+        self.n_clusters = n_clusters
+        self.n_sub = len(sub_sizes)
+        self.kinds = kinds
+        self.seq_off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        self.seq_off[1:] = np.cumsum([len(s) for s in seqs])
+        self.seqs = np.ascontiguousarray(np.concatenate(seqs))
+        self.cluster_off = np.zeros(self.n_sub + 1, dtype=np.int64)
+        self.cluster_off[1:] = np.cumsum(sub_sizes)
+        self.ref_off = np.zeros(self.n_sub + 1, dtype=np.int64)
+        self.ref_off[1:] = np.cumsum([len(r) for r in refs])
+        self.refs = np.ascontiguousarray(np.concatenate(refs))
+        from svdss_amd.caller import KSW_MAT           # caller.cpp:333-337: 5 x 5, match 1, mismatch -9, N 0
+        self.mat = np.ascontiguousarray(KSW_MAT)
+        self._poa = C.c_void_p()
+        self._aln = C.c_void_p()
+        self.last = {}
+
+    def run(self, lib, check, device):
+        """POA -> consensus to the host -> realignment against the reference windows -> ratio of adjacent consensus
+        pairs; returns nothing, leaves timings / results in self.last."""
+        t0 = time.perf_counter()
+        check(lib.svdss_poa_consensus_batch(self.seqs.ctypes.data, self.seq_off.ctypes.data,
+                                            self.cluster_off.ctypes.data, self.n_sub, device, C.byref(self._poa)),
+              "svdss_poa_consensus_batch")
+        cons_len = np.zeros(self.n_sub, dtype=np.int64)
+        cons = np.zeros(max(1, lib.svdss_poa_batch_total(self._poa)), dtype=np.uint8)
+        check(lib.svdss_poa_batch_fetch(self._poa, cons_len.ctypes.data, cons.ctypes.data), "svdss_poa_batch_fetch")
+        t1 = time.perf_counter()
+        q_off = np.zeros(self.n_sub + 1, dtype=np.int64)
+        q_off[1:] = np.cumsum(cons_len)
+        check(lib.svdss_align_global_batch(cons.ctypes.data, q_off.ctypes.data, self.refs.ctypes.data,
+                                           self.ref_off.ctypes.data, self.n_sub, 5, self.mat.ctypes.data, 16, 2, 41, 1,
+                                           device, C.byref(self._aln)), "svdss_align_global_batch")
+        scores = np.zeros(self.n_sub, dtype=np.int32)
+        n_cig = np.zeros(self.n_sub, dtype=np.int64)
+        cig = np.zeros(max(1, lib.svdss_aln_batch_total_cigar(self._aln)), dtype=np.uint32)
+        check(lib.svdss_aln_batch_fetch(self._aln, scores.ctypes.data, n_cig.ctypes.data, cig.ctypes.data),
+              "svdss_aln_batch_fetch")
+        t2 = time.perf_counter()
+        ratio = np.zeros(self.n_sub - 1, dtype=np.float64)
+        a_off, b_off = q_off[:-1].copy(), q_off[1:].copy()
+        # pairs (k, k+1): a = consensus k, b = consensus k+1 -- both views of the same buffer
+        check(lib.svdss_indel_ratio_batch(cons.ctypes.data, a_off.ctypes.data, cons.ctypes.data + int(q_off[1]),
+                                          (b_off - q_off[1]).ctypes.data, self.n_sub - 1, device, ratio.ctypes.data,
+                                          None), "svdss_indel_ratio_batch")
+        t3 = time.perf_counter()
+        self.last = {"poa_wall_ms": (t1 - t0) * 1e3, "realign_wall_ms": (t2 - t1) * 1e3, "ratio_wall_ms": (t3 - t2) * 1e3,
+                     "poa_kernel_ms": lib.svdss_poa_batch_kernel_ms(self._poa),
+                     "poa_cells": lib.svdss_poa_batch_cells(self._poa), "poa_hbm": lib.svdss_poa_batch_hbm(self._poa),
+                     "realign_kernel_ms": lib.svdss_aln_batch_kernel_ms(self._aln),
+                     "realign_cells": lib.svdss_aln_batch_cells(self._aln),
+                     "cons_len": cons_len, "n_cig": n_cig, "cig": cig, "scores": scores}
+
+    def svs_recovered(self, min_len=50):
+        """sub-clusters of the alt allele whose CIGAR carries the implanted I/D (length within 2 %)."""
+        ok = n_alt = 0
+        o = 0
+        for k, (ins, is_alt, ln) in enumerate(self.kinds):
+            ops = self.last["cig"][o:o + int(self.last["n_cig"][k])]
+            o += int(self.last["n_cig"][k])
+            if not is_alt:
+                continue
+            n_alt += 1
+            want = 1 if ins else 2
+            if any((int(x) & 0xf) == want and abs((int(x) >> 4) - ln) <= max(2, ln // 50) for x in ops):
+                ok += 1
+        return ok, n_alt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["chr20", "wg"], default="chr20",
-                    help="chr20: one 64,444,167 bp contig, 30x; wg: 24 contigs with GRCh38 primary lengths "
-                         "(3,088,269,832 bp), 1,048,576 reads per step (a 30x set is 6.2 M reads = 6 steps)")
+    ap.add_argument("--workload", choices=["wg", "chr20"], default="wg",
+                    help="wg (default, the metric's configuration): 24 contigs with GRCh38 primary lengths, 1,048,576 "
+                         "reads per GPU per step; chr20: one 64,444,167 bp contig, 30x = 128,888 reads per step")
     ap.add_argument("--ref-len", type=int, default=0, help="override: single contig of this many bases")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--read-len", type=int, default=15000)
     ap.add_argument("--err", type=float, default=0.005)
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: coverage*ref/read_len)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-call-dp", action="store_true", help="skip the call-side DP kernel measurement")
-    ap.add_argument("--gather", action="store_true", help="multi-GPU: gather the SFS on rank 0 inside every timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (also skips verification)")
+    ap.add_argument("--no-call-dp", action="store_true", help="search only (value is then NOT the headline metric)")
+    ap.add_argument("--no-gather", action="store_true", help="multi-GPU: leave the SFS on the ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,6 +250,7 @@ def main():
 
     import svdss_amd
     from svdss_amd import multi, synth
+    from svdss_amd._lib import check, lib
 
     if args.ref_len:
         contig_lens = [args.ref_len]
@@ -129,36 +259,39 @@ def main():
     else:
         contig_lens = [64_444_167]
     ref_total = sum(contig_lens)
+    L = args.read_len
     if args.reads:
         n_reads = args.reads
     elif args.workload == "wg" and not args.ref_len:
         n_reads = 1 << 20
     else:
-        n_reads = int(round(args.coverage * ref_total / args.read_len))
-    L = args.read_len
+        n_reads = int(round(args.coverage * ref_total / L))
+    gather = world > 1 and not args.no_gather
 
-    # ---- index: built once (rank 0), replicated into every GPU's HBM -------
+    # ---- index: every rank builds its own replica in its HBM (svdss_index_build_device) -------
     t0 = time.time()
     ref = synth.make_reference(contig_lens, seed=11)
-    idx_path = f"/tmp/svdss_bench_{ref_total}.fmd"
-    if rank == 0:
-        ix = svdss_amd.FMDIndex.build(ref)
-        if world > 1:
-            ix.save(idx_path)
-    if world > 1:
-        dist.barrier()
-        if rank != 0:
-            ix = svdss_amd.FMDIndex.load(idx_path)
-    ix.to_device(local_rank)
+    t_ref = time.time() - t0
+    t0 = time.time()
+    ix = svdss_amd.FMDIndex.build(ref, device=local_rank)
     t_index = time.time() - t0
 
-    # ---- reads: generated on the GPU, one independent shard per rank -------
+    # ---- reads: generated on the GPU from the contigs LPT gives this rank -------
+    owner = lpt_partition(contig_lens, world)
+    starts = np.concatenate([[0], np.cumsum(contig_lens)[:-1]])
+    mine = [(int(starts[i]), int(contig_lens[i])) for i in range(len(contig_lens)) if owner[i] == rank]
     ref_t = torch.from_numpy(ref[0] if len(ref) == 1 else np.concatenate(ref)).to(device)
     del ref
-    d_reads, d_offs = simulate_reads_gpu(ref_t, n_reads, L, args.err, seed=13 + 1000 * rank, device=device)
+    d_reads, d_offs = simulate_reads_gpu(ref_t, mine, n_reads, L, args.err, seed=13 + 1000 * rank, device=device)
     total_syms = n_reads * L
     del ref_t
     torch.cuda.synchronize()
+
+    # ---- call-side work of one step's reads ------
+    cw = None
+    if not args.no_call_dp:
+        n_clusters = max(2, int(round(SVS_30X_WG * n_reads / READS_30X_WG)))   # the SV density per read of config 4
+        cw = CallWorkload(n_clusters, seed=99 + rank)
 
     pp = svdss_amd.PingPong(ix, assemble=True)
     stream = torch.cuda.current_stream()
@@ -166,11 +299,13 @@ def main():
     def step():
         pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
                                    stream=stream.cuda_stream, fetch=False)
-        if world > 1 and args.gather:
+        if cw is not None:
+            cw.run(lib, check, local_rank)
+        if gather:
             counts, qs, ln = pp.device_results()
             multi.gather_sfs(counts, qs, ln)
 
-    # raw (unassembled) SFS count: the N_sfs of the algorithmic-bytes formula
+    # raw (unassembled) SFS count: the N_sfs of SURVEY 8(d)'s reference-model bytes
     pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
                                stream=stream.cuda_stream, assemble=False, fetch=False)
     n_sfs_raw = pp.last_total
@@ -180,12 +315,16 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms, pipeline_ms = [], []
+    kernel_ms, pipeline_ms, poa_ms, aln_ms, call_wall_ms = [], [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         kernel_ms.append(pp.last_search_kernel_ms)   # HIP events recorded on `stream` around the search kernel alone
         pipeline_ms.append(pp.last_kernel_ms)        # ... and around order + search + stitch + assemble
+        if cw is not None:
+            poa_ms.append(cw.last["poa_kernel_ms"])
+            aln_ms.append(cw.last["realign_kernel_ms"])
+            call_wall_ms.append(cw.last["poa_wall_ms"] + cw.last["realign_wall_ms"] + cw.last["ratio_wall_ms"])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -198,14 +337,13 @@ def main():
 
     n_ext = pp.last_total_ext
     n_sfs_asm = pp.last_total
-    # algorithmic bytes per read = N_ext*64 + L + 16*N_sfs
-    alg_bytes = n_ext * 64 + total_syms + 16 * n_sfs_raw
     k_ms = float(np.mean(kernel_ms))
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
     if rank == 0:
+        wl = "GRCh38 primary lengths" if len(contig_lens) == 24 else "chr20 length" if ref_total == 64_444_167 else "custom"
         out = {
-            "metric": "reads/sec through SFS search (ping-pong FMD search + assemble), HiFi 15 kb reads",
+            "metric": "reads/sec through search+call, 30x HiFi 15 kb reads vs 3 Gb ref, 1/2/4/8 GPU"
+                      if cw is not None else "reads/sec through SFS search only (NOT the headline metric: --no-call-dp)",
             "value": world * n_reads * args.steps / elapsed,
             "unit": "reads/s",
             "n_gpus": world,
@@ -218,122 +356,122 @@ def main():
             "dtype": "int64",
             "data": "synthetic",
             "config": {
-                "workload": (f"synthetic {ref_total} bp reference in {len(contig_lens)} contig(s) "
-                             f"({'GRCh38 primary lengths' if len(contig_lens) == 24 else 'chr20 length' if ref_total == 64_444_167 else 'custom'}"
-                             f", iid ACGT + 3% diverged repeats, both strands indexed: {ix.size} BWT symbols), "
-                             f"{n_reads} reads/GPU/step x {L} bp ({n_reads * L / ref_total:.2f}x per step), "
-                             f"{args.err * 100:.2f}% errors, search with fused assemble, all reads searched "
-                             "(--noputative semantics)"),
+                "workload": (f"synthetic {ref_total} bp reference in {len(contig_lens)} contig(s) ({wl}, iid ACGT + 3% diverged "
+                             f"repeats, both strands indexed: {ix.size} BWT symbols), {n_reads} reads/GPU/step x {L} bp "
+                             f"({n_reads * L / ref_total:.2f}x per step; a 30x set = {30 * ref_total / L / n_reads:.2f} steps), "
+                             f"{args.err * 100:.2f}% errors; step = search (ping-pong + fused assemble, all reads searched = "
+                             "--noputative semantics, reads resident in HBM)"
+                             + (f" + call DP for the {cw.n_clusters} clusters / {cw.n_sub} sub-clusters those reads imply "
+                                f"(20,000 SVs per 30x: POA of {int(cw.cluster_off[-1])} sub-reads, realignment, chain-filter "
+                                "ratio; sub-reads handed over as host buffers)" if cw is not None else "")),
                 "reads_per_gpu": n_reads, "read_len": L, "index_bytes": ix.device_bytes,
-                "parallelism": (f"reads sharded over {world} GPU(s), index replicated, no data-path collective"
-                                + (", SFS gathered on rank 0 every step" if (world > 1 and args.gather) else "")),
+                "parallelism": (f"contigs dealt to {world} GPU(s) by LPT, reads drawn from each rank's contigs, index "
+                                "replicated (built per rank in HBM), "
+                                + ("assembled SFS gathered on rank 0 over RCCL every step" if gather
+                                   else "no data-path collective")),
                 "ext_per_read": n_ext / n_reads, "raw_sfs_per_read": n_sfs_raw / n_reads,
-                "assembled_sfs_per_read": n_sfs_asm / n_reads, "index_build_s": round(t_index, 1),
-                "kmer_table_k": ix.kmer_k, "segments_per_read": pp.last_segments,
+                "assembled_sfs_per_read": n_sfs_asm / n_reads, "reference_build_s": round(t_ref, 1),
+                "index_build_s": round(t_index, 1), "kmer_table_k": ix.kmer_k, "segments_per_read": pp.last_segments,
                 "reads_redone_unsegmented": pp.last_fallbacks,
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": "sfs_search2_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(ref_total, n_reads, L, ix.kmer_k),
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
-                # measured HBM-side rate of the same kernel (traffic / kernel time) next to the spec peak
-                "traffic_gbs": (measured_traffic(ref_total, n_reads, L, ix.kmer_k) or 0) / (k_ms * 1e-3) / 1e9 or None,
-                "traffic_frac_of_peak": ((measured_traffic(ref_total, n_reads, L, ix.kmer_k) or 0) / (k_ms * 1e-3) / 1e9
-                                         / HBM_PEAK_GBS) or None,
-                "note": ("achieved = SURVEY 8(d) algorithmic bytes (one 64-B BWT block per rb3_fmd_extend the reference "
-                         "would make) / search-kernel time; the k-mer table, text-compare and SET operations answer "
-                         "most of those extensions without fetching their blocks, so frac exceeds 1 -- `traffic` "
-                         "(TCC_EA0_RDREQ_128B x 128 B + writes: every random 16-B read moves a 128-B line) is what really "
-                         "crosses the fabric, `traffic_frac_of_peak` its share of the 8 TB/s peak, and `random_access` "
-                         "the limit that binds"),
-                "all_kernels_ms": float(np.mean(pipeline_ms)),
-                # the kernel's memory operations are dependent random reads (one per lane per iteration): the
-                # measured ceiling of that access pattern on this GPU (tools/random_read_probe.hip) next to the
-                # rate at which the kernel's measured traffic arrives, both in memory requests (128-B lines) per second
-                "random_access": random_access_info(measured_traffic(ref_total, n_reads, L, ix.kmer_k, "_transactions"),
-                                                    measured_traffic(ref_total, n_reads, L, ix.kmer_k, "_read_transactions"), k_ms),
+                "search_ms_per_step": float(np.mean(pipeline_ms)),
             },
         }
+        out["roofline"] = search_roofline(ref_total, n_reads, L, ix.kmer_k, k_ms, n_ext, total_syms, n_sfs_raw,
+                                          float(np.mean(pipeline_ms)))
+        if cw is not None:
+            okc, n_alt = cw.svs_recovered()
+            poa_k, aln_k = float(np.mean(poa_ms)), float(np.mean(aln_ms))
+            out["config"]["call_dp"] = {
+                "clusters": cw.n_clusters, "subclusters": cw.n_sub, "subreads": int(cw.cluster_off[-1]),
+                "call_wall_ms_per_step": float(np.mean(call_wall_ms)),
+                "poa_kernel_ms": round(poa_k, 3), "poa_cells": cw.last["poa_cells"],
+                "poa_gcups": cw.last["poa_cells"] / (poa_k * 1e-3) / 1e9, "poa_subclusters_on_hbm_kernel": cw.last["poa_hbm"],
+                "realign_kernel_ms": round(aln_k, 3), "realign_cells": cw.last["realign_cells"],
+                "realign_gcups": cw.last["realign_cells"] / (aln_k * 1e-3) / 1e9,
+                "ratio_wall_ms": round(cw.last["ratio_wall_ms"], 3),
+                "alt_subclusters_with_the_implanted_sv_in_the_cigar": f"{okc}/{n_alt}",
+                # integer DP, not HBM- and not MFMA-bound: cell updates x VALU lane-operations per cell
+                # against the int32 issue rate of 256 CUs x 4 SIMD-32 x 2.4 GHz
+                "roofline": call_rooflines(cw.last["poa_cells"], poa_k, cw.last["realign_cells"], aln_k),
+            }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ix, d_reads, L, n_reads, args.cpu_seconds)
-        if world == 1 and not args.no_call_dp:
-            out["config"]["call_dp"] = call_dp_throughput(local_rank)
+            out["cpu_baseline"], out["verified_reads"] = cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads,
+                                                                               args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def random_access_info(transactions, read_transactions, k_ms):
-    try:
-        with open(os.path.join(ROOT, "profiles", "random_access.json")) as fh:
-            probe = json.load(fh)
-    except OSError:
-        return None
-    out = {"ceiling_dependent_lines_per_s": probe["dependent_random_lines_per_s"],
-           "ceiling_independent_lines_per_s": probe["independent_random_lines_per_s"], "source": probe["source"]}
-    if transactions:   # TCC_EA0_RDREQ + TCC_EA0_WRREQ of one launch (profiles/r01_final_pmc.csv)
-        rate = transactions / (k_ms * 1e-3)
-        out["achieved_transactions_per_s"] = rate
-    if read_transactions:   # the probe measures reads: compare reads with reads
-        rrate = read_transactions / (k_ms * 1e-3)
-        out["achieved_read_transactions_per_s"] = rrate
-        out["read_frac_of_dependent_ceiling"] = rrate / probe["dependent_random_lines_per_s"]
-        out["read_frac_of_independent_ceiling"] = rrate / probe["independent_random_lines_per_s"]
-    return out
+# VALU lane-operations per DP cell, counted in the kernels' inner loops:
+POA_OPS_PER_CELL = 30      # convex-gap POA cell: 2 predecessors x (H, E1, E2) max/add + F scan share + direction word
+ALN_OPS_PER_CELL = 24      # dual-affine cell: H, E, F, E2, F2 + direction byte
 
 
-def measured_traffic(ref_total, n_reads, L, k, suffix=""):
-    """HBM-side bytes per launch of the search kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE + WRITE_SIZE, profiles/traffic.json), for exactly this workload; None if that
-    configuration has not been profiled.  Counters cannot be read from inside the timed run."""
+def call_rooflines(poa_cells, poa_ms, aln_cells, aln_ms):
+    def one(cells, ms, ops):
+        ach = cells / (ms * 1e-3) / 1e9
+        peak = VALU_LANE_OPS / ops / 1e9
+        return {"bound": "valu-int32", "achieved": ach, "peak": peak, "unit": "GCUPS", "frac": ach / peak,
+                "lane_ops_per_cell": ops}
+    return {"poa": one(poa_cells, poa_ms, POA_OPS_PER_CELL), "realign": one(aln_cells, aln_ms, ALN_OPS_PER_CELL)}
+
+
+def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw, all_ms):
+    """HBM roofline of the search kernel.  `achieved` = the bytes the kernel's own memory operations move per launch
+    (TCC_EA0_RDREQ x 128 B + WRREQ x 32|64 B from the committed rocprofv3 --pmc pass of exactly this workload,
+    profiles/traffic.json) / the kernel time measured live with HIP events on the launch stream; null when this
+    workload has not been profiled.  The reference algorithm's cost model (one 64-B block per
+    rb3_fmd_extend) is reported as `reference_model_bytes`: the kernel answers most of those extensions from its k-mer
+    table / text compare without fetching their blocks, so that figure is not a bound of this kernel."""
+    prof = profiled(ref_total, n_reads, L, k)
+    ref_model = n_ext * 64 + total_syms + 16 * n_sfs_raw
+    r = {"bound": "hbm", "kernel": "sfs_search2_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": k_ms,
+         "all_search_kernels_ms": all_ms, "reference_model_bytes": ref_model,
+         "reference_model_gbs": ref_model / (k_ms * 1e-3) / 1e9}
+    if prof:
+        traffic = prof["read_requests"] * 128 + prof["write_bytes"]
+        r.update({"achieved": traffic / (k_ms * 1e-3) / 1e9, "traffic": traffic, "traffic_source": prof["source"],
+                  "useful_bytes": prof.get("useful_bytes"),
+                  "lines_per_read": prof["read_requests"] / n_reads})
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        if prof.get("useful_bytes"):
+            r["traffic_over_useful"] = traffic / prof["useful_bytes"]
+        probe = random_probe()
+        if probe:
+            rate = prof["read_requests"] / (k_ms * 1e-3)
+            r["random_access"] = {"read_lines_per_s": rate,
+                                  "ceiling_independent_lines_per_s": probe["independent_random_lines_per_s"],
+                                  "frac_of_ceiling": rate / probe["independent_random_lines_per_s"],
+                                  "source": probe["source"]}
+    else:
+        r.update({"achieved": None, "traffic": None, "frac": None,
+                  "note": "no committed --pmc pass for this workload / kernel version"})
+    return r
+
+
+def profiled(ref_total, n_reads, L, k):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             table = json.load(fh)
     except OSError:
         return None
-    return table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}{suffix}")
+    e = table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}")
+    return e if isinstance(e, dict) else None
 
 
-def call_dp_throughput(device):
-    """Side measurement (not part of `value`): the call-stage DP kernels on synthetic sub-clusters of the
-    SURVEY 2.3 shapes -- 1024 sub-clusters x 12 reads x ~1 kb with 1% errors and one 150-bp insertion in
-    half of them: POA consensus, consensus->reference realignment (full matrix + traceback), and the
-    chain filter's ratio on the resulting alleles.  Integer DP: reported in cell updates per second."""
-    from svdss_amd import caller
-    rng = np.random.default_rng(99)
-    clusters, refs = [], []
-    for c in range(1024):
-        ln = int(rng.integers(600, 1400))
-        t = rng.integers(0, 4, size=ln).astype(np.uint8)
-        alt = np.concatenate([t[:ln // 2], rng.integers(0, 4, size=150).astype(np.uint8), t[ln // 2:]]) if c % 2 else t
-        reads = []
-        for _ in range(12):
-            r = alt.copy()
-            e = rng.random(len(r)) < 0.01
-            r[e] = rng.integers(0, 4, size=int(e.sum()), dtype=np.uint8)
-            reads.append(r)
-        clusters.append(reads)
-        refs.append(t)
-    cons, poa = caller.run_poa(clusters, device=device)
-    scores, cigars, aln = caller.ksw_extd2_global(cons, refs, device=device)
-    t0 = time.perf_counter()
-    ratio, _ = caller.fuzz_ratio(cons[:-1], cons[1:], device=device)
-    t_ratio = time.perf_counter() - t0
-    n_ins = sum(1 for cg in cigars if any((int(x) & 0xf) == 1 and (int(x) >> 4) >= 100 for x in cg))
-    return {"subclusters": len(clusters), "reads_per_subcluster": 12,
-            "poa_cells": poa["cells"], "poa_kernel_ms": round(poa["kernel_ms"], 3),
-            "poa_gcups": poa["cells"] / (poa["kernel_ms"] * 1e-3) / 1e9,
-            "realign_cells": aln["cells"], "realign_kernel_ms": round(aln["kernel_ms"], 3),
-            "realign_gcups": aln["cells"] / (aln["kernel_ms"] * 1e-3) / 1e9,
-            "ratio_pairs": len(ratio), "ratio_wall_ms": round(t_ratio * 1e3, 3),
-            "insertions_recovered": n_ins}
+def random_probe():
+    try:
+        with open(os.path.join(ROOT, "profiles", "random_access.json")) as fh:
+            return json.load(fh)
+    except OSError:
+        return None
 
 
-def cpu_baseline(ix, d_reads, L, n_reads, target_s):
-    """The oracle (CPU restatement of ping_pong.cpp:4-49 + assembler.cpp:34-56, OpenMP over reads
-    like ping_pong.cpp:329) timed on this box's cores on a bounded sample of the same reads."""
+def cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads, target_s):
+    """The oracle (CPU restatement of ping_pong.cpp:4-49 + assembler.cpp:34-56, OpenMP over reads like
+    ping_pong.cpp:329) timed on this box's cores on a bounded sample of the same reads -- and, since it computes the
+    SFS of those reads anyway, the checker of the GPU's results for them (counts, starts, lengths, extension counts)."""
     from tests import oracle_lib as O
     fm = O.OracleFMD.from_bwt(ix.bwt())
     threads = O.max_threads()
@@ -342,17 +480,24 @@ def cpu_baseline(ix, d_reads, L, n_reads, target_s):
         flat = d_reads[:k * L].cpu().numpy()
         offs = np.arange(k + 1, dtype=np.int64) * L
         t0 = time.perf_counter()
-        fm.search_batch(flat, offs, True, threads)
-        return time.perf_counter() - t0
+        res = fm.search_batch(flat, offs, True, threads)
+        return time.perf_counter() - t0, res
 
     k = min(n_reads, 4 * threads)
-    t = run(k)
+    t, _ = run(k)
     k2 = int(min(n_reads, max(k, k * target_s / max(t, 1e-3))))
-    t2 = run(k2)
-    return {"value": k2 / t2, "unit": "reads/s", "cores": threads, "kind": "port",
-            "sample": f"first {k2} reads of the rank-0 batch, {t2:.1f} s, oracle/svdss_oracle.c "
-                      f"orc_search_batch with {threads} OpenMP threads (plain sampled-Occ FMD, faster than "
-                      "ropebwt3's rld0: the GPU/CPU ratio is conservative)"}
+    t2, (c, q, l, e) = run(k2)
+    got = pp._fetch()      # results of the last timed step (assembled)
+    tot = int(c.sum())
+    ok = ((got.counts[:k2] == c).all() and (got.n_ext[:k2] == e).all() and int(got.counts[:k2].sum()) == tot
+          and (got.qs[:tot] == q).all() and (got.len[:tot] == l).all())
+    if not ok:
+        raise SystemExit(f"VERIFICATION FAILED: GPU SFS of the first {k2} reads differ from the oracle's")
+    base = {"value": k2 / t2, "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": f"first {k2} reads of the rank-0 batch, {t2:.1f} s, oracle/svdss_oracle.c orc_search_batch with "
+                      f"{threads} OpenMP threads (search + assemble only; plain sampled-Occ FMD, faster than ropebwt3's "
+                      "rld0: the GPU/CPU ratio is conservative)"}
+    return base, k2
 
 
 if __name__ == "__main__":

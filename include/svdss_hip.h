@@ -47,6 +47,13 @@ typedef struct svdss_index svdss_index_t;
 
 int svdss_index_build(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
                       int32_t threads, svdss_index_t** out);
+/* The same index built directly in the HBM of `device` and left resident there, k-mer table included
+ * (csrc/index_gpu.hip: text, suffix sorting, BWT and rank blocks on the GPU; GRCh38 lengths in tens of seconds
+ * instead of minutes of host cores).  Text and suffix array stay on the device -- svdss_index_save fetches them
+ * when asked.  Falls back to svdss_index_build + svdss_index_to_device when the device lacks the memory.
+ * This is what every rank of a multi-GPU run calls for its own replica (index replicated). */
+int svdss_index_build_device(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
+                             int32_t threads, int32_t device, svdss_index_t** out);
 int svdss_index_save(const svdss_index_t* ix, const char* path);
 int svdss_index_load(const char* path, svdss_index_t** out);
 void svdss_index_free(svdss_index_t* ix);

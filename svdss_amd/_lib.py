@@ -46,6 +46,7 @@ SIGNATURES = {
     "svdss_last_hip_error": (C.c_char_p, []),
     "svdss_nt6_encode": (C.c_int, [C.c_char_p, _i64, _p]),
     "svdss_index_build": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
+    "svdss_index_build_device": (C.c_int, [_p, _p, _i32, _i32, _i32, C.POINTER(_p)]),
     "svdss_index_save": (C.c_int, [_p, C.c_char_p]),
     "svdss_index_load": (C.c_int, [C.c_char_p, C.POINTER(_p)]),
     "svdss_index_free": (None, [_p]),

@@ -5,7 +5,8 @@
 // index that `SVDSS search` restores (ping_pong.cpp:245).  The on-disk format
 // is this repo's own (fmd_layout.h); rld0 import/export is SURVEY 8(f) item 1.
 //
-// Suffix sorting: one parallel sort on 63-bit keys (first 21 symbols, 3 bits
+// This is the builder for machines without a GPU (and the fallback of index_gpu.hip, which builds the same
+// index in HBM).  Suffix sorting: one parallel sort on 63-bit keys (first 21 symbols, 3 bits
 // each) followed by prefix doubling restricted to the still-tied groups
 // (Larsson-Sadakane style, Jacobi updates so groups can be refined in
 // parallel).  On near-random DNA almost every suffix is a singleton after the
@@ -21,8 +22,6 @@
 
 #include "../../include/svdss_hip.h"
 #include "index_host.h"
-
-extern "C" int svdss_sa32_gpu(const uint8_t* t, int64_t n, int32_t* sa_out);   // index_gpu.hip
 
 namespace {
 
@@ -153,15 +152,10 @@ int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t 
   try {
     bwt.resize((size_t)n);
     const bool force64 = getenv("SVDSS_FORCE_SA64") != nullptr;  // test hook for the 64-bit path
-    if (n < (int64_t)0x7fffffff && !force64) {
+    ix->sa_wide = !(n < (int64_t)0x7fffffff && !force64);
+    if (!ix->sa_wide) {
       std::vector<int32_t> sa;
-      // the GPU sorter when there is one (index_gpu.hip; SVDSS_INDEX_CPU=1 keeps the host builder), same result
-      bool done = false;
-      if (!getenv("SVDSS_INDEX_CPU")) {
-        sa.resize((size_t)n);
-        done = svdss_sa32_gpu(t.data(), n, sa.data()) == 0;
-      }
-      if (!done) suffix_array<int32_t>(t.data(), n, sa, threads);
+      suffix_array<int32_t>(t.data(), n, sa, threads);
       ix->sa32.resize((size_t)n);
       ix->sa64.clear();
 #pragma omp parallel for num_threads(threads) schedule(static)
@@ -261,12 +255,12 @@ int svdss_index_save_host(const svdss_index* ix, const char* path) {
   h.n_dollar = (int64_t)ix->dollar.size();
   h.n_contigs = ix->n_contigs;
   h.block_syms = SVDSS_BLOCK_SYMS;
-  h.sa_wide = ix->sa64.empty() ? 0 : 1;
+  h.sa_wide = ix->sa_wide ? 1 : 0;
   bool ok = fwrite(&h, sizeof h, 1, f) == 1;
   ok = ok && fwrite(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
   ok = ok && fwrite(ix->dollar.data(), sizeof(int64_t), ix->dollar.size(), f) == ix->dollar.size();
   ok = ok && fwrite(ix->text.data(), 1, ix->text.size(), f) == ix->text.size();
-  if (!ix->sa64.empty())
+  if (ix->sa_wide)
     ok = ok && fwrite(ix->sa64.data(), sizeof(uint64_t), ix->sa64.size(), f) == ix->sa64.size();
   else
     ok = ok && fwrite(ix->sa32.data(), sizeof(uint32_t), ix->sa32.size(), f) == ix->sa32.size();
@@ -287,6 +281,7 @@ int svdss_index_load_host(const char* path, svdss_index* ix) {
   ix->n = h.n;
   memcpy(ix->acc, h.acc, sizeof h.acc);
   ix->n_contigs = h.n_contigs;
+  ix->sa_wide = h.sa_wide != 0;
   try {
     ix->blocks.resize((size_t)(4 * h.n_blocks));
     ix->dollar.resize((size_t)h.n_dollar);
@@ -296,7 +291,7 @@ int svdss_index_load_host(const char* path, svdss_index* ix) {
   bool ok = fread(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
   ok = ok && fread(ix->dollar.data(), sizeof(int64_t), ix->dollar.size(), f) == ix->dollar.size();
   ok = ok && fread(ix->text.data(), 1, ix->text.size(), f) == ix->text.size();
-  if (!ix->sa64.empty())
+  if (ix->sa_wide)
     ok = ok && fread(ix->sa64.data(), sizeof(uint64_t), ix->sa64.size(), f) == ix->sa64.size();
   else
     ok = ok && fread(ix->sa32.data(), sizeof(uint32_t), ix->sa32.size(), f) == ix->sa32.size();

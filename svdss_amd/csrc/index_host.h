@@ -14,6 +14,7 @@ struct svdss_index {
   std::vector<uint8_t> text;      // nt6 text (contig $ revcomp $ ...), n symbols
   std::vector<uint32_t> sa32;     // suffix array when n < 2^32 ...
   std::vector<uint64_t> sa64;     // ... else 64-bit
+  bool sa_wide = false;           // suffix array entries are 64-bit (n >= 2^31 - 1)
   // device residency (filled by svdss_index_to_device)
   int device = -1;
   void* d_blocks = nullptr;
@@ -31,3 +32,9 @@ int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t 
 int svdss_index_save_host(const svdss_index* ix, const char* path);
 int svdss_index_load_host(const char* path, svdss_index* ix);
 void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt);
+// index_gpu.hip: the whole index built in the HBM of `device` and left resident there (text and suffix array are
+// not copied to the host: svdss_index_fetch_host does that on demand).  0 = done, -1 = not possible here (use the
+// host builder), SVDSS_EINVAL / SVDSS_ERANGE as svdss_index_build_host reports them.
+int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
+                          svdss_index* out);
+int svdss_index_fetch_host(svdss_index* ix);

@@ -78,19 +78,60 @@ extern "C" int svdss_nt6_encode(const char* seq, int64_t n, uint8_t* out) {
 
 // ------------------------------------------------------------------ index
 
+static void free_device_side(svdss_index* ix);
+
 extern "C" int svdss_index_build(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
                                  int32_t threads, svdss_index_t** out) {
   if (!out) return SVDSS_EINVAL;
   svdss_index* ix = new (std::nothrow) svdss_index();
   if (!ix) return SVDSS_ENOMEM;
-  int rc = svdss_index_build_host(contigs, lens, n_contigs, threads, ix);
+  int rc = -1;
+  // on the GPU when there is one (index_gpu.hip; SVDSS_INDEX_CPU=1 keeps the host builder) -- same index
+  if (!getenv("SVDSS_INDEX_CPU")) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+    if (dev >= 0) rc = svdss_index_build_gpu(contigs, lens, n_contigs, dev, ix);
+    if (rc == SVDSS_OK) {
+      rc = svdss_index_fetch_host(ix);
+      free_device_side(ix);
+      if (rc != SVDSS_OK) { delete ix; return rc; }
+      *out = ix;
+      return SVDSS_OK;
+    }
+    if (rc > 0) { delete ix; return rc; }   // bad input: the host builder would say the same
+    free_device_side(ix);
+  }
+  rc = svdss_index_build_host(contigs, lens, n_contigs, threads, ix);
   if (rc != SVDSS_OK) { delete ix; return rc; }
+  *out = ix;
+  return SVDSS_OK;
+}
+
+static int build_table(svdss_index* ix);
+
+extern "C" int svdss_index_build_device(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
+                                        int32_t threads, int32_t device, svdss_index_t** out) {
+  if (!out || device < 0) return SVDSS_EINVAL;
+  svdss_index* ix = new (std::nothrow) svdss_index();
+  if (!ix) return SVDSS_ENOMEM;
+  int rc = getenv("SVDSS_INDEX_CPU") ? -1 : svdss_index_build_gpu(contigs, lens, n_contigs, device, ix);
+  if (rc == SVDSS_OK) {
+    rc = build_table(ix);
+  } else if (rc < 0) {   // no GPU / no room / degenerate text: host builder, then upload
+    free_device_side(ix);
+    rc = svdss_index_build_host(contigs, lens, n_contigs, threads, ix);
+    if (rc == SVDSS_OK) rc = svdss_index_to_device(ix, device);
+  }
+  if (rc != SVDSS_OK) { free_device_side(ix); delete ix; return rc; }
   *out = ix;
   return SVDSS_OK;
 }
 
 extern "C" int svdss_index_save(const svdss_index_t* ix, const char* path) {
   if (!ix || !path) return SVDSS_EINVAL;
+  // an index built in HBM keeps text and suffix array there until somebody needs them on the host
+  const int rc = svdss_index_fetch_host(const_cast<svdss_index*>(ix));
+  if (rc != SVDSS_OK) return rc;
   return svdss_index_save_host(ix, path);
 }
 
@@ -155,7 +196,7 @@ static int auto_kmer(int64_t n) {
 extern "C" int64_t svdss_index_device_bytes(const svdss_index_t* ix) {
   if (!ix) return -1;
   const int k = ix->table_k;   // known once the index is resident
-  const int64_t sa_bytes = ix->sa64.empty() ? 4 * ix->n : 8 * ix->n;
+  const int64_t sa_bytes = ix->sa_wide ? 8 * ix->n : 4 * ix->n;
   return (int64_t)(ix->blocks.size() * sizeof(svdss_u4) + ix->dollar.size() * sizeof(int64_t)) +
          ix->n + 144 + sa_bytes + (k > 0 ? ((int64_t)16 << (2 * k)) : 0);
 }
@@ -189,34 +230,12 @@ __global__ void __launch_bounds__(256) build_table_kernel(SvdssDevIndex ix, Svds
   }
 }
 
-extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
-  if (!ix || device < 0) return SVDSS_EINVAL;
-  HIPCHK(hipSetDevice(device));
-  free_device_side(ix);
-  ix->device = device;  // so that a failure below still frees what was allocated
-  const size_t bb = ix->blocks.size() * sizeof(svdss_u4);
-  const size_t db = (ix->dollar.size() + 1) * sizeof(int64_t);
-  HIPCHK(hipMalloc(&ix->d_blocks, bb));
-  HIPCHK(hipMalloc(&ix->d_dollar, db));
-  HIPCHK(hipMemcpy(ix->d_blocks, ix->blocks.data(), bb, hipMemcpyHostToDevice));
-  if (!ix->dollar.empty())
-    HIPCHK(hipMemcpy(ix->d_dollar, ix->dollar.data(), ix->dollar.size() * sizeof(int64_t),
-                     hipMemcpyHostToDevice));
-  // text with 64 bytes of '$' padding on both sides (the TEXT windows may start before /
-  // end after the text); suffix array with 16 bytes of slack for the 16-byte entry loads
-  const bool wide = !ix->sa64.empty();
-  if ((int64_t)ix->text.size() == ix->n && (wide || (int64_t)ix->sa32.size() == ix->n)) {
-    const size_t tb = (size_t)ix->n + 128 + 16;
-    HIPCHK(hipMalloc(&ix->d_text, tb));
-    HIPCHK(hipMemset(ix->d_text, 0, tb));
-    HIPCHK(hipMemcpy((uint8_t*)ix->d_text + 64, ix->text.data(), (size_t)ix->n, hipMemcpyHostToDevice));
-    const size_t sb = (size_t)ix->n * (wide ? 8 : 4);
-    HIPCHK(hipMalloc(&ix->d_sa, sb + 16));
-    HIPCHK(hipMemcpy(ix->d_sa, wide ? (const void*)ix->sa64.data() : (const void*)ix->sa32.data(), sb,
-                     hipMemcpyHostToDevice));
-  }
+// the 4^K k-mer table of an index whose blocks, text and suffix array are resident
+static int build_table(svdss_index* ix) {
+  if (ix->d_table) { (void)hipFree(ix->d_table); ix->d_table = nullptr; ix->table_k = 0; }
+  const bool wide = ix->sa_wide;
   const int k = auto_kmer(ix->n);
-  if (k > 0) {
+  if (k > 0 && ix->d_text && ix->d_sa) {
     const size_t tbytes = (size_t)16 << (2 * k);
     HIPCHK(hipMalloc(&ix->d_table, tbytes));
     SvdssDevIndex v = device_view(ix);
@@ -235,6 +254,42 @@ extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
     ix->table_k = k;
   }
   return SVDSS_OK;
+}
+
+extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
+  if (!ix || device < 0) return SVDSS_EINVAL;
+  HIPCHK(hipSetDevice(device));
+  if (ix->device == device && ix->d_blocks && ix->d_text && ix->d_sa)   // built there (svdss_index_build_device)
+    return ix->d_table ? SVDSS_OK : build_table(ix);
+  if (ix->device >= 0 && ix->d_text && ix->d_sa) {   // resident elsewhere: the host copy travels
+    const int rc = svdss_index_fetch_host(ix);
+    if (rc != SVDSS_OK) return rc;
+    HIPCHK(hipSetDevice(device));
+  }
+  free_device_side(ix);
+  ix->device = device;  // so that a failure below still frees what was allocated
+  const size_t bb = ix->blocks.size() * sizeof(svdss_u4);
+  const size_t db = (ix->dollar.size() + 1) * sizeof(int64_t);
+  HIPCHK(hipMalloc(&ix->d_blocks, bb));
+  HIPCHK(hipMalloc(&ix->d_dollar, db));
+  HIPCHK(hipMemcpy(ix->d_blocks, ix->blocks.data(), bb, hipMemcpyHostToDevice));
+  if (!ix->dollar.empty())
+    HIPCHK(hipMemcpy(ix->d_dollar, ix->dollar.data(), ix->dollar.size() * sizeof(int64_t),
+                     hipMemcpyHostToDevice));
+  // text with 64 bytes of '$' padding on both sides (the TEXT windows may start before /
+  // end after the text); suffix array with 16 bytes of slack for the 16-byte entry loads
+  const bool wide = ix->sa_wide;
+  if ((int64_t)ix->text.size() == ix->n && (int64_t)(wide ? ix->sa64.size() : ix->sa32.size()) == ix->n) {
+    const size_t tb = (size_t)ix->n + 128 + 16;
+    HIPCHK(hipMalloc(&ix->d_text, tb));
+    HIPCHK(hipMemset(ix->d_text, 0, tb));
+    HIPCHK(hipMemcpy((uint8_t*)ix->d_text + 64, ix->text.data(), (size_t)ix->n, hipMemcpyHostToDevice));
+    const size_t sb = (size_t)ix->n * (wide ? 8 : 4);
+    HIPCHK(hipMalloc(&ix->d_sa, sb + 16));
+    HIPCHK(hipMemcpy(ix->d_sa, wide ? (const void*)ix->sa64.data() : (const void*)ix->sa32.data(), sb,
+                     hipMemcpyHostToDevice));
+  }
+  return build_table(ix);
 }
 
 static SvdssDevIndex host_view(const svdss_index* ix) {
@@ -1065,7 +1120,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   for (int pass = 0; pass < 2; ++pass) {
     HIPCHK(hipMemsetAsync(b->misc.p, 0, 64, stream));
     HIPCHK(hipMemsetAsync((int64_t*)b->counts.p + n_reads, 0, sizeof(int64_t), stream));
-    const bool wide = !ix->sa64.empty();
+    const bool wide = ix->sa_wide;
     const bool seg = n_seg > 1 && pass == 0;   // the exact-capacity rerun is always unsegmented
     HIPCHK(hipEventRecord(b->ev0, stream));
     if (use_order && pass == 0) {

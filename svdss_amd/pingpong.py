@@ -60,7 +60,9 @@ class FMDIndex:
         self._h = C.c_void_p(handle)
 
     @classmethod
-    def build(cls, contigs: Sequence, threads: int = 0) -> "FMDIndex":
+    def build(cls, contigs: Sequence, threads: int = 0, device: Optional[int] = None) -> "FMDIndex":
+        """`SVDSS index` (main.cpp:34-37).  device=None: host-side index (built on the GPU when there is one,
+        then fetched); device=d: built in the HBM of GPU d and left resident there, k-mer table included."""
         enc = [_as_nt6(c) for c in contigs]
         lens = np.array([len(e) for e in enc], dtype=np.int64)
         flat = np.ascontiguousarray(np.concatenate(enc) if enc else np.zeros(0, np.uint8))
@@ -68,6 +70,10 @@ class FMDIndex:
             import os
             threads = os.cpu_count() or 1
         h = C.c_void_p()
+        if device is not None:
+            check(lib.svdss_index_build_device(flat.ctypes.data, lens.ctypes.data, len(enc), threads, device,
+                                               C.byref(h)), "svdss_index_build_device")
+            return cls(h.value)
         check(lib.svdss_index_build(flat.ctypes.data, lens.ctypes.data, len(enc), threads, C.byref(h)),
               "svdss_index_build")
         return cls(h.value)
