@@ -178,12 +178,13 @@ class CallWorkload:
         check(lib.svdss_aln_batch_fetch(self._aln, scores.ctypes.data, n_cig.ctypes.data, cig.ctypes.data),
               "svdss_aln_batch_fetch")
         t2 = time.perf_counter()
+        # chain filter: pairs (k, k + 1) of adjacent consensus sequences -- a and b are two views of one buffer
         ratio = np.zeros(self.n_sub - 1, dtype=np.float64)
-        a_off, b_off = q_off[:-1].copy(), q_off[1:].copy()
-        # pairs (k, k+1): a = consensus k, b = consensus k+1 -- both views of the same buffer
+        a_off = np.ascontiguousarray(q_off[:-1])
+        b_off = np.ascontiguousarray(q_off[1:] - q_off[1])
         check(lib.svdss_indel_ratio_batch(cons.ctypes.data, a_off.ctypes.data, cons.ctypes.data + int(q_off[1]),
-                                          (b_off - q_off[1]).ctypes.data, self.n_sub - 1, device, ratio.ctypes.data,
-                                          None), "svdss_indel_ratio_batch")
+                                          b_off.ctypes.data, self.n_sub - 1, device, ratio.ctypes.data, None),
+              "svdss_indel_ratio_batch")
         t3 = time.perf_counter()
         self.last = {"poa_wall_ms": (t1 - t0) * 1e3, "realign_wall_ms": (t2 - t1) * 1e3, "ratio_wall_ms": (t3 - t2) * 1e3,
                      "poa_kernel_ms": lib.svdss_poa_batch_kernel_ms(self._poa),

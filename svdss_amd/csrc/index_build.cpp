@@ -221,6 +221,7 @@ int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t 
 }
 
 void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < ix->n; ++i) {
     const svdss_u4& q = ix->blocks[(size_t)(4 * (i >> SVDSS_BLOCK_SHIFT) + ((i >> 5) & 3))];
     const int bit = (int)(i & 31);

@@ -395,6 +395,38 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaTask* tasks,
 
 // ------------------------------------------------------------------- ABI
 
+namespace {
+struct DevMem3 {
+  void* p = nullptr;
+  ~DevMem3() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { HIPCHK3(hipMalloc(&p, bytes ? bytes : 16)); return SVDSS_OK; }
+};
+
+// grow-only device buffer handed out by a bump pointer: the workspaces of a call (tens of GB of graph and
+// direction-word pools) are reused by the next call instead of going through hipMalloc / hipFree again
+struct DevArena {
+  void* p = nullptr;
+  size_t cap = 0, used = 0;
+  ~DevArena() { drop(); }
+  void drop() { if (p) (void)hipFree(p); p = nullptr; cap = used = 0; }
+  int reserve(size_t bytes) {   // only while nothing handed out is still in use
+    used = 0;
+    if (bytes <= cap) return SVDSS_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 8 + 4096;
+    HIPCHK3(hipMalloc(&p, want));
+    cap = want;
+    return SVDSS_OK;
+  }
+  void* take(size_t bytes) {
+    const size_t at = (used + 255) & ~(size_t)255;
+    used = at + bytes;
+    return (char*)p + at;
+  }
+  static size_t padded(size_t bytes) { return ((bytes + 255) & ~(size_t)255) + 256; }
+};
+}  // namespace
+
 struct svdss_poa_batch {
   int64_t n_clusters = 0;
   int64_t n_hbm = 0;   // clusters the LDS kernel handed to the HBM kernel
@@ -402,15 +434,15 @@ struct svdss_poa_batch {
   double kernel_ms = 0.0;
   std::vector<int64_t> cons_len;
   std::vector<uint8_t> cons;   // concatenated, symbols 0..4
+  // device state kept between calls
+  int device = -1;
+  DevArena in_arena, ws_arena;
+  std::vector<hipStream_t> streams;
+  ~svdss_poa_batch() {
+    if (device >= 0) (void)hipSetDevice(device);
+    for (hipStream_t st : streams) (void)hipStreamDestroy(st);
+  }
 };
-
-namespace {
-struct DevMem3 {
-  void* p = nullptr;
-  ~DevMem3() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) { HIPCHK3(hipMalloc(&p, bytes ? bytes : 16)); return SVDSS_OK; }
-};
-}  // namespace
 
 extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq_off, const int64_t* cluster_off,
                                          int64_t n_clusters, int32_t device, svdss_poa_batch_t** out) {
@@ -435,27 +467,51 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     if (l >= (1 << 24)) return SVDSS_ERANGE;
   }
   if (total_syms > 0 && !seqs) return SVDSS_EINVAL;
-  DevMem3 d_seqs, d_off, d_cells;
   int rc;
-  if ((rc = d_seqs.alloc((size_t)total_syms)) || (rc = d_off.alloc(sizeof(int64_t) * (size_t)(n_seqs_total + 1))) ||
-      (rc = d_cells.alloc(8)))
+  if (b->device != device) {   // (a batch object is normally used with one device)
+    for (hipStream_t st : b->streams) (void)hipStreamDestroy(st);
+    b->streams.clear();
+    b->in_arena.drop(); b->ws_arena.drop();
+    b->device = device;
+  }
+  const size_t off_bytes = sizeof(int64_t) * (size_t)(n_seqs_total + 1);
+  if ((rc = b->in_arena.reserve(DevArena::padded((size_t)total_syms) + DevArena::padded(off_bytes) + DevArena::padded(8))))
     return rc;
+  struct { void* p; } d_seqs{b->in_arena.take((size_t)total_syms)}, d_off{b->in_arena.take(off_bytes)},
+      d_cells{b->in_arena.take(8)};
   if (total_syms) HIPCHK3(hipMemcpy(d_seqs.p, seqs, (size_t)total_syms, hipMemcpyHostToDevice));
-  HIPCHK3(hipMemcpy(d_off.p, seq_off, sizeof(int64_t) * (size_t)(n_seqs_total + 1), hipMemcpyHostToDevice));
+  HIPCHK3(hipMemcpy(d_off.p, seq_off, off_bytes, hipMemcpyHostToDevice));
   HIPCHK3(hipMemset(d_cells.p, 0, 8));
   hipEvent_t ev0, ev1;
   HIPCHK3(hipEventCreate(&ev0));
   HIPCHK3(hipEventCreate(&ev1));
   std::vector<std::vector<uint8_t>> results((size_t)n_clusters);
-  // fast path: the LDS-resident kernel, sized for the common case (banded rows, a graph ~1.5 x the longest
-  // read); clusters that outgrow that (band lost -> full matrix, more nodes) get a second, roomier LDS
-  // round when that still fits; what is left (status 3) falls through to the HBM kernel:
-  // pass 0 with a banded workspace, pass 1 with a full-size DP pool
+  // fast path: the LDS-resident kernel in up to three rounds of growing generosity -- ring rows of 2w + 33 columns
+  // and a graph of ~1.5 x the longest read (what nearly every sub-cluster needs); then the specification's widest
+  // band (2w + 129) and 3 x; then full-matrix rows (a band that lost the sink).  What is still left (status 3)
+  // falls through to the HBM kernel: pass 0 with a banded workspace, pass 1 with a full-size DP pool
   std::vector<int64_t> todo;
   const bool use_lds = getenv("SVDSS_POA_HBM") == nullptr;
   std::vector<int64_t> cur((size_t)n_clusters), retry;
   for (int64_t c = 0; c < n_clusters; ++c) cur[(size_t)c] = c;
-  for (int round = 0; round < 2 && !cur.empty(); ++round) {
+  int n_cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+  }
+  size_t ws_budget = (size_t)32 << 30;   // bytes of workspace per wave of launches
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws_budget = std::min(ws_budget, (free_b + b->ws_arena.cap) / 2);
+    if (ws_budget < ((size_t)1 << 30)) ws_budget = (size_t)1 << 30;
+  }
+  while (b->streams.size() < 8) {
+    hipStream_t st;
+    HIPCHK3(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    b->streams.push_back(st);
+  }
+  const int n_rounds = 3;
+  for (int round = 0; round < n_rounds && !cur.empty(); ++round) {
     struct Cand { int64_t c; size_t lds; int cols; PoaWaveTask t; };
     std::vector<Cand> cands;
     const size_t LDS_MAX = 160 * 1024 - 512;
@@ -470,14 +526,16 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         tot += l;
         if (l > maxl) maxl = l;
       }
-      // the graph rarely grows beyond ~1.5 x the longest read (round 1: 3 x); a cluster that outgrows its
+      // the graph rarely grows beyond ~1.5 x the longest read (later rounds: 3 x); a cluster that outgrows its
       // allocation is redone.  SVDSS_POA_NC scales the first estimate (percent).
       const int nc_pct = round ? 300 : getenv("SVDSS_POA_NC") ? std::max(atoi(getenv("SVDSS_POA_NC")), 100) : 150;
       int64_t nc = std::min<int64_t>(tot + 2, maxl * nc_pct / 100 + 8 * t.n_seqs + 64);
       if (nc > 65000) nc = 65000;
       const int64_t ecap = std::min<int64_t>(nc + nc / (round ? 2 : 4) + t.n_seqs + 64, 100000);
-      // widest row: the band (round 0) or the full matrix (round 1, after a band fallback did not fit)
-      const int64_t wcap = round ? maxl + 1 : std::min<int64_t>(2 * (10 + (int64_t)(0.01 * (double)maxl)) + 129, maxl + 1);
+      // widest row the ring holds: the band as it is in practice (round 0), as wide as the specification lets it
+      // get (round 1), the full matrix (round 2, after the band lost the sink)
+      const int64_t w_band = 10 + (int64_t)(0.01 * (double)maxl);
+      const int64_t wcap = std::min<int64_t>(round == 0 ? 2 * w_band + 33 : round == 1 ? 2 * w_band + 129 : maxl + 1, maxl + 1);
       int64_t ws = 64;
       while (ws < wcap) ws <<= 1;
       const int64_t rs = (wcap + 3) & ~(int64_t)3;
@@ -486,7 +544,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
       t.nc = (int32_t)nc; t.ec = (int32_t)ecap; t.max_len = (int32_t)maxl; t.ws = (int32_t)ws; t.rs = (int32_t)rs;
       t.ring = (int32_t)ring;
       const size_t lds = poa_wave_lds_bytes(t.nc, t.max_len, t.rs, t.ring);
-      if (!use_lds || lds > LDS_MAX || ws > 4096 || t.n_seqs <= 0 || t.n_seqs > 8191) {
+      if (!use_lds || lds > LDS_MAX || poa_bundle_lds_bytes(t.nc) > LDS_MAX || ws > 4096 || t.n_seqs <= 0 || t.n_seqs > 8191) {
         todo.push_back(c);
         if (t.n_seqs > 0) ++b->n_hbm;
         continue;
@@ -499,20 +557,18 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     // filled by running many of them, whichever launch they came from)
     struct Group {
       int cols = 0;
-      size_t lds = 0;
+      size_t lds = 0, bundle_lds = 0;
       std::vector<PoaWaveTask> tasks;
       std::vector<int64_t> ids;
       int64_t w32 = 0, w8 = 0;
-      DevMem3 d_tasks, d32, d8, d_len, d_st;
-      hipStream_t stream = nullptr;
-      ~Group() { if (stream) (void)hipStreamDestroy(stream); }
+      void *d_tasks = nullptr, *d32 = nullptr, *d8 = nullptr, *d_len = nullptr, *d_st = nullptr;
+      size_t bytes() const {
+        const size_t nt = tasks.size();
+        return DevArena::padded(sizeof(PoaWaveTask) * nt) + DevArena::padded(sizeof(int32_t) * (size_t)w32) +
+               DevArena::padded((size_t)w8) + 2 * DevArena::padded(sizeof(int32_t) * nt);
+      }
     };
     std::vector<std::unique_ptr<Group>> groups;
-    int n_cus = 256;
-    {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
-    }
     const int64_t group_budget32 = (int64_t)2 << 30;    // ints of workspace per launch
     std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.lds > y.lds; });
     for (int ci = 0; ci < 3; ++ci) {
@@ -528,37 +584,40 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
           g = groups.back().get();
           g->cols = kPoaWaveCols[ci];
           g->lds = cd.lds;
-          fill = (size_t)n_cus * std::max<size_t>(1, LDS_MAX / cd.lds);
+          fill = (size_t)n_cus * std::min<size_t>(32, std::max<size_t>(1, LDS_MAX / cd.lds));
         }
         t.ws_off = g->w32; g->w32 += need;
         t.cons_off = g->w8; g->w8 += t.nc;
+        g->bundle_lds = std::max(g->bundle_lds, poa_bundle_lds_bytes(t.nc));
         g->tasks.push_back(t);
         g->ids.push_back(cd.c);
       }
     }
-    // run the groups in waves of at most ~32 GB of workspace
+    // run the groups in waves that fit the workspace budget
     size_t gpos = 0;
     while (gpos < groups.size()) {
-      size_t gend = gpos;
-      int64_t tot32 = 0;
-      while (gend < groups.size() && (gend == gpos || tot32 + groups[gend]->w32 <= ((int64_t)8 << 30))) tot32 += groups[gend++]->w32;
+      size_t gend = gpos, tot_bytes = 0;
+      while (gend < groups.size() && (gend == gpos || tot_bytes + groups[gend]->bytes() <= ws_budget)) tot_bytes += groups[gend++]->bytes();
+      if ((rc = b->ws_arena.reserve(tot_bytes))) return rc;
       for (size_t gi = gpos; gi < gend; ++gi) {
         Group& g = *groups[gi];
         const size_t nt = g.tasks.size();
-        if ((rc = g.d_tasks.alloc(sizeof(PoaWaveTask) * nt)) || (rc = g.d32.alloc(sizeof(int32_t) * (size_t)g.w32)) ||
-            (rc = g.d8.alloc((size_t)g.w8)) || (rc = g.d_len.alloc(sizeof(int32_t) * nt)) || (rc = g.d_st.alloc(sizeof(int32_t) * nt)))
-          return rc;
-        HIPCHK3(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-        HIPCHK3(hipMemcpy(g.d_tasks.p, g.tasks.data(), sizeof(PoaWaveTask) * nt, hipMemcpyHostToDevice));
-        HIPCHK3(hipMemset(g.d_st.p, 0xff, sizeof(int32_t) * nt));
+        g.d_tasks = b->ws_arena.take(sizeof(PoaWaveTask) * nt);
+        g.d32 = b->ws_arena.take(sizeof(int32_t) * (size_t)g.w32);
+        g.d8 = b->ws_arena.take((size_t)g.w8);
+        g.d_len = b->ws_arena.take(sizeof(int32_t) * nt);
+        g.d_st = b->ws_arena.take(sizeof(int32_t) * nt);
+        HIPCHK3(hipMemcpy(g.d_tasks, g.tasks.data(), sizeof(PoaWaveTask) * nt, hipMemcpyHostToDevice));
+        HIPCHK3(hipMemset(g.d_st, 0xff, sizeof(int32_t) * nt));
       }
       HIPCHK3(hipDeviceSynchronize());
       const auto t0 = std::chrono::steady_clock::now();
       for (size_t gi = gpos; gi < gend; ++gi) {
         Group& g = *groups[gi];
-        HIPCHK3(poa_wave_launch(g.cols, (const PoaWaveTask*)g.d_tasks.p, (int)g.tasks.size(), g.lds, (const uint8_t*)d_seqs.p,
-                                (const int64_t*)d_off.p, (int32_t*)g.d32.p, (uint8_t*)g.d8.p, (int32_t*)g.d_len.p,
-                                (int32_t*)g.d_st.p, (unsigned long long*)d_cells.p, g.stream));
+        HIPCHK3(poa_wave_launch(g.cols, (const PoaWaveTask*)g.d_tasks, (int)g.tasks.size(), g.lds, g.bundle_lds,
+                                (const uint8_t*)d_seqs.p, (const int64_t*)d_off.p, (int32_t*)g.d32, (uint8_t*)g.d8,
+                                (int32_t*)g.d_len, (int32_t*)g.d_st, (unsigned long long*)d_cells.p,
+                                b->streams[(gi - gpos) % b->streams.size()]));
       }
       HIPCHK3(hipDeviceSynchronize());
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -571,21 +630,21 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         n_run += nt;
         std::vector<int32_t> lens((size_t)nt), st((size_t)nt);
         std::vector<uint8_t> h8((size_t)g.w8);
-        HIPCHK3(hipMemcpy(lens.data(), g.d_len.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-        HIPCHK3(hipMemcpy(st.data(), g.d_st.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-        if (g.w8) HIPCHK3(hipMemcpy(h8.data(), g.d8.p, (size_t)g.w8, hipMemcpyDeviceToHost));
+        HIPCHK3(hipMemcpy(lens.data(), g.d_len, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+        HIPCHK3(hipMemcpy(st.data(), g.d_st, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+        if (g.w8) HIPCHK3(hipMemcpy(h8.data(), g.d8, (size_t)g.w8, hipMemcpyDeviceToHost));
         for (int64_t k = 0; k < nt; ++k) {
           if (st[(size_t)k] == 0) {
             const uint8_t* src = h8.data() + g.tasks[(size_t)k].cons_off;
             results[(size_t)g.ids[(size_t)k]].assign(src, src + lens[(size_t)k]);
           } else {
             const int reason = (st[(size_t)k] >> 8) & 7;
-            if (round == 0 && (reason == 3 || reason == 4 || reason == 5)) retry.push_back(g.ids[(size_t)k]);
+            if (round + 1 < n_rounds && (reason == 3 || reason == 4 || reason == 5)) retry.push_back(g.ids[(size_t)k]);
             else { todo.push_back(g.ids[(size_t)k]); ++b->n_hbm; }
             ++why[reason];
           }
         }
-        groups[gi].reset();   // frees the workspace
+        groups[gi].reset();
       }
       if (getenv("SVDSS_DEBUG")) poa_wave_debug_report();
       if (getenv("SVDSS_DEBUG"))

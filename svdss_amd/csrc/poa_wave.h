@@ -20,8 +20,10 @@ struct PoaWaveTask {
 static const int kPoaWaveCols[3] = {1, 3, 5};
 
 size_t poa_wave_lds_bytes(int nc, int max_len, int rs, int ring);
+size_t poa_bundle_lds_bytes(int nc);
 int64_t poa_wave_ws_ints(int nc, int ec, int max_len, int ws);
-hipError_t poa_wave_launch(int cols, const PoaWaveTask* d_tasks, int n_tasks, size_t lds_bytes, const uint8_t* d_seqs,
-                           const int64_t* d_seq_off, int32_t* ws32, uint8_t* ws8, int32_t* d_len, int32_t* d_status,
-                           unsigned long long* d_cells, hipStream_t stream);
+// the row-loop kernel followed by the consensus kernel on the same stream
+hipError_t poa_wave_launch(int cols, const PoaWaveTask* d_tasks, int n_tasks, size_t lds_bytes, size_t bundle_lds_bytes,
+                           const uint8_t* d_seqs, const int64_t* d_seq_off, int32_t* ws32, uint8_t* ws8, int32_t* d_len,
+                           int32_t* d_status, unsigned long long* d_cells, hipStream_t stream);
 void poa_wave_debug_report();

@@ -3,12 +3,18 @@
 // Same specification as poa.hip / oracle/svdss_oracle_poa.c, bit for bit.  POA over a dozen ~1 kb reads is
 // a chain of ~10^4 short dependent steps per sub-cluster (graph rows, traceback steps); what bounds it on
 // this machine is the latency of each step and how many sub-clusters a CU can keep in flight, not bandwidth.
-// So the kernel keeps in LDS only what the row loop touches -- ~25 KB per sub-cluster, six per CU:
-//   * one 32-bit descriptor per graph row (base, up to two predecessor-row deltas, flags), rebuilt in
-//     parallel before each read is aligned, so the row loop never chases graph pointers;
+// So the kernel keeps in LDS only what the row loop touches -- ~7 KB per sub-cluster of ~1 kb reads, twenty
+// per CU:
 //   * the read being aligned;
-//   * a ring of the last `ring` DP rows (H, E1, E2) plus two staging rows.
-// The graph itself (int32 arrays) lives in HBM: it is touched by the parallel phases only.
+//   * a ring of the last `ring` DP rows (H, E1, E2) plus two staging rows, as wide as the band gets in
+//     practice (2w + 33 columns; a wider row sends the sub-cluster to a second round with the
+//     specification's 2w + 129).
+// One 32-bit descriptor per graph row (base, up to two predecessor-row deltas, flags) is rebuilt in parallel
+// in HBM before each read is aligned, so the row loop never chases graph pointers: it takes the descriptors
+// of 64 rows at a time into a register and reads them with v_readlane.  The graph itself (int32 arrays)
+// lives in HBM: it is touched by the parallel phases only.  The heaviest-bundle consensus runs as its own
+// small kernel afterwards (poa_bundle_kernel), so that its per-row tables do not count against the LDS of
+// the row loop.
 //
 //   forward    one wavefront computes a DP row per step, C consecutive band columns per lane (C = 1, 3, 5:
 //              odd strides are LDS-bank-conflict free).  The horizontal gap states are prefix maxima
@@ -54,7 +60,7 @@
 struct WsLayout {
   int64_t out_head, in_head, order, index, col, base;
   int64_t row_beg, row_end, hl, prow0, prow1, row_mpl, row_mpr;
-  int64_t aln, scr;
+  int64_t aln, scr, rinfo, keepf;
   int64_t e_from, e_to, e_w, e_next_out, e_next_in;
   int64_t op_node, op_q, path_use, path_aux;
   int64_t gdir, gH, gE1, gE2;
@@ -70,6 +76,7 @@ __host__ __device__ inline WsLayout ws_layout(int nc, int ec, int max_len, int w
   w.row_mpl = take(nc); w.row_mpr = take(nc);
   w.aln = take(5 * (int64_t)nc);
   w.scr = take((int64_t)nc + 64);
+  w.rinfo = take((int64_t)nc + 64); w.keepf = take((int64_t)nc + 64);
   w.e_from = take(ec); w.e_to = take(ec); w.e_w = take(ec); w.e_next_out = take(ec); w.e_next_in = take(ec);
   const int64_t opcap = (int64_t)nc + max_len + 4;
   w.op_node = take(opcap); w.op_q = take(opcap); w.path_use = take(opcap); w.path_aux = take(opcap);
@@ -147,8 +154,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   constexpr int G = 4;            // -inf guard cells on each side of a ring row
   const int RST = RS + 2 * G;     // LDS stride of a ring row
   // ---- LDS
-  uint16_t* rowinfo = (uint16_t*)smem;
-  int32_t* rH = (int32_t*)(smem + ((2 * (size_t)nc + 15) & ~(size_t)15));
+  int32_t* rH = (int32_t*)smem;
   int32_t* rE1 = rH + NS * RST;
   int32_t* rE2 = rE1 + NS * RST;
   int32_t* rbeg = rE2 + NS * RST;
@@ -166,6 +172,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   uint32_t *prow0 = (uint32_t*)(W + wl.prow0), *prow1 = (uint32_t*)(W + wl.prow1);
   int32_t *row_mpl = W + wl.row_mpl, *row_mpr = W + wl.row_mpr;
   int32_t *aln = W + wl.aln, *scr = W + wl.scr;
+  uint32_t *rinfo = (uint32_t*)(W + wl.rinfo), *keepf = (uint32_t*)(W + wl.keepf);
   int32_t *e_from = W + wl.e_from, *e_to = W + wl.e_to, *e_w = W + wl.e_w, *e_next_out = W + wl.e_next_out,
           *e_next_in = W + wl.e_next_in;
   int32_t *op_node = W + wl.op_node, *op_q = W + wl.op_q, *path_use = W + wl.path_use;
@@ -173,7 +180,6 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   uint32_t* gdir = (uint32_t*)(W + wl.gdir);
   int32_t *gH = W + wl.gH, *gE1 = W + wl.gE1, *gE2 = W + wl.gE2;
   const int opcap = nc + T.max_len + 4;
-  uint8_t* cons = ws8 + T.cons_off;
   const int n = (int)T.n_seqs;
   unsigned long long my_cells = 0;
   unsigned long long prof[5] = {0, 0, 0, 0, 0}, prof_t;
@@ -218,25 +224,29 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
     if (L > T.max_len) FAIL(3 | (6 << 8));
     PROF_T();
     for (int j = lane; j < L; j += 64) q[j] = qg[j];
-    // ---------------------------------------------------------- row descriptors
-    for (int r = lane; r < N; r += 64) {
-      const int v = order[r];
-      uint32_t ri = (uint32_t)base[v] & 7u;
-      int np = 0, d0 = 0, d1 = 0;
-      for (int e = in_head[v]; e >= 0; e = e_next_in[e]) {
-        const int d = r - index[e_from[e]];
-        if (np == 0) d0 = d; else if (np == 1) d1 = d;
-        ++np;
+    // ---------------------------------------------------------- row descriptors (HBM)
+    for (int r = lane; r < N + 64; r += 64) {
+      uint32_t ri = 0;
+      if (r < N) {
+        const int v = order[r];
+        ri = (uint32_t)base[v] & 7u;
+        int np = 0, d0 = 0, d1 = 0;
+        for (int e = in_head[v]; e >= 0; e = e_next_in[e]) {
+          const int d = r - index[e_from[e]];
+          if (np == 0) d0 = d; else if (np == 1) d1 = d;
+          ++np;
+        }
+        if (np > 2 || d0 > 31 || d1 > 31) ri |= RI_SLOW << 3;
+        else ri |= ((uint32_t)np << 3) | ((uint32_t)d0 << 5) | ((uint32_t)d1 << 10);
       }
-      if (np > 2 || d0 > 31 || d1 > 31) ri |= RI_SLOW << 3;
-      else ri |= ((uint32_t)np << 3) | ((uint32_t)d0 << 5) | ((uint32_t)d1 << 10);
-      rowinfo[r] = (uint16_t)ri;
+      rinfo[r] = ri;
+      keepf[r] = 0;
     }
     __syncthreads();
-    // flag the rows that are read back after they left the ring (32-bit LDS atomics on the word that holds the flag)
-    auto flag_row = [&](int rr) { atomicOr((uint32_t*)rowinfo + (rr >> 1), 0x8000u << (16 * (rr & 1))); };
+    // flag the rows that are read back after they left the ring (plain stores of the same value: no atomics needed)
+    auto flag_row = [&](int rr) { keepf[rr] = 0x8000u; };
     for (int r = lane; r < N - 1; r += 64) {
-      const uint32_t ri = rowinfo[r];
+      const uint32_t ri = rinfo[r];
       const uint32_t np = (ri >> 3) & 3u;
       if (np == RI_SLOW) {
         for (int e = in_head[order[r]]; e >= 0; e = e_next_in[e]) {
@@ -273,12 +283,13 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         if (lane == 0) { rbeg[s] = pb; rend[s] = pe; rmpl[s] = row_mpl[ur]; rmpr[s] = row_mpr[ur]; }
         __syncthreads();
       };
-      uint32_t ri_n = rowinfo[0];   // (row N-1, the sink, has a descriptor too: r + 1 below stays in range)
+      uint32_t ri_blk = 0;          // descriptors of rows [blk0, blk0 + 64), one per lane
+      int blk0 = -64;
       // ------------------------------------------------------------ forward (the sink is order[N-1])
       for (int r = 0; r < N - 1; ++r) {
         FP(5);
-        const uint32_t ri = __builtin_amdgcn_readfirstlane(ri_n);
-        ri_n = rowinfo[r + 1];
+        if (r - blk0 >= 64) { blk0 = r; ri_blk = rinfo[r + lane] | keepf[r + lane]; }   // (both arrays are N + 64 long)
+        const uint32_t ri = __builtin_amdgcn_readlane(ri_blk, r - blk0);
         const int slot = r & rm;
         const int bv = (int)(ri & 7u);
         int np = (int)((ri >> 3) & 3u);
@@ -748,73 +759,88 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
     __syncthreads();
     PROF_ADD(3);
   }
-  // ----------------------------------------------------------- heaviest bundle
-  PROF_T();
-  {
-    const int N = sh[0];
-    // per row: up to two successors (row, weight) and the base, staged in LDS; rows with more go to the graph
-    uint32_t* succ0 = (uint32_t*)smem;
-    uint32_t* succ1 = succ0 + nc;
-    int32_t* score = (int32_t*)(succ1 + nc);
-    __syncthreads();
-    if (n > 8191) FAIL(3 | (7 << 8));
-    for (int r = lane; r < N; r += 64) {
-      const int v = order[r];
-      uint32_t s0 = 0xFFFFu, s1 = 0xFFFFu;   // row 0xFFFF: none; weight 0x1FFF in s1: more than two, walk the list
-      int k = 0;
-      for (int e = out_head[v]; e >= 0; e = e_next_out[e]) {
-        const uint32_t ent = (uint32_t)index[e_to[e]] | ((uint32_t)e_w[e] << 16);
-        if (k == 0) s0 = ent; else if (k == 1) s1 = ent;
-        ++k;
-      }
-      if (k > 2) s1 = 0xFFFFu | (0x1FFFu << 16);
-      succ0[r] = s0 | ((uint32_t)base[v] << 29);
-      succ1[r] = s1;
-    }
-    __syncthreads();
-    if (lane == 0) {
-      for (int r = N - 1; r >= 0; --r) {
-        const uint32_t s0 = succ0[r], s1 = succ1[r];
-        int bst = -1, bw = -1; int32_t bsc = -1;
-        if ((s1 & 0xFFFFu) == 0xFFFFu && ((s1 >> 16) & 0x1FFFu) == 0x1FFFu) {
-          for (int e = out_head[order[r]]; e >= 0; e = e_next_out[e]) {
-            const int x = index[e_to[e]], wgt = e_w[e];
-            const int32_t sx = score[x];
-            if (wgt > bw || (wgt == bw && sx > bsc)) { bw = wgt; bsc = sx; bst = x; }
-          }
-        } else {
-          if ((s0 & 0xFFFFu) != 0xFFFFu) { bst = (int)(s0 & 0xFFFFu); bw = (int)((s0 >> 16) & 0x1FFFu); bsc = score[bst]; }
-          if ((s1 & 0xFFFFu) != 0xFFFFu) {
-            const int x = (int)(s1 & 0xFFFFu), wgt = (int)((s1 >> 16) & 0x1FFFu);
-            const int32_t sx = score[x];
-            if (wgt > bw || (wgt == bw && sx > bsc)) { bw = wgt; bsc = sx; bst = x; }
-          }
-        }
-        succ1[r] = (uint32_t)bst;
-        score[r] = bst >= 0 ? bw + bsc : 0;
-      }
-      int len = 0;
-      const int sink_row = N - 1;
-      for (int r = (int)succ1[0]; r >= 0 && r != sink_row; r = (int)succ1[r]) cons[len++] = (uint8_t)(succ0[r] >> 29);
-      cons_len[blockIdx.x] = len;
-      status[blockIdx.x] = 0;
-      atomicAdd(cells, my_cells);
-      PROF_ADD(4);
-      for (int k = 0; k < 5; ++k) atomicAdd(&g_poaw_prof[k], prof[k]);
+  // the heaviest-bundle consensus is poa_bundle_kernel's job: hand over the number of graph rows
+  if (lane == 0) {
+    cons_len[blockIdx.x] = sh[0];
+    status[blockIdx.x] = 0;
+    atomicAdd(cells, my_cells);
+    for (int k = 0; k < 5; ++k) atomicAdd(&g_poaw_prof[k], prof[k]);
 #ifdef POA_FINE_PROF
-      for (int k = 0; k < 6; ++k) printf("fp%d %lld\n", k, fp[k]);
+    for (int k = 0; k < 6; ++k) printf("fp%d %lld\n", k, fp[k]);
 #endif
-    }
   }
 #undef FAIL
 }
 
-size_t poa_wave_lds_bytes(int nc, int max_len, int rs, int ring) {
-  const size_t ns = (size_t)ring + 2;
-  const size_t fwd = ((2 * (size_t)nc + 15) & ~(size_t)15) + 12 * ns * ((size_t)rs + 8) + 16 * ns + 64 + (((size_t)max_len + 15) & ~(size_t)15);
-  const size_t bundle = 12 * (size_t)nc;
-  return (fwd > bundle ? fwd : bundle) + 64;
+// ----------------------------------------------------------- heaviest bundle (consensus), one wavefront per sub-cluster
+// in: cons_len[task] = number of graph rows N left by poa_wave_kernel (status 0); out: the consensus and its length
+__global__ void __launch_bounds__(64) poa_bundle_kernel(const PoaWaveTask* tasks, int32_t* ws32, uint8_t* ws8, int32_t* cons_len,
+                                                       const int32_t* status) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (status[blockIdx.x] != 0) return;
+  const PoaWaveTask T = tasks[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int nc = T.nc;
+  const int N = cons_len[blockIdx.x];
+  if (T.n_seqs <= 0 || N <= 0) return;   // (an empty sub-cluster already has length 0)
+  const WsLayout wl = ws_layout(nc, T.ec, T.max_len, T.ws);
+  int32_t* W = ws32 + T.ws_off;
+  const int32_t *out_head = W + wl.out_head, *order = W + wl.order, *index = W + wl.index, *base = W + wl.base;
+  const int32_t *e_to = W + wl.e_to, *e_w = W + wl.e_w, *e_next_out = W + wl.e_next_out;
+  uint8_t* cons = ws8 + T.cons_off;
+  // per row: up to two successors (row, weight) and the base, staged in LDS; rows with more go to the graph
+  uint32_t* succ0 = (uint32_t*)smem;
+  uint32_t* succ1 = succ0 + nc;
+  int32_t* score = (int32_t*)(succ1 + nc);
+  for (int r = lane; r < N; r += 64) {
+    const int v = order[r];
+    uint32_t s0 = 0xFFFFu, s1 = 0xFFFFu;   // row 0xFFFF: none; weight 0x1FFF in s1: more than two, walk the list
+    int k = 0;
+    for (int e = out_head[v]; e >= 0; e = e_next_out[e]) {
+      const uint32_t ent = (uint32_t)index[e_to[e]] | ((uint32_t)e_w[e] << 16);
+      if (k == 0) s0 = ent; else if (k == 1) s1 = ent;
+      ++k;
+    }
+    if (k > 2) s1 = 0xFFFFu | (0x1FFFu << 16);
+    succ0[r] = s0 | ((uint32_t)base[v] << 29);
+    succ1[r] = s1;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    for (int r = N - 1; r >= 0; --r) {
+      const uint32_t s0 = succ0[r], s1 = succ1[r];
+      int bst = -1, bw = -1; int32_t bsc = -1;
+      if ((s1 & 0xFFFFu) == 0xFFFFu && ((s1 >> 16) & 0x1FFFu) == 0x1FFFu) {
+        for (int e = out_head[order[r]]; e >= 0; e = e_next_out[e]) {
+          const int x = index[e_to[e]], wgt = e_w[e];
+          const int32_t sx = score[x];
+          if (wgt > bw || (wgt == bw && sx > bsc)) { bw = wgt; bsc = sx; bst = x; }
+        }
+      } else {
+        if ((s0 & 0xFFFFu) != 0xFFFFu) { bst = (int)(s0 & 0xFFFFu); bw = (int)((s0 >> 16) & 0x1FFFu); bsc = score[bst]; }
+        if ((s1 & 0xFFFFu) != 0xFFFFu) {
+          const int x = (int)(s1 & 0xFFFFu), wgt = (int)((s1 >> 16) & 0x1FFFu);
+          const int32_t sx = score[x];
+          if (wgt > bw || (wgt == bw && sx > bsc)) { bw = wgt; bsc = sx; bst = x; }
+        }
+      }
+      succ1[r] = (uint32_t)bst;
+      score[r] = bst >= 0 ? bw + bsc : 0;
+    }
+    int len = 0;
+    const int sink_row = N - 1;
+    for (int r = (int)succ1[0]; r >= 0 && r != sink_row; r = (int)succ1[r]) cons[len++] = (uint8_t)(succ0[r] >> 29);
+    cons_len[blockIdx.x] = len;
+  }
 }
+
+size_t poa_wave_lds_bytes(int nc, int max_len, int rs, int ring) {
+  (void)nc;
+  const size_t ns = (size_t)ring + 2;
+  return 12 * ns * ((size_t)rs + 8) + 16 * ns + 64 + (((size_t)max_len + 15) & ~(size_t)15) + 64;
+}
+
+size_t poa_bundle_lds_bytes(int nc) { return 12 * (size_t)nc + 64; }
 
 int64_t poa_wave_ws_ints(int nc, int ec, int max_len, int ws) { return ws_layout(nc, ec, max_len, ws).total; }
 
@@ -829,15 +855,20 @@ static hipError_t launch_c(const PoaWaveTask* d_tasks, int n_tasks, size_t lds_b
   return hipGetLastError();
 }
 
-hipError_t poa_wave_launch(int cols, const PoaWaveTask* d_tasks, int n_tasks, size_t lds_bytes, const uint8_t* d_seqs,
-                           const int64_t* d_seq_off, int32_t* ws32, uint8_t* ws8, int32_t* d_len, int32_t* d_status,
-                           unsigned long long* d_cells, hipStream_t stream) {
+hipError_t poa_wave_launch(int cols, const PoaWaveTask* d_tasks, int n_tasks, size_t lds_bytes, size_t bundle_lds_bytes,
+                           const uint8_t* d_seqs, const int64_t* d_seq_off, int32_t* ws32, uint8_t* ws8, int32_t* d_len,
+                           int32_t* d_status, unsigned long long* d_cells, hipStream_t stream) {
   hipError_t e;
   if (cols == 1) e = launch_c<1>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
   else if (cols == 3) e = launch_c<3>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
   else if (cols == 5) e = launch_c<5>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
   else return hipErrorInvalidValue;
-  return e;
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)poa_bundle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bundle_lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(poa_bundle_kernel, dim3((unsigned)n_tasks), dim3(64), bundle_lds_bytes, stream, d_tasks, ws32, ws8, d_len,
+                     (const int32_t*)d_status);
+  return hipGetLastError();
 }
 
 // SVDSS_DEBUG: in-kernel phase timers summed over the sub-clusters run since the last call

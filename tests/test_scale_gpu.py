@@ -1,0 +1,173 @@
+"""Parity at the sizes and table orders the product actually runs: K = 14 / 16 tables checked
+bit for bit against the oracle, BASELINE config 2 (chr20 length, 3x), a reference above 2^31 BWT symbols (64-bit
+suffix array and intervals where 32 bits would overflow), and the index builder of csrc/index_gpu.hip against the
+host builder.  Integer work: every comparison is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import svdss_amd
+from svdss_amd import synth
+from tests import oracle_lib as O
+from tests.common import small_workload, split
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(ix, flat, offs, assemble):
+    pp = svdss_amd.PingPong(ix, assemble=assemble)
+    b = pp.ping_pong_search(flat, offs)
+    segs, fb = pp.last_segments, pp.last_fallbacks
+    pp.close()
+    return b, segs, fb
+
+
+def _same(got, c, q, l, e):
+    assert (got.counts == c).all() and (got.n_ext == e).all()
+    assert (got.qs == q).all() and (got.len == l).all()
+
+
+@pytest.mark.parametrize("kmer", ["14", "16"])
+def test_large_table_orders_match_oracle(monkeypatch, kmer):
+    """The table orders of chr20 / GRCh38 runs (K = 14..16) on a reference small enough for the full oracle: at
+    K = 16 the `K >= 16` masks of sv_ring_kmer / sv_key_revcomp, the shift-by-0 path and the 64 GiB table build run;
+    1,200 reads, so both the several-lanes-per-read launch (with heavy-first ordering) and the one-lane launch."""
+    monkeypatch.setenv("SVDSS_KMER", kmer)
+    ref, hap, svs, flat, offs = small_workload(seed=61, ref_lens=(300000, 120000), n_reads=1200, read_len=3000)
+    ix = svdss_amd.FMDIndex.build(ref, device=0)
+    assert ix.kmer_k == int(kmer)
+    fm = O.OracleFMD.build(ref)
+    for assemble in (True, False):
+        c, q, l, e = fm.search_batch(flat, offs, assemble)
+        got, segs, _ = _search(ix, flat, offs, assemble)
+        assert segs > 1                       # small batch: segmented launch
+        _same(got, c, q, l, e)
+        monkeypatch.setenv("SVDSS_SEGMENTS", "1")
+        got1, segs1, _ = _search(ix, flat, offs, assemble)
+        monkeypatch.delenv("SVDSS_SEGMENTS")
+        assert segs1 == 1
+        _same(got1, c, q, l, e)
+    assert c.sum() > 1200 * 5
+    # reads with N and reads shorter than K
+    extra = [np.full(40, 5, np.uint8), flat[offs[3]:offs[3] + 9].copy(), flat[offs[5]:offs[5] + 16].copy(),
+             np.concatenate([flat[offs[7]:offs[7] + 500], np.full(3, 5, np.uint8), flat[offs[7] + 500:offs[7] + 900]])]
+    eflat, eoffs = svdss_amd.pack_reads(extra)
+    c, q, l, e = fm.search_batch(eflat, eoffs, False)
+    got, _, _ = _search(ix, eflat, eoffs, False)
+    _same(got, c, q, l, e)
+
+
+def test_config2_chr20_3x():
+    """BASELINE config 2: chr20-length contig (64,444,167 bp), 12,889 reads of 15 kb (3x), K = 16 chosen by the
+    library itself.  A sample of the reads against the oracle (index contents handed over as a BWT), every read
+    against the one-lane launch, and the size-independent properties of an SFS set on all of them."""
+    L, n_reads = 15000, 12889
+    ref = synth.make_reference([64_444_167], seed=11)
+    ix = svdss_amd.FMDIndex.build(ref, device=0)
+    assert ix.kmer_k == 16 and ix.size == 2 * (64_444_167 + 1)
+    hap, svs = synth.implant_svs(ref, 64, seed=12)
+    flat, offs, truth = synth.simulate_reads(hap, n_reads, L, 0.005, seed=13)
+    raw, segs, _ = _search(ix, flat, offs, False)
+    asm, _, _ = _search(ix, flat, offs, True)
+    assert segs > 1
+    os.environ["SVDSS_SEGMENTS"] = "1"
+    try:
+        raw1, segs1, _ = _search(ix, flat, offs, False)
+    finally:
+        del os.environ["SVDSS_SEGMENTS"]
+    assert segs1 == 1
+    _same(raw1, raw.counts, raw.qs, raw.len, raw.n_ext)
+    # oracle on a sample (every 16th read: ~800 reads)
+    fm = O.OracleFMD.from_bwt(ix.bwt())
+    sub = list(range(0, n_reads, 16))
+    sflat, soffs = svdss_amd.pack_reads([flat[offs[i]:offs[i + 1]] for i in sub])
+    rr, aa = raw.per_read(), asm.per_read()
+    c, q, l, e = fm.search_batch(sflat, soffs, False)
+    assert (raw.counts[sub] == c).all() and (raw.n_ext[sub] == e).all()
+    assert split(c, q, l) == [rr[i] for i in sub]
+    c, q, l, e = fm.search_batch(sflat, soffs, True)
+    assert (asm.counts[sub] == c).all()
+    assert split(c, q, l) == [aa[i] for i in sub]
+    # properties on every read: strictly descending starts and ends, assembly = oracle's assemble of the raw list
+    qs, ln, cnt = raw.qs.astype(np.int64), raw.len.astype(np.int64), raw.counts
+    rid = np.repeat(np.arange(n_reads), cnt)
+    same = rid[1:] == rid[:-1]                       # adjacent records of one read
+    assert (qs[1:][same] < qs[:-1][same]).all()
+    assert ((qs + ln)[1:][same] < (qs + ln)[:-1][same]).all()
+    assert (qs >= 0).all() and (qs + ln <= L).all() and (ln > 0).all()
+    for i in range(0, n_reads, 97):
+        assert aa[i] == O.assemble(rr[i])
+    # reads that cover an implanted SV breakpoint carry an SFS over it (truth recovery at the read level)
+    assert raw.counts.sum() > n_reads * 300
+
+
+def test_reference_above_2_31_symbols():
+    """A 1.1 Gb contig: 2.2e9 BWT symbols, past the 32-bit range -- the <uint64_t> kernel instantiation and the
+    64-bit suffix array run where 32 bits would overflow (SVDSS_FORCE_SA64 only ever exercised them at 230 kb).
+    Built in HBM by csrc/index_gpu.hip (several pieces), checked against the oracle on a sample of the reads."""
+    L, n_reads = 15000, 2048
+    n_ref = 1_100_000_000
+    ref = synth.make_reference([n_ref], seed=81)
+    ix = svdss_amd.FMDIndex.build(ref, device=0)
+    assert ix.size == 2 * (n_ref + 1) > 2 ** 31
+    # reads from the far end of the contig, so that text positions and SA indices above 2^31 and 2^32 are hit
+    tail = [ref[0][n_ref - 40_000_000:]]
+    hap, svs = synth.implant_svs(tail, 8, seed=82)
+    flat, offs, truth = synth.simulate_reads(hap, n_reads, L, 0.005, seed=83)
+    raw, _, _ = _search(ix, flat, offs, False)
+    asm, _, _ = _search(ix, flat, offs, True)
+    exact = [ref[0][n_ref - 20000:n_ref - 5000].copy(), synth.revcomp(ref[0][n_ref - 20000:n_ref - 5000]),
+             ref[0][:L].copy()]
+    eflat, eoffs = svdss_amd.pack_reads(exact)
+    got, _, _ = _search(ix, eflat, eoffs, False)
+    assert got.counts.sum() == 0 and (got.n_ext == L - 1).all()
+    fm = O.OracleFMD.from_bwt(ix.bwt())
+    sub = list(range(0, n_reads, 8))
+    sflat, soffs = svdss_amd.pack_reads([flat[offs[i]:offs[i + 1]] for i in sub])
+    rr, aa = raw.per_read(), asm.per_read()
+    c, q, l, e = fm.search_batch(sflat, soffs, False)
+    assert (raw.counts[sub] == c).all() and (raw.n_ext[sub] == e).all()
+    assert split(c, q, l) == [rr[i] for i in sub]
+    c, q, l, e = fm.search_batch(sflat, soffs, True)
+    assert split(c, q, l) == [aa[i] for i in sub]
+    assert raw.counts.sum() > n_reads * 300
+
+
+@pytest.mark.parametrize("piece", [None, "100000", "20000"])
+@pytest.mark.parametrize("wide", [False, True])
+def test_index_built_in_hbm_is_the_host_builders_index(monkeypatch, tmp_path, piece, wide):
+    """svdss_index_build_device (csrc/index_gpu.hip: text, bucketed key sort, prefix doubling on the tied suffixes,
+    BWT blocks from wave ballots) writes the file the host builder writes, for one piece and for many small ones,
+    32- and 64-bit suffix arrays; long repeats, N runs, several contigs, a tandem repeat."""
+    ref = synth.make_reference([180000, 90000, 700], seed=33, repeat_frac=0.5, divergence=0.0005, n_runs=(500, 30))
+    ref.append(np.tile(np.array([1, 2, 3, 4], np.uint8), 3000))
+    if wide:
+        monkeypatch.setenv("SVDSS_FORCE_SA64", "1")
+    monkeypatch.setenv("SVDSS_INDEX_CPU", "1")
+    svdss_amd.FMDIndex.build(ref).save(str(tmp_path / "cpu.fmd"))
+    monkeypatch.delenv("SVDSS_INDEX_CPU")
+    if piece:
+        monkeypatch.setenv("SVDSS_SA_PIECE", piece)
+    g = svdss_amd.FMDIndex.build(ref, device=0)
+    g.save(str(tmp_path / "gpu.fmd"))
+    assert (tmp_path / "gpu.fmd").read_bytes() == (tmp_path / "cpu.fmd").read_bytes()
+    # and it is searchable as built (resident, k-mer table included)
+    flat, offs, _ = synth.simulate_reads(ref[:2], 64, 1500, 0.005, seed=5)
+    fm = O.OracleFMD.build(ref)
+    got, _, _ = _search(g, flat, offs, True)
+    _same(got, *fm.search_batch(flat, offs, True))
+
+
+def test_degenerate_text_falls_back_to_the_host_builder(monkeypatch, tmp_path):
+    """One 4-symbol bucket larger than a piece (poly-A) is refused by the GPU sorter; svdss_index_build_device then
+    builds on the host and uploads -- same index, no error."""
+    ref = [np.full(5000, 1, np.uint8), synth.make_reference([3000], seed=2)[0]]
+    monkeypatch.setenv("SVDSS_INDEX_CPU", "1")
+    svdss_amd.FMDIndex.build(ref).save(str(tmp_path / "cpu.fmd"))
+    monkeypatch.delenv("SVDSS_INDEX_CPU")
+    monkeypatch.setenv("SVDSS_SA_PIECE", "3000")
+    g = svdss_amd.FMDIndex.build(ref, device=0)
+    g.save(str(tmp_path / "gpu.fmd"))
+    assert (tmp_path / "gpu.fmd").read_bytes() == (tmp_path / "cpu.fmd").read_bytes()
+    assert g.kmer_k > 0
