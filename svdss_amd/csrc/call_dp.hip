@@ -3,19 +3,27 @@
 //     (consensus -> reference window, global, dual affine gap, full matrix, CIGAR)
 //   * rapidfuzz::fuzz::ratio(a, b)                              /root/reference/caller.cpp:456,458
 //
-// Both are integer DPs whose anti-diagonals are independent: one workgroup per
-// pair sweeps the anti-diagonals, lanes stride over the cells of a diagonal,
-// the previous two diagonals stay resident (LDS when they fit, HBM otherwise).
+// Both are integer DPs whose anti-diagonals are independent.
+//   realignment: one WAVEFRONT per pair, no LDS and no barrier.  The target is cut into stripes of 64 rows, lane l
+//     owns row 64 s + l; at step tau the lane computes column tau - l, so the wave sweeps an anti-diagonal per step:
+//     H/F/F2 of (i, j-1) are the lane's own registers, H/E/E2 of (i-1, j) arrive from lane l-1 with one DPP shift
+//     each, H of (i-1, j-1) is last step's shifted H.  The last row of a stripe leaves H/E/E2 per column in a
+//     boundary buffer the next stripe's lane 0 reads 64 columns at a time.  ~1 wave instruction per cell; the chip is
+//     filled by running thousands of pairs at once (longest first).
+//   ratio: one workgroup per pair sweeps the anti-diagonals, the previous two diagonals stay resident in LDS.
 // Not HBM- and not MFMA-bound: the figure of merit is cell updates/s.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/svdss_hip.h"
+#include "dev_arena.h"
 
 extern thread_local std::string g_svdss_hip_err;
 
@@ -40,105 +48,126 @@ __device__ __forceinline__ int dp_gap(int l, const GapModel& g) {
 
 struct AlnPair {
   int64_t q_off, t_off;   // into the concatenated query / target symbol buffers
-  int64_t ws_off;         // int32 workspace: 11 arrays of (tl + 1)
+  int64_t bnd_off;        // int32 workspace: 2 x 3 arrays of (ql + 64): H, E, E2 of a stripe's last row (in / out)
   int64_t dir_off;        // (tl+ql)*tl direction bytes, diagonal-major: cell (i, j) at (i+j)*tl + i
   int64_t cig_off;        // uint32 ops in backtrack order, capacity tl + ql + 2
   int32_t ql, tl;
+  int32_t slot;           // index of the pair in the caller's order (results are written there)
+  int32_t pad_;
 };
 
-// barrier that orders LDS traffic only (the direction bytes stream out to HBM on every diagonal; waiting for them
-// at each of the ~2000 barriers of a pair would cost more than the diagonal itself)
-__device__ __forceinline__ void dp_lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+__device__ __forceinline__ int dp_shr1(int x) {   // value of the lane below (lane 0: unchanged, it is overwritten)
+  return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false);
 }
 
-// One workgroup per pair.  Cell (i, j): i indexes the target, j the query, r = i + j.
+// One wavefront per pair.  Cell (i, j): i indexes the target, j the query.
 // Recurrences and tie rules are those of ksw2's extd2 (left-aligned), see the oracle
 // (oracle/svdss_oracle_call.c, orc_ksw_extd2_global) which this kernel must match bit for bit.
-// The rotating diagonals (H of r-1 and r-2, the four gap states of r-1: 11 arrays of tl+1) live in LDS when
-// they fit (LDS = true, 44 bytes per target symbol), else in the HBM workspace.
-template <bool LDS>
-__global__ void __launch_bounds__(DP_THREADS) align_global_kernel(
+__global__ void __launch_bounds__(64) align_wave_kernel(
     const AlnPair* pairs, const uint8_t* qsyms, const uint8_t* tsyms, int m, const int8_t* mat_g,
     GapModel gm, int32_t* ws, uint8_t* dirs, uint32_t* cigars, int32_t* scores, int32_t* n_cigar) {
-  extern __shared__ int32_t dp_lds[];
-  __shared__ int8_t mat[64];
   const AlnPair P = pairs[blockIdx.x];
   const int ql = P.ql, tl = P.tl;
-  if (threadIdx.x < m * m && threadIdx.x < 64) mat[threadIdx.x] = mat_g[threadIdx.x];
+  const int lane = threadIdx.x;
   if (ql <= 0 || tl <= 0) {   // ksw2 returns before touching ez: score 0, no CIGAR
-    if (threadIdx.x == 0) { scores[blockIdx.x] = 0; n_cigar[blockIdx.x] = 0; }
+    if (lane == 0) { scores[P.slot] = 0; n_cigar[P.slot] = 0; }
     return;
   }
-  const int stride = tl + 1;
-  int32_t* buf = LDS ? dp_lds : ws + P.ws_off;
-  // the two sequences sit behind the diagonals in LDS (a global byte load per cell would put ~1 us of latency on
-  // every diagonal)
   const uint8_t* q = qsyms + P.q_off;
   const uint8_t* t = tsyms + P.t_off;
-  if (LDS) {
-    uint8_t* sq = (uint8_t*)(dp_lds + 11 * stride);
-    uint8_t* st_ = sq + ql;
-    for (int x = threadIdx.x; x < ql; x += DP_THREADS) sq[x] = q[x];
-    for (int x = threadIdx.x; x < tl; x += DP_THREADS) st_[x] = t[x];
-    q = sq;
-    t = st_;
-  }
-  // array k of the 11 at buf + k * stride: H x3 (rotating: needs r-1 and r-2), then E, F, E2, F2 x2 (r-1)
   uint8_t* dir = dirs + P.dir_off;
+  const int bstride = ql + 64;
+  int32_t* bnd = ws + P.bnd_off;
+  // boundary above row 0: H(-1, j) = -gap(j + 1), no gap state
+  for (int j = lane; j < ql; j += 64) { bnd[j] = -dp_gap(j + 1, gm); bnd[bstride + j] = DP_NEG; bnd[2 * bstride + j] = DP_NEG; }
   __syncthreads();
-  const int n_diag = tl + ql - 1;
-  for (int r = 0; r < n_diag; ++r) {
-    const int32_t* Hm1 = buf + ((r + 2) % 3) * stride;
-    const int32_t* Hm2 = buf + ((r + 1) % 3) * stride;
-    int32_t* Hc = buf + (r % 3) * stride;
-    const int cur = r & 1, prv = cur ^ 1;
-    const int32_t *Ep_ = buf + (3 + prv) * stride, *Fp_ = buf + (5 + prv) * stride;
-    const int32_t *E2p_ = buf + (7 + prv) * stride, *F2p_ = buf + (9 + prv) * stride;
-    int32_t *Ec = buf + (3 + cur) * stride, *Fc = buf + (5 + cur) * stride;
-    int32_t *E2c = buf + (7 + cur) * stride, *F2c = buf + (9 + cur) * stride;
-    const int ilo = r - (ql - 1) > 0 ? r - (ql - 1) : 0;
-    const int ihi = r < tl - 1 ? r : tl - 1;
-    for (int i = ilo + (int)threadIdx.x; i <= ihi; i += DP_THREADS) {
-      const int j = r - i;
-      int32_t hdiag, hup, hleft, Ep, E2p, Fp, F2p;
-      if (i > 0 && j > 0) hdiag = Hm2[i - 1];
-      else if (i == 0) hdiag = j == 0 ? 0 : -dp_gap(j, gm);
-      else hdiag = -dp_gap(i, gm);
-      if (i > 0) { hup = Hm1[i - 1]; Ep = Ep_[i - 1]; E2p = E2p_[i - 1]; }
-      else { hup = -dp_gap(j + 1, gm); Ep = DP_NEG; E2p = DP_NEG; }
-      if (j > 0) { hleft = Hm1[i]; Fp = Fp_[i]; F2p = F2p_[i]; }
-      else { hleft = -dp_gap(i + 1, gm); Fp = DP_NEG; F2p = DP_NEG; }
-      const int32_t Ein = (hup - gm.q > Ep ? hup - gm.q : Ep) - gm.e;
-      const int32_t E2in = (hup - gm.q2 > E2p ? hup - gm.q2 : E2p) - gm.e2;
-      const int32_t Fin = (hleft - gm.q > Fp ? hleft - gm.q : Fp) - gm.e;
-      const int32_t F2in = (hleft - gm.q2 > F2p ? hleft - gm.q2 : F2p) - gm.e2;
-      int32_t z = hdiag + mat[t[i] * m + q[j]];
-      uint32_t d = 0;
-      if (Ein > z) { d = 1; z = Ein; }
-      if (Fin > z) { d = 2; z = Fin; }
-      if (E2in > z) { d = 3; z = E2in; }
-      if (F2in > z) { d = 4; z = F2in; }
-      if (Ein > z - gm.q) d |= 0x08;
-      if (Fin > z - gm.q) d |= 0x10;
-      if (E2in > z - gm.q2) d |= 0x20;
-      if (F2in > z - gm.q2) d |= 0x40;
-      dir[(int64_t)r * tl + i] = (uint8_t)d;   // diagonal-major: the lanes of a diagonal write consecutive bytes
-      Hc[i] = z;
-      Ec[i] = Ein; E2c[i] = E2in;
-      Fc[i] = Fin; F2c[i] = F2in;
+  const int n_stripes = (tl + 63) >> 6;
+  int32_t final_score = 0;
+  for (int s = 0; s < n_stripes; ++s) {
+    const int32_t* bin = bnd + (s & 1) * 3 * bstride;
+    int32_t* bout = bnd + ((s & 1) ^ 1) * 3 * bstride;
+    const int i = (s << 6) + lane;
+    const bool row_ok = i < tl;
+    const int rows = tl - (s << 6) < 64 ? tl - (s << 6) : 64;
+    const bool writes_bnd = lane == 63 && s + 1 < n_stripes;
+    // substitution scores of this row's target symbol, one byte per query symbol (m <= 8)
+    uint64_t rowbits = 0;
+    {
+      const int ti = row_ok ? t[i] : 0;
+      for (int k = 0; k < m; ++k) rowbits |= (uint64_t)(uint8_t)mat_g[ti * m + k] << (8 * k);
     }
-    if (LDS) dp_lds_barrier(); else __syncthreads();
+    int32_t Hl = -dp_gap(i + 1, gm), Fl = DP_NEG, F2l = DP_NEG;          // (i, j-1): the column left of j = 0
+    int32_t Hout = 0, Eout = DP_NEG, E2out = DP_NEG;                    // what the lane above reads next step
+    int32_t Hd = 0;                                                     // (i-1, j-1)
+    int qcur = 0;
+    const int n_steps = ql + rows - 1;
+    // the next 64 columns of the query and of the boundary row, one per lane, fetched a block ahead
+    int32_t nH = 0, nE = 0, nE2 = 0;
+    int nq = 0;
+    auto fetch = [&](int tau0) {
+      const int jj = tau0 + lane;
+      const bool in = jj < ql;
+      nq = in ? q[jj] : 0;
+      nH = in ? bin[jj] : 0; nE = in ? bin[bstride + jj] : 0; nE2 = in ? bin[2 * bstride + jj] : 0;
+    };
+    fetch(0);
+    uint8_t* dcell = dir + (int64_t)(s << 6) * tl + i;   // cell (i, j) at (i + j) * tl + i: + tl per step
+    for (int tau0 = 0; tau0 < n_steps; tau0 += 64) {
+      // wait for the block here, once, so that the 64 steps below never wait on memory (their direction-byte stores
+      // stay in flight: vmcnt counts stores too)
+      asm volatile("" : "+v"(nq), "+v"(nH), "+v"(nE), "+v"(nE2));
+      const int qblk = nq;
+      const int32_t bH = nH, bE = nE, bE2 = nE2;
+      if (tau0 + 64 < n_steps) fetch(tau0 + 64);
+      const int kmax = n_steps - tau0 < 64 ? n_steps - tau0 : 64;
+      for (int k = 0; k < kmax; ++k) {
+        const int tau = tau0 + k;
+        const int qs = __builtin_amdgcn_readlane(qblk, k);
+        const int32_t hb = __builtin_amdgcn_readlane(bH, k), eb = __builtin_amdgcn_readlane(bE, k),
+                      e2b = __builtin_amdgcn_readlane(bE2, k);
+        qcur = dp_shr1(qcur);
+        int32_t Hu = dp_shr1(Hout), Eu = dp_shr1(Eout), E2u = dp_shr1(E2out);
+        if (lane == 0) { qcur = qs; Hu = hb; Eu = eb; E2u = e2b; }
+        const int j = tau - lane;
+        if (row_ok && j >= 0 && j < ql) {
+          const int32_t hdiag = j == 0 ? (i == 0 ? 0 : -dp_gap(i, gm)) : Hd;
+          const int32_t Ein = (Hu - gm.q > Eu ? Hu - gm.q : Eu) - gm.e;
+          const int32_t E2in = (Hu - gm.q2 > E2u ? Hu - gm.q2 : E2u) - gm.e2;
+          const int32_t Fin = (Hl - gm.q > Fl ? Hl - gm.q : Fl) - gm.e;
+          const int32_t F2in = (Hl - gm.q2 > F2l ? Hl - gm.q2 : F2l) - gm.e2;
+          int32_t z = hdiag + (int32_t)(int8_t)(rowbits >> (8 * qcur));
+          uint32_t d = 0;
+          if (Ein > z) { d = 1; z = Ein; }
+          if (Fin > z) { d = 2; z = Fin; }
+          if (E2in > z) { d = 3; z = E2in; }
+          if (F2in > z) { d = 4; z = F2in; }
+          if (Ein > z - gm.q) d |= 0x08;
+          if (Fin > z - gm.q) d |= 0x10;
+          if (E2in > z - gm.q2) d |= 0x20;
+          if (F2in > z - gm.q2) d |= 0x40;
+          *dcell = (uint8_t)d;   // diagonal-major: the lanes of a step write consecutive bytes
+          Hout = z; Eout = Ein; E2out = E2in;
+          Hl = z; Fl = Fin; F2l = F2in;
+          if (writes_bnd) { bout[j] = z; bout[bstride + j] = Ein; bout[2 * bstride + j] = E2in; }
+          if (i == tl - 1 && j == ql - 1) final_score = z;
+        }
+        Hd = Hu;
+        dcell += tl;
+      }
+    }
+    __syncthreads();   // the boundary row is in memory before the next stripe reads it
+  }
+  // the lane that owned (tl-1, ql-1) has the score
+  {
+    const int owner = (tl - 1) & 63;
+    final_score = __builtin_amdgcn_readlane(final_score, owner);
   }
   __syncthreads();   // the direction bytes are in HBM
-  if (threadIdx.x < 64) {
-    // ksw_backtrack from (tl-1, ql-1) by the first wavefront; ops are left in backtrack order, the host reverses
+  {
+    // ksw_backtrack from (tl-1, ql-1); ops are left in backtrack order, the host reverses
     // them.  A register window holds the direction bytes of 64 rows x 4 columns along the current diagonal (one HBM
     // latency per ~60 steps of a mostly diagonal path instead of one per step); runs are merged in registers.
-    const int lane = threadIdx.x;
-    if (lane == 0) scores[blockIdx.x] = buf[((n_diag - 1) % 3) * stride + tl - 1];
+    if (lane == 0) scores[P.slot] = final_score;
     uint32_t* cg = cigars + P.cig_off;
     int n = 0, i = tl - 1, j = ql - 1, state = 0;
     uint32_t cur_op = 0xffffffffu, cur_len = 0;
@@ -176,8 +205,15 @@ __global__ void __launch_bounds__(DP_THREADS) align_global_kernel(
     if (i >= 0) push(2, (uint32_t)(i + 1));
     if (j >= 0) push(1, (uint32_t)(j + 1));
     if (cur_op != 0xffffffffu) { if (lane == 0) cg[n] = (cur_len << 4) | cur_op; ++n; }
-    if (lane == 0) n_cigar[blockIdx.x] = n;
+    if (lane == 0) n_cigar[P.slot] = n;
   }
+}
+
+// barrier that orders LDS traffic only
+__device__ __forceinline__ void dp_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 struct LcsPair {
@@ -247,6 +283,9 @@ struct svdss_aln_batch {
   std::vector<int32_t> scores;
   std::vector<int64_t> n_cigar;
   std::vector<uint32_t> cigar;   // per pair, forward order, concatenated
+  // device state kept between calls
+  int device = -1;
+  DevArena arena;
 };
 
 namespace {
@@ -284,82 +323,100 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
     if (ql < 0 || tl < 0) return SVDSS_EINVAL;
     if (ql >= (1 << 28) || tl >= (1 << 28)) return SVDSS_ERANGE;
   }
-  const int64_t qtot = q_off[n_pairs], ttot = t_off[n_pairs];
-  DevMem d_q, d_t, d_mat;
-  int rc;
-  if ((rc = d_q.alloc((size_t)qtot)) || (rc = d_t.alloc((size_t)ttot)) || (rc = d_mat.alloc(64))) return rc;
-  if (qtot) HIPCHK2(hipMemcpy(d_q.p, queries + q_off[0], (size_t)(qtot - q_off[0]), hipMemcpyHostToDevice));
-  if (ttot) HIPCHK2(hipMemcpy(d_t.p, targets + t_off[0], (size_t)(ttot - t_off[0]), hipMemcpyHostToDevice));
-  HIPCHK2(hipMemcpy(d_mat.p, mat, (size_t)(m * m), hipMemcpyHostToDevice));
+  const int64_t qtot = q_off[n_pairs] - q_off[0], ttot = t_off[n_pairs] - t_off[0];
+  if (b->device != device) { b->arena.drop(); b->device = device; }
   const GapModel gm{gapo, gape, gapo2, gape2};
   hipEvent_t ev0, ev1;
   HIPCHK2(hipEventCreate(&ev0));
   HIPCHK2(hipEventCreate(&ev1));
-  // chunks of pairs whose direction matrices fit the workspace budget (8 GiB; HBM has 288)
-  const int64_t dir_budget = (int64_t)8 << 30;
+  // chunks of pairs whose direction matrices fit the workspace budget (HBM has 288 GB; the index may hold half of it)
+  int64_t dir_budget = (int64_t)24 << 30;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      dir_budget = std::min<int64_t>(dir_budget, (int64_t)((free_b + b->arena.cap) / 2));
+    if (dir_budget < ((int64_t)1 << 30)) dir_budget = (int64_t)1 << 30;
+  }
+  std::vector<int32_t> h_nc((size_t)n_pairs, 0);
+  std::vector<std::pair<int64_t, int64_t>> cig_at((size_t)n_pairs);   // (chunk-local offset, chunk index)
+  std::vector<std::vector<uint32_t>> chunk_cigs;
   int64_t start = 0;
   while (start < n_pairs) {
     std::vector<AlnPair> hp;
-    int64_t ws = 0, dirb = 0, cig = 0, end = start, tl_max = 0, ql_max = 0;
+    int64_t ws = 0, dirb = 0, cig = 0, end = start;
     while (end < n_pairs) {
       const int64_t ql = q_off[end + 1] - q_off[end], tl = t_off[end + 1] - t_off[end];
       const int64_t need = (ql + tl) * tl;   // direction bytes, one row of tl per anti-diagonal
       if (end > start && dirb + need > dir_budget) break;
       AlnPair a;
+      memset(&a, 0, sizeof a);
       a.q_off = q_off[end] - q_off[0];
       a.t_off = t_off[end] - t_off[0];
-      a.ws_off = ws;
+      a.bnd_off = ws;
       a.dir_off = dirb;
       a.cig_off = cig;
       a.ql = (int32_t)ql;
       a.tl = (int32_t)tl;
+      a.slot = (int32_t)(end - start);
       hp.push_back(a);
-      ws += 11 * (tl + 1);
-      if (tl > tl_max) tl_max = tl;
-      if (ql > ql_max) ql_max = ql;
+      cig_at[(size_t)end] = {cig, (int64_t)chunk_cigs.size()};
+      ws += 6 * (ql + 64);
       dirb += need;
       cig += ql + tl + 2;
       b->cells += ql * tl;
       ++end;
     }
     const int64_t np = end - start;
-    DevMem d_pairs, d_ws, d_dir, d_cig, d_sc, d_nc;
-    if ((rc = d_pairs.alloc(sizeof(AlnPair) * (size_t)np)) || (rc = d_ws.alloc(sizeof(int32_t) * (size_t)ws)) ||
-        (rc = d_dir.alloc((size_t)dirb)) || (rc = d_cig.alloc(sizeof(uint32_t) * (size_t)cig)) ||
-        (rc = d_sc.alloc(sizeof(int32_t) * (size_t)np)) || (rc = d_nc.alloc(sizeof(int32_t) * (size_t)np)))
-      return rc;
-    HIPCHK2(hipMemcpy(d_pairs.p, hp.data(), sizeof(AlnPair) * (size_t)np, hipMemcpyHostToDevice));
+    // longest pairs first: a pair is one chain of (tl / 64) x (ql + 63) dependent steps, the longest ones decide when
+    // the launch ends
+    std::stable_sort(hp.begin(), hp.end(), [](const AlnPair& x, const AlnPair& y) {
+      return (int64_t)x.ql * x.tl > (int64_t)y.ql * y.tl;
+    });
+    const size_t need_bytes = DevArena::padded((size_t)qtot) + DevArena::padded((size_t)ttot) + DevArena::padded(64) +
+                              DevArena::padded(sizeof(AlnPair) * (size_t)np) + DevArena::padded(sizeof(int32_t) * (size_t)ws) +
+                              DevArena::padded((size_t)dirb) + DevArena::padded(sizeof(uint32_t) * (size_t)cig) +
+                              2 * DevArena::padded(sizeof(int32_t) * (size_t)np);
+    HIPCHK2(b->arena.reserve(need_bytes));
+    void* d_q = b->arena.take((size_t)qtot);
+    void* d_t = b->arena.take((size_t)ttot);
+    void* d_mat = b->arena.take(64);
+    void* d_pairs = b->arena.take(sizeof(AlnPair) * (size_t)np);
+    void* d_ws = b->arena.take(sizeof(int32_t) * (size_t)ws);
+    void* d_dir = b->arena.take((size_t)dirb);
+    void* d_cig = b->arena.take(sizeof(uint32_t) * (size_t)cig);
+    void* d_sc = b->arena.take(sizeof(int32_t) * (size_t)np);
+    void* d_nc = b->arena.take(sizeof(int32_t) * (size_t)np);
+    if (qtot) HIPCHK2(hipMemcpy(d_q, queries + q_off[0], (size_t)qtot, hipMemcpyHostToDevice));
+    if (ttot) HIPCHK2(hipMemcpy(d_t, targets + t_off[0], (size_t)ttot, hipMemcpyHostToDevice));
+    HIPCHK2(hipMemcpy(d_mat, mat, (size_t)(m * m), hipMemcpyHostToDevice));
+    HIPCHK2(hipMemcpy(d_pairs, hp.data(), sizeof(AlnPair) * (size_t)np, hipMemcpyHostToDevice));
     HIPCHK2(hipEventRecord(ev0, 0));
-    const size_t lds_need = sizeof(int32_t) * 11 * (size_t)(tl_max + 1) + (size_t)ql_max + (size_t)tl_max + 16;
-    if (lds_need <= 150 * 1024) {
-      HIPCHK2(hipFuncSetAttribute((const void*)align_global_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-      hipLaunchKernelGGL(align_global_kernel<true>, dim3((unsigned)np), dim3(DP_THREADS), lds_need, 0,
-                         (const AlnPair*)d_pairs.p, (const uint8_t*)d_q.p, (const uint8_t*)d_t.p, (int)m,
-                         (const int8_t*)d_mat.p, gm, (int32_t*)d_ws.p, (uint8_t*)d_dir.p, (uint32_t*)d_cig.p,
-                         (int32_t*)d_sc.p, (int32_t*)d_nc.p);
-    } else {
-      hipLaunchKernelGGL(align_global_kernel<false>, dim3((unsigned)np), dim3(DP_THREADS), 0, 0,
-                         (const AlnPair*)d_pairs.p, (const uint8_t*)d_q.p, (const uint8_t*)d_t.p, (int)m,
-                         (const int8_t*)d_mat.p, gm, (int32_t*)d_ws.p, (uint8_t*)d_dir.p, (uint32_t*)d_cig.p,
-                         (int32_t*)d_sc.p, (int32_t*)d_nc.p);
-    }
+    hipLaunchKernelGGL(align_wave_kernel, dim3((unsigned)np), dim3(64), 0, 0, (const AlnPair*)d_pairs,
+                       (const uint8_t*)d_q, (const uint8_t*)d_t, (int)m, (const int8_t*)d_mat, gm, (int32_t*)d_ws,
+                       (uint8_t*)d_dir, (uint32_t*)d_cig, (int32_t*)d_sc, (int32_t*)d_nc);
     HIPCHK2(hipGetLastError());
     HIPCHK2(hipEventRecord(ev1, 0));
     HIPCHK2(hipDeviceSynchronize());
     float ms = 0.f;
     HIPCHK2(hipEventElapsedTime(&ms, ev0, ev1));
     b->kernel_ms += ms;
-    std::vector<int32_t> nc((size_t)np);
-    std::vector<uint32_t> cg((size_t)cig);
-    HIPCHK2(hipMemcpy(&b->scores[(size_t)start], d_sc.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost));
-    HIPCHK2(hipMemcpy(nc.data(), d_nc.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost));
-    if (cig) HIPCHK2(hipMemcpy(cg.data(), d_cig.p, sizeof(uint32_t) * (size_t)cig, hipMemcpyDeviceToHost));
-    for (int64_t k = 0; k < np; ++k) {
-      b->n_cigar[(size_t)(start + k)] = nc[(size_t)k];
-      const uint32_t* src = cg.data() + hp[(size_t)k].cig_off;
-      for (int x = nc[(size_t)k] - 1; x >= 0; --x) b->cigar.push_back(src[x]);  // reverse (ksw_backtrack tail)
-    }
+    chunk_cigs.emplace_back((size_t)cig);
+    HIPCHK2(hipMemcpy(&b->scores[(size_t)start], d_sc, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost));
+    HIPCHK2(hipMemcpy(&h_nc[(size_t)start], d_nc, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost));
+    if (cig) HIPCHK2(hipMemcpy(chunk_cigs.back().data(), d_cig, sizeof(uint32_t) * (size_t)cig, hipMemcpyDeviceToHost));
     start = end;
+  }
+  {
+    int64_t total = 0;
+    for (int64_t k = 0; k < n_pairs; ++k) total += h_nc[(size_t)k];
+    b->cigar.resize((size_t)total);
+    int64_t o = 0;
+    for (int64_t k = 0; k < n_pairs; ++k) {
+      const int32_t nc = h_nc[(size_t)k];
+      b->n_cigar[(size_t)k] = nc;
+      const uint32_t* src = chunk_cigs[(size_t)cig_at[(size_t)k].second].data() + cig_at[(size_t)k].first;
+      for (int x = nc - 1; x >= 0; --x) b->cigar[(size_t)o++] = src[x];  // reverse (ksw_backtrack tail)
+    }
   }
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);

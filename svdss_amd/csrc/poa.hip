@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/svdss_hip.h"
+#include "dev_arena.h"
 #include "poa_wave.h"
 
 extern thread_local std::string g_svdss_hip_err;
@@ -402,29 +403,6 @@ struct DevMem3 {
   int alloc(size_t bytes) { HIPCHK3(hipMalloc(&p, bytes ? bytes : 16)); return SVDSS_OK; }
 };
 
-// grow-only device buffer handed out by a bump pointer: the workspaces of a call (tens of GB of graph and
-// direction-word pools) are reused by the next call instead of going through hipMalloc / hipFree again
-struct DevArena {
-  void* p = nullptr;
-  size_t cap = 0, used = 0;
-  ~DevArena() { drop(); }
-  void drop() { if (p) (void)hipFree(p); p = nullptr; cap = used = 0; }
-  int reserve(size_t bytes) {   // only while nothing handed out is still in use
-    used = 0;
-    if (bytes <= cap) return SVDSS_OK;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    const size_t want = bytes + bytes / 8 + 4096;
-    HIPCHK3(hipMalloc(&p, want));
-    cap = want;
-    return SVDSS_OK;
-  }
-  void* take(size_t bytes) {
-    const size_t at = (used + 255) & ~(size_t)255;
-    used = at + bytes;
-    return (char*)p + at;
-  }
-  static size_t padded(size_t bytes) { return ((bytes + 255) & ~(size_t)255) + 256; }
-};
 }  // namespace
 
 struct svdss_poa_batch {
@@ -475,8 +453,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     b->device = device;
   }
   const size_t off_bytes = sizeof(int64_t) * (size_t)(n_seqs_total + 1);
-  if ((rc = b->in_arena.reserve(DevArena::padded((size_t)total_syms) + DevArena::padded(off_bytes) + DevArena::padded(8))))
-    return rc;
+  HIPCHK3(b->in_arena.reserve(DevArena::padded((size_t)total_syms) + DevArena::padded(off_bytes) + DevArena::padded(8)));
   struct { void* p; } d_seqs{b->in_arena.take((size_t)total_syms)}, d_off{b->in_arena.take(off_bytes)},
       d_cells{b->in_arena.take(8)};
   if (total_syms) HIPCHK3(hipMemcpy(d_seqs.p, seqs, (size_t)total_syms, hipMemcpyHostToDevice));
@@ -535,7 +512,11 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
       // widest row the ring holds: the band as it is in practice (round 0), as wide as the specification lets it
       // get (round 1), the full matrix (round 2, after the band lost the sink)
       const int64_t w_band = 10 + (int64_t)(0.01 * (double)maxl);
-      const int64_t wcap = std::min<int64_t>(round == 0 ? 2 * w_band + 33 : round == 1 ? 2 * w_band + 129 : maxl + 1, maxl + 1);
+      // (round 0: 2w + 1 columns plus slack for the spread of the predecessors' maxima -- rounded up to 64 where that
+      // leaves at least 8 of slack, so that a row is one column per lane: the C = 1 instantiation)
+      const int64_t w2 = 2 * w_band + 1;
+      const int64_t wcap0 = w2 + 8 <= 64 ? 64 : w2 + 32;
+      const int64_t wcap = std::min<int64_t>(round == 0 ? wcap0 : round == 1 ? 2 * w_band + 129 : maxl + 1, maxl + 1);
       int64_t ws = 64;
       while (ws < wcap) ws <<= 1;
       const int64_t rs = (wcap + 3) & ~(int64_t)3;
@@ -571,6 +552,16 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     std::vector<std::unique_ptr<Group>> groups;
     const int64_t group_budget32 = (int64_t)2 << 30;    // ints of workspace per launch
     std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.lds > y.lds; });
+    // a sub-cluster is one chain of n_seqs x length dependent row steps: the longest chains of the batch decide
+    // when it ends, so they get the issue priority (s_setprio) over the short ones that fill the CUs beside them
+    if (!getenv("SVDSS_POA_NOPRIO")) {
+      int64_t wmax = 1;
+      for (const Cand& cd : cands) wmax = std::max<int64_t>(wmax, cd.t.n_seqs * (int64_t)cd.t.max_len);
+      for (Cand& cd : cands) {
+        const int64_t wk = cd.t.n_seqs * (int64_t)cd.t.max_len;
+        cd.t.prio = wk * 2 > wmax ? 3 : wk * 4 > wmax ? 2 : wk * 8 > wmax ? 1 : 0;
+      }
+    }
     for (int ci = 0; ci < 3; ++ci) {
       Group* g = nullptr;
       size_t fill = 0;   // sub-clusters that fill the machine at the group's LDS size
@@ -598,7 +589,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     while (gpos < groups.size()) {
       size_t gend = gpos, tot_bytes = 0;
       while (gend < groups.size() && (gend == gpos || tot_bytes + groups[gend]->bytes() <= ws_budget)) tot_bytes += groups[gend++]->bytes();
-      if ((rc = b->ws_arena.reserve(tot_bytes))) return rc;
+      HIPCHK3(b->ws_arena.reserve(tot_bytes));
       for (size_t gi = gpos; gi < gend; ++gi) {
         Group& g = *groups[gi];
         const size_t nt = g.tasks.size();

@@ -12,6 +12,8 @@ struct PoaWaveTask {
   int32_t ws;              // HBM stride of a DP row: power of two >= the widest row
   int32_t rs;              // LDS stride of a ring row: >= the widest row
   int32_t ring;            // DP rows kept in LDS (power of two); two more slots stage rows read back from HBM
+  int32_t prio;            // s_setprio level (0-3): the longest chains of a batch decide its duration
+  int32_t pad_;
   int64_t ws_off;          // into the int32 workspace (poa_wave_ws_ints of it)
   int64_t cons_off;        // into the byte workspace, nc bytes
 };

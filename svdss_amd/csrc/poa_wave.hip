@@ -190,6 +190,9 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
 #define FP(k)
 #endif
   if (n <= 0) { if (lane == 0) { cons_len[blockIdx.x] = 0; status[blockIdx.x] = 0; } return; }
+  if (T.prio >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (T.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (T.prio == 1) __builtin_amdgcn_s_setprio(1);
 #define FAIL(code) do { if (lane == 0) status[blockIdx.x] = (code); return; } while (0)
   // ------------------------------------------------------------------ graph of the first read
   {
