@@ -32,6 +32,11 @@ import os
 import sys
 import time
 
+# The step pipeline keeps several HIP streams busy at once (search, and per call thread: POA x2, realignment, ratio).
+# The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a
+# queue execute in order; give it enough queues before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -156,6 +161,16 @@ class CallWorkload:
         self._aln = C.c_void_p()
         self.last = {}
 
+    def clone(self):
+        """The same packed workload with its own batch objects (one per call thread: device buffers and streams are
+        per batch object)."""
+        import copy
+        c = copy.copy(self)
+        c._poa = C.c_void_p()
+        c._aln = C.c_void_p()
+        c.last = {}
+        return c
+
     def run(self, lib, check, device):
         """POA -> consensus to the host -> realignment against the reference windows -> ratio of adjacent consensus
         pairs; returns nothing, leaves timings / results in self.last."""
@@ -226,6 +241,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (also skips verification)")
     ap.add_argument("--no-call-dp", action="store_true", help="search only (value is then NOT the headline metric)")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: leave the SFS on the ranks")
+    ap.add_argument("--call-threads", type=int, default=3,
+                    help="steps whose call-side DP may be in flight at once (0: no pipelining, search and call of a "
+                         "step run back to back)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -295,37 +313,104 @@ def main():
         cw = CallWorkload(n_clusters, seed=99 + rank)
 
     pp = svdss_amd.PingPong(ix, assemble=True)
-    stream = torch.cuda.current_stream()
+    # the search runs on its own non-blocking stream (the library's call-side entry points use private streams too), so
+    # that the call-side DP of earlier steps overlaps the search of the next one
+    sstream = torch.cuda.Stream(device=device)
 
-    def step():
+    def search(assemble=True):
         pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
-                                   stream=stream.cuda_stream, fetch=False)
-        if cw is not None:
-            cw.run(lib, check, local_rank)
-        if gather:
-            counts, qs, ln = pp.device_results()
-            multi.gather_sfs(counts, qs, ln)
+                                   stream=sstream.cuda_stream, assemble=assemble, fetch=False)
+        if gather and assemble:
+            with torch.cuda.stream(sstream):
+                counts, qs, ln = pp.device_results()
+                multi.gather_sfs(counts, qs, ln)
+            sstream.synchronize()
 
-    # raw (unassembled) SFS count: the N_sfs of SURVEY 8(d)'s reference-model bytes
-    pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
-                               stream=stream.cuda_stream, assemble=False, fetch=False)
+    stats = {"kernel_ms": [], "pipeline_ms": [], "poa_ms": [], "aln_ms": [], "call_wall_ms": []}
+
+    def run_steps(n_steps, record):
+        """n_steps steps: step i = search(i), then call(i).  With --call-threads T > 0 the steps are software-pipelined:
+        one thread searches step after step, T threads take the call-side DP of the steps whose search is done -- call(i)
+        overlaps search(i+1..) and the calls of neighbouring steps (a sub-cluster is one long chain of dependent row
+        steps: a single step's POA batch leaves most of the chip idle while its longest chains finish)."""
+        import queue
+        import threading
+        if cw is None or args.call_threads <= 0:
+            for _ in range(n_steps):
+                search()
+                if record:
+                    stats["kernel_ms"].append(pp.last_search_kernel_ms)
+                    stats["pipeline_ms"].append(pp.last_kernel_ms)
+                if cw is not None:
+                    cw.run(lib, check, local_rank)
+                    if record:
+                        note_call(cw)
+            return
+        todo = queue.Queue()
+        errors = []
+
+        def caller(w):
+            torch.cuda.set_device(local_rank)
+            try:
+                while True:
+                    i = todo.get()
+                    if i is None:
+                        return
+                    w.run(lib, check, local_rank)
+                    if record:
+                        note_call(w)
+            except BaseException as e:   # noqa: BLE001  (re-raised in the main thread)
+                errors.append(e)
+
+        threads = [threading.Thread(target=caller, args=(w,)) for w in workers]
+        for t in threads:
+            t.start()
+        try:
+            for i in range(n_steps):
+                search()
+                if record:
+                    stats["kernel_ms"].append(pp.last_search_kernel_ms)   # HIP events on the search stream
+                    stats["pipeline_ms"].append(pp.last_kernel_ms)
+                todo.put(i)
+        finally:
+            for _ in threads:
+                todo.put(None)
+            for t in threads:
+                t.join()
+        if errors:
+            raise errors[0]
+
+    lock = __import__("threading").Lock()
+
+    def note_call(w):
+        with lock:
+            stats["poa_ms"].append(w.last["poa_kernel_ms"])
+            stats["aln_ms"].append(w.last["realign_kernel_ms"])
+            stats["call_wall_ms"].append(w.last["poa_wall_ms"] + w.last["realign_wall_ms"] + w.last["ratio_wall_ms"])
+
+    workers = [cw] + [cw.clone() for _ in range(max(0, args.call_threads - 1))] if cw is not None else []
+
+    # raw (unassembled) SFS count: the N_sfs of SURVEY 8(d)'s reference-model bytes; and the search kernel on an
+    # otherwise idle GPU
+    search(assemble=False)
     n_sfs_raw = pp.last_total
-    for _ in range(args.warmup):
-        step()
+    alone_ms = []
+    for _ in range(2):
+        search()
+        alone_ms.append(pp.last_search_kernel_ms)
+    call_alone = None
+    if cw is not None:
+        for w in workers:       # first call of every batch object: allocates its device arena
+            w.run(lib, check, local_rank)
+        cw.run(lib, check, local_rank)
+        call_alone = dict(cw.last)
+    run_steps(args.warmup, record=False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms, pipeline_ms, poa_ms, aln_ms, call_wall_ms = [], [], [], [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(pp.last_search_kernel_ms)   # HIP events recorded on `stream` around the search kernel alone
-        pipeline_ms.append(pp.last_kernel_ms)        # ... and around order + search + stitch + assemble
-        if cw is not None:
-            poa_ms.append(cw.last["poa_kernel_ms"])
-            aln_ms.append(cw.last["realign_kernel_ms"])
-            call_wall_ms.append(cw.last["poa_wall_ms"] + cw.last["realign_wall_ms"] + cw.last["ratio_wall_ms"])
+    run_steps(args.steps, record=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -335,6 +420,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    kernel_ms, pipeline_ms = stats["kernel_ms"], stats["pipeline_ms"]
+    poa_ms, aln_ms, call_wall_ms = stats["poa_ms"], stats["aln_ms"], stats["call_wall_ms"]
+    search(assemble=True)     # leave the assembled results of one more search in the batch object for the verification
 
     n_ext = pp.last_total_ext
     n_sfs_asm = pp.last_total
@@ -375,16 +463,25 @@ def main():
                 "index_build_s": round(t_index, 1), "kmer_table_k": ix.kmer_k, "segments_per_read": pp.last_segments,
                 "reads_redone_unsegmented": pp.last_fallbacks,
                 "search_ms_per_step": float(np.mean(pipeline_ms)),
+                "search_kernel_ms_on_idle_gpu": float(np.mean(alone_ms)),
+                "pipelining": (f"{args.call_threads} call thread(s): the call-side DP of up to {args.call_threads} earlier "
+                               "steps runs beside the search of the current one" if cw is not None and args.call_threads > 0
+                               else "none: search and call of a step back to back"),
             },
         }
         out["roofline"] = search_roofline(ref_total, n_reads, L, ix.kmer_k, k_ms, n_ext, total_syms, n_sfs_raw,
-                                          float(np.mean(pipeline_ms)))
+                                          float(np.mean(pipeline_ms)), float(np.mean(alone_ms)))
         if cw is not None:
             okc, n_alt = cw.svs_recovered()
             poa_k, aln_k = float(np.mean(poa_ms)), float(np.mean(aln_ms))
             out["config"]["call_dp"] = {
                 "clusters": cw.n_clusters, "subclusters": cw.n_sub, "subreads": int(cw.cluster_off[-1]),
                 "call_wall_ms_per_step": float(np.mean(call_wall_ms)),
+                "one_call_on_idle_gpu": {"poa_kernel_ms": round(call_alone["poa_kernel_ms"], 3),
+                                         "realign_kernel_ms": round(call_alone["realign_kernel_ms"], 3),
+                                         "ratio_wall_ms": round(call_alone["ratio_wall_ms"], 3),
+                                         "wall_ms": round(call_alone["poa_wall_ms"] + call_alone["realign_wall_ms"]
+                                                          + call_alone["ratio_wall_ms"], 3)},
                 "poa_kernel_ms": round(poa_k, 3), "poa_cells": cw.last["poa_cells"],
                 "poa_gcups": cw.last["poa_cells"] / (poa_k * 1e-3) / 1e9, "poa_subclusters_on_hbm_kernel": cw.last["poa_hbm"],
                 "realign_kernel_ms": round(aln_k, 3), "realign_cells": cw.last["realign_cells"],
@@ -393,7 +490,8 @@ def main():
                 "alt_subclusters_with_the_implanted_sv_in_the_cigar": f"{okc}/{n_alt}",
                 # integer DP, not HBM- and not MFMA-bound: cell updates x VALU lane-operations per cell
                 # against the int32 issue rate of 256 CUs x 4 SIMD-32 x 2.4 GHz
-                "roofline": call_rooflines(cw.last["poa_cells"], poa_k, cw.last["realign_cells"], aln_k),
+                "roofline": call_rooflines(cw.last["poa_cells"], call_alone["poa_kernel_ms"], cw.last["realign_cells"],
+                                           call_alone["realign_kernel_ms"]),
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["verified_reads"] = cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads,
@@ -418,7 +516,7 @@ def call_rooflines(poa_cells, poa_ms, aln_cells, aln_ms):
     return {"poa": one(poa_cells, poa_ms, POA_OPS_PER_CELL), "realign": one(aln_cells, aln_ms, ALN_OPS_PER_CELL)}
 
 
-def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw, all_ms):
+def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw, all_ms, alone_ms):
     """HBM roofline of the search kernel.  `achieved` = the bytes the kernel's own memory operations move per launch
     (TCC_EA0_RDREQ x 128 B + WRREQ x 32|64 B from the committed rocprofv3 --pmc pass of exactly this workload,
     profiles/traffic.json) / the kernel time measured live with HIP events on the launch stream; null when this
@@ -428,7 +526,7 @@ def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw
     prof = profiled(ref_total, n_reads, L, k)
     ref_model = n_ext * 64 + total_syms + 16 * n_sfs_raw
     r = {"bound": "hbm", "kernel": "sfs_search2_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": k_ms,
-         "all_search_kernels_ms": all_ms, "reference_model_bytes": ref_model,
+         "all_search_kernels_ms": all_ms, "kernel_ms_on_idle_gpu": alone_ms, "reference_model_bytes": ref_model,
          "reference_model_gbs": ref_model / (k_ms * 1e-3) / 1e9}
     if prof:
         traffic = prof["read_requests"] * 128 + prof["write_bytes"]
@@ -436,6 +534,8 @@ def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw
                   "useful_bytes": prof.get("useful_bytes"),
                   "lines_per_read": prof["read_requests"] / n_reads})
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        # (kernel_ms is the average over the timed region, where the call-side kernels of earlier steps share the chip)
+        r["frac_on_idle_gpu"] = traffic / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if prof.get("useful_bytes"):
             r["traffic_over_useful"] = traffic / prof["useful_bytes"]
         probe = random_probe()

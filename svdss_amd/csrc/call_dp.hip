@@ -286,6 +286,10 @@ struct svdss_aln_batch {
   // device state kept between calls
   int device = -1;
   DevArena arena;
+  hipStream_t stream = nullptr;   // the batch object's own non-blocking stream: calls on different objects overlap
+  ~svdss_aln_batch() {
+    if (stream) { if (device >= 0) (void)hipSetDevice(device); (void)hipStreamDestroy(stream); }
+  }
 };
 
 namespace {
@@ -324,7 +328,13 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
     if (ql >= (1 << 28) || tl >= (1 << 28)) return SVDSS_ERANGE;
   }
   const int64_t qtot = q_off[n_pairs] - q_off[0], ttot = t_off[n_pairs] - t_off[0];
-  if (b->device != device) { b->arena.drop(); b->device = device; }
+  if (b->device != device) {
+    b->arena.drop();
+    if (b->stream) { (void)hipStreamDestroy(b->stream); b->stream = nullptr; }
+    b->device = device;
+  }
+  if (!b->stream) HIPCHK2(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  const hipStream_t st = b->stream;
   const GapModel gm{gapo, gape, gapo2, gape2};
   hipEvent_t ev0, ev1;
   HIPCHK2(hipEventCreate(&ev0));
@@ -386,24 +396,24 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
     void* d_cig = b->arena.take(sizeof(uint32_t) * (size_t)cig);
     void* d_sc = b->arena.take(sizeof(int32_t) * (size_t)np);
     void* d_nc = b->arena.take(sizeof(int32_t) * (size_t)np);
-    if (qtot) HIPCHK2(hipMemcpy(d_q, queries + q_off[0], (size_t)qtot, hipMemcpyHostToDevice));
-    if (ttot) HIPCHK2(hipMemcpy(d_t, targets + t_off[0], (size_t)ttot, hipMemcpyHostToDevice));
-    HIPCHK2(hipMemcpy(d_mat, mat, (size_t)(m * m), hipMemcpyHostToDevice));
-    HIPCHK2(hipMemcpy(d_pairs, hp.data(), sizeof(AlnPair) * (size_t)np, hipMemcpyHostToDevice));
-    HIPCHK2(hipEventRecord(ev0, 0));
-    hipLaunchKernelGGL(align_wave_kernel, dim3((unsigned)np), dim3(64), 0, 0, (const AlnPair*)d_pairs,
+    if (qtot) HIPCHK2(hipMemcpyAsync(d_q, queries + q_off[0], (size_t)qtot, hipMemcpyHostToDevice, st));
+    if (ttot) HIPCHK2(hipMemcpyAsync(d_t, targets + t_off[0], (size_t)ttot, hipMemcpyHostToDevice, st));
+    HIPCHK2(hipMemcpyAsync(d_mat, mat, (size_t)(m * m), hipMemcpyHostToDevice, st));
+    HIPCHK2(hipMemcpyAsync(d_pairs, hp.data(), sizeof(AlnPair) * (size_t)np, hipMemcpyHostToDevice, st));
+    HIPCHK2(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(align_wave_kernel, dim3((unsigned)np), dim3(64), 0, st, (const AlnPair*)d_pairs,
                        (const uint8_t*)d_q, (const uint8_t*)d_t, (int)m, (const int8_t*)d_mat, gm, (int32_t*)d_ws,
                        (uint8_t*)d_dir, (uint32_t*)d_cig, (int32_t*)d_sc, (int32_t*)d_nc);
     HIPCHK2(hipGetLastError());
-    HIPCHK2(hipEventRecord(ev1, 0));
-    HIPCHK2(hipDeviceSynchronize());
+    HIPCHK2(hipEventRecord(ev1, st));
+    chunk_cigs.emplace_back((size_t)cig);
+    HIPCHK2(hipMemcpyAsync(&b->scores[(size_t)start], d_sc, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
+    HIPCHK2(hipMemcpyAsync(&h_nc[(size_t)start], d_nc, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
+    if (cig) HIPCHK2(hipMemcpyAsync(chunk_cigs.back().data(), d_cig, sizeof(uint32_t) * (size_t)cig, hipMemcpyDeviceToHost, st));
+    HIPCHK2(hipStreamSynchronize(st));
     float ms = 0.f;
     HIPCHK2(hipEventElapsedTime(&ms, ev0, ev1));
     b->kernel_ms += ms;
-    chunk_cigs.emplace_back((size_t)cig);
-    HIPCHK2(hipMemcpy(&b->scores[(size_t)start], d_sc, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost));
-    HIPCHK2(hipMemcpy(&h_nc[(size_t)start], d_nc, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost));
-    if (cig) HIPCHK2(hipMemcpy(chunk_cigs.back().data(), d_cig, sizeof(uint32_t) * (size_t)cig, hipMemcpyDeviceToHost));
     start = end;
   }
   {
@@ -463,29 +473,45 @@ extern "C" int svdss_indel_ratio_batch(const uint8_t* a, const int64_t* a_off, c
     if (lb > lb_max) lb_max = lb;
   }
   const int64_t atot = a_off[n_pairs] - a_off[0], btot = b_off[n_pairs] - b_off[0];
-  DevMem d_a, d_b, d_pairs, d_ws, d_lcs, d_ratio;
-  int rc;
-  if ((rc = d_a.alloc((size_t)atot)) || (rc = d_b.alloc((size_t)btot)) ||
-      (rc = d_pairs.alloc(sizeof(LcsPair) * (size_t)n_pairs)) || (rc = d_ws.alloc(sizeof(int32_t) * (size_t)ws)) ||
-      (rc = d_lcs.alloc(sizeof(int64_t) * (size_t)n_pairs)) || (rc = d_ratio.alloc(sizeof(double) * (size_t)n_pairs)))
-    return rc;
-  if (atot) HIPCHK2(hipMemcpy(d_a.p, a + a_off[0], (size_t)atot, hipMemcpyHostToDevice));
-  if (btot) HIPCHK2(hipMemcpy(d_b.p, bsy + b_off[0], (size_t)btot, hipMemcpyHostToDevice));
-  HIPCHK2(hipMemcpy(d_pairs.p, hp.data(), sizeof(LcsPair) * (size_t)n_pairs, hipMemcpyHostToDevice));
+  // workspace and stream of the calling thread, kept between calls (no hipMalloc / hipFree -- a device-wide
+  // synchronisation each -- and nothing on the default stream)
+  struct RatioState {
+    int device = -1;
+    DevArena arena;
+    hipStream_t stream = nullptr;
+    ~RatioState() { if (stream) { if (device >= 0) (void)hipSetDevice(device); (void)hipStreamDestroy(stream); } }
+  };
+  static thread_local RatioState R;
+  if (R.device != device) {
+    R.arena.drop();
+    if (R.stream) { (void)hipStreamDestroy(R.stream); R.stream = nullptr; }
+    R.device = device;
+  }
+  if (!R.stream) HIPCHK2(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+  const hipStream_t st = R.stream;
+  HIPCHK2(R.arena.reserve(DevArena::padded((size_t)atot) + DevArena::padded((size_t)btot) +
+                          DevArena::padded(sizeof(LcsPair) * (size_t)n_pairs) + DevArena::padded(sizeof(int32_t) * (size_t)ws) +
+                          DevArena::padded(sizeof(int64_t) * (size_t)n_pairs) + DevArena::padded(sizeof(double) * (size_t)n_pairs)));
+  struct { void* p; } d_a{R.arena.take((size_t)atot)}, d_b{R.arena.take((size_t)btot)},
+      d_pairs{R.arena.take(sizeof(LcsPair) * (size_t)n_pairs)}, d_ws{R.arena.take(sizeof(int32_t) * (size_t)ws)},
+      d_lcs{R.arena.take(sizeof(int64_t) * (size_t)n_pairs)}, d_ratio{R.arena.take(sizeof(double) * (size_t)n_pairs)};
+  if (atot) HIPCHK2(hipMemcpyAsync(d_a.p, a + a_off[0], (size_t)atot, hipMemcpyHostToDevice, st));
+  if (btot) HIPCHK2(hipMemcpyAsync(d_b.p, bsy + b_off[0], (size_t)btot, hipMemcpyHostToDevice, st));
+  HIPCHK2(hipMemcpyAsync(d_pairs.p, hp.data(), sizeof(LcsPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
   const size_t lds_need = sizeof(int32_t) * 3 * (size_t)(la_max + 1) + (size_t)la_max + (size_t)lb_max + 16;
   if (lds_need <= 150 * 1024) {
     HIPCHK2(hipFuncSetAttribute((const void*)lcs_ratio_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-    hipLaunchKernelGGL(lcs_ratio_kernel<true>, dim3((unsigned)n_pairs), dim3(DP_THREADS), lds_need, 0,
+    hipLaunchKernelGGL(lcs_ratio_kernel<true>, dim3((unsigned)n_pairs), dim3(DP_THREADS), lds_need, st,
                        (const LcsPair*)d_pairs.p, (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (int32_t*)d_ws.p,
                        (int64_t*)d_lcs.p, (double*)d_ratio.p);
   } else {
-    hipLaunchKernelGGL(lcs_ratio_kernel<false>, dim3((unsigned)n_pairs), dim3(DP_THREADS), 0, 0,
+    hipLaunchKernelGGL(lcs_ratio_kernel<false>, dim3((unsigned)n_pairs), dim3(DP_THREADS), 0, st,
                        (const LcsPair*)d_pairs.p, (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (int32_t*)d_ws.p,
                        (int64_t*)d_lcs.p, (double*)d_ratio.p);
   }
   HIPCHK2(hipGetLastError());
-  HIPCHK2(hipDeviceSynchronize());
-  HIPCHK2(hipMemcpy(ratio_out, d_ratio.p, sizeof(double) * (size_t)n_pairs, hipMemcpyDeviceToHost));
-  if (lcs_out) HIPCHK2(hipMemcpy(lcs_out, d_lcs.p, sizeof(int64_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+  HIPCHK2(hipMemcpyAsync(ratio_out, d_ratio.p, sizeof(double) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
+  if (lcs_out) HIPCHK2(hipMemcpyAsync(lcs_out, d_lcs.p, sizeof(int64_t) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
+  HIPCHK2(hipStreamSynchronize(st));
   return SVDSS_OK;
 }

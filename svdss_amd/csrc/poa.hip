@@ -456,9 +456,19 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   HIPCHK3(b->in_arena.reserve(DevArena::padded((size_t)total_syms) + DevArena::padded(off_bytes) + DevArena::padded(8)));
   struct { void* p; } d_seqs{b->in_arena.take((size_t)total_syms)}, d_off{b->in_arena.take(off_bytes)},
       d_cells{b->in_arena.take(8)};
-  if (total_syms) HIPCHK3(hipMemcpy(d_seqs.p, seqs, (size_t)total_syms, hipMemcpyHostToDevice));
-  HIPCHK3(hipMemcpy(d_off.p, seq_off, off_bytes, hipMemcpyHostToDevice));
-  HIPCHK3(hipMemset(d_cells.p, 0, 8));
+  // every copy and launch of this call goes to the batch object's own non-blocking streams and every wait is a
+  // wait for those streams: calls on different batch objects (threads) and a search running beside them overlap
+  // (few streams: the runtime multiplexes streams onto a handful of hardware queues, and streams that share one run
+  // in order)
+  while (b->streams.size() < 2) {
+    hipStream_t st;
+    HIPCHK3(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    b->streams.push_back(st);
+  }
+  const hipStream_t s0 = b->streams[0];
+  if (total_syms) HIPCHK3(hipMemcpyAsync(d_seqs.p, seqs, (size_t)total_syms, hipMemcpyHostToDevice, s0));
+  HIPCHK3(hipMemcpyAsync(d_off.p, seq_off, off_bytes, hipMemcpyHostToDevice, s0));
+  HIPCHK3(hipMemsetAsync(d_cells.p, 0, 8, s0));
   hipEvent_t ev0, ev1;
   HIPCHK3(hipEventCreate(&ev0));
   HIPCHK3(hipEventCreate(&ev1));
@@ -481,11 +491,6 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws_budget = std::min(ws_budget, (free_b + b->ws_arena.cap) / 2);
     if (ws_budget < ((size_t)1 << 30)) ws_budget = (size_t)1 << 30;
-  }
-  while (b->streams.size() < 8) {
-    hipStream_t st;
-    HIPCHK3(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    b->streams.push_back(st);
   }
   const int n_rounds = 3;
   for (int round = 0; round < n_rounds && !cur.empty(); ++round) {
@@ -598,10 +603,10 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         g.d8 = b->ws_arena.take((size_t)g.w8);
         g.d_len = b->ws_arena.take(sizeof(int32_t) * nt);
         g.d_st = b->ws_arena.take(sizeof(int32_t) * nt);
-        HIPCHK3(hipMemcpy(g.d_tasks, g.tasks.data(), sizeof(PoaWaveTask) * nt, hipMemcpyHostToDevice));
-        HIPCHK3(hipMemset(g.d_st, 0xff, sizeof(int32_t) * nt));
+        HIPCHK3(hipMemcpyAsync(g.d_tasks, g.tasks.data(), sizeof(PoaWaveTask) * nt, hipMemcpyHostToDevice, s0));
+        HIPCHK3(hipMemsetAsync(g.d_st, 0xff, sizeof(int32_t) * nt, s0));
       }
-      HIPCHK3(hipDeviceSynchronize());
+      HIPCHK3(hipStreamSynchronize(s0));
       const auto t0 = std::chrono::steady_clock::now();
       for (size_t gi = gpos; gi < gend; ++gi) {
         Group& g = *groups[gi];
@@ -610,7 +615,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
                                 (int32_t*)g.d_len, (int32_t*)g.d_st, (unsigned long long*)d_cells.p,
                                 b->streams[(gi - gpos) % b->streams.size()]));
       }
-      HIPCHK3(hipDeviceSynchronize());
+      for (size_t k = 0; k < std::min(gend - gpos, b->streams.size()); ++k) HIPCHK3(hipStreamSynchronize(b->streams[k]));
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       b->kernel_ms += ms;   // wall time of the concurrent launches
       int why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -621,9 +626,10 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         n_run += nt;
         std::vector<int32_t> lens((size_t)nt), st((size_t)nt);
         std::vector<uint8_t> h8((size_t)g.w8);
-        HIPCHK3(hipMemcpy(lens.data(), g.d_len, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-        HIPCHK3(hipMemcpy(st.data(), g.d_st, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-        if (g.w8) HIPCHK3(hipMemcpy(h8.data(), g.d8, (size_t)g.w8, hipMemcpyDeviceToHost));
+        HIPCHK3(hipMemcpyAsync(lens.data(), g.d_len, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, s0));
+        HIPCHK3(hipMemcpyAsync(st.data(), g.d_st, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, s0));
+        if (g.w8) HIPCHK3(hipMemcpyAsync(h8.data(), g.d8, (size_t)g.w8, hipMemcpyDeviceToHost, s0));
+        HIPCHK3(hipStreamSynchronize(s0));
         for (int64_t k = 0; k < nt; ++k) {
           if (st[(size_t)k] == 0) {
             const uint8_t* src = h8.data() + g.tasks[(size_t)k].cons_off;
@@ -693,23 +699,24 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
           (rc = d64.alloc(sizeof(int64_t) * (size_t)w64)) || (rc = d8.alloc((size_t)w8)) ||
           (rc = d_len.alloc(sizeof(int32_t) * (size_t)nt)) || (rc = d_st.alloc(sizeof(int32_t) * (size_t)nt)))
         return rc;
-      HIPCHK3(hipMemcpy(d_tasks.p, tasks.data(), sizeof(PoaTask) * (size_t)nt, hipMemcpyHostToDevice));
-      HIPCHK3(hipMemset(d_st.p, 0xff, sizeof(int32_t) * (size_t)nt));
-      HIPCHK3(hipEventRecord(ev0, 0));
-      hipLaunchKernelGGL(poa_consensus_kernel, dim3((unsigned)nt), dim3(64), 0, 0, (const PoaTask*)d_tasks.p,
+      HIPCHK3(hipMemcpyAsync(d_tasks.p, tasks.data(), sizeof(PoaTask) * (size_t)nt, hipMemcpyHostToDevice, s0));
+      HIPCHK3(hipMemsetAsync(d_st.p, 0xff, sizeof(int32_t) * (size_t)nt, s0));
+      HIPCHK3(hipEventRecord(ev0, s0));
+      hipLaunchKernelGGL(poa_consensus_kernel, dim3((unsigned)nt), dim3(64), 0, s0, (const PoaTask*)d_tasks.p,
                          (const uint8_t*)d_seqs.p, (const int64_t*)d_off.p, (int32_t*)d32.p, (int64_t*)d64.p,
                          (uint8_t*)d8.p, (int32_t*)d_len.p, (int32_t*)d_st.p, (unsigned long long*)d_cells.p);
       HIPCHK3(hipGetLastError());
-      HIPCHK3(hipEventRecord(ev1, 0));
-      HIPCHK3(hipDeviceSynchronize());
+      HIPCHK3(hipEventRecord(ev1, s0));
+      HIPCHK3(hipStreamSynchronize(s0));
       float ms = 0.f;
       HIPCHK3(hipEventElapsedTime(&ms, ev0, ev1));
       b->kernel_ms += ms;
       std::vector<int32_t> lens((size_t)nt), st((size_t)nt);
       std::vector<uint8_t> h8((size_t)w8);
-      HIPCHK3(hipMemcpy(lens.data(), d_len.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-      HIPCHK3(hipMemcpy(st.data(), d_st.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-      if (w8) HIPCHK3(hipMemcpy(h8.data(), d8.p, (size_t)w8, hipMemcpyDeviceToHost));
+      HIPCHK3(hipMemcpyAsync(lens.data(), d_len.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, s0));
+      HIPCHK3(hipMemcpyAsync(st.data(), d_st.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, s0));
+      if (w8) HIPCHK3(hipMemcpyAsync(h8.data(), d8.p, (size_t)w8, hipMemcpyDeviceToHost, s0));
+      HIPCHK3(hipStreamSynchronize(s0));
       for (int64_t k = 0; k < nt; ++k) {
         if (st[(size_t)k] == 0) {
           const uint8_t* src = h8.data() + tasks[(size_t)k].cons_off;
@@ -727,7 +734,8 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
   unsigned long long cells = 0;
-  HIPCHK3(hipMemcpy(&cells, d_cells.p, 8, hipMemcpyDeviceToHost));
+  HIPCHK3(hipMemcpyAsync(&cells, d_cells.p, 8, hipMemcpyDeviceToHost, s0));
+  HIPCHK3(hipStreamSynchronize(s0));
   b->cells = (int64_t)cells;
   for (int64_t c = 0; c < n_clusters; ++c) {
     b->cons_len[(size_t)c] = (int64_t)results[(size_t)c].size();

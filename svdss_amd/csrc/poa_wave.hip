@@ -139,6 +139,15 @@ __device__ __forceinline__ int wave_shr1(int x, int fill) { return dppi<0x138, 0
 //  16 bits: bits 0-2 base, bits 3-4 number of predecessors (0-2, or RI_SLOW: look at the graph), bits 5-9 and
 //  10-14 the row deltas (< 32) of predecessor 0 / 1, bit 15: some later row reads this row after it left the ring
 
+struct ArrI {
+  int32_t* W; uint32_t o;
+  __device__ __forceinline__ int32_t& operator[](int i) const { return W[o + (uint32_t)i]; }
+};
+struct ArrU {
+  int32_t* W; uint32_t o;
+  __device__ __forceinline__ uint32_t& operator[](int i) const { return ((uint32_t*)W)[o + (uint32_t)i]; }
+};
+
 __device__ unsigned long long g_poaw_prof[8];   // SVDSS_DEBUG: time in prepare, forward, traceback, update, bundle
 #define PROF_T() (prof_t = wall_clock64())
 #define PROF_ADD(k) do { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - prof_t; prof_t = t_; } while (0)
@@ -165,20 +174,18 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   uint8_t* q = (uint8_t*)(sh + 16);
   // ---- HBM
   const WsLayout wl = ws_layout(nc, ec, T.max_len, WS);
-  int32_t* W = ws32 + T.ws_off;
-  int32_t *out_head = W + wl.out_head, *in_head = W + wl.in_head, *order = W + wl.order, *index = W + wl.index;
-  int32_t *col = W + wl.col, *base = W + wl.base;
-  int32_t *row_beg = W + wl.row_beg, *row_end = W + wl.row_end, *hl = W + wl.hl;
-  uint32_t *prow0 = (uint32_t*)(W + wl.prow0), *prow1 = (uint32_t*)(W + wl.prow1);
-  int32_t *row_mpl = W + wl.row_mpl, *row_mpr = W + wl.row_mpr;
-  int32_t *aln = W + wl.aln, *scr = W + wl.scr;
-  uint32_t *rinfo = (uint32_t*)(W + wl.rinfo), *keepf = (uint32_t*)(W + wl.keepf);
-  int32_t *e_from = W + wl.e_from, *e_to = W + wl.e_to, *e_w = W + wl.e_w, *e_next_out = W + wl.e_next_out,
-          *e_next_in = W + wl.e_next_in;
-  int32_t *op_node = W + wl.op_node, *op_q = W + wl.op_q, *path_use = W + wl.path_use;
-  uint32_t* path_aux = (uint32_t*)(W + wl.path_aux);
-  uint32_t* gdir = (uint32_t*)(W + wl.gdir);
-  int32_t *gH = W + wl.gH, *gE1 = W + wl.gE1, *gE2 = W + wl.gE2;
+  // every HBM array of the sub-cluster is (one base pointer, a 32-bit offset): thirty 64-bit pointers would not fit
+  // the scalar registers and the row loop would keep reloading spilled ones
+  int32_t* const W = ws32 + T.ws_off;
+  const ArrI out_head{W, (uint32_t)wl.out_head}, in_head{W, (uint32_t)wl.in_head}, order{W, (uint32_t)wl.order},
+      index{W, (uint32_t)wl.index}, col{W, (uint32_t)wl.col}, base{W, (uint32_t)wl.base}, row_beg{W, (uint32_t)wl.row_beg},
+      row_end{W, (uint32_t)wl.row_end}, hl{W, (uint32_t)wl.hl}, row_mpl{W, (uint32_t)wl.row_mpl},
+      row_mpr{W, (uint32_t)wl.row_mpr}, aln{W, (uint32_t)wl.aln}, scr{W, (uint32_t)wl.scr}, e_from{W, (uint32_t)wl.e_from},
+      e_to{W, (uint32_t)wl.e_to}, e_w{W, (uint32_t)wl.e_w}, e_next_out{W, (uint32_t)wl.e_next_out},
+      e_next_in{W, (uint32_t)wl.e_next_in}, op_node{W, (uint32_t)wl.op_node}, op_q{W, (uint32_t)wl.op_q},
+      path_use{W, (uint32_t)wl.path_use}, gH{W, (uint32_t)wl.gH}, gE1{W, (uint32_t)wl.gE1}, gE2{W, (uint32_t)wl.gE2};
+  const ArrU prow0{W, (uint32_t)wl.prow0}, prow1{W, (uint32_t)wl.prow1}, rinfo{W, (uint32_t)wl.rinfo},
+      keepf{W, (uint32_t)wl.keepf}, path_aux{W, (uint32_t)wl.path_aux}, gdir{W, (uint32_t)wl.gdir};
   const int opcap = nc + T.max_len + 4;
   const int n = (int)T.n_seqs;
   unsigned long long my_cells = 0;
@@ -273,9 +280,9 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
       auto stage = [&](int ur, int s) {
         __syncthreads();
         const int pb = row_beg[ur], pe = row_end[ur];
-        const int64_t po = (int64_t)ur * WS;
+        const int po = ur * WS;
         for (int x = lane; x <= pe - pb; x += 64) {
-          const int64_t o = po + ((pb + x) & wm);
+          const int o = po + ((pb + x) & wm);
           rH[s * RST + G + x] = gH[o]; rE1[s * RST + G + x] = gE1[o]; rE2[s * RST + G + x] = gE2[o];
         }
         if (lane < G) {
@@ -291,7 +298,13 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
       // ------------------------------------------------------------ forward (the sink is order[N-1])
       for (int r = 0; r < N - 1; ++r) {
         FP(5);
-        if (r - blk0 >= 64) { blk0 = r; ri_blk = rinfo[r + lane] | keepf[r + lane]; }   // (both arrays are N + 64 long)
+        if (r - blk0 >= 64) {   // (both arrays are N + 64 long)
+          blk0 = r;
+          ri_blk = rinfo[r + lane] | keepf[r + lane];
+          // wait for the block here, once per 64 rows: a wait at the use below would be a vmcnt(0) in every row, i.e.
+          // every row would wait for its own direction-word stores to reach HBM
+          asm volatile("" : "+v"(ri_blk));
+        }
         const uint32_t ri = __builtin_amdgcn_readlane(ri_blk, r - blk0);
         const int slot = r & rm;
         const int bv = (int)(ri & 7u);
@@ -357,7 +370,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
           if (keep) { row_beg[r] = beg; row_end[r] = end; }
         }
         FP(0);
-        const int64_t rowo = (int64_t)r * WS;
+        const int rowo = r * WS;
         const int sb = slot * RST + G;
         if (lane < G) {   // -inf guard cells on both sides of the row: successors read them unchecked
           const int o1 = slot * RST + lane, o2 = sb + width + lane;
@@ -528,7 +541,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               const uint32_t dHp = (m[c] == hp[c] && mk) ? (uint32_t)km[c] : e1[c] == hp[c] ? 8u : 9u;
               const uint32_t o1 = hp_left - P_O1 - P_E1 == f1 ? 1u : 0u;
               const uint32_t o2 = hp_left - P_O2 - P_E2 == f2 ? 1u : 0u;
-              const int64_t o = rowo + (j & wm);
+              const int o = rowo + (j & wm);
               gdir[o] = dH | (dHp << 4) | (dE1[c] << 8) | (dE2[c] << 12) | (o1 << 16) | (o2 << 17);
               if (keep) { gH[o] = h; gE1[o] = e1[c]; gE2[o] = e2[c]; }
               rH[sb + (j - beg)] = h; rE1[sb + (j - beg)] = e1[c]; rE2[sb + (j - beg)] = e2[c];
@@ -591,9 +604,10 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               r0 = r; j0 = j; k = 0; d = 0;
               const int rr = r0 - lane;
               if (rr >= 0) {
-                const uint32_t* bp = gdir + (int64_t)rr * WS;
+                const int bp = rr * WS;
                 const int c = j0 - lane;
-                W0 = bp[c & wm]; W1 = bp[(c + 1) & wm]; W2 = bp[(c + 2) & wm]; W3 = bp[(c + 3) & wm];
+                W0 = gdir[bp + (c & wm)]; W1 = gdir[bp + ((c + 1) & wm)]; W2 = gdir[bp + ((c + 2) & wm)];
+                W3 = gdir[bp + ((c + 3) & wm)];
                 P0 = prow0[rr]; P1 = prow1[rr];
               }
               // wait for the window here, not at the join below (where the wait would also cover the op
