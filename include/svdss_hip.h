@@ -55,6 +55,17 @@ int svdss_index_build(const uint8_t* contigs, const int64_t* lens, int32_t n_con
 int svdss_index_build_device(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
                              int32_t threads, int32_t device, svdss_index_t** out);
 int svdss_index_save(const svdss_index_t* ix, const char* path);
+/* The index as ropebwt3 dumps it: the rld0 run-length BWT (`.fmd`, magic "RLD\3"), the file `ropebwt3 build -d` /
+ * upstream `SVDSS index` writes and rb3_fmi_restore reads (main.cpp:34-37, ping_pong.cpp:245; run_svdss:136-147 reuses
+ * an existing $FA.fmd).  Format restated from the published rld0 sources in csrc/rld0.cpp [UPSTREAM-UNVERIFIED]. */
+int svdss_index_save_fmd(const svdss_index_t* ix, const char* path);
+/* The BWT an rld0 `.fmd` holds, as nt6 bytes: *n_out symbols (bwt_out may be NULL to ask for the size only;
+ * SVDSS_ERANGE if cap is too small). */
+int svdss_fmd_read_bwt(const char* path, uint8_t* bwt_out, int64_t cap, int64_t* n_out);
+/* Restores an index: this library's own file (svdss_index_save), or an rld0 `.fmd` -- then `<path>.svdss` (the
+ * own-format copy `SVDSS index` leaves beside the .fmd) is read if it is there and not older; otherwise the BWT is
+ * decoded, the records are recovered from it (they must come with their reverse complements, as ropebwt3 build -d
+ * inserts them) and the index is rebuilt, on the GPU when there is one. */
 int svdss_index_load(const char* path, svdss_index_t** out);
 void svdss_index_free(svdss_index_t* ix);
 /* number of BWT symbols, = sum_i 2*(lens[i]+1) */

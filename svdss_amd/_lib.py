@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvdss_hip.so")
+# SVDSS_LIB: another build of the same library (developer builds such as the op-counting one, `make count`)
+LIB_PATH = os.environ.get("SVDSS_LIB") or os.path.join(_HERE, "libsvdss_hip.so")
 
 SVDSS_OK = 0
 SVDSS_SFS_ASSEMBLE = 1
@@ -48,6 +49,8 @@ SIGNATURES = {
     "svdss_index_build": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
     "svdss_index_build_device": (C.c_int, [_p, _p, _i32, _i32, _i32, C.POINTER(_p)]),
     "svdss_index_save": (C.c_int, [_p, C.c_char_p]),
+    "svdss_index_save_fmd": (C.c_int, [_p, C.c_char_p]),
+    "svdss_fmd_read_bwt": (C.c_int, [C.c_char_p, _p, _i64, _p]),
     "svdss_index_load": (C.c_int, [C.c_char_p, C.POINTER(_p)]),
     "svdss_index_free": (None, [_p]),
     "svdss_index_size": (_i64, [_p]),

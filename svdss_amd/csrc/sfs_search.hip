@@ -13,6 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <omp.h>
+#include <sys/stat.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +26,7 @@
 #include "../../include/svdss_hip.h"
 #include "fmd_layout.h"
 #include "index_host.h"
+#include "rld0.h"
 #include "sfs_core.h"
 #include "sfs_core2.h"
 #include "sym_window.h"
@@ -135,11 +139,74 @@ extern "C" int svdss_index_save(const svdss_index_t* ix, const char* path) {
   return svdss_index_save_host(ix, path);
 }
 
+extern "C" int svdss_index_save_fmd(const svdss_index_t* ix, const char* path) {
+  if (!ix || !path) return SVDSS_EINVAL;
+  std::vector<uint8_t> bwt;
+  try { bwt.resize((size_t)ix->n); } catch (...) { return SVDSS_ENOMEM; }
+  svdss_index_decode_bwt(ix, bwt.data());
+  return rld0_write(path, bwt.data(), ix->n);
+}
+
+extern "C" int svdss_fmd_read_bwt(const char* path, uint8_t* bwt_out, int64_t cap, int64_t* n_out) {
+  if (!path || !n_out) return SVDSS_EINVAL;
+  std::vector<uint8_t> bwt;
+  const int rc = rld0_read(path, bwt);
+  if (rc != SVDSS_OK) return rc;
+  *n_out = (int64_t)bwt.size();
+  if (bwt_out) {
+    if (cap < (int64_t)bwt.size()) return SVDSS_ERANGE;
+    memcpy(bwt_out, bwt.data(), bwt.size());
+  }
+  return SVDSS_OK;
+}
+
+// an rld0 file (ropebwt3 / upstream `SVDSS index`): decode the BWT, recover the strings, rebuild this layout
+static int import_fmd(const char* path, svdss_index_t** out) {
+  std::vector<uint8_t> bwt;
+  int rc = rld0_read(path, bwt);
+  if (rc != SVDSS_OK) return rc;
+  int threads = 1;
+#ifdef _OPENMP
+  threads = omp_get_max_threads();
+#endif
+  std::vector<std::vector<uint8_t>> strings;
+  rc = rld0_strings_of_bwt(bwt.data(), (int64_t)bwt.size(), threads, strings);
+  if (rc != SVDSS_OK) return rc;
+  std::vector<uint8_t>().swap(bwt);
+  std::vector<int64_t> picked;
+  rc = rld0_pick_strands(strings, picked);
+  if (rc != SVDSS_OK) {
+    g_svdss_hip_err = "the .fmd is not an index of records AND their reverse complements (ropebwt3 build without -d?)";
+    return rc;
+  }
+  std::vector<int64_t> lens;
+  int64_t total = 0;
+  for (int64_t i : picked) { lens.push_back((int64_t)strings[(size_t)i].size()); total += lens.back(); }
+  std::vector<uint8_t> cat;
+  try { cat.reserve((size_t)total); } catch (...) { return SVDSS_ENOMEM; }
+  for (int64_t i : picked) {
+    cat.insert(cat.end(), strings[(size_t)i].begin(), strings[(size_t)i].end());
+    std::vector<uint8_t>().swap(strings[(size_t)i]);
+  }
+  strings.clear();
+  return svdss_index_build(cat.data(), lens.data(), (int32_t)lens.size(), threads, out);
+}
+
 extern "C" int svdss_index_load(const char* path, svdss_index_t** out) {
   if (!path || !out) return SVDSS_EINVAL;
+  std::string file = path;
+  if (rld0_is_fmd(path)) {
+    // `SVDSS index` leaves this library's own layout beside the .fmd it writes: restoring that is a plain read
+    const std::string cache = file + ".svdss";
+    struct stat a, c;
+    if (!getenv("SVDSS_INDEX_NO_CACHE") && stat(path, &a) == 0 && stat(cache.c_str(), &c) == 0 && c.st_mtime >= a.st_mtime)
+      file = cache;
+    else
+      return import_fmd(path, out);
+  }
   svdss_index* ix = new (std::nothrow) svdss_index();
   if (!ix) return SVDSS_ENOMEM;
-  int rc = svdss_index_load_host(path, ix);
+  int rc = svdss_index_load_host(file.c_str(), ix);
   if (rc != SVDSS_OK) { delete ix; return rc; }
   *out = ix;
   return SVDSS_OK;
@@ -490,6 +557,22 @@ typedef uint32_t sv_u32x4 __attribute__((ext_vector_type(4)));
 #ifdef SV_COUNT_ITERS
 __device__ unsigned long long g_sfs_iters[48];   // [0] wave iterations, [1] lane ops, [2+op] lane ops by type
 #endif
+
+// counting build (make count -> libsvdss_hip_count.so, SVDSS_LIB selects it): lane operations of the launches since
+// the last report, by type -- what `useful_bytes` in profiles/traffic.json is computed from
+static void sfs_report_op_counts() {
+#ifdef SV_COUNT_ITERS
+  unsigned long long h[48];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess)
+    fprintf(stderr, "[svdss] wave-iterations %llu; lane ops: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu "
+            "PEEK %llu SA_SET %llu SET %llu\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+  fprintf(stderr, "[svdss] items by ops (2^k .. 2^(k+1)-1, k=4..15):");
+  for (int k = 4; k < 16; ++k) fprintf(stderr, " %llu", h[16 + k]);
+  fprintf(stderr, "\n");
+  memset(h, 0, sizeof h);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sfs_iters), h, sizeof h);
+#endif
+}
 
 template <class P, bool SEG>
 __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
@@ -1167,17 +1250,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
         (void)hipEventElapsedTime(&t, b->ev0, e2);
         fprintf(stderr, "[svdss] segmented search + stitch: %.3f ms, %llu of %lld reads to redo\n", t, n_fb,
                 (long long)n_reads);
-#ifdef SV_COUNT_ITERS
-        unsigned long long h[48];
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess)
-          fprintf(stderr, "[svdss] wave-iterations %llu; lane ops: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu "
-                  "PEEK %llu SA_SET %llu SET %llu\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
-        fprintf(stderr, "[svdss] items by ops (2^k .. 2^(k+1)-1, k=4..15):");
-        for (int k = 4; k < 16; ++k) fprintf(stderr, " %llu", h[16 + k]);
-        fprintf(stderr, "\n");
-        memset(h, 0, sizeof h);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sfs_iters), h, sizeof h);
-#endif
+        sfs_report_op_counts();
         (void)hipEventDestroy(e2);
       }
       // reads whose chains could not be stitched are searched again with a quarter of the segments (their
@@ -1232,6 +1305,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     HIPCHK(hipMemcpyAsync(&total, (int64_t*)b->out_off.p + n_reads, sizeof(int64_t),
                           hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    if (p.n_seg == 1 && getenv("SVDSS_DEBUG")) sfs_report_op_counts();
     if ((rc = ensure(b->out_qs, (size_t)(total + 1) * sizeof(int32_t)))) return rc;
     if ((rc = ensure(b->out_len, (size_t)(total + 1) * sizeof(int32_t)))) return rc;
     hipLaunchKernelGGL(sfs_gather_kernel, dim3(gblocks), dim3(256), 0, stream, p,

@@ -166,7 +166,10 @@ static int main_index(int argc, char** argv) {
   logmsg("info", "Indexing " + std::to_string(lens.size()) + " record(s), " + std::to_string(cat.size()) + " bases..");
   svdss_index_t* ix = nullptr;
   check(svdss_index_build(cat.data(), lens.data(), (int32_t)lens.size(), threads, &ix), "svdss_index_build");
-  check(svdss_index_save(ix, out.c_str()), "svdss_index_save");
+  // the file ropebwt3 build -d writes (rld0), so that the index serves upstream SVDSS as well -- and beside it this
+  // program's own layout (text, suffix array, rank blocks), which `search` restores with a plain read
+  check(svdss_index_save_fmd(ix, out.c_str()), "svdss_index_save_fmd");
+  if (!getenv("SVDSS_INDEX_NO_CACHE")) check(svdss_index_save(ix, (out + ".svdss").c_str()), "svdss_index_save");
   svdss_index_free(ix);
   return 0;
 }

@@ -87,6 +87,10 @@ class FMDIndex:
     def save(self, path: str) -> None:
         check(lib.svdss_index_save(self._h, path.encode()), "svdss_index_save")
 
+    def save_fmd(self, path: str) -> None:
+        """ropebwt3's rld0 dump (`ropebwt3 build -d` / upstream `SVDSS index`)."""
+        check(lib.svdss_index_save_fmd(self._h, path.encode()), "svdss_index_save_fmd")
+
     def close(self) -> None:
         if self._h:
             lib.svdss_index_free(self._h)

@@ -132,3 +132,31 @@ def test_search_fastx_and_bam_text(tmp_path, assemble):
     # the text parses back (sfs.cpp:5-30)
     parsed = svdss_amd.parse_sfsfile(r2.stdout)
     assert set(parsed) <= set(keep_names)
+
+
+def test_index_writes_an_rld0_fmd_and_the_own_layout_beside_it(tmp_path):
+    """`SVDSS index -d ref.fa -o ref.fa.fmd` (run_svdss:142): the .fmd is ropebwt3's rld0 dump (what upstream restores),
+    `<fmd>.svdss` this program's own layout; both restore to an index with the same BWT.  (Host builder: no GPU needed.)"""
+    import ctypes as C
+    from svdss_amd._lib import lib
+    ref = synth.make_reference([20000, 3000], seed=9, n_runs=(50,))
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as fh:
+        for i, c in enumerate(ref):
+            s = synth.to_ascii(c)
+            fh.write(f">chr{i + 1} x\n" + "\n".join(s[k:k + 70] for k in range(0, len(s), 70)) + "\n")
+    fmd = tmp_path / "ref.fa.fmd"
+    r = run("index", "-t", "2", "-d", str(fa), "-o", str(fmd))
+    assert r.returncode == 0, r.stderr
+    assert fmd.read_bytes()[:4] == b"RLD\x03"
+    assert (tmp_path / "ref.fa.fmd.svdss").read_bytes()[:8] == b"SVDSSFM2"
+    want = svdss_amd.FMDIndex.build(ref, threads=2)
+    n = C.c_int64()
+    assert lib.svdss_fmd_read_bwt(str(fmd).encode(), None, 0, C.byref(n)) == 0 and n.value == want.size
+    got = np.zeros(n.value, np.uint8)
+    assert lib.svdss_fmd_read_bwt(str(fmd).encode(), got.ctypes.data, n.value, C.byref(n)) == 0
+    assert (got == want.bwt()).all()
+    assert (svdss_amd.FMDIndex.load(str(fmd)).bwt() == want.bwt()).all()          # through <fmd>.svdss
+    os.remove(tmp_path / "ref.fa.fmd.svdss")
+    back = svdss_amd.FMDIndex.load(str(fmd))                                       # through the rld0 import
+    assert back.size == want.size and (back.acc == want.acc).all()
