@@ -42,13 +42,26 @@ struct __attribute__((aligned(16))) svdss_u4 { uint32_t x, y, z, w; };  // == ui
 //                                    (taken from the END of W) that still occur; (info >> 8) & 0xff = df =
 //                                    how many leading symbols of the d + 1 that do not occur together still
 //                                    do (outcome of the forward phase that follows, 0 = not recorded)
-//   info >> 62 == SVDSS_TAB_UNIQUE : one occurrence; lo = SA index, info & MASK = text position
-//   info >> 62 == SVDSS_TAB_MULTI  : lo = SA index of the interval, info & MASK = size (>= 2)
+//   info >> 62 == SVDSS_TAB_UNIQUE : one occurrence; lo = SA index, info bits 0-39 = text position,
+//                                    bits 40-57 = its extension symbols
+//   info >> 62 == SVDSS_TAB_FEW    : 2-4 occurrences (SA rows lo .. lo+size-1); lo bits 0-35 = SA index,
+//                                    info bits 59-61 = size, extension symbols of occurrences 0, 1, 2 in info bits
+//                                    0-17, 18-35, 36-53, of occurrence 3 in lo bits 36-53
+//   info >> 62 == SVDSS_TAB_MULTI  : lo = SA index of the interval, info & MASK = size (>= 5)
+// Extension symbols of an occurrence: the SVDSS_TAB_EXT text symbols in front of it (nt6, 3 bits each, the
+// nearest one in the low bits; '$' from the record start on) -- what the next SVDSS_TAB_EXT backward extensions
+// (or, for the reverse-complement key of a forward phase, forward extensions) of the K-mer must match.  A chance
+// match of a K-mer that contains a sequencing error dies within a symbol or two: with these the lane sees
+// that in the entry it already holds instead of fetching a BWT block or a text window per symbol.
 struct __attribute__((aligned(16))) SvdssTabEntry { uint64_t lo, info; };
 #define SVDSS_TAB_EMPTY 0ull
 #define SVDSS_TAB_UNIQUE 1ull
 #define SVDSS_TAB_MULTI 2ull
+#define SVDSS_TAB_FEW 3ull
 #define SVDSS_TAB_MASK ((1ull << 62) - 1)
+#define SVDSS_TAB_EXT 6
+#define SVDSS_TAB_POS_MASK ((1ull << 40) - 1)
+#define SVDSS_TAB_LO_MASK ((1ull << 36) - 1)
 
 struct SvdssDevIndex {
   const svdss_u4* blocks;   // 4 quarters per block, (n/128 + 1) blocks
@@ -112,4 +125,30 @@ SVDSS_HD int64_t svdss_rank_in_block(const SvdssDevIndex& ix, const svdss_u4 q[4
 #pragma unroll
   for (int j = 0; j < 4; ++j) acgt += svdss_popc(~q[j].w & svdss_lowmask(r - 32 * j));
   return k - nd - acgt;
+}
+
+// BWT symbol at row i, from the block layout
+SVDSS_HD int svdss_bwt_at(const SvdssDevIndex& ix, int64_t i) {
+  const svdss_u4 q = ix.blocks[4 * (i >> SVDSS_BLOCK_SHIFT) + ((i >> 5) & 3)];
+  const int bit = (int)(i & 31);
+  const uint32_t p0 = (q.y >> bit) & 1u, p1 = (q.z >> bit) & 1u, p2 = (q.w >> bit) & 1u;
+  return p2 ? (p0 ? 5 : 0) : (int)(1u + (p1 << 1 | p0));
+}
+
+// extension symbols (see SvdssTabEntry) of the suffix at SA row `row`: BWT[row], BWT[LF(row)], ...
+SVDSS_HD uint32_t svdss_ext_symbols(const SvdssDevIndex& ix, int64_t row) {
+  uint32_t x = 0;
+  for (int e = 0; e < SVDSS_TAB_EXT; ++e) {
+    const int sym = svdss_bwt_at(ix, row);
+    if (sym == 0) break;   // start of the record: '$' from here on
+    x |= (uint32_t)sym << (3 * e);
+    row = svdss_acc(ix, sym) + svdss_rank_in_block(ix, ix.blocks + 4 * (row >> SVDSS_BLOCK_SHIFT), sym, row);
+  }
+  return x;
+}
+
+// extension symbols of occurrence j of a UNIQUE / FEW entry
+SVDSS_HD uint32_t svdss_tab_ext(uint64_t lo, uint64_t info, int j) {
+  if ((info >> 62) == SVDSS_TAB_UNIQUE) return (uint32_t)(info >> 40) & 0x3ffffu;
+  return j < 3 ? (uint32_t)(info >> (18 * j)) & 0x3ffffu : (uint32_t)(lo >> 36) & 0x3ffffu;
 }

@@ -78,6 +78,8 @@ struct SvLane {
 #define SV_LFC_SHIFT 12   // mode bits 12-13: LF steps taken on an interval of 2-4 since the phase started
 #define SV_LFC_MASK (3 << SV_LFC_SHIFT)
 #define SV_SET_AFTER 2    // ... chance matches of a K-mer die within a symbol or two; real copies do not
+#define SV_M_SHIFT (1 << 14)   // s.c = read symbols consumed since the table lookup whose SA rows are being fetched
+#define SV_M_FEWSET (1 << 15)  // the alive bits already hold the occurrences of a FEW entry that are left: fetch their rows
 #define SV_PEEK_VISIBLE 16 // records per segment stored so that a concurrently running neighbour can see them
 
 struct SvOp {
@@ -236,6 +238,11 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
     const bool nonempty = s.hi > s.lo;
     if (!dir) {
       if (nonempty && s.pos > 0) {                    // ping_pong.cpp:15
+        if (s.mode & SV_M_FEWSET) {                   // the survivors of a FEW entry: their text positions, then SET
+          o.op = SV_OP_SA_SET;
+          o.a = (int64_t)s.lo;
+          return o;
+        }
         if (s.hi - s.lo == 1 && ix.sa != nullptr) {   // single occurrence: switch to TEXT
           o.op = SV_OP_SA;
           o.a = (int64_t)s.lo;
@@ -330,8 +337,11 @@ SVDSS_HD void sv_apply_lf(SvLane<P>& s, const SvdssDevIndex& ix, const svdss_u4 
   ++s.n_ext;
 }
 
+// g / off: the lane's window of read symbols (the extension symbols of a UNIQUE / FEW entry are compared with the
+// read symbols next to the K-mer when those are resident); can_set: SET mode may be entered (sv_decide's rule)
 template <class P>
-SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_lo, uint64_t e_info) {
+SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_lo, uint64_t e_info, const SvRing& g,
+                             int64_t off, bool can_set) {
   const int K = ix.k;
   const int dir = s.mode & SV_M_DIR;
   const uint64_t type = e_info >> 62;
@@ -358,32 +368,109 @@ SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_l
   }
   s.pos = dir ? s.pos + (K - 1) : s.pos - (K - 1);
   s.n_ext += K - 1;
-  s.lo = (P)e_lo;
-  if (type == SVDSS_TAB_UNIQUE) {
-    s.hi = (P)(e_lo + 1);
-    if (!dir && s.pos > 0) {              // go straight to TEXT mode: no SA lookup needed
-      s.tdelta = (int64_t)val - s.pos;
+  if (type == SVDSS_TAB_MULTI) {
+    s.lo = (P)e_lo;
+    s.hi = (P)(e_lo + val);
+    return;
+  }
+  // one to four occurrences, each with the SVDSS_TAB_EXT text symbols in front of it: the next extensions
+  // (ping_pong.cpp:15-22 backward, :31-37 forward on the reverse-complement key) keep the occurrences whose symbol
+  // agrees with the read's -- the interval size the reference looks at is the number that are left
+  const bool uniq = type == SVDSS_TAB_UNIQUE;
+  const int size = uniq ? 1 : (int)((e_info >> 59) & 7u);
+  const uint64_t sa_lo = uniq ? e_lo : (e_lo & SVDSS_TAB_LO_MASK);
+  const int pk = s.pos;                   // read position of the K-mer's last consumed symbol
+  int steps_max;
+  if (!dir) {
+    steps_max = pk < SVDSS_TAB_EXT ? pk : SVDSS_TAB_EXT;
+    if (pk - steps_max < s.wrel) steps_max = pk - s.wrel;          // (positions below wrel are not resident)
+  } else {
+    steps_max = s.len - 1 - pk < SVDSS_TAB_EXT ? s.len - 1 - pk : SVDSS_TAB_EXT;
+    if (pk + steps_max >= s.wrel + 64) steps_max = s.wrel + 63 - pk;
+  }
+  if (steps_max < 0) steps_max = 0;
+  int alive = (1 << size) - 1, e = 0;
+  bool emptied = false;
+  for (; e < steps_max; ++e) {
+    int c = sv_ring_sym(g, off + (dir ? pk + 1 + e : pk - 1 - e));
+    if (dir) c = svdss_comp(c);
+    int next = 0;
+#pragma unroll
+    for (int j = 0; j < SV_SET_MAX; ++j)
+      if (((alive >> j) & 1) && (int)((svdss_tab_ext(e_lo, e_info, j) >> (3 * e)) & 7u) == c) next |= 1 << j;
+    if (!next) { emptied = true; break; }
+    alive = next;
+  }
+  if (emptied) {                          // extension e + 1 emptied the interval
+    s.pos = dir ? pk + e + 1 : pk - e - 1;
+    s.n_ext += e + 1;
+    s.lo = 0;
+    s.hi = 0;
+    return;
+  }
+  if (dir || e == 0) {
+    // forward and still occurring after the symbols at hand (rare: the string with the error in it goes on
+    // matching), or nothing resident to compare with: go on from the K-mer's interval as before
+    s.lo = (P)sa_lo;
+    s.hi = (P)(sa_lo + (uint64_t)size);
+    if (uniq && !dir && pk > 0) {         // straight to TEXT mode: no SA lookup needed
+      s.tdelta = (int64_t)(val & SVDSS_TAB_POS_MASK) - pk;
       s.mode |= SV_M_TEXT;
     }
-  } else {
-    s.hi = (P)(e_lo + val);
+    return;
   }
+  // backward, e symbols further, at least one occurrence left
+  s.pos = pk - e;
+  s.n_ext += e;
+  if (s.pos == 0) {                       // ping_pong.cpp:24: prefix matched, size != 0
+    s.lo = 0;
+    s.hi = 1;
+    return;
+  }
+  if (uniq) {
+    s.lo = (P)sa_lo;
+    s.hi = (P)(sa_lo + 1);
+    s.tdelta = (int64_t)(val & SVDSS_TAB_POS_MASK) - pk;
+    s.mode |= SV_M_TEXT;
+    return;
+  }
+  if ((alive & (alive - 1)) == 0) {       // one left: its text position (suffix array row sa_lo + j), then TEXT
+    const int j = alive == 1 ? 0 : alive == 2 ? 1 : alive == 4 ? 2 : 3;
+    s.lo = (P)(sa_lo + (uint64_t)j);
+    s.hi = (P)(sa_lo + (uint64_t)j + 1);
+    s.c = e;
+    s.mode |= SV_M_SHIFT;
+    return;
+  }
+  s.lo = (P)sa_lo;
+  s.hi = (P)(sa_lo + (uint64_t)size);
+  if (can_set && ix.sa != nullptr) {      // several left after SVDSS_TAB_EXT more symbols: copies; follow them in the text
+    s.c = e;
+    s.mode = (s.mode & ~(((1 << SV_SET_MAX) - 1) << SV_SET_SHIFT)) | (alive << SV_SET_SHIFT) | SV_M_SHIFT | SV_M_FEWSET;
+    return;
+  }
+  // no SET mode here: forget the e symbols, walk the BWT from the K-mer's interval
+  s.pos = pk;
+  s.n_ext -= e;
 }
 
 template <class P>
 SVDSS_HD void sv_apply_sa(SvLane<P>& s, int64_t text_pos) {
-  s.tdelta = text_pos - s.pos;
-  s.mode |= SV_M_TEXT;
+  // (SV_M_SHIFT: the row belongs to the K-mer of the last table lookup, s.c read symbols back)
+  s.tdelta = text_pos - s.pos - ((s.mode & SV_M_SHIFT) ? s.c : 0);
+  s.mode = (s.mode & ~SV_M_SHIFT) | SV_M_TEXT;
 }
 
 // SA_SET: text positions of the hi - lo <= SV_SET_MAX occurrences (suffix array entries lo, lo+1, ...)
 template <class P>
 SVDSS_HD void sv_apply_sa_set(SvLane<P>& s, const SvSet& ts, const int64_t text_pos[SV_SET_MAX]) {
   const int n = (int)(s.hi - s.lo);
+  const int shift = (s.mode & SV_M_SHIFT) ? s.c : 0;   // rows of the K-mer of the last table lookup, s.c symbols back
 #pragma unroll
   for (int i = 0; i < SV_SET_MAX; ++i)
-    if (i < n) ts.base[i * ts.stride] = text_pos[i] - s.pos;
-  s.mode |= SV_M_SET | (((1 << n) - 1) << SV_SET_SHIFT);
+    if (i < n) ts.base[i * ts.stride] = text_pos[i] - s.pos - shift;
+  if (s.mode & SV_M_FEWSET) s.mode = (s.mode & ~(SV_M_SHIFT | SV_M_FEWSET)) | SV_M_SET;   // alive bits are set already
+  else s.mode |= SV_M_SET | (((1 << n) - 1) << SV_SET_SHIFT);
 }
 
 // SET: tw[i] = the 16 text bytes of occurrence i for read positions [pos-16, pos), rb = the read's.  Every
@@ -569,10 +656,17 @@ SVDSS_HD void sv_table_entry(const SvdssDevIndex& ix, uint32_t key, int K, uint6
   if (d == K) {
     const uint64_t size = (uint64_t)(hi - lo);
     e_lo = (uint64_t)lo;
-    if (size == 1 && ix.sa != nullptr)
-      e_info = (SVDSS_TAB_UNIQUE << 62) | (uint64_t)((const P*)ix.sa)[lo];
-    else
+    if (size == 1 && ix.sa != nullptr) {
+      e_info = (SVDSS_TAB_UNIQUE << 62) | ((uint64_t)svdss_ext_symbols(ix, lo) << 40) | (uint64_t)((const P*)ix.sa)[lo];
+    } else if (size >= 2 && size <= 4 && ix.sa != nullptr) {
+      e_info = (SVDSS_TAB_FEW << 62) | (size << 59);
+      for (int j = 0; j < (int)size; ++j) {
+        const uint64_t x = svdss_ext_symbols(ix, lo + j);
+        if (j < 3) e_info |= x << (18 * j); else e_lo |= x << 36;
+      }
+    } else {
       e_info = (SVDSS_TAB_MULTI << 62) | size;
+    }
   } else {
     // W[K-1-d .. K-1] (d + 1 symbols) does not occur: how many of its leading symbols do -- the forward phase the
     // reference starts at W[K-1-d] (interval of revcomp, extended with complemented symbols, ping_pong.cpp:30-37)

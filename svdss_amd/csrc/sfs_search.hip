@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(256) sfs_order_kernel(SfsParams p, int64_t* he
         const uint32_t c = ((wb[t >> 2] >> (8 * (t & 3))) & 0xffu) - 1u;
         if (t < K) { bad |= (a | c) & ~3u; k1 |= (a & 3u) << (2 * t); k2 |= (c & 3u) << (2 * t); }
       }
-      if (!bad) hit = (p.ix.table[k1].info >> 62) == SVDSS_TAB_MULTI && (p.ix.table[k2].info >> 62) == SVDSS_TAB_MULTI;
+      if (!bad) hit = (p.ix.table[k1].info >> 62) >= SVDSS_TAB_MULTI && (p.ix.table[k2].info >> 62) >= SVDSS_TAB_MULTI;   // (2+ occurrences: MULTI or FEW)
     }
   }
   const unsigned long long hm = __ballot(hit);
@@ -813,7 +813,7 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
       sv_apply_lf(st, p.ix, A, B, !need_b);
     } else if (o.op == SV_OP_TABLE) {
       sv_apply_table(st, p.ix, (uint64_t)A[0].x | ((uint64_t)A[0].y << 32),
-                     (uint64_t)A[0].z | ((uint64_t)A[0].w << 32));
+                     (uint64_t)A[0].z | ((uint64_t)A[0].w << 32), g, off, p.use_set != 0 && off >= 64);
     } else if (o.op == SV_OP_SA) {
       const int64_t tp = sizeof(P) == 4 ? (int64_t)A[0].x
                                         : (int64_t)((uint64_t)A[0].x | ((uint64_t)A[0].y << 32));

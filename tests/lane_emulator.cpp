@@ -154,7 +154,7 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
         sv_apply_lf(st, v, A, B, bhi == blo);
       } else if (o.op == SV_OP_TABLE) {
         const SvdssTabEntry e = v.table[o.a];
-        sv_apply_table(st, v, e.lo, e.info);
+        sv_apply_table(st, v, e.lo, e.info, g, off, use_set && off >= 64);
       } else if (o.op == SV_OP_SA) {
         sv_apply_sa(st, (int64_t)((const P*)v.sa)[o.a]);
       } else if (o.op == SV_OP_TEXT) {

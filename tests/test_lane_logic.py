@@ -170,7 +170,7 @@ def test_kmer_table_entries_against_plain_substring_search():
     occurs = lambda x: any(x in t for t in strands)
     K = 6
     lo, info = E.kmer_table(ix, K)
-    n_empty = n_df = 0
+    n_empty = n_df = n_ext_checked = 0
     for key in range(1 << (2 * K)):
         w = "".join("ACGT"[(key >> (2 * i)) & 3] for i in range(K))     # first symbol in the low bits
         d = 0
@@ -178,10 +178,23 @@ def test_kmer_table_entries_against_plain_substring_search():
             d += 1
         typ = int(info[key]) >> 62
         if d == K:
-            assert typ in (1, 2), (w, typ)
-            size = sum(t.count(w) if len(set(w)) > 1 else sum(1 for i in range(len(t) - K + 1) if t[i:i + K] == w) for t in strands)
-            if typ == 1:
-                assert size == 1
+            assert typ in (1, 2, 3), (w, typ)
+            starts = [(t, i) for t in strands for i in range(len(t) - K + 1) if t[i:i + K] == w]
+            size = len(starts)
+            assert (typ == 1) == (size == 1) and (typ == 3) == (2 <= size <= 4) and (typ == 2) == (size >= 5), (w, typ, size)
+            if typ in (1, 3):
+                # extension symbols: the 6 text symbols in front of every occurrence, nearest first, '$' (0) from the
+                # record start on -- as a multiset (the entry lists the occurrences in suffix-array order)
+                want = sorted(sum(("$ACGTN".index(t[i - 1 - e]) if i - 1 - e >= 0 else 0) << (3 * e) for e in range(6))
+                              for t, i in starts)
+                ilo, iin = int(lo[key]), int(info[key])
+                if typ == 1:
+                    got = [(iin >> 40) & 0x3ffff]
+                else:
+                    assert (iin >> 59) & 7 == size
+                    got = [((iin >> (18 * j)) & 0x3ffff) if j < 3 else ((ilo >> 36) & 0x3ffff) for j in range(size)]
+                assert sorted(got) == want, (w, got, want)
+                n_ext_checked += 1
             continue
         n_empty += 1
         assert typ == 0 and (int(info[key]) & 0xff) == d, (w, d, int(info[key]) & 0xff)
@@ -194,7 +207,7 @@ def test_kmer_table_entries_against_plain_substring_search():
         assert df <= d
         assert ((int(info[key]) >> 8) & 0xff) == df, (w, f, df, (int(info[key]) >> 8) & 0xff)
         n_df += 1
-    assert n_empty > 500 and n_df > 500
+    assert n_empty > 500 and n_df > 500 and n_ext_checked > 500
 
 
 @pytest.mark.parametrize("seed", [101, 102, 103, 104])
