@@ -82,6 +82,13 @@ int32_t svdss_index_kmer(const svdss_index_t* ix);
  * text, suffix array, and the 4^K k-mer table (K = floor(log4 n)+1, env SVDSS_KMER overrides) */
 int svdss_index_to_device(svdss_index_t* ix, int32_t device);
 
+/* GPUs this process sees (0: none). */
+int svdss_device_count(void);
+/* One more replica of the index, in the HBM of `device` (the index is replicated per GPU, reads and
+ * sub-clusters shard): a new handle with its own device buffers; *src is not modified (its text and suffix array are
+ * fetched to the host first if it was built on a device). */
+int svdss_index_replicate(const svdss_index_t* src, int32_t device, svdss_index_t** out);
+
 /* Size of the interval of a pattern (occurrences in contigs + revcomps) via
  * the host copy of the index; rb3_fmd_set_intv + repeated rb3_fmd_extend(...,1)
  * as in ping_pong.cpp:12-22.  For tests/diagnostics; not a hot path. */
@@ -110,6 +117,17 @@ typedef struct svdss_sfs_batch svdss_sfs_batch_t;
  * results in *out (created if *out == NULL, otherwise its buffers are reused). */
 int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* reads, const int64_t* offsets,
                            int64_t n_reads, int32_t flags, svdss_sfs_batch_t** out);
+/* BAM-record entry point: the reads as they sit in BAM records -- 4-bit packed bases ("=ACMGRSVTWYHKDBN", two per
+ * byte, high nibble first), read i at seq4[byte_off[i]] with l_seq[i] bases -- are uploaded packed (half the bytes of
+ * the nt6 form) and expanded to nt6 on the GPU, which stands for the per-base loop of ping_pong.cpp:90-94
+ * (seq_nt16_str, then seq_nt6_table: A/C/G/T -> 1..4, every other code -> 5).  Everything else as
+ * svdss_sfs_search_batch.  Copies go through the batch object's own stream: calls on different batch objects overlap. */
+int svdss_sfs_search_batch_bam(const svdss_index_t* ix, const uint8_t* seq4, const int64_t* byte_off,
+                               const int32_t* l_seq, int64_t n_reads, int32_t flags, svdss_sfs_batch_t** out);
+/* Page-locked host memory for the buffers handed to the host-buffer entry points (copies from it run at PCIe speed
+ * and asynchronously; pageable memory works too, slower). */
+int svdss_host_alloc(int64_t bytes, void** out);
+void svdss_host_free(void* p);
 /* Device-buffer entry point: d_reads/d_offsets already resident in HBM on the
  * index's device; work is enqueued on `stream` (a hipStream_t, NULL = default
  * stream) and is complete when this returns. */

@@ -60,7 +60,12 @@ SIGNATURES = {
     "svdss_index_kmer": (_i32, [_p]),
     "svdss_index_to_device": (C.c_int, [_p, _i32]),
     "svdss_index_count": (_i64, [_p, _p, _i64]),
+    "svdss_device_count": (C.c_int, []),
+    "svdss_index_replicate": (C.c_int, [_p, _i32, C.POINTER(_p)]),
     "svdss_sfs_search_batch": (C.c_int, [_p, _p, _p, _i64, _i32, C.POINTER(_p)]),
+    "svdss_sfs_search_batch_bam": (C.c_int, [_p, _p, _p, _p, _i64, _i32, C.POINTER(_p)]),
+    "svdss_host_alloc": (C.c_int, [_i64, C.POINTER(_p)]),
+    "svdss_host_free": (None, [_p]),
     "svdss_sfs_search_batch_device": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, C.POINTER(_p)]),
     "svdss_sfs_batch_nreads": (_i64, [_p]),
     "svdss_sfs_batch_total": (_i64, [_p]),

@@ -644,6 +644,9 @@ int main_call(const CallOptions& o) {
     fclose(f);
   }
   logmsg("info", "Calling SVs from " + std::to_string(clusters.size()) + " clusters..");
+  // (SVDSS_GPUS_OVERSUBSCRIBE: more shards than GPUs, shard g on GPU g % count -- exercises the sharding on a one-GPU box)
+  const int n_dev = std::max(1, svdss_device_count());
+  const int G = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev));
   // ---- pcall (caller.cpp:311-406): split, then the three GPU batches
   struct Sub { size_t parent; Cluster cl; };
   std::vector<Sub> subs;
@@ -663,13 +666,45 @@ int main_call(const CallOptions& o) {
       }
       cl_off.push_back((int64_t)seq_off.size() - 1);
     }
-    svdss_poa_batch_t* pb = nullptr;
-    check(svdss_poa_consensus_batch(flat.data(), seq_off.data(), cl_off.data(), (int64_t)subs.size(), 0, &pb),
-          "svdss_poa_consensus_batch");
+    // --gpus G: sub-cluster k goes to GPU k % G (no exchange between the GPUs: a sub-cluster is self-contained), the
+    // consensus sequences come back in sub-cluster order -- the same bytes as with one GPU
     std::vector<int64_t> lens(subs.size());
-    std::vector<uint8_t> cons((size_t)svdss_poa_batch_total(pb));
-    check(svdss_poa_batch_fetch(pb, lens.data(), cons.data()), "svdss_poa_batch_fetch");
-    svdss_poa_batch_free(pb);
+    std::vector<uint8_t> cons;
+    {
+      const size_t nsub = subs.size();
+      std::vector<std::vector<uint8_t>> part_cons((size_t)G);
+      std::vector<std::vector<int64_t>> part_lens((size_t)G);
+      std::vector<std::thread> pool;
+      auto run = [&](int g) {
+        std::vector<uint8_t> f;
+        std::vector<int64_t> so(1, 0), co(1, 0);
+        for (size_t k = (size_t)g; k < nsub; k += (size_t)G) {
+          for (int64_t sq = cl_off[k]; sq < cl_off[k + 1]; ++sq) {
+            f.insert(f.end(), flat.begin() + seq_off[(size_t)sq], flat.begin() + seq_off[(size_t)sq + 1]);
+            so.push_back((int64_t)f.size());
+          }
+          co.push_back((int64_t)so.size() - 1);
+        }
+        svdss_poa_batch_t* pb = nullptr;
+        check(svdss_poa_consensus_batch(G == 1 ? flat.data() : f.data(), G == 1 ? seq_off.data() : so.data(),
+                                        G == 1 ? cl_off.data() : co.data(), (int64_t)co.size() - 1, g % n_dev, &pb),
+              "svdss_poa_consensus_batch");
+        part_lens[(size_t)g].resize(co.size() - 1);
+        part_cons[(size_t)g].resize((size_t)svdss_poa_batch_total(pb));
+        check(svdss_poa_batch_fetch(pb, part_lens[(size_t)g].data(), part_cons[(size_t)g].data()), "svdss_poa_batch_fetch");
+        svdss_poa_batch_free(pb);
+      };
+      for (int g = 1; g < G; ++g) pool.emplace_back(run, g);
+      run(0);
+      for (std::thread& th : pool) th.join();
+      std::vector<size_t> at((size_t)G, 0), idx((size_t)G, 0);
+      for (size_t k = 0; k < nsub; ++k) {
+        const size_t g = k % (size_t)G;
+        lens[k] = part_lens[g][idx[g]++];
+        cons.insert(cons.end(), part_cons[g].begin() + (long)at[g], part_cons[g].begin() + (long)(at[g] + (size_t)lens[k]));
+        at[g] += (size_t)lens[k];
+      }
+    }
     size_t p = 0;
     for (size_t i = 0; i < subs.size(); ++i) {
       consensus[i].resize((size_t)lens[i]);
@@ -692,14 +727,49 @@ int main_call(const CallOptions& o) {
       for (int p = cl.s; p <= cl.e && p < (int)cs.size(); ++p) t.push_back(enc26(cs[(size_t)p]));   // caller.cpp:329
       to.push_back((int64_t)t.size());
     }
-    svdss_aln_batch_t* ab = nullptr;
-    check(svdss_align_global_batch(q.data(), qo.data(), t.data(), to.data(), (int64_t)subs.size(), 5, mat, 16, 2, 41, 1,
-                                   0, &ab), "svdss_align_global_batch");
     std::vector<int32_t> scores(subs.size());
     std::vector<int64_t> ncig(subs.size());
-    std::vector<uint32_t> cig((size_t)svdss_aln_batch_total_cigar(ab));
-    check(svdss_aln_batch_fetch(ab, scores.data(), ncig.data(), cig.data()), "svdss_aln_batch_fetch");
-    svdss_aln_batch_free(ab);
+    std::vector<uint32_t> cig;
+    {
+      const size_t nsub = subs.size();
+      std::vector<std::vector<int32_t>> p_sc((size_t)G);
+      std::vector<std::vector<int64_t>> p_nc((size_t)G);
+      std::vector<std::vector<uint32_t>> p_cg((size_t)G);
+      std::vector<std::thread> pool;
+      auto run = [&](int g) {
+        std::vector<uint8_t> q2, t2;
+        std::vector<int64_t> qo2(1, 0), to2(1, 0);
+        if (G > 1)
+          for (size_t k = (size_t)g; k < nsub; k += (size_t)G) {
+            q2.insert(q2.end(), q.begin() + qo[k], q.begin() + qo[k + 1]);
+            qo2.push_back((int64_t)q2.size());
+            t2.insert(t2.end(), t.begin() + to[k], t.begin() + to[k + 1]);
+            to2.push_back((int64_t)t2.size());
+          }
+        const int64_t np = G == 1 ? (int64_t)nsub : (int64_t)qo2.size() - 1;
+        svdss_aln_batch_t* ab = nullptr;
+        check(svdss_align_global_batch(G == 1 ? q.data() : q2.data(), G == 1 ? qo.data() : qo2.data(),
+                                       G == 1 ? t.data() : t2.data(), G == 1 ? to.data() : to2.data(), np, 5, mat, 16, 2, 41,
+                                       1, g % n_dev, &ab), "svdss_align_global_batch");
+        p_sc[(size_t)g].resize((size_t)np);
+        p_nc[(size_t)g].resize((size_t)np);
+        p_cg[(size_t)g].resize((size_t)svdss_aln_batch_total_cigar(ab));
+        check(svdss_aln_batch_fetch(ab, p_sc[(size_t)g].data(), p_nc[(size_t)g].data(), p_cg[(size_t)g].data()),
+              "svdss_aln_batch_fetch");
+        svdss_aln_batch_free(ab);
+      };
+      for (int g = 1; g < G; ++g) pool.emplace_back(run, g);
+      run(0);
+      for (std::thread& th : pool) th.join();
+      std::vector<size_t> at((size_t)G, 0), idx((size_t)G, 0);
+      for (size_t k = 0; k < nsub; ++k) {
+        const size_t g = k % (size_t)G;
+        scores[k] = p_sc[g][idx[g]];
+        ncig[k] = p_nc[g][idx[g]++];
+        cig.insert(cig.end(), p_cg[g].begin() + (long)at[g], p_cg[g].begin() + (long)(at[g] + (size_t)ncig[k]));
+        at[g] += (size_t)ncig[k];
+      }
+    }
     std::vector<std::vector<SV>> per_thread((size_t)T);
     sam_rows.resize((size_t)T);
     size_t cp = 0;

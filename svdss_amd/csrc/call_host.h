@@ -12,6 +12,7 @@ struct CallOptions {
   float min_ratio = 0.97f;
   float accp = 0.98f;          // smooth only
   bool verbose = false;         // stage timings on stderr
+  int gpus = 1;                 // --gpus N: POA / realignment batches shard by sub-cluster index
   std::string poa;             // --poa <FILE>: consensus alignments as SAM (caller.cpp:65-75)
   std::string clusters;        // --clusters <FILE>: the filled clusters (clusterer.cpp:613-626)
 };

@@ -359,6 +359,52 @@ extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
   return build_table(ix);
 }
 
+extern "C" int svdss_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+// another replica of a resident (or host-side) index in the HBM of `device`: SURVEY 8(e), index replicated per GPU.
+// The new handle owns its device buffers and a copy of the small host-side parts; the source stays as it is.
+extern "C" int svdss_index_replicate(const svdss_index_t* src, int32_t device, svdss_index_t** out) {
+  if (!src || !out || device < 0) return SVDSS_EINVAL;
+  // text and suffix array travel through the host copy of the source
+  int rc = svdss_index_fetch_host(const_cast<svdss_index*>(src));
+  if (rc != SVDSS_OK && rc != SVDSS_ENODEV) return rc;
+  svdss_index* ix = new (std::nothrow) svdss_index();
+  if (!ix) return SVDSS_ENOMEM;
+  ix->n = src->n;
+  memcpy(ix->acc, src->acc, sizeof ix->acc);
+  ix->n_contigs = src->n_contigs;
+  ix->sa_wide = src->sa_wide;
+  try { ix->blocks = src->blocks; ix->dollar = src->dollar; } catch (...) { delete ix; return SVDSS_ENOMEM; }
+  HIPCHK(hipSetDevice(device));
+  ix->device = device;
+  const size_t bb = ix->blocks.size() * sizeof(svdss_u4), db = (ix->dollar.size() + 1) * sizeof(int64_t);
+  const bool have = (int64_t)src->text.size() == src->n &&
+                    (int64_t)(src->sa_wide ? src->sa64.size() : src->sa32.size()) == src->n;
+  auto fail = [&](int code) { free_device_side(ix); delete ix; return code; };
+  if (hipMalloc(&ix->d_blocks, bb) != hipSuccess || hipMalloc(&ix->d_dollar, db) != hipSuccess) return fail(SVDSS_ENOMEM);
+  if (hipMemcpy(ix->d_blocks, ix->blocks.data(), bb, hipMemcpyHostToDevice) != hipSuccess) return fail(SVDSS_EHIP);
+  if (!ix->dollar.empty() &&
+      hipMemcpy(ix->d_dollar, ix->dollar.data(), ix->dollar.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(SVDSS_EHIP);
+  if (have) {
+    const size_t tb = (size_t)ix->n + 128 + 16, sb = (size_t)ix->n * (ix->sa_wide ? 8 : 4);
+    if (hipMalloc(&ix->d_text, tb) != hipSuccess || hipMalloc(&ix->d_sa, sb + 16) != hipSuccess) return fail(SVDSS_ENOMEM);
+    if (hipMemset(ix->d_text, 0, tb) != hipSuccess ||
+        hipMemcpy((uint8_t*)ix->d_text + 64, src->text.data(), (size_t)ix->n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ix->d_sa, src->sa_wide ? (const void*)src->sa64.data() : (const void*)src->sa32.data(), sb,
+                  hipMemcpyHostToDevice) != hipSuccess)
+      return fail(SVDSS_EHIP);
+  }
+  rc = build_table(ix);
+  if (rc != SVDSS_OK) return fail(rc);
+  *out = ix;
+  return SVDSS_OK;
+}
+
 static SvdssDevIndex host_view(const svdss_index* ix) {
   SvdssDevIndex v;
   v.blocks = ix->blocks.data();
@@ -1026,6 +1072,10 @@ struct svdss_sfs_batch {
   int32_t n_seg = 1;        // segments per read used by the last call
   uint32_t epoch = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ek0 = nullptr, ek1 = nullptr;
+  // host-buffer entry points: the batch object's own non-blocking stream (copies in, kernels, copies out), so that
+  // calls on different batch objects -- e.g. two threads feeding the GPU from a BAM file -- overlap
+  hipStream_t own_stream = nullptr;
+  DevBuf packed, byte_off, lens32;   // svdss_sfs_search_batch_bam: the 4-bit bases as they sit in the BAM records
 };
 
 static int ensure(DevBuf& b, size_t bytes) {
@@ -1048,8 +1098,9 @@ extern "C" void svdss_sfs_batch_free(svdss_sfs_batch_t* b) {
   if (b->device >= 0) (void)hipSetDevice(b->device);
   for (DevBuf* d : {&b->rec, &b->counts, &b->n_ext, &b->out_off, &b->out_qs, &b->out_len, &b->tmp,
                     &b->misc, &b->reads, &b->offsets, &b->base2, &b->sum, &b->seg_rec, &b->seg_info,
-                    &b->fallback, &b->fallback2, &b->seg_take, &b->order, &b->order_cnt})
+                    &b->fallback, &b->fallback2, &b->seg_take, &b->order, &b->order_cnt, &b->packed, &b->byte_off, &b->lens32})
     release(*d);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->ek0) (void)hipEventDestroy(b->ek0);
@@ -1349,12 +1400,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   return SVDSS_OK;
 }
 
-extern "C" int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* reads,
-                                      const int64_t* offsets, int64_t n_reads, int32_t flags,
-                                      svdss_sfs_batch_t** out) {
-  if (!ix || !out || n_reads < 0) return SVDSS_EINVAL;
-  if (n_reads > 0 && (!reads || !offsets)) return SVDSS_EINVAL;
-  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;
+static int batch_for_host_entry(const svdss_index_t* ix, svdss_sfs_batch_t** out, svdss_sfs_batch** bp) {
   HIPCHK(hipSetDevice(ix->device));
   svdss_sfs_batch* b = *out;
   if (!b) {
@@ -1363,6 +1409,20 @@ extern "C" int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* re
     b->device = ix->device;
     *out = b;
   }
+  if (!b->own_stream) HIPCHK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+  *bp = b;
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* reads,
+                                      const int64_t* offsets, int64_t n_reads, int32_t flags,
+                                      svdss_sfs_batch_t** out) {
+  if (!ix || !out || n_reads < 0) return SVDSS_EINVAL;
+  if (n_reads > 0 && (!reads || !offsets)) return SVDSS_EINVAL;
+  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;
+  svdss_sfs_batch* b = nullptr;
+  int rc;
+  if ((rc = batch_for_host_entry(ix, out, &b))) return rc;
   if (n_reads == 0) {
     b->n_reads = 0; b->total = 0; b->total_ext = 0; b->kernel_ms = 0.0; b->search_ms = 0.0;
     return SVDSS_OK;
@@ -1374,15 +1434,95 @@ extern "C" int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* re
     if (l >= (int64_t)0x7fffffff) return SVDSS_ERANGE;
   }
   const int64_t total = offsets[n_reads];
-  int rc;
   const size_t padded = (size_t)((total + 15) & ~(int64_t)15) + 16;
   if ((rc = ensure(b->reads, padded))) return rc;
   if ((rc = ensure(b->offsets, (size_t)(n_reads + 1) * sizeof(int64_t)))) return rc;
-  HIPCHK(hipMemset(b->reads.p, 0, padded));
-  if (total > 0) HIPCHK(hipMemcpy(b->reads.p, reads, (size_t)total, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(b->offsets.p, offsets, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  const hipStream_t st = b->own_stream;
+  HIPCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded - 32), 0, 32, st));   // the bytes past the last read
+  if (total > 0) HIPCHK(hipMemcpyAsync(b->reads.p, reads, (size_t)total, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->offsets.p, offsets, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
   return svdss_sfs_search_batch_device(ix, (const uint8_t*)b->reads.p, (const int64_t*)b->offsets.p,
-                                       n_reads, total, flags, nullptr, out);
+                                       n_reads, total, flags, st, out);
+}
+
+// ---- BAM records in: 4-bit bases -> nt6 on the GPU (ping_pong.cpp:90-94: seq_nt16_str, then seq_nt6_table) ----
+
+// read r = blockIdx.y (+ y0), 16 symbols per thread: 8 packed bytes in, 16 nt6 bytes out
+__global__ void __launch_bounds__(256) decode_seq4_kernel(const uint8_t* packed, const int64_t* byte_off, const int64_t* sym_off,
+                                                          int64_t y0, int64_t n_reads, uint8_t* out) {
+  const int64_t r = y0 + blockIdx.y;
+  if (r >= n_reads) return;
+  const int64_t len = sym_off[r + 1] - sym_off[r];
+  const int64_t j0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (j0 >= len) return;
+  const uint8_t* src = packed + byte_off[r] + (j0 >> 1);
+  uint8_t* dst = out + sym_off[r] + j0;
+  const int n = len - j0 < 16 ? (int)(len - j0) : 16;
+  // "=ACMGRSVTWYHKDBN": A=1 C=2 G=4 T=8 -> nt6 1..4, every other code (IUPAC, '=') -> 5 like seq_nt6_table
+  const uint64_t lut = 0x5555555455535215ull >> 0;   // nibble v -> nt6 at bits 4v (v=1:1, 2:2, 4:3, 8:4, else 5)
+  for (int k = 0; k < n; ++k) {
+    const uint8_t bb = src[k >> 1];
+    const int v = (k & 1) ? (bb & 15) : (bb >> 4);
+    dst[k] = (uint8_t)((lut >> (4 * v)) & 15u);
+  }
+}
+
+extern "C" int svdss_sfs_search_batch_bam(const svdss_index_t* ix, const uint8_t* seq4, const int64_t* byte_off,
+                                          const int32_t* l_seq, int64_t n_reads, int32_t flags,
+                                          svdss_sfs_batch_t** out) {
+  if (!ix || !out || n_reads < 0) return SVDSS_EINVAL;
+  if (n_reads > 0 && (!seq4 || !byte_off || !l_seq)) return SVDSS_EINVAL;
+  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;
+  svdss_sfs_batch* b = nullptr;
+  int rc;
+  if ((rc = batch_for_host_entry(ix, out, &b))) return rc;
+  if (n_reads == 0) {
+    b->n_reads = 0; b->total = 0; b->total_ext = 0; b->kernel_ms = 0.0; b->search_ms = 0.0;
+    return SVDSS_OK;
+  }
+  std::vector<int64_t> sym_off((size_t)n_reads + 1, 0);
+  int64_t max_len = 0;
+  for (int64_t i = 0; i < n_reads; ++i) {
+    if (l_seq[i] < 0 || byte_off[i + 1] - byte_off[i] < ((int64_t)l_seq[i] + 1) / 2) return SVDSS_EINVAL;
+    sym_off[(size_t)i + 1] = sym_off[(size_t)i] + l_seq[i];
+    if (l_seq[i] > max_len) max_len = l_seq[i];
+  }
+  const int64_t total = sym_off[(size_t)n_reads], pbytes = byte_off[n_reads] - byte_off[0];
+  const size_t padded = (size_t)((total + 15) & ~(int64_t)15) + 16;
+  if ((rc = ensure(b->reads, padded))) return rc;
+  if ((rc = ensure(b->offsets, (size_t)(n_reads + 1) * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(b->byte_off, (size_t)(n_reads + 1) * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(b->packed, (size_t)pbytes + 16))) return rc;
+  const hipStream_t st = b->own_stream;
+  std::vector<int64_t> rel((size_t)n_reads + 1);
+  for (int64_t i = 0; i <= n_reads; ++i) rel[(size_t)i] = byte_off[i] - byte_off[0];
+  HIPCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded - 32), 0, 32, st));
+  if (pbytes > 0) HIPCHK(hipMemcpyAsync(b->packed.p, seq4 + byte_off[0], (size_t)pbytes, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->byte_off.p, rel.data(), (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->offsets.p, sym_off.data(), (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  if (max_len > 0) {
+    const unsigned gx = (unsigned)((max_len + 256 * 16 - 1) / (256 * 16));
+    for (int64_t y0 = 0; y0 < n_reads; y0 += 65535) {
+      const unsigned gy = (unsigned)std::min<int64_t>(65535, n_reads - y0);
+      hipLaunchKernelGGL(decode_seq4_kernel, dim3(gx, gy), dim3(256), 0, st, (const uint8_t*)b->packed.p,
+                         (const int64_t*)b->byte_off.p, (const int64_t*)b->offsets.p, y0, n_reads, (uint8_t*)b->reads.p);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(st));   // rel / sym_off are locals: the copies must have left them
+  return svdss_sfs_search_batch_device(ix, (const uint8_t*)b->reads.p, (const int64_t*)b->offsets.p,
+                                       n_reads, total, flags, st, out);
+}
+
+extern "C" int svdss_host_alloc(int64_t bytes, void** out) {
+  if (!out || bytes < 0) return SVDSS_EINVAL;
+  *out = nullptr;
+  HIPCHK(hipHostMalloc(out, (size_t)(bytes ? bytes : 16), hipHostMallocDefault));
+  return SVDSS_OK;
+}
+
+extern "C" void svdss_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 extern "C" int svdss_sfs_batch_device_ptrs(const svdss_sfs_batch_t* b, void** counts, void** qs,
@@ -1400,6 +1540,15 @@ extern "C" int svdss_sfs_batch_fetch(const svdss_sfs_batch_t* b, int64_t* counts
   if (!b) return SVDSS_EINVAL;
   if (b->n_reads == 0) return SVDSS_OK;
   HIPCHK(hipSetDevice(b->device));
+  if (b->own_stream) {   // (results of a host-buffer call: stay off the default stream)
+    const hipStream_t st = b->own_stream;
+    if (counts) HIPCHK(hipMemcpyAsync(counts, b->counts.p, (size_t)b->n_reads * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (n_ext) HIPCHK(hipMemcpyAsync(n_ext, b->n_ext.p, (size_t)b->n_reads * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (qs && b->total > 0) HIPCHK(hipMemcpyAsync(qs, b->out_qs.p, (size_t)b->total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (len && b->total > 0) HIPCHK(hipMemcpyAsync(len, b->out_len.p, (size_t)b->total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SVDSS_OK;
+  }
   if (counts)
     HIPCHK(hipMemcpy(counts, b->counts.p, (size_t)b->n_reads * sizeof(int64_t), hipMemcpyDeviceToHost));
   if (n_ext)

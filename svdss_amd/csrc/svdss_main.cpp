@@ -87,6 +87,7 @@ struct Options {
   bool useht = true;
   int threads = 4, bsize = 10000, omax = 100000;  // config.hpp:68-69,88
   int io_threads = 0;                              // BGZF inflate workers (0: up to 16)
+  int gpus = 1;                                    // --gpus N: index replicated, batches / sub-clusters shard
   bool putative = true, assemble = true, verbose = false, version = false, help = false;
 };
 
@@ -109,6 +110,7 @@ static Options parse(int argc, char** argv) {
     else if (take(argc, argv, i, "--fastx", v)) o.fastx = v;
     else if (take(argc, argv, i, "--threads", v)) o.threads = atoi(v.c_str());
     else if (take(argc, argv, i, "--io-threads", v)) o.io_threads = atoi(v.c_str());
+    else if (take(argc, argv, i, "--gpus", v)) o.gpus = v == "all" ? svdss_device_count() : atoi(v.c_str());
     else if (take(argc, argv, i, "--bsize", v)) o.bsize = atoi(v.c_str());
     else if (take(argc, argv, i, "--omax", v)) o.omax = atoi(v.c_str());
     else if (take(argc, argv, i, "--reference", v)) o.reference = v;
@@ -188,11 +190,43 @@ struct Read {
   int64_t first = 0, count = 0;  // into the result arrays (-1: not searched)
 };
 
+// page-locked staging buffers (svdss_host_alloc), recycled between batches
+struct PinnedPool {
+  std::mutex m;
+  std::vector<std::pair<uint8_t*, size_t>> free_;
+  uint8_t* get(size_t bytes, size_t& cap) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i].second >= bytes) {
+          uint8_t* p = free_[i].first;
+          cap = free_[i].second;
+          free_.erase(free_.begin() + (long)i);
+          return p;
+        }
+    }
+    void* p = nullptr;
+    cap = bytes + bytes / 8 + 4096;
+    check(svdss_host_alloc((int64_t)cap, &p), "svdss_host_alloc");
+    return (uint8_t*)p;
+  }
+  void put(uint8_t* p, size_t cap) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(m);
+    free_.emplace_back(p, cap);
+  }
+  ~PinnedPool() { for (auto& f : free_) svdss_host_free(f.first); }
+};
+
 struct SearchBatch {
+  uint64_t seq = 0;              // position in the input: batches are written in this order
   std::vector<Read> reads;
   std::vector<uint8_t> gbuf;     // nt6 bases of the searched reads, back to back (FASTX mode)
-  std::unique_ptr<uint8_t[]> graw; // ... or this uninitialised buffer (BAM mode: filled by the decode workers)
-  const uint8_t* bases() const { return graw ? graw.get() : gbuf.data(); }
+  // BAM mode: the 4-bit bases exactly as the records hold them, in page-locked memory; the GPU expands them
+  uint8_t* seq4 = nullptr;
+  size_t seq4_cap = 0;
+  std::vector<int64_t> boff;     // byte offset of every searched read in seq4 (+ end)
+  std::vector<int32_t> lseq;
   std::vector<int64_t> goff;
   std::vector<size_t> gidx;      // searched read -> index into reads
   std::vector<int32_t> qs, ln;   // results
@@ -251,6 +285,18 @@ int main_search(const Options& o) {
   if (o.verbose) logmsg("debug", "index file read at +" + since() + " s");
   check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
   if (o.verbose) logmsg("debug", "index and k-mer table on the device at +" + since() + " s");
+  // --gpus N: one replica of the index per GPU; the batches of reads go to whichever GPU is free, the
+  // text is written in input order whatever GPU searched a batch -- the same bytes as with one GPU
+  // (SVDSS_GPUS_OVERSUBSCRIBE: more replicas than GPUs, replica d on GPU d % count -- exercises the path on a one-GPU box)
+  const int n_dev = std::max(1, svdss_device_count());
+  const int n_gpus = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev));
+  std::vector<svdss_index_t*> replicas(1, ix);
+  for (int d = 1; d < n_gpus; ++d) {
+    svdss_index_t* r = nullptr;
+    check(svdss_index_replicate(ix, d % n_dev, &r), "svdss_index_replicate");
+    replicas.push_back(r);
+  }
+  if (n_gpus > 1) logmsg("info", "Index replicated on " + std::to_string(n_gpus) + " GPUs");
   const bool bam_mode = !o.bam.empty();
   BamReader* bam = nullptr;
   FastxReader* fx = nullptr;
@@ -268,13 +314,14 @@ int main_search(const Options& o) {
   // batch, thread slice by thread slice, read names in std::map order (ping_pong.cpp:215-217).
   // (32 k reads keep the GPU efficient and let parsing, search and output of successive batches overlap)
   const int64_t super = std::max<int64_t>(o.bsize, 32768 / o.bsize * (int64_t)o.bsize);
-  // a packed pair of 4-bit BAM bases -> two nt6 codes
-  uint8_t nt16_to_nt6[16];
-  check(svdss_nt6_encode(NT16, 16, nt16_to_nt6), "svdss_nt6_encode");
-  uint16_t pair_to_nt6[256];
-  for (int v = 0; v < 256; ++v) pair_to_nt6[v] = (uint16_t)(nt16_to_nt6[v >> 4] | (nt16_to_nt6[v & 15] << 8));
-
-  BoundedQueue<SearchBatch> parsed(2), searched(2);
+  BoundedQueue<SearchBatch> parsed(3);   // (the GPU threads are created below, after the replicas)
+  PinnedPool pinned;
+  // searched batches wait here for their turn: two GPU threads finish them out of order
+  std::mutex done_m;
+  std::condition_variable done_cv;
+  std::map<uint64_t, std::unique_ptr<SearchBatch>> done;
+  bool gpu_finished = false;
+  uint64_t next_seq = 0;
   uint64_t n_seen = 0, total_sfs = 0;
   double t_slice = 0, t_decode = 0, t_gpu = 0, t_write = 0;   // busy seconds of the stages (--verbose)
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -343,15 +390,18 @@ int main_search(const Options& o) {
           bt->gidx.push_back(i);
           bt->goff.push_back(bt->goff.back() + bt->reads[i].len);
         }
-        bt->graw.reset(new uint8_t[(size_t)bt->goff.back() + 16]);
+        bt->boff.assign(1, 0);
+        bt->lseq.resize(bt->gidx.size());
+        for (size_t k = 0; k < bt->gidx.size(); ++k) {
+          const int32_t l = recs[bt->gidx[k]].l_seq;
+          bt->lseq[k] = l;
+          bt->boff.push_back(bt->boff.back() + ((int64_t)l + 1) / 2);
+        }
+        bt->seq4 = pinned.get((size_t)bt->boff.back() + 16, bt->seq4_cap);
         parallel_for(bt->gidx.size(), [&](size_t lo, size_t hi) {
           for (size_t k = lo; k < hi; ++k) {
             const BamReader::RawView& rr = recs[bt->gidx[k]];
-            const uint8_t* seq4 = rr.seq4();
-            uint8_t* dst = bt->graw.get() + bt->goff[k];
-            const size_t full = (size_t)rr.l_seq / 2;
-            for (size_t x = 0; x < full; ++x) memcpy(dst + 2 * x, &pair_to_nt6[seq4[x]], 2);
-            if (rr.l_seq & 1) dst[rr.l_seq - 1] = nt16_to_nt6[seq4[full] >> 4];
+            memcpy(bt->seq4 + bt->boff[k], rr.seq4(), (size_t)(bt->boff[k + 1] - bt->boff[k]));
           }
         });
         t_decode += secs(ts1, now());
@@ -370,14 +420,26 @@ int main_search(const Options& o) {
           bt->reads.push_back(std::move(r));
         }
       }
-      if (!bt->reads.empty()) parsed.push(std::move(bt));
+      if (!bt->reads.empty()) { bt->seq = next_seq++; parsed.push(std::move(bt)); }
     }
     parsed.close();
   });
 
   std::thread writer([&] {
     std::string out;
-    while (std::unique_ptr<SearchBatch> bt = searched.pop()) {
+    uint64_t want = 0;
+    for (;;) {
+      std::unique_ptr<SearchBatch> bt;
+      {
+        std::unique_lock<std::mutex> lk(done_m);
+        done_cv.wait(lk, [&] { return done.count(want) || (gpu_finished && done.empty()); });
+        auto it = done.find(want);
+        if (it == done.end()) break;
+        bt = std::move(it->second);
+        done.erase(it);
+        ++want;
+      }
+      done_cv.notify_all();
       const auto tw0 = now();
       const std::vector<Read>& reads = bt->reads;
       // output_batch order: reference batches of bsize reads -> thread t takes reads n with
@@ -415,29 +477,56 @@ int main_search(const Options& o) {
     fflush(stdout);
   });
 
-  svdss_sfs_batch_t* res = nullptr;
-  while (std::unique_ptr<SearchBatch> bt = parsed.pop()) {
-    const auto tg0 = now();
-    if (!bt->gidx.empty()) {
-      std::vector<int64_t> counts(bt->gidx.size());
-      check(svdss_sfs_search_batch(ix, bt->bases(), bt->goff.data(), (int64_t)bt->gidx.size(),
-                                   o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch");
-      bt->qs.resize((size_t)svdss_sfs_batch_total(res));
-      bt->ln.resize(bt->qs.size());
-      check(svdss_sfs_batch_fetch(res, counts.data(), bt->qs.data(), bt->ln.data(), nullptr), "svdss_sfs_batch_fetch");
-      int64_t acc = 0;
-      for (size_t k = 0; k < bt->gidx.size(); ++k) {
-        bt->reads[bt->gidx[k]].first = acc;
-        bt->reads[bt->gidx[k]].count = counts[k];
-        acc += counts[k];
+  // two threads feed the GPU, each with its own batch object (own stream): the upload of one batch overlaps the
+  // search of the other
+  std::mutex t_m;
+  auto gpu_worker = [&](svdss_index_t* ix) {
+    svdss_sfs_batch_t* res = nullptr;
+    while (std::unique_ptr<SearchBatch> bt = parsed.pop()) {
+      const auto tg0 = now();
+      if (!bt->gidx.empty()) {
+        std::vector<int64_t> counts(bt->gidx.size());
+        if (bam_mode)
+          check(svdss_sfs_search_batch_bam(ix, bt->seq4, bt->boff.data(), bt->lseq.data(), (int64_t)bt->gidx.size(),
+                                           o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch_bam");
+        else
+          check(svdss_sfs_search_batch(ix, bt->gbuf.data(), bt->goff.data(), (int64_t)bt->gidx.size(),
+                                       o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch");
+        bt->qs.resize((size_t)svdss_sfs_batch_total(res));
+        bt->ln.resize(bt->qs.size());
+        check(svdss_sfs_batch_fetch(res, counts.data(), bt->qs.data(), bt->ln.data(), nullptr), "svdss_sfs_batch_fetch");
+        int64_t acc = 0;
+        for (size_t k = 0; k < bt->gidx.size(); ++k) {
+          bt->reads[bt->gidx[k]].first = acc;
+          bt->reads[bt->gidx[k]].count = counts[k];
+          acc += counts[k];
+        }
       }
+      std::vector<uint8_t>().swap(bt->gbuf);
+      pinned.put(bt->seq4, bt->seq4_cap);
+      bt->seq4 = nullptr;
+      { std::lock_guard<std::mutex> lk(t_m); t_gpu += secs(tg0, now()); }
+      {
+        // (bounded: a finished batch waits until the writer is at most 3 batches behind)
+        std::unique_lock<std::mutex> lk(done_m);
+        const uint64_t sq = bt->seq;
+        done_cv.wait(lk, [&] { return done.size() < 4 || done.begin()->first > sq; });
+        done[sq] = std::move(bt);
+      }
+      done_cv.notify_all();
     }
-    std::vector<uint8_t>().swap(bt->gbuf);
-    bt->graw.reset();
-    t_gpu += secs(tg0, now());
-    searched.push(std::move(bt));
+    svdss_sfs_batch_free(res);
+  };
+  {
+    std::vector<std::thread> gpu_threads;
+    for (int d = 0; d < n_gpus; ++d)
+      for (int k = 0; k < 2; ++k)
+        if (d || k) gpu_threads.emplace_back(gpu_worker, replicas[(size_t)d]);
+    gpu_worker(replicas[0]);
+    for (std::thread& th : gpu_threads) th.join();
   }
-  searched.close();
+  { std::lock_guard<std::mutex> lk(done_m); gpu_finished = true; }
+  done_cv.notify_all();
   producer.join();
   writer.join();
   if (o.verbose) {
@@ -445,8 +534,7 @@ int main_search(const Options& o) {
     logmsg("debug", "stage busy seconds: inflate+slice " + std::to_string(t_slice) + ", decode " + std::to_string(t_decode) +
                         ", GPU search + copies " + std::to_string(t_gpu) + ", format+write " + std::to_string(t_write));
   }
-  svdss_sfs_batch_free(res);
-  svdss_index_free(ix);
+  for (svdss_index_t* r : replicas) svdss_index_free(r);
   delete bam;
   delete fx;
   return 0;
@@ -473,7 +561,7 @@ int main(int argc, char** argv) {
     } else if (!strcmp(argv[1], "call")) {
       if (o.reference.empty() || o.bam.empty() || o.sfs.empty()) { fputs(CALL_USAGE, stderr); return EXIT_FAILURE; }  // main.cpp:56-59
       CallOptions c;
-      c.reference = o.reference; c.bam = o.bam; c.sfs = o.sfs; c.threads = o.threads;
+      c.reference = o.reference; c.bam = o.bam; c.sfs = o.sfs; c.threads = o.threads; c.gpus = o.gpus;
       c.min_cluster_weight = o.min_cluster_weight; c.min_sv_length = o.min_sv_length; c.min_mapq = o.min_mapq;
       c.useht = o.useht; c.min_ratio = o.min_ratio; c.poa = o.poa; c.clusters = o.clusters; c.verbose = o.verbose;
       main_call(c);

@@ -129,6 +129,12 @@ def test_search_fastx_and_bam_text(tmp_path, assemble):
     assert r2.returncode == 0
     assert r2.stdout == _expected_text(keep_names, keep_reads, hps, [True] * len(keep_names), fm, assemble, 4, 16)
     assert len(r2.stdout) > len(r.stdout)
+    # --gpus N (index replicated, batches go to whichever GPU is free, output in input order): the same bytes.  On a
+    # one-GPU box SVDSS_GPUS_OVERSUBSCRIBE puts the replicas on the same device -- the code path is the same
+    r3 = run("search", "--index", str(fmd), "--bam", str(bam), "--noputative", "--threads", "4", "--bsize", "16", "--gpus", "3",
+             *extra, env=dict(os.environ, SVDSS_GPUS_OVERSUBSCRIBE="1"))
+    assert r3.returncode == 0, r3.stderr
+    assert r3.stdout == r2.stdout and "replicated on 3 GPUs" in r3.stderr
     # the text parses back (sfs.cpp:5-30)
     parsed = svdss_amd.parse_sfsfile(r2.stdout)
     assert set(parsed) <= set(keep_names)

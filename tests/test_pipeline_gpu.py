@@ -80,6 +80,13 @@ def test_index_search_call_recovers_implanted_svs(tmp_path, het):
     r2 = subprocess.run([BIN, "call", "--reference", str(fa), "--bam", str(bam), "--sfs", str(sfs_path), "--threads", "4",
                          "--min-sv-length", "50"], capture_output=True, text=True, env=dict(os.environ, SVDSS_CALL_CACHE_GB="0"))
     assert r2.returncode == 0 and r2.stdout == vcf
+    # --gpus N: POA and realignment batches shard by sub-cluster index, the rows come back in order, dedup and chain
+    # filter run once on all of them: the same VCF and SAM bytes
+    r3 = subprocess.run([BIN, "call", "--reference", str(fa), "--bam", str(bam), "--sfs", str(sfs_path), "--threads", "4",
+                         "--min-sv-length", "50", "--gpus", "3", "--poa", str(tmp_path / "poa3.sam")], capture_output=True,
+                        text=True, env=dict(os.environ, SVDSS_GPUS_OVERSUBSCRIBE="1"))
+    assert r3.returncode == 0, r3.stderr
+    assert r3.stdout == vcf and (tmp_path / "poa3.sam").read_text() == sam
 
 
 def test_run_svdss_chain_with_raw_reads(tmp_path):
