@@ -1,0 +1,67 @@
+"""BASELINE config 3: chr20-length reference, 10x HiFi-length reads (42,963 x 15 kb), SFS search + clustering + POA +
+realignment end to end through the `SVDSS` binaries, VCF checked against the implanted truth (heterozygous and
+homozygous SVs) and -- on the reads around a few of the SVs, where the Python mirror of the reference's host logic
+finishes in seconds -- byte for byte against svdss_amd.caller.call."""
+import os
+import subprocess
+
+import pytest
+
+from svdss_amd import bamio, caller, synth
+from tests.common import ROOT
+from tools import e2e_call
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "svdss_amd", "SVDSS")
+
+
+def _chain(work, fa, bam, threads="4"):
+    fmd = os.path.join(work, "ref.fa.fmd")
+    if not os.path.exists(fmd):
+        r = subprocess.run([BIN, "index", "-t", "16", "-d", fa, "-o", fmd], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run([BIN, "search", "--index", fmd, "--bam", bam, "--threads", threads], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sfs = bam + ".sfs"
+    with open(sfs, "w") as fh:
+        fh.write(r.stdout)
+    r2 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", sfs, "--threads", threads,
+                         "--min-sv-length", "50"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    return r.stdout, r2.stdout
+
+
+def test_chr20_10x_end_to_end(tmp_path):
+    work = str(tmp_path)
+    L, ref_bp = 15000, 64_444_167
+    fa, bam, svs, het, recs, hdr, ref = e2e_call.write_dataset(work, ref_bp, 64, 10.0, L, seed=11, het_every=2, max_len=2000)
+    assert 42_000 < len(recs) < 43_500 and sum(het) == 32
+    sfs_text, vcf = _chain(work, fa, bam)
+    called = e2e_call.parse_vcf(vcf)
+    truth = [(s.pos, s.kind, s.length) for s in svs]
+    # every implanted SV is called once, at its position (insertion points may shift within a repeat of the flanks),
+    # with its type and length; nothing else is called
+    for (p, k, l), h in zip(truth, het):
+        hits = [c for c in called if c[1] == k and c[2] == l and abs(c[0] - p) <= 12]
+        assert len(hits) == 1, (p, k, l, h, [(c[0], c[1], c[2]) for c in called if abs(c[0] - p) < 3000])
+    assert len(called) == len(truth)
+    # the reads around four SVs (two heterozygous, two homozygous): the same chain on that sub-BAM, and the Python mirror
+    # of the host logic (clusterer.cpp / caller.cpp restated in svdss_amd/) on the same inputs -> the same VCF bytes
+    pick = [k for k in range(len(svs)) if het[k]][:2] + [k for k in range(len(svs)) if not het[k]][:2]
+    win = [(svs[k].pos - 25_000, svs[k].pos + 25_000) for k in pick]
+    sub = [r[2] for r in recs if any(r[0] < b and r[1] > a for a, b in win)]
+    assert 100 < len(sub) < 600
+    sub_bam = os.path.join(work, "sub.bam")
+    e2e_call.write_bam_records(sub_bam, hdr, sub)
+    sub_sfs, sub_vcf = _chain(work, fa, sub_bam)
+    ref_names, ref_lens, alns = bamio.read_bam(sub_bam)
+    chromosomes = {"chrS": synth.to_ascii(ref[0])}
+    mirror_vcf, info = caller.call(alns, sub_sfs, chromosomes, list(zip(ref_names, ref_lens)), ref_names, threads=4,
+                                   min_sv_length=50)
+    assert sub_vcf == mirror_vcf
+    sub_called = e2e_call.parse_vcf(sub_vcf)
+    assert len(sub_called) == 4
+    full_rows = {(c[0], c[1], c[2]): c[3] for c in called}
+    for c in sub_called:       # and those rows are the rows of the full run (same reads in the cluster, same consensus)
+        f = full_rows[(c[0], c[1], c[2])]
+        assert f[:5] == c[3][:5]
