@@ -90,6 +90,10 @@ void write_record(ByteSink& w, const BamRecord& r, const std::vector<uint32_t>& 
   } lut_obj;
   const uint8_t* lut = lut_obj.t;
   for (int32_t i = 0; i < l_seq; ++i) packed[(size_t)i >> 1] |= (uint8_t)(lut[(uint8_t)seq[(size_t)i]] << ((~i & 1) << 2));
+  // BAM keeps l_read_name in 8 bits and n_cigar_op in 16 (longer CIGARs live in a CG tag, which this writer does not
+  // produce): refuse instead of writing a record that no longer parses
+  if (r.qname.size() + 1 > 255) die("read name longer than 254 characters: " + r.qname);
+  if (cigar.size() > 65535) die("more than 65535 CIGAR operations (CG tag records are not supported): " + r.qname);
   const uint8_t l_name = (uint8_t)(r.qname.size() + 1);
   const uint16_t n_cig = (uint16_t)cigar.size();
   const int32_t block = 32 + l_name + 4 * n_cig + (int32_t)packed.size() + l_seq + (int32_t)aux.size();
@@ -161,6 +165,25 @@ int main_smooth(const CallOptions& o) {
   auto smooth_one = [&](const BamRecord& r, ByteSink& sink) {
     const std::string& ref = chrom.at(bam.ref_names()[(size_t)r.tid]);
     const std::string seq = r.seq_string();
+    {
+      // the walk below indexes ref[pos ..] and seq[..] by the CIGAR: an alignment that overhangs the contig end or
+      // whose CIGAR does not add up to l_seq is passed through unchanged with XF = 3, the reference's tag for a record
+      // it could not rebuild consistently (smoother.cpp:219-228)
+      size_t rl = 0, ql = 0;
+      for (uint32_t c : r.cigar) {
+        const uint32_t l = c >> 4, op = c & 0xf;
+        if (is_m(op)) { rl += l; ql += l; }
+        else if (op == 1 || op == 4) ql += l;
+        else if (op == 2) rl += l;
+        else break;
+      }
+      if (r.pos < 0 || (size_t)r.pos + rl > ref.size() || ql != seq.size()) {
+        std::vector<uint8_t> aux3 = r.aux;
+        set_xf(aux3, 3);
+        write_record(sink, r, r.cigar, seq, r.qual, aux3);
+        return;
+      }
+    }
     std::string nseq;
     std::vector<uint8_t> nqual;
     std::vector<uint32_t> ncig;

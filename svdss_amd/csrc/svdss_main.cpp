@@ -1,13 +1,15 @@
 // svdss_main.cpp -- `SVDSS` host CLI on top of libsvdss_hip.so.
 //
-// Keeps the process boundary B1 of SURVEY.md 8(b) for the path built so far:
+// Keeps the process boundary B1 of SURVEY.md 8(b):
 //   SVDSS index  -d ref.fa -o ref.fa.fmd [-t T]        (/root/reference/main.cpp:34-37, run_svdss:142)
+//   SVDSS smooth --reference R --bam B [--threads T] [--min-mapq N] [--accp F]      (main.cpp:69-77; smooth_host.cpp)
 //   SVDSS search --index F --bam B | --fastx Q [--threads T] [--bsize N] [--noputative]
 //                [--noassemble] [--omax N] [--verbose]  (config.cpp:30-55, main.cpp:62-68)
+//   SVDSS call   --reference R --bam B --sfs S [...]    (main.cpp:55-61; call_host.cpp)
 //   SVDSS --version                                     (main.cpp:45-47)
 // SFS text goes to stdout exactly as PingPong::output_batch prints it
 // (ping_pong.cpp:213-236), logs to stderr, fatal conditions exit(1).
-// `smooth` and `call` are not part of this build yet.
+// Additions of this program: --gpus N (search, call), --io-threads N, --verbose stage timings.
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -128,6 +130,10 @@ static Options parse(int argc, char** argv) {
     else if (!strcmp(argv[i], "--verbose")) o.verbose = true;
     else if (!strcmp(argv[i], "--version")) o.version = true;
     else if (!strcmp(argv[i], "--help") || !strcmp(argv[i], "-h")) o.help = true;
+    else if (!strcmp(argv[i], "--clipped")) {
+      // declared by the reference (config.cpp:44, "EXPERIMENTAL"); its output is not reproducible
+      logmsg("warning", "--clipped (experimental in the reference) is not supported: calling from SFS clusters only");
+    }
     else die(std::string("Option '") + argv[i] + "' does not exist");  // cxxopts throws here
   }
   if (o.threads < 1) o.threads = 1;

@@ -132,3 +132,32 @@ def test_smooth_output_does_not_depend_on_threads_and_spans_many_bgzf_chunks(tmp
     assert out.read_bytes() == outs[0]
     names, lens, alns = bamio.read_bam(str(tmp_path / "out6.bam"))
     assert len(alns) == n_reads and names == ["c1"]
+
+
+def test_inconsistent_records_pass_through_with_xf3(tmp_path):
+    """an alignment that overhangs the contig end, or whose CIGAR does not add up to l_seq, used to be walked
+    past the end of the reference / read (invalid BAM written silently).  Such a record now leaves `SVDSS smooth` as it
+    came in, tagged XF = 3 (the reference's tag for a record it could not rebuild, smoother.cpp:219-228); the valid
+    records around it are smoothed as usual."""
+    rng = np.random.default_rng(4)
+    ref = synth.to_ascii(rng.integers(1, 5, size=3000).astype(np.uint8))
+    fa = tmp_path / "ref.fa"
+    fa.write_text(f">c0\n{ref}\n")
+    good = ref[1000:1070] + ref[1100:1180]                   # 30 bases deleted after the 70th
+    over = ref[2900:3000] + "ACGT" * 13                      # 152 bases "aligned" at 2900 with 152M: 52 past the contig end
+    short = ref[500:600]                                     # 100 bases with a 120M CIGAR
+    recs = [bam_writer.record("short", 0, 0, 500, 60, [("M", 120)], short, [], bytes([30] * 100)),
+            bam_writer.record("good", 0, 0, 1000, 60, [("M", 70), ("D", 30), ("M", 80)], good, [], bytes([30] * 150)),
+            bam_writer.record("over", 0, 0, 2900, 60, [("M", 152)], over, [], bytes([30] * 152))]
+    bam = tmp_path / "in.bam"
+    bam.write_bytes(bam_writer.bam([("c0", 3000)], recs))
+    out = tmp_path / "out.bam"
+    with open(out, "wb") as fh:
+        r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam), "--threads", "2"], stdout=fh,
+                           stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    _, _, got = bamio.read_bam(str(out))
+    by = {a.qname: a for a in got}
+    assert by["over"].tags["XF"] == 3 and by["over"].seq == over and by["over"].cigar == [(152, 0)]
+    assert by["short"].tags["XF"] == 3 and by["short"].seq == short and by["short"].cigar == [(120, 0)]
+    assert by["good"].tags["XF"] == 0 and by["good"].cigar == [(70, 0), (30, 2), (80, 0)]
