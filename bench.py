@@ -299,6 +299,9 @@ def main():
     owner = lpt_partition(contig_lens, world)
     starts = np.concatenate([[0], np.cumsum(contig_lens)[:-1]])
     mine = [(int(starts[i]), int(contig_lens[i])) for i in range(len(contig_lens)) if owner[i] == rank]
+    if len(contig_lens) < world:      # fewer contigs than ranks (chr20 workload): equal slices of the reference instead
+        sl = ref_total // world
+        mine = [(rank * sl, sl)]
     ref_t = torch.from_numpy(ref[0] if len(ref) == 1 else np.concatenate(ref)).to(device)
     del ref
     d_reads, d_offs = simulate_reads_gpu(ref_t, mine, n_reads, L, args.err, seed=13 + 1000 * rank, device=device)

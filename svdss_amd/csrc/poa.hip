@@ -525,7 +525,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
       int64_t ws = 64;
       while (ws < wcap) ws <<= 1;
       const int64_t rs = (wcap + 3) & ~(int64_t)3;
-      const int cols = wcap <= 64 ? 1 : wcap <= 192 ? 3 : 5;
+      const int cols = wcap <= 64 ? 1 : wcap <= 128 ? 2 : wcap <= 192 ? 3 : 5;
       const int64_t ring = 4;
       t.nc = (int32_t)nc; t.ec = (int32_t)ecap; t.max_len = (int32_t)maxl; t.ws = (int32_t)ws; t.rs = (int32_t)rs;
       t.ring = (int32_t)ring;
@@ -567,7 +567,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         cd.t.prio = wk * 2 > wmax ? 3 : wk * 4 > wmax ? 2 : wk * 8 > wmax ? 1 : 0;
       }
     }
-    for (int ci = 0; ci < 3; ++ci) {
+    for (int ci = 0; ci < kPoaWaveNCols; ++ci) {
       Group* g = nullptr;
       size_t fill = 0;   // sub-clusters that fill the machine at the group's LDS size
       for (Cand& cd : cands) {

@@ -19,7 +19,8 @@ struct PoaWaveTask {
 };
 
 // columns per lane the kernel is instantiated for
-static const int kPoaWaveCols[3] = {1, 3, 5};
+static const int kPoaWaveCols[4] = {1, 2, 3, 5};
+static const int kPoaWaveNCols = 4;
 
 size_t poa_wave_lds_bytes(int nc, int max_len, int rs, int ring);
 size_t poa_bundle_lds_bytes(int nc);

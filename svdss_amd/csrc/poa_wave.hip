@@ -877,6 +877,7 @@ hipError_t poa_wave_launch(int cols, const PoaWaveTask* d_tasks, int n_tasks, si
                            int32_t* d_status, unsigned long long* d_cells, hipStream_t stream) {
   hipError_t e;
   if (cols == 1) e = launch_c<1>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
+  else if (cols == 2) e = launch_c<2>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
   else if (cols == 3) e = launch_c<3>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
   else if (cols == 5) e = launch_c<5>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
   else return hipErrorInvalidValue;
