@@ -4,17 +4,20 @@
 // /root/reference/ping_pong.cpp:58,247-249,196-201.  Only what `search` consumes is
 // decoded: flag, refID, l_seq, read name, 4-bit SEQ, integer aux tags (XF, HP).
 #pragma once
+#include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -22,6 +25,131 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+// raw-deflate decoder of one BGZF block: libdeflate when the shared library is on the machine (no header needed: its C
+// API is four functions; 2-3 x zlib's speed, and inflate is what bounds `search` end to end), zlib otherwise
+struct BgzfInflater {
+  typedef void* (*alloc_fn)(void);
+  typedef int (*decomp_fn)(void*, const void*, size_t, void*, size_t, size_t*);
+  typedef void (*free_fn)(void*);
+  typedef uint32_t (*crc_fn)(uint32_t, const void*, size_t);
+  struct Lib {
+    alloc_fn alloc = nullptr; decomp_fn decomp = nullptr; free_fn free_ = nullptr; crc_fn crc = nullptr;
+    Lib() {
+      if (getenv("SVDSS_NO_LIBDEFLATE")) return;
+      void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+      if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+      if (!h) return;
+      alloc = (alloc_fn)dlsym(h, "libdeflate_alloc_decompressor");
+      decomp = (decomp_fn)dlsym(h, "libdeflate_deflate_decompress");
+      free_ = (free_fn)dlsym(h, "libdeflate_free_decompressor");
+      crc = (crc_fn)dlsym(h, "libdeflate_crc32");
+      if (!alloc || !decomp || !free_ || !crc) alloc = nullptr;
+    }
+  };
+  static const Lib& lib() { static Lib l; return l; }
+  void* d = nullptr;
+  BgzfInflater() { if (lib().alloc) d = lib().alloc(); }
+  ~BgzfInflater() { if (d) lib().free_(d); }
+  BgzfInflater(const BgzfInflater&) = delete;
+  BgzfInflater& operator=(const BgzfInflater&) = delete;
+  // nullptr = ok, else what went wrong
+  const char* run(const uint8_t* in, size_t clen, uint8_t* out, uint32_t isize, uint32_t crc) {
+    if (d) {
+      size_t got = 0;
+      if (lib().decomp(d, in, clen, out, isize, &got) != 0 || got != isize) return "BGZF inflate failed";
+      if (lib().crc(0, out, isize) != crc) return "BGZF block CRC mismatch";
+      return nullptr;
+    }
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return "zlib init failed";
+    zs.next_in = const_cast<uint8_t*>(in);
+    zs.avail_in = (uInt)clen;
+    zs.next_out = out;
+    zs.avail_out = isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) return "BGZF inflate failed";
+    if ((uint32_t)crc32(0L, out, isize) != crc) return "BGZF block CRC mismatch";
+    return nullptr;
+  }
+};
+
+// persistent worker threads for the inflate of BGZF blocks (the chunks in flight share them; a thread per chunk per
+// block range used to be spawned and joined for every 32 MB of input)
+class InflatePool {
+ public:
+  explicit InflatePool(int n) {
+    for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+  }
+  ~InflatePool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    for (std::thread& t : th_) t.join();
+  }
+  // fn(k, inflater) for k in [0, n): spread over the workers and the caller; returns when all are done
+  void run(size_t n, const std::function<void(size_t, BgzfInflater&)>& fn) {
+    if (n == 0) return;
+    auto job = std::make_shared<Job>();
+    job->n = n;
+    job->fn = &fn;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      jobs_.push_back(job);
+    }
+    cv_.notify_all();
+    BgzfInflater mine;
+    work_on(*job, mine);
+    std::unique_lock<std::mutex> lk(job->dm);
+    job->dcv.wait(lk, [&] { return job->done == job->n; });
+  }
+
+ private:
+  struct Job {
+    size_t n = 0;
+    std::atomic<size_t> next{0};
+    size_t done = 0;
+    const std::function<void(size_t, BgzfInflater&)>* fn = nullptr;
+    std::mutex dm;
+    std::condition_variable dcv;
+  };
+  void work_on(Job& j, BgzfInflater& inf) {
+    size_t did = 0;
+    for (;;) {
+      const size_t k = j.next.fetch_add(1);
+      if (k >= j.n) break;
+      (*j.fn)(k, inf);
+      ++did;
+    }
+    if (did) {
+      std::lock_guard<std::mutex> lk(j.dm);
+      j.done += did;
+      if (j.done == j.n) j.dcv.notify_all();
+    }
+  }
+  void loop() {
+    BgzfInflater inf;
+    for (;;) {
+      std::shared_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] {
+          while (!jobs_.empty() && jobs_.front()->next.load() >= jobs_.front()->n) jobs_.pop_front();
+          return stop_ || !jobs_.empty();
+        });
+        if (stop_) return;
+        j = jobs_.front();
+      }
+      work_on(*j, inf);
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::shared_ptr<Job>> jobs_;
+  bool stop_ = false;
+};
 
 struct BamRecord {
   int32_t tid = -1, pos = 0, l_seq = 0;
@@ -64,10 +192,12 @@ class BamReader {
       }
     }
     const unsigned hw = std::thread::hardware_concurrency();
-    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(32u, hw ? hw : 1u));
+    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(48u, hw ? hw / 2 : 1u));
+    pool_.reset(new InflatePool(threads_));
   }
   ~BamReader() {
     drain();
+    pool_.reset();
     if (map_) munmap((void*)map_, map_size_);
     if (f_) fclose(f_);
   }
@@ -145,12 +275,12 @@ class BamReader {
 
   struct Bytes {   // uninitialised buffer (std::vector would zero-fill what inflate overwrites anyway)
     std::unique_ptr<uint8_t[]> p;
-    size_t n = 0;
-    void alloc(size_t k) { p.reset(new uint8_t[k ? k : 1]); n = k; }
+    size_t n = 0, cap = 0;
+    void alloc(size_t k) { if (k > cap || !p) { p.reset(new uint8_t[k ? k : 1]); cap = k ? k : 1; } n = k; }
     uint8_t* data() { return p.get(); }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
-    void swap(Bytes& o) { p.swap(o.p); std::swap(n, o.n); }
+    void swap(Bytes& o) { p.swap(o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
   };
 
   // A record sliced but not decoded: core fields + where name / cigar / packed bases / aux tags sit in an
@@ -394,7 +524,15 @@ class BamReader {
     pending_.pop_front();
     if (!c.err.empty()) { err_ = c.err; eof_seen_ = true; drain(); return false; }
     if (c.eof) { eof_seen_ = true; drain(); }
-    chunk_ = std::make_shared<Bytes>();
+    // the buffer goes back to the free list when the last holder of the chunk lets go of it (a fresh 50-100 MB
+    // allocation per chunk is a page fault per 4 KB for the inflate workers)
+    {
+      std::shared_ptr<FreeList> fl = free_;
+      chunk_ = std::shared_ptr<Bytes>(new Bytes(), [fl](Bytes* b) {
+        { std::lock_guard<std::mutex> lk(fl->m); if (fl->v.size() < 8) fl->v.push_back(std::move(*b)); }
+        delete b;
+      });
+    }
     chunk_->swap(c.data);
     ++chunk_id_;
     upos_ = 0;
@@ -480,40 +618,36 @@ class BamReader {
       }
     }
     release();
-    c.data.alloc(total);
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, blocks.size()));
-    std::vector<std::string> errs((size_t)nt);
-    auto work = [&](int t) {
-      for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)nt) {
+    take_buffer(c.data, total);
+    // groups of 8 blocks per task
+    const size_t per = 8, n_tasks = (blocks.size() + per - 1) / per;
+    std::vector<std::string> errs(n_tasks);
+    const std::function<void(size_t, BgzfInflater&)> work = [&](size_t t, BgzfInflater& inf) {
+      for (size_t i = t * per; i < std::min(blocks.size(), (t + 1) * per); ++i) {
         const BlockRef& b = blocks[i];
         if (b.isize == 0) continue;
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) { errs[(size_t)t] = "zlib init failed"; return; }
-        zs.next_in = const_cast<uint8_t*>(src + b.coff);
-        zs.avail_in = (uInt)b.clen;
-        zs.next_out = c.data.data() + b.uoff;
-        zs.avail_out = b.isize;
-        const int rc = inflate(&zs, Z_FINISH);
-        inflateEnd(&zs);
-        if (rc != Z_STREAM_END) { errs[(size_t)t] = "BGZF inflate failed"; return; }
-        if ((uint32_t)crc32(0L, c.data.data() + b.uoff, b.isize) != b.crc) { errs[(size_t)t] = "BGZF block CRC mismatch"; return; }
+        if (const char* e = inf.run(src + b.coff, b.clen, c.data.data() + b.uoff, b.isize, b.crc)) { errs[t] = e; return; }
       }
     };
-    if (nt == 1) work(0);
-    else {
-      std::vector<std::thread> pool;
-      for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-      work(0);
-      for (std::thread& th : pool) th.join();
-    }
+    pool_->run(n_tasks, work);
     for (const std::string& e : errs) if (!e.empty()) { c.err = e; break; }
     return c;
   }
 
+  struct FreeList { std::mutex m; std::vector<Bytes> v; };
+  std::shared_ptr<FreeList> free_ = std::make_shared<FreeList>();
+  void take_buffer(Bytes& dst, size_t bytes) {
+    {
+      std::lock_guard<std::mutex> lk(free_->m);
+      for (size_t i = 0; i < free_->v.size(); ++i)
+        if (free_->v[i].cap >= bytes) { dst.swap(free_->v[i]); free_->v.erase(free_->v.begin() + (long)i); break; }
+    }
+    dst.alloc(bytes);
+  }
+  std::unique_ptr<InflatePool> pool_;
   FILE* f_;
   int threads_ = 1;
-  static constexpr size_t kAhead = 3;
+  static constexpr size_t kAhead = 4;
   std::deque<std::future<Chunk>> pending_;
   std::mutex file_m_;
   std::condition_variable file_cv_;
