@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
     // banded first; if the band loses the sink the read is aligned again with the full matrix (w = L)
     for (int attempt = 0; attempt < 2 && nops < 0; ++attempt) {
       const int w = attempt ? L : 10 + (int)(0.01 * L);
-      int last_r = -1, last_mpl = 0, last_mpr = 0;
+      int last_r = -1, last_mpl = 0, last_mpr = 0, last_beg = 0, last_end = 0;
       // a row that left the ring comes back from HBM into staging slot s (its stores may still be in flight)
       auto stage = [&](int ur, int s) {
         __syncthreads();
@@ -381,12 +381,55 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         int pb0 = 0, pb1 = 0;
         bool fast = !slow && np >= 1;
         if (fast) {
-          pb0 = rbeg[ps0];
-          fast = beg - 1 >= pb0 - G && end <= rend[ps0] + G;
+          // (the predecessor is nearly always the previous row: its band is still in scalar registers)
+          int pe0;
+          if (np == 1 && (int)(pd0 & 255u) == 1 && last_r == r - 1) { pb0 = last_beg; pe0 = last_end; }
+          else { pb0 = __builtin_amdgcn_readfirstlane(rbeg[ps0]); pe0 = __builtin_amdgcn_readfirstlane(rend[ps0]); }
+          fast = beg - 1 >= pb0 - G && end <= pe0 + G;
           if (np == 2) {
-            pb1 = rbeg[ps1];
-            fast = fast && beg - 1 >= pb1 - G && end <= rend[ps1] + G;
+            pb1 = __builtin_amdgcn_readfirstlane(rbeg[ps1]);
+            fast = fast && beg - 1 >= pb1 - G && end <= __builtin_amdgcn_readfirstlane(rend[ps1]) + G;
           }
+        }
+        const int this_beg = beg, this_end = end;
+        if (C == 1 && fast && np == 1 && !keep && width <= 64) {
+          // ---- the common row, written out flat: one predecessor inside the ring whose band covers this one, one
+          // column per lane, nothing to keep for later.  Same arithmetic and the same tie rules as the general code
+          // below (which it mirrors line by line for C = 1, one chunk, km = 0), without its loops, carries and
+          // per-cell validity branches.
+          const int j = beg + lane;
+          const bool valid = j <= end;
+          const int scv = (j >= 1 && valid) ? pl_score(bv, q[j - 1]) : 0;
+          const int bi0 = ps0 * RST + G + (j - 1 - pb0);
+          const int32_t hvA = rH[bi0], hvB = rH[bi0 + 1], xa = rE1[bi0 + 1], xb = rE2[bi0 + 1];
+          const int32_t m0 = hvA + scv;
+          const int32_t a1 = hvB - P_O1 - P_E1, b1 = xa - P_E1;
+          const int32_t e1v = imax(a1, b1);
+          const uint32_t dE1v = a1 == e1v ? 0u : 8u;
+          const int32_t a2 = hvB - P_O2 - P_E2, b2 = xb - P_E2;
+          const int32_t e2v = imax(a2, b2);
+          const uint32_t dE2v = a2 == e2v ? 0u : 8u;
+          const int32_t hpv = valid ? imax(m0, imax(e1v, e2v)) : PNEG;
+          const int32_t s1 = wave_scan_max(hpv + j * P_E1, PNEG), s2 = wave_scan_max(hpv + j * P_E2, PNEG);
+          const int32_t f1 = wave_shr1(s1, PNEG) - P_O1 - j * P_E1, f2 = wave_shr1(s2, PNEG) - P_O2 - j * P_E2;
+          const int32_t h = imax(hpv, imax(f1, f2));
+          const int32_t hp_left = wave_shr1(hpv, PNEG);
+          if (valid) {
+            const uint32_t dH = m0 == h ? 0u : e1v == h ? 8u : e2v == h ? 9u : f1 == h ? 10u : 11u;
+            const uint32_t dHp = m0 == hpv ? 0u : e1v == hpv ? 8u : 9u;
+            const uint32_t o1 = hp_left - P_O1 - P_E1 == f1 ? 1u : 0u;
+            const uint32_t o2 = hp_left - P_O2 - P_E2 == f2 ? 1u : 0u;
+            gdir[rowo + (j & wm)] = dH | (dHp << 4) | (dE1v << 8) | (dE2v << 12) | (o1 << 16) | (o2 << 17);
+            rH[sb + lane] = h; rE1[sb + lane] = e1v; rE2[sb + lane] = e2v;
+            if (j == L) hl[r] = h;
+          }
+          const int32_t wmx = __builtin_amdgcn_readlane(wave_scan_max(valid ? h : -0x7fffffff - 1, -0x7fffffff - 1), 63);
+          const unsigned long long em = __ballot(valid && h == wmx);
+          int l = beg + (int)__builtin_ctzll(em), rr = beg + 63 - (int)__builtin_clzll(em);
+          if (wmx <= PNEG / 2) { l = beg; rr = end; }
+          last_r = r; last_mpl = l; last_mpr = rr; last_beg = this_beg; last_end = this_end;
+          if (lane == 0) { rmpl[slot] = l; rmpr[slot] = rr; }
+          continue;
         }
         // leftmost / rightmost column of the row maximum, per lane (cells in increasing column order)
         int32_t lbest = -0x7fffffff - 1; int ll = -1, lr = -1;
@@ -568,7 +611,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             rr = __builtin_amdgcn_readlane(wave_scan_max(eq ? lr : -1, -1), 63);
           }
           if (wmx <= PNEG / 2) { l = beg; rr = end; }
-          last_r = r; last_mpl = l; last_mpr = rr;
+          last_r = r; last_mpl = l; last_mpr = rr; last_beg = this_beg; last_end = this_end;
           if (lane == 0) {
             rmpl[slot] = l; rmpr[slot] = rr;
             if (keep) { row_mpl[r] = l; row_mpr[r] = rr; }
