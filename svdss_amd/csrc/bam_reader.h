@@ -529,7 +529,7 @@ class BamReader {
     {
       std::shared_ptr<FreeList> fl = free_;
       chunk_ = std::shared_ptr<Bytes>(new Bytes(), [fl](Bytes* b) {
-        { std::lock_guard<std::mutex> lk(fl->m); if (fl->v.size() < 8) fl->v.push_back(std::move(*b)); }
+        { std::lock_guard<std::mutex> lk(fl->m); if (fl->v.size() < 32) fl->v.push_back(std::move(*b)); }
         delete b;
       });
     }

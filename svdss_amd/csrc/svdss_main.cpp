@@ -233,9 +233,15 @@ struct SearchBatch {
   size_t seq4_cap = 0;
   std::vector<int64_t> boff;     // byte offset of every searched read in seq4 (+ end)
   std::vector<int32_t> lseq;
+  // the record views of the batch and the inflated chunks they point into, until the searching thread has copied the
+  // packed bases out of them
+  std::vector<BamReader::RawView> recs;
+  std::vector<std::shared_ptr<BamReader::Bytes>> keep;
   std::vector<int64_t> goff;
   std::vector<size_t> gidx;      // searched read -> index into reads
   std::vector<int32_t> qs, ln;   // results
+  std::string text;              // the batch's lines, formatted by the thread that searched it
+  uint64_t n_lines = 0;
 };
 
 // decimal text of v at w, returns the end
@@ -329,7 +335,7 @@ int main_search(const Options& o) {
   bool gpu_finished = false;
   uint64_t next_seq = 0;
   uint64_t n_seen = 0, total_sfs = 0;
-  double t_slice = 0, t_decode = 0, t_gpu = 0, t_write = 0;   // busy seconds of the stages (--verbose)
+  double t_slice = 0, t_decode = 0, t_gpu = 0, t_write = 0, t_format = 0;   // busy seconds of the stages (--verbose)
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
@@ -403,13 +409,8 @@ int main_search(const Options& o) {
           bt->lseq[k] = l;
           bt->boff.push_back(bt->boff.back() + ((int64_t)l + 1) / 2);
         }
-        bt->seq4 = pinned.get((size_t)bt->boff.back() + 16, bt->seq4_cap);
-        parallel_for(bt->gidx.size(), [&](size_t lo, size_t hi) {
-          for (size_t k = lo; k < hi; ++k) {
-            const BamReader::RawView& rr = recs[bt->gidx[k]];
-            memcpy(bt->seq4 + bt->boff[k], rr.seq4(), (size_t)(bt->boff[k + 1] - bt->boff[k]));
-          }
-        });
+        bt->recs.swap(recs);
+        bt->keep.swap(keep_chunks);
         t_decode += secs(ts1, now());
       } else {
         while ((int64_t)bt->reads.size() < super) {
@@ -432,7 +433,6 @@ int main_search(const Options& o) {
   });
 
   std::thread writer([&] {
-    std::string out;
     uint64_t want = 0;
     for (;;) {
       std::unique_ptr<SearchBatch> bt;
@@ -447,44 +447,49 @@ int main_search(const Options& o) {
       }
       done_cv.notify_all();
       const auto tw0 = now();
-      const std::vector<Read>& reads = bt->reads;
-      // output_batch order: reference batches of bsize reads -> thread t takes reads n with
-      // n % T == t (ping_pong.cpp:59,101-104) -> std::map<qname, vector<SFS>> order (:217)
-      char num[64];
-      for (size_t b0 = 0; b0 < reads.size(); b0 += (size_t)o.bsize) {
-        const size_t b1 = std::min(reads.size(), b0 + (size_t)o.bsize);
-        for (int t = 0; t < o.threads; ++t) {
-          std::map<std::string, std::vector<size_t>> by_name;
-          for (size_t n = b0 + (size_t)t; n < b1; n += (size_t)o.threads)
-            if (reads[n].count >= 0) by_name[reads[n].name].push_back(n);
-          for (const auto& kv : by_name) {
-            bool first = true;
-            for (size_t n : kv.second) {
-              const Read& r = reads[n];
-              for (int64_t k = 0; k < r.count; ++k) {
-                if (first) out += r.name; else out += '*';
-                char* w = num;                      // "\t<qs>\t<len>\t<hp>\t\n" without printf (11 M lines per GB of reads)
-                *w++ = '\t'; w = put_int(w, bt->qs[(size_t)(r.first + k)]);
-                *w++ = '\t'; w = put_int(w, bt->ln[(size_t)(r.first + k)]);
-                *w++ = '\t'; w = put_int(w, r.hp);
-                *w++ = '\t'; *w++ = '\n';
-                out.append(num, (size_t)(w - num));
-                first = false;
-                ++total_sfs;
-              }
-            }
-          }
-        }
-        if (out.size() > (1u << 20)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
-      }
+      fwrite(bt->text.data(), 1, bt->text.size(), stdout);
+      total_sfs += bt->n_lines;
       t_write += secs(tw0, now());
     }
-    fwrite(out.data(), 1, out.size(), stdout);
     fflush(stdout);
   });
 
-  // two threads feed the GPU, each with its own batch object (own stream): the upload of one batch overlaps the
-  // search of the other
+  // the text of one batch.  output_batch order: reference batches of bsize reads -> thread t takes reads n with
+  // n % T == t (ping_pong.cpp:59,101-104) -> std::map<qname, vector<SFS>> order (:217)
+  auto format_batch = [&](SearchBatch& b) {
+    const std::vector<Read>& reads = b.reads;
+    std::string& out = b.text;
+    out.reserve(b.qs.size() * 24 + 1024);
+    char num[64];
+    for (size_t b0 = 0; b0 < reads.size(); b0 += (size_t)o.bsize) {
+      const size_t b1 = std::min(reads.size(), b0 + (size_t)o.bsize);
+      for (int t = 0; t < o.threads; ++t) {
+        std::map<std::string, std::vector<size_t>> by_name;
+        for (size_t n = b0 + (size_t)t; n < b1; n += (size_t)o.threads)
+          if (reads[n].count >= 0) by_name[reads[n].name].push_back(n);
+        for (const auto& kv : by_name) {
+          bool first = true;
+          for (size_t n : kv.second) {
+            const Read& r = reads[n];
+            for (int64_t k = 0; k < r.count; ++k) {
+              if (first) out += r.name; else out += '*';
+              char* w = num;                      // "\t<qs>\t<len>\t<hp>\t\n" without printf (11 M lines per GB of reads)
+              *w++ = '\t'; w = put_int(w, b.qs[(size_t)(r.first + k)]);
+              *w++ = '\t'; w = put_int(w, b.ln[(size_t)(r.first + k)]);
+              *w++ = '\t'; w = put_int(w, r.hp);
+              *w++ = '\t'; *w++ = '\n';
+              out.append(num, (size_t)(w - num));
+              first = false;
+              ++b.n_lines;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // two threads per GPU feed it, each with its own batch object (own stream): the upload of one batch overlaps the
+  // search of the other; the thread that searched a batch also formats its text, the writer only writes
   std::mutex t_m;
   auto gpu_worker = [&](svdss_index_t* ix) {
     svdss_sfs_batch_t* res = nullptr;
@@ -492,6 +497,14 @@ int main_search(const Options& o) {
       const auto tg0 = now();
       if (!bt->gidx.empty()) {
         std::vector<int64_t> counts(bt->gidx.size());
+        if (bam_mode) {
+          // the packed bases of the batch, back to back in page-locked memory
+          bt->seq4 = pinned.get((size_t)bt->boff.back() + 16, bt->seq4_cap);
+          for (size_t k = 0; k < bt->gidx.size(); ++k)
+            memcpy(bt->seq4 + bt->boff[k], bt->recs[bt->gidx[k]].seq4(), (size_t)(bt->boff[k + 1] - bt->boff[k]));
+          std::vector<BamReader::RawView>().swap(bt->recs);
+          bt->keep.clear();
+        }
         if (bam_mode)
           check(svdss_sfs_search_batch_bam(ix, bt->seq4, bt->boff.data(), bt->lseq.data(), (int64_t)bt->gidx.size(),
                                            o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch_bam");
@@ -511,7 +524,9 @@ int main_search(const Options& o) {
       std::vector<uint8_t>().swap(bt->gbuf);
       pinned.put(bt->seq4, bt->seq4_cap);
       bt->seq4 = nullptr;
-      { std::lock_guard<std::mutex> lk(t_m); t_gpu += secs(tg0, now()); }
+      const auto tg1 = now();
+      format_batch(*bt);
+      { std::lock_guard<std::mutex> lk(t_m); t_gpu += secs(tg0, tg1); t_format += secs(tg1, now()); }
       {
         // (bounded: a finished batch waits until the writer is at most 3 batches behind)
         std::unique_lock<std::mutex> lk(done_m);
@@ -526,7 +541,7 @@ int main_search(const Options& o) {
   {
     std::vector<std::thread> gpu_threads;
     for (int d = 0; d < n_gpus; ++d)
-      for (int k = 0; k < 2; ++k)
+      for (int k = 0; k < 3; ++k)
         if (d || k) gpu_threads.emplace_back(gpu_worker, replicas[(size_t)d]);
     gpu_worker(replicas[0]);
     for (std::thread& th : gpu_threads) th.join();
@@ -538,7 +553,7 @@ int main_search(const Options& o) {
   if (o.verbose) {
     logmsg("debug", std::to_string(n_seen) + " records read, " + std::to_string(total_sfs) + " SFS written at +" + since() + " s");
     logmsg("debug", "stage busy seconds: inflate+slice " + std::to_string(t_slice) + ", decode " + std::to_string(t_decode) +
-                        ", GPU search + copies " + std::to_string(t_gpu) + ", format+write " + std::to_string(t_write));
+                        ", GPU search + copies " + std::to_string(t_gpu) + ", format " + std::to_string(t_format) + ", write " + std::to_string(t_write));
   }
   for (svdss_index_t* r : replicas) svdss_index_free(r);
   delete bam;

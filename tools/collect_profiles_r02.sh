@@ -37,6 +37,10 @@ for c in "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B" "TCC_
 done
 summarize "$O/pmcwg_" "sfs_" "$O/pmc_wg.csv"
 rm -rf $O/pmcwg_[0-9]*
+# the chr20 workload of round 1 (128,888 reads, several lanes per read) with the same kernel
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B --kernel-trace --kernel-include-regex "sfs_search2" --output-format csv -d $O/pmcchr20_1 -- python $R/tools/search_only.py chr20 128888 5 > $O/search_only_chr20.log 2>&1
+summarize "$O/pmcchr20_" "sfs_" "$O/pmc_chr20.csv"
+rm -rf $O/pmcchr20_[0-9]*
 i=0
 for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCC_EA0_RDREQ TCC_EA0_WRREQ TCC_EA0_WRREQ_64B"; do
   i=$((i+1))
