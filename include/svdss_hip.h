@@ -157,6 +157,26 @@ int svdss_sfs_batch_device_ptrs(const svdss_sfs_batch_t* b, void** counts, void*
                                 void** n_ext);
 void svdss_sfs_batch_free(svdss_sfs_batch_t* b);
 
+/* ---- a10: SFS placement ------------------------------------------------------
+ * Replaces Clusterer::extend_alignment (clusterer.cpp:159-346) with get_aligned_pairs (bam.cpp:92-134) and
+ * get_unique_kmers (clusterer.cpp:351-405) for a batch of alignments: every SFS (qs, len) of a read is mapped to the
+ * reference through the read's CIGAR, extended on both sides to the nearest unique clean 7-mer within 100 aligned
+ * pairs (ksize 7, flank 100: config.hpp:89-90), and overlapping extended SFS of one read are merged (:314-336).
+ * svdss_ref_upload: the chromosome sequences as `call` holds them (upper-case ASCII, chromosomes.cpp:9-27), back to
+ * back with off[n_chrom + 1], resident on `device`.
+ * Per alignment i: tid[i] (index into the uploaded chromosomes; outside -> nothing placed), pos[i], its BAM CIGAR words
+ * cigar[cigar_off[i] .. cigar_off[i+1]) (len << 4 | op), and its SFS sfs_qs/sfs_len[sfs_off[i] .. sfs_off[i+1]) in the
+ * order the .sfs file lists them (the reference carries `last_pos` from one to the next, :172-192).
+ * Out: out_count[i] merged extended SFS, written at out[5 * (sfs_off[i] + j)]: rs, re, qs, qe (sfs.hpp:52-62 as filled at
+ * clusterer.cpp:305-308) and the index (within the read's list) of the first SFS merged into it, whose qname / htag the
+ * entry keeps.  stats: SFS counted unplaced, s_unplaced, e_unplaced, unknown (clusterer.cpp:207-226,296). */
+typedef struct svdss_ref svdss_ref_t;
+int svdss_ref_upload(const uint8_t* seqs, const int64_t* off, int32_t n_chrom, int32_t device, svdss_ref_t** out);
+void svdss_ref_free(svdss_ref_t* ref);
+int svdss_place_sfs_batch(svdss_ref_t* ref, const int32_t* tid, const int32_t* pos, const uint32_t* cigar,
+                          const int64_t* cigar_off, const int32_t* sfs_qs, const int32_t* sfs_len, const int64_t* sfs_off,
+                          int64_t n_aln, int32_t* out_count, int32_t* out, int64_t stats[4]);
+
 /* ---- a15: global dual-affine realignment of consensus to reference --------
  * Replaces ksw_extd2_sse(km=0, qlen, query, tlen, target, m, mat, q, e, q2, e2,
  * w=-1, zdrop=-1, end_bonus=-1, flag=0, &ez) as called at caller.cpp:348-349

@@ -77,6 +77,9 @@ SIGNATURES = {
     "svdss_sfs_batch_fetch": (C.c_int, [_p, _p, _p, _p, _p]),
     "svdss_sfs_batch_device_ptrs": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "svdss_sfs_batch_free": (None, [_p]),
+    "svdss_ref_upload": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
+    "svdss_ref_free": (None, [_p]),
+    "svdss_place_sfs_batch": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
     "svdss_align_global_batch": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _i32,
                                            C.POINTER(_p)]),
     "svdss_aln_batch_npairs": (_i64, [_p]),

@@ -379,6 +379,21 @@ int main_call(const CallOptions& o) {
     ref_names = bam.ref_names();
     const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
     std::vector<std::vector<ESFS>> per_thread((size_t)T);
+    // the chromosomes in BAM header order on the GPU, for the placement kernel (SVDSS_PLACE_HOST=1: host code instead)
+    svdss_ref_t* dref = nullptr;
+    std::vector<int32_t> tid_map(ref_names.size(), -1);
+    if (!getenv("SVDSS_PLACE_HOST")) {
+      std::string all;
+      std::vector<int64_t> off(1, 0);
+      for (size_t t = 0; t < ref_names.size(); ++t) {
+        auto it = C.chrom_seqs.find(ref_names[t]);
+        if (it == C.chrom_seqs.end()) continue;
+        tid_map[t] = (int32_t)off.size() - 1;
+        all += it->second;
+        off.push_back((int64_t)all.size());
+      }
+      check(svdss_ref_upload((const uint8_t*)all.data(), off.data(), (int32_t)off.size() - 1, 0, &dref), "svdss_ref_upload");
+    }
     // two batches: the next one is read (inflate + slicing, this thread) while the T slices of the previous one run
     std::vector<BamRecord> batches[2];
     std::thread worker;
@@ -420,7 +435,43 @@ int main_call(const CallOptions& o) {
       if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
       // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
       // the same order per slice
-      worker = std::thread([&C, &ref_names, &per_thread, &batch, T]() {
+      worker = std::thread([&C, &ref_names, &per_thread, &batch, T, dref, &tid_map]() {
+        if (dref) {
+          // placement on the GPU (csrc/place.hip: one lane per alignment); the results go to the T per-thread lists in
+          // the order the reference's slices would have produced them (record n belongs to slice n % T)
+          std::vector<int32_t> tid, pos, sq, sl, cnt;
+          std::vector<uint32_t> cig;
+          std::vector<int64_t> cig_off(1, 0), sfs_off(1, 0);
+          std::vector<const std::vector<RawSFS>*> lists;
+          for (const BamRecord& r : batch) {
+            const bool known = r.tid >= 0 && r.tid < (int)ref_names.size() && tid_map[(size_t)r.tid] >= 0;
+            tid.push_back(known ? tid_map[(size_t)r.tid] : -1);
+            pos.push_back(r.pos);
+            cig.insert(cig.end(), r.cigar.begin(), r.cigar.end());
+            cig_off.push_back((int64_t)cig.size());
+            const std::vector<RawSFS>& v = C.sfs.at(r.qname);
+            lists.push_back(&v);
+            if (known) for (const RawSFS& x : v) { sq.push_back(x.qs); sl.push_back(x.l); }
+            sfs_off.push_back((int64_t)sq.size());
+          }
+          cnt.resize(batch.size());
+          std::vector<int32_t> out(5 * std::max<size_t>(1, sq.size()));
+          int64_t st[4];
+          check(svdss_place_sfs_batch(dref, tid.data(), pos.data(), cig.data(), cig_off.data(), sq.data(), sl.data(),
+                                      sfs_off.data(), (int64_t)batch.size(), cnt.data(), out.data(), st),
+                "svdss_place_sfs_batch");
+          C.unplaced += st[0]; C.s_unplaced += st[1]; C.e_unplaced += st[2]; C.unknown += st[3];
+          for (int t = 0; t < T; ++t)
+            for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
+              const BamRecord& r = batch[n];
+              if (tid[n] < 0) continue;
+              const int32_t* o = out.data() + 5 * sfs_off[n];
+              for (int32_t j = 0; j < cnt[n]; ++j, o += 5)
+                per_thread[(size_t)t].push_back(ESFS{ref_names[(size_t)r.tid], r.qname, o[0], o[1], o[2], o[3],
+                                                     (*lists[n])[(size_t)o[4]].htag});
+            }
+          return;
+        }
         auto slice = [&](int t) {
           for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
             const BamRecord& r = batch[n];
@@ -439,6 +490,7 @@ int main_call(const CallOptions& o) {
       cur ^= 1;
     }
     if (worker.joinable()) worker.join();
+    svdss_ref_free(dref);
     for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
   }
   stage("pass 1: placement");

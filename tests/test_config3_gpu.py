@@ -45,6 +45,10 @@ def test_chr20_10x_end_to_end(tmp_path):
         hits = [c for c in called if c[1] == k and c[2] == l and abs(c[0] - p) <= 12]
         assert len(hits) == 1, (p, k, l, h, [(c[0], c[1], c[2]) for c in called if abs(c[0] - p) < 3000])
     assert len(called) == len(truth)
+    # (placement on the GPU, the default, and on the host give the same VCF at this size too)
+    r_host = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4",
+                             "--min-sv-length", "50"], capture_output=True, text=True, env=dict(os.environ, SVDSS_PLACE_HOST="1"))
+    assert r_host.returncode == 0 and r_host.stdout == vcf
     # the reads around four SVs (two heterozygous, two homozygous): the same chain on that sub-BAM, and the Python mirror
     # of the host logic (clusterer.cpp / caller.cpp restated in svdss_amd/) on the same inputs -> the same VCF bytes
     pick = [k for k in range(len(svs)) if het[k]][:2] + [k for k in range(len(svs)) if not het[k]][:2]

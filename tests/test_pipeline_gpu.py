@@ -87,6 +87,12 @@ def test_index_search_call_recovers_implanted_svs(tmp_path, het):
                         text=True, env=dict(os.environ, SVDSS_GPUS_OVERSUBSCRIBE="1"))
     assert r3.returncode == 0, r3.stderr
     assert r3.stdout == vcf and (tmp_path / "poa3.sam").read_text() == sam
+    # SFS placement runs on the GPU by default (csrc/place.hip); the host code of call_host.cpp gives the same bytes
+    r4 = subprocess.run([BIN, "call", "--reference", str(fa), "--bam", str(bam), "--sfs", str(sfs_path), "--threads", "4",
+                         "--min-sv-length", "50", "--clusters", str(tmp_path / "clusters_host.txt")], capture_output=True,
+                        text=True, env=dict(os.environ, SVDSS_PLACE_HOST="1"))
+    assert r4.returncode == 0, r4.stderr
+    assert r4.stdout == vcf and (tmp_path / "clusters_host.txt").read_text() == cl_text
 
 
 def test_run_svdss_chain_with_raw_reads(tmp_path):
