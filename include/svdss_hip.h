@@ -177,6 +177,22 @@ int svdss_place_sfs_batch(svdss_ref_t* ref, const int32_t* tid, const int32_t* p
                           const int64_t* cigar_off, const int32_t* sfs_qs, const int32_t* sfs_len, const int64_t* sfs_off,
                           int64_t n_aln, int32_t* out_count, int32_t* out, int64_t stats[4]);
 
+/* ---- smooth: Smoother::smooth_read (smoother.cpp:84-232) for a batch of alignments --------------------------------
+ * Per alignment i (all of them eligible and consistent: the caller filters as smoother.cpp:509-537 does and checks that
+ * the CIGAR stays inside the chromosome and adds up to l_seq): tid / pos / CIGAR words as for svdss_place_sfs_batch, the
+ * packed 4-bit bases at seq4[seq4_off[i]], the qualities at qual[qual_off[i]], l_seq[i].  The kernel walks the CIGAR:
+ * M/=/X copy the reference and count matches / mismatches against the read; I and D of at most 20 bases (config.hpp:95)
+ * are dropped / filled from the reference, longer ones and soft clips are kept; adjacent M runs merge.  Out, per
+ * alignment: the new bases 4-bit packed at out_seq4[cap_off[i] / 2], the new qualities at out_qual[cap_off[i]]
+ * (cap_off: caller-chosen even capacities in bases, >= query + reference length of the alignment), the new CIGAR words at
+ * out_cigar[cigar_off[i]] with out_ncig[i] of them, out_len[i] bases, out_match_mismatch[2i], [2i+1] (the XF = 1 test is
+ * mismatch / match > accuracy, smoother.cpp:213) and out_ignore[i] (nothing interesting: XF = 2, :215). */
+int svdss_smooth_batch(svdss_ref_t* ref, const int32_t* tid, const int32_t* pos, const uint32_t* cigar,
+                       const int64_t* cigar_off, const uint8_t* seq4, const int64_t* seq4_off, const uint8_t* qual,
+                       const int64_t* qual_off, const int32_t* l_seq, const int64_t* cap_off, int64_t n,
+                       uint8_t* out_seq4, uint8_t* out_qual, uint32_t* out_cigar, int32_t* out_ncig, int32_t* out_len,
+                       int64_t* out_match_mismatch, uint8_t* out_ignore);
+
 /* ---- a15: global dual-affine realignment of consensus to reference --------
  * Replaces ksw_extd2_sse(km=0, qlen, query, tlen, target, m, mat, q, e, q2, e2,
  * w=-1, zdrop=-1, end_bonus=-1, flag=0, &ez) as called at caller.cpp:348-349

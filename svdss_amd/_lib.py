@@ -80,6 +80,7 @@ SIGNATURES = {
     "svdss_ref_upload": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
     "svdss_ref_free": (None, [_p]),
     "svdss_place_sfs_batch": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
+    "svdss_smooth_batch": (C.c_int, [_p] * 11 + [_i64] + [_p] * 7),
     "svdss_align_global_batch": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _i32,
                                            C.POINTER(_p)]),
     "svdss_aln_batch_npairs": (_i64, [_p]),

@@ -13,6 +13,7 @@
 // into lane-private arrays; 7-mers are compared as 56-bit integers read from the reference sequence resident in HBM.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -340,5 +341,209 @@ extern "C" int svdss_place_sfs_batch(svdss_ref_t* ref, const int32_t* tid, const
   HIPCHK5(hipMemcpyAsync(hs, A.stats, 32, hipMemcpyDeviceToHost, st));
   HIPCHK5(hipStreamSynchronize(st));
   if (stats) for (int k = 0; k < 4; ++k) stats[k] = (int64_t)hs[k];
+  return SVDSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K6: `SVDSS smooth` -- Smoother::smooth_read (/root/reference/smoother.cpp:84-232) for a batch of alignments.
+// One wavefront per alignment: the CIGAR operations are taken in order (their output offsets depend on the ones
+// before), the bases of an operation are copied / compared 64 at a time: matches are replaced by the reference and
+// counted as match / mismatch, insertions and deletions of at most 20 bases are removed (the deletion filled from
+// the reference), longer ones and soft clips are kept.  Lane 0 keeps the new CIGAR (adjacent M runs merge).  The new
+// bases are written as characters into a scratch row and packed to BAM's 4-bit form by the same wavefront.
+
+namespace {
+
+constexpr int SM_MIN_INDEL = 20;   // config.hpp:95
+
+struct SmoothArgs {
+  const uint8_t* ref;
+  const int64_t* ref_off;
+  const int32_t* tid;
+  const int32_t* pos;
+  const uint32_t* cigar;
+  const int64_t* cigar_off;
+  const uint8_t* seq4;        // packed bases of all records
+  const int64_t* seq4_off;    // byte offset of every record's bases
+  const uint8_t* qual;
+  const int64_t* qual_off;    // byte offset of every record's qualities
+  const int32_t* l_seq;
+  const int64_t* cap_off;     // output capacity offsets in bases (even), n + 1
+  int64_t n;
+  uint8_t* scratch;           // cap_off[n] characters
+  uint8_t* out_seq4;          // cap_off[n] / 2 bytes
+  uint8_t* out_qual;          // cap_off[n] bytes
+  uint32_t* out_cigar;        // at cigar_off
+  int32_t* out_ncig;
+  int32_t* out_len;
+  unsigned long long* out_nm; // matches, mismatches (2 per record)
+  uint8_t* out_ignore;
+};
+
+__device__ __forceinline__ char sm_base(const uint8_t* s4, int64_t i) {
+  const uint8_t b = s4[i >> 1];
+  return "=ACMGRSVTWYHKDBN"[(i & 1) ? (b & 15) : (b >> 4)];
+}
+
+__device__ __forceinline__ uint8_t sm_code(char c) {   // the inverse table write_record uses (upper / lower case)
+  switch (c) {
+    case '=': return 0; case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'M': case 'm': return 3;
+    case 'G': case 'g': return 4; case 'R': case 'r': return 5; case 'S': case 's': return 6; case 'V': case 'v': return 7;
+    case 'T': case 't': return 8; case 'W': case 'w': return 9; case 'Y': case 'y': return 10; case 'H': case 'h': return 11;
+    case 'K': case 'k': return 12; case 'D': case 'd': return 13; case 'B': case 'b': return 14; default: return 15;
+  }
+}
+
+__global__ void __launch_bounds__(64) smooth_kernel(SmoothArgs A) {
+  const int64_t a = blockIdx.x;
+  if (a >= A.n) return;
+  const int lane = threadIdx.x;
+  const uint8_t* cseq = A.ref + A.ref_off[A.tid[a]];
+  const uint8_t* s4 = A.seq4 + A.seq4_off[a];
+  const uint8_t* q = A.qual + A.qual_off[a];
+  const int64_t lq = A.l_seq[a];
+  uint8_t* ns = A.scratch + A.cap_off[a];
+  uint8_t* nq = A.out_qual + A.cap_off[a];
+  uint32_t* nc = A.out_cigar + A.cigar_off[a];
+  int64_t ref_off = A.pos[a], q_off = 0, no = 0;
+  unsigned long long nm = 0, nx = 0;
+  uint32_t m_diff = 0;
+  int n_nc = 0;
+  bool ignore = true;
+  uint32_t last_word = 0;       // nc[n_nc - 1], kept in a register by every lane (uniform)
+  for (int64_t c = A.cigar_off[a]; c < A.cigar_off[a + 1]; ++c) {
+    const uint32_t w = A.cigar[c], l = w >> 4, op = w & 0xf;
+    if (op == 0 || op == 7 || op == 8) {
+      for (uint32_t j = lane; j < l; j += 64) {
+        const char rc = (char)cseq[ref_off + j];
+        ns[no + j] = (uint8_t)rc;
+        nq[no + j] = q_off + j < lq ? q[q_off + j] : 255;
+        if (rc == sm_base(s4, q_off + j)) ++nm; else ++nx;
+      }
+      no += l; ref_off += l; q_off += l;
+      if (n_nc && (last_word & 0xf) == 0) last_word += (l + m_diff) << 4;
+      else { last_word = ((l + m_diff) << 4) | 0; ++n_nc; }
+      if (lane == 0) nc[n_nc - 1] = last_word;
+      m_diff = 0;
+    } else if (op == 1) {
+      if ((int)l > SM_MIN_INDEL) {
+        ignore = false;
+        for (uint32_t j = lane; j < l; j += 64) {
+          ns[no + j] = (uint8_t)sm_base(s4, q_off + j);
+          nq[no + j] = q_off + j < lq ? q[q_off + j] : 255;
+        }
+        no += l;
+        last_word = w; ++n_nc;
+        if (lane == 0) nc[n_nc - 1] = w;
+      }
+      q_off += l;
+    } else if (op == 2) {
+      if ((int)l <= SM_MIN_INDEL) {
+        for (uint32_t j = lane; j < l; j += 64) {
+          ns[no + j] = cseq[ref_off + j];
+          nq[no + j] = q_off + j < lq ? q[q_off + j] : 255;     // qualities of the NEXT read bases (smoother.cpp:164-166)
+        }
+        no += l;
+        m_diff += l;
+      } else {
+        ignore = false;
+        last_word = w; ++n_nc;
+        if (lane == 0) nc[n_nc - 1] = w;
+      }
+      ref_off += l;
+    } else if (op == 4) {
+      ignore = false;
+      for (uint32_t j = lane; j < l; j += 64) {
+        ns[no + j] = (uint8_t)sm_base(s4, q_off + j);
+        nq[no + j] = q_off + j < lq ? q[q_off + j] : 255;
+      }
+      no += l; q_off += l;
+      last_word = w; ++n_nc;
+      if (lane == 0) nc[n_nc - 1] = w;
+    } else break;
+  }
+  // match / mismatch totals over the wave
+  for (int d = 32; d >= 1; d >>= 1) {
+    nm += __shfl_xor(nm, d, 64);
+    nx += __shfl_xor(nx, d, 64);
+  }
+  __syncthreads();   // the scratch row is complete
+  uint8_t* o4 = A.out_seq4 + (A.cap_off[a] >> 1);
+  for (int64_t b = lane; b < (no + 1) / 2; b += 64) {
+    const uint8_t hi = sm_code((char)ns[2 * b]), lo = 2 * b + 1 < no ? sm_code((char)ns[2 * b + 1]) : 0;
+    o4[b] = (uint8_t)((hi << 4) | lo);
+  }
+  if (lane == 0) {
+    A.out_ncig[a] = n_nc;
+    A.out_len[a] = (int32_t)no;
+    A.out_nm[2 * a] = nm; A.out_nm[2 * a + 1] = nx;
+    A.out_ignore[a] = ignore ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" int svdss_smooth_batch(svdss_ref_t* ref, const int32_t* tid, const int32_t* pos, const uint32_t* cigar,
+                                  const int64_t* cigar_off, const uint8_t* seq4, const int64_t* seq4_off, const uint8_t* qual,
+                                  const int64_t* qual_off, const int32_t* l_seq, const int64_t* cap_off, int64_t n,
+                                  uint8_t* out_seq4, uint8_t* out_qual, uint32_t* out_cigar, int32_t* out_ncig,
+                                  int32_t* out_len, int64_t* out_match_mismatch, uint8_t* out_ignore) {
+  if (!ref || n < 0) return SVDSS_EINVAL;
+  if (n == 0) return SVDSS_OK;
+  if (!tid || !pos || !cigar || !cigar_off || !seq4 || !seq4_off || !qual || !qual_off || !l_seq || !cap_off || !out_seq4 ||
+      !out_qual || !out_cigar || !out_ncig || !out_len || !out_match_mismatch || !out_ignore)
+    return SVDSS_EINVAL;
+  HIPCHK5(hipSetDevice(ref->device));
+  for (int64_t i = 0; i < n; ++i)
+    if (tid[i] < 0 || tid[i] >= ref->n_chrom || (cap_off[i] & 1) || cap_off[i + 1] < cap_off[i]) return SVDSS_EINVAL;
+  const int64_t n_cig = cigar_off[n], cap = cap_off[n];
+  int64_t s4_bytes = 0, q_bytes = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    s4_bytes = std::max<int64_t>(s4_bytes, seq4_off[i] + ((int64_t)l_seq[i] + 1) / 2);
+    q_bytes = std::max<int64_t>(q_bytes, qual_off[i] + l_seq[i]);
+  }
+  DevArena& ar = ref->arena;
+  HIPCHK5(ar.reserve(3 * DevArena::padded(4 * (size_t)n) + 4 * DevArena::padded(8 * (size_t)(n + 1)) + 2 * DevArena::padded(4 * (size_t)n_cig) +
+                     DevArena::padded((size_t)s4_bytes) + DevArena::padded((size_t)q_bytes) + 2 * DevArena::padded((size_t)cap) +
+                     DevArena::padded((size_t)cap / 2 + 8) + 2 * DevArena::padded(4 * (size_t)n) + DevArena::padded(16 * (size_t)n) +
+                     DevArena::padded((size_t)n)));
+  const hipStream_t st = ref->stream;
+  auto up = [&](const void* src, size_t bytes) -> void* {
+    void* d = ar.take(bytes ? bytes : 16);
+    if (bytes) (void)hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, st);
+    return d;
+  };
+  SmoothArgs A;
+  A.ref = (const uint8_t*)ref->d_ref;
+  A.ref_off = (const int64_t*)ref->d_off;
+  A.tid = (const int32_t*)up(tid, 4 * (size_t)n);
+  A.pos = (const int32_t*)up(pos, 4 * (size_t)n);
+  A.cigar = (const uint32_t*)up(cigar, 4 * (size_t)n_cig);
+  A.cigar_off = (const int64_t*)up(cigar_off, 8 * (size_t)(n + 1));
+  A.seq4 = (const uint8_t*)up(seq4, (size_t)s4_bytes);
+  A.seq4_off = (const int64_t*)up(seq4_off, 8 * (size_t)n);
+  A.qual = (const uint8_t*)up(qual, (size_t)q_bytes);
+  A.qual_off = (const int64_t*)up(qual_off, 8 * (size_t)n);
+  A.l_seq = (const int32_t*)up(l_seq, 4 * (size_t)n);
+  A.cap_off = (const int64_t*)up(cap_off, 8 * (size_t)(n + 1));
+  A.n = n;
+  A.scratch = (uint8_t*)ar.take((size_t)cap);
+  A.out_seq4 = (uint8_t*)ar.take((size_t)cap / 2 + 8);
+  A.out_qual = (uint8_t*)ar.take((size_t)cap);
+  A.out_cigar = (uint32_t*)ar.take(4 * (size_t)(n_cig ? n_cig : 1));
+  A.out_ncig = (int32_t*)ar.take(4 * (size_t)n);
+  A.out_len = (int32_t*)ar.take(4 * (size_t)n);
+  A.out_nm = (unsigned long long*)ar.take(16 * (size_t)n);
+  A.out_ignore = (uint8_t*)ar.take((size_t)n);
+  hipLaunchKernelGGL(smooth_kernel, dim3((unsigned)n), dim3(64), 0, st, A);
+  HIPCHK5(hipGetLastError());
+  HIPCHK5(hipMemcpyAsync(out_seq4, A.out_seq4, (size_t)cap / 2, hipMemcpyDeviceToHost, st));
+  HIPCHK5(hipMemcpyAsync(out_qual, A.out_qual, (size_t)cap, hipMemcpyDeviceToHost, st));
+  if (n_cig) HIPCHK5(hipMemcpyAsync(out_cigar, A.out_cigar, 4 * (size_t)n_cig, hipMemcpyDeviceToHost, st));
+  HIPCHK5(hipMemcpyAsync(out_ncig, A.out_ncig, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPCHK5(hipMemcpyAsync(out_len, A.out_len, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPCHK5(hipMemcpyAsync(out_match_mismatch, A.out_nm, 16 * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPCHK5(hipMemcpyAsync(out_ignore, A.out_ignore, (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPCHK5(hipStreamSynchronize(st));
   return SVDSS_OK;
 }

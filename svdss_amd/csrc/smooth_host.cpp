@@ -13,6 +13,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "../../include/svdss_hip.h"
 #include "bam_reader.h"
 #include "bam_writer.h"
 #include "call_host.h"
@@ -74,29 +75,17 @@ struct ByteSink {
   void write(const void* p, size_t n) { v.insert(v.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
 };
 
-void write_record(ByteSink& w, const BamRecord& r, const std::vector<uint32_t>& cigar, const std::string& seq,
-                  const std::vector<uint8_t>& qual, const std::vector<uint8_t>& aux) {
-  static const int8_t code[256] = {0};
-  (void)code;
-  const int32_t l_seq = (int32_t)seq.size();
-  std::vector<uint8_t> packed((size_t)(l_seq + 1) / 2, 0);
-  static const struct Lut {   // (initialised once, before any worker thread runs: function-local static)
-    uint8_t t[256];
-    Lut() {
-      memset(t, 15, sizeof t);
-      const char* nt16 = "=ACMGRSVTWYHKDBN";
-      for (int i = 0; i < 16; ++i) { t[(uint8_t)nt16[i]] = (uint8_t)i; t[(uint8_t)tolower(nt16[i])] = (uint8_t)i; }
-    }
-  } lut_obj;
-  const uint8_t* lut = lut_obj.t;
-  for (int32_t i = 0; i < l_seq; ++i) packed[(size_t)i >> 1] |= (uint8_t)(lut[(uint8_t)seq[(size_t)i]] << ((~i & 1) << 2));
+// one record with the bases already in BAM's 4-bit form
+void write_record_packed(ByteSink& w, const BamRecord& r, const uint32_t* cigar, size_t n_cigar, const uint8_t* packed,
+                         int32_t l_seq, const uint8_t* qual, const std::vector<uint8_t>& aux) {
   // BAM keeps l_read_name in 8 bits and n_cigar_op in 16 (longer CIGARs live in a CG tag, which this writer does not
   // produce): refuse instead of writing a record that no longer parses
   if (r.qname.size() + 1 > 255) die("read name longer than 254 characters: " + r.qname);
-  if (cigar.size() > 65535) die("more than 65535 CIGAR operations (CG tag records are not supported): " + r.qname);
+  if (n_cigar > 65535) die("more than 65535 CIGAR operations (CG tag records are not supported): " + r.qname);
   const uint8_t l_name = (uint8_t)(r.qname.size() + 1);
-  const uint16_t n_cig = (uint16_t)cigar.size();
-  const int32_t block = 32 + l_name + 4 * n_cig + (int32_t)packed.size() + l_seq + (int32_t)aux.size();
+  const uint16_t n_cig = (uint16_t)n_cigar;
+  const size_t pbytes = (size_t)(l_seq + 1) / 2;
+  const int32_t block = 32 + l_name + 4 * n_cig + (int32_t)pbytes + l_seq + (int32_t)aux.size();
   uint8_t core[36];
   memcpy(core, &block, 4);
   memcpy(core + 4, &r.tid, 4);
@@ -111,10 +100,27 @@ void write_record(ByteSink& w, const BamRecord& r, const std::vector<uint32_t>& 
   memcpy(core + 32, &r.isize, 4);
   w.write(core, 36);
   w.write(r.qname.c_str(), l_name);
-  if (n_cig) w.write(cigar.data(), 4u * n_cig);
-  w.write(packed.data(), packed.size());
-  w.write(qual.data(), (size_t)l_seq);
+  if (n_cig) w.write(cigar, 4u * n_cig);
+  w.write(packed, pbytes);
+  w.write(qual, (size_t)l_seq);
   w.write(aux.data(), aux.size());
+}
+
+void write_record(ByteSink& w, const BamRecord& r, const std::vector<uint32_t>& cigar, const std::string& seq,
+                  const std::vector<uint8_t>& qual, const std::vector<uint8_t>& aux) {
+  const int32_t l_seq = (int32_t)seq.size();
+  std::vector<uint8_t> packed((size_t)(l_seq + 1) / 2, 0);
+  static const struct Lut {   // (initialised once, before any worker thread runs: function-local static)
+    uint8_t t[256];
+    Lut() {
+      memset(t, 15, sizeof t);
+      const char* nt16 = "=ACMGRSVTWYHKDBN";
+      for (int i = 0; i < 16; ++i) { t[(uint8_t)nt16[i]] = (uint8_t)i; t[(uint8_t)tolower(nt16[i])] = (uint8_t)i; }
+    }
+  } lut_obj;
+  const uint8_t* lut = lut_obj.t;
+  for (int32_t i = 0; i < l_seq; ++i) packed[(size_t)i >> 1] |= (uint8_t)(lut[(uint8_t)seq[(size_t)i]] << ((~i & 1) << 2));
+  write_record_packed(w, r, cigar.data(), cigar.size(), packed.data(), l_seq, qual.data(), aux);
 }
 }  // namespace
 
@@ -224,6 +230,23 @@ int main_smooth(const CallOptions& o) {
     else if (ignore) { set_xf(aux, 2); write_record(sink, r, r.cigar, seq, r.qual, aux); }
     else { set_xf(aux, 0); write_record(sink, r, ncig, nseq, nqual, aux); }
   };
+  // with a GPU the walk runs there (SVDSS_SMOOTH_HOST=1, or no GPU: the host code above); the chromosomes go up once, in
+  // BAM header order
+  svdss_ref_t* dref = nullptr;
+  std::vector<int32_t> tid_map(bam.ref_names().size(), -1);
+  if (!getenv("SVDSS_SMOOTH_HOST") && svdss_device_count() > 0) {
+    std::string all;
+    std::vector<int64_t> off(1, 0);
+    for (size_t t = 0; t < bam.ref_names().size(); ++t) {
+      auto it = chrom.find(bam.ref_names()[t]);
+      if (it == chrom.end()) continue;
+      tid_map[t] = (int32_t)off.size() - 1;
+      all += it->second;
+      off.push_back((int64_t)all.size());
+    }
+    if (svdss_ref_upload((const uint8_t*)all.data(), off.data(), (int32_t)off.size() - 1, 0, &dref) != SVDSS_OK)
+      die(std::string("svdss_ref_upload: ") + svdss_last_hip_error());
+  }
   // batches of eligible records: read in order, smoothed by T workers, written in order (the reference's
   // batch loop, smoother.cpp:441-537)
   const size_t batch_size = 4096;
@@ -240,6 +263,77 @@ int main_smooth(const CallOptions& o) {
       batch.push_back(std::move(r));
     }
     outs.assign(batch.size(), ByteSink());
+    if (dref && !batch.empty()) {
+      // the CIGAR walk of the whole batch on the GPU (csrc/place.hip, smooth_kernel: one wavefront per record); the host
+      // keeps what is per record and tiny: the consistency check, the XF decision, the record header
+      std::vector<size_t> idx;                      // batch index of the records that go to the GPU
+      std::vector<int32_t> tid, pos, lq;
+      std::vector<uint32_t> cig;
+      std::vector<int64_t> cig_off(1, 0), s4_off, q_off, cap_off(1, 0);
+      std::vector<uint8_t> s4, ql;
+      for (size_t i = 0; i < batch.size(); ++i) {
+        const BamRecord& r = batch[i];
+        const std::string& ref = chrom.at(bam.ref_names()[(size_t)r.tid]);
+        size_t rl = 0, qlen = 0;
+        for (uint32_t c : r.cigar) {
+          const uint32_t l = c >> 4, op = c & 0xf;
+          if (is_m(op)) { rl += l; qlen += l; }
+          else if (op == 1 || op == 4) qlen += l;
+          else if (op == 2) rl += l;
+          else break;
+        }
+        if (r.pos < 0 || (size_t)r.pos + rl > ref.size() || qlen != (size_t)r.l_seq || r.qual.size() != (size_t)r.l_seq) {
+          smooth_one(r, outs[i]);                   // inconsistent record: the host path tags it XF = 3
+          continue;
+        }
+        idx.push_back(i);
+        tid.push_back(tid_map[(size_t)r.tid]);
+        pos.push_back(r.pos);
+        lq.push_back(r.l_seq);
+        cig.insert(cig.end(), r.cigar.begin(), r.cigar.end());
+        cig_off.push_back((int64_t)cig.size());
+        s4_off.push_back((int64_t)s4.size());
+        s4.insert(s4.end(), r.seq4.begin(), r.seq4.end());
+        q_off.push_back((int64_t)ql.size());
+        ql.insert(ql.end(), r.qual.begin(), r.qual.end());
+        cap_off.push_back(cap_off.back() + (int64_t)((qlen + rl + 1) & ~(size_t)1));
+      }
+      const size_t n = idx.size();
+      if (n) {
+        std::vector<uint8_t> o4((size_t)cap_off.back() / 2 + 8), oq((size_t)cap_off.back()), oign(n);
+        std::vector<uint32_t> ocig(cig.size() + 1);
+        std::vector<int32_t> oncig(n), olen(n);
+        std::vector<int64_t> onm(2 * n);
+        if (svdss_smooth_batch(dref, tid.data(), pos.data(), cig.data(), cig_off.data(), s4.data(), s4_off.data(), ql.data(),
+                               q_off.data(), lq.data(), cap_off.data(), (int64_t)n, o4.data(), oq.data(), ocig.data(),
+                               oncig.data(), olen.data(), onm.data(), oign.data()) != SVDSS_OK)
+          die(std::string("svdss_smooth_batch: ") + svdss_last_hip_error());
+        auto finish = [&](size_t t, size_t nt) {
+          for (size_t k = t; k < n; k += nt) {
+            const BamRecord& r = batch[idx[k]];
+            std::vector<uint8_t> aux = r.aux;
+            const double nm = (double)onm[2 * k], nx = (double)onm[2 * k + 1];
+            if (nx / nm > al_accuracy) { set_xf(aux, 1); write_record(outs[idx[k]], r, r.cigar, r.seq_string(), r.qual, aux); }
+            else if (oign[k]) { set_xf(aux, 2); write_record(outs[idx[k]], r, r.cigar, r.seq_string(), r.qual, aux); }
+            else {
+              set_xf(aux, 0);
+              write_record_packed(outs[idx[k]], r, ocig.data() + cig_off[k], (size_t)oncig[k], o4.data() + cap_off[k] / 2,
+                                  olen[k], oq.data() + cap_off[k], aux);
+            }
+          }
+        };
+        const size_t nt = std::min<size_t>((size_t)T, n);
+        if (nt <= 1) finish(0, 1);
+        else {
+          std::vector<std::thread> pool;
+          for (size_t t = 1; t < nt; ++t) pool.emplace_back(finish, t, nt);
+          finish(0, nt);
+          for (std::thread& th : pool) th.join();
+        }
+      }
+      for (const ByteSink& sk : outs) w.write(sk.v.data(), sk.v.size());
+      continue;
+    }
     auto work = [&](size_t t, size_t nt) { for (size_t i = t; i < batch.size(); i += nt) smooth_one(batch[i], outs[i]); };
     const size_t nt = std::min<size_t>((size_t)T, batch.size());
     if (nt <= 1) work(0, 1);
@@ -251,6 +345,7 @@ int main_smooth(const CallOptions& o) {
     }
     for (const ByteSink& sk : outs) w.write(sk.v.data(), sk.v.size());
   }
+  svdss_ref_free(dref);
   if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
   if (!w.finish()) die("error writing the BAM to stdout");
   return 0;
