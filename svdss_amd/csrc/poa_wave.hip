@@ -128,6 +128,19 @@ __device__ __forceinline__ int wave_scan_add(int x) {
 
 // value of the lane below (lane 0 receives `fill`)
 __device__ __forceinline__ int wave_shr1(int x, int fill) { return dppi<0x138, 0xf>(fill, x); }
+// value of the lane above (lane 63 receives `fill`)
+__device__ __forceinline__ int wave_shl1(int x, int fill) { return dppi<0x130, 0xf>(fill, x); }
+
+// inclusive max-scan whose steps are single DPP instructions (a lane without a source keeps its own value)
+__device__ __forceinline__ int wave_scan_max_self(int x) {
+  x = imax(x, dppi<0x111, 0xf>(x, x));
+  x = imax(x, dppi<0x112, 0xf>(x, x));
+  x = imax(x, dppi<0x114, 0xf>(x, x));
+  x = imax(x, dppi<0x118, 0xf>(x, x));
+  x = imax(x, dppi<0x142, 0xa>(x, x));
+  x = imax(x, dppi<0x143, 0xc>(x, x));
+  return x;
+}
 
 // direction word layout
 //  bits 0-3  source of H : 0-7 match through predecessor slot k, 8 E1, 9 E2, 10 F1, 11 F2
@@ -137,7 +150,13 @@ __device__ __forceinline__ int wave_shr1(int x, int fill) { return dppi<0x138, 0
 //
 // row descriptor layout (rowinfo[r], one per topological position)
 //  16 bits: bits 0-2 base, bits 3-4 number of predecessors (0-2, or RI_SLOW: look at the graph), bits 5-9 and
-//  10-14 the row deltas (< 32) of predecessor 0 / 1, bit 15: some later row reads this row after it left the ring
+//  10-14 the row deltas (< 32) of predecessor 0 / 1, bit 15: some later row reads this row after it left the ring,
+//  bit 16: some later row other than the next one reads this row from the ring
+#define RI_KEEP 0x8000u
+#define RI_RING 0x10000u
+// a chain row: one predecessor, the previous row, and no copy kept in HBM
+#define RI_CHAIN_MASK ((3u << 3) | (31u << 5) | RI_KEEP)
+#define RI_CHAIN_VAL ((1u << 3) | (1u << 5))
 
 struct ArrI {
   int32_t* W; uint32_t o;
@@ -149,6 +168,12 @@ struct ArrU {
 };
 
 __device__ unsigned long long g_poaw_prof[8];   // SVDSS_DEBUG: time in prepare, forward, traceback, update, bundle
+#ifdef POA_COUNT_ROWS
+__device__ unsigned long long g_poaw_rows[16];  // rows by type (developer build)
+#define ROWCNT(k) (++rowcnt[k])
+#else
+#define ROWCNT(k)
+#endif
 #define PROF_T() (prof_t = wall_clock64())
 #define PROF_ADD(k) do { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - prof_t; prof_t = t_; } while (0)
 
@@ -161,6 +186,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   const int lane = threadIdx.x;
   const int nc = T.nc, ec = T.ec, WS = T.ws, wm = WS - 1, RS = T.rs, RING = T.ring, rm = RING - 1, NS = RING + 2;
   constexpr int G = 4;            // -inf guard cells on each side of a ring row
+  constexpr bool CHAIN = C <= 2;  // (the wider instantiations only see the second and third rounds)
   const int RST = RS + 2 * G;     // LDS stride of a ring row
   // ---- LDS
   int32_t* rH = (int32_t*)smem;
@@ -171,7 +197,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   int32_t* rmpl = rend + NS;
   int32_t* rmpr = rmpl + NS;
   int32_t* sh = rmpr + NS;          // 0 nodes, 1 edges, 2 columns, 3 nops; 8..15 predecessor slots of a slow row
-  uint8_t* q = (uint8_t*)(sh + 16);
+  uint8_t* q = (uint8_t*)(sh + 16) + 16;   // q[-1] = N: column 0 has no match score
   // ---- HBM
   const WsLayout wl = ws_layout(nc, ec, T.max_len, WS);
   // every HBM array of the sub-cluster is (one base pointer, a 32-bit offset): thirty 64-bit pointers would not fit
@@ -190,6 +216,9 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   const int n = (int)T.n_seqs;
   unsigned long long my_cells = 0;
   unsigned long long prof[5] = {0, 0, 0, 0, 0}, prof_t;
+#ifdef POA_COUNT_ROWS
+  unsigned rowcnt[16] = {0};
+#endif
 #ifdef POA_FINE_PROF
   long long fp[6] = {0, 0, 0, 0, 0, 0}, ft = 0;
 #define FP(k) do { const long long t_ = clock64(); fp[k] += t_ - ft; ft = t_; } while (0)
@@ -234,6 +263,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
     if (L > T.max_len) FAIL(3 | (6 << 8));
     PROF_T();
     for (int j = lane; j < L; j += 64) q[j] = qg[j];
+    if (lane == 0) q[-1] = 4;
     // ---------------------------------------------------------- row descriptors (HBM)
     for (int r = lane; r < N + 64; r += 64) {
       uint32_t ri = 0;
@@ -247,26 +277,33 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
           ++np;
         }
         if (np > 2 || d0 > 31 || d1 > 31) ri |= RI_SLOW << 3;
-        else ri |= ((uint32_t)np << 3) | ((uint32_t)d0 << 5) | ((uint32_t)d1 << 10);
+        else {
+          ri |= ((uint32_t)np << 3) | ((uint32_t)d0 << 5) | ((uint32_t)d1 << 10);
+          // (the predecessor deltas the traceback reads: chain rows do not store them again)
+          prow0[r] = (uint32_t)d0 | ((uint32_t)d1 << 8);
+          prow1[r] = 0;
+        }
+        hl[r] = PNEG;
       }
       rinfo[r] = ri;
       keepf[r] = 0;
     }
     __syncthreads();
-    // flag the rows that are read back after they left the ring (plain stores of the same value: no atomics needed)
-    auto flag_row = [&](int rr) { keepf[rr] = 0x8000u; };
+    // flag the rows that are read back after they left the ring, and those a row other than the next one reads
+    // from the ring (a chain row leaves its values in registers unless it is flagged)
+    auto flag_row = [&](int rr, int d) { if (d >= 2) atomicOr(&keepf[rr], d >= RING ? RI_KEEP : RI_RING); };
     for (int r = lane; r < N - 1; r += 64) {
       const uint32_t ri = rinfo[r];
       const uint32_t np = (ri >> 3) & 3u;
       if (np == RI_SLOW) {
         for (int e = in_head[order[r]]; e >= 0; e = e_next_in[e]) {
           const int d = r - index[e_from[e]];
-          if (d >= RING) flag_row(r - d);
+          flag_row(r - d, d);
         }
       } else {
         const int d0 = (int)((ri >> 5) & 31u), d1 = (int)((ri >> 10) & 31u);
-        if (np >= 1 && d0 >= RING) flag_row(r - d0);
-        if (np >= 2 && d1 >= RING) flag_row(r - d1);
+        if (np >= 1) flag_row(r - d0, d0);
+        if (np >= 2) flag_row(r - d1, d1);
       }
     }
     __syncthreads();
@@ -305,7 +342,148 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
           // every row would wait for its own direction-word stores to reach HBM
           asm volatile("" : "+v"(ri_blk));
         }
-        const uint32_t ri = __builtin_amdgcn_readlane(ri_blk, r - blk0);
+        uint32_t ri = __builtin_amdgcn_readlane(ri_blk, r - blk0);
+        // ---- chain rows: one predecessor, the previous row, nothing kept in HBM (9 rows in 10).  The previous row
+        // stays in registers -- lane l holds columns beg + C*l .. beg + C*l + C-1 of its band, -inf outside -- and
+        // moves with the band (a band that starts one column further reads its right neighbour's values through one
+        // DPP shift); a row goes to the LDS ring only if a row other than the next one reads it (RI_RING), or when
+        // the chain ends.  Same arithmetic and tie rules as the general code below for np == 1.
+        if (CHAIN && r > 0 && last_r == r - 1 && (ri & RI_CHAIN_MASK) == RI_CHAIN_VAL) {
+          int pbeg = last_beg, pend = last_end;
+          int32_t pH[C], pE1[C], pE2[C];
+          {
+            const int so = ((r - 1) & rm) * RST + G;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const int idx = lane * C + c;
+              const bool ok = idx <= pend - pbeg;
+              const int a = so + (ok ? idx : 0);
+              const int32_t x0 = rH[a], x1 = rE1[a], x2 = rE2[a];
+              pH[c] = ok ? x0 : PNEG; pE1[c] = ok ? x1 : PNEG; pE2[c] = ok ? x2 : PNEG;
+            }
+          }
+          bool in_ring = true;
+          // read symbols: qc = q[j - 1] of this row's columns, qx = q[j] (what the next row needs if its band starts
+          // one column further; fetched a row ahead)
+          int qc[C], qx[C];
+          {
+            const int jb = pbeg + lane * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { qc[c] = q[imin(jb + c, L) - 1]; qx[c] = q[imin(jb + c, L - 1)]; }
+          }
+          auto ring_store = [&](int rr_, int b_, int e_, const int32_t* h_, const int32_t* e1_, const int32_t* e2_, int l_, int r_) {
+            const int sl = rr_ & rm, sb_ = sl * RST + G;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const int idx = lane * C + c;
+              if (idx <= e_ - b_) { rH[sb_ + idx] = h_[c]; rE1[sb_ + idx] = e1_[c]; rE2[sb_ + idx] = e2_[c]; }
+            }
+            if (lane < G) {
+              const int o1 = sl * RST + lane, o2 = sb_ + (e_ - b_ + 1) + lane;
+              rH[o1] = PNEG; rE1[o1] = PNEG; rE2[o1] = PNEG;
+              rH[o2] = PNEG; rE1[o2] = PNEG; rE2[o2] = PNEG;
+            }
+            if (lane == 0) { rbeg[sl] = b_; rend[sl] = e_; rmpl[sl] = l_; rmpr[sl] = r_; }
+          };
+          for (;;) {
+            int beg = last_mpl + 1 - w; if (beg < 0) beg = 0;
+            int end = last_mpr + 1 + w; if (end > L) end = L;
+            if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
+            const int width = end - beg + 1;
+            const int delta = beg - pbeg;
+            if (width > 64 * C || width > RS || width > WS || (unsigned)delta > 1u) break;   // (the general code's business)
+            my_cells += (unsigned long long)width;
+            ROWCNT(1);
+            const int bv = (int)(ri & 7u);
+            const int s_mat = bv < 4 ? P_MATCH : 0, s_mis = bv < 4 ? -P_MISMATCH : 0;
+            const int jb = beg + lane * C;
+            // predecessor values of columns j - 1 (hA) and j (hB, xa, xb)
+            int32_t hA[C], hB[C], xa[C], xb[C];
+            if (delta == 1) {
+              const int32_t nH = wave_shl1(pH[0], PNEG), n1 = wave_shl1(pE1[0], PNEG), n2 = wave_shl1(pE2[0], PNEG);
+#pragma unroll
+              for (int c = 0; c < C; ++c) {
+                hA[c] = pH[c];
+                hB[c] = c + 1 < C ? pH[c + 1] : nH; xa[c] = c + 1 < C ? pE1[c + 1] : n1; xb[c] = c + 1 < C ? pE2[c + 1] : n2;
+                qc[c] = qx[c];
+              }
+            } else {
+              const int32_t lH = wave_shr1(pH[C - 1], PNEG);
+#pragma unroll
+              for (int c = 0; c < C; ++c) { hA[c] = c ? pH[c - 1] : lH; hB[c] = pH[c]; xa[c] = pE1[c]; xb[c] = pE2[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) qx[c] = q[imin(jb + c, L - 1)];
+            int32_t m0[C], e1[C], e2[C], hp[C], p1[C], p2[C];
+            uint32_t dw[C];
+            bool valid[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const int j = jb + c;
+              valid[c] = j <= end;
+              int sc = qc[c] == bv ? s_mat : s_mis;
+              sc = qc[c] >= 4 ? 0 : sc;
+              m0[c] = hA[c] + sc;
+              const int32_t a1 = hB[c] - P_O1 - P_E1, b1 = xa[c] - P_E1, a2 = hB[c] - P_O2 - P_E2, b2 = xb[c] - P_E2;
+              e1[c] = imax(a1, b1); e2[c] = imax(a2, b2);
+              dw[c] = (b1 > a1 ? 0x800u : 0u) | (b2 > a2 ? 0x8000u : 0u);
+              hp[c] = valid[c] ? imax(m0[c], imax(e1[c], e2[c])) : PNEG;
+              const int32_t t1 = hp[c] + j * P_E1, t2 = hp[c] + j * P_E2;
+              p1[c] = c ? imax(p1[c - 1], t1) : t1;
+              p2[c] = c ? imax(p2[c - 1], t2) : t2;
+            }
+            const int32_t s1 = wave_scan_max_self(p1[C - 1]), s2 = wave_scan_max_self(p2[C - 1]);
+            const int32_t X1 = wave_shr1(s1, PNEG), X2 = wave_shr1(s2, PNEG);
+            const int32_t hp_prev = wave_shr1(hp[C - 1], PNEG);
+            int32_t h[C];
+            int32_t lbest = -0x7fffffff - 1; int ll = -1, lr = -1;
+            const int rowo = r * WS;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const int j = jb + c;
+              const int32_t x1 = c ? imax(X1, p1[c - 1]) : X1, x2 = c ? imax(X2, p2[c - 1]) : X2;
+              const int32_t f1 = x1 - P_O1 - j * P_E1, f2 = x2 - P_O2 - j * P_E2;
+              h[c] = imax(hp[c], imax(f1, f2));
+              const int32_t hp_left = c ? hp[c - 1] : hp_prev;
+              if (valid[c]) {
+                const uint32_t dH = m0[c] == h[c] ? 0u : e1[c] == h[c] ? 8u : e2[c] == h[c] ? 9u : f1 == h[c] ? 10u : 11u;
+                const uint32_t dHp = m0[c] == hp[c] ? 0u : e1[c] == hp[c] ? 0x80u : 0x90u;
+                const uint32_t o1 = hp_left - P_O1 - P_E1 == f1 ? 0x10000u : 0u;
+                const uint32_t o2 = hp_left - P_O2 - P_E2 == f2 ? 0x20000u : 0u;
+                gdir[rowo + (j & wm)] = dw[c] | dH | dHp | o1 | o2;
+                if (h[c] > lbest) { lbest = h[c]; ll = j; lr = j; }
+                else if (h[c] == lbest) lr = j;
+              }
+              pH[c] = valid[c] ? h[c] : PNEG; pE1[c] = valid[c] ? e1[c] : PNEG; pE2[c] = valid[c] ? e2[c] : PNEG;
+            }
+            if (end == L) {
+#pragma unroll
+              for (int c = 0; c < C; ++c) if (jb + c == L) hl[r] = h[c];
+            }
+            // leftmost / rightmost column of the row maximum
+            const int32_t wmx = __builtin_amdgcn_readlane(wave_scan_max_self(lbest), 63);
+            const unsigned long long em = __ballot(ll >= 0 && lbest == wmx);
+            int l, rr;
+            if (C == 1) { l = beg + (int)__builtin_ctzll(em); rr = beg + 63 - (int)__builtin_clzll(em); }
+            else { l = __builtin_amdgcn_readlane(ll, (int)__builtin_ctzll(em)); rr = __builtin_amdgcn_readlane(lr, 63 - (int)__builtin_clzll(em)); }
+            if (wmx <= PNEG / 2) { l = beg; rr = end; }
+            last_r = r; last_mpl = l; last_mpr = rr; last_beg = beg; last_end = end;
+            pbeg = beg; pend = end;
+            in_ring = (ri & RI_RING) != 0;
+            if (in_ring) ring_store(r, beg, end, pH, pE1, pE2, l, rr);
+            ++r;
+            if (r >= N - 1) break;
+            if (r - blk0 >= 64) {
+              blk0 = r;
+              ri_blk = rinfo[r + lane] | keepf[r + lane];
+              asm volatile("" : "+v"(ri_blk));
+            }
+            ri = __builtin_amdgcn_readlane(ri_blk, r - blk0);
+            if ((ri & RI_CHAIN_MASK) != RI_CHAIN_VAL) break;
+          }
+          if (!in_ring) ring_store(r - 1, pbeg, pend, pH, pE1, pE2, last_mpl, last_mpr);
+          if (r >= N - 1) break;
+        }
         const int slot = r & rm;
         const int bv = (int)(ri & 7u);
         int np = (int)((ri >> 3) & 3u);
@@ -392,6 +570,16 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
           }
         }
         const int this_beg = beg, this_end = end;
+#ifdef POA_COUNT_ROWS
+        ROWCNT(7);
+        if (slow) ROWCNT(4); else if (!fast) ROWCNT(3); else if (np == 2) ROWCNT(2);
+        else if (C == 1 && !keep && width <= 64) ROWCNT(0); else ROWCNT(1);
+        if (!slow && np == 1 && (pd0 & 255u) == 1 && !keep) { ROWCNT(5); if (width <= 64 * C) ROWCNT(8); if (last_beg == beg - 1) ROWCNT(9); if (last_beg == beg) ROWCNT(10); }
+        if (!slow && np == 2 && ((pd0 & 255u) == 1 || ((pd0 >> 8) & 255u) == 1) && fast && !keep) ROWCNT(6);
+        if (!slow && np == 1 && (pd0 & 255u) > 1 && fast && !keep) ROWCNT(11);
+        if (keep) ROWCNT(12);
+        if (width <= 64) ROWCNT(13);
+#endif
         if (C == 1 && fast && np == 1 && !keep && width <= 64) {
           // ---- the common row, written out flat: one predecessor inside the ring whose band covers this one, one
           // column per lane, nothing to keep for later.  Same arithmetic and the same tie rules as the general code
@@ -825,6 +1013,10 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
     status[blockIdx.x] = 0;
     atomicAdd(cells, my_cells);
     for (int k = 0; k < 5; ++k) atomicAdd(&g_poaw_prof[k], prof[k]);
+#ifdef POA_COUNT_ROWS
+    for (int k = 0; k < 16; ++k) atomicAdd(&g_poaw_rows[k], (unsigned long long)rowcnt[k]);
+    atomicAdd(&g_poaw_rows[14 + (C > 1)], 1ull);
+#endif
 #ifdef POA_FINE_PROF
     for (int k = 0; k < 6; ++k) printf("fp%d %lld\n", k, fp[k]);
 #endif
@@ -897,7 +1089,7 @@ __global__ void __launch_bounds__(64) poa_bundle_kernel(const PoaWaveTask* tasks
 size_t poa_wave_lds_bytes(int nc, int max_len, int rs, int ring) {
   (void)nc;
   const size_t ns = (size_t)ring + 2;
-  return 12 * ns * ((size_t)rs + 8) + 16 * ns + 64 + (((size_t)max_len + 15) & ~(size_t)15) + 64;
+  return 12 * ns * ((size_t)rs + 8) + 16 * ns + 64 + (((size_t)max_len + 15) & ~(size_t)15) + 64 + 256;
 }
 
 size_t poa_bundle_lds_bytes(int nc) { return 12 * (size_t)nc + 64; }
@@ -940,4 +1132,13 @@ void poa_wave_debug_report() {
           h[0], h[1], h[2], h[3], h[4]);
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_poaw_prof), h, sizeof h);
+#ifdef POA_COUNT_ROWS
+  unsigned long long rc[16];
+  if (hipMemcpyFromSymbol(rc, HIP_SYMBOL(g_poaw_rows), sizeof rc) != hipSuccess) return;
+  fprintf(stderr, "[poa_wave] rows: total %llu | flat %llu fast1 %llu fast2 %llu general %llu slow %llu | chain-eligible %llu (fits lanes %llu, band +1 %llu, +0 %llu) "
+          "np2-with-prev %llu np1-far %llu keep %llu width<=64 %llu | clusters C=1 %llu C>1 %llu\n", rc[7], rc[0], rc[1], rc[2], rc[3], rc[4], rc[5], rc[8], rc[9],
+          rc[10], rc[6], rc[11], rc[12], rc[13], rc[14], rc[15]);
+  memset(rc, 0, sizeof rc);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_poaw_rows), rc, sizeof rc);
+#endif
 }
