@@ -47,6 +47,7 @@
 #include "poa_wave.h"
 
 #define PNEG (-0x20000000)
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
 #define P_O1 4
 #define P_E1 2
 #define P_O2 24
@@ -131,16 +132,9 @@ __device__ __forceinline__ int wave_shr1(int x, int fill) { return dppi<0x138, 0
 // value of the lane above (lane 63 receives `fill`)
 __device__ __forceinline__ int wave_shl1(int x, int fill) { return dppi<0x130, 0xf>(fill, x); }
 
-// inclusive max-scan whose steps are single DPP instructions (a lane without a source keeps its own value)
-__device__ __forceinline__ int wave_scan_max_self(int x) {
-  x = imax(x, dppi<0x111, 0xf>(x, x));
-  x = imax(x, dppi<0x112, 0xf>(x, x));
-  x = imax(x, dppi<0x114, 0xf>(x, x));
-  x = imax(x, dppi<0x118, 0xf>(x, x));
-  x = imax(x, dppi<0x142, 0xa>(x, x));
-  x = imax(x, dppi<0x143, 0xc>(x, x));
-  return x;
-}
+// inclusive max-scan whose steps are single DPP instructions: a lane without a source keeps its own value (INT_MIN is
+// the identity the DPP combiner folds into v_max_i32_dpp)
+__device__ __forceinline__ int wave_scan_max_self(int x) { return wave_scan_max(x, -0x7fffffff - 1); }
 
 // direction word layout
 //  bits 0-3  source of H : 0-7 match through predecessor slot k, 8 E1, 9 E2, 10 F1, 11 F2
@@ -229,7 +223,9 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   if (T.prio >= 3) __builtin_amdgcn_s_setprio(3);
   else if (T.prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (T.prio == 1) __builtin_amdgcn_s_setprio(1);
-#define FAIL(code) do { if (lane == 0) status[blockIdx.x] = (code); return; } while (0)
+  // (every lane stores the same word: a branch on the lane number in front of a return would make every loop
+  // around it a loop with a divergent exit, and the compiler would carry all their scalars in vector registers)
+#define FAIL(code) do { status[blockIdx.x] = (code); return; } while (0)
   // ------------------------------------------------------------------ graph of the first read
   {
     const uint8_t* q0 = seqs + seq_off[T.seq_first];
@@ -258,8 +254,10 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
   }
   for (int i = 1; i < n; ++i) {
     const uint8_t* qg = seqs + seq_off[T.seq_first + i];
-    const int L = (int)(seq_off[T.seq_first + i + 1] - seq_off[T.seq_first + i]);
-    const int N = sh[0];
+    const int L = UNI((int)(seq_off[T.seq_first + i + 1] - seq_off[T.seq_first + i]));
+    // (values read back from LDS / HBM are uniform by construction; the compiler has to be told, or the whole row
+    // loop -- its counter, bands and branches -- is carried in vector registers under exec masks)
+    const int N = __builtin_amdgcn_readfirstlane(sh[0]);
     if (L > T.max_len) FAIL(3 | (6 << 8));
     PROF_T();
     for (int j = lane; j < L; j += 64) q[j] = qg[j];
@@ -311,12 +309,12 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
     int nops = -1;
     // banded first; if the band loses the sink the read is aligned again with the full matrix (w = L)
     for (int attempt = 0; attempt < 2 && nops < 0; ++attempt) {
-      const int w = attempt ? L : 10 + (int)(0.01 * L);
+      const int w = UNI(attempt ? L : 10 + (int)(0.01 * L));
       int last_r = -1, last_mpl = 0, last_mpr = 0, last_beg = 0, last_end = 0;
       // a row that left the ring comes back from HBM into staging slot s (its stores may still be in flight)
       auto stage = [&](int ur, int s) {
         __syncthreads();
-        const int pb = row_beg[ur], pe = row_end[ur];
+        const int pb = __builtin_amdgcn_readfirstlane(row_beg[ur]), pe = __builtin_amdgcn_readfirstlane(row_end[ur]);
         const int po = ur * WS;
         for (int x = lane; x <= pe - pb; x += 64) {
           const int o = po + ((pb + x) & wm);
@@ -333,7 +331,12 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
       uint32_t ri_blk = 0;          // descriptors of rows [blk0, blk0 + 64), one per lane
       int blk0 = -64;
       // ------------------------------------------------------------ forward (the sink is order[N-1])
-      for (int r = 0; r < N - 1; ++r) {
+      for (int r_ = 0; r_ < N - 1; ++r_) {
+        // (the loop-carried scalars, told to be uniform once per row: the tail of the body is a branch on the lane
+        // number, which makes the analysis treat everything that flows around the loop as divergent)
+        int r = UNI(r_);
+        last_r = UNI(last_r); last_mpl = UNI(last_mpl); last_mpr = UNI(last_mpr); last_beg = UNI(last_beg); last_end = UNI(last_end);
+        blk0 = UNI(blk0);
         FP(5);
         if (r - blk0 >= 64) {   // (both arrays are N + 64 long)
           blk0 = r;
@@ -348,7 +351,10 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         // moves with the band (a band that starts one column further reads its right neighbour's values through one
         // DPP shift); a row goes to the LDS ring only if a row other than the next one reads it (RI_RING), or when
         // the chain ends.  Same arithmetic and tie rules as the general code below for np == 1.
-        if (CHAIN && r > 0 && last_r == r - 1 && (ri & RI_CHAIN_MASK) == RI_CHAIN_VAL) {
+        if (CHAIN && 64 * C <= WS && r > 0 && last_r == r - 1 && (ri & RI_CHAIN_MASK) == RI_CHAIN_VAL) {
+#ifdef POA_COUNT_ROWS
+          const unsigned long long chain_t0 = wall_clock64();
+#endif
           int pbeg = last_beg, pend = last_end;
           int32_t pH[C], pE1[C], pE2[C];
           {
@@ -391,29 +397,25 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
             const int width = end - beg + 1;
             const int delta = beg - pbeg;
-            if (width > 64 * C || width > RS || width > WS || (unsigned)delta > 1u) break;   // (the general code's business)
+            if (width > 64 * C || width > RS || (unsigned)delta > 1u) break;   // (the general code's business)
+            if (delta == 0) {
+              // one row in fifty: the band did not move.  The previous row moves one column up the lanes (its origin
+              // becomes pbeg - 1) and the code below applies unchanged
+              if (pend - pbeg + 1 >= 64 * C) break;
+              const int32_t tH = wave_shr1(pH[C - 1], PNEG), t1 = wave_shr1(pE1[C - 1], PNEG), t2 = wave_shr1(pE2[C - 1], PNEG);
+#pragma unroll
+              for (int c = C - 1; c > 0; --c) { pH[c] = pH[c - 1]; pE1[c] = pE1[c - 1]; pE2[c] = pE2[c - 1]; }
+              pH[0] = tH; pE1[0] = t1; pE2[0] = t2;
+#pragma unroll
+              for (int c = 0; c < C; ++c) qx[c] = qc[c];
+            }
             my_cells += (unsigned long long)width;
             ROWCNT(1);
             const int bv = (int)(ri & 7u);
             const int s_mat = bv < 4 ? P_MATCH : 0, s_mis = bv < 4 ? -P_MISMATCH : 0;
             const int jb = beg + lane * C;
-            // predecessor values of columns j - 1 (hA) and j (hB, xa, xb)
-            int32_t hA[C], hB[C], xa[C], xb[C];
-            if (delta == 1) {
-              const int32_t nH = wave_shl1(pH[0], PNEG), n1 = wave_shl1(pE1[0], PNEG), n2 = wave_shl1(pE2[0], PNEG);
-#pragma unroll
-              for (int c = 0; c < C; ++c) {
-                hA[c] = pH[c];
-                hB[c] = c + 1 < C ? pH[c + 1] : nH; xa[c] = c + 1 < C ? pE1[c + 1] : n1; xb[c] = c + 1 < C ? pE2[c + 1] : n2;
-                qc[c] = qx[c];
-              }
-            } else {
-              const int32_t lH = wave_shr1(pH[C - 1], PNEG);
-#pragma unroll
-              for (int c = 0; c < C; ++c) { hA[c] = c ? pH[c - 1] : lH; hB[c] = pH[c]; xa[c] = pE1[c]; xb[c] = pE2[c]; }
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) qx[c] = q[imin(jb + c, L - 1)];
+            // predecessor values of columns j - 1 (own registers) and j (the next register / the next lane's first)
+            const int32_t nH = wave_shl1(pH[0], PNEG), n1 = wave_shl1(pE1[0], PNEG), n2 = wave_shl1(pE2[0], PNEG);
             int32_t m0[C], e1[C], e2[C], hp[C], p1[C], p2[C];
             uint32_t dw[C];
             bool valid[C];
@@ -421,10 +423,12 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             for (int c = 0; c < C; ++c) {
               const int j = jb + c;
               valid[c] = j <= end;
+              const int32_t hA = pH[c], hB = c + 1 < C ? pH[c + 1] : nH, xa = c + 1 < C ? pE1[c + 1] : n1, xb = c + 1 < C ? pE2[c + 1] : n2;
+              qc[c] = qx[c];
               int sc = qc[c] == bv ? s_mat : s_mis;
               sc = qc[c] >= 4 ? 0 : sc;
-              m0[c] = hA[c] + sc;
-              const int32_t a1 = hB[c] - P_O1 - P_E1, b1 = xa[c] - P_E1, a2 = hB[c] - P_O2 - P_E2, b2 = xb[c] - P_E2;
+              m0[c] = hA + sc;
+              const int32_t a1 = hB - P_O1 - P_E1, b1 = xa - P_E1, a2 = hB - P_O2 - P_E2, b2 = xb - P_E2;
               e1[c] = imax(a1, b1); e2[c] = imax(a2, b2);
               dw[c] = (b1 > a1 ? 0x800u : 0u) | (b2 > a2 ? 0x8000u : 0u);
               hp[c] = valid[c] ? imax(m0[c], imax(e1[c], e2[c])) : PNEG;
@@ -432,11 +436,12 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               p1[c] = c ? imax(p1[c - 1], t1) : t1;
               p2[c] = c ? imax(p2[c - 1], t2) : t2;
             }
+#pragma unroll
+            for (int c = 0; c < C; ++c) qx[c] = q[imin(jb + c, L - 1)];
             const int32_t s1 = wave_scan_max_self(p1[C - 1]), s2 = wave_scan_max_self(p2[C - 1]);
             const int32_t X1 = wave_shr1(s1, PNEG), X2 = wave_shr1(s2, PNEG);
             const int32_t hp_prev = wave_shr1(hp[C - 1], PNEG);
             int32_t h[C];
-            int32_t lbest = -0x7fffffff - 1; int ll = -1, lr = -1;
             const int rowo = r * WS;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -445,29 +450,37 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               const int32_t f1 = x1 - P_O1 - j * P_E1, f2 = x2 - P_O2 - j * P_E2;
               h[c] = imax(hp[c], imax(f1, f2));
               const int32_t hp_left = c ? hp[c - 1] : hp_prev;
-              if (valid[c]) {
-                const uint32_t dH = m0[c] == h[c] ? 0u : e1[c] == h[c] ? 8u : e2[c] == h[c] ? 9u : f1 == h[c] ? 10u : 11u;
-                const uint32_t dHp = m0[c] == hp[c] ? 0u : e1[c] == hp[c] ? 0x80u : 0x90u;
-                const uint32_t o1 = hp_left - P_O1 - P_E1 == f1 ? 0x10000u : 0u;
-                const uint32_t o2 = hp_left - P_O2 - P_E2 == f2 ? 0x20000u : 0u;
-                gdir[rowo + (j & wm)] = dw[c] | dH | dHp | o1 | o2;
-                if (h[c] > lbest) { lbest = h[c]; ll = j; lr = j; }
-                else if (h[c] == lbest) lr = j;
-              }
-              pH[c] = valid[c] ? h[c] : PNEG; pE1[c] = valid[c] ? e1[c] : PNEG; pE2[c] = valid[c] ? e2[c] : PNEG;
+              // the traceback's decisions, in the order the specification tries them.  Every lane stores: the columns
+              // past the band's end land in slots of this row that nothing reads (64 * C <= WS)
+              uint32_t dH = f1 == h[c] ? 10u : 11u;
+              dH = e2[c] == h[c] ? 9u : dH; dH = e1[c] == h[c] ? 8u : dH; dH = m0[c] == h[c] ? 0u : dH;
+              uint32_t dHp = e1[c] == hp[c] ? 0x80u : 0x90u;
+              dHp = m0[c] == hp[c] ? 0u : dHp;
+              const uint32_t o1 = hp_left - P_O1 - P_E1 == f1 ? 0x10000u : 0u;
+              const uint32_t o2 = hp_left - P_O2 - P_E2 == f2 ? 0x20000u : 0u;
+              gdir[rowo + (j & wm)] = dw[c] | dH | dHp | o1 | o2;
             }
             if (end == L) {
 #pragma unroll
               for (int c = 0; c < C; ++c) if (jb + c == L) hl[r] = h[c];
             }
-            // leftmost / rightmost column of the row maximum
-            const int32_t wmx = __builtin_amdgcn_readlane(wave_scan_max_self(lbest), 63);
-            const unsigned long long em = __ballot(ll >= 0 && lbest == wmx);
-            int l, rr;
-            if (C == 1) { l = beg + (int)__builtin_ctzll(em); rr = beg + 63 - (int)__builtin_clzll(em); }
-            else { l = __builtin_amdgcn_readlane(ll, (int)__builtin_ctzll(em)); rr = __builtin_amdgcn_readlane(lr, 63 - (int)__builtin_clzll(em)); }
+#pragma unroll
+            for (int c = 0; c < C; ++c) { pH[c] = valid[c] ? h[c] : PNEG; pE1[c] = valid[c] ? e1[c] : PNEG; pE2[c] = valid[c] ? e2[c] : PNEG; }
+            // leftmost / rightmost column of the row maximum (the columns past the end hold -inf: they can only tie
+            // with a row of unreachable cells, which the test below sends to beg / end anyway)
+            int32_t lmax = pH[0];
+#pragma unroll
+            for (int c = 1; c < C; ++c) lmax = imax(lmax, pH[c]);
+            const int32_t wmx = __builtin_amdgcn_readlane(wave_scan_max_self(lmax), 63);
+            int l = 1 << 20, rr = -1;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const unsigned long long em = __ballot(pH[c] == wmx);
+              if (em) { l = imin(l, C * (int)__builtin_ctzll(em) + c); rr = imax(rr, C * (63 - (int)__builtin_clzll(em)) + c); }
+            }
+            l += beg; rr += beg;
             if (wmx <= PNEG / 2) { l = beg; rr = end; }
-            last_r = r; last_mpl = l; last_mpr = rr; last_beg = beg; last_end = end;
+            last_r = r; last_mpl = UNI(l); last_mpr = UNI(rr); last_beg = beg; last_end = end;
             pbeg = beg; pend = end;
             in_ring = (ri & RI_RING) != 0;
             if (in_ring) ring_store(r, beg, end, pH, pE1, pE2, l, rr);
@@ -482,7 +495,12 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             if ((ri & RI_CHAIN_MASK) != RI_CHAIN_VAL) break;
           }
           if (!in_ring) ring_store(r - 1, pbeg, pend, pH, pE1, pE2, last_mpl, last_mpr);
+#ifdef POA_COUNT_ROWS
+          prof[4] += wall_clock64() - chain_t0;
+          ROWCNT(2);
+#endif
           if (r >= N - 1) break;
+          r_ = r;
         }
         const int slot = r & rm;
         const int bv = (int)(ri & 7u);
@@ -498,21 +516,23 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             const int d = (int)((ri >> 5) & 31u), ur = r - d;
             pd0 = (uint32_t)imin(d, 255);
             if (d < RING) ps0 = ur & rm; else { ps0 = RING + nfar++; stage(ur, ps0); }
-            const int a = ur == last_r ? last_mpl : rmpl[ps0], b = ur == last_r ? last_mpr : rmpr[ps0];
+            const int a = ur == last_r ? last_mpl : __builtin_amdgcn_readfirstlane(rmpl[ps0]);
+            const int b = ur == last_r ? last_mpr : __builtin_amdgcn_readfirstlane(rmpr[ps0]);
             lo = imin(lo, a); hi = imax(hi, b);
           }
           if (np >= 2) {
             const int d = (int)((ri >> 10) & 31u), ur = r - d;
             pd0 |= (uint32_t)imin(d, 255) << 8;
             if (d < RING) ps1 = ur & rm; else { ps1 = RING + nfar++; stage(ur, ps1); }
-            const int a = ur == last_r ? last_mpl : rmpl[ps1], b = ur == last_r ? last_mpr : rmpr[ps1];
+            const int a = ur == last_r ? last_mpl : __builtin_amdgcn_readfirstlane(rmpl[ps1]);
+            const int b = ur == last_r ? last_mpr : __builtin_amdgcn_readfirstlane(rmpr[ps1]);
             lo = imin(lo, a); hi = imax(hi, b);
           }
         } else {
           int nfar = 0;
           np = 0;
-          for (int e = in_head[order[r]]; e >= 0; e = e_next_in[e]) {
-            const int ur = index[e_from[e]];
+          for (int e = __builtin_amdgcn_readfirstlane(in_head[order[r]]); e >= 0; e = __builtin_amdgcn_readfirstlane(e_next_in[e])) {
+            const int ur = __builtin_amdgcn_readfirstlane(index[e_from[e]]);
             if (np < 8) {
               const uint32_t dl = (uint32_t)imin(r - ur, 255);
               if (np < 4) pd0 |= dl << (8 * np); else pd1 |= dl << (8 * (np - 4));
@@ -524,7 +544,8 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
                 stage(ur, s);
               }
               sh[8 + np] = s;
-              const int a = ur == last_r ? last_mpl : rmpl[s], b = ur == last_r ? last_mpr : rmpr[s];
+              const int a = ur == last_r ? last_mpl : __builtin_amdgcn_readfirstlane(rmpl[s]);
+              const int b = ur == last_r ? last_mpr : __builtin_amdgcn_readfirstlane(rmpr[s]);
               lo = imin(lo, a); hi = imax(hi, b);
             }
             ++np;
@@ -572,8 +593,8 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         const int this_beg = beg, this_end = end;
 #ifdef POA_COUNT_ROWS
         ROWCNT(7);
-        if (slow) ROWCNT(4); else if (!fast) ROWCNT(3); else if (np == 2) ROWCNT(2);
-        else if (C == 1 && !keep && width <= 64) ROWCNT(0); else ROWCNT(1);
+        if (slow) ROWCNT(4); else if (!fast) ROWCNT(3); else if (np == 2) ROWCNT(15);
+        else if (C == 1 && !keep && width <= 64) ROWCNT(0); else ROWCNT(14);
         if (!slow && np == 1 && (pd0 & 255u) == 1 && !keep) { ROWCNT(5); if (width <= 64 * C) ROWCNT(8); if (last_beg == beg - 1) ROWCNT(9); if (last_beg == beg) ROWCNT(10); }
         if (!slow && np == 2 && ((pd0 & 255u) == 1 || ((pd0 >> 8) & 255u) == 1) && fast && !keep) ROWCNT(6);
         if (!slow && np == 1 && (pd0 & 255u) > 1 && fast && !keep) ROWCNT(11);
@@ -615,7 +636,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
           const unsigned long long em = __ballot(valid && h == wmx);
           int l = beg + (int)__builtin_ctzll(em), rr = beg + 63 - (int)__builtin_clzll(em);
           if (wmx <= PNEG / 2) { l = beg; rr = end; }
-          last_r = r; last_mpl = l; last_mpr = rr; last_beg = this_beg; last_end = this_end;
+          last_r = r; last_mpl = UNI(l); last_mpr = UNI(rr); last_beg = this_beg; last_end = this_end;
           if (lane == 0) { rmpl[slot] = l; rmpr[slot] = rr; }
           continue;
         }
@@ -681,7 +702,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               km[c] = 15; ko1[c] = 15; kx1[c] = 15; ko2[c] = 15; kx2[c] = 15;
             }
             auto accum = [&](int k, int sl) {
-              const int pb = rbeg[sl], pe = rend[sl];
+              const int pb = __builtin_amdgcn_readfirstlane(rbeg[sl]), pe = __builtin_amdgcn_readfirstlane(rend[sl]);
               const int so = sl * RST + G;
               int32_t hv[C + 1], x1v[C], x2v[C];
 #pragma unroll
@@ -729,7 +750,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               if (np >= 2) accum(1, ps1);
             } else {
 #pragma unroll 1
-              for (int k = 0; k < np; ++k) accum(k, sh[8 + k]);
+              for (int k = 0; k < np; ++k) accum(k, __builtin_amdgcn_readfirstlane(sh[8 + k]));
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -799,7 +820,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             rr = __builtin_amdgcn_readlane(wave_scan_max(eq ? lr : -1, -1), 63);
           }
           if (wmx <= PNEG / 2) { l = beg; rr = end; }
-          last_r = r; last_mpl = l; last_mpr = rr; last_beg = this_beg; last_end = this_end;
+          last_r = r; last_mpl = UNI(l); last_mpr = UNI(rr); last_beg = this_beg; last_end = this_end;
           if (lane == 0) {
             rmpl[slot] = l; rmpr[slot] = rr;
             if (keep) { row_mpl[r] = l; row_mpr[r] = rr; }
@@ -824,6 +845,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
           int r0 = -(1 << 28), j0 = 0;
           uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0, P0 = 0, P1 = 0;
           while (r != 0 || j > 0) {
+            r = UNI(r); j = UNI(j); st = UNI(st); nops = UNI(nops); r0 = UNI(r0); j0 = UNI(j0);
             if (nops + j + 2 > opcap) { nops = -1; break; }   // cannot happen on a valid path
             if (r == 0) {   // only inserted bases remain
               for (int t = lane; t < j; t += 64) { op_node[nops + t] = -1; op_q[nops + t] = j - 1 - t; }
@@ -885,7 +907,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
     if (nops < 0) FAIL(3 | (4 << 8));
     if (nops > 32000) FAIL(3 | (5 << 8));   // (path positions are packed into 15 bits of a scan key)
     // ------------------------------------------------------- graph update
-    const int ncols = sh[2], n_old = N;
+    const int ncols = __builtin_amdgcn_readfirstlane(sh[2]), n_old = N;
     for (int c = lane; c < ncols; c += 64) scr[c] = 0;
     __syncthreads();
     int carry_c = 0, carry_n = 0, carry_key = 0;
@@ -1015,7 +1037,6 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
     for (int k = 0; k < 5; ++k) atomicAdd(&g_poaw_prof[k], prof[k]);
 #ifdef POA_COUNT_ROWS
     for (int k = 0; k < 16; ++k) atomicAdd(&g_poaw_rows[k], (unsigned long long)rowcnt[k]);
-    atomicAdd(&g_poaw_rows[14 + (C > 1)], 1ull);
 #endif
 #ifdef POA_FINE_PROF
     for (int k = 0; k < 6; ++k) printf("fp%d %lld\n", k, fp[k]);
@@ -1135,9 +1156,9 @@ void poa_wave_debug_report() {
 #ifdef POA_COUNT_ROWS
   unsigned long long rc[16];
   if (hipMemcpyFromSymbol(rc, HIP_SYMBOL(g_poaw_rows), sizeof rc) != hipSuccess) return;
-  fprintf(stderr, "[poa_wave] rows: total %llu | flat %llu fast1 %llu fast2 %llu general %llu slow %llu | chain-eligible %llu (fits lanes %llu, band +1 %llu, +0 %llu) "
-          "np2-with-prev %llu np1-far %llu keep %llu width<=64 %llu | clusters C=1 %llu C>1 %llu\n", rc[7], rc[0], rc[1], rc[2], rc[3], rc[4], rc[5], rc[8], rc[9],
-          rc[10], rc[6], rc[11], rc[12], rc[13], rc[14], rc[15]);
+  fprintf(stderr, "[poa_wave] rows: chain %llu in %llu chains (time: the 'bundle' figure above) | other rows %llu: flat %llu fast1 %llu fast2 %llu general %llu slow %llu | "
+          "of them chain-eligible %llu (fits lanes %llu, band +1 %llu, +0 %llu) np2-with-prev %llu np1-far %llu keep %llu width<=64 %llu\n", rc[1], rc[2], rc[7],
+          rc[0], rc[14], rc[15], rc[3], rc[4], rc[5], rc[8], rc[9], rc[10], rc[6], rc[11], rc[12], rc[13]);
   memset(rc, 0, sizeof rc);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_poaw_rows), rc, sizeof rc);
 #endif
