@@ -7,10 +7,12 @@
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <condition_variable>
@@ -186,16 +188,35 @@ class BamReader {
   explicit BamReader(const std::string& path, int threads = 0) : f_(fopen(path.c_str(), "rb")) {
     if (f_) {   // regular files are mapped: blocks are inflated straight from the page cache, no read() copies
       struct stat st;
-      if (!getenv("SVDSS_NO_MMAP") && fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      if (fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && !getenv("SVDSS_BAM_STREAM")) {
+        // regular files: every chunk loader reads its own range with pread into a private (recycled) buffer, in
+        // parallel with the others; the blocks are then located in ticket order.  (Inflating straight from a mapping
+        // of the file was tried first: with a hundred workers the page faults on one mapping serialise in the kernel.)
+        pread_size_ = (size_t)st.st_size;
+      }
+      if (getenv("SVDSS_BAM_MMAP") && fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        pread_size_ = 0;
         void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f_), 0);
         if (m != MAP_FAILED) { map_ = (const uint8_t*)m; map_size_ = (size_t)st.st_size; (void)madvise(m, map_size_, MADV_SEQUENTIAL); }
       }
     }
     const unsigned hw = std::thread::hardware_concurrency();
-    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(48u, hw ? hw / 2 : 1u));
+    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(128u, hw ? hw / 2 : 1u));
     pool_.reset(new InflatePool(threads_));
+    if (const char* e = getenv("SVDSS_BAM_AHEAD")) ahead_ = (size_t)std::max(1, atoi(e));
+    // the page tables of the mapping are filled ahead of the block scanner and the inflate workers, 16 MB per call:
+    // without it every BGZF block costs its worker a page fault, and faults of many threads on one mapping serialise
+    // in the kernel (the inflate rate did not move between 48 and 224 workers)
+    if (map_ && getenv("SVDSS_BAM_POPULATE")) prefault_ = std::thread([this] { prefault_loop(); });
   }
   ~BamReader() {
+    { std::lock_guard<std::mutex> lk(file_m_); prefault_stop_ = true; }
+    file_cv_.notify_all();
+    if (prefault_.joinable()) prefault_.join();
+    if (getenv("SVDSS_DEBUG"))
+      fprintf(stderr, "[bam_reader] %llu chunks: locate %.3f s (under the file lock), buffers %.3f s (%llu fresh), inflate %.3f s summed wall, parser waited %.3f s; %d workers\n",
+              (unsigned long long)n_launched_, t_scan_.load() * 1e-9, t_buf_.load() * 1e-9, (unsigned long long)n_fresh_.load(), t_inf_.load() * 1e-9,
+              t_wait_ * 1e-9, threads_);
     drain();
     pool_.reset();
     if (map_) munmap((void*)map_, map_size_);
@@ -274,14 +295,34 @@ class BamReader {
   }
 
   struct Bytes {   // uninitialised buffer (std::vector would zero-fill what inflate overwrites anyway)
-    std::unique_ptr<uint8_t[]> p;
+    struct FreeDeleter { void operator()(uint8_t* q) const { free(q); } };
+    std::unique_ptr<uint8_t[], FreeDeleter> p;
     size_t n = 0, cap = 0;
-    void alloc(size_t k) { if (k > cap || !p) { p.reset(new uint8_t[k ? k : 1]); cap = k ? k : 1; } n = k; }
+    // (chunk-sized buffers: 2 MB-aligned and advised for huge pages -- 25 faults per 50 MB chunk instead of 12,800)
+    void alloc(size_t k) {
+      if (k > cap || !p) {
+        size_t c = k ? k : 1;
+        if (c >= ((size_t)4 << 20)) {
+          c = (c + c / 8 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+          void* q = nullptr;
+          if (posix_memalign(&q, (size_t)2 << 20, c) != 0) throw std::bad_alloc();
+          (void)madvise(q, c, MADV_HUGEPAGE);
+          p = std::unique_ptr<uint8_t[], FreeDeleter>((uint8_t*)q);
+        } else {
+          p = std::unique_ptr<uint8_t[], FreeDeleter>((uint8_t*)malloc(c));
+          if (!p) throw std::bad_alloc();
+        }
+        cap = c;
+      }
+      n = k;
+    }
     uint8_t* data() { return p.get(); }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
     void swap(Bytes& o) { p.swap(o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
   };
+
+  struct FreeList { std::mutex m; std::vector<Bytes> v; };
 
   // A record sliced but not decoded: core fields + where name / cigar / packed bases / aux tags sit in an
   // arena the caller owns (qualities are skipped).  Slicing is sequential and runs at memcpy speed; the
@@ -515,12 +556,14 @@ class BamReader {
 
   bool next_chunk() {
     if (eof_seen_) return false;   // the final chunk was already handed out
-    while (pending_.size() < kAhead && !launched_eof_) {
+    while (pending_.size() < ahead_ && !launched_eof_) {
       const uint64_t ticket = n_launched_++;
       pending_.push_back(std::async(std::launch::async, [this, ticket] { return load_chunk(ticket); }));
     }
     if (pending_.empty()) { eof_seen_ = true; return false; }
+    const auto tw0 = std::chrono::steady_clock::now();
     Chunk c = pending_.front().get();
+    t_wait_ += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw0).count();
     pending_.pop_front();
     if (!c.err.empty()) { err_ = c.err; eof_seen_ = true; drain(); return false; }
     if (c.eof) { eof_seen_ = true; drain(); }
@@ -529,7 +572,7 @@ class BamReader {
     {
       std::shared_ptr<FreeList> fl = free_;
       chunk_ = std::shared_ptr<Bytes>(new Bytes(), [fl](Bytes* b) {
-        { std::lock_guard<std::mutex> lk(fl->m); if (fl->v.size() < 32) fl->v.push_back(std::move(*b)); }
+        { std::lock_guard<std::mutex> lk(fl->m); if (fl->v.size() < 512) fl->v.push_back(std::move(*b)); }
         delete b;
       });
     }
@@ -550,6 +593,20 @@ class BamReader {
     Chunk c;
     std::vector<BlockRef> blocks;
     size_t total = 0;
+    // pread mode: this loader's nominal range [base, base + slab) plus what the last block may need beyond it
+    std::shared_ptr<Bytes> own;
+    size_t own_got = 0;
+    const size_t base = (size_t)ticket * kSlabBytes;
+    if (pread_size_ && base < pread_size_) {
+      own = take_comp();
+      const size_t want = std::min(kSlabBytes + kOverlap, pread_size_ - base);
+      own->alloc(kSlabBytes + kOverlap);
+      while (own_got < want) {
+        const ssize_t k = pread(fileno(f_), own->data() + own_got, want - own_got, (off_t)(base + own_got));
+        if (k <= 0) break;
+        own_got += (size_t)k;
+      }
+    }
     std::unique_lock<std::mutex> file_lock(file_m_);
     file_cv_.wait(file_lock, [&] { return next_ticket_ == ticket; });
     struct Release {   // hand the file to the next loader on every exit path
@@ -558,12 +615,22 @@ class BamReader {
       ~Release() { (*this)(); }
     } release{this, &file_lock};
     if (file_eof_) { c.eof = true; return c; }
+    const auto ts0 = std::chrono::steady_clock::now();
     // mapped file: the blocks of this chunk are located in the mapping; otherwise one large read per chunk (plus the
     // partial block the previous chunk left over)
     Bytes comp;
     const uint8_t* src;
     size_t avail, got;
-    if (map_) {
+    size_t start = 0;
+    if (pread_size_) {
+      if (base >= pread_size_ || next_off_ >= pread_size_) { c.eof = true; file_eof_ = true; return c; }
+      if (next_off_ < base || next_off_ > base + kSlabBytes + kOverlap) { c.err = "BGZF block chain lost"; file_eof_ = true; return c; }
+      src = own->data();
+      start = next_off_ - base;              // the first block of this chunk (the previous chunk's last one ended here)
+      got = std::min(kSlabBytes, own_got);   // blocks start before the end of the nominal range ..
+      avail = own_got;                       // .. and may end in the overlap
+      if (start >= got && own_got < kSlabBytes + kOverlap && base + own_got < pread_size_) { c.err = "short read"; file_eof_ = true; return c; }
+    } else if (map_) {
       src = map_ + map_pos_;
       got = std::min(kSlabBytes, map_size_ - map_pos_);
       avail = map_size_ - map_pos_;          // a block may end past the slab: the mapping has it
@@ -574,8 +641,8 @@ class BamReader {
       avail = carry_.size() + got;
       src = comp.data();
     }
-    const size_t scan_end = map_ ? got : avail;   // where to stop starting new blocks
-    size_t pos = 0;
+    const size_t scan_end = (map_ || pread_size_) ? got : avail;   // where to stop starting new blocks
+    size_t pos = start;
     while (pos + 18 <= avail && pos < scan_end) {
       const uint8_t* h = src + pos;
       if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { c.err = "bad BGZF block"; file_eof_ = true; return c; }
@@ -602,7 +669,11 @@ class BamReader {
       blocks.push_back(b);
       pos += (size_t)bsize + 1;
     }
-    if (map_) {
+    if (pread_size_) {
+      next_off_ = base + pos;
+      if (next_off_ >= pread_size_) { c.eof = true; file_eof_ = true; }
+      else if (pos < scan_end) { c.eof = true; file_eof_ = true; c.err = "truncated BGZF block"; return c; }   // stopped early
+    } else if (map_) {
       map_pos_ += pos;
       if (pos == 0) {                       // nothing complete left: end of file (or a truncated last block)
         c.eof = true;
@@ -618,7 +689,9 @@ class BamReader {
       }
     }
     release();
+    const auto ts1 = std::chrono::steady_clock::now();
     take_buffer(c.data, total);
+    const auto ts2 = std::chrono::steady_clock::now();
     // groups of 8 blocks per task
     const size_t per = 8, n_tasks = (blocks.size() + per - 1) / per;
     std::vector<std::string> errs(n_tasks);
@@ -630,11 +703,49 @@ class BamReader {
       }
     };
     pool_->run(n_tasks, work);
+    const auto ts3 = std::chrono::steady_clock::now();
+    auto ns = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+    };
+    t_scan_ += ns(ts0, ts1); t_buf_ += ns(ts1, ts2); t_inf_ += ns(ts2, ts3);
     for (const std::string& e : errs) if (!e.empty()) { c.err = e; break; }
     return c;
   }
 
-  struct FreeList { std::mutex m; std::vector<Bytes> v; };
+  static constexpr size_t kOverlap = (size_t)128 << 10;   // a block that starts inside a loader's range ends within this
+  size_t pread_size_ = 0;          // file size when the loaders pread their own ranges (0: mapping or stream)
+  size_t next_off_ = 0;            // file offset of the next block to locate (guarded by file_m_)
+  std::shared_ptr<FreeList> comp_free_ = std::make_shared<FreeList>();
+  std::shared_ptr<Bytes> take_comp() {
+    std::shared_ptr<FreeList> fl = comp_free_;
+    std::shared_ptr<Bytes> b(new Bytes(), [fl](Bytes* x) {
+      { std::lock_guard<std::mutex> lk(fl->m); if (fl->v.size() < 64) fl->v.push_back(std::move(*x)); }
+      delete x;
+    });
+    std::lock_guard<std::mutex> lk(fl->m);
+    if (!fl->v.empty()) { b->swap(fl->v.back()); fl->v.pop_back(); }
+    return b;
+  }
+  void prefault_loop() {
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+    const size_t step = (size_t)16 << 20, lead = (size_t)1 << 30;
+    size_t done = 0;
+    while (done < map_size_) {
+      {
+        std::unique_lock<std::mutex> lk(file_m_);
+        file_cv_.wait(lk, [&] { return prefault_stop_ || done < map_pos_ + lead; });
+        if (prefault_stop_) return;
+      }
+      const size_t n = std::min(step, map_size_ - done);
+      if (madvise((void*)(map_ + done), n, MADV_POPULATE_READ) != 0) return;   // (older kernels: faults as before)
+      done += n;
+    }
+  }
+  std::thread prefault_;
+  bool prefault_stop_ = false;     // (guarded by file_m_)
+  size_t ahead_ = 16;              // chunks located / being inflated ahead of the parser (SVDSS_BAM_AHEAD)
   std::shared_ptr<FreeList> free_ = std::make_shared<FreeList>();
   void take_buffer(Bytes& dst, size_t bytes) {
     {
@@ -642,12 +753,14 @@ class BamReader {
       for (size_t i = 0; i < free_->v.size(); ++i)
         if (free_->v[i].cap >= bytes) { dst.swap(free_->v[i]); free_->v.erase(free_->v.begin() + (long)i); break; }
     }
+    if (dst.cap < bytes || !dst.p) ++n_fresh_;
     dst.alloc(bytes);
   }
+  std::atomic<long long> t_scan_{0}, t_buf_{0}, t_inf_{0}, n_fresh_{0};   // SVDSS_DEBUG: nanoseconds per stage
+  double t_wait_ = 0;
   std::unique_ptr<InflatePool> pool_;
   FILE* f_;
   int threads_ = 1;
-  static constexpr size_t kAhead = 4;
   std::deque<std::future<Chunk>> pending_;
   std::mutex file_m_;
   std::condition_variable file_cv_;

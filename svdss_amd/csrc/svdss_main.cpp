@@ -19,6 +19,7 @@
 #include <ctime>
 #include <deque>
 #include <functional>
+#include <malloc.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -240,6 +241,7 @@ struct SearchBatch {
   std::vector<int64_t> goff;
   std::vector<size_t> gidx;      // searched read -> index into reads
   std::vector<int32_t> qs, ln;   // results
+  std::vector<int64_t> counts;
   std::string text;              // the batch's lines, formatted by the thread that searched it
   uint64_t n_lines = 0;
 };
@@ -326,7 +328,27 @@ int main_search(const Options& o) {
   // batch, thread slice by thread slice, read names in std::map order (ping_pong.cpp:215-217).
   // (32 k reads keep the GPU efficient and let parsing, search and output of successive batches overlap)
   const int64_t super = std::max<int64_t>(o.bsize, 32768 / o.bsize * (int64_t)o.bsize);
-  BoundedQueue<SearchBatch> parsed(3);   // (the GPU threads are created below, after the replicas)
+  BoundedQueue<SearchBatch> parsed(4);   // (the GPU threads are created below, after the replicas)
+  // batch objects go round: their vectors and text buffers keep their capacity (tens of MB each; a fresh allocation of
+  // that size is an mmap, a page fault per 4 KB and a munmap that stalls every other thread of the process)
+  std::mutex pool_m;
+  std::vector<std::unique_ptr<SearchBatch>> batch_pool;
+  auto new_batch = [&]() {
+    std::unique_ptr<SearchBatch> b;
+    {
+      std::lock_guard<std::mutex> lk(pool_m);
+      if (!batch_pool.empty()) { b = std::move(batch_pool.back()); batch_pool.pop_back(); }
+    }
+    if (!b) b.reset(new SearchBatch);
+    b->reads.clear(); b->gbuf.clear(); b->boff.clear(); b->lseq.clear(); b->recs.clear(); b->keep.clear();
+    b->goff.clear(); b->gidx.clear(); b->qs.clear(); b->ln.clear(); b->text.clear(); b->counts.clear();
+    b->n_lines = 0; b->seq = 0;
+    return b;
+  };
+  auto recycle_batch = [&](std::unique_ptr<SearchBatch> b) {
+    std::lock_guard<std::mutex> lk(pool_m);
+    if (batch_pool.size() < 32) batch_pool.push_back(std::move(b));
+  };
   PinnedPool pinned;
   // searched batches wait here for their turn: two GPU threads finish them out of order
   std::mutex done_m;
@@ -339,7 +361,8 @@ int main_search(const Options& o) {
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
-  const int n_workers = o.io_threads > 0 ? o.io_threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  // (threads of the small per-batch loops -- tag decoding, the copy of the packed bases; --io-threads sizes the inflate pool)
+  const int n_workers = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   // items [0, n) over the worker threads, contiguous slices
   auto parallel_for = [&](size_t n, const std::function<void(size_t, size_t)>& body) {
     const size_t nt = std::min<size_t>((size_t)n_workers, std::max<size_t>(1, n / 64));
@@ -355,7 +378,7 @@ int main_search(const Options& o) {
     std::vector<BamReader::RawView> recs;
     std::vector<std::shared_ptr<BamReader::Bytes>> keep_chunks;
     while (!eof) {
-      std::unique_ptr<SearchBatch> bt(new SearchBatch);
+      std::unique_ptr<SearchBatch> bt = new_batch();
       bt->goff.assign(1, 0);
       if (bam_mode) {
         // locate the records of one batch in the inflated chunks (sequential, no copies: the chunks are kept
@@ -450,6 +473,7 @@ int main_search(const Options& o) {
       fwrite(bt->text.data(), 1, bt->text.size(), stdout);
       total_sfs += bt->n_lines;
       t_write += secs(tw0, now());
+      recycle_batch(std::move(bt));
     }
     fflush(stdout);
   });
@@ -496,13 +520,16 @@ int main_search(const Options& o) {
     while (std::unique_ptr<SearchBatch> bt = parsed.pop()) {
       const auto tg0 = now();
       if (!bt->gidx.empty()) {
-        std::vector<int64_t> counts(bt->gidx.size());
+        std::vector<int64_t>& counts = bt->counts;
+        counts.assign(bt->gidx.size(), 0);
         if (bam_mode) {
           // the packed bases of the batch, back to back in page-locked memory
           bt->seq4 = pinned.get((size_t)bt->boff.back() + 16, bt->seq4_cap);
-          for (size_t k = 0; k < bt->gidx.size(); ++k)
-            memcpy(bt->seq4 + bt->boff[k], bt->recs[bt->gidx[k]].seq4(), (size_t)(bt->boff[k + 1] - bt->boff[k]));
-          std::vector<BamReader::RawView>().swap(bt->recs);
+          parallel_for(bt->gidx.size(), [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k)
+              memcpy(bt->seq4 + bt->boff[k], bt->recs[bt->gidx[k]].seq4(), (size_t)(bt->boff[k + 1] - bt->boff[k]));
+          });
+          bt->recs.clear();
           bt->keep.clear();
         }
         if (bam_mode)
@@ -521,7 +548,7 @@ int main_search(const Options& o) {
           acc += counts[k];
         }
       }
-      std::vector<uint8_t>().swap(bt->gbuf);
+      bt->gbuf.clear();
       pinned.put(bt->seq4, bt->seq4_cap);
       bt->seq4 = nullptr;
       const auto tg1 = now();
@@ -531,7 +558,7 @@ int main_search(const Options& o) {
         // (bounded: a finished batch waits until the writer is at most 3 batches behind)
         std::unique_lock<std::mutex> lk(done_m);
         const uint64_t sq = bt->seq;
-        done_cv.wait(lk, [&] { return done.size() < 4 || done.begin()->first > sq; });
+        done_cv.wait(lk, [&] { return done.size() < 8 || done.begin()->first > sq; });
         done[sq] = std::move(bt);
       }
       done_cv.notify_all();
@@ -540,8 +567,11 @@ int main_search(const Options& o) {
   };
   {
     std::vector<std::thread> gpu_threads;
+    // (several feeding threads per GPU, each with its own batch object and stream: upload, search, download and the
+    // text formatting of different batches overlap; formatting alone needs four to five threads at a million reads/s)
+    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
     for (int d = 0; d < n_gpus; ++d)
-      for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < per_gpu; ++k)
         if (d || k) gpu_threads.emplace_back(gpu_worker, replicas[(size_t)d]);
     gpu_worker(replicas[0]);
     for (std::thread& th : gpu_threads) th.join();
@@ -563,6 +593,11 @@ int main_search(const Options& o) {
 
 int main(int argc, char** argv) {
   const time_t t0 = time(nullptr);
+  // large blocks stay in the allocator instead of going back to the kernel with every free (with a hundred threads an
+  // munmap is a stall for all of them)
+  mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 64 << 20);
   if (argc == 1) {
     fputs(MAIN_USAGE, stderr);
     return EXIT_FAILURE;

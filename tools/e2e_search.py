@@ -25,13 +25,13 @@ def _bgzf_block(data):
     return hdr + cdata + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
 
 
-def write_bam(path, ref_name, ref, n_reads, read_len, seed=5, err=0.005):
+def write_bam(path, ref_name, ref, n_reads, read_len, seed=5, err=0.005, repeat=1):
     rng = np.random.default_rng(seed)
     text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (ref_name, len(ref))
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1)
     hdr += struct.pack("<i", len(ref_name) + 1) + ref_name.encode() + b"\0" + struct.pack("<i", len(ref))
     starts = np.sort(rng.integers(0, len(ref) - read_len, size=n_reads))
-    chunks, cur, cur_len = [], [hdr], len(hdr)
+    chunks, cur, cur_len = [], [], 0
     for i, st in enumerate(starts):
         seq = ref[st:st + read_len].copy()
         e = rng.random(read_len) < err
@@ -54,11 +54,16 @@ def write_bam(path, ref_name, ref, n_reads, read_len, seed=5, err=0.005):
     blocks = [data[i:i + 65280] for i in range(0, len(data), 65280)]
     with mp.Pool(min(64, os.cpu_count() or 1)) as pool:
         comp = pool.map(_bgzf_block, blocks, chunksize=64)
+    # the header in BGZF blocks of its own, then the record blocks `repeat` times (blocks are independent deflate
+    # streams: a long input for the price of a short one; read names repeat at a distance of n_reads)
     with open(path, "wb") as f:
-        for b in comp:
-            f.write(b)
+        for i in range(0, len(hdr), 65280):
+            f.write(_bgzf_block(hdr[i:i + 65280]))
+        for _ in range(repeat):
+            for b in comp:
+                f.write(b)
         f.write(_bgzf_block(b""))
-    return len(data)
+    return len(hdr) + len(data) * repeat
 
 
 def main():
@@ -66,6 +71,7 @@ def main():
     n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 43000
     read_len = int(sys.argv[3]) if len(sys.argv) > 3 else 15000
     work = sys.argv[4] if len(sys.argv) > 4 else "/tmp/svdss_e2e"
+    repeat = int(os.environ.get("E2E_REPEAT", "1"))     # the record blocks written this many times
     os.makedirs(work, exist_ok=True)
     rng = np.random.default_rng(1)
     ref = rng.integers(0, 4, size=ref_bp, dtype=np.uint8)
@@ -75,7 +81,8 @@ def main():
         f.write(np.frombuffer(b"ACGT", dtype=np.uint8)[ref].tobytes())
         f.write(b"\n")
     t0 = time.time()
-    raw = write_bam(os.path.join(work, "reads.bam"), "chrS", ref, n_reads, read_len)
+    raw = write_bam(os.path.join(work, "reads.bam"), "chrS", ref, n_reads, read_len, repeat=repeat)
+    n_reads *= repeat
     t_gen = time.time() - t0
     exe = os.path.join(ROOT, "svdss_amd", "SVDSS")
     out = {"ref_bp": ref_bp, "n_reads": n_reads, "read_len": read_len, "bam_bytes": os.path.getsize(os.path.join(work, "reads.bam")),
