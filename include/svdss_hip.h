@@ -128,6 +128,30 @@ int svdss_sfs_search_batch_bam(const svdss_index_t* ix, const uint8_t* seq4, con
  * and asynchronously; pageable memory works too, slower). */
 int svdss_host_alloc(int64_t bytes, void** out);
 void svdss_host_free(void* p);
+/* ---- BGZF blocks inflated on the GPU (csrc/inflate.hip).  Stands where htslib's bgzf_read / inflate stand under
+ * sam_read1 (/root/reference/ping_pong.cpp:58,247-249): every BGZF block is an independent deflate stream of at most
+ * 64 KB, one wavefront inflates one block.  `comp` holds the compressed bytes (host memory, page-locked for speed);
+ * block i is the raw deflate stream comp[coff, coff + clen) and inflates to exactly isize bytes at d_out + uoff (d_out: a
+ * device buffer of out_bytes bytes, e.g. from svdss_device_alloc).  If host_out is not NULL the inflated bytes are also
+ * copied there.  Returns when everything is done (work runs on the object's own stream: calls on different objects
+ * overlap).  A block that does not inflate to isize bytes gives SVDSS_EIO and its index in *bad_block; the CRC32 of the
+ * BGZF footer is NOT checked on this path. */
+typedef struct svdss_inflate svdss_inflate_t;
+typedef struct svdss_bgzf_block {
+  int64_t coff;    /* first byte of the deflate stream in comp */
+  int32_t clen;    /* its length */
+  int32_t isize;   /* inflated size (BGZF footer), 0..65536 */
+  int64_t uoff;    /* where the block inflates to, relative to d_out */
+} svdss_bgzf_block_t;
+int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8_t* comp, int64_t comp_bytes,
+                       const svdss_bgzf_block_t* blocks, int64_t n_blocks, void* d_out, uint8_t* host_out,
+                       int64_t out_bytes, int64_t* bad_block);
+void svdss_inflate_free(svdss_inflate_t* obj);
+/* plain device memory for the callers of the entry points that take device pointers */
+int svdss_device_alloc(int device, int64_t bytes, void** out);
+void svdss_device_free(int device, void* p);
+int svdss_device_memset(int device, void* d_dst, int value, int64_t bytes);
+int svdss_device_download(int device, void* dst, const void* d_src, int64_t bytes);
 /* Device-buffer entry point: d_reads/d_offsets already resident in HBM on the
  * index's device; work is enqueued on `stream` (a hipStream_t, NULL = default
  * stream) and is complete when this returns. */

@@ -66,6 +66,12 @@ SIGNATURES = {
     "svdss_sfs_search_batch_bam": (C.c_int, [_p, _p, _p, _p, _i64, _i32, C.POINTER(_p)]),
     "svdss_host_alloc": (C.c_int, [_i64, C.POINTER(_p)]),
     "svdss_host_free": (None, [_p]),
+    "svdss_bgzf_inflate": (C.c_int, [C.POINTER(_p), _i32, _p, _i64, _p, _i64, _p, _p, _i64, _pi64]),
+    "svdss_inflate_free": (None, [_p]),
+    "svdss_device_alloc": (C.c_int, [_i32, _i64, C.POINTER(_p)]),
+    "svdss_device_free": (None, [_i32, _p]),
+    "svdss_device_memset": (C.c_int, [_i32, _p, C.c_int, _i64]),
+    "svdss_device_download": (C.c_int, [_i32, _p, _p, _i64]),
     "svdss_sfs_search_batch_device": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, C.POINTER(_p)]),
     "svdss_sfs_batch_nreads": (_i64, [_p]),
     "svdss_sfs_batch_total": (_i64, [_p]),

@@ -1,0 +1,437 @@
+// inflate.hip -- BGZF blocks inflated on the GPU (svdss_bgzf_inflate).
+//
+// Stands where htslib's bgzf_read / inflate stand under sam_read1 (/root/reference/ping_pong.cpp:58,247-249;
+// clusterer.cpp:101; smoother.cpp:262): `SVDSS search` reads ~1.5 bytes of BAM per base, all of it deflate streams of
+// at most 64 KB, and inflating them is what bounds the binary end to end (a host core inflates ~0.3 GB/s of this kind of
+// data; a 30x human sample is ~140 GB inflated).  Every BGZF block is an independent stream, so the GPU takes one
+// wavefront per block and a few thousand blocks at a time:
+//   * the last 32 KB of output (deflate's whole window) live in an LDS ring, so literals and matches never touch HBM;
+//     the ring is written out in aligned dwords 16 KB at a time;
+//   * the compressed bytes pass through a 2 KB LDS ring, refilled 1 KB at a time by the whole wave;
+//   * Huffman tables (10-bit literal/length, 8-bit distance, 16-bit entries; longer codes are decoded canonically) are
+//     built by the wave in parallel: the canonical code of a symbol is the rank of the symbol among those of its length
+//     (wave ballots), and every lane fills the table entries of its own symbols;
+//   * the decode loop itself is a serial chain per block (a symbol's position depends on the length of the one before):
+//     the scalar unit carries the bit buffer, one LDS lookup per symbol; matches are copied by all 64 lanes.
+// 38 KB of LDS per block: four blocks per CU, 1,024 in flight.  No CRC check on this path (the host path checks it).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/svdss_hip.h"
+
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+
+namespace {
+
+constexpr int WIN = 32768, WM = WIN - 1;
+constexpr int LB = 10, DB = 8, CB = 7;
+constexpr int INB = 2048;
+constexpr int FLUSH = 16384;
+
+__constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct Lds {
+  uint32_t win[WIN / 4];
+  uint16_t lit[1 << LB];
+  uint16_t dst[1 << DB];
+  uint32_t inb[INB / 4];
+  uint8_t lens[320];
+  uint16_t lsym[288];
+  uint16_t dsym[32];
+  uint16_t lcnt[16], dcnt[16];
+};
+
+// status codes (per block)
+enum { ST_OK = 0, ST_BTYPE = 1, ST_STORED = 2, ST_LENS = 3, ST_CODE = 4, ST_DIST = 5, ST_OUT = 6, ST_IN = 7, ST_SIZE = 8 };
+
+// Canonical Huffman code of n symbols with lengths lens[0..n): table of 2^tb 16-bit entries (symbol << 4 | length, 0 =
+// a longer code or none), per-length counts and the symbols sorted by (length, symbol) for the bit-by-bit decoder.
+// Returns false if the lengths over-subscribe the code space.
+__device__ bool build_table(const uint8_t* lens, int n, uint16_t* tab, int tb, uint16_t* cnt, uint16_t* sym, int lane) {
+  for (int k = lane; k < (1 << tb); k += 64) tab[k] = 0;
+  int count[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) count[l] = 0;
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const int s = s0 + lane;
+    const int ml = s < n ? (int)lens[s] : 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) count[l] += (int)__popcll(__ballot(ml == l));
+  }
+  int offs[16], code0[16];
+  int left = 1, code = 0, o = 0;
+  offs[0] = 0; code0[0] = 0;
+  bool over = false;
+#pragma unroll
+  for (int l = 1; l < 16; ++l) {
+    left = (left << 1) - count[l];
+    if (left < 0) over = true;
+    code = (code + (l > 1 ? count[l - 1] : 0)) << 1;
+    code0[l] = code;
+    offs[l] = o;
+    o += count[l];
+  }
+  if (over) return false;
+  if (lane < 16) {
+    int c = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) c = lane == l ? count[l] : c;
+    cnt[lane] = (uint16_t)c;
+  }
+  int run[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) run[l] = 0;
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const int s = s0 + lane;
+    const int ml = s < n ? (int)lens[s] : 0;
+    int rank = 0, first = 0, base = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+      const unsigned long long m = __ballot(ml == l);
+      if (ml == l) { rank = run[l] + (int)__popcll(m & lt); first = code0[l]; base = offs[l]; }
+      run[l] += (int)__popcll(m);
+    }
+    if (ml) {
+      sym[base + rank] = (uint16_t)s;
+      if (ml <= tb) {
+        const uint32_t rev = __brev((uint32_t)(first + rank)) >> (32 - ml);
+        const uint16_t e = (uint16_t)((s << 4) | ml);
+        for (uint32_t k = rev; k < (1u << tb); k += (1u << ml)) tab[k] = e;
+      }
+    }
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const svdss_bgzf_block_t* __restrict__ blks,
+                                                         uint8_t* __restrict__ out, int32_t* __restrict__ status) {
+  __shared__ Lds L;
+  const int lane = threadIdx.x;
+  const svdss_bgzf_block_t B = blks[blockIdx.x];
+  const uint32_t isize = (uint32_t)B.isize;
+  const uint64_t in_first = (uint64_t)B.coff, in_end = in_first + (uint64_t)(uint32_t)B.clen;
+  uint8_t* const o8 = out + B.uoff;
+  uint8_t* const winb = (uint8_t*)L.win;
+  if (isize == 0) { if (lane == 0) status[blockIdx.x] = ST_OK; return; }
+#define FAIL(code) do { status[blockIdx.x] = (code); return; } while (0)
+
+  // ---- input: absolute offsets into comp; the ring holds [base, base + INB)
+  uint64_t base = in_first & ~(uint64_t)1023, in_addr = in_first;
+  auto load_half = [&](uint64_t a0) {
+    const uint4 v = *(const uint4*)(comp + a0 + (uint64_t)lane * 16);
+    *(uint4*)((uint8_t*)L.inb + ((a0 + (uint64_t)lane * 16) & (INB - 1))) = v;
+  };
+  load_half(base);
+  load_half(base + 1024);
+  uint64_t bb = 0;
+  int bc = 0;
+  auto step_half = [&]() {
+    if (in_addr - base >= 1024) { load_half(base + INB); base += 1024; }
+  };
+  for (; (in_addr & 3) != 0; ++in_addr) {
+    const uint32_t b = UNI((uint32_t)((const uint8_t*)L.inb)[in_addr & (INB - 1)]);
+    bb |= (uint64_t)b << bc;
+    bc += 8;
+  }
+  step_half();
+  auto refill = [&]() {   // at least 33 bits afterwards
+    if (bc <= 32) {
+      const uint32_t w = UNI(L.inb[(in_addr & (INB - 1)) >> 2]);
+      bb |= (uint64_t)w << bc;
+      bc += 32;
+      in_addr += 4;
+      step_half();
+    }
+  };
+  auto take = [&](int n) { const uint32_t v = (uint32_t)(bb & ((1ull << n) - 1)); bb >>= n; bc -= n; return v; };
+  auto decode = [&](const uint16_t* tab, int tb, const uint16_t* cnt, const uint16_t* sym) -> int {
+    refill();
+    const uint32_t e = UNI((uint32_t)tab[bb & ((1u << tb) - 1)]);
+    const int len = (int)(e & 15u);
+    if (len) { bb >>= len; bc -= len; return (int)(e >> 4); }
+    int code = 0, first = 0, index = 0;
+    uint64_t b = bb;
+    for (int l = 1; l <= 15; ++l) {
+      code |= (int)(b & 1);
+      b >>= 1;
+      const int count = UNI((int)cnt[l]);
+      if (code - count < first) { bb >>= l; bc -= l; return UNI((int)sym[index + (code - first)]); }
+      index += count; first += count; first <<= 1; code <<= 1;
+    }
+    return -1;
+  };
+
+  // ---- output: the ring holds the last 32 KB; [flushed, wpos) is not in HBM yet
+  uint32_t wpos = 0, flushed = 0;
+  auto flush = [&](bool final) {
+    const uint32_t upto = wpos;
+    // head: single bytes until the HBM address is dword-aligned
+    uint32_t head = (uint32_t)((4 - ((B.uoff + flushed) & 3)) & 3);
+    if (head > upto - flushed) head = upto - flushed;
+    if ((uint32_t)lane < head) o8[flushed + lane] = winb[(flushed + lane) & WM];
+    flushed += head;
+    const uint32_t nd = (upto - flushed) >> 2;
+    uint32_t* const o32 = (uint32_t*)(o8 + flushed);
+    for (uint32_t i = lane; i < nd; i += 64) {
+      const uint32_t r = (flushed + 4 * i) & WM;
+      const uint32_t w0 = L.win[r >> 2], w1 = L.win[((r >> 2) + 1) & (WIN / 4 - 1)];
+      o32[i] = __builtin_amdgcn_alignbyte(w1, w0, r & 3);
+    }
+    flushed += 4 * nd;
+    if (final) {
+      const uint32_t tail = upto - flushed;
+      if ((uint32_t)lane < tail) o8[flushed + lane] = winb[(flushed + lane) & WM];
+      flushed += tail;
+    }
+  };
+
+  for (;;) {
+    refill();
+    const uint32_t bfinal = take(1), btype = take(2);
+    if (btype == 0) {
+      // stored: to the byte boundary, LEN / NLEN, LEN bytes straight from the input
+      take(bc & 7);
+      refill();
+      const uint32_t len = take(16), nlen = take(16);
+      if ((len ^ 0xffffu) != nlen) FAIL(ST_STORED);
+      if (wpos + len > isize) FAIL(ST_OUT);
+      // the whole bytes still in the bit buffer are the first of them
+      const uint64_t src = in_addr - (uint64_t)(bc >> 3);
+      if (src + len > in_end) FAIL(ST_IN);
+      // (through the ring in pieces of at most 16 KB: less than 16 KB are waiting to be written out at any time)
+      for (uint32_t done = 0; done < len;) {
+        const uint32_t n = len - done < (uint32_t)FLUSH ? len - done : (uint32_t)FLUSH;
+        for (uint32_t i = lane; i < n; i += 64) winb[(wpos + i) & WM] = comp[src + done + i];
+        wpos += n;
+        done += n;
+        if (wpos - flushed >= (uint32_t)FLUSH) flush(false);
+      }
+      // restart the reader behind the stored bytes
+      in_addr = src + len;
+      base = in_addr & ~(uint64_t)1023;
+      load_half(base);
+      load_half(base + 1024);
+      bb = 0; bc = 0;
+      for (; (in_addr & 3) != 0; ++in_addr) {
+        const uint32_t b = UNI((uint32_t)((const uint8_t*)L.inb)[in_addr & (INB - 1)]);
+        bb |= (uint64_t)b << bc;
+        bc += 8;
+      }
+      step_half();
+    } else if (btype == 1 || btype == 2) {
+      int nlen, ndist;
+      if (btype == 1) {
+        for (int s = lane; s < 320; s += 64) L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
+        nlen = 288; ndist = 30;
+      } else {
+        nlen = (int)take(5) + 257;
+        ndist = (int)take(5) + 1;
+        const int ncode = (int)take(4) + 4;
+        if (nlen > 286 || ndist > 30) FAIL(ST_LENS);
+        if (lane < 19) L.lens[lane] = 0;
+        for (int i = 0; i < ncode; ++i) {
+          refill();
+          const uint32_t v = take(3);
+          if (lane == 0) L.lens[c_clorder[i]] = (uint8_t)v;
+        }
+        if (!build_table(L.lens, 19, L.dst, CB, L.dcnt, L.dsym, lane)) FAIL(ST_LENS);
+        // the code lengths of the literal/length and distance codes, run-length coded (all lanes keep the same copy)
+        uint8_t* const tmp = (uint8_t*)L.lsym;   // (free until the tables are built)
+        int i = 0, prev = 0;
+        while (i < nlen + ndist) {
+          const int s = decode(L.dst, CB, L.dcnt, L.dsym);
+          if (s < 0) FAIL(ST_LENS);
+          if (s < 16) { if (lane == 0) tmp[i] = (uint8_t)s; prev = s; ++i; continue; }
+          refill();
+          int rep, val = 0;
+          if (s == 16) { if (i == 0) FAIL(ST_LENS); rep = 3 + (int)take(2); val = prev; }
+          else if (s == 17) { rep = 3 + (int)take(3); prev = 0; }
+          else { rep = 11 + (int)take(7); prev = 0; }
+          if (i + rep > nlen + ndist) FAIL(ST_LENS);
+          for (int k = lane; k < rep; k += 64) tmp[i + k] = (uint8_t)val;
+          i += rep;
+        }
+        for (int s = lane; s < 320; s += 64) {
+          const int v = s < nlen ? tmp[s] : (s >= 288 && s - 288 < ndist) ? tmp[nlen + (s - 288)] : 0;
+          // (read everything before anything is overwritten: lens and tmp are different arrays)
+          L.lens[s] = (uint8_t)v;
+        }
+        if (UNI((int)L.lens[256]) == 0) FAIL(ST_LENS);
+        nlen = 288; ndist = 30;
+      }
+      if (!build_table(L.lens, nlen, L.lit, LB, L.lcnt, L.lsym, lane)) FAIL(ST_LENS);
+      if (!build_table(L.lens + 288, ndist, L.dst, DB, L.dcnt, L.dsym, lane)) FAIL(ST_LENS);
+      // ---- symbols
+      for (;;) {
+        const int s = decode(L.lit, LB, L.lcnt, L.lsym);
+        if (s < 256) {
+          if (s < 0) FAIL(ST_CODE);
+          if (wpos >= isize) FAIL(ST_OUT);
+          if (lane == 0) winb[wpos & WM] = (uint8_t)s;
+          ++wpos;
+        } else if (s == 256) {
+          break;
+        } else {
+          if (s > 285) FAIL(ST_CODE);
+          refill();
+          const uint32_t len = (uint32_t)c_lbase[s - 257] + take((int)c_lext[s - 257]);
+          const int ds = decode(L.dst, DB, L.dcnt, L.dsym);
+          if (ds < 0 || ds > 29) FAIL(ST_DIST);
+          refill();
+          const uint32_t dist = (uint32_t)c_dbase[ds] + take((int)c_dext[ds]);
+          if (dist > wpos) FAIL(ST_DIST);
+          if (wpos + len > isize) FAIL(ST_OUT);
+          const uint32_t from = wpos - dist;
+          if (dist >= len) {
+            for (uint32_t k = lane; k < len; k += 64) winb[(wpos + k) & WM] = winb[(from + k) & WM];
+          } else {
+            // the match overlaps its own output: byte k repeats byte k mod dist of the dist bytes before it
+            uint8_t v[5];
+            int nk = 0;
+            for (uint32_t k = lane; k < len; k += 64) v[nk++] = winb[(from + k % dist) & WM];
+            nk = 0;
+            for (uint32_t k = lane; k < len; k += 64) winb[(wpos + k) & WM] = v[nk++];
+          }
+          wpos += len;
+        }
+        if (wpos - flushed >= (uint32_t)FLUSH) flush(false);
+        if (in_addr > in_end + 16) FAIL(ST_IN);
+      }
+    } else {
+      FAIL(ST_BTYPE);
+    }
+    if (bfinal) break;
+  }
+  if (wpos != isize) FAIL(ST_SIZE);
+  flush(true);
+  if (lane == 0) status[blockIdx.x] = ST_OK;
+#undef FAIL
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct svdss_inflate {
+  int device = -1;
+  hipStream_t st = nullptr;
+  DevBuf comp, blks, status;
+  std::vector<int32_t> h_status;
+};
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) {                                                                         \
+      if (getenv("SVDSS_DEBUG")) fprintf(stderr, "[inflate] %s: %s\n", #x, hipGetErrorString(e_));  \
+      return e_ == hipErrorOutOfMemory ? SVDSS_ENOMEM : SVDSS_EHIP;                                 \
+    }                                                                                               \
+  } while (0)
+
+static int ensure(DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return SVDSS_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  const size_t want = bytes + (bytes >> 2) + 4096;
+  HIPCHK(hipMalloc(&b.p, want));
+  b.cap = want;
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8_t* comp, int64_t comp_bytes,
+                                  const svdss_bgzf_block_t* blocks, int64_t n_blocks, void* d_out, uint8_t* host_out,
+                                  int64_t out_bytes, int64_t* bad_block) {
+  if (!obj || comp_bytes < 0 || n_blocks < 0 || out_bytes < 0) return SVDSS_EINVAL;
+  if (n_blocks > 0 && (!comp || !blocks || !d_out)) return SVDSS_EINVAL;
+  if (bad_block) *bad_block = -1;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return SVDSS_ENODEV;
+  for (int64_t i = 0; i < n_blocks; ++i) {
+    const svdss_bgzf_block_t& b = blocks[i];
+    if (b.coff < 0 || b.clen < 0 || b.isize < 0 || b.isize > 65536 || b.uoff < 0 || b.coff + b.clen > comp_bytes ||
+        b.uoff + b.isize > out_bytes)
+      return SVDSS_EINVAL;
+  }
+  HIPCHK(hipSetDevice(device));
+  svdss_inflate* o = *obj;
+  if (!o) {
+    o = new (std::nothrow) svdss_inflate();
+    if (!o) return SVDSS_ENOMEM;
+    o->device = device;
+    *obj = o;
+  }
+  if (o->device != device) return SVDSS_EINVAL;
+  if (!o->st) HIPCHK(hipStreamCreateWithFlags(&o->st, hipStreamNonBlocking));
+  if (n_blocks == 0) return SVDSS_OK;
+  int rc;
+  // (the kernel reads the input in aligned 1 KB pieces, up to 3 KB past a block's last byte)
+  if ((rc = ensure(o->comp, (size_t)comp_bytes + 4096))) return rc;
+  if ((rc = ensure(o->blks, sizeof(svdss_bgzf_block_t) * (size_t)n_blocks))) return rc;
+  if ((rc = ensure(o->status, sizeof(int32_t) * (size_t)n_blocks))) return rc;
+  HIPCHK(hipMemcpyAsync(o->comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, o->st));
+  HIPCHK(hipMemcpyAsync(o->blks.p, blocks, sizeof(svdss_bgzf_block_t) * (size_t)n_blocks, hipMemcpyHostToDevice, o->st));
+  hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, o->st, (const uint8_t*)o->comp.p,
+                     (const svdss_bgzf_block_t*)o->blks.p, (uint8_t*)d_out, (int32_t*)o->status.p);
+  HIPCHK(hipGetLastError());
+  o->h_status.resize((size_t)n_blocks);
+  HIPCHK(hipMemcpyAsync(o->h_status.data(), o->status.p, sizeof(int32_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, o->st));
+  if (host_out && out_bytes > 0) HIPCHK(hipMemcpyAsync(host_out, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, o->st));
+  HIPCHK(hipStreamSynchronize(o->st));
+  for (int64_t i = 0; i < n_blocks; ++i)
+    if (o->h_status[(size_t)i] != 0) {
+      if (bad_block) *bad_block = i;
+      if (getenv("SVDSS_DEBUG")) fprintf(stderr, "[inflate] block %lld: status %d\n", (long long)i, o->h_status[(size_t)i]);
+      return SVDSS_EIO;
+    }
+  return SVDSS_OK;
+}
+
+extern "C" void svdss_inflate_free(svdss_inflate_t* o) {
+  if (!o) return;
+  if (o->device >= 0) (void)hipSetDevice(o->device);
+  for (DevBuf* d : {&o->comp, &o->blks, &o->status})
+    if (d->p) (void)hipFree(d->p);
+  if (o->st) (void)hipStreamDestroy(o->st);
+  delete o;
+}
+
+extern "C" int svdss_device_alloc(int device, int64_t bytes, void** out) {
+  if (!out || bytes < 0) return SVDSS_EINVAL;
+  *out = nullptr;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipMalloc(out, (size_t)(bytes ? bytes : 16)));
+  return SVDSS_OK;
+}
+
+extern "C" void svdss_device_free(int device, void* p) {
+  if (!p) return;
+  (void)hipSetDevice(device);
+  (void)hipFree(p);
+}
+
+extern "C" int svdss_device_memset(int device, void* d_dst, int value, int64_t bytes) {
+  if (bytes < 0 || (bytes > 0 && !d_dst)) return SVDSS_EINVAL;
+  HIPCHK(hipSetDevice(device));
+  if (bytes) HIPCHK(hipMemset(d_dst, value, (size_t)bytes));
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_device_download(int device, void* dst, const void* d_src, int64_t bytes) {
+  if (bytes < 0 || (bytes > 0 && (!dst || !d_src))) return SVDSS_EINVAL;
+  HIPCHK(hipSetDevice(device));
+  if (bytes) HIPCHK(hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return SVDSS_OK;
+}

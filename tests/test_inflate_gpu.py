@@ -1,0 +1,128 @@
+"""BGZF / raw deflate streams inflated on the GPU (csrc/inflate.hip, svdss_bgzf_inflate) against zlib: every block
+type (stored, fixed, dynamic), every compression level and strategy, matches that overlap their own output, maximum
+distances, block sizes 0 .. 65536, arbitrary output alignment, corrupt input.  Bit-exact."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def _payloads(rng):
+    p = {}
+    p["empty"] = b""
+    p["one"] = b"A"
+    p["text"] = (b"the quick brown fox jumps over the lazy dog. " * 1500)[:65280]
+    p["random"] = rng.integers(0, 256, size=65280, dtype=np.uint8).tobytes()
+    p["random_max"] = rng.integers(0, 256, size=65536, dtype=np.uint8).tobytes()
+    p["nibbles"] = rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88],
+                                       dtype=np.uint8), size=60000).tobytes()
+    p["quals"] = rng.integers(20, 60, size=65000, dtype=np.uint8).tobytes()
+    p["binned"] = rng.choice(np.array([2, 10, 20, 30, 40, 93], dtype=np.uint8), p=[.02, .03, .05, .1, .3, .5], size=65536).tobytes()
+    p["run"] = b"\x00" * 65536                      # distance 1, length 258 over and over
+    p["run3"] = (b"abc" * 22000)[:65536]              # distance 3 < length
+    p["far"] = rng.integers(0, 256, size=32768, dtype=np.uint8).tobytes() * 2      # matches at distance 32768
+    p["skew"] = rng.choice(np.arange(200, dtype=np.uint8), p=np.r_[0.9, np.full(199, 0.1 / 199)], size=65000).tobytes()  # long codes
+    rec = bytearray()
+    for i in range(3):                                # BAM-like: core, name, cigar, packed bases, quals
+        l = 9000
+        rec += struct.pack("<iiiBBHHHiiii", 32 + 8 + 4 + l // 2 + l, 0, 1000 * i, 8, 60, 4680, 1, 0, l, -1, -1, 0)
+        rec += b"read%03d\0" % i + struct.pack("<I", l << 4)
+        rec += rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x48, 0x84, 0x88], dtype=np.uint8), size=l // 2).tobytes()
+        rec += rng.integers(20, 60, size=l, dtype=np.uint8).tobytes()
+    p["bam"] = bytes(rec)
+    return p
+
+
+def test_every_block_type_level_and_strategy():
+    from svdss_amd.bamio import gpu_inflate
+    rng = np.random.default_rng(11)
+    pay = _payloads(rng)
+    streams, want = [], []
+    for name, data in pay.items():
+        for level in (0, 1, 6, 9):
+            streams.append(_raw(data, level)); want.append(data)
+        for strat in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+            streams.append(_raw(data, 6, strat)); want.append(data)
+        streams.append(_raw(data, 9, memlevel=1)); want.append(data)        # many small deflate blocks per stream
+    # back to back in one buffer at odd offsets, outputs back to back too (arbitrary alignment of both)
+    comp, blocks = bytearray(), []
+    for s, w in zip(streams, want):
+        comp += b"\xee" * (len(comp) % 3)
+        blocks.append((len(comp), len(s), len(w)))
+        comp += s
+    out = gpu_inflate(bytes(comp), blocks).tobytes()
+    o = 0
+    for i, w in enumerate(want):
+        assert out[o:o + len(w)] == w, "stream %d" % i
+        o += len(w)
+    assert o == len(out)
+
+
+def test_scattered_outputs_do_not_touch_their_neighbours():
+    from svdss_amd.bamio import gpu_inflate
+    rng = np.random.default_rng(5)
+    datas = [rng.integers(0, 4, size=int(n), dtype=np.uint8).tobytes() for n in (1, 2, 3, 5, 4097, 65535, 7, 16384, 16385)]
+    comp, blocks, uoff = bytearray(), [], []
+    at = 3
+    for d in datas:
+        s = _raw(d, 6)
+        blocks.append((len(comp), len(s), len(d)))
+        comp += s
+        uoff.append(at)
+        at += len(d) + 5            # 5 bytes between the outputs must stay zero
+    out = gpu_inflate(bytes(comp), blocks, uoff=uoff).tobytes()
+    for d, u in zip(datas, uoff):
+        assert out[u:u + len(d)] == d
+        assert out[u - 3:u] == b"\0\0\0"
+
+
+def test_bgzf_file_blocks():
+    """a BGZF file as bgzip / htslib write it (header with BC subfield, footer with CRC32 and ISIZE)"""
+    from svdss_amd.bamio import bgzf_blocks, gpu_inflate
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 8, size=300000, dtype=np.uint8).tobytes()
+    data = bytearray()
+    for i in range(0, len(raw), 65280):
+        blk = raw[i:i + 65280]
+        cd = _raw(blk, 6)
+        data += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(cd) + 25) + cd
+        data += struct.pack("<II", zlib.crc32(blk) & 0xffffffff, len(blk))
+    data += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")     # the EOF marker block
+    blocks = bgzf_blocks(bytes(data))
+    assert blocks[-1][2] == 0
+    out = gpu_inflate(bytes(data), [b[:3] for b in blocks]).tobytes()
+    assert out == raw
+    assert [zlib.crc32(raw[i:i + 65280]) & 0xffffffff for i in range(0, len(raw), 65280)] == [b[3] for b in blocks[:-1]]
+
+
+def test_corrupt_streams_are_reported_not_trusted():
+    from svdss_amd._lib import SvdssError
+    from svdss_amd.bamio import gpu_inflate
+    rng = np.random.default_rng(9)
+    good = rng.integers(0, 16, size=20000, dtype=np.uint8).tobytes()
+    s = bytearray(_raw(good, 6))
+    cases = []
+    # (a flipped bit in the middle of the symbols can turn one literal into another of the same code length: only the
+    # CRC32 of the footer sees that, and the caller checks it on the host -- see BamReader; structural damage is the
+    # kernel's to report)
+    t = bytearray(s); t[1] ^= 0xff; t[2] ^= 0xff; cases.append((bytes(t), len(good)))     # damaged code-length header
+    cases.append((bytes(s), len(good) - 1))                                           # wrong isize (too small)
+    cases.append((bytes(s), len(good) + 1))                                           # wrong isize (too large)
+    cases.append((bytes(s[:len(s) // 2]), len(good)))                                 # truncated
+    cases.append((b"\x07" + bytes(s[1:]), len(good)))                                 # block type 3
+    for k, (c, isz) in enumerate(cases):
+        ok = _raw(good, 1)
+        comp = ok + c
+        with pytest.raises(SvdssError) as ei:
+            gpu_inflate(comp, [(0, len(ok), len(good)), (len(ok), len(c), isz)])
+        assert ei.value.bad_block == 1, k
+    # and the undamaged pair inflates
+    assert gpu_inflate(ok + bytes(s), [(0, len(ok), len(good)), (len(ok), len(s), len(good))]).tobytes() == good + good
