@@ -146,6 +146,7 @@ typedef struct svdss_bgzf_block {
 int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8_t* comp, int64_t comp_bytes,
                        const svdss_bgzf_block_t* blocks, int64_t n_blocks, void* d_out, uint8_t* host_out,
                        int64_t out_bytes, int64_t* bad_block);
+double svdss_inflate_kernel_ms(const svdss_inflate_t* obj);   /* the inflate kernel of the last call, HIP events */
 void svdss_inflate_free(svdss_inflate_t* obj);
 /* plain device memory for the callers of the entry points that take device pointers */
 int svdss_device_alloc(int device, int64_t bytes, void** out);

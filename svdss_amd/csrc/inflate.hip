@@ -34,11 +34,6 @@ constexpr int LB = 10, DB = 8, CB = 7;
 constexpr int INB = 2048;
 constexpr int FLUSH = 16384;
 
-__constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct Lds {
   uint32_t win[WIN / 4];
@@ -51,13 +46,21 @@ struct Lds {
   uint16_t lcnt[16], dcnt[16];
 };
 
+#ifdef INF_COUNT
+__device__ unsigned long long g_inf_cnt[8];   // rounds, literals, matches, one-symbol steps, deflate blocks, copy bytes, overlap copies
+#define CNT(k, v) (cnt[k] += (v))
+#else
+#define CNT(k, v)
+#endif
+
 // status codes (per block)
 enum { ST_OK = 0, ST_BTYPE = 1, ST_STORED = 2, ST_LENS = 3, ST_CODE = 4, ST_DIST = 5, ST_OUT = 6, ST_IN = 7, ST_SIZE = 8 };
 
 // Canonical Huffman code of n symbols with lengths lens[0..n): table of 2^tb 16-bit entries (symbol << 4 | length, 0 =
 // a longer code or none), per-length counts and the symbols sorted by (length, symbol) for the bit-by-bit decoder.
 // Returns false if the lengths over-subscribe the code space.
-__device__ bool build_table(const uint8_t* lens, int n, uint16_t* tab, int tb, uint16_t* cnt, uint16_t* sym, int lane) {
+__device__ bool build_table(const uint8_t* lens, int n, uint16_t* tab, int tb, uint16_t* cnt, uint16_t* sym, int lane,
+                            int n_flagged = 0) {   // entries of the symbols below n_flagged carry bit 15 (literals)
   for (int k = lane; k < (1 << tb); k += 64) tab[k] = 0;
   int count[16];
 #pragma unroll
@@ -106,7 +109,7 @@ __device__ bool build_table(const uint8_t* lens, int n, uint16_t* tab, int tb, u
       sym[base + rank] = (uint16_t)s;
       if (ml <= tb) {
         const uint32_t rev = __brev((uint32_t)(first + rank)) >> (32 - ml);
-        const uint16_t e = (uint16_t)((s << 4) | ml);
+        const uint16_t e = (uint16_t)((s << 4) | ml | (s < n_flagged ? 0x8000 : 0));
         for (uint32_t k = rev; k < (1u << tb); k += (1u << ml)) tab[k] = e;
       }
     }
@@ -123,7 +126,11 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
   const uint64_t in_first = (uint64_t)B.coff, in_end = in_first + (uint64_t)(uint32_t)B.clen;
   uint8_t* const o8 = out + B.uoff;
   uint8_t* const winb = (uint8_t*)L.win;
+  const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
   if (isize == 0) { if (lane == 0) status[blockIdx.x] = ST_OK; return; }
+#ifdef INF_COUNT
+  unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #define FAIL(code) do { status[blockIdx.x] = (code); return; } while (0)
 
   // ---- input: absolute offsets into comp; the ring holds [base, base + INB)
@@ -137,7 +144,9 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
   uint64_t bb = 0;
   int bc = 0;
   auto step_half = [&]() {
-    if (in_addr - base >= 1024) { load_half(base + INB); base += 1024; }
+    // (32 bytes late: the bit buffer holds up to 8 bytes that were read before in_addr, and the literal runs read the
+    // ring at the position of the first unused bit)
+    if (in_addr - base >= 1024 + 32) { load_half(base + INB); base += 1024; }
   };
   for (; (in_addr & 3) != 0; ++in_addr) {
     const uint32_t b = UNI((uint32_t)((const uint8_t*)L.inb)[in_addr & (INB - 1)]);
@@ -159,7 +168,7 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
     refill();
     const uint32_t e = UNI((uint32_t)tab[bb & ((1u << tb) - 1)]);
     const int len = (int)(e & 15u);
-    if (len) { bb >>= len; bc -= len; return (int)(e >> 4); }
+    if (len) { bb >>= len; bc -= len; return (int)((e & 0x7fffu) >> 4); }
     int code = 0, first = 0, index = 0;
     uint64_t b = bb;
     for (int l = 1; l <= 15; ++l) {
@@ -243,7 +252,9 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
         for (int i = 0; i < ncode; ++i) {
           refill();
           const uint32_t v = take(3);
-          if (lane == 0) L.lens[c_clorder[i]] = (uint8_t)v;
+          // (the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15, five bits each)
+          const int ord = i < 12 ? (int)((0x022caa324e804a30ull >> (5 * i)) & 31) : (int)((0x3c2e1346cull >> (5 * (i - 12))) & 31);
+          if (lane == 0) L.lens[ord] = (uint8_t)v;
         }
         if (!build_table(L.lens, 19, L.dst, CB, L.dcnt, L.dsym, lane)) FAIL(ST_LENS);
         // the code lengths of the literal/length and distance codes, run-length coded (all lanes keep the same copy)
@@ -270,44 +281,146 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
         if (UNI((int)L.lens[256]) == 0) FAIL(ST_LENS);
         nlen = 288; ndist = 30;
       }
-      if (!build_table(L.lens, nlen, L.lit, LB, L.lcnt, L.lsym, lane)) FAIL(ST_LENS);
+      CNT(4, 1);
+      if (!build_table(L.lens, nlen, L.lit, LB, L.lcnt, L.lsym, lane, 256)) FAIL(ST_LENS);
       if (!build_table(L.lens + 288, ndist, L.dst, DB, L.dcnt, L.dsym, lane)) FAIL(ST_LENS);
-      // ---- symbols
+      // ---- symbols, a round of up to 64 bits at a time.  Lane l fetches the 32 bits that start l bits ahead (straight
+      // from the input ring) and looks them up in both tables; the scalar unit then follows the chain from offset 0 --
+      // a code's length names the lane that holds what comes next: the next code, a length's extra bits, the distance
+      // code, its extra bits -- with lane reads only, no memory in the chain.  Literals are stored together by the lanes
+      // they start at; a match is copied by all lanes as soon as the literals before it are in the window.  A code
+      // longer than the table's index bits takes the one-symbol path (bit buffer, canonical decoding).  The cursor of
+      // the rounds is the bit position P alone; errors are collected and reported after the loop.
+      uint32_t err = 0;
+      bool eob = false;
+      uint64_t P = in_addr * 8 - (uint64_t)bc;
       for (;;) {
-        const int s = decode(L.lit, LB, L.lcnt, L.lsym);
-        if (s < 256) {
-          if (s < 0) FAIL(ST_CODE);
-          if (wpos >= isize) FAIL(ST_OUT);
-          if (lane == 0) winb[wpos & WM] = (uint8_t)s;
-          ++wpos;
-        } else if (s == 256) {
-          break;
-        } else {
-          if (s > 285) FAIL(ST_CODE);
-          refill();
-          const uint32_t len = (uint32_t)c_lbase[s - 257] + take((int)c_lext[s - 257]);
-          const int ds = decode(L.dst, DB, L.dcnt, L.dsym);
-          if (ds < 0 || ds > 29) FAIL(ST_DIST);
-          refill();
-          const uint32_t dist = (uint32_t)c_dbase[ds] + take((int)c_dext[ds]);
-          if (dist > wpos) FAIL(ST_DIST);
-          if (wpos + len > isize) FAIL(ST_OUT);
+        if ((P >> 3) - base >= 1024 + 32) { load_half(base + INB); base += 1024; }
+        CNT(0, 1);
+        const uint32_t pl = (uint32_t)P + (uint32_t)lane;   // (the ring is indexed modulo 2^14 bits)
+        const uint32_t di = pl >> 5;
+        const uint32_t w0 = L.inb[di & (INB / 4 - 1)], w1 = L.inb[(di + 1) & (INB / 4 - 1)];
+        const uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, pl & 31u);
+        const uint32_t E = (uint32_t)L.lit[bits & ((1u << LB) - 1)], D = (uint32_t)L.dst[bits & ((1u << DB) - 1)];
+        uint32_t off = 0;
+        unsigned long long chain = 0;   // the offsets at which the literals not yet stored start
+        bool slow = false;
+        while (off < 64) {
+          const uint32_t e = __builtin_amdgcn_readlane(E, off);
+          if (e & 0x8000u) { chain |= 1ull << off; off += e & 15u; continue; }
+          const uint32_t len = e & 15u;
+          if (len == 0) { slow = true; break; }
+          const uint32_t sym = e >> 4;
+          if (sym == 256) { off += len; eob = true; break; }
+          if (sym > 285) { err = ST_CODE; break; }
+          // (base and extra bits of the length / distance codes in closed form: a table in memory is a trip to L2 per
+          // match for the scalar unit)
+          const uint32_t ls = sym - 257;
+          const uint32_t lx = ls < 8 || ls == 28 ? 0 : (ls >> 2) - 1;
+          const uint32_t lb = ls < 8 ? 3u + ls : ls == 28 ? 258u : 3u + ((4u + (ls & 3u)) << lx);
+          const uint32_t o2 = off + len, o3 = o2 + lx;
+          if (o3 > 63) break;   // (the rest of this match is beyond the round: it starts the next one)
+          const uint32_t mlen = lb + (__builtin_amdgcn_readlane(bits, o2 & 63) & ((1u << lx) - 1));
+          const uint32_t d = __builtin_amdgcn_readlane(D, o3);
+          const uint32_t dl = d & 15u, ds = d >> 4;
+          if (dl == 0) { slow = true; break; }
+          if (ds > 29) { err = ST_DIST; break; }
+          const uint32_t dx = ds < 4 ? 0 : (ds >> 1) - 1;
+          const uint32_t db = ds < 4 ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx);
+          const uint32_t o4 = o3 + dl;
+          if (dx && o4 > 63) break;
+          const uint32_t dist = db + (__builtin_amdgcn_readlane(bits, o4 & 63) & ((1u << dx) - 1));
+          if (chain) {
+            if ((chain >> lane) & 1ull) winb[(wpos + (uint32_t)__popcll(chain & lt_mask)) & WM] = (uint8_t)(E >> 4);
+            wpos += (uint32_t)__popcll(chain);
+            chain = 0;
+          }
+          CNT(2, 1);
+          if (dist > wpos) { err = ST_DIST; break; }
+          if (wpos + mlen > isize) { err = ST_OUT; break; }
           const uint32_t from = wpos - dist;
-          if (dist >= len) {
-            for (uint32_t k = lane; k < len; k += 64) winb[(wpos + k) & WM] = winb[(from + k) & WM];
+          if (dist >= mlen) {
+            if ((uint32_t)lane < mlen) winb[(wpos + (uint32_t)lane) & WM] = winb[(from + (uint32_t)lane) & WM];
+            if (mlen > 64)
+              for (uint32_t k = 64 + lane; k < mlen; k += 64) winb[(wpos + k) & WM] = winb[(from + k) & WM];
           } else {
             // the match overlaps its own output: byte k repeats byte k mod dist of the dist bytes before it
             uint8_t v[5];
             int nk = 0;
-            for (uint32_t k = lane; k < len; k += 64) v[nk++] = winb[(from + k % dist) & WM];
+            for (uint32_t k = lane; k < mlen; k += 64) v[nk++] = winb[(from + k % dist) & WM];
             nk = 0;
-            for (uint32_t k = lane; k < len; k += 64) winb[(wpos + k) & WM] = v[nk++];
+            for (uint32_t k = lane; k < mlen; k += 64) winb[(wpos + k) & WM] = v[nk++];
           }
+          wpos += mlen;
+          off = o4 + dx;
+        }
+        if (chain) {
+          if ((chain >> lane) & 1ull) winb[(wpos + (uint32_t)__popcll(chain & lt_mask)) & WM] = (uint8_t)(E >> 4);
+          wpos += (uint32_t)__popcll(chain);
+        }
+        P += (uint64_t)off;
+        if (wpos > isize) err = ST_OUT;
+        if ((P >> 3) > in_end + 16) err = ST_IN;
+        if (err || eob) break;
+        if (wpos - flushed >= (uint32_t)FLUSH) flush(false);
+        if (!slow && off != 0) continue;
+        // ---- one symbol through the bit buffer
+        CNT(3, 1);
+        {
+          in_addr = (P >> 5) << 2;
+          const uint32_t v0 = UNI(L.inb[(in_addr & (INB - 1)) >> 2]), v1 = UNI(L.inb[((in_addr + 4) & (INB - 1)) >> 2]);
+          const int sh = (int)(P & 31);
+          bb = (((uint64_t)v1 << 32) | v0) >> sh;
+          bc = 64 - sh;
+          in_addr += 8;
+          step_half();
+        }
+        const int s = decode(L.lit, LB, L.lcnt, L.lsym);
+        if (s < 0) { err = ST_CODE; break; }
+        if (s < 256) {
+          if (wpos >= isize) { err = ST_OUT; break; }
+          if (lane == 0) winb[wpos & WM] = (uint8_t)s;
+          ++wpos;
+        } else if (s == 256) {
+          eob = true;
+        } else {
+          if (s > 285) { err = ST_CODE; break; }
+          refill();
+          const int ls = s - 257;
+          const int lx = ls < 8 || ls == 28 ? 0 : (ls >> 2) - 1;
+          const uint32_t lb = ls < 8 ? 3u + (uint32_t)ls : ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << lx);
+          const uint32_t len = lb + take(lx);
+          const int ds = decode(L.dst, DB, L.dcnt, L.dsym);
+          if (ds < 0 || ds > 29) { err = ST_DIST; break; }
+          refill();
+          const int dx = ds < 4 ? 0 : (ds >> 1) - 1;
+          const uint32_t db = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << dx);
+          const uint32_t dist = db + take(dx);
+          if (dist > wpos) { err = ST_DIST; break; }
+          if (wpos + len > isize) { err = ST_OUT; break; }
+          const uint32_t from = wpos - dist;
+          uint8_t v[5];
+          int nk = 0;
+          for (uint32_t k = lane; k < len; k += 64) v[nk++] = winb[(from + (dist >= len ? k : k % dist)) & WM];
+          nk = 0;
+          for (uint32_t k = lane; k < len; k += 64) winb[(wpos + k) & WM] = v[nk++];
           wpos += len;
         }
-        if (wpos - flushed >= (uint32_t)FLUSH) flush(false);
-        if (in_addr > in_end + 16) FAIL(ST_IN);
+        P = in_addr * 8 - (uint64_t)bc;
+        if (eob) break;
       }
+      if (err) FAIL((int)err);
+      {   // the bit buffer again, behind the end-of-block code
+        in_addr = (P >> 5) << 2;
+        step_half();
+        const uint32_t v0 = UNI(L.inb[(in_addr & (INB - 1)) >> 2]), v1 = UNI(L.inb[((in_addr + 4) & (INB - 1)) >> 2]);
+        const int sh = (int)(P & 31);
+        bb = (((uint64_t)v1 << 32) | v0) >> sh;
+        bc = 64 - sh;
+        in_addr += 8;
+        step_half();
+      }
+      if (wpos - flushed >= (uint32_t)FLUSH) flush(false);
     } else {
       FAIL(ST_BTYPE);
     }
@@ -316,6 +429,9 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
   if (wpos != isize) FAIL(ST_SIZE);
   flush(true);
   if (lane == 0) status[blockIdx.x] = ST_OK;
+#ifdef INF_COUNT
+  if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_inf_cnt[k], (unsigned long long)cnt[k]);
+#endif
 #undef FAIL
 }
 
@@ -331,6 +447,8 @@ struct svdss_inflate {
   hipStream_t st = nullptr;
   DevBuf comp, blks, status;
   std::vector<int32_t> h_status;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double kernel_ms = 0.0;
 };
 
 #define HIPCHK(x)                                                                                   \
@@ -383,13 +501,32 @@ extern "C" int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8
   if ((rc = ensure(o->status, sizeof(int32_t) * (size_t)n_blocks))) return rc;
   HIPCHK(hipMemcpyAsync(o->comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, o->st));
   HIPCHK(hipMemcpyAsync(o->blks.p, blocks, sizeof(svdss_bgzf_block_t) * (size_t)n_blocks, hipMemcpyHostToDevice, o->st));
+  if (!o->ev0) { HIPCHK(hipEventCreate(&o->ev0)); HIPCHK(hipEventCreate(&o->ev1)); }
+  HIPCHK(hipEventRecord(o->ev0, o->st));
   hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, o->st, (const uint8_t*)o->comp.p,
                      (const svdss_bgzf_block_t*)o->blks.p, (uint8_t*)d_out, (int32_t*)o->status.p);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(o->ev1, o->st));
   o->h_status.resize((size_t)n_blocks);
   HIPCHK(hipMemcpyAsync(o->h_status.data(), o->status.p, sizeof(int32_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, o->st));
   if (host_out && out_bytes > 0) HIPCHK(hipMemcpyAsync(host_out, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, o->st));
   HIPCHK(hipStreamSynchronize(o->st));
+  {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, o->ev0, o->ev1) == hipSuccess) o->kernel_ms = (double)ms;
+  }
+#ifdef INF_COUNT
+  {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_inf_cnt), sizeof h) == hipSuccess) {
+      fprintf(stderr, "[inflate] per block: rounds %.0f literals %.0f matches %.0f (bytes %.0f, overlapping %.0f) one-symbol steps %.0f deflate blocks %.2f\n",
+              (double)h[0] / n_blocks, (double)h[1] / n_blocks, (double)h[2] / n_blocks, (double)h[5] / n_blocks, (double)h[6] / n_blocks,
+              (double)h[3] / n_blocks, (double)h[4] / n_blocks);
+      memset(h, 0, sizeof h);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inf_cnt), h, sizeof h);
+    }
+  }
+#endif
   for (int64_t i = 0; i < n_blocks; ++i)
     if (o->h_status[(size_t)i] != 0) {
       if (bad_block) *bad_block = i;
@@ -399,9 +536,13 @@ extern "C" int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8
   return SVDSS_OK;
 }
 
+extern "C" double svdss_inflate_kernel_ms(const svdss_inflate_t* o) { return o ? o->kernel_ms : -1.0; }
+
 extern "C" void svdss_inflate_free(svdss_inflate_t* o) {
   if (!o) return;
   if (o->device >= 0) (void)hipSetDevice(o->device);
+  if (o->ev0) (void)hipEventDestroy(o->ev0);
+  if (o->ev1) (void)hipEventDestroy(o->ev1);
   for (DevBuf* d : {&o->comp, &o->blks, &o->status})
     if (d->p) (void)hipFree(d->p);
   if (o->st) (void)hipStreamDestroy(o->st);
