@@ -28,6 +28,23 @@
 #include <thread>
 #include <vector>
 
+// the processors this process may actually use: the hardware threads, capped by the cgroup's CPU quota (a container
+// with 256 visible threads and a quota of 16 runs 16 inflate workers at full speed and 128 of them at an eighth)
+inline unsigned effective_cpus() {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long long period = 0;
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long long quota = atoll(q);
+      if (quota > 0) hw = (unsigned)std::max<long long>(1, std::min<long long>(hw, (quota + period - 1) / period));
+    }
+    fclose(f);
+  }
+  return hw;
+}
+
 // raw-deflate decoder of one BGZF block: libdeflate when the shared library is on the machine (no header needed: its C
 // API is four functions; 2-3 x zlib's speed, and inflate is what bounds `search` end to end), zlib otherwise
 struct BgzfInflater {
@@ -200,8 +217,8 @@ class BamReader {
         if (m != MAP_FAILED) { map_ = (const uint8_t*)m; map_size_ = (size_t)st.st_size; (void)madvise(m, map_size_, MADV_SEQUENTIAL); }
       }
     }
-    const unsigned hw = std::thread::hardware_concurrency();
-    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(128u, hw ? hw / 2 : 1u));
+    const unsigned hw = effective_cpus();
+    threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(128u, hw > 32 ? hw / 2 : hw));
     pool_.reset(new InflatePool(threads_));
     if (const char* e = getenv("SVDSS_BAM_AHEAD")) ahead_ = (size_t)std::max(1, atoi(e));
     // the page tables of the mapping are filled ahead of the block scanner and the inflate workers, 16 MB per call:
@@ -213,18 +230,39 @@ class BamReader {
     { std::lock_guard<std::mutex> lk(file_m_); prefault_stop_ = true; }
     file_cv_.notify_all();
     if (prefault_.joinable()) prefault_.join();
+    if (getenv("SVDSS_DEBUG") && n_gpu_chunks_.load())
+      fprintf(stderr, "[bam_reader] %llu chunks inflated on the GPU (%.3f s summed wall incl. copies), CRC check %.3f s\n",
+              (unsigned long long)n_gpu_chunks_.load(), t_gpu_.load() * 1e-9, t_crc_.load() * 1e-9);
     if (getenv("SVDSS_DEBUG"))
       fprintf(stderr, "[bam_reader] %llu chunks: locate %.3f s (under the file lock), buffers %.3f s (%llu fresh), inflate %.3f s summed wall, parser waited %.3f s; %d workers\n",
               (unsigned long long)n_launched_, t_scan_.load() * 1e-9, t_buf_.load() * 1e-9, (unsigned long long)n_fresh_.load(), t_inf_.load() * 1e-9,
               t_wait_ * 1e-9, threads_);
     drain();
     pool_.reset();
+    for (GpuObj& g : gpu_objs_) { if (g.h) gpu_.inflate_free(g.h); if (g.d_out) gpu_.device_free(gpu_device_, g.d_out); }
     if (map_) munmap((void*)map_, map_size_);
     if (f_) fclose(f_);
   }
   BamReader(const BamReader&) = delete;
   BamReader& operator=(const BamReader&) = delete;
   bool ok() const { return f_ != nullptr; }
+
+  // BGZF blocks inflated on the GPU (csrc/inflate.hip) instead of by the host workers: `percent` of the chunks (the
+  // rest stay with the host pool, which otherwise idles); the CRC32 of every block is still checked here, on the host.
+  // The entry points come as function pointers so that this header stays free of the library's.
+  struct GpuInflateApi {
+    int (*inflate)(void** obj, int device, const uint8_t* comp, int64_t comp_bytes, const void* blocks, int64_t n_blocks,
+                   void* d_out, uint8_t* host_out, int64_t out_bytes, int64_t* bad_block) = nullptr;
+    void (*inflate_free)(void* obj) = nullptr;
+    int (*device_alloc)(int device, int64_t bytes, void** out) = nullptr;
+    void (*device_free)(int device, void* p) = nullptr;
+    int (*host_alloc)(int64_t bytes, void** out) = nullptr;
+    void (*host_free)(void* p) = nullptr;
+  };
+  void enable_gpu_inflate(const GpuInflateApi& api, int device, int percent) {
+    gpu_ = api; gpu_device_ = device; gpu_percent_ = std::max(0, std::min(100, percent));
+    pin_hooks().alloc = api.host_alloc; pin_hooks().free_ = api.host_free;
+  }
   const std::string& error() const { return err_; }
   const std::vector<std::string>& ref_names() const { return refs_; }
   const std::vector<int32_t>& ref_lens() const { return ref_lens_; }
@@ -294,22 +332,39 @@ class BamReader {
     return 1;
   }
 
+  // page-locked buffers for the GPU inflate path (set by enable_gpu_inflate: the reader itself does not know HIP)
+  struct PinHooks {
+    int (*alloc)(int64_t, void**) = nullptr;
+    void (*free_)(void*) = nullptr;
+  };
+  static PinHooks& pin_hooks() { static PinHooks h; return h; }
+
   struct Bytes {   // uninitialised buffer (std::vector would zero-fill what inflate overwrites anyway)
-    struct FreeDeleter { void operator()(uint8_t* q) const { free(q); } };
-    std::unique_ptr<uint8_t[], FreeDeleter> p;
+    struct Deleter {
+      bool pinned;
+      Deleter() : pinned(false) {}
+      explicit Deleter(bool p_) : pinned(p_) {}
+      void operator()(uint8_t* q) const { if (pinned) pin_hooks().free_(q); else free(q); }
+    };
+    std::unique_ptr<uint8_t[], Deleter> p;
     size_t n = 0, cap = 0;
     // (chunk-sized buffers: 2 MB-aligned and advised for huge pages -- 25 faults per 50 MB chunk instead of 12,800)
-    void alloc(size_t k) {
-      if (k > cap || !p) {
+    void alloc(size_t k, bool pinned = false) {
+      if (k > cap || !p || (pinned && !p.get_deleter().pinned)) {
         size_t c = k ? k : 1;
-        if (c >= ((size_t)4 << 20)) {
+        if (pinned && pin_hooks().alloc) {
+          c = (c + c / 8 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+          void* q = nullptr;
+          if (pin_hooks().alloc((int64_t)c, &q) != 0 || !q) throw std::bad_alloc();
+          p = std::unique_ptr<uint8_t[], Deleter>((uint8_t*)q, Deleter(true));
+        } else if (c >= ((size_t)4 << 20)) {
           c = (c + c / 8 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
           void* q = nullptr;
           if (posix_memalign(&q, (size_t)2 << 20, c) != 0) throw std::bad_alloc();
           (void)madvise(q, c, MADV_HUGEPAGE);
-          p = std::unique_ptr<uint8_t[], FreeDeleter>((uint8_t*)q);
+          p = std::unique_ptr<uint8_t[], Deleter>((uint8_t*)q, Deleter(false));
         } else {
-          p = std::unique_ptr<uint8_t[], FreeDeleter>((uint8_t*)malloc(c));
+          p = std::unique_ptr<uint8_t[], Deleter>((uint8_t*)malloc(c), Deleter(false));
           if (!p) throw std::bad_alloc();
         }
         cap = c;
@@ -600,7 +655,7 @@ class BamReader {
     if (pread_size_ && base < pread_size_) {
       own = take_comp();
       const size_t want = std::min(kSlabBytes + kOverlap, pread_size_ - base);
-      own->alloc(kSlabBytes + kOverlap);
+      own->alloc(kSlabBytes + kOverlap, gpu_.inflate != nullptr);
       while (own_got < want) {
         const ssize_t k = pread(fileno(f_), own->data() + own_got, want - own_got, (off_t)(base + own_got));
         if (k <= 0) break;
@@ -690,8 +745,53 @@ class BamReader {
     }
     release();
     const auto ts1 = std::chrono::steady_clock::now();
-    take_buffer(c.data, total);
+    // which side inflates this chunk: with percent = 100 the host pool still takes a chunk whenever it would otherwise
+    // idle (fewer than two chunks in its queue), everything else goes to the GPU; a smaller percent fixes the share
+    bool on_gpu = gpu_.inflate && pread_size_ && !blocks.empty();
+    if (on_gpu) {
+      if (gpu_percent_ >= 100) {
+        if (cpu_inflight_.fetch_add(1) < 2) on_gpu = false; else cpu_inflight_.fetch_sub(1);
+      } else {
+        on_gpu = (ticket + 1) * (uint64_t)gpu_percent_ / 100 != ticket * (uint64_t)gpu_percent_ / 100;
+        if (!on_gpu) cpu_inflight_.fetch_add(1);
+      }
+    } else cpu_inflight_.fetch_add(1);
+    struct CpuDone { std::atomic<int>* c; bool armed; ~CpuDone() { if (armed) c->fetch_sub(1); } } cpu_done{&cpu_inflight_, !on_gpu};
+    take_buffer(c.data, total, on_gpu);
     const auto ts2 = std::chrono::steady_clock::now();
+    if (on_gpu) {
+      struct Blk { int64_t coff; int32_t clen; int32_t isize; int64_t uoff; };
+      std::vector<Blk> tb(blocks.size());
+      for (size_t i = 0; i < blocks.size(); ++i) tb[i] = Blk{(int64_t)blocks[i].coff, (int32_t)blocks[i].clen, (int32_t)blocks[i].isize, (int64_t)blocks[i].uoff};
+      GpuObj g = take_gpu_obj();
+      int rc = 0;
+      if (g.d_cap < total + 256) {
+        if (g.d_out) gpu_.device_free(gpu_device_, g.d_out);
+        g.d_out = nullptr; g.d_cap = 0;
+        const size_t want = total + total / 4 + 4096;
+        rc = gpu_.device_alloc(gpu_device_, (int64_t)want, &g.d_out);
+        if (rc == 0) g.d_cap = want;
+      }
+      int64_t bad = -1;
+      if (rc == 0) rc = gpu_.inflate(&g.h, gpu_device_, src, (int64_t)avail, tb.data(), (int64_t)tb.size(), g.d_out, c.data.data(), (int64_t)total, &bad);
+      put_gpu_obj(g);
+      const auto tg = std::chrono::steady_clock::now();
+      if (rc != 0) c.err = bad >= 0 ? "BGZF inflate failed (GPU)" : "GPU inflate call failed";
+      else {
+        // the footers' CRC32, here on the host (libdeflate's runs at tens of GB/s per core)
+        for (const BlockRef& b : blocks) {
+          if (b.isize == 0) continue;
+          const uint32_t got = BgzfInflater::lib().crc ? BgzfInflater::lib().crc(0, c.data.data() + b.uoff, b.isize)
+                                                       : (uint32_t)crc32(0L, c.data.data() + b.uoff, b.isize);
+          if (got != b.crc) { c.err = "BGZF block CRC mismatch"; break; }
+        }
+      }
+      const auto tc = std::chrono::steady_clock::now();
+      t_gpu_ += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(tg - ts2).count();
+      t_crc_ += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(tc - tg).count();
+      ++n_gpu_chunks_;
+      return c;
+    }
     // groups of 8 blocks per task
     const size_t per = 8, n_tasks = (blocks.size() + per - 1) / per;
     std::vector<std::string> errs(n_tasks);
@@ -747,15 +847,33 @@ class BamReader {
   bool prefault_stop_ = false;     // (guarded by file_m_)
   size_t ahead_ = 16;              // chunks located / being inflated ahead of the parser (SVDSS_BAM_AHEAD)
   std::shared_ptr<FreeList> free_ = std::make_shared<FreeList>();
-  void take_buffer(Bytes& dst, size_t bytes) {
+  void take_buffer(Bytes& dst, size_t bytes, bool pinned = false) {
     {
       std::lock_guard<std::mutex> lk(free_->m);
       for (size_t i = 0; i < free_->v.size(); ++i)
-        if (free_->v[i].cap >= bytes) { dst.swap(free_->v[i]); free_->v.erase(free_->v.begin() + (long)i); break; }
+        if (free_->v[i].cap >= bytes && (!pinned || free_->v[i].p.get_deleter().pinned)) {
+          dst.swap(free_->v[i]); free_->v.erase(free_->v.begin() + (long)i); break;
+        }
     }
-    if (dst.cap < bytes || !dst.p) ++n_fresh_;
-    dst.alloc(bytes);
+    if (dst.cap < bytes || !dst.p || (pinned && !dst.p.get_deleter().pinned)) ++n_fresh_;
+    dst.alloc(bytes, pinned);
   }
+  // per-call state of the GPU inflate (stream, device buffers), one per concurrent loader
+  struct GpuObj { void* h = nullptr; void* d_out = nullptr; size_t d_cap = 0; };
+  GpuInflateApi gpu_;
+  int gpu_device_ = 0, gpu_percent_ = 100;
+  std::mutex gpu_m_;
+  std::vector<GpuObj> gpu_objs_;
+  std::atomic<long long> t_gpu_{0}, t_crc_{0}, n_gpu_chunks_{0};
+  std::atomic<int> cpu_inflight_{0};   // chunks with the host pool right now
+  GpuObj take_gpu_obj() {
+    std::lock_guard<std::mutex> lk(gpu_m_);
+    if (gpu_objs_.empty()) return GpuObj();
+    GpuObj g = gpu_objs_.back();
+    gpu_objs_.pop_back();
+    return g;
+  }
+  void put_gpu_obj(const GpuObj& g) { std::lock_guard<std::mutex> lk(gpu_m_); gpu_objs_.push_back(g); }
   std::atomic<long long> t_scan_{0}, t_buf_{0}, t_inf_{0}, n_fresh_{0};   // SVDSS_DEBUG: nanoseconds per stage
   double t_wait_ = 0;
   std::unique_ptr<InflatePool> pool_;

@@ -646,7 +646,7 @@ int main_call(const CallOptions& o) {
     if (cache_ok) {
       stage("pass 2: setup");
       const size_t n = cache_views.size();
-      const size_t W = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, n / 4096 + 1}));
+      const size_t W = std::max<size_t>(1, std::min<size_t>({(size_t)effective_cpus(), (size_t)32, n / 4096 + 1}));
       std::vector<std::vector<Ev>> evs(W);
       auto range = [&](size_t w) {
         std::string nm;

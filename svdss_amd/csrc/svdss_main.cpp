@@ -316,6 +316,23 @@ int main_search(const Options& o) {
   FastxReader* fx = nullptr;
   if (bam_mode) {
     bam = new BamReader(o.bam, o.io_threads);
+    // BGZF blocks are inflated on the GPU (csrc/inflate.hip).  SVDSS_GPU_INFLATE: 0 = host workers only; 1..99 = that
+    // share of the chunks goes to the GPU; 100 (default) = the GPU takes whatever the host workers cannot start at once
+    const int gpu_pct = getenv("SVDSS_GPU_INFLATE") ? atoi(getenv("SVDSS_GPU_INFLATE")) : 100;
+    if (gpu_pct > 0) {
+      BamReader::GpuInflateApi api;
+      api.inflate = [](void** obj, int device, const uint8_t* comp, int64_t comp_bytes, const void* blocks, int64_t n_blocks,
+                       void* d_out, uint8_t* host_out, int64_t out_bytes, int64_t* bad) {
+        return svdss_bgzf_inflate((svdss_inflate_t**)obj, device, comp, comp_bytes, (const svdss_bgzf_block_t*)blocks, n_blocks,
+                                  d_out, host_out, out_bytes, bad);
+      };
+      api.inflate_free = [](void* obj) { svdss_inflate_free((svdss_inflate_t*)obj); };
+      api.device_alloc = svdss_device_alloc;
+      api.device_free = svdss_device_free;
+      api.host_alloc = svdss_host_alloc;
+      api.host_free = svdss_host_free;
+      bam->enable_gpu_inflate(api, 0, gpu_pct);
+    }
     if (!bam->ok() || !bam->read_header()) die("cannot read " + o.bam + ": " + bam->error());
   } else {
     logmsg("warning", "FASTX mode is not optimized (higher running times and larger SFSs set).");
@@ -362,7 +379,7 @@ int main_search(const Options& o) {
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
   // (threads of the small per-batch loops -- tag decoding, the copy of the packed bases; --io-threads sizes the inflate pool)
-  const int n_workers = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  const int n_workers = (int)std::max(1u, std::min(16u, effective_cpus()));
   // items [0, n) over the worker threads, contiguous slices
   auto parallel_for = [&](size_t n, const std::function<void(size_t, size_t)>& body) {
     const size_t nt = std::min<size_t>((size_t)n_workers, std::max<size_t>(1, n / 64));
@@ -432,8 +449,17 @@ int main_search(const Options& o) {
           bt->lseq[k] = l;
           bt->boff.push_back(bt->boff.back() + ((int64_t)l + 1) / 2);
         }
-        bt->recs.swap(recs);
-        bt->keep.swap(keep_chunks);
+        // the packed bases of the batch, back to back in page-locked memory; the inflated chunks go back to the reader
+        // at once (they are page-locked too when the GPU inflates: few should be in flight)
+        if (!bt->gidx.empty()) {
+          bt->seq4 = pinned.get((size_t)bt->boff.back() + 16, bt->seq4_cap);
+          parallel_for(bt->gidx.size(), [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k)
+              memcpy(bt->seq4 + bt->boff[k], recs[bt->gidx[k]].seq4(), (size_t)(bt->boff[k + 1] - bt->boff[k]));
+          });
+        }
+        recs.clear();
+        keep_chunks.clear();
         t_decode += secs(ts1, now());
       } else {
         while ((int64_t)bt->reads.size() < super) {
@@ -522,16 +548,6 @@ int main_search(const Options& o) {
       if (!bt->gidx.empty()) {
         std::vector<int64_t>& counts = bt->counts;
         counts.assign(bt->gidx.size(), 0);
-        if (bam_mode) {
-          // the packed bases of the batch, back to back in page-locked memory
-          bt->seq4 = pinned.get((size_t)bt->boff.back() + 16, bt->seq4_cap);
-          parallel_for(bt->gidx.size(), [&](size_t lo, size_t hi) {
-            for (size_t k = lo; k < hi; ++k)
-              memcpy(bt->seq4 + bt->boff[k], bt->recs[bt->gidx[k]].seq4(), (size_t)(bt->boff[k + 1] - bt->boff[k]));
-          });
-          bt->recs.clear();
-          bt->keep.clear();
-        }
         if (bam_mode)
           check(svdss_sfs_search_batch_bam(ix, bt->seq4, bt->boff.data(), bt->lseq.data(), (int64_t)bt->gidx.size(),
                                            o.assemble ? SVDSS_SFS_ASSEMBLE : 0, &res), "svdss_sfs_search_batch_bam");

@@ -2,12 +2,12 @@
 export PYTHONPATH=.
 export SVDSS_DEBUG=1
 E2E_REPEAT=${E2E_REPEAT:-6} timeout 1200 python tools/e2e_search.py 64444167 172000 15000 /tmp/e2e --verbose 2>&1 | grep -v amdgpu.ids | grep "^{" 
-cat /sys/kernel/mm/transparent_hugepage/enabled
 run() {
   echo "== $*"
-  env "$@" ./svdss_amd/SVDSS search --index /tmp/e2e/ref.fmd --bam /tmp/e2e/reads.bam --noputative --verbose 2>&1 >/dev/null | grep "bam_reader\|stage busy\|records read\|device at"
+  env "$@" ./svdss_amd/SVDSS search --index /tmp/e2e/ref.fmd --bam /tmp/e2e/reads.bam --noputative --verbose 2>&1 >/tmp/e2e/out_$N.sfs | grep "bam_reader\|stage busy\|records read\|device at\|rror"
+  md5sum /tmp/e2e/out_$N.sfs | cut -c1-12
 }
-run SVDSS_SEARCH_FEEDERS=3
-run SVDSS_SEARCH_FEEDERS=6
-run SVDSS_SEARCH_FEEDERS=6 SVDSS_BAM_AHEAD=32
-run SVDSS_SEARCH_FEEDERS=6 SVDSS_BAM_MMAP=1
+N=0 run SVDSS_GPU_INFLATE=0
+N=1 run SVDSS_GPU_INFLATE=100
+N=2 run SVDSS_GPU_INFLATE=100 SVDSS_SEARCH_FEEDERS=3
+N=3 run SVDSS_GPU_INFLATE=75
