@@ -260,7 +260,7 @@ class BamReader {
     void (*host_free)(void* p) = nullptr;
   };
   void enable_gpu_inflate(const GpuInflateApi& api, int device, int percent) {
-    gpu_ = api; gpu_device_ = device; gpu_percent_ = std::max(0, std::min(100, percent));
+    gpu_ = api; gpu_device_ = device; gpu_percent_ = std::max(0, std::min(101, percent));   // (101: every chunk)
     pin_hooks().alloc = api.host_alloc; pin_hooks().free_ = api.host_free;
   }
   const std::string& error() const { return err_; }
@@ -749,7 +749,8 @@ class BamReader {
     // idle (fewer than two chunks in its queue), everything else goes to the GPU; a smaller percent fixes the share
     bool on_gpu = gpu_.inflate && pread_size_ && !blocks.empty();
     if (on_gpu) {
-      if (gpu_percent_ >= 100) {
+      if (gpu_percent_ > 100) {
+      } else if (gpu_percent_ == 100) {
         if (cpu_inflight_.fetch_add(1) < 2) on_gpu = false; else cpu_inflight_.fetch_sub(1);
       } else {
         on_gpu = (ticket + 1) * (uint64_t)gpu_percent_ / 100 != ticket * (uint64_t)gpu_percent_ / 100;

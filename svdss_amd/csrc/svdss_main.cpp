@@ -317,7 +317,8 @@ int main_search(const Options& o) {
   if (bam_mode) {
     bam = new BamReader(o.bam, o.io_threads);
     // BGZF blocks are inflated on the GPU (csrc/inflate.hip).  SVDSS_GPU_INFLATE: 0 = host workers only; 1..99 = that
-    // share of the chunks goes to the GPU; 100 (default) = the GPU takes whatever the host workers cannot start at once
+    // share of the chunks goes to the GPU; 100 (default) = the GPU takes whatever the host workers cannot start at once;
+    // 101 = every chunk
     const int gpu_pct = getenv("SVDSS_GPU_INFLATE") ? atoi(getenv("SVDSS_GPU_INFLATE")) : 100;
     if (gpu_pct > 0) {
       BamReader::GpuInflateApi api;

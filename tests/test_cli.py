@@ -171,3 +171,43 @@ def test_index_writes_an_rld0_fmd_and_the_own_layout_beside_it(tmp_path):
     os.remove(tmp_path / "ref.fa.fmd.svdss")
     back = svdss_amd.FMDIndex.load(str(fmd))                                       # through the rld0 import
     assert back.size == want.size and (back.acc == want.acc).all()
+
+
+@pytest.mark.gpu
+def test_search_bam_inflated_on_the_gpu_or_the_host_same_bytes(tmp_path):
+    """BGZF blocks inflated by csrc/inflate.hip (default), by the host workers, or half / half: the same text; a block
+    whose content does not match its CRC32 footer ends the run with exit code 1 on every path."""
+    import struct
+    import zlib
+    ref, hap, svs, flat, offs = small_workload(seed=83, n_reads=400, read_len=3000, ref_lens=(120000,))
+    ix = svdss_amd.FMDIndex.build(ref)
+    fmd = tmp_path / "ref.fmd"
+    ix.save(str(fmd))
+    rng = np.random.default_rng(4)
+    recs = []
+    for i in range(400):
+        rd = flat[offs[i]:offs[i + 1]]
+        qual = bytes(rng.integers(20, 60, size=len(rd), dtype=np.uint8).tolist())
+        recs.append(bam_writer.record(f"r{i:04d}", 0, 0, 100 + i, 60, [("M", len(rd))], synth.to_ascii(rd), [("HP", "C", i % 3)], qual=qual))
+    bam = tmp_path / "reads.bam"
+    data = bam_writer.bam([("chr1", 120000)], recs)
+    bam.write_bytes(data)
+    assert len(data) > 300000          # several BGZF blocks, records straddling them
+    outs = {}
+    for mode in ("101", "0", "50", "100"):     # every chunk on the GPU / none / every other one / the default
+        r = run("search", "--index", str(fmd), "--bam", str(bam), "--noputative", "--threads", "4", "--bsize", "64", "--verbose",
+                env=dict(os.environ, SVDSS_GPU_INFLATE=mode, SVDSS_DEBUG="1"))
+        assert r.returncode == 0, r.stderr
+        outs[mode] = r.stdout
+        if mode in ("101", "0"):
+            assert ("inflated on the GPU" in r.stderr) == (mode == "101"), r.stderr
+    assert outs["101"] == outs["0"] == outs["50"] == outs["100"] and outs["0"].count("\n") > 400
+    # flip one bit in the middle of the second block's deflate stream
+    bad = bytearray(data)
+    first = struct.unpack_from("<H", data, 16)[0] + 1
+    second = struct.unpack_from("<H", data, first + 16)[0] + 1
+    bad[first + 18 + (second - 26) // 2] ^= 0x10
+    (tmp_path / "bad.bam").write_bytes(bytes(bad))
+    for mode in ("101", "0"):
+        r = run("search", "--index", str(fmd), "--bam", str(tmp_path / "bad.bam"), "--noputative", env=dict(os.environ, SVDSS_GPU_INFLATE=mode))
+        assert r.returncode == 1 and ("CRC" in r.stderr or "inflate" in r.stderr), (mode, r.stderr[-300:])
