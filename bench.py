@@ -239,6 +239,8 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (also skips verification)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the SVDSS binary on a BAM file")
+    ap.add_argument("--e2e-reads", type=int, default=516000, help="reads in the BAM of the end-to-end run")
     ap.add_argument("--no-call-dp", action="store_true", help="search only (value is then NOT the headline metric)")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: leave the SFS on the ranks")
     ap.add_argument("--call-threads", type=int, default=3,
@@ -499,6 +501,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["verified_reads"] = cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads,
                                                                                args.cpu_seconds)
+        if world == 1 and not args.no_e2e:
+            out.update(e2e_search_rate(args.e2e_reads))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -572,13 +576,71 @@ def random_probe():
         return None
 
 
+def cpu_quota():
+    """processors this container may use: visible hardware threads capped by the cgroup's CPU quota"""
+    n = os.cpu_count() or 1
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def e2e_search_rate(n_reads):
+    """`SVDSS search` as a user of run_svdss sees it (file- and PCIe-inclusive, never `value`): a synthetic BAM of 15 kb
+    reads against a chr20-length index, through the binary -- BGZF inflate (GPU + host workers), record parsing, 4-bit
+    upload, search, text output to /dev/null.  e2e_reads_per_s = reads / (end of output - index resident), i.e. the
+    streaming rate a 30x sample (6.2 M reads) approaches; the whole-process figure is beside it."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from tools import e2e_search as E
+    work = tempfile.mkdtemp(prefix="svdss_bench_e2e_", dir="/tmp")
+    try:
+        rng = np.random.default_rng(1)
+        ref_bp, unit = 64444167, 86000
+        repeat = max(1, round(n_reads / unit))
+        ref = rng.integers(0, 4, size=ref_bp, dtype=np.uint8)
+        fa = os.path.join(work, "ref.fa")
+        with open(fa, "wb") as f:
+            f.write(b">chrS\n")
+            f.write(np.frombuffer(b"ACGT", dtype=np.uint8)[ref].tobytes())
+            f.write(b"\n")
+        bam = os.path.join(work, "reads.bam")
+        raw = E.write_bam(bam, "chrS", ref, unit, 15000, repeat=repeat)
+        exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "svdss_amd", "SVDSS")
+        subprocess.run([exe, "index", "-d", fa, "-o", os.path.join(work, "ref.fmd")], check=True, capture_output=True)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "search", "--index", os.path.join(work, "ref.fmd"), "--bam", bam, "--noputative", "--verbose"],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, check=True,
+                           env=dict(os.environ, SVDSS_DEBUG="1"))
+        wall = time.perf_counter() - t0
+        t_ix = float(re.search(r"on the device at \+([0-9.]+) s", r.stderr).group(1))
+        m = re.search(r"(\d+) records read, (\d+) SFS written at \+([0-9.]+) s", r.stderr)
+        n, n_sfs, t_end = int(m.group(1)), int(m.group(2)), float(m.group(3))
+        g = re.search(r"(\d+) chunks inflated on the GPU", r.stderr)
+        c = re.search(r"\] (\d+) chunks: locate", r.stderr)
+        return {"e2e_reads_per_s": n / max(t_end - t_ix, 1e-9),
+                "e2e": {"what": "SVDSS search --bam (binary): synthetic BAM, %d x 15 kb reads, %.1f GB file (%.1f GB inflated), "
+                                "chr20-length index, text to /dev/null" % (n, os.path.getsize(bam) / 1e9, raw / 1e9),
+                        "reads": n, "sfs": n_sfs, "streaming_s": round(t_end - t_ix, 3), "index_restore_s": round(t_ix, 3),
+                        "whole_process_s": round(wall, 3), "whole_process_reads_per_s": n / wall,
+                        "bgzf_chunks": int(c.group(1)) if c else None, "bgzf_chunks_inflated_on_gpu": int(g.group(1)) if g else 0,
+                        "host_cpu_quota_cores": cpu_quota()}}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads, target_s):
     """The oracle (CPU restatement of ping_pong.cpp:4-49 + assembler.cpp:34-56, OpenMP over reads like
     ping_pong.cpp:329) timed on this box's cores on a bounded sample of the same reads -- and, since it computes the
     SFS of those reads anyway, the checker of the GPU's results for them (counts, starts, lengths, extension counts)."""
     from tests import oracle_lib as O
     fm = O.OracleFMD.from_bwt(ix.bwt())
-    threads = O.max_threads()
+    threads = min(O.max_threads(), cpu_quota())     # (more threads than the container's CPU quota only add contention)
 
     def run(k):
         flat = d_reads[:k * L].cpu().numpy()

@@ -151,6 +151,9 @@ __device__ __forceinline__ int wave_scan_max_self(int x) { return wave_scan_max(
 // a chain row: one predecessor, the previous row, and no copy kept in HBM
 #define RI_CHAIN_MASK ((3u << 3) | (31u << 5) | RI_KEEP)
 #define RI_CHAIN_VAL ((1u << 3) | (1u << 5))
+// one predecessor (any row), no copy kept in HBM
+#define RI_ONE_MASK ((3u << 3) | RI_KEEP)
+#define RI_ONE_VAL (1u << 3)
 
 struct ArrI {
   int32_t* W; uint32_t o;
@@ -351,14 +354,24 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
         // moves with the band (a band that starts one column further reads its right neighbour's values through one
         // DPP shift); a row goes to the LDS ring only if a row other than the next one reads it (RI_RING), or when
         // the chain ends.  Same arithmetic and tie rules as the general code below for np == 1.
-        if (CHAIN && 64 * C <= WS && r > 0 && last_r == r - 1 && (ri & RI_CHAIN_MASK) == RI_CHAIN_VAL) {
+        if (CHAIN && 64 * C <= WS && r > 0 && (ri & RI_ONE_MASK) == RI_ONE_VAL && (int)((ri >> 5) & 31u) < RING &&
+            ((ri >> 5) & 31u) >= 1u && (((ri >> 5) & 31u) != 1u || last_r == r - 1)) {
 #ifdef POA_COUNT_ROWS
           const unsigned long long chain_t0 = wall_clock64();
 #endif
-          int pbeg = last_beg, pend = last_end;
+          int pbeg = 0, pend = 0, pm_l = 0, pm_r = 0;   // band and maximum columns of the row in the registers
           int32_t pH[C], pE1[C], pE2[C];
-          {
-            const int so = ((r - 1) & rm) * RST + G;
+          bool in_ring = true;
+          // read symbols: qc = q[j - 1] of this row's columns, qx = q[j] (what the next row needs if its band starts
+          // one column further; fetched a row ahead)
+          int qc[C], qx[C];
+          // the row ur of the ring becomes the row in the registers (a chain starts, or goes on from an earlier row:
+          // a row whose one predecessor is not the previous row)
+          auto load_pred = [&](int ur) {
+            const int sl = ur & rm;
+            if (ur == last_r) { pbeg = last_beg; pend = last_end; pm_l = last_mpl; pm_r = last_mpr; }
+            else { pbeg = UNI(rbeg[sl]); pend = UNI(rend[sl]); pm_l = UNI(rmpl[sl]); pm_r = UNI(rmpr[sl]); }
+            const int so = sl * RST + G;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
               const int idx = lane * C + c;
@@ -367,16 +380,12 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               const int32_t x0 = rH[a], x1 = rE1[a], x2 = rE2[a];
               pH[c] = ok ? x0 : PNEG; pE1[c] = ok ? x1 : PNEG; pE2[c] = ok ? x2 : PNEG;
             }
-          }
-          bool in_ring = true;
-          // read symbols: qc = q[j - 1] of this row's columns, qx = q[j] (what the next row needs if its band starts
-          // one column further; fetched a row ahead)
-          int qc[C], qx[C];
-          {
             const int jb = pbeg + lane * C;
 #pragma unroll
             for (int c = 0; c < C; ++c) { qc[c] = q[imin(jb + c, L) - 1]; qx[c] = q[imin(jb + c, L - 1)]; }
-          }
+            in_ring = true;
+          };
+          load_pred(r - (int)((ri >> 5) & 31u));
           auto ring_store = [&](int rr_, int b_, int e_, const int32_t* h_, const int32_t* e1_, const int32_t* e2_, int l_, int r_) {
             const int sl = rr_ & rm, sb_ = sl * RST + G;
 #pragma unroll
@@ -392,8 +401,8 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             if (lane == 0) { rbeg[sl] = b_; rend[sl] = e_; rmpl[sl] = l_; rmpr[sl] = r_; }
           };
           for (;;) {
-            int beg = last_mpl + 1 - w; if (beg < 0) beg = 0;
-            int end = last_mpr + 1 + w; if (end > L) end = L;
+            int beg = pm_l + 1 - w; if (beg < 0) beg = 0;
+            int end = pm_r + 1 + w; if (end > L) end = L;
             if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
             const int width = end - beg + 1;
             const int delta = beg - pbeg;
@@ -481,7 +490,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             l += beg; rr += beg;
             if (wmx <= PNEG / 2) { l = beg; rr = end; }
             last_r = r; last_mpl = UNI(l); last_mpr = UNI(rr); last_beg = beg; last_end = end;
-            pbeg = beg; pend = end;
+            pbeg = beg; pend = end; pm_l = last_mpl; pm_r = last_mpr;
             in_ring = (ri & RI_RING) != 0;
             if (in_ring) ring_store(r, beg, end, pH, pE1, pE2, l, rr);
             ++r;
@@ -492,7 +501,15 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               asm volatile("" : "+v"(ri_blk));
             }
             ri = __builtin_amdgcn_readlane(ri_blk, r - blk0);
-            if ((ri & RI_CHAIN_MASK) != RI_CHAIN_VAL) break;
+            if ((ri & RI_ONE_MASK) != RI_ONE_VAL) break;
+            const int dn = (int)((ri >> 5) & 31u);
+            if (dn != 1) {
+              // the one predecessor of the next row is an earlier row of the ring: the row just computed stays behind
+              // (it is in the ring if any later row reads it), that one comes into the registers
+              if (dn < 1 || dn >= RING) break;
+              ROWCNT(9);
+              load_pred(r - dn);
+            }
           }
           if (!in_ring) ring_store(r - 1, pbeg, pend, pH, pE1, pE2, last_mpl, last_mpr);
 #ifdef POA_COUNT_ROWS
