@@ -885,6 +885,20 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               asm volatile("" : "+v"(W0), "+v"(W1), "+v"(W2), "+v"(W3), "+v"(P0), "+v"(P1));
             }
             const uint32_t wsel = d == 0 ? W0 : d == 1 ? W1 : d == 2 ? W2 : W3;
+            if (st == 0) {
+              // a run of plain diagonal steps -- a match through predecessor slot 0, which is the row above -- all at
+              // once: the cells of the window's current diagonal that are such steps form a ballot, the run is its
+              // ones from lane k on, and lane i stores the i-th operation of the run (most of an alignment is this)
+              const bool diag = (wsel & 15u) == 0u && (P0 & 255u) == 1u && r0 - lane >= 1;
+              const unsigned long long dm = __ballot(diag) >> k;
+              int run = dm == ~0ull ? 64 : (int)__builtin_ctzll(~dm);
+              if (run > j) run = j;
+              if (run > 0) {
+                if (lane < run) { op_node[nops + lane] = r - lane; op_q[nops + lane] = j - 1 - lane; }
+                nops += run; r -= run; j -= run;
+                continue;
+              }
+            }
             const uint32_t dw = __builtin_amdgcn_readlane(wsel, k);
             const uint32_t p0 = __builtin_amdgcn_readlane(P0, k), p1 = __builtin_amdgcn_readlane(P1, k);
             int s = -1;   // predecessor slot to follow
