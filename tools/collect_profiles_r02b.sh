@@ -24,7 +24,7 @@ rows = []
 for f in sorted(glob.glob("$1*/**/*counter_collection.csv", recursive=True)):
     acc, n = {}, {}
     for row in csv.DictReader(open(f)):
-        k = (row["Kernel_Name"].split("(")[0][:70], row["Counter_Name"])
+        k = (row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:70], row["Counter_Name"])
         acc[k] = acc.get(k, 0.0) + float(row["Counter_Value"]); n[k] = n.get(k, 0) + 1
     for (kern, ctr), v in sorted(acc.items()):
         if re.search("$2", kern):
