@@ -649,7 +649,7 @@ def cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads, target_s):
         res = fm.search_batch(flat, offs, True, threads)
         return time.perf_counter() - t0, res
 
-    k = min(n_reads, 4 * threads)
+    k = min(n_reads, max(4 * threads, 512))     # (a first sample large enough to predict the second one)
     t, _ = run(k)
     k2 = int(min(n_reads, max(k, k * target_s / max(t, 1e-3))))
     t2, (c, q, l, e) = run(k2)

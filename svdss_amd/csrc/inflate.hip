@@ -56,6 +56,21 @@ __device__ unsigned long long g_inf_cnt[8];   // rounds, literals, matches, one-
 // status codes (per block)
 enum { ST_OK = 0, ST_BTYPE = 1, ST_STORED = 2, ST_LENS = 3, ST_CODE = 4, ST_DIST = 5, ST_OUT = 6, ST_IN = 7, ST_SIZE = 8 };
 
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+template <int CTRL, int RMASK>
+__device__ __forceinline__ int dpp_add(int x) { return x + __builtin_amdgcn_update_dpp(0, x, CTRL, RMASK, 0xf, false); }
+// inclusive sum over the 64 lanes: four row_shr steps, then row_bcast15 / row_bcast31
+__device__ __forceinline__ int wave_scan_add(int x) {
+  x = dpp_add<0x111, 0xf>(x);
+  x = dpp_add<0x112, 0xf>(x);
+  x = dpp_add<0x114, 0xf>(x);
+  x = dpp_add<0x118, 0xf>(x);
+  x = dpp_add<0x142, 0xa>(x);
+  x = dpp_add<0x143, 0xc>(x);
+  return x;
+}
+
 // Canonical Huffman code of n symbols with lengths lens[0..n): table of 2^tb 16-bit entries (symbol << 4 | length, 0 =
 // a longer code or none), per-length counts and the symbols sorted by (length, symbol) for the bit-by-bit decoder.
 // Returns false if the lengths over-subscribe the code space.
@@ -297,69 +312,94 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
       for (;;) {
         if ((P >> 3) - base >= 1024 + 32) { load_half(base + INB); base += 1024; }
         CNT(0, 1);
+        // ---- every lane decodes the symbol that would start at its bit offset, whole: a literal, or a match with its
+        // extra bits and its distance (all inside the 64 bits that start there), or the end-of-block code -- and where
+        // the next symbol starts
         const uint32_t pl = (uint32_t)P + (uint32_t)lane;   // (the ring is indexed modulo 2^14 bits)
         const uint32_t di = pl >> 5;
-        const uint32_t w0 = L.inb[di & (INB / 4 - 1)], w1 = L.inb[(di + 1) & (INB / 4 - 1)];
-        const uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, pl & 31u);
-        const uint32_t E = (uint32_t)L.lit[bits & ((1u << LB) - 1)], D = (uint32_t)L.dst[bits & ((1u << DB) - 1)];
+        const uint32_t w0 = L.inb[di & (INB / 4 - 1)], w1 = L.inb[(di + 1) & (INB / 4 - 1)], w2 = L.inb[(di + 2) & (INB / 4 - 1)];
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, pl & 31u), hi = __builtin_amdgcn_alignbit(w2, w1, pl & 31u);
+        const uint64_t b64 = ((uint64_t)hi << 32) | lo;
+        const uint32_t E = (uint32_t)L.lit[lo & ((1u << LB) - 1)];
+        const uint32_t len = E & 15u, sym = (E & 0x7fffu) >> 4;
+        const bool is_lit = (E & 0x8000u) != 0;
+        const uint32_t ls = umin(sym - 257u, 28u);   // (lanes that hold no length code compute on a harmless value)
+        const uint32_t lx = ls < 8 || ls == 28 ? 0 : (ls >> 2) - 1;
+        const uint32_t lb = ls < 8 ? 3u + ls : ls == 28 ? 258u : 3u + ((4u + (ls & 3u)) << lx);
+        const uint32_t mlen = lb + ((lo >> len) & ((1u << lx) - 1));
+        const uint32_t doff = len + lx;
+        const uint32_t D = (uint32_t)L.dst[(uint32_t)(b64 >> doff) & ((1u << DB) - 1)];
+        const uint32_t dl = D & 15u, ds = umin(D >> 4, 29u);
+        const uint32_t dx = ds < 4 ? 0 : (ds >> 1) - 1;
+        const uint32_t db = ds < 4 ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx);
+        const uint32_t eoff = doff + dl;
+        const uint32_t dist = db + ((uint32_t)(b64 >> eoff) & ((1u << dx) - 1));
+        // kind: 0 literal, 1 match, 2 end of block, 3 = a code longer than the table's index bits or an invalid one (the
+        // one-symbol path decodes it, or reports it)
+        const bool is_match = !is_lit && sym >= 257u;
+        uint32_t kind = is_lit ? 0u : sym == 256u ? 2u : 1u;
+        if (len == 0 || (is_match && (sym > 285u || dl == 0 || (D >> 4) > 29u))) kind = 3u;
+        const uint32_t nbits = kind == 1u ? eoff + dx : len;
+        const uint32_t outlen = kind == 0u ? 1u : kind == 1u ? mlen : 0u;
+        const uint32_t NX = ((uint32_t)lane + nbits) | (kind << 8);
+        // ---- the scalar unit follows the chain of symbol starts from offset 0
         uint32_t off = 0;
-        unsigned long long chain = 0;   // the offsets at which the literals not yet stored start
+        unsigned long long chain = 0;
         bool slow = false;
         while (off < 64) {
-          const uint32_t e = __builtin_amdgcn_readlane(E, off);
-          if (e & 0x8000u) { chain |= 1ull << off; off += e & 15u; continue; }
-          const uint32_t len = e & 15u;
-          if (len == 0) { slow = true; break; }
-          const uint32_t sym = e >> 4;
-          if (sym == 256) { off += len; eob = true; break; }
-          if (sym > 285) { err = ST_CODE; break; }
-          // (base and extra bits of the length / distance codes in closed form: a table in memory is a trip to L2 per
-          // match for the scalar unit)
-          const uint32_t ls = sym - 257;
-          const uint32_t lx = ls < 8 || ls == 28 ? 0 : (ls >> 2) - 1;
-          const uint32_t lb = ls < 8 ? 3u + ls : ls == 28 ? 258u : 3u + ((4u + (ls & 3u)) << lx);
-          const uint32_t o2 = off + len, o3 = o2 + lx;
-          if (o3 > 63) break;   // (the rest of this match is beyond the round: it starts the next one)
-          const uint32_t mlen = lb + (__builtin_amdgcn_readlane(bits, o2 & 63) & ((1u << lx) - 1));
-          const uint32_t d = __builtin_amdgcn_readlane(D, o3);
-          const uint32_t dl = d & 15u, ds = d >> 4;
-          if (dl == 0) { slow = true; break; }
-          if (ds > 29) { err = ST_DIST; break; }
-          const uint32_t dx = ds < 4 ? 0 : (ds >> 1) - 1;
-          const uint32_t db = ds < 4 ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx);
-          const uint32_t o4 = o3 + dl;
-          if (dx && o4 > 63) break;
-          const uint32_t dist = db + (__builtin_amdgcn_readlane(bits, o4 & 63) & ((1u << dx) - 1));
-          if (chain) {
-            if ((chain >> lane) & 1ull) winb[(wpos + (uint32_t)__popcll(chain & lt_mask)) & WM] = (uint8_t)(E >> 4);
-            wpos += (uint32_t)__popcll(chain);
-            chain = 0;
+          const uint32_t nx = __builtin_amdgcn_readlane(NX, off);
+          if (nx >= (3u << 8)) { slow = true; break; }
+          chain |= 1ull << off;
+          off = nx & 255u;
+          if (nx >= (2u << 8)) { eob = true; break; }
+        }
+        // ---- where every symbol of the chain puts its output: a scan over the chain's lanes
+        bool onc = ((chain >> lane) & 1ull) != 0;
+        uint32_t x = onc ? outlen : 0u;
+        uint32_t incl = (uint32_t)wave_scan_add((int)x);
+        uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        // (the literals are stored ahead of the matches that precede them: a match whose source lies within
+        // `total - its offset` of the ring's far end would see its source overwritten -- cut the round at that match)
+        {
+          const unsigned long long hz = __ballot(onc && kind == 1u && dist > (uint32_t)WIN - (total - (incl - x)));
+          if (hz) {
+            const int h = (int)__builtin_ctzll(hz);
+            chain &= (2ull << h) - 1;
+            off = __builtin_amdgcn_readlane(NX, h) & 255u;
+            eob = false;
+            onc = ((chain >> lane) & 1ull) != 0;
+            x = onc ? outlen : 0u;
+            incl = (uint32_t)wave_scan_add((int)x);
+            total = __builtin_amdgcn_readlane(incl, 63);
           }
+        }
+        const uint32_t opos = wpos + (incl - x);
+        if (wpos + total > isize) { err = ST_OUT; break; }
+        if (__ballot(onc && kind == 1u && dist > opos)) { err = ST_DIST; break; }
+        if (onc && kind == 0u) winb[opos & WM] = (uint8_t)sym;
+        // ---- the matches, in order
+        unsigned long long mm = __ballot(onc && kind == 1u);
+        while (mm) {
+          const int h = (int)__builtin_ctzll(mm);
+          mm &= mm - 1;
           CNT(2, 1);
-          if (dist > wpos) { err = ST_DIST; break; }
-          if (wpos + mlen > isize) { err = ST_OUT; break; }
-          const uint32_t from = wpos - dist;
-          if (dist >= mlen) {
-            if ((uint32_t)lane < mlen) winb[(wpos + (uint32_t)lane) & WM] = winb[(from + (uint32_t)lane) & WM];
-            if (mlen > 64)
-              for (uint32_t k = 64 + lane; k < mlen; k += 64) winb[(wpos + k) & WM] = winb[(from + k) & WM];
+          const uint32_t o = __builtin_amdgcn_readlane(opos, h), ml = __builtin_amdgcn_readlane(mlen, h), dd = __builtin_amdgcn_readlane(dist, h);
+          const uint32_t from = o - dd;
+          if (dd >= ml) {
+            if ((uint32_t)lane < ml) winb[(o + (uint32_t)lane) & WM] = winb[(from + (uint32_t)lane) & WM];
+            if (ml > 64)
+              for (uint32_t k = 64 + lane; k < ml; k += 64) winb[(o + k) & WM] = winb[(from + k) & WM];
           } else {
             // the match overlaps its own output: byte k repeats byte k mod dist of the dist bytes before it
             uint8_t v[5];
             int nk = 0;
-            for (uint32_t k = lane; k < mlen; k += 64) v[nk++] = winb[(from + k % dist) & WM];
+            for (uint32_t k = lane; k < ml; k += 64) v[nk++] = winb[(from + k % dd) & WM];
             nk = 0;
-            for (uint32_t k = lane; k < mlen; k += 64) winb[(wpos + k) & WM] = v[nk++];
+            for (uint32_t k = lane; k < ml; k += 64) winb[(o + k) & WM] = v[nk++];
           }
-          wpos += mlen;
-          off = o4 + dx;
         }
-        if (chain) {
-          if ((chain >> lane) & 1ull) winb[(wpos + (uint32_t)__popcll(chain & lt_mask)) & WM] = (uint8_t)(E >> 4);
-          wpos += (uint32_t)__popcll(chain);
-        }
+        wpos += total;
         P += (uint64_t)off;
-        if (wpos > isize) err = ST_OUT;
         if ((P >> 3) > in_end + 16) err = ST_IN;
         if (err || eob) break;
         if (wpos - flushed >= (uint32_t)FLUSH) flush(false);

@@ -3,22 +3,17 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export PYTHONPATH=$R
 O=$R/gpurun_out/r02b/pmc_inf
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 i=0
-for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU"; do
+for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "bgzf_inflate" --output-format csv -d $O/p$i -- python $R/tools/inflate_probe.py 1024 1 bam > $O/log_$i.txt 2>&1
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "bgzf_inflate" --output-format csv -d $O/p$i -- python $R/tools/inflate_probe.py ${NB:-1024} 1 bam > $O/log_$i.txt 2>&1
   f=$(find $O/p$i -name "*counter_collection.csv" | head -1)
-  echo "== $c"
   python3 - "$f" <<'PY'
 import csv, sys, collections
-acc = collections.defaultdict(float); n = collections.defaultdict(int)
-try:
-    for r in csv.DictReader(open(sys.argv[1])):
-        acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-    disp = max(n.values()) if n else 1
-    for k in acc: print(f"  {k}: {acc[k] / 8:.4g} per dispatch (8 dispatches)")
-except Exception as e:
-    print("  (no data)", e)
+acc = collections.defaultdict(float)
+for r in csv.DictReader(open(sys.argv[1])):
+    acc[r["Counter_Name"]] += float(r["Counter_Value"])
+for k in acc: print(f"  {k}: {acc[k] / 8:.4g} per dispatch")
 PY
 done
