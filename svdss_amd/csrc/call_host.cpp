@@ -25,6 +25,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
+#include "gpu_inflate_hook.h"
 #include "call_host.h"
 #include "fastx_reader.h"
 
@@ -375,6 +376,7 @@ int main_call(const CallOptions& o) {
   }
   {
     BamReader bam(o.bam);
+    svdss_enable_gpu_inflate(bam);
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
     ref_names = bam.ref_names();
     const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
@@ -665,6 +667,7 @@ int main_call(const CallOptions& o) {
       cache_release = std::thread([v = std::move(cache_views), c = std::move(cache_chunks)]() mutable { v.clear(); c.clear(); });
     } else {
       BamReader bam(o.bam);
+      svdss_enable_gpu_inflate(bam);
       if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
       BamReader::RawView rr;   // zero-copy: the record is used where it was inflated, within this iteration only
       int rc;

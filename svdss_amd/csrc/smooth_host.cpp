@@ -15,6 +15,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
+#include "gpu_inflate_hook.h"
 #include "bam_writer.h"
 #include "call_host.h"
 #include "fastx_reader.h"
@@ -145,6 +146,7 @@ int main_smooth(const CallOptions& o) {
   double al_accuracy;
   {
     BamReader bam(o.bam);
+    svdss_enable_gpu_inflate(bam);
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
     std::vector<double> acc;
     BamRecord r;
@@ -163,6 +165,7 @@ int main_smooth(const CallOptions& o) {
     }
   }
   BamReader bam(o.bam);
+  svdss_enable_gpu_inflate(bam);
   if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
   const int T = std::max(1, o.threads);
   BgzfWriter w(stdout, T);

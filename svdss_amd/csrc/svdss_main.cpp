@@ -29,6 +29,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
+#include "gpu_inflate_hook.h"
 #include "call_host.h"
 #include "fastx_reader.h"
 
@@ -316,24 +317,7 @@ int main_search(const Options& o) {
   FastxReader* fx = nullptr;
   if (bam_mode) {
     bam = new BamReader(o.bam, o.io_threads);
-    // BGZF blocks are inflated on the GPU (csrc/inflate.hip).  SVDSS_GPU_INFLATE: 0 = host workers only; 1..99 = that
-    // share of the chunks goes to the GPU; 100 (default) = the GPU takes whatever the host workers cannot start at once;
-    // 101 = every chunk
-    const int gpu_pct = getenv("SVDSS_GPU_INFLATE") ? atoi(getenv("SVDSS_GPU_INFLATE")) : 100;
-    if (gpu_pct > 0) {
-      BamReader::GpuInflateApi api;
-      api.inflate = [](void** obj, int device, const uint8_t* comp, int64_t comp_bytes, const void* blocks, int64_t n_blocks,
-                       void* d_out, uint8_t* host_out, int64_t out_bytes, int64_t* bad) {
-        return svdss_bgzf_inflate((svdss_inflate_t**)obj, device, comp, comp_bytes, (const svdss_bgzf_block_t*)blocks, n_blocks,
-                                  d_out, host_out, out_bytes, bad);
-      };
-      api.inflate_free = [](void* obj) { svdss_inflate_free((svdss_inflate_t*)obj); };
-      api.device_alloc = svdss_device_alloc;
-      api.device_free = svdss_device_free;
-      api.host_alloc = svdss_host_alloc;
-      api.host_free = svdss_host_free;
-      bam->enable_gpu_inflate(api, 0, gpu_pct);
-    }
+    svdss_enable_gpu_inflate(*bam);   // (BGZF blocks inflated on the GPU, csrc/inflate.hip; SVDSS_GPU_INFLATE)
     if (!bam->ok() || !bam->read_header()) die("cannot read " + o.bam + ": " + bam->error());
   } else {
     logmsg("warning", "FASTX mode is not optimized (higher running times and larger SFSs set).");

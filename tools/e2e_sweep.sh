@@ -8,6 +8,7 @@ run() {
   md5sum /tmp/e2e/out_$N.sfs | cut -c1-12
 }
 N=0 run SVDSS_GPU_INFLATE=0
-N=1 run SVDSS_GPU_INFLATE=100
-N=2 run SVDSS_GPU_INFLATE=100 SVDSS_SEARCH_FEEDERS=3
-N=3 run SVDSS_GPU_INFLATE=75
+N=1 run SVDSS_GPU_INFLATE=101
+N=2 run SVDSS_GPU_INFLATE=100
+N=3 run SVDSS_GPU_INFLATE=100 SVDSS_BAM_AHEAD=32
+N=4 run SVDSS_GPU_INFLATE=100 SVDSS_SEARCH_FEEDERS=3
