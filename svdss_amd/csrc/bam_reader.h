@@ -221,6 +221,7 @@ class BamReader {
     threads_ = threads > 0 ? threads : (int)std::max(1u, std::min(128u, hw > 32 ? hw / 2 : hw));
     pool_.reset(new InflatePool(threads_));
     if (const char* e = getenv("SVDSS_BAM_AHEAD")) ahead_ = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("SVDSS_BAM_SLAB_KB")) slab_ = (size_t)std::max(64, atoi(e)) << 10;
     // the page tables of the mapping are filled ahead of the block scanner and the inflate workers, 16 MB per call:
     // without it every BGZF block costs its worker a page fault, and faults of many threads on one mapping serialise
     // in the kernel (the inflate rate did not move between 48 and 224 workers)
@@ -270,7 +271,7 @@ class BamReader {
 
   bool read_header() {
     char magic[4];
-    if (!read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { err_ = "not a BAM file"; return false; }
+    if (!read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { if (err_.empty()) err_ = "not a BAM file"; return false; }
     int32_t l_text, n_ref;
     if (!read(&l_text, 4)) return fail("truncated header");
     std::string text((size_t)l_text, '\0');
@@ -294,7 +295,7 @@ class BamReader {
   int next(BamRecord& r, bool want_qual = true) {
     int32_t block_size;
     size_t got = read_some(&block_size, 4);
-    if (got == 0) return 0;
+    if (got == 0) return err_.empty() ? 0 : -1;
     if (got != 4 || block_size < 32) { err_ = "truncated record"; return -1; }
     buf_.resize((size_t)block_size);
     if (!read(buf_.data(), (size_t)block_size)) { err_ = "truncated record"; return -1; }
@@ -421,7 +422,7 @@ class BamReader {
   int next_raw(Arena& arena, RawRec& rr) {
     int32_t block_size;
     const size_t got = read_some(&block_size, 4);
-    if (got == 0) return 0;
+    if (got == 0) return err_.empty() ? 0 : -1;
     uint8_t core[32];
     if (got != 4 || block_size < 32 || !read(core, 32)) { err_ = "truncated record"; return -1; }
     uint16_t n_cigar;
@@ -467,7 +468,7 @@ class BamReader {
   int next_view(RawView& v) {
     int32_t block_size;
     const size_t got = read_some(&block_size, 4);
-    if (got == 0) return 0;
+    if (got == 0) return err_.empty() ? 0 : -1;
     if (got != 4 || block_size < 32) { err_ = "truncated record"; return -1; }
     v.own.reset();
     if (chunk_->size() - upos_ >= (size_t)block_size) {   // whole record inside the current chunk
@@ -605,12 +606,16 @@ class BamReader {
     Bytes data;
     bool eof = false;
     std::string err;
+    std::string late_err;   // reported after the chunk's data has been consumed
   };
   struct BlockRef { size_t coff, clen, uoff; uint32_t isize, crc; };
-  static constexpr size_t kSlabBytes = (size_t)32 << 20;   // compressed bytes read per chunk (~512 blocks)
+  size_t slab_ = (size_t)32 << 20;   // compressed bytes read per chunk (~512 blocks; SVDSS_BAM_SLAB_KB: tests)
 
   bool next_chunk() {
-    if (eof_seen_) return false;   // the final chunk was already handed out
+    if (eof_seen_) {               // the final chunk was already handed out
+      if (!pending_err_.empty()) { err_ = pending_err_; pending_err_.clear(); }
+      return false;
+    }
     while (pending_.size() < ahead_ && !launched_eof_) {
       const uint64_t ticket = n_launched_++;
       pending_.push_back(std::async(std::launch::async, [this, ticket] { return load_chunk(ticket); }));
@@ -622,6 +627,7 @@ class BamReader {
     pending_.pop_front();
     if (!c.err.empty()) { err_ = c.err; eof_seen_ = true; drain(); return false; }
     if (c.eof) { eof_seen_ = true; drain(); }
+    if (!c.late_err.empty()) pending_err_ = c.late_err;
     // the buffer goes back to the free list when the last holder of the chunk lets go of it (a fresh 50-100 MB
     // allocation per chunk is a page fault per 4 KB for the inflate workers)
     {
@@ -634,7 +640,11 @@ class BamReader {
     chunk_->swap(c.data);
     ++chunk_id_;
     upos_ = 0;
-    return !(c.eof && chunk_->empty());
+    if (c.eof && chunk_->empty()) {
+      if (!pending_err_.empty()) { err_ = pending_err_; pending_err_.clear(); }
+      return false;
+    }
+    return true;
   }
 
   void drain() {
@@ -651,11 +661,11 @@ class BamReader {
     // pread mode: this loader's nominal range [base, base + slab) plus what the last block may need beyond it
     std::shared_ptr<Bytes> own;
     size_t own_got = 0;
-    const size_t base = (size_t)ticket * kSlabBytes;
+    const size_t base = (size_t)ticket * slab_;
     if (pread_size_ && base < pread_size_) {
       own = take_comp();
-      const size_t want = std::min(kSlabBytes + kOverlap, pread_size_ - base);
-      own->alloc(kSlabBytes + kOverlap, gpu_.inflate != nullptr);
+      const size_t want = std::min(slab_ + kOverlap, pread_size_ - base);
+      own->alloc(slab_ + kOverlap, gpu_.inflate != nullptr);
       while (own_got < want) {
         const ssize_t k = pread(fileno(f_), own->data() + own_got, want - own_got, (off_t)(base + own_got));
         if (k <= 0) break;
@@ -679,20 +689,20 @@ class BamReader {
     size_t start = 0;
     if (pread_size_) {
       if (base >= pread_size_ || next_off_ >= pread_size_) { c.eof = true; file_eof_ = true; return c; }
-      if (next_off_ < base || next_off_ > base + kSlabBytes + kOverlap) { c.err = "BGZF block chain lost"; file_eof_ = true; return c; }
+      if (next_off_ < base || next_off_ > base + slab_ + kOverlap) { c.err = "BGZF block chain lost"; file_eof_ = true; return c; }
       src = own->data();
       start = next_off_ - base;              // the first block of this chunk (the previous chunk's last one ended here)
-      got = std::min(kSlabBytes, own_got);   // blocks start before the end of the nominal range ..
+      got = std::min(slab_, own_got);   // blocks start before the end of the nominal range ..
       avail = own_got;                       // .. and may end in the overlap
-      if (start >= got && own_got < kSlabBytes + kOverlap && base + own_got < pread_size_) { c.err = "short read"; file_eof_ = true; return c; }
+      if (start >= got && own_got < slab_ + kOverlap && base + own_got < pread_size_) { c.err = "short read"; file_eof_ = true; return c; }
     } else if (map_) {
       src = map_ + map_pos_;
-      got = std::min(kSlabBytes, map_size_ - map_pos_);
+      got = std::min(slab_, map_size_ - map_pos_);
       avail = map_size_ - map_pos_;          // a block may end past the slab: the mapping has it
     } else {
-      comp.alloc(carry_.size() + kSlabBytes);
+      comp.alloc(carry_.size() + slab_);
       if (!carry_.empty()) memcpy(comp.data(), carry_.data(), carry_.size());
-      got = fread(comp.data() + carry_.size(), 1, kSlabBytes, f_);
+      got = fread(comp.data() + carry_.size(), 1, slab_, f_);
       avail = carry_.size() + got;
       src = comp.data();
     }
@@ -727,7 +737,9 @@ class BamReader {
     if (pread_size_) {
       next_off_ = base + pos;
       if (next_off_ >= pread_size_) { c.eof = true; file_eof_ = true; }
-      else if (pos < scan_end) { c.eof = true; file_eof_ = true; c.err = "truncated BGZF block"; return c; }   // stopped early
+      // (stopped early: the file ends inside a block -- the complete blocks before it are still delivered, the error
+      // comes when the parser asks for more)
+      else if (pos < scan_end) { c.eof = true; file_eof_ = true; c.late_err = "truncated BGZF block"; }
     } else if (map_) {
       map_pos_ += pos;
       if (pos == 0) {                       // nothing complete left: end of file (or a truncated last block)
@@ -889,6 +901,7 @@ class BamReader {
   const uint8_t* map_ = nullptr;   // the whole file, when it could be mapped
   size_t map_size_ = 0, map_pos_ = 0;
   bool launched_eof_ = false;
+  std::string pending_err_;
   bool eof_seen_ = false;
   std::string err_;
   std::vector<std::string> refs_;

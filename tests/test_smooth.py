@@ -123,13 +123,24 @@ def test_smooth_output_does_not_depend_on_threads_and_spans_many_bgzf_chunks(tmp
         assert r.returncode == 0, r.stderr
         outs.append(out.read_bytes())
     assert outs[0] == outs[1] and len(outs[0]) > 0
-    # the read() path of the BGZF loader (pipes, or SVDSS_NO_MMAP) gives the same stream as the mapped file
-    out = tmp_path / "out_nommap.bam"
-    with open(out, "wb") as fh:
-        r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam), "--threads", "4"], stdout=fh,
-                           stderr=subprocess.PIPE, env=dict(os.environ, SVDSS_NO_MMAP="1"))
-    assert r.returncode == 0, r.stderr
-    assert out.read_bytes() == outs[0]
+    # every way the BGZF loader gets at the file gives the same stream: per-loader pread of file ranges (default; with
+    # ranges as small as one block, so that block chains cross many range boundaries and some ranges hold no block start),
+    # sequential reads (pipes), a mapping of the file; few or many chunks in flight
+    for k, env in enumerate(({"SVDSS_BAM_STREAM": "1"}, {"SVDSS_BAM_MMAP": "1"}, {"SVDSS_BAM_SLAB_KB": "64", "SVDSS_BAM_AHEAD": "3"},
+                             {"SVDSS_BAM_SLAB_KB": "100"}, {"SVDSS_BAM_SLAB_KB": "1000", "SVDSS_BAM_AHEAD": "40"})):
+        out = tmp_path / f"out_v{k}.bam"
+        with open(out, "wb") as fh:
+            r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam), "--threads", "4"], stdout=fh,
+                               stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert r.returncode == 0, (env, r.stderr)
+        assert out.read_bytes() == outs[0], env
+    # a file cut in the middle of a block is an error, not a shorter stream
+    cut = tmp_path / "cut.bam"
+    cut.write_bytes(bam.read_bytes()[:os.path.getsize(bam) // 2])
+    for env in ({}, {"SVDSS_BAM_SLAB_KB": "100"}, {"SVDSS_BAM_STREAM": "1"}):
+        r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(cut), "--threads", "4"], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert r.returncode == 1 and b"truncated" in r.stderr, (env, r.stderr[-300:])
     names, lens, alns = bamio.read_bam(str(tmp_path / "out6.bam"))
     assert len(alns) == n_reads and names == ["c1"]
 
