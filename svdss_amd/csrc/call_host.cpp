@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/svdss_hip.h"
+#include "bai_index.h"
 #include "bam_reader.h"
 #include "gpu_inflate_hook.h"
 #include "call_host.h"
@@ -666,13 +667,46 @@ int main_call(const CallOptions& o) {
       // (gigabytes of inflated records: released while the DP batches run)
       cache_release = std::thread([v = std::move(cache_views), c = std::move(cache_chunks)]() mutable { v.clear(); c.clear(); });
     } else {
-      BamReader bam(o.bam);
-      svdss_enable_gpu_inflate(bam);
-      if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
-      BamReader::RawView rr;   // zero-copy: the record is used where it was inflated, within this iteration only
-      int rc;
-      while ((rc = bam.next_view(rr)) > 0) process(rr, qname, apply);
-      if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
+      // the records of pass 1 did not fit in memory.  With a BAI index beside the file (what the reference requires:
+      // sam_index_load + one sam_itr_querys per cluster, clusterer.cpp:495-527) only the file chunks around the
+      // clusters are read -- all regions turned into one sorted, merged chunk list, read once in file order, which
+      // visits the same records in the same order as the full scan below does among those that touch a cluster
+      BaiIndex bai;
+      bool have_bai = false;
+      if (!getenv("SVDSS_CALL_NO_BAI")) {
+        have_bai = bai.load(o.bam + ".bai");
+        if (!have_bai && o.bam.size() > 4 && o.bam.compare(o.bam.size() - 4, 4, ".bam") == 0)
+          have_bai = bai.load(o.bam.substr(0, o.bam.size() - 4) + ".bai");
+        if (have_bai && bai.refs.size() != ref_names.size()) have_bai = false;
+      }
+      if (have_bai) {
+        std::vector<std::pair<uint64_t, uint64_t>> chunks;
+        size_t n_regions = 0;
+        for (size_t t = 0; t < ref_names.size(); ++t) {
+          if (!tid_clusters[t]) continue;
+          int64_t rb = -1, re = -1;   // current merged region
+          for (size_t ci : *tid_clusters[t]) {
+            const int64_t b0 = std::max(min_s[ci] - 1, 0), e0 = max_e[ci];
+            if (re >= 0 && b0 <= re) { re = std::max(re, e0); continue; }
+            if (re >= 0) { bai.query((int)t, rb, re, chunks); ++n_regions; }
+            rb = b0; re = e0;
+          }
+          if (re >= 0) { bai.query((int)t, rb, re, chunks); ++n_regions; }
+        }
+        BaiIndex::merge(chunks);
+        logmsg("debug", "pass 2 through the BAI index: " + std::to_string(n_regions) + " regions, " + std::to_string(chunks.size()) +
+                            " file chunks");
+        const std::string e = bam_scan_chunks(o.bam, chunks, [&](const BamReader::RawView& rr) { process(rr, qname, apply); });
+        if (!e.empty()) die("error reading " + o.bam + ": " + e);
+      } else {
+        BamReader bam(o.bam);
+        svdss_enable_gpu_inflate(bam);
+        if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
+        BamReader::RawView rr;   // zero-copy: the record is used where it was inflated, within this iteration only
+        int rc;
+        while ((rc = bam.next_view(rr)) > 0) process(rr, qname, apply);
+        if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
+      }
     }
     for (size_t i = 0; i < clusters.size(); ++i) {
       if (!live[i]) { clusters[i].reads.clear(); clusters[i].subreads.clear(); continue; }

@@ -47,3 +47,90 @@ def bam(refs, records) -> bytes:
     for n, l in refs:
         hdr += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
     return bgzf(hdr + b"".join(records))
+
+
+def reg2bin(beg: int, end: int) -> int:
+    """SAM specification, section 5.3 (0-based half-open [beg, end))"""
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def bai(bam_bytes: bytes) -> bytes:
+    """A BAI index of a coordinate-sorted BAM as `samtools index` writes it (SAM specification 5.2): bins with their
+    chunks (virtual offsets, adjacent chunks of a bin merged), the 16 kb linear index, without the metadata pseudo-bin.
+    Virtual offsets of positions at a block boundary are written as "end of the previous block", like htslib's
+    bgzf_tell after a record that ends there."""
+    import zlib
+    # inflate every block, remember where it starts (compressed offset, inflated offset)
+    blocks, data, pos = [], bytearray(), 0
+    while pos + 18 <= len(bam_bytes):
+        bsize = struct.unpack_from("<H", bam_bytes, pos + 16)[0] + 1
+        raw = zlib.decompress(bam_bytes[pos + 18:pos + bsize - 8], -15)
+        blocks.append((pos, len(data), len(raw)))
+        data += raw
+        pos += bsize
+
+    import bisect
+    nonempty = [b for b in blocks if b[2] > 0]
+    starts = [b[1] for b in nonempty]
+
+    def voff(u):   # virtual offset of inflated position u ("end of block" form at boundaries)
+        k = max(bisect.bisect_left(starts, u) - 1, 0)      # the last block that starts before u (the first, for u = 0)
+        c, s, n = nonempty[k]
+        if not s <= u <= s + n:
+            raise ValueError(u)
+        return (c << 16) | (u - s)
+
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    n_ref = struct.unpack_from("<i", data, 8 + l_text)[0]
+    p = 12 + l_text
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", data, p)[0]
+        p += 8 + l_name
+    bins = [dict() for _ in range(n_ref)]
+    lin = [dict() for _ in range(n_ref)]
+    while p + 4 <= len(data):
+        bs = struct.unpack_from("<i", data, p)[0]
+        tid, start = struct.unpack_from("<ii", data, p + 4)
+        l_name = data[p + 12]
+        n_cig = struct.unpack_from("<H", data, p + 16)[0]
+        ref_len = 0
+        for k in range(n_cig):
+            c = struct.unpack_from("<I", data, p + 36 + l_name + 4 * k)[0]
+            if (c & 15) in (0, 2, 3, 7, 8):
+                ref_len += c >> 4
+        end = start + max(ref_len, 1)
+        v0, v1 = voff(p), voff(p + 4 + bs)
+        if tid >= 0:
+            ch = bins[tid].setdefault(reg2bin(start, end), [])
+            if ch and ch[-1][1] == v0:
+                ch[-1][1] = v1
+            else:
+                ch.append([v0, v1])
+            for w in range(start >> 14, ((end - 1) >> 14) + 1):
+                lin[tid].setdefault(w, v0)
+        p += 4 + bs
+    out = bytearray(b"BAI\1" + struct.pack("<i", n_ref))
+    for t in range(n_ref):
+        out += struct.pack("<i", len(bins[t]))
+        for b in sorted(bins[t]):
+            out += struct.pack("<Ii", b, len(bins[t][b]))
+            for v0, v1 in bins[t][b]:
+                out += struct.pack("<QQ", v0, v1)
+        n_intv = max(lin[t]) + 1 if lin[t] else 0
+        out += struct.pack("<i", n_intv)
+        last = 0
+        for w in range(n_intv):      # windows no record starts in inherit the next smaller offset (htslib fills them)
+            last = lin[t].get(w, last)
+            out += struct.pack("<Q", last)
+    return bytes(out)

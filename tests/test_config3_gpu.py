@@ -49,6 +49,23 @@ def test_chr20_10x_end_to_end(tmp_path):
     r_host = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4",
                              "--min-sv-length", "50"], capture_output=True, text=True, env=dict(os.environ, SVDSS_PLACE_HOST="1"))
     assert r_host.returncode == 0 and r_host.stdout == vcf
+    # the second BAM pass without the records of pass 1 in memory: the whole file again, or -- with a BAI index beside
+    # the file, as the reference requires -- only the chunks the index names for the cluster regions (records here
+    # straddle BGZF blocks, chunks start and end inside blocks): the same VCF
+    for with_bai in (False, True):
+        if with_bai:
+            from tests import bam_writer
+            with open(bam, "rb") as fh:
+                idx = bam_writer.bai(fh.read())
+            with open(bam + ".bai", "wb") as fh:
+                fh.write(idx)
+        r_p2 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4",
+                               "--min-sv-length", "50", "--verbose"], capture_output=True, text=True,
+                              env=dict(os.environ, SVDSS_CALL_CACHE_GB="0"))
+        assert r_p2.returncode == 0, r_p2.stderr[-500:]
+        assert ("through the BAI index" in r_p2.stderr) == with_bai
+        assert r_p2.stdout == vcf
+    os.remove(bam + ".bai")
     # the reads around four SVs (two heterozygous, two homozygous): the same chain on that sub-BAM, and the Python mirror
     # of the host logic (clusterer.cpp / caller.cpp restated in svdss_amd/) on the same inputs -> the same VCF bytes
     pick = [k for k in range(len(svs)) if het[k]][:2] + [k for k in range(len(svs)) if not het[k]][:2]

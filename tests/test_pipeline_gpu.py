@@ -66,6 +66,18 @@ def test_index_search_call_recovers_implanted_svs(tmp_path, het):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout == vcf
+    # the second BAM pass three ways -- records of pass 1 kept in memory (above), the whole file read again, only the
+    # file chunks a BAI index names for the cluster regions (sam_itr_querys in the reference): the same bytes
+    clusters_text = (tmp_path / "clusters.txt").read_text()
+    for with_bai in (False, True):
+        if with_bai:
+            (tmp_path / "smoothed.bam.bai").write_bytes(bam_writer.bai(bam.read_bytes()))
+        r2 = subprocess.run([BIN, "call", "--reference", str(fa), "--bam", str(bam), "--sfs", str(sfs_path), "--threads", "4",
+                             "--min-sv-length", "50", "--clusters", str(tmp_path / "clusters2.txt"), "--verbose"],
+                            capture_output=True, text=True, env=dict(os.environ, SVDSS_CALL_CACHE_GB="0"))
+        assert r2.returncode == 0, r2.stderr
+        assert ("through the BAI index" in r2.stderr) == with_bai, r2.stderr[-600:]
+        assert r2.stdout == vcf and (tmp_path / "clusters2.txt").read_text() == clusters_text
     # side outputs (caller.cpp:65-75, clusterer.cpp:613-626)
     sam = (tmp_path / "poa.sam").read_text()
     assert sam == info["sam"]
