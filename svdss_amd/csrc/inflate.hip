@@ -29,10 +29,14 @@
 
 namespace {
 
-constexpr int WIN = 32768, WM = WIN - 1;
+// the LDS ring holds the most recent output only; a match that reaches further back than NEAR reads the bytes the block
+// itself wrote to HBM earlier (they left the ring at least FLUSH + one round ago)
+constexpr int WIN = 8192, WM = WIN - 1;
+constexpr int NEAR = 5120;        // sources within this distance of a match's output position are read from the ring
+constexpr int ROUND_MAX = 1024;   // a round stops taking symbols once it has produced this many bytes (+ one match)
 constexpr int LB = 10, DB = 8, CB = 7;
 constexpr int INB = 2048;
-constexpr int FLUSH = 16384;
+constexpr int FLUSH = 2048;
 
 
 struct Lds {
@@ -133,7 +137,7 @@ __device__ bool build_table(const uint8_t* lens, int n, uint16_t* tab, int tb, u
 }
 
 __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const svdss_bgzf_block_t* __restrict__ blks,
-                                                         uint8_t* __restrict__ out, int32_t* __restrict__ status) {
+                                                         uint8_t* out, int32_t* __restrict__ status) {
   __shared__ Lds L;
   const int lane = threadIdx.x;
   const svdss_bgzf_block_t B = blks[blockIdx.x];
@@ -218,6 +222,24 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
       if ((uint32_t)lane < tail) o8[flushed + lane] = winb[(flushed + lane) & WM];
       flushed += tail;
     }
+  };
+
+  // a match of ml bytes at output position o, dd bytes back.  Sources closer than NEAR are in the ring; older ones were
+  // written to HBM by an earlier flush (complete 128-byte lines by now: nothing of this block's output is read from HBM
+  // within FLUSH + ROUND_MAX + 258 of its end) and are read back from there -- with the ring this small a CU holds a dozen
+  // blocks, and that latency is what the other wavefronts are for.
+  auto copy_match = [&](uint32_t o, uint32_t ml, uint32_t dd) {
+    const uint32_t from = o - dd;
+    const bool far = dd > (uint32_t)NEAR;
+    if (far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this block's own stores of long ago)
+    uint8_t v[5];
+    int nk = 0;
+    for (uint32_t k = lane; k < ml; k += 64) {
+      const uint32_t sp = from + (dd >= ml ? k : k % dd);   // (an overlapping match repeats its first dd bytes)
+      v[nk++] = (far && o - sp > (uint32_t)NEAR) ? __hip_atomic_load(o8 + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : winb[sp & WM];
+    }
+    nk = 0;
+    for (uint32_t k = lane; k < ml; k += 64) winb[(o + k) & WM] = v[nk++];
   };
 
   for (;;) {
@@ -341,38 +363,26 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
         if (len == 0 || (is_match && (sym > 285u || dl == 0 || (D >> 4) > 29u))) kind = 3u;
         const uint32_t nbits = kind == 1u ? eoff + dx : len;
         const uint32_t outlen = kind == 0u ? 1u : kind == 1u ? mlen : 0u;
-        const uint32_t NX = ((uint32_t)lane + nbits) | (kind << 8);
+        const uint32_t NX = ((uint32_t)lane + nbits) | (kind << 8) | (outlen << 10);
         // ---- the scalar unit follows the chain of symbol starts from offset 0
         uint32_t off = 0;
         unsigned long long chain = 0;
         bool slow = false;
-        while (off < 64) {
+        uint32_t produced = 0;
+        while (off < 64 && produced < (uint32_t)ROUND_MAX) {
           const uint32_t nx = __builtin_amdgcn_readlane(NX, off);
-          if (nx >= (3u << 8)) { slow = true; break; }
+          const uint32_t k = (nx >> 8) & 3u;
+          if (k == 3u) { slow = true; break; }
           chain |= 1ull << off;
           off = nx & 255u;
-          if (nx >= (2u << 8)) { eob = true; break; }
+          produced += nx >> 10;
+          if (k == 2u) { eob = true; break; }
         }
         // ---- where every symbol of the chain puts its output: a scan over the chain's lanes
-        bool onc = ((chain >> lane) & 1ull) != 0;
-        uint32_t x = onc ? outlen : 0u;
-        uint32_t incl = (uint32_t)wave_scan_add((int)x);
-        uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        // (the literals are stored ahead of the matches that precede them: a match whose source lies within
-        // `total - its offset` of the ring's far end would see its source overwritten -- cut the round at that match)
-        {
-          const unsigned long long hz = __ballot(onc && kind == 1u && dist > (uint32_t)WIN - (total - (incl - x)));
-          if (hz) {
-            const int h = (int)__builtin_ctzll(hz);
-            chain &= (2ull << h) - 1;
-            off = __builtin_amdgcn_readlane(NX, h) & 255u;
-            eob = false;
-            onc = ((chain >> lane) & 1ull) != 0;
-            x = onc ? outlen : 0u;
-            incl = (uint32_t)wave_scan_add((int)x);
-            total = __builtin_amdgcn_readlane(incl, 63);
-          }
-        }
+        const bool onc = ((chain >> lane) & 1ull) != 0;
+        const uint32_t x = onc ? outlen : 0u;
+        const uint32_t incl = (uint32_t)wave_scan_add((int)x);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
         const uint32_t opos = wpos + (incl - x);
         if (wpos + total > isize) { err = ST_OUT; break; }
         if (__ballot(onc && kind == 1u && dist > opos)) { err = ST_DIST; break; }
@@ -384,19 +394,7 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
           mm &= mm - 1;
           CNT(2, 1);
           const uint32_t o = __builtin_amdgcn_readlane(opos, h), ml = __builtin_amdgcn_readlane(mlen, h), dd = __builtin_amdgcn_readlane(dist, h);
-          const uint32_t from = o - dd;
-          if (dd >= ml) {
-            if ((uint32_t)lane < ml) winb[(o + (uint32_t)lane) & WM] = winb[(from + (uint32_t)lane) & WM];
-            if (ml > 64)
-              for (uint32_t k = 64 + lane; k < ml; k += 64) winb[(o + k) & WM] = winb[(from + k) & WM];
-          } else {
-            // the match overlaps its own output: byte k repeats byte k mod dist of the dist bytes before it
-            uint8_t v[5];
-            int nk = 0;
-            for (uint32_t k = lane; k < ml; k += 64) v[nk++] = winb[(from + k % dd) & WM];
-            nk = 0;
-            for (uint32_t k = lane; k < ml; k += 64) winb[(o + k) & WM] = v[nk++];
-          }
+          copy_match(o, ml, dd);
         }
         wpos += total;
         P += (uint64_t)off;
@@ -438,12 +436,7 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
           const uint32_t dist = db + take(dx);
           if (dist > wpos) { err = ST_DIST; break; }
           if (wpos + len > isize) { err = ST_OUT; break; }
-          const uint32_t from = wpos - dist;
-          uint8_t v[5];
-          int nk = 0;
-          for (uint32_t k = lane; k < len; k += 64) v[nk++] = winb[(from + (dist >= len ? k : k % dist)) & WM];
-          nk = 0;
-          for (uint32_t k = lane; k < len; k += 64) winb[(wpos + k) & WM] = v[nk++];
+          copy_match(wpos, len, dist);
           wpos += len;
         }
         P = in_addr * 8 - (uint64_t)bc;
