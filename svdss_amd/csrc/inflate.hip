@@ -5,15 +5,19 @@
 // at most 64 KB, and inflating them is what bounds the binary end to end (a host core inflates ~0.3 GB/s of this kind of
 // data; a 30x human sample is ~140 GB inflated).  Every BGZF block is an independent stream, so the GPU takes one
 // wavefront per block and a few thousand blocks at a time:
-//   * the last 32 KB of output (deflate's whole window) live in an LDS ring, so literals and matches never touch HBM;
-//     the ring is written out in aligned dwords 16 KB at a time;
-//   * the compressed bytes pass through a 2 KB LDS ring, refilled 1 KB at a time by the whole wave;
+//   * the most recent 4 KB of output live in an LDS ring: literals and near matches never touch HBM, the ring is written
+//     out in aligned dwords 512 bytes at a time; a match that reaches further back (deflate allows 32 KB) reads the bytes
+//     the block itself wrote to HBM earlier -- the ring is that small so that a CU holds 18 blocks instead of 4, and
+//     the latency of those reads (and of everything else) is hidden by the other wavefronts;
+//   * the compressed bytes pass through a 1 KB LDS ring, refilled 512 bytes at a time by the whole wave;
 //   * Huffman tables (10-bit literal/length, 8-bit distance, 16-bit entries; longer codes are decoded canonically) are
 //     built by the wave in parallel: the canonical code of a symbol is the rank of the symbol among those of its length
 //     (wave ballots), and every lane fills the table entries of its own symbols;
-//   * the decode loop itself is a serial chain per block (a symbol's position depends on the length of the one before):
-//     the scalar unit carries the bit buffer, one LDS lookup per symbol; matches are copied by all 64 lanes.
-// 38 KB of LDS per block: four blocks per CU, 1,024 in flight.  No CRC check on this path (the host path checks it).
+//   * symbols are decoded in rounds of 64 bits: every lane decodes the whole symbol that would start at its bit offset
+//     (literal, or length + extra bits + distance code + extra bits, or end of block) from the 64 bits that start there;
+//     the scalar unit follows the chain of symbol starts with lane reads, a wave scan places the outputs, literals are
+//     stored together, matches are copied in order by all 64 lanes.
+// 8.7 KB of LDS per block.  No CRC check on this path (the caller checks the BGZF footers on the host).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -31,12 +35,18 @@ namespace {
 
 // the LDS ring holds the most recent output only; a match that reaches further back than NEAR reads the bytes the block
 // itself wrote to HBM earlier (they left the ring at least FLUSH + one round ago)
-constexpr int WIN = 8192, WM = WIN - 1;
-constexpr int NEAR = 5120;        // sources within this distance of a match's output position are read from the ring
-constexpr int ROUND_MAX = 1024;   // a round stops taking symbols once it has produced this many bytes (+ one match)
+#ifndef INF_WIN
+#define INF_WIN 4096
+#endif
+constexpr int WIN = INF_WIN, WM = WIN - 1;
+constexpr int FLUSH = WIN / 8;        // the ring is written out whenever this many bytes are waiting
+constexpr int ROUND_MAX = WIN / 8;    // a round stops taking symbols once it has produced this many bytes (+ one match)
+// sources within this distance of a match's output position are read from the ring: everything further back has been
+// written out (FLUSH + ROUND_MAX + 258 < NEAR) and nothing closer has been overwritten (NEAR + ROUND_MAX + 258 < WIN)
+constexpr int NEAR = WIN / 2 - WIN / 8;
+static_assert(FLUSH + ROUND_MAX + 258 + 64 < NEAR && NEAR + ROUND_MAX + 258 + 64 < WIN, "ring too small");
 constexpr int LB = 10, DB = 8, CB = 7;
-constexpr int INB = 2048;
-constexpr int FLUSH = 2048;
+constexpr int INB = 1024, HALF = INB / 2;   // input ring, refilled a half at a time
 
 
 struct Lds {
@@ -153,19 +163,20 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
 #define FAIL(code) do { status[blockIdx.x] = (code); return; } while (0)
 
   // ---- input: absolute offsets into comp; the ring holds [base, base + INB)
-  uint64_t base = in_first & ~(uint64_t)1023, in_addr = in_first;
-  auto load_half = [&](uint64_t a0) {
-    const uint4 v = *(const uint4*)(comp + a0 + (uint64_t)lane * 16);
-    *(uint4*)((uint8_t*)L.inb + ((a0 + (uint64_t)lane * 16) & (INB - 1))) = v;
+  uint64_t base = in_first & ~(uint64_t)(HALF - 1), in_addr = in_first;
+  auto load_half = [&](uint64_t a0) {   // HALF bytes, 8 per lane
+    static_assert(HALF == 64 * 8, "one uint2 per lane");
+    const uint2 v = *(const uint2*)(comp + a0 + (uint64_t)lane * 8);
+    *(uint2*)((uint8_t*)L.inb + ((a0 + (uint64_t)lane * 8) & (INB - 1))) = v;
   };
   load_half(base);
-  load_half(base + 1024);
+  load_half(base + HALF);
   uint64_t bb = 0;
   int bc = 0;
   auto step_half = [&]() {
     // (32 bytes late: the bit buffer holds up to 8 bytes that were read before in_addr, and the literal runs read the
     // ring at the position of the first unused bit)
-    if (in_addr - base >= 1024 + 32) { load_half(base + INB); base += 1024; }
+    if (in_addr - base >= HALF + 32) { load_half(base + INB); base += HALF; }
   };
   for (; (in_addr & 3) != 0; ++in_addr) {
     const uint32_t b = UNI((uint32_t)((const uint8_t*)L.inb)[in_addr & (INB - 1)]);
@@ -230,6 +241,10 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
   // blocks, and that latency is what the other wavefronts are for.
   auto copy_match = [&](uint32_t o, uint32_t ml, uint32_t dd) {
     const uint32_t from = o - dd;
+    if (dd <= (uint32_t)NEAR && dd >= ml && ml <= 64) {   // the common one: short, from the ring, not overlapping itself
+      if ((uint32_t)lane < ml) winb[(o + (uint32_t)lane) & WM] = winb[(from + (uint32_t)lane) & WM];
+      return;
+    }
     const bool far = dd > (uint32_t)NEAR;
     if (far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this block's own stores of long ago)
     uint8_t v[5];
@@ -265,9 +280,9 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
       }
       // restart the reader behind the stored bytes
       in_addr = src + len;
-      base = in_addr & ~(uint64_t)1023;
+      base = in_addr & ~(uint64_t)(HALF - 1);
       load_half(base);
-      load_half(base + 1024);
+      load_half(base + HALF);
       bb = 0; bc = 0;
       for (; (in_addr & 3) != 0; ++in_addr) {
         const uint32_t b = UNI((uint32_t)((const uint8_t*)L.inb)[in_addr & (INB - 1)]);
@@ -332,7 +347,7 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
       bool eob = false;
       uint64_t P = in_addr * 8 - (uint64_t)bc;
       for (;;) {
-        if ((P >> 3) - base >= 1024 + 32) { load_half(base + INB); base += 1024; }
+        if ((P >> 3) - base >= HALF + 32) { load_half(base + INB); base += HALF; }
         CNT(0, 1);
         // ---- every lane decodes the symbol that would start at its bit offset, whole: a literal, or a match with its
         // extra bits and its distance (all inside the 64 bits that start there), or the end-of-block code -- and where
