@@ -6,10 +6,11 @@
 #include "bam_reader.h"
 
 // BGZF blocks of `bam` are inflated on the GPU (csrc/inflate.hip) when one is present.  SVDSS_GPU_INFLATE: 0 = host
-// workers only; 1..99 = that share of the chunks goes to the GPU; 100 (default) = the GPU takes whatever the host workers
-// cannot start at once; 101 = every chunk.  Returns whether the GPU path is on.
+// workers only; 1..99 = that share of the chunks goes to the GPU; 100 = the GPU takes whatever the host workers cannot
+// start at once; 101 (default) = every chunk (the host's cores are better spent on the other stages).  Returns whether
+// the GPU path is on.
 inline bool svdss_enable_gpu_inflate(BamReader& bam, int device = 0) {
-  const int pct = getenv("SVDSS_GPU_INFLATE") ? atoi(getenv("SVDSS_GPU_INFLATE")) : 100;
+  const int pct = getenv("SVDSS_GPU_INFLATE") ? atoi(getenv("SVDSS_GPU_INFLATE")) : 101;
   if (pct <= 0 || svdss_device_count() <= 0) return false;
   BamReader::GpuInflateApi api;
   api.inflate = [](void** obj, int dev, const uint8_t* comp, int64_t comp_bytes, const void* blocks, int64_t n_blocks,

@@ -596,6 +596,9 @@ int main(int argc, char** argv) {
   const time_t t0 = time(nullptr);
   // large blocks stay in the allocator instead of going back to the kernel with every free (with a hundred threads an
   // munmap is a stall for all of them)
+  // (the chunk loaders, the feeding threads and the call-side batches each work on a stream of their own; the runtime
+  // multiplexes streams onto 4 hardware queues by default, and streams that share one run in order)
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   mallopt(M_MMAP_THRESHOLD, 32 << 20);
   mallopt(M_TRIM_THRESHOLD, 1 << 30);
   mallopt(M_TOP_PAD, 64 << 20);

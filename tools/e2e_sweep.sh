@@ -7,8 +7,7 @@ run() {
   env "$@" ./svdss_amd/SVDSS search --index /tmp/e2e/ref.fmd --bam /tmp/e2e/reads.bam --noputative --verbose 2>&1 >/tmp/e2e/out_$N.sfs | grep "bam_reader\|stage busy\|records read\|device at\|rror"
   md5sum /tmp/e2e/out_$N.sfs | cut -c1-12
 }
-N=0 run SVDSS_GPU_INFLATE=0
-N=1 run SVDSS_GPU_INFLATE=101
-N=2 run SVDSS_GPU_INFLATE=100
-N=3 run SVDSS_GPU_INFLATE=100 SVDSS_BAM_AHEAD=32
-N=4 run SVDSS_GPU_INFLATE=100 SVDSS_SEARCH_FEEDERS=3
+N=1 run X=1
+N=2 run SVDSS_SEARCH_FEEDERS=4
+N=3 run SVDSS_BAM_AHEAD=24
+N=4 run SVDSS_GPU_INFLATE=0
