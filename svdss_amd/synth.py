@@ -45,6 +45,34 @@ def make_reference(lengths, seed: int, repeat_frac: float = 0.03, divergence: fl
     return contigs
 
 
+def make_family_reference(lengths, seed: int, repeat_frac: float = 0.45, divergence: float = 0.10,
+                          n_families: int = 40) -> List[np.ndarray]:
+    """iid ACGT contigs in which repeat_frac of the bases are copies of a few repeat families (consensus of 300 bp --
+    6 kb, every copy on a random strand, mutated at `divergence`, truncated at a random point like 5'-truncated L1
+    copies): thousands of copies per family, the way half of a mammalian genome looks, instead of make_reference's
+    pairwise segmental copies."""
+    rng = np.random.default_rng(seed)
+    fam = [rng.integers(1, 5, size=int(n), dtype=np.uint8)
+           for n in rng.choice([300, 300, 300, 1000, 2000, 6000], size=n_families)]
+    contigs = []
+    for L in lengths:
+        c = rng.integers(1, 5, size=L, dtype=np.uint8)
+        target, done = int(L * repeat_frac), 0
+        while done < target and L > 8000:
+            f = fam[int(rng.integers(0, n_families))]
+            n = len(f) if rng.random() < 0.5 else int(rng.integers(100, len(f) + 1))
+            piece = f[len(f) - n:].copy()
+            mut = rng.random(n) < divergence
+            piece[mut] = rng.integers(1, 5, size=int(mut.sum()), dtype=np.uint8)
+            if rng.random() < 0.5:
+                piece = revcomp(piece)
+            dst = int(rng.integers(0, L - n))
+            c[dst:dst + n] = piece
+            done += n
+        contigs.append(c)
+    return contigs
+
+
 @dataclass
 class SV:
     contig: int

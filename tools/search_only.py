@@ -2,7 +2,8 @@
 """The search launches of bench.py's default workload on their own (no torch kernels of the read simulator around
 them inside the profiled region would be better, but the simulator runs once): index built in HBM, one batch of reads,
 N searches.  Used under rocprofv3 --pmc (tools/collect_profiles_r02.sh).
-  python tools/search_only.py [wg|chr20] [n_reads] [repeats]"""
+  python tools/search_only.py [wg|chr20] [n_reads] [repeats] [families:<fraction>:<divergence>]
+(the last argument: a reference in which that fraction of the bases are copies of 40 repeat families, synth.make_family_reference)"""
 import os
 import sys
 
@@ -21,7 +22,12 @@ rep = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 L = 15000
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-ref = synth.make_reference(lens, seed=11)
+if len(sys.argv) > 4 and sys.argv[4].startswith("families:"):
+    _, frac, div = sys.argv[4].split(":")
+    ref = synth.make_family_reference(lens, seed=11, repeat_frac=float(frac), divergence=float(div))
+    wl += " " + sys.argv[4]
+else:
+    ref = synth.make_reference(lens, seed=11)
 ix = svdss_amd.FMDIndex.build(ref, device=0)
 starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
 ref_t = torch.from_numpy(ref[0] if len(ref) == 1 else np.concatenate(ref)).to(dev)
