@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (also skips verification)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the SVDSS binary on a BAM file")
-    ap.add_argument("--e2e-reads", type=int, default=516000, help="reads in the BAM of the end-to-end run")
+    ap.add_argument("--e2e-reads", type=int, default=1032000, help="reads in the BAM of the end-to-end run")
     ap.add_argument("--no-call-dp", action="store_true", help="search only (value is then NOT the headline metric)")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: leave the SFS on the ranks")
     ap.add_argument("--call-threads", type=int, default=3,
@@ -601,7 +601,7 @@ def e2e_search_rate(n_reads):
     work = tempfile.mkdtemp(prefix="svdss_bench_e2e_", dir="/tmp")
     try:
         rng = np.random.default_rng(1)
-        ref_bp, unit = 64444167, 86000
+        ref_bp, unit = 64444167, 172000     # (the record blocks of `unit` reads are written n_reads / unit times)
         repeat = max(1, round(n_reads / unit))
         ref = rng.integers(0, 4, size=ref_bp, dtype=np.uint8)
         fa = os.path.join(work, "ref.fa")
