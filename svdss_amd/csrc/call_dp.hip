@@ -273,6 +273,70 @@ __global__ void __launch_bounds__(DP_THREADS) lcs_ratio_kernel(const LcsPair* pa
   }
 }
 
+// LCS length bit-parallel (Crochemore et al. / Hyyro: V = (V + U) | (V - U) with U = V & PM[text symbol]; the LCS is the
+// number of zero bits of V), one wavefront per pair: lane w holds word w of the bit vector over the shorter string (up to
+// 64 x 64 = 4,096 symbols), the carries of the multi-word addition come from two ballots -- lanes that generate a carry
+// and lanes that would pass one on -- and one 64-bit scalar addition: carry-in mask = ((pass + (gen << 1)) ^ pass).  The
+// match masks PM[symbol] (at most 8 distinct symbols, `sym_id` maps bytes to 0..7, 255 = absent) sit in LDS, the one of
+// the next text symbol is fetched while the current step computes.  ~20 instructions per text symbol instead of one DP
+// cell per lane per step: 5,092 pairs of ~1.2 kb take well under a millisecond (the anti-diagonal kernel: 11.6 ms).
+__global__ void __launch_bounds__(64) lcs_bits_kernel(const LcsPair* pairs, const uint8_t* as, const uint8_t* bs,
+                                                      const uint8_t* sym_id, int64_t* lcs_out, double* ratio_out) {
+  __shared__ unsigned long long pm[8][64];
+  const LcsPair P = pairs[blockIdx.x];
+  const int lane = threadIdx.x;
+  // pattern = the shorter string, text = the longer one
+  const bool swap = P.la > P.lb;
+  const uint8_t* pat = swap ? bs + P.b_off : as + P.a_off;
+  const uint8_t* txt = swap ? as + P.a_off : bs + P.b_off;
+  const int m = swap ? P.lb : P.la, n = swap ? P.la : P.lb;
+  int64_t lcs = 0;
+  if (m > 0) {
+    unsigned long long mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 64; ++i) {
+      const int pos = 64 * lane + i;
+      const int id = pos < m ? (int)sym_id[pat[pos]] : 255;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mk[k] |= (unsigned long long)(id == k) << i;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pm[k][lane] = mk[k];
+    __syncthreads();
+    unsigned long long V = ~0ull;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int tid = j0 + lane < n ? (int)sym_id[txt[j0 + lane]] : 255;
+      const int cnt = n - j0 < 64 ? n - j0 : 64;
+      int id = __builtin_amdgcn_readlane(tid, 0);
+      unsigned long long cur = id < 8 ? pm[id][lane] : 0ull;
+      for (int t = 0; t < cnt; ++t) {
+        const int idn = __builtin_amdgcn_readlane(tid, t + 1 < cnt ? t + 1 : t);
+        const unsigned long long nxt = idn < 8 ? pm[idn][lane] : 0ull;
+        const unsigned long long U = V & cur;
+        unsigned long long sum = V + U;
+        const unsigned long long gen = __ballot(sum < V), pass = __ballot(sum == ~0ull);
+        const unsigned long long carry = (pass + (gen << 1)) ^ pass;
+        sum += (carry >> lane) & 1ull;
+        V = sum | (V - U);
+        cur = nxt;
+      }
+    }
+    // zeros of V among the pattern's m bits
+    const int valid = m - 64 * lane;
+    const unsigned long long vm = valid >= 64 ? ~0ull : valid <= 0 ? 0ull : ((1ull << valid) - 1);
+    int z = (int)__popcll(~V & vm);
+    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+    lcs = z;
+  }
+  if (lane == 0) {
+    const int64_t maximum = (int64_t)P.la + P.lb;
+    const int64_t dist = maximum - 2 * lcs;
+    const double norm_dist = maximum ? (double)dist / (double)maximum : 0.0;
+    const double norm_sim = 1.0 - norm_dist;
+    lcs_out[blockIdx.x] = lcs;
+    ratio_out[blockIdx.x] = norm_sim * 100.0;
+  }
+}
+
 // ------------------------------------------------------------------- ABI
 
 struct svdss_aln_batch {
@@ -491,13 +555,46 @@ extern "C" int svdss_indel_ratio_batch(const uint8_t* a, const int64_t* a_off, c
   const hipStream_t st = R.stream;
   HIPCHK2(R.arena.reserve(DevArena::padded((size_t)atot) + DevArena::padded((size_t)btot) +
                           DevArena::padded(sizeof(LcsPair) * (size_t)n_pairs) + DevArena::padded(sizeof(int32_t) * (size_t)ws) +
-                          DevArena::padded(sizeof(int64_t) * (size_t)n_pairs) + DevArena::padded(sizeof(double) * (size_t)n_pairs)));
+                          DevArena::padded(sizeof(int64_t) * (size_t)n_pairs) + DevArena::padded(sizeof(double) * (size_t)n_pairs) +
+                          DevArena::padded(256)));
   struct { void* p; } d_a{R.arena.take((size_t)atot)}, d_b{R.arena.take((size_t)btot)},
       d_pairs{R.arena.take(sizeof(LcsPair) * (size_t)n_pairs)}, d_ws{R.arena.take(sizeof(int32_t) * (size_t)ws)},
       d_lcs{R.arena.take(sizeof(int64_t) * (size_t)n_pairs)}, d_ratio{R.arena.take(sizeof(double) * (size_t)n_pairs)};
   if (atot) HIPCHK2(hipMemcpyAsync(d_a.p, a + a_off[0], (size_t)atot, hipMemcpyHostToDevice, st));
   if (btot) HIPCHK2(hipMemcpyAsync(d_b.p, bsy + b_off[0], (size_t)btot, hipMemcpyHostToDevice, st));
   HIPCHK2(hipMemcpyAsync(d_pairs.p, hp.data(), sizeof(LcsPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+  // the bit-parallel kernel takes batches over at most 8 distinct symbols whose shorter strings fit 64 x 64 bits
+  bool bits_ok = !getenv("SVDSS_RATIO_DP");
+  uint8_t sym_id[256];
+  if (bits_ok) {
+    for (int64_t i = 0; i < n_pairs && bits_ok; ++i) bits_ok = std::min(hp[(size_t)i].la, hp[(size_t)i].lb) <= 4096;
+    uint8_t any = 0;
+    for (int64_t i = 0; i < atot; ++i) any |= a[a_off[0] + i];
+    for (int64_t i = 0; i < btot; ++i) any |= bsy[b_off[0] + i];
+    memset(sym_id, 255, sizeof sym_id);
+    if (any < 8) {
+      for (int k = 0; k < 8; ++k) sym_id[k] = (uint8_t)k;
+    } else if (bits_ok) {
+      bool seen[256] = {false};
+      for (int64_t i = 0; i < atot; ++i) seen[a[a_off[0] + i]] = true;
+      for (int64_t i = 0; i < btot; ++i) seen[bsy[b_off[0] + i]] = true;
+      int nd = 0;
+      for (int c = 0; c < 256; ++c)
+        if (seen[c]) { if (nd < 8) sym_id[c] = (uint8_t)nd; ++nd; }
+      if (nd > 8) bits_ok = false;
+    }
+  }
+  if (bits_ok) {
+    void* d_map = R.arena.take(256);
+    HIPCHK2(hipMemcpyAsync(d_map, sym_id, 256, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lcs_bits_kernel, dim3((unsigned)n_pairs), dim3(64), 0, st, (const LcsPair*)d_pairs.p,
+                       (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (const uint8_t*)d_map, (int64_t*)d_lcs.p, (double*)d_ratio.p);
+    HIPCHK2(hipGetLastError());
+    HIPCHK2(hipMemcpyAsync(ratio_out, d_ratio.p, sizeof(double) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
+    if (lcs_out) HIPCHK2(hipMemcpyAsync(lcs_out, d_lcs.p, sizeof(int64_t) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
+    HIPCHK2(hipStreamSynchronize(st));   // (sym_id is a local: the copy must have left it)
+    return SVDSS_OK;
+  }
   const size_t lds_need = sizeof(int32_t) * 3 * (size_t)(la_max + 1) + (size_t)la_max + (size_t)lb_max + 16;
   if (lds_need <= 150 * 1024) {
     HIPCHK2(hipFuncSetAttribute((const void*)lcs_ratio_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));

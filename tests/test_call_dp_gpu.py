@@ -1,5 +1,7 @@
 """Call-side DP kernels (global dual-affine alignment with traceback; LCS ratio) against the
 oracle: scores, CIGARs and ratios bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,3 +105,41 @@ def test_fuzz_ratio_matches_oracle():
     b = a[:2500] + a[2600:]
     ratio, lcs = caller.fuzz_ratio([a], [b])
     assert lcs[0] == O.lcs(a, b) and ratio[0] == O.fuzz_ratio(a, b) and ratio[0] > 70
+
+
+def test_fuzz_ratio_bit_parallel_kernel():
+    """batches the bit-parallel LCS kernel takes (at most 8 distinct symbols, shorter string <= 4,096): symbol codes 0..3
+    as the bench passes them, ASCII alleles as `SVDSS call` does; word boundaries of the 64 x 64-bit vector, carries that
+    run through every word (equal strings), empty strings, a text much longer than the pattern"""
+    rng = np.random.default_rng(21)
+    for alphabet in (np.arange(4, dtype=np.uint8), np.frombuffer(b"ACGTN", dtype=np.uint8), np.array([7, 200, 255], dtype=np.uint8)):
+        a_list, b_list = [], []
+        for la in (0, 1, 2, 63, 64, 65, 127, 128, 129, 1000, 4095, 4096):
+            a = rng.choice(alphabet, size=la)
+            for kind in range(4):
+                if kind == 0:
+                    b = a.copy()                                        # equal: the carry runs through all words
+                elif kind == 1:
+                    b = a.copy()
+                    for _ in range(1 + la // 50):
+                        if len(b):
+                            b[int(rng.integers(0, len(b)))] = rng.choice(alphabet)
+                    b = np.delete(b, slice(la // 3, la // 3 + la // 10))
+                elif kind == 2:
+                    b = rng.choice(alphabet, size=int(rng.integers(0, 3000)))
+                else:
+                    b = np.concatenate([rng.choice(alphabet, size=700), a, rng.choice(alphabet, size=900)])   # longer text
+                a_list.append(bytes(a.astype(np.uint8)))
+                b_list.append(bytes(b.astype(np.uint8)))
+        a_list.append(bytes(np.full(4096, alphabet[0], dtype=np.uint8)))
+        b_list.append(bytes(np.full(20000, alphabet[0], dtype=np.uint8)))
+        ratio, lcs = caller.fuzz_ratio(a_list, b_list)
+        for a, b, r, l in zip(a_list, b_list, ratio.tolist(), lcs.tolist()):
+            assert l == O.lcs(a, b), (len(a), len(b))
+            assert r == O.fuzz_ratio(a, b)
+        os.environ["SVDSS_RATIO_DP"] = "1"                              # the anti-diagonal kernel on the same batch
+        try:
+            ratio2, lcs2 = caller.fuzz_ratio(a_list, b_list)
+        finally:
+            del os.environ["SVDSS_RATIO_DP"]
+        assert (ratio2 == ratio).all() and (lcs2 == lcs).all()
