@@ -789,7 +789,9 @@ class BamReader {
       if (rc == 0) rc = gpu_.inflate(&g.h, gpu_device_, src, (int64_t)avail, tb.data(), (int64_t)tb.size(), g.d_out, c.data.data(), (int64_t)total, &bad);
       put_gpu_obj(g);
       const auto tg = std::chrono::steady_clock::now();
-      if (rc != 0) c.err = bad >= 0 ? "BGZF inflate failed (GPU)" : "GPU inflate call failed";
+      bool host_instead = false;
+      if (rc != 0 && bad >= 0) c.err = "BGZF inflate failed";
+      else if (rc != 0) host_instead = true;   // (no memory, no device ...: this chunk goes to the host workers after all)
       else {
         // the footers' CRC32, here on the host (libdeflate's runs at tens of GB/s per core)
         for (const BlockRef& b : blocks) {
@@ -802,8 +804,8 @@ class BamReader {
       const auto tc = std::chrono::steady_clock::now();
       t_gpu_ += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(tg - ts2).count();
       t_crc_ += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(tc - tg).count();
-      ++n_gpu_chunks_;
-      return c;
+      if (!host_instead) { ++n_gpu_chunks_; return c; }
+      if (!gpu_warned_.exchange(true)) fprintf(stderr, "[bam_reader] GPU inflate call failed (code %d): the host inflates this chunk\n", rc);
     }
     // groups of 8 blocks per task
     const size_t per = 8, n_tasks = (blocks.size() + per - 1) / per;
@@ -879,6 +881,7 @@ class BamReader {
   std::vector<GpuObj> gpu_objs_;
   std::atomic<long long> t_gpu_{0}, t_crc_{0}, n_gpu_chunks_{0};
   std::atomic<int> cpu_inflight_{0};   // chunks with the host pool right now
+  std::atomic<bool> gpu_warned_{false};
   GpuObj take_gpu_obj() {
     std::lock_guard<std::mutex> lk(gpu_m_);
     if (gpu_objs_.empty()) return GpuObj();
