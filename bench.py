@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--e2e-reads", type=int, default=1032000, help="reads in the BAM of the end-to-end run")
     ap.add_argument("--no-call-dp", action="store_true", help="search only (value is then NOT the headline metric)")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: leave the SFS on the ranks")
+    ap.add_argument("--search-threads", type=int, default=1,
+                    help="batch objects / threads that take the steps' searches in turn (the launch of step i+1 is under "
+                         "way while step i runs its tail kernels)")
     ap.add_argument("--call-threads", type=int, default=3,
                     help="steps whose call-side DP may be in flight at once (0: no pipelining, search and call of a "
                          "step run back to back)")
@@ -322,7 +325,7 @@ def main():
     # that the call-side DP of earlier steps overlaps the search of the next one
     sstream = torch.cuda.Stream(device=device)
 
-    def search(assemble=True):
+    def search(assemble=True, pp=pp, sstream=sstream):
         pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
                                    stream=sstream.cuda_stream, assemble=assemble, fetch=False)
         if gather and assemble:
@@ -330,6 +333,11 @@ def main():
                 counts, qs, ln = pp.device_results()
                 multi.gather_sfs(counts, qs, ln)
             sstream.synchronize()
+
+    # --search-threads S > 1: S batch objects / streams / threads take the steps' searches in turn, so that the launch of
+    # step i+1 is under way while step i runs its short tail kernels and host-side waits (order, scan, gather)
+    searchers = [(pp, sstream)] + [(svdss_amd.PingPong(ix, assemble=True), torch.cuda.Stream(device=device))
+                                   for _ in range(max(0, args.search_threads - 1))]
 
     stats = {"kernel_ms": [], "pipeline_ms": [], "poa_ms": [], "aln_ms": [], "call_wall_ms": []}
 
@@ -370,13 +378,34 @@ def main():
         threads = [threading.Thread(target=caller, args=(w,)) for w in workers]
         for t in threads:
             t.start()
+        steps_q = queue.Queue()
+        for i in range(n_steps):
+            steps_q.put(i)
+
+        def searcher(spp, sst):
+            torch.cuda.set_device(local_rank)
+            try:
+                while True:
+                    try:
+                        i = steps_q.get_nowait()
+                    except queue.Empty:
+                        return
+                    search(pp=spp, sstream=sst)
+                    if record:
+                        with lock:
+                            stats["kernel_ms"].append(spp.last_search_kernel_ms)   # HIP events on the search stream
+                            stats["pipeline_ms"].append(spp.last_kernel_ms)
+                    todo.put(i)
+            except BaseException as e:   # noqa: BLE001
+                errors.append(e)
+
+        sthreads = [threading.Thread(target=searcher, args=sp) for sp in searchers[1:]]
         try:
-            for i in range(n_steps):
-                search()
-                if record:
-                    stats["kernel_ms"].append(pp.last_search_kernel_ms)   # HIP events on the search stream
-                    stats["pipeline_ms"].append(pp.last_kernel_ms)
-                todo.put(i)
+            for t in sthreads:
+                t.start()
+            searcher(*searchers[0])
+            for t in sthreads:
+                t.join()
         finally:
             for _ in threads:
                 todo.put(None)
