@@ -240,7 +240,7 @@ class BamReader {
               t_wait_ * 1e-9, threads_);
     drain();
     pool_.reset();
-    for (GpuObj& g : gpu_objs_) { if (g.h) gpu_.inflate_free(g.h); if (g.d_out) gpu_.device_free(gpu_device_, g.d_out); }
+    for (GpuObj& g : gpu_objs_) { if (g.h) gpu_.inflate_free(g.h); if (g.d_out) gpu_.device_free(g.dev, g.d_out); }
     if (map_) munmap((void*)map_, map_size_);
     if (f_) fclose(f_);
   }
@@ -260,8 +260,10 @@ class BamReader {
     int (*host_alloc)(int64_t bytes, void** out) = nullptr;
     void (*host_free)(void* p) = nullptr;
   };
-  void enable_gpu_inflate(const GpuInflateApi& api, int device, int percent) {
+  // (n_devices > 1: the chunks go to devices device, device + 1, ... in turn -- `search --gpus N` inflates on all of them)
+  void enable_gpu_inflate(const GpuInflateApi& api, int device, int percent, int n_devices = 1) {
     gpu_ = api; gpu_device_ = device; gpu_percent_ = std::max(0, std::min(101, percent));   // (101: every chunk)
+    gpu_n_devices_ = std::max(1, n_devices);
     pin_hooks().alloc = api.host_alloc; pin_hooks().free_ = api.host_free;
   }
   const std::string& error() const { return err_; }
@@ -776,17 +778,17 @@ class BamReader {
       struct Blk { int64_t coff; int32_t clen; int32_t isize; int64_t uoff; };
       std::vector<Blk> tb(blocks.size());
       for (size_t i = 0; i < blocks.size(); ++i) tb[i] = Blk{(int64_t)blocks[i].coff, (int32_t)blocks[i].clen, (int32_t)blocks[i].isize, (int64_t)blocks[i].uoff};
-      GpuObj g = take_gpu_obj();
+      GpuObj g = take_gpu_obj(gpu_device_ + (int)(ticket % (uint64_t)gpu_n_devices_));
       int rc = 0;
       if (g.d_cap < total + 256) {
-        if (g.d_out) gpu_.device_free(gpu_device_, g.d_out);
+        if (g.d_out) gpu_.device_free(g.dev, g.d_out);
         g.d_out = nullptr; g.d_cap = 0;
         const size_t want = total + total / 4 + 4096;
-        rc = gpu_.device_alloc(gpu_device_, (int64_t)want, &g.d_out);
+        rc = gpu_.device_alloc(g.dev, (int64_t)want, &g.d_out);
         if (rc == 0) g.d_cap = want;
       }
       int64_t bad = -1;
-      if (rc == 0) rc = gpu_.inflate(&g.h, gpu_device_, src, (int64_t)avail, tb.data(), (int64_t)tb.size(), g.d_out, c.data.data(), (int64_t)total, &bad);
+      if (rc == 0) rc = gpu_.inflate(&g.h, g.dev, src, (int64_t)avail, tb.data(), (int64_t)tb.size(), g.d_out, c.data.data(), (int64_t)total, &bad);
       put_gpu_obj(g);
       const auto tg = std::chrono::steady_clock::now();
       bool host_instead = false;
@@ -874,19 +876,24 @@ class BamReader {
     dst.alloc(bytes, pinned);
   }
   // per-call state of the GPU inflate (stream, device buffers), one per concurrent loader
-  struct GpuObj { void* h = nullptr; void* d_out = nullptr; size_t d_cap = 0; };
+  struct GpuObj { void* h = nullptr; void* d_out = nullptr; size_t d_cap = 0; int dev = 0; };
   GpuInflateApi gpu_;
-  int gpu_device_ = 0, gpu_percent_ = 100;
+  int gpu_device_ = 0, gpu_percent_ = 100, gpu_n_devices_ = 1;
   std::mutex gpu_m_;
   std::vector<GpuObj> gpu_objs_;
   std::atomic<long long> t_gpu_{0}, t_crc_{0}, n_gpu_chunks_{0};
   std::atomic<int> cpu_inflight_{0};   // chunks with the host pool right now
   std::atomic<bool> gpu_warned_{false};
-  GpuObj take_gpu_obj() {
+  GpuObj take_gpu_obj(int dev) {
     std::lock_guard<std::mutex> lk(gpu_m_);
-    if (gpu_objs_.empty()) return GpuObj();
-    GpuObj g = gpu_objs_.back();
-    gpu_objs_.pop_back();
+    for (size_t i = gpu_objs_.size(); i-- > 0;)
+      if (gpu_objs_[i].dev == dev) {
+        GpuObj g = gpu_objs_[i];
+        gpu_objs_.erase(gpu_objs_.begin() + (long)i);
+        return g;
+      }
+    GpuObj g;
+    g.dev = dev;
     return g;
   }
   void put_gpu_obj(const GpuObj& g) { std::lock_guard<std::mutex> lk(gpu_m_); gpu_objs_.push_back(g); }

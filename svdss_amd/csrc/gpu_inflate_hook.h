@@ -9,7 +9,7 @@
 // workers only; 1..99 = that share of the chunks goes to the GPU; 100 = the GPU takes whatever the host workers cannot
 // start at once; 101 (default) = every chunk (the host's cores are better spent on the other stages).  Returns whether
 // the GPU path is on.
-inline bool svdss_enable_gpu_inflate(BamReader& bam, int device = 0) {
+inline bool svdss_enable_gpu_inflate(BamReader& bam, int device = 0, int n_devices = 1) {
   const int pct = getenv("SVDSS_GPU_INFLATE") ? atoi(getenv("SVDSS_GPU_INFLATE")) : 101;
   if (pct <= 0 || svdss_device_count() <= 0) return false;
   BamReader::GpuInflateApi api;
@@ -23,6 +23,6 @@ inline bool svdss_enable_gpu_inflate(BamReader& bam, int device = 0) {
   api.device_free = svdss_device_free;
   api.host_alloc = svdss_host_alloc;
   api.host_free = svdss_host_free;
-  bam.enable_gpu_inflate(api, device, pct);
+  bam.enable_gpu_inflate(api, device, pct, n_devices);
   return true;
 }

@@ -317,7 +317,8 @@ int main_search(const Options& o) {
   FastxReader* fx = nullptr;
   if (bam_mode) {
     bam = new BamReader(o.bam, o.io_threads);
-    svdss_enable_gpu_inflate(*bam);   // (BGZF blocks inflated on the GPU, csrc/inflate.hip; SVDSS_GPU_INFLATE)
+    // (BGZF blocks inflated on the GPU, csrc/inflate.hip, on every GPU of --gpus in turn; SVDSS_GPU_INFLATE)
+    svdss_enable_gpu_inflate(*bam, 0, std::min(n_gpus, n_dev));
     if (!bam->ok() || !bam->read_header()) die("cannot read " + o.bam + ": " + bam->error());
   } else {
     logmsg("warning", "FASTX mode is not optimized (higher running times and larger SFSs set).");
