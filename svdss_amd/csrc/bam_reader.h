@@ -227,17 +227,17 @@ class BamReader {
     // in the kernel (the inflate rate did not move between 48 and 224 workers)
     if (map_ && getenv("SVDSS_BAM_POPULATE")) prefault_ = std::thread([this] { prefault_loop(); });
   }
+  // SVDSS_DEBUG: the reader's counters on stderr (once; also called by a program that ends without destructors)
+  void report() {
+    if (reported_ || !getenv("SVDSS_DEBUG")) return;
+    reported_ = true;
+    report_impl();
+  }
   ~BamReader() {
     { std::lock_guard<std::mutex> lk(file_m_); prefault_stop_ = true; }
     file_cv_.notify_all();
     if (prefault_.joinable()) prefault_.join();
-    if (getenv("SVDSS_DEBUG") && n_gpu_chunks_.load())
-      fprintf(stderr, "[bam_reader] %llu chunks inflated on the GPU (%.3f s summed wall incl. copies), CRC check %.3f s\n",
-              (unsigned long long)n_gpu_chunks_.load(), t_gpu_.load() * 1e-9, t_crc_.load() * 1e-9);
-    if (getenv("SVDSS_DEBUG"))
-      fprintf(stderr, "[bam_reader] %llu chunks: locate %.3f s (under the file lock), buffers %.3f s (%llu fresh), inflate %.3f s summed wall, parser waited %.3f s; %d workers\n",
-              (unsigned long long)n_launched_, t_scan_.load() * 1e-9, t_buf_.load() * 1e-9, (unsigned long long)n_fresh_.load(), t_inf_.load() * 1e-9,
-              t_wait_ * 1e-9, threads_);
+    report();
     drain();
     pool_.reset();
     for (GpuObj& g : gpu_objs_) { if (g.h) gpu_.inflate_free(g.h); if (g.d_out) gpu_.device_free(g.dev, g.d_out); }
@@ -247,6 +247,9 @@ class BamReader {
   BamReader(const BamReader&) = delete;
   BamReader& operator=(const BamReader&) = delete;
   bool ok() const { return f_ != nullptr; }
+  // chunks located / inflated ahead of the parser (before the first read; a reader that only looks at the first few
+  // thousand records should not pull the whole file through the inflater)
+  void set_ahead(size_t n) { ahead_ = std::max<size_t>(1, n); }
 
   // BGZF blocks inflated on the GPU (csrc/inflate.hip) instead of by the host workers: `percent` of the chunks (the
   // rest stay with the host pool, which otherwise idles); the CRC32 of every block is still checked here, on the host.
@@ -910,6 +913,17 @@ class BamReader {
   std::vector<uint8_t> carry_;     // partial block at the end of the previous read (guarded by file_m_)
   const uint8_t* map_ = nullptr;   // the whole file, when it could be mapped
   size_t map_size_ = 0, map_pos_ = 0;
+  bool reported_ = false;
+  void report_impl() {
+    if (n_gpu_chunks_.load())
+      fprintf(stderr, "[bam_reader] %llu chunks inflated on the GPU (%.3f s summed wall incl. copies), CRC check %.3f s\n",
+              (unsigned long long)n_gpu_chunks_.load(), t_gpu_.load() * 1e-9, t_crc_.load() * 1e-9);
+    {
+      fprintf(stderr, "[bam_reader] %llu chunks: locate %.3f s (under the file lock), buffers %.3f s (%llu fresh), inflate %.3f s summed wall, parser waited %.3f s; %d workers\n",
+              (unsigned long long)n_launched_, t_scan_.load() * 1e-9, t_buf_.load() * 1e-9, (unsigned long long)n_fresh_.load(), t_inf_.load() * 1e-9,
+              t_wait_ * 1e-9, threads_);
+    }
+  }
   bool launched_eof_ = false;
   std::string pending_err_;
   bool eof_seen_ = false;

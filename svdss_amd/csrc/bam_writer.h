@@ -60,7 +60,12 @@ class BgzfWriter {
     };
     static const Lib& lib() { static Lib l; return l; }
     void* c = nullptr;
-    Deflater() { if (lib().alloc) c = lib().alloc(6); }
+    // (htslib's default for BAM is level 6; SVDSS_BAM_LEVEL = 1..9 for a pipe into a sorter, where speed matters more)
+    static int level() {
+      static const int l = [] { const char* e = getenv("SVDSS_BAM_LEVEL"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : v > 9 ? 9 : v; }();
+      return l;
+    }
+    Deflater() { if (lib().alloc) c = lib().alloc(level()); }
     ~Deflater() { if (c) lib().free_(c); }
     Deflater(const Deflater&) = delete;
     Deflater& operator=(const Deflater&) = delete;
@@ -72,7 +77,7 @@ class BgzfWriter {
     if (clen == 0) {   // zlib (also: the empty block, and a block libdeflate could not fit)
       z_stream zs;
       memset(&zs, 0, sizeof zs);
-      deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+      deflateInit2(&zs, Deflater::level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
       zs.next_in = const_cast<uint8_t*>(in);
       zs.avail_in = (uInt)n;
       zs.next_out = out + 18;

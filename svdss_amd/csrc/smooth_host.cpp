@@ -8,7 +8,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <chrono>
 #include <string>
+
+#include <unistd.h>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -142,10 +149,15 @@ int main_smooth(const CallOptions& o) {
     if (r.tid < 0) die("core.tid < 0. Why are we here? Please check");
     return r.tid < (int)names.size() && chrom.count(names[(size_t)r.tid]) > 0;
   };
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  const bool dbg = getenv("SVDSS_DEBUG") != nullptr;
+  double t_read = 0, t_proc = 0, t_write = 0;
   // compute_maxaccuracy (smoother.cpp:259-346)
   double al_accuracy;
   {
     BamReader bam(o.bam);
+    bam.set_ahead(2);   // (10,000 records are a few chunks)
     svdss_enable_gpu_inflate(bam);
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
     std::vector<double> acc;
@@ -164,6 +176,7 @@ int main_smooth(const CallOptions& o) {
       al_accuracy = (1.0 - h) * acc[(size_t)lo] + h * acc[(size_t)hi];
     }
   }
+  if (dbg) fprintf(stderr, "[smooth] accuracy threshold at +%.3f s\n", since());
   BamReader bam(o.bam);
   svdss_enable_gpu_inflate(bam);
   if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
@@ -252,19 +265,59 @@ int main_smooth(const CallOptions& o) {
   }
   // batches of eligible records: read in order, smoothed by T workers, written in order (the reference's
   // batch loop, smoother.cpp:441-537)
+  // Three stages run side by side, joined by short queues: a thread reads and filters the next batch (BGZF inflate on
+  // the GPU or the host workers), this thread smooths the current one (GPU kernel + T finishing threads, or T host
+  // workers), a thread deflates and writes the previous one (T workers).  Output order = input order.
   const size_t batch_size = 4096;
-  std::vector<BamRecord> batch;
-  std::vector<ByteSink> outs;
-  int rc = 1;
-  while (rc > 0) {
-    batch.clear();
-    while (batch.size() < batch_size) {
-      BamRecord r;
-      rc = bam.next(r);
-      if (rc <= 0) break;
-      if (!eligible(r, bam.ref_names())) continue;   // dropped from the output (smoother.cpp:509-537)
-      batch.push_back(std::move(r));
+  struct Item { std::vector<BamRecord> batch; std::vector<ByteSink> outs; };
+  struct ItemQueue {
+    std::mutex m; std::condition_variable cv; std::deque<std::unique_ptr<Item>> q; bool closed = false; size_t cap = 2;
+    void push(std::unique_ptr<Item> it) {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return q.size() < cap; });
+      q.push_back(std::move(it));
+      cv.notify_all();
     }
+    std::unique_ptr<Item> pop() {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return !q.empty() || closed; });
+      if (q.empty()) return nullptr;
+      std::unique_ptr<Item> it = std::move(q.front());
+      q.pop_front();
+      cv.notify_all();
+      return it;
+    }
+    void close() { std::lock_guard<std::mutex> lk(m); closed = true; cv.notify_all(); }
+  } q_read, q_write;
+  int rc = 1;
+  std::thread reader([&] {
+    int r_rc = 1;
+    while (r_rc > 0) {
+      const auto t0 = std::chrono::steady_clock::now();
+      std::unique_ptr<Item> it(new Item);
+      while (it->batch.size() < batch_size) {
+        BamRecord r;
+        r_rc = bam.next(r);
+        if (r_rc <= 0) break;
+        if (!eligible(r, bam.ref_names())) continue;   // dropped from the output (smoother.cpp:509-537)
+        it->batch.push_back(std::move(r));
+      }
+      t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (!it->batch.empty()) q_read.push(std::move(it));
+    }
+    rc = r_rc;
+    q_read.close();
+  });
+  bool write_ok = true;
+  std::thread writer([&] {
+    while (std::unique_ptr<Item> it = q_write.pop()) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (const ByteSink& sk : it->outs) w.write(sk.v.data(), sk.v.size());
+      t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    write_ok = w.finish();
+  });
+  auto process = [&](std::vector<BamRecord>& batch, std::vector<ByteSink>& outs) {
     outs.assign(batch.size(), ByteSink());
     if (dref && !batch.empty()) {
       // the CIGAR walk of the whole batch on the GPU (csrc/place.hip, smooth_kernel: one wavefront per record); the host
@@ -334,8 +387,7 @@ int main_smooth(const CallOptions& o) {
           for (std::thread& th : pool) th.join();
         }
       }
-      for (const ByteSink& sk : outs) w.write(sk.v.data(), sk.v.size());
-      continue;
+      return;
     }
     auto work = [&](size_t t, size_t nt) { for (size_t i = t; i < batch.size(); i += nt) smooth_one(batch[i], outs[i]); };
     const size_t nt = std::min<size_t>((size_t)T, batch.size());
@@ -346,10 +398,28 @@ int main_smooth(const CallOptions& o) {
       work(0, nt);
       for (std::thread& th : pool) th.join();
     }
-    for (const ByteSink& sk : outs) w.write(sk.v.data(), sk.v.size());
+  };
+  if (dbg) fprintf(stderr, "[smooth] reference on the device at +%.3f s\n", since());
+  while (std::unique_ptr<Item> it = q_read.pop()) {
+    const auto t0 = std::chrono::steady_clock::now();
+    process(it->batch, it->outs);
+    t_proc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<BamRecord>().swap(it->batch);
+    q_write.push(std::move(it));
   }
+  q_write.close();
+  reader.join();
+  writer.join();
+  if (dbg) fprintf(stderr, "[smooth] done at +%.3f s; stage busy seconds: read + filter %.3f, smooth %.3f, deflate + write %.3f\n", since(), t_read, t_proc, t_write);
   svdss_ref_free(dref);
   if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
-  if (!w.finish()) die("error writing the BAM to stdout");
+  if (!write_ok) die("error writing the BAM to stdout");
+  if (!getenv("SVDSS_CLEAN_EXIT")) {   // (see main_search: the teardown of page-locked buffers is left to the OS)
+    bam.report();
+    fprintf(stderr, "[smooth] [info] All done!\n");
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);
+  }
   return 0;
 }
