@@ -198,109 +198,113 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
   if (s.len <= 0) return o;
   if (s.mode & SV_M_PARTIAL) return o;
   if (s.mode & SV_M_PEEK) { o.op = SV_OP_PEEK; return o; }
+  // One pass of this loop takes a lane from the end of a phase (interval empty) through the start of the next one to
+  // its table lookup: the phase-end handling comes first and falls through into the phase start.  (With the phase
+  // start on top, as ping_pong.cpp is written, every phase end cost the whole wavefront a second pass over the body.)
   for (;;) {
     if (s.mode & SV_M_SET) { o.op = SV_OP_SET; return o; }
     if (s.mode & SV_M_TEXT) {
       o.op = (off + s.pos >= 64) ? SV_OP_TEXT : SV_OP_TEXT_SLOW;
       return o;
     }
-    const int dir = s.mode & SV_M_DIR;
-    if (s.mode & SV_M_START) {
-      const int K = ix.k;
-      const int st = s.pos;
-      const int first = dir ? st : st - K + 1;  // lowest read position of the K-mer
-      if (K > 0 && first >= 0 && first + K <= s.len) {
-        if (first < s.wrel || first + K > s.wrel + 64) {    // the K symbols must be resident
-          o.op = SV_OP_FILL;
-          o.a = ((off + first - 20) >> 4);
-          return o;
-        }
-        uint32_t key;
-        if (sv_ring_kmer(g, off + first, K, key)) {
-          o.op = SV_OP_TABLE;
-          o.a = dir ? sv_key_revcomp(key, K) : key;
-          return o;
-        }
-      }
-      // fewer than K symbols left in this direction, or an N among them: start
-      // from the single symbol like the reference does (rb3_fmd_set_intv, :12 / :30)
-      if (!sv_in_window(s, st)) {
-        o.op = SV_OP_FILL;
-        o.a = ((off + st - 24) >> 4);
-        return o;
-      }
-      int c = sv_ring_sym(g, off + st);
-      if (dir) c = svdss_comp(c);
-      s.lo = (P)svdss_acc(ix, c);
-      s.hi = (P)svdss_acc(ix, c + 1);
-      s.mode &= ~SV_M_START;
-    }
-    const bool nonempty = s.hi > s.lo;
-    if (!dir) {
-      if (nonempty && s.pos > 0) {                    // ping_pong.cpp:15
-        if (s.mode & SV_M_FEWSET) {                   // the survivors of a FEW entry: their text positions, then SET
-          o.op = SV_OP_SA_SET;
-          o.a = (int64_t)s.lo;
-          return o;
-        }
-        if (s.hi - s.lo == 1 && ix.sa != nullptr) {   // single occurrence: switch to TEXT
-          o.op = SV_OP_SA;
-          o.a = (int64_t)s.lo;
-          return o;
-        }
-        if (use_set && s.hi - s.lo <= SV_SET_MAX && ix.sa != nullptr && off >= 64) {
-          // a few left: if they survived SV_SET_AFTER more symbols they are copies, follow them all in the text
-          if (((s.mode & SV_LFC_MASK) >> SV_LFC_SHIFT) >= SV_SET_AFTER) {
+    if (!(s.mode & SV_M_START)) {
+      const bool nonempty = s.hi > s.lo;
+      if (!(s.mode & SV_M_DIR)) {
+        if (nonempty && s.pos > 0) {                    // ping_pong.cpp:15
+          if (s.mode & SV_M_FEWSET) {                   // the survivors of a FEW entry: their text positions, then SET
             o.op = SV_OP_SA_SET;
             o.a = (int64_t)s.lo;
             return o;
           }
-          s.mode += 1 << SV_LFC_SHIFT;
-        }
-        const int np = s.pos - 1;
-        if (!sv_in_window(s, np)) {
-          o.op = SV_OP_FILL;
-          o.a = ((off + np - 40) >> 4);
+          if (s.hi - s.lo == 1 && ix.sa != nullptr) {   // single occurrence: switch to TEXT
+            o.op = SV_OP_SA;
+            o.a = (int64_t)s.lo;
+            return o;
+          }
+          if (use_set && s.hi - s.lo <= SV_SET_MAX && ix.sa != nullptr && off >= 64) {
+            // a few left: if they survived SV_SET_AFTER more symbols they are copies, follow them all in the text
+            if (((s.mode & SV_LFC_MASK) >> SV_LFC_SHIFT) >= SV_SET_AFTER) {
+              o.op = SV_OP_SA_SET;
+              o.a = (int64_t)s.lo;
+              return o;
+            }
+            s.mode += 1 << SV_LFC_SHIFT;
+          }
+          const int np = s.pos - 1;
+          if (!sv_in_window(s, np)) {
+            o.op = SV_OP_FILL;
+            o.a = ((off + np - 40) >> 4);
+            return o;
+          }
+          s.pos = np;
+          s.c = sv_ring_sym(g, off + np);               // :21
+          o.op = SV_OP_LF;
           return o;
         }
-        s.pos = np;
-        s.c = sv_ring_sym(g, off + np);               // :21
-        o.op = SV_OP_LF;
-        return o;
+        if (s.pos == 0 && nonempty) return o;           // :24 -> DONE
+        s.begin = s.pos;                                // :28
+        s.mode = (s.mode & ~SV_LFC_MASK) | SV_M_DIR | SV_M_START;
+      } else {
+        if (nonempty) {                                 // :31
+          const int np = s.pos + 1;
+          if (np < s.len && !sv_in_window(s, np)) {
+            o.op = SV_OP_FILL;
+            o.a = ((off + np - 24) >> 4);
+            return o;
+          }
+          s.pos = np;
+          s.c = svdss_comp(np < s.len ? sv_ring_sym(g, off + np) : 0);  // :36, P[l] == 0
+          o.op = SV_OP_LF;
+          return o;
+        }
+        sv_emit(s, s.begin, s.pos - s.begin + 1, assemble, emit);  // :38-41
+        if (s.begin == 0) return o;                     // :42 -> DONE
+        if (s.begin < s.stop_lo) {
+          if (can_peek) {                               // ask the neighbour before going on
+            s.mode |= SV_M_PEEK;
+            s.c = 0;
+            o.op = SV_OP_PEEK;
+            return o;
+          }
+          if (++s.n_below >= SV_OVERRUN) {
+            s.mode |= SV_M_PARTIAL;                     // segment finished; the stitcher takes over
+            return o;
+          }
+        }
+        s.pos = s.pos - 1;                              // :47
+        s.mode = (s.mode & ~(SV_M_DIR | SV_LFC_MASK)) | SV_M_START;
       }
-      if (s.pos == 0 && nonempty) return o;           // :24 -> DONE
-      s.begin = s.pos;                                // :28
-      s.mode = (s.mode & ~SV_LFC_MASK) | SV_M_DIR | SV_M_START;
-    } else {
-      if (nonempty) {                                 // :31
-        const int np = s.pos + 1;
-        if (np < s.len && !sv_in_window(s, np)) {
-          o.op = SV_OP_FILL;
-          o.a = ((off + np - 24) >> 4);
-          return o;
-        }
-        s.pos = np;
-        s.c = svdss_comp(np < s.len ? sv_ring_sym(g, off + np) : 0);  // :36, P[l] == 0
-        o.op = SV_OP_LF;
-        return o;
-      }
-      sv_emit(s, s.begin, s.pos - s.begin + 1, assemble, emit);  // :38-41
-      if (s.begin == 0) return o;                     // :42 -> DONE
-      if (s.begin < s.stop_lo) {
-        if (can_peek) {                               // ask the neighbour before going on
-          s.mode |= SV_M_PEEK;
-          s.c = 0;
-          o.op = SV_OP_PEEK;
-          return o;
-        }
-        if (++s.n_below >= SV_OVERRUN) {
-          s.mode |= SV_M_PARTIAL;                     // segment finished; the stitcher takes over
-          return o;
-        }
-      }
-      s.pos = s.pos - 1;                              // :47
-      s.mode = (s.mode & ~(SV_M_DIR | SV_LFC_MASK)) | SV_M_START;
     }
+    // a phase starts (backward :12, forward :30): its first K symbols through the table
+    const int dir = s.mode & SV_M_DIR;
+    const int K = ix.k;
+    const int st = s.pos;
+    const int first = dir ? st : st - K + 1;  // lowest read position of the K-mer
+    if (K > 0 && first >= 0 && first + K <= s.len) {
+      if (first < s.wrel || first + K > s.wrel + 64) {    // the K symbols must be resident
+        o.op = SV_OP_FILL;
+        o.a = ((off + first - 20) >> 4);
+        return o;
+      }
+      uint32_t key;
+      if (sv_ring_kmer(g, off + first, K, key)) {
+        o.op = SV_OP_TABLE;
+        o.a = dir ? sv_key_revcomp(key, K) : key;
+        return o;
+      }
+    }
+    // fewer than K symbols left in this direction, or an N among them: start
+    // from the single symbol like the reference does (rb3_fmd_set_intv, :12 / :30)
+    if (!sv_in_window(s, st)) {
+      o.op = SV_OP_FILL;
+      o.a = ((off + st - 24) >> 4);
+      return o;
+    }
+    int c = sv_ring_sym(g, off + st);
+    if (dir) c = svdss_comp(c);
+    s.lo = (P)svdss_acc(ix, c);
+    s.hi = (P)svdss_acc(ix, c + 1);
+    s.mode &= ~SV_M_START;
   }
 }
 
@@ -389,18 +393,39 @@ SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_l
     if (pk + steps_max >= s.wrel + 64) steps_max = s.wrel + 63 - pk;
   }
   if (steps_max < 0) steps_max = 0;
-  int alive = (1 << size) - 1, e = 0;
-  bool emptied = false;
-  for (; e < steps_max; ++e) {
-    int c = sv_ring_sym(g, off + (dir ? pk + 1 + e : pk - 1 - e));
-    if (dir) c = svdss_comp(c);
-    int next = 0;
+  // All SVDSS_TAB_EXT steps at once: the read's next symbols in the order they are consumed, 3 bits each like the
+  // entry's; occurrence j agrees with the first m[j] of them.  Extension after extension keeps the occurrences that
+  // agree so far, so the interval empties at step max(m) + 1 -- or not within the steps_max symbols at hand.
+  uint32_t rs = 0;
+  {
+    const int64_t a0 = off + (dir ? pk + 1 : pk - SVDSS_TAB_EXT);   // lowest buffer position of the six
+    const int r0 = (int)((a0 & 63) >> 2);
+    const int sh = (int)(a0 & 3) * 8;
+    const uint32_t w0 = sv_ring_row(g, r0), w1 = sv_ring_row(g, r0 + 1), w2 = sv_ring_row(g, r0 + 2);
+    uint64_t w = (uint64_t)(uint32_t)(((((uint64_t)w1) << 32) | w0) >> sh) |
+                 ((uint64_t)(uint32_t)(((((uint64_t)w2) << 32) | w1) >> sh) << 32);
+    if (!dir) w = __builtin_bswap64(w << 16);                       // nearest symbol first
 #pragma unroll
-    for (int j = 0; j < SV_SET_MAX; ++j)
-      if (((alive >> j) & 1) && (int)((svdss_tab_ext(e_lo, e_info, j) >> (3 * e)) & 7u) == c) next |= 1 << j;
-    if (!next) { emptied = true; break; }
-    alive = next;
+    for (int e = 0; e < SVDSS_TAB_EXT; ++e) {
+      int c = (int)((w >> (8 * e)) & 7u);                           // (positions past steps_max: not looked at)
+      if (dir) c = svdss_comp(c);
+      rs |= (uint32_t)c << (3 * e);
+    }
   }
+  int m[SV_SET_MAX], e = -1;
+#pragma unroll
+  for (int j = 0; j < SV_SET_MAX; ++j) {
+    const uint32_t x = (svdss_tab_ext(e_lo, e_info, j) ^ rs) & 0x3ffffu;
+    const uint32_t y = (x | (x >> 1) | (x >> 2)) & 0x9249u;         // bit 3i: symbol i differs
+    int mj = y ? (__builtin_ctz(y) * 11) >> 5 : SVDSS_TAB_EXT;
+    if (mj > steps_max) mj = steps_max;
+    m[j] = j < size ? mj : -1;
+    if (m[j] > e) e = m[j];
+  }
+  const bool emptied = e < steps_max;
+  int alive = 0;
+#pragma unroll
+  for (int j = 0; j < SV_SET_MAX; ++j) if (m[j] >= e) alive |= 1 << j;
   if (emptied) {                          // extension e + 1 emptied the interval
     s.pos = dir ? pk + e + 1 : pk - e - 1;
     s.n_ext += e + 1;
