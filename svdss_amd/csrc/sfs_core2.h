@@ -23,6 +23,10 @@
 #pragma once
 #include "fmd_layout.h"
 
+#ifndef SV_COUNT_PASS
+#define SV_COUNT_PASS()
+#endif
+
 enum { SV_OP_DONE = 0, SV_OP_LF = 1, SV_OP_TABLE = 2, SV_OP_SA = 3, SV_OP_TEXT = 4, SV_OP_FILL = 5,
        SV_OP_TEXT_SLOW = 6, SV_OP_PEEK = 7, SV_OP_SA_SET = 8, SV_OP_SET = 9 };
 
@@ -202,6 +206,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
   // its table lookup: the phase-end handling comes first and falls through into the phase start.  (With the phase
   // start on top, as ping_pong.cpp is written, every phase end cost the whole wavefront a second pass over the body.)
   for (;;) {
+    SV_COUNT_PASS();
     if (s.mode & SV_M_SET) { o.op = SV_OP_SET; return o; }
     if (s.mode & SV_M_TEXT) {
       o.op = (off + s.pos >= 64) ? SV_OP_TEXT : SV_OP_TEXT_SLOW;
@@ -310,6 +315,13 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
 
 // ---- apply: the result of the iteration's memory operation -----------------
 
+// matches among the first r (< 128) positions of a block: whole words below word r / 32, part of that word
+SVDSS_HD int sv_rank128(const uint32_t m[4], int r) {
+  const int wi = r >> 5;
+  const uint32_t part = (wi == 0 ? m[0] : wi == 1 ? m[1] : wi == 2 ? m[2] : m[3]) & ((1u << (r & 31)) - 1u);
+  return svdss_popc(part) + svdss_popc(wi > 0 ? m[0] : 0u) + svdss_popc(wi > 1 ? m[1] : 0u) + svdss_popc(wi > 2 ? m[2] : 0u);
+}
+
 template <class P>
 SVDSS_HD void sv_apply_lf(SvLane<P>& s, const SvdssDevIndex& ix, const svdss_u4 qa[4],
                           const svdss_u4 qb[4], bool same_block) {
@@ -323,15 +335,14 @@ SVDSS_HD void sv_apply_lf(SvLane<P>& s, const SvdssDevIndex& ix, const svdss_u4 
     uint32_t cl = code == 0 ? qa[0].x : code == 1 ? qa[1].x : code == 2 ? qa[2].x : qa[3].x;
     uint32_t cb = code == 0 ? qb[0].x : code == 1 ? qb[1].x : code == 2 ? qb[2].x : qb[3].x;
     uint32_t ch = same_block ? cl : cb;
-    int sl = 0, sh = 0;
+    uint32_t ml[4], mh[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t ma = (qa[j].y ^ m0) & (qa[j].z ^ m1) & ~qa[j].w;
+      ml[j] = (qa[j].y ^ m0) & (qa[j].z ^ m1) & ~qa[j].w;
       const uint32_t mb = (qb[j].y ^ m0) & (qb[j].z ^ m1) & ~qb[j].w;
-      const uint32_t mh = same_block ? ma : mb;
-      sl += svdss_popc(ma & svdss_lowmask(rl - 32 * j));
-      sh += svdss_popc(mh & svdss_lowmask(rh - 32 * j));
+      mh[j] = same_block ? ml[j] : mb;
     }
+    const int sl = sv_rank128(ml, rl), sh = sv_rank128(mh, rh);
     s.lo = (P)(a + cl + sl);
     s.hi = (P)(a + ch + sh);
   } else {
@@ -406,10 +417,13 @@ SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_l
                  ((uint64_t)(uint32_t)(((((uint64_t)w2) << 32) | w1) >> sh) << 32);
     if (!dir) w = __builtin_bswap64(w << 16);                       // nearest symbol first
 #pragma unroll
-    for (int e = 0; e < SVDSS_TAB_EXT; ++e) {
-      int c = (int)((w >> (8 * e)) & 7u);                           // (positions past steps_max: not looked at)
-      if (dir) c = svdss_comp(c);
-      rs |= (uint32_t)c << (3 * e);
+    for (int e = 0; e < SVDSS_TAB_EXT; ++e)
+      rs |= (uint32_t)((w >> (8 * e)) & 7u) << (3 * e);             // (positions past steps_max: not looked at)
+    if (dir) {
+      // complement of all six at once (svdss_comp: 1 <-> 4, 2 <-> 3, 0 and 5 stay): bit 0 flips for 1..4, bit 2 for 1 and 4
+      const uint32_t b0 = rs & 0x9249u, b1 = (rs >> 1) & 0x9249u, b2 = (rs >> 2) & 0x9249u;
+      const uint32_t t = b2 ^ b0;
+      rs ^= (t | b1) | ((t & ~b1) << 2);
     }
   }
   int m[SV_SET_MAX], e = -1;
@@ -510,12 +524,9 @@ SVDSS_HD void sv_apply_set(SvLane<P>& s, const SvSet& ts, const svdss_u4 tw[SV_S
   for (int i = 0; i < SV_SET_MAX; ++i) {
     const uint32_t x3 = tw[i].w ^ rb.w, x2 = tw[i].z ^ rb.z, x1 = tw[i].y ^ rb.y, x0 = tw[i].x ^ rb.x;
     // matching symbols counted down from pos-1 (byte 15 of the window)
-    int k;
-    if (x3) k = 3 - ((31 - __builtin_clz(x3)) >> 3);
-    else if (x2) k = 7 - ((31 - __builtin_clz(x2)) >> 3);
-    else if (x1) k = 11 - ((31 - __builtin_clz(x1)) >> 3);
-    else if (x0) k = 15 - ((31 - __builtin_clz(x0)) >> 3);
-    else k = SV_SET_WIN;
+    const uint32_t v = x3 ? x3 : x2 ? x2 : x1 ? x1 : x0;         // the highest word that differs (selects, no branches)
+    const int top = x3 ? 3 : x2 ? 7 : x1 ? 11 : 15;
+    const int k = v ? top - ((31 - __builtin_clz(v | 1u)) >> 3) : SV_SET_WIN;
     m[i] = ((alive >> i) & 1) ? k : -1;
     if (m[i] > best) best = m[i];
   }

@@ -28,6 +28,11 @@
 #include "index_host.h"
 #include "rld0.h"
 #include "sfs_core.h"
+#ifdef SV_COUNT_ITERS
+// counting build: passes of sv_decide's loop, per wavefront (any lane inside)
+extern __device__ unsigned long long g_sfs_iters[64];
+#define SV_COUNT_PASS() do { if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(&g_sfs_iters[1], 1ULL); } while (0)
+#endif
 #include "sfs_core2.h"
 #include "sym_window.h"
 
@@ -601,17 +606,20 @@ __global__ void __launch_bounds__(256) sfs_order_scatter_kernel(int64_t n_reads,
 typedef uint32_t sv_u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef SV_COUNT_ITERS
-__device__ unsigned long long g_sfs_iters[48];   // [0] wave iterations, [1] lane ops, [2+op] lane ops by type
+__device__ unsigned long long g_sfs_iters[64];   // [0] wave iterations, [1] passes of the decision loop, [2+op] lane ops by type, [32+op] wave iterations with a lane in op
 #endif
 
 // counting build (make count -> libsvdss_hip_count.so, SVDSS_LIB selects it): lane operations of the launches since
 // the last report, by type -- what `useful_bytes` in profiles/traffic.json is computed from
 static void sfs_report_op_counts() {
 #ifdef SV_COUNT_ITERS
-  unsigned long long h[48];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess)
+  unsigned long long h[64];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess) {
+    fprintf(stderr, "[svdss] decision-loop passes %llu; wave-iterations with a lane in: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu "
+            "PEEK %llu SA_SET %llu SET %llu\n", h[1], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[39], h[40], h[41]);
     fprintf(stderr, "[svdss] wave-iterations %llu; lane ops: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu "
             "PEEK %llu SA_SET %llu SET %llu\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+  }
   fprintf(stderr, "[svdss] items by ops (2^k .. 2^(k+1)-1, k=4..15):");
   for (int k = 4; k < 16; ++k) fprintf(stderr, " %llu", h[16 + k]);
   fprintf(stderr, "\n");
@@ -621,7 +629,10 @@ static void sfs_report_op_counts() {
 }
 
 template <class P, bool SEG>
-__global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
+#ifndef SV_SEARCH_OCC
+#define SV_SEARCH_OCC 4   // workgroups per CU the register budget is set for
+#endif
+__global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsParams p) {
   __shared__ uint32_t ring_lds[16 * 256];   // 64 read symbols per lane: row r of lane t at [r*256 + t]
   SvRing g;
   g.base = &ring_lds[threadIdx.x];
@@ -748,6 +759,10 @@ __global__ void __launch_bounds__(256, 4) sfs_search2_kernel(SfsParams p) {
 #ifdef SV_COUNT_ITERS
     if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(&g_sfs_iters[0], 1ULL);
     atomicAdd(&g_sfs_iters[2 + o.op], 1ULL);
+    for (int q = 0; q < 10; ++q) {
+      const unsigned long long bm = __ballot(o.op == q);
+      if (bm && (threadIdx.x & 63) == __builtin_ctzll(bm)) atomicAdd(&g_sfs_iters[32 + q], 1ULL);
+    }
     ++item_ops;
     if (o.op == SV_OP_DONE) { atomicAdd(&g_sfs_iters[16 + (31 - __builtin_clz(item_ops | 1))], 1ULL); item_ops = 0; }
 #endif
