@@ -117,7 +117,7 @@ def test_v2_repeats_and_long_unique_stretches():
         reads.append(synth.revcomp(w) if k % 2 else w)
     flat, offs = svdss_amd.pack_reads(reads)
     c2, q2, l2, e2 = fm.search_batch(flat, offs, False)
-    for K, use_text in [(8, True), (0, True)]:
+    for K, use_text in [(8, True), (0, True), (12, True)]:   # (12: 16.7 M table entries; K = 14 / 16 need the GPU, test_sfs_gpu.py)
         c, q, l, e, ops = E.search2(ix, flat, offs, False, K, use_text)
         assert (c == c2).all() and (e == e2).all() and (q == q2).all() and (l == l2).all()
 
