@@ -125,8 +125,17 @@ struct Ctx {
   std::atomic<long> unplaced{0}, s_unplaced{0}, e_unplaced{0}, unknown{0}, unextended{0}, small{0}, small2{0};
 };
 
-// clusterer.cpp:159-346 (without the --clipped bookkeeping)
-void extend_alignment(Ctx& C, const BamRecord& aln, const std::string& chrom, std::vector<ESFS>& out) {
+// a soft clip next to SFS that could not be placed on one side (clipper.hpp:21-42)
+struct Clip {
+  std::string name, chrom;
+  unsigned p = 0, l = 0;
+  bool starting = false;   // leading clip (the read continues to the right of p)
+  unsigned w = 0;
+};
+
+// clusterer.cpp:159-346; clips: --clipped bookkeeping (:207-226, :338-345), nullptr without the option
+void extend_alignment(Ctx& C, const BamRecord& aln, const std::string& chrom, std::vector<ESFS>& out,
+                      std::vector<Clip>* clips = nullptr) {
   auto cs = C.chrom_seqs.find(chrom);
   if (cs == C.chrom_seqs.end()) return;
   const std::string& cseq = cs->second;
@@ -134,6 +143,7 @@ void extend_alignment(Ctx& C, const BamRecord& aln, const std::string& chrom, st
   const int k = 7, flank = 100;   // config.hpp:89-90, not settable
   size_t last_pos = 0;
   std::vector<ESFS> local;
+  unsigned lclip_p = 0, lclip_l = 0, rclip_p = 0, rclip_l = 0;
   for (const RawSFS& sfs : C.sfs.at(aln.qname)) {
     const int s = sfs.qs, e = sfs.qs + sfs.l - 1;
     int aln_start = -1, aln_end = -1, refs = -1, refe = -1;
@@ -144,8 +154,19 @@ void extend_alignment(Ctx& C, const BamRecord& aln, const std::string& chrom, st
       else if (q > e) { refe = r; aln_end = (int)i; break; }
     }
     if (refs == -1 && refe == -1) { ++C.unplaced; continue; }
-    else if (refs == -1) { ++C.s_unplaced; continue; }
-    else if (refe == -1) { ++C.e_unplaced; continue; }
+    else if (refs == -1) {
+      // the SFS starts in front of the first placed base: with --clipped a leading soft clip is remembered instead of
+      // counting the SFS (every such SFS of the alignment sets the same pair)
+      const uint32_t c0 = aln.cigar.empty() ? 0u : aln.cigar.front();
+      if (clips && (c0 & 0xf) == 4) { lclip_p = (unsigned)aln.pos; lclip_l = c0 >> 4; }
+      else ++C.s_unplaced;
+      continue;
+    } else if (refe == -1) {
+      const uint32_t c1 = aln.cigar.empty() ? 0u : aln.cigar.back();
+      if (clips && (c1 & 0xf) == 4) { rclip_p = (unsigned)aln.endpos(); rclip_l = c1 >> 4; }
+      else ++C.e_unplaced;
+      continue;
+    }
     Pairs loc;
     int last_r = refs - 1;
     for (int i = aln_start; i <= aln_end; ++i) {
@@ -177,6 +198,10 @@ void extend_alignment(Ctx& C, const BamRecord& aln, const std::string& chrom, st
     } else merged.push_back(x);
   }
   out.insert(out.end(), merged.begin(), merged.end());
+  if (clips) {   // clusterer.cpp:338-345
+    if (lclip_l > 0) clips->push_back(Clip{aln.qname, chrom, lclip_p, lclip_l, true, 0});
+    if (rclip_l > 0) clips->push_back(Clip{aln.qname, chrom, rclip_p, rclip_l, false, 0});
+  }
 }
 
 float len_ratio(float cl, float sl) { return std::min(cl, sl) / std::max(cl, sl); }
@@ -289,6 +314,145 @@ SV make_sv(const std::string& type, const std::string& chrom, int s, const std::
   return v;
 }
 
+// ---- imprecise SVs from soft clips (--clipped; Clipper, clipper.cpp) -------------------------------------------
+//
+// What the reference computes, stage by stage, with its quirks kept where they are defined behaviour:
+//   * a side's clips (leading / trailing) -> first clip per read name (:5-15) -> one breakpoint per (chromosome,
+//     position) with the longest clip and the number of reads (:17-52), listed chromosome slot by slot (i % 4, the
+//     slots concatenated back to front) and inside a chromosome in the iteration order of a
+//     std::unordered_map<uint, ...> filled in list order -- the same container here, hence the same order as a
+//     reference built against libstdc++;
+//   * breakpoints seen by fewer than two reads are dropped (:54-63), so are those within the +-1,000 bp window of
+//     a called SV of ANY chromosome (the interval tree has no chromosome, caller.cpp:39-41, clipper.cpp:93-102);
+//   * greedy grouping in list order (:66-91): a breakpoint within 1,000 bp of existing centres adds its reads to
+//     ALL of them, otherwise it becomes a centre; `centre - 1000` is unsigned arithmetic, so a centre below 1,000
+//     never absorbs anything (and is overwritten by a breakpoint at its own position);
+//   * insertions (:170-194): every leading centre looks up a trailing centre with the search of :104-124 and calls
+//     <INS> when the two are less than 1,000 bp apart; deletions (:196-214): every trailing centre looks up a leading
+//     one 2,000 to 50,000 bp to its right, at least five reads; positions of different chromosomes are compared as
+//     plain numbers;
+//   * rows leave per OpenMP slot (i % threads; insertions before deletions), the slots back to front (caller.cpp:45-50).
+// Where the reference is undefined this code is defined: the search of :104-124 walks off the
+// array when the query lies left of every centre of the other side (`m - 1` on an unsigned 0: it reads two billion
+// entries past the list) -- here it returns what its comment says it looks for, the first centre right of the query; the
+// record's COV0 / COV1 / COV2 / GQ are printed from fields nothing ever set (sv.cpp:5-27) -- 0 here; a reference base
+// beyond the chromosome's end (positions of two chromosomes mixed) is 'N'.
+namespace clipper {
+
+std::vector<Clip> breakpoints(const std::vector<Clip>& side, const std::vector<std::string>& chromosomes,
+                              const std::vector<std::pair<int, int>>& called) {
+  std::vector<const Clip*> first;
+  {
+    std::set<std::string> seen;
+    for (const Clip& c : side)
+      if (seen.insert(c.name).second) first.push_back(&c);
+  }
+  std::unordered_map<std::string, std::unordered_map<unsigned, std::vector<const Clip*>>> at;
+  for (const Clip* c : first) at[c->chrom][c->p].push_back(c);
+  std::vector<Clip> slot[4];
+  for (size_t i = 0; i < chromosomes.size(); ++i) {
+    const auto chrom = at.find(chromosomes[i]);
+    if (chrom == at.end()) continue;
+    for (const auto& bp : chrom->second) {
+      Clip b;
+      b.chrom = chromosomes[i];
+      b.p = bp.first;
+      for (const Clip* c : bp.second) b.l = std::max(b.l, c->l);
+      b.starting = bp.second.front()->starting;
+      b.w = (unsigned)bp.second.size();
+      slot[i % 4].push_back(b);
+    }
+  }
+  std::map<unsigned, Clip> centres;
+  for (int k = 3; k >= 0; --k)
+    for (const Clip& b : slot[k]) {
+      if (b.w < 2) continue;
+      bool near_call = false;
+      for (const auto& iv : called)
+        if (iv.first <= (int)b.p + 1 && (int)b.p <= iv.second) { near_call = true; break; }
+      if (near_call) continue;
+      bool absorbed = false;
+      for (auto& kv : centres)
+        if (kv.first - 1000u <= b.p && b.p <= kv.first + 1000u) {
+          absorbed = true;
+          kv.second.l = std::max(kv.second.l, b.l);
+          kv.second.w += b.w;
+        }
+      if (!absorbed) centres[b.p] = b;
+    }
+  std::vector<Clip> out;
+  for (const auto& kv : centres) out.push_back(kv.second);
+  return out;   // ascending position (std::map), what the sort of :151,158 leaves
+}
+
+// clipper.cpp:104-124 on a list sorted by position: the entry after one at the query's position (that entry itself
+// when it is the last), else the first entry to the right of the query whose left neighbour lies left of it; -1
+// when there is none; a query left of every entry gets entry 0 (the reference's recursion leaves the array there)
+int partner(const std::vector<Clip>& v, unsigned q) {
+  if (v.empty()) return -1;
+  size_t lo = 0, hi = v.size() - 1;
+  for (;;) {
+    if (lo > hi || lo >= v.size()) return -1;
+    const size_t m = (lo + hi) / 2;
+    if (v[m].p == q) return (int)(m + 1 < v.size() ? m + 1 : m);
+    if (v[m].p > q) {
+      if (m > 0 && v[m - 1].p < q) return (int)m;
+      if (m == 0) return 0;               // (the reference goes on with end = UINT_MAX)
+      hi = m - 1;
+    } else lo = m + 1;
+  }
+}
+
+}  // namespace clipper
+
+// Clipper::call + the caller's collection (clipper.cpp:126-215, caller.cpp:36-53): rows in output order
+std::vector<SV> call_clipped(const std::vector<Clip>& clips, const std::vector<std::string>& chromosomes,
+                             const std::unordered_map<std::string, std::string>& chrom_seqs, int T,
+                             const std::vector<std::pair<int, int>>& called) {
+  std::vector<Clip> lead, trail;
+  for (const Clip& c : clips) (c.starting ? lead : trail).push_back(c);
+  const std::vector<Clip> rc = clipper::breakpoints(trail, chromosomes, called);
+  const std::vector<Clip> lc = clipper::breakpoints(lead, chromosomes, called);
+  std::vector<std::vector<SV>> per_slot((size_t)T);
+  if (!lc.empty() && !rc.empty()) {
+    auto base_at = [&](const std::string& chrom, unsigned p) {
+      const auto it = chrom_seqs.find(chrom);
+      return std::string(1, it != chrom_seqs.end() && p < it->second.size() ? it->second[p] : 'N');
+    };
+    for (size_t i = 0; i < lc.size(); ++i) {
+      const Clip& l = lc[i];
+      const int k = clipper::partner(rc, l.p);
+      if (k < 0) continue;
+      const Clip& r = rc[(size_t)k];
+      if (r.w == 0) continue;
+      if (std::abs((int)r.p - (int)l.p) < 1000) {
+        const unsigned s = l.w > r.w ? l.p : r.p;
+        SV v = make_sv("INS", l.chrom, (int)s, base_at(l.chrom, s), "<INS>", std::max(l.w, r.w), 0, 0, 0,
+                       (int)std::max(l.l, r.l), ".");
+        v.imprecise = true;
+        per_slot[i % (size_t)T].push_back(v);
+      }
+    }
+    for (size_t i = 0; i < rc.size(); ++i) {
+      const Clip& r = rc[i];
+      const int k = clipper::partner(lc, r.p);
+      if (k < 0) continue;
+      const Clip& l = lc[(size_t)k];
+      if (l.w == 0) continue;
+      const unsigned gap = l.p - r.p;     // (unsigned: a leading centre left of the trailing one is out of range)
+      if (gap >= 2000 && gap <= 50000 && std::max(l.w, r.w) >= 5) {
+        SV v = make_sv("DEL", r.chrom, (int)r.p, base_at(r.chrom, r.p), "<DEL>", std::max(l.w, r.w), 0, 0, 0,
+                       (int)(gap + 1), ".");
+        v.imprecise = true;
+        per_slot[i % (size_t)T].push_back(v);
+      }
+    }
+  }
+  std::vector<SV> rows;
+  for (size_t t = (size_t)T; t-- > 0;) rows.insert(rows.end(), per_slot[t].begin(), per_slot[t].end());
+  return rows;
+}
+
 const char* VCF_INFO[][4] = {
     {"VARTYPE", "A", "String", "Variant class"}, {"SVTYPE", "1", "String", "Variant type"},
     {"SVLEN", "1", "Integer", "Difference in length between REF and ALT alleles"},
@@ -351,6 +515,7 @@ int main_call(const CallOptions& o) {
   // ---- align_and_extend (clusterer.cpp:56-156): pass 1 over the BAM
   std::vector<std::string> ref_names;
   std::vector<ESFS> extended;
+  std::vector<Clip> clips;       // --clipped
   // The inflated records of pass 1 are kept for pass 2 when they fit in memory (a second inflate of the whole file
   // otherwise): SVDSS_CALL_CACHE_GB, default 40 % of MemAvailable, at most 64 GiB.
   std::vector<BamReader::RawView> cache_views;
@@ -382,10 +547,12 @@ int main_call(const CallOptions& o) {
     ref_names = bam.ref_names();
     const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
     std::vector<std::vector<ESFS>> per_thread((size_t)T);
-    // the chromosomes in BAM header order on the GPU, for the placement kernel (SVDSS_PLACE_HOST=1: host code instead)
+    std::vector<std::vector<Clip>> per_thread_clips((size_t)T);
+    // the chromosomes in BAM header order on the GPU, for the placement kernel (SVDSS_PLACE_HOST=1: host code instead;
+    // --clipped: host code as well -- the kernel reports how many SFS stay unplaced, not next to which soft clip)
     svdss_ref_t* dref = nullptr;
     std::vector<int32_t> tid_map(ref_names.size(), -1);
-    if (!getenv("SVDSS_PLACE_HOST")) {
+    if (!getenv("SVDSS_PLACE_HOST") && !o.clipped) {
       std::string all;
       std::vector<int64_t> off(1, 0);
       for (size_t t = 0; t < ref_names.size(); ++t) {
@@ -438,7 +605,7 @@ int main_call(const CallOptions& o) {
       if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
       // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
       // the same order per slice
-      worker = std::thread([&C, &ref_names, &per_thread, &batch, T, dref, &tid_map]() {
+      worker = std::thread([&C, &ref_names, &per_thread, &per_thread_clips, &batch, T, dref, &tid_map]() {
         if (dref) {
           // placement on the GPU (csrc/place.hip: one lane per alignment); the results go to the T per-thread lists in
           // the order the reference's slices would have produced them (record n belongs to slice n % T)
@@ -479,7 +646,8 @@ int main_call(const CallOptions& o) {
           for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
             const BamRecord& r = batch[n];
             if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
-            extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t]);
+            extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t],
+                             C.o.clipped ? &per_thread_clips[(size_t)t] : nullptr);
           }
         };
         if (T == 1 || batch.size() < 64) { for (int t = 0; t < T; ++t) slice(t); }
@@ -495,7 +663,12 @@ int main_call(const CallOptions& o) {
     if (worker.joinable()) worker.join();
     svdss_ref_free(dref);
     for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
+    for (int t = T; t-- > 0;)   // each thread's list goes in front of the others' (clusterer.cpp:24)
+      clips.insert(clips.end(), per_thread_clips[(size_t)t].begin(), per_thread_clips[(size_t)t].end());
   }
+  logmsg("info", std::to_string(C.unplaced.load()) + "/" + std::to_string(C.s_unplaced.load()) + "/" + std::to_string(C.e_unplaced.load()) +
+                     " unplaced SFSs. " + std::to_string(C.unknown.load()) + " erroneus SFSs. " + std::to_string(clips.size()) +
+                     " clipped SFSs.");   // clusterer.cpp:26-27
   stage("pass 1: placement");
   // ---- cluster_by_proximity (clusterer.cpp:407-474)
   std::vector<Cluster> clusters;
@@ -998,6 +1171,17 @@ int main_call(const CallOptions& o) {
     for (size_t t = sam_rows.size(); t-- > 0;)
       for (const std::string& row : sam_rows[t]) { fwrite(row.data(), 1, row.size(), f); fputc('\n', f); }
     fclose(f);
+  }
+  if (o.clipped) {   // caller.cpp:36-53: imprecise rows after the VCF, in the Clipper's own order (not sorted)
+    logmsg("warning", "Calling imprecise SVs from clipped alignments is experimental");
+    std::vector<std::pair<int, int>> called;
+    for (const SV& v : svs) called.emplace_back(v.s - 1000, v.e + 1000);
+    const std::vector<SV> rows = call_clipped(clips, C.chrom_names, C.chrom_seqs, T, called);
+    logmsg("info", "Predicted " + std::to_string(rows.size()) + " SVs from clipped alignments");
+    std::string text;
+    for (const SV& v : rows) text += v.line() + "\n";
+    fwrite(text.data(), 1, text.size(), stdout);
+    fflush(stdout);
   }
   return 0;
 }

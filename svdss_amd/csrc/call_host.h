@@ -15,6 +15,7 @@ struct CallOptions {
   int gpus = 1;                 // --gpus N: POA / realignment batches shard by sub-cluster index
   std::string poa;             // --poa <FILE>: consensus alignments as SAM (caller.cpp:65-75)
   std::string clusters;        // --clusters <FILE>: the filled clusters (clusterer.cpp:613-626)
+  bool clipped = false;        // --clipped: imprecise SVs from soft-clipped alignments (clipper.cpp; EXPERIMENTAL)
 };
 
 int main_call(const CallOptions& o);

@@ -58,7 +58,8 @@ static const char* CALL_USAGE =
     "      --poa <FILE>                store POA consensus alignments in .sam format to this file\n"
     "      --clusters <FILE>           store clusters to this file\n"
     "      -l <float>                  minimum length ratio for sub-clusters and chain merging (default: 0.97)\n"
-    "      --noht                      ignore the HP tag\n";
+    "      --noht                      ignore the HP tag\n"
+    "      --clipped                   also call imprecise SVs from soft-clipped alignments (EXPERIMENTAL)\n";
 
 static const char* SEARCH_USAGE =
     "Usage: SVDSS search --index <FMD> --bam <BAM> | --fastx <FASTA/FASTQ>\n"
@@ -94,7 +95,7 @@ struct Options {
   int threads = 4, bsize = 10000, omax = 100000;  // config.hpp:68-69,88
   int io_threads = 0;                              // BGZF inflate workers (0: up to 16)
   int gpus = 1;                                    // --gpus N: index replicated, batches / sub-clusters shard
-  bool putative = true, assemble = true, verbose = false, version = false, help = false;
+  bool putative = true, assemble = true, verbose = false, version = false, help = false, clipped = false;
 };
 
 static bool take(int argc, char** argv, int& i, const char* name, std::string& val) {
@@ -134,10 +135,7 @@ static Options parse(int argc, char** argv) {
     else if (!strcmp(argv[i], "--verbose")) o.verbose = true;
     else if (!strcmp(argv[i], "--version")) o.version = true;
     else if (!strcmp(argv[i], "--help") || !strcmp(argv[i], "-h")) o.help = true;
-    else if (!strcmp(argv[i], "--clipped")) {
-      // declared by the reference (config.cpp:44, "EXPERIMENTAL"); its output is not reproducible
-      logmsg("warning", "--clipped (experimental in the reference) is not supported: calling from SFS clusters only");
-    }
+    else if (!strcmp(argv[i], "--clipped")) o.clipped = true;   // config.cpp:46 (EXPERIMENTAL)
     else die(std::string("Option '") + argv[i] + "' does not exist");  // cxxopts throws here
   }
   if (o.threads < 1) o.threads = 1;
@@ -640,6 +638,7 @@ int main(int argc, char** argv) {
       c.reference = o.reference; c.bam = o.bam; c.sfs = o.sfs; c.threads = o.threads; c.gpus = o.gpus;
       c.min_cluster_weight = o.min_cluster_weight; c.min_sv_length = o.min_sv_length; c.min_mapq = o.min_mapq;
       c.useht = o.useht; c.min_ratio = o.min_ratio; c.poa = o.poa; c.clusters = o.clusters; c.verbose = o.verbose;
+      c.clipped = o.clipped;
       main_call(c);
     } else if (!strcmp(argv[1], "smooth")) {
       if (o.reference.empty() || o.bam.empty()) { fputs(SMOOTH_USAGE, stderr); return EXIT_FAILURE; }   // main.cpp:73-76

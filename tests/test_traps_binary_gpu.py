@@ -128,3 +128,26 @@ def test_trap9_int_truncated_ratios_drop_the_in_between_read(tmp_path):
     got = sorted((i["SVLEN"], i["WEIGHT"], tuple(sorted(i["READS"].split(",")))) for i in info)
     assert got == [("60", "4", ("h1a", "h1b", "h1c", "u60")), ("62", "3", ("h2a", "h2b", "h2c"))]
     assert all(f[1] == "3000" for f in rows)
+
+
+def test_clipped_breakpoints_near_a_called_sv_of_any_chromosome_are_dropped(tmp_path):
+    """--clipped (caller.cpp:36-53, clipper.cpp:93-102): the called insertion chr1:3000 puts [2000, 4000] into an interval
+    tree that has no chromosome, so the facing soft clips at chr2:3500 (three reads each side) are dropped although chr2
+    has no call; those at chr2:4900 are kept and give an imprecise <INS> after the VCF rows (both sides at 4900: every
+    lookup of clipper.cpp:104-124 stays inside the lists).  Clip reads: 800M300S ending at B / 300S800M starting at B,
+    SFS over the clipped end (clusterer.cpp:207-226)."""
+    ref1, ref2, ins = _reference(11), _reference(12), _ins(13, 60)
+    seq, cig = _read(ref1, ins)
+    recs = [(n, 0, 2000, cig, seq, []) for n in ("r1", "r2")]
+    sfs = [f"{n}\t995\t70\t0\t\n" for n in ("r1", "r2")]
+    tail = "ACT" * 100
+    for b in (3500, 4900):
+        for i in range(3):
+            recs.append((f"t{b}_{i}", 1, b - 800, [("M", 800), ("S", 300)], ref2[b - 800:b] + tail, []))
+            sfs.append(f"t{b}_{i}\t790\t310\t0\t\n")
+            recs.append((f"l{b}_{i}", 1, b, [("S", 300), ("M", 800)], tail + ref2[b:b + 800], []))
+            sfs.append(f"l{b}_{i}\t0\t310\t0\t\n")
+    rows, info, clusters = _call(tmp_path, [("chr1", ref1), ("chr2", ref2)], recs, sfs, 2, extra=("--clipped",))
+    assert [(f[0], f[1], f[4] if f[4].startswith("<") else "seq") for f in rows] == [("chr1", "3000", "seq"), ("chr2", "4900", "<INS>")]
+    assert rows[1][2] == "INS_chr2:4900-4900_300" and rows[1][3] == ref2[4900] and rows[1][7].endswith(";READS=;IMPRECISE")
+    assert info[1]["WEIGHT"] == "3" and info[1]["SVLEN"] == "300" and rows[1][9] == "./.:0"
