@@ -2,6 +2,7 @@
 (whole process wall time: BGZF inflate, record parsing, GPU search, text output).  Runs on the GPU box.
 
   python tools/e2e_search.py [ref_bp] [n_reads] [read_len] [workdir]
+E2E_REPEAT=k writes the record blocks k times; E2E_QUAL=binned draws the qualities from seven values (default: 40).
 """
 import json
 import multiprocessing as mp
@@ -40,7 +41,10 @@ def write_bam(path, ref_name, ref, n_reads, read_len, seed=5, err=0.005, repeat=
         if read_len & 1:
             c = np.append(c, np.uint8(0))
         packed = ((c[0::2] << 4) | c[1::2]).tobytes()
-        qual = rng.integers(20, 60, size=read_len, dtype=np.uint8).tobytes()
+        if os.environ.get("E2E_QUAL", "random") == "binned":   # seven quality values, as the sequencers of HiFi reads bin them
+            qual = np.array([3, 10, 17, 22, 27, 33, 40], dtype=np.uint8)[rng.integers(0, 7, size=read_len)].tobytes()
+        else:
+            qual = rng.integers(20, 60, size=read_len, dtype=np.uint8).tobytes()
         name = ("read%07d" % i).encode() + b"\0"
         core = struct.pack("<iiBBHHHiiii", 0, int(st), len(name), 60, 4680, 1, 0, read_len, -1, -1, 0)
         body = core + name + struct.pack("<I", read_len << 4) + packed + qual
