@@ -1,6 +1,7 @@
 """Parity at the sizes and table orders the product actually runs: K = 14 / 16 tables checked
 bit for bit against the oracle, BASELINE config 2 (chr20 length, 3x), a reference above 2^31 BWT symbols (64-bit
-suffix array and intervals where 32 bits would overflow), and the index builder of csrc/index_gpu.hip against the
+suffix array and intervals where 32 bits would overflow), BASELINE config 4's reference (GRCh38 primary lengths, above
+2^32 symbols), and the index builder of csrc/index_gpu.hip against the
 host builder.  Integer work: every comparison is bit-exact."""
 import os
 
@@ -131,6 +132,60 @@ def test_reference_above_2_31_symbols():
     assert split(c, q, l) == [rr[i] for i in sub]
     c, q, l, e = fm.search_batch(sflat, soffs, True)
     assert split(c, q, l) == [aa[i] for i in sub]
+    assert raw.counts.sum() > n_reads * 300
+
+
+def test_config4_grch38_primary_lengths():
+    """BASELINE config 4 at its full reference size: 24 contigs with the GRCh38 primary lengths (3,088,269,832 bp,
+    6.18e9 BWT symbols -- text positions and suffix-array rows beyond 2^32, the K = 16 table with three quarters of all
+    16-mers present, UNIQUE / FEW entries with extension symbols on nearly every lookup), index built in HBM the way
+    bench.py builds it.  15 kb reads with 0.5 % errors from the first, a middle and the last contig: the several-lanes-
+    per-read launch and the one-lane launch against each other on all reads, a sample against the oracle (index
+    contents handed over as a BWT), exact reads of both strands, and the size-independent properties of an SFS set."""
+    import bench
+    L, n_reads = 15000, 2048
+    lens = list(bench.GRCH38_PRIMARY)
+    ref = synth.make_reference(lens, seed=11)
+    ix = svdss_amd.FMDIndex.build(ref, device=0)
+    assert ix.kmer_k == 16 and ix.size == 2 * (sum(lens) + len(lens)) > 2 ** 32
+    span = 30_000_000
+    pieces = [ref[0][:span], ref[11][5_000_000:5_000_000 + span], ref[23][len(ref[23]) - span:]]
+    hap, svs = synth.implant_svs(pieces, 12, seed=42)
+    flat, offs, truth = synth.simulate_reads(hap, n_reads, L, 0.005, seed=43)
+    raw, segs, _ = _search(ix, flat, offs, False)
+    asm, _, _ = _search(ix, flat, offs, True)
+    assert segs > 1
+    os.environ["SVDSS_SEGMENTS"] = "1"
+    try:
+        raw1, segs1, _ = _search(ix, flat, offs, False)
+        asm1, _, _ = _search(ix, flat, offs, True)
+    finally:
+        del os.environ["SVDSS_SEGMENTS"]
+    assert segs1 == 1
+    _same(raw1, raw.counts, raw.qs, raw.len, raw.n_ext)
+    _same(asm1, asm.counts, asm.qs, asm.len, asm.n_ext)
+    last = ref[23]
+    exact = [last[len(last) - 20000:len(last) - 5000].copy(), synth.revcomp(last[len(last) - 20000:len(last) - 5000]),
+             ref[0][:L].copy(), synth.revcomp(ref[12][7_000_000:7_000_000 + L])]
+    eflat, eoffs = svdss_amd.pack_reads(exact)
+    got, _, _ = _search(ix, eflat, eoffs, False)
+    assert got.counts.sum() == 0 and (got.n_ext == L - 1).all()
+    fm = O.OracleFMD.from_bwt(ix.bwt())
+    sub = list(range(0, n_reads, 8))
+    sflat, soffs = svdss_amd.pack_reads([flat[offs[i]:offs[i + 1]] for i in sub])
+    rr, aa = raw.per_read(), asm.per_read()
+    c, q, l, e = fm.search_batch(sflat, soffs, False)
+    assert (raw.counts[sub] == c).all() and (raw.n_ext[sub] == e).all()
+    assert split(c, q, l) == [rr[i] for i in sub]
+    c, q, l, e = fm.search_batch(sflat, soffs, True)
+    assert split(c, q, l) == [aa[i] for i in sub]
+    qs, ln, cnt = raw.qs.astype(np.int64), raw.len.astype(np.int64), raw.counts
+    rid = np.repeat(np.arange(n_reads), cnt)
+    same = rid[1:] == rid[:-1]
+    assert (qs[1:][same] < qs[:-1][same]).all() and ((qs + ln)[1:][same] < (qs + ln)[:-1][same]).all()
+    assert (qs >= 0).all() and (qs + ln <= L).all() and (ln > 0).all()
+    for i in range(0, n_reads, 61):
+        assert aa[i] == O.assemble(rr[i])
     assert raw.counts.sum() > n_reads * 300
 
 
