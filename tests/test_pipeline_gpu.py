@@ -156,6 +156,58 @@ def test_run_svdss_chain_with_raw_reads(tmp_path):
     assert len(called) == len(truth)
 
 
+def test_config1_shape_1k_reads_10mb_full_chain(tmp_path):
+    """BASELINE config 1 at its own size: 1,000 reads of 15 kb with 0.5 % errors against a 10 Mb reference (1.5x),
+    index -> smooth -> search -> call through the binaries (run_svdss:136-178).  At 1.5x only part of the implanted SVs
+    is seen by two reads: what is called must be an implanted SV (type, length, position), and the VCF must equal the
+    Python mirror of the reference's host logic (svdss_amd.caller.call: clusterer.cpp / caller.cpp restated) run on the
+    same smoothed BAM and SFS file, byte for byte."""
+    from tests.pipeline_sim import add_errors
+    ref, svs, reads = simulate(ref_lens=(10_000_000,), n_svs=40, coverage=1.5, read_len=15000, seed=21)
+    assert 990 <= len(reads) <= 1000
+    rng = np.random.default_rng(22)
+    fa = tmp_path / "ref.fa"
+    fa.write_text(f">chr10M\n{synth.to_ascii(ref[0])}\n")
+    recs = []
+    for n, tid, pos, cig, seq, hp in reads:
+        s2, c2 = add_errors(seq, cig, rng, 0.005)
+        recs.append(bam_writer.record(n, 0, tid, pos, 60, c2, s2))
+    bam = tmp_path / "reads.bam"
+    bam.write_bytes(bam_writer.bam([("chr10M", len(ref[0]))], recs))
+    fmd = tmp_path / "ref.fa.fmd"
+    assert subprocess.run([BIN, "index", "-t", "8", "-d", str(fa), "-o", str(fmd)], capture_output=True).returncode == 0
+    smoothed = tmp_path / "smoothed.bam"
+    with open(smoothed, "wb") as fh:
+        r = subprocess.run([BIN, "smooth", "--threads", "4", "--reference", str(fa), "--bam", str(bam)], stdout=fh,
+                           stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run([BIN, "search", "--threads", "4", "--index", str(fmd), "--bam", str(smoothed)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sfs = tmp_path / "specifics.txt"
+    sfs.write_text(r.stdout)
+    r = subprocess.run([BIN, "call", "--threads", "4", "--min-sv-length", "50", "--reference", str(fa), "--bam", str(smoothed),
+                        "--sfs", str(sfs)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    vcf = r.stdout
+    called = []
+    for line in vcf.splitlines():
+        if line.startswith("#"):
+            continue
+        f = line.split("\t")
+        kv = dict(x.split("=", 1) for x in f[7].split(";") if "=" in x)
+        called.append((int(f[1]), kv["SVTYPE"], abs(int(kv["SVLEN"])), int(kv["WEIGHT"])))
+    truth = [(s.pos, s.kind, s.length) for s in svs]
+    assert 5 <= len(called) <= len(truth)
+    for pos, kind, length, w in called:
+        assert w >= 2 and any(k == kind and abs(l - length) <= 2 and abs(p - pos) <= 15 for p, k, l in truth), (pos, kind, length)
+    ref_names, ref_lens, alns = bamio.read_bam(str(smoothed))
+    mirror_vcf, info = caller.call(alns, sfs.read_text(), {"chr10M": synth.to_ascii(ref[0])}, list(zip(ref_names, ref_lens)),
+                                   ref_names, threads=4, min_sv_length=50)
+    assert vcf == mirror_vcf
+
+
+
 def _sharded_hip_worker(rank, world, port, q):
     import torch.distributed as dist
     from svdss_amd import multi
