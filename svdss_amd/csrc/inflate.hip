@@ -38,14 +38,23 @@ namespace {
 #ifndef INF_WIN
 #define INF_WIN 4096
 #endif
+#ifndef INF_FRAC
+#define INF_FRAC 8
+#endif
 constexpr int WIN = INF_WIN, WM = WIN - 1;
-constexpr int FLUSH = WIN / 8;        // the ring is written out whenever this many bytes are waiting
-constexpr int ROUND_MAX = WIN / 8;    // a round stops taking symbols once it has produced this many bytes (+ one match)
+constexpr int FLUSH = WIN / INF_FRAC;        // the ring is written out whenever this many bytes are waiting
+constexpr int ROUND_MAX = WIN / INF_FRAC;    // a round stops taking symbols once it has produced this many bytes (+ one match)
 // sources within this distance of a match's output position are read from the ring: everything further back has been
 // written out (FLUSH + ROUND_MAX + 258 < NEAR) and nothing closer has been overwritten (NEAR + ROUND_MAX + 258 < WIN)
-constexpr int NEAR = WIN / 2 - WIN / 8;
+constexpr int NEAR = WIN / 2 - WIN / INF_FRAC;
 static_assert(FLUSH + ROUND_MAX + 258 + 64 < NEAR && NEAR + ROUND_MAX + 258 + 64 < WIN, "ring too small");
-constexpr int LB = 10, DB = 8, CB = 7;
+#ifndef INF_LB
+#define INF_LB 10
+#endif
+#ifndef INF_DB
+#define INF_DB 8
+#endif
+constexpr int LB = INF_LB, DB = INF_DB, CB = 7;   // bits of the direct tables (literal / length, distance, code lengths)
 constexpr int INB = 1024, HALF = INB / 2;   // input ring, refilled a half at a time
 
 
@@ -378,27 +387,41 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
         if (len == 0 || (is_match && (sym > 285u || dl == 0 || (D >> 4) > 29u))) kind = 3u;
         const uint32_t nbits = kind == 1u ? eoff + dx : len;
         const uint32_t outlen = kind == 0u ? 1u : kind == 1u ? mlen : 0u;
-        const uint32_t NX = ((uint32_t)lane + nbits) | (kind << 8) | (outlen << 10);
-        // ---- the scalar unit follows the chain of symbol starts from offset 0
-        uint32_t off = 0;
-        unsigned long long chain = 0;
-        bool slow = false;
-        uint32_t produced = 0;
-        while (off < 64 && produced < (uint32_t)ROUND_MAX) {
-          const uint32_t nx = __builtin_amdgcn_readlane(NX, off);
-          const uint32_t k = (nx >> 8) & 3u;
-          if (k == 3u) { slow = true; break; }
-          chain |= 1ull << off;
-          off = nx & 255u;
-          produced += nx >> 10;
-          if (k == 2u) { eob = true; break; }
+        // ---- the chain of symbol starts from offset 0, by pointer doubling on the lanes: lane l knows where the symbol
+        // after its own starts (J) and which offsets the chain from l visits (M); six rounds of "append the chain of
+        // the lane I point at" close M over the 64 offsets (a symbol is at least one bit long), and the chain of the
+        // round is M of lane 0.  A symbol the tables cannot decode (kind 3) is on nobody's chain and ends the chains
+        // that reach it; so do the end-of-block code and a symbol that ends beyond the 64 offsets -- after being
+        // visited.  (One scalar instruction per CU and cycle: followed symbol by symbol on the scalar unit, ~14
+        // instructions each, the chain was what bound the kernel.)
+        const uint32_t nextl = (uint32_t)lane + nbits;
+        uint32_t J = (kind == 3u || kind == 2u || nextl >= 64u) ? 64u : nextl;
+        uint32_t Mlo = kind == 3u ? 0u : (lane < 32 ? 1u << lane : 0u), Mhi = kind == 3u ? 0u : (lane >= 32 ? 1u << (lane - 32) : 0u);
+        while (__ballot(J < 64u)) {
+          const int a = (int)(J << 2);
+          const uint32_t jj = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)J);
+          const uint32_t ml_ = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)Mlo), mh_ = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)Mhi);
+          if (J < 64u) { Mlo |= ml_; Mhi |= mh_; J = jj; }
         }
-        // ---- where every symbol of the chain puts its output: a scan over the chain's lanes
-        const bool onc = ((chain >> lane) & 1ull) != 0;
-        const uint32_t x = onc ? outlen : 0u;
-        const uint32_t incl = (uint32_t)wave_scan_add((int)x);
-        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        const uint32_t opos = wpos + (incl - x);
+        const unsigned long long chain0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)Mlo) |
+                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)Mhi) << 32);
+        // ---- where every symbol of the chain puts its output: a scan over the chain's lanes; the round takes the
+        // symbols that start before ROUND_MAX bytes of it
+        const bool onc0 = ((chain0 >> lane) & 1ull) != 0;
+        const uint32_t x0 = onc0 ? outlen : 0u;
+        const uint32_t incl = (uint32_t)wave_scan_add((int)x0);
+        const bool onc = onc0 && incl - x0 < (uint32_t)ROUND_MAX;
+        const unsigned long long chain = __ballot(onc);
+        uint32_t off = 0, total = 0;
+        bool slow = false;
+        if (chain) {
+          const int h = 63 - (int)__builtin_clzll(chain);          // the last symbol taken
+          total = __builtin_amdgcn_readlane(incl, h);
+          off = __builtin_amdgcn_readlane(nextl, h);
+          if (__builtin_amdgcn_readlane(kind, h) == 2u) eob = true;
+          else if (off < 64u && total < (uint32_t)ROUND_MAX) slow = __builtin_amdgcn_readlane(kind, off) == 3u;
+        } else slow = true;                                          // (the symbol at offset 0 itself)
+        const uint32_t opos = wpos + (incl - x0);
         if (wpos + total > isize) { err = ST_OUT; break; }
         if (__ballot(onc && kind == 1u && dist > opos)) { err = ST_DIST; break; }
         if (onc && kind == 0u) winb[opos & WM] = (uint8_t)sym;
