@@ -269,6 +269,31 @@ class BamReader {
     gpu_n_devices_ = std::max(1, n_devices);
     pin_hooks().alloc = api.host_alloc; pin_hooks().free_ = api.host_free;
   }
+  // Page-locked chunk buffers ahead of the first read.  A page-locked allocation of a chunk's size takes ~0.1 s, and the
+  // first `ahead` loaders would each pay for two of them before the first record is seen: a caller with something else
+  // to do first (`search` restores its index) runs this beside it.  est_ratio: inflated / compressed size expected.
+  void prewarm(double est_ratio = 1.75) {
+    if (!gpu_.inflate || !pread_size_ || !pin_hooks().alloc) return;
+    // compressed: one per loader in flight; inflated: those plus the chunks a batch of records keeps alive while its
+    // packed bases are copied out (about as many again)
+    const size_t n_file = (pread_size_ + slab_ - 1) / slab_;
+    const size_t n_comp = std::min<size_t>(ahead_ + 2, n_file), n_out = std::min<size_t>(2 * ahead_, n_file);
+    const size_t out_bytes = (size_t)((double)slab_ * est_ratio) + ((size_t)8 << 20);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < 8; ++t)
+      th.emplace_back([this, t, n_comp, n_out, out_bytes] {
+        for (size_t i = t; i < n_comp + n_out; i += 8) {
+          try {
+            Bytes b;
+            b.alloc(i < n_comp ? slab_ + kOverlap : out_bytes, true);
+            FreeList& fl = i < n_comp ? *comp_free_ : *free_;
+            std::lock_guard<std::mutex> lk(fl.m);
+            fl.v.push_back(std::move(b));
+          } catch (const std::bad_alloc&) { return; }   // (the loaders allocate what they need, or fall back)
+        }
+      });
+    for (std::thread& x : th) x.join();
+  }
   const std::string& error() const { return err_; }
   const std::vector<std::string>& ref_names() const { return refs_; }
   const std::vector<int32_t>& ref_lens() const { return ref_lens_; }
@@ -875,8 +900,13 @@ class BamReader {
           dst.swap(free_->v[i]); free_->v.erase(free_->v.begin() + (long)i); break;
         }
     }
-    if (dst.cap < bytes || !dst.p || (pinned && !dst.p.get_deleter().pinned)) ++n_fresh_;
+    const bool fresh = dst.cap < bytes || !dst.p || (pinned && !dst.p.get_deleter().pinned);
+    const auto t0 = std::chrono::steady_clock::now();
     dst.alloc(bytes, pinned);
+    if (fresh) {
+      ++n_fresh_;
+      t_fresh_ += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
   }
   // per-call state of the GPU inflate (stream, device buffers), one per concurrent loader
   struct GpuObj { void* h = nullptr; void* d_out = nullptr; size_t d_cap = 0; int dev = 0; };
@@ -900,7 +930,7 @@ class BamReader {
     return g;
   }
   void put_gpu_obj(const GpuObj& g) { std::lock_guard<std::mutex> lk(gpu_m_); gpu_objs_.push_back(g); }
-  std::atomic<long long> t_scan_{0}, t_buf_{0}, t_inf_{0}, n_fresh_{0};   // SVDSS_DEBUG: nanoseconds per stage
+  std::atomic<long long> t_scan_{0}, t_buf_{0}, t_inf_{0}, n_fresh_{0}, t_fresh_{0};   // SVDSS_DEBUG: nanoseconds per stage
   double t_wait_ = 0;
   std::unique_ptr<InflatePool> pool_;
   FILE* f_;
@@ -919,8 +949,8 @@ class BamReader {
       fprintf(stderr, "[bam_reader] %llu chunks inflated on the GPU (%.3f s summed wall incl. copies), CRC check %.3f s\n",
               (unsigned long long)n_gpu_chunks_.load(), t_gpu_.load() * 1e-9, t_crc_.load() * 1e-9);
     {
-      fprintf(stderr, "[bam_reader] %llu chunks: locate %.3f s (under the file lock), buffers %.3f s (%llu fresh), inflate %.3f s summed wall, parser waited %.3f s; %d workers\n",
-              (unsigned long long)n_launched_, t_scan_.load() * 1e-9, t_buf_.load() * 1e-9, (unsigned long long)n_fresh_.load(), t_inf_.load() * 1e-9,
+      fprintf(stderr, "[bam_reader] %llu chunks: locate %.3f s (under the file lock), buffers %.3f s (%llu fresh: %.3f s summed), inflate %.3f s summed wall, parser waited %.3f s; %d workers\n",
+              (unsigned long long)n_launched_, t_scan_.load() * 1e-9, t_buf_.load() * 1e-9, (unsigned long long)n_fresh_.load(), t_fresh_.load() * 1e-9, t_inf_.load() * 1e-9,
               t_wait_ * 1e-9, threads_);
     }
   }

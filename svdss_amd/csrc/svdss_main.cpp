@@ -298,6 +298,17 @@ int main_search(const Options& o) {
   svdss_index_t* ix = nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto since = [&] { return std::to_string(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
+  const bool bam_mode = !o.bam.empty();
+  BamReader* bam = nullptr;
+  std::thread bam_prewarm;
+  if (bam_mode) {
+    // the reader's page-locked chunk buffers are allocated while the index is restored (BamReader::prewarm)
+    bam = new BamReader(o.bam, o.io_threads);
+    // (BGZF blocks inflated on the GPU, csrc/inflate.hip, on every GPU of --gpus in turn; SVDSS_GPU_INFLATE)
+    const int n_dev0 = std::max(1, svdss_device_count());
+    svdss_enable_gpu_inflate(*bam, 0, std::min(std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev0)), n_dev0));
+    if (bam->ok() && !getenv("SVDSS_NO_PREWARM")) bam_prewarm = std::thread([bam] { bam->prewarm(); });
+  }
   check(svdss_index_load(o.index.c_str(), &ix), "svdss_index_load");
   if (o.verbose) logmsg("debug", "index file read at +" + since() + " s");
   check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
@@ -314,13 +325,9 @@ int main_search(const Options& o) {
     replicas.push_back(r);
   }
   if (n_gpus > 1) logmsg("info", "Index replicated on " + std::to_string(n_gpus) + " GPUs");
-  const bool bam_mode = !o.bam.empty();
-  BamReader* bam = nullptr;
   FastxReader* fx = nullptr;
   if (bam_mode) {
-    bam = new BamReader(o.bam, o.io_threads);
-    // (BGZF blocks inflated on the GPU, csrc/inflate.hip, on every GPU of --gpus in turn; SVDSS_GPU_INFLATE)
-    svdss_enable_gpu_inflate(*bam, 0, std::min(n_gpus, n_dev));
+    if (bam_prewarm.joinable()) bam_prewarm.join();
     if (!bam->ok() || !bam->read_header()) die("cannot read " + o.bam + ": " + bam->error());
   } else {
     logmsg("warning", "FASTX mode is not optimized (higher running times and larger SFSs set).");
