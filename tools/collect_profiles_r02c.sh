@@ -5,6 +5,7 @@
 #   gpurun_out/r02c/bench_under_rocprof.json + kernel_stats.csv   rocprofv3 --kernel-trace --stats -- python bench.py ...
 #   gpurun_out/r02c/pmc_wg.csv, pmc_chr20.csv           separate --pmc passes on the search launches (tools/search_only.py)
 #   gpurun_out/r02c/op_counts_wg.txt                    counting build (make count): lane operations by type
+#   gpurun_out/r02c/pmc_inflate.csv                     the inflate kernel (tools/inflate_probe.py 8192 1 bam)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02c
 mkdir -p $O
@@ -25,7 +26,7 @@ rows = []
 for f in sorted(glob.glob("$1*/**/*counter_collection.csv", recursive=True)):
     acc, n = {}, {}
     for row in csv.DictReader(open(f)):
-        k = (row["Kernel_Name"].split("(")[0][:70], row["Counter_Name"])
+        k = (row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:70], row["Counter_Name"])
         acc[k] = acc.get(k, 0.0) + float(row["Counter_Value"]); n[k] = n.get(k, 0) + 1
     for (kern, ctr), v in sorted(acc.items()):
         if re.search("$2", kern):
@@ -47,6 +48,14 @@ rm -rf $O/pmcwg_[0-9]*
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B --kernel-trace --kernel-include-regex "sfs_search2" --output-format csv -d $O/pmcchr20_1 -- python $R/tools/search_only.py chr20 128888 5 > $O/search_only_chr20.log 2>&1
 summarize "$O/pmcchr20_" "sfs_" "$O/pmc_chr20.csv"
 rm -rf $O/pmcchr20_[0-9]*
+i=0
+for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "TCC_EA0_RDREQ TCC_EA0_WRREQ TCC_EA0_WRREQ_64B"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "bgzf_inflate" --output-format csv -d $O/pmcinf_$i -- python $R/tools/inflate_probe.py 8192 1 bam > $O/inflate_probe_$i.log 2>&1
+done
+summarize "$O/pmcinf_" "bgzf_inflate" "$O/pmc_inflate.csv"
+rm -rf $O/pmcinf_[0-9]*
+grep "no   copy" $O/inflate_probe_1.log | tail -1
 SVDSS_DEBUG=1 SVDSS_LIB=$R/svdss_amd/libsvdss_hip_count.so timeout 600 python $R/tools/search_only.py wg 1048576 1 2>&1 | grep "^\[svdss\]\|^wg" > $O/op_counts_wg.txt
 cat $O/op_counts_wg.txt | cut -c1-250
 head -14 $O/kernel_stats.csv | cut -c1-170
