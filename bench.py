@@ -531,6 +531,18 @@ def main():
             out["cpu_baseline"], out["verified_reads"] = cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads,
                                                                                args.cpu_seconds)
         if world == 1 and not args.no_e2e:
+            # the end-to-end run is a process of its own on the same GPU: this one lets go of the index (127 GB), the
+            # reads and the call-side arenas first
+            for sp, _ in searchers:
+                sp.close()
+            for w in workers:
+                for h, free in ((w._poa, lib.svdss_poa_batch_free), (w._aln, lib.svdss_aln_batch_free)):
+                    if h:
+                        free(h)
+                w._poa, w._aln = C.c_void_p(), C.c_void_p()
+            ix.close()
+            del d_reads, d_offs
+            torch.cuda.empty_cache()
             out.update(e2e_search_rate(args.e2e_reads))
         print(json.dumps(out), flush=True)
     if world > 1:
