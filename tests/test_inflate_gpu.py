@@ -66,6 +66,52 @@ def test_every_block_type_level_and_strategy():
     assert o == len(out)
 
 
+def test_random_mixtures_of_literals_runs_and_copies():
+    """400 streams stitched from random pieces -- bytes of alphabets of 2 to 256 symbols (code lengths from 1 bit to
+    the one-symbol path), runs, copies of earlier pieces at every distance, BAM-like records -- at random levels and
+    strategies: rounds that end at a match, at the byte budget of a round, at the end-of-block code or at a code the
+    tables cannot decode, in every combination the pointer-doubling chain has to get right."""
+    from svdss_amd.bamio import gpu_inflate
+    rng = np.random.default_rng(2024)
+    streams, want = [], []
+    for k in range(400):
+        target = int(rng.integers(1, 65537))
+        buf = bytearray()
+        while len(buf) < target:
+            kind = int(rng.integers(0, 5))
+            n = int(rng.integers(1, 3000))
+            if kind == 0:
+                a = int(rng.choice([2, 3, 4, 16, 40, 200, 256]))
+                buf += rng.integers(0, a, size=n, dtype=np.uint8).tobytes()
+            elif kind == 1:
+                buf += bytes([int(rng.integers(0, 256))]) * n
+            elif kind == 2 and buf:
+                d = int(rng.integers(1, min(len(buf), 32768) + 1))
+                for _ in range(n):                      # (a copy may overlap itself)
+                    buf.append(buf[-d])
+            elif kind == 3:
+                w = bytes(rng.integers(97, 123, size=int(rng.integers(2, 12)), dtype=np.uint8))
+                buf += (w + b" ") * (n // len(w) + 1)
+            else:
+                p_ = np.r_[0.97, np.full(254, 0.03 / 254)]   # one very short code, many very long ones
+                buf += rng.choice(np.arange(255, dtype=np.uint8), p=p_, size=n).tobytes()
+        data = bytes(buf[:target])
+        level = int(rng.choice([1, 1, 6, 9]))
+        strat = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 6))]
+        streams.append(_raw(data, level, strat, memlevel=int(rng.choice([1, 8, 9])))); want.append(data)
+    comp, blocks = bytearray(), []
+    for s_, w in zip(streams, want):
+        comp += b"\x5a" * int(rng.integers(0, 4))
+        blocks.append((len(comp), len(s_), len(w)))
+        comp += s_
+    out = gpu_inflate(bytes(comp), blocks).tobytes()
+    o = 0
+    for i, w in enumerate(want):
+        assert out[o:o + len(w)] == w, "stream %d" % i
+        o += len(w)
+    assert o == len(out)
+
+
 def test_scattered_outputs_do_not_touch_their_neighbours():
     from svdss_amd.bamio import gpu_inflate
     rng = np.random.default_rng(5)
