@@ -227,8 +227,8 @@ class CallWorkload:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["wg", "chr20"], default="wg",
                     help="wg (default, the metric's configuration): 24 contigs with GRCh38 primary lengths, 1,048,576 "
                          "reads per GPU per step; chr20: one 64,444,167 bp contig, 30x = 128,888 reads per step")
