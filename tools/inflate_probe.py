@@ -1,5 +1,5 @@
 """Developer probe: throughput of the GPU BGZF inflate (svdss_bgzf_inflate) on BAM-like blocks.
-  python tools/inflate_probe.py [n_blocks] [level] [kind]     kind: bam (packed bases + random qualities) | binned | text"""
+  python tools/inflate_probe.py [n_blocks] [level] [kind]     kind: bam (packed bases + random qualities) | binned | skew | text"""
 import ctypes as C
 import sys
 import time
@@ -21,6 +21,13 @@ for i in range(uniq):
     elif kind == "binned":
         a = rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88], dtype=np.uint8), size=21760)
         b = rng.choice(np.array([2, 10, 20, 30, 40, 93], dtype=np.uint8), p=[.02, .03, .05, .1, .3, .5], size=43520)
+        raw = np.concatenate([a, b]).tobytes()
+    elif kind == "skew":
+        # qualities over the full range with a long tail of rare values (unbinned HiFi: most bases at the cap): codes
+        # of 1 to 13+ bits, the rare ones longer than the direct table's index
+        a = rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88], dtype=np.uint8), size=21760)
+        pq = np.r_[np.full(93, 0.35 / 93) * np.linspace(0.05, 1.95, 93), 0.65]
+        b = rng.choice(np.arange(94, dtype=np.uint8), p=pq / pq.sum(), size=43520)
         raw = np.concatenate([a, b]).tobytes()
     else:
         raw = (b"the quick brown fox jumps over the lazy dog %d. " % i * 1500)[:65280]
