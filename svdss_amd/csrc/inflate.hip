@@ -164,7 +164,6 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
   const uint64_t in_first = (uint64_t)B.coff, in_end = in_first + (uint64_t)(uint32_t)B.clen;
   uint8_t* const o8 = out + B.uoff;
   uint8_t* const winb = (uint8_t*)L.win;
-  const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
   if (isize == 0) { if (lane == 0) status[blockIdx.x] = ST_OK; return; }
 #ifdef INF_COUNT
   unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
