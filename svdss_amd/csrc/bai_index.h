@@ -123,12 +123,14 @@ inline std::string bam_scan_chunks(const std::string& path, const std::vector<st
       memcpy(&xlen, h + 10, 2);
       if (xlen != 6 || h[12] != 'B' || h[13] != 'C') { err = "BGZF block without BC field"; return false; }
       memcpy(&bsize, h + 16, 2);
+      if ((size_t)bsize + 1 < 18u + 8u) { err = "bad BGZF block"; return false; }
       const size_t clen = (size_t)bsize + 1 - 18 - 8;
       if (cbuf.size() < clen + 8) cbuf.resize(clen + 8);
       if (fread(cbuf.data(), 1, clen + 8, f) != clen + 8) { err = "truncated BGZF block"; return false; }
       uint32_t crc, isize;
       memcpy(&crc, cbuf.data() + clen, 4);
       memcpy(&isize, cbuf.data() + clen + 4, 4);
+      if (isize > 65536u) { err = "bad BGZF block"; return false; }   // (BGZF caps a block's inflated size)
       block_at.emplace_back(cpos, ubuf.size());
       const size_t at = ubuf.size();
       ubuf.resize(at + isize);
@@ -175,6 +177,19 @@ inline std::string bam_scan_chunks(const std::string& path, const std::vector<st
       v.l_aux = (uint32_t)((size_t)block_size - head);
       fn(v);
       upos += 4 + (size_t)block_size;
+      // a merged chunk can span whole chromosomes: drop the blocks the walk has left behind once they add up to 4 MB
+      // (the block that holds upos stays, so voff_of keeps answering for every position still reachable)
+      if (upos >= ((size_t)4 << 20)) {
+        size_t k = 0;
+        while (k + 1 < block_at.size() && block_at[k + 1].second <= upos) ++k;
+        const size_t cut = std::min(block_at[k].second, upos);
+        if (k > 0 && cut > 0) {
+          ubuf.erase(ubuf.begin(), ubuf.begin() + (long)cut);
+          block_at.erase(block_at.begin(), block_at.begin() + (long)k);
+          for (auto& b : block_at) b.second -= cut;
+          upos -= cut;
+        }
+      }
     }
     if (!err.empty()) break;
     (void)file_end;

@@ -286,6 +286,7 @@ class BamReader {
           try {
             Bytes b;
             b.alloc(i < n_comp ? slab_ + kOverlap : out_bytes, true);
+            if (b.pin_refused) return;   // no more page-locked memory to be had: the loaders use ordinary buffers
             FreeList& fl = i < n_comp ? *comp_free_ : *free_;
             std::lock_guard<std::mutex> lk(fl.m);
             fl.v.push_back(std::move(b));
@@ -370,24 +371,54 @@ class BamReader {
   };
   static PinHooks& pin_hooks() { static PinHooks h; return h; }
 
+  // Page-locked memory is a bounded resource: the buffers in flight between the loaders and the parser are pinned, what
+  // a caller keeps for long (the record cache of `call` pass 1) must not be.  Pinned bytes are counted and capped
+  // (SVDSS_PIN_CAP_GB, default 8); past the cap, or when the runtime refuses, a buffer is ordinary memory -- the GPU
+  // inflate path takes either kind.
+  static std::atomic<long long>& pinned_bytes() { static std::atomic<long long> v{0}; return v; }
+  static long long pin_cap_bytes() {
+    static const long long cap = [] {
+      const char* e = getenv("SVDSS_PIN_CAP_GB");
+      const double gb = e && *e ? atof(e) : 8.0;
+      return (long long)(gb * (double)(1ll << 30));
+    }();
+    return cap;
+  }
+
   struct Bytes {   // uninitialised buffer (std::vector would zero-fill what inflate overwrites anyway)
     struct Deleter {
       bool pinned;
-      Deleter() : pinned(false) {}
-      explicit Deleter(bool p_) : pinned(p_) {}
-      void operator()(uint8_t* q) const { if (pinned) pin_hooks().free_(q); else free(q); }
+      size_t bytes;
+      Deleter() : pinned(false), bytes(0) {}
+      explicit Deleter(bool p_, size_t b_ = 0) : pinned(p_), bytes(b_) {}
+      void operator()(uint8_t* q) const {
+        if (pinned) { pin_hooks().free_(q); pinned_bytes().fetch_sub((long long)bytes); }
+        else free(q);
+      }
     };
     std::unique_ptr<uint8_t[], Deleter> p;
     size_t n = 0, cap = 0;
+    bool pin_refused = false;   // this buffer asked for page-locked memory and got ordinary memory: do not ask again
     // (chunk-sized buffers: 2 MB-aligned and advised for huge pages -- 25 faults per 50 MB chunk instead of 12,800)
     void alloc(size_t k, bool pinned = false) {
-      if (k > cap || !p || (pinned && !p.get_deleter().pinned)) {
+      if (k > cap || !p || (pinned && !p.get_deleter().pinned && !pin_refused)) {
         size_t c = k ? k : 1;
+        bool done = false;
         if (pinned && pin_hooks().alloc) {
-          c = (c + c / 8 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+          const size_t cp = (c + c / 8 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
           void* q = nullptr;
-          if (pin_hooks().alloc((int64_t)c, &q) != 0 || !q) throw std::bad_alloc();
-          p = std::unique_ptr<uint8_t[], Deleter>((uint8_t*)q, Deleter(true));
+          if (pinned_bytes().fetch_add((long long)cp) + (long long)cp <= pin_cap_bytes() &&
+              pin_hooks().alloc((int64_t)cp, &q) == 0 && q) {
+            p = std::unique_ptr<uint8_t[], Deleter>((uint8_t*)q, Deleter(true, cp));
+            c = cp;
+            done = true;
+            pin_refused = false;
+          } else {
+            pinned_bytes().fetch_sub((long long)cp);
+            pin_refused = true;          // cap reached or the runtime said no: pageable memory below
+          }
+        }
+        if (done) {
         } else if (c >= ((size_t)4 << 20)) {
           c = (c + c / 8 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
           void* q = nullptr;
@@ -405,7 +436,7 @@ class BamReader {
     uint8_t* data() { return p.get(); }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
-    void swap(Bytes& o) { p.swap(o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+    void swap(Bytes& o) { p.swap(o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(pin_refused, o.pin_refused); }
   };
 
   struct FreeList { std::mutex m; std::vector<Bytes> v; };
@@ -685,6 +716,12 @@ class BamReader {
   // runs on background threads.  File reads happen in ticket order (one loader at a time); the inflate of a
   // chunk overlaps the file read of the next one.
   Chunk load_chunk(uint64_t ticket) {
+    // (std::async would carry an exception to the parser's get() and end the process: report it like any other error)
+    try { return load_chunk_impl(ticket); }
+    catch (const std::bad_alloc&) { Chunk c; c.err = "out of memory while loading a BAM chunk"; return c; }
+    catch (const std::exception& e) { Chunk c; c.err = std::string("BAM chunk loader: ") + e.what(); return c; }
+  }
+  Chunk load_chunk_impl(uint64_t ticket) {
     Chunk c;
     std::vector<BlockRef> blocks;
     size_t total = 0;
@@ -692,15 +729,19 @@ class BamReader {
     std::shared_ptr<Bytes> own;
     size_t own_got = 0;
     const size_t base = (size_t)ticket * slab_;
+    // (nothing may leave this function before the ticket below is taken and released: the other loaders wait for it)
+    const char* early_err = nullptr;
     if (pread_size_ && base < pread_size_) {
-      own = take_comp();
-      const size_t want = std::min(slab_ + kOverlap, pread_size_ - base);
-      own->alloc(slab_ + kOverlap, gpu_.inflate != nullptr);
-      while (own_got < want) {
-        const ssize_t k = pread(fileno(f_), own->data() + own_got, want - own_got, (off_t)(base + own_got));
-        if (k <= 0) break;
-        own_got += (size_t)k;
-      }
+      try {
+        own = take_comp();
+        const size_t want = std::min(slab_ + kOverlap, pread_size_ - base);
+        own->alloc(slab_ + kOverlap, gpu_.inflate != nullptr);
+        while (own_got < want) {
+          const ssize_t k = pread(fileno(f_), own->data() + own_got, want - own_got, (off_t)(base + own_got));
+          if (k <= 0) break;
+          own_got += (size_t)k;
+        }
+      } catch (const std::bad_alloc&) { early_err = "out of memory while loading a BAM chunk"; }
     }
     std::unique_lock<std::mutex> file_lock(file_m_);
     file_cv_.wait(file_lock, [&] { return next_ticket_ == ticket; });
@@ -709,6 +750,7 @@ class BamReader {
       void operator()() { if (!done) { done = true; ++r->next_ticket_; lk->unlock(); r->file_cv_.notify_all(); } }
       ~Release() { (*this)(); }
     } release{this, &file_lock};
+    if (early_err) { c.err = early_err; file_eof_ = true; return c; }
     if (file_eof_) { c.eof = true; return c; }
     const auto ts0 = std::chrono::steady_clock::now();
     // mapped file: the blocks of this chunk are located in the mapping; otherwise one large read per chunk (plus the
@@ -760,6 +802,7 @@ class BamReader {
       b.coff = pos + 12 + xlen; b.clen = cdata; b.uoff = total;
       memcpy(&b.crc, src + b.coff + cdata, 4);
       memcpy(&b.isize, src + b.coff + cdata + 4, 4);
+      if (b.isize > 65536u) { c.err = "bad BGZF block"; file_eof_ = true; return c; }   // (BGZF caps the inflated size)
       total += b.isize;
       blocks.push_back(b);
       pos += (size_t)bsize + 1;
@@ -896,11 +939,11 @@ class BamReader {
     {
       std::lock_guard<std::mutex> lk(free_->m);
       for (size_t i = 0; i < free_->v.size(); ++i)
-        if (free_->v[i].cap >= bytes && (!pinned || free_->v[i].p.get_deleter().pinned)) {
+        if (free_->v[i].cap >= bytes && (!pinned || free_->v[i].p.get_deleter().pinned || free_->v[i].pin_refused)) {
           dst.swap(free_->v[i]); free_->v.erase(free_->v.begin() + (long)i); break;
         }
     }
-    const bool fresh = dst.cap < bytes || !dst.p || (pinned && !dst.p.get_deleter().pinned);
+    const bool fresh = dst.cap < bytes || !dst.p || (pinned && !dst.p.get_deleter().pinned && !dst.pin_refused);
     const auto t0 = std::chrono::steady_clock::now();
     dst.alloc(bytes, pinned);
     if (fresh) {

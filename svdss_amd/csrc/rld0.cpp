@@ -9,7 +9,7 @@
 //            | u64 mcnt[asize] (occurrences of every symbol)
 //   data     k words, a sequence of small blocks of ssize = 2^sbits words.  A block starts with the symbol counts of
 //            the PREVIOUS block -- asize + 1 values (total first), 16-bit each if the total is below 0x4000 (type 0,
-//            2 words for asize = 6), else 32-bit (type 1, 4 words); the type sits in the top two bits of the first
+//            2 words for asize = 6), 32-bit below 2^30 (type 1, 4 words), else 64-bit (type 2, 7 words); the type sits in the top two bits of the first
 //            word -- followed by the runs of the BWT: Elias-delta code of the run length, then the symbol in
 //            abits = ilog2(asize) + 1 bits, packed most-significant-bit first.  A code never crosses a block
 //            boundary (the block is zero-padded); data is kept in 2^23-word pieces, the last block of a piece ends
@@ -41,7 +41,7 @@ constexpr int RLD_LBITS = 23;
 constexpr int64_t RLD_LSIZE = (int64_t)1 << RLD_LBITS;
 constexpr int RLD_IBITS_PLUS = 4;
 constexpr int ASIZE = 6, ASIZE1 = 7, ABITS = 3, SBITS = 3, SSIZE = 1 << SBITS;
-constexpr int OFFSET0[2] = {(ASIZE1 * 16 + 63) / 64, (ASIZE1 * 32 + 63) / 64};   // header words of a type 0 / 1 block
+constexpr int OFFSET0[3] = {(ASIZE1 * 16 + 63) / 64, (ASIZE1 * 32 + 63) / 64, ASIZE1};   // header words of a type 0 / 1 / 2 block
 
 inline int ilog2_64(uint64_t v) { return 63 - __builtin_clzll(v); }
 
@@ -83,17 +83,21 @@ struct Encoder {
       for (int i = 0; i < ASIZE1; ++i) h[i] = (uint16_t)(cnt[i] - mcnt[i]);
       memcpy(&z[(size_t)shead], h, sizeof h);
       type = 0;
-    } else {
+    } else if (cnt[0] - mcnt[0] < 0x40000000) {
       uint32_t h[ASIZE1];
       for (int i = 0; i < ASIZE1; ++i) h[i] = (uint32_t)(cnt[i] - mcnt[i]);
       memcpy(&z[(size_t)shead], h, sizeof h);
       type = 1;
+    } else {   // a run of 2^30 symbols or more: 64-bit counts (readers mask type-1 counts to 30 bits)
+      for (int i = 0; i < ASIZE1; ++i) z[(size_t)shead + (size_t)i] = cnt[i] - mcnt[i];
+      type = 2;
     }
     z[(size_t)shead] |= (uint64_t)type << 62;
     p = shead + OFFSET0[type];
     stail = block_tail(shead);
     r = 64;
     for (int i = 0; i < ASIZE1; ++i) mcnt[i] = cnt[i];
+    if (p > stail) next_block();   // (a type-2 header in the short last block of a piece leaves no data word)
   }
   void enc1(int64_t l, int c) {   // rld_enc1
     int w;
@@ -163,7 +167,9 @@ int rld0_write(const char* path, const uint8_t* bwt, int64_t n) {
     uint64_t fk = 1;
     for (int64_t i = SSIZE; i <= last; i += SSIZE) {
       const uint64_t w0 = e.z[(size_t)i];
-      if (w0 >> 62) {
+      if ((w0 >> 62) == 2) {
+        for (int j = 1; j <= ASIZE; ++j) cnt[j - 1] += e.z[(size_t)i + (size_t)j];
+      } else if (w0 >> 62) {
         uint32_t h[ASIZE1];
         memcpy(h, &e.z[(size_t)i], sizeof h);
         for (int j = 1; j <= ASIZE; ++j) cnt[j - 1] += h[j] & 0x3fffffffu;
@@ -198,6 +204,19 @@ int rld0_write(const char* path, const uint8_t* bwt, int64_t n) {
   return ok ? SVDSS_OK : SVDSS_EIO;
 }
 
+int rld0_header_counts(const char* path, uint64_t mcnt_out[6]) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return SVDSS_EIO;
+  char magic[4];
+  uint32_t a = 0;
+  uint64_t k = 0, n_frames = 0;
+  const bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "RLD\3", 4) == 0 && fread(&a, 4, 1, f) == 1 &&
+                  fread(&k, 8, 1, f) == 1 && fread(&n_frames, 8, 1, f) == 1 && (a >> 16) == (uint32_t)ASIZE &&
+                  fread(mcnt_out, 8, ASIZE, f) == (size_t)ASIZE;
+  fclose(f);
+  return ok ? SVDSS_OK : SVDSS_EIO;
+}
+
 int rld0_read(const char* path, std::vector<uint8_t>& bwt) {
   FILE* f = fopen(path, "rb");
   if (!f) return SVDSS_EIO;
@@ -209,19 +228,22 @@ int rld0_read(const char* path, std::vector<uint8_t>& bwt) {
   const int asize = (int)(a >> 16), sbits = (int)(a & 0xffff);
   if (asize != ASIZE || sbits < 2 || sbits > 16) { fclose(f); return SVDSS_EIO; }   // nt6 indexes only
   if (fread(mcnt, 8, (size_t)asize, f) != (size_t)asize) { fclose(f); return SVDSS_EIO; }
+  // (a block is read up to its tail whatever k says: room for the whole last block, zeroed)
+  const uint64_t ssz = (uint64_t)1 << sbits;
+  if (k > ((uint64_t)1 << 40)) { fclose(f); return SVDSS_EIO; }
   std::vector<uint64_t> z;
-  try { z.resize((size_t)k + 2, 0); } catch (...) { fclose(f); return SVDSS_ENOMEM; }
+  try { z.resize((size_t)((k + ssz - 1) / ssz * ssz + ssz + 2), 0); } catch (...) { fclose(f); return SVDSS_ENOMEM; }
   if (k && fread(z.data(), 8, (size_t)k, f) != (size_t)k) { fclose(f); return SVDSS_EIO; }
   fclose(f);
   uint64_t total = 0;
   for (int c = 0; c < asize; ++c) total += mcnt[c];
   try { bwt.assign((size_t)total, 0); } catch (...) { return SVDSS_ENOMEM; }
   const int ssize = 1 << sbits;
-  const int off0[2] = {(ASIZE1 * 16 + 63) / 64, (ASIZE1 * 32 + 63) / 64};
+  const int off0[3] = {(ASIZE1 * 16 + 63) / 64, (ASIZE1 * 32 + 63) / 64, ASIZE1};
   uint64_t out = 0;
   for (int64_t shead = 0; shead < (int64_t)k && out < total; shead += ssize) {
     const int type = (int)(z[(size_t)shead] >> 62);
-    if (type > 1) return SVDSS_EIO;
+    if (type > 2) return SVDSS_EIO;
     int64_t p = shead + off0[type];
     const int64_t stail = shead + ssize - (((shead + ssize) & (RLD_LSIZE - 1)) == 0 ? 2 : 1);
     int r = 64;

@@ -9,6 +9,8 @@ struct svdss_index;
 bool rld0_is_fmd(const char* path);
 // BWT symbols 0..5 -> file; SVDSS_OK / SVDSS_EINVAL / SVDSS_EIO
 int rld0_write(const char* path, const uint8_t* bwt, int64_t n);
+// the header's occurrence count of every symbol (cheap: 72 bytes read)
+int rld0_header_counts(const char* path, uint64_t mcnt_out[6]);
 // file -> BWT symbols
 int rld0_read(const char* path, std::vector<uint8_t>& bwt);
 // rank blocks, acc and '$' rows of a BWT into *ix (text and suffix array stay empty)

@@ -200,19 +200,48 @@ static int import_fmd(const char* path, svdss_index_t** out) {
 extern "C" int svdss_index_load(const char* path, svdss_index_t** out) {
   if (!path || !out) return SVDSS_EINVAL;
   std::string file = path;
+  bool is_cache = false;
+  uint64_t mcnt[6] = {0, 0, 0, 0, 0, 0};
   if (rld0_is_fmd(path)) {
-    // `SVDSS index` leaves this library's own layout beside the .fmd it writes: restoring that is a plain read
+    // `SVDSS index` leaves this library's own layout beside the .fmd it writes: restoring that is a plain read.  The
+    // cache must belong to THIS .fmd: not older, and with the symbol counts of the .fmd's header (an .fmd replaced
+    // under a preserved mtime, or an upstream-built one for another reference, is imported instead).
     const std::string cache = file + ".svdss";
     struct stat a, c;
-    if (!getenv("SVDSS_INDEX_NO_CACHE") && stat(path, &a) == 0 && stat(cache.c_str(), &c) == 0 && c.st_mtime >= a.st_mtime)
+    if (!getenv("SVDSS_INDEX_NO_CACHE") && stat(path, &a) == 0 && stat(cache.c_str(), &c) == 0 &&
+        c.st_mtime >= a.st_mtime && rld0_header_counts(path, mcnt) == SVDSS_OK) {
       file = cache;
-    else
+      is_cache = true;
+    } else
       return import_fmd(path, out);
+  } else {
+    // Neither rld0 nor this library's own layout: most likely ropebwt3's other format (.fmr, mrope -- what `ropebwt3
+    // build` writes without -d; rb3_fmi_restore of ping_pong.cpp:245 falls back to it when the rld0 restore fails).
+    // It is not read here; say so instead of a bare I/O error.  (Its magic is not restated from memory: the file is
+    // recognised by what it is not.)
+    FILE* f = fopen(path, "rb");
+    char m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool readable = f && fread(m, 1, 8, f) == 8;
+    if (f) fclose(f);
+    if (readable && memcmp(m, "SVDSSFM2", 8) != 0) {
+      g_svdss_hip_err = "not an rld0 .fmd (magic RLD\\3) and not this library's index layout; if it is an .fmr (mrope) "
+                        "index, convert it with `ropebwt3 build -i in.fmr -do out.fmd` or rebuild with `SVDSS index -d`";
+      return SVDSS_EINVAL;
+    }
   }
   svdss_index* ix = new (std::nothrow) svdss_index();
   if (!ix) return SVDSS_ENOMEM;
   int rc = svdss_index_load_host(file.c_str(), ix);
-  if (rc != SVDSS_OK) { delete ix; return rc; }
+  if (rc == SVDSS_OK && is_cache) {
+    bool same = true;
+    for (int c = 0; c < 6; ++c) same = same && (uint64_t)(ix->acc[c + 1] - ix->acc[c]) == mcnt[c];
+    if (!same) rc = SVDSS_EIO;
+  }
+  if (rc != SVDSS_OK) {
+    delete ix;
+    if (is_cache) return import_fmd(path, out);   // stale, truncated or foreign cache: the .fmd itself is the index
+    return rc;
+  }
   *out = ix;
   return SVDSS_OK;
 }

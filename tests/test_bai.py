@@ -75,3 +75,39 @@ def test_regions_through_the_index_are_the_overlapping_records_of_a_sequential_r
         assert len(set(got)) == len(got), regions
     # the index is worth having: a small region reads a small part of the file
     assert len(through_index([(0, 1_000_000, 1_000_001)])) < len(meta) // 10
+
+
+def test_corrupt_block_headers_are_reported_not_followed(tmp_path, exe):
+    """a BSIZE below the fixed header + footer, or an ISIZE above BGZF's 64 KB, must end in
+    "bad BGZF block" -- not in a wrapped length or a multi-GB allocation -- in the indexed scan (bai_index.h) and in
+    the sequential reader (bam_reader.h)."""
+    import struct
+    rng = np.random.default_rng(5)
+    recs = []
+    for k in range(60):
+        l = 9000
+        seq = "".join("ACGT"[x] for x in rng.integers(0, 4, size=l))
+        recs.append(bam_writer.record(f"r{k}", 0, 0, 1000 * k, 60, [("M", l)], seq,
+                                      qual=bytes(rng.integers(20, 60, size=l, dtype=np.uint8).tolist())))
+    data = bytearray(bam_writer.bam([("c0", 500_000)], recs))
+    (tmp_path / "ok.bam").write_bytes(data)
+    (tmp_path / "ok.bam.bai").write_bytes(bam_writer.bai(bytes(data)))
+    # walk the blocks, pick the third one
+    offs, pos = [], 0
+    while pos < len(data):
+        bsize = struct.unpack_from("<H", data, pos + 16)[0]
+        offs.append((pos, bsize + 1))
+        pos += bsize + 1
+    assert len(offs) > 6
+    at, ln = offs[2]
+    for name, patch in (("bsize", lambda d: struct.pack_into("<H", d, at + 16, 10)),
+                        ("isize", lambda d: struct.pack_into("<I", d, at + ln - 4, 0x7fffffff))):
+        bad = bytearray(data)
+        patch(bad)
+        p = tmp_path / f"{name}.bam"
+        p.write_bytes(bad)
+        (tmp_path / f"{name}.bam.bai").write_bytes((tmp_path / "ok.bam.bai").read_bytes())
+        r = subprocess.run([exe, str(p), str(p) + ".bai", "0:0-500000"], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "bad BGZF block" in r.stderr, (name, r.stderr)
+        r = subprocess.run([exe, str(p), "-"], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "BGZF" in r.stderr, (name, r.stderr)

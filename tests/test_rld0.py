@@ -184,3 +184,48 @@ def test_rejects_what_is_not_a_both_strand_index(tmp_path):
     (tmp_path / "junk.fmd").write_bytes(b"RLD\x03" + b"\1" * 10)
     with pytest.raises(SvdssError):
         svdss_amd.FMDIndex.load(str(tmp_path / "junk.fmd"))
+
+
+def test_cache_of_another_fmd_is_not_used(tmp_path):
+    """nothing but the mtime tied `<fmd>.svdss` to the .fmd.  A cache with other symbol counts (an .fmd
+    swapped under a preserved mtime) or a truncated one must send the load through the import path."""
+    ref_a = synth.make_reference([9000], seed=8)
+    ref_b = synth.make_reference([7000], seed=9)
+    a = svdss_amd.FMDIndex.build(ref_a)
+    b = svdss_amd.FMDIndex.build(ref_b)
+    a.save_fmd(str(tmp_path / "x.fmd"))
+    b.save(str(tmp_path / "x.fmd.svdss"))                      # newer, but the layout of ANOTHER reference
+    got = svdss_amd.FMDIndex.load(str(tmp_path / "x.fmd"))
+    assert got.size == a.size and (got.acc == a.acc).all()
+    assert got.count(ref_a[0][500:560]) == a.count(ref_a[0][500:560]) >= 1
+    a.save(str(tmp_path / "x.fmd.svdss"))
+    raw = (tmp_path / "x.fmd.svdss").read_bytes()
+    (tmp_path / "x.fmd.svdss").write_bytes(raw[:len(raw) // 2])  # truncated cache: fall back, do not fail
+    got = svdss_amd.FMDIndex.load(str(tmp_path / "x.fmd"))
+    assert got.size == a.size and got.count(ref_a[0][100:160]) == a.count(ref_a[0][100:160])
+
+
+def test_an_index_in_another_format_is_diagnosed(tmp_path):
+    """rb3_fmi_restore (ping_pong.cpp:245) also takes ropebwt3's .fmr; this library does not and says what to do."""
+    (tmp_path / "ref.fmr").write_bytes(b"\x01\x02\x03\x04" + bytes(200))
+    with pytest.raises(SvdssError) as e:
+        svdss_amd.FMDIndex.load(str(tmp_path / "ref.fmr"))
+    assert ".fmr" in str(e.value) and "ropebwt3 build" in str(e.value)
+
+
+def test_reader_takes_64_bit_block_headers_and_bounds_its_reads(tmp_path):
+    """A type-2 block (64-bit counts, written when a block covers 2^30 symbols or more) leaves one data word at
+    sbits = 3; a data length that is not a whole number of blocks must not be read past."""
+    def delta(x):
+        y = x.bit_length() - 1
+        z = (y + 1).bit_length() - 1
+        return "0" * z + format(y + 1, f"0{z + 1}b") + (format(x ^ (1 << y), f"0{y}b") if y else "")
+    w_a = int((delta(5) + "001").ljust(64, "0"), 2)             # block 0: AAAAA
+    w_b = int((delta(3) + "010" + delta(2) + "000").ljust(64, "0"), 2)   # block 1 (type 2): CCC $$
+    blk0 = [0, 0, w_a, 0, 0, 0, 0, 0]
+    blk1 = [5 | (2 << 62), 0, 5, 0, 0, 0, 0, w_b]               # counts of block 0: total 5, A 5
+    words = blk0 + blk1 + [5, 2, 0, 3]                            # + the start of a closing header, cut short
+    raw = b"RLD\x03" + struct.pack("<IQQ", 6 << 16 | 3, len(words), 1) + struct.pack("<6Q", 2, 5, 3, 0, 0, 0)
+    raw += struct.pack(f"<{len(words)}Q", *words) + struct.pack("<7Q", *([0] * 7))
+    (tmp_path / "t2.fmd").write_bytes(raw)
+    assert read_bwt(tmp_path / "t2.fmd").tolist() == [1] * 5 + [2] * 3 + [0] * 2
