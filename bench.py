@@ -12,9 +12,13 @@ A "step" = one pass of the hot path over one batch of 1,048,576 reads per GPU (a
           svdss_poa_consensus_batch (caller.cpp:257-308), svdss_align_global_batch of every consensus against its
           reference window (caller.cpp:332-355), svdss_indel_ratio_batch on adjacent alleles (caller.cpp:456-458).
           The sub-reads are handed over as host buffers (~120 MB per step), as `pcall` hands them to abPOA.
-value = reads / wall time of the steps.  In the same run the first reads of the batch are searched by the CPU oracle
-(cpu_baseline) and the GPU's counts / starts / lengths / extension counts for those reads are compared with it:
-`verified_reads`; the bench fails on a mismatch.
+value = reads / wall time of the steps.  In the same run the index is checked row by row against its text
+(svdss_index_verify_device: `index_verified_rows`), the first reads of the batch are searched by the CPU oracle and a
+sample of the step's sub-clusters goes through the oracle's POA / realignment / ratio (cpu_baseline: search, call and
+the combined rate), and the GPU's results for those reads (counts / starts / lengths / extension counts) and
+sub-clusters (consensus lengths, alignment scores, CIGAR lengths, ratios) are compared with them: `verified_reads`,
+`verified_subclusters`; the bench fails on a mismatch.  Then the binaries run end to end (file- and PCIe-inclusive,
+never `value`): `SVDSS search` on a BAM against a chr20-length and against the whole-genome index, `SVDSS call`.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -22,8 +26,9 @@ value = reads / wall time of the steps.  In the same run the first reads of the 
 Multi-GPU (config 5): the index is replicated (every rank builds its own replica in its HBM, svdss_index_build_device),
 the contigs are dealt to the ranks by LPT bin packing and every rank searches reads drawn from ITS contigs (weak
 scaling: 1,048,576 reads per rank per step) and calls its share of the clusters; the only collective is the gather of
-the assembled SFS on rank 0 (svdss_amd/multi.py: RCCL send/recv over xGMI straight from the library's HBM buffers),
-inside every timed step.  Rank 0 prints ONE JSON line.
+the assembled SFS on rank 0 (svdss_amd/multi.py SfsGatherer: RCCL send/recv over xGMI of exactly the bytes there are
+into pre-allocated buffers, step i's exchange beside step i+1's search), every step's exchange complete inside the
+timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -206,7 +211,7 @@ class CallWorkload:
                      "poa_cells": lib.svdss_poa_batch_cells(self._poa), "poa_hbm": lib.svdss_poa_batch_hbm(self._poa),
                      "realign_kernel_ms": lib.svdss_aln_batch_kernel_ms(self._aln),
                      "realign_cells": lib.svdss_aln_batch_cells(self._aln),
-                     "cons_len": cons_len, "n_cig": n_cig, "cig": cig, "scores": scores}
+                     "cons_len": cons_len, "n_cig": n_cig, "cig": cig, "scores": scores, "ratio": ratio}
 
     def svs_recovered(self, min_len=50):
         """sub-clusters of the alt allele whose CIGAR carries the implanted I/D (length within 2 %)."""
@@ -241,6 +246,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (also skips verification)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the SVDSS binary on a BAM file")
     ap.add_argument("--e2e-reads", type=int, default=1032000, help="reads in the BAM of the end-to-end run")
+    ap.add_argument("--no-e2e-wg", action="store_true", help="skip the end-to-end run against the whole-genome index")
+    ap.add_argument("--no-e2e-call", action="store_true", help="skip the end-to-end run of `SVDSS call`")
     ap.add_argument("--no-call-dp", action="store_true", help="search only (value is then NOT the headline metric)")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: leave the SFS on the ranks")
     ap.add_argument("--search-threads", type=int, default=1,
@@ -299,6 +306,18 @@ def main():
     t0 = time.time()
     ix = svdss_amd.FMDIndex.build(ref, device=local_rank)
     t_index = time.time() - t0
+    # the index against its own text, row by row, by code that shares nothing with the builder (csrc/index_verify.hip):
+    # the oracle below is built from this index's BWT and must not inherit an unchecked index
+    t0 = time.time()
+    iv = ix.verify()
+    t_verify = time.time() - t0
+    if iv["rows"] != ix.size or iv["first_bad"] != -1 or any(iv[k] for k in ("bad_order", "bad_bwt", "bad_range", "bad_block", "bad_dollar")):
+        raise SystemExit(f"INDEX VERIFICATION FAILED: {iv}")
+    e2e_dir = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        import tempfile
+        e2e_dir = tempfile.mkdtemp(prefix="svdss_bench_e2e_", dir="/tmp")
+        e2e_prepare(e2e_dir, ref, wg=(len(contig_lens) == 24 and not args.no_e2e_wg))
 
     # ---- reads: generated on the GPU from the contigs LPT gives this rank -------
     owner = lpt_partition(contig_lens, world)
@@ -325,19 +344,33 @@ def main():
     # that the call-side DP of earlier steps overlaps the search of the next one
     sstream = torch.cuda.Stream(device=device)
 
+    gatherer = multi.SfsGatherer(slots=2) if gather else None
+    pending_gather = []
+
     def search(assemble=True, pp=pp, sstream=sstream):
         pp.ping_pong_search_device(d_reads.data_ptr(), d_offs.data_ptr(), n_reads, total_syms,
                                    stream=sstream.cuda_stream, assemble=assemble, fetch=False)
         if gather and assemble:
+            # the exchange of this step is posted (results copied to a staging slot first) and waited for when the
+            # NEXT step's exchange is posted: it runs beside the next search
             with torch.cuda.stream(sstream):
                 counts, qs, ln = pp.device_results()
-                multi.gather_sfs(counts, qs, ln)
+                h = gatherer.gather(counts, qs, ln)
+                while pending_gather:
+                    gatherer.wait(pending_gather.pop(), concat=False)
+                pending_gather.append(h)
+
+    def finish_gathers():
+        if gather:
+            with torch.cuda.stream(sstream):
+                while pending_gather:
+                    gatherer.wait(pending_gather.pop(), concat=False)
             sstream.synchronize()
 
     # --search-threads S > 1: S batch objects / streams / threads take the steps' searches in turn, so that the launch of
     # step i+1 is under way while step i runs its short tail kernels and host-side waits (order, scan, gather)
     searchers = [(pp, sstream)] + [(svdss_amd.PingPong(ix, assemble=True), torch.cuda.Stream(device=device))
-                                   for _ in range(max(0, args.search_threads - 1))]
+                                   for _ in range(max(0, (1 if gather else args.search_threads) - 1))]
 
     stats = {"kernel_ms": [], "pipeline_ms": [], "poa_ms": [], "aln_ms": [], "call_wall_ms": []}
 
@@ -439,12 +472,14 @@ def main():
         cw.run(lib, check, local_rank)
         call_alone = dict(cw.last)
     run_steps(args.warmup, record=False)
+    finish_gathers()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(args.steps, record=True)
+    finish_gathers()          # every step's exchange completes inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -457,6 +492,7 @@ def main():
     kernel_ms, pipeline_ms = stats["kernel_ms"], stats["pipeline_ms"]
     poa_ms, aln_ms, call_wall_ms = stats["poa_ms"], stats["aln_ms"], stats["call_wall_ms"]
     search(assemble=True)     # leave the assembled results of one more search in the batch object for the verification
+    finish_gathers()
 
     n_ext = pp.last_total_ext
     n_sfs_asm = pp.last_total
@@ -494,7 +530,7 @@ def main():
                                    else "no data-path collective")),
                 "ext_per_read": n_ext / n_reads, "raw_sfs_per_read": n_sfs_raw / n_reads,
                 "assembled_sfs_per_read": n_sfs_asm / n_reads, "reference_build_s": round(t_ref, 1),
-                "index_build_s": round(t_index, 1), "kmer_table_k": ix.kmer_k, "segments_per_read": pp.last_segments,
+                "index_build_s": round(t_index, 1), "index_verify_s": round(t_verify, 2), "kmer_table_k": ix.kmer_k, "segments_per_read": pp.last_segments,
                 "reads_redone_unsegmented": pp.last_fallbacks,
                 "search_ms_per_step": float(np.mean(pipeline_ms)),
                 "search_kernel_ms_on_idle_gpu": float(np.mean(alone_ms)),
@@ -503,6 +539,7 @@ def main():
                                else "none: search and call of a step back to back"),
             },
         }
+        out["index_verified_rows"] = iv["rows"]
         out["roofline"] = search_roofline(ref_total, n_reads, L, ix.kmer_k, k_ms, n_ext, total_syms, n_sfs_raw,
                                           float(np.mean(pipeline_ms)), float(np.mean(alone_ms)))
         if cw is not None:
@@ -528,8 +565,8 @@ def main():
                                            call_alone["realign_kernel_ms"]),
             }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["verified_reads"] = cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads,
-                                                                               args.cpu_seconds)
+            out["cpu_baseline"], out["verified_reads"], out["verified_subclusters"] = cpu_baseline_and_verify(
+                ix, pp, d_reads, L, n_reads, args.cpu_seconds, cw)
         if world == 1 and not args.no_e2e:
             # the end-to-end run is a process of its own on the same GPU: this one lets go of the index (127 GB), the
             # reads and the call-side arenas first
@@ -543,7 +580,11 @@ def main():
             ix.close()
             del d_reads, d_offs
             torch.cuda.empty_cache()
-            out.update(e2e_search_rate(args.e2e_reads))
+            try:
+                out.update(e2e_runs(e2e_dir, args.e2e_reads, call=not args.no_e2e_call))
+            finally:
+                import shutil
+                shutil.rmtree(e2e_dir, ignore_errors=True)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -579,6 +620,7 @@ def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw
     if prof:
         traffic = prof["read_requests"] * 128 + prof["write_bytes"]
         r.update({"achieved": traffic / (k_ms * 1e-3) / 1e9, "traffic": traffic, "traffic_source": prof["source"],
+                  "kernel_hash": prof["kernel_hash"],
                   "useful_bytes": prof.get("useful_bytes"),
                   "lines_per_read": prof["read_requests"] / n_reads})
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
@@ -595,8 +637,23 @@ def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw
                                   "source": probe["source"]}
     else:
         r.update({"achieved": None, "traffic": None, "frac": None,
-                  "note": "no committed --pmc pass for this workload / kernel version"})
+                  "note": "no committed --pmc pass for this workload and this version of the kernel (hash "
+                          + search_kernel_hash() + " of " + " ".join(SEARCH_KERNEL_SOURCES) + "): profiles/traffic.json"})
     return r
+
+
+SEARCH_KERNEL_SOURCES = ("sfs_search.hip", "sfs_core2.h", "fmd_layout.h", "sym_window.h")
+
+
+def search_kernel_hash():
+    """sha256 (16 hex digits) over the sources the search kernel is compiled from: a committed counter pass
+    (profiles/traffic.json) is only quoted for the kernel it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SEARCH_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "svdss_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def profiled(ref_total, n_reads, L, k):
@@ -606,7 +663,9 @@ def profiled(ref_total, n_reads, L, k):
     except OSError:
         return None
     e = table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}")
-    return e if isinstance(e, dict) else None
+    if not isinstance(e, dict) or e.get("kernel_hash") != search_kernel_hash():
+        return None          # never profiled, or profiled on another version of the kernel: no fraction is claimed
+    return e
 
 
 def random_probe():
@@ -629,56 +688,134 @@ def cpu_quota():
     return n
 
 
-def e2e_search_rate(n_reads):
-    """`SVDSS search` as a user of run_svdss sees it (file- and PCIe-inclusive, never `value`): a synthetic BAM of 15 kb
-    reads against a chr20-length index, through the binary -- BGZF inflate (GPU + host workers), record parsing, 4-bit
-    upload, search, text output to /dev/null.  e2e_reads_per_s = reads / (end of output - index resident), i.e. the
-    streaming rate a 30x sample (6.2 M reads) approaches; the whole-process figure is beside it."""
+E2E_CHR_BP = 64_444_167
+
+
+def e2e_prepare(work, ref, wg):
+    """Files of the end-to-end runs, written while the host copy of the reference exists: chr.fa = the first
+    64,444,167 bases of the first contig, wg.fa = all contigs (the whole-genome run), ref0.npy = chr.fa's bases 0..3 for
+    the BAM writer."""
+    lut = np.frombuffer(b"NACGTN", dtype=np.uint8)
+    first = ref[0][:E2E_CHR_BP]
+    with open(os.path.join(work, "chr.fa"), "wb") as f:
+        f.write(b">chrS\n")
+        f.write(lut[first].tobytes())
+        f.write(b"\n")
+    np.save(os.path.join(work, "ref0.npy"), (first - 1) & 3)
+    if wg:
+        with open(os.path.join(work, "wg.fa"), "wb") as f:
+            for i, c in enumerate(ref):
+                f.write(b">c%d\n" % (i + 1))
+                f.write(lut[c].tobytes())
+                f.write(b"\n")
+
+
+def _run_search(exe, fmd, bam):
+    """`SVDSS search --bam` -> (dict of timings from its --verbose log, wall seconds)"""
     import re
-    import shutil
     import subprocess
-    import tempfile
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, "search", "--index", fmd, "--bam", bam, "--noputative", "--verbose"],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, check=True,
+                       env=dict(os.environ, SVDSS_DEBUG="1"))
+    wall = time.perf_counter() - t0
+    t_file = float(re.search(r"index file read at \+([0-9.]+) s", r.stderr).group(1))
+    t_ix = float(re.search(r"on the device at \+([0-9.]+) s", r.stderr).group(1))
+    m = re.search(r"(\d+) records read, (\d+) SFS written at \+([0-9.]+) s", r.stderr)
+    n, n_sfs, t_end = int(m.group(1)), int(m.group(2)), float(m.group(3))
+    g = re.search(r"(\d+) chunks inflated on the GPU", r.stderr)
+    c = re.search(r"\] (\d+) chunks: locate", r.stderr)
+    return {"reads": n, "sfs": n_sfs, "streaming_s": round(t_end - t_ix, 3), "index_file_read_s": round(t_file, 3),
+            "index_restore_s": round(t_ix, 3), "whole_process_s": round(wall, 3),
+            "reads_per_s_streaming": n / max(t_end - t_ix, 1e-9), "whole_process_reads_per_s": n / wall,
+            "bgzf_chunks": int(c.group(1)) if c else None, "bgzf_chunks_inflated_on_gpu": int(g.group(1)) if g else 0}
+
+
+def e2e_runs(work, n_reads, call=True):
+    """The binaries as a user of run_svdss sees them (file- and PCIe-inclusive, never `value`), on the GPU the main
+    measurement has just let go of.
+      e2e       `SVDSS search --bam`: a synthetic BAM of 15 kb reads against a chr20-length index -- BGZF inflate (GPU),
+                record parsing, 4-bit upload, search, text to /dev/null.  e2e_reads_per_s = reads / (end of output -
+                index resident), the streaming rate a 30x sample (6.2 M reads) approaches.
+      e2e_wg    the same BAM against the index of the WHOLE reference (GRCh38 primary lengths): what run_svdss:151-166
+                does for a human sample; `SVDSS index` time and the restore time (records file read + index rebuilt in
+                HBM + k-mer table) are stated beside the streaming rate.
+      e2e_call  `SVDSS index` -> `search` -> `call` on a 30 Mb genome with 200 implanted SVs (config 4's density), 30x of
+                15 kb error-free ("smoothed") reads with truth alignments: call_reads_per_s = reads / wall of `call`,
+                search_plus_call_reads_per_s = reads / (wall of search + wall of call) (run_svdss:151-178)."""
+    import subprocess
     from tools import e2e_search as E
-    work = tempfile.mkdtemp(prefix="svdss_bench_e2e_", dir="/tmp")
-    try:
-        rng = np.random.default_rng(1)
-        ref_bp, unit = 64444167, 172000     # (the record blocks of `unit` reads are written n_reads / unit times)
-        repeat = max(1, round(n_reads / unit))
-        ref = rng.integers(0, 4, size=ref_bp, dtype=np.uint8)
-        fa = os.path.join(work, "ref.fa")
-        with open(fa, "wb") as f:
-            f.write(b">chrS\n")
-            f.write(np.frombuffer(b"ACGT", dtype=np.uint8)[ref].tobytes())
-            f.write(b"\n")
-        bam = os.path.join(work, "reads.bam")
-        raw = E.write_bam(bam, "chrS", ref, unit, 15000, repeat=repeat)
-        exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "svdss_amd", "SVDSS")
-        subprocess.run([exe, "index", "-d", fa, "-o", os.path.join(work, "ref.fmd")], check=True, capture_output=True)
+    exe = os.path.join(ROOT, "svdss_amd", "SVDSS")
+    out = {}
+    unit = 172000            # (the record blocks of `unit` reads are written n_reads / unit times)
+    repeat = max(1, round(n_reads / unit))
+    ref0 = np.load(os.path.join(work, "ref0.npy"))
+    bam = os.path.join(work, "reads.bam")
+    raw = E.write_bam(bam, "chrS", ref0, unit, 15000, repeat=repeat)
+    del ref0
+    t0 = time.perf_counter()
+    subprocess.run([exe, "index", "-d", os.path.join(work, "chr.fa"), "-o", os.path.join(work, "chr.fmd")], check=True, capture_output=True)
+    t_index = time.perf_counter() - t0
+    r = _run_search(exe, os.path.join(work, "chr.fmd"), bam)
+    out["e2e_reads_per_s"] = r["reads_per_s_streaming"]
+    r["what"] = ("SVDSS search --bam (binary): synthetic BAM, %d x 15 kb reads, %.1f GB file (%.1f GB inflated), "
+                 "chr20-length index, text to /dev/null" % (r["reads"], os.path.getsize(bam) / 1e9, raw / 1e9))
+    r["index_s"] = round(t_index, 2)
+    r["host_cpu_quota_cores"] = cpu_quota()
+    out["e2e"] = r
+    if os.path.exists(os.path.join(work, "wg.fa")):
         t0 = time.perf_counter()
-        r = subprocess.run([exe, "search", "--index", os.path.join(work, "ref.fmd"), "--bam", bam, "--noputative", "--verbose"],
-                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, check=True,
-                           env=dict(os.environ, SVDSS_DEBUG="1"))
-        wall = time.perf_counter() - t0
-        t_ix = float(re.search(r"on the device at \+([0-9.]+) s", r.stderr).group(1))
-        m = re.search(r"(\d+) records read, (\d+) SFS written at \+([0-9.]+) s", r.stderr)
-        n, n_sfs, t_end = int(m.group(1)), int(m.group(2)), float(m.group(3))
-        g = re.search(r"(\d+) chunks inflated on the GPU", r.stderr)
-        c = re.search(r"\] (\d+) chunks: locate", r.stderr)
-        return {"e2e_reads_per_s": n / max(t_end - t_ix, 1e-9),
-                "e2e": {"what": "SVDSS search --bam (binary): synthetic BAM, %d x 15 kb reads, %.1f GB file (%.1f GB inflated), "
-                                "chr20-length index, text to /dev/null" % (n, os.path.getsize(bam) / 1e9, raw / 1e9),
-                        "reads": n, "sfs": n_sfs, "streaming_s": round(t_end - t_ix, 3), "index_restore_s": round(t_ix, 3),
-                        "whole_process_s": round(wall, 3), "whole_process_reads_per_s": n / wall,
-                        "bgzf_chunks": int(c.group(1)) if c else None, "bgzf_chunks_inflated_on_gpu": int(g.group(1)) if g else 0,
-                        "host_cpu_quota_cores": cpu_quota()}}
-    finally:
-        shutil.rmtree(work, ignore_errors=True)
+        subprocess.run([exe, "index", "-d", os.path.join(work, "wg.fa"), "-o", os.path.join(work, "wg.fmd")], check=True, capture_output=True)
+        t_index = time.perf_counter() - t0
+        os.remove(os.path.join(work, "wg.fa"))
+        r = _run_search(exe, os.path.join(work, "wg.fmd"), bam)
+        r["what"] = ("the same BAM against the index of the whole reference (24 contigs, GRCh38 primary lengths, 6.18e9 BWT "
+                     "symbols): restore = records file (%.1f GB) read + index rebuilt in HBM + K = 16 table"
+                     % (os.path.getsize(os.path.join(work, "wg.fmd.svdss")) / 1e9))
+        r["index_s"] = round(t_index, 2)
+        r["fmd_bytes"] = os.path.getsize(os.path.join(work, "wg.fmd"))
+        out["e2e_wg"] = r
+        for f in ("wg.fmd", "wg.fmd.svdss"):
+            os.remove(os.path.join(work, f))
+    os.remove(bam)
+    if call:
+        from tools import e2e_call as EC
+        cdir = os.path.join(work, "call")
+        fa, cbam, svs, het, recs, hdr, _ = EC.write_dataset(cdir, 30_000_000, 200, 30, 15000, het_every=2, max_len=2000)
+        fmd = os.path.join(cdir, "ref.fmd")
+        subprocess.run([exe, "index", "-d", fa, "-o", fmd], check=True, capture_output=True)
+        sfs = os.path.join(cdir, "specifics.txt")
+        t0 = time.perf_counter()
+        with open(sfs, "wb") as f:
+            subprocess.run([exe, "search", "--index", fmd, "--bam", cbam], check=True, stdout=f, stderr=subprocess.DEVNULL)
+        t_search = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        vcf = subprocess.run([exe, "call", "--reference", fa, "--bam", cbam, "--sfs", sfs, "--threads", "16",
+                              "--min-sv-length", "50"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        t_call = time.perf_counter() - t0
+        called = [c[:3] for c in EC.parse_vcf(vcf)]
+        truth = [(sv.pos, sv.kind, sv.length) for sv in svs]
+        hit = sum(1 for p, k, l in truth if any(k == ck and l == cl and abs(cp - p) <= 12 for cp, ck, cl in called))
+        n = len(recs)
+        out["e2e_call"] = {"what": "SVDSS index -> search -> call (binaries): 30 Mb genome, %d implanted SVs (every other one "
+                                   "heterozygous), %d error-free 15 kb reads with truth alignments (30x), whole-process wall "
+                                   "times" % (len(svs), n),
+                           "reads": n, "search_s": round(t_search, 3), "call_s": round(t_call, 3),
+                           "call_reads_per_s": n / t_call, "search_plus_call_reads_per_s": n / (t_search + t_call),
+                           "svs_called": len(called), "svs_truth": len(truth), "truth_recovered": hit}
+    return out
 
 
-def cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads, target_s):
-    """The oracle (CPU restatement of ping_pong.cpp:4-49 + assembler.cpp:34-56, OpenMP over reads like
-    ping_pong.cpp:329) timed on this box's cores on a bounded sample of the same reads -- and, since it computes the
-    SFS of those reads anyway, the checker of the GPU's results for them (counts, starts, lengths, extension counts)."""
+def cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads, target_s, cw):
+    """The oracle timed on this box's cores on a bounded sample of the same work -- and, since it computes those
+    results anyway, the checker of the GPU's.
+      search  CPU restatement of ping_pong.cpp:4-49 + assembler.cpp:34-56, OpenMP over reads like ping_pong.cpp:329, on
+              the first reads of the batch; the GPU's counts / starts / lengths / extension counts must equal it;
+      call    oracle POA (caller.cpp:257-308), extd2 realignment (:332-355) and chain-filter ratio (:456-458), OpenMP over
+              sub-clusters like caller.cpp:319-321, on the first sub-clusters of the step; the GPU's consensus lengths,
+              alignment scores, CIGAR lengths and ratios must equal it.
+    value = reads/s of search + call together: the reads of a step / (their search time + the call time of the
+    sub-clusters those reads imply), each scaled from its sample."""
     from tests import oracle_lib as O
     fm = O.OracleFMD.from_bwt(ix.bwt())
     threads = min(O.max_threads(), cpu_quota())     # (more threads than the container's CPU quota only add contention)
@@ -700,11 +837,40 @@ def cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads, target_s):
           and (got.qs[:tot] == q).all() and (got.len[:tot] == l).all())
     if not ok:
         raise SystemExit(f"VERIFICATION FAILED: GPU SFS of the first {k2} reads differ from the oracle's")
-    base = {"value": k2 / t2, "unit": "reads/s", "cores": threads, "kind": "port",
-            "sample": f"first {k2} reads of the rank-0 batch, {t2:.1f} s, oracle/svdss_oracle.c orc_search_batch with "
-                      f"{threads} OpenMP threads (search + assemble only; plain sampled-Occ FMD, faster than ropebwt3's "
+    search_rate = k2 / t2
+    base = {"value": search_rate, "unit": "reads/s", "cores": threads, "kind": "port",
+            "search": {"value": search_rate, "unit": "reads/s", "sample_reads": k2, "seconds": round(t2, 2)},
+            "sample": f"search: first {k2} reads of the rank-0 batch, {t2:.1f} s, oracle/svdss_oracle.c orc_search_batch with "
+                      f"{threads} OpenMP threads (search + assemble; plain sampled-Occ FMD, faster than ropebwt3's "
                       "rld0: the GPU/CPU ratio is conservative)"}
-    return base, k2
+    m2 = 0
+    if cw is not None:
+        def run_call(m):
+            so, co, ro = cw.seq_off, cw.cluster_off, cw.ref_off
+            t0 = time.perf_counter()
+            res = O.call_batch(cw.seqs[:so[co[m]]], so[:co[m] + 1], co[:m + 1], cw.refs[:ro[m]], ro[:m + 1], cw.mat, threads)
+            return time.perf_counter() - t0, res
+        m = min(cw.n_sub, 4 * threads)
+        t, _ = run_call(m)
+        m2 = int(min(cw.n_sub, max(m, m * (0.7 * target_s) / max(t, 1e-3))))
+        t2c, (cl, sc, nc, ra) = run_call(m2)
+        g = cw.last
+        okc = ((g["cons_len"][:m2] == cl).all() and (g["scores"][:m2] == sc).all() and (g["n_cig"][:m2] == nc).all()
+               and (g["ratio"][:m2 - 1] == ra).all())
+        if not okc:
+            raise SystemExit(f"VERIFICATION FAILED: GPU consensus / alignment / ratio of the first {m2} sub-clusters differ "
+                             "from the oracle's")
+        sub_rate = m2 / t2c
+        # a step's reads imply cw.n_sub sub-clusters
+        call_s_per_step = cw.n_sub / sub_rate
+        search_s_per_step = n_reads / search_rate
+        base["call"] = {"value": sub_rate, "unit": "sub-clusters/s", "sample_subclusters": m2, "seconds": round(t2c, 2),
+                        "reads_equivalent_per_s": n_reads / call_s_per_step}
+        base["value"] = n_reads / (search_s_per_step + call_s_per_step)
+        base["sample"] += (f"; call: first {m2} of the step's {cw.n_sub} sub-clusters, {t2c:.1f} s, oracle POA + extd2 + ratio "
+                           f"(oracle/svdss_oracle_callbatch.c) with {threads} OpenMP threads; value = reads of a step / (their "
+                           "search time + the call time of the sub-clusters they imply)")
+    return base, k2, m2
 
 
 if __name__ == "__main__":

@@ -55,6 +55,13 @@ int svdss_index_build(const uint8_t* contigs, const int64_t* lens, int32_t n_con
 int svdss_index_build_device(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
                              int32_t threads, int32_t device, svdss_index_t** out);
 int svdss_index_save(const svdss_index_t* ix, const char* path);
+/* The records file (magic "SVDSSRC1": BWT length, acc[], record lengths, the nt6 records): what `SVDSS index` leaves
+ * beside the .fmd as `<fmd>.svdss`.  svdss_index_load takes it and returns an index that holds the records only; the
+ * layout is built when the index is made resident (svdss_index_to_device / svdss_index_replicate: in the HBM of that
+ * device, seconds for GRCh38 lengths -- faster than any disk delivers the 58 GB of text + suffix array
+ * svdss_index_save writes) or when a host-side accessor needs it.  Stands where the .fmd stands between main_build and
+ * rb3_fmi_restore (main.cpp:34-37, ping_pong.cpp:245). */
+int svdss_index_save_records(const svdss_index_t* ix, const char* path);
 /* The index as ropebwt3 dumps it: the rld0 run-length BWT (`.fmd`, magic "RLD\3"), the file `ropebwt3 build -d` /
  * upstream `SVDSS index` writes and rb3_fmi_restore reads (main.cpp:34-37, ping_pong.cpp:245; run_svdss:136-147 reuses
  * an existing $FA.fmd).  Format restated from the published rld0 sources in csrc/rld0.cpp [UPSTREAM-UNVERIFIED]. */
@@ -62,8 +69,9 @@ int svdss_index_save_fmd(const svdss_index_t* ix, const char* path);
 /* The BWT an rld0 `.fmd` holds, as nt6 bytes: *n_out symbols (bwt_out may be NULL to ask for the size only;
  * SVDSS_ERANGE if cap is too small). */
 int svdss_fmd_read_bwt(const char* path, uint8_t* bwt_out, int64_t cap, int64_t* n_out);
-/* Restores an index: this library's own file (svdss_index_save), or an rld0 `.fmd` -- then `<path>.svdss` (the
- * own-format copy `SVDSS index` leaves beside the .fmd) is read if it is there and not older; otherwise the BWT is
+/* Restores an index: this library's own files (svdss_index_save, svdss_index_save_records), or an rld0 `.fmd` -- then
+ * `<path>.svdss` (the file `SVDSS index` leaves beside the .fmd) is read if it is there, not older, and carries the
+ * symbol counts of the .fmd's header; otherwise the BWT is
  * decoded, the records are recovered from it (they must come with their reverse complements, as ropebwt3 build -d
  * inserts them) and the index is rebuilt, on the GPU when there is one. */
 int svdss_index_load(const char* path, svdss_index_t** out);
@@ -81,6 +89,15 @@ int32_t svdss_index_kmer(const svdss_index_t* ix);
 /* copy the index into the HBM of `device` (replicated per GPU): BWT blocks,
  * text, suffix array, and the 4^K k-mer table (K = floor(log4 n)+1, env SVDSS_KMER overrides) */
 int svdss_index_to_device(svdss_index_t* ix, int32_t device);
+
+/* A resident index checked against its own text by direct comparison, independently of how it was built
+ * (csrc/index_verify.hip): every `stride`-th suffix-array row i has SA[i] in range, text[SA[i]..) < text[SA[i+1]..)
+ * as strings, BWT[i] == text[SA[i]-1]; every rank block's counters continue the previous block's; the '$' rows are
+ * the listed ones; the text's symbol histogram is acc[].  stride 1 = the whole index (GRCh38 lengths: ~1 s).
+ * out[0] rows checked, [1] order violations, [2] BWT mismatches, [3] entries out of range, [4] block / histogram
+ * violations, [5] '$'-list violations, [6] first bad row or -1, [7] longest common prefix met.  The index this
+ * stands for is the one rb3_fmi_restore returns (ping_pong.cpp:245). */
+int svdss_index_verify_device(const svdss_index_t* ix, int64_t stride, int64_t out[8]);
 
 /* GPUs this process sees (0: none). */
 int svdss_device_count(void);

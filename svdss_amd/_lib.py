@@ -49,6 +49,7 @@ SIGNATURES = {
     "svdss_index_build": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
     "svdss_index_build_device": (C.c_int, [_p, _p, _i32, _i32, _i32, C.POINTER(_p)]),
     "svdss_index_save": (C.c_int, [_p, C.c_char_p]),
+    "svdss_index_save_records": (C.c_int, [_p, C.c_char_p]),
     "svdss_index_save_fmd": (C.c_int, [_p, C.c_char_p]),
     "svdss_fmd_read_bwt": (C.c_int, [C.c_char_p, _p, _i64, _p]),
     "svdss_index_load": (C.c_int, [C.c_char_p, C.POINTER(_p)]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     "svdss_index_kmer": (_i32, [_p]),
     "svdss_index_to_device": (C.c_int, [_p, _i32]),
     "svdss_index_count": (_i64, [_p, _p, _i64]),
+    "svdss_index_verify_device": (C.c_int, [_p, _i64, _p]),
     "svdss_device_count": (C.c_int, []),
     "svdss_index_replicate": (C.c_int, [_p, _i32, C.POINTER(_p)]),
     "svdss_sfs_search_batch": (C.c_int, [_p, _p, _p, _i64, _i32, C.POINTER(_p)]),

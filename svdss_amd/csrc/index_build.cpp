@@ -269,6 +269,82 @@ int svdss_index_save_host(const svdss_index* ix, const char* path) {
   return ok ? SVDSS_OK : SVDSS_EIO;
 }
 
+namespace {
+struct RecHeader {
+  char magic[8];  // "SVDSSRC1"
+  int64_t n;      // BWT length of the index of these records: sum of 2 * (len + 1)
+  int64_t acc[7];
+  int64_t total;  // sum of the record lengths
+  int32_t n_contigs;
+  int32_t reserved;
+};
+}  // namespace
+
+int svdss_index_save_records_host(const svdss_index* ix, const char* path) {
+  RecHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "SVDSSRC1", 8);
+  h.n = ix->n;
+  memcpy(h.acc, ix->acc, sizeof h.acc);
+  h.n_contigs = ix->n_contigs;
+  std::vector<int64_t> lens;
+  const uint8_t* rec = nullptr;
+  std::vector<uint8_t> tmp;
+  if (!ix->rec_lens.empty()) {
+    lens = ix->rec_lens;
+    rec = ix->records.data();
+  } else {
+    // the forward strands out of the text  r0 $ revcomp(r0) $ r1 $ ...
+    if ((int64_t)ix->text.size() != ix->n) return SVDSS_EINVAL;
+    try { tmp.reserve((size_t)(ix->n / 2)); } catch (...) { return SVDSS_ENOMEM; }
+    int64_t pos = 0;
+    for (int32_t i = 0; i < ix->n_contigs; ++i) {
+      const void* z = memchr(ix->text.data() + pos, 0, (size_t)(ix->n - pos));
+      if (!z) return SVDSS_EINVAL;
+      const int64_t len = (const uint8_t*)z - (ix->text.data() + pos);
+      tmp.insert(tmp.end(), ix->text.begin() + pos, ix->text.begin() + pos + len);
+      lens.push_back(len);
+      pos += 2 * (len + 1);
+    }
+    if (pos != ix->n) return SVDSS_EINVAL;
+    rec = tmp.data();
+  }
+  for (int64_t l : lens) h.total += l;
+  if ((int32_t)lens.size() != ix->n_contigs) return SVDSS_EINVAL;
+  FILE* f = fopen(path, "wb");
+  if (!f) return SVDSS_EIO;
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  ok = ok && fwrite(lens.data(), sizeof(int64_t), lens.size(), f) == lens.size();
+  ok = ok && (h.total == 0 || fwrite(rec, 1, (size_t)h.total, f) == (size_t)h.total);
+  ok = (fclose(f) == 0) && ok;
+  return ok ? SVDSS_OK : SVDSS_EIO;
+}
+
+int svdss_index_load_records_host(const char* path, svdss_index* ix) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return SVDSS_EIO;
+  RecHeader h;
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SVDSSRC1", 8) != 0 || h.n < 0 || h.total < 0 ||
+      h.n_contigs <= 0 || h.n != 2 * (h.total + h.n_contigs)) {
+    fclose(f);
+    return SVDSS_EIO;
+  }
+  try {
+    ix->rec_lens.resize((size_t)h.n_contigs);
+    ix->records.resize((size_t)h.total);
+  } catch (...) { fclose(f); return SVDSS_ENOMEM; }
+  bool ok = fread(ix->rec_lens.data(), sizeof(int64_t), ix->rec_lens.size(), f) == ix->rec_lens.size();
+  ok = ok && (h.total == 0 || fread(ix->records.data(), 1, (size_t)h.total, f) == (size_t)h.total);
+  fclose(f);
+  int64_t sum = 0;
+  for (int64_t l : ix->rec_lens) { if (l < 0) ok = false; sum += l; }
+  if (!ok || sum != h.total) { ix->rec_lens.clear(); ix->records.clear(); return SVDSS_EIO; }
+  ix->n = h.n;
+  memcpy(ix->acc, h.acc, sizeof h.acc);
+  ix->n_contigs = h.n_contigs;
+  return SVDSS_OK;
+}
+
 int svdss_index_load_host(const char* path, svdss_index* ix) {
   FILE* f = fopen(path, "rb");
   if (!f) return SVDSS_EIO;

@@ -654,6 +654,21 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
   return 0;
 }
 
+// the text of a device-built index -> host vector (no-op when it is there already)
+int svdss_index_fetch_text(svdss_index* ix) {
+  if (!ix) return SVDSS_EINVAL;
+  if ((int64_t)ix->text.size() == ix->n) return SVDSS_OK;
+  if (ix->device < 0 || !ix->d_text) return SVDSS_ENODEV;
+  if (hipSetDevice(ix->device) != hipSuccess) { (void)hipGetLastError(); return SVDSS_EHIP; }
+  try { ix->text.resize((size_t)ix->n); } catch (...) { return SVDSS_ENOMEM; }
+  if (hipMemcpy(ix->text.data(), (const uint8_t*)ix->d_text + 64, (size_t)ix->n, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    ix->text.clear();
+    return SVDSS_EHIP;
+  }
+  return SVDSS_OK;
+}
+
 // text and suffix array of a device-built index -> host vectors (no-op when they are there already)
 int svdss_index_fetch_host(svdss_index* ix) {
   if (!ix) return SVDSS_EINVAL;

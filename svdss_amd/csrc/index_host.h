@@ -15,6 +15,11 @@ struct svdss_index {
   std::vector<uint32_t> sa32;     // suffix array when n < 2^32 ...
   std::vector<uint64_t> sa64;     // ... else 64-bit
   bool sa_wide = false;           // suffix array entries are 64-bit (n >= 2^31 - 1)
+  // The records the index stands for (nt6, concatenated) -- all an index restored from a records file holds until it
+  // is made resident or a host-side accessor needs the layout (svdss_index_materialize): rebuilding GRCh38 lengths in
+  // HBM takes seconds, reading the 58 GB of text + suffix array from a file takes longer on any disk.
+  std::vector<uint8_t> records;
+  std::vector<int64_t> rec_lens;
   // device residency (filled by svdss_index_to_device)
   int device = -1;
   void* d_blocks = nullptr;
@@ -30,6 +35,11 @@ struct svdss_index {
 int svdss_index_build_host(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
                            int32_t threads, svdss_index* out);
 int svdss_index_save_host(const svdss_index* ix, const char* path);
+// the records file ("SVDSSRC1": n, acc, record lengths, nt6 records): what `SVDSS index` leaves beside the .fmd
+int svdss_index_save_records_host(const svdss_index* ix, const char* path);
+int svdss_index_load_records_host(const char* path, svdss_index* ix);
+// true when *ix holds records only (restored from a records file, nothing built yet)
+inline bool svdss_index_is_lazy(const svdss_index* ix) { return ix->blocks.empty() && !ix->rec_lens.empty(); }
 int svdss_index_load_host(const char* path, svdss_index* ix);
 void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt);
 // index_gpu.hip: the whole index built in the HBM of `device` and left resident there (text and suffix array are
@@ -38,3 +48,6 @@ void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt);
 int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
                           svdss_index* out);
 int svdss_index_fetch_host(svdss_index* ix);
+int svdss_index_fetch_text(svdss_index* ix);   // the text alone (n bytes, not the 4-8 n of the suffix array)
+// the kernels' view of a resident index (index_api.hip)
+SvdssDevIndex svdss_device_view(const svdss_index* ix);

@@ -14,7 +14,6 @@
 #include <hipcub/hipcub.hpp>
 
 #include <omp.h>
-#include <sys/stat.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -25,8 +24,8 @@
 
 #include "../../include/svdss_hip.h"
 #include "fmd_layout.h"
+#include "hip_check.h"
 #include "index_host.h"
-#include "rld0.h"
 #include "sfs_core.h"
 #ifdef SV_COUNT_ITERS
 // counting build: passes of sv_decide's loop, per wavefront (any lane inside)
@@ -35,436 +34,6 @@ extern __device__ unsigned long long g_sfs_iters[64];
 #endif
 #include "sfs_core2.h"
 #include "sym_window.h"
-
-// ------------------------------------------------------------------ errors
-
-thread_local std::string g_svdss_hip_err;   // shared with call_dp.hip
-
-#define HIPCHK(expr)                                                              \
-  do {                                                                            \
-    hipError_t e_ = (expr);                                                       \
-    if (e_ != hipSuccess) {                                                       \
-      g_svdss_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
-      return (e_ == hipErrorOutOfMemory) ? SVDSS_ENOMEM : SVDSS_EHIP;             \
-    }                                                                             \
-  } while (0)
-
-extern "C" const char* svdss_strerror(int code) {
-  switch (code) {
-    case SVDSS_OK: return "ok";
-    case SVDSS_EINVAL: return "invalid argument";
-    case SVDSS_ENOMEM: return "out of memory";
-    case SVDSS_EIO: return "i/o error or bad index file";
-    case SVDSS_EHIP: return "HIP runtime error (is a GPU present?)";
-    case SVDSS_ENODEV: return "index is not resident on a device";
-    case SVDSS_ERANGE: return "input exceeds a layout limit";
-    default: return "unknown error";
-  }
-}
-
-extern "C" const char* svdss_last_hip_error(void) { return g_svdss_hip_err.c_str(); }
-
-// --------------------------------------------------------------------- a1
-
-extern "C" int svdss_nt6_encode(const char* seq, int64_t n, uint8_t* out) {
-  if ((!seq || !out) && n > 0) return SVDSS_EINVAL;
-  // seq_nt6_table, ping_pong.hpp:46-52: A/a=1 C/c=2 G/g=3 T/t=4, NUL=0, rest 5
-  for (int64_t i = 0; i < n; ++i) {
-    const unsigned char ch = (unsigned char)seq[i];
-    uint8_t v = 5;
-    switch (ch) {
-      case 0: v = 0; break;
-      case 'A': case 'a': v = 1; break;
-      case 'C': case 'c': v = 2; break;
-      case 'G': case 'g': v = 3; break;
-      case 'T': case 't': v = 4; break;
-      default: break;
-    }
-    out[i] = v;
-  }
-  return SVDSS_OK;
-}
-
-// ------------------------------------------------------------------ index
-
-static void free_device_side(svdss_index* ix);
-
-extern "C" int svdss_index_build(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
-                                 int32_t threads, svdss_index_t** out) {
-  if (!out) return SVDSS_EINVAL;
-  svdss_index* ix = new (std::nothrow) svdss_index();
-  if (!ix) return SVDSS_ENOMEM;
-  int rc = -1;
-  // on the GPU when there is one (index_gpu.hip; SVDSS_INDEX_CPU=1 keeps the host builder) -- same index
-  if (!getenv("SVDSS_INDEX_CPU")) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
-    if (dev >= 0) rc = svdss_index_build_gpu(contigs, lens, n_contigs, dev, ix);
-    if (rc == SVDSS_OK) {
-      rc = svdss_index_fetch_host(ix);
-      free_device_side(ix);
-      if (rc != SVDSS_OK) { delete ix; return rc; }
-      *out = ix;
-      return SVDSS_OK;
-    }
-    if (rc > 0) { delete ix; return rc; }   // bad input: the host builder would say the same
-    free_device_side(ix);
-  }
-  rc = svdss_index_build_host(contigs, lens, n_contigs, threads, ix);
-  if (rc != SVDSS_OK) { delete ix; return rc; }
-  *out = ix;
-  return SVDSS_OK;
-}
-
-static int build_table(svdss_index* ix);
-
-extern "C" int svdss_index_build_device(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
-                                        int32_t threads, int32_t device, svdss_index_t** out) {
-  if (!out || device < 0) return SVDSS_EINVAL;
-  svdss_index* ix = new (std::nothrow) svdss_index();
-  if (!ix) return SVDSS_ENOMEM;
-  int rc = getenv("SVDSS_INDEX_CPU") ? -1 : svdss_index_build_gpu(contigs, lens, n_contigs, device, ix);
-  if (rc == SVDSS_OK) {
-    rc = build_table(ix);
-  } else if (rc < 0) {   // no GPU / no room / degenerate text: host builder, then upload
-    free_device_side(ix);
-    rc = svdss_index_build_host(contigs, lens, n_contigs, threads, ix);
-    if (rc == SVDSS_OK) rc = svdss_index_to_device(ix, device);
-  }
-  if (rc != SVDSS_OK) { free_device_side(ix); delete ix; return rc; }
-  *out = ix;
-  return SVDSS_OK;
-}
-
-extern "C" int svdss_index_save(const svdss_index_t* ix, const char* path) {
-  if (!ix || !path) return SVDSS_EINVAL;
-  // an index built in HBM keeps text and suffix array there until somebody needs them on the host
-  const int rc = svdss_index_fetch_host(const_cast<svdss_index*>(ix));
-  if (rc != SVDSS_OK) return rc;
-  return svdss_index_save_host(ix, path);
-}
-
-extern "C" int svdss_index_save_fmd(const svdss_index_t* ix, const char* path) {
-  if (!ix || !path) return SVDSS_EINVAL;
-  std::vector<uint8_t> bwt;
-  try { bwt.resize((size_t)ix->n); } catch (...) { return SVDSS_ENOMEM; }
-  svdss_index_decode_bwt(ix, bwt.data());
-  return rld0_write(path, bwt.data(), ix->n);
-}
-
-extern "C" int svdss_fmd_read_bwt(const char* path, uint8_t* bwt_out, int64_t cap, int64_t* n_out) {
-  if (!path || !n_out) return SVDSS_EINVAL;
-  std::vector<uint8_t> bwt;
-  const int rc = rld0_read(path, bwt);
-  if (rc != SVDSS_OK) return rc;
-  *n_out = (int64_t)bwt.size();
-  if (bwt_out) {
-    if (cap < (int64_t)bwt.size()) return SVDSS_ERANGE;
-    memcpy(bwt_out, bwt.data(), bwt.size());
-  }
-  return SVDSS_OK;
-}
-
-// an rld0 file (ropebwt3 / upstream `SVDSS index`): decode the BWT, recover the strings, rebuild this layout
-static int import_fmd(const char* path, svdss_index_t** out) {
-  std::vector<uint8_t> bwt;
-  int rc = rld0_read(path, bwt);
-  if (rc != SVDSS_OK) return rc;
-  int threads = 1;
-#ifdef _OPENMP
-  threads = omp_get_max_threads();
-#endif
-  std::vector<std::vector<uint8_t>> strings;
-  rc = rld0_strings_of_bwt(bwt.data(), (int64_t)bwt.size(), threads, strings);
-  if (rc != SVDSS_OK) return rc;
-  std::vector<uint8_t>().swap(bwt);
-  std::vector<int64_t> picked;
-  rc = rld0_pick_strands(strings, picked);
-  if (rc != SVDSS_OK) {
-    g_svdss_hip_err = "the .fmd is not an index of records AND their reverse complements (ropebwt3 build without -d?)";
-    return rc;
-  }
-  std::vector<int64_t> lens;
-  int64_t total = 0;
-  for (int64_t i : picked) { lens.push_back((int64_t)strings[(size_t)i].size()); total += lens.back(); }
-  std::vector<uint8_t> cat;
-  try { cat.reserve((size_t)total); } catch (...) { return SVDSS_ENOMEM; }
-  for (int64_t i : picked) {
-    cat.insert(cat.end(), strings[(size_t)i].begin(), strings[(size_t)i].end());
-    std::vector<uint8_t>().swap(strings[(size_t)i]);
-  }
-  strings.clear();
-  return svdss_index_build(cat.data(), lens.data(), (int32_t)lens.size(), threads, out);
-}
-
-extern "C" int svdss_index_load(const char* path, svdss_index_t** out) {
-  if (!path || !out) return SVDSS_EINVAL;
-  std::string file = path;
-  bool is_cache = false;
-  uint64_t mcnt[6] = {0, 0, 0, 0, 0, 0};
-  if (rld0_is_fmd(path)) {
-    // `SVDSS index` leaves this library's own layout beside the .fmd it writes: restoring that is a plain read.  The
-    // cache must belong to THIS .fmd: not older, and with the symbol counts of the .fmd's header (an .fmd replaced
-    // under a preserved mtime, or an upstream-built one for another reference, is imported instead).
-    const std::string cache = file + ".svdss";
-    struct stat a, c;
-    if (!getenv("SVDSS_INDEX_NO_CACHE") && stat(path, &a) == 0 && stat(cache.c_str(), &c) == 0 &&
-        c.st_mtime >= a.st_mtime && rld0_header_counts(path, mcnt) == SVDSS_OK) {
-      file = cache;
-      is_cache = true;
-    } else
-      return import_fmd(path, out);
-  } else {
-    // Neither rld0 nor this library's own layout: most likely ropebwt3's other format (.fmr, mrope -- what `ropebwt3
-    // build` writes without -d; rb3_fmi_restore of ping_pong.cpp:245 falls back to it when the rld0 restore fails).
-    // It is not read here; say so instead of a bare I/O error.  (Its magic is not restated from memory: the file is
-    // recognised by what it is not.)
-    FILE* f = fopen(path, "rb");
-    char m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool readable = f && fread(m, 1, 8, f) == 8;
-    if (f) fclose(f);
-    if (readable && memcmp(m, "SVDSSFM2", 8) != 0) {
-      g_svdss_hip_err = "not an rld0 .fmd (magic RLD\\3) and not this library's index layout; if it is an .fmr (mrope) "
-                        "index, convert it with `ropebwt3 build -i in.fmr -do out.fmd` or rebuild with `SVDSS index -d`";
-      return SVDSS_EINVAL;
-    }
-  }
-  svdss_index* ix = new (std::nothrow) svdss_index();
-  if (!ix) return SVDSS_ENOMEM;
-  int rc = svdss_index_load_host(file.c_str(), ix);
-  if (rc == SVDSS_OK && is_cache) {
-    bool same = true;
-    for (int c = 0; c < 6; ++c) same = same && (uint64_t)(ix->acc[c + 1] - ix->acc[c]) == mcnt[c];
-    if (!same) rc = SVDSS_EIO;
-  }
-  if (rc != SVDSS_OK) {
-    delete ix;
-    if (is_cache) return import_fmd(path, out);   // stale, truncated or foreign cache: the .fmd itself is the index
-    return rc;
-  }
-  *out = ix;
-  return SVDSS_OK;
-}
-
-static void free_device_side(svdss_index* ix) {
-  if (ix->device < 0) return;
-  (void)hipSetDevice(ix->device);
-  for (void** p : {&ix->d_blocks, &ix->d_dollar, &ix->d_text, &ix->d_sa, &ix->d_table}) {
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-  }
-  ix->table_k = 0;
-  ix->device = -1;
-}
-
-extern "C" void svdss_index_free(svdss_index_t* ix) {
-  if (!ix) return;
-  free_device_side(ix);
-  delete ix;
-}
-
-extern "C" int64_t svdss_index_size(const svdss_index_t* ix) { return ix ? ix->n : -1; }
-
-extern "C" int svdss_index_acc(const svdss_index_t* ix, int64_t acc[7]) {
-  if (!ix || !acc) return SVDSS_EINVAL;
-  memcpy(acc, ix->acc, sizeof ix->acc);
-  return SVDSS_OK;
-}
-
-extern "C" int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out) {
-  if (!ix || !bwt_out) return SVDSS_EINVAL;
-  svdss_index_decode_bwt(ix, bwt_out);
-  return SVDSS_OK;
-}
-
-static int auto_kmer(int64_t n) {
-  // K = floor(log4 n) + 3, at most 16: nearly every K-mer of the text is then unique and
-  // nearly every other K-mer absent, so ONE lookup resolves a phase start (unique -> TEXT
-  // mode, absent -> fail depth).  The table costs 4^K * 16 B (K=16: 64 GiB of the 288 GB
-  // of HBM); it is shrunk until it fits in a third of the free device memory.
-  int k = 1;
-  while (k < 16 && ((int64_t)1 << (2 * k)) <= n) ++k;   // floor(log4 n) + 1
-  k = k + 2 > 16 ? 16 : k + 2;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-    while (k > 4 && ((size_t)16 << (2 * k)) > free_b / 3) --k;
-  if (const char* e = getenv("SVDSS_KMER")) k = atoi(e);
-  if (k < 0) k = 0;
-  if (k > 16) k = 16;
-  return k;
-}
-
-extern "C" int64_t svdss_index_device_bytes(const svdss_index_t* ix) {
-  if (!ix) return -1;
-  const int k = ix->table_k;   // known once the index is resident
-  const int64_t sa_bytes = ix->sa_wide ? 8 * ix->n : 4 * ix->n;
-  return (int64_t)(ix->blocks.size() * sizeof(svdss_u4) + ix->dollar.size() * sizeof(int64_t)) +
-         ix->n + 144 + sa_bytes + (k > 0 ? ((int64_t)16 << (2 * k)) : 0);
-}
-
-extern "C" int32_t svdss_index_kmer(const svdss_index_t* ix) { return ix ? ix->table_k : -1; }
-
-static SvdssDevIndex device_view(const svdss_index* ix) {
-  SvdssDevIndex v;
-  v.blocks = (const svdss_u4*)ix->d_blocks;
-  v.dollar = (const int64_t*)ix->d_dollar;
-  v.n = ix->n;
-  v.n_dollar = (int32_t)ix->dollar.size();
-  v.k = ix->table_k;
-  memcpy(v.acc, ix->acc, sizeof v.acc);
-  v.text = ix->d_text ? (const uint8_t*)ix->d_text + 64 : nullptr;
-  v.sa = ix->d_sa;
-  v.table = (const SvdssTabEntry*)ix->d_table;
-  return v;
-}
-
-template <class P>
-__global__ void __launch_bounds__(256) build_table_kernel(SvdssDevIndex ix, SvdssTabEntry* tab, int K, int forward) {
-  const uint64_t nkeys = (uint64_t)1 << (2 * K);
-  for (uint64_t key = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; key < nkeys;
-       key += (uint64_t)gridDim.x * blockDim.x) {
-    uint64_t lo, info;
-    sv_table_entry<P>(ix, (uint32_t)key, K, lo, info);
-    if (!forward && (info >> 62) == SVDSS_TAB_EMPTY) info &= ~0xff00ull;   // SVDSS_TABLE_FORWARD=0 (A/B measurements)
-    tab[key].lo = lo;
-    tab[key].info = info;
-  }
-}
-
-// the 4^K k-mer table of an index whose blocks, text and suffix array are resident
-static int build_table(svdss_index* ix) {
-  if (ix->d_table) { (void)hipFree(ix->d_table); ix->d_table = nullptr; ix->table_k = 0; }
-  const bool wide = ix->sa_wide;
-  const int k = auto_kmer(ix->n);
-  if (k > 0 && ix->d_text && ix->d_sa) {
-    const size_t tbytes = (size_t)16 << (2 * k);
-    HIPCHK(hipMalloc(&ix->d_table, tbytes));
-    SvdssDevIndex v = device_view(ix);
-    const uint64_t nkeys = (uint64_t)1 << (2 * k);
-    const int blocks = (int)((nkeys + 255) / 256 < 65536 ? (nkeys + 255) / 256 : 65536);
-    const char* fw = getenv("SVDSS_TABLE_FORWARD");
-    const int forward = (fw && atoi(fw) == 0) ? 0 : 1;   // 0: entries without the forward-phase outcome
-    if (wide)
-      hipLaunchKernelGGL(build_table_kernel<uint64_t>, dim3(blocks), dim3(256), 0, 0, v,
-                         (SvdssTabEntry*)ix->d_table, k, forward);
-    else
-      hipLaunchKernelGGL(build_table_kernel<uint32_t>, dim3(blocks), dim3(256), 0, 0, v,
-                         (SvdssTabEntry*)ix->d_table, k, forward);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-    ix->table_k = k;
-  }
-  return SVDSS_OK;
-}
-
-extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
-  if (!ix || device < 0) return SVDSS_EINVAL;
-  HIPCHK(hipSetDevice(device));
-  if (ix->device == device && ix->d_blocks && ix->d_text && ix->d_sa)   // built there (svdss_index_build_device)
-    return ix->d_table ? SVDSS_OK : build_table(ix);
-  if (ix->device >= 0 && ix->d_text && ix->d_sa) {   // resident elsewhere: the host copy travels
-    const int rc = svdss_index_fetch_host(ix);
-    if (rc != SVDSS_OK) return rc;
-    HIPCHK(hipSetDevice(device));
-  }
-  free_device_side(ix);
-  ix->device = device;  // so that a failure below still frees what was allocated
-  const size_t bb = ix->blocks.size() * sizeof(svdss_u4);
-  const size_t db = (ix->dollar.size() + 1) * sizeof(int64_t);
-  HIPCHK(hipMalloc(&ix->d_blocks, bb));
-  HIPCHK(hipMalloc(&ix->d_dollar, db));
-  HIPCHK(hipMemcpy(ix->d_blocks, ix->blocks.data(), bb, hipMemcpyHostToDevice));
-  if (!ix->dollar.empty())
-    HIPCHK(hipMemcpy(ix->d_dollar, ix->dollar.data(), ix->dollar.size() * sizeof(int64_t),
-                     hipMemcpyHostToDevice));
-  // text with 64 bytes of '$' padding on both sides (the TEXT windows may start before /
-  // end after the text); suffix array with 16 bytes of slack for the 16-byte entry loads
-  const bool wide = ix->sa_wide;
-  if ((int64_t)ix->text.size() == ix->n && (int64_t)(wide ? ix->sa64.size() : ix->sa32.size()) == ix->n) {
-    const size_t tb = (size_t)ix->n + 128 + 16;
-    HIPCHK(hipMalloc(&ix->d_text, tb));
-    HIPCHK(hipMemset(ix->d_text, 0, tb));
-    HIPCHK(hipMemcpy((uint8_t*)ix->d_text + 64, ix->text.data(), (size_t)ix->n, hipMemcpyHostToDevice));
-    const size_t sb = (size_t)ix->n * (wide ? 8 : 4);
-    HIPCHK(hipMalloc(&ix->d_sa, sb + 16));
-    HIPCHK(hipMemcpy(ix->d_sa, wide ? (const void*)ix->sa64.data() : (const void*)ix->sa32.data(), sb,
-                     hipMemcpyHostToDevice));
-  }
-  return build_table(ix);
-}
-
-extern "C" int svdss_device_count(void) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  return n;
-}
-
-// another replica of a resident (or host-side) index in the HBM of `device`: SURVEY 8(e), index replicated per GPU.
-// The new handle owns its device buffers and a copy of the small host-side parts; the source stays as it is.
-extern "C" int svdss_index_replicate(const svdss_index_t* src, int32_t device, svdss_index_t** out) {
-  if (!src || !out || device < 0) return SVDSS_EINVAL;
-  // text and suffix array travel through the host copy of the source
-  int rc = svdss_index_fetch_host(const_cast<svdss_index*>(src));
-  if (rc != SVDSS_OK && rc != SVDSS_ENODEV) return rc;
-  svdss_index* ix = new (std::nothrow) svdss_index();
-  if (!ix) return SVDSS_ENOMEM;
-  ix->n = src->n;
-  memcpy(ix->acc, src->acc, sizeof ix->acc);
-  ix->n_contigs = src->n_contigs;
-  ix->sa_wide = src->sa_wide;
-  try { ix->blocks = src->blocks; ix->dollar = src->dollar; } catch (...) { delete ix; return SVDSS_ENOMEM; }
-  HIPCHK(hipSetDevice(device));
-  ix->device = device;
-  const size_t bb = ix->blocks.size() * sizeof(svdss_u4), db = (ix->dollar.size() + 1) * sizeof(int64_t);
-  const bool have = (int64_t)src->text.size() == src->n &&
-                    (int64_t)(src->sa_wide ? src->sa64.size() : src->sa32.size()) == src->n;
-  auto fail = [&](int code) { free_device_side(ix); delete ix; return code; };
-  if (hipMalloc(&ix->d_blocks, bb) != hipSuccess || hipMalloc(&ix->d_dollar, db) != hipSuccess) return fail(SVDSS_ENOMEM);
-  if (hipMemcpy(ix->d_blocks, ix->blocks.data(), bb, hipMemcpyHostToDevice) != hipSuccess) return fail(SVDSS_EHIP);
-  if (!ix->dollar.empty() &&
-      hipMemcpy(ix->d_dollar, ix->dollar.data(), ix->dollar.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess)
-    return fail(SVDSS_EHIP);
-  if (have) {
-    const size_t tb = (size_t)ix->n + 128 + 16, sb = (size_t)ix->n * (ix->sa_wide ? 8 : 4);
-    if (hipMalloc(&ix->d_text, tb) != hipSuccess || hipMalloc(&ix->d_sa, sb + 16) != hipSuccess) return fail(SVDSS_ENOMEM);
-    if (hipMemset(ix->d_text, 0, tb) != hipSuccess ||
-        hipMemcpy((uint8_t*)ix->d_text + 64, src->text.data(), (size_t)ix->n, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ix->d_sa, src->sa_wide ? (const void*)src->sa64.data() : (const void*)src->sa32.data(), sb,
-                  hipMemcpyHostToDevice) != hipSuccess)
-      return fail(SVDSS_EHIP);
-  }
-  rc = build_table(ix);
-  if (rc != SVDSS_OK) return fail(rc);
-  *out = ix;
-  return SVDSS_OK;
-}
-
-static SvdssDevIndex host_view(const svdss_index* ix) {
-  SvdssDevIndex v;
-  v.blocks = ix->blocks.data();
-  v.dollar = ix->dollar.data();
-  v.n = ix->n;
-  v.n_dollar = (int32_t)ix->dollar.size();
-  v.k = 0; v.text = nullptr; v.sa = nullptr; v.table = nullptr;
-  memcpy(v.acc, ix->acc, sizeof v.acc);
-  return v;
-}
-
-extern "C" int64_t svdss_index_count(const svdss_index_t* ix, const uint8_t* pat, int64_t len) {
-  if (!ix || !pat || len <= 0) return -1;
-  const SvdssDevIndex v = host_view(ix);
-  int c = pat[len - 1];
-  if (c > 5) return -1;
-  int64_t lo = v.acc[c], hi = v.acc[c + 1];
-  for (int64_t i = len - 2; i >= 0 && hi > lo; --i) {
-    c = pat[i];
-    if (c > 5) return -1;
-    const int64_t a = v.acc[c];
-    lo = a + svdss_rank_in_block(v, v.blocks + 4 * (lo >> SVDSS_BLOCK_SHIFT), c, lo);
-    hi = a + svdss_rank_in_block(v, v.blocks + 4 * (hi >> SVDSS_BLOCK_SHIFT), c, hi);
-  }
-  return hi - lo;
-}
 
 // ---------------------------------------------------------------- kernels
 
@@ -1206,7 +775,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   if ((rc = ensure(b->sum, 64))) return rc;
 
   SfsParams p;
-  p.ix = device_view(ix);
+  p.ix = svdss_device_view(ix);
   p.chunks = (const svdss_u4*)d_reads;
   p.max_chunk = total_syms > 0 ? ((total_syms + 15) >> 4) - 1 : 0;
   p.offsets = d_offsets;

@@ -176,10 +176,14 @@ static int main_index(int argc, char** argv) {
   logmsg("info", "Indexing " + std::to_string(lens.size()) + " record(s), " + std::to_string(cat.size()) + " bases..");
   svdss_index_t* ix = nullptr;
   check(svdss_index_build(cat.data(), lens.data(), (int32_t)lens.size(), threads, &ix), "svdss_index_build");
-  // the file ropebwt3 build -d writes (rld0), so that the index serves upstream SVDSS as well -- and beside it this
-  // program's own layout (text, suffix array, rank blocks), which `search` restores with a plain read
+  // the file ropebwt3 build -d writes (rld0), so that the index serves upstream SVDSS as well -- and beside it the
+  // records themselves (nt6), from which `search` rebuilds the index in HBM in less time than the text + suffix array
+  // (19 bytes per base) take to read from any disk.  SVDSS_INDEX_FULL=1: the full layout instead (a plain read).
   check(svdss_index_save_fmd(ix, out.c_str()), "svdss_index_save_fmd");
-  if (!getenv("SVDSS_INDEX_NO_CACHE")) check(svdss_index_save(ix, (out + ".svdss").c_str()), "svdss_index_save");
+  if (!getenv("SVDSS_INDEX_NO_CACHE")) {
+    if (getenv("SVDSS_INDEX_FULL")) check(svdss_index_save(ix, (out + ".svdss").c_str()), "svdss_index_save");
+    else check(svdss_index_save_records(ix, (out + ".svdss").c_str()), "svdss_index_save_records");
+  }
   svdss_index_free(ix);
   return 0;
 }
@@ -318,11 +322,15 @@ int main_search(const Options& o) {
   // (SVDSS_GPUS_OVERSUBSCRIBE: more replicas than GPUs, replica d on GPU d % count -- exercises the path on a one-GPU box)
   const int n_dev = std::max(1, svdss_device_count());
   const int n_gpus = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev));
-  std::vector<svdss_index_t*> replicas(1, ix);
-  for (int d = 1; d < n_gpus; ++d) {
-    svdss_index_t* r = nullptr;
-    check(svdss_index_replicate(ix, d % n_dev, &r), "svdss_index_replicate");
-    replicas.push_back(r);
+  std::vector<svdss_index_t*> replicas((size_t)n_gpus, ix);
+  {
+    // every replica is built in the HBM of its own GPU from the records (or copied there), all of them at once
+    std::vector<std::thread> th;
+    std::vector<int> rcs((size_t)n_gpus, SVDSS_OK);
+    for (int d = 1; d < n_gpus; ++d)
+      th.emplace_back([&, d] { rcs[(size_t)d] = svdss_index_replicate(ix, d % n_dev, &replicas[(size_t)d]); });
+    for (std::thread& t : th) t.join();
+    for (int d = 1; d < n_gpus; ++d) check(rcs[(size_t)d], "svdss_index_replicate");
   }
   if (n_gpus > 1) logmsg("info", "Index replicated on " + std::to_string(n_gpus) + " GPUs");
   FastxReader* fx = nullptr;

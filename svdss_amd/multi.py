@@ -29,45 +29,108 @@ def shard_reads(flat: np.ndarray, offsets: np.ndarray, rank: int, world: int):
     return flat[o[0]:o[-1]], (o - o[0]).astype(np.int64), s
 
 
+class SfsGatherer:
+    """The per-step gather of the assembled SFS on rank 0 (`AllGather(counts)` + direct send/recv),
+    built for a step that repeats: the sizes travel in one all_gather of 2 int64 per rank, the payloads as three
+    point-to-point messages per peer of exactly the bytes there are (counts as int32, starts, lengths -- no packing, no
+    padding to the largest shard), every peer on its own xGMI link, into receive buffers rank 0 allocates once and only
+    ever grows.  gather() returns at once with a handle; wait() on it gives rank 0 the views (valid until the next
+    gather() into the same slot) -- so the exchange of step i runs beside the search of step i+1 (two slots)."""
+
+    def __init__(self, group=None, slots: int = 2):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.gloo = dist.get_backend(group) == "gloo"     # (CPU tests / oversubscribed developer runs: host staging)
+        self.slots = [dict(bufs={}, stage=None) for _ in range(slots)]
+        self.turn = 0
+        self._sizes = None
+
+    def _comm(self, t: torch.Tensor) -> torch.Tensor:
+        return t.cpu() if self.gloo and t.is_cuda else t
+
+    def _buf(self, slot, key, n, dtype, dev):
+        b = slot["bufs"].get(key)
+        if b is None or b.numel() < n:
+            b = torch.empty(int(n * 1.25) + 1024, dtype=dtype, device=dev)
+            slot["bufs"][key] = b
+        return b[:n]
+
+    def gather(self, counts: torch.Tensor, qs: torch.Tensor, ln: torch.Tensor):
+        """counts: int64[n_reads_local]; qs / ln: int32[total_local] on the rank's device (the library's own HBM
+        buffers: they are copied to a slot's staging buffers first, so the caller may search again at once)."""
+        slot = self.slots[self.turn % len(self.slots)]
+        self.turn += 1
+        if slot.get("pending") is not None:
+            self.wait(slot["pending"])
+        dev = counts.device
+        cdev = torch.device("cpu") if self.gloo else dev
+        c32 = self._buf(slot, "c", counts.numel(), torch.int32, dev)
+        c32.copy_(counts)
+        q = self._buf(slot, "q", qs.numel(), torch.int32, dev)
+        q.copy_(qs)
+        l = self._buf(slot, "l", ln.numel(), torch.int32, dev)
+        l.copy_(ln)
+        sizes = torch.tensor([counts.numel(), qs.numel()], dtype=torch.int64, device=cdev)
+        all_sizes = torch.empty(2 * self.world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(all_sizes, sizes, group=self.group)
+        ops, views = [], None
+        if self.rank == 0:
+            sz = all_sizes.cpu().view(self.world, 2)
+            views = [(c32, q, l)]
+            for r in range(1, self.world):
+                nr, nrec = int(sz[r, 0]), int(sz[r, 1])
+                rc = self._buf(slot, ("rc", r), nr, torch.int32, cdev)
+                rq = self._buf(slot, ("rq", r), nrec, torch.int32, cdev)
+                rl = self._buf(slot, ("rl", r), nrec, torch.int32, cdev)
+                views.append((rc, rq, rl))
+                for t in (rc, rq, rl):
+                    if t.numel():
+                        ops.append(dist.P2POp(dist.irecv, t, r, self.group))
+        else:
+            send = [self._comm(t) for t in (c32, q, l)]
+            slot["stage"] = send          # (kept alive until the sends are done)
+            for t in send:
+                if t.numel():
+                    ops.append(dist.P2POp(dist.isend, t, 0, self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        h = {"works": works, "views": views, "slot": slot}
+        slot["pending"] = h
+        return h
+
+    def wait(self, h, concat: bool = True):
+        """Completes the exchange of handle h.  Rank 0 gets (counts int64, starts, lengths) of all ranks in rank order
+        (concat=False: the per-rank views [(counts int32, starts, lengths)] as they sit in the receive buffers, nothing
+        copied); the other ranks None."""
+        for w in h["works"]:
+            w.wait()
+        h["works"] = []
+        if h["slot"].get("pending") is h:
+            h["slot"]["pending"] = None
+        if self.rank != 0:
+            return None
+        if not concat:
+            return h["views"]
+        cs = torch.cat([v[0] for v in h["views"]]).to(torch.int64)
+        return cs, torch.cat([v[1] for v in h["views"]]), torch.cat([v[2] for v in h["views"]])
+
+    def flush(self):
+        for s in self.slots:
+            if s.get("pending") is not None:
+                self.wait(s["pending"])
+
+
+_default_gatherers = {}
+
+
 def gather_sfs(counts: torch.Tensor, qs: torch.Tensor, ln: torch.Tensor, group=None
                ) -> Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-    """Gather per-read SFS records of every rank on rank 0, in rank (= read) order.
-
-    counts: int64[n_reads_local]; qs/ln: int32[total_local], all on the rank's device.
-    Sizes are exchanged with one all_gather of 2 int64 per rank, payloads with one
-    gather of buffers padded to the largest shard (RCCL needs equal sizes; at <=
-    a few hundred MB per node the padding is cheaper than a second round of sizes).
-    Returns (counts, qs, len) on rank 0, None elsewhere.
-    """
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    dev = counts.device
-    sizes = torch.tensor([counts.numel(), qs.numel()], dtype=torch.int64, device=dev)
-    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    all_sizes = torch.stack(all_sizes).cpu()
-    max_reads = int(all_sizes[:, 0].max())
-    max_recs = int(all_sizes[:, 1].max())
-    # one int64 payload per rank: [counts | qs<<32|len]
-    payload = torch.zeros(max_reads + max_recs, dtype=torch.int64, device=dev)
-    payload[:counts.numel()] = counts
-    if qs.numel():
-        payload[max_reads:max_reads + qs.numel()] = (qs.to(torch.int64) << 32) | ln.to(torch.int64)
-    # direct gather: every peer sends to rank 0 on its own xGMI link (RCCL implements
-    # gather as grouped send/recv), nothing is replicated to ranks that do not need it
-    bufs = [torch.zeros_like(payload) for _ in range(world)] if rank == 0 else None
-    dist.gather(payload, gather_list=bufs, dst=0, group=group)
-    if rank != 0:
-        return None
-    cs, qq, ll = [], [], []
-    for r in range(world):
-        nr, nrec = int(all_sizes[r, 0]), int(all_sizes[r, 1])
-        cs.append(bufs[r][:nr])
-        rec = bufs[r][max_reads:max_reads + nrec]
-        qq.append((rec >> 32).to(torch.int32))
-        ll.append((rec & 0xFFFFFFFF).to(torch.int32))
-    return torch.cat(cs), torch.cat(qq), torch.cat(ll)
-
+    """Gather per-read SFS records of every rank on rank 0, in rank (= read) order (blocking form of SfsGatherer).
+    Returns (counts int64, qs int32, len int32) on rank 0 -- on the device the ranks exchange on --, None elsewhere."""
+    g = _default_gatherers.get(group)
+    if g is None:
+        g = _default_gatherers[group] = SfsGatherer(group, slots=1)
+    return g.wait(g.gather(counts, qs, ln))
 
 
 def call_sharded(alignments, sfs_text: str, chromosomes: dict, contigs, ref_names, group=None, **kw):

@@ -87,6 +87,11 @@ class FMDIndex:
     def save(self, path: str) -> None:
         check(lib.svdss_index_save(self._h, path.encode()), "svdss_index_save")
 
+    def save_records(self, path: str) -> None:
+        """The records file `SVDSS index` leaves beside the .fmd: load() of it rebuilds the index where it is made
+        resident instead of reading text + suffix array from disk."""
+        check(lib.svdss_index_save_records(self._h, path.encode()), "svdss_index_save_records")
+
     def save_fmd(self, path: str) -> None:
         """ropebwt3's rld0 dump (`ropebwt3 build -d` / upstream `SVDSS index`)."""
         check(lib.svdss_index_save_fmd(self._h, path.encode()), "svdss_index_save_fmd")
@@ -132,6 +137,14 @@ class FMDIndex:
     def to_device(self, device: int = 0) -> "FMDIndex":
         check(lib.svdss_index_to_device(self._h, device), "svdss_index_to_device")
         return self
+
+    def verify(self, stride: int = 1) -> dict:
+        """The resident index against its own text, by direct comparison (svdss_index_verify_device): suffix-array
+        rows strictly increasing as strings, BWT[i] == text[SA[i]-1], rank blocks, '$' rows, symbol histogram."""
+        o = np.zeros(8, dtype=np.int64)
+        check(lib.svdss_index_verify_device(self._h, stride, o.ctypes.data), "svdss_index_verify_device")
+        keys = ("rows", "bad_order", "bad_bwt", "bad_range", "bad_block", "bad_dollar", "first_bad", "max_lcp")
+        return dict(zip(keys, (int(x) for x in o)))
 
 
 @dataclass

@@ -246,3 +246,31 @@ def poa_consensus(seqs) -> np.ndarray:
     m = _lib.orc_poa_consensus(flat.ctypes.data, offs.ctypes.data, n, out.ctypes.data, cap)
     assert m >= 0
     return out[:m].copy()
+
+
+# ---- the call-side DP of a list of sub-clusters on host threads (oracle/svdss_oracle_callbatch.c) ---------------
+_lib.orc_call_batch.restype = C.c_int
+_lib.orc_call_batch.argtypes = [_p, _p, _p, _i64, _p, _p, _p, C.c_int, _p, _p, _p, _p]
+
+
+def call_batch(seqs, seq_off, cluster_off, refs, ref_off, mat, threads=0):
+    """POA -> realignment of every sub-cluster (OpenMP over sub-clusters, caller.cpp:319-321), then the ratio of
+    adjacent consensus pairs.  -> (cons_len int64[n], score int32[n], n_cigar int64[n], ratio float64[n - 1])."""
+    n = len(cluster_off) - 1
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+    cluster_off = np.ascontiguousarray(cluster_off, dtype=np.int64)
+    refs = np.ascontiguousarray(refs, dtype=np.uint8)
+    ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
+    mat = np.ascontiguousarray(mat, dtype=np.int8)
+    cons_len = np.zeros(n, np.int64)
+    score = np.zeros(n, np.int32)
+    n_cig = np.zeros(n, np.int64)
+    ratio = np.zeros(max(0, n - 1), np.float64)
+    if threads <= 0:
+        threads = _lib.orc_max_threads()
+    rc = _lib.orc_call_batch(seqs.ctypes.data, seq_off.ctypes.data, cluster_off.ctypes.data, n, refs.ctypes.data,
+                             ref_off.ctypes.data, mat.ctypes.data, threads, cons_len.ctypes.data, score.ctypes.data,
+                             n_cig.ctypes.data, ratio.ctypes.data)
+    assert rc == 0
+    return cons_len, score, n_cig, ratio

@@ -145,9 +145,10 @@ def test_search_fastx_and_bam_text(tmp_path, assemble):
     assert set(parsed) <= set(keep_names)
 
 
-def test_index_writes_an_rld0_fmd_and_the_own_layout_beside_it(tmp_path):
+def test_index_writes_an_rld0_fmd_and_the_records_beside_it(tmp_path):
     """`SVDSS index -d ref.fa -o ref.fa.fmd` (run_svdss:142): the .fmd is ropebwt3's rld0 dump (what upstream restores),
-    `<fmd>.svdss` this program's own layout; both restore to an index with the same BWT.  (Host builder: no GPU needed.)"""
+    `<fmd>.svdss` the records themselves (the index is rebuilt from them where it is made resident; SVDSS_INDEX_FULL=1:
+    the full layout); all three restore to an index with the same BWT.  (Host builder: no GPU needed.)"""
     import ctypes as C
     from svdss_amd._lib import lib
     ref = synth.make_reference([20000, 3000], seed=9, n_runs=(50,))
@@ -160,14 +161,25 @@ def test_index_writes_an_rld0_fmd_and_the_own_layout_beside_it(tmp_path):
     r = run("index", "-t", "2", "-d", str(fa), "-o", str(fmd))
     assert r.returncode == 0, r.stderr
     assert fmd.read_bytes()[:4] == b"RLD\x03"
-    assert (tmp_path / "ref.fa.fmd.svdss").read_bytes()[:8] == b"SVDSSFM2"
+    assert (tmp_path / "ref.fa.fmd.svdss").read_bytes()[:8] == b"SVDSSRC1"
+    assert os.path.getsize(tmp_path / "ref.fa.fmd.svdss") < 24000                  # ~1 byte per base, not 19
+    r = run("index", "-t", "2", "-d", str(fa), "-o", str(tmp_path / "full.fmd"), env=dict(os.environ, SVDSS_INDEX_FULL="1"))
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "full.fmd.svdss").read_bytes()[:8] == b"SVDSSFM2"
     want = svdss_amd.FMDIndex.build(ref, threads=2)
     n = C.c_int64()
     assert lib.svdss_fmd_read_bwt(str(fmd).encode(), None, 0, C.byref(n)) == 0 and n.value == want.size
     got = np.zeros(n.value, np.uint8)
     assert lib.svdss_fmd_read_bwt(str(fmd).encode(), got.ctypes.data, n.value, C.byref(n)) == 0
     assert (got == want.bwt()).all()
-    assert (svdss_amd.FMDIndex.load(str(fmd)).bwt() == want.bwt()).all()          # through <fmd>.svdss
+    lazy = svdss_amd.FMDIndex.load(str(fmd))                                       # through <fmd>.svdss
+    assert lazy.size == want.size and (lazy.acc == want.acc).all()                 # known before anything is built
+    assert (lazy.bwt() == want.bwt()).all() and lazy.count(ref[0][50:90]) == want.count(ref[0][50:90])
+    assert (svdss_amd.FMDIndex.load(str(tmp_path / "full.fmd")).bwt() == want.bwt()).all()
+    lazy.save_records(str(tmp_path / "again.rc"))
+    assert (tmp_path / "again.rc").read_bytes() == (tmp_path / "ref.fa.fmd.svdss").read_bytes()
+    want.save_records(str(tmp_path / "fromtext.rc"))                               # records out of the text
+    assert (tmp_path / "fromtext.rc").read_bytes() == (tmp_path / "ref.fa.fmd.svdss").read_bytes()
     os.remove(tmp_path / "ref.fa.fmd.svdss")
     back = svdss_amd.FMDIndex.load(str(fmd))                                       # through the rld0 import
     assert back.size == want.size and (back.acc == want.acc).all()

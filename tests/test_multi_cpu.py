@@ -48,6 +48,64 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_steps(rank, world, port, q):
+    """Three steps through one two-slot SfsGatherer: step i's exchange is waited for only after step i+1 was posted;
+    the receive buffers are reused (grow-only) and every step's result is exact."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = multi.SfsGatherer(slots=2)
+    out, prev = [], None
+    for step in range(3):
+        rng = np.random.default_rng(1000 * step + rank)
+        n_reads = 4 + 2 * rank + step
+        counts = rng.integers(0, 5 + 3 * step, size=n_reads)
+        total = int(counts.sum())
+        qs = rng.integers(0, 15000, size=total).astype(np.int32)
+        ln = rng.integers(1, 2000, size=total).astype(np.int32)
+        h = g.gather(torch.from_numpy(counts.astype(np.int64)), torch.from_numpy(qs), torch.from_numpy(ln))
+        if prev is not None:
+            r = g.wait(prev)
+            if rank == 0:
+                out.append([t.numpy().copy() for t in r])
+        prev = h
+    r = g.wait(prev)
+    if rank == 0:
+        out.append([t.numpy().copy() for t in r])
+        q.put(out)
+    g.flush()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gatherer_overlapped_steps_gloo():
+    world = 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_steps, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for step in range(3):
+        cs, qq, ll = [], [], []
+        for rank in range(world):
+            rng = np.random.default_rng(1000 * step + rank)
+            counts = rng.integers(0, 5 + 3 * step, size=4 + 2 * rank + step)
+            total = int(counts.sum())
+            cs.append(counts)
+            qq.append(rng.integers(0, 15000, size=total).astype(np.int32))
+            ll.append(rng.integers(1, 2000, size=total).astype(np.int32))
+        c, qv, lv = got[step]
+        assert (c == np.concatenate(cs)).all() and (qv == np.concatenate(qq)).all() and (lv == np.concatenate(ll)).all()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_gather_sfs_gloo(world):
     s = socket.socket()

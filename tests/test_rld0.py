@@ -229,3 +229,24 @@ def test_reader_takes_64_bit_block_headers_and_bounds_its_reads(tmp_path):
     raw += struct.pack(f"<{len(words)}Q", *words) + struct.pack("<7Q", *([0] * 7))
     (tmp_path / "t2.fmd").write_bytes(raw)
     assert read_bwt(tmp_path / "t2.fmd").tolist() == [1] * 5 + [2] * 3 + [0] * 2
+
+
+def test_second_encoder_writes_the_same_bytes_and_ropebwt_sentinel_order_imports(tmp_path):
+    """tests/rld0_py.py encodes rld0 in Python from the format description: byte-identical to csrc/rld0.cpp on the
+    library's own BWT; and a BWT in ropebwt's sentinel order (string i's '$' before string j's -- not the order of
+    this library's index, so not a file its writer could produce) imports to the index of the same records."""
+    from tests import rld0_py
+    ref = synth.make_reference([30000, 9000, 40], seed=3, repeat_frac=0.2, n_runs=(60,))
+    jx = svdss_amd.FMDIndex.build(ref)
+    jx.save_fmd(str(tmp_path / "own.fmd"))
+    assert (tmp_path / "own.fmd").read_bytes() == rld0_py.encode_rld0(jx.bwt())
+    strings = []
+    for c in ref:
+        strings += [c, synth.revcomp(c)]
+    bwt = rld0_py.collection_bwt(strings)
+    assert not (bwt == jx.bwt()).all() and np.bincount(bwt, minlength=6).tolist() == np.bincount(jx.bwt(), minlength=6).tolist()
+    (tmp_path / "up.fmd").write_bytes(rld0_py.encode_rld0(bwt))
+    assert (read_bwt(tmp_path / "up.fmd") == bwt).all()
+    assert (py_decode(tmp_path / "up.fmd")[0] == bwt).all()
+    ix = svdss_amd.FMDIndex.load(str(tmp_path / "up.fmd"))
+    assert ix.size == jx.size and (ix.acc == jx.acc).all() and (ix.bwt() == jx.bwt()).all()

