@@ -234,9 +234,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["wg", "chr20"], default="wg",
+    ap.add_argument("--workload", choices=["wg", "chr20", "wg-families"], default="wg",
                     help="wg (default, the metric's configuration): 24 contigs with GRCh38 primary lengths, 1,048,576 "
-                         "reads per GPU per step; chr20: one 64,444,167 bp contig, 30x = 128,888 reads per step")
+                         "reads per GPU per step; chr20: one 64,444,167 bp contig, 30x = 128,888 reads per step; "
+                         "wg-families: the wg lengths with 45 %% of the bases in copies of 40 repeat families at "
+                         "--divergence (a repeat-rich genome instead of iid sequence; reported beside the wg line, "
+                         "never as the headline)")
+    ap.add_argument("--divergence", type=float, default=0.05, help="wg-families: divergence of the family copies")
     ap.add_argument("--ref-len", type=int, default=0, help="override: single contig of this many bases")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--read-len", type=int, default=15000)
@@ -285,7 +289,7 @@ def main():
 
     if args.ref_len:
         contig_lens = [args.ref_len]
-    elif args.workload == "wg":
+    elif args.workload in ("wg", "wg-families"):
         contig_lens = GRCH38_PRIMARY
     else:
         contig_lens = [64_444_167]
@@ -293,7 +297,7 @@ def main():
     L = args.read_len
     if args.reads:
         n_reads = args.reads
-    elif args.workload == "wg" and not args.ref_len:
+    elif args.workload in ("wg", "wg-families") and not args.ref_len:
         n_reads = 1 << 20
     else:
         n_reads = int(round(args.coverage * ref_total / L))
@@ -301,7 +305,9 @@ def main():
 
     # ---- index: every rank builds its own replica in its HBM (svdss_index_build_device) -------
     t0 = time.time()
-    ref = synth.make_reference(contig_lens, seed=11)
+    families = args.workload == "wg-families"
+    ref = (synth.make_family_reference(contig_lens, seed=11, divergence=args.divergence) if families
+           else synth.make_reference(contig_lens, seed=11))
     t_ref = time.time() - t0
     t0 = time.time()
     ix = svdss_amd.FMDIndex.build(ref, device=local_rank)
@@ -317,7 +323,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_e2e:
         import tempfile
         e2e_dir = tempfile.mkdtemp(prefix="svdss_bench_e2e_", dir="/tmp")
-        e2e_prepare(e2e_dir, ref, wg=(len(contig_lens) == 24 and not args.no_e2e_wg))
+        e2e_prepare(e2e_dir, ref, wg=(len(contig_lens) == 24 and not args.no_e2e_wg and not families))
 
     # ---- reads: generated on the GPU from the contigs LPT gives this rank -------
     owner = lpt_partition(contig_lens, world)
@@ -501,7 +507,8 @@ def main():
     if rank == 0:
         wl = "GRCh38 primary lengths" if len(contig_lens) == 24 else "chr20 length" if ref_total == 64_444_167 else "custom"
         out = {
-            "metric": "reads/sec through search+call, 30x HiFi 15 kb reads vs 3 Gb ref, 1/2/4/8 GPU"
+            "metric": ("reads/sec through search+call, 30x HiFi 15 kb reads vs 3 Gb ref, 1/2/4/8 GPU"
+                       + (" [repeat-rich variant of the reference: NOT the headline configuration]" if families else ""))
                       if cw is not None else "reads/sec through SFS search only (NOT the headline metric: --no-call-dp)",
             "value": world * n_reads * args.steps / elapsed,
             "unit": "reads/s",
@@ -515,8 +522,10 @@ def main():
             "dtype": "int64",
             "data": "synthetic",
             "config": {
-                "workload": (f"synthetic {ref_total} bp reference in {len(contig_lens)} contig(s) ({wl}, iid ACGT + 3% diverged "
-                             f"repeats, both strands indexed: {ix.size} BWT symbols), {n_reads} reads/GPU/step x {L} bp "
+                "workload": (f"synthetic {ref_total} bp reference in {len(contig_lens)} contig(s) ({wl}, "
+                             + (f"45% of the bases in copies of 40 repeat families at {args.divergence * 100:g}% divergence"
+                                if families else "iid ACGT + 3% diverged repeats")
+                             + f", both strands indexed: {ix.size} BWT symbols), {n_reads} reads/GPU/step x {L} bp "
                              f"({n_reads * L / ref_total:.2f}x per step; a 30x set = {30 * ref_total / L / n_reads:.2f} steps), "
                              f"{args.err * 100:.2f}% errors; step = search (ping-pong + fused assemble, all reads searched = "
                              "--noputative semantics, reads resident in HBM)"
@@ -541,7 +550,8 @@ def main():
         }
         out["index_verified_rows"] = iv["rows"]
         out["roofline"] = search_roofline(ref_total, n_reads, L, ix.kmer_k, k_ms, n_ext, total_syms, n_sfs_raw,
-                                          float(np.mean(pipeline_ms)), float(np.mean(alone_ms)))
+                                          float(np.mean(pipeline_ms)), float(np.mean(alone_ms)),
+                                          tag=(f"_families{args.divergence:g}" if families else ""))
         if cw is not None:
             okc, n_alt = cw.svs_recovered()
             poa_k, aln_k = float(np.mean(poa_ms)), float(np.mean(aln_ms))
@@ -605,14 +615,14 @@ def call_rooflines(poa_cells, poa_ms, aln_cells, aln_ms):
     return {"poa": one(poa_cells, poa_ms, POA_OPS_PER_CELL), "realign": one(aln_cells, aln_ms, ALN_OPS_PER_CELL)}
 
 
-def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw, all_ms, alone_ms):
+def search_roofline(ref_total, n_reads, L, k, k_ms, n_ext, total_syms, n_sfs_raw, all_ms, alone_ms, tag=""):
     """HBM roofline of the search kernel.  `achieved` = the bytes the kernel's own memory operations move per launch
     (TCC_EA0_RDREQ x 128 B + WRREQ x 32|64 B from the committed rocprofv3 --pmc pass of exactly this workload,
     profiles/traffic.json) / the kernel time measured live with HIP events on the launch stream; null when this
     workload has not been profiled.  The reference algorithm's cost model (one 64-B block per
     rb3_fmd_extend) is reported as `reference_model_bytes`: the kernel answers most of those extensions from its k-mer
     table / text compare without fetching their blocks, so that figure is not a bound of this kernel."""
-    prof = profiled(ref_total, n_reads, L, k)
+    prof = profiled(ref_total, n_reads, L, k, tag)
     ref_model = n_ext * 64 + total_syms + 16 * n_sfs_raw
     r = {"bound": "hbm", "kernel": "sfs_search2_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": k_ms,
          "all_search_kernels_ms": all_ms, "kernel_ms_on_idle_gpu": alone_ms, "reference_model_bytes": ref_model,
@@ -656,13 +666,13 @@ def search_kernel_hash():
     return h.hexdigest()[:16]
 
 
-def profiled(ref_total, n_reads, L, k):
+def profiled(ref_total, n_reads, L, k, tag=""):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             table = json.load(fh)
     except OSError:
         return None
-    e = table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}")
+    e = table.get(f"ref{ref_total}_reads{n_reads}_len{L}_k{k}{tag}")
     if not isinstance(e, dict) or e.get("kernel_hash") != search_kernel_hash():
         return None          # never profiled, or profiled on another version of the kernel: no fraction is claimed
     return e
