@@ -160,7 +160,7 @@ class CallWorkload:
         self.ref_off = np.zeros(self.n_sub + 1, dtype=np.int64)
         self.ref_off[1:] = np.cumsum([len(r) for r in refs])
         self.refs = np.ascontiguousarray(np.concatenate(refs))
-        from svdss_amd.caller import KSW_MAT           # caller.cpp:333-337: 5 x 5, match 1, mismatch -9, N 0
+        from svdss_amd.calldp import KSW_MAT           # caller.cpp:333-337: 5 x 5, match 1, mismatch -9, N 0
         self.mat = np.ascontiguousarray(KSW_MAT)
         self._poa = C.c_void_p()
         self._aln = C.c_void_p()

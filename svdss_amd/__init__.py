@@ -8,4 +8,4 @@ raises ImportError -- there is no CPU fallback.
 from ._lib import LIB_PATH, SVDSS_SFS_ASSEMBLE, SvdssError, lib  # noqa: F401
 from .pingpong import (FMDIndex, NT6_TABLE, PingPong, SFSBatch, nt6_encode, output_batch,  # noqa: F401
                        pack_reads, parse_sfsfile)
-from . import caller  # noqa: F401,E402
+from . import calldp  # noqa: F401,E402

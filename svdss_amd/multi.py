@@ -5,8 +5,9 @@ gives each OpenMP worker a disjoint slice), so the path shards with NO data-path
 collective: the index is replicated in every GPU's HBM, each rank searches its
 slice of the reads.  The only exchange is the final gather of the (assembled)
 SFS records to rank 0, which writes the .sfs text (ping_pong.cpp:213-236).
-`call` shards its DP batches (POA, realignment) by sub-cluster index and gathers the
-per-sub-cluster rows before the global sort / dedup / chain filter (call_sharded).
+`call` shards its DP batches (POA, realignment) by sub-cluster index and gathers the per-sub-cluster rows before
+the global sort / dedup / chain filter: in the product that is `SVDSS call --gpus N` (csrc/call_host.cpp); its Python
+mirror over torch.distributed is tests/mirror/multi_call.py.
 """
 from typing import Optional, Tuple
 
@@ -131,22 +132,3 @@ def gather_sfs(counts: torch.Tensor, qs: torch.Tensor, ln: torch.Tensor, group=N
     if g is None:
         g = _default_gatherers[group] = SfsGatherer(group, slots=1)
     return g.wait(g.gather(counts, qs, ln))
-
-
-def call_sharded(alignments, sfs_text: str, chromosomes: dict, contigs, ref_names, group=None, **kw):
-    """`SVDSS call` over the ranks of one node (one process per GPU, torch.distributed already initialised):
-    svdss_amd.caller.call with the POA / realignment batches sharded by sub-cluster index and one
-    all_gather_object of the per-sub-cluster rows (consensus, score, CIGAR -- a few hundred bytes each).  Every rank
-    returns the same (vcf_text, info), byte-identical to the single-GPU call.  kw: caller.call's keyword arguments
-    (device defaults to this rank's current CUDA device)."""
-    from . import caller
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-
-    def all_gather(rows):
-        parts = [None] * world
-        dist.all_gather_object(parts, rows, group=group)
-        return parts
-
-    if "device" not in kw and torch.cuda.is_available():
-        kw["device"] = torch.cuda.current_device()
-    return caller.call(alignments, sfs_text, chromosomes, contigs, ref_names, shard=(rank, world, all_gather), **kw)

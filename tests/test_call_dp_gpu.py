@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from svdss_amd import caller
+from tests.mirror import caller
 from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu

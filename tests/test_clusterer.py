@@ -2,7 +2,7 @@
 import numpy as np
 
 from svdss_amd import synth
-from svdss_amd.clusterer import (Alignment, BAM_CDEL, BAM_CINS, BAM_CMATCH, BAM_CSOFT_CLIP, Clusterer, ExtSFS,
+from tests.mirror.clusterer import (Alignment, BAM_CDEL, BAM_CINS, BAM_CMATCH, BAM_CSOFT_CLIP, Clusterer, ExtSFS,
                                  get_aligned_pairs, get_unique_kmers)
 
 

@@ -7,7 +7,8 @@ import subprocess
 
 import pytest
 
-from svdss_amd import bamio, caller, synth
+from svdss_amd import synth
+from tests.mirror import bamio, caller
 from tests.common import ROOT
 from tools import e2e_call
 

@@ -42,7 +42,7 @@ def _payloads(rng):
 
 
 def test_every_block_type_level_and_strategy():
-    from svdss_amd.bamio import gpu_inflate
+    from svdss_amd.bgzf import gpu_inflate
     rng = np.random.default_rng(11)
     pay = _payloads(rng)
     streams, want = [], []
@@ -71,7 +71,7 @@ def test_random_mixtures_of_literals_runs_and_copies():
     the one-symbol path), runs, copies of earlier pieces at every distance, BAM-like records -- at random levels and
     strategies: rounds that end at a match, at the byte budget of a round, at the end-of-block code or at a code the
     tables cannot decode, in every combination the pointer-doubling chain has to get right."""
-    from svdss_amd.bamio import gpu_inflate
+    from svdss_amd.bgzf import gpu_inflate
     rng = np.random.default_rng(2024)
     streams, want = [], []
     for k in range(400):
@@ -113,7 +113,7 @@ def test_random_mixtures_of_literals_runs_and_copies():
 
 
 def test_scattered_outputs_do_not_touch_their_neighbours():
-    from svdss_amd.bamio import gpu_inflate
+    from svdss_amd.bgzf import gpu_inflate
     rng = np.random.default_rng(5)
     datas = [rng.integers(0, 4, size=int(n), dtype=np.uint8).tobytes() for n in (1, 2, 3, 5, 4097, 65535, 7, 16384, 16385)]
     comp, blocks, uoff = bytearray(), [], []
@@ -132,7 +132,7 @@ def test_scattered_outputs_do_not_touch_their_neighbours():
 
 def test_bgzf_file_blocks():
     """a BGZF file as bgzip / htslib write it (header with BC subfield, footer with CRC32 and ISIZE)"""
-    from svdss_amd.bamio import bgzf_blocks, gpu_inflate
+    from svdss_amd.bgzf import bgzf_blocks, gpu_inflate
     rng = np.random.default_rng(3)
     raw = rng.integers(0, 8, size=300000, dtype=np.uint8).tobytes()
     data = bytearray()
@@ -151,7 +151,7 @@ def test_bgzf_file_blocks():
 
 def test_corrupt_streams_are_reported_not_trusted():
     from svdss_amd._lib import SvdssError
-    from svdss_amd.bamio import gpu_inflate
+    from svdss_amd.bgzf import gpu_inflate
     rng = np.random.default_rng(9)
     good = rng.integers(0, 16, size=20000, dtype=np.uint8).tobytes()
     s = bytearray(_raw(good, 6))

@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from svdss_amd import multi
+from tests.mirror import multi_call
 
 
 def test_shard_range_partitions_exactly():
@@ -139,7 +140,7 @@ def test_gather_sfs_gloo(world):
 # kernels behind the default functions are compared with the same oracle in the -m gpu tests).
 
 def _oracle_fns():
-    from svdss_amd import caller
+    from tests.mirror import caller
     from tests import oracle_lib as O
 
     def poa_fn(clusters, device=0):
@@ -158,7 +159,8 @@ def _oracle_fns():
 def _call_inputs():
     import tempfile
     import svdss_amd
-    from svdss_amd import bamio, pingpong, synth
+    from svdss_amd import pingpong, synth
+    from tests.mirror import bamio
     from tests import bam_writer
     from tests import oracle_lib as O
     from tests.pipeline_sim import simulate
@@ -187,7 +189,7 @@ def _call_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     alns, sfs_text, chromosomes, contigs, ref_names, _ = _call_inputs()
-    vcf, info = multi.call_sharded(alns, sfs_text, chromosomes, contigs, ref_names, threads=4, min_sv_length=50,
+    vcf, info = multi_call.call_sharded(alns, sfs_text, chromosomes, contigs, ref_names, threads=4, min_sv_length=50,
                                    device=0, **_oracle_fns())
     q.put((rank, vcf, info["sam"], info["subclusters"]))
     dist.barrier()
@@ -196,7 +198,7 @@ def _call_worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_call_sharded_gloo_equals_single_rank(world):
-    from svdss_amd import caller
+    from tests.mirror import caller
     alns, sfs_text, chromosomes, contigs, ref_names, n_truth = _call_inputs()
     vcf0, info0 = caller.call(alns, sfs_text, chromosomes, contigs, ref_names, threads=4, min_sv_length=50, **_oracle_fns())
     rows0 = [l for l in vcf0.splitlines() if not l.startswith("#")]

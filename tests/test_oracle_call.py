@@ -4,7 +4,7 @@ left-alignment convention, the ratio against the closed form of SURVEY App. B.4.
 import numpy as np
 import pytest
 
-from svdss_amd import caller
+from tests.mirror import caller
 from tests import oracle_lib as O
 
 MAT = caller.KSW_MAT

@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 import pytest
 
-from svdss_amd import bamio, caller, synth
+from svdss_amd import synth
+from tests.mirror import bamio, caller
 from tests import bam_writer
 from tests.common import ROOT
 from tests.pipeline_sim import simulate
@@ -210,13 +211,13 @@ def test_config1_shape_1k_reads_10mb_full_chain(tmp_path):
 
 def _sharded_hip_worker(rank, world, port, q):
     import torch.distributed as dist
-    from svdss_amd import multi
+    from tests.mirror import multi_call
     from tests.test_multi_cpu import _call_inputs
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)   # (the ranks share the one GPU of the test box)
     alns, sfs_text, chromosomes, contigs, ref_names, _ = _call_inputs()
-    vcf, info = multi.call_sharded(alns, sfs_text, chromosomes, contigs, ref_names, threads=4, min_sv_length=50, device=0)
+    vcf, info = multi_call.call_sharded(alns, sfs_text, chromosomes, contigs, ref_names, threads=4, min_sv_length=50, device=0)
     q.put((rank, vcf, info["sam"]))
     dist.barrier()
     dist.destroy_process_group()

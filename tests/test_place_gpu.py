@@ -10,7 +10,7 @@ import pytest
 
 from svdss_amd import synth
 from svdss_amd._lib import check, lib
-from svdss_amd.clusterer import Alignment, Clusterer
+from tests.mirror.clusterer import Alignment, Clusterer
 
 pytestmark = pytest.mark.gpu
 OPS = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "=": 7, "X": 8}

@@ -3,7 +3,7 @@ plus the invariants and the stated tolerance vs the truth at SURVEY 2.3 K3 sizes
 import numpy as np
 import pytest
 
-from svdss_amd import caller
+from tests.mirror import caller
 from tests import oracle_lib as O
 from tests.test_oracle_poa import edit_distance, mutate
 

@@ -5,8 +5,9 @@ import subprocess
 
 import numpy as np
 
-from svdss_amd import bamio, smoother, synth
-from svdss_amd.clusterer import Alignment
+from svdss_amd import synth
+from tests.mirror import bamio, smoother
+from tests.mirror.clusterer import Alignment
 from tests import bam_writer
 from tests.common import ROOT
 from tests.pipeline_sim import add_errors, simulate

@@ -1,5 +1,5 @@
 """a13: Caller::split_cluster (/root/reference/caller.cpp:78-255) host logic, hand-worked cases."""
-from svdss_amd.caller import Cluster, SubRead, split_cluster, split_cluster_by_len
+from tests.mirror.caller import Cluster, SubRead, split_cluster, split_cluster_by_len
 
 
 def _cluster(lens_tags, cov=(12, 4, 5, 3)):

@@ -4,7 +4,7 @@
 import sys
 import time
 import numpy as np
-from svdss_amd import caller
+from svdss_amd import calldp as caller
 
 n, ln, depth = (int(x) for x in (sys.argv[1:4] + ["16", "2600", "30"][len(sys.argv) - 1:]))
 rng = np.random.default_rng(7)

@@ -1,7 +1,7 @@
 """Developer probe: POA consensus on a few synthetic sub-clusters (prints the batch statistics)."""
 import sys
 import numpy as np
-from svdss_amd import caller
+from svdss_amd import calldp as caller
 
 n, ln, depth = (int(x) for x in (sys.argv[1:4] + ["2", "1200", "12"][len(sys.argv) - 1:]))
 rng = np.random.default_rng(99)
