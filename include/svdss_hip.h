@@ -165,6 +165,19 @@ int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8_t* comp, i
                        int64_t out_bytes, int64_t* bad_block);
 double svdss_inflate_kernel_ms(const svdss_inflate_t* obj);   /* the inflate kernel of the last call, HIP events */
 void svdss_inflate_free(svdss_inflate_t* obj);
+/* ---- BGZF blocks DEFLATED on the GPU (csrc/deflate.hip).  Stands where htslib's bgzf_write / deflate stand under
+ * sam_write1 in `SVDSS smooth` (/root/reference/smoother.cpp:441-494).  `in` (host memory) is cut into blocks of
+ * block_bytes (<= 0xff00; the last one may be short); block i becomes a BGZF member at out + i * out_stride (host
+ * memory; out_stride >= block_bytes + 64, a multiple of 4): 18-byte header with BSIZE, a deflate stream of dynamic-
+ * Huffman coded literals (no matches: a level-1-class encoder for packed bases and qualities; incompressible quarters
+ * are stored), and 8 bytes LEFT FOR THE CALLER to fill with CRC32 and ISIZE; out_len[i] = the member's length with
+ * those 8 bytes.  Any inflater reads the result; it is not the byte stream zlib would write.  Returns when done (the
+ * object's own stream: calls on different objects overlap). */
+typedef struct svdss_deflate svdss_deflate_t;
+int svdss_bgzf_deflate(svdss_deflate_t** obj, int32_t device, const uint8_t* in, int64_t in_bytes, int32_t block_bytes,
+                       uint8_t* out, int64_t out_stride, int32_t* out_len);
+double svdss_deflate_kernel_ms(const svdss_deflate_t* obj);
+void svdss_deflate_free(svdss_deflate_t* obj);
 /* plain device memory for the callers of the entry points that take device pointers */
 int svdss_device_alloc(int device, int64_t bytes, void** out);
 void svdss_device_free(int device, void* p);

@@ -71,6 +71,9 @@ SIGNATURES = {
     "svdss_bgzf_inflate": (C.c_int, [C.POINTER(_p), _i32, _p, _i64, _p, _i64, _p, _p, _i64, _pi64]),
     "svdss_inflate_kernel_ms": (C.c_double, [_p]),
     "svdss_inflate_free": (None, [_p]),
+    "svdss_bgzf_deflate": (C.c_int, [C.POINTER(_p), _i32, _p, _i64, _i32, _p, _i64, _p]),
+    "svdss_deflate_kernel_ms": (C.c_double, [_p]),
+    "svdss_deflate_free": (None, [_p]),
     "svdss_device_alloc": (C.c_int, [_i32, _i64, C.POINTER(_p)]),
     "svdss_device_free": (None, [_i32, _p]),
     "svdss_device_memset": (C.c_int, [_i32, _p, C.c_int, _i64]),

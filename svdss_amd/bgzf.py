@@ -65,3 +65,37 @@ def gpu_inflate(data, blocks, device=0, uoff=None):
         lib.svdss_inflate_free(obj)
         lib.svdss_device_free(device, d_out)
     return out[:total]
+
+
+def gpu_deflate(data, block_bytes=0xff00, device=0, return_stats=False):
+    """BGZF members written by the GPU encoder (svdss_bgzf_deflate, csrc/deflate.hip) for `data` cut into blocks of
+    block_bytes; the CRC32 / ISIZE footers are filled in here, as the binary's writer does (csrc/bam_writer.h).
+    Returns the concatenated members (bytes) -- a valid BGZF stream without the EOF marker block."""
+    import ctypes as C
+    import zlib
+    import numpy as np
+    from ._lib import check, lib
+    raw = np.frombuffer(bytes(data), dtype=np.uint8)
+    n = len(raw)
+    if n == 0:
+        return (b"", {}) if return_stats else b""
+    nb = (n + block_bytes - 1) // block_bytes
+    stride = 0x10000 + 64
+    out = np.zeros(nb * stride, dtype=np.uint8)
+    lens = np.zeros(nb, dtype=np.int32)
+    obj = C.c_void_p()
+    try:
+        check(lib.svdss_bgzf_deflate(C.byref(obj), device, raw.ctypes.data, n, block_bytes, out.ctypes.data, stride,
+                                     lens.ctypes.data), "svdss_bgzf_deflate")
+        ms = lib.svdss_deflate_kernel_ms(obj)
+    finally:
+        lib.svdss_deflate_free(obj)
+    parts = []
+    for i in range(nb):
+        blk = raw[i * block_bytes:(i + 1) * block_bytes]
+        m = bytearray(out[i * stride:i * stride + int(lens[i])].tobytes())
+        m[-8:-4] = struct.pack("<I", zlib.crc32(blk.tobytes()) & 0xffffffff)
+        m[-4:] = struct.pack("<I", len(blk))
+        parts.append(bytes(m))
+    res = b"".join(parts)
+    return (res, {"kernel_ms": ms, "members": nb}) if return_stats else res

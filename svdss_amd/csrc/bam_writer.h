@@ -21,11 +21,28 @@
 // output bytes do not depend on the number of threads.
 class BgzfWriter {
  public:
-  explicit BgzfWriter(FILE* f, int threads = 1) : f_(f), threads_(threads < 1 ? 1 : threads) { buf_.reserve(BLOCK * kBatch); }
+  explicit BgzfWriter(FILE* f, int threads = 1) : f_(f), threads_(threads < 1 ? 1 : threads) { buf_.reserve(BLOCK * batch_); }
+  ~BgzfWriter() { if (gpu_.obj && gpu_.free_) gpu_.free_(gpu_.obj); }
+  BgzfWriter(const BgzfWriter&) = delete;
+  BgzfWriter& operator=(const BgzfWriter&) = delete;
+  // Blocks deflated on the GPU (csrc/deflate.hip through gpu_deflate_hook.h; the writer itself does not know HIP): a
+  // batch of blocks goes up, comes back as BGZF members without their footers, and the workers add CRC32 / ISIZE.
+  struct GpuDeflateApi {
+    int (*deflate)(void** obj, int device, const uint8_t* in, int64_t in_bytes, int32_t block_bytes, uint8_t* out,
+                   int64_t out_stride, int32_t* out_len) = nullptr;
+    void (*free_)(void* obj) = nullptr;
+    void* obj = nullptr;
+    int device = 0;
+  };
+  void enable_gpu_deflate(const GpuDeflateApi& api) {
+    gpu_ = api;
+    batch_ = 1024;            // (a launch wants a few blocks per CU)
+    buf_.reserve(BLOCK * batch_);
+  }
   void write(const void* p, size_t n) {
     const uint8_t* s = (const uint8_t*)p;
     buf_.insert(buf_.end(), s, s + n);
-    if (buf_.size() >= BLOCK * kBatch) flush_full_blocks();
+    if (buf_.size() >= BLOCK * batch_) flush_full_blocks();
   }
   bool finish() {   // flush + the 28-byte EOF marker block
     flush_full_blocks();
@@ -36,8 +53,10 @@ class BgzfWriter {
 
  private:
   static constexpr size_t BLOCK = 0xff00;
-  static constexpr size_t kBatch = 256;
   static constexpr size_t OUT = 0x10000 + 64;
+  size_t batch_ = 256;
+  GpuDeflateApi gpu_;
+  bool gpu_warned_ = false;
 
   // libdeflate's compressor through dlopen (no header needed): level 6 at two to three times zlib's speed.  The bytes
   // differ from zlib's (both are valid deflate streams); whichever is used, the output does not depend on the threads.
@@ -98,10 +117,43 @@ class BgzfWriter {
     return clen + 26;
   }
 
+  // the batch through the GPU encoder; false: not done (no GPU path, or it failed: the host compresses the batch)
+  bool emit_gpu(const uint8_t* data, size_t bytes, size_t nblocks, std::vector<uint8_t>& out, std::vector<size_t>& len) {
+    if (!gpu_.deflate || !data || bytes == 0) return false;
+    std::vector<int32_t> l32(nblocks);
+    const int rc = gpu_.deflate(&gpu_.obj, gpu_.device, data, (int64_t)bytes, (int32_t)BLOCK, out.data(), (int64_t)OUT, l32.data());
+    if (rc != 0) {
+      if (!gpu_warned_) fprintf(stderr, "[bam_writer] GPU deflate call failed (code %d): the host deflates\n", rc);
+      gpu_warned_ = true;
+      return false;
+    }
+    // the footers: CRC32 of the block's bytes and their number (RFC 1952), by the workers
+    const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)threads_, nblocks));
+    auto work = [&](size_t t) {
+      for (size_t i = t; i < nblocks; i += nt) {
+        const size_t off = i * BLOCK, n = std::min(BLOCK, bytes - off);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)n), isize = (uint32_t)n;
+        len[i] = (size_t)l32[i];
+        memcpy(out.data() + i * OUT + len[i] - 8, &crc, 4);
+        memcpy(out.data() + i * OUT + len[i] - 4, &isize, 4);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (std::thread& th : pool) th.join();
+    return true;
+  }
+
   // compresses `nblocks` consecutive blocks of `data` (the last one may be short) and writes them in order
   void emit(const uint8_t* data, size_t bytes, size_t nblocks) {
     std::vector<uint8_t> out(nblocks * OUT);
     std::vector<size_t> len(nblocks);
+    if (emit_gpu(data, bytes, nblocks, out, len)) {
+      for (size_t i = 0; i < nblocks; ++i)
+        if (fwrite(out.data() + i * OUT, 1, len[i], f_) != len[i]) ok_ = false;
+      return;
+    }
     const size_t nt = std::min<size_t>((size_t)threads_, nblocks);
     while (deflaters_.size() < std::max<size_t>(nt, 1)) deflaters_.emplace_back(new Deflater());
     auto work = [&](size_t t, size_t nt) {

@@ -447,7 +447,13 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) qx[c] = q[imin(jb + c, L - 1)];
-            const int32_t s1 = wave_scan_max_self(p1[C - 1]), s2 = wave_scan_max_self(p2[C - 1]);
+            // the row maximum rides along with the two F scans: F(j) = max_{k<j} H'(k) - o - (j - k) e < max H', so the
+            // maximum of H over the row is the maximum of H' and H(j) attains it exactly where H'(j) does -- known three
+            // scans earlier than from the finished H (a third DPP chain in the shadow of the other two)
+            int32_t lmax = hp[0];
+#pragma unroll
+            for (int c = 1; c < C; ++c) lmax = imax(lmax, hp[c]);
+            const int32_t s1 = wave_scan_max_self(p1[C - 1]), s2 = wave_scan_max_self(p2[C - 1]), s3 = wave_scan_max_self(lmax);
             const int32_t X1 = wave_shr1(s1, PNEG), X2 = wave_shr1(s2, PNEG);
             const int32_t hp_prev = wave_shr1(hp[C - 1], PNEG);
             int32_t h[C];
@@ -477,14 +483,11 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             for (int c = 0; c < C; ++c) { pH[c] = valid[c] ? h[c] : PNEG; pE1[c] = valid[c] ? e1[c] : PNEG; pE2[c] = valid[c] ? e2[c] : PNEG; }
             // leftmost / rightmost column of the row maximum (the columns past the end hold -inf: they can only tie
             // with a row of unreachable cells, which the test below sends to beg / end anyway)
-            int32_t lmax = pH[0];
-#pragma unroll
-            for (int c = 1; c < C; ++c) lmax = imax(lmax, pH[c]);
-            const int32_t wmx = __builtin_amdgcn_readlane(wave_scan_max_self(lmax), 63);
+            const int32_t wmx = __builtin_amdgcn_readlane(s3, 63);
             int l = 1 << 20, rr = -1;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-              const unsigned long long em = __ballot(pH[c] == wmx);
+              const unsigned long long em = __ballot(hp[c] == wmx);
               if (em) { l = imin(l, C * (int)__builtin_ctzll(em) + c); rr = imax(rr, C * (63 - (int)__builtin_clzll(em)) + c); }
             }
             l += beg; rr += beg;
@@ -636,7 +639,8 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
           const int32_t e2v = imax(a2, b2);
           const uint32_t dE2v = a2 == e2v ? 0u : 8u;
           const int32_t hpv = valid ? imax(m0, imax(e1v, e2v)) : PNEG;
-          const int32_t s1 = wave_scan_max(hpv + j * P_E1, PNEG), s2 = wave_scan_max(hpv + j * P_E2, PNEG);
+          // (the third scan: the row maximum is the maximum of H', attained where H' attains it -- see the chain rows)
+          const int32_t s1 = wave_scan_max(hpv + j * P_E1, PNEG), s2 = wave_scan_max(hpv + j * P_E2, PNEG), s3 = wave_scan_max(hpv, PNEG);
           const int32_t f1 = wave_shr1(s1, PNEG) - P_O1 - j * P_E1, f2 = wave_shr1(s2, PNEG) - P_O2 - j * P_E2;
           const int32_t h = imax(hpv, imax(f1, f2));
           const int32_t hp_left = wave_shr1(hpv, PNEG);
@@ -649,8 +653,8 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             rH[sb + lane] = h; rE1[sb + lane] = e1v; rE2[sb + lane] = e2v;
             if (j == L) hl[r] = h;
           }
-          const int32_t wmx = __builtin_amdgcn_readlane(wave_scan_max(valid ? h : -0x7fffffff - 1, -0x7fffffff - 1), 63);
-          const unsigned long long em = __ballot(valid && h == wmx);
+          const int32_t wmx = __builtin_amdgcn_readlane(s3, 63);
+          const unsigned long long em = __ballot(valid && hpv == wmx);
           int l = beg + (int)__builtin_ctzll(em), rr = beg + 63 - (int)__builtin_clzll(em);
           if (wmx <= PNEG / 2) { l = beg; rr = end; }
           last_r = r; last_mpl = UNI(l); last_mpr = UNI(rr); last_beg = this_beg; last_end = this_end;

@@ -22,6 +22,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
+#include "gpu_deflate_hook.h"
 #include "gpu_inflate_hook.h"
 #include "bam_writer.h"
 #include "call_host.h"
@@ -182,6 +183,7 @@ int main_smooth(const CallOptions& o) {
   if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
   const int T = std::max(1, o.threads);
   BgzfWriter w(stdout, T);
+  svdss_enable_gpu_deflate(w);   // (csrc/deflate.hip; SVDSS_GPU_DEFLATE=0: libdeflate / zlib on the host)
   bam_write_header(w, bam.header_text(), bam.ref_names(), bam.ref_lens());
   // smooth_read (smoother.cpp:84-232) of one record into its serialised BAM bytes
   auto smooth_one = [&](const BamRecord& r, ByteSink& sink) {

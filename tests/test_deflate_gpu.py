@@ -1,0 +1,143 @@
+"""BGZF blocks deflated on the GPU (csrc/deflate.hip, svdss_bgzf_deflate; SURVEY 8(f)3 "later GPU deflate": the
+writing half of `SVDSS smooth`'s BAM stream, /root/reference/smoother.cpp:441-494).  The encoder's output is pinned to
+the standard the way the inflater is: every member must inflate, with zlib (the library htslib inflates with), to exactly
+the bytes that went in -- block types, code lengths folded back to 15 bits, stored quarters, sizes 1 .. 0xff00, many
+blocks with a short tail --, Python's gzip must read the whole stream as BGZF, the footers must hold, and the GPU
+inflater (csrc/inflate.hip) must read what the GPU encoder wrote.  Through the binary: `SVDSS smooth` writes the same
+records whether the GPU or the host's deflate packed them."""
+import gzip
+import io
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from svdss_amd.bgzf import bgzf_blocks, gpu_deflate, gpu_inflate
+from tests.common import ROOT
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "svdss_amd", "SVDSS")
+
+
+def members(stream):
+    """[(header dict, raw deflate bytes, crc, isize)] of a BGZF stream, by the SAM specification's layout"""
+    out, pos = [], 0
+    while pos < len(stream):
+        assert stream[pos:pos + 4] == b"\x1f\x8b\x08\x04"
+        xlen, = struct.unpack_from("<H", stream, pos + 10)
+        assert xlen == 6 and stream[pos + 12:pos + 16] == b"BC\x02\x00"
+        bsize, = struct.unpack_from("<H", stream, pos + 16)
+        raw = stream[pos + 18:pos + bsize + 1 - 8]
+        crc, isize = struct.unpack_from("<II", stream, pos + bsize + 1 - 8)
+        out.append((raw, crc, isize))
+        pos += bsize + 1
+    assert pos == len(stream)
+    return out
+
+
+def check_roundtrip(data, block_bytes=0xff00):
+    data = bytes(data)
+    stream = gpu_deflate(data, block_bytes)
+    ms = members(stream)
+    assert len(ms) == (len(data) + block_bytes - 1) // block_bytes
+    back = []
+    for i, (raw, crc, isize) in enumerate(ms):
+        d = zlib.decompressobj(-15)
+        got = d.decompress(raw) + d.flush()
+        assert d.eof and d.unused_data == b""               # one complete stream, nothing behind it
+        want = data[i * block_bytes:(i + 1) * block_bytes]
+        assert got == want, (i, len(got), len(want))
+        assert isize == len(want) and crc == zlib.crc32(want) & 0xffffffff
+        assert 18 + len(raw) + 8 <= 65536                    # a BGZF member
+        back.append(got)
+    assert gzip.GzipFile(fileobj=io.BytesIO(stream)).read() == data   # concatenated gzip members
+    return stream, ms
+
+
+def test_every_kind_of_block_inflates_with_zlib():
+    rng = np.random.default_rng(7)
+    fib = [1, 1]
+    while len(fib) < 32:
+        fib.append(fib[-1] + fib[-2])
+    cases = {
+        "one byte": b"x",
+        "two bytes": b"ab",
+        "all the same": bytes([9]) * 0xff00,
+        "random (stored)": bytes(rng.integers(0, 256, size=0xff00, dtype=np.uint8)),
+        "packed bases": bytes(rng.choice([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88],
+                                         size=50000).astype(np.uint8)),
+        "qualities": bytes(rng.integers(20, 60, size=0xff00, dtype=np.uint8)),
+        "binned qualities": bytes(np.array([3, 10, 17, 22, 27, 33, 40], np.uint8)[rng.integers(0, 7, size=40000)]),
+        "skewed (geometric)": bytes(np.minimum(255, rng.geometric(0.03, size=0xff00)).astype(np.uint8)),
+        "code lengths past 15 bits": b"".join(bytes([i]) * min(c, 9000) for i, c in enumerate(fib))[:0xff00],
+        "text": (b"@SQ\tSN:chr1\tLN:248956422\n" * 4000)[:0xff00],
+        "quarter boundaries": bytes(range(256)) * 3 + b"z",
+    }
+    for name, data in cases.items():
+        stream, ms = check_roundtrip(data)
+        if name in ("packed bases", "binned qualities", "all the same", "text"):
+            assert len(stream) < 0.62 * len(data), (name, len(stream), len(data))
+        if name == "random (stored)":
+            assert len(data) < len(stream) <= len(data) + 26 + 6 * 4
+    # sizes around the lane / quarter arithmetic
+    for n in (3, 63, 64, 65, 255, 256, 257, 1019, 1020, 1021, 4 * 16320 - 1, 0xff00 - 1):
+        check_roundtrip(bytes(rng.integers(60, 70, size=n, dtype=np.uint8)))
+
+
+def test_many_blocks_short_tail_and_the_gpu_inflater_reads_them():
+    rng = np.random.default_rng(8)
+    # BAM-like: records of packed bases + qualities + names, 300 blocks and a tail of 777 bytes
+    rec = []
+    while sum(len(r) for r in rec) < 300 * 0xff00 + 777:
+        l = int(rng.integers(9000, 16000))
+        rec.append(b"read%07d\0" % len(rec) + bytes(rng.choice([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28], size=l // 2).astype(np.uint8))
+                   + bytes(rng.integers(25, 50, size=l, dtype=np.uint8)))
+    data = b"".join(rec)[:300 * 0xff00 + 777]
+    stream, ms = check_roundtrip(data)
+    assert len(ms) == 301 and ms[-1][2] == 777
+    # within a few percent of zlib level 1 on this kind of data (no matches to find: Huffman is what compresses it)
+    z1 = sum(len(zlib.compress(data[i:i + 0xff00], 1)) for i in range(0, len(data), 0xff00))
+    assert len(stream) < 1.08 * z1, (len(stream), z1)
+    blocks = bgzf_blocks(stream)
+    got = gpu_inflate(stream, [(c, l, i) for c, l, i, _ in blocks])
+    assert bytes(got) == data
+    # other block sizes (the writer always uses 0xff00)
+    check_roundtrip(data[:200000], block_bytes=4096)
+    check_roundtrip(data[:70000], block_bytes=333)
+
+
+def test_smooth_writes_the_same_records_with_either_deflate(tmp_path):
+    """`SVDSS smooth` packs its output on the GPU by default; SVDSS_GPU_DEFLATE=0 keeps the host's deflate.  Different
+    compressed bytes, the same BAM."""
+    from svdss_amd import synth
+    from tests import bam_writer
+    rng = np.random.default_rng(3)
+    ref = synth.make_reference([400000], seed=5)
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1\n" + synth.to_ascii(ref[0]) + "\n")
+    recs = []
+    for k in range(120):
+        st = int(rng.integers(0, 380000))
+        l = int(rng.integers(5000, 15000))
+        seq = ref[0][st:st + l].copy()
+        e = rng.random(l) < 0.004
+        seq[e] = (seq[e] % 4) + 1
+        recs.append((st, bam_writer.record(f"r{k}", 0, 0, st, 60, [("M", l)], synth.to_ascii(seq),
+                                           qual=bytes(rng.integers(20, 50, size=l, dtype=np.uint8).tolist()))))
+    recs.sort(key=lambda r: r[0])
+    bam = tmp_path / "in.bam"
+    bam.write_bytes(bam_writer.bam([("chr1", 400000)], [r for _, r in recs]))
+    outs = {}
+    for tag, env in (("gpu", {}), ("host", {"SVDSS_GPU_DEFLATE": "0"})):
+        r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam), "--threads", "4"], capture_output=True,
+                           timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()
+        outs[tag] = r.stdout
+    assert outs["gpu"] != outs["host"]
+    a, b = (gzip.GzipFile(fileobj=io.BytesIO(outs[t])).read() for t in ("gpu", "host"))
+    assert a == b and len(a) > 1_000_000
+    assert outs["gpu"][-28:] == outs["host"][-28:]          # the EOF marker block
+    members(outs["gpu"])                                      # well-formed BGZF throughout
