@@ -12,9 +12,8 @@
 //   LF     one backward rank step on the BWT block layout (fmd_layout.h), as in v1;
 //   TEXT   once a backward phase has narrowed to a single occurrence (size 1),
 //          "prepend c succeeds" <=> "the text byte before the occurrence is c",
-//          so up to 128 read symbols per iteration -- the lane's window of the read, resident in LDS -- are
-//          compared directly with the reference text (located through the full suffix array): no BWT walk,
-//          and the read's bytes are fetched from HBM once, a whole 128-byte line at a time (FILL).
+//          so up to 64 read symbols per iteration are compared directly with the
+//          reference text (located through the full suffix array) -- no BWT walk.
 //   SET    the same with 2-4 occurrences left (reads in low-copy repeats, where LF would spend one
 //          iteration per symbol until the copies diverge): their text positions are kept, 16 read symbols
 //          per iteration are compared with every surviving copy; the interval size is the number of
@@ -37,12 +36,9 @@ enum { SV_OP_DONE = 0, SV_OP_LF = 1, SV_OP_TABLE = 2, SV_OP_SA = 3, SV_OP_TEXT =
 #define SV_M_CHAIN 8   // streaming assembler has an open chain
 #define SV_NO_WINDOW (-0x40000000)
 
-// Per-lane window of SV_WIN = 128 read symbols staged in LDS (device) or a local array (emulator), 4 bits per symbol:
-// dword row r lives at base[r * stride]; the symbol at absolute read-buffer position a is nibble (a & 7) of row
-// ((a & 127) >> 3).  128 symbols = one 128-byte line of the read buffer: a window that starts on a line boundary costs
-// one line to fill, and everything that looks at read symbols -- K-mers, the symbols next to them, the unique-match text
-// compare -- reads them from here (round 3: the text compare used to fetch its 64 read bytes from HBM again).
-#define SV_WIN 128
+// Per-lane window of 64 read symbols staged in LDS (device) or a local array
+// (emulator): dword row r lives at base[r * stride]; the byte of absolute read
+// buffer position a is byte (a & 3) of row ((a & 63) >> 2).
 struct SvRing {
   uint32_t* base;
   int stride;
@@ -63,7 +59,7 @@ struct SvLane {
   int32_t len;
   int32_t mode;
   int32_t c;         // symbol of the pending LF step / start of the pending table lookup
-  int32_t wrel;      // ring holds read positions [wrel, wrel+SV_WIN)
+  int32_t wrel;      // ring holds read positions [wrel, wrel+64)
   int32_t n_sfs;
   int32_t n_ext;
   int32_t chain_lo, chain_end;
@@ -98,70 +94,40 @@ struct SvOp {
 SVDSS_HD uint32_t sv_ring_row(const SvRing& g, int r) { return g.base[(r & 15) * g.stride]; }
 
 SVDSS_HD int sv_ring_sym(const SvRing& g, int64_t a) {
-  return (int)((sv_ring_row(g, (int)((a & 127) >> 3)) >> ((a & 7) * 4)) & 0xfu);
+  return (int)((sv_ring_row(g, (int)((a & 63) >> 2)) >> ((a & 3) * 8)) & 0xffu);
 }
 
-// 8 nt6 bytes (two dwords, the lower addresses in lo) -> 8 nibbles
-SVDSS_HD uint32_t sv_pack8(uint32_t lo, uint32_t hi) {
-  uint32_t a = (lo | (lo >> 4)) & 0x00ff00ffu, b = (hi | (hi >> 4)) & 0x00ff00ffu;
-  a = (a | (a >> 8)) & 0xffffu;
-  b = (b | (b >> 8)) & 0xffffu;
-  return a | (b << 16);
-}
-
-// the 128 bytes of the read buffer that start at 16-byte chunk first_chunk
-SVDSS_HD void sv_ring_fill(const SvRing& g, int64_t first_chunk, const svdss_u4 b[8]) {
+SVDSS_HD void sv_ring_fill(const SvRing& g, int64_t first_chunk, const svdss_u4 b[4]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int r = (int)(((first_chunk + j) & 7) * 2);
-    g.base[(r + 0) * g.stride] = sv_pack8(b[j].x, b[j].y);
-    g.base[(r + 1) * g.stride] = sv_pack8(b[j].z, b[j].w);
+  for (int j = 0; j < 4; ++j) {
+    const int r = (int)(((first_chunk + j) & 3) * 4);
+    g.base[(r + 0) * g.stride] = b[j].x;
+    g.base[(r + 1) * g.stride] = b[j].y;
+    g.base[(r + 2) * g.stride] = b[j].z;
+    g.base[(r + 3) * g.stride] = b[j].w;
   }
-}
-
-// the 16 symbols at absolute positions [a0, a0 + 16), 4 bits each, the first one in the low bits
-SVDSS_HD uint64_t sv_ring_16(const SvRing& g, int64_t a0) {
-  const int r0 = (int)((a0 & 127) >> 3);
-  const int sh = (int)(a0 & 7) * 4;
-  const uint64_t w01 = (uint64_t)sv_ring_row(g, r0) | ((uint64_t)sv_ring_row(g, r0 + 1) << 32);
-  const uint64_t w2 = sv_ring_row(g, r0 + 2);
-  return sh ? (w01 >> sh) | (w2 << (64 - sh)) : w01;
 }
 
 // 2-bit key (text order, first symbol in the low bits) of the K symbols at
 // absolute positions [a0, a0+K); returns false if any of them is not A/C/G/T.
 SVDSS_HD bool sv_ring_kmer(const SvRing& g, int64_t a0, int K, uint32_t& key) {
-  const uint64_t w = sv_ring_16(g, a0);
-  const uint64_t t = w - 0x1111111111111111ull;       // A,C,G,T -> 0..3; N -> 4; '$' -> 0xf (and a borrow: flagged)
-  const uint64_t m = K >= 16 ? ~0ull : ((1ull << (4 * K)) - 1ull);
-  const uint64_t bad = t & 0xccccccccccccccccull & m;
-  uint64_t x = t & 0x3333333333333333ull;
-  x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
-  x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
-  x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
-  x = (x | (x >> 16)) & 0xffffffffull;
-  const uint32_t k = (uint32_t)x;
+  const int r0 = (int)((a0 & 63) >> 2);
+  const int sh = (int)(a0 & 3) * 8;
+  uint32_t row[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) row[i] = sv_ring_row(g, r0 + i);
+  uint32_t k = 0, bad = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t w = (uint32_t)(((((uint64_t)row[i + 1]) << 32) | row[i]) >> sh);
+    const uint32_t t = w - 0x01010101u;             // A,C,G,T -> 0..3; '$' -> 0xff; N -> 4
+    const int nb = K - 4 * i;                       // bytes of this dword that belong to the K-mer
+    const uint32_t m = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+    bad |= t & 0xfcfcfcfcu & m;
+    k |= (((t & 0x03030303u) * 0x01041040u) >> 24) << (8 * i);
+  }
   key = K >= 16 ? k : (k & ((1u << (2 * K)) - 1u));
   return bad == 0;
-}
-
-// Where a FILL puts the window so that it holds the read-buffer positions [a_lo, a_hi] (a_hi - a_lo < 64): on a line
-// boundary (one line to fetch) when the line of a_lo holds them all, else on the 64-byte boundary below a_lo (two
-// lines).  Returned as a 16-byte chunk index.
-SVDSS_HD int64_t sv_fill_at(int64_t a_lo, int64_t a_hi) {
-  if (a_lo < 0) a_lo = 0;
-  const int64_t line = a_lo >> 7;
-  if (a_hi < (line << 7) + SV_WIN) return line << 3;
-  return (a_lo >> 6) << 2;
-}
-
-// ... so that it holds position a_top and as many positions below it as a window can (the lane walks down): the line of
-// a_top if that leaves at least 32 of them, else the window that ends in the middle of that line (two lines, 65+)
-SVDSS_HD int64_t sv_fill_below(int64_t a_top) {
-  if (a_top < 0) a_top = 0;
-  const int64_t line = a_top >> 7;
-  if ((a_top & 127) >= 31 || line == 0) return line << 3;
-  return (line << 3) - 4;
 }
 
 // key of revcomp(W) from the key of W (K symbols)
@@ -196,7 +162,7 @@ SVDSS_HD void sv_lane_init(SvLane<P>& s, int len, int start_pos = -1, int stop_l
 }
 
 template <class P>
-SVDSS_HD bool sv_in_window(const SvLane<P>& s, int p) { return p >= s.wrel && p < s.wrel + SV_WIN; }
+SVDSS_HD bool sv_in_window(const SvLane<P>& s, int p) { return p >= s.wrel && p < s.wrel + 64; }
 
 // Streaming Assembler::assemble (/root/reference/assembler.cpp:34-56), see sfs_core.h.
 template <class P, class Emit>
@@ -243,13 +209,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
     SV_COUNT_PASS();
     if (s.mode & SV_M_SET) { o.op = SV_OP_SET; return o; }
     if (s.mode & SV_M_TEXT) {
-      // the read symbols below pos come from the window; none there: fetch the line(s) below pos first
-      if (s.pos - 1 < s.wrel || s.pos - 1 >= s.wrel + SV_WIN) {
-        o.op = SV_OP_FILL;
-        o.a = sv_fill_below(off + s.pos - 1);
-        return o;
-      }
-      o.op = SV_OP_TEXT;
+      o.op = (off + s.pos >= 64) ? SV_OP_TEXT : SV_OP_TEXT_SLOW;
       return o;
     }
     if (!(s.mode & SV_M_START)) {
@@ -278,7 +238,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
           const int np = s.pos - 1;
           if (!sv_in_window(s, np)) {
             o.op = SV_OP_FILL;
-            o.a = sv_fill_below(off + np);
+            o.a = ((off + np - 40) >> 4);
             return o;
           }
           s.pos = np;
@@ -294,7 +254,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
           const int np = s.pos + 1;
           if (np < s.len && !sv_in_window(s, np)) {
             o.op = SV_OP_FILL;
-            o.a = sv_fill_at(off + np - 8, off + np + 24);
+            o.a = ((off + np - 24) >> 4);
             return o;
           }
           s.pos = np;
@@ -326,11 +286,9 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
     const int st = s.pos;
     const int first = dir ? st : st - K + 1;  // lowest read position of the K-mer
     if (K > 0 && first >= 0 && first + K <= s.len) {
-      if (first < s.wrel || first + K > s.wrel + SV_WIN) {    // the K symbols must be resident
-        // (and, where they fit, the SVDSS_TAB_EXT symbols the entry's extension symbols are compared with)
+      if (first < s.wrel || first + K > s.wrel + 64) {    // the K symbols must be resident
         o.op = SV_OP_FILL;
-        o.a = dir ? sv_fill_at(off + first, off + first + K - 1 + SVDSS_TAB_EXT)
-                  : sv_fill_at(off + first - SVDSS_TAB_EXT - 2, off + first + K - 1);
+        o.a = ((off + first - 20) >> 4);
         return o;
       }
       uint32_t key;
@@ -344,7 +302,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
     // from the single symbol like the reference does (rb3_fmd_set_intv, :12 / :30)
     if (!sv_in_window(s, st)) {
       o.op = SV_OP_FILL;
-      o.a = sv_fill_at(off + st - 8, off + st + 8);
+      o.a = ((off + st - 24) >> 4);
       return o;
     }
     int c = sv_ring_sym(g, off + st);
@@ -443,7 +401,7 @@ SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_l
     if (pk - steps_max < s.wrel) steps_max = pk - s.wrel;          // (positions below wrel are not resident)
   } else {
     steps_max = s.len - 1 - pk < SVDSS_TAB_EXT ? s.len - 1 - pk : SVDSS_TAB_EXT;
-    if (pk + steps_max >= s.wrel + SV_WIN) steps_max = s.wrel + SV_WIN - 1 - pk;
+    if (pk + steps_max >= s.wrel + 64) steps_max = s.wrel + 63 - pk;
   }
   if (steps_max < 0) steps_max = 0;
   // All SVDSS_TAB_EXT steps at once: the read's next symbols in the order they are consumed, 3 bits each like the
@@ -452,15 +410,15 @@ SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_l
   uint32_t rs = 0;
   {
     const int64_t a0 = off + (dir ? pk + 1 : pk - SVDSS_TAB_EXT);   // lowest buffer position of the six
-    const int r0 = (int)((a0 & 127) >> 3);
-    const int sh = (int)(a0 & 7) * 4;
-    const uint64_t w01 = (uint64_t)sv_ring_row(g, r0) | ((uint64_t)sv_ring_row(g, r0 + 1) << 32);
-    uint32_t w = (uint32_t)(w01 >> sh) & 0xffffffu;                 // six nibbles, the lowest position first
-    if (!dir)                                                       // nearest symbol first
-      w = ((w & 0xf) << 20) | ((w & 0xf0) << 12) | ((w & 0xf00) << 4) | ((w >> 4) & 0xf00) | ((w >> 12) & 0xf0) | ((w >> 20) & 0xf);
+    const int r0 = (int)((a0 & 63) >> 2);
+    const int sh = (int)(a0 & 3) * 8;
+    const uint32_t w0 = sv_ring_row(g, r0), w1 = sv_ring_row(g, r0 + 1), w2 = sv_ring_row(g, r0 + 2);
+    uint64_t w = (uint64_t)(uint32_t)(((((uint64_t)w1) << 32) | w0) >> sh) |
+                 ((uint64_t)(uint32_t)(((((uint64_t)w2) << 32) | w1) >> sh) << 32);
+    if (!dir) w = __builtin_bswap64(w << 16);                       // nearest symbol first
 #pragma unroll
     for (int e = 0; e < SVDSS_TAB_EXT; ++e)
-      rs |= ((w >> (4 * e)) & 7u) << (3 * e);                       // (positions past steps_max: not looked at)
+      rs |= (uint32_t)((w >> (8 * e)) & 7u) << (3 * e);             // (positions past steps_max: not looked at)
     if (dir) {
       // complement of all six at once (svdss_comp: 1 <-> 4, 2 <-> 3, 0 and 5 stay): bit 0 flips for 1..4, bit 2 for 1 and 4
       const uint32_t b0 = rs & 0x9249u, b1 = (rs >> 1) & 0x9249u, b2 = (rs >> 2) & 0x9249u;
@@ -626,56 +584,21 @@ SVDSS_HD void sv_apply_peek(SvLane<P>& s, const int32_t q[SV_PEEK_RECS], const b
   s.mode = (s.mode & ~(SV_M_DIR | SV_LFC_MASK)) | SV_M_START;
 }
 
-// TEXT: ta[k] = the 16 text bytes that face read positions [wrel + 16 k, wrel + 16 k + 16) -- loaded for the chunks
-// sv_text_chunks() names, the others are not looked at --, the read's symbols come from the window.  The lane consumes
-// symbols pos-1, pos-2, ... while they agree (one rb3_fmd_extend each, ping_pong.cpp:15-22 with a size-1 interval),
-// down to the bottom of the window or the read start.
+// TEXT: ta[] = text bytes, rb[] = read bytes, both for read positions
+// [pos-64, pos) (byte 0 of ta[0]/rb[0] <-> position pos-64).  The lane consumes
+// symbols pos-1, pos-2, ... while they agree (one rb3_fmd_extend each,
+// ping_pong.cpp:15-22 with a size-1 interval), stops at the read start.
 template <class P>
-SVDSS_HD int sv_text_lo(const SvLane<P>& s) {
-  // lowest window index that is compared: not below the read start (the bytes there belong to the read before), and
-  // not more than 16 symbols in front of the text (the '$' padding there ends any match; nothing is loaded below it)
-  int i_lo = s.wrel < 0 ? -s.wrel : 0;
-  const int64_t t16 = -(s.tdelta + (int64_t)s.wrel) - 16;
-  if (t16 > (int64_t)i_lo) i_lo = t16 > SV_WIN ? SV_WIN : (int)t16;
-  return i_lo;
-}
-
-template <class P>
-SVDSS_HD void sv_text_chunks(const SvLane<P>& s, int& k_lo, int& k_hi) {
-  const int i_hi = s.pos - s.wrel;                 // window indices [i_lo, i_hi) are compared
-  const int i_lo = sv_text_lo(s);
-  k_lo = i_lo >> 4;
-  k_hi = i_hi > i_lo ? (i_hi - 1) >> 4 : -1;
-}
-
-template <class P>
-SVDSS_HD void sv_apply_text(SvLane<P>& s, const svdss_u4 ta[8], const SvRing& g, int64_t off) {
-  const int i_hi = s.pos - s.wrel;                 // 1 .. SV_WIN
-  const int i_lo = sv_text_lo(s);
-  if (i_lo >= i_hi) {                              // the occurrence starts the text: nothing in front of it to agree with
-    s.pos -= 1;
-    s.n_ext += 1;
-    s.mode &= ~SV_M_TEXT;
-    s.lo = 0;
-    s.hi = 0;
-    return;
-  }
-  const int r0 = (int)(((off + s.wrel) & 127) >> 3);   // window index 0 sits in this row (the window starts on a 16-byte boundary)
+SVDSS_HD void sv_apply_text(SvLane<P>& s, const svdss_u4 ta[4], const svdss_u4 rb[4]) {
   uint32_t x[16];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    x[2 * k + 0] = sv_pack8(ta[k].x, ta[k].y) ^ sv_ring_row(g, r0 + 2 * k);
-    x[2 * k + 1] = sv_pack8(ta[k].z, ta[k].w) ^ sv_ring_row(g, r0 + 2 * k + 1);
+  for (int j = 0; j < 4; ++j) {
+    x[4 * j + 0] = ta[j].x ^ rb[j].x;
+    x[4 * j + 1] = ta[j].y ^ rb[j].y;
+    x[4 * j + 2] = ta[j].z ^ rb[j].z;
+    x[4 * j + 3] = ta[j].w ^ rb[j].w;
   }
-  // only indices [i_lo, i_hi) count
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int above = i_hi - 8 * r, below = i_lo - 8 * r;
-    const uint32_t mh = above >= 8 ? 0xffffffffu : above <= 0 ? 0u : ((1u << (4 * above)) - 1u);
-    const uint32_t ml = below <= 0 ? 0xffffffffu : below >= 8 ? 0u : ~((1u << (4 * below)) - 1u);
-    x[r] &= mh & ml;
-  }
-  // highest differing symbol of the 128: binary selection, upper half first
+  // highest differing byte of the 64: binary selection, upper half first
   int idx = 0;
   uint32_t v8[8], v4[4], v2[2], v1;
   {
@@ -701,9 +624,13 @@ SVDSS_HD void sv_apply_text(SvLane<P>& s, const svdss_u4 ta[8], const SvRing& g,
     idx += up ? 1 : 0;
     v1 = up ? v2[1] : v2[0];
   }
-  const int avail = i_hi - i_lo;                 // symbols of the window below pos (down to the read start)
-  if (v1 == 0) {
-    // every one of them agrees
+  // number of matching symbols counted down from pos-1
+  int matched;
+  if (v1 == 0) matched = 64;
+  else matched = 63 - (4 * idx + ((31 - __builtin_clz(v1)) >> 3));
+  const int avail = s.pos < 64 ? s.pos : 64;     // symbols left before the read start
+  if (matched >= avail) {
+    // every remaining symbol of this window agrees
     s.pos -= avail;
     s.n_ext += avail;
     if (s.pos == 0) {                            // ping_pong.cpp:24: prefix matched, size != 0
@@ -712,9 +639,7 @@ SVDSS_HD void sv_apply_text(SvLane<P>& s, const svdss_u4 ta[8], const SvRing& g,
       s.hi = 1;
     }
   } else {
-    // the highest symbol that disagrees: that extend empties the interval (:15 fails next)
-    const int at = 8 * idx + ((31 - __builtin_clz(v1)) >> 2);   // its window index
-    const int matched = i_hi - 1 - at;
+    // symbol pos-1-matched disagrees: that extend empties the interval (:15 fails next)
     s.pos -= matched + 1;
     s.n_ext += matched + 1;
     s.mode &= ~SV_M_TEXT;

@@ -383,97 +383,108 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
       active = false;
       continue;
     }
+    if (o.op == SV_OP_TEXT_SLOW) {   // only the first 64 bytes of the whole batch
+      sv_apply_text_slow(st, p.ix.text, reads, off);
+      continue;
+    }
     if (pf >= 1 && pf < 3) {   // the next item's ticket is here: get its read id, then its offsets, under way
       if (nt < (uint32_t)p.n_items) {
         if (pf == 1) pf_read_id(); else pf_offsets();
       }
       ++pf;
     }
-    // one memory operation per lane: up to 8 x 16 B
-    svdss_u4 M[8];
+    // one memory operation per lane: up to 4 x 16 B from pa and 4 x 16 B from pb
+    const uint8_t* pa = blocks;
+    const uint8_t* pb = blocks;
+    bool wide_a = false, need_b = false;
     int64_t c0 = 0;
-    bool same_block = true;
     if (o.op == SV_OP_LF) {
       const int64_t blo = (int64_t)st.lo >> SVDSS_BLOCK_SHIFT, bhi = (int64_t)st.hi >> SVDSS_BLOCK_SHIFT;
-      const uint8_t* pa = blocks + blo * SVDSS_BLOCK_BYTES;
-      M[0] = sv_load16(pa); M[1] = sv_load16(pa + 16); M[2] = sv_load16(pa + 32); M[3] = sv_load16(pa + 48);
-      same_block = bhi == blo;
-      if (!same_block) {
-        const uint8_t* pb = blocks + bhi * SVDSS_BLOCK_BYTES;
-        M[4] = sv_load16(pb); M[5] = sv_load16(pb + 16); M[6] = sv_load16(pb + 32); M[7] = sv_load16(pb + 48);
-      }
+      pa = blocks + blo * SVDSS_BLOCK_BYTES;
+      pb = blocks + bhi * SVDSS_BLOCK_BYTES;
+      wide_a = true;
+      need_b = bhi != blo;
     } else if (o.op == SV_OP_TABLE) {
-      M[0] = sv_load16((const uint8_t*)(p.ix.table + o.a));
+      pa = (const uint8_t*)(p.ix.table + o.a);
     } else if (o.op == SV_OP_SA) {
-      M[0] = sv_load16((const uint8_t*)p.ix.sa + o.a * (int64_t)sizeof(P));
+      pa = (const uint8_t*)p.ix.sa + o.a * (int64_t)sizeof(P);
     } else if (o.op == SV_OP_TEXT) {
-      // the text bytes that face the window's read positions [wrel, wrel + 128): only the 16-byte pieces the compare
-      // looks at (positions below pos, not below the read start)
-      int k_lo, k_hi;
-      sv_text_chunks(st, k_lo, k_hi);
-      const uint8_t* pa = p.ix.text + st.tdelta + st.wrel;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        M[k].x = M[k].y = M[k].z = M[k].w = 0;
-        if (k >= k_lo && k <= k_hi) M[k] = sv_load16(pa + 16 * k);
-      }
+      pa = p.ix.text + st.tdelta + st.pos - 64;
+      pb = reads + off + st.pos - 64;
+      wide_a = true;
+      need_b = true;
     } else if (o.op == SV_OP_PEEK) {
       // the left neighbour's records sit right below this lane's region, tagged with this launch's epoch as
       // they are produced; the segments of a read are fetched back to back, so the neighbour is normally far ahead
       int32_t i0 = nb_cur;
       if (i0 > (int32_t)cap - SV_PEEK_RECS) i0 = (int32_t)cap - SV_PEEK_RECS;   // stay inside its region
       if (i0 < 0) i0 = 0;
-      const uint8_t* pa = (const uint8_t*)(p.seg_rec + (base - cap + i0));
+      pa = (const uint8_t*)(p.seg_rec + (base - cap + i0));
       c0 = i0;
+    } else if (o.op == SV_OP_SET || o.op == SV_OP_SA_SET) {
+      // (their loads are issued below, next to the others)
+    } else {  // SV_OP_FILL
+      c0 = o.a;
+      if (c0 > p.max_chunk - 3) c0 = p.max_chunk - 3;
+      if (c0 < 0) c0 = 0;
+      pb = reads + 16 * c0;
+      need_b = true;
+    }
+    svdss_u4 A[4], B[4];
+    if (o.op == SV_OP_PEEK) {
       // agent-scope loads: the records were stored (write-through) by lanes that may sit on another XCD
 #pragma unroll
       for (int i = 0; i < SV_PEEK_RECS; ++i) {
         const unsigned long long* rp = (const unsigned long long*)pa + 2 * i;
         const unsigned long long lo = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        M[i].x = (uint32_t)lo; M[i].y = (uint32_t)(lo >> 32); M[i].z = (uint32_t)hi; M[i].w = (uint32_t)(hi >> 32);
+        A[i].x = (uint32_t)lo; A[i].y = (uint32_t)(lo >> 32); A[i].z = (uint32_t)hi; A[i].w = (uint32_t)(hi >> 32);
       }
     } else if (o.op == SV_OP_SET) {
       const int alive = (st.mode >> SV_SET_SHIFT) & ((1 << SV_SET_MAX) - 1);
 #pragma unroll
       for (int i = 0; i < SV_SET_MAX; ++i) {
-        M[i].x = M[i].y = M[i].z = M[i].w = 0;
-        if ((alive >> i) & 1) M[i] = sv_load16(p.ix.text + ts.base[i * ts.stride] + st.pos - SV_SET_WIN);
+        A[i].x = A[i].y = A[i].z = A[i].w = 0;
+        if ((alive >> i) & 1) A[i] = sv_load16(p.ix.text + ts.base[i * ts.stride] + st.pos - SV_SET_WIN);
       }
-      M[4] = sv_load16(reads + off + st.pos - SV_SET_WIN);
+      B[0] = sv_load16(reads + off + st.pos - SV_SET_WIN);
     } else if (o.op == SV_OP_SA_SET) {
       const int n_occ = (int)(st.hi - st.lo);
 #pragma unroll
       for (int i = 0; i < SV_SET_MAX; ++i) {   // (entries past the interval are not used: read the first one again)
         const P v = ((const P*)p.ix.sa)[(int64_t)st.lo + (i < n_occ ? i : 0)];
-        M[i].x = (uint32_t)v;
-        M[i].y = (uint32_t)((uint64_t)v >> 32);
+        A[i].x = (uint32_t)v;
+        A[i].y = (uint32_t)((uint64_t)v >> 32);
       }
-    } else {  // SV_OP_FILL: 128 bytes of the read buffer -- one line when the window starts on a line boundary
-      c0 = o.a;
-      if (c0 > p.max_chunk - 7) c0 = p.max_chunk - 7;
-      if (c0 < 0) c0 = 0;
-      const uint8_t* pb = reads + 16 * c0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) M[k] = sv_load16(pb + 16 * k);
+    } else if (o.op != SV_OP_FILL) A[0] = sv_load16(pa);
+    if (wide_a) {
+      A[1] = sv_load16(pa + 16);
+      A[2] = sv_load16(pa + 32);
+      A[3] = sv_load16(pa + 48);
+    }
+    if (need_b) {
+      B[0] = sv_load16(pb);
+      B[1] = sv_load16(pb + 16);
+      B[2] = sv_load16(pb + 32);
+      B[3] = sv_load16(pb + 48);
     }
     if (o.op == SV_OP_LF) {
-      sv_apply_lf(st, p.ix, M, M + 4, same_block);
+      sv_apply_lf(st, p.ix, A, B, !need_b);
     } else if (o.op == SV_OP_TABLE) {
-      sv_apply_table(st, p.ix, (uint64_t)M[0].x | ((uint64_t)M[0].y << 32),
-                     (uint64_t)M[0].z | ((uint64_t)M[0].w << 32), g, off, p.use_set != 0 && off >= 64);
+      sv_apply_table(st, p.ix, (uint64_t)A[0].x | ((uint64_t)A[0].y << 32),
+                     (uint64_t)A[0].z | ((uint64_t)A[0].w << 32), g, off, p.use_set != 0 && off >= 64);
     } else if (o.op == SV_OP_SA) {
-      const int64_t tp = sizeof(P) == 4 ? (int64_t)M[0].x
-                                        : (int64_t)((uint64_t)M[0].x | ((uint64_t)M[0].y << 32));
+      const int64_t tp = sizeof(P) == 4 ? (int64_t)A[0].x
+                                        : (int64_t)((uint64_t)A[0].x | ((uint64_t)A[0].y << 32));
       sv_apply_sa(st, tp);
     } else if (o.op == SV_OP_TEXT) {
-      sv_apply_text(st, M, g, off);
+      sv_apply_text(st, A, B);
     } else if (o.op == SV_OP_SET) {
-      sv_apply_set(st, ts, M, M[4]);
+      sv_apply_set(st, ts, A, B[0]);
     } else if (o.op == SV_OP_SA_SET) {
       int64_t tp[SV_SET_MAX];
 #pragma unroll
-      for (int i = 0; i < SV_SET_MAX; ++i) tp[i] = (int64_t)((uint64_t)M[i].x | ((uint64_t)M[i].y << 32));
+      for (int i = 0; i < SV_SET_MAX; ++i) tp[i] = (int64_t)((uint64_t)A[i].x | ((uint64_t)A[i].y << 32));
       sv_apply_sa_set(st, ts, tp);
     } else if (o.op == SV_OP_PEEK) {
       int32_t q[SV_PEEK_RECS];
@@ -482,14 +493,14 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
 #pragma unroll
       for (int i = 0; i < SV_PEEK_RECS; ++i) {
         const int k = i + sh;
-        const uint32_t qq = k == 0 ? M[0].x : k == 1 ? M[1].x : k == 2 ? M[2].x : M[3].x;
-        const uint32_t ee = k == 0 ? M[0].w : k == 1 ? M[1].w : k == 2 ? M[2].w : M[3].w;
+        const uint32_t qq = k == 0 ? A[0].x : k == 1 ? A[1].x : k == 2 ? A[2].x : A[3].x;
+        const uint32_t ee = k == 0 ? A[0].w : k == 1 ? A[1].w : k == 2 ? A[2].w : A[3].w;
         q[i] = (int32_t)qq;
         written[i] = k < SV_PEEK_RECS && ee == p.epoch;
       }
       sv_apply_peek(st, q, written, nb_cur, (int32_t)cap);
     } else {
-      sv_ring_fill(g, c0, M);
+      sv_ring_fill(g, c0, B);
       st.wrel = (int32_t)(16 * c0 - off);
     }
   }
@@ -795,7 +806,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
 
   // SVDSS_KERNEL=1 selects the v1 kernel (plain LF walk) for A/B measurements
   const char* kv = getenv("SVDSS_KERNEL");
-  const bool use_v1 = (kv && atoi(kv) == 1) || total_syms < 256;   // (the v2 kernel fills its window 128 bytes at a time)
+  const bool use_v1 = (kv && atoi(kv) == 1) || total_syms < 64;
   int max_blocks = 0;
   if ((rc = launch_grid(ix->device, &max_blocks))) return rc;
   // Small batches cannot fill the GPU with one lane per read (256 CUs x 16 waves x 64 lanes):

@@ -23,7 +23,7 @@ def search(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool):
     """index: svdss_amd.FMDIndex.  Returns (counts, qs, len, n_ext)."""
     n = len(offsets) - 1
     total_syms = int(offsets[-1])
-    padded = np.zeros(((total_syms + 15) // 16) * 16 + 272, dtype=np.uint8)
+    padded = np.zeros(((total_syms + 15) // 16) * 16 + 16, dtype=np.uint8)
     padded[:total_syms] = flat
     cap = total_syms + n + 1
     counts = np.zeros(n, dtype=np.int64)
@@ -59,7 +59,7 @@ def search2(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool, K: int
     """v2 lane code (k-mer table of order K, LF, TEXT).  Returns (counts, qs, len, n_ext, op_counts)."""
     n = len(offsets) - 1
     total_syms = int(offsets[-1])
-    padded = np.zeros(max(((total_syms + 15) // 16) * 16 + 16, 272), dtype=np.uint8)
+    padded = np.zeros(max(((total_syms + 15) // 16) * 16 + 16, 80), dtype=np.uint8)
     padded[:total_syms] = flat
     alloc_syms = len(padded) - 16
     cap = total_syms + n + 1
@@ -75,6 +75,5 @@ def search2(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool, K: int
                          n_ext.ctypes.data, ops.ctypes.data, n_seg, seg_stats.ctypes.data)
     assert t >= 0
     d = dict(zip(OP_NAMES, ops.tolist()))
-    d["text_lines"], d["fill_lines"] = int(ops[10]), int(ops[11])
     d["stitched"], d["fallback"] = seg_stats.tolist()
     return counts, qs[:t].copy(), ln[:t].copy(), n_ext, d

@@ -117,6 +117,7 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
       SvOp o = sv_decide(st, v, g, off, asm_, emit, left != nullptr, use_set);
       if (op_counts) op_counts[o.op]++;
       if (o.op == SV_OP_DONE) break;
+      if (o.op == SV_OP_TEXT_SLOW) { sv_apply_text_slow(st, v.text, reads_padded, off); continue; }
       if (o.op == SV_OP_SA_SET) {
         int64_t tp[SV_SET_MAX];
         const int n_occ = (int)(st.hi - st.lo);
@@ -144,7 +145,7 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
         sv_apply_peek(st, q, written, nb_cur, 1 << 30);
         continue;
       }
-      svdss_u4 A[8], B[4];
+      svdss_u4 A[4], B[4];
       if (o.op == SV_OP_LF) {
         const int64_t blo = (int64_t)st.lo >> SVDSS_BLOCK_SHIFT, bhi = (int64_t)st.hi >> SVDSS_BLOCK_SHIFT;
         for (int j = 0; j < 4; ++j) A[j] = v.blocks[4 * blo + j];
@@ -157,28 +158,15 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
       } else if (o.op == SV_OP_SA) {
         sv_apply_sa(st, (int64_t)((const P*)v.sa)[o.a]);
       } else if (o.op == SV_OP_TEXT) {
-        // only the 16-byte pieces the kernel loads; the others hold garbage that must not matter
-        int k_lo, k_hi;
-        sv_text_chunks(st, k_lo, k_hi);
-        memset(A, 0xa5, sizeof A);
-        for (int k = 0; k < 8; ++k)
-          if (k >= k_lo && k <= k_hi) {
-            const int64_t at = st.tdelta + st.wrel + 16 * k;
-            if (at < -64 || at + 16 > (int64_t)ix->n + 64) { fprintf(stderr, "emu2: TEXT load outside the padded text (%ld)\n", (long)at); abort(); }
-            memcpy(&A[k], v.text + at, 16);
-          }
-        if (op_counts && k_hi >= k_lo) {   // 128-byte lines of the text this operation touches (text base taken as line-aligned)
-          const int64_t a0 = st.tdelta + st.wrel + 16 * k_lo + (1 << 20), a1 = st.tdelta + st.wrel + 16 * k_hi + 15 + (1 << 20);
-          op_counts[10] += (a1 >> 7) - (a0 >> 7) + 1;
-        }
-        sv_apply_text(st, A, g, off);
+        memcpy(A, v.text + st.tdelta + st.pos - 64, 64);
+        memcpy(B, reads_padded + off + st.pos - 64, 64);
+        sv_apply_text(st, A, B);
       } else if (o.op == SV_OP_FILL) {
         int64_t c0 = o.a;
-        if (c0 > max_chunk - 7) c0 = max_chunk - 7;
+        if (c0 > max_chunk - 3) c0 = max_chunk - 3;
         if (c0 < 0) c0 = 0;
-        memcpy(A, reads_padded + 16 * c0, 128);
-        if (op_counts) op_counts[11] += ((16 * c0 + 127) >> 7) - ((16 * c0) >> 7) + 1;   // lines of the read buffer
-        sv_ring_fill(g, c0, A);
+        memcpy(B, reads_padded + 16 * c0, 64);
+        sv_ring_fill(g, c0, B);
         st.wrel = (int32_t)(16 * c0 - off);
       }
     }
