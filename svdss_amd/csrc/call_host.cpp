@@ -542,7 +542,8 @@ int main_call(const CallOptions& o) {
   }
   {
     BamReader bam(o.bam);
-    svdss_enable_gpu_inflate(bam);
+    // (--gpus N: the chunks of pass 1 are inflated on all N GPUs in turn, as `search` does)
+    svdss_enable_gpu_inflate(bam, 0, std::max(1, std::min(o.gpus, svdss_device_count())));
     if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
     ref_names = bam.ref_names();
     const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106

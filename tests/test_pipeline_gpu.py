@@ -247,3 +247,30 @@ def test_call_sharded_over_two_ranks_with_the_hip_kernels():
         assert p.exitcode == 0
     for _, vcf, sam in got:
         assert vcf == vcf0 and sam == info0["sam"]
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (python -m torch.distributed.run, one rank per GPU), here with both
+    ranks on the box's one GPU: SVDSS_BENCH_BACKEND=gloo (RCCL refuses two ranks on one device; the exchange then goes
+    through host staging).  The N > 1 path end to end on hardware: LPT partition of the contigs, per-rank index built in
+    HBM and verified, reads from the rank's contigs, the pre-allocated SFS gather (step i's exchange beside step i+1's
+    search, every step's exchange complete inside the timed region), max-over-ranks timing, ONE JSON line from rank 0."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SVDSS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "chr20", "--reads", "8192"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "reads/s"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8192 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert "gathered on rank 0" in d["config"]["parallelism"]
+    assert d["index_verified_rows"] == 2 * (64_444_167 + 1)
