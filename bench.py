@@ -319,11 +319,21 @@ def main():
     t_verify = time.time() - t0
     if iv["rows"] != ix.size or iv["first_bad"] != -1 or any(iv[k] for k in ("bad_order", "bad_bwt", "bad_range", "bad_block", "bad_dollar")):
         raise SystemExit(f"INDEX VERIFICATION FAILED: {iv}")
-    e2e_dir = None
+    e2e_dir, e2e_error = None, None
     if rank == 0 and world == 1 and not args.no_e2e:
+        # (the end-to-end legs are auxiliary: whatever goes wrong there -- a full /tmp, a missing binary -- is reported
+        # in the JSON line and must not cost the run its headline measurement)
+        import shutil
         import tempfile
-        e2e_dir = tempfile.mkdtemp(prefix="svdss_bench_e2e_", dir="/tmp")
-        e2e_prepare(e2e_dir, ref, wg=(len(contig_lens) == 24 and not args.no_e2e_wg and not families))
+        e2e_error = None
+        try:
+            e2e_dir = tempfile.mkdtemp(prefix="svdss_bench_e2e_", dir="/tmp")
+            e2e_prepare(e2e_dir, ref, wg=(len(contig_lens) == 24 and not args.no_e2e_wg and not families))
+        except Exception as e:   # noqa: BLE001
+            e2e_error = f"prepare: {type(e).__name__}: {e}"
+            if e2e_dir:
+                shutil.rmtree(e2e_dir, ignore_errors=True)
+            e2e_dir = None
 
     # ---- reads: generated on the GPU from the contigs LPT gives this rank -------
     owner = lpt_partition(contig_lens, world)
@@ -577,7 +587,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["verified_reads"], out["verified_subclusters"] = cpu_baseline_and_verify(
                 ix, pp, d_reads, L, n_reads, args.cpu_seconds, cw)
-        if world == 1 and not args.no_e2e:
+        if e2e_error:
+            out["e2e_error"] = e2e_error
+        if world == 1 and not args.no_e2e and e2e_dir:
             # the end-to-end run is a process of its own on the same GPU: this one lets go of the index (127 GB), the
             # reads and the call-side arenas first
             for sp, _ in searchers:
@@ -592,6 +604,8 @@ def main():
             torch.cuda.empty_cache()
             try:
                 out.update(e2e_runs(e2e_dir, args.e2e_reads, call=not args.no_e2e_call))
+            except Exception as e:   # noqa: BLE001
+                out["e2e_error"] = f"{type(e).__name__}: {str(e)[-400:]}"
             finally:
                 import shutil
                 shutil.rmtree(e2e_dir, ignore_errors=True)
@@ -774,45 +788,51 @@ def e2e_runs(work, n_reads, call=True):
     r["host_cpu_quota_cores"] = cpu_quota()
     out["e2e"] = r
     if os.path.exists(os.path.join(work, "wg.fa")):
-        t0 = time.perf_counter()
-        subprocess.run([exe, "index", "-d", os.path.join(work, "wg.fa"), "-o", os.path.join(work, "wg.fmd")], check=True, capture_output=True)
-        t_index = time.perf_counter() - t0
-        os.remove(os.path.join(work, "wg.fa"))
-        r = _run_search(exe, os.path.join(work, "wg.fmd"), bam)
-        r["what"] = ("the same BAM against the index of the whole reference (24 contigs, GRCh38 primary lengths, 6.18e9 BWT "
-                     "symbols): restore = records file (%.1f GB) read + index rebuilt in HBM + K = 16 table"
-                     % (os.path.getsize(os.path.join(work, "wg.fmd.svdss")) / 1e9))
-        r["index_s"] = round(t_index, 2)
-        r["fmd_bytes"] = os.path.getsize(os.path.join(work, "wg.fmd"))
-        out["e2e_wg"] = r
-        for f in ("wg.fmd", "wg.fmd.svdss"):
-            os.remove(os.path.join(work, f))
+        try:
+            t0 = time.perf_counter()
+            subprocess.run([exe, "index", "-d", os.path.join(work, "wg.fa"), "-o", os.path.join(work, "wg.fmd")], check=True, capture_output=True)
+            t_index = time.perf_counter() - t0
+            os.remove(os.path.join(work, "wg.fa"))
+            r = _run_search(exe, os.path.join(work, "wg.fmd"), bam)
+            r["what"] = ("the same BAM against the index of the whole reference (24 contigs, GRCh38 primary lengths, 6.18e9 BWT "
+                         "symbols): restore = records file (%.1f GB) read + index rebuilt in HBM + K = 16 table"
+                         % (os.path.getsize(os.path.join(work, "wg.fmd.svdss")) / 1e9))
+            r["index_s"] = round(t_index, 2)
+            r["fmd_bytes"] = os.path.getsize(os.path.join(work, "wg.fmd"))
+            out["e2e_wg"] = r
+            for f in ("wg.fmd", "wg.fmd.svdss"):
+                os.remove(os.path.join(work, f))
+        except Exception as e:   # noqa: BLE001
+            out["e2e_wg_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
     os.remove(bam)
     if call:
-        from tools import e2e_call as EC
-        cdir = os.path.join(work, "call")
-        fa, cbam, svs, het, recs, hdr, _ = EC.write_dataset(cdir, 30_000_000, 200, 30, 15000, het_every=2, max_len=2000)
-        fmd = os.path.join(cdir, "ref.fmd")
-        subprocess.run([exe, "index", "-d", fa, "-o", fmd], check=True, capture_output=True)
-        sfs = os.path.join(cdir, "specifics.txt")
-        t0 = time.perf_counter()
-        with open(sfs, "wb") as f:
-            subprocess.run([exe, "search", "--index", fmd, "--bam", cbam], check=True, stdout=f, stderr=subprocess.DEVNULL)
-        t_search = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        vcf = subprocess.run([exe, "call", "--reference", fa, "--bam", cbam, "--sfs", sfs, "--threads", "16",
-                              "--min-sv-length", "50"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
-        t_call = time.perf_counter() - t0
-        called = [c[:3] for c in EC.parse_vcf(vcf)]
-        truth = [(sv.pos, sv.kind, sv.length) for sv in svs]
-        hit = sum(1 for p, k, l in truth if any(k == ck and l == cl and abs(cp - p) <= 12 for cp, ck, cl in called))
-        n = len(recs)
-        out["e2e_call"] = {"what": "SVDSS index -> search -> call (binaries): 30 Mb genome, %d implanted SVs (every other one "
-                                   "heterozygous), %d error-free 15 kb reads with truth alignments (30x), whole-process wall "
-                                   "times" % (len(svs), n),
-                           "reads": n, "search_s": round(t_search, 3), "call_s": round(t_call, 3),
-                           "call_reads_per_s": n / t_call, "search_plus_call_reads_per_s": n / (t_search + t_call),
-                           "svs_called": len(called), "svs_truth": len(truth), "truth_recovered": hit}
+        try:
+            from tools import e2e_call as EC
+            cdir = os.path.join(work, "call")
+            fa, cbam, svs, het, recs, hdr, _ = EC.write_dataset(cdir, 30_000_000, 200, 30, 15000, het_every=2, max_len=2000)
+            fmd = os.path.join(cdir, "ref.fmd")
+            subprocess.run([exe, "index", "-d", fa, "-o", fmd], check=True, capture_output=True)
+            sfs = os.path.join(cdir, "specifics.txt")
+            t0 = time.perf_counter()
+            with open(sfs, "wb") as f:
+                subprocess.run([exe, "search", "--index", fmd, "--bam", cbam], check=True, stdout=f, stderr=subprocess.DEVNULL)
+            t_search = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            vcf = subprocess.run([exe, "call", "--reference", fa, "--bam", cbam, "--sfs", sfs, "--threads", "16",
+                                  "--min-sv-length", "50"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+            t_call = time.perf_counter() - t0
+            called = [c[:3] for c in EC.parse_vcf(vcf)]
+            truth = [(sv.pos, sv.kind, sv.length) for sv in svs]
+            hit = sum(1 for p, k, l in truth if any(k == ck and l == cl and abs(cp - p) <= 12 for cp, ck, cl in called))
+            n = len(recs)
+            out["e2e_call"] = {"what": "SVDSS index -> search -> call (binaries): 30 Mb genome, %d implanted SVs (every other one "
+                                       "heterozygous), %d error-free 15 kb reads with truth alignments (30x), whole-process wall "
+                                       "times" % (len(svs), n),
+                               "reads": n, "search_s": round(t_search, 3), "call_s": round(t_call, 3),
+                               "call_reads_per_s": n / t_call, "search_plus_call_reads_per_s": n / (t_search + t_call),
+                               "svs_called": len(called), "svs_truth": len(truth), "truth_recovered": hit}
+        except Exception as e:   # noqa: BLE001
+            out["e2e_call_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
     return out
 
 

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -98,6 +99,9 @@ extern "C" int svdss_index_build(const uint8_t* contigs, const int64_t* lens, in
 // host (BWT, count, save).  Making it resident (svdss_index_to_device) builds it in HBM instead and never comes here.
 static int materialize(const svdss_index* cix) {
   svdss_index* ix = const_cast<svdss_index*>(cix);
+  // (several threads may hold the same handle -- the replicas of `--gpus N` are made concurrently: one of them builds)
+  static std::mutex m;
+  std::lock_guard<std::mutex> lk(m);
   if (!svdss_index_is_lazy(ix)) return SVDSS_OK;
   int threads = 1;
 #ifdef _OPENMP
