@@ -474,48 +474,18 @@ uint8_t enc26(char c) {   // caller.hpp:25-37
 
 }  // namespace
 
-int main_call(const CallOptions& o) {
+namespace {
+
+// `SVDSS call`, stage by stage in the order of Caller::run / Clusterer::run (caller.cpp:12-57, clusterer.cpp:12-54); the
+// members are what one stage hands to the next.
+struct CallRun {
+  const CallOptions& o;
   Ctx C;
-  C.o = o;
-  const int T = std::max(1, o.threads);
-  auto t_last = std::chrono::steady_clock::now();
-  auto stage = [&](const char* what) {   // --verbose: seconds since the previous stage mark
-    if (!o.verbose) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[call] [time] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
-    t_last = now;
-  };
-  // ---- load_chromosomes (chromosomes.cpp:9-27): upper-cased, FASTA order
-  {
-    FastxReader fx(o.reference);
-    if (!fx.ok()) die("cannot open " + o.reference);
-    std::string name, seq;
-    while (fx.next(name, seq)) {
-      for (char& ch : seq) ch = (char)toupper((unsigned char)ch);
-      C.chrom_names.push_back(name);
-      C.chrom_seqs[name] = seq;
-    }
-  }
-  // ---- parse_sfsfile (sfs.cpp:5-30)
-  {
-    FILE* f = fopen(o.sfs.c_str(), "r");
-    if (f) {
-      char nm[4096]; int qs, l, ht; std::string cur;
-      char line[8192];
-      while (fgets(line, sizeof line, f)) {
-        if (sscanf(line, "%4095s %d %d %d", nm, &qs, &l, &ht) != 4) continue;
-        if (strcmp(nm, "*") != 0) { cur = nm; C.sfs[cur] = std::vector<RawSFS>(); }
-        C.sfs[cur].push_back(RawSFS{qs, l, ht});
-      }
-      fclose(f);
-    }
-  }
-  stage("reference + sfs file");
-  logmsg("info", "Placing SFSs on reference genome");
-  // ---- align_and_extend (clusterer.cpp:56-156): pass 1 over the BAM
-  std::vector<std::string> ref_names;
-  std::vector<ESFS> extended;
-  std::vector<Clip> clips;       // --clipped
+  const int T;
+  std::chrono::steady_clock::time_point t_last = std::chrono::steady_clock::now();
+  std::vector<std::string> ref_names;    // BAM header order
+  std::vector<ESFS> extended;            // pass 1: every placed SFS
+  std::vector<Clip> clips;               // --clipped
   // The inflated records of pass 1 are kept for pass 2 when they fit in memory (a second inflate of the whole file
   // otherwise): SVDSS_CALL_CACHE_GB, default 40 % of MemAvailable, at most 64 GiB.
   std::vector<BamReader::RawView> cache_views;
@@ -523,666 +493,762 @@ int main_call(const CallOptions& o) {
   size_t cache_bytes = 0, cache_limit = 0;
   bool cache_ok = true;
   std::thread cache_release;
-  {
-    double gb = 0;
-    if (const char* e = getenv("SVDSS_CALL_CACHE_GB")) gb = atof(e);
-    else {
-      if (FILE* f = fopen("/proc/meminfo", "r")) {
-        char line[256];
+  std::vector<Cluster> clusters;
+  int n_dev = 1, G = 1;                  // GPUs present / shards of the DP batches (--gpus)
+  struct Sub { size_t parent; Cluster cl; };
+  std::vector<Sub> subs;                 // sub-clusters after split_cluster, in the reference's order
+  std::vector<std::string> consensus;    // one per sub-cluster
+  std::vector<SV> svs;
+  std::vector<std::vector<std::string>> sam_rows;   // per reference thread, --poa only
+
+  explicit CallRun(const CallOptions& opt) : o(opt), T(std::max(1, opt.threads)) { C.o = opt; }
+
+  void stage(const char* what) {   // --verbose: seconds since the previous stage mark
+    if (!o.verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[call] [time] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  }
+
+  // load_chromosomes + parse_sfsfile (chromosomes.cpp:9-27, sfs.cpp:5-30)
+  void load_inputs() {
+    // ---- load_chromosomes (chromosomes.cpp:9-27): upper-cased, FASTA order
+    {
+      FastxReader fx(o.reference);
+      if (!fx.ok()) die("cannot open " + o.reference);
+      std::string name, seq;
+      while (fx.next(name, seq)) {
+        for (char& ch : seq) ch = (char)toupper((unsigned char)ch);
+        C.chrom_names.push_back(name);
+        C.chrom_seqs[name] = seq;
+      }
+    }
+    // ---- parse_sfsfile (sfs.cpp:5-30)
+    {
+      FILE* f = fopen(o.sfs.c_str(), "r");
+      if (f) {
+        char nm[4096]; int qs, l, ht; std::string cur;
+        char line[8192];
         while (fgets(line, sizeof line, f)) {
-          long long kb;
-          if (sscanf(line, "MemAvailable: %lld kB", &kb) == 1) { gb = 0.4 * (double)kb / (1024.0 * 1024.0); break; }
+          if (sscanf(line, "%4095s %d %d %d", nm, &qs, &l, &ht) != 4) continue;
+          if (strcmp(nm, "*") != 0) { cur = nm; C.sfs[cur] = std::vector<RawSFS>(); }
+          C.sfs[cur].push_back(RawSFS{qs, l, ht});
         }
         fclose(f);
       }
-      if (gb > 64) gb = 64;
     }
-    cache_limit = gb > 0 ? (size_t)(gb * 1024.0 * 1024.0 * 1024.0) : 0;
-    if (cache_limit == 0) cache_ok = false;
+    stage("reference + sfs file");
   }
-  {
-    BamReader bam(o.bam);
-    // (--gpus N: the chunks of pass 1 are inflated on all N GPUs in turn, as `search` does)
-    svdss_enable_gpu_inflate(bam, 0, std::max(1, std::min(o.gpus, svdss_device_count())));
-    if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
-    ref_names = bam.ref_names();
-    const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
-    std::vector<std::vector<ESFS>> per_thread((size_t)T);
-    std::vector<std::vector<Clip>> per_thread_clips((size_t)T);
-    // the chromosomes in BAM header order on the GPU, for the placement kernel (SVDSS_PLACE_HOST=1: host code instead;
-    // --clipped: host code as well -- the kernel reports how many SFS stay unplaced, not next to which soft clip)
-    svdss_ref_t* dref = nullptr;
-    std::vector<int32_t> tid_map(ref_names.size(), -1);
-    if (!getenv("SVDSS_PLACE_HOST") && !o.clipped) {
-      std::string all;
-      std::vector<int64_t> off(1, 0);
-      for (size_t t = 0; t < ref_names.size(); ++t) {
-        auto it = C.chrom_seqs.find(ref_names[t]);
-        if (it == C.chrom_seqs.end()) continue;
-        tid_map[t] = (int32_t)off.size() - 1;
-        all += it->second;
-        off.push_back((int64_t)all.size());
-      }
-      check(svdss_ref_upload((const uint8_t*)all.data(), off.data(), (int32_t)off.size() - 1, 0, &dref), "svdss_ref_upload");
-    }
-    // two batches: the next one is read (inflate + slicing, this thread) while the T slices of the previous one run
-    std::vector<BamRecord> batches[2];
-    std::thread worker;
-    int cur = 0;
-    std::string qname;
-    bool eof = false;
-    uint64_t seen_chunk = ~0ull;
-    std::shared_ptr<BamReader::Bytes> cur_chunk;
-    while (!eof) {
-      std::vector<BamRecord>& batch = batches[cur];
-      batch.clear();
-      while ((int)batch.size() < bsize) {
-        // records are located in the inflated chunks and only decoded if the read has SFS at all
-        BamReader::RawView rr;
-        const int rc = bam.next_view(rr);
-        if (rc == 0) { eof = true; break; }
-        if (rc < 0) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": " + bam.error()); }
-        if (bam.chunk_id() != seen_chunk) {
-          seen_chunk = bam.chunk_id();
-          cur_chunk = bam.chunk();
-          if (cache_ok) {
-            cache_bytes += cur_chunk->size();
-            if (cache_bytes > cache_limit) {   // too big to keep: pass 2 reads the file again
-              cache_ok = false;
-              cache_views.clear(); cache_views.shrink_to_fit();
-              cache_chunks.clear(); cache_chunks.shrink_to_fit();
-            } else cache_chunks.push_back(cur_chunk);
+
+  // Clusterer::align_and_extend (clusterer.cpp:56-156): pass 1 over the BAM, placement of every SFS
+  void align_and_extend() {
+    logmsg("info", "Placing SFSs on reference genome");
+    // ---- align_and_extend (clusterer.cpp:56-156): pass 1 over the BAM
+    // The inflated records of pass 1 are kept for pass 2 when they fit in memory (a second inflate of the whole file
+    // otherwise): SVDSS_CALL_CACHE_GB, default 40 % of MemAvailable, at most 64 GiB.
+    {
+      double gb = 0;
+      if (const char* e = getenv("SVDSS_CALL_CACHE_GB")) gb = atof(e);
+      else {
+        if (FILE* f = fopen("/proc/meminfo", "r")) {
+          char line[256];
+          while (fgets(line, sizeof line, f)) {
+            long long kb;
+            if (sscanf(line, "MemAvailable: %lld kB", &kb) == 1) { gb = 0.4 * (double)kb / (1024.0 * 1024.0); break; }
           }
+          fclose(f);
         }
-        if (rr.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
-        if ((int)rr.mapq < o.min_mapq) continue;
-        if (cache_ok) cache_views.push_back(rr);    // every record pass 2 looks at (same filters, clusterer.cpp:535-540)
-        qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
-        if (C.sfs.find(qname) == C.sfs.end()) continue;
-        BamRecord r;
-        BamReader::materialize(rr, r);
-        batch.push_back(std::move(r));
+        if (gb > 64) gb = 64;
       }
-      if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
-      // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
-      // the same order per slice
-      worker = std::thread([&C, &ref_names, &per_thread, &per_thread_clips, &batch, T, dref, &tid_map]() {
-        if (dref) {
-          // placement on the GPU (csrc/place.hip: one lane per alignment); the results go to the T per-thread lists in
-          // the order the reference's slices would have produced them (record n belongs to slice n % T)
-          std::vector<int32_t> tid, pos, sq, sl, cnt;
-          std::vector<uint32_t> cig;
-          std::vector<int64_t> cig_off(1, 0), sfs_off(1, 0);
-          std::vector<const std::vector<RawSFS>*> lists;
-          for (const BamRecord& r : batch) {
-            const bool known = r.tid >= 0 && r.tid < (int)ref_names.size() && tid_map[(size_t)r.tid] >= 0;
-            tid.push_back(known ? tid_map[(size_t)r.tid] : -1);
-            pos.push_back(r.pos);
-            cig.insert(cig.end(), r.cigar.begin(), r.cigar.end());
-            cig_off.push_back((int64_t)cig.size());
-            const std::vector<RawSFS>& v = C.sfs.at(r.qname);
-            lists.push_back(&v);
-            if (known) for (const RawSFS& x : v) { sq.push_back(x.qs); sl.push_back(x.l); }
-            sfs_off.push_back((int64_t)sq.size());
+      cache_limit = gb > 0 ? (size_t)(gb * 1024.0 * 1024.0 * 1024.0) : 0;
+      if (cache_limit == 0) cache_ok = false;
+    }
+    {
+      BamReader bam(o.bam);
+      // (--gpus N: the chunks of pass 1 are inflated on all N GPUs in turn, as `search` does)
+      svdss_enable_gpu_inflate(bam, 0, std::max(1, std::min(o.gpus, svdss_device_count())));
+      if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
+      ref_names = bam.ref_names();
+      const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
+      std::vector<std::vector<ESFS>> per_thread((size_t)T);
+      std::vector<std::vector<Clip>> per_thread_clips((size_t)T);
+      // the chromosomes in BAM header order on the GPU, for the placement kernel (SVDSS_PLACE_HOST=1: host code instead;
+      // --clipped: host code as well -- the kernel reports how many SFS stay unplaced, not next to which soft clip)
+      svdss_ref_t* dref = nullptr;
+      std::vector<int32_t> tid_map(ref_names.size(), -1);
+      if (!getenv("SVDSS_PLACE_HOST") && !o.clipped) {
+        std::string all;
+        std::vector<int64_t> off(1, 0);
+        for (size_t t = 0; t < ref_names.size(); ++t) {
+          auto it = C.chrom_seqs.find(ref_names[t]);
+          if (it == C.chrom_seqs.end()) continue;
+          tid_map[t] = (int32_t)off.size() - 1;
+          all += it->second;
+          off.push_back((int64_t)all.size());
+        }
+        check(svdss_ref_upload((const uint8_t*)all.data(), off.data(), (int32_t)off.size() - 1, 0, &dref), "svdss_ref_upload");
+      }
+      // two batches: the next one is read (inflate + slicing, this thread) while the T slices of the previous one run
+      std::vector<BamRecord> batches[2];
+      std::thread worker;
+      int cur = 0;
+      std::string qname;
+      bool eof = false;
+      uint64_t seen_chunk = ~0ull;
+      std::shared_ptr<BamReader::Bytes> cur_chunk;
+      while (!eof) {
+        std::vector<BamRecord>& batch = batches[cur];
+        batch.clear();
+        while ((int)batch.size() < bsize) {
+          // records are located in the inflated chunks and only decoded if the read has SFS at all
+          BamReader::RawView rr;
+          const int rc = bam.next_view(rr);
+          if (rc == 0) { eof = true; break; }
+          if (rc < 0) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": " + bam.error()); }
+          if (bam.chunk_id() != seen_chunk) {
+            seen_chunk = bam.chunk_id();
+            cur_chunk = bam.chunk();
+            if (cache_ok) {
+              cache_bytes += cur_chunk->size();
+              if (cache_bytes > cache_limit) {   // too big to keep: pass 2 reads the file again
+                cache_ok = false;
+                cache_views.clear(); cache_views.shrink_to_fit();
+                cache_chunks.clear(); cache_chunks.shrink_to_fit();
+              } else cache_chunks.push_back(cur_chunk);
+            }
           }
-          cnt.resize(batch.size());
-          std::vector<int32_t> out(5 * std::max<size_t>(1, sq.size()));
-          int64_t st[4];
-          check(svdss_place_sfs_batch(dref, tid.data(), pos.data(), cig.data(), cig_off.data(), sq.data(), sl.data(),
-                                      sfs_off.data(), (int64_t)batch.size(), cnt.data(), out.data(), st),
-                "svdss_place_sfs_batch");
-          C.unplaced += st[0]; C.s_unplaced += st[1]; C.e_unplaced += st[2]; C.unknown += st[3];
-          for (int t = 0; t < T; ++t)
+          if (rr.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
+          if ((int)rr.mapq < o.min_mapq) continue;
+          if (cache_ok) cache_views.push_back(rr);    // every record pass 2 looks at (same filters, clusterer.cpp:535-540)
+          qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
+          if (C.sfs.find(qname) == C.sfs.end()) continue;
+          BamRecord r;
+          BamReader::materialize(rr, r);
+          batch.push_back(std::move(r));
+        }
+        if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
+        // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
+        // the same order per slice
+        worker = std::thread([this, &per_thread, &per_thread_clips, &batch, dref, &tid_map]() {
+          if (dref) {
+            // placement on the GPU (csrc/place.hip: one lane per alignment); the results go to the T per-thread lists in
+            // the order the reference's slices would have produced them (record n belongs to slice n % T)
+            std::vector<int32_t> tid, pos, sq, sl, cnt;
+            std::vector<uint32_t> cig;
+            std::vector<int64_t> cig_off(1, 0), sfs_off(1, 0);
+            std::vector<const std::vector<RawSFS>*> lists;
+            for (const BamRecord& r : batch) {
+              const bool known = r.tid >= 0 && r.tid < (int)ref_names.size() && tid_map[(size_t)r.tid] >= 0;
+              tid.push_back(known ? tid_map[(size_t)r.tid] : -1);
+              pos.push_back(r.pos);
+              cig.insert(cig.end(), r.cigar.begin(), r.cigar.end());
+              cig_off.push_back((int64_t)cig.size());
+              const std::vector<RawSFS>& v = C.sfs.at(r.qname);
+              lists.push_back(&v);
+              if (known) for (const RawSFS& x : v) { sq.push_back(x.qs); sl.push_back(x.l); }
+              sfs_off.push_back((int64_t)sq.size());
+            }
+            cnt.resize(batch.size());
+            std::vector<int32_t> out(5 * std::max<size_t>(1, sq.size()));
+            int64_t st[4];
+            check(svdss_place_sfs_batch(dref, tid.data(), pos.data(), cig.data(), cig_off.data(), sq.data(), sl.data(),
+                                        sfs_off.data(), (int64_t)batch.size(), cnt.data(), out.data(), st),
+                  "svdss_place_sfs_batch");
+            C.unplaced += st[0]; C.s_unplaced += st[1]; C.e_unplaced += st[2]; C.unknown += st[3];
+            for (int t = 0; t < T; ++t)
+              for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
+                const BamRecord& r = batch[n];
+                if (tid[n] < 0) continue;
+                const int32_t* o = out.data() + 5 * sfs_off[n];
+                for (int32_t j = 0; j < cnt[n]; ++j, o += 5)
+                  per_thread[(size_t)t].push_back(ESFS{ref_names[(size_t)r.tid], r.qname, o[0], o[1], o[2], o[3],
+                                                       (*lists[n])[(size_t)o[4]].htag});
+              }
+            return;
+          }
+          auto slice = [&](int t) {
             for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
               const BamRecord& r = batch[n];
-              if (tid[n] < 0) continue;
-              const int32_t* o = out.data() + 5 * sfs_off[n];
-              for (int32_t j = 0; j < cnt[n]; ++j, o += 5)
-                per_thread[(size_t)t].push_back(ESFS{ref_names[(size_t)r.tid], r.qname, o[0], o[1], o[2], o[3],
-                                                     (*lists[n])[(size_t)o[4]].htag});
+              if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
+              extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t],
+                               C.o.clipped ? &per_thread_clips[(size_t)t] : nullptr);
             }
-          return;
-        }
-        auto slice = [&](int t) {
-          for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
-            const BamRecord& r = batch[n];
-            if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
-            extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t],
-                             C.o.clipped ? &per_thread_clips[(size_t)t] : nullptr);
+          };
+          if (T == 1 || batch.size() < 64) { for (int t = 0; t < T; ++t) slice(t); }
+          else {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < T; ++t) pool.emplace_back(slice, t);
+            slice(0);
+            for (std::thread& th : pool) th.join();
           }
-        };
-        if (T == 1 || batch.size() < 64) { for (int t = 0; t < T; ++t) slice(t); }
-        else {
-          std::vector<std::thread> pool;
-          for (int t = 1; t < T; ++t) pool.emplace_back(slice, t);
-          slice(0);
-          for (std::thread& th : pool) th.join();
-        }
-      });
-      cur ^= 1;
+        });
+        cur ^= 1;
+      }
+      if (worker.joinable()) worker.join();
+      svdss_ref_free(dref);
+      for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
+      for (int t = T; t-- > 0;)   // each thread's list goes in front of the others' (clusterer.cpp:24)
+        clips.insert(clips.end(), per_thread_clips[(size_t)t].begin(), per_thread_clips[(size_t)t].end());
     }
-    if (worker.joinable()) worker.join();
-    svdss_ref_free(dref);
-    for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
-    for (int t = T; t-- > 0;)   // each thread's list goes in front of the others' (clusterer.cpp:24)
-      clips.insert(clips.end(), per_thread_clips[(size_t)t].begin(), per_thread_clips[(size_t)t].end());
+    logmsg("info", std::to_string(C.unplaced.load()) + "/" + std::to_string(C.s_unplaced.load()) + "/" + std::to_string(C.e_unplaced.load()) +
+                       " unplaced SFSs. " + std::to_string(C.unknown.load()) + " erroneus SFSs. " + std::to_string(clips.size()) +
+                       " clipped SFSs.");   // clusterer.cpp:26-27
+    stage("pass 1: placement");
   }
-  logmsg("info", std::to_string(C.unplaced.load()) + "/" + std::to_string(C.s_unplaced.load()) + "/" + std::to_string(C.e_unplaced.load()) +
-                     " unplaced SFSs. " + std::to_string(C.unknown.load()) + " erroneus SFSs. " + std::to_string(clips.size()) +
-                     " clipped SFSs.");   // clusterer.cpp:26-27
-  stage("pass 1: placement");
-  // ---- cluster_by_proximity (clusterer.cpp:407-474)
-  std::vector<Cluster> clusters;
-  if (!extended.empty()) {
-    std::sort(extended.begin(), extended.end());
-    int maxlen = 0;
-    for (const ESFS& s : extended) maxlen = std::max(maxlen, s.re - s.rs);
-    const int dist = (int)(maxlen * 1.1);
-    std::vector<std::pair<int, int>> intervals;
-    int prev_i = 0, prev_e = extended[0].re;
-    std::string prev_chrom = extended[0].chrom;
-    for (size_t i = 1; i < extended.size(); ++i) {
-      const ESFS& s = extended[i];
-      if (s.chrom != prev_chrom) {
-        prev_chrom = s.chrom; intervals.emplace_back(prev_i, (int)i - 1); prev_i = (int)i; prev_e = s.re; continue;
-      }
-      if (s.rs - prev_e > dist) { intervals.emplace_back(prev_i, (int)i - 1); prev_e = s.re; prev_i = (int)i; }
-    }
-    intervals.emplace_back(prev_i, (int)extended.size() - 1);
-    std::vector<std::map<std::pair<int, int>, std::vector<ESFS>>> per_thread((size_t)T);
-    for (size_t i = 0; i < intervals.size(); ++i) {
-      auto& mp = per_thread[i % (size_t)T];   // schedule(static, 1)
-      int j = intervals[i].first, low = extended[(size_t)j].rs, high = extended[(size_t)j].re, last_j = j;
-      ++j;
-      for (; j <= intervals[i].second; ++j) {
-        const ESFS& s = extended[(size_t)j];
-        if (s.rs <= high) { low = std::min(low, s.rs); high = std::max(high, s.re); }
-        else {
-          for (int k = last_j; k < j; ++k) mp[{low, high}].push_back(extended[(size_t)k]);
-          low = s.rs; high = s.re; last_j = j;
+
+  // Clusterer::cluster_by_proximity (clusterer.cpp:407-474)
+  void cluster_by_proximity() {
+    // ---- cluster_by_proximity (clusterer.cpp:407-474)
+    if (!extended.empty()) {
+      std::sort(extended.begin(), extended.end());
+      int maxlen = 0;
+      for (const ESFS& s : extended) maxlen = std::max(maxlen, s.re - s.rs);
+      const int dist = (int)(maxlen * 1.1);
+      std::vector<std::pair<int, int>> intervals;
+      int prev_i = 0, prev_e = extended[0].re;
+      std::string prev_chrom = extended[0].chrom;
+      for (size_t i = 1; i < extended.size(); ++i) {
+        const ESFS& s = extended[i];
+        if (s.chrom != prev_chrom) {
+          prev_chrom = s.chrom; intervals.emplace_back(prev_i, (int)i - 1); prev_i = (int)i; prev_e = s.re; continue;
         }
+        if (s.rs - prev_e > dist) { intervals.emplace_back(prev_i, (int)i - 1); prev_e = s.re; prev_i = (int)i; }
       }
-      for (int k = last_j; k <= intervals[i].second; ++k) mp[{low, high}].push_back(extended[(size_t)k]);
+      intervals.emplace_back(prev_i, (int)extended.size() - 1);
+      std::vector<std::map<std::pair<int, int>, std::vector<ESFS>>> per_thread((size_t)T);
+      for (size_t i = 0; i < intervals.size(); ++i) {
+        auto& mp = per_thread[i % (size_t)T];   // schedule(static, 1)
+        int j = intervals[i].first, low = extended[(size_t)j].rs, high = extended[(size_t)j].re, last_j = j;
+        ++j;
+        for (; j <= intervals[i].second; ++j) {
+          const ESFS& s = extended[(size_t)j];
+          if (s.rs <= high) { low = std::min(low, s.rs); high = std::max(high, s.re); }
+          else {
+            for (int k = last_j; k < j; ++k) mp[{low, high}].push_back(extended[(size_t)k]);
+            low = s.rs; high = s.re; last_j = j;
+          }
+        }
+        for (int k = last_j; k <= intervals[i].second; ++k) mp[{low, high}].push_back(extended[(size_t)k]);
+      }
+      for (int t = 0; t < T; ++t)
+        for (auto& kv : per_thread[(size_t)t]) {
+          Cluster c;
+          c.sfss = kv.second;
+          c.chrom = c.sfss[0].chrom;
+          clusters.push_back(std::move(c));
+        }
     }
-    for (int t = 0; t < T; ++t)
-      for (auto& kv : per_thread[(size_t)t]) {
-        Cluster c;
-        c.sfss = kv.second;
-        c.chrom = c.sfss[0].chrom;
-        clusters.push_back(std::move(c));
-      }
+    stage("cluster_by_proximity");
   }
-  stage("cluster_by_proximity");
-  // ---- fill_clusters (clusterer.cpp:477-610): pass 2 over the BAM
-  {
-    std::vector<std::set<std::string>> reads(clusters.size());
-    std::vector<int> min_s(clusters.size()), max_e(clusters.size());
-    std::vector<char> live(clusters.size(), 0);
-    std::vector<std::vector<int>> cov(clusters.size(), std::vector<int>(3, 0));
-    std::map<std::string, std::vector<size_t>> by_chrom;   // cluster indices per chrom, sorted by region start
-    for (size_t i = 0; i < clusters.size(); ++i) {
-      int mn = std::numeric_limits<int>::max(), mx = 0;
-      for (const ESFS& s : clusters[i].sfss) { mn = std::min(mn, s.rs); mx = std::max(mx, s.re); reads[i].insert(s.qname); }
-      min_s[i] = mn; max_e[i] = mx;
-      if ((int)reads[i].size() < o.min_cluster_weight) { ++C.small; continue; }
-      clusters[i].s = mn; clusters[i].e = mx;
-      live[i] = 1;
-      by_chrom[clusters[i].chrom].push_back(i);
-    }
-    std::map<std::string, std::vector<int>> run_max_end;   // per chrom: running maximum of the region ends, same order
-    for (auto& kv : by_chrom) {
-      std::sort(kv.second.begin(), kv.second.end(), [&](size_t a, size_t b) { return min_s[a] < min_s[b]; });
-      std::vector<int>& rm = run_max_end[kv.first];
-      int m = 0;
-      for (size_t ci : kv.second) { m = std::max(m, max_e[ci]); rm.push_back(m); }
-    }
-    // per reference id: the clusters of that chromosome (sorted by start) and the running maximum of their ends
-    std::vector<const std::vector<size_t>*> tid_clusters(ref_names.size(), nullptr);
-    std::vector<const std::vector<int>*> tid_run_max(ref_names.size(), nullptr);
-    for (size_t t = 0; t < ref_names.size(); ++t) {
-      auto it = by_chrom.find(ref_names[t]);
-      if (it == by_chrom.end()) continue;
-      tid_clusters[t] = &it->second;
-      tid_run_max[t] = &run_max_end[it->first];
-    }
-    static const char NT16[] = "=ACMGRSVTWYHKDBN";
-    std::string qname;
-    // Records stay in their raw form: the end position and the two query positions the reference reads off the
-    // aligned-pairs vector (bam.cpp:92-134, clusterer.cpp:555-580) are functions of the CIGAR blocks alone, and only
-    // the bases of the extracted sub-read are decoded.
-    // what one alignment does to one cluster it overlaps; applied in BAM order (sequentially, or collected by worker
-    // threads over contiguous record ranges and applied range after range)
-    struct Ev { size_t ci; int hp; bool in_reads, unext; std::string name, sub; };
-    auto apply = [&](Ev& e) {
-      if (e.hp >= 0 && e.hp < 3) ++cov[e.ci][(size_t)e.hp];
-      clusters[e.ci].reads.emplace_back(e.in_reads ? 1 : 0, e.hp == 0 ? 3 : e.hp);
-      if (!e.in_reads) return;
-      if (e.unext) ++C.unextended;
-      else clusters[e.ci].subreads.push_back(SubRead{std::move(e.name), std::move(e.sub), e.hp});
-    };
-    auto process = [&](const BamReader::RawView& rr, std::string& qname, auto&& sink) {
-      if (rr.tid < 0 || rr.tid >= (int)ref_names.size() || !tid_clusters[(size_t)rr.tid]) return;
-      if (rr.flag & (4 | 2048 | 256)) return;        // clusterer.cpp:535-540: such a record touches no cluster
-      if ((int)rr.mapq < o.min_mapq) return;
-      const uint8_t* cg = rr.name() + rr.l_name;
-      auto cig = [&](uint32_t i) { uint32_t c; memcpy(&c, cg + 4u * i, 4); return c; };
-      int32_t ref_len = 0;
-      for (uint32_t i = 0; i < rr.n_cigar; ++i) {
-        const uint32_t c = cig(i), op = c & 0xf;
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += (int32_t)(c >> 4);
+
+  // Clusterer::fill_clusters (clusterer.cpp:477-610): pass 2 over the BAM
+  void fill_clusters() {
+    // ---- fill_clusters (clusterer.cpp:477-610): pass 2 over the BAM
+    {
+      std::vector<std::set<std::string>> reads(clusters.size());
+      std::vector<int> min_s(clusters.size()), max_e(clusters.size());
+      std::vector<char> live(clusters.size(), 0);
+      std::vector<std::vector<int>> cov(clusters.size(), std::vector<int>(3, 0));
+      std::map<std::string, std::vector<size_t>> by_chrom;   // cluster indices per chrom, sorted by region start
+      for (size_t i = 0; i < clusters.size(); ++i) {
+        int mn = std::numeric_limits<int>::max(), mx = 0;
+        for (const ESFS& s : clusters[i].sfss) { mn = std::min(mn, s.rs); mx = std::max(mx, s.re); reads[i].insert(s.qname); }
+        min_s[i] = mn; max_e[i] = mx;
+        if ((int)reads[i].size() < o.min_cluster_weight) { ++C.small; continue; }
+        clusters[i].s = mn; clusters[i].e = mx;
+        live[i] = 1;
+        by_chrom[clusters[i].chrom].push_back(i);
       }
-      const int a_beg = rr.pos, a_end = rr.pos + (ref_len ? ref_len : 1);   // bam_endpos
-      const std::vector<size_t>& cl_ids = *tid_clusters[(size_t)rr.tid];
-      // clusters before `first` end at or before the alignment's start: none of them can overlap it
-      const std::vector<int>& rm = *tid_run_max[(size_t)rr.tid];
-      const size_t first = (size_t)(std::upper_bound(rm.begin(), rm.end(), a_beg) - rm.begin());
-      bool have_tags = false;
-      int64_t hp = 0;
-      for (size_t k = first; k < cl_ids.size(); ++k) {
-        const size_t ci = cl_ids[k];
-        // region "chrom:min_s-max_e" = 0-based half-open [min_s-1, max_e)
-        const int beg0 = std::max(min_s[ci] - 1, 0), end0 = max_e[ci];
-        if (beg0 >= a_end) break;   // clusters are sorted by start
-        if (!(a_beg < end0 && a_end > beg0)) continue;
-        if (!have_tags) {
-          have_tags = true;
-          BamReader::aux_int(rr.aux(), rr.l_aux, "HP", hp);
-          qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
-        }
-        Ev ev{ci, (int)hp, false, false, std::string(), std::string()};
-        if (reads[ci].find(qname) == reads[ci].end()) { sink(ev); continue; }
-        ev.in_reads = true;
-        // qs: query position of the last aligned (M/=/X) pair with reference position <= min_s;
-        // qe: of the first one with reference position >= max_e
-        int qs = -1, qe = -1, ref_pos = rr.pos, read_pos = 0;
+      std::map<std::string, std::vector<int>> run_max_end;   // per chrom: running maximum of the region ends, same order
+      for (auto& kv : by_chrom) {
+        std::sort(kv.second.begin(), kv.second.end(), [&](size_t a, size_t b) { return min_s[a] < min_s[b]; });
+        std::vector<int>& rm = run_max_end[kv.first];
+        int m = 0;
+        for (size_t ci : kv.second) { m = std::max(m, max_e[ci]); rm.push_back(m); }
+      }
+      // per reference id: the clusters of that chromosome (sorted by start) and the running maximum of their ends
+      std::vector<const std::vector<size_t>*> tid_clusters(ref_names.size(), nullptr);
+      std::vector<const std::vector<int>*> tid_run_max(ref_names.size(), nullptr);
+      for (size_t t = 0; t < ref_names.size(); ++t) {
+        auto it = by_chrom.find(ref_names[t]);
+        if (it == by_chrom.end()) continue;
+        tid_clusters[t] = &it->second;
+        tid_run_max[t] = &run_max_end[it->first];
+      }
+      static const char NT16[] = "=ACMGRSVTWYHKDBN";
+      std::string qname;
+      // Records stay in their raw form: the end position and the two query positions the reference reads off the
+      // aligned-pairs vector (bam.cpp:92-134, clusterer.cpp:555-580) are functions of the CIGAR blocks alone, and only
+      // the bases of the extracted sub-read are decoded.
+      // what one alignment does to one cluster it overlaps; applied in BAM order (sequentially, or collected by worker
+      // threads over contiguous record ranges and applied range after range)
+      struct Ev { size_t ci; int hp; bool in_reads, unext; std::string name, sub; };
+      auto apply = [&](Ev& e) {
+        if (e.hp >= 0 && e.hp < 3) ++cov[e.ci][(size_t)e.hp];
+        clusters[e.ci].reads.emplace_back(e.in_reads ? 1 : 0, e.hp == 0 ? 3 : e.hp);
+        if (!e.in_reads) return;
+        if (e.unext) ++C.unextended;
+        else clusters[e.ci].subreads.push_back(SubRead{std::move(e.name), std::move(e.sub), e.hp});
+      };
+      auto process = [&](const BamReader::RawView& rr, std::string& qname, auto&& sink) {
+        if (rr.tid < 0 || rr.tid >= (int)ref_names.size() || !tid_clusters[(size_t)rr.tid]) return;
+        if (rr.flag & (4 | 2048 | 256)) return;        // clusterer.cpp:535-540: such a record touches no cluster
+        if ((int)rr.mapq < o.min_mapq) return;
+        const uint8_t* cg = rr.name() + rr.l_name;
+        auto cig = [&](uint32_t i) { uint32_t c; memcpy(&c, cg + 4u * i, 4); return c; };
+        int32_t ref_len = 0;
         for (uint32_t i = 0; i < rr.n_cigar; ++i) {
           const uint32_t c = cig(i), op = c & 0xf;
-          const int l = (int)(c >> 4);
-          if (op == 0 || op == 7 || op == 8) {
-            if (l > 0) {
-              if (ref_pos <= min_s[ci]) qs = read_pos + (std::min(min_s[ci], ref_pos + l - 1) - ref_pos);
-              if (qe == -1 && ref_pos + l - 1 >= max_e[ci]) qe = read_pos + (std::max(max_e[ci], ref_pos) - ref_pos);
-            }
-            read_pos += l; ref_pos += l;
-          } else if (op == 1 || op == 4) read_pos += l;
-          else if (op == 2 || op == 3) ref_pos += l;
+          if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += (int32_t)(c >> 4);
         }
-        if (qs == -1 || qe == -1) ev.unext = true;
-        else {
-          if (qs > rr.l_seq) die("corrupt alignment: sub-read start past the end of read " + qname);   // (std::string::substr throws in the reference)
-          const int n = std::max(0, std::min(qe - qs + 1, rr.l_seq - qs));
-          const uint8_t* sq = rr.seq4();
-          std::string sub((size_t)n, 'N');
-          for (int i = 0; i < n; ++i) { const int q = qs + i; sub[(size_t)i] = NT16[(sq[q >> 1] >> ((~q & 1) << 2)) & 0xf]; }
-          ev.name = qname;
-          ev.sub = std::move(sub);
-        }
-        sink(ev);
-      }
-    };
-    if (cache_ok) {
-      stage("pass 2: setup");
-      const size_t n = cache_views.size();
-      const size_t W = std::max<size_t>(1, std::min<size_t>({(size_t)effective_cpus(), (size_t)32, n / 4096 + 1}));
-      std::vector<std::vector<Ev>> evs(W);
-      auto range = [&](size_t w) {
-        std::string nm;
-        auto sink = [&](Ev& e) { evs[w].push_back(std::move(e)); };
-        for (size_t i = n * w / W; i < n * (w + 1) / W; ++i) process(cache_views[i], nm, sink);
-      };
-      std::vector<std::thread> pool;
-      for (size_t w = 1; w < W; ++w) pool.emplace_back(range, w);
-      range(0);
-      for (std::thread& th : pool) th.join();
-      stage("pass 2: scan");
-      for (size_t w = 0; w < W; ++w)
-        for (Ev& e : evs[w]) apply(e);
-      stage("pass 2: apply");
-      // (gigabytes of inflated records: released while the DP batches run)
-      cache_release = std::thread([v = std::move(cache_views), c = std::move(cache_chunks)]() mutable { v.clear(); c.clear(); });
-    } else {
-      // the records of pass 1 did not fit in memory.  With a BAI index beside the file (what the reference requires:
-      // sam_index_load + one sam_itr_querys per cluster, clusterer.cpp:495-527) only the file chunks around the
-      // clusters are read -- all regions turned into one sorted, merged chunk list, read once in file order, which
-      // visits the same records in the same order as the full scan below does among those that touch a cluster
-      BaiIndex bai;
-      bool have_bai = false;
-      if (!getenv("SVDSS_CALL_NO_BAI")) {
-        have_bai = bai.load(o.bam + ".bai");
-        if (!have_bai && o.bam.size() > 4 && o.bam.compare(o.bam.size() - 4, 4, ".bam") == 0)
-          have_bai = bai.load(o.bam.substr(0, o.bam.size() - 4) + ".bai");
-        if (have_bai && bai.refs.size() != ref_names.size()) have_bai = false;
-      }
-      if (have_bai) {
-        std::vector<std::pair<uint64_t, uint64_t>> chunks;
-        size_t n_regions = 0;
-        for (size_t t = 0; t < ref_names.size(); ++t) {
-          if (!tid_clusters[t]) continue;
-          int64_t rb = -1, re = -1;   // current merged region
-          for (size_t ci : *tid_clusters[t]) {
-            const int64_t b0 = std::max(min_s[ci] - 1, 0), e0 = max_e[ci];
-            if (re >= 0 && b0 <= re) { re = std::max(re, e0); continue; }
-            if (re >= 0) { bai.query((int)t, rb, re, chunks); ++n_regions; }
-            rb = b0; re = e0;
+        const int a_beg = rr.pos, a_end = rr.pos + (ref_len ? ref_len : 1);   // bam_endpos
+        const std::vector<size_t>& cl_ids = *tid_clusters[(size_t)rr.tid];
+        // clusters before `first` end at or before the alignment's start: none of them can overlap it
+        const std::vector<int>& rm = *tid_run_max[(size_t)rr.tid];
+        const size_t first = (size_t)(std::upper_bound(rm.begin(), rm.end(), a_beg) - rm.begin());
+        bool have_tags = false;
+        int64_t hp = 0;
+        for (size_t k = first; k < cl_ids.size(); ++k) {
+          const size_t ci = cl_ids[k];
+          // region "chrom:min_s-max_e" = 0-based half-open [min_s-1, max_e)
+          const int beg0 = std::max(min_s[ci] - 1, 0), end0 = max_e[ci];
+          if (beg0 >= a_end) break;   // clusters are sorted by start
+          if (!(a_beg < end0 && a_end > beg0)) continue;
+          if (!have_tags) {
+            have_tags = true;
+            BamReader::aux_int(rr.aux(), rr.l_aux, "HP", hp);
+            qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
           }
-          if (re >= 0) { bai.query((int)t, rb, re, chunks); ++n_regions; }
+          Ev ev{ci, (int)hp, false, false, std::string(), std::string()};
+          if (reads[ci].find(qname) == reads[ci].end()) { sink(ev); continue; }
+          ev.in_reads = true;
+          // qs: query position of the last aligned (M/=/X) pair with reference position <= min_s;
+          // qe: of the first one with reference position >= max_e
+          int qs = -1, qe = -1, ref_pos = rr.pos, read_pos = 0;
+          for (uint32_t i = 0; i < rr.n_cigar; ++i) {
+            const uint32_t c = cig(i), op = c & 0xf;
+            const int l = (int)(c >> 4);
+            if (op == 0 || op == 7 || op == 8) {
+              if (l > 0) {
+                if (ref_pos <= min_s[ci]) qs = read_pos + (std::min(min_s[ci], ref_pos + l - 1) - ref_pos);
+                if (qe == -1 && ref_pos + l - 1 >= max_e[ci]) qe = read_pos + (std::max(max_e[ci], ref_pos) - ref_pos);
+              }
+              read_pos += l; ref_pos += l;
+            } else if (op == 1 || op == 4) read_pos += l;
+            else if (op == 2 || op == 3) ref_pos += l;
+          }
+          if (qs == -1 || qe == -1) ev.unext = true;
+          else {
+            if (qs > rr.l_seq) die("corrupt alignment: sub-read start past the end of read " + qname);   // (std::string::substr throws in the reference)
+            const int n = std::max(0, std::min(qe - qs + 1, rr.l_seq - qs));
+            const uint8_t* sq = rr.seq4();
+            std::string sub((size_t)n, 'N');
+            for (int i = 0; i < n; ++i) { const int q = qs + i; sub[(size_t)i] = NT16[(sq[q >> 1] >> ((~q & 1) << 2)) & 0xf]; }
+            ev.name = qname;
+            ev.sub = std::move(sub);
+          }
+          sink(ev);
         }
-        BaiIndex::merge(chunks);
-        logmsg("debug", "pass 2 through the BAI index: " + std::to_string(n_regions) + " regions, " + std::to_string(chunks.size()) +
-                            " file chunks");
-        const std::string e = bam_scan_chunks(o.bam, chunks, [&](const BamReader::RawView& rr) { process(rr, qname, apply); });
-        if (!e.empty()) die("error reading " + o.bam + ": " + e);
+      };
+      if (cache_ok) {
+        stage("pass 2: setup");
+        const size_t n = cache_views.size();
+        const size_t W = std::max<size_t>(1, std::min<size_t>({(size_t)effective_cpus(), (size_t)32, n / 4096 + 1}));
+        std::vector<std::vector<Ev>> evs(W);
+        auto range = [&](size_t w) {
+          std::string nm;
+          auto sink = [&](Ev& e) { evs[w].push_back(std::move(e)); };
+          for (size_t i = n * w / W; i < n * (w + 1) / W; ++i) process(cache_views[i], nm, sink);
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < W; ++w) pool.emplace_back(range, w);
+        range(0);
+        for (std::thread& th : pool) th.join();
+        stage("pass 2: scan");
+        for (size_t w = 0; w < W; ++w)
+          for (Ev& e : evs[w]) apply(e);
+        stage("pass 2: apply");
+        // (gigabytes of inflated records: released while the DP batches run)
+        cache_release = std::thread([v = std::move(cache_views), c = std::move(cache_chunks)]() mutable { v.clear(); c.clear(); });
       } else {
-        BamReader bam(o.bam);
-        svdss_enable_gpu_inflate(bam);
-        if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
-        BamReader::RawView rr;   // zero-copy: the record is used where it was inflated, within this iteration only
-        int rc;
-        while ((rc = bam.next_view(rr)) > 0) process(rr, qname, apply);
-        if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
-      }
-    }
-    for (size_t i = 0; i < clusters.size(); ++i) {
-      if (!live[i]) { clusters[i].reads.clear(); clusters[i].subreads.clear(); continue; }
-      if ((int)clusters[i].size() >= o.min_cluster_weight) {
-        clusters[i].cov0 = cov[i][0]; clusters[i].cov1 = cov[i][1]; clusters[i].cov2 = cov[i][2];
-        clusters[i].cov = cov[i][0] + cov[i][1] + cov[i][2];
-      } else ++C.small2;
-    }
-  }
-  stage("pass 2: fill_clusters");
-  // ---- store_clusters (clusterer.cpp:613-626): every cluster, also the filtered ones (their coordinates are
-  // uninitialised in the reference; 0 here)
-  if (!o.clusters.empty()) {
-    logmsg("info", "Storing clusters to " + o.clusters);
-    FILE* f = fopen(o.clusters.c_str(), "w");
-    if (!f) die("cannot write " + o.clusters);
-    std::string line;
-    for (const Cluster& c : clusters) {
-      line = c.chrom + ":" + std::to_string(c.s + 1) + "-" + std::to_string(c.e + 1) + "\t" + std::to_string(c.size());
-      for (const SubRead& sr : c.subreads) { line += "\t"; line += sr.name; line += ":"; line += sr.seq; }
-      line += "\n";
-      fwrite(line.data(), 1, line.size(), f);
-    }
-    fclose(f);
-  }
-  logmsg("info", "Calling SVs from " + std::to_string(clusters.size()) + " clusters..");
-  // (SVDSS_GPUS_OVERSUBSCRIBE: more shards than GPUs, shard g on GPU g % count -- exercises the sharding on a one-GPU box)
-  const int n_dev = std::max(1, svdss_device_count());
-  const int G = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev));
-  // ---- pcall (caller.cpp:311-406): split, then the three GPU batches
-  struct Sub { size_t parent; Cluster cl; };
-  std::vector<Sub> subs;
-  for (size_t i = 0; i < clusters.size(); ++i) {
-    if ((int)clusters[i].size() < o.min_cluster_weight) continue;
-    for (Cluster& cl : split_cluster(clusters[i], o.useht, o.min_ratio)) subs.push_back(Sub{i, std::move(cl)});
-  }
-  stage("split_cluster");
-  std::vector<std::string> consensus(subs.size());
-  if (!subs.empty()) {
-    std::vector<uint8_t> flat;
-    std::vector<int64_t> seq_off(1, 0), cl_off(1, 0);
-    for (const Sub& s : subs) {
-      for (const SubRead& sr : s.cl.subreads) {
-        for (char ch : sr.seq) flat.push_back(enc26(ch));
-        seq_off.push_back((int64_t)flat.size());
-      }
-      cl_off.push_back((int64_t)seq_off.size() - 1);
-    }
-    // --gpus G: sub-cluster k goes to GPU k % G (no exchange between the GPUs: a sub-cluster is self-contained), the
-    // consensus sequences come back in sub-cluster order -- the same bytes as with one GPU
-    std::vector<int64_t> lens(subs.size());
-    std::vector<uint8_t> cons;
-    {
-      const size_t nsub = subs.size();
-      std::vector<std::vector<uint8_t>> part_cons((size_t)G);
-      std::vector<std::vector<int64_t>> part_lens((size_t)G);
-      std::vector<std::thread> pool;
-      auto run = [&](int g) {
-        std::vector<uint8_t> f;
-        std::vector<int64_t> so(1, 0), co(1, 0);
-        for (size_t k = (size_t)g; k < nsub; k += (size_t)G) {
-          for (int64_t sq = cl_off[k]; sq < cl_off[k + 1]; ++sq) {
-            f.insert(f.end(), flat.begin() + seq_off[(size_t)sq], flat.begin() + seq_off[(size_t)sq + 1]);
-            so.push_back((int64_t)f.size());
-          }
-          co.push_back((int64_t)so.size() - 1);
+        // the records of pass 1 did not fit in memory.  With a BAI index beside the file (what the reference requires:
+        // sam_index_load + one sam_itr_querys per cluster, clusterer.cpp:495-527) only the file chunks around the
+        // clusters are read -- all regions turned into one sorted, merged chunk list, read once in file order, which
+        // visits the same records in the same order as the full scan below does among those that touch a cluster
+        BaiIndex bai;
+        bool have_bai = false;
+        if (!getenv("SVDSS_CALL_NO_BAI")) {
+          have_bai = bai.load(o.bam + ".bai");
+          if (!have_bai && o.bam.size() > 4 && o.bam.compare(o.bam.size() - 4, 4, ".bam") == 0)
+            have_bai = bai.load(o.bam.substr(0, o.bam.size() - 4) + ".bai");
+          if (have_bai && bai.refs.size() != ref_names.size()) have_bai = false;
         }
-        svdss_poa_batch_t* pb = nullptr;
-        check(svdss_poa_consensus_batch(G == 1 ? flat.data() : f.data(), G == 1 ? seq_off.data() : so.data(),
-                                        G == 1 ? cl_off.data() : co.data(), (int64_t)co.size() - 1, g % n_dev, &pb),
-              "svdss_poa_consensus_batch");
-        part_lens[(size_t)g].resize(co.size() - 1);
-        part_cons[(size_t)g].resize((size_t)svdss_poa_batch_total(pb));
-        check(svdss_poa_batch_fetch(pb, part_lens[(size_t)g].data(), part_cons[(size_t)g].data()), "svdss_poa_batch_fetch");
-        svdss_poa_batch_free(pb);
-      };
-      for (int g = 1; g < G; ++g) pool.emplace_back(run, g);
-      run(0);
-      for (std::thread& th : pool) th.join();
-      std::vector<size_t> at((size_t)G, 0), idx((size_t)G, 0);
-      for (size_t k = 0; k < nsub; ++k) {
-        const size_t g = k % (size_t)G;
-        lens[k] = part_lens[g][idx[g]++];
-        cons.insert(cons.end(), part_cons[g].begin() + (long)at[g], part_cons[g].begin() + (long)(at[g] + (size_t)lens[k]));
-        at[g] += (size_t)lens[k];
-      }
-    }
-    size_t p = 0;
-    for (size_t i = 0; i < subs.size(); ++i) {
-      consensus[i].resize((size_t)lens[i]);
-      for (int64_t k = 0; k < lens[i]; ++k) consensus[i][(size_t)k] = "ACGTN"[cons[p++]];   // caller.cpp:297
-    }
-  }
-  stage("POA");
-  std::vector<SV> svs;
-  std::vector<std::vector<std::string>> sam_rows;   // per reference thread, --poa only
-  if (!subs.empty()) {
-    const int8_t a = 1, b = -9;   // caller.cpp:333-337
-    const int8_t mat[25] = {a, b, b, b, 0, b, a, b, b, 0, b, b, a, b, 0, b, b, b, a, 0, 0, 0, 0, 0, 0};
-    std::vector<uint8_t> q, t;
-    std::vector<int64_t> qo(1, 0), to(1, 0);
-    for (size_t i = 0; i < subs.size(); ++i) {
-      const Cluster& cl = subs[i].cl;
-      const std::string& cs = C.chrom_seqs[cl.chrom];
-      for (char ch : consensus[i]) q.push_back(enc26(ch));
-      qo.push_back((int64_t)q.size());
-      for (int p = cl.s; p <= cl.e && p < (int)cs.size(); ++p) t.push_back(enc26(cs[(size_t)p]));   // caller.cpp:329
-      to.push_back((int64_t)t.size());
-    }
-    std::vector<int32_t> scores(subs.size());
-    std::vector<int64_t> ncig(subs.size());
-    std::vector<uint32_t> cig;
-    {
-      const size_t nsub = subs.size();
-      std::vector<std::vector<int32_t>> p_sc((size_t)G);
-      std::vector<std::vector<int64_t>> p_nc((size_t)G);
-      std::vector<std::vector<uint32_t>> p_cg((size_t)G);
-      std::vector<std::thread> pool;
-      auto run = [&](int g) {
-        std::vector<uint8_t> q2, t2;
-        std::vector<int64_t> qo2(1, 0), to2(1, 0);
-        if (G > 1)
-          for (size_t k = (size_t)g; k < nsub; k += (size_t)G) {
-            q2.insert(q2.end(), q.begin() + qo[k], q.begin() + qo[k + 1]);
-            qo2.push_back((int64_t)q2.size());
-            t2.insert(t2.end(), t.begin() + to[k], t.begin() + to[k + 1]);
-            to2.push_back((int64_t)t2.size());
+        if (have_bai) {
+          std::vector<std::pair<uint64_t, uint64_t>> chunks;
+          size_t n_regions = 0;
+          for (size_t t = 0; t < ref_names.size(); ++t) {
+            if (!tid_clusters[t]) continue;
+            int64_t rb = -1, re = -1;   // current merged region
+            for (size_t ci : *tid_clusters[t]) {
+              const int64_t b0 = std::max(min_s[ci] - 1, 0), e0 = max_e[ci];
+              if (re >= 0 && b0 <= re) { re = std::max(re, e0); continue; }
+              if (re >= 0) { bai.query((int)t, rb, re, chunks); ++n_regions; }
+              rb = b0; re = e0;
+            }
+            if (re >= 0) { bai.query((int)t, rb, re, chunks); ++n_regions; }
           }
-        const int64_t np = G == 1 ? (int64_t)nsub : (int64_t)qo2.size() - 1;
-        svdss_aln_batch_t* ab = nullptr;
-        check(svdss_align_global_batch(G == 1 ? q.data() : q2.data(), G == 1 ? qo.data() : qo2.data(),
-                                       G == 1 ? t.data() : t2.data(), G == 1 ? to.data() : to2.data(), np, 5, mat, 16, 2, 41,
-                                       1, g % n_dev, &ab), "svdss_align_global_batch");
-        p_sc[(size_t)g].resize((size_t)np);
-        p_nc[(size_t)g].resize((size_t)np);
-        p_cg[(size_t)g].resize((size_t)svdss_aln_batch_total_cigar(ab));
-        check(svdss_aln_batch_fetch(ab, p_sc[(size_t)g].data(), p_nc[(size_t)g].data(), p_cg[(size_t)g].data()),
-              "svdss_aln_batch_fetch");
-        svdss_aln_batch_free(ab);
-      };
-      for (int g = 1; g < G; ++g) pool.emplace_back(run, g);
-      run(0);
-      for (std::thread& th : pool) th.join();
-      std::vector<size_t> at((size_t)G, 0), idx((size_t)G, 0);
-      for (size_t k = 0; k < nsub; ++k) {
-        const size_t g = k % (size_t)G;
-        scores[k] = p_sc[g][idx[g]];
-        ncig[k] = p_nc[g][idx[g]++];
-        cig.insert(cig.end(), p_cg[g].begin() + (long)at[g], p_cg[g].begin() + (long)(at[g] + (size_t)ncig[k]));
-        at[g] += (size_t)ncig[k];
-      }
-    }
-    std::vector<std::vector<SV>> per_thread((size_t)T);
-    sam_rows.resize((size_t)T);
-    size_t cp = 0;
-    for (size_t i = 0; i < subs.size(); ++i) {
-      const Cluster& cl = subs[i].cl;
-      const Cluster& parent = clusters[subs[i].parent];
-      const std::string& cs = C.chrom_seqs[cl.chrom];
-      std::string cigar_str;
-      for (int64_t k = 0; k < ncig[i]; ++k) cigar_str += std::to_string(cig[cp + (size_t)k] >> 4) + "MID"[cig[cp + (size_t)k] & 0xf];
-      if (!o.poa.empty()) {   // Consensus, caller.hpp:56-69 / caller.cpp:356-357
-        const std::string p1 = std::to_string(cl.s + 1);
-        sam_rows[subs[i].parent % (size_t)T].push_back(cl.chrom + ":" + p1 + "-" + std::to_string(cl.e + 1) + "\t0\t" + cl.chrom +
-                                                       "\t" + p1 + "\t60\t" + cigar_str + "\t*\t0\t0\t" + consensus[i] + "\t*");
-      }
-      std::string names;
-      for (const SubRead& sr : cl.subreads) names += sr.name + ",";
-      if (!names.empty()) names.pop_back();
-      std::string rvec;
-      for (const auto& rd : parent.reads) rvec += std::to_string(rd.first) + ":" + std::to_string(rd.second) + "-";
-      if (!rvec.empty()) rvec.pop_back();
-      std::vector<SV> local;
-      unsigned rpos = (unsigned)cl.s, cpos = 0;
-      int nv = 0;
-      for (int64_t k = 0; k < ncig[i]; ++k) {
-        const unsigned l = cig[cp + (size_t)k] >> 4;
-        const char op = "MID"[cig[cp + (size_t)k] & 0xf];
-        if (op == 'M') { rpos += l; cpos += l; }
-        else if (op == 'I') {
-          if (l >= (unsigned)o.min_sv_length) {
-            const std::string anchor(1, cs[rpos - 1]);
-            SV v = make_sv("INS", cl.chrom, (int)rpos, anchor, anchor + consensus[i].substr(cpos, l), (unsigned)cl.size(),
-                           cl.cov, nv, scores[i], (int)l, cigar_str);
-            v.reads = names;
-            local.push_back(v);
-            ++nv;
-          }
-          cpos += l;
+          BaiIndex::merge(chunks);
+          logmsg("debug", "pass 2 through the BAI index: " + std::to_string(n_regions) + " regions, " + std::to_string(chunks.size()) +
+                              " file chunks");
+          const std::string e = bam_scan_chunks(o.bam, chunks, [&](const BamReader::RawView& rr) { process(rr, qname, apply); });
+          if (!e.empty()) die("error reading " + o.bam + ": " + e);
         } else {
-          if (l >= (unsigned)o.min_sv_length) {
-            SV v = make_sv("DEL", cl.chrom, (int)rpos, cs.substr(rpos - 1, l + 1), std::string(1, cs[rpos - 1]),
-                           (unsigned)cl.size(), cl.cov, nv, scores[i], (int)l, cigar_str);
-            v.reads = names;
-            local.push_back(v);
-            ++nv;
+          BamReader bam(o.bam);
+          svdss_enable_gpu_inflate(bam);
+          if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
+          BamReader::RawView rr;   // zero-copy: the record is used where it was inflated, within this iteration only
+          int rc;
+          while ((rc = bam.next_view(rr)) > 0) process(rr, qname, apply);
+          if (rc < 0) die("error reading " + o.bam + ": " + bam.error());
+        }
+      }
+      for (size_t i = 0; i < clusters.size(); ++i) {
+        if (!live[i]) { clusters[i].reads.clear(); clusters[i].subreads.clear(); continue; }
+        if ((int)clusters[i].size() >= o.min_cluster_weight) {
+          clusters[i].cov0 = cov[i][0]; clusters[i].cov1 = cov[i][1]; clusters[i].cov2 = cov[i][2];
+          clusters[i].cov = cov[i][0] + cov[i][1] + cov[i][2];
+        } else ++C.small2;
+      }
+    }
+    stage("pass 2: fill_clusters");
+  }
+
+  // Clusterer::store_clusters (clusterer.cpp:613-626), then Caller::split_cluster (caller.cpp:100-255)
+  void store_and_split() {
+    // ---- store_clusters (clusterer.cpp:613-626): every cluster, also the filtered ones (their coordinates are
+    // uninitialised in the reference; 0 here)
+    if (!o.clusters.empty()) {
+      logmsg("info", "Storing clusters to " + o.clusters);
+      FILE* f = fopen(o.clusters.c_str(), "w");
+      if (!f) die("cannot write " + o.clusters);
+      std::string line;
+      for (const Cluster& c : clusters) {
+        line = c.chrom + ":" + std::to_string(c.s + 1) + "-" + std::to_string(c.e + 1) + "\t" + std::to_string(c.size());
+        for (const SubRead& sr : c.subreads) { line += "\t"; line += sr.name; line += ":"; line += sr.seq; }
+        line += "\n";
+        fwrite(line.data(), 1, line.size(), f);
+      }
+      fclose(f);
+    }
+    logmsg("info", "Calling SVs from " + std::to_string(clusters.size()) + " clusters..");
+    // (SVDSS_GPUS_OVERSUBSCRIBE: more shards than GPUs, shard g on GPU g % count -- exercises the sharding on a one-GPU box)
+    n_dev = std::max(1, svdss_device_count());
+    G = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev));
+    // ---- pcall (caller.cpp:311-406): split, then the three GPU batches
+    for (size_t i = 0; i < clusters.size(); ++i) {
+      if ((int)clusters[i].size() < o.min_cluster_weight) continue;
+      for (Cluster& cl : split_cluster(clusters[i], o.useht, o.min_ratio)) subs.push_back(Sub{i, std::move(cl)});
+    }
+    stage("split_cluster");
+  }
+
+  // Caller::run_poa for every sub-cluster (caller.cpp:257-308), one GPU batch per device
+  void run_poa() {
+    consensus.assign(subs.size(), std::string());
+    if (!subs.empty()) {
+      std::vector<uint8_t> flat;
+      std::vector<int64_t> seq_off(1, 0), cl_off(1, 0);
+      for (const Sub& s : subs) {
+        for (const SubRead& sr : s.cl.subreads) {
+          for (char ch : sr.seq) flat.push_back(enc26(ch));
+          seq_off.push_back((int64_t)flat.size());
+        }
+        cl_off.push_back((int64_t)seq_off.size() - 1);
+      }
+      // --gpus G: sub-cluster k goes to GPU k % G (no exchange between the GPUs: a sub-cluster is self-contained), the
+      // consensus sequences come back in sub-cluster order -- the same bytes as with one GPU
+      std::vector<int64_t> lens(subs.size());
+      std::vector<uint8_t> cons;
+      {
+        const size_t nsub = subs.size();
+        std::vector<std::vector<uint8_t>> part_cons((size_t)G);
+        std::vector<std::vector<int64_t>> part_lens((size_t)G);
+        std::vector<std::thread> pool;
+        auto run = [&](int g) {
+          std::vector<uint8_t> f;
+          std::vector<int64_t> so(1, 0), co(1, 0);
+          for (size_t k = (size_t)g; k < nsub; k += (size_t)G) {
+            for (int64_t sq = cl_off[k]; sq < cl_off[k + 1]; ++sq) {
+              f.insert(f.end(), flat.begin() + seq_off[(size_t)sq], flat.begin() + seq_off[(size_t)sq + 1]);
+              so.push_back((int64_t)f.size());
+            }
+            co.push_back((int64_t)so.size() - 1);
           }
-          rpos += l;
+          svdss_poa_batch_t* pb = nullptr;
+          check(svdss_poa_consensus_batch(G == 1 ? flat.data() : f.data(), G == 1 ? seq_off.data() : so.data(),
+                                          G == 1 ? cl_off.data() : co.data(), (int64_t)co.size() - 1, g % n_dev, &pb),
+                "svdss_poa_consensus_batch");
+          part_lens[(size_t)g].resize(co.size() - 1);
+          part_cons[(size_t)g].resize((size_t)svdss_poa_batch_total(pb));
+          check(svdss_poa_batch_fetch(pb, part_lens[(size_t)g].data(), part_cons[(size_t)g].data()), "svdss_poa_batch_fetch");
+          svdss_poa_batch_free(pb);
+        };
+        for (int g = 1; g < G; ++g) pool.emplace_back(run, g);
+        run(0);
+        for (std::thread& th : pool) th.join();
+        std::vector<size_t> at((size_t)G, 0), idx((size_t)G, 0);
+        for (size_t k = 0; k < nsub; ++k) {
+          const size_t g = k % (size_t)G;
+          lens[k] = part_lens[g][idx[g]++];
+          cons.insert(cons.end(), part_cons[g].begin() + (long)at[g], part_cons[g].begin() + (long)(at[g] + (size_t)lens[k]));
+          at[g] += (size_t)lens[k];
         }
       }
-      cp += (size_t)ncig[i];
-      for (SV& v : local) {
-        v.ngaps = nv; v.gt = "0/1"; v.gtq = 100;
-        v.cov = cl.cov; v.cov0 = cl.cov0; v.cov1 = cl.cov1; v.cov2 = cl.cov2;
-        v.rvec = rvec;
-        per_thread[subs[i].parent % (size_t)T].push_back(v);
+      size_t p = 0;
+      for (size_t i = 0; i < subs.size(); ++i) {
+        consensus[i].resize((size_t)lens[i]);
+        for (int64_t k = 0; k < lens[i]; ++k) consensus[i][(size_t)k] = "ACGTN"[cons[p++]];   // caller.cpp:297
       }
     }
-    for (int t = 0; t < T; ++t) svs.insert(svs.begin(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());   // caller.cpp:18-22
+    stage("POA");
   }
-  stage("realign + SV extraction");
-  std::sort(svs.begin(), svs.end());   // same libstdc++ std::sort as the reference (caller.cpp:23)
-  {   // clean_dups (caller.cpp:409-426)
-    std::vector<SV> kept;
-    std::string lc, lr, la; int lp = -1;
-    for (const SV& v : svs) {
-      if (lc != v.chrom || lp != v.s || lr != v.refall || la != v.altall) kept.push_back(v);
-      lc = v.chrom; lp = v.s; lr = v.refall; la = v.altall;
-    }
-    svs.swap(kept);
-  }
-  if (svs.size() >= 2) {   // filter_sv_chains (caller.cpp:429-475): ratios of adjacent candidates in one batch
-    std::vector<size_t> cand;
-    std::vector<uint8_t> A, B;
-    std::vector<int64_t> ao(1, 0), bo(1, 0);
-    for (size_t i = 1; i < svs.size(); ++i) {
-      const SV &prev = svs[i - 1], &sv = svs[i];
-      if (sv.chrom == prev.chrom && sv.s - prev.e < 2 * sv.l && prev.type == sv.type) {
-        const double w_r = std::min((double)sv.w, (double)prev.w) / std::max((double)sv.w, (double)prev.w);
-        const double l_r = std::min((double)sv.l, (double)prev.l) / std::max((double)sv.l, (double)prev.l);
-        const int d = sv.s - prev.s;
-        if (d < 100 && w_r >= 0.9 && l_r >= o.min_ratio) {
-          const std::string& x = sv.type == "DEL" ? sv.refall : sv.altall;
-          const std::string& y = sv.type == "DEL" ? prev.refall : prev.altall;
-          A.insert(A.end(), x.begin(), x.end()); ao.push_back((int64_t)A.size());
-          B.insert(B.end(), y.begin(), y.end()); bo.push_back((int64_t)B.size());
-          cand.push_back(i);
+
+  // ksw_extd2 of every consensus against its window, SV extraction (caller.cpp:326-406)
+  void realign_and_extract() {
+    if (!subs.empty()) {
+      const int8_t a = 1, b = -9;   // caller.cpp:333-337
+      const int8_t mat[25] = {a, b, b, b, 0, b, a, b, b, 0, b, b, a, b, 0, b, b, b, a, 0, 0, 0, 0, 0, 0};
+      std::vector<uint8_t> q, t;
+      std::vector<int64_t> qo(1, 0), to(1, 0);
+      for (size_t i = 0; i < subs.size(); ++i) {
+        const Cluster& cl = subs[i].cl;
+        const std::string& cs = C.chrom_seqs[cl.chrom];
+        for (char ch : consensus[i]) q.push_back(enc26(ch));
+        qo.push_back((int64_t)q.size());
+        for (int p = cl.s; p <= cl.e && p < (int)cs.size(); ++p) t.push_back(enc26(cs[(size_t)p]));   // caller.cpp:329
+        to.push_back((int64_t)t.size());
+      }
+      std::vector<int32_t> scores(subs.size());
+      std::vector<int64_t> ncig(subs.size());
+      std::vector<uint32_t> cig;
+      {
+        const size_t nsub = subs.size();
+        std::vector<std::vector<int32_t>> p_sc((size_t)G);
+        std::vector<std::vector<int64_t>> p_nc((size_t)G);
+        std::vector<std::vector<uint32_t>> p_cg((size_t)G);
+        std::vector<std::thread> pool;
+        auto run = [&](int g) {
+          std::vector<uint8_t> q2, t2;
+          std::vector<int64_t> qo2(1, 0), to2(1, 0);
+          if (G > 1)
+            for (size_t k = (size_t)g; k < nsub; k += (size_t)G) {
+              q2.insert(q2.end(), q.begin() + qo[k], q.begin() + qo[k + 1]);
+              qo2.push_back((int64_t)q2.size());
+              t2.insert(t2.end(), t.begin() + to[k], t.begin() + to[k + 1]);
+              to2.push_back((int64_t)t2.size());
+            }
+          const int64_t np = G == 1 ? (int64_t)nsub : (int64_t)qo2.size() - 1;
+          svdss_aln_batch_t* ab = nullptr;
+          check(svdss_align_global_batch(G == 1 ? q.data() : q2.data(), G == 1 ? qo.data() : qo2.data(),
+                                         G == 1 ? t.data() : t2.data(), G == 1 ? to.data() : to2.data(), np, 5, mat, 16, 2, 41,
+                                         1, g % n_dev, &ab), "svdss_align_global_batch");
+          p_sc[(size_t)g].resize((size_t)np);
+          p_nc[(size_t)g].resize((size_t)np);
+          p_cg[(size_t)g].resize((size_t)svdss_aln_batch_total_cigar(ab));
+          check(svdss_aln_batch_fetch(ab, p_sc[(size_t)g].data(), p_nc[(size_t)g].data(), p_cg[(size_t)g].data()),
+                "svdss_aln_batch_fetch");
+          svdss_aln_batch_free(ab);
+        };
+        for (int g = 1; g < G; ++g) pool.emplace_back(run, g);
+        run(0);
+        for (std::thread& th : pool) th.join();
+        std::vector<size_t> at((size_t)G, 0), idx((size_t)G, 0);
+        for (size_t k = 0; k < nsub; ++k) {
+          const size_t g = k % (size_t)G;
+          scores[k] = p_sc[g][idx[g]];
+          ncig[k] = p_nc[g][idx[g]++];
+          cig.insert(cig.end(), p_cg[g].begin() + (long)at[g], p_cg[g].begin() + (long)(at[g] + (size_t)ncig[k]));
+          at[g] += (size_t)ncig[k];
         }
       }
+      std::vector<std::vector<SV>> per_thread((size_t)T);
+      sam_rows.resize((size_t)T);
+      size_t cp = 0;
+      for (size_t i = 0; i < subs.size(); ++i) {
+        const Cluster& cl = subs[i].cl;
+        const Cluster& parent = clusters[subs[i].parent];
+        const std::string& cs = C.chrom_seqs[cl.chrom];
+        std::string cigar_str;
+        for (int64_t k = 0; k < ncig[i]; ++k) cigar_str += std::to_string(cig[cp + (size_t)k] >> 4) + "MID"[cig[cp + (size_t)k] & 0xf];
+        if (!o.poa.empty()) {   // Consensus, caller.hpp:56-69 / caller.cpp:356-357
+          const std::string p1 = std::to_string(cl.s + 1);
+          sam_rows[subs[i].parent % (size_t)T].push_back(cl.chrom + ":" + p1 + "-" + std::to_string(cl.e + 1) + "\t0\t" + cl.chrom +
+                                                         "\t" + p1 + "\t60\t" + cigar_str + "\t*\t0\t0\t" + consensus[i] + "\t*");
+        }
+        std::string names;
+        for (const SubRead& sr : cl.subreads) names += sr.name + ",";
+        if (!names.empty()) names.pop_back();
+        std::string rvec;
+        for (const auto& rd : parent.reads) rvec += std::to_string(rd.first) + ":" + std::to_string(rd.second) + "-";
+        if (!rvec.empty()) rvec.pop_back();
+        std::vector<SV> local;
+        unsigned rpos = (unsigned)cl.s, cpos = 0;
+        int nv = 0;
+        for (int64_t k = 0; k < ncig[i]; ++k) {
+          const unsigned l = cig[cp + (size_t)k] >> 4;
+          const char op = "MID"[cig[cp + (size_t)k] & 0xf];
+          if (op == 'M') { rpos += l; cpos += l; }
+          else if (op == 'I') {
+            if (l >= (unsigned)o.min_sv_length) {
+              const std::string anchor(1, cs[rpos - 1]);
+              SV v = make_sv("INS", cl.chrom, (int)rpos, anchor, anchor + consensus[i].substr(cpos, l), (unsigned)cl.size(),
+                             cl.cov, nv, scores[i], (int)l, cigar_str);
+              v.reads = names;
+              local.push_back(v);
+              ++nv;
+            }
+            cpos += l;
+          } else {
+            if (l >= (unsigned)o.min_sv_length) {
+              SV v = make_sv("DEL", cl.chrom, (int)rpos, cs.substr(rpos - 1, l + 1), std::string(1, cs[rpos - 1]),
+                             (unsigned)cl.size(), cl.cov, nv, scores[i], (int)l, cigar_str);
+              v.reads = names;
+              local.push_back(v);
+              ++nv;
+            }
+            rpos += l;
+          }
+        }
+        cp += (size_t)ncig[i];
+        for (SV& v : local) {
+          v.ngaps = nv; v.gt = "0/1"; v.gtq = 100;
+          v.cov = cl.cov; v.cov0 = cl.cov0; v.cov1 = cl.cov1; v.cov2 = cl.cov2;
+          v.rvec = rvec;
+          per_thread[subs[i].parent % (size_t)T].push_back(v);
+        }
+      }
+      for (int t = 0; t < T; ++t) svs.insert(svs.begin(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());   // caller.cpp:18-22
     }
-    std::map<size_t, double> sim;
-    if (!cand.empty()) {
-      std::vector<double> ratio(cand.size());
-      uint8_t dummy = 0;
-      check(svdss_indel_ratio_batch(A.empty() ? &dummy : A.data(), ao.data(), B.empty() ? &dummy : B.data(), bo.data(),
-                                    (int64_t)cand.size(), 0, ratio.data(), nullptr), "svdss_indel_ratio_batch");
-      for (size_t k = 0; k < cand.size(); ++k) sim[cand[k]] = ratio[k];
+    stage("realign + SV extraction");
+  }
+
+  // sort, clean_dups, filter_sv_chains, sort (caller.cpp:23-28, 409-475)
+  void dedup_and_filter() {
+    std::sort(svs.begin(), svs.end());   // same libstdc++ std::sort as the reference (caller.cpp:23)
+    {   // clean_dups (caller.cpp:409-426)
+      std::vector<SV> kept;
+      std::string lc, lr, la; int lp = -1;
+      for (const SV& v : svs) {
+        if (lc != v.chrom || lp != v.s || lr != v.refall || la != v.altall) kept.push_back(v);
+        lc = v.chrom; lp = v.s; lr = v.refall; la = v.altall;
+      }
+      svs.swap(kept);
     }
-    std::vector<SV> kept;
-    SV prev = svs[0];
-    bool reset = false;
-    for (size_t i = 1; i < svs.size(); ++i) {
-      if (reset) { reset = false; prev = svs[i]; continue; }
-      const SV& sv = svs[i];
-      auto it = sim.find(i);
-      if (it != sim.end() && it->second > 70) { kept.push_back(sv.w > prev.w ? sv : prev); reset = true; continue; }
+    if (svs.size() >= 2) {   // filter_sv_chains (caller.cpp:429-475): ratios of adjacent candidates in one batch
+      std::vector<size_t> cand;
+      std::vector<uint8_t> A, B;
+      std::vector<int64_t> ao(1, 0), bo(1, 0);
+      for (size_t i = 1; i < svs.size(); ++i) {
+        const SV &prev = svs[i - 1], &sv = svs[i];
+        if (sv.chrom == prev.chrom && sv.s - prev.e < 2 * sv.l && prev.type == sv.type) {
+          const double w_r = std::min((double)sv.w, (double)prev.w) / std::max((double)sv.w, (double)prev.w);
+          const double l_r = std::min((double)sv.l, (double)prev.l) / std::max((double)sv.l, (double)prev.l);
+          const int d = sv.s - prev.s;
+          if (d < 100 && w_r >= 0.9 && l_r >= o.min_ratio) {
+            const std::string& x = sv.type == "DEL" ? sv.refall : sv.altall;
+            const std::string& y = sv.type == "DEL" ? prev.refall : prev.altall;
+            A.insert(A.end(), x.begin(), x.end()); ao.push_back((int64_t)A.size());
+            B.insert(B.end(), y.begin(), y.end()); bo.push_back((int64_t)B.size());
+            cand.push_back(i);
+          }
+        }
+      }
+      std::map<size_t, double> sim;
+      if (!cand.empty()) {
+        std::vector<double> ratio(cand.size());
+        uint8_t dummy = 0;
+        check(svdss_indel_ratio_batch(A.empty() ? &dummy : A.data(), ao.data(), B.empty() ? &dummy : B.data(), bo.data(),
+                                      (int64_t)cand.size(), 0, ratio.data(), nullptr), "svdss_indel_ratio_batch");
+        for (size_t k = 0; k < cand.size(); ++k) sim[cand[k]] = ratio[k];
+      }
+      std::vector<SV> kept;
+      SV prev = svs[0];
+      bool reset = false;
+      for (size_t i = 1; i < svs.size(); ++i) {
+        if (reset) { reset = false; prev = svs[i]; continue; }
+        const SV& sv = svs[i];
+        auto it = sim.find(i);
+        if (it != sim.end() && it->second > 70) { kept.push_back(sv.w > prev.w ? sv : prev); reset = true; continue; }
+        kept.push_back(prev);
+        prev = sv;
+      }
       kept.push_back(prev);
-      prev = sv;
+      svs.swap(kept);
     }
-    kept.push_back(prev);
-    svs.swap(kept);
+    std::sort(svs.begin(), svs.end());
+    stage("dups + chain filter");
+    // ---- write_vcf (caller.cpp:59-63, 477-550)
   }
-  std::sort(svs.begin(), svs.end());
-  stage("dups + chain filter");
-  // ---- write_vcf (caller.cpp:59-63, 477-550)
-  std::string out = "##fileformat=VCFv4.2\n##reference=ftp://ftp.1000genomes.ebi.ac.uk/vol1/ftp/data_collections/HGSVC2/"
-                    "technical/reference/20200513_hg38_NoALT/hg38.no_alt.fa.gz\n";
-  for (const std::string& n : C.chrom_names) out += "##contig=<ID=" + n + ",length=" + std::to_string(C.chrom_seqs[n].size()) + ">\n";
-  out += "##FILTER=<ID=PASS,Description=\"All filters passed\">\n";
-  for (const auto& f : VCF_INFO) out += std::string("##INFO=<ID=") + f[0] + ",Number=" + f[1] + ",Type=" + f[2] + ",Description=\"" + f[3] + "\">\n";
-  out += "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n";
-  out += "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype quality\">\n";
-  out += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tDEFAULT\n";
-  for (const SV& v : svs) out += v.line() + "\n";
-  fwrite(out.data(), 1, out.size(), stdout);
-  fflush(stdout);
-  logmsg("info", "Writing " + std::to_string(svs.size()) + " SVs.");
-  stage("vcf");
-  if (cache_release.joinable()) cache_release.join();
-  // ---- write_sam (caller.cpp:65-75): rows in the order of the reference's per-thread lists, each inserted at the
-  // front of the global one (caller.cpp:18-22)
-  if (!o.poa.empty()) {
-    logmsg("info", "Writing POA alignments to " + o.poa + "..");
-    FILE* f = fopen(o.poa.c_str(), "w");
-    if (!f) die("cannot write " + o.poa);
-    std::string hdr = "@HD\tVN:1.4\n";
-    for (const std::string& n : C.chrom_names) hdr += "@SQ\tSN:" + n + "\tLN:" + std::to_string(C.chrom_seqs[n].size()) + "\n";
-    fwrite(hdr.data(), 1, hdr.size(), f);
-    for (size_t t = sam_rows.size(); t-- > 0;)
-      for (const std::string& row : sam_rows[t]) { fwrite(row.data(), 1, row.size(), f); fputc('\n', f); }
-    fclose(f);
-  }
-  if (o.clipped) {   // caller.cpp:36-53: imprecise rows after the VCF, in the Clipper's own order (not sorted)
-    logmsg("warning", "Calling imprecise SVs from clipped alignments is experimental");
-    std::vector<std::pair<int, int>> called;
-    for (const SV& v : svs) called.emplace_back(v.s - 1000, v.e + 1000);
-    const std::vector<SV> rows = call_clipped(clips, C.chrom_names, C.chrom_seqs, T, called);
-    logmsg("info", "Predicted " + std::to_string(rows.size()) + " SVs from clipped alignments");
-    std::string text;
-    for (const SV& v : rows) text += v.line() + "\n";
-    fwrite(text.data(), 1, text.size(), stdout);
+
+  // write_vcf / write_sam / --clipped rows (caller.cpp:36-75, 477-550)
+  void write_outputs() {
+    std::string out = "##fileformat=VCFv4.2\n##reference=ftp://ftp.1000genomes.ebi.ac.uk/vol1/ftp/data_collections/HGSVC2/"
+                      "technical/reference/20200513_hg38_NoALT/hg38.no_alt.fa.gz\n";
+    for (const std::string& n : C.chrom_names) out += "##contig=<ID=" + n + ",length=" + std::to_string(C.chrom_seqs[n].size()) + ">\n";
+    out += "##FILTER=<ID=PASS,Description=\"All filters passed\">\n";
+    for (const auto& f : VCF_INFO) out += std::string("##INFO=<ID=") + f[0] + ",Number=" + f[1] + ",Type=" + f[2] + ",Description=\"" + f[3] + "\">\n";
+    out += "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n";
+    out += "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype quality\">\n";
+    out += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tDEFAULT\n";
+    for (const SV& v : svs) out += v.line() + "\n";
+    fwrite(out.data(), 1, out.size(), stdout);
     fflush(stdout);
+    logmsg("info", "Writing " + std::to_string(svs.size()) + " SVs.");
+    stage("vcf");
+    if (cache_release.joinable()) cache_release.join();
+    // ---- write_sam (caller.cpp:65-75): rows in the order of the reference's per-thread lists, each inserted at the
+    // front of the global one (caller.cpp:18-22)
+    if (!o.poa.empty()) {
+      logmsg("info", "Writing POA alignments to " + o.poa + "..");
+      FILE* f = fopen(o.poa.c_str(), "w");
+      if (!f) die("cannot write " + o.poa);
+      std::string hdr = "@HD\tVN:1.4\n";
+      for (const std::string& n : C.chrom_names) hdr += "@SQ\tSN:" + n + "\tLN:" + std::to_string(C.chrom_seqs[n].size()) + "\n";
+      fwrite(hdr.data(), 1, hdr.size(), f);
+      for (size_t t = sam_rows.size(); t-- > 0;)
+        for (const std::string& row : sam_rows[t]) { fwrite(row.data(), 1, row.size(), f); fputc('\n', f); }
+      fclose(f);
+    }
+    if (o.clipped) {   // caller.cpp:36-53: imprecise rows after the VCF, in the Clipper's own order (not sorted)
+      logmsg("warning", "Calling imprecise SVs from clipped alignments is experimental");
+      std::vector<std::pair<int, int>> called;
+      for (const SV& v : svs) called.emplace_back(v.s - 1000, v.e + 1000);
+      const std::vector<SV> rows = call_clipped(clips, C.chrom_names, C.chrom_seqs, T, called);
+      logmsg("info", "Predicted " + std::to_string(rows.size()) + " SVs from clipped alignments");
+      std::string text;
+      for (const SV& v : rows) text += v.line() + "\n";
+      fwrite(text.data(), 1, text.size(), stdout);
+      fflush(stdout);
+    }
   }
-  return 0;
+
+  int run() {
+    load_inputs();
+    align_and_extend();
+    cluster_by_proximity();
+    fill_clusters();
+    store_and_split();
+    run_poa();
+    realign_and_extract();
+    dedup_and_filter();
+    write_outputs();
+    return 0;
+  }
+};
+
+}  // namespace
+
+int main_call(const CallOptions& o) {
+  CallRun run(o);
+  return run.run();
 }
