@@ -268,12 +268,20 @@ class BamReader {
     gpu_ = api; gpu_device_ = device; gpu_percent_ = std::max(0, std::min(101, percent));   // (101: every chunk)
     gpu_n_devices_ = std::max(1, n_devices);
     pin_hooks().alloc = api.host_alloc; pin_hooks().free_ = api.host_free;
+    // A page-locked allocation of a chunk's size takes ~0.2 s: it pays when the buffer is used again and again (a
+    // 15 GB file: thirty times per loader), not when the whole file is a handful of chunks -- those go through ordinary
+    // memory (a pageable copy of 200 MB costs a tenth of that).  SVDSS_PIN_MIN_CHUNKS overrides the threshold.
+    {
+      const char* e = getenv("SVDSS_PIN_MIN_CHUNKS");
+      const size_t min_chunks = e && *e ? (size_t)atoll(e) : 4 * ahead_;
+      pin_buffers_ = pread_size_ == 0 || (pread_size_ + slab_ - 1) / slab_ >= min_chunks;
+    }
   }
   // Page-locked chunk buffers ahead of the first read.  A page-locked allocation of a chunk's size takes ~0.1 s, and the
   // first `ahead` loaders would each pay for two of them before the first record is seen: a caller with something else
   // to do first (`search` restores its index) runs this beside it.  est_ratio: inflated / compressed size expected.
   void prewarm(double est_ratio = 1.75) {
-    if (!gpu_.inflate || !pread_size_ || !pin_hooks().alloc) return;
+    if (!gpu_.inflate || !pread_size_ || !pin_hooks().alloc || !pin_buffers_) return;
     // compressed: one per loader in flight; inflated: those plus the chunks a batch of records keeps alive while its
     // packed bases are copied out (about as many again)
     const size_t n_file = (pread_size_ + slab_ - 1) / slab_;
@@ -735,7 +743,7 @@ class BamReader {
       try {
         own = take_comp();
         const size_t want = std::min(slab_ + kOverlap, pread_size_ - base);
-        own->alloc(slab_ + kOverlap, gpu_.inflate != nullptr);
+        own->alloc(slab_ + kOverlap, gpu_.inflate != nullptr && pin_buffers_);
         while (own_got < want) {
           const ssize_t k = pread(fileno(f_), own->data() + own_got, want - own_got, (off_t)(base + own_got));
           if (k <= 0) break;
@@ -843,7 +851,7 @@ class BamReader {
       }
     } else cpu_inflight_.fetch_add(1);
     struct CpuDone { std::atomic<int>* c; bool armed; ~CpuDone() { if (armed) c->fetch_sub(1); } } cpu_done{&cpu_inflight_, !on_gpu};
-    take_buffer(c.data, total, on_gpu);
+    take_buffer(c.data, total, on_gpu && pin_buffers_);
     const auto ts2 = std::chrono::steady_clock::now();
     if (on_gpu) {
       struct Blk { int64_t coff; int32_t clen; int32_t isize; int64_t uoff; };
@@ -902,6 +910,7 @@ class BamReader {
 
   static constexpr size_t kOverlap = (size_t)128 << 10;   // a block that starts inside a loader's range ends within this
   size_t pread_size_ = 0;          // file size when the loaders pread their own ranges (0: mapping or stream)
+  bool pin_buffers_ = true;        // chunk buffers of the GPU inflate path are page-locked (large files)
   size_t next_off_ = 0;            // file offset of the next block to locate (guarded by file_m_)
   std::shared_ptr<FreeList> comp_free_ = std::make_shared<FreeList>();
   std::shared_ptr<Bytes> take_comp() {

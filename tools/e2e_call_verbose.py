@@ -18,3 +18,6 @@ for rep in range(2):
     r = subprocess.run([exe, "call", "--reference", fa, "--bam", cbam, "--sfs", sfs, "--threads", "16", "--min-sv-length", "50", "--verbose"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     print("call wall", round(time.perf_counter() - t0, 3))
     print("\n".join(l for l in r.stderr.splitlines() if "[time]" in l))
+t0 = time.perf_counter()
+subprocess.run([exe, "--version"], capture_output=True)
+print("SVDSS --version wall", round(time.perf_counter() - t0, 3))
