@@ -171,7 +171,8 @@ void svdss_inflate_free(svdss_inflate_t* obj);
  * memory; out_stride >= block_bytes + 64, a multiple of 4): 18-byte header with BSIZE, a deflate stream of dynamic-
  * Huffman coded literals (no matches: a level-1-class encoder for packed bases and qualities; incompressible quarters
  * are stored), and 8 bytes LEFT FOR THE CALLER to fill with CRC32 and ISIZE; out_len[i] = the member's length with
- * those 8 bytes.  Any inflater reads the result; it is not the byte stream zlib would write.  Returns when done (the
+ * those 8 bytes.  out_stride 0: the members are written back to back instead (out needs in_bytes + 64 per block).
+ * Any inflater reads the result; it is not the byte stream zlib would write.  Returns when done (the
  * object's own stream: calls on different objects overlap). */
 typedef struct svdss_deflate svdss_deflate_t;
 int svdss_bgzf_deflate(svdss_deflate_t** obj, int32_t device, const uint8_t* in, int64_t in_bytes, int32_t block_bytes,

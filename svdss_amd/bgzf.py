@@ -67,10 +67,11 @@ def gpu_inflate(data, blocks, device=0, uoff=None):
     return out[:total]
 
 
-def gpu_deflate(data, block_bytes=0xff00, device=0, return_stats=False):
+def gpu_deflate(data, block_bytes=0xff00, device=0, return_stats=False, dense=False):
     """BGZF members written by the GPU encoder (svdss_bgzf_deflate, csrc/deflate.hip) for `data` cut into blocks of
     block_bytes; the CRC32 / ISIZE footers are filled in here, as the binary's writer does (csrc/bam_writer.h).
-    Returns the concatenated members (bytes) -- a valid BGZF stream without the EOF marker block."""
+    Returns the concatenated members (bytes) -- a valid BGZF stream without the EOF marker block.  dense: the library
+    writes the members back to back itself (out_stride 0, what the binary's writer asks for) instead of one per stride."""
     import ctypes as C
     import zlib
     import numpy as np
@@ -80,8 +81,8 @@ def gpu_deflate(data, block_bytes=0xff00, device=0, return_stats=False):
     if n == 0:
         return (b"", {}) if return_stats else b""
     nb = (n + block_bytes - 1) // block_bytes
-    stride = 0x10000 + 64
-    out = np.zeros(nb * stride, dtype=np.uint8)
+    stride = 0 if dense else 0x10000 + 64
+    out = np.zeros(nb * (block_bytes + 128) if dense else nb * stride, dtype=np.uint8)
     lens = np.zeros(nb, dtype=np.int32)
     obj = C.c_void_p()
     try:
@@ -91,9 +92,10 @@ def gpu_deflate(data, block_bytes=0xff00, device=0, return_stats=False):
     finally:
         lib.svdss_deflate_free(obj)
     parts = []
+    at = np.concatenate([[0], np.cumsum(lens)]) if dense else np.arange(nb + 1) * stride
     for i in range(nb):
         blk = raw[i * block_bytes:(i + 1) * block_bytes]
-        m = bytearray(out[i * stride:i * stride + int(lens[i])].tobytes())
+        m = bytearray(out[int(at[i]):int(at[i]) + int(lens[i])].tobytes())
         m[-8:-4] = struct.pack("<I", zlib.crc32(blk.tobytes()) & 0xffffffff)
         m[-4:] = struct.pack("<I", len(blk))
         parts.append(bytes(m))

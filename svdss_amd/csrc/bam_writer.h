@@ -22,7 +22,11 @@
 class BgzfWriter {
  public:
   explicit BgzfWriter(FILE* f, int threads = 1) : f_(f), threads_(threads < 1 ? 1 : threads) { buf_.reserve(BLOCK * batch_); }
-  ~BgzfWriter() { if (gpu_.obj && gpu_.free_) gpu_.free_(gpu_.obj); }
+  ~BgzfWriter() {
+    if (gpu_.obj && gpu_.free_) gpu_.free_(gpu_.obj);
+    if (pin_ && gpu_.host_free) gpu_.host_free(pin_);
+    if (pout_ && gpu_.host_free) gpu_.host_free(pout_);
+  }
   BgzfWriter(const BgzfWriter&) = delete;
   BgzfWriter& operator=(const BgzfWriter&) = delete;
   // Blocks deflated on the GPU (csrc/deflate.hip through gpu_deflate_hook.h; the writer itself does not know HIP): a
@@ -31,22 +35,48 @@ class BgzfWriter {
     int (*deflate)(void** obj, int device, const uint8_t* in, int64_t in_bytes, int32_t block_bytes, uint8_t* out,
                    int64_t out_stride, int32_t* out_len) = nullptr;
     void (*free_)(void* obj) = nullptr;
+    int (*host_alloc)(int64_t bytes, void** out) = nullptr;   // page-locked memory (the copies to and from the GPU)
+    void (*host_free)(void* p) = nullptr;
     void* obj = nullptr;
     int device = 0;
   };
   void enable_gpu_deflate(const GpuDeflateApi& api) {
     gpu_ = api;
     batch_ = 1024;            // (a launch wants a few blocks per CU)
-    buf_.reserve(BLOCK * batch_);
+    // the collecting buffer itself is page-locked, and so is the one the members come back into (back to back): no
+    // staging copies on either side of the GPU
+    void* a = nullptr; void* b = nullptr;
+    if (gpu_.host_alloc && gpu_.host_alloc((int64_t)(BLOCK * batch_ + 64), &a) == 0 && a &&
+        gpu_.host_alloc((int64_t)((BLOCK + 128) * batch_), &b) == 0 && b) {
+      pin_ = (uint8_t*)a; pin_cap_ = BLOCK * batch_;
+      pout_ = (uint8_t*)b;
+    } else {
+      if (a && gpu_.host_free) gpu_.host_free(a);
+      buf_.reserve(BLOCK * batch_);
+    }
   }
   void write(const void* p, size_t n) {
     const uint8_t* s = (const uint8_t*)p;
+    if (pin_) {
+      while (n) {
+        const size_t take = std::min(n, pin_cap_ - pin_n_);
+        memcpy(pin_ + pin_n_, s, take);
+        pin_n_ += take; s += take; n -= take;
+        if (pin_n_ == pin_cap_) { emit(pin_, pin_n_, batch_); pin_n_ = 0; }
+      }
+      return;
+    }
     buf_.insert(buf_.end(), s, s + n);
     if (buf_.size() >= BLOCK * batch_) flush_full_blocks();
   }
   bool finish() {   // flush + the 28-byte EOF marker block
-    flush_full_blocks();
-    if (!buf_.empty()) { emit(buf_.data(), buf_.size(), 1); buf_.clear(); }
+    if (pin_) {
+      if (pin_n_) emit(pin_, pin_n_, (pin_n_ + BLOCK - 1) / BLOCK);
+      pin_n_ = 0;
+    } else {
+      flush_full_blocks();
+      if (!buf_.empty()) { emit(buf_.data(), buf_.size(), 1); buf_.clear(); }
+    }
     emit(nullptr, 0, 1);
     return fflush(f_) == 0 && ok_;
   }
@@ -57,6 +87,9 @@ class BgzfWriter {
   size_t batch_ = 256;
   GpuDeflateApi gpu_;
   bool gpu_warned_ = false;
+  uint8_t* pin_ = nullptr;    // GPU path: the collecting buffer (page-locked), pin_n_ of pin_cap_ bytes filled
+  size_t pin_n_ = 0, pin_cap_ = 0;
+  uint8_t* pout_ = nullptr;   // ... and the members of a batch as they come back
 
   // libdeflate's compressor through dlopen (no header needed): level 6 at two to three times zlib's speed.  The bytes
   // differ from zlib's (both are valid deflate streams); whichever is used, the output does not depend on the threads.
@@ -117,43 +150,45 @@ class BgzfWriter {
     return clen + 26;
   }
 
-  // the batch through the GPU encoder; false: not done (no GPU path, or it failed: the host compresses the batch)
-  bool emit_gpu(const uint8_t* data, size_t bytes, size_t nblocks, std::vector<uint8_t>& out, std::vector<size_t>& len) {
+  // the batch through the GPU encoder, written out; false: not done (no GPU path, or it failed: the host compresses it)
+  bool emit_gpu(const uint8_t* data, size_t bytes, size_t nblocks) {
     if (!gpu_.deflate || !data || bytes == 0) return false;
     std::vector<int32_t> l32(nblocks);
-    const int rc = gpu_.deflate(&gpu_.obj, gpu_.device, data, (int64_t)bytes, (int32_t)BLOCK, out.data(), (int64_t)OUT, l32.data());
+    std::vector<uint8_t> own;                      // (no page-locked buffer: an ordinary one)
+    uint8_t* out = pout_;
+    if (!out) { own.resize((BLOCK + 128) * nblocks); out = own.data(); }
+    // out_stride 0: the members come back to back
+    const int rc = gpu_.deflate(&gpu_.obj, gpu_.device, data, (int64_t)bytes, (int32_t)BLOCK, out, 0, l32.data());
     if (rc != 0) {
       if (!gpu_warned_) fprintf(stderr, "[bam_writer] GPU deflate call failed (code %d): the host deflates\n", rc);
       gpu_warned_ = true;
       return false;
     }
+    std::vector<size_t> off(nblocks + 1, 0);
+    for (size_t i = 0; i < nblocks; ++i) off[i + 1] = off[i] + (size_t)l32[i];
     // the footers: CRC32 of the block's bytes and their number (RFC 1952), by the workers
     const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)threads_, nblocks));
     auto work = [&](size_t t) {
       for (size_t i = t; i < nblocks; i += nt) {
-        const size_t off = i * BLOCK, n = std::min(BLOCK, bytes - off);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, (uInt)n), isize = (uint32_t)n;
-        len[i] = (size_t)l32[i];
-        memcpy(out.data() + i * OUT + len[i] - 8, &crc, 4);
-        memcpy(out.data() + i * OUT + len[i] - 4, &isize, 4);
+        const size_t at = i * BLOCK, n = std::min(BLOCK, bytes - at);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + at, (uInt)n), isize = (uint32_t)n;
+        memcpy(out + off[i + 1] - 8, &crc, 4);
+        memcpy(out + off[i + 1] - 4, &isize, 4);
       }
     };
     std::vector<std::thread> pool;
     for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t);
     work(0);
     for (std::thread& th : pool) th.join();
+    if (fwrite(out, 1, off[nblocks], f_) != off[nblocks]) ok_ = false;
     return true;
   }
 
   // compresses `nblocks` consecutive blocks of `data` (the last one may be short) and writes them in order
   void emit(const uint8_t* data, size_t bytes, size_t nblocks) {
+    if (emit_gpu(data, bytes, nblocks)) return;
     std::vector<uint8_t> out(nblocks * OUT);
     std::vector<size_t> len(nblocks);
-    if (emit_gpu(data, bytes, nblocks, out, len)) {
-      for (size_t i = 0; i < nblocks; ++i)
-        if (fwrite(out.data() + i * OUT, 1, len[i], f_) != len[i]) ok_ = false;
-      return;
-    }
     const size_t nt = std::min<size_t>((size_t)threads_, nblocks);
     while (deflaters_.size() < std::max<size_t>(nt, 1)) deflaters_.emplace_back(new Deflater());
     auto work = [&](size_t t, size_t nt) {

@@ -264,6 +264,42 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
   }
 }
 
+// exclusive prefix sum of the members' lengths (one wavefront; a launch has a few thousand blocks at most)
+__global__ void __launch_bounds__(64) deflate_offsets_kernel(const int32_t* len, int64_t nb, int64_t* off) {
+  const int lane = threadIdx.x;
+  int64_t carry = 0;
+  for (int64_t b0 = 0; b0 < nb; b0 += 64) {
+    const int64_t b = b0 + lane;
+    const int x = b < nb ? len[b] : 0;
+    const int incl = wave_scan_add(x);
+    if (b < nb) off[b] = carry + incl - x;
+    carry += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (lane == 0) off[nb] = carry;
+}
+
+// the members back to back: block b's bytes from its stride slot to off[b] (dword loads, byte-granular destination)
+__global__ void __launch_bounds__(256) deflate_compact_kernel(const uint8_t* strided, int64_t stride, const int32_t* len,
+                                                             const int64_t* off, uint8_t* dense) {
+  const int64_t b = blockIdx.x;
+  const uint8_t* src = strided + b * stride;
+  uint8_t* dst = dense + off[b];
+  const int n = len[b];
+  // head bytes until dst is dword-aligned, then dwords (src is dword-aligned at every multiple of 4: shift by the head)
+  const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3) < n ? (int)((4 - ((uintptr_t)dst & 3)) & 3) : n;
+  if ((int)threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+  const int nd = (n - head) >> 2;
+  const uint32_t* s32 = (const uint32_t*)src;
+  uint32_t* d32 = (uint32_t*)(dst + head);
+  for (int i = threadIdx.x; i < nd; i += 256) {
+    const int byte = head + 4 * i;
+    const uint32_t w0 = s32[byte >> 2], w1 = s32[(byte >> 2) + 1];
+    d32[i] = __builtin_amdgcn_alignbyte(w1, w0, byte & 3);
+  }
+  const int done = head + 4 * nd;
+  if ((int)threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+}
+
 }  // namespace
 
 struct svdss_deflate {
@@ -273,6 +309,8 @@ struct svdss_deflate {
   uint8_t* d_in = nullptr; size_t in_cap = 0;
   uint8_t* d_out = nullptr; size_t out_cap = 0;
   int32_t* d_len = nullptr; size_t len_cap = 0;
+  uint8_t* d_dense = nullptr; size_t dense_cap = 0;   // compact mode: the members back to back
+  int64_t* d_off = nullptr; size_t off_cap = 0;
   double kernel_ms = 0;
 };
 
@@ -282,6 +320,8 @@ extern "C" void svdss_deflate_free(svdss_deflate_t* o) {
   if (o->d_in) (void)hipFree(o->d_in);
   if (o->d_out) (void)hipFree(o->d_out);
   if (o->d_len) (void)hipFree(o->d_len);
+  if (o->d_dense) (void)hipFree(o->d_dense);
+  if (o->d_off) (void)hipFree(o->d_off);
   if (o->e0) (void)hipEventDestroy(o->e0);
   if (o->e1) (void)hipEventDestroy(o->e1);
   if (o->stream) (void)hipStreamDestroy(o->stream);
@@ -293,6 +333,9 @@ extern "C" double svdss_deflate_kernel_ms(const svdss_deflate_t* o) { return o ?
 extern "C" int svdss_bgzf_deflate(svdss_deflate_t** obj, int32_t device, const uint8_t* in, int64_t in_bytes,
                                   int32_t block_bytes, uint8_t* out, int64_t out_stride, int32_t* out_len) {
   if (!obj || !in || !out || !out_len || in_bytes <= 0 || block_bytes <= 0 || block_bytes > MAX_IN) return SVDSS_EINVAL;
+  // out_stride 0: the members back to back in `out` (room for in_bytes + 64 per block), out_len gives their lengths
+  const bool dense = out_stride == 0;
+  if (dense) out_stride = ((int64_t)block_bytes + 26 + 6 * SUBS + 4 + 63) & ~(int64_t)63;
   // a stored quarter block costs 5 bytes (+ 1 of padding), header and footer 26
   if (out_stride < block_bytes + 26 + 6 * SUBS + 4 || (out_stride & 3)) return SVDSS_EINVAL;
   HIPCHK(hipSetDevice(device));
@@ -334,9 +377,34 @@ extern "C" int svdss_bgzf_deflate(svdss_deflate_t** obj, int32_t device, const u
                      out_stride, o->d_len);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(o->e1, o->stream));
-  HIPCHK(hipMemcpyAsync(out, o->d_out, out_need, hipMemcpyDeviceToHost, o->stream));
-  HIPCHK(hipMemcpyAsync(out_len, o->d_len, len_need, hipMemcpyDeviceToHost, o->stream));
-  HIPCHK(hipStreamSynchronize(o->stream));
+  if (dense) {
+    if (o->dense_cap < out_need) {
+      if (o->d_dense) (void)hipFree(o->d_dense);
+      o->d_dense = nullptr; o->dense_cap = 0;
+      HIPCHK(hipMalloc((void**)&o->d_dense, out_need + out_need / 4));
+      o->dense_cap = out_need + out_need / 4;
+    }
+    if (o->off_cap < (size_t)(nb + 1) * 8) {
+      if (o->d_off) (void)hipFree(o->d_off);
+      o->d_off = nullptr; o->off_cap = 0;
+      HIPCHK(hipMalloc((void**)&o->d_off, (size_t)(nb + 1) * 16 + 64));
+      o->off_cap = (size_t)(nb + 1) * 16 + 64;
+    }
+    hipLaunchKernelGGL(deflate_offsets_kernel, dim3(1), dim3(64), 0, o->stream, o->d_len, nb, o->d_off);
+    hipLaunchKernelGGL(deflate_compact_kernel, dim3((unsigned)nb), dim3(256), 0, o->stream, o->d_out, out_stride, o->d_len, o->d_off,
+                       o->d_dense);
+    HIPCHK(hipGetLastError());
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(out_len, o->d_len, len_need, hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipMemcpyAsync(&total, o->d_off + nb, 8, hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    HIPCHK(hipMemcpyAsync(out, o->d_dense, (size_t)total, hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(out, o->d_out, out_need, hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipMemcpyAsync(out_len, o->d_len, len_need, hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+  }
   float ms = 0;
   if (hipEventElapsedTime(&ms, o->e0, o->e1) == hipSuccess) o->kernel_ms = ms;
   return SVDSS_OK;

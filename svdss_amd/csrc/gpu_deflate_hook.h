@@ -17,6 +17,8 @@ inline bool svdss_enable_gpu_deflate(BgzfWriter& w, int device = 0) {
     return svdss_bgzf_deflate((svdss_deflate_t**)obj, dev, in, in_bytes, block_bytes, out, out_stride, out_len);
   };
   api.free_ = [](void* obj) { svdss_deflate_free((svdss_deflate_t*)obj); };
+  api.host_alloc = svdss_host_alloc;
+  api.host_free = svdss_host_free;
   api.device = device;
   w.enable_gpu_deflate(api);
   return true;

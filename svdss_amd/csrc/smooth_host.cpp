@@ -79,6 +79,30 @@ void set_xf(std::vector<uint8_t>& aux, int v) {
   aux.push_back('X'); aux.push_back('F'); aux.push_back('C'); aux.push_back((uint8_t)v);
 }
 
+// grow-only buffer for what goes to / comes from the GPU in every batch: page-locked when the runtime gives it (the
+// copies then run at PCIe speed), never zero-filled
+struct PinBuf {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  ~PinBuf() { release(); }
+  void release() {
+    if (!p) return;
+    if (pinned) svdss_host_free(p); else free(p);
+    p = nullptr; cap = 0;
+  }
+  uint8_t* ensure(size_t n) {
+    if (n <= cap) return p;
+    release();
+    const size_t want = n + n / 4 + 4096;
+    void* q = nullptr;
+    if (svdss_host_alloc((int64_t)want, &q) == SVDSS_OK && q) { p = (uint8_t*)q; pinned = true; }
+    else { p = (uint8_t*)malloc(want); pinned = false; if (!p) { fprintf(stderr, "[smooth] [critical] out of memory\n"); exit(EXIT_FAILURE); } }
+    cap = want;
+    return p;
+  }
+};
+
 struct ByteSink {
   std::vector<uint8_t> v;
   void write(const void* p, size_t n) { v.insert(v.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
@@ -107,6 +131,7 @@ void write_record_packed(ByteSink& w, const BamRecord& r, const uint32_t* cigar,
   memcpy(core + 24, &r.mtid, 4);
   memcpy(core + 28, &r.mpos, 4);
   memcpy(core + 32, &r.isize, 4);
+  w.v.reserve(w.v.size() + 4 + (size_t)block);   // (one allocation per record instead of a doubling series)
   w.write(core, 36);
   w.write(r.qname.c_str(), l_name);
   if (n_cig) w.write(cigar, 4u * n_cig);
@@ -319,6 +344,7 @@ int main_smooth(const CallOptions& o) {
     }
     write_ok = w.finish();
   });
+  PinBuf pb_s4, pb_q, pb_cig, pb_o4, pb_oq, pb_ocig;   // the batch's packed bases / qualities / CIGARs, in and out
   auto process = [&](std::vector<BamRecord>& batch, std::vector<ByteSink>& outs) {
     outs.assign(batch.size(), ByteSink());
     if (dref && !batch.empty()) {
@@ -326,9 +352,9 @@ int main_smooth(const CallOptions& o) {
       // keeps what is per record and tiny: the consistency check, the XF decision, the record header
       std::vector<size_t> idx;                      // batch index of the records that go to the GPU
       std::vector<int32_t> tid, pos, lq;
-      std::vector<uint32_t> cig;
       std::vector<int64_t> cig_off(1, 0), s4_off, q_off, cap_off(1, 0);
-      std::vector<uint8_t> s4, ql;
+      // first the sizes (cheap, in order), then the bytes (T threads into page-locked buffers kept from batch to batch)
+      size_t s4_bytes = 0, q_bytes = 0;
       for (size_t i = 0; i < batch.size(); ++i) {
         const BamRecord& r = batch[i];
         const std::string& ref = chrom.at(bam.ref_names()[(size_t)r.tid]);
@@ -348,22 +374,45 @@ int main_smooth(const CallOptions& o) {
         tid.push_back(tid_map[(size_t)r.tid]);
         pos.push_back(r.pos);
         lq.push_back(r.l_seq);
-        cig.insert(cig.end(), r.cigar.begin(), r.cigar.end());
-        cig_off.push_back((int64_t)cig.size());
-        s4_off.push_back((int64_t)s4.size());
-        s4.insert(s4.end(), r.seq4.begin(), r.seq4.end());
-        q_off.push_back((int64_t)ql.size());
-        ql.insert(ql.end(), r.qual.begin(), r.qual.end());
+        cig_off.push_back(cig_off.back() + (int64_t)r.cigar.size());
+        s4_off.push_back((int64_t)s4_bytes);
+        s4_bytes += r.seq4.size();
+        q_off.push_back((int64_t)q_bytes);
+        q_bytes += r.qual.size();
         cap_off.push_back(cap_off.back() + (int64_t)((qlen + rl + 1) & ~(size_t)1));
       }
       const size_t n = idx.size();
       if (n) {
-        std::vector<uint8_t> o4((size_t)cap_off.back() / 2 + 8), oq((size_t)cap_off.back()), oign(n);
-        std::vector<uint32_t> ocig(cig.size() + 1);
+        const size_t n_cig_in = (size_t)cig_off.back();
+        uint8_t* s4 = pb_s4.ensure(s4_bytes + 16);
+        uint8_t* ql = pb_q.ensure(q_bytes + 16);
+        uint32_t* cig = (uint32_t*)pb_cig.ensure(4 * n_cig_in + 16);
+        uint8_t* o4 = pb_o4.ensure((size_t)cap_off.back() / 2 + 8);
+        uint8_t* oq = pb_oq.ensure((size_t)cap_off.back() + 8);
+        uint32_t* ocig = (uint32_t*)pb_ocig.ensure(4 * (n_cig_in + 1) + 16);
+        std::vector<uint8_t> oign(n);
         std::vector<int32_t> oncig(n), olen(n);
         std::vector<int64_t> onm(2 * n);
-        if (svdss_smooth_batch(dref, tid.data(), pos.data(), cig.data(), cig_off.data(), s4.data(), s4_off.data(), ql.data(),
-                               q_off.data(), lq.data(), cap_off.data(), (int64_t)n, o4.data(), oq.data(), ocig.data(),
+        {
+          auto pack = [&](size_t t, size_t nt) {
+            for (size_t k = n * t / nt; k < n * (t + 1) / nt; ++k) {
+              const BamRecord& r = batch[idx[k]];
+              memcpy(s4 + s4_off[k], r.seq4.data(), r.seq4.size());
+              memcpy(ql + q_off[k], r.qual.data(), r.qual.size());
+              memcpy(cig + cig_off[k], r.cigar.data(), 4 * r.cigar.size());
+            }
+          };
+          const size_t nt = std::min<size_t>((size_t)T, std::max<size_t>(1, n / 64));
+          if (nt <= 1) pack(0, 1);
+          else {
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < nt; ++t) pool.emplace_back(pack, t, nt);
+            pack(0, nt);
+            for (std::thread& th : pool) th.join();
+          }
+        }
+        if (svdss_smooth_batch(dref, tid.data(), pos.data(), cig, cig_off.data(), s4, s4_off.data(), ql,
+                               q_off.data(), lq.data(), cap_off.data(), (int64_t)n, o4, oq, ocig,
                                oncig.data(), olen.data(), onm.data(), oign.data()) != SVDSS_OK)
           die(std::string("svdss_smooth_batch: ") + svdss_last_hip_error());
         auto finish = [&](size_t t, size_t nt) {
@@ -375,8 +424,8 @@ int main_smooth(const CallOptions& o) {
             else if (oign[k]) { set_xf(aux, 2); write_record(outs[idx[k]], r, r.cigar, r.seq_string(), r.qual, aux); }
             else {
               set_xf(aux, 0);
-              write_record_packed(outs[idx[k]], r, ocig.data() + cig_off[k], (size_t)oncig[k], o4.data() + cap_off[k] / 2,
-                                  olen[k], oq.data() + cap_off[k], aux);
+              write_record_packed(outs[idx[k]], r, ocig + cig_off[k], (size_t)oncig[k], o4 + cap_off[k] / 2,
+                                  olen[k], oq + cap_off[k], aux);
             }
           }
         };

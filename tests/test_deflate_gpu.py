@@ -104,6 +104,9 @@ def test_many_blocks_short_tail_and_the_gpu_inflater_reads_them():
     blocks = bgzf_blocks(stream)
     got = gpu_inflate(stream, [(c, l, i) for c, l, i, _ in blocks])
     assert bytes(got) == data
+    # the members written back to back by the library itself (what csrc/bam_writer.h asks for): the same bytes
+    assert gpu_deflate(data, dense=True) == stream
+    assert gpu_deflate(data[:70001], block_bytes=333, dense=True) == gpu_deflate(data[:70001], block_bytes=333)
     # other block sizes (the writer always uses 0xff00)
     check_roundtrip(data[:200000], block_bytes=4096)
     check_roundtrip(data[:70000], block_bytes=333)
