@@ -956,14 +956,33 @@ struct CallRun {
   void run_poa() {
     consensus.assign(subs.size(), std::string());
     if (!subs.empty()) {
-      std::vector<uint8_t> flat;
+      // the sub-reads of every sub-cluster back to back in abPOA's alphabet: offsets first, then the bytes by T
+      // threads (a 30x human sample is ~1 GB of sub-reads: one byte at a time on one thread took seconds)
       std::vector<int64_t> seq_off(1, 0), cl_off(1, 0);
+      std::vector<const std::string*> srcs;
       for (const Sub& s : subs) {
         for (const SubRead& sr : s.cl.subreads) {
-          for (char ch : sr.seq) flat.push_back(enc26(ch));
-          seq_off.push_back((int64_t)flat.size());
+          srcs.push_back(&sr.seq);
+          seq_off.push_back(seq_off.back() + (int64_t)sr.seq.size());
         }
         cl_off.push_back((int64_t)seq_off.size() - 1);
+      }
+      std::vector<uint8_t> flat((size_t)seq_off.back());
+      {
+        uint8_t lut[256];
+        for (int c = 0; c < 256; ++c) lut[c] = enc26((char)c);
+        const size_t ns = srcs.size(), nt = std::min<size_t>((size_t)T, std::max<size_t>(1, ns / 256));
+        auto enc = [&](size_t t) {
+          for (size_t k = ns * t / nt; k < ns * (t + 1) / nt; ++k) {
+            uint8_t* d = flat.data() + seq_off[k];
+            const std::string& q = *srcs[k];
+            for (size_t x = 0; x < q.size(); ++x) d[x] = lut[(uint8_t)q[x]];
+          }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; ++t) pool.emplace_back(enc, t);
+        enc(0);
+        for (std::thread& th : pool) th.join();
       }
       // --gpus G: sub-cluster k goes to GPU k % G (no exchange between the GPUs: a sub-cluster is self-contained), the
       // consensus sequences come back in sub-cluster order -- the same bytes as with one GPU
