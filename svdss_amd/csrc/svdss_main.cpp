@@ -15,7 +15,9 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <sys/stat.h>
 #include <ctime>
 #include <deque>
 #include <functional>
@@ -161,6 +163,11 @@ static int main_index(int argc, char** argv) {
     fprintf(stderr, "Usage: SVDSS index [-t threads] -d <reference.fa[.gz]> -o <reference.fmd>\n");
     return EXIT_FAILURE;
   }
+  const bool dbg = getenv("SVDSS_DEBUG") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (dbg) fprintf(stderr, "[index] %-28s at +%.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+  };
   FastxReader fx(fasta);
   if (!fx.ok()) die("cannot open " + fasta);
   std::vector<uint8_t> cat;
@@ -173,17 +180,21 @@ static int main_index(int argc, char** argv) {
     lens.push_back((int64_t)seq.size());
   }
   if (lens.empty()) die("no sequence in " + fasta);
+  mark("FASTA read + nt6");
   logmsg("info", "Indexing " + std::to_string(lens.size()) + " record(s), " + std::to_string(cat.size()) + " bases..");
   svdss_index_t* ix = nullptr;
   check(svdss_index_build(cat.data(), lens.data(), (int32_t)lens.size(), threads, &ix), "svdss_index_build");
+  mark("index built");
   // the file ropebwt3 build -d writes (rld0), so that the index serves upstream SVDSS as well -- and beside it the
   // records themselves (nt6), from which `search` rebuilds the index in HBM in less time than the text + suffix array
   // (19 bytes per base) take to read from any disk.  SVDSS_INDEX_FULL=1: the full layout instead (a plain read).
   check(svdss_index_save_fmd(ix, out.c_str()), "svdss_index_save_fmd");
+  mark("rld0 .fmd written");
   if (!getenv("SVDSS_INDEX_NO_CACHE")) {
     if (getenv("SVDSS_INDEX_FULL")) check(svdss_index_save(ix, (out + ".svdss").c_str()), "svdss_index_save");
     else check(svdss_index_save_records(ix, (out + ".svdss").c_str()), "svdss_index_save_records");
   }
+  mark("sidecar written");
   svdss_index_free(ix);
   return 0;
 }
@@ -315,6 +326,34 @@ int main_search(const Options& o) {
   }
   check(svdss_index_load(o.index.c_str(), &ix), "svdss_index_load");
   if (o.verbose) logmsg("debug", "index file read at +" + since() + " s");
+  if (!getenv("SVDSS_KMER")) {
+    // The order K of the k-mer table trades its build time (4^K entries: 1.6 s at K = 16, a quarter of that per step
+    // down) against the search kernel's speed (about a third slower per step down).  The library's own choice (K = 16
+    // from 64 Mb on) is the one for a resident index that searches batch after batch; a process that restores the
+    // index for ONE input knows roughly how many reads are coming (a BAM is ~1 byte per base, a FASTQ ~2) and takes the
+    // K that minimises build + search.  Results never depend on K (tests/test_sfs_gpu.py, tests/test_scale_gpu.py).
+    struct stat st;
+    const std::string& in = bam_mode ? o.bam : o.fastx;
+    // (references above 2^31 symbols keep the library's K: nothing below 16 was measured there)
+    if (stat(in.c_str(), &st) == 0 && st.st_size > 0 && svdss_index_size(ix) < ((int64_t)1 << 31)) {
+      const double est_reads = (double)st.st_size / (bam_mode ? 15000.0 : 30000.0);
+      const int64_t n = svdss_index_size(ix);
+      int k_auto = 1;
+      while (k_auto < 16 && ((int64_t)1 << (2 * k_auto)) <= n) ++k_auto;
+      k_auto = std::min(16, k_auto + 2);
+      int best = k_auto;
+      double best_cost = 1e300;
+      for (int k = k_auto; k >= std::max(8, k_auto - 5); --k) {
+        // (the kernel's seconds count double: they are GPU time the BGZF inflate of the stream wants too)
+        const double build = 1.6 * std::pow(4.0, k - 16), kernel = est_reads / 15e6 * std::pow(1.35, 16 - k);
+        if (build + 2 * kernel < best_cost) { best_cost = build + 2 * kernel; best = k; }
+      }
+      if (best != k_auto) {
+        setenv("SVDSS_KMER", std::to_string(best).c_str(), 0);
+        if (o.verbose) logmsg("debug", "k-mer table of order " + std::to_string(best) + " for ~" + std::to_string((long long)est_reads) + " reads");
+      }
+    }
+  }
   check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
   if (o.verbose) logmsg("debug", "index and k-mer table on the device at +" + since() + " s");
   // --gpus N: one replica of the index per GPU; the batches of reads go to whichever GPU is free, the
