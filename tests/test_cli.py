@@ -214,6 +214,15 @@ def test_search_bam_inflated_on_the_gpu_or_the_host_same_bytes(tmp_path):
         if mode in ("101", "0"):
             assert ("inflated on the GPU" in r.stderr) == (mode == "101"), r.stderr
     assert outs["101"] == outs["0"] == outs["50"] == outs["100"] and outs["0"].count("\n") > 400
+    # chunk buffers page-locked (forced: the file is far below the size at which the reader pins them), with no
+    # page-locked memory to be had at all (cap 0: every buffer falls back to ordinary memory), several small chunks in
+    # flight, and the k-mer table order left to the binary or fixed: the same text
+    for env in ({"SVDSS_PIN_MIN_CHUNKS": "0"}, {"SVDSS_PIN_MIN_CHUNKS": "0", "SVDSS_PIN_CAP_GB": "0"},
+                {"SVDSS_PIN_MIN_CHUNKS": "0", "SVDSS_BAM_SLAB_KB": "64"}, {"SVDSS_KMER": "16"}, {"SVDSS_KMER": "9"}):
+        r = run("search", "--index", str(fmd), "--bam", str(bam), "--noputative", "--threads", "4", "--bsize", "64",
+                env=dict(os.environ, **env))
+        assert r.returncode == 0, (env, r.stderr[-300:])
+        assert r.stdout == outs["0"], env
     # flip one bit in the middle of the second block's deflate stream
     bad = bytearray(data)
     first = struct.unpack_from("<H", data, 16)[0] + 1

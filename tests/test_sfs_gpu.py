@@ -358,3 +358,49 @@ def test_gpu_suffix_sorter_builds_the_same_index(monkeypatch, tmp_path):
     b.save(str(tmp_path / "cpu.fmd"))
     assert (a.bwt() == b.bwt()).all()
     assert (tmp_path / "gpu.fmd").read_bytes() == (tmp_path / "cpu.fmd").read_bytes()
+
+
+@pytest.mark.parametrize("kmer", [None, "4", "16"])
+def test_degenerate_references_and_reads(monkeypatch, kmer):
+    """References the synthetic genomes never produce: records of 1, 2, K-1, K and K+1 bases, a record of N only, a
+    record that is one base repeated, a record equal to another's reverse complement (every suffix tied with one of the
+    other strand), beside ordinary ones -- index built in HBM (or by the fallback), verified against its text, searched
+    by both launch shapes and compared with the oracle; reads of 1 .. K+1 bases, reads of N only, reads that ARE a
+    record, its reverse complement, a record plus one base on either side (ping_pong.cpp:4-49 on its boundary cases:
+    the phase that starts at the last symbol, the forward phase that runs off the read end at P[l] = 0)."""
+    if kmer:
+        monkeypatch.setenv("SVDSS_KMER", kmer)
+    rng = np.random.default_rng(77)
+    base = synth.make_reference([40000, 9000], seed=78, n_runs=(300,))
+    tiny = [np.array(x, np.uint8) for x in ([1], [3, 2], [4] * 15, [2, 1, 4, 3] * 4, [1, 2, 3, 4, 1, 1, 2, 2, 3, 3, 4, 4, 2, 4, 1, 3, 2])]
+    ref = base + tiny + [np.full(700, 5, np.uint8), np.full(3000, 2, np.uint8), synth.revcomp(base[1][1000:6000])]
+    ix = svdss_amd.FMDIndex.build(ref, device=0)
+    v = ix.verify()
+    assert v["rows"] == ix.size and v["first_bad"] == -1 and v["bad_order"] == v["bad_bwt"] == v["bad_block"] == v["bad_dollar"] == 0, v
+    fm = O.OracleFMD.build(ref)
+    reads = [np.array([c], np.uint8) for c in (1, 2, 3, 4, 5)]
+    reads += [rng.integers(1, 5, size=n).astype(np.uint8) for n in (2, 3, 15, 16, 17, 31, 33, 64, 65, 127, 129)]
+    reads += [np.full(n, 5, np.uint8) for n in (1, 16, 200)]
+    reads += [t.copy() for t in tiny] + [synth.revcomp(t) for t in tiny]
+    reads += [np.concatenate([[3], tiny[3]]), np.concatenate([tiny[3], [1]]), np.concatenate([[4], tiny[4], [4]])]
+    reads += [base[0][100:3100].copy(), synth.revcomp(base[0][20000:23000]), base[1][990:6010].copy()]
+    reads += [np.full(500, 2, np.uint8), np.full(3001, 2, np.uint8), np.full(40, 3, np.uint8)]
+    hap, _ = synth.implant_svs(base, 3, seed=79, min_len=50, max_len=200)
+    f2, o2, _ = synth.simulate_reads(hap, 40, 2500, 0.01, seed=80)
+    reads += [f2[o2[i]:o2[i + 1]] for i in range(40)]
+    flat, offs = svdss_amd.pack_reads(reads)
+    for assemble in (False, True):
+        c, q, l, e = fm.search_batch(flat, offs, assemble)
+        for seg in (None, "1"):
+            if seg:
+                monkeypatch.setenv("SVDSS_SEGMENTS", seg)
+            pp = svdss_amd.PingPong(ix, assemble=assemble)
+            got = pp.ping_pong_search(flat, offs)
+            pp.close()
+            if seg:
+                monkeypatch.delenv("SVDSS_SEGMENTS")
+            assert (got.counts == c).all() and (got.n_ext == e).all(), (assemble, seg)
+            assert (got.qs == q).all() and (got.len == l).all(), (assemble, seg)
+    # the records themselves and their reverse complements occur: nothing specific in them
+    k = [i for i, r in enumerate(reads) if any(len(r) == len(t) and ((r == t).all() or (r == synth.revcomp(t)).all()) for t in tiny)]
+    assert len(k) >= 10 and all(c[i] == 0 for i in k)
