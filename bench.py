@@ -764,7 +764,7 @@ def e2e_runs(work, n_reads, call=True):
       e2e_wg    the same BAM against the index of the WHOLE reference (GRCh38 primary lengths): what run_svdss:151-166
                 does for a human sample; `SVDSS index` time and the restore time (records file read + index rebuilt in
                 HBM + k-mer table) are stated beside the streaming rate.
-      e2e_call  `SVDSS index` -> `search` -> `call` on a 30 Mb genome with 200 implanted SVs (config 4's density), 30x of
+      e2e_call  `SVDSS index` -> `search` -> `call` on a 100 Mb genome with 648 implanted SVs (config 4's density), 30x of
                 15 kb error-free ("smoothed") reads with truth alignments: call_reads_per_s = reads / wall of `call`,
                 search_plus_call_reads_per_s = reads / (wall of search + wall of call) (run_svdss:151-178)."""
     import subprocess
@@ -809,7 +809,7 @@ def e2e_runs(work, n_reads, call=True):
         try:
             from tools import e2e_call as EC
             cdir = os.path.join(work, "call")
-            fa, cbam, svs, het, recs, hdr, _ = EC.write_dataset(cdir, 30_000_000, 200, 30, 15000, het_every=2, max_len=2000)
+            fa, cbam, svs, het, recs, hdr, _ = EC.write_dataset(cdir, 100_000_000, 648, 30, 15000, het_every=2, max_len=2000)
             fmd = os.path.join(cdir, "ref.fmd")
             subprocess.run([exe, "index", "-d", fa, "-o", fmd], check=True, capture_output=True)
             sfs = os.path.join(cdir, "specifics.txt")
@@ -825,7 +825,7 @@ def e2e_runs(work, n_reads, call=True):
             truth = [(sv.pos, sv.kind, sv.length) for sv in svs]
             hit = sum(1 for p, k, l in truth if any(k == ck and l == cl and abs(cp - p) <= 12 for cp, ck, cl in called))
             n = len(recs)
-            out["e2e_call"] = {"what": "SVDSS index -> search -> call (binaries): 30 Mb genome, %d implanted SVs (every other one "
+            out["e2e_call"] = {"what": "SVDSS index -> search -> call (binaries): 100 Mb genome, %d implanted SVs (every other one "
                                        "heterozygous), %d error-free 15 kb reads with truth alignments (30x), whole-process wall "
                                        "times" % (len(svs), n),
                                "reads": n, "search_s": round(t_search, 3), "call_s": round(t_call, 3),
