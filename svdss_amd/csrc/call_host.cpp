@@ -518,7 +518,7 @@ struct CallRun {
       if (!fx.ok()) die("cannot open " + o.reference);
       std::string name, seq;
       while (fx.next(name, seq)) {
-        for (char& ch : seq) ch = (char)toupper((unsigned char)ch);
+        for (char& ch : seq) ch = (char)(ch - ((ch >= 'a' && ch <= 'z') ? 32 : 0));   // toupper of chromosomes.cpp:19 (ASCII; vectorises)
         C.chrom_names.push_back(name);
         C.chrom_seqs[name] = seq;
       }

@@ -165,7 +165,7 @@ int main_smooth(const CallOptions& o) {
     if (!fx.ok()) die("cannot open " + o.reference);
     std::string name, seq;
     while (fx.next(name, seq)) {
-      for (char& c : seq) c = (char)toupper((unsigned char)c);
+      for (char& c : seq) c = (char)(c - ((c >= 'a' && c <= 'z') ? 32 : 0));   // toupper (ASCII; vectorises)
       chrom[name] = seq;
     }
   }

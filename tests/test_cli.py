@@ -232,3 +232,42 @@ def test_search_bam_inflated_on_the_gpu_or_the_host_same_bytes(tmp_path):
     for mode in ("101", "0"):
         r = run("search", "--index", str(fmd), "--bam", str(tmp_path / "bad.bam"), "--noputative", env=dict(os.environ, SVDSS_GPU_INFLATE=mode))
         assert r.returncode == 1 and ("CRC" in r.stderr or "inflate" in r.stderr), (mode, r.stderr[-300:])
+
+
+def test_fastx_reader_line_shapes(tmp_path, monkeypatch):
+    """csrc/fastx_reader.h (kseq's role, chromosomes.cpp:9-27, fastq.hpp:17-35) reads the file in blocks and finds lines
+    with memchr: 60-column lines, one base per line, a chromosome on one line, CRLF, blank lines and stray text in front
+    of the first header, gzip, lower case, FASTQ with quality lines that start with '@' and span lines -- `SVDSS index`
+    of each of them is the index of the same records."""
+    monkeypatch.setenv("SVDSS_INDEX_CPU", "1")
+    ref = synth.make_reference([30011, 7, 1, 8000], seed=5, n_runs=(25,))
+    want = svdss_amd.FMDIndex.build(ref, threads=4).bwt()
+
+    def write(path, width, crlf, blank, gz, lower, fastq):
+        nl = "\r\n" if crlf else "\n"
+        with (gzip.open if gz else open)(path, "wt", newline="") as fh:
+            if blank:
+                fh.write(nl + "junk line" + nl)
+            for i, c in enumerate(ref):
+                s = synth.to_ascii(c)
+                if lower and i % 2:
+                    s = s.lower()
+                fh.write((f"@chr{i} d" if fastq else f">chr{i}\tdesc") + nl)
+                for k in range(0, len(s), width):
+                    fh.write(s[k:k + width] + nl)
+                if fastq:
+                    fh.write("+" + nl)
+                    for k in range(0, len(s), width):
+                        fh.write("@" * len(s[k:k + width]) + nl)
+                elif blank and i == 0:
+                    fh.write(nl)
+
+    shapes = [(60, False, False, False, False, False), (70, True, True, True, True, False), (10 ** 9, False, False, False, True, False),
+              (1, False, False, False, False, False), (61, True, False, False, False, True), (4096, False, True, True, False, True)]
+    for n, (width, crlf, blank, gz, lower, fastq) in enumerate(shapes):
+        p = tmp_path / (f"f{n}.fa" + (".gz" if gz else ""))
+        write(p, width, crlf, blank, gz, lower, fastq)
+        out = tmp_path / f"f{n}.fmd"
+        r = run("index", "-t", "4", "-d", str(p), "-o", str(out))
+        assert r.returncode == 0, r.stderr
+        assert (svdss_amd.FMDIndex.load(str(out)).bwt() == want).all(), shapes[n]
