@@ -99,19 +99,32 @@ struct Encoder {
     for (int i = 0; i < ASIZE1; ++i) mcnt[i] = cnt[i];
     if (p > stail) next_block();   // (a type-2 header in the short last block of a piece leaves no data word)
   }
+  // Elias-delta codes of the run lengths below 1024 (nearly every run of a DNA BWT), value and width
+  struct DeltaLut {
+    uint32_t val[1024];
+    uint8_t width[1024];
+    DeltaLut() {
+      val[0] = 0; width[0] = 0;
+      for (int x = 1; x < 1024; ++x) { int w; val[x] = (uint32_t)delta_enc((uint64_t)x, &w); width[x] = (uint8_t)w; }
+    }
+  };
   void enc1(int64_t l, int c) {   // rld_enc1
+    static const DeltaLut lut;
     int w;
-    const uint64_t x = (delta_enc((uint64_t)l, &w) << ABITS) | (uint64_t)c;
-    w += ABITS;
+    uint64_t x;
+    if (l < 1024) { x = ((uint64_t)lut.val[l] << ABITS) | (uint64_t)c; w = lut.width[l] + ABITS; }
+    else { x = (delta_enc((uint64_t)l, &w) << ABITS) | (uint64_t)c; w += ABITS; }
     if (w > r && p == stail) next_block();
+    uint64_t* zp = &z[(size_t)p];
     if (w > r) {
       w -= r;
-      z[(size_t)p++] |= x >> w;
+      zp[0] |= x >> w;
+      ++p;
       r = 64 - w;
-      z[(size_t)p] = x << r;
+      zp[1] = x << r;
     } else {
       r -= w;
-      z[(size_t)p] |= x << r;
+      zp[0] |= x << r;
     }
     cnt[0] += (uint64_t)l;
     cnt[c + 1] += (uint64_t)l;
@@ -144,16 +157,80 @@ bool rld0_is_fmd(const char* path) {
   return ok;
 }
 
-int rld0_write(const char* path, const uint8_t* bwt, int64_t n) {
-  Encoder e;
-  for (int64_t i = 0; i < n;) {
-    const uint8_t c = bwt[i];
-    if (c >= ASIZE) return SVDSS_EINVAL;
-    int64_t j = i + 1;
-    while (j < n && bwt[j] == c) ++j;
-    e.push(j - i, c);
-    i = j;
+// All maximal runs of bwt[0, n) through the encoder.  The encoder's cursor lives in locals here (the stores into the
+// data words may alias its members, and the compiler would reload them after every one); the boundaries of 64 symbols
+// at a time come from a vectorisable compare, so that the loop has no data-dependent branch per SYMBOL.
+static void encode_runs(Encoder& e, const uint8_t* bwt, int64_t n) {
+  if (n <= 0) return;
+  static const Encoder::DeltaLut lut;
+  int64_t p = e.p, stail = e.stail;
+  int r = e.r;
+  uint64_t cnt[ASIZE1];
+  for (int i = 0; i < ASIZE1; ++i) cnt[i] = e.cnt[i];
+  uint64_t* z = e.z.data();
+  auto emit = [&](int64_t l, int c) {
+    int w;
+    uint64_t x;
+    if (l < 1024) { x = ((uint64_t)lut.val[l] << ABITS) | (uint64_t)c; w = lut.width[l] + ABITS; }
+    else { x = (delta_enc((uint64_t)l, &w) << ABITS) | (uint64_t)c; w += ABITS; }
+    if (w > r && p == stail) {
+      e.p = p; e.r = r;
+      for (int i = 0; i < ASIZE1; ++i) e.cnt[i] = cnt[i];
+      e.next_block();
+      p = e.p; r = e.r; stail = e.stail; z = e.z.data();
+    }
+    if (w > r) {
+      w -= r;
+      z[p] |= x >> w;
+      ++p;
+      r = 64 - w;
+      z[p] = x << r;
+    } else {
+      r -= w;
+      z[p] |= x << r;
+    }
+    cnt[0] += (uint64_t)l;
+    cnt[c + 1] += (uint64_t)l;
+  };
+  uint8_t c = bwt[0];
+  int64_t start = 0;
+  int64_t i = 1;
+  for (; i + 64 <= n; i += 64) {
+    uint64_t m = 0;
+    for (int k = 0; k < 64; ++k)   // (vectorises: bit k = symbol i + k differs from the one before it)
+      m |= (uint64_t)(bwt[i + k] != bwt[i + k - 1]) << k;
+    while (m) {
+      const int k = __builtin_ctzll(m);
+      m &= m - 1;
+      emit(i + k - start, c);
+      c = bwt[i + k];
+      start = i + k;
+    }
   }
+  for (; i < n; ++i) {
+    const uint8_t d = bwt[i];
+    if (d == c) continue;
+    emit(i - start, c);
+    c = d;
+    start = i;
+  }
+  emit(n - start, c);
+  e.p = p; e.r = r;
+  for (int k = 0; k < ASIZE1; ++k) e.cnt[k] = cnt[k];
+}
+
+int rld0_write(const char* path, const uint8_t* bwt, int64_t n) {
+  {
+    // every symbol must be below ASIZE: a 6 or 7 would be written as a symbol the format does not have
+    bool ok = true;
+#pragma omp parallel for reduction(&& : ok) schedule(static)
+    for (int64_t i = 0; i < n; ++i) ok = ok && bwt[i] < ASIZE;
+    if (!ok) return SVDSS_EINVAL;
+  }
+  Encoder e;
+  // (the data grows by a block whenever one fills up: reserve what a DNA BWT needs, ~5 bits per symbol)
+  try { e.z.reserve((size_t)(n / 12 + 1024)); } catch (...) {}
+  encode_runs(e, bwt, n);
   const int64_t k = e.finish();
   // rld_rank_index: one frame per 2^ibits positions
   const uint64_t total = e.cnt[0];
