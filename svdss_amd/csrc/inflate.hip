@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
       // the whole bytes still in the bit buffer are the first of them
       const uint64_t src = in_addr - (uint64_t)(bc >> 3);
       if (src + len > in_end) FAIL(ST_IN);
-      // (through the ring in pieces of at most 16 KB: less than 16 KB are waiting to be written out at any time)
+      // (through the ring in pieces of at most FLUSH bytes: less than that is waiting to be written out at any time)
       for (uint32_t done = 0; done < len;) {
         const uint32_t n = len - done < (uint32_t)FLUSH ? len - done : (uint32_t)FLUSH;
         for (uint32_t i = lane; i < n; i += 64) winb[(wpos + i) & WM] = comp[src + done + i];
