@@ -2,7 +2,8 @@
 writing half of `SVDSS smooth`'s BAM stream, /root/reference/smoother.cpp:441-494).  The encoder's output is pinned to
 the standard the way the inflater is: every member must inflate, with zlib (the library htslib inflates with), to exactly
 the bytes that went in -- block types, code lengths folded back to 15 bits, stored quarters, sizes 1 .. 0xff00, many
-blocks with a short tail --, Python's gzip must read the whole stream as BGZF, the footers must hold, and the GPU
+blocks with a short tail --, libdeflate (what htslib uses when built with it) must agree on a sample of the members,
+Python's gzip must read the whole stream as BGZF, the footers must hold, and the GPU
 inflater (csrc/inflate.hip) must read what the GPU encoder wrote.  Through the binary: `SVDSS smooth` writes the same
 records whether the GPU or the host's deflate packed them."""
 import gzip
@@ -38,6 +39,37 @@ def members(stream):
     return out
 
 
+def _libdeflate():
+    """libdeflate's decompressor (what htslib inflates with when built with it; stricter than zlib about incomplete
+    codes) through ctypes, or None when the shared library is not on the machine"""
+    import ctypes as C
+    for name in ("libdeflate.so.0", "libdeflate.so"):
+        try:
+            lib = C.CDLL(name)
+        except OSError:
+            continue
+        lib.libdeflate_alloc_decompressor.restype = C.c_void_p
+        lib.libdeflate_deflate_decompress.restype = C.c_int
+        lib.libdeflate_deflate_decompress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.libdeflate_free_decompressor.argtypes = [C.c_void_p]
+        return lib
+    return None
+
+
+def libdeflate_inflate(raw, isize):
+    import ctypes as C
+    lib = _libdeflate()
+    if lib is None:
+        return None
+    d = lib.libdeflate_alloc_decompressor()
+    out = C.create_string_buffer(max(isize, 1))
+    got = C.c_size_t()
+    rc = lib.libdeflate_deflate_decompress(d, raw, len(raw), out, isize, C.byref(got))
+    lib.libdeflate_free_decompressor(d)
+    assert rc == 0, rc                                      # LIBDEFLATE_SUCCESS
+    return out.raw[:got.value]
+
+
 def check_roundtrip(data, block_bytes=0xff00):
     data = bytes(data)
     stream = gpu_deflate(data, block_bytes)
@@ -50,6 +82,9 @@ def check_roundtrip(data, block_bytes=0xff00):
         assert d.eof and d.unused_data == b""               # one complete stream, nothing behind it
         want = data[i * block_bytes:(i + 1) * block_bytes]
         assert got == want, (i, len(got), len(want))
+        if i % 7 == 0:                                       # a second, independent inflater
+            ld = libdeflate_inflate(raw, len(want))
+            assert ld is None or ld == want, i
         assert isize == len(want) and crc == zlib.crc32(want) & 0xffffffff
         assert 18 + len(raw) + 8 <= 65536                    # a BGZF member
         back.append(got)
