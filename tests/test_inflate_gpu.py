@@ -172,3 +172,40 @@ def test_corrupt_streams_are_reported_not_trusted():
         assert ei.value.bad_block == 1, k
     # and the undamaged pair inflates
     assert gpu_inflate(ok + bytes(s), [(0, len(ok), len(good)), (len(ok), len(s), len(good))]).tobytes() == good + good
+
+
+def test_streams_written_by_libdeflate():
+    """htslib deflates BGZF blocks with libdeflate when it is built with it (and so does this repo's own BAM writer):
+    its streams -- other block splits, other Huffman codes, other match choices than zlib's at every level 1 .. 12 -- must
+    inflate to the same bytes on the GPU."""
+    import ctypes as C
+    from svdss_amd.bgzf import gpu_inflate
+    lib = None
+    for name in ("libdeflate.so.0", "libdeflate.so"):
+        try:
+            lib = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    if lib is None:
+        pytest.skip("libdeflate is not on this machine")
+    lib.libdeflate_alloc_compressor.restype = C.c_void_p
+    lib.libdeflate_alloc_compressor.argtypes = [C.c_int]
+    lib.libdeflate_deflate_compress.restype = C.c_size_t
+    lib.libdeflate_deflate_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.libdeflate_free_compressor.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(21)
+    pay = {k: v for k, v in _payloads(rng).items() if v}
+    blob, blocks, want = bytearray(), [], bytearray()
+    for level in (1, 3, 6, 9, 12):
+        comp = lib.libdeflate_alloc_compressor(level)
+        for name, data in pay.items():
+            out = C.create_string_buffer(len(data) + 1024)
+            n = lib.libdeflate_deflate_compress(comp, data, len(data), out, len(out))
+            assert n > 0, (level, name)
+            blocks.append((len(blob), n, len(data)))
+            blob += out.raw[:n]
+            want += data
+        lib.libdeflate_free_compressor(comp)
+    got = gpu_inflate(bytes(blob), blocks)
+    assert bytes(got) == bytes(want)
