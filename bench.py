@@ -358,7 +358,17 @@ def main():
     pp = svdss_amd.PingPong(ix, assemble=True)
     # the search runs on its own non-blocking stream (the library's call-side entry points use private streams too), so
     # that the call-side DP of earlier steps overlaps the search of the next one
-    sstream = torch.cuda.Stream(device=device)
+    def search_stream():
+        # (SVDSS_SEARCH_CUS / SVDSS_CALL_CUS: the search and the call-side DP on disjoint compute units -- the stream
+        # then comes from the library, which knows how to restrict it)
+        if os.environ.get("SVDSS_SEARCH_CUS"):
+            import ctypes as C
+            h = C.c_void_p()
+            check(lib.svdss_search_stream_create(local_rank, C.byref(h)), "svdss_search_stream_create")
+            return torch.cuda.ExternalStream(h.value, device=device)
+        return torch.cuda.Stream(device=device)
+
+    sstream = search_stream()
 
     gatherer = multi.SfsGatherer(slots=2) if gather else None
     pending_gather = []
@@ -385,7 +395,7 @@ def main():
 
     # --search-threads S > 1: S batch objects / streams / threads take the steps' searches in turn, so that the launch of
     # step i+1 is under way while step i runs its short tail kernels and host-side waits (order, scan, gather)
-    searchers = [(pp, sstream)] + [(svdss_amd.PingPong(ix, assemble=True), torch.cuda.Stream(device=device))
+    searchers = [(pp, sstream)] + [(svdss_amd.PingPong(ix, assemble=True), search_stream())
                                    for _ in range(max(0, (1 if gather else args.search_threads) - 1))]
 
     stats = {"kernel_ms": [], "pipeline_ms": [], "poa_ms": [], "aln_ms": [], "call_wall_ms": []}

@@ -101,6 +101,13 @@ int svdss_index_verify_device(const svdss_index_t* ix, int64_t stride, int64_t o
 
 /* GPUs this process sees (0: none). */
 int svdss_device_count(void);
+/* A stream of the kind the library makes for its own searches, for callers that pass their stream to
+ * svdss_sfs_search_batch_device (bench.py): non-blocking, and restricted to the compute units SVDSS_SEARCH_CUS names
+ * ("first,count": bits of hipExtStreamCreateWithCUMask's mask; csrc/hip_check.h) when that is set.  The call-side
+ * batch objects do the same with SVDSS_CALL_CUS: kernels that each fill the chip run side by side on disjoint CUs
+ * instead of taking turns (no counterpart in the reference: its threads share cores the same way through OpenMP). */
+int svdss_search_stream_create(int32_t device, void** stream);
+int svdss_stream_destroy(void* stream);
 /* One more replica of the index, in the HBM of `device` (the index is replicated per GPU, reads and
  * sub-clusters shard): a new handle with its own device buffers; *src is not modified (its text and suffix array are
  * fetched to the host first if it was built on a device). */

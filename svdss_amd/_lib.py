@@ -63,6 +63,8 @@ SIGNATURES = {
     "svdss_index_count": (_i64, [_p, _p, _i64]),
     "svdss_index_verify_device": (C.c_int, [_p, _i64, _p]),
     "svdss_device_count": (C.c_int, []),
+    "svdss_search_stream_create": (C.c_int, [_i32, C.POINTER(_p)]),
+    "svdss_stream_destroy": (C.c_int, [_p]),
     "svdss_index_replicate": (C.c_int, [_p, _i32, C.POINTER(_p)]),
     "svdss_sfs_search_batch": (C.c_int, [_p, _p, _p, _i64, _i32, C.POINTER(_p)]),
     "svdss_sfs_search_batch_bam": (C.c_int, [_p, _p, _p, _p, _i64, _i32, C.POINTER(_p)]),

@@ -24,6 +24,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "dev_arena.h"
+#include "hip_check.h"
 
 extern thread_local std::string g_svdss_hip_err;
 
@@ -397,7 +398,7 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
     if (b->stream) { (void)hipStreamDestroy(b->stream); b->stream = nullptr; }
     b->device = device;
   }
-  if (!b->stream) HIPCHK2(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  if (!b->stream) HIPCHK2(svdss_make_stream(&b->stream, "SVDSS_CALL_CUS"));
   const hipStream_t st = b->stream;
   const GapModel gm{gapo, gape, gapo2, gape2};
   hipEvent_t ev0, ev1;
@@ -551,7 +552,7 @@ extern "C" int svdss_indel_ratio_batch(const uint8_t* a, const int64_t* a_off, c
     if (R.stream) { (void)hipStreamDestroy(R.stream); R.stream = nullptr; }
     R.device = device;
   }
-  if (!R.stream) HIPCHK2(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+  if (!R.stream) HIPCHK2(svdss_make_stream(&R.stream, "SVDSS_CALL_CUS"));
   const hipStream_t st = R.stream;
   HIPCHK2(R.arena.reserve(DevArena::padded((size_t)atot) + DevArena::padded((size_t)btot) +
                           DevArena::padded(sizeof(LcsPair) * (size_t)n_pairs) + DevArena::padded(sizeof(int32_t) * (size_t)ws) +

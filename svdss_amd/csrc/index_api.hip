@@ -423,6 +423,20 @@ extern "C" int svdss_device_count(void) {
   return n;
 }
 
+extern "C" int svdss_search_stream_create(int32_t device, void** stream) {
+  if (!stream) return SVDSS_EINVAL;
+  HIPCHK(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  HIPCHK(svdss_make_stream(&st, "SVDSS_SEARCH_CUS"));
+  *stream = (void*)st;
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_stream_destroy(void* stream) {
+  if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  return SVDSS_OK;
+}
+
 // another replica of a resident (or host-side) index in the HBM of `device`: SURVEY 8(e), index replicated per GPU.
 // The new handle owns its device buffers and a copy of the small host-side parts; the source stays as it is.
 extern "C" int svdss_index_replicate(const svdss_index_t* src, int32_t device, svdss_index_t** out) {

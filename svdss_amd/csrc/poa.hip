@@ -28,6 +28,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "dev_arena.h"
+#include "hip_check.h"
 #include "poa_wave.h"
 
 extern thread_local std::string g_svdss_hip_err;
@@ -462,7 +463,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   // in order)
   while (b->streams.size() < 2) {
     hipStream_t st;
-    HIPCHK3(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHK3(svdss_make_stream(&st, "SVDSS_CALL_CUS"));
     b->streams.push_back(st);
   }
   const hipStream_t s0 = b->streams[0];

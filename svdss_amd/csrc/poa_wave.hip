@@ -48,6 +48,13 @@
 
 #define PNEG (-0x20000000)
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
+// the chain rows compute on score * TG + tag (see there)
+#define TG 16
+#define TG_M 15
+#define TG_E1 7
+#define TG_E2 6
+#define TG_F1 5
+#define TG_F2 4
 #define P_O1 4
 #define P_E1 2
 #define P_O2 24
@@ -87,6 +94,8 @@ __host__ __device__ inline WsLayout ws_layout(int nc, int ec, int max_len, int w
   return w;
 }
 
+__device__ __forceinline__ int tg_up(int x, int tag) { return x <= PNEG / 2 ? PNEG : (int)(((unsigned)x << 4) | (unsigned)tag); }
+__device__ __forceinline__ int tg_down(int x) { return x <= PNEG / 2 ? PNEG : x >> 4; }
 __device__ __forceinline__ int pl_score(int a, int b) { return (a >= 4 || b >= 4) ? 0 : (a == b ? P_MATCH : -P_MISMATCH); }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -378,7 +387,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               const bool ok = idx <= pend - pbeg;
               const int a = so + (ok ? idx : 0);
               const int32_t x0 = rH[a], x1 = rE1[a], x2 = rE2[a];
-              pH[c] = ok ? x0 : PNEG; pE1[c] = ok ? x1 : PNEG; pE2[c] = ok ? x2 : PNEG;
+              pH[c] = ok ? tg_up(x0, TG_M) : PNEG; pE1[c] = ok ? tg_up(x1, TG_E1) : PNEG; pE2[c] = ok ? tg_up(x2, TG_E2) : PNEG;
             }
             const int jb = pbeg + lane * C;
 #pragma unroll
@@ -391,7 +400,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
 #pragma unroll
             for (int c = 0; c < C; ++c) {
               const int idx = lane * C + c;
-              if (idx <= e_ - b_) { rH[sb_ + idx] = h_[c]; rE1[sb_ + idx] = e1_[c]; rE2[sb_ + idx] = e2_[c]; }
+              if (idx <= e_ - b_) { rH[sb_ + idx] = tg_down(h_[c]); rE1[sb_ + idx] = tg_down(e1_[c]); rE2[sb_ + idx] = tg_down(e2_[c]); }
             }
             if (lane < G) {
               const int o1 = sl * RST + lane, o2 = sb_ + (e_ - b_ + 1) + lane;
@@ -407,7 +416,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             const int width = end - beg + 1;
             const int delta = beg - pbeg;
             if (width > 64 * C || width > RS || (unsigned)delta > 1u) break;   // (the general code's business)
-            if (delta == 0) {
+            if (__builtin_expect(delta == 0, 0)) {
               // one row in fifty: the band did not move.  The previous row moves one column up the lanes (its origin
               // becomes pbeg - 1) and the code below applies unchanged
               if (pend - pbeg + 1 >= 64 * C) break;
@@ -421,11 +430,17 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             my_cells += (unsigned long long)width;
             ROWCNT(1);
             const int bv = (int)(ri & 7u);
-            const int s_mat = bv < 4 ? P_MATCH : 0, s_mis = bv < 4 ? -P_MISMATCH : 0;
+            const int s_mat = bv < 4 ? P_MATCH * TG : 0, s_mis = bv < 4 ? -P_MISMATCH * TG : 0;
             const int jb = beg + lane * C;
             // predecessor values of columns j - 1 (own registers) and j (the next register / the next lane's first)
             const int32_t nH = wave_shl1(pH[0], PNEG), n1 = wave_shl1(pE1[0], PNEG), n2 = wave_shl1(pE2[0], PNEG);
-            int32_t m0[C], e1[C], e2[C], hp[C], p1[C], p2[C];
+            // All values of the chain loop are score * 16 + tag, the tag naming where the value came from by the code the
+            // traceback reads, inverted (15 - code: M 15, E1 7, E2 6, F1 5, F2 4): a three-way maximum then picks the
+            // value AND, among equal scores, the source the specification tries first, and the direction nibbles are
+            // the inverted low bits of H and H' -- no chain of compares and selects.  (A larger score wins whatever the
+            // tags: 16 > 15.)  Values that meet each other as candidates of one state carry the same tag, so their
+            // order and their ties are those of the scores.
+            int32_t m0[C], e1[C], e2[C], hp[C], hq[C], t1[C], t2[C], p1[C], p2[C];
             uint32_t dw[C];
             bool valid[C];
 #pragma unroll
@@ -436,58 +451,63 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               qc[c] = qx[c];
               int sc = qc[c] == bv ? s_mat : s_mis;
               sc = qc[c] >= 4 ? 0 : sc;
-              m0[c] = hA + sc;
-              const int32_t a1 = hB - P_O1 - P_E1, b1 = xa - P_E1, a2 = hB - P_O2 - P_E2, b2 = xb - P_E2;
+              m0[c] = hA + sc;                                                                   // tag M
+              const int32_t a1 = hB - (P_O1 + P_E1) * TG - (TG_M - TG_E1), b1 = xa - P_E1 * TG;   // tag E1
+              const int32_t a2 = hB - (P_O2 + P_E2) * TG - (TG_M - TG_E2), b2 = xb - P_E2 * TG;   // tag E2
               e1[c] = imax(a1, b1); e2[c] = imax(a2, b2);
               dw[c] = (b1 > a1 ? 0x800u : 0u) | (b2 > a2 ? 0x8000u : 0u);
-              hp[c] = valid[c] ? imax(m0[c], imax(e1[c], e2[c])) : PNEG;
-              const int32_t t1 = hp[c] + j * P_E1, t2 = hp[c] + j * P_E2;
-              p1[c] = c ? imax(p1[c - 1], t1) : t1;
-              p2[c] = c ? imax(p2[c - 1], t2) : t2;
+              hp[c] = valid[c] ? imax(m0[c], imax(e1[c], e2[c])) : PNEG;                       // tag = its source
+              hq[c] = hp[c] | TG_M;                                                              // H' as a candidate: tag M
+              t1[c] = hq[c] + j * (P_E1 * TG); t2[c] = hq[c] + j * (P_E2 * TG);
+              p1[c] = c ? imax(p1[c - 1], t1[c]) : t1[c];
+              p2[c] = c ? imax(p2[c - 1], t2[c]) : t2[c];
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) qx[c] = q[imin(jb + c, L - 1)];
             // the row maximum rides along with the two F scans: F(j) = max_{k<j} H'(k) - o - (j - k) e < max H', so the
             // maximum of H over the row is the maximum of H' and H(j) attains it exactly where H'(j) does -- known three
             // scans earlier than from the finished H (a third DPP chain in the shadow of the other two)
-            int32_t lmax = hp[0];
+            int32_t lmax = hq[0];
 #pragma unroll
-            for (int c = 1; c < C; ++c) lmax = imax(lmax, hp[c]);
+            for (int c = 1; c < C; ++c) lmax = imax(lmax, hq[c]);
             const int32_t s1 = wave_scan_max_self(p1[C - 1]), s2 = wave_scan_max_self(p2[C - 1]), s3 = wave_scan_max_self(lmax);
             const int32_t X1 = wave_shr1(s1, PNEG), X2 = wave_shr1(s2, PNEG);
-            const int32_t hp_prev = wave_shr1(hp[C - 1], PNEG);
+            // (F opens at j from H'(j - 1) when that is a maximum of the prefix: t(j - 1) == x(j), the same test as
+            // H'(j - 1) - o - e == F(j) without the two subtractions)
+            const int32_t t1_prev = wave_shr1(t1[C - 1], PNEG), t2_prev = wave_shr1(t2[C - 1], PNEG);
             int32_t h[C];
             const int rowo = r * WS;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
               const int j = jb + c;
               const int32_t x1 = c ? imax(X1, p1[c - 1]) : X1, x2 = c ? imax(X2, p2[c - 1]) : X2;
-              const int32_t f1 = x1 - P_O1 - j * P_E1, f2 = x2 - P_O2 - j * P_E2;
+              const int32_t f1 = x1 - (P_O1 * TG + (TG_M - TG_F1)) - j * (P_E1 * TG), f2 = x2 - (P_O2 * TG + (TG_M - TG_F2)) - j * (P_E2 * TG);
               h[c] = imax(hp[c], imax(f1, f2));
-              const int32_t hp_left = c ? hp[c - 1] : hp_prev;
-              // the traceback's decisions, in the order the specification tries them.  Every lane stores: the columns
-              // past the band's end land in slots of this row that nothing reads (64 * C <= WS)
-              uint32_t dH = f1 == h[c] ? 10u : 11u;
-              dH = e2[c] == h[c] ? 9u : dH; dH = e1[c] == h[c] ? 8u : dH; dH = m0[c] == h[c] ? 0u : dH;
-              uint32_t dHp = e1[c] == hp[c] ? 0x80u : 0x90u;
-              dHp = m0[c] == hp[c] ? 0u : dHp;
-              const uint32_t o1 = hp_left - P_O1 - P_E1 == f1 ? 0x10000u : 0u;
-              const uint32_t o2 = hp_left - P_O2 - P_E2 == f2 ? 0x20000u : 0u;
-              gdir[rowo + (j & wm)] = dw[c] | dH | dHp | o1 | o2;
+              // the traceback's decisions.  Every lane stores: the columns past the band's end land in slots of this
+              // row that nothing reads (64 * C <= WS)
+              const uint32_t dH = ~(uint32_t)h[c] & 15u, dHp = ~(uint32_t)hp[c] & 15u;
+              const uint32_t o1 = (c ? t1[c - 1] : t1_prev) == x1 ? 0x10000u : 0u;
+              const uint32_t o2 = (c ? t2[c - 1] : t2_prev) == x2 ? 0x20000u : 0u;
+              // (a 32-bit byte offset from the uniform base: one address instruction less than a 64-bit sum.  gdir is
+              // the first of the row pools and a task has at most 65,000 rows of at most 4,096 words -- poa.hip --, so
+              // it ends below 2^30 words of the sub-cluster's workspace)
+              *(uint32_t*)((char*)W + (((gdir.o + (uint32_t)(rowo + (j & wm))) << 2) & 0xfffffffcu)) = dw[c] | dH | (dHp << 4) | o1 | o2;
             }
             if (end == L) {
 #pragma unroll
-              for (int c = 0; c < C; ++c) if (jb + c == L) hl[r] = h[c];
+              for (int c = 0; c < C; ++c) if (jb + c == L) hl[r] = tg_down(h[c]);
             }
 #pragma unroll
-            for (int c = 0; c < C; ++c) { pH[c] = valid[c] ? h[c] : PNEG; pE1[c] = valid[c] ? e1[c] : PNEG; pE2[c] = valid[c] ? e2[c] : PNEG; }
+            // (E1 / E2 of the columns past the band's end need no reset: they only ever derive from H = -inf of such
+            // columns and from each other, i.e. stay "no path" values)
+            for (int c = 0; c < C; ++c) { pH[c] = valid[c] ? (h[c] | TG_M) : PNEG; pE1[c] = e1[c]; pE2[c] = e2[c]; }
             // leftmost / rightmost column of the row maximum (the columns past the end hold -inf: they can only tie
             // with a row of unreachable cells, which the test below sends to beg / end anyway)
             const int32_t wmx = __builtin_amdgcn_readlane(s3, 63);
             int l = 1 << 20, rr = -1;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-              const unsigned long long em = __ballot(hp[c] == wmx);
+              const unsigned long long em = __ballot(hq[c] == wmx);
               if (em) { l = imin(l, C * (int)__builtin_ctzll(em) + c); rr = imax(rr, C * (63 - (int)__builtin_clzll(em)) + c); }
             }
             l += beg; rr += beg;

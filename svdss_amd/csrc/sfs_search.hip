@@ -1022,7 +1022,7 @@ static int batch_for_host_entry(const svdss_index_t* ix, svdss_sfs_batch_t** out
     b->device = ix->device;
     *out = b;
   }
-  if (!b->own_stream) HIPCHK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+  if (!b->own_stream) HIPCHK(svdss_make_stream(&b->own_stream, "SVDSS_SEARCH_CUS"));
   *bp = b;
   return SVDSS_OK;
 }
