@@ -50,6 +50,7 @@
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 // the chain rows compute on score * TG + tag (see there)
 #define TG 16
+#define TGB 0x20000000
 #define TG_M 15
 #define TG_E1 7
 #define TG_E2 6
@@ -94,8 +95,9 @@ __host__ __device__ inline WsLayout ws_layout(int nc, int ec, int max_len, int w
   return w;
 }
 
-__device__ __forceinline__ int tg_up(int x, int tag) { return x <= PNEG / 2 ? PNEG : (int)(((unsigned)x << 4) | (unsigned)tag); }
-__device__ __forceinline__ int tg_down(int x) { return x <= PNEG / 2 ? PNEG : x >> 4; }
+// (... + TGB: "no path" is 0 and everything near it, so that a lane shift can fill with zero)
+__device__ __forceinline__ int tg_up(int x, int tag) { return x <= PNEG / 2 ? 0 : (int)(((unsigned)x << 4) | (unsigned)tag) + TGB; }
+__device__ __forceinline__ int tg_down(int x) { return x <= TGB / 2 ? PNEG : (x - TGB) >> 4; }
 __device__ __forceinline__ int pl_score(int a, int b) { return (a >= 4 || b >= 4) ? 0 : (a == b ? P_MATCH : -P_MISMATCH); }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -138,6 +140,9 @@ __device__ __forceinline__ int wave_scan_add(int x) {
 
 // value of the lane below (lane 0 receives `fill`)
 __device__ __forceinline__ int wave_shr1(int x, int fill) { return dppi<0x138, 0xf>(fill, x); }
+// the same with 0 for the lane that has no neighbour (bound_ctrl: no register to preload with the fill value)
+__device__ __forceinline__ int wave_shr1z(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_shl1z(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true); }
 // value of the lane above (lane 63 receives `fill`)
 __device__ __forceinline__ int wave_shl1(int x, int fill) { return dppi<0x130, 0xf>(fill, x); }
 
@@ -387,7 +392,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               const bool ok = idx <= pend - pbeg;
               const int a = so + (ok ? idx : 0);
               const int32_t x0 = rH[a], x1 = rE1[a], x2 = rE2[a];
-              pH[c] = ok ? tg_up(x0, TG_M) : PNEG; pE1[c] = ok ? tg_up(x1, TG_E1) : PNEG; pE2[c] = ok ? tg_up(x2, TG_E2) : PNEG;
+              pH[c] = ok ? tg_up(x0, TG_M) : 0; pE1[c] = ok ? tg_up(x1, TG_E1) : 0; pE2[c] = ok ? tg_up(x2, TG_E2) : 0;
             }
             const int jb = pbeg + lane * C;
 #pragma unroll
@@ -420,7 +425,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               // one row in fifty: the band did not move.  The previous row moves one column up the lanes (its origin
               // becomes pbeg - 1) and the code below applies unchanged
               if (pend - pbeg + 1 >= 64 * C) break;
-              const int32_t tH = wave_shr1(pH[C - 1], PNEG), t1 = wave_shr1(pE1[C - 1], PNEG), t2 = wave_shr1(pE2[C - 1], PNEG);
+              const int32_t tH = wave_shr1z(pH[C - 1]), t1 = wave_shr1z(pE1[C - 1]), t2 = wave_shr1z(pE2[C - 1]);
 #pragma unroll
               for (int c = C - 1; c > 0; --c) { pH[c] = pH[c - 1]; pE1[c] = pE1[c - 1]; pE2[c] = pE2[c - 1]; }
               pH[0] = tH; pE1[0] = t1; pE2[0] = t2;
@@ -433,8 +438,9 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
             const int s_mat = bv < 4 ? P_MATCH * TG : 0, s_mis = bv < 4 ? -P_MISMATCH * TG : 0;
             const int jb = beg + lane * C;
             // predecessor values of columns j - 1 (own registers) and j (the next register / the next lane's first)
-            const int32_t nH = wave_shl1(pH[0], PNEG), n1 = wave_shl1(pE1[0], PNEG), n2 = wave_shl1(pE2[0], PNEG);
-            // All values of the chain loop are score * 16 + tag, the tag naming where the value came from by the code the
+            const int32_t nH = wave_shl1z(pH[0]), n1 = wave_shl1z(pE1[0]), n2 = wave_shl1z(pE2[0]);
+            // All values of the chain loop are TGB + score * 16 + tag ("no path": 0 and what is near it, so that the
+            // lane shifts fill with zero through bound_ctrl), the tag naming where the value came from by the code the
             // traceback reads, inverted (15 - code: M 15, E1 7, E2 6, F1 5, F2 4): a three-way maximum then picks the
             // value AND, among equal scores, the source the specification tries first, and the direction nibbles are
             // the inverted low bits of H and H' -- no chain of compares and selects.  (A larger score wins whatever the
@@ -456,7 +462,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               const int32_t a2 = hB - (P_O2 + P_E2) * TG - (TG_M - TG_E2), b2 = xb - P_E2 * TG;   // tag E2
               e1[c] = imax(a1, b1); e2[c] = imax(a2, b2);
               dw[c] = (b1 > a1 ? 0x800u : 0u) | (b2 > a2 ? 0x8000u : 0u);
-              hp[c] = valid[c] ? imax(m0[c], imax(e1[c], e2[c])) : PNEG;                       // tag = its source
+              hp[c] = valid[c] ? imax(m0[c], imax(e1[c], e2[c])) : 0;                         // tag = its source
               hq[c] = hp[c] | TG_M;                                                              // H' as a candidate: tag M
               t1[c] = hq[c] + j * (P_E1 * TG); t2[c] = hq[c] + j * (P_E2 * TG);
               p1[c] = c ? imax(p1[c - 1], t1[c]) : t1[c];
@@ -471,10 +477,10 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
 #pragma unroll
             for (int c = 1; c < C; ++c) lmax = imax(lmax, hq[c]);
             const int32_t s1 = wave_scan_max_self(p1[C - 1]), s2 = wave_scan_max_self(p2[C - 1]), s3 = wave_scan_max_self(lmax);
-            const int32_t X1 = wave_shr1(s1, PNEG), X2 = wave_shr1(s2, PNEG);
+            const int32_t X1 = wave_shr1z(s1), X2 = wave_shr1z(s2);
             // (F opens at j from H'(j - 1) when that is a maximum of the prefix: t(j - 1) == x(j), the same test as
             // H'(j - 1) - o - e == F(j) without the two subtractions)
-            const int32_t t1_prev = wave_shr1(t1[C - 1], PNEG), t2_prev = wave_shr1(t2[C - 1], PNEG);
+            const int32_t t1_prev = wave_shr1z(t1[C - 1]), t2_prev = wave_shr1z(t2[C - 1]);
             int32_t h[C];
             const int rowo = r * WS;
 #pragma unroll
@@ -500,7 +506,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
 #pragma unroll
             // (E1 / E2 of the columns past the band's end need no reset: they only ever derive from H = -inf of such
             // columns and from each other, i.e. stay "no path" values)
-            for (int c = 0; c < C; ++c) { pH[c] = valid[c] ? (h[c] | TG_M) : PNEG; pE1[c] = e1[c]; pE2[c] = e2[c]; }
+            for (int c = 0; c < C; ++c) { pH[c] = valid[c] ? (h[c] | TG_M) : 0; pE1[c] = e1[c]; pE2[c] = e2[c]; }
             // leftmost / rightmost column of the row maximum (the columns past the end hold -inf: they can only tie
             // with a row of unreachable cells, which the test below sends to beg / end anyway)
             const int32_t wmx = __builtin_amdgcn_readlane(s3, 63);
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               if (em) { l = imin(l, C * (int)__builtin_ctzll(em) + c); rr = imax(rr, C * (63 - (int)__builtin_clzll(em)) + c); }
             }
             l += beg; rr += beg;
-            if (wmx <= PNEG / 2) { l = beg; rr = end; }
+            if (wmx <= TGB / 2) { l = beg; rr = end; }
             last_r = r; last_mpl = UNI(l); last_mpr = UNI(rr); last_beg = beg; last_end = end;
             pbeg = beg; pend = end; pm_l = last_mpl; pm_r = last_mpr;
             in_ring = (ri & RI_RING) != 0;
