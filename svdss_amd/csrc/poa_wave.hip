@@ -504,9 +504,10 @@ __global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, 
               for (int c = 0; c < C; ++c) if (jb + c == L) hl[r] = tg_down(h[c]);
             }
 #pragma unroll
-            // (E1 / E2 of the columns past the band's end need no reset: they only ever derive from H = -inf of such
-            // columns and from each other, i.e. stay "no path" values)
-            for (int c = 0; c < C; ++c) { pH[c] = valid[c] ? (h[c] | TG_M) : 0; pE1[c] = e1[c]; pE2[c] = e2[c]; }
+            // (E1 / E2 of the columns past the band's end are reset like H: the end of the band can move left -- the
+            // rightmost maximum jumps --, so such a column may have been inside the previous row's band and hold
+            // real values, and it may be inside the next row's band again)
+            for (int c = 0; c < C; ++c) { pH[c] = valid[c] ? (h[c] | TG_M) : 0; pE1[c] = valid[c] ? e1[c] : 0; pE2[c] = valid[c] ? e2[c] : 0; }
             // leftmost / rightmost column of the row maximum (the columns past the end hold -inf: they can only tie
             // with a row of unreachable cells, which the test below sends to beg / end anyway)
             const int32_t wmx = __builtin_amdgcn_readlane(s3, 63);

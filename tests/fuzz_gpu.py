@@ -543,7 +543,26 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="gpurun_out/fuzz")
     ap.add_argument("--max-iterations", type=int, default=0)
+    ap.add_argument("--replay", default="", help="a poa_*.npz written by an earlier run: that cluster alone, again")
     args = ap.parse_args()
+    if args.replay:
+        from svdss_amd import calldp
+        d = np.load(args.replay)
+        flat, off = d["reads_flat"], d["reads_off"]
+        reads = [np.ascontiguousarray(flat[off[i]:off[i + 1]], dtype=np.uint8) for i in range(len(off) - 1)]
+        want = bytes(LET[O.poa_consensus(reads)]).decode()
+        got, stats = calldp.run_poa([reads])
+        print(f"[replay] {len(reads)} reads of {[len(r) for r in reads]}: consensus {len(got[0])} vs the oracle's {len(want)}: "
+              f"{'same' if got[0] == want else 'DIFFERENT'} ({stats})")
+        # which reads does it take?  every prefix of the cluster, and the cluster without its empty reads
+        for n in range(1, len(reads) + 1):
+            g, _ = calldp.run_poa([reads[:n]])
+            w = bytes(LET[O.poa_consensus(reads[:n])]).decode()
+            print(f"[replay]   first {n} read(s): {'same' if g[0] == w else 'DIFFERENT'}")
+        ne = [r for r in reads if len(r)]
+        g, _ = calldp.run_poa([ne])
+        print(f"[replay]   without empty reads: {'same' if g[0] == bytes(LET[O.poa_consensus(ne)]).decode() else 'DIFFERENT'}")
+        sys.exit(0 if got[0] == want else 1)
     os.makedirs(args.out, exist_ok=True)
     rc = 0
     for name in args.what.split(","):

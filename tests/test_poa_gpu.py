@@ -105,3 +105,28 @@ def test_node_with_many_predecessors_falls_back():
     got, stats = caller.run_poa([reads, [t, t]])
     assert got[0] == _to_str(O.poa_consensus(reads)) and got[1] == _to_str(t)
     assert stats["hbm"] >= 1
+
+
+def test_band_whose_end_moves_left():
+    """Found by tests/fuzz_gpu.py (seed 7, iteration 105; the cluster is tests/golden/poa_fuzz_seed7_105.npz): a short
+    read of homopolymer runs against the graph of a longer unrelated one.  The row maximum jumps, the band's end moves
+    LEFT and right again, so a column can leave the band and come back: what it held (E1 / E2 as well as H) must read
+    as "no path" in between.  Also more reads of that kind, and the band standing still at the last column for a
+    hundred rows (query shorter than the graph)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "poa_fuzz_seed7_105.npz"))
+    flat, off = d["reads_flat"], d["reads_off"]
+    reads = [np.ascontiguousarray(flat[off[i]:off[i + 1]], dtype=np.uint8) for i in range(len(off) - 1)]
+    assert [len(r) for r in reads] == [186, 0, 83]
+    rng = np.random.default_rng(105)
+    clusters = [reads, [reads[0], reads[2]]]
+    for k in range(40):
+        long_ = rng.integers(0, 4, size=int(rng.integers(100, 900)), dtype=np.uint8)
+        runs = rng.geometric(0.25, size=400)
+        short = np.repeat(rng.integers(0, 4, size=400, dtype=np.uint8), runs)[:int(rng.integers(20, len(long_)))]
+        other = mutate(rng, long_, 0.1)
+        clusters.append([long_, short, other] if k % 2 else [short, long_, short[::-1].copy(), other])
+    got, stats = caller.run_poa(clusters)
+    for k, (cl, g) in enumerate(zip(clusters, got)):
+        assert g == _to_str(O.poa_consensus(cl)), k
+    assert stats["hbm"] <= 2
