@@ -195,7 +195,7 @@ def _mutate(rng, s, e):
 
 def _weird_cluster(rng):
     kind = int(rng.integers(0, 8))
-    L = int(rng.choice([5, 40, 200, 200, 700, 700, 1500, 2400]))
+    L = int(rng.choice([5, 40, 200, 200, 700, 700, 1500, 2400, 5600 if rng.random() < 0.15 else 300]))
     if kind == 0:
         t = rng.integers(0, 4, size=L, dtype=np.uint8)
     elif kind == 1:                                       # tandem repeat: every alignment has ties
@@ -207,6 +207,8 @@ def _weird_cluster(rng):
     else:
         t = rng.integers(0, 4, size=L, dtype=np.uint8)
     n = int(rng.choice([1, 2, 3, 5, 8, 12, 20, 45]))
+    if L > 3000:
+        n = min(n, 4)
     e = float(rng.choice([0, 0.005, 0.02, 0.1, 0.2]))
     alts = [t]
     for _ in range(int(rng.integers(0, 4))):              # haplotypes: an insertion, a deletion, a duplication, a different start
@@ -236,6 +238,23 @@ def _weird_cluster(rng):
         elif x < 0.12:
             r = np.full(int(rng.integers(1, 50)), 4, np.uint8)
         reads.append(np.ascontiguousarray(r, dtype=np.uint8))
+    if kind in (3, 4):                                    # lengths all over the place: slices of the template, unrelated reads, runs
+        reads = []                                        # (bands that stand still, jump, lose the sink: fuzz seed 7 / 105)
+        for i in range(min(n, 12) + 1):
+            x = rng.random()
+            if x < 0.4:
+                a = int(rng.integers(0, len(t)))
+                r = _mutate(rng, t[a:a + int(rng.integers(1, len(t) - a + 1))], e)
+            elif x < 0.7:
+                runs = rng.geometric(float(rng.choice([0.15, 0.3, 0.6])), size=len(t) + 1)
+                r = np.repeat(rng.integers(0, 4, size=len(t) + 1, dtype=np.uint8), runs)[:int(rng.integers(1, len(t) + 1))]
+            elif x < 0.85:
+                r = rng.integers(0, 4, size=int(rng.integers(1, 2 * len(t) + 1)), dtype=np.uint8)
+            else:
+                r = _mutate(rng, t, e)
+            reads.append(np.ascontiguousarray(r, dtype=np.uint8))
+        if L > 3000:
+            reads = reads[:4]
     if kind == 7:                                         # many different insertions at one place: a node with many predecessors
         at = len(t) // 2
         reads = [t] + [np.concatenate([t[:at], rng.integers(0, 4, size=3 + i, dtype=np.uint8), t[at:]]) for i in range(int(rng.integers(2, 14)))]
