@@ -12,7 +12,6 @@ exits 1; a summary line per fuzzer otherwise.  Runs on a GPU box (`gpurun`), min
 runs made are under profiles/."""
 import argparse
 import os
-import struct
 import sys
 import time
 import zlib
