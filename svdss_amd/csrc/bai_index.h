@@ -72,14 +72,26 @@ struct BaiIndex {
     char magic[4];
     int32_t n_ref;
     if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "BAI\1", 4) != 0 || fread(&n_ref, 4, 1, f) != 1 || n_ref < 0) return false;
+    // a count in the file is believed only as far as the file has bytes for what it counts: a damaged index is
+    // refused, not answered with an allocation of gigabytes
+    uint64_t left = 0;
+    {
+      const off_t here = ftello(f);
+      if (here < 0 || fseeko(f, 0, SEEK_END) != 0) return false;
+      const off_t end = ftello(f);
+      if (end < here || fseeko(f, here, SEEK_SET) != 0) return false;
+      left = (uint64_t)(end - here);
+    }
+    auto fits = [&](uint64_t count, uint64_t bytes_each) { return count <= left / bytes_each; };
+    if (!fits((uint64_t)n_ref, 8)) return false;
     refs.resize((size_t)n_ref);
     for (Ref& r : refs) {
       int32_t n_bin;
-      if (fread(&n_bin, 4, 1, f) != 1 || n_bin < 0) return false;
+      if (fread(&n_bin, 4, 1, f) != 1 || n_bin < 0 || !fits((uint64_t)n_bin, 8)) return false;
       for (int32_t b = 0; b < n_bin; ++b) {
         uint32_t bin;
         int32_t n_chunk;
-        if (fread(&bin, 4, 1, f) != 1 || fread(&n_chunk, 4, 1, f) != 1 || n_chunk < 0) return false;
+        if (fread(&bin, 4, 1, f) != 1 || fread(&n_chunk, 4, 1, f) != 1 || n_chunk < 0 || !fits((uint64_t)n_chunk, 16)) return false;
         std::vector<std::pair<uint64_t, uint64_t>> ch((size_t)n_chunk);
         for (auto& c : ch)
           if (fread(&c.first, 8, 1, f) != 1 || fread(&c.second, 8, 1, f) != 1) return false;
@@ -87,7 +99,7 @@ struct BaiIndex {
       }
       std::sort(r.bins.begin(), r.bins.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
       int32_t n_intv;
-      if (fread(&n_intv, 4, 1, f) != 1 || n_intv < 0) return false;
+      if (fread(&n_intv, 4, 1, f) != 1 || n_intv < 0 || !fits((uint64_t)n_intv, 8)) return false;
       r.linear.resize((size_t)n_intv);
       if (n_intv && fread(r.linear.data(), 8, (size_t)n_intv, f) != (size_t)n_intv) return false;
     }
@@ -172,7 +184,7 @@ inline std::string bam_scan_chunks(const std::string& path, const std::vector<st
       v.n_cigar = n_cigar;
       memcpy(&v.flag, core + 14, 2);
       memcpy(&v.l_seq, core + 16, 4);
-      const size_t head = 32 + (size_t)v.l_name + 4u * v.n_cigar + (size_t)(v.l_seq < 0 ? 0 : (v.l_seq + 1) / 2 + v.l_seq);
+      const size_t head = 32 + (size_t)v.l_name + 4u * v.n_cigar + (v.l_seq < 0 ? (size_t)0 : ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq);
       if (v.l_seq < 0 || head > (size_t)block_size) { err = "corrupt record"; break; }
       v.l_aux = (uint32_t)((size_t)block_size - head);
       fn(v);

@@ -313,15 +313,19 @@ class BamReader {
     if (!read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { if (err_.empty()) err_ = "not a BAM file"; return false; }
     int32_t l_text, n_ref;
     if (!read(&l_text, 4)) return fail("truncated header");
-    std::string text((size_t)l_text, '\0');
-    if (l_text && !read(&text[0], (size_t)l_text)) return fail("truncated header");
+    if (l_text < 0) return fail("corrupt header");
+    // (the text and the names are read in pieces: a length field is not trusted with an allocation of its size)
+    std::string text;
+    if (!read_string(text, (size_t)l_text)) return fail("truncated header");
     text_ = text;
     if (!read(&n_ref, 4)) return fail("truncated header");
+    if (n_ref < 0) return fail("corrupt header");
     for (int i = 0; i < n_ref; ++i) {
       int32_t l_name, l_ref;
       if (!read(&l_name, 4)) return fail("truncated header");
-      std::string name((size_t)l_name, '\0');
-      if (!read(&name[0], (size_t)l_name) || !read(&l_ref, 4)) return fail("truncated header");
+      if (l_name < 0) return fail("corrupt header");
+      std::string name;
+      if (!read_string(name, (size_t)l_name) || !read(&l_ref, 4)) return fail("truncated header");
       if (!name.empty() && name.back() == '\0') name.pop_back();
       refs_.push_back(name);
       ref_lens_.push_back(l_ref);
@@ -350,7 +354,7 @@ class BamReader {
     memcpy(&flag, p + 14, 2);
     memcpy(&l_seq, p + 16, 4);
     size_t o = 32;
-    if (o + l_read_name + 4u * n_cigar + (size_t)(l_seq + 1) / 2 + (size_t)l_seq > (size_t)block_size) {
+    if (l_seq < 0 || o + l_read_name + 4u * n_cigar + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)block_size) {
       err_ = "corrupt record";
       return -1;
     }
@@ -364,8 +368,8 @@ class BamReader {
     memcpy(&r.mtid, p + 20, 4);
     memcpy(&r.mpos, p + 24, 4);
     memcpy(&r.isize, p + 28, 4);
-    r.seq4.assign(p + o, p + o + (size_t)(l_seq + 1) / 2);
-    o += (size_t)(l_seq + 1) / 2;
+    r.seq4.assign(p + o, p + o + ((size_t)l_seq + 1) / 2);
+    o += ((size_t)l_seq + 1) / 2;
     if (want_qual) r.qual.assign(p + o, p + o + (size_t)l_seq); else r.qual.clear();
     o += (size_t)l_seq;
     r.aux.assign(p + o, p + block_size);
@@ -460,7 +464,7 @@ class BamReader {
     uint8_t mapq = 0;
     size_t name_off() const { return off; }
     size_t seq_off() const { return off + l_name + 4u * n_cigar; }
-    size_t aux_off() const { return seq_off() + (size_t)(l_seq + 1) / 2; }
+    size_t aux_off() const { return seq_off() + ((size_t)l_seq + 1) / 2; }
   };
 
   // growable byte buffer without the zero-fill of std::vector::resize (the arena is written exactly once)
@@ -504,7 +508,7 @@ class BamReader {
     memcpy(&rr.flag, core + 14, 2);
     memcpy(&rr.l_seq, core + 16, 4);
     if (rr.l_seq < 0) { err_ = "corrupt record"; return -1; }
-    const size_t head = (size_t)rr.l_name + 4u * rr.n_cigar + (size_t)(rr.l_seq + 1) / 2;
+    const size_t head = (size_t)rr.l_name + 4u * rr.n_cigar + ((size_t)rr.l_seq + 1) / 2;
     if (32 + head + (size_t)rr.l_seq > (size_t)block_size) { err_ = "corrupt record"; return -1; }
     rr.l_aux = (uint32_t)((size_t)block_size - 32 - head - (size_t)rr.l_seq);
     rr.off = arena.size;
@@ -528,7 +532,7 @@ class BamReader {
     uint8_t mapq = 0;
     const uint8_t* name() const { return p + 32; }
     const uint8_t* seq4() const { return p + 32 + l_name + 4u * n_cigar; }
-    const uint8_t* aux() const { return seq4() + (size_t)(l_seq + 1) / 2 + (size_t)l_seq; }
+    const uint8_t* aux() const { return seq4() + ((size_t)l_seq + 1) / 2 + (size_t)l_seq; }
   };
   std::shared_ptr<Bytes> chunk() const { return chunk_; }
   uint64_t chunk_id() const { return chunk_id_; }
@@ -559,7 +563,7 @@ class BamReader {
     memcpy(&v.flag, core + 14, 2);
     memcpy(&v.l_seq, core + 16, 4);
     if (v.l_seq < 0) { err_ = "corrupt record"; return -1; }
-    const size_t head = 32 + (size_t)v.l_name + 4u * v.n_cigar + (size_t)(v.l_seq + 1) / 2 + (size_t)v.l_seq;
+    const size_t head = 32 + (size_t)v.l_name + 4u * v.n_cigar + ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq;
     if (head > (size_t)block_size) { err_ = "corrupt record"; return -1; }
     v.l_aux = (uint32_t)((size_t)block_size - head);
     return 1;
@@ -573,7 +577,7 @@ class BamReader {
     r.cigar.resize(rr.n_cigar);
     if (rr.n_cigar) memcpy(r.cigar.data(), p + rr.l_name, 4u * rr.n_cigar);
     const uint8_t* sq = arena.data() + rr.seq_off();
-    if (want_seq) r.seq4.assign(sq, sq + (size_t)(rr.l_seq + 1) / 2); else r.seq4.clear();
+    if (want_seq) r.seq4.assign(sq, sq + ((size_t)rr.l_seq + 1) / 2); else r.seq4.clear();
     r.qual.clear();
     const uint8_t* ax = arena.data() + rr.aux_off();
     r.aux.assign(ax, ax + rr.l_aux);
@@ -584,13 +588,13 @@ class BamReader {
     r.qname.assign((const char*)v.name(), v.l_name ? v.l_name - 1 : 0);
     r.cigar.resize(v.n_cigar);
     if (v.n_cigar) memcpy(r.cigar.data(), v.name() + v.l_name, 4u * v.n_cigar);
-    if (want_seq) r.seq4.assign(v.seq4(), v.seq4() + (size_t)(v.l_seq + 1) / 2); else r.seq4.clear();
+    if (want_seq) r.seq4.assign(v.seq4(), v.seq4() + ((size_t)v.l_seq + 1) / 2); else r.seq4.clear();
     r.qual.clear();
     r.aux.assign(v.aux(), v.aux() + v.l_aux);
   }
   static void materialize_seq(const Arena& arena, const RawRec& rr, BamRecord& r) {
     const uint8_t* sq = arena.data() + rr.seq_off();
-    r.seq4.assign(sq, sq + (size_t)(rr.l_seq + 1) / 2);
+    r.seq4.assign(sq, sq + ((size_t)rr.l_seq + 1) / 2);
   }
 
   // integer aux tag (bam_aux_get + bam_aux2i); returns false if absent or not an integer
@@ -638,6 +642,18 @@ class BamReader {
  private:
   bool fail(const char* m) { err_ = m; return false; }
   bool read(void* dst, size_t n) { return read_some(dst, n) == n; }
+  // n bytes into a string that grows as they arrive (a damaged length field costs a failed read, not an allocation)
+  bool read_string(std::string& out, size_t n) {
+    out.clear();
+    char piece[65536];
+    while (n) {
+      const size_t take = n < sizeof piece ? n : sizeof piece;
+      if (!read(piece, take)) return false;
+      out.append(piece, take);
+      n -= take;
+    }
+    return true;
+  }
 
   bool skip(size_t n) {
     while (n) {

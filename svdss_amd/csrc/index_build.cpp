@@ -320,12 +320,21 @@ int svdss_index_save_records_host(const svdss_index* ix, const char* path) {
   return ok ? SVDSS_OK : SVDSS_EIO;
 }
 
+// true if the file has at least `bytes` more bytes: a header's sizes are believed only as far as the file goes
+static bool file_holds(FILE* f, uint64_t bytes) {
+  const off_t here = ftello(f);
+  if (here < 0 || fseeko(f, 0, SEEK_END) != 0) return false;
+  const off_t end = ftello(f);
+  return fseeko(f, here, SEEK_SET) == 0 && end >= here && (uint64_t)(end - here) >= bytes;
+}
+
 int svdss_index_load_records_host(const char* path, svdss_index* ix) {
   FILE* f = fopen(path, "rb");
   if (!f) return SVDSS_EIO;
   RecHeader h;
   if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SVDSSRC1", 8) != 0 || h.n < 0 || h.total < 0 ||
-      h.n_contigs <= 0 || h.n != 2 * (h.total + h.n_contigs)) {
+      h.n_contigs <= 0 || h.total > ((int64_t)1 << 46) || h.n != 2 * (h.total + h.n_contigs) ||
+      !file_holds(f, (uint64_t)h.n_contigs * 8 + (uint64_t)h.total)) {
     fclose(f);
     return SVDSS_EIO;
   }
@@ -337,7 +346,14 @@ int svdss_index_load_records_host(const char* path, svdss_index* ix) {
   ok = ok && (h.total == 0 || fread(ix->records.data(), 1, (size_t)h.total, f) == (size_t)h.total);
   fclose(f);
   int64_t sum = 0;
-  for (int64_t l : ix->rec_lens) { if (l < 0) ok = false; sum += l; }
+  for (int64_t l : ix->rec_lens) { if (l < 0 || l > h.total) ok = false; else sum += l; }
+  // (the records are nt6 symbols 1..5: anything else would index the builder's tables out of range)
+  if (ok && sum == h.total) {
+    bool sym_ok = true;
+#pragma omp parallel for reduction(&& : sym_ok) schedule(static)
+    for (int64_t i = 0; i < h.total; ++i) sym_ok = sym_ok && ix->records[(size_t)i] >= 1 && ix->records[(size_t)i] <= 5;
+    ok = sym_ok;
+  }
   if (!ok || sum != h.total) { ix->rec_lens.clear(); ix->records.clear(); return SVDSS_EIO; }
   ix->n = h.n;
   memcpy(ix->acc, h.acc, sizeof h.acc);
@@ -350,8 +366,9 @@ int svdss_index_load_host(const char* path, svdss_index* ix) {
   if (!f) return SVDSS_EIO;
   FileHeader h;
   if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SVDSSFM2", 8) != 0 ||
-      h.block_syms != SVDSS_BLOCK_SYMS || h.n < 0 || h.n_blocks != h.n / SVDSS_BLOCK_SYMS + 1 ||
-      h.n_dollar < 0) {
+      h.block_syms != SVDSS_BLOCK_SYMS || h.n < 0 || h.n > ((int64_t)1 << 46) || h.n_blocks != h.n / SVDSS_BLOCK_SYMS + 1 ||
+      h.n_dollar < 0 || h.n_dollar > h.n ||
+      !file_holds(f, (uint64_t)h.n_blocks * 4 * sizeof(svdss_u4) + (uint64_t)h.n_dollar * 8 + (uint64_t)h.n * (h.sa_wide ? 9 : 5))) {
     fclose(f);
     return SVDSS_EIO;
   }
@@ -373,5 +390,19 @@ int svdss_index_load_host(const char* path, svdss_index* ix) {
   else
     ok = ok && fread(ix->sa32.data(), sizeof(uint32_t), ix->sa32.size(), f) == ix->sa32.size();
   fclose(f);
+  if (ok) {
+    // what the kernels index with must be in range (a damaged file is refused here, not found out on the GPU): text
+    // symbols, suffix-array entries, '$' rows, the symbol totals
+    const int64_t n = h.n;
+    bool in_range = ix->acc[0] == 0 && ix->acc[6] == n;
+    for (int c = 0; c < 6 && in_range; ++c) in_range = ix->acc[c] <= ix->acc[c + 1];
+    for (size_t i = 0; i < ix->dollar.size() && in_range; ++i)
+      in_range = ix->dollar[i] >= 0 && ix->dollar[i] < n && (i == 0 || ix->dollar[i] > ix->dollar[i - 1]);
+    bool cells = true;
+#pragma omp parallel for reduction(&& : cells) schedule(static)
+    for (int64_t i = 0; i < n; ++i)
+      cells = cells && ix->text[(size_t)i] <= 5 && (ix->sa_wide ? ix->sa64[(size_t)i] < (uint64_t)n : (int64_t)ix->sa32[(size_t)i] < n);
+    ok = in_range && cells;
+  }
   return ok ? SVDSS_OK : SVDSS_EIO;
 }

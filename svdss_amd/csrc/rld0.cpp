@@ -307,51 +307,64 @@ int rld0_read(const char* path, std::vector<uint8_t>& bwt) {
   if (fread(mcnt, 8, (size_t)asize, f) != (size_t)asize) { fclose(f); return SVDSS_EIO; }
   // (a block is read up to its tail whatever k says: room for the whole last block, zeroed)
   const uint64_t ssz = (uint64_t)1 << sbits;
-  if (k > ((uint64_t)1 << 40)) { fclose(f); return SVDSS_EIO; }
+  {   // the data length the header states must be in the file (it is not trusted with an allocation otherwise)
+    const off_t here = ftello(f);
+    if (here < 0 || fseeko(f, 0, SEEK_END) != 0) { fclose(f); return SVDSS_EIO; }
+    const off_t end = ftello(f);
+    if (end < here || fseeko(f, here, SEEK_SET) != 0 || k > (uint64_t)(end - here) / 8) { fclose(f); return SVDSS_EIO; }
+  }
   std::vector<uint64_t> z;
   try { z.resize((size_t)((k + ssz - 1) / ssz * ssz + ssz + 2), 0); } catch (...) { fclose(f); return SVDSS_ENOMEM; }
   if (k && fread(z.data(), 8, (size_t)k, f) != (size_t)k) { fclose(f); return SVDSS_EIO; }
   fclose(f);
   uint64_t total = 0;
-  for (int c = 0; c < asize; ++c) total += mcnt[c];
-  try { bwt.assign((size_t)total, 0); } catch (...) { return SVDSS_ENOMEM; }
+  for (int c = 0; c < asize; ++c) {
+    if (mcnt[c] > ((uint64_t)1 << 48) || total + mcnt[c] > ((uint64_t)1 << 48)) return SVDSS_EIO;
+    total += mcnt[c];
+  }
   const int ssize = 1 << sbits;
   const int off0[3] = {(ASIZE1 * 16 + 63) / 64, (ASIZE1 * 32 + 63) / 64, ASIZE1};
-  uint64_t out = 0;
-  for (int64_t shead = 0; shead < (int64_t)k && out < total; shead += ssize) {
-    const int type = (int)(z[(size_t)shead] >> 62);
-    if (type > 2) return SVDSS_EIO;
-    int64_t p = shead + off0[type];
-    const int64_t stail = shead + ssize - (((shead + ssize) & (RLD_LSIZE - 1)) == 0 ? 2 : 1);
-    int r = 64;
-    while (p <= stail && out < total) {
-      // the next 64 bits of the block, zero beyond its last word
-      uint64_t x = r == 64 ? z[(size_t)p] : (z[(size_t)p] << (64 - r)) | (p != stail ? z[(size_t)p + 1] >> r : 0);
-      if ((x >> 58) == 0) break;   // no code starts with six zeros: the rest of the block is padding
-      const int zc = __builtin_clzll(x);
-      const int y = (int)((x << zc) >> (64 - (zc + 1))) - 1;   // the gamma part holds y + 1 in zc + 1 bits
-      int w = 2 * zc + 1;
-      if (y < 0 || w + y + ABITS > 64) return SVDSS_EIO;
-      const uint64_t l = y ? ((x << w) >> (64 - y)) | ((uint64_t)1 << y) : 1;
-      w += y;
-      const int c = (int)((x << w) >> (64 - ABITS));
-      w += ABITS;
-      if (c >= asize) break;
-      if (out + l > total) return SVDSS_EIO;
-      memset(&bwt[(size_t)out], c, (size_t)l);
-      out += l;
-      if (r > w) r -= w;
-      else { ++p; r = 64 + r - w; }
+  // The runs are walked twice: first only counted -- the symbol counts of the header must be the decoded ones before
+  // a byte is allocated for them (a damaged header would otherwise ask for terabytes) --, then written.
+  auto walk = [&](auto&& emit) -> int {   // emit(symbol, run length, position); returns SVDSS_OK or SVDSS_EIO
+    uint64_t out = 0;
+    for (int64_t shead = 0; shead < (int64_t)k && out < total; shead += ssize) {
+      const int type = (int)(z[(size_t)shead] >> 62);
+      if (type > 2) return SVDSS_EIO;
+      int64_t p = shead + off0[type];
+      const int64_t stail = shead + ssize - (((shead + ssize) & (RLD_LSIZE - 1)) == 0 ? 2 : 1);
+      int r = 64;
+      while (p <= stail && out < total) {
+        // the next 64 bits of the block, zero beyond its last word
+        uint64_t x = r == 64 ? z[(size_t)p] : (z[(size_t)p] << (64 - r)) | (p != stail ? z[(size_t)p + 1] >> r : 0);
+        if ((x >> 58) == 0) break;   // no code starts with six zeros: the rest of the block is padding
+        const int zc = __builtin_clzll(x);
+        const int y = (int)((x << zc) >> (64 - (zc + 1))) - 1;   // the gamma part holds y + 1 in zc + 1 bits
+        int w = 2 * zc + 1;
+        if (y < 0 || w + y + ABITS > 64) return SVDSS_EIO;
+        const uint64_t l = y ? ((x << w) >> (64 - y)) | ((uint64_t)1 << y) : 1;
+        w += y;
+        const int c = (int)((x << w) >> (64 - ABITS));
+        w += ABITS;
+        if (c >= asize) break;
+        if (l > total - out) return SVDSS_EIO;
+        emit(c, l, out);
+        out += l;
+        if (r > w) r -= w;
+        else { ++p; r = 64 + r - w; }
+      }
     }
-  }
-  if (out != total) return SVDSS_EIO;
-  {   // the header's symbol counts must be the decoded ones
+    return out == total ? SVDSS_OK : SVDSS_EIO;
+  };
+  {
     uint64_t seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint64_t i = 0; i < total; ++i) seen[bwt[(size_t)i] & 7]++;
+    const int rc = walk([&](int c, uint64_t l, uint64_t) { seen[c & 7] += l; });
+    if (rc != SVDSS_OK) return rc;
     for (int c = 0; c < asize; ++c)
       if (seen[c] != mcnt[c]) return SVDSS_EIO;
   }
-  return SVDSS_OK;
+  try { bwt.assign((size_t)total, 0); } catch (...) { return SVDSS_ENOMEM; }
+  return walk([&](int c, uint64_t l, uint64_t at) { memset(&bwt[(size_t)at], c, (size_t)l); });
 }
 
 // rank blocks + acc + '$' rows of a BWT (the layout of fmd_layout.h); text and suffix array stay empty

@@ -117,7 +117,7 @@ void write_record_packed(ByteSink& w, const BamRecord& r, const uint32_t* cigar,
   if (n_cigar > 65535) die("more than 65535 CIGAR operations (CG tag records are not supported): " + r.qname);
   const uint8_t l_name = (uint8_t)(r.qname.size() + 1);
   const uint16_t n_cig = (uint16_t)n_cigar;
-  const size_t pbytes = (size_t)(l_seq + 1) / 2;
+  const size_t pbytes = ((size_t)l_seq + 1) / 2;
   const int32_t block = 32 + l_name + 4 * n_cig + (int32_t)pbytes + l_seq + (int32_t)aux.size();
   uint8_t core[36];
   memcpy(core, &block, 4);
@@ -143,7 +143,7 @@ void write_record_packed(ByteSink& w, const BamRecord& r, const uint32_t* cigar,
 void write_record(ByteSink& w, const BamRecord& r, const std::vector<uint32_t>& cigar, const std::string& seq,
                   const std::vector<uint8_t>& qual, const std::vector<uint8_t>& aux) {
   const int32_t l_seq = (int32_t)seq.size();
-  std::vector<uint8_t> packed((size_t)(l_seq + 1) / 2, 0);
+  std::vector<uint8_t> packed(((size_t)l_seq + 1) / 2, 0);
   static const struct Lut {   // (initialised once, before any worker thread runs: function-local static)
     uint8_t t[256];
     Lut() {

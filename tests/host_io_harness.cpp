@@ -1,0 +1,151 @@
+// host_io_harness.cpp -- the host-side file readers of the SVDSS binary (csrc/bam_reader.h, bai_index.h,
+// fastx_reader.h, rld0.cpp) run over one input file, for tests/test_host_io_robustness.py: built with
+// -fsanitize=address,undefined, fed valid files and damaged ones.  A reader may accept a file or refuse it with its
+// error message; it may not read outside its buffers, overflow, throw out of main or hang.  Test infrastructure.
+//   host_io_harness bam <file> | bai <file.bam> | fastx <file> | fmd <file> | sidecar <file>
+// exit 0: read to a clean end; 1: the reader reported an error (printed); anything else: a finding.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../svdss_amd/csrc/bai_index.h"
+#include "../svdss_amd/csrc/bam_reader.h"
+#include "../svdss_amd/csrc/fastx_reader.h"
+#include "../svdss_amd/csrc/index_host.h"
+#include "../svdss_amd/csrc/rld0.h"
+
+static uint64_t g_sum = 0;   // every byte a reader hands out is read once (ASan sees an out-of-bounds view)
+static void touch(const void* p, size_t n) {
+  const uint8_t* b = (const uint8_t*)p;
+  for (size_t i = 0; i < n; ++i) g_sum += b[i];
+}
+
+static int run_bam(const std::string& path) {
+  for (int pass = 0; pass < 2; ++pass) {   // the zero-copy views, then the copying reader
+    BamReader bam(path, 2);
+    if (!bam.ok() || !bam.read_header()) { printf("error: %s\n", bam.error().c_str()); return 1; }
+    for (const std::string& n : bam.ref_names()) touch(n.data(), n.size());
+    long n_rec = 0;
+    for (;;) {
+      int rc;
+      if (pass == 0) {
+        BamReader::RawView v;
+        rc = bam.next_view(v);
+        if (rc == 1) {
+          touch(v.name(), v.l_name);
+          touch(v.name() + v.l_name, 4u * v.n_cigar);
+          touch(v.seq4(), ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq);
+          touch(v.aux(), v.l_aux);
+          int64_t x = 0;
+          BamReader::aux_int(v.aux(), v.l_aux, "XF", x);
+          BamReader::aux_int(v.aux(), v.l_aux, "HP", x);
+          BamRecord r;
+          BamReader::materialize(v, r);
+          touch(r.seq4.data(), r.seq4.size());
+        }
+      } else {
+        BamRecord r;
+        rc = bam.next(r, n_rec % 2 == 0);
+        if (rc == 1) {
+          touch(r.qname.data(), r.qname.size());
+          touch(r.cigar.data(), 4 * r.cigar.size());
+          touch(r.seq4.data(), r.seq4.size());
+          touch(r.qual.data(), r.qual.size());
+          touch(r.aux.data(), r.aux.size());
+          int64_t x = 0;
+          BamReader::aux_int(r, "XF", x);
+        }
+      }
+      if (rc == 0) break;
+      if (rc < 0) { printf("error: %s\n", bam.error().c_str()); return 1; }
+      ++n_rec;
+    }
+    printf("pass %d: %ld records\n", pass, n_rec);
+  }
+  return 0;
+}
+
+static int run_bai(const std::string& bam_path) {
+  BaiIndex idx;
+  if (!idx.load(bam_path + ".bai")) { printf("error: cannot load the index\n"); return 1; }
+  std::vector<std::pair<uint64_t, uint64_t>> chunks;
+  for (int tid = -1; tid <= (int)idx.refs.size(); ++tid)
+    for (int64_t beg : {(int64_t)-5, (int64_t)0, (int64_t)1000, (int64_t)70000, (int64_t)1 << 29})
+      idx.query(tid, beg, beg + 5000, chunks);
+  BaiIndex::merge(chunks);
+  long n = 0;
+  const std::string err = bam_scan_chunks(bam_path, chunks, [&](const BamReader::RawView& v) {
+    touch(v.name(), v.l_name);
+    touch(v.seq4(), ((size_t)v.l_seq + 1) / 2);
+    touch(v.aux(), v.l_aux);
+    ++n;
+  });
+  if (!err.empty()) { printf("error: %s\n", err.c_str()); return 1; }
+  printf("%zu chunks, %ld records\n", chunks.size(), n);
+  return 0;
+}
+
+static int run_fastx(const std::string& path) {
+  FastxReader fx(path);
+  if (!fx.ok()) { printf("error: cannot open\n"); return 1; }
+  std::string name, seq;
+  long n = 0;
+  while (fx.next(name, seq)) { touch(name.data(), name.size()); touch(seq.data(), seq.size()); ++n; }
+  printf("%ld records\n", n);
+  return 0;
+}
+
+static int run_fmd(const std::string& path) {
+  std::vector<uint8_t> bwt;
+  uint64_t mcnt[6];
+  if (!rld0_is_fmd(path.c_str())) { printf("error: not an rld0 file\n"); return 1; }
+  if (rld0_header_counts(path.c_str(), mcnt) != 0) { printf("error: header\n"); return 1; }
+  const int rc = rld0_read(path.c_str(), bwt);
+  if (rc != 0) { printf("error: rld0_read %d\n", rc); return 1; }
+  touch(bwt.data(), bwt.size());
+  std::vector<std::vector<uint8_t>> strings;
+  if (rld0_strings_of_bwt(bwt.data(), (int64_t)bwt.size(), 2, strings) != 0) { printf("error: not the BWT of a string collection\n"); return 1; }
+  std::vector<int64_t> picked;
+  if (rld0_pick_strands(strings, picked) != 0) { printf("error: strands\n"); return 1; }
+  printf("%zu symbols, %zu strings\n", bwt.size(), strings.size());
+  return 0;
+}
+
+static int run_sidecar(const std::string& path) {
+  // the two sidecars `SVDSS index` can leave beside the .fmd: the records (default) and the full layout
+  svdss_index a, b;
+  const int r1 = svdss_index_load_records_host(path.c_str(), &a);
+  const int r2 = r1 == 0 ? -1 : svdss_index_load_host(path.c_str(), &b);
+  if (r1 != 0 && r2 != 0) { printf("error: neither sidecar format loads (%d, %d)\n", r1, r2); return 1; }
+  if (r1 == 0) {
+    touch(a.records.data(), a.records.size());
+    svdss_index built;   // what `search` does with the records when there is no GPU builder: the host builder
+    const int rc = svdss_index_build_host(a.records.data(), a.rec_lens.data(), (int32_t)a.rec_lens.size(), 2, &built);
+    if (rc != 0) { printf("error: build %d\n", rc); return 1; }
+    printf("records: %zu bases, index of %lld symbols\n", a.records.size(), (long long)built.n);
+  } else {
+    touch(b.text.data(), b.text.size());
+    printf("full layout: %lld symbols\n", (long long)b.n);
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 3) { fprintf(stderr, "usage: host_io_harness bam|bai|fastx|fmd <file>\n"); return 2; }
+  const std::string mode = argv[1], path = argv[2];
+  int rc = 2;
+  try {
+    if (mode == "bam") rc = run_bam(path);
+    else if (mode == "bai") rc = run_bai(path);
+    else if (mode == "fastx") rc = run_fastx(path);
+    else if (mode == "fmd") rc = run_fmd(path);
+    else if (mode == "sidecar") rc = run_sidecar(path);
+  } catch (const std::exception& e) {
+    printf("finding: exception out of a reader: %s\n", e.what());
+    return 3;
+  }
+  if (g_sum == 0x5eed) printf(" ");
+  return rc;
+}
