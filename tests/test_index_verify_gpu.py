@@ -82,8 +82,11 @@ def test_catches_every_kind_of_damage(monkeypatch, tmp_path):
             b[o_sa + 4 * row + 4:o_sa + 4 * row + 8], b[o_sa + 4 * row:o_sa + 4 * row + 4]
     v = damaged(swap)
     assert v["bad_order"] >= 1 and v["first_bad"] in (row - 1, row, row + 1)
-    v = damaged(lambda b: struct.pack_into("<I", b, o_sa + 4 * 777, n + 5))
-    assert v["bad_range"] >= 1 and v["first_bad"] in (776, 777)
+    # (an entry out of range and a '$' row out of order no longer reach the GPU: the loader checks the ranges of what
+    # the kernels index with -- tests/test_host_io_robustness.py -- and refuses the file)
+    from svdss_amd._lib import SvdssError
+    with pytest.raises(SvdssError):
+        damaged(lambda b: struct.pack_into("<I", b, o_sa + 4 * 777, n + 5))
     v = damaged(lambda b: struct.pack_into("<I", b, o_sa + 4 * 5000, int(sa[5001])))
     assert v["bad_order"] >= 1
     # a BWT bit plane of block 40, quarter 1 (p0 of row 40*128 + 32 + 3)
@@ -94,6 +97,8 @@ def test_catches_every_kind_of_damage(monkeypatch, tmp_path):
     assert v["bad_block"] >= 1 and v["bad_bwt"] == 0 and v["bad_order"] == 0
     v = damaged(lambda b: struct.pack_into("<q", b, o_dollar + 8, struct.unpack_from("<q", b, o_dollar + 8)[0] + 1))
     assert v["bad_dollar"] >= 1
+    with pytest.raises(SvdssError):      # the list out of order: refused by the loader
+        damaged(lambda b: struct.pack_into("<q", b, o_dollar + 8, struct.unpack_from("<q", b, o_dollar)[0]))
     # a text symbol: the rows of the suffixes through it are out of order now, and some BWT symbol disagrees
     tpos = 30000
     v = damaged(lambda b: b.__setitem__(o_text + tpos, 1 + (b[o_text + tpos] % 4)))
