@@ -6,13 +6,17 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "_lane_emulator.so")
+# SVDSS_EMU_SANITIZE=1: the same code built with AddressSanitizer + UndefinedBehaviorSanitizer (the process must have
+# libasan preloaded: tests/test_lane_logic.py::test_lane_code_under_sanitizers runs the module's tests that way)
+SANITIZE = os.environ.get("SVDSS_EMU_SANITIZE") == "1"
+SO = os.path.join(HERE, "_lane_emulator_san.so" if SANITIZE else "_lane_emulator.so")
 SRC = os.path.join(HERE, "lane_emulator.cpp")
 _deps = [SRC] + [os.path.join(HERE, "..", "svdss_amd", "csrc", f)
                  for f in ("sfs_core.h", "sfs_core2.h", "sym_window.h", "fmd_layout.h", "index_host.h")]
 if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in _deps):
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-                           "-o", SO, SRC])
+    subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas"] +
+                          (["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if SANITIZE else ["-O2"]) +
+                          ["-o", SO, SRC])
 _lib = C.CDLL(SO)
 _p, _i64 = C.c_void_p, C.c_int64
 _lib.emu_search.restype = _i64

@@ -242,3 +242,25 @@ def test_v2_randomised_configurations(seed):
                 c, q, l, e, ops = E.search2(ix, flat, offs, assemble, K, True, n_seg=n_seg)
                 assert (c == c2).all() and (e == e2).all(), (seed, K, n_seg, assemble)
                 assert (q == q2).all() and (l == l2).all(), (seed, K, n_seg, assemble)
+
+
+def test_lane_code_under_sanitizers():
+    """The kernel's per-lane code (sfs_core.h, sfs_core2.h, sym_window.h, fmd_layout.h: the search state machine, the
+    k-mer table entries, SET / TEXT windows) has no GPU sanitizer to run under on this pool; its CPU emulation has:
+    this module's tests again in a process with AddressSanitizer preloaded and the emulator built with
+    -fsanitize=address,undefined -- an out-of-bounds window index, a shift by the word size, a signed overflow in the
+    interval arithmetic would stop it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("SVDSS_EMU_SANITIZE") == "1":
+        return                                        # (this IS the sanitized run)
+    asan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan beside this g++")
+    env = dict(os.environ, SVDSS_EMU_SANITIZE="1", LD_PRELOAD=asan, OMP_NUM_THREADS="2",
+               ASAN_OPTIONS="detect_leaks=0:exitcode=99", UBSAN_OPTIONS="halt_on_error=1:exitcode=98:print_stacktrace=1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_lane_logic.py", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "not under_sanitizers and not 103 and not 104"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
