@@ -638,7 +638,8 @@ struct CallRun {
             std::vector<int64_t> cig_off(1, 0), sfs_off(1, 0);
             std::vector<const std::vector<RawSFS>*> lists;
             for (const BamRecord& r : batch) {
-              const bool known = r.tid >= 0 && r.tid < (int)ref_names.size() && tid_map[(size_t)r.tid] >= 0;
+              // (a negative position on a record that claims to be mapped: not placed -- the walk indexes the chromosome with it)
+              const bool known = r.tid >= 0 && r.tid < (int)ref_names.size() && tid_map[(size_t)r.tid] >= 0 && r.pos >= 0;
               tid.push_back(known ? tid_map[(size_t)r.tid] : -1);
               pos.push_back(r.pos);
               cig.insert(cig.end(), r.cigar.begin(), r.cigar.end());
@@ -669,7 +670,7 @@ struct CallRun {
           auto slice = [&](int t) {
             for (size_t n = (size_t)t; n < batch.size(); n += (size_t)T) {
               const BamRecord& r = batch[n];
-              if (r.tid < 0 || r.tid >= (int)ref_names.size()) continue;
+              if (r.tid < 0 || r.tid >= (int)ref_names.size() || r.pos < 0) continue;
               extend_alignment(C, r, ref_names[(size_t)r.tid], per_thread[(size_t)t],
                                C.o.clipped ? &per_thread_clips[(size_t)t] : nullptr);
             }
