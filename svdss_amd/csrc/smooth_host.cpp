@@ -273,11 +273,14 @@ int main_smooth(const CallOptions& o) {
     else if (ignore) { set_xf(aux, 2); write_record(sink, r, r.cigar, seq, r.qual, aux); }
     else { set_xf(aux, 0); write_record(sink, r, ncig, nseq, nqual, aux); }
   };
-  // with a GPU the walk runs there (SVDSS_SMOOTH_HOST=1, or no GPU: the host code above); the chromosomes go up once, in
+  // the walk runs on the GPU (SVDSS_SMOOTH_HOST=1: the host code above, a developer switch); the chromosomes go up once, in
   // BAM header order
   svdss_ref_t* dref = nullptr;
   std::vector<int32_t> tid_map(bam.ref_names().size(), -1);
-  if (!getenv("SVDSS_SMOOTH_HOST") && svdss_device_count() > 0) {
+  // (no GPU and no SVDSS_SMOOTH_HOST=1: the command fails rather than quietly running the host walk)
+  if (!getenv("SVDSS_SMOOTH_HOST") && svdss_device_count() <= 0)
+    die("no GPU found: SVDSS smooth walks the alignments on the GPU (SVDSS_SMOOTH_HOST=1 runs the host code instead)");
+  if (!getenv("SVDSS_SMOOTH_HOST")) {
     std::string all;
     std::vector<int64_t> off(1, 0);
     for (size_t t = 0; t < bam.ref_names().size(); ++t) {

@@ -163,6 +163,11 @@ static int main_index(int argc, char** argv) {
     fprintf(stderr, "Usage: SVDSS index [-t threads] -d <reference.fa[.gz]> -o <reference.fmd>\n");
     return EXIT_FAILURE;
   }
+  // The index is built in HBM.  Without a GPU the command fails instead of quietly taking the host builder (which
+  // stays in the library for the texts the GPU builder refuses, and for SVDSS_INDEX_CPU=1: developer runs on a
+  // machine without a GPU).
+  if (svdss_device_count() <= 0 && !getenv("SVDSS_INDEX_CPU"))
+    die("no GPU found: SVDSS index builds the index in HBM (SVDSS_INDEX_CPU=1 runs the host builder instead)");
   const bool dbg = getenv("SVDSS_DEBUG") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {

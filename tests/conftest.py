@@ -26,6 +26,23 @@ def _ensure_built():
 _ensure_built()
 
 
+def _host_logic_knobs():
+    """On a machine without a GPU the host-logic tests of this suite (CLI, file formats, the smoothing rules) drive the
+    binary through its developer switches, explicitly: `SVDSS index` / `SVDSS smooth` themselves refuse to run without a
+    GPU.  On the GPU box nothing is set and the HIP paths run."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:   # noqa: BLE001
+        has_gpu = False
+    if not has_gpu:
+        os.environ.setdefault("SVDSS_INDEX_CPU", "1")
+        os.environ.setdefault("SVDSS_SMOOTH_HOST", "1")
+
+
+_host_logic_knobs()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from tests import oracle_lib

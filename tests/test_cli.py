@@ -38,6 +38,28 @@ def test_version_usage_and_errors():
     assert r.returncode == 1 and "does not exist" in r.stderr
 
 
+def test_commands_fail_loudly_without_a_gpu(tmp_path):
+    """No silent CPU fallback in the binary: on a machine without a GPU `index` and `smooth` stop with a message
+    unless the developer switch for their host code is given (tests/conftest.py gives it to the host-logic tests of
+    this suite); `search` and `call` have no host path at all."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this machine has a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("SVDSS_INDEX_CPU", "SVDSS_SMOOTH_HOST")}
+    fa = tmp_path / "r.fa"
+    fa.write_text(">c\n" + "ACGT" * 500 + "\n")
+    r = run("index", "-d", str(fa), "-o", str(tmp_path / "r.fmd"), env=env)
+    assert r.returncode == 1 and "no GPU found" in r.stderr and not (tmp_path / "r.fmd").exists()
+    bam = tmp_path / "x.bam"
+    bam.write_bytes(bam_writer.bam([("c", 2000)], [bam_writer.record("q", 0, 0, 10, 60, [("M", 100)], "ACGT" * 25)]))
+    r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam)], capture_output=True, timeout=120, env=env)
+    assert r.returncode == 1 and b"no GPU found" in r.stderr and r.stdout == b""
+    r = run("index", "-d", str(fa), "-o", str(tmp_path / "r.fmd"), env=dict(env, SVDSS_INDEX_CPU="1"))
+    assert r.returncode == 0 and (tmp_path / "r.fmd").exists()
+    r = run("search", "--index", str(tmp_path / "r.fmd"), "--fastx", str(fa), env=env)
+    assert r.returncode == 1 and r.stdout == ""
+
+
 def test_index_subcommand_roundtrip(tmp_path):
     ref = synth.make_reference([30000, 8000], seed=5, n_runs=(25,))
     fa = tmp_path / "ref.fa.gz"
