@@ -67,16 +67,22 @@ extern "C" int svdss_nt6_encode(const char* seq, int64_t n, uint8_t* out) {
 
 static void free_device_side(svdss_index* ix);
 
-// the index of the given records into *ix: on the GPU when there is one (index_gpu.hip; SVDSS_INDEX_CPU=1 keeps the
-// host builder), else the host builder -- same index.  A GPU-built index stays resident where it was built (without a
+// the index of the given records into *ix: on the GPU (index_gpu.hip); the host builder -- same index -- takes over
+// for SVDSS_INDEX_CPU=1 and for the texts the GPU builder refuses, not for a missing GPU (that is an error).  A GPU-built index stays resident where it was built (without a
 // k-mer table): rank blocks, '$' rows and acc are on the host already, text and suffix array (5-9 n bytes) come down
 // only if somebody asks for them (svdss_index_save, another device) -- `SVDSS index` never does.
 static int build_into(svdss_index* ix, const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t threads) {
   int rc = -1;
   if (!getenv("SVDSS_INDEX_CPU")) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
-    if (dev >= 0) rc = svdss_index_build_gpu(contigs, lens, n_contigs, dev, ix);
+    if (hipGetDevice(&dev) != hipSuccess) {
+      // no GPU: an error, not a quiet run of the host builder (that one is for the texts the GPU builder refuses
+      // -- below -- and for SVDSS_INDEX_CPU=1)
+      (void)hipGetLastError();
+      g_svdss_hip_err = "no GPU found: the index is built in HBM (SVDSS_INDEX_CPU=1 runs the host builder)";
+      return SVDSS_EHIP;
+    }
+    rc = svdss_index_build_gpu(contigs, lens, n_contigs, dev, ix);
     if (rc == SVDSS_OK) return rc;
     if (rc > 0) return rc;   // bad input: the host builder would say the same
     free_device_side(ix);

@@ -58,6 +58,13 @@ def test_commands_fail_loudly_without_a_gpu(tmp_path):
     assert r.returncode == 0 and (tmp_path / "r.fmd").exists()
     r = run("search", "--index", str(tmp_path / "r.fmd"), "--fastx", str(fa), env=env)
     assert r.returncode == 1 and r.stdout == ""
+    # the library's entry point as well (svdss_index_build: the Python mirror FMDIndex.build)
+    import sys
+    r = subprocess.run([sys.executable, "-c", "import numpy as np, svdss_amd\n"
+                        "try:\n    svdss_amd.FMDIndex.build([np.ones(100, np.uint8)])\n    print('built')\n"
+                        "except svdss_amd.SvdssError as e:\n    print('refused', e)"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert "refused" in r.stdout and "no GPU found" in r.stdout, r.stdout + r.stderr
 
 
 def test_index_subcommand_roundtrip(tmp_path):
