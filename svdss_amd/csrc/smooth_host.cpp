@@ -35,6 +35,20 @@ const int MIN_INDEL = 20;   // config.hpp:95
 
 bool is_m(uint32_t op) { return op == 0 || op == 7 || op == 8; }
 
+// the walks of this file index ref[pos ..] and the read by the CIGAR: true if the alignment stays inside its contig and
+// its CIGAR adds up to the read (what is not is passed through with XF = 3 and left out of the accuracy percentile)
+bool cigar_fits(const BamRecord& r, size_t seq_len, size_t ref_len) {
+  size_t rl = 0, ql = 0;
+  for (uint32_t c : r.cigar) {
+    const uint32_t l = c >> 4, op = c & 0xf;
+    if (is_m(op)) { rl += l; ql += l; }
+    else if (op == 1 || op == 4) ql += l;
+    else if (op == 2) rl += l;
+    else break;
+  }
+  return r.pos >= 0 && (size_t)r.pos + rl <= ref_len && ql == seq_len;
+}
+
 void mismatch_counts(const BamRecord& r, const std::string& seq, const std::string& ref, double& nm, double& nx) {
   size_t ref_off = (size_t)r.pos, q_off = 0;
   nm = nx = 0;
@@ -191,7 +205,11 @@ int main_smooth(const CallOptions& o) {
     while (acc.size() < 10000 && bam.next(r) > 0) {
       if (!eligible(r, bam.ref_names())) continue;
       double nm, nx;
-      mismatch_counts(r, r.seq_string(), chrom[bam.ref_names()[(size_t)r.tid]], nm, nx);
+      const std::string& ref = chrom[bam.ref_names()[(size_t)r.tid]];
+      // (a record the smoothing pass will refuse -- XF = 3 -- has no defined mismatch rate: the reference walks off its
+      // buffers on it, smoother.cpp:259-346)
+      if (!cigar_fits(r, (size_t)r.l_seq, ref.size())) continue;
+      mismatch_counts(r, r.seq_string(), ref, nm, nx);
       acc.push_back(nx / nm);
     }
     if (acc.empty()) al_accuracy = 0.0;
@@ -218,15 +236,7 @@ int main_smooth(const CallOptions& o) {
       // the walk below indexes ref[pos ..] and seq[..] by the CIGAR: an alignment that overhangs the contig end or
       // whose CIGAR does not add up to l_seq is passed through unchanged with XF = 3, the reference's tag for a record
       // it could not rebuild consistently (smoother.cpp:219-228)
-      size_t rl = 0, ql = 0;
-      for (uint32_t c : r.cigar) {
-        const uint32_t l = c >> 4, op = c & 0xf;
-        if (is_m(op)) { rl += l; ql += l; }
-        else if (op == 1 || op == 4) ql += l;
-        else if (op == 2) rl += l;
-        else break;
-      }
-      if (r.pos < 0 || (size_t)r.pos + rl > ref.size() || ql != seq.size()) {
+      if (!cigar_fits(r, seq.size(), ref.size())) {
         std::vector<uint8_t> aux3 = r.aux;
         set_xf(aux3, 3);
         write_record(sink, r, r.cigar, seq, r.qual, aux3);

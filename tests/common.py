@@ -32,3 +32,9 @@ def small_workload(seed=11, ref_lens=(150000, 80000), n_reads=64, read_len=1500,
     hap, svs = synth.implant_svs(ref, n_svs, seed=seed + 1, min_len=50, max_len=400)
     flat, offs, truth = synth.simulate_reads(hap, n_reads, read_len, err, seed=seed + 2, ragged=True)
     return ref, hap, svs, flat, offs
+
+
+# the SVDSS binary the process-level tests run (SVDSS_TEST_BIN: another build of it, e.g. the sanitized one of
+# tests/test_sanitized_binary.py)
+BIN = os.environ.get("SVDSS_TEST_BIN") or os.path.join(ROOT, "svdss_amd", "SVDSS")
+

@@ -11,7 +11,7 @@ from svdss_amd import synth
 from tests import bam_writer, oracle_lib as O
 from tests.common import ROOT, small_workload
 
-BIN = os.path.join(ROOT, "svdss_amd", "SVDSS")
+from tests.common import BIN  # noqa: E402
 
 
 def run(*args, **kw):

@@ -21,7 +21,7 @@ from svdss_amd import synth
 from tests import bam_writer
 from tests.common import ROOT
 
-BIN = os.path.join(ROOT, "svdss_amd", "SVDSS")
+from tests.common import BIN  # noqa: E402
 CLIP = "ACGGTCA" * 72            # 504 bases; the first 500 are the clipped part of every read
 
 

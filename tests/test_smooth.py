@@ -12,7 +12,7 @@ from tests import bam_writer
 from tests.common import ROOT
 from tests.pipeline_sim import add_errors, simulate
 
-BIN = os.path.join(ROOT, "svdss_amd", "SVDSS")
+from tests.common import BIN  # noqa: E402
 OPS = {"M": 0, "I": 1, "D": 2, "S": 4}
 
 
