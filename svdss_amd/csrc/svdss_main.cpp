@@ -27,6 +27,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utime.h>
 #include <vector>
 
 #include <unistd.h>
@@ -193,11 +194,23 @@ static int main_index(int argc, char** argv) {
   // the file ropebwt3 build -d writes (rld0), so that the index serves upstream SVDSS as well -- and beside it the
   // records themselves (nt6), from which `search` rebuilds the index in HBM in less time than the text + suffix array
   // (19 bytes per base) take to read from any disk.  SVDSS_INDEX_FULL=1: the full layout instead (a plain read).
-  check(svdss_index_save_fmd(ix, out.c_str()), "svdss_index_save_fmd");
+  // (the records sidecar is written beside the rld0 encoding, by a second thread: the two read different parts of the
+  // index -- the BWT, the records -- and the encoder is one serial pass over six billion symbols at human scale)
+  int rc_side = SVDSS_OK;
+  std::thread side;
+  const bool records_side = !getenv("SVDSS_INDEX_NO_CACHE") && !getenv("SVDSS_INDEX_FULL");
+  if (records_side) side = std::thread([&] { rc_side = svdss_index_save_records(ix, (out + ".svdss.tmp").c_str()); });
+  const int rc_fmd = svdss_index_save_fmd(ix, out.c_str());
+  if (side.joinable()) side.join();
+  check(rc_fmd, "svdss_index_save_fmd");
   mark("rld0 .fmd written");
-  if (!getenv("SVDSS_INDEX_NO_CACHE")) {
-    if (getenv("SVDSS_INDEX_FULL")) check(svdss_index_save(ix, (out + ".svdss").c_str()), "svdss_index_save");
-    else check(svdss_index_save_records(ix, (out + ".svdss").c_str()), "svdss_index_save_records");
+  if (records_side) {
+    check(rc_side, "svdss_index_save_records");
+    // (renamed into place after the .fmd is complete: a sidecar is trusted only if it is not older than its .fmd)
+    if (rename((out + ".svdss.tmp").c_str(), (out + ".svdss").c_str()) != 0 || utime((out + ".svdss").c_str(), nullptr) != 0)
+      die("cannot write " + out + ".svdss");
+  } else if (!getenv("SVDSS_INDEX_NO_CACHE")) {
+    check(svdss_index_save(ix, (out + ".svdss").c_str()), "svdss_index_save");
   }
   mark("sidecar written");
   svdss_index_free(ix);
