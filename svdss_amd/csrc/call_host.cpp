@@ -27,6 +27,7 @@
 #include "bai_index.h"
 #include "bam_reader.h"
 #include "gpu_inflate_hook.h"
+#include "sfs_file.h"
 #include "call_host.h"
 #include "fastx_reader.h"
 
@@ -38,7 +39,6 @@ void check(int rc, const char* what) {
   if (rc != SVDSS_OK) die(std::string(what) + ": " + svdss_strerror(rc) + " " + svdss_last_hip_error());
 }
 
-struct RawSFS { int qs, l, htag; };
 
 struct ESFS {   // SFS after placement (sfs.hpp:52-62)
   std::string chrom, qname;
@@ -524,19 +524,9 @@ struct CallRun {
       }
     }
     // ---- parse_sfsfile (sfs.cpp:5-30)
-    {
-      FILE* f = fopen(o.sfs.c_str(), "r");
-      if (f) {
-        char nm[4096]; int qs, l, ht; std::string cur;
-        char line[8192];
-        while (fgets(line, sizeof line, f)) {
-          if (sscanf(line, "%4095s %d %d %d", nm, &qs, &l, &ht) != 4) continue;
-          if (strcmp(nm, "*") != 0) { cur = nm; C.sfs[cur] = std::vector<RawSFS>(); }
-          C.sfs[cur].push_back(RawSFS{qs, l, ht});
-        }
-        fclose(f);
-      }
-    }
+    // (csrc/sfs_file.h: the file mapped and parsed by T threads; a file that cannot be opened leaves the map empty, as
+    // the reference's ifstream does)
+    (void)sfs_parse_file(o.sfs.c_str(), T, C.sfs);
     stage("reference + sfs file");
   }
 

@@ -2,7 +2,7 @@
 // fastx_reader.h, rld0.cpp) run over one input file, for tests/test_host_io_robustness.py: built with
 // -fsanitize=address,undefined, fed valid files and damaged ones.  A reader may accept a file or refuse it with its
 // error message; it may not read outside its buffers, overflow, throw out of main or hang.  Test infrastructure.
-//   host_io_harness bam <file> | bai <file.bam> | fastx <file> | fmd <file> | sidecar <file>
+//   host_io_harness bam <file> | bai <file.bam> | fastx <file> | fmd <file> | sidecar <file> | sfs <file>
 // exit 0: read to a clean end; 1: the reader reported an error (printed); anything else: a finding.
 #include <cstdint>
 #include <cstdio>
@@ -15,6 +15,7 @@
 #include "../svdss_amd/csrc/fastx_reader.h"
 #include "../svdss_amd/csrc/index_host.h"
 #include "../svdss_amd/csrc/rld0.h"
+#include "../svdss_amd/csrc/sfs_file.h"
 
 static uint64_t g_sum = 0;   // every byte a reader hands out is read once (ASan sees an out-of-bounds view)
 static void touch(const void* p, size_t n) {
@@ -132,6 +133,28 @@ static int run_sidecar(const std::string& path) {
   return 0;
 }
 
+static int run_sfs(const std::string& path) {
+  // the piecewise reader against the line-by-line one, with several piece counts
+  SfsMap want;
+  if (!sfs_parse_lines(path.c_str(), want)) { printf("error: cannot open\n"); return 1; }
+  size_t n = 0;
+  for (const auto& kv : want) n += kv.second.size();
+  for (int threads : {1, 2, 3, 7, 16}) {
+    SfsMap got;
+    if (!sfs_parse_file(path.c_str(), threads, got)) { printf("finding: the piecewise reader cannot open the file\n"); return 4; }
+    bool same = got.size() == want.size();
+    for (const auto& kv : want) {
+      auto it = got.find(kv.first);
+      if (it == got.end() || it->second.size() != kv.second.size()) { same = false; break; }
+      for (size_t i = 0; i < kv.second.size(); ++i)
+        if (it->second[i].qs != kv.second[i].qs || it->second[i].l != kv.second[i].l || it->second[i].htag != kv.second[i].htag) same = false;
+    }
+    if (!same) { printf("finding: %d threads read another map (%zu reads vs %zu)\n", threads, got.size(), want.size()); return 4; }
+  }
+  printf("%zu reads, %zu records\n", want.size(), n);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc != 3) { fprintf(stderr, "usage: host_io_harness bam|bai|fastx|fmd <file>\n"); return 2; }
   const std::string mode = argv[1], path = argv[2];
@@ -142,6 +165,7 @@ int main(int argc, char** argv) {
     else if (mode == "fastx") rc = run_fastx(path);
     else if (mode == "fmd") rc = run_fmd(path);
     else if (mode == "sidecar") rc = run_sidecar(path);
+    else if (mode == "sfs") rc = run_sfs(path);
   } catch (const std::exception& e) {
     printf("finding: exception out of a reader: %s\n", e.what());
     return 3;

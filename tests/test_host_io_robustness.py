@@ -17,7 +17,7 @@ from tests.common import ROOT
 HARNESS = os.path.join(ROOT, "tests", "_host_io_harness")
 SRC = [os.path.join(ROOT, "tests", "host_io_harness.cpp"), os.path.join(ROOT, "svdss_amd", "csrc", "rld0.cpp"),
        os.path.join(ROOT, "svdss_amd", "csrc", "index_build.cpp")]
-DEPS = SRC + [os.path.join(ROOT, "svdss_amd", "csrc", h) for h in ("bam_reader.h", "bai_index.h", "fastx_reader.h", "rld0.h", "index_host.h", "fmd_layout.h")]
+DEPS = SRC + [os.path.join(ROOT, "svdss_amd", "csrc", h) for h in ("bam_reader.h", "bai_index.h", "fastx_reader.h", "rld0.h", "index_host.h", "fmd_layout.h", "sfs_file.h")]
 
 
 @pytest.fixture(scope="module")
@@ -238,3 +238,44 @@ def test_index_sidecars_on_damaged_files(harness, tmp_path, monkeypatch):
             rc, out = run(harness, "sidecar", path)
             n_err += rc == 1
         assert n_err > 20
+
+
+def test_sfs_file_readers_agree(harness, tmp_path):
+    """csrc/sfs_file.h: the piecewise .sfs reader of `SVDSS call` against the line-by-line one it replaces, on the text
+    `SVDSS search` writes and on every kind of line the format does not have."""
+    rng = np.random.default_rng(8)
+    path = str(tmp_path / "x.sfs")
+
+    def good(n_reads):
+        out = []
+        for i in range(n_reads):
+            name = f"m64011_190830_220126/{int(rng.integers(0, n_reads // 2 + 2))}/ccs"     # (names repeat: the later list wins)
+            for k in range(int(rng.integers(1, 90))):
+                out.append(f"{name if k == 0 else '*'}\t{int(rng.integers(0, 20000))}\t{int(rng.integers(1, 300))}\t{int(rng.integers(0, 3))}\t\n")
+        return out
+    lines = good(30000)
+    open(path, "w").write("".join(lines))                      # 1.3 M lines, ~18 MB: several pieces per thread count
+    rc, out = run(harness, "sfs", path)
+    assert rc == 0 and "reads" in out
+    odd = ["*\t1\t2\t0\t\n", "\n", "   \n", "name only\n", "r1\t5\n", "r2\t5\t6\n", "r3\t5\t6\t7\textra\tfields\n", "r4 5 6 7\n",
+           "r5\t-5\t+6\t7\n", "r6\t5x\t6\t7\n", "r7\t5\t6\t7x\n", "*\t9\t9\t9\r\n", "r8\t\t5\t\t6\t\t7\n", "*\n", "* * * *\n",
+           "r9\t99999999999\t1\t1\n", "r" * 4095 + "\t1\t2\t3\n", "q" * 4096 + "\t1\t2\t3\n", "\tr10\t1\t2\t3\n", "r11\t1\t2\t3"]
+    for trial in range(12):
+        body = lines[:int(rng.integers(0, 3000))]
+        for _ in range(int(rng.integers(1, 60))):
+            body.insert(int(rng.integers(0, len(body) + 1)), odd[int(rng.integers(0, len(odd)))])
+        if trial % 4 == 1:
+            body.insert(len(body) // 2, "L" * 9000 + "\t1\t2\t3\n")              # a line fgets would split
+        if trial % 4 == 2:
+            body = ["*\t4\t4\t4\t\n"] * 3 + body                                  # '*' before any name
+        data = "".join(body)
+        if trial % 4 == 3:
+            data = data[:int(rng.integers(0, len(data) + 1))]                     # cut anywhere
+        open(path, "w").write(data)
+        rc, out = run(harness, "sfs", path)
+        assert rc == 0, out
+    open(path, "wb").write(bytes(rng.integers(0, 256, size=300000, dtype=np.uint8)))   # not a text file at all
+    rc, out = run(harness, "sfs", path)
+    assert rc == 0, out
+    open(path, "w").write("")
+    assert run(harness, "sfs", path)[0] == 0
