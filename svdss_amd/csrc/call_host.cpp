@@ -28,6 +28,7 @@
 #include "bam_reader.h"
 #include "gpu_inflate_hook.h"
 #include "sfs_file.h"
+#include "sv_record.h"
 #include "call_host.h"
 #include "fastx_reader.h"
 
@@ -284,34 +285,6 @@ std::vector<Cluster> split_cluster(const Cluster& cluster, bool useht, float min
     }
   }
   return out;
-}
-
-struct SV {   // sv.hpp / sv.cpp
-  std::string type, chrom, idx, refall, altall, gt = "./.", cigar, reads, rvec;
-  int s = 0, e = 0, cov = 0, cov0 = 0, cov1 = 0, cov2 = 0, l = 0, ngaps = 0, score = 0, gtq = 0;
-  unsigned w = 0;
-  bool imprecise = false;
-  bool operator<(const SV& c) const { return chrom < c.chrom ? true : (chrom > c.chrom ? false : s < c.s); }
-  std::string line() const {   // sv.cpp:53-80
-    std::string o = chrom + "\t" + std::to_string(s) + "\t" + idx + "\t" + refall + "\t" + altall + "\t.\tPASS\t";
-    o += "VARTYPE=SV;SVTYPE=" + type + ";SVLEN=" + std::to_string(type == "DEL" ? -l : l) + ";END=" + std::to_string(e);
-    o += ";WEIGHT=" + std::to_string(w) + ";COV=" + std::to_string(cov) + ";COV0=" + std::to_string(cov0);
-    o += ";COV1=" + std::to_string(cov1) + ";COV2=" + std::to_string(cov2) + ";AS=" + std::to_string(score);
-    o += ";NV=" + std::to_string(ngaps) + ";CIGAR=" + cigar + ";RVEC=" + rvec + ";READS=" + reads;
-    o += imprecise ? ";IMPRECISE\t" : "\t";
-    o += "GT:GQ\t" + gt + ":" + std::to_string(gtq);
-    return o;
-  }
-};
-
-SV make_sv(const std::string& type, const std::string& chrom, int s, const std::string& refall,
-           const std::string& altall, unsigned w, int cov, int ngaps, int score, int l, const std::string& cigar) {
-  SV v;
-  v.type = type; v.chrom = chrom; v.s = s; v.refall = refall; v.altall = altall;
-  v.e = s + (int)refall.size() - 1;
-  v.w = w; v.l = l; v.cov = cov; v.ngaps = ngaps; v.score = score; v.cigar = cigar;
-  v.idx = type + "_" + chrom + ":" + std::to_string(s) + "-" + std::to_string(v.e) + "_" + std::to_string(std::abs(l));
-  return v;
 }
 
 // ---- imprecise SVs from soft clips (--clipped; Clipper, clipper.cpp) -------------------------------------------
@@ -608,7 +581,7 @@ struct CallRun {
             }
           }
           if (rr.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
-          if ((int)rr.mapq < o.min_mapq) continue;
+          if ((unsigned)rr.mapq < o.min_mapq) continue;
           if (cache_ok) cache_views.push_back(rr);    // every record pass 2 looks at (same filters, clusterer.cpp:535-540)
           qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
           if (C.sfs.find(qname) == C.sfs.end()) continue;
@@ -745,7 +718,7 @@ struct CallRun {
         int mn = std::numeric_limits<int>::max(), mx = 0;
         for (const ESFS& s : clusters[i].sfss) { mn = std::min(mn, s.rs); mx = std::max(mx, s.re); reads[i].insert(s.qname); }
         min_s[i] = mn; max_e[i] = mx;
-        if ((int)reads[i].size() < o.min_cluster_weight) { ++C.small; continue; }
+        if (reads[i].size() < (size_t)o.min_cluster_weight) { ++C.small; continue; }
         clusters[i].s = mn; clusters[i].e = mx;
         live[i] = 1;
         by_chrom[clusters[i].chrom].push_back(i);
@@ -784,7 +757,7 @@ struct CallRun {
       auto process = [&](const BamReader::RawView& rr, std::string& qname, auto&& sink) {
         if (rr.tid < 0 || rr.tid >= (int)ref_names.size() || !tid_clusters[(size_t)rr.tid]) return;
         if (rr.flag & (4 | 2048 | 256)) return;        // clusterer.cpp:535-540: such a record touches no cluster
-        if ((int)rr.mapq < o.min_mapq) return;
+        if ((unsigned)rr.mapq < o.min_mapq) return;
         const uint8_t* cg = rr.name() + rr.l_name;
         auto cig = [&](uint32_t i) { uint32_t c; memcpy(&c, cg + 4u * i, 4); return c; };
         int32_t ref_len = 0;
@@ -905,7 +878,7 @@ struct CallRun {
       }
       for (size_t i = 0; i < clusters.size(); ++i) {
         if (!live[i]) { clusters[i].reads.clear(); clusters[i].subreads.clear(); continue; }
-        if ((int)clusters[i].size() >= o.min_cluster_weight) {
+        if (clusters[i].size() >= (size_t)o.min_cluster_weight) {
           clusters[i].cov0 = cov[i][0]; clusters[i].cov1 = cov[i][1]; clusters[i].cov2 = cov[i][2];
           clusters[i].cov = cov[i][0] + cov[i][1] + cov[i][2];
         } else ++C.small2;
@@ -937,7 +910,7 @@ struct CallRun {
     G = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev));
     // ---- pcall (caller.cpp:311-406): split, then the three GPU batches
     for (size_t i = 0; i < clusters.size(); ++i) {
-      if ((int)clusters[i].size() < o.min_cluster_weight) continue;
+      if (clusters[i].size() < (size_t)o.min_cluster_weight) continue;
       for (Cluster& cl : split_cluster(clusters[i], o.useht, o.min_ratio)) subs.push_back(Sub{i, std::move(cl)});
     }
     stage("split_cluster");
@@ -1109,7 +1082,7 @@ struct CallRun {
           const char op = "MID"[cig[cp + (size_t)k] & 0xf];
           if (op == 'M') { rpos += l; cpos += l; }
           else if (op == 'I') {
-            if (l >= (unsigned)o.min_sv_length) {
+            if (l >= o.min_sv_length) {
               const std::string anchor(1, cs[rpos - 1]);
               SV v = make_sv("INS", cl.chrom, (int)rpos, anchor, anchor + consensus[i].substr(cpos, l), (unsigned)cl.size(),
                              cl.cov, nv, scores[i], (int)l, cigar_str);
@@ -1119,7 +1092,7 @@ struct CallRun {
             }
             cpos += l;
           } else {
-            if (l >= (unsigned)o.min_sv_length) {
+            if (l >= o.min_sv_length) {
               SV v = make_sv("DEL", cl.chrom, (int)rpos, cs.substr(rpos - 1, l + 1), std::string(1, cs[rpos - 1]),
                              (unsigned)cl.size(), cl.cov, nv, scores[i], (int)l, cigar_str);
               v.reads = names;

@@ -5,9 +5,9 @@
 struct CallOptions {
   std::string reference, bam, sfs;
   int threads = 4;
-  int min_cluster_weight = 2;
-  int min_sv_length = 25;
-  int min_mapq = 20;
+  unsigned min_cluster_weight = 2;   // (unsigned as in the reference, config.hpp:92-96: a negative value on the command
+  unsigned min_sv_length = 25;       //  line is a huge one)
+  unsigned min_mapq = 20;
   bool useht = true;
   float min_ratio = 0.97f;
   float accp = 0.98f;          // smooth only

@@ -185,7 +185,7 @@ int main_smooth(const CallOptions& o) {
   }
   auto eligible = [&](const BamRecord& r, const std::vector<std::string>& names) {
     if (r.flag & (4 | 2048 | 256)) return false;
-    if ((int)r.mapq < o.min_mapq || r.l_seq < 2) return false;
+    if ((unsigned)r.mapq < o.min_mapq || r.l_seq < 2) return false;
     if (r.tid < 0) die("core.tid < 0. Why are we here? Please check");
     return r.tid < (int)names.size() && chrom.count(names[(size_t)r.tid]) > 0;
   };

@@ -35,6 +35,7 @@
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
 #include "gpu_inflate_hook.h"
+#include "cli_options.h"
 #include "call_host.h"
 #include "fastx_reader.h"
 
@@ -90,59 +91,11 @@ static void check(int rc, const char* what) {
 // seq_nt16_str of htslib, then seq_nt6_table (ping_pong.cpp:90-94)
 static const char NT16[] = "=ACMGRSVTWYHKDBN";
 
-struct Options {
-  std::string index, bam, fastx, reference, sfs, poa, clusters;
-  int min_sv_length = 25, min_mapq = 20, min_cluster_weight = 2;   // config.hpp:92-96
-  float accp = 0.98f, min_ratio = 0.97f;
-  bool useht = true;
-  int threads = 4, bsize = 10000, omax = 100000;  // config.hpp:68-69,88
-  int io_threads = 0;                              // BGZF inflate workers (0: up to 16)
-  int gpus = 1;                                    // --gpus N: index replicated, batches / sub-clusters shard
-  bool putative = true, assemble = true, verbose = false, version = false, help = false, clipped = false;
-};
-
-static bool take(int argc, char** argv, int& i, const char* name, std::string& val) {
-  const size_t n = strlen(name);
-  if (strncmp(argv[i], name, n) != 0) return false;
-  if (argv[i][n] == '=') { val = argv[i] + n + 1; return true; }
-  if (argv[i][n] != '\0') return false;
-  if (i + 1 >= argc) die(std::string("option ") + name + " needs a value");
-  val = argv[++i];
-  return true;
-}
-
 static Options parse(int argc, char** argv) {
   Options o;
-  std::string v;
-  for (int i = 2; i < argc; ++i) {
-    if (take(argc, argv, i, "--index", v)) o.index = v;
-    else if (take(argc, argv, i, "--bam", v)) o.bam = v;
-    else if (take(argc, argv, i, "--fastx", v)) o.fastx = v;
-    else if (take(argc, argv, i, "--threads", v)) o.threads = atoi(v.c_str());
-    else if (take(argc, argv, i, "--io-threads", v)) o.io_threads = atoi(v.c_str());
-    else if (take(argc, argv, i, "--gpus", v)) o.gpus = v == "all" ? svdss_device_count() : atoi(v.c_str());
-    else if (take(argc, argv, i, "--bsize", v)) o.bsize = atoi(v.c_str());
-    else if (take(argc, argv, i, "--omax", v)) o.omax = atoi(v.c_str());
-    else if (take(argc, argv, i, "--reference", v)) o.reference = v;
-    else if (take(argc, argv, i, "--sfs", v)) o.sfs = v;
-    else if (take(argc, argv, i, "--poa", v)) o.poa = v;            // config.cpp:65-68
-    else if (take(argc, argv, i, "--clusters", v)) o.clusters = v;
-    else if (take(argc, argv, i, "--min-sv-length", v)) o.min_sv_length = std::max(25, atoi(v.c_str()));  // config.cpp:87
-    else if (take(argc, argv, i, "--min-cluster-weight", v)) o.min_cluster_weight = atoi(v.c_str());
-    else if (take(argc, argv, i, "--min-mapq", v)) o.min_mapq = atoi(v.c_str());
-    else if (take(argc, argv, i, "--accp", v)) o.accp = (float)atof(v.c_str());
-    else if (take(argc, argv, i, "-l", v)) o.min_ratio = (float)atof(v.c_str());
-    else if (!strcmp(argv[i], "--noht")) o.useht = false;
-    else if (!strcmp(argv[i], "--noputative")) o.putative = false;
-    else if (!strcmp(argv[i], "--noassemble")) o.assemble = false;
-    else if (!strcmp(argv[i], "--verbose")) o.verbose = true;
-    else if (!strcmp(argv[i], "--version")) o.version = true;
-    else if (!strcmp(argv[i], "--help") || !strcmp(argv[i], "-h")) o.help = true;
-    else if (!strcmp(argv[i], "--clipped")) o.clipped = true;   // config.cpp:46 (EXPERIMENTAL)
-    else die(std::string("Option '") + argv[i] + "' does not exist");  // cxxopts throws here
-  }
-  if (o.threads < 1) o.threads = 1;
-  o.bsize = (o.bsize / o.threads) * o.threads;  // config.cpp:106
+  std::string err;
+  if (!parse_options(argc, argv, 2, o, err)) die(err);
+  if (o.gpus_all) o.gpus = svdss_device_count();
   return o;
 }
 
