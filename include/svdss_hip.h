@@ -42,7 +42,9 @@ int svdss_nt6_encode(const char* seq, int64_t n, uint8_t* out);
  * (main.cpp:15-17,34-37); svdss_index_load replaces rb3_fmi_restore
  * (ping_pong.cpp:245).  contigs = concatenated nt6 symbols of all records,
  * lens[i] symbols each.  The index covers every record and its reverse
- * complement, each '$'-terminated. */
+ * complement, each '$'-terminated.  The index is built in HBM; a machine without a GPU gets SVDSS_EHIP ("no GPU
+ * found"), not a quiet run of the host builder -- that one serves the texts the GPU builder refuses and
+ * SVDSS_INDEX_CPU=1. */
 typedef struct svdss_index svdss_index_t;
 
 int svdss_index_build(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
@@ -73,7 +75,8 @@ int svdss_fmd_read_bwt(const char* path, uint8_t* bwt_out, int64_t cap, int64_t*
  * `<path>.svdss` (the file `SVDSS index` leaves beside the .fmd) is read if it is there, not older, and carries the
  * symbol counts of the .fmd's header; otherwise the BWT is
  * decoded, the records are recovered from it (they must come with their reverse complements, as ropebwt3 build -d
- * inserts them) and the index is rebuilt, on the GPU when there is one. */
+ * inserts them) and the index is rebuilt on the GPU (no GPU: SVDSS_EHIP, unless SVDSS_INDEX_CPU=1 asks for the host
+ * builder). */
 int svdss_index_load(const char* path, svdss_index_t** out);
 void svdss_index_free(svdss_index_t* ix);
 /* number of BWT symbols, = sum_i 2*(lens[i]+1) */

@@ -61,7 +61,7 @@ class FMDIndex:
 
     @classmethod
     def build(cls, contigs: Sequence, threads: int = 0, device: Optional[int] = None) -> "FMDIndex":
-        """`SVDSS index` (main.cpp:34-37).  device=None: host-side index (built on the GPU when there is one,
+        """`SVDSS index` (main.cpp:34-37).  device=None: host-side index (built on the GPU -- without one: SvdssError unless SVDSS_INDEX_CPU=1 --,
         then fetched); device=d: built in the HBM of GPU d and left resident there, k-mer table included."""
         enc = [_as_nt6(c) for c in contigs]
         lens = np.array([len(e) for e in enc], dtype=np.int64)
