@@ -653,7 +653,11 @@ int main(int argc, char** argv) {
     for (int i = 1; i < argc; ++i)
       if (!strcmp(argv[i], "--version")) { printf("SVDSS, %s\n", VERSION); return EXIT_SUCCESS; }
     const Options o = parse(argc, argv);
-    if (o.help) { fputs(!strcmp(argv[1], "search") ? SEARCH_USAGE : MAIN_USAGE, stderr); return EXIT_SUCCESS; }
+    if (o.help) {   // Configuration::print_help(argv[1]), config.cpp:12-24: the mode's own usage text
+      fputs(!strcmp(argv[1], "search") ? SEARCH_USAGE : !strcmp(argv[1], "call") ? CALL_USAGE :
+            !strcmp(argv[1], "smooth") ? SMOOTH_USAGE : MAIN_USAGE, stderr);
+      return EXIT_SUCCESS;
+    }
     if (!strcmp(argv[1], "search")) {
       if (o.index.empty() || (o.fastx.empty() && o.bam.empty())) { fputs(SEARCH_USAGE, stderr); return EXIT_FAILURE; }
       main_search(o);

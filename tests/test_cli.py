@@ -36,6 +36,16 @@ def test_version_usage_and_errors():
     assert r.returncode == 1 and "does not exist" not in r.stderr
     r = run("call", "--reference", "a", "--bam", "b", "--sfs", "c", "--frobnicate")
     assert r.returncode == 1 and "does not exist" in r.stderr
+    # --help prints the mode's own usage and succeeds (main.cpp:47-50, config.cpp:12-24); cxxopts' rules for the rest
+    # (tests/test_ref_pins.py holds the parser against the reference's): positional arguments are left alone, a number
+    # that is not one is an error
+    for mode in ("search", "call", "smooth"):
+        r = run(mode, "--help")
+        assert r.returncode == 0 and f"Usage: SVDSS {mode}" in r.stderr and r.stdout == ""
+    r = run("search", "stray", "--index", "/nonexistent.fmd", "--fastx", "/nonexistent.fq")
+    assert r.returncode == 1 and "does not exist" not in r.stderr
+    r = run("search", "--index", "x", "--fastx", "y", "--threads", "four")
+    assert r.returncode == 1 and "failed to parse" in r.stderr
 
 
 def test_commands_fail_loudly_without_a_gpu(tmp_path):
