@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_lib = C.CDLL(os.path.join(ROOT, "oracle", "libsvdss_oracle.so"))
+# (SVDSS_ORACLE_LIB: another build of the checker, e.g. the sanitized one of `make -C oracle san`)
+_lib = C.CDLL(os.environ.get("SVDSS_ORACLE_LIB") or os.path.join(ROOT, "oracle", "libsvdss_oracle.so"))
 
 _p, _i64 = C.c_void_p, C.c_int64
 _lib.orc_fmd_build.restype = _p

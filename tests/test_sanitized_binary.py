@@ -31,3 +31,19 @@ def test_process_level_tests_against_the_sanitized_binary():
                         "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=3000)
     assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
+
+
+def test_the_oracle_itself_under_sanitizers():
+    """The checker must not owe an answer to undefined behaviour either: the oracle's own tests (brute-force pins of the
+    search, the independent score re-derivation, POA invariants) against `make -C oracle san` -- the same C files built
+    with -fsanitize=address,undefined -- in a process with libasan preloaded.  Seconds, so it runs in the default suite."""
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan beside this gcc")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "san"], check=True, capture_output=True)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:exitcode=99", OMP_NUM_THREADS="4",
+               UBSAN_OPTIONS="halt_on_error=1:exitcode=98:print_stacktrace=1",
+               SVDSS_ORACLE_LIB=os.path.join(ROOT, "oracle", "libsvdss_oracle_san.so"))
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_oracle.py", "tests/test_oracle_call.py", "tests/test_oracle_poa.py",
+                        "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
