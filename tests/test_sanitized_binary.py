@@ -45,5 +45,6 @@ def test_the_oracle_itself_under_sanitizers():
                UBSAN_OPTIONS="halt_on_error=1:exitcode=98:print_stacktrace=1",
                SVDSS_ORACLE_LIB=os.path.join(ROOT, "oracle", "libsvdss_oracle_san.so"))
     p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_oracle.py", "tests/test_oracle_call.py", "tests/test_oracle_poa.py",
+                        "tests/test_bench_helpers.py",      # (the batch entry points bench.py's cpu_baseline leg times)
                         "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
