@@ -57,3 +57,27 @@ def test_compute_fails_loudly_without_gpu():
     with pytest.raises(svdss_amd.SvdssError) as e:
         ix.to_device(0)                           # no device to put it on
     assert e.value.code in (2, 4)
+
+
+def test_null_arguments_are_refused_not_dereferenced():
+    """Every entry point of include/svdss_hip.h called with null pointers and zero counts (in a child process: a crash
+    is the failure): status codes are errors or the empty-batch success, counters answer -1, frees are no-ops."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys
+from svdss_amd import _lib
+ok_zero = {"svdss_indel_ratio_batch", "svdss_nt6_encode", "svdss_stream_destroy", "svdss_device_count"}
+for n in sorted(_lib.SIGNATURES):
+    restype, argtypes = _lib.SIGNATURES[n]
+    args = [a(0) if a in (C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_double) else None for a in argtypes]
+    r = getattr(_lib.lib, n)(*args)
+    if restype in (C.c_int, C.c_int32) and n not in ok_zero and not n.endswith(("_nreads", "_segments", "_hbm", "_kmer", "_nclusters", "_npairs", "_fallbacks")):
+        assert r != 0, (n, r)
+    if restype is C.c_int64 and n not in ok_zero:
+        assert r == -1, (n, r)
+print("all", len(_lib.SIGNATURES))
+'''
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "all" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
