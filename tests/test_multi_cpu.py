@@ -107,7 +107,7 @@ def test_gatherer_overlapped_steps_gloo():
         assert (c == np.concatenate(cs)).all() and (qv == np.concatenate(qq)).all() and (lv == np.concatenate(ll)).all()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])      # (8: the node the metric is quoted on)
 def test_gather_sfs_gloo(world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
