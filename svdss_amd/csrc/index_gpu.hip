@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/svdss_hip.h"
@@ -655,8 +656,11 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
 }
 
 // the text of a device-built index -> host vector (no-op when it is there already)
+static std::mutex g_fetch_m;   // guards the host-side vectors of a shared handle while they are brought down
+
 int svdss_index_fetch_text(svdss_index* ix) {
   if (!ix) return SVDSS_EINVAL;
+  std::lock_guard<std::mutex> fetch_lk(g_fetch_m);
   if ((int64_t)ix->text.size() == ix->n) return SVDSS_OK;
   if (ix->device < 0 || !ix->d_text) return SVDSS_ENODEV;
   if (hipSetDevice(ix->device) != hipSuccess) { (void)hipGetLastError(); return SVDSS_EHIP; }
@@ -672,6 +676,10 @@ int svdss_index_fetch_text(svdss_index* ix) {
 // text and suffix array of a device-built index -> host vectors (no-op when they are there already)
 int svdss_index_fetch_host(svdss_index* ix) {
   if (!ix) return SVDSS_EINVAL;
+  // several threads may come here with the SAME handle (svdss_index_replicate of `--gpus N`, one thread per replica): the
+  // vectors are resized and filled by one of them, the others find them complete (the size test alone would let a
+  // second thread through between the resize and the end of the copy)
+  std::lock_guard<std::mutex> fetch_lk(g_fetch_m);
   const bool have_sa = ix->sa_wide ? (int64_t)ix->sa64.size() == ix->n : (int64_t)ix->sa32.size() == ix->n;
   if ((int64_t)ix->text.size() == ix->n && have_sa) return SVDSS_OK;
   if (ix->device < 0 || !ix->d_text || !ix->d_sa) return SVDSS_ENODEV;

@@ -67,6 +67,12 @@ def test_binary_takes_the_fmd_alone(case, tmp_path):
     b = subprocess.run([BIN, "search", "--index", str(d / "up.fmd"), "--fastx", str(fq), "--threads", "4"], capture_output=True, text=True, timeout=600)
     assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
     assert a.stdout == b.stdout and a.stdout.count("\n") > 300
+    # three replicas made at once from the handle of an imported .fmd (no records: text and suffix array travel through
+    # the source's host copy, which the replicating threads share -- ADVICE r3: guarded by one mutex now)
+    e = subprocess.run([BIN, "search", "--index", str(d / "up.fmd"), "--fastx", str(fq), "--threads", "4", "--gpus", "3"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SVDSS_GPUS_OVERSUBSCRIBE="1"))
+    assert e.returncode == 0, e.stderr
+    assert e.stdout == a.stdout
     # and the .fmd `SVDSS index` wrote, with its sidecar taken away
     os.remove(str(own) + ".svdss")
     c = subprocess.run([BIN, "search", "--index", str(own), "--fastx", str(fq), "--threads", "4"], capture_output=True, text=True, timeout=600)
