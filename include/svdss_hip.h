@@ -223,6 +223,59 @@ int svdss_sfs_batch_device_ptrs(const svdss_sfs_batch_t* b, void** counts, void*
                                 void** n_ext);
 void svdss_sfs_batch_free(svdss_sfs_batch_t* b);
 
+/* ---- a6 + a7 on the device: BAM records in, SFS out (csrc/bam_device.hip) ------------------------------------
+ * Replaces PingPong::load_batch_bam (ping_pong.cpp:53-128: sam_read1 = BGZF inflate + the block_size chain of the
+ * records, the flag / l_qseq / tid filters :66-79, 4-bit -> nt6 :90-94) and the head of PingPong::process_batch (:196-203:
+ * bam_aux_get("XF"/"HP"), the putative filter) for a run of consecutive BGZF blocks at once, followed by the search of
+ * svdss_sfs_search_batch_device.  Only compressed bytes go up; names, tags and SFS come down.
+ *
+ * A svdss_bam_stream_t is one BAM file being read: it holds the bytes of the record that straddles two consecutive
+ * batches and gives the batches their turn in file order (everything else of a batch -- inflate, the record chain of
+ * its segments, unpack, search -- overlaps with the other batches, each on its own svdss_bam_batch_t / stream / thread).
+ * n_ref = reference sequences in the BAM header (tid / mtid outside -1 .. n_ref - 1 never start a record).
+ *
+ * svdss_bam_batch_run, batch number seq = 0, 1, 2, ... of the file (every number exactly once, from any thread; is_last on
+ * the final one): n_chunks pieces of the file in page-locked or ordinary host memory; piece c holds n_blocks[c] BGZF
+ * blocks, block i = the raw deflate stream comp[c][coff, coff + clen) that inflates to isize bytes with CRC32 crc[c][i]
+ * (uoff is ignored: the blocks of a batch inflate back to back in the order given).  skip = inflated bytes in front of the
+ * first record (the BAM header; batch 0 only).  flags: SVDSS_SFS_ASSEMBLE, SVDSS_BAM_PUTATIVE (reads whose XF tag is not 0
+ * keep their slot but are not searched, ping_pong.cpp:202-203).
+ * Errors: SVDSS_EIO with svdss_bam_batch_error() = "BGZF inflate failed" | "BGZF block CRC mismatch" | "truncated record" |
+ * "corrupt record" | "core.tid < 0. Why are we here? Please check" (the reference's fatal message, :76-79); once a batch
+ * failed every later batch of the stream returns its error. */
+typedef struct svdss_bam_stream svdss_bam_stream_t;
+typedef struct svdss_bam_batch svdss_bam_batch_t;
+#define SVDSS_BAM_PUTATIVE 0x100
+int svdss_bam_stream_create(int32_t n_ref, svdss_bam_stream_t** out);
+void svdss_bam_stream_free(svdss_bam_stream_t* s);
+const char* svdss_bam_stream_error(const svdss_bam_stream_t* s);
+/* segments whose guessed first record the chain did not arrive at (walked again, exactly), of *n_segments in all */
+int64_t svdss_bam_stream_rewalked(const svdss_bam_stream_t* s, int64_t* n_segments);
+int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_index_t* ix,
+                        int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                        const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                        int32_t flags, svdss_bam_batch_t** out);
+/* What the last run of a batch object left on the host (valid until its next run / svdss_bam_batch_free).  A "slot" is a
+ * record that passed the filters of ping_pong.cpp:66-75, in file order -- what load_batch_bam deals to the threads. */
+typedef struct svdss_bam_result {
+  int64_t n_records;        /* records of the batch (passed or not) */
+  int64_t n_slots;          /* passed the flag and length filters */
+  int64_t n_searched;       /* of them searched (all, unless SVDSS_BAM_PUTATIVE) */
+  int64_t n_short;          /* dropped for l_qseq < 100 (the reference warns once per read, :70-75) */
+  int64_t total_sfs;
+  const int32_t* name_off;  /* n_slots + 1: slot i is called names[name_off[i] .. name_off[i + 1]) */
+  const char* names;
+  const int32_t* hp;        /* n_slots: HP tag, 0 if absent */
+  const int32_t* sidx;      /* n_slots: index among the searched reads, -1 = not searched */
+  const int64_t* counts;    /* n_searched: SFS per searched read */
+  const int32_t* qs;        /* total_sfs, read after read */
+  const int32_t* len;
+  double inflate_kernel_ms;
+} svdss_bam_result_t;
+int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_result_t* out);
+const char* svdss_bam_batch_error(const svdss_bam_batch_t* b);
+void svdss_bam_batch_free(svdss_bam_batch_t* b);
+
 /* ---- a10: SFS placement ------------------------------------------------------
  * Replaces Clusterer::extend_alignment (clusterer.cpp:159-346) with get_aligned_pairs (bam.cpp:92-134) and
  * get_unique_kmers (clusterer.cpp:351-405) for a batch of alignments: every SFS (qs, len) of a read is mapped to the

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SVDSS_LIB") or os.path.join(_HERE, "libsvdss_hip.so")
 
 SVDSS_OK = 0
 SVDSS_SFS_ASSEMBLE = 1
+SVDSS_BAM_PUTATIVE = 0x100
 
 
 class SvdssError(RuntimeError):
@@ -91,6 +92,14 @@ SIGNATURES = {
     "svdss_sfs_batch_fetch": (C.c_int, [_p, _p, _p, _p, _p]),
     "svdss_sfs_batch_device_ptrs": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "svdss_sfs_batch_free": (None, [_p]),
+    "svdss_bam_stream_create": (C.c_int, [_i32, C.POINTER(_p)]),
+    "svdss_bam_stream_free": (None, [_p]),
+    "svdss_bam_stream_error": (C.c_char_p, [_p]),
+    "svdss_bam_stream_rewalked": (_i64, [_p, _pi64]),
+    "svdss_bam_batch_run": (C.c_int, [_p, _i64, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p, _i32, C.POINTER(_p)]),
+    "svdss_bam_batch_result": (C.c_int, [_p, _p]),
+    "svdss_bam_batch_error": (C.c_char_p, [_p]),
+    "svdss_bam_batch_free": (None, [_p]),
     "svdss_ref_upload": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
     "svdss_ref_free": (None, [_p]),
     "svdss_place_sfs_batch": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),

@@ -1,0 +1,854 @@
+// bam_device.hip -- BAM records walked, filtered and unpacked where they are inflated: compressed BGZF blocks in, SFS out
+// (svdss_bam_batch_run).
+//
+// Stands where PingPong::load_batch_bam and the head of PingPong::process_batch stand (/root/reference/ping_pong.cpp:
+// 53-128, 176-209): sam_read1 (bgzf inflate + the block_size chain of the records, :58), the flag / length / tid filters
+// (:66-79), the 4-bit -> nt6 expansion (:90-94), the XF / HP aux lookup and the putative filter (:196-203).  Until round 3
+// the inflated bytes went down to the host, one thread sliced the records there and the packed bases came up again
+// (0.55-0.69 M reads/s against 8 M for the kernels).  Here only the compressed bytes go up and ~40 bytes per
+// read (name, tags) plus the SFS come down.
+//
+// One batch = a run of consecutive BGZF blocks (a few hundred MB inflated), inflated into ONE device buffer so that a
+// record that straddles two blocks is contiguous.  The record that straddles two BATCHES is carried: the bytes behind the
+// last complete record of batch b are copied in front of batch b + 1's data (head room).  Per batch:
+//   inflate     csrc/inflate.hip, one wavefront per block; crc32_kernel checks the BGZF footers (one wavefront per block:
+//               64 slices through a 4 x 256-entry table in LDS, combined with x^(8 n) mod P products -- the arithmetic of
+//               zlib's crc32_combine);
+//   walk        the records form a chain (offset += 4 + block_size): ~23,000 dependent loads per batch if one lane
+//               follows it.  walk_kernel cuts the batch into segments, one wavefront each: the 64 lanes look for the
+//               first plausible record start in the segment (64 candidates per step; plausible = every field in range
+//               and the record behind it plausible too), lane 0 follows the chain from there to the segment's end.
+//               link_kernel then proves the guesses: starting from the TRUE first record (the carry, or the end of the
+//               BAM header) the chain must arrive exactly at every segment's guessed start; a segment it does not arrive
+//               at is walked again from where it did arrive.  The result never depends on the guess, only the speed does
+//               (the same contract as the segmented search);
+//   meta        one lane per record: core fields, the filters, XF / HP from the aux block (bam_aux_get + bam_aux2i);
+//   scatter     exclusive scans (hipcub) place the names, the tags and the reads that are searched;
+//   unpack      4-bit bases -> nt6, 16 output bytes per lane, straight from the inflated records;
+//   search      svdss_sfs_search_batch_device on the batch's stream.
+// Batches of one file run concurrently on their own streams (several feeding threads); only the link step is ordered
+// (it needs the carry of the previous batch): svdss_bam_stream holds the carry and the turn.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/svdss_hip.h"
+#include "hip_check.h"
+#include "index_host.h"
+#include "inflate_dev.h"
+
+namespace {
+
+constexpr int64_t kHeadDefault = (int64_t)16 << 20;   // room in front of a batch's data for the carried bytes
+constexpr int kMaxSeg = 2048;
+constexpr int64_t kMinRec = 36;                        // block_size field + the 32 core bytes
+
+// error bits a batch's kernels raise (hdr[H_ERR])
+enum { E_CORRUPT = 1, E_TID = 2 };
+enum { H_NREC = 0, H_TAIL = 1, H_ERR = 2, H_REWALK = 3, H_PRE = 4, H_SHORT = 5, H_N = 8 };
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* base, int64_t off) {
+  const uint32_t* w = (const uint32_t*)(base + (off & ~(int64_t)3));
+  return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(off & 3));
+}
+
+// ------------------------------------------------------------------ CRC32 of the inflated blocks
+// a(x) * b(x) mod P in the reflected representation zlib uses (bit 31 = x^0); P = 0xEDB88320
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    p ^= (a & 0x80000000u) ? b : 0u;
+    a <<= 1;
+    b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+  }
+  return p;
+}
+// x^(8 n) mod P
+__device__ __forceinline__ uint32_t gf_xpow8(uint32_t n) {
+  uint32_t r = 0x80000000u;            // x^0
+  uint32_t sq = 0x00800000u;           // x^8
+  while (n) {
+    if (n & 1u) r = gf_mul(r, sq);
+    sq = gf_mul(sq, sq);
+    n >>= 1;
+  }
+  return r;
+}
+
+struct CrcBlk { int64_t uoff; int32_t isize; uint32_t crc; };
+
+// one wavefront per BGZF block: lane l takes the S bytes that end (63 - l) * S bytes before the block's end
+__global__ void __launch_bounds__(64) crc32_kernel(const uint8_t* __restrict__ data, const CrcBlk* __restrict__ blks, int32_t* bad) {
+  __shared__ uint32_t T[4][256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) {
+    uint32_t c = (uint32_t)i;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+    T[0][i] = c;
+  }
+  __syncthreads();
+  for (int i = lane; i < 256; i += 64) {
+    uint32_t c = T[0][i];
+    for (int t = 1; t < 4; ++t) { c = T[0][c & 0xff] ^ (c >> 8); T[t][i] = c; }
+  }
+  __syncthreads();
+  const CrcBlk b = blks[blockIdx.x];
+  const int n = b.isize;
+  if (n <= 0) return;
+  const int S = (((n + 63) >> 6) + 3) & ~3;
+  int hi = n - (63 - lane) * S, lo = hi - S;
+  if (lo < 0) lo = 0;
+  uint32_t c = 0;
+  if (hi > lo) {
+    const uint8_t* p = data + b.uoff;
+    int i = lo;
+    c = 0xFFFFFFFFu;
+    while (i < hi && (((uintptr_t)(p + i)) & 3u)) { c = T[0][(c ^ p[i]) & 0xff] ^ (c >> 8); ++i; }
+    for (; i + 4 <= hi; i += 4) {
+      c ^= *(const uint32_t*)(p + i);
+      c = T[3][c & 0xff] ^ T[2][(c >> 8) & 0xff] ^ T[1][(c >> 16) & 0xff] ^ T[0][c >> 24];
+    }
+    for (; i < hi; ++i) c = T[0][(c ^ p[i]) & 0xff] ^ (c >> 8);
+    c = ~c;
+  }
+  // crc(A || B) = x^(8 |B|) crc(A) + crc(B): lane l's slice is followed by (63 - l) * S bytes
+  const uint32_t g = gf_xpow8((uint32_t)S);     // uniform
+  uint32_t pw = 0x80000000u, gp = g;
+  const int e = 63 - lane;
+#pragma unroll 1
+  for (int k = 0; k < 6; ++k) {
+    if ((e >> k) & 1) pw = gf_mul(pw, gp);
+    gp = gf_mul(gp, gp);
+  }
+  c = gf_mul(c, pw);
+  for (int d = 32; d >= 1; d >>= 1) c ^= (uint32_t)__shfl_xor((int)c, d, 64);
+  if (lane == 0 && c != b.crc) atomicAdd(bad, 1);
+}
+
+// ------------------------------------------------------------------ the chain of records
+struct WalkP {
+  const uint8_t* buf;
+  int64_t lo, hi;          // fresh data of this batch: [lo, hi) (lo = head room [+ BAM header in the first batch])
+  int64_t seg_bytes;
+  int32_t n_seg, n_ref;
+  uint32_t* seg_start;     // guessed first record of the segment (0xffffffff: none found)
+  uint32_t* seg_end;       // where the chain from there left the segment (or stopped: tail / nonsense)
+  int32_t* seg_cnt;
+  uint32_t* lists;         // n_seg lists of list_cap offsets
+  int64_t list_cap;
+};
+
+// necessary conditions on the 36 bytes at p (and the name's terminator) for a record of a file htslib reads
+__device__ __forceinline__ bool plausible(const uint8_t* buf, int64_t p, int64_t hi, int32_t n_ref) {
+  if (p + kMinRec > hi) return false;
+  const uint32_t bs = ld32(buf, p);
+  if (bs < 32u || bs > (1u << 28)) return false;
+  const int32_t tid = (int32_t)ld32(buf, p + 4), pos = (int32_t)ld32(buf, p + 8);
+  if (tid < -1 || tid >= n_ref || pos < -1) return false;
+  const uint32_t w3 = ld32(buf, p + 12), w4 = ld32(buf, p + 16);
+  const int32_t l_seq = (int32_t)ld32(buf, p + 20), mtid = (int32_t)ld32(buf, p + 24), mpos = (int32_t)ld32(buf, p + 28);
+  if (l_seq < 0 || mtid < -1 || mtid >= n_ref || mpos < -1) return false;
+  const uint32_t l_name = w3 & 0xffu, n_cig = w4 & 0xffffu;
+  if (l_name == 0) return false;
+  const int64_t head = 32 + (int64_t)l_name + 4 * (int64_t)n_cig + ((int64_t)l_seq + 1) / 2 + l_seq;
+  if (head > (int64_t)bs) return false;
+  const int64_t nul = p + 36 + l_name - 1;
+  if (nul < hi && buf[nul] != 0) return false;
+  return true;
+}
+
+__global__ void __launch_bounds__(64) walk_kernel(WalkP P) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int64_t s_lo = P.lo + (int64_t)s * P.seg_bytes;
+  int64_t s_hi = s_lo + P.seg_bytes;
+  if (s_hi > P.hi || s == P.n_seg - 1) s_hi = P.hi;
+  int64_t found = -1;
+  for (int64_t p0 = s_lo; p0 < s_hi; p0 += 64) {
+    const int64_t p = p0 + lane;
+    bool ok = p < s_hi && plausible(P.buf, p, P.hi, P.n_ref);
+    if (ok) {   // the record behind it: plausible too, or not visible any more
+      const int64_t p2 = p + 4 + (int64_t)ld32(P.buf, p);
+      ok = p2 + kMinRec > P.hi ? p2 <= P.hi + ((int64_t)1 << 28) : plausible(P.buf, p2, P.hi, P.n_ref);
+    }
+    const unsigned long long m = __ballot(ok);
+    if (m) { found = p0 + __builtin_ctzll(m); break; }
+  }
+  found = ((int64_t)__builtin_amdgcn_readfirstlane((int)(found >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)found);
+  uint32_t* list = P.lists + (int64_t)s * P.list_cap;
+  int64_t p = found;
+  int cnt = 0;
+  if (found >= 0) {
+    while (p < s_hi) {
+      if (p + 4 > P.hi) break;
+      const uint32_t bs = ld32(P.buf, p);
+      if (bs < 32u) break;                                   // not a chain of records (or a damaged file: link_kernel says which)
+      if (p + 4 + (int64_t)bs > P.hi) break;
+      if (lane == 0) list[cnt] = (uint32_t)p;
+      ++cnt;
+      p += 4 + (int64_t)bs;
+    }
+  }
+  if (lane == 0) {
+    P.seg_start[s] = found >= 0 ? (uint32_t)found : 0xffffffffu;
+    P.seg_end[s] = (uint32_t)(found >= 0 ? p : 0);
+    P.seg_cnt[s] = cnt;
+  }
+}
+
+// From the true first record through every segment: hdr[H_NREC] records, their offsets in lists / pre, hdr[H_TAIL] = the
+// first byte that belongs to no complete record.  One wavefront; the segment table sits in LDS.
+__global__ void __launch_bounds__(64) link_kernel(WalkP P, int64_t start, uint32_t* pre, int32_t* seg_base, int64_t* hdr) {
+  __shared__ uint32_t sst[kMaxSeg], sen[kMaxSeg];
+  __shared__ int32_t scn[kMaxSeg];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < P.n_seg; i += 64) { sst[i] = P.seg_start[i]; sen[i] = P.seg_end[i]; scn[i] = P.seg_cnt[i]; }
+  __syncthreads();
+  if (lane != 0) return;
+  int64_t err = 0, n_rewalk = 0;
+  int64_t cur = start;
+  int n_pre = 0;
+  bool stop = false;    // the chain reached the tail (or nonsense)
+  auto step = [&](int64_t p, int64_t& next) -> bool {   // is there a complete record at p?
+    if (p + 4 > P.hi) return false;
+    const uint32_t bs = ld32(P.buf, p);
+    if (bs < 32u) { err |= E_CORRUPT; return false; }
+    if (p + 4 + (int64_t)bs > P.hi) return false;
+    next = p + 4 + (int64_t)bs;
+    return true;
+  };
+  // records that begin in the carried bytes
+  while (!stop && cur < P.lo) {
+    int64_t nx;
+    if (!step(cur, nx)) { stop = true; break; }
+    if (n_pre < 4) pre[n_pre] = (uint32_t)cur;
+    else err |= E_CORRUPT;     // (cannot happen: the carry is one incomplete record)
+    ++n_pre;
+    cur = nx;
+  }
+  int total = n_pre;
+  for (int s = 0; s < P.n_seg; ++s) {
+    const int64_t s_lo = P.lo + (int64_t)s * P.seg_bytes;
+    int64_t s_hi = s_lo + P.seg_bytes;
+    if (s_hi > P.hi || s == P.n_seg - 1) s_hi = P.hi;
+    seg_base[s] = total;
+    if (stop || cur >= s_hi) { scn[s] = 0; P.seg_cnt[s] = 0; continue; }   // nothing begins here
+    if ((int64_t)sst[s] == cur) {
+      total += scn[s];
+      cur = sen[s];
+      if (cur < s_hi) { int64_t nx; (void)step(cur, nx); stop = true; }   // the tail -- or a block_size below 32 (step says which)
+      continue;
+    }
+    // the guess was wrong (or there was none): walk the segment from where the chain really arrives
+    ++n_rewalk;
+    uint32_t* list = P.lists + (int64_t)s * P.list_cap;
+    int cnt = 0;
+    while (cur < s_hi) {
+      int64_t nx;
+      if (!step(cur, nx)) { stop = true; break; }
+      list[cnt++] = (uint32_t)cur;
+      cur = nx;
+    }
+    P.seg_cnt[s] = cnt;
+    total += cnt;
+  }
+  hdr[H_NREC] = total;
+  hdr[H_TAIL] = cur < P.hi ? cur : P.hi;
+  hdr[H_ERR] = err;
+  hdr[H_REWALK] = n_rewalk;
+  hdr[H_PRE] = n_pre;
+}
+
+// ------------------------------------------------------------------ per record: fields, filters, tags
+struct MetaP {
+  const uint8_t* buf;
+  const uint32_t* lists; int64_t list_cap;
+  const int32_t* seg_cnt; const int32_t* seg_base; const uint32_t* pre;
+  int32_t n_seg, putative;
+  int64_t n_rec;
+  uint32_t* rpos;                 // record offsets, in file order
+  int64_t *f_pass, *f_srch, *f_name, *f_sym;   // n_rec + 1 each: inputs of the four scans
+  int32_t* hp;
+  int64_t* hdr;
+};
+
+// bam_aux_get + bam_aux2i for one two-letter tag, as BamReader::aux_int reads it (csrc/bam_reader.h): integer types
+// only, anything unexpected ends the scan with "absent"
+__device__ bool aux_int(const uint8_t* p, const uint8_t* e, char a, char b, int64_t& out) {
+  while (p + 3 <= e) {
+    const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
+    p += 3;
+    int64_t sz = 0;
+    switch (ty) {
+      case 'A': case 'c': case 'C': sz = 1; break;
+      case 's': case 'S': sz = 2; break;
+      case 'i': case 'I': case 'f': sz = 4; break;
+      case 'Z': case 'H': { const uint8_t* z = p; while (z < e && *z) ++z; sz = (int64_t)(z - p) + 1; break; }
+      case 'B': {
+        if (p + 5 > e) return false;
+        const char st = (char)p[0];
+        const int32_t cnt = (int32_t)((uint32_t)p[1] | ((uint32_t)p[2] << 8) | ((uint32_t)p[3] << 16) | ((uint32_t)p[4] << 24));
+        const int64_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+        sz = 5 + es * (int64_t)(uint32_t)cnt;     // (size_t arithmetic on the host: a negative count is a huge one)
+        break;
+      }
+      default: return false;
+    }
+    if (sz > (int64_t)(e - p)) return false;
+    if (t0 == a && t1 == b) {
+      switch (ty) {
+        case 'c': out = (int8_t)p[0]; return true;
+        case 'C': out = p[0]; return true;
+        case 's': out = (int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8)); return true;
+        case 'S': out = (uint16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8)); return true;
+        case 'i': out = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); return true;
+        case 'I': out = (uint32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); return true;
+        default: return false;
+      }
+    }
+    p += sz;
+  }
+  return false;
+}
+
+// block s < n_seg: the records of segment s; block n_seg: those that begin in the carried bytes
+__global__ void __launch_bounds__(64) meta_kernel(MetaP M) {
+  const int s = blockIdx.x;
+  const int cnt = s < M.n_seg ? M.seg_cnt[s] : (int)(M.hdr[H_PRE] < 4 ? M.hdr[H_PRE] : 4);
+  const int base = s < M.n_seg ? M.seg_base[s] : 0;
+  const uint32_t* list = s < M.n_seg ? M.lists + (int64_t)s * M.list_cap : M.pre;
+  for (int i = threadIdx.x; i < cnt; i += 64) {
+    const int64_t gi = base + i;
+    const int64_t p = list[i];
+    const uint32_t bs = ld32(M.buf, p);
+    const int32_t tid = (int32_t)ld32(M.buf, p + 4);
+    const uint32_t w3 = ld32(M.buf, p + 12), w4 = ld32(M.buf, p + 16);
+    const int32_t l_seq = (int32_t)ld32(M.buf, p + 20);
+    const uint32_t l_name = w3 & 0xffu, n_cig = w4 & 0xffffu, flag = w4 >> 16;
+    const int64_t head = 32 + (int64_t)l_name + 4 * (int64_t)n_cig + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
+    bool keep = false, srch = false;
+    int64_t hp = 0;
+    if (l_seq < 0 || head > (int64_t)bs) atomicOr((unsigned long long*)&M.hdr[H_ERR], (unsigned long long)E_CORRUPT);   // BamReader::next_view: "corrupt record"
+    else {
+      keep = !(flag & (4u | 2048u | 256u));                  // ping_pong.cpp:66-69
+      if (keep && l_seq < 100) {                             // :70-75 (the host prints the warnings)
+        atomicAdd((unsigned long long*)&M.hdr[H_SHORT], 1ull);
+        keep = false;
+      }
+      if (keep && tid < 0) atomicOr((unsigned long long*)&M.hdr[H_ERR], (unsigned long long)E_TID);   // :76-79
+      if (keep) {
+        const uint8_t* aux = M.buf + p + 4 + head;
+        const uint8_t* end = M.buf + p + 4 + (int64_t)bs;
+        int64_t xf = 0;
+        (void)aux_int(aux, end, 'X', 'F', xf);               // :196-201, missing => 0
+        (void)aux_int(aux, end, 'H', 'P', hp);
+        srch = !(M.putative && xf != 0);                     // :202-203
+      }
+    }
+    M.rpos[gi] = (uint32_t)p;
+    M.f_pass[gi] = keep ? 1 : 0;
+    M.f_srch[gi] = srch ? 1 : 0;
+    M.f_name[gi] = keep ? (int64_t)(l_name ? l_name - 1 : 0) : 0;
+    M.f_sym[gi] = srch ? (int64_t)l_seq : 0;
+    M.hp[gi] = (int32_t)hp;
+  }
+  if (s == 0 && threadIdx.x == 0) { M.f_pass[M.n_rec] = 0; M.f_srch[M.n_rec] = 0; M.f_name[M.n_rec] = 0; M.f_sym[M.n_rec] = 0; }
+}
+
+struct ScatP {
+  const uint8_t* buf;
+  int64_t n_rec;
+  const uint32_t* rpos;
+  const int64_t *f_pass, *f_srch;            // the flags
+  const int64_t *s_pass, *s_srch, *s_name, *s_sym;   // their exclusive scans (n_rec + 1: the last entry is the total)
+  const int32_t* hp;
+  int32_t* o_name_off;   // slots + 1
+  char* o_names;
+  int32_t* o_hp;         // slots
+  int32_t* o_sidx;       // slots: index among the searched reads, -1 = not searched (putative filter)
+  int64_t* sym_off;      // searched + 1
+  int64_t* seq_src;      // searched: where the packed bases sit in buf
+  int64_t* totals;       // slots, searched, name bytes, symbols
+};
+
+__global__ void __launch_bounds__(256) scatter_kernel(ScatP S) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi > S.n_rec) return;
+  if (gi == S.n_rec) {
+    S.o_name_off[S.s_pass[gi]] = (int32_t)S.s_name[gi];
+    S.sym_off[S.s_srch[gi]] = S.s_sym[gi];
+    S.totals[0] = S.s_pass[gi]; S.totals[1] = S.s_srch[gi]; S.totals[2] = S.s_name[gi]; S.totals[3] = S.s_sym[gi];
+    return;
+  }
+  if (!S.f_pass[gi]) return;
+  const int64_t p = S.rpos[gi];
+  const uint32_t w3 = ld32(S.buf, p + 12), w4 = ld32(S.buf, p + 16);
+  const uint32_t l_name = w3 & 0xffu, n_cig = w4 & 0xffffu;
+  const int64_t slot = S.s_pass[gi];
+  S.o_name_off[slot] = (int32_t)S.s_name[gi];
+  S.o_hp[slot] = S.hp[gi];
+  const uint8_t* nm = S.buf + p + 36;
+  char* dst = S.o_names + S.s_name[gi];
+  for (uint32_t k = 0; k + 1 < l_name; ++k) dst[k] = (char)nm[k];
+  if (S.f_srch[gi]) {
+    const int64_t k = S.s_srch[gi];
+    S.o_sidx[slot] = (int32_t)k;
+    S.sym_off[k] = S.s_sym[gi];
+    S.seq_src[k] = p + 36 + (int64_t)l_name + 4 * (int64_t)n_cig;
+  } else S.o_sidx[slot] = -1;
+}
+
+// 4-bit bases -> nt6 (ping_pong.cpp:90-94: seq_nt16_str, then seq_nt6_table): read r = y0 + blockIdx.y, one lane per 16
+// ALIGNED output bytes (whole chunks leave as one 16-byte store; the two ends of a read byte by byte)
+__global__ void __launch_bounds__(256) unpack_kernel(const uint8_t* __restrict__ buf, const int64_t* __restrict__ seq_src,
+                                                     const int64_t* __restrict__ sym_off, int64_t y0, int64_t n_reads, uint8_t* out) {
+  const int64_t r = y0 + blockIdx.y;
+  if (r >= n_reads) return;
+  const int64_t s = sym_off[r], e = sym_off[r + 1];
+  const int64_t c = (s >> 4) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t o0 = c << 4;
+  if (o0 >= e) return;
+  const int64_t a = o0 < s ? s : o0, b = o0 + 16 < e ? o0 + 16 : e;    // output bytes [a, b)
+  const int64_t i0 = a - s;                                            // first symbol of the read this lane writes
+  const int64_t sb = seq_src[r] + (i0 >> 1);
+  const uint64_t lo = (uint64_t)ld32(buf, sb) | ((uint64_t)ld32(buf, sb + 4) << 32);
+  const uint32_t hi = ld32(buf, sb + 8);
+  // "=ACMGRSVTWYHKDBN": A=1 C=2 G=4 T=8 -> nt6 1..4, every other code (IUPAC, '=') -> 5 like seq_nt6_table
+  const uint64_t lut = 0x5555555455535215ull;
+  uint32_t w[4] = {0, 0, 0, 0};
+  const int n = (int)(b - a);
+  const int odd = (int)(i0 & 1);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int ni = k + odd;                        // nibble index from the first loaded byte
+    const int by = ni >> 1;
+    const uint32_t byte = by < 8 ? (uint32_t)(lo >> (8 * by)) & 0xffu : (hi >> (8 * (by - 8))) & 0xffu;
+    const uint32_t v = (ni & 1) ? (byte & 15u) : (byte >> 4);
+    const uint32_t sym = (uint32_t)(lut >> (4 * v)) & 15u;
+    w[k >> 2] |= sym << (8 * (k & 3));
+  }
+  if (n == 16) {
+    *(uint4*)(out + a) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    for (int k = 0; k < n; ++k) out[a + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+  }
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct OffDiff {   // length of searched read k
+  const int64_t* o;
+  __host__ __device__ int64_t operator()(int64_t k) const { return o[k + 1] - o[k]; }
+};
+
+}  // namespace
+
+struct svdss_bam_stream {
+  int32_t n_ref = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int64_t next_seq = 0;
+  int failed = 0;
+  std::string err;
+  std::vector<uint8_t> carry;      // the bytes behind the last complete record of the batch that had its turn last
+  int64_t n_rewalked = 0, n_segments = 0;
+};
+
+struct svdss_bam_batch {
+  int device = -1;
+  hipStream_t st = nullptr;
+  DevBuf comp, blks, crcb, status, buf, seg, lists, pre, hdr, rpos, flags, scans, d_hp, tmp, o_small, d_names, sym_off, seq_src, reads, totals;
+  uint8_t* h_pin = nullptr;        // page-locked staging: block tables up, small results down
+  size_t h_pin_cap = 0;
+  std::vector<int32_t> h_status;
+  svdss_sfs_batch_t* sfs = nullptr;
+  // results of the last run (host side)
+  std::vector<int32_t> name_off, hp, sidx, qs, len;
+  std::vector<char> names;
+  std::vector<int64_t> counts;
+  int64_t n_records = 0, n_slots = 0, n_searched = 0, n_short = 0, total_sfs = 0;
+  double inflate_ms = 0, walk_ms = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::string err;
+};
+
+static int ensure(DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return SVDSS_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  const size_t want = bytes + (bytes >> 3) + 4096;
+  HIPCHK(hipMalloc(&b.p, want));
+  b.cap = want;
+  return SVDSS_OK;
+}
+
+static int ensure_pin(svdss_bam_batch* b, size_t bytes) {
+  if (bytes <= b->h_pin_cap && b->h_pin) return SVDSS_OK;
+  if (b->h_pin) { (void)hipHostFree(b->h_pin); b->h_pin = nullptr; b->h_pin_cap = 0; }
+  const size_t want = bytes + (bytes >> 2) + 4096;
+  HIPCHK(hipHostMalloc((void**)&b->h_pin, want, hipHostMallocDefault));
+  b->h_pin_cap = want;
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_bam_stream_create(int32_t n_ref, svdss_bam_stream_t** out) {
+  if (!out || n_ref < 0) return SVDSS_EINVAL;
+  svdss_bam_stream* s = new (std::nothrow) svdss_bam_stream();
+  if (!s) return SVDSS_ENOMEM;
+  s->n_ref = n_ref;
+  *out = s;
+  return SVDSS_OK;
+}
+
+extern "C" void svdss_bam_stream_free(svdss_bam_stream_t* s) { delete s; }
+
+extern "C" const char* svdss_bam_stream_error(const svdss_bam_stream_t* s) { return s ? s->err.c_str() : ""; }
+
+extern "C" int64_t svdss_bam_stream_rewalked(const svdss_bam_stream_t* s, int64_t* n_segments) {
+  if (!s) return -1;
+  if (n_segments) *n_segments = s->n_segments;
+  return s->n_rewalked;
+}
+
+extern "C" void svdss_bam_batch_free(svdss_bam_batch_t* b) {
+  if (!b) return;
+  if (b->device >= 0) (void)hipSetDevice(b->device);
+  for (DevBuf* d : {&b->comp, &b->blks, &b->crcb, &b->status, &b->buf, &b->seg, &b->lists, &b->pre, &b->hdr, &b->rpos, &b->flags,
+                    &b->scans, &b->d_hp, &b->tmp, &b->o_small, &b->d_names, &b->sym_off, &b->seq_src, &b->reads, &b->totals})
+    if (d->p) (void)hipFree(d->p);
+  if (b->h_pin) (void)hipHostFree(b->h_pin);
+  if (b->sfs) svdss_sfs_batch_free(b->sfs);
+  if (b->e0) (void)hipEventDestroy(b->e0);
+  if (b->e1) (void)hipEventDestroy(b->e1);
+  if (b->st) (void)hipStreamDestroy(b->st);
+  delete b;
+}
+
+// the turn of batch `seq` at the carry: taken by wait_turn, given up by done_turn (on every path)
+static bool wait_turn(svdss_bam_stream* s, int64_t seq) {
+  std::unique_lock<std::mutex> lk(s->m);
+  s->cv.wait(lk, [&] { return s->next_seq == seq || s->failed; });
+  return !s->failed;
+}
+static void done_turn(svdss_bam_stream* s, int fail_code, const std::string& msg) {
+  {
+    std::lock_guard<std::mutex> lk(s->m);
+    if (fail_code && !s->failed) { s->failed = fail_code; s->err = msg; }
+    ++s->next_seq;
+  }
+  s->cv.notify_all();
+}
+
+extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_index_t* ix,
+                                   int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                                   const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                                   int32_t flags, svdss_bam_batch_t** out) {
+  if (!s || !ix || !out || seq < 0 || skip < 0 || n_chunks < 0) return SVDSS_EINVAL;
+  if (n_chunks > 0 && (!comp || !comp_bytes || !blocks || !crc || !n_blocks)) return SVDSS_EINVAL;
+  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;
+  // a failure before the batch had its turn still has to pass the turn on: the batches behind it wait for it
+  bool had_turn = false;
+  auto fail = [&](int code, const std::string& msg) {
+    if (!had_turn) {
+      if (wait_turn(s, seq)) done_turn(s, code, msg);   // (a stream that already failed has let everybody through)
+      had_turn = true;
+    }
+    if (*out) (*out)->err = msg;
+    return code;
+  };
+#define BCHK(expr)                                                                                    \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      g_svdss_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
+      return fail(e_ == hipErrorOutOfMemory ? SVDSS_ENOMEM : SVDSS_EHIP, g_svdss_hip_err);            \
+    }                                                                                                 \
+  } while (0)
+#define RCHK(expr) do { const int rc_ = (expr); if (rc_ != SVDSS_OK) return fail(rc_, g_svdss_hip_err); } while (0)
+  BCHK(hipSetDevice(ix->device));
+  svdss_bam_batch* b = *out;
+  if (!b) {
+    b = new (std::nothrow) svdss_bam_batch();
+    if (!b) return fail(SVDSS_ENOMEM, "out of memory");
+    b->device = ix->device;
+    *out = b;
+  }
+  if (b->device != ix->device) return fail(SVDSS_EINVAL, "batch object of another device");
+  if (!b->st) BCHK(svdss_make_stream(&b->st, "SVDSS_SEARCH_CUS"));
+  if (!b->e0) { BCHK(hipEventCreate(&b->e0)); BCHK(hipEventCreate(&b->e1)); }
+  const hipStream_t st = b->st;
+  b->n_records = b->n_slots = b->n_searched = b->n_short = b->total_sfs = 0;
+  b->err.clear();
+  static const int64_t HEAD = [] {
+    const char* e = getenv("SVDSS_BAM_HEADROOM_MB");
+    const int64_t mb = e && *e ? atoll(e) : 0;
+    return mb > 0 ? mb << 20 : kHeadDefault;
+  }();
+
+  // ---- the batch's blocks: compressed bytes back to back, inflated bytes back to back behind the head room
+  int64_t total_blocks = 0, total_comp = 0, total_inf = 0;
+  for (int32_t c = 0; c < n_chunks; ++c) {
+    if (comp_bytes[c] < 0 || n_blocks[c] < 0 || (n_blocks[c] > 0 && (!comp[c] || !blocks[c] || !crc[c]))) return fail(SVDSS_EINVAL, "bad chunk");
+    total_blocks += n_blocks[c];
+    total_comp += (comp_bytes[c] + 15) & ~(int64_t)15;
+    for (int64_t i = 0; i < n_blocks[c]; ++i) {
+      const svdss_bgzf_block_t& k = blocks[c][i];
+      if (k.coff < 0 || k.clen < 0 || k.isize < 0 || k.isize > 65536 || k.coff + k.clen > comp_bytes[c]) return fail(SVDSS_EINVAL, "bad block");
+      total_inf += k.isize;
+    }
+  }
+  if (HEAD + total_inf + skip >= ((int64_t)1 << 32) - 65536) return fail(SVDSS_ERANGE, "batch too large");
+  if (skip > total_inf) return fail(SVDSS_EIO, "truncated header");
+  RCHK(ensure(b->comp, (size_t)total_comp + 8192));
+  RCHK(ensure(b->blks, sizeof(svdss_bgzf_block_t) * (size_t)(total_blocks + 1)));
+  RCHK(ensure(b->crcb, sizeof(CrcBlk) * (size_t)(total_blocks + 1)));
+  RCHK(ensure(b->status, sizeof(int32_t) * (size_t)(total_blocks + 2)));
+  RCHK(ensure(b->buf, (size_t)(HEAD + total_inf) + 4096));
+  RCHK(ensure(b->hdr, sizeof(int64_t) * H_N));
+  RCHK(ensure(b->pre, 64));
+  RCHK(ensure(b->totals, 64));
+  const size_t tab_bytes = (sizeof(svdss_bgzf_block_t) + sizeof(CrcBlk)) * (size_t)(total_blocks + 1);
+  RCHK(ensure_pin(b, tab_bytes + 4096));
+  svdss_bgzf_block_t* h_blk = (svdss_bgzf_block_t*)b->h_pin;
+  CrcBlk* h_crc = (CrcBlk*)(b->h_pin + sizeof(svdss_bgzf_block_t) * (size_t)(total_blocks + 1));
+  {
+    int64_t k = 0, coff = 0, uoff = 0;
+    for (int32_t c = 0; c < n_chunks; ++c) {
+      if (comp_bytes[c] > 0) BCHK(hipMemcpyAsync((uint8_t*)b->comp.p + coff, comp[c], (size_t)comp_bytes[c], hipMemcpyHostToDevice, st));
+      for (int64_t i = 0; i < n_blocks[c]; ++i, ++k) {
+        h_blk[k] = blocks[c][i];
+        h_blk[k].coff += coff;
+        h_blk[k].uoff = HEAD + uoff;
+        h_crc[k] = CrcBlk{HEAD + uoff, blocks[c][i].isize, crc[c][i]};
+        uoff += blocks[c][i].isize;
+      }
+      coff += (comp_bytes[c] + 15) & ~(int64_t)15;
+    }
+  }
+  BCHK(hipMemsetAsync(b->status.p, 0, sizeof(int32_t) * (size_t)(total_blocks + 2), st));
+  BCHK(hipMemsetAsync(b->hdr.p, 0, sizeof(int64_t) * H_N, st));
+  int32_t* d_status = (int32_t*)b->status.p;
+  int32_t* d_crcbad = d_status + total_blocks;
+  if (total_blocks > 0) {
+    BCHK(hipMemcpyAsync(b->blks.p, h_blk, sizeof(svdss_bgzf_block_t) * (size_t)total_blocks, hipMemcpyHostToDevice, st));
+    BCHK(hipMemcpyAsync(b->crcb.p, h_crc, sizeof(CrcBlk) * (size_t)total_blocks, hipMemcpyHostToDevice, st));
+    BCHK(hipEventRecord(b->e0, st));
+    BCHK(svdss_inflate_enqueue(st, (const uint8_t*)b->comp.p, (const svdss_bgzf_block_t*)b->blks.p, total_blocks, (uint8_t*)b->buf.p, d_status));
+    BCHK(hipEventRecord(b->e1, st));
+    hipLaunchKernelGGL(crc32_kernel, dim3((unsigned)total_blocks), dim3(64), 0, st, (const uint8_t*)b->buf.p, (const CrcBlk*)b->crcb.p, d_crcbad);
+    BCHK(hipGetLastError());
+  }
+  // ---- the chain of records, guessed per segment (does not need the carry)
+  WalkP W;
+  W.buf = (const uint8_t*)b->buf.p;
+  W.lo = HEAD + (seq == 0 ? skip : 0);
+  W.hi = HEAD + total_inf;
+  W.n_ref = s->n_ref;
+  {
+    int64_t seg_target = (int64_t)256 << 10;
+    if (const char* e = getenv("SVDSS_BAM_SEG_KB")) if (atoll(e) > 0) seg_target = atoll(e) << 10;
+    const int64_t fresh = W.hi - W.lo;
+    int64_t n_seg = (fresh + seg_target - 1) / seg_target;
+    n_seg = std::max<int64_t>(1, std::min<int64_t>(kMaxSeg, n_seg));
+    W.n_seg = (int32_t)n_seg;
+    W.seg_bytes = std::max<int64_t>(64, ((fresh + n_seg - 1) / n_seg + 63) & ~(int64_t)63);
+    W.list_cap = W.seg_bytes / kMinRec + 4;
+  }
+  RCHK(ensure(b->seg, (size_t)W.n_seg * 16 + 64));
+  RCHK(ensure(b->lists, (size_t)W.n_seg * (size_t)W.list_cap * sizeof(uint32_t)));
+  W.seg_start = (uint32_t*)b->seg.p;
+  W.seg_end = W.seg_start + W.n_seg;
+  W.seg_cnt = (int32_t*)(W.seg_end + W.n_seg);
+  int32_t* seg_base = W.seg_cnt + W.n_seg;
+  W.lists = (uint32_t*)b->lists.p;
+  hipLaunchKernelGGL(walk_kernel, dim3((unsigned)W.n_seg), dim3(64), 0, st, W);
+  BCHK(hipGetLastError());
+  b->h_status.resize((size_t)total_blocks + 2);
+  BCHK(hipMemcpyAsync(b->h_status.data(), d_status, sizeof(int32_t) * (size_t)(total_blocks + 2), hipMemcpyDeviceToHost, st));
+  BCHK(hipStreamSynchronize(st));
+  if (total_blocks > 0) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->e0, b->e1) == hipSuccess) b->inflate_ms = ms;
+  }
+  for (int64_t i = 0; i < total_blocks; ++i)
+    if (b->h_status[(size_t)i] != 0) return fail(SVDSS_EIO, "BGZF inflate failed");
+  if (b->h_status[(size_t)total_blocks] != 0) return fail(SVDSS_EIO, "BGZF block CRC mismatch");
+
+  // ---- this batch's turn: carry in, the chain proved and completed, carry out
+  if (!wait_turn(s, seq)) { had_turn = true; return fail(s->failed, s->err); }
+  had_turn = true;
+  int turn_code = SVDSS_OK;
+  std::string turn_msg;
+  int64_t hdr[H_N] = {0};
+  {
+    const int64_t carry_len = (int64_t)s->carry.size();
+    auto turn_fail = [&](int code, const std::string& msg) { turn_code = code; turn_msg = msg; };
+    hipError_t e = hipSuccess;
+    if (carry_len > HEAD) turn_fail(SVDSS_ERANGE, "a record larger than the head room (SVDSS_BAM_HEADROOM_MB)");
+    if (!turn_code && carry_len > 0)
+      e = hipMemcpyAsync((uint8_t*)b->buf.p + (HEAD - carry_len), s->carry.data(), (size_t)carry_len, hipMemcpyHostToDevice, st);
+    if (!turn_code && e == hipSuccess) {
+      const int64_t start = seq == 0 ? W.lo : HEAD - carry_len;
+      hipLaunchKernelGGL(link_kernel, dim3(1), dim3(64), 0, st, W, start, (uint32_t*)b->pre.p, seg_base, (int64_t*)b->hdr.p);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(hdr, b->hdr.p, sizeof hdr, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e == hipSuccess) {
+        if (hdr[H_ERR] & E_CORRUPT) turn_fail(SVDSS_EIO, "truncated record");   // (a block_size below 32: BamReader says the same)
+        else {
+          const int64_t tail = hdr[H_TAIL], tail_len = W.hi - tail;
+          try { s->carry.resize((size_t)tail_len); } catch (...) { turn_fail(SVDSS_ENOMEM, "out of memory"); }
+          if (!turn_code && tail_len > 0) {
+            e = hipMemcpyAsync(s->carry.data(), (const uint8_t*)b->buf.p + tail, (size_t)tail_len, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+          }
+          if (!turn_code && is_last && tail_len > 0) turn_fail(SVDSS_EIO, "truncated record");
+          s->n_rewalked += hdr[H_REWALK];
+          s->n_segments += W.n_seg;
+        }
+      }
+    }
+    if (e != hipSuccess && !turn_code) {
+      g_svdss_hip_err = std::string("bam batch turn: ") + hipGetErrorString(e);
+      turn_fail(e == hipErrorOutOfMemory ? SVDSS_ENOMEM : SVDSS_EHIP, g_svdss_hip_err);
+    }
+  }
+  done_turn(s, turn_code, turn_msg);
+  if (turn_code) { b->err = turn_msg; return turn_code; }
+
+  // ---- fields, filters, tags; where everything goes
+  const int64_t n_rec = hdr[H_NREC];
+  b->n_records = n_rec;
+  RCHK(ensure(b->rpos, sizeof(uint32_t) * (size_t)(n_rec + 1)));
+  RCHK(ensure(b->flags, sizeof(int64_t) * 4 * (size_t)(n_rec + 1)));
+  RCHK(ensure(b->scans, sizeof(int64_t) * 4 * (size_t)(n_rec + 1)));
+  RCHK(ensure(b->d_hp, sizeof(int32_t) * (size_t)(n_rec + 1)));
+  MetaP M;
+  M.buf = W.buf; M.lists = W.lists; M.list_cap = W.list_cap; M.seg_cnt = W.seg_cnt; M.seg_base = seg_base; M.pre = (const uint32_t*)b->pre.p;
+  M.n_seg = W.n_seg; M.putative = (flags & SVDSS_BAM_PUTATIVE) ? 1 : 0; M.n_rec = n_rec;
+  M.rpos = (uint32_t*)b->rpos.p;
+  M.f_pass = (int64_t*)b->flags.p; M.f_srch = M.f_pass + (n_rec + 1); M.f_name = M.f_srch + (n_rec + 1); M.f_sym = M.f_name + (n_rec + 1);
+  M.hp = (int32_t*)b->d_hp.p; M.hdr = (int64_t*)b->hdr.p;
+  hipLaunchKernelGGL(meta_kernel, dim3((unsigned)W.n_seg + 1), dim3(64), 0, st, M);
+  BCHK(hipGetLastError());
+  int64_t* sc = (int64_t*)b->scans.p;
+  {
+    size_t tb = 0;
+    BCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, M.f_pass, sc, (int)(n_rec + 1), st));
+    RCHK(ensure(b->tmp, tb + 256));
+    for (int k = 0; k < 4; ++k) {
+      size_t t2 = b->tmp.cap;
+      BCHK(hipcub::DeviceScan::ExclusiveSum(b->tmp.p, t2, M.f_pass + (int64_t)k * (n_rec + 1), sc + (int64_t)k * (n_rec + 1), (int)(n_rec + 1), st));
+    }
+  }
+  // (sizes of the outputs are not known yet: bounded by the records / the inflated bytes)
+  RCHK(ensure(b->o_small, sizeof(int32_t) * 3 * (size_t)(n_rec + 2)));
+  RCHK(ensure(b->d_names, (size_t)n_rec * 255 + 64 < (size_t)total_inf + (size_t)HEAD ? (size_t)n_rec * 255 + 64 : (size_t)total_inf + (size_t)HEAD + 64));
+  RCHK(ensure(b->sym_off, sizeof(int64_t) * (size_t)(n_rec + 2)));
+  RCHK(ensure(b->seq_src, sizeof(int64_t) * (size_t)(n_rec + 2)));
+  ScatP S;
+  S.buf = W.buf; S.n_rec = n_rec; S.rpos = M.rpos; S.f_pass = M.f_pass; S.f_srch = M.f_srch;
+  S.s_pass = sc; S.s_srch = sc + (n_rec + 1); S.s_name = sc + 2 * (n_rec + 1); S.s_sym = sc + 3 * (n_rec + 1);
+  S.hp = M.hp;
+  S.o_name_off = (int32_t*)b->o_small.p; S.o_hp = S.o_name_off + (n_rec + 2); S.o_sidx = S.o_hp + (n_rec + 2);
+  S.o_names = (char*)b->d_names.p; S.sym_off = (int64_t*)b->sym_off.p; S.seq_src = (int64_t*)b->seq_src.p;
+  S.totals = (int64_t*)b->totals.p;
+  hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((n_rec + 1 + 255) / 256)), dim3(256), 0, st, S);
+  BCHK(hipGetLastError());
+  int64_t totals[4] = {0, 0, 0, 0}, hdr2[H_N] = {0};
+  BCHK(hipMemcpyAsync(totals, b->totals.p, sizeof totals, hipMemcpyDeviceToHost, st));
+  BCHK(hipMemcpyAsync(hdr2, b->hdr.p, sizeof hdr2, hipMemcpyDeviceToHost, st));
+  BCHK(hipStreamSynchronize(st));
+  if (hdr2[H_ERR] & E_CORRUPT) return fail(SVDSS_EIO, "corrupt record");
+  if (hdr2[H_ERR] & E_TID) return fail(SVDSS_EIO, "core.tid < 0. Why are we here? Please check");
+  const int64_t n_slots = totals[0], n_srch = totals[1], name_bytes = totals[2], total_syms = totals[3];
+  b->n_slots = n_slots; b->n_searched = n_srch; b->n_short = hdr2[H_SHORT];
+  if (total_syms >= ((int64_t)1 << 40)) return fail(SVDSS_ERANGE, "batch too large");
+
+  // ---- bases, search
+  const size_t padded = (size_t)((total_syms + 15) & ~(int64_t)15) + 16;
+  RCHK(ensure(b->reads, padded + 16));
+  if (n_srch > 0) {
+    BCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded - 32), 0, 32, st));
+    // (the longest read decides the grid's width: the scan's inputs hold the lengths, the host does not -- bounded by
+    // the largest record of the batch, i.e. by the batch itself; a second pass over the symbol offsets would cost more)
+    int64_t max_len = 0;
+    {
+      // longest searched read = max over k of sym_off[k + 1] - sym_off[k]: one small reduction
+      size_t tb = 0;
+      hipcub::CountingInputIterator<int64_t> cnt(0);
+      hipcub::TransformInputIterator<int64_t, OffDiff, hipcub::CountingInputIterator<int64_t>> it(cnt, OffDiff{S.sym_off});
+      int64_t* d_max = (int64_t*)b->totals.p + 4;
+      BCHK(hipcub::DeviceReduce::Max(nullptr, tb, it, d_max, (int)n_srch, st));
+      RCHK(ensure(b->tmp, tb + 256));
+      tb = b->tmp.cap;
+      BCHK(hipcub::DeviceReduce::Max(b->tmp.p, tb, it, d_max, (int)n_srch, st));
+      BCHK(hipMemcpyAsync(&max_len, d_max, sizeof max_len, hipMemcpyDeviceToHost, st));
+      BCHK(hipStreamSynchronize(st));
+    }
+    if (max_len >= (int64_t)0x7fffffff) return fail(SVDSS_ERANGE, "read too long");
+    if (max_len > 0) {
+      const unsigned gx = (unsigned)((max_len + 15 + 256 * 16 - 1) / (256 * 16) + 1);
+      for (int64_t y0 = 0; y0 < n_srch; y0 += 65535) {
+        const unsigned gy = (unsigned)std::min<int64_t>(65535, n_srch - y0);
+        hipLaunchKernelGGL(unpack_kernel, dim3(gx, gy), dim3(256), 0, st, W.buf, (const int64_t*)S.seq_src, (const int64_t*)S.sym_off, y0, n_srch,
+                           (uint8_t*)b->reads.p);
+      }
+      BCHK(hipGetLastError());
+    }
+  }
+  {
+    const int rc = svdss_sfs_search_batch_device(ix, (const uint8_t*)b->reads.p, (const int64_t*)S.sym_off, n_srch, total_syms,
+                                                 (flags & SVDSS_SFS_ASSEMBLE), (void*)st, &b->sfs);
+    if (rc != SVDSS_OK) return fail(rc, std::string("search: ") + svdss_last_hip_error());
+  }
+  // ---- what the host needs: names and tags of the slots, counts and SFS of the searched reads
+  b->total_sfs = svdss_sfs_batch_total(b->sfs);
+  try {
+    b->name_off.resize((size_t)n_slots + 1); b->hp.resize((size_t)n_slots); b->sidx.resize((size_t)n_slots);
+    b->names.resize((size_t)name_bytes + 1); b->counts.resize((size_t)n_srch); b->qs.resize((size_t)b->total_sfs); b->len.resize((size_t)b->total_sfs);
+  } catch (...) { return fail(SVDSS_ENOMEM, "out of memory"); }
+  BCHK(hipMemcpyAsync(b->name_off.data(), S.o_name_off, sizeof(int32_t) * (size_t)(n_slots + 1), hipMemcpyDeviceToHost, st));
+  if (n_slots > 0) {
+    BCHK(hipMemcpyAsync(b->hp.data(), S.o_hp, sizeof(int32_t) * (size_t)n_slots, hipMemcpyDeviceToHost, st));
+    BCHK(hipMemcpyAsync(b->sidx.data(), S.o_sidx, sizeof(int32_t) * (size_t)n_slots, hipMemcpyDeviceToHost, st));
+  }
+  if (name_bytes > 0) BCHK(hipMemcpyAsync(b->names.data(), S.o_names, (size_t)name_bytes, hipMemcpyDeviceToHost, st));
+  if (n_srch > 0) {
+    void *d_counts = nullptr, *d_qs = nullptr, *d_len = nullptr;
+    RCHK(svdss_sfs_batch_device_ptrs(b->sfs, &d_counts, &d_qs, &d_len, nullptr));
+    BCHK(hipMemcpyAsync(b->counts.data(), d_counts, sizeof(int64_t) * (size_t)n_srch, hipMemcpyDeviceToHost, st));
+    if (b->total_sfs > 0) {
+      BCHK(hipMemcpyAsync(b->qs.data(), d_qs, sizeof(int32_t) * (size_t)b->total_sfs, hipMemcpyDeviceToHost, st));
+      BCHK(hipMemcpyAsync(b->len.data(), d_len, sizeof(int32_t) * (size_t)b->total_sfs, hipMemcpyDeviceToHost, st));
+    }
+  }
+  BCHK(hipStreamSynchronize(st));
+  return SVDSS_OK;
+#undef BCHK
+#undef RCHK
+}
+
+extern "C" int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_result_t* r) {
+  if (!b || !r) return SVDSS_EINVAL;
+  r->n_records = b->n_records; r->n_slots = b->n_slots; r->n_searched = b->n_searched; r->n_short = b->n_short;
+  r->total_sfs = b->total_sfs;
+  r->name_off = b->name_off.data(); r->names = b->names.data(); r->hp = b->hp.data(); r->sidx = b->sidx.data();
+  r->counts = b->counts.data(); r->qs = b->qs.data(); r->len = b->len.data();
+  r->inflate_kernel_ms = b->inflate_ms;
+  return SVDSS_OK;
+}
+
+extern "C" const char* svdss_bam_batch_error(const svdss_bam_batch_t* b) { return b ? b->err.c_str() : ""; }

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/svdss_hip.h"
+#include "inflate_dev.h"
 
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 
@@ -511,6 +512,13 @@ struct DevBuf {
 };
 
 }  // namespace
+
+hipError_t svdss_inflate_enqueue(hipStream_t st, const uint8_t* d_comp, const svdss_bgzf_block_t* d_blocks, int64_t n_blocks,
+                                 uint8_t* d_out, int32_t* d_status) {
+  if (n_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, d_comp, d_blocks, d_out, d_status);
+  return hipGetLastError();
+}
 
 struct svdss_inflate {
   int device = -1;

@@ -188,8 +188,14 @@ __device__ unsigned long long g_poaw_rows[16];  // rows by type (developer build
 #define PROF_T() (prof_t = wall_clock64())
 #define PROF_ADD(k) do { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - prof_t; prof_t = t_; } while (0)
 
+// POA_MIN_WAVES (developer builds, `make poaocc W=5`): wavefronts per SIMD the register allocation is asked to leave room for
+#ifdef POA_MIN_WAVES
+#define POA_BOUNDS __launch_bounds__(64, POA_MIN_WAVES)
+#else
+#define POA_BOUNDS __launch_bounds__(64)
+#endif
 template <int C>
-__global__ void __launch_bounds__(64) poa_wave_kernel(const PoaWaveTask* tasks, const uint8_t* seqs, const int64_t* seq_off,
+__global__ void POA_BOUNDS poa_wave_kernel(const PoaWaveTask* tasks, const uint8_t* seqs, const int64_t* seq_off,
                                                      int32_t* ws32, uint8_t* ws8, int32_t* cons_len, int32_t* status,
                                                      unsigned long long* cells) {
   extern __shared__ __align__(16) unsigned char smem[];

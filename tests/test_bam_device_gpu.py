@@ -1,0 +1,218 @@
+"""svdss_bam_batch_run (csrc/bam_device.hip): compressed BGZF blocks in, names / tags / SFS out, with the record chain,
+the filters of ping_pong.cpp:66-79, the XF / HP lookup of :196-203 and the 4-bit -> nt6 expansion of :90-94 on the GPU.
+Checked against the records as the test wrote them and the oracle's search of the same reads; batch sizes and segment
+sizes are forced small so that records straddle blocks, segments and batches, and the segment guesses go wrong."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import svdss_amd
+from svdss_amd import bamdev, bgzf, synth
+from svdss_amd._lib import SvdssError
+from tests import bam_writer, oracle_lib as O
+from tests.common import small_workload
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(names, reads, rng, decoys=False):
+    """records with every filter / tag shape; returns (record bytes list, expected slots [(name, hp, searched, read)])"""
+    recs, slots = [], []
+    for i, (nm, rd) in enumerate(zip(names, reads)):
+        flag = 0
+        if i % 11 == 3:
+            flag = 256
+        if i % 13 == 5:
+            flag = 2048
+        if i % 17 == 9:
+            flag = 4
+        if i % 19 == 2:
+            flag = 16          # reverse strand: kept
+        xf = 1 if i % 5 == 0 else 0
+        hp = i % 3
+        tags = [("NM", "i", 3)]
+        if i % 2:
+            tags.append(("XF", "C", xf))
+        elif xf:
+            tags.append(("XF", "i", xf))
+        if i % 7 == 1:
+            tags.append(("MD", "Z", "12A" * (i % 40)))
+        if hp:
+            tags.append(("HP", ["s", "c", "I"][i % 3], hp))
+        tags.append(("RG", "Z", "grp"))
+        qual = None
+        if decoys and i % 4 == 0:
+            # qualities that look like a chain of records (block_size, refID, pos, l_read_name ...): the segment guesser
+            # may take them for one; the link step must not
+            def mini(l_seq, name):
+                body = struct.pack("<iiBBHHHiiii", 0, 5, len(name), 60, 4680, 0, 0, l_seq, -1, -1, 0) + name + b"\x11" * ((l_seq + 1) // 2) + b"\x20" * l_seq
+                return struct.pack("<i", len(body)) + body
+            fake = mini(8, b"abc\0") + mini(0, b"de\0") + mini(2, b"f\0")
+            q = bytearray(rng.integers(20, 60, size=len(rd), dtype=np.uint8).tobytes())
+            for at in range(10, len(q) - len(fake), 700):
+                q[at:at + len(fake)] = fake
+            qual = bytes(q)
+        recs.append(bam_writer.record(nm, flag, 0, 100 + i, 60, [("M", len(rd))], synth.to_ascii(rd), tags, qual=qual))
+        if flag in (0, 16) and len(rd) >= 100:
+            slots.append((nm, hp, xf == 0, rd))
+    return recs, slots
+
+
+def _bgzf_levels(data, rng, block=60000):
+    """BGZF members of varying size and zlib level (stored blocks included)"""
+    out, i = [], 0
+    while i < len(data):
+        n = int(rng.integers(1, block))
+        piece = data[i:i + n]
+        i += n
+        comp = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, -15)
+        c = comp.compress(piece) + comp.flush()
+        out.append(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(c) + 25) + c +
+                   struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+        if rng.random() < 0.05:
+            out.append(bam_writer._bgzf_block(b""))      # empty members in the middle of the file are legal
+    out.append(bam_writer._bgzf_block(b""))
+    return b"".join(out)
+
+
+def _raw_bam(refs, recs):
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
+    for n, l in refs:
+        hdr += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    return hdr + b"".join(recs)
+
+
+@pytest.fixture(scope="module")
+def case():
+    ref, hap, svs, flat, offs = small_workload(seed=91, n_reads=400, read_len=1500, ref_lens=(150000,))
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    reads = [flat[offs[i]:offs[i + 1]].copy() for i in range(400)]
+    reads[7][40] = 5
+    reads[11] = reads[11][:99]          # l_qseq < 100: dropped, counted
+    reads[12] = reads[12][:100]         # kept
+    reads[13] = reads[13][:101]         # odd length: the last nibble
+    reads[14] = np.concatenate([reads[14], reads[15], reads[16], reads[17]])   # a record larger than a BGZF block's share
+    names = [f"m64/{(i * 37) % 400}/ccs" for i in range(400)]
+    names[21] = "x"
+    return ref, ix, fm, reads, names
+
+
+def _check(out, slots, fm, assemble, putative):
+    assert [(o[0], o[1]) for o in out] == [(s[0], s[1]) for s in slots]
+    for (nm, hp, sfs), (_, _, srch, rd) in zip(out, slots):
+        if putative and not srch:
+            assert sfs is None
+            continue
+        raw, _ = fm.ping_pong_search(rd)
+        exp = O.assemble(raw) if assemble else raw
+        assert sfs == [tuple(x) for x in exp], nm
+
+
+@pytest.mark.parametrize("assemble,putative", [(True, True), (False, False)])
+def test_whole_file_in_one_batch(case, assemble, putative):
+    ref, ix, fm, reads, names = case
+    rng = np.random.default_rng(5)
+    recs, slots = _records(names, reads, rng)
+    data = bam_writer.bam([("chr1", 150000)], recs)
+    out, st = bamdev.search_bam(ix, data, assemble=assemble, putative=putative)
+    assert st["records"] == len(recs) and st["short"] == 1
+    _check(out, slots, fm, assemble, putative)
+
+
+@pytest.mark.parametrize("batch_kb,seg_kb", [(64, 1), (200, 4), (1000, 16), (5, 1)])
+def test_records_straddle_blocks_segments_and_batches(case, batch_kb, seg_kb, monkeypatch):
+    ref, ix, fm, reads, names = case
+    rng = np.random.default_rng(batch_kb)
+    recs, slots = _records(names, reads, rng, decoys=True)
+    data = _bgzf_levels(_raw_bam([("chr1", 150000)], recs), rng, block=20000)
+    monkeypatch.setenv("SVDSS_BAM_SEG_KB", str(seg_kb))
+    out, st = bamdev.search_bam(ix, data, assemble=True, putative=True, batch_bytes=batch_kb << 10)
+    assert st["records"] == len(recs) and st["short"] == 1 and (st["batches"] > 3 or batch_kb >= 1000)
+    _check(out, slots, fm, True, True)
+    # most guesses hold; the decoys and the long record make some fail, and the result does not care
+    assert st["segments"] > st["batches"] and st["rewalked"] < st["segments"]
+
+
+def test_header_only_and_empty_inputs(case):
+    ref, ix, fm, reads, names = case
+    out, st = bamdev.search_bam(ix, bam_writer.bam([("chr1", 150000)], []))
+    assert out == [] and st["records"] == 0
+    rec = bam_writer.record("only", 0, 0, 5, 60, [("M", len(reads[0]))], synth.to_ascii(reads[0]))
+    out, st = bamdev.search_bam(ix, bam_writer.bam([("chr1", 150000), ("chr2", 5)], [rec]), batch_bytes=1 << 10)
+    raw, _ = fm.ping_pong_search(reads[0])
+    assert [(o[0], o[1], o[2]) for o in out] == [("only", 0, [tuple(x) for x in O.assemble(raw)])]
+
+
+def test_damage_is_reported(case):
+    ref, ix, fm, reads, names = case
+    rng = np.random.default_rng(3)
+    recs, _ = _records(names[:40], reads[:40], rng)
+    raw = _raw_bam([("chr1", 150000)], recs)
+    good = bam_writer.bgzf(raw, block=30000)
+    # a flipped bit inside a deflate stream: inflate or CRC must say so
+    blocks = bgzf.bgzf_blocks(good)
+    bad = bytearray(good)
+    coff, clen, isize, crc = blocks[len(blocks) // 2]
+    bad[coff + clen // 2] ^= 0x10
+    with pytest.raises(SvdssError) as e:
+        bamdev.search_bam(ix, bytes(bad))
+    assert e.value.detail in ("BGZF inflate failed", "BGZF block CRC mismatch")
+    # a wrong CRC in a footer
+    coff, clen, isize, crc = blocks[1]
+    bad = bytearray(good)
+    bad[coff + clen:coff + clen + 4] = struct.pack("<I", crc ^ 1)
+    with pytest.raises(SvdssError) as e:
+        bamdev.search_bam(ix, bytes(bad))
+    assert e.value.detail == "BGZF block CRC mismatch"
+    # the file ends inside a record
+    cut = bam_writer.bgzf(raw[:-37], block=30000)
+    with pytest.raises(SvdssError) as e:
+        bamdev.search_bam(ix, cut, batch_bytes=20 << 10)
+    assert e.value.detail == "truncated record"
+    # a mapped read without a reference (ping_pong.cpp:76-79)
+    recs2 = list(recs)
+    recs2[5] = bam_writer.record("notid", 0, -1, 5, 60, [("M", len(reads[5]))], synth.to_ascii(reads[5]))
+    with pytest.raises(SvdssError) as e:
+        bamdev.search_bam(ix, bam_writer.bam([("chr1", 150000)], recs2))
+    assert "core.tid < 0" in e.value.detail
+    # l_seq that does not fit its record
+    r6 = bytearray(recs[6])
+    r6[4 + 16:4 + 20] = struct.pack("<i", 10_000_000)
+    recs3 = list(recs)
+    recs3[6] = bytes(r6)
+    with pytest.raises(SvdssError) as e:
+        bamdev.search_bam(ix, bam_writer.bam([("chr1", 150000)], recs3))
+    assert e.value.detail == "corrupt record"
+
+
+def test_crc32_kernel_on_every_block_size(case):
+    """the footer check alone: members of 1 .. 65536 bytes, unaligned starts (a CRC mismatch would raise)"""
+    ref, ix, fm, reads, names = case
+    rng = np.random.default_rng(11)
+    body = _raw_bam([("chr1", 150000)], [])
+    filler = bytes(rng.integers(0, 4, size=70000, dtype=np.uint8) * 67 + 1)   # (compressible: a member of 65,536 bytes must fit 64 KB)
+    # one big unmapped record per size class so that the chain stays valid whatever the member sizes are
+    recs = []
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 4095, 4097, 65535 - 40, 65536 - 40):
+        q = filler[:n]
+        recs.append(bam_writer.record("f%d" % n, 4, -1, -1, 0, [], "", qual=None) + b"")
+        core = struct.pack("<iiBBHHHiiii", -1, -1, 2, 0, 4680, 0, 4, 0, -1, -1, 0) + b"f\0" + b"ZZZ" + q + b"\0"
+        recs.append(struct.pack("<i", len(core)) + core)
+    data = body + b"".join(recs)
+    out = []
+    i = 0
+    sizes = [1, 2, 3, 4, 5, 7, 63, 64, 65, 100, 255, 256, 257, 1000, 1023, 1024, 1025, 4095, 4096, 4097, 30000, 65535, 65536]
+    k = 0
+    while i < len(data):
+        n = sizes[k % len(sizes)]
+        k += 1
+        out.append(bam_writer._bgzf_block(data[i:i + n]))
+        i += n
+    out.append(bam_writer._bgzf_block(b""))
+    res, st = bamdev.search_bam(ix, b"".join(out))
+    assert res == [] and st["records"] == len(recs)

@@ -28,16 +28,16 @@ __global__ void __launch_bounds__(64) spin(int iters, uint32_t* out) {
 }
 
 template <int KIND>
-static void run(const char* what, int instr_per_iter, int n_simd, uint32_t* out) {
+static void run(const char* what, int instr_per_iter, int n_simd, uint32_t* out, int threads = 64) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   int clock_khz = 0;
   hipDeviceGetAttribute(&clock_khz, hipDeviceAttributeClockRate, 0);
   for (int per_simd : {1, 2, 4, 8}) {
     const int blocks = n_simd * per_simd, iters = 20000;
-    spin<KIND><<<blocks, 64>>>(100, out);
+    spin<KIND><<<blocks, threads>>>(100, out);
     hipEventRecord(e0);
-    spin<KIND><<<blocks, 64>>>(iters, out);
+    spin<KIND><<<blocks, threads>>>(iters, out);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -62,5 +62,10 @@ int main() {
   run<1>("dependent s_add_u32", 64, n_simd, out);
   run<4>("two independent s_add_u32 chains", 128, n_simd, out);
   run<2>("v_add_u32 / s_add_u32 alternating", 128, n_simd, out);
+  // round 4: does a wavefront whose upper 32 lanes are switched off (workgroup of 32 threads) issue its vector
+  // instructions in half the time?  (POA rows are 15-40 lanes wide)
+  run<0>("dependent v_add_u32, 32 lanes on", 64, n_simd, out, 32);
+  run<3>("four independent chains, 32 lanes", 64, n_simd, out, 32);
+  run<0>("dependent v_add_u32, 16 lanes on", 64, n_simd, out, 16);
   return 0;
 }
