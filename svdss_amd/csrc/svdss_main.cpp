@@ -34,6 +34,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
+#include "bgzf_scanner.h"
 #include "gpu_inflate_hook.h"
 #include "cli_options.h"
 #include "call_host.h"
@@ -279,6 +280,348 @@ class BoundedQueue {
 
 static time_t g_t0 = 0;   // process start (the final log line)
 
+// the text of one batch.  output_batch order: reference batches of bsize reads -> thread t takes reads n with
+// n % T == t (ping_pong.cpp:59,101-104) -> std::map<qname, vector<SFS>> order (:217)
+static void format_batch(const Options& o, SearchBatch& b) {
+  const std::vector<Read>& reads = b.reads;
+  std::string& out = b.text;
+  out.reserve(b.qs.size() * 24 + 1024);
+  char num[64];
+  for (size_t b0 = 0; b0 < reads.size(); b0 += (size_t)o.bsize) {
+    const size_t b1 = std::min(reads.size(), b0 + (size_t)o.bsize);
+    for (int t = 0; t < o.threads; ++t) {
+      std::map<std::string, std::vector<size_t>> by_name;
+      for (size_t n = b0 + (size_t)t; n < b1; n += (size_t)o.threads)
+        if (reads[n].count >= 0) by_name[reads[n].name].push_back(n);
+      for (const auto& kv : by_name) {
+        bool first = true;
+        for (size_t n : kv.second) {
+          const Read& r = reads[n];
+          for (int64_t k = 0; k < r.count; ++k) {
+            if (first) out += r.name; else out += '*';
+            char* w = num;                      // "\t<qs>\t<len>\t<hp>\t\n" without printf (11 M lines per GB of reads)
+            *w++ = '\t'; w = put_int(w, b.qs[(size_t)(r.first + k)]);
+            *w++ = '\t'; w = put_int(w, b.ln[(size_t)(r.first + k)]);
+            *w++ = '\t'; w = put_int(w, r.hp);
+            *w++ = '\t'; *w++ = '\n';
+            out.append(num, (size_t)(w - num));
+            first = false;
+            ++b.n_lines;
+          }
+        }
+      }
+    }
+  }
+}
+
+// The BAM header read on the host (the first BGZF members, zlib / libdeflate): number of reference sequences and the
+// length of the header in the inflated stream -- where the first record begins (sam_hdr_read, ping_pong.cpp:248).
+static bool bam_header_probe(const std::string& path, int32_t& n_ref, int64_t& skip, std::string& err) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { err = "cannot open file"; return false; }
+  std::vector<uint8_t> comp, buf;
+  size_t pos = 0;
+  bool eof = false;
+  BgzfInflater inf;
+  auto more = [&]() -> bool {        // one more member inflated onto buf
+    for (;;) {
+      if (pos + 18 <= comp.size()) {
+        const uint8_t* h = comp.data() + pos;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BAM file"; return false; }
+        uint16_t xlen;
+        memcpy(&xlen, h + 10, 2);
+        int bsize = -1;
+        if (pos + 12 + xlen <= comp.size()) {
+          for (size_t o = 0; o + 4 <= xlen;) {
+            const uint8_t* x = h + 12 + o;
+            uint16_t slen;
+            memcpy(&slen, x + 2, 2);
+            if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) { uint16_t v; memcpy(&v, x + 4, 2); bsize = v; break; }
+            o += 4u + slen;
+          }
+          if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) { err = "BGZF block without BC field"; return false; }
+          if (pos + (size_t)bsize + 1 <= comp.size()) {
+            const size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
+            uint32_t crc, isize;
+            memcpy(&crc, h + 12 + xlen + clen, 4);
+            memcpy(&isize, h + 12 + xlen + clen + 4, 4);
+            if (isize > 65536u) { err = "bad BGZF block"; return false; }
+            const size_t at = buf.size();
+            buf.resize(at + isize);
+            if (isize) if (const char* e = inf.run(h + 12 + xlen, clen, buf.data() + at, isize, crc)) { err = e; return false; }
+            pos += (size_t)bsize + 1;
+            return true;
+          }
+        }
+      }
+      if (eof) { err = "truncated header"; return false; }
+      const size_t at = comp.size();
+      comp.resize(at + ((size_t)256 << 10));
+      const size_t got = fread(comp.data() + at, 1, (size_t)256 << 10, f);
+      comp.resize(at + got);
+      if (got == 0) eof = true;
+    }
+  };
+  auto need = [&](size_t n) -> bool { while (buf.size() < n) if (!more()) return false; return true; };
+  bool ok = false;
+  do {
+    if (!need(12)) break;
+    if (memcmp(buf.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; break; }
+    int32_t l_text;
+    memcpy(&l_text, buf.data() + 4, 4);
+    if (l_text < 0) { err = "corrupt header"; break; }
+    if (!need(12 + (size_t)l_text)) break;
+    memcpy(&n_ref, buf.data() + 8 + l_text, 4);
+    if (n_ref < 0) { err = "corrupt header"; break; }
+    size_t o = 12 + (size_t)l_text;
+    bool bad = false;
+    for (int32_t i = 0; i < n_ref && !bad; ++i) {
+      if (!need(o + 4)) { bad = true; break; }
+      int32_t l_name;
+      memcpy(&l_name, buf.data() + o, 4);
+      if (l_name < 0) { err = "corrupt header"; bad = true; break; }
+      o += 4 + (size_t)l_name + 4;
+      if (!need(o)) bad = true;
+    }
+    if (bad) break;
+    skip = (int64_t)o;
+    ok = true;
+  } while (false);
+  fclose(f);
+  return ok;
+}
+
+// ---- `search --bam` with the records handled where they are inflated (csrc/bam_device.hip): the host reads the file,
+// finds the BGZF members, hands runs of them to the GPUs and gets names, tags and SFS back.  Stages: scanner (loader
+// threads) -> batcher -> feeding threads (svdss_bam_batch_run, one batch object each) -> assembler (device batches end
+// where a BGZF member ends; the text is defined on batches of --bsize reads, ping_pong.cpp:213-236: the reads are dealt
+// again into units of whole reference batches) -> formatting threads -> writer.  The same bytes as the host path.
+static void search_bam_device(const Options& o, const std::vector<svdss_index_t*>& replicas, BgzfScanner& sc, int32_t n_ref,
+                              int64_t skip, const std::function<std::string()>& since) {
+  svdss_bam_stream_t* stream = nullptr;
+  check(svdss_bam_stream_create(n_ref, &stream), "svdss_bam_stream_create");
+  const int64_t super = std::max<int64_t>(o.bsize, 32768 / o.bsize * (int64_t)o.bsize);
+  const int64_t target = (getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 256) << 20;
+  struct DevJob { uint64_t seq = 0; bool last = false; std::vector<std::unique_ptr<CompChunk>> chunks; };
+  struct DevOut { std::vector<Read> reads; std::vector<int32_t> qs, ln; };
+  BoundedQueue<DevJob> jobs(2);
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  std::mutex t_m;
+  double t_gpu = 0, t_inflate_ms = 0, t_build = 0, t_format = 0, t_write = 0, t_assemble = 0;
+  uint64_t n_seen = 0, n_batches = 0, total_sfs = 0;
+
+  std::thread batcher([&] {
+    std::unique_ptr<DevJob> cur(new DevJob);
+    int64_t acc = 0;
+    uint64_t seq = 0;
+    bool any_last = false;
+    while (std::unique_ptr<CompChunk> c = sc.next()) {
+      acc += c->inflated;
+      const bool last = c->last;
+      cur->chunks.push_back(std::move(c));
+      if (acc >= target || last) {
+        cur->seq = seq++;
+        cur->last = last;
+        any_last = any_last || last;
+        jobs.push(std::move(cur));
+        cur.reset(new DevJob);
+        acc = 0;
+      }
+    }
+    if (!sc.error().empty()) die("error reading " + o.bam + ": " + sc.error());
+    if (!any_last) {            // (cannot happen with a readable file: the scanner marks the final slab)
+      cur->seq = seq++;
+      cur->last = true;
+      jobs.push(std::move(cur));
+    }
+    jobs.close();
+  });
+
+  // device batches in file order
+  std::mutex dev_m;
+  std::condition_variable dev_cv;
+  std::map<uint64_t, std::unique_ptr<DevOut>> dev_done;
+  bool feeders_finished = false;
+  const int32_t flags = (o.assemble ? SVDSS_SFS_ASSEMBLE : 0) | (o.putative ? SVDSS_BAM_PUTATIVE : 0);
+  auto feeder = [&](svdss_index_t* ix) {
+    svdss_bam_batch_t* batch = nullptr;
+    std::vector<const uint8_t*> comp;
+    std::vector<int64_t> comp_bytes, n_blocks;
+    std::vector<const svdss_bgzf_block_t*> blocks;
+    std::vector<const uint32_t*> crcs;
+    while (std::unique_ptr<DevJob> job = jobs.pop()) {
+      const auto t0 = now();
+      comp.clear(); comp_bytes.clear(); n_blocks.clear(); blocks.clear(); crcs.clear();
+      for (const std::unique_ptr<CompChunk>& c : job->chunks) {
+        comp.push_back(c->data); comp_bytes.push_back((int64_t)c->n_bytes); n_blocks.push_back((int64_t)c->blocks.size());
+        blocks.push_back(c->blocks.data()); crcs.push_back(c->crc.data());
+      }
+      const int rc = svdss_bam_batch_run(stream, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? skip : 0, ix, (int32_t)comp.size(),
+                                         comp.data(), comp_bytes.data(), blocks.data(), crcs.data(), n_blocks.data(), flags, &batch);
+      for (std::unique_ptr<CompChunk>& c : job->chunks) sc.recycle(std::move(c));
+      if (rc != SVDSS_OK) {
+        std::string msg = batch ? svdss_bam_batch_error(batch) : "";
+        if (msg.empty()) msg = svdss_bam_stream_error(stream);
+        if (msg.find("core.tid") != std::string::npos) die(msg);                       // ping_pong.cpp:76-79
+        if (rc == SVDSS_EIO) die("error reading " + o.bam + ": " + msg);
+        die(std::string("svdss_bam_batch_run: ") + svdss_strerror(rc) + " " + msg + " " + svdss_last_hip_error());
+      }
+      const auto t1 = now();
+      svdss_bam_result_t r;
+      check(svdss_bam_batch_result(batch, &r), "svdss_bam_batch_result");
+      for (int64_t k = 0; k < r.n_short; ++k) logmsg("warning", "Alignment filtered due to l_qseq. Why are we here? Please check");   // :70-75
+      std::unique_ptr<DevOut> out(new DevOut);
+      out->reads.resize((size_t)r.n_slots);
+      out->qs.assign(r.qs, r.qs + r.total_sfs);
+      out->ln.assign(r.len, r.len + r.total_sfs);
+      {
+        // (searched reads are numbered in slot order, so their SFS follow each other in slot order too)
+        int64_t acc = 0;
+        for (int64_t i = 0; i < r.n_slots; ++i) {
+          Read& rd = out->reads[(size_t)i];
+          rd.name.assign(r.names + r.name_off[i], (size_t)(r.name_off[i + 1] - r.name_off[i]));
+          rd.hp = r.hp[i];
+          if (r.sidx[i] < 0) { rd.count = -1; rd.first = acc; }
+          else { rd.first = acc; rd.count = r.counts[r.sidx[i]]; acc += rd.count; }
+        }
+      }
+      {
+        std::lock_guard<std::mutex> lk(t_m);
+        t_gpu += secs(t0, t1); t_build += secs(t1, now()); t_inflate_ms += r.inflate_kernel_ms;
+        n_seen += (uint64_t)r.n_records; ++n_batches;
+      }
+      {
+        std::unique_lock<std::mutex> lk(dev_m);
+        const uint64_t sq = job->seq;
+        dev_cv.wait(lk, [&] { return dev_done.size() < 8 || dev_done.begin()->first > sq; });
+        dev_done[sq] = std::move(out);
+      }
+      dev_cv.notify_all();
+    }
+    svdss_bam_batch_free(batch);
+  };
+
+  // units of whole reference batches, formatted by a few threads, written in order
+  BoundedQueue<SearchBatch> units(4);
+  std::mutex done_m;
+  std::condition_variable done_cv;
+  std::map<uint64_t, std::unique_ptr<SearchBatch>> done;
+  bool format_finished = false;
+  std::mutex pool_m;
+  std::vector<std::unique_ptr<SearchBatch>> batch_pool;
+  auto new_unit = [&]() {
+    std::unique_ptr<SearchBatch> b;
+    {
+      std::lock_guard<std::mutex> lk(pool_m);
+      if (!batch_pool.empty()) { b = std::move(batch_pool.back()); batch_pool.pop_back(); }
+    }
+    if (!b) b.reset(new SearchBatch);
+    b->reads.clear(); b->qs.clear(); b->ln.clear(); b->text.clear(); b->n_lines = 0; b->seq = 0;
+    return b;
+  };
+  std::thread assembler([&] {
+    uint64_t want = 0, unit_seq = 0;
+    std::unique_ptr<SearchBatch> unit = new_unit();
+    for (;;) {
+      std::unique_ptr<DevOut> d;
+      {
+        std::unique_lock<std::mutex> lk(dev_m);
+        dev_cv.wait(lk, [&] { return dev_done.count(want) || (feeders_finished && dev_done.empty()); });
+        auto it = dev_done.find(want);
+        if (it == dev_done.end()) break;
+        d = std::move(it->second);
+        dev_done.erase(it);
+        ++want;
+      }
+      dev_cv.notify_all();
+      const auto ta = now();
+      for (Read& r : d->reads) {
+        const int64_t first = r.first;
+        r.first = (int64_t)unit->qs.size();
+        if (r.count > 0) {
+          unit->qs.insert(unit->qs.end(), d->qs.begin() + first, d->qs.begin() + first + r.count);
+          unit->ln.insert(unit->ln.end(), d->ln.begin() + first, d->ln.begin() + first + r.count);
+        }
+        unit->reads.push_back(std::move(r));
+        if ((int64_t)unit->reads.size() == super) {
+          unit->seq = unit_seq++;
+          units.push(std::move(unit));
+          unit = new_unit();
+        }
+      }
+      t_assemble += secs(ta, now());
+    }
+    if (!unit->reads.empty()) { unit->seq = unit_seq++; units.push(std::move(unit)); }
+    units.close();
+  });
+  auto formatter = [&] {
+    while (std::unique_ptr<SearchBatch> u = units.pop()) {
+      const auto tf = now();
+      format_batch(o, *u);
+      { std::lock_guard<std::mutex> lk(t_m); t_format += secs(tf, now()); }
+      {
+        std::unique_lock<std::mutex> lk(done_m);
+        const uint64_t sq = u->seq;
+        done_cv.wait(lk, [&] { return done.size() < 8 || done.begin()->first > sq; });
+        done[sq] = std::move(u);
+      }
+      done_cv.notify_all();
+    }
+  };
+  std::thread writer([&] {
+    uint64_t want = 0;
+    for (;;) {
+      std::unique_ptr<SearchBatch> bt;
+      {
+        std::unique_lock<std::mutex> lk(done_m);
+        done_cv.wait(lk, [&] { return done.count(want) || (format_finished && done.empty()); });
+        auto it = done.find(want);
+        if (it == done.end()) break;
+        bt = std::move(it->second);
+        done.erase(it);
+        ++want;
+      }
+      done_cv.notify_all();
+      const auto tw0 = now();
+      fwrite(bt->text.data(), 1, bt->text.size(), stdout);
+      total_sfs += bt->n_lines;
+      t_write += secs(tw0, now());
+      std::lock_guard<std::mutex> lk(pool_m);
+      if (batch_pool.size() < 16) batch_pool.push_back(std::move(bt));
+    }
+    fflush(stdout);
+  });
+  {
+    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 4;
+    const int n_fmt = getenv("SVDSS_FORMAT_THREADS") ? std::max(1, atoi(getenv("SVDSS_FORMAT_THREADS"))) : 5;
+    std::vector<std::thread> fmt;
+    for (int k = 0; k < n_fmt; ++k) fmt.emplace_back(formatter);
+    std::vector<std::thread> feeders;
+    for (size_t d = 0; d < replicas.size(); ++d)
+      for (int k = 0; k < per_gpu; ++k) feeders.emplace_back(feeder, replicas[d]);
+    for (std::thread& th : feeders) th.join();
+    { std::lock_guard<std::mutex> lk(dev_m); feeders_finished = true; }
+    dev_cv.notify_all();
+    batcher.join();
+    assembler.join();
+    for (std::thread& th : fmt) th.join();
+    { std::lock_guard<std::mutex> lk(done_m); format_finished = true; }
+    done_cv.notify_all();
+    writer.join();
+  }
+  if (o.verbose) {
+    int64_t n_seg = 0;
+    const int64_t rew = svdss_bam_stream_rewalked(stream, &n_seg);
+    logmsg("debug", std::to_string(n_seen) + " records read, " + std::to_string(total_sfs) + " SFS written at +" + since() + " s");
+    logmsg("debug", "device path: " + std::to_string(n_batches) + " batches, " + std::to_string(n_seg) + " segments (" + std::to_string(rew) +
+                        " walked again); busy seconds: GPU batches " + std::to_string(t_gpu) + " (inflate kernels " + std::to_string(t_inflate_ms * 1e-3) +
+                        "), result unpacking " + std::to_string(t_build) + ", re-dealing " + std::to_string(t_assemble) + ", format " + std::to_string(t_format) +
+                        ", write " + std::to_string(t_write));
+  }
+  svdss_bam_stream_free(stream);
+}
+
 int main_search(const Options& o) {
   logmsg("info", "Restoring index..");
   svdss_index_t* ix = nullptr;
@@ -287,7 +630,30 @@ int main_search(const Options& o) {
   const bool bam_mode = !o.bam.empty();
   BamReader* bam = nullptr;
   std::thread bam_prewarm;
-  if (bam_mode) {
+  // BAM records handled on the GPU (csrc/bam_device.hip; the default when there is one): only compressed bytes go up.
+  // SVDSS_BAM_DEVICE=0: the host path below (BamReader: chunks inflated on the GPU or by the host pool, records sliced
+  // on the host, packed bases uploaded) -- the tested fallback, and what a reader of stdin-like inputs needs.
+  const bool dev_bam = bam_mode && svdss_device_count() > 0 && !(getenv("SVDSS_BAM_DEVICE") && atoi(getenv("SVDSS_BAM_DEVICE")) == 0);
+  std::unique_ptr<BgzfScanner> scanner;
+  int32_t bam_n_ref = 0;
+  int64_t bam_skip = 0;
+  if (dev_bam) {
+    std::string herr;
+    if (!bam_header_probe(o.bam, bam_n_ref, bam_skip, herr)) die("cannot read " + o.bam + ": " + herr);
+    BgzfScanner::Hooks hooks;
+    hooks.host_alloc = svdss_host_alloc;
+    hooks.host_free = svdss_host_free;
+    const size_t slab = (getenv("SVDSS_BAM_SLAB_KB") && atoll(getenv("SVDSS_BAM_SLAB_KB")) >= 64 ? (size_t)atoll(getenv("SVDSS_BAM_SLAB_KB")) << 10 : (size_t)16 << 20);
+    const size_t target = (size_t)(getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 256) << 20;
+    const int n_dev0 = std::max(1, svdss_device_count());
+    const int n_g = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev0));
+    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 4;
+    // slabs alive at once: those the loaders read ahead + those of the batches being fed, queued and cut
+    const size_t per_batch = target / slab + 2;
+    scanner.reset(new BgzfScanner(o.bam, hooks, slab, 8, 8 + ((size_t)(n_g * per_gpu) + 3) * per_batch));
+    if (!scanner->ok()) die("cannot open " + o.bam);
+    if (!getenv("SVDSS_NO_PREWARM")) bam_prewarm = std::thread([&scanner] { scanner->prewarm(); });
+  } else if (bam_mode) {
     // the reader's page-locked chunk buffers are allocated while the index is restored (BamReader::prewarm)
     bam = new BamReader(o.bam, o.io_threads);
     // (BGZF blocks inflated on the GPU, csrc/inflate.hip, on every GPU of --gpus in turn; SVDSS_GPU_INFLATE)
@@ -344,6 +710,21 @@ int main_search(const Options& o) {
   }
   if (n_gpus > 1) logmsg("info", "Index replicated on " + std::to_string(n_gpus) + " GPUs");
   FastxReader* fx = nullptr;
+  if (dev_bam) {
+    if (bam_prewarm.joinable()) bam_prewarm.join();
+    if (o.bsize <= 0) die("batch size smaller than the number of threads");
+    logmsg("info", "Extracting SFS strings on the GPU (output order as with " + std::to_string(o.threads) + " threads)..");
+    search_bam_device(o, replicas, *scanner, bam_n_ref, bam_skip, since);
+    if (!getenv("SVDSS_CLEAN_EXIT")) {
+      logmsg("info", "All done! Runtime: " + std::to_string((long)(time(nullptr) - g_t0)) + " seconds");
+      fflush(stdout);
+      fflush(stderr);
+      _exit(0);
+    }
+    scanner.reset();
+    for (svdss_index_t* r : replicas) svdss_index_free(r);
+    return 0;
+  }
   if (bam_mode) {
     if (bam_prewarm.joinable()) bam_prewarm.join();
     if (!bam->ok() || !bam->read_header()) die("cannot read " + o.bam + ": " + bam->error());
@@ -517,40 +898,6 @@ int main_search(const Options& o) {
     fflush(stdout);
   });
 
-  // the text of one batch.  output_batch order: reference batches of bsize reads -> thread t takes reads n with
-  // n % T == t (ping_pong.cpp:59,101-104) -> std::map<qname, vector<SFS>> order (:217)
-  auto format_batch = [&](SearchBatch& b) {
-    const std::vector<Read>& reads = b.reads;
-    std::string& out = b.text;
-    out.reserve(b.qs.size() * 24 + 1024);
-    char num[64];
-    for (size_t b0 = 0; b0 < reads.size(); b0 += (size_t)o.bsize) {
-      const size_t b1 = std::min(reads.size(), b0 + (size_t)o.bsize);
-      for (int t = 0; t < o.threads; ++t) {
-        std::map<std::string, std::vector<size_t>> by_name;
-        for (size_t n = b0 + (size_t)t; n < b1; n += (size_t)o.threads)
-          if (reads[n].count >= 0) by_name[reads[n].name].push_back(n);
-        for (const auto& kv : by_name) {
-          bool first = true;
-          for (size_t n : kv.second) {
-            const Read& r = reads[n];
-            for (int64_t k = 0; k < r.count; ++k) {
-              if (first) out += r.name; else out += '*';
-              char* w = num;                      // "\t<qs>\t<len>\t<hp>\t\n" without printf (11 M lines per GB of reads)
-              *w++ = '\t'; w = put_int(w, b.qs[(size_t)(r.first + k)]);
-              *w++ = '\t'; w = put_int(w, b.ln[(size_t)(r.first + k)]);
-              *w++ = '\t'; w = put_int(w, r.hp);
-              *w++ = '\t'; *w++ = '\n';
-              out.append(num, (size_t)(w - num));
-              first = false;
-              ++b.n_lines;
-            }
-          }
-        }
-      }
-    }
-  };
-
   // two threads per GPU feed it, each with its own batch object (own stream): the upload of one batch overlaps the
   // search of the other; the thread that searched a batch also formats its text, the writer only writes
   std::mutex t_m;
@@ -581,7 +928,7 @@ int main_search(const Options& o) {
       pinned.put(bt->seq4, bt->seq4_cap);
       bt->seq4 = nullptr;
       const auto tg1 = now();
-      format_batch(*bt);
+      format_batch(o, *bt);
       { std::lock_guard<std::mutex> lk(t_m); t_gpu += secs(tg0, tg1); t_format += secs(tg1, now()); }
       {
         // (bounded: a finished batch waits until the writer is at most 3 batches behind)

@@ -216,3 +216,46 @@ def test_crc32_kernel_on_every_block_size(case):
     out.append(bam_writer._bgzf_block(b""))
     res, st = bamdev.search_bam(ix, b"".join(out))
     assert res == [] and st["records"] == len(recs)
+
+
+def test_binary_device_path_writes_the_host_paths_bytes(case, tmp_path):
+    """`SVDSS search --bam`: records handled on the GPU (default) against SVDSS_BAM_DEVICE=0 (records sliced on the
+    host) -- the same stdout byte for byte, with slabs / batches so small that the file is dozens of batches, with
+    several feeding threads per GPU and two (oversubscribed) GPUs, for two --threads / --bsize settings (the text order
+    depends on them, ping_pong.cpp:213-236: device batches never end where reference batches do)."""
+    import subprocess
+    from tests.common import BIN
+    ref, ix, fm, reads, names = case
+    rng = np.random.default_rng(23)
+    # 3,200 records: the 400 reads eight times under other names
+    recs = []
+    for rep in range(8):
+        r, _ = _records([f"{n}/{rep}" for n in names], reads, rng, decoys=(rep % 2 == 0))
+        recs += r
+    bam = tmp_path / "reads.bam"
+    bam.write_bytes(_bgzf_levels(_raw_bam([("chr1", 150000)], recs), rng, block=60000))
+    fmd = tmp_path / "ref.fmd"
+    ix.save(str(fmd))
+
+    def run(env, *extra):
+        r = subprocess.run([BIN, "search", "--index", str(fmd), "--bam", str(bam), "--verbose", *extra], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        return r
+    for extra in (("--threads", "4", "--bsize", "100"), ("--threads", "3", "--bsize", "1000", "--noputative", "--noassemble")):
+        host = run({"SVDSS_BAM_DEVICE": "0"}, *extra)
+        assert "device path" not in host.stderr and host.stdout.count("\n") > 5000
+        dev = run({"SVDSS_BAM_SLAB_KB": "64", "SVDSS_BAM_BATCH_MB": "1", "SVDSS_BAM_SEG_KB": "8"}, *extra)
+        assert "device path" in dev.stderr and dev.stdout == host.stdout
+        assert dev.stderr.count("Alignment filtered due to l_qseq") == host.stderr.count("Alignment filtered due to l_qseq") == 8
+        dev2 = run({"SVDSS_BAM_SLAB_KB": "128", "SVDSS_BAM_BATCH_MB": "2", "SVDSS_GPUS_OVERSUBSCRIBE": "1", "SVDSS_SEARCH_FEEDERS": "3"},
+                   "--gpus", "2", *extra)
+        assert dev2.stdout == host.stdout
+        big = run({}, *extra)          # the default sizes: one batch
+        assert big.stdout == host.stdout
+    # damage through the binary: message + exit 1
+    data = bytearray(bam.read_bytes())
+    data[len(data) // 2] ^= 0x40
+    (tmp_path / "bad.bam").write_bytes(bytes(data))
+    r = subprocess.run([BIN, "search", "--index", str(fmd), "--bam", str(tmp_path / "bad.bam")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and "critical" in r.stderr

@@ -226,8 +226,10 @@ def test_index_writes_an_rld0_fmd_and_the_records_beside_it(tmp_path):
 
 @pytest.mark.gpu
 def test_search_bam_inflated_on_the_gpu_or_the_host_same_bytes(tmp_path):
-    """BGZF blocks inflated by csrc/inflate.hip (default), by the host workers, or half / half: the same text; a block
-    whose content does not match its CRC32 footer ends the run with exit code 1 on every path."""
+    """The host path of `search --bam` (SVDSS_BAM_DEVICE=0: records sliced on the host; the default since round 4 handles
+    them on the GPU, tests/test_bam_device_gpu.py): BGZF blocks inflated by csrc/inflate.hip, by the host workers, or
+    half / half: the same text, and the text of the device path; a block whose content does not match its CRC32 footer
+    ends the run with exit code 1 on every path."""
     import struct
     import zlib
     ref, hap, svs, flat, offs = small_workload(seed=83, n_reads=400, read_len=3000, ref_lens=(120000,))
@@ -247,29 +249,33 @@ def test_search_bam_inflated_on_the_gpu_or_the_host_same_bytes(tmp_path):
     outs = {}
     for mode in ("101", "0", "50", "100"):     # every chunk on the GPU / none / every other one / the default
         r = run("search", "--index", str(fmd), "--bam", str(bam), "--noputative", "--threads", "4", "--bsize", "64", "--verbose",
-                env=dict(os.environ, SVDSS_GPU_INFLATE=mode, SVDSS_DEBUG="1"))
+                env=dict(os.environ, SVDSS_GPU_INFLATE=mode, SVDSS_DEBUG="1", SVDSS_BAM_DEVICE="0"))
         assert r.returncode == 0, r.stderr
         outs[mode] = r.stdout
         if mode in ("101", "0"):
             assert ("inflated on the GPU" in r.stderr) == (mode == "101"), r.stderr
     assert outs["101"] == outs["0"] == outs["50"] == outs["100"] and outs["0"].count("\n") > 400
+    r = run("search", "--index", str(fmd), "--bam", str(bam), "--noputative", "--threads", "4", "--bsize", "64", "--verbose")
+    assert r.returncode == 0 and "device path" in r.stderr and r.stdout == outs["0"]
     # chunk buffers page-locked (forced: the file is far below the size at which the reader pins them), with no
     # page-locked memory to be had at all (cap 0: every buffer falls back to ordinary memory), several small chunks in
     # flight, and the k-mer table order left to the binary or fixed: the same text
     for env in ({"SVDSS_PIN_MIN_CHUNKS": "0"}, {"SVDSS_PIN_MIN_CHUNKS": "0", "SVDSS_PIN_CAP_GB": "0"},
                 {"SVDSS_PIN_MIN_CHUNKS": "0", "SVDSS_BAM_SLAB_KB": "64"}, {"SVDSS_KMER": "16"}, {"SVDSS_KMER": "9"}):
-        r = run("search", "--index", str(fmd), "--bam", str(bam), "--noputative", "--threads", "4", "--bsize", "64",
-                env=dict(os.environ, **env))
-        assert r.returncode == 0, (env, r.stderr[-300:])
-        assert r.stdout == outs["0"], env
+        for dev in ("0", "1"):
+            r = run("search", "--index", str(fmd), "--bam", str(bam), "--noputative", "--threads", "4", "--bsize", "64",
+                    env=dict(os.environ, SVDSS_BAM_DEVICE=dev, **env))
+            assert r.returncode == 0, (env, r.stderr[-300:])
+            assert r.stdout == outs["0"], env
     # flip one bit in the middle of the second block's deflate stream
     bad = bytearray(data)
     first = struct.unpack_from("<H", data, 16)[0] + 1
     second = struct.unpack_from("<H", data, first + 16)[0] + 1
     bad[first + 18 + (second - 26) // 2] ^= 0x10
     (tmp_path / "bad.bam").write_bytes(bytes(bad))
-    for mode in ("101", "0"):
-        r = run("search", "--index", str(fmd), "--bam", str(tmp_path / "bad.bam"), "--noputative", env=dict(os.environ, SVDSS_GPU_INFLATE=mode))
+    for mode in ("101", "0", "device"):
+        env = dict(os.environ, SVDSS_GPU_INFLATE=mode, SVDSS_BAM_DEVICE="0") if mode != "device" else dict(os.environ)
+        r = run("search", "--index", str(fmd), "--bam", str(tmp_path / "bad.bam"), "--noputative", env=env)
         assert r.returncode == 1 and ("CRC" in r.stderr or "inflate" in r.stderr), (mode, r.stderr[-300:])
 
 
