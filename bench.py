@@ -744,14 +744,14 @@ def e2e_prepare(work, ref, wg):
                 f.write(b"\n")
 
 
-def _run_search(exe, fmd, bam):
+def _run_search(exe, fmd, bam, env=None):
     """`SVDSS search --bam` -> (dict of timings from its --verbose log, wall seconds)"""
     import re
     import subprocess
     t0 = time.perf_counter()
     r = subprocess.run([exe, "search", "--index", fmd, "--bam", bam, "--noputative", "--verbose"],
                        stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, check=True,
-                       env=dict(os.environ, SVDSS_DEBUG="1"))
+                       env=dict(os.environ, SVDSS_DEBUG="1", **(env or {})))
     wall = time.perf_counter() - t0
     t_file = float(re.search(r"index file read at \+([0-9.]+) s", r.stderr).group(1))
     t_ix = float(re.search(r"on the device at \+([0-9.]+) s", r.stderr).group(1))
@@ -759,10 +759,18 @@ def _run_search(exe, fmd, bam):
     n, n_sfs, t_end = int(m.group(1)), int(m.group(2)), float(m.group(3))
     g = re.search(r"(\d+) chunks inflated on the GPU", r.stderr)
     c = re.search(r"\] (\d+) chunks: locate", r.stderr)
-    return {"reads": n, "sfs": n_sfs, "streaming_s": round(t_end - t_ix, 3), "index_file_read_s": round(t_file, 3),
-            "index_restore_s": round(t_ix, 3), "whole_process_s": round(wall, 3),
-            "reads_per_s_streaming": n / max(t_end - t_ix, 1e-9), "whole_process_reads_per_s": n / wall,
-            "bgzf_chunks": int(c.group(1)) if c else None, "bgzf_chunks_inflated_on_gpu": int(g.group(1)) if g else 0}
+    d = re.search(r"device path: (\d+) batches, (\d+) segments \((\d+) walked again\); busy seconds: GPU batches ([0-9.]+) \(inflate kernels ([0-9.]+)\)", r.stderr)
+    out = {"reads": n, "sfs": n_sfs, "streaming_s": round(t_end - t_ix, 3), "index_file_read_s": round(t_file, 3),
+           "index_restore_s": round(t_ix, 3), "whole_process_s": round(wall, 3),
+           "reads_per_s_streaming": n / max(t_end - t_ix, 1e-9), "whole_process_reads_per_s": n / wall}
+    if d:   # records handled on the GPU (csrc/bam_device.hip): only compressed bytes went up
+        out.update({"path": "device (BAM records walked, filtered and unpacked on the GPU)", "device_batches": int(d.group(1)),
+                    "record_chain_segments": int(d.group(2)), "segments_walked_again": int(d.group(3)),
+                    "inflate_kernel_s_summed": float(d.group(5))})
+    else:
+        out.update({"path": "host (records sliced on the host)", "bgzf_chunks": int(c.group(1)) if c else None,
+                    "bgzf_chunks_inflated_on_gpu": int(g.group(1)) if g else 0})
+    return out
 
 
 def e2e_runs(work, n_reads, call=True):
@@ -797,6 +805,32 @@ def e2e_runs(work, n_reads, call=True):
     r["index_s"] = round(t_index, 2)
     r["host_cpu_quota_cores"] = cpu_quota()
     out["e2e"] = r
+    try:
+        # the same run with the records sliced on the host (the path of rounds 1-3, kept as the fallback)
+        h = _run_search(exe, os.path.join(work, "chr.fmd"), bam, env={"SVDSS_BAM_DEVICE": "0"})
+        out["e2e_host_path"] = {k: h[k] for k in ("path", "streaming_s", "reads_per_s_streaming", "whole_process_s")}
+    except Exception as e:   # noqa: BLE001
+        out["e2e_host_path_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
+    try:
+        # run_svdss:151-165: `SVDSS smooth` writes the BAM that `SVDSS search` reads.  smooth's output is deflated by this
+        # repository's own encoder (csrc/deflate.hip: dynamic Huffman, literals only), which the GPU inflater decodes
+        # about twice as fast as zlib's level-1 streams with their thousands of 3-byte matches per block
+        sm = os.path.join(work, "smoothed.bam")
+        t0 = time.perf_counter()
+        with open(sm, "wb") as f:
+            subprocess.run([exe, "smooth", "--reference", os.path.join(work, "chr.fa"), "--bam", bam, "--threads", "16"], check=True,
+                           stdout=f, stderr=subprocess.DEVNULL)
+        t_smooth = time.perf_counter() - t0
+        r2 = _run_search(exe, os.path.join(work, "chr.fmd"), sm)
+        r2["what"] = ("SVDSS smooth -> SVDSS search (binaries), as run_svdss:151-165 chains them: search reads the BAM smooth wrote "
+                      "(%.1f GB, deflated on the GPU); smooth: %.2f s whole process = %.0f reads/s"
+                      % (os.path.getsize(sm) / 1e9, t_smooth, r["reads"] / t_smooth))
+        r2["smooth_s"] = round(t_smooth, 3)
+        r2["smooth_reads_per_s"] = r["reads"] / t_smooth
+        out["e2e_smoothed"] = r2
+        os.remove(sm)
+    except Exception as e:   # noqa: BLE001
+        out["e2e_smoothed_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
     if os.path.exists(os.path.join(work, "wg.fa")):
         try:
             t0 = time.perf_counter()

@@ -10,6 +10,7 @@ from svdss_amd._lib import lib, check
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 kind = sys.argv[3] if len(sys.argv) > 3 else "bam"
+strategy = zlib.Z_HUFFMAN_ONLY if len(sys.argv) > 4 and sys.argv[4] == "huff" else zlib.Z_DEFAULT_STRATEGY   # huff: literals only, what csrc/deflate.hip writes
 rng = np.random.default_rng(1)
 uniq = 64
 raws, comps = [], []
@@ -31,7 +32,7 @@ for i in range(uniq):
         raw = np.concatenate([a, b]).tobytes()
     else:
         raw = (b"the quick brown fox jumps over the lazy dog %d. " % i * 1500)[:65280]
-    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
     comps.append(c.compress(raw) + c.flush())
     raws.append(raw)
 comp = bytearray()
