@@ -271,6 +271,8 @@ typedef struct svdss_bam_result {
   const int32_t* qs;        /* total_sfs, read after read */
   const int32_t* len;
   double inflate_kernel_ms;
+  double stage_ms[8];       /* host clock between the waits of the run: 0 upload + inflate + CRC + segment walk, 1 waiting for
+                               the turn, 2 the turn (carry, link), 3 fields / filters / scans, 4 unpack, 5 search, 6 results down */
 } svdss_bam_result_t;
 int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_result_t* out);
 const char* svdss_bam_batch_error(const svdss_bam_batch_t* b);

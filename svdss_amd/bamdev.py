@@ -16,7 +16,8 @@ class BamResult(C.Structure):
     _fields_ = [("n_records", C.c_int64), ("n_slots", C.c_int64), ("n_searched", C.c_int64), ("n_short", C.c_int64),
                 ("total_sfs", C.c_int64), ("name_off", C.POINTER(C.c_int32)), ("names", C.POINTER(C.c_char)),
                 ("hp", C.POINTER(C.c_int32)), ("sidx", C.POINTER(C.c_int32)), ("counts", C.POINTER(C.c_int64)),
-                ("qs", C.POINTER(C.c_int32)), ("len", C.POINTER(C.c_int32)), ("inflate_kernel_ms", C.c_double)]
+                ("qs", C.POINTER(C.c_int32)), ("len", C.POINTER(C.c_int32)), ("inflate_kernel_ms", C.c_double),
+                ("stage_ms", C.c_double * 8)]
 
 
 def bam_header(data, blocks):

@@ -32,6 +32,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -480,7 +481,8 @@ struct svdss_bam_batch {
   std::vector<char> names;
   std::vector<int64_t> counts;
   int64_t n_records = 0, n_slots = 0, n_searched = 0, n_short = 0, total_sfs = 0;
-  double inflate_ms = 0, walk_ms = 0;
+  double inflate_ms = 0;
+  double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // host clock between the waits of the last run (svdss_bam_result_t::stage_ms)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::string err;
 };
@@ -591,6 +593,12 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   const hipStream_t st = b->st;
   b->n_records = b->n_slots = b->n_searched = b->n_short = b->total_sfs = 0;
   b->err.clear();
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](int k) {
+    const auto t = std::chrono::steady_clock::now();
+    b->stage_ms[k] = std::chrono::duration<double, std::milli>(t - t_prev).count();
+    t_prev = t;
+  };
   static const int64_t HEAD = [] {
     const char* e = getenv("SVDSS_BAM_HEADROOM_MB");
     const int64_t mb = e && *e ? atoll(e) : 0;
@@ -682,6 +690,7 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->e0, b->e1) == hipSuccess) b->inflate_ms = ms;
   }
+  lap(0);   // buffers, upload, inflate, CRC, segment walk
   for (int64_t i = 0; i < total_blocks; ++i)
     if (b->h_status[(size_t)i] != 0) return fail(SVDSS_EIO, "BGZF inflate failed");
   if (b->h_status[(size_t)total_blocks] != 0) return fail(SVDSS_EIO, "BGZF block CRC mismatch");
@@ -689,6 +698,7 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   // ---- this batch's turn: carry in, the chain proved and completed, carry out
   if (!wait_turn(s, seq)) { had_turn = true; return fail(s->failed, s->err); }
   had_turn = true;
+  lap(1);   // waiting for the turn
   int turn_code = SVDSS_OK;
   std::string turn_msg;
   int64_t hdr[H_N] = {0};
@@ -727,6 +737,7 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   }
   done_turn(s, turn_code, turn_msg);
   if (turn_code) { b->err = turn_msg; return turn_code; }
+  lap(2);   // the turn: carry in, link, carry out
 
   // ---- fields, filters, tags; where everything goes
   const int64_t n_rec = hdr[H_NREC];
@@ -771,6 +782,7 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   BCHK(hipMemcpyAsync(totals, b->totals.p, sizeof totals, hipMemcpyDeviceToHost, st));
   BCHK(hipMemcpyAsync(hdr2, b->hdr.p, sizeof hdr2, hipMemcpyDeviceToHost, st));
   BCHK(hipStreamSynchronize(st));
+  lap(3);   // fields / filters / tags, scans, scatter
   if (hdr2[H_ERR] & E_CORRUPT) return fail(SVDSS_EIO, "corrupt record");
   if (hdr2[H_ERR] & E_TID) return fail(SVDSS_EIO, "core.tid < 0. Why are we here? Please check");
   const int64_t n_slots = totals[0], n_srch = totals[1], name_bytes = totals[2], total_syms = totals[3];
@@ -809,11 +821,14 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
       BCHK(hipGetLastError());
     }
   }
+  BCHK(hipStreamSynchronize(st));
+  lap(4);   // unpack
   {
     const int rc = svdss_sfs_search_batch_device(ix, (const uint8_t*)b->reads.p, (const int64_t*)S.sym_off, n_srch, total_syms,
                                                  (flags & SVDSS_SFS_ASSEMBLE), (void*)st, &b->sfs);
     if (rc != SVDSS_OK) return fail(rc, std::string("search: ") + svdss_last_hip_error());
   }
+  lap(5);   // search
   // ---- what the host needs: names and tags of the slots, counts and SFS of the searched reads
   b->total_sfs = svdss_sfs_batch_total(b->sfs);
   try {
@@ -836,6 +851,7 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
     }
   }
   BCHK(hipStreamSynchronize(st));
+  lap(6);   // results down
   return SVDSS_OK;
 #undef BCHK
 #undef RCHK
@@ -848,6 +864,7 @@ extern "C" int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_resu
   r->name_off = b->name_off.data(); r->names = b->names.data(); r->hp = b->hp.data(); r->sidx = b->sidx.data();
   r->counts = b->counts.data(); r->qs = b->qs.data(); r->len = b->len.data();
   r->inflate_kernel_ms = b->inflate_ms;
+  for (int k = 0; k < 8; ++k) r->stage_ms[k] = b->stage_ms[k];
   return SVDSS_OK;
 }
 

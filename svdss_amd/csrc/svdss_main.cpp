@@ -409,6 +409,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   std::mutex t_m;
   double t_gpu = 0, t_inflate_ms = 0, t_build = 0, t_format = 0, t_write = 0, t_assemble = 0;
+  double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t n_seen = 0, n_batches = 0, total_sfs = 0;
 
   std::thread batcher([&] {
@@ -490,6 +491,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
         std::lock_guard<std::mutex> lk(t_m);
         t_gpu += secs(t0, t1); t_build += secs(t1, now()); t_inflate_ms += r.inflate_kernel_ms;
         n_seen += (uint64_t)r.n_records; ++n_batches;
+        for (int k = 0; k < 8; ++k) t_stage[k] += r.stage_ms[k] * 1e-3;
       }
       {
         std::unique_lock<std::mutex> lk(dev_m);
@@ -618,6 +620,10 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
                         " walked again); busy seconds: GPU batches " + std::to_string(t_gpu) + " (inflate kernels " + std::to_string(t_inflate_ms * 1e-3) +
                         "), result unpacking " + std::to_string(t_build) + ", re-dealing " + std::to_string(t_assemble) + ", format " + std::to_string(t_format) +
                         ", write " + std::to_string(t_write));
+    char buf[320];
+    snprintf(buf, sizeof buf, "device batches, seconds summed: upload+inflate+crc+walk %.3f, waiting for the turn %.3f, turn (carry, link) %.3f, "
+             "fields+scans %.3f, unpack %.3f, search %.3f, results down %.3f", t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5], t_stage[6]);
+    logmsg("debug", buf);
   }
   svdss_bam_stream_free(stream);
 }

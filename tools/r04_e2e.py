@@ -28,7 +28,8 @@ def run_search(exe, fmd, bam, env):
     dev = re.search(r"device path: .*", r.stderr)
     return {"reads": n, "sfs": n_sfs, "index_resident_s": round(t_ix, 3), "streaming_s": round(t_end - t_ix, 3),
             "reads_per_s_streaming": round(n / max(t_end - t_ix, 1e-9)), "whole_process_s": round(wall, 3),
-            "stages": dev.group(0) if dev else re.search(r"stage busy seconds: .*", r.stderr).group(0)}
+            "stages": dev.group(0) if dev else re.search(r"stage busy seconds: .*", r.stderr).group(0),
+            "device_stages": (re.search(r"device batches, seconds summed: .*", r.stderr) or [None])[0]}
 
 
 def main():
@@ -57,9 +58,24 @@ def main():
                 ("device path, 128 MB batches, 8 feeders", {"SVDSS_SEARCH_FEEDERS": "8", "SVDSS_BAM_BATCH_MB": "128"}),
                 ("device path, 512 MB batches", {"SVDSS_BAM_BATCH_MB": "512"}),
                 ("device path, 2 feeders", {"SVDSS_SEARCH_FEEDERS": "2"})]
+    if os.environ.get("R04_SMOOTHED"):
+        # the BAM `SVDSS smooth` writes (literal-only dynamic Huffman from csrc/deflate.hip), as search sees it in run_svdss
+        sm = os.path.join(work, "smoothed.bam")
+        t0 = time.perf_counter()
+        with open(sm, "wb") as f:
+            subprocess.run([exe, "smooth", "--reference", fa, "--bam", bam, "--threads", "16"], check=True, stdout=f, stderr=subprocess.DEVNULL)
+        out["smooth_s"] = round(time.perf_counter() - t0, 2)
+        print("smooth", out["smooth_s"], "s", flush=True)
+        os.remove(bam)
+        bam = sm
+        settings = [("device path, defaults", {}), ("1 feeder", {"SVDSS_SEARCH_FEEDERS": "1"}), ("2 feeders", {"SVDSS_SEARCH_FEEDERS": "2"}),
+                    ("8 feeders, 128 MB", {"SVDSS_SEARCH_FEEDERS": "8", "SVDSS_BAM_BATCH_MB": "128"})]
     for name, env in settings:
         out[name] = run_search(exe, fmd, bam, env)
         print(name, json.dumps(out[name]), flush=True)
+    if os.environ.get("R04_ROCPROF"):
+        subprocess.run("cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d %s/prof -o search -- %s search --index %s --bam %s --noputative > /dev/null 2> %s/prof.err"
+                       % (work, exe, fmd, bam, work), shell=True)
     print(json.dumps(out))
 
 
