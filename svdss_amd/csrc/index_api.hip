@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -356,7 +357,11 @@ static int build_table(svdss_index* ix) {
   const int k = auto_kmer(ix->n);
   if (k > 0 && ix->d_text && ix->d_sa) {
     const size_t tbytes = (size_t)16 << (2 * k);
+    const bool verbose = getenv("SVDSS_INDEX_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipMalloc(&ix->d_table, tbytes));
+    if (verbose) fprintf(stderr, "[index] k-mer table of order %d: %.1f GiB allocated in %.3f s\n", k, (double)tbytes / (1 << 30),
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     SvdssDevIndex v = svdss_device_view(ix);
     const uint64_t nkeys = (uint64_t)1 << (2 * k);
     const int blocks = (int)((nkeys + 255) / 256 < 65536 ? (nkeys + 255) / 256 : 65536);
@@ -370,6 +375,7 @@ static int build_table(svdss_index* ix) {
                          (SvdssTabEntry*)ix->d_table, k, forward);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
+    if (verbose) fprintf(stderr, "[index] k-mer table filled at +%.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     ix->table_k = k;
   }
   return SVDSS_OK;

@@ -29,6 +29,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -523,6 +524,12 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
   GCHK(hipMemGetInfo(&free_b, &total_b));
   const size_t N = (size_t)n;
   if (N * 18 + N / 2 + ((size_t)3 << 30) > free_b) return SVDSS_GPU_NO;   // text + SA + ranks + blocks, plus the sort buffers
+  const auto t_build0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {      // SVDSS_INDEX_VERBOSE: seconds since the build began (waits for the device)
+    if (!verbose) return;
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "[index_gpu] %-34s at +%.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count());
+  };
   Pool P;
   uint8_t* d_textalloc;
   const size_t text_bytes = N + 128 + 16;
@@ -547,11 +554,14 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
     P.release(d_src); P.release(d_off); P.release(d_bad);
     if (bad) return SVDSS_EINVAL;
   }
+  mark("records up, text laid down");
   uint64_t *d_sa64, *d_rank;
   PALLOC(P, d_sa64, N * 8 + 16);
   PALLOC(P, d_rank, N * 8);
   GCHK(hipMemGetInfo(&free_b, &total_b));
+  mark("suffix array + rank buffers");
   if (suffix_sort(d_text, n, d_sa64, d_rank, free_b, verbose)) return SVDSS_GPU_NO;
+  mark("suffixes sorted");
   P.release(d_rank);
   void* d_sa = d_sa64;
   if (!wide) {
@@ -585,6 +595,7 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
   }
   ull nd = 0;
   GCHK(hipMemcpy(&nd, d_nd, sizeof nd, hipMemcpyDeviceToHost));
+  mark("BWT + rank blocks");
   if ((int64_t)nd != n_dollar) return SVDSS_GPU_NO;
   // totals per symbol (64-bit), then 32-bit exclusive scans over the blocks
   int64_t totals[4];
@@ -652,6 +663,7 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
   ix->d_dollar = P.take(d_dollar_final);
   ix->d_table = nullptr;
   ix->table_k = 0;
+  mark("counters, blocks to the host");
   return 0;
 }
 

@@ -32,8 +32,16 @@ _lib.orc_search_batch.argtypes = [_p, _p, _p, _i64, C.c_int, C.c_int, _p, _p, C.
 _lib.orc_free.argtypes = [_p]
 _lib.orc_nt6_encode.argtypes = [C.c_char_p, _i64, _p]
 _lib.orc_max_threads.restype = C.c_int
+_lib.orc_terminator_reads.restype = _i64
+_lib.orc_terminator_reads.argtypes = []
 _lib.orc_fmd_set_intv.argtypes = [_p, C.c_int, _p]
 _lib.orc_fmd_extend.argtypes = [_p, _p, _p, C.c_int]
+
+
+def terminator_reads() -> int:
+    """accesses at or behind a read's terminator P[l] by the forward loops of both restatements since the library was
+    loaded (oracle/svdss_oracle.c: provably none)"""
+    return _lib.orc_terminator_reads()
 
 
 def nt6_encode(s: bytes) -> np.ndarray:

@@ -79,3 +79,34 @@ def test_batch_matches_single_and_threads():
         assert n_ext == e1[i]
         o += c1[i]
     assert c1.sum() > 0
+
+
+def test_golden_set_is_wide_and_the_terminator_is_never_read():
+    """Round 4: the committed set holds > 200 brute-force reads by kind (both strands, N runs, reads shorter than any
+    k-mer order, palindromes, contig ends and the '$' junctions of the text).  The forward loop of ping_pong.cpp:31-37
+    has no test for the read's end; oracle/svdss_oracle.c says why it never gets to P[l] (let alone behind it) and counts
+    every access there: after the golden set, reads that end exactly at a contig end and a few hundred random reads
+    through BOTH restatements the counter is still 0 -- there is no behaviour behind the terminator to agree on."""
+    cases = load_golden()
+    assert sum(len(c["reads"]) for c in cases) >= 200
+    names = {c["name"] for c in cases}
+    assert {"both_strands_errors", "n_runs", "shorter_than_k", "palindromes", "contig_ends_and_junctions"} <= names
+    rng = np.random.default_rng(77)
+    for case in cases:
+        contigs = [from_ascii(c) for c in case["contigs"]]
+        fm = O.OracleFMD.build(contigs)
+        text = O.build_text(contigs)
+        for rd in case["reads"]:
+            r = from_ascii(rd["read"])
+            assert fm.ping_pong_search(r) == O.ping_pong_bruteforce(text, r)
+        if case["name"] == "contig_ends_and_junctions":
+            for c in contigs:            # every suffix length 1 .. 60 of every contig, both strands, and with a last-base error
+                for ln in range(1, 61):
+                    for r in (c[-ln:], synth.revcomp(c[:ln])):
+                        assert fm.ping_pong_search(r) == O.ping_pong_bruteforce(text, r) == ([], ln - 1)
+                    e = c[-ln:].copy(); e[-1] = (e[-1] % 4) + 1
+                    assert fm.ping_pong_search(e) == O.ping_pong_bruteforce(text, e)
+            for _ in range(300):
+                r = rng.integers(1, 5, size=int(rng.integers(1, 80)), dtype=np.uint8)
+                assert fm.ping_pong_search(r) == O.ping_pong_bruteforce(text, r)
+    assert O.terminator_reads() == 0

@@ -40,6 +40,32 @@ def test_golden_vectors_on_gpu():
             assert [list(x) for x in got] == rd["assembled"], case["name"]
 
 
+@pytest.mark.parametrize("k,segments", [(0, 1), (0, 4), (12, 1), (12, 4), (16, 1), (16, 4)])
+def test_golden_vectors_for_every_table_order_and_launch_shape(k, segments, monkeypatch):
+    """The committed vectors (219 brute-force reads: tests/golden/make_golden.py) through the HIP path without a k-mer
+    table, with one of order 12 and with the order the whole-genome index uses (16: every case's table is 64 GiB; the
+    two largest cases only), one lane per read and four segments per read: SFS, assembled SFS and extension counts."""
+    monkeypatch.setenv("SVDSS_KMER", str(k))
+    monkeypatch.setenv("SVDSS_SEGMENTS", str(segments))
+    cases = load_golden()
+    if k == 16:
+        cases = [c for c in cases if c["name"] in ("both_strands_errors", "contig_ends_and_junctions")]
+    for case in cases:
+        contigs = [from_ascii(c) for c in case["contigs"]]
+        ix = svdss_amd.FMDIndex.build(contigs, threads=2).to_device(0)
+        assert ix.kmer_k == k
+        reads = [from_ascii(r["read"]) for r in case["reads"]]
+        flat, offs = svdss_amd.pack_reads(reads)
+        raw = _search(ix, flat, offs, False)
+        for got, rd, ne in zip(raw.per_read(), case["reads"], raw.n_ext.tolist()):
+            assert [list(x) for x in got] == rd["sfs"], case["name"]
+            assert ne == rd["n_ext"], case["name"]
+        asm = _search(ix, flat, offs, True)
+        for got, rd in zip(asm.per_read(), case["reads"]):
+            assert [list(x) for x in got] == rd["assembled"], case["name"]
+        del ix
+
+
 @pytest.mark.parametrize("assemble", [False, True])
 @pytest.mark.parametrize("seed", [31, 32])
 def test_random_reads_match_oracle(assemble, seed):

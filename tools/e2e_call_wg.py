@@ -267,7 +267,8 @@ def run(work, n_reads, n_svs, scale=1.0, threads=16):
     c = subprocess.run([exe, "call", "--reference", fa, "--bam", bam, "--sfs", sfs, "--threads", str(threads), "--min-sv-length", "50", "--verbose"],
                        check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     out["call_s"] = round(time.perf_counter() - t0, 3)
-    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "debug" in ln or "stage" in ln][-30:]
+    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "[time]" in ln or "debug" in ln][-40:]
+    out["search_log"] = [ln for ln in r.stderr.splitlines() if "debug" in ln][-8:]
     called = []
     for line in c.stdout.decode().splitlines():
         if line.startswith("#"):
