@@ -275,6 +275,34 @@ typedef struct svdss_bam_result {
                                the turn, 2 the turn (carry, link), 3 fields / filters / scans, 4 unpack, 5 search, 6 results down */
 } svdss_bam_result_t;
 int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_result_t* out);
+/* The same front end (inflate, CRC, record chain, the turn) for `SVDSS call`, which needs whole records of FEW reads:
+ * Clusterer::load_batch keeps the primary alignments with mapq >= min_mapq whose read has SFS (clusterer.cpp:108-145),
+ * fill_clusters those that overlap a cluster (sam_itr_querys per cluster, :495-545).  A filter names what is kept: records
+ * without flags 4 / 256 / 2048, with mapq >= min_mapq, and -- when names and / or regions are given -- whose read name is
+ * in `names` (name i = names[name_off[i] .. name_off[i + 1])) or whose alignment [pos, bam_endpos) overlaps one of the
+ * regions [reg_beg, reg_end) of its reference (sorted by (tid, beg)).  Names are compared by a 64-bit hash: a kept record
+ * may rarely be one nobody asked for (the caller looks at the name anyway), a wanted one is never dropped.
+ * svdss_bam_select_run takes a batch like svdss_bam_batch_run; the kept records (block_size field first, as in the file)
+ * come back in file order at 4-aligned offsets of one page-locked buffer. */
+typedef struct svdss_bam_filter svdss_bam_filter_t;
+int svdss_bam_filter_create(int32_t device, int32_t min_mapq, int32_t n_ref, const char* names, const int64_t* name_off,
+                            int64_t n_names, const int32_t* reg_tid, const int32_t* reg_beg, const int32_t* reg_end,
+                            int64_t n_regions, svdss_bam_filter_t** out);
+void svdss_bam_filter_free(svdss_bam_filter_t* f);
+int svdss_bam_select_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_filter_t* f,
+                         int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                         const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                         svdss_bam_batch_t** out);
+typedef struct svdss_bam_selection {
+  int64_t n_records;        /* records of the batch */
+  int64_t n_selected;       /* kept */
+  int64_t n_bytes;
+  const int64_t* rec_off;   /* n_selected + 1: kept record k begins at bytes + rec_off[k] (its 4-byte block_size, then the record) */
+  const uint8_t* bytes;
+  double inflate_kernel_ms;
+  double stage_ms[8];
+} svdss_bam_selection_t;
+int svdss_bam_batch_selection(const svdss_bam_batch_t* b, svdss_bam_selection_t* out);
 const char* svdss_bam_batch_error(const svdss_bam_batch_t* b);
 void svdss_bam_batch_free(svdss_bam_batch_t* b);
 

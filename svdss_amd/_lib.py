@@ -99,6 +99,10 @@ SIGNATURES = {
     "svdss_bam_batch_run": (C.c_int, [_p, _i64, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p, _i32, C.POINTER(_p)]),
     "svdss_bam_batch_result": (C.c_int, [_p, _p]),
     "svdss_bam_batch_error": (C.c_char_p, [_p]),
+    "svdss_bam_filter_create": (C.c_int, [_i32, _i32, _i32, _p, _p, _i64, _p, _p, _p, _i64, C.POINTER(_p)]),
+    "svdss_bam_filter_free": (None, [_p]),
+    "svdss_bam_select_run": (C.c_int, [_p, _i64, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p, C.POINTER(_p)]),
+    "svdss_bam_batch_selection": (C.c_int, [_p, _p]),
     "svdss_bam_batch_free": (None, [_p]),
     "svdss_ref_upload": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
     "svdss_ref_free": (None, [_p]),

@@ -118,3 +118,73 @@ def search_bam(index, data, assemble=True, putative=False, batch_bytes=256 << 20
             lib.svdss_bam_batch_free(batch)
         lib.svdss_bam_stream_free(stream)
     return out, stats
+
+
+class BamSelection(C.Structure):
+    _fields_ = [("n_records", C.c_int64), ("n_selected", C.c_int64), ("n_bytes", C.c_int64), ("rec_off", C.POINTER(C.c_int64)),
+                ("bytes", C.POINTER(C.c_uint8)), ("inflate_kernel_ms", C.c_double), ("stage_ms", C.c_double * 8)]
+
+
+def select_bam(data, names=None, regions=None, min_mapq=0, batch_bytes=256 << 20, device=0):
+    """svdss_bam_select_run over a whole BAM file (bytes): the records `SVDSS call` keeps -- no flag 4 / 256 / 2048,
+    mapq >= min_mapq, and (when given) read name in `names` or alignment overlapping one of `regions` =
+    [(tid, beg, end)] sorted by (tid, beg).  Returns ([record bytes without the block_size field], counters)."""
+    blocks = bgzf.bgzf_blocks(data)
+    n_ref, skip = bam_header(data, blocks)
+    comp = np.frombuffer(bytes(data), dtype=np.uint8)
+    nm = b"".join(n.encode() if isinstance(n, str) else n for n in (names or []))
+    nm_off = np.zeros(len(names or []) + 1, dtype=np.int64)
+    if names:
+        nm_off[1:] = np.cumsum([len(n) for n in names])
+    rt = np.array([r[0] for r in (regions or [])], dtype=np.int32)
+    rb = np.array([r[1] for r in (regions or [])], dtype=np.int32)
+    re_ = np.array([r[2] for r in (regions or [])], dtype=np.int32)
+    flt = C.c_void_p()
+    rc = lib.svdss_bam_filter_create(device, min_mapq, n_ref, nm if names else None, nm_off.ctypes.data if names else None, len(names or []),
+                                     rt.ctypes.data if regions else None, rb.ctypes.data if regions else None,
+                                     re_.ctypes.data if regions else None, len(regions or []), C.byref(flt))
+    if rc:
+        raise SvdssError(rc, "svdss_bam_filter_create")
+    stream = C.c_void_p()
+    lib.svdss_bam_stream_create(n_ref, C.byref(stream))
+    batch = C.c_void_p()
+    out, stats = [], {"records": 0, "batches": 0}
+    try:
+        groups, cur, acc = [], [], 0
+        for b in blocks:
+            cur.append(b)
+            acc += b[2]
+            if acc >= batch_bytes:
+                groups.append(cur)
+                cur, acc = [], 0
+        groups.append(cur)
+        for seq, g in enumerate(groups):
+            rec = np.zeros(max(1, len(g)), dtype=[("coff", "<i8"), ("clen", "<i4"), ("isize", "<i4"), ("uoff", "<i8")])
+            crc = np.zeros(max(1, len(g)), dtype=np.uint32)
+            for i, b in enumerate(g):
+                rec[i] = (b[0], b[1], b[2], 0)
+                crc[i] = b[3]
+            rc = lib.svdss_bam_select_run(stream, seq, 1 if seq == len(groups) - 1 else 0, skip if seq == 0 else 0, flt, 1,
+                                          (C.c_void_p * 1)(comp.ctypes.data), (C.c_int64 * 1)(len(comp)), (C.c_void_p * 1)(rec.ctypes.data),
+                                          (C.c_void_p * 1)(crc.ctypes.data), (C.c_int64 * 1)(len(g)), C.byref(batch))
+            if rc:
+                e = SvdssError(rc, "svdss_bam_select_run")
+                e.detail = (lib.svdss_bam_batch_error(batch) or b"").decode() if batch else ""
+                raise e
+            r = BamSelection()
+            lib.svdss_bam_batch_selection(batch, C.byref(r))
+            stats["records"] += r.n_records
+            stats["batches"] += 1
+            if r.n_selected:
+                off = np.ctypeslib.as_array(r.rec_off, shape=(r.n_selected + 1,))
+                raw = C.string_at(r.bytes, r.n_bytes)
+                for k in range(r.n_selected):
+                    o = int(off[k])
+                    bs = struct.unpack_from("<i", raw, o)[0]
+                    out.append(raw[o + 4:o + 4 + bs])
+    finally:
+        if batch:
+            lib.svdss_bam_batch_free(batch)
+        lib.svdss_bam_stream_free(stream)
+        lib.svdss_bam_filter_free(flt)
+    return out, stats

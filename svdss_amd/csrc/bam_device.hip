@@ -445,6 +445,101 @@ __global__ void __launch_bounds__(256) unpack_kernel(const uint8_t* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ records selected for `call` (svdss_bam_select_run)
+__host__ __device__ inline uint64_t name_hash(const uint8_t* p, uint32_t n) {   // FNV-1a, 0 kept for "empty slot"
+  uint64_t h = 1469598103934665603ull;
+  for (uint32_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h ? h : 1;
+}
+
+struct SelP {
+  const uint8_t* buf;
+  const uint32_t* lists; int64_t list_cap;
+  const int32_t* seg_cnt; const int32_t* seg_base; const uint32_t* pre;
+  int32_t n_seg, min_mapq, n_ref;
+  int64_t n_rec;
+  const uint64_t* hash; uint64_t hash_mask;              // read names wanted (hash == nullptr: no such test)
+  const int64_t* reg_off; const int32_t* reg_beg; const int32_t* reg_runmax;   // regions per tid (reg_off == nullptr: none)
+  uint32_t* rpos;
+  int64_t *f_sel, *f_bytes;       // n_rec + 1 each
+  int64_t* hdr;
+};
+
+// block s < n_seg: the records of segment s; block n_seg: those that begin in the carried bytes.  A record is kept if it
+// passes the flag / mapq filters of clusterer.cpp:118-122 (= :535-540) and, when names and / or regions are given, is
+// named in the set or overlaps a region (either is enough: the host looks again, exactly)
+__global__ void __launch_bounds__(64) select_kernel(SelP M) {
+  const int s = blockIdx.x;
+  const int cnt = s < M.n_seg ? M.seg_cnt[s] : (int)(M.hdr[H_PRE] < 4 ? M.hdr[H_PRE] : 4);
+  const int base = s < M.n_seg ? M.seg_base[s] : 0;
+  const uint32_t* list = s < M.n_seg ? M.lists + (int64_t)s * M.list_cap : M.pre;
+  for (int i = threadIdx.x; i < cnt; i += 64) {
+    const int64_t gi = base + i;
+    const int64_t p = list[i];
+    const uint32_t bs = ld32(M.buf, p);
+    const int32_t tid = (int32_t)ld32(M.buf, p + 4), pos = (int32_t)ld32(M.buf, p + 8);
+    const uint32_t w3 = ld32(M.buf, p + 12), w4 = ld32(M.buf, p + 16);
+    const int32_t l_seq = (int32_t)ld32(M.buf, p + 20);
+    const uint32_t l_name = w3 & 0xffu, mapq = (w3 >> 8) & 0xffu, n_cig = w4 & 0xffffu, flag = w4 >> 16;
+    const int64_t head = 32 + (int64_t)l_name + 4 * (int64_t)n_cig + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
+    bool keep = false;
+    if (l_seq < 0 || head > (int64_t)bs) atomicOr((unsigned long long*)&M.hdr[H_ERR], (unsigned long long)E_CORRUPT);
+    else {
+      keep = !(flag & (4u | 2048u | 256u)) && (int32_t)mapq >= M.min_mapq;
+      if (keep && (M.hash || M.reg_off)) {
+        bool hit = false;
+        if (M.hash) {
+          const uint64_t h = name_hash(M.buf + p + 36, l_name ? l_name - 1 : 0);
+          for (uint64_t k = h & M.hash_mask;; k = (k + 1) & M.hash_mask) {
+            const uint64_t e = M.hash[k];
+            if (e == h) { hit = true; break; }
+            if (e == 0) break;
+          }
+        }
+        if (!hit && M.reg_off && tid >= 0 && tid < M.n_ref) {
+          const int64_t lo = M.reg_off[tid], hi = M.reg_off[tid + 1];
+          if (hi > lo) {
+            int64_t ref_len = 0;
+            const int64_t cg = p + 36 + l_name;
+            for (uint32_t k = 0; k < n_cig; ++k) {
+              const uint32_t c = ld32(M.buf, cg + 4 * (int64_t)k), op = c & 15u;
+              if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+            }
+            const int64_t a_beg = pos, a_end = (int64_t)pos + (ref_len ? ref_len : 1);      // bam_endpos
+            // regions sorted by start; runmax = running maximum of their ends: the first one whose running maximum
+            // passes a_beg overlaps iff it starts before a_end (csrc/call_host.cpp, fill_clusters)
+            int64_t a = lo, b = hi;
+            while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)M.reg_runmax[m] > a_beg) b = m; else a = m + 1; }
+            hit = a < hi && (int64_t)M.reg_beg[a] < a_end;
+          }
+        }
+        keep = hit;
+      }
+    }
+    M.rpos[gi] = (uint32_t)p;
+    M.f_sel[gi] = keep ? 1 : 0;
+    M.f_bytes[gi] = keep ? (((int64_t)bs + 4 + 3) & ~(int64_t)3) : 0;
+  }
+  if (s == 0 && threadIdx.x == 0) { M.f_sel[M.n_rec] = 0; M.f_bytes[M.n_rec] = 0; }
+}
+
+// one wavefront per kept record: its bytes (block_size field included) to a 4-aligned place of the output
+__global__ void __launch_bounds__(64) export_kernel(const uint8_t* __restrict__ buf, int64_t n_rec, const uint32_t* __restrict__ rpos,
+                                                    const int64_t* __restrict__ f_sel, const int64_t* __restrict__ s_sel,
+                                                    const int64_t* __restrict__ s_bytes, uint8_t* out, int64_t* out_off, int64_t* totals) {
+  const int64_t gi = blockIdx.x;
+  if (gi == n_rec) {
+    if (threadIdx.x == 0) { out_off[s_sel[gi]] = s_bytes[gi]; totals[0] = s_sel[gi]; totals[1] = s_bytes[gi]; }
+    return;
+  }
+  if (!f_sel[gi]) return;
+  const int64_t p = rpos[gi], o = s_bytes[gi];
+  const uint32_t n = ld32(buf, p) + 4u;
+  if (threadIdx.x == 0) out_off[s_sel[gi]] = o;
+  uint32_t* dst = (uint32_t*)(out + o);
+  for (uint32_t k = threadIdx.x; k < (n + 3) / 4; k += 64) dst[k] = ld32(buf, p + 4 * (int64_t)k);
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -468,12 +563,26 @@ struct svdss_bam_stream {
   int64_t n_rewalked = 0, n_segments = 0;
 };
 
+struct svdss_bam_filter {
+  int device = -1;
+  int32_t min_mapq = 0, n_ref = 0;
+  uint64_t* d_hash = nullptr;
+  uint64_t hash_mask = 0;
+  int64_t* d_reg_off = nullptr;
+  int32_t *d_reg_beg = nullptr, *d_reg_runmax = nullptr;
+};
+
 struct svdss_bam_batch {
   int device = -1;
   hipStream_t st = nullptr;
   DevBuf comp, blks, crcb, status, buf, seg, lists, pre, hdr, rpos, flags, scans, d_hp, tmp, o_small, d_names, sym_off, seq_src, reads, totals;
   uint8_t* h_pin = nullptr;        // page-locked staging: block tables up, small results down
   size_t h_pin_cap = 0;
+  DevBuf sel_out, sel_off;         // svdss_bam_select_run: the kept records, their offsets
+  uint8_t* h_sel = nullptr;        // ... on the host (page-locked)
+  size_t h_sel_cap = 0;
+  std::vector<int64_t> h_sel_off;
+  int64_t n_selected = 0, sel_bytes = 0;
   std::vector<int32_t> h_status;
   svdss_sfs_batch_t* sfs = nullptr;
   // results of the last run (host side)
@@ -531,6 +640,9 @@ extern "C" void svdss_bam_batch_free(svdss_bam_batch_t* b) {
                     &b->scans, &b->d_hp, &b->tmp, &b->o_small, &b->d_names, &b->sym_off, &b->seq_src, &b->reads, &b->totals})
     if (d->p) (void)hipFree(d->p);
   if (b->h_pin) (void)hipHostFree(b->h_pin);
+  if (b->h_sel) (void)hipHostFree(b->h_sel);
+  for (DevBuf* d : {&b->sel_out, &b->sel_off})
+    if (d->p) (void)hipFree(d->p);
   if (b->sfs) svdss_sfs_batch_free(b->sfs);
   if (b->e0) (void)hipEventDestroy(b->e0);
   if (b->e1) (void)hipEventDestroy(b->e1);
@@ -553,13 +665,29 @@ static void done_turn(svdss_bam_stream* s, int fail_code, const std::string& msg
   s->cv.notify_all();
 }
 
-extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_index_t* ix,
-                                   int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
-                                   const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
-                                   int32_t flags, svdss_bam_batch_t** out) {
-  if (!s || !ix || !out || seq < 0 || skip < 0 || n_chunks < 0) return SVDSS_EINVAL;
-  if (n_chunks > 0 && (!comp || !comp_bytes || !blocks || !crc || !n_blocks)) return SVDSS_EINVAL;
-  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;
+// What both entry points do first: the batch's blocks up, inflated, checked; the record chain of its segments; the batch's
+// turn at the carry.  On success the records of the batch are listed (F.W / F.seg_base / pre, F.hdr) and the turn is over.
+struct Front {
+  WalkP W;
+  int32_t* seg_base = nullptr;
+  int64_t hdr[H_N];
+  int64_t total_inf = 0, HEAD = 0;
+};
+
+#define BCHK(expr)                                                                                    \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      g_svdss_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
+      return fail(e_ == hipErrorOutOfMemory ? SVDSS_ENOMEM : SVDSS_EHIP, g_svdss_hip_err);            \
+    }                                                                                                 \
+  } while (0)
+#define RCHK(expr) do { const int rc_ = (expr); if (rc_ != SVDSS_OK) return fail(rc_, g_svdss_hip_err); } while (0)
+
+static int batch_front(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, int device,
+                       int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                       const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                       svdss_bam_batch_t** out, Front& F) {
   // a failure before the batch had its turn still has to pass the turn on: the batches behind it wait for it
   bool had_turn = false;
   auto fail = [&](int code, const std::string& msg) {
@@ -570,24 +698,16 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
     if (*out) (*out)->err = msg;
     return code;
   };
-#define BCHK(expr)                                                                                    \
-  do {                                                                                                \
-    hipError_t e_ = (expr);                                                                           \
-    if (e_ != hipSuccess) {                                                                           \
-      g_svdss_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
-      return fail(e_ == hipErrorOutOfMemory ? SVDSS_ENOMEM : SVDSS_EHIP, g_svdss_hip_err);            \
-    }                                                                                                 \
-  } while (0)
-#define RCHK(expr) do { const int rc_ = (expr); if (rc_ != SVDSS_OK) return fail(rc_, g_svdss_hip_err); } while (0)
-  BCHK(hipSetDevice(ix->device));
+  if (n_chunks > 0 && (!comp || !comp_bytes || !blocks || !crc || !n_blocks)) return fail(SVDSS_EINVAL, "bad argument");
+  BCHK(hipSetDevice(device));
   svdss_bam_batch* b = *out;
   if (!b) {
     b = new (std::nothrow) svdss_bam_batch();
     if (!b) return fail(SVDSS_ENOMEM, "out of memory");
-    b->device = ix->device;
+    b->device = device;
     *out = b;
   }
-  if (b->device != ix->device) return fail(SVDSS_EINVAL, "batch object of another device");
+  if (b->device != device) return fail(SVDSS_EINVAL, "batch object of another device");
   if (!b->st) BCHK(svdss_make_stream(&b->st, "SVDSS_SEARCH_CUS"));
   if (!b->e0) { BCHK(hipEventCreate(&b->e0)); BCHK(hipEventCreate(&b->e1)); }
   const hipStream_t st = b->st;
@@ -738,6 +858,35 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   done_turn(s, turn_code, turn_msg);
   if (turn_code) { b->err = turn_msg; return turn_code; }
   lap(2);   // the turn: carry in, link, carry out
+  F.W = W; F.seg_base = seg_base; F.total_inf = total_inf; F.HEAD = HEAD;
+  memcpy(F.hdr, hdr, sizeof hdr);
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_index_t* ix,
+                                   int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                                   const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                                   int32_t flags, svdss_bam_batch_t** out) {
+  if (!s || !ix || !out || seq < 0 || skip < 0 || n_chunks < 0) return SVDSS_EINVAL;
+  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;   // (the caller's mistake: the stream's turn is not taken)
+  Front F;
+  {
+    const int rc = batch_front(s, seq, is_last, skip, ix->device, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, out, F);
+    if (rc != SVDSS_OK) return rc;
+  }
+  svdss_bam_batch* b = *out;
+  const hipStream_t st = b->st;
+  const WalkP& W = F.W;
+  int32_t* seg_base = F.seg_base;
+  const int64_t* hdr = F.hdr;
+  const int64_t total_inf = F.total_inf, HEAD = F.HEAD;
+  auto fail = [&](int code, const std::string& msg) { b->err = msg; return code; };
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](int k) {
+    const auto t = std::chrono::steady_clock::now();
+    b->stage_ms[k] = std::chrono::duration<double, std::milli>(t - t_prev).count();
+    t_prev = t;
+  };
 
   // ---- fields, filters, tags; where everything goes
   const int64_t n_rec = hdr[H_NREC];
@@ -853,8 +1002,148 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   BCHK(hipStreamSynchronize(st));
   lap(6);   // results down
   return SVDSS_OK;
-#undef BCHK
-#undef RCHK
+}
+
+extern "C" int svdss_bam_filter_create(int32_t device, int32_t min_mapq, int32_t n_ref, const char* names, const int64_t* name_off,
+                                       int64_t n_names, const int32_t* reg_tid, const int32_t* reg_beg, const int32_t* reg_end,
+                                       int64_t n_regions, svdss_bam_filter_t** out) {
+  if (!out || device < 0 || n_ref < 0 || n_names < 0 || n_regions < 0) return SVDSS_EINVAL;
+  if ((n_names > 0 && (!names || !name_off)) || (n_regions > 0 && (!reg_tid || !reg_beg || !reg_end))) return SVDSS_EINVAL;
+  HIPCHK(hipSetDevice(device));
+  svdss_bam_filter* f = new (std::nothrow) svdss_bam_filter();
+  if (!f) return SVDSS_ENOMEM;
+  f->device = device; f->min_mapq = min_mapq; f->n_ref = n_ref;
+  auto bail = [&](int code) { svdss_bam_filter_free(f); return code; };
+  try {
+    if (n_names > 0) {
+      uint64_t size = 64;
+      while (size < 2 * (uint64_t)n_names) size <<= 1;
+      std::vector<uint64_t> tab((size_t)size, 0);
+      for (int64_t i = 0; i < n_names; ++i) {
+        if (name_off[i + 1] < name_off[i]) return bail(SVDSS_EINVAL);
+        const uint64_t h = name_hash((const uint8_t*)names + name_off[i], (uint32_t)(name_off[i + 1] - name_off[i]));
+        for (uint64_t k = h & (size - 1);; k = (k + 1) & (size - 1)) {
+          if (tab[(size_t)k] == h) break;
+          if (tab[(size_t)k] == 0) { tab[(size_t)k] = h; break; }
+        }
+      }
+      if (hipMalloc((void**)&f->d_hash, size * 8) != hipSuccess) return bail(SVDSS_ENOMEM);
+      if (hipMemcpy(f->d_hash, tab.data(), size * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(SVDSS_EHIP);
+      f->hash_mask = size - 1;
+    }
+    if (n_regions > 0) {
+      std::vector<int64_t> off((size_t)n_ref + 1, 0);
+      std::vector<int32_t> runmax((size_t)n_regions);
+      for (int64_t i = 0; i < n_regions; ++i) {
+        if (reg_tid[i] < 0 || reg_tid[i] >= n_ref) return bail(SVDSS_EINVAL);
+        if (i > 0 && (reg_tid[i] < reg_tid[i - 1] || (reg_tid[i] == reg_tid[i - 1] && reg_beg[i] < reg_beg[i - 1]))) return bail(SVDSS_EINVAL);
+        ++off[(size_t)reg_tid[i] + 1];
+        runmax[(size_t)i] = (i > 0 && reg_tid[i] == reg_tid[i - 1]) ? std::max(runmax[(size_t)i - 1], reg_end[i]) : reg_end[i];
+      }
+      for (int32_t t = 0; t < n_ref; ++t) off[(size_t)t + 1] += off[(size_t)t];
+      if (hipMalloc((void**)&f->d_reg_off, off.size() * 8) != hipSuccess || hipMalloc((void**)&f->d_reg_beg, (size_t)n_regions * 4) != hipSuccess ||
+          hipMalloc((void**)&f->d_reg_runmax, (size_t)n_regions * 4) != hipSuccess)
+        return bail(SVDSS_ENOMEM);
+      if (hipMemcpy(f->d_reg_off, off.data(), off.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(f->d_reg_beg, reg_beg, (size_t)n_regions * 4, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(f->d_reg_runmax, runmax.data(), (size_t)n_regions * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(SVDSS_EHIP);
+    }
+  } catch (...) { return bail(SVDSS_ENOMEM); }
+  *out = f;
+  return SVDSS_OK;
+}
+
+extern "C" void svdss_bam_filter_free(svdss_bam_filter_t* f) {
+  if (!f) return;
+  if (f->device >= 0) (void)hipSetDevice(f->device);
+  if (f->d_hash) (void)hipFree(f->d_hash);
+  if (f->d_reg_off) (void)hipFree(f->d_reg_off);
+  if (f->d_reg_beg) (void)hipFree(f->d_reg_beg);
+  if (f->d_reg_runmax) (void)hipFree(f->d_reg_runmax);
+  delete f;
+}
+
+extern "C" int svdss_bam_select_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_filter_t* f,
+                                    int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                                    const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                                    svdss_bam_batch_t** out) {
+  if (!s || !f || !out || seq < 0 || skip < 0 || n_chunks < 0) return SVDSS_EINVAL;
+  Front F;
+  {
+    const int rc = batch_front(s, seq, is_last, skip, f->device, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, out, F);
+    if (rc != SVDSS_OK) return rc;
+  }
+  svdss_bam_batch* b = *out;
+  const hipStream_t st = b->st;
+  const WalkP& W = F.W;
+  auto fail = [&](int code, const std::string& msg) { b->err = msg; return code; };
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](int k) {
+    const auto t = std::chrono::steady_clock::now();
+    b->stage_ms[k] = std::chrono::duration<double, std::milli>(t - t_prev).count();
+    t_prev = t;
+  };
+  const int64_t n_rec = F.hdr[H_NREC];
+  b->n_records = n_rec;
+  b->n_selected = 0; b->sel_bytes = 0;
+  RCHK(ensure(b->rpos, sizeof(uint32_t) * (size_t)(n_rec + 1)));
+  RCHK(ensure(b->flags, sizeof(int64_t) * 2 * (size_t)(n_rec + 1)));
+  RCHK(ensure(b->scans, sizeof(int64_t) * 2 * (size_t)(n_rec + 1)));
+  SelP M;
+  M.buf = W.buf; M.lists = W.lists; M.list_cap = W.list_cap; M.seg_cnt = W.seg_cnt; M.seg_base = F.seg_base; M.pre = (const uint32_t*)b->pre.p;
+  M.n_seg = W.n_seg; M.min_mapq = f->min_mapq; M.n_ref = f->n_ref; M.n_rec = n_rec;
+  M.hash = f->d_hash; M.hash_mask = f->hash_mask; M.reg_off = f->d_reg_off; M.reg_beg = f->d_reg_beg; M.reg_runmax = f->d_reg_runmax;
+  M.rpos = (uint32_t*)b->rpos.p;
+  M.f_sel = (int64_t*)b->flags.p; M.f_bytes = M.f_sel + (n_rec + 1);
+  M.hdr = (int64_t*)b->hdr.p;
+  hipLaunchKernelGGL(select_kernel, dim3((unsigned)W.n_seg + 1), dim3(64), 0, st, M);
+  BCHK(hipGetLastError());
+  int64_t* sc = (int64_t*)b->scans.p;
+  {
+    size_t tb = 0;
+    BCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, M.f_sel, sc, (int)(n_rec + 1), st));
+    RCHK(ensure(b->tmp, tb + 256));
+    for (int k = 0; k < 2; ++k) {
+      size_t t2 = b->tmp.cap;
+      BCHK(hipcub::DeviceScan::ExclusiveSum(b->tmp.p, t2, M.f_sel + (int64_t)k * (n_rec + 1), sc + (int64_t)k * (n_rec + 1), (int)(n_rec + 1), st));
+    }
+  }
+  // (how much is kept is only known on the device: bounded by the batch itself)
+  RCHK(ensure(b->sel_out, (size_t)(F.total_inf + F.HEAD) + 4 * (size_t)(n_rec + 1) + 64));
+  RCHK(ensure(b->sel_off, sizeof(int64_t) * (size_t)(n_rec + 2)));
+  hipLaunchKernelGGL(export_kernel, dim3((unsigned)(n_rec + 1)), dim3(64), 0, st, W.buf, n_rec, (const uint32_t*)M.rpos, (const int64_t*)M.f_sel,
+                     (const int64_t*)sc, (const int64_t*)(sc + (n_rec + 1)), (uint8_t*)b->sel_out.p, (int64_t*)b->sel_off.p, (int64_t*)b->totals.p);
+  BCHK(hipGetLastError());
+  int64_t totals[2] = {0, 0}, hdr2[H_N] = {0};
+  BCHK(hipMemcpyAsync(totals, b->totals.p, sizeof totals, hipMemcpyDeviceToHost, st));
+  BCHK(hipMemcpyAsync(hdr2, b->hdr.p, sizeof hdr2, hipMemcpyDeviceToHost, st));
+  BCHK(hipStreamSynchronize(st));
+  lap(3);
+  if (hdr2[H_ERR] & E_CORRUPT) return fail(SVDSS_EIO, "corrupt record");
+  b->n_selected = totals[0];
+  b->sel_bytes = totals[1];
+  if ((size_t)totals[1] + 64 > b->h_sel_cap || !b->h_sel) {
+    if (b->h_sel) { (void)hipHostFree(b->h_sel); b->h_sel = nullptr; b->h_sel_cap = 0; }
+    const size_t want = (size_t)totals[1] + ((size_t)totals[1] >> 2) + ((size_t)1 << 20);
+    BCHK(hipHostMalloc((void**)&b->h_sel, want, hipHostMallocDefault));
+    b->h_sel_cap = want;
+  }
+  try { b->h_sel_off.resize((size_t)totals[0] + 1); } catch (...) { return fail(SVDSS_ENOMEM, "out of memory"); }
+  BCHK(hipMemcpyAsync(b->h_sel_off.data(), b->sel_off.p, sizeof(int64_t) * (size_t)(totals[0] + 1), hipMemcpyDeviceToHost, st));
+  if (totals[1] > 0) BCHK(hipMemcpyAsync(b->h_sel, b->sel_out.p, (size_t)totals[1], hipMemcpyDeviceToHost, st));
+  BCHK(hipStreamSynchronize(st));
+  lap(6);
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_bam_batch_selection(const svdss_bam_batch_t* b, svdss_bam_selection_t* r) {
+  if (!b || !r) return SVDSS_EINVAL;
+  r->n_records = b->n_records; r->n_selected = b->n_selected; r->n_bytes = b->sel_bytes;
+  r->rec_off = b->h_sel_off.data(); r->bytes = b->h_sel;
+  r->inflate_kernel_ms = b->inflate_ms;
+  for (int k = 0; k < 8; ++k) r->stage_ms[k] = b->stage_ms[k];
+  return SVDSS_OK;
 }
 
 extern "C" int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_result_t* r) {
@@ -869,3 +1158,6 @@ extern "C" int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_resu
 }
 
 extern "C" const char* svdss_bam_batch_error(const svdss_bam_batch_t* b) { return b ? b->err.c_str() : ""; }
+
+#undef BCHK
+#undef RCHK

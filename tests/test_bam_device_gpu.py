@@ -259,3 +259,58 @@ def test_binary_device_path_writes_the_host_paths_bytes(case, tmp_path):
     (tmp_path / "bad.bam").write_bytes(bytes(data))
     r = subprocess.run([BIN, "search", "--index", str(fmd), "--bam", str(tmp_path / "bad.bam")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 1 and "critical" in r.stderr
+
+
+def test_select_records_by_name_and_by_region(case):
+    """svdss_bam_select_run, what `SVDSS call` keeps of a BAM: against the same filters applied in Python to the records
+    as written (clusterer.cpp:118-122, :535-545), with batches so small that records straddle them."""
+    ref, ix, fm, reads, names = case
+    rng = np.random.default_rng(41)
+    recs, metas = [], []
+    for i, (nm, rd) in enumerate(zip(names, reads)):
+        flag = [0, 16, 256, 2048, 4, 0, 0, 1024][i % 8]
+        mapq = [60, 5, 20, 19, 0, 33][i % 6]
+        pos = int(rng.integers(0, 140000))
+        # CIGARs with every reference-consuming and query-consuming operation
+        L = len(rd)
+        if i % 3 == 0:
+            cigar = [("S", 5), ("M", L - 25), ("D", 40), ("I", 10), ("M", 10)]
+        elif i % 3 == 1:
+            cigar = [("M", L // 2), ("N", 300), ("=", L - L // 2 - 3), ("X", 3)]
+        else:
+            cigar = [("M", L)]
+        ref_len = sum(l for op, l in cigar if op in "MDN=X")
+        recs.append(bam_writer.record(nm, flag, 0, pos, mapq, cigar, synth.to_ascii(rd), [("HP", "C", i % 3)]))
+        metas.append((nm, flag, mapq, pos, pos + max(ref_len, 1)))
+    data = _bgzf_levels(_raw_bam([("chr1", 150000)], recs), rng, block=30000)
+    bodies = [r[4:] for r in recs]
+
+    def expect(min_mapq, wanted=None, regions=None):
+        out = []
+        for body, (nm, flag, mapq, a, b) in zip(bodies, metas):
+            if flag & (4 | 256 | 2048) or mapq < min_mapq:
+                continue
+            if wanted is not None or regions is not None:
+                hit = wanted is not None and nm in wanted
+                hit = hit or (regions is not None and any(t == 0 and a < e and b > s for t, s, e in regions))
+                if not hit:
+                    continue
+            out.append(body)
+        return out
+    wanted = [names[i] for i in range(0, 400, 7)] + ["not/in/the/file"]
+    got, st = bamdev.select_bam(data, names=wanted, min_mapq=20, batch_bytes=40 << 10)
+    assert st["records"] == 400 and st["batches"] > 5
+    assert got == expect(20, wanted=set(wanted))
+    regions = sorted((0, int(s), int(s) + int(rng.integers(1, 3000))) for s in rng.integers(0, 150000, size=25))
+    got, st = bamdev.select_bam(data, regions=regions, min_mapq=0, batch_bytes=100 << 10)
+    assert got == expect(0, regions=regions) and 0 < len(got) < 300
+    got, _ = bamdev.select_bam(data, names=wanted, regions=regions, min_mapq=20)
+    assert got == expect(20, wanted=set(wanted), regions=regions)
+    got, _ = bamdev.select_bam(data, min_mapq=30)           # no names, no regions: the flag / mapq filters alone
+    assert got == expect(30)
+    # a region that ends exactly where an alignment begins does not overlap it; one base more does
+    nm0, f0, q0, a0, b0 = next(m for m in metas if not m[1] & (4 | 256 | 2048))
+    g1, _ = bamdev.select_bam(data, regions=[(0, max(a0 - 10, 0), a0)])
+    g2, _ = bamdev.select_bam(data, regions=[(0, max(a0 - 10, 0), a0 + 1)])
+    assert g1 == expect(0, regions=[(0, max(a0 - 10, 0), a0)]) and g2 == expect(0, regions=[(0, max(a0 - 10, 0), a0 + 1)])
+    assert len(g2) > len(g1)
