@@ -1,0 +1,291 @@
+// bam_device_select.h -- host side of the device path for callers that need whole records of a few reads (`SVDSS call`,
+// csrc/bam_device.hip svdss_bam_select_run): the BAM header probe, and a reader that hands out, in file order, the records
+// a svdss_bam_filter_t keeps.  Scanner (loader threads) -> batcher -> feeding threads (one batch object each) -> ordered
+// output; the caller sees plain record bytes.
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/svdss_hip.h"
+#include "bam_reader.h"
+#include "bgzf_scanner.h"
+
+// The BAM header read on the host (the first BGZF members, zlib / libdeflate): number of reference sequences and the
+// length of the header in the inflated stream -- where the first record begins (sam_hdr_read, ping_pong.cpp:248).
+inline bool bam_header_probe(const std::string& path, int32_t& n_ref, int64_t& skip, std::string& err, std::vector<std::string>* ref_names) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { err = "cannot open file"; return false; }
+  std::vector<uint8_t> comp, buf;
+  size_t pos = 0;
+  bool eof = false;
+  BgzfInflater inf;
+  auto more = [&]() -> bool {        // one more member inflated onto buf
+    for (;;) {
+      if (pos + 18 <= comp.size()) {
+        const uint8_t* h = comp.data() + pos;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BAM file"; return false; }
+        uint16_t xlen;
+        memcpy(&xlen, h + 10, 2);
+        int bsize = -1;
+        if (pos + 12 + xlen <= comp.size()) {
+          for (size_t o = 0; o + 4 <= xlen;) {
+            const uint8_t* x = h + 12 + o;
+            uint16_t slen;
+            memcpy(&slen, x + 2, 2);
+            if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) { uint16_t v; memcpy(&v, x + 4, 2); bsize = v; break; }
+            o += 4u + slen;
+          }
+          if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) { err = "BGZF block without BC field"; return false; }
+          if (pos + (size_t)bsize + 1 <= comp.size()) {
+            const size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
+            uint32_t crc, isize;
+            memcpy(&crc, h + 12 + xlen + clen, 4);
+            memcpy(&isize, h + 12 + xlen + clen + 4, 4);
+            if (isize > 65536u) { err = "bad BGZF block"; return false; }
+            const size_t at = buf.size();
+            buf.resize(at + isize);
+            if (isize) if (const char* e = inf.run(h + 12 + xlen, clen, buf.data() + at, isize, crc)) { err = e; return false; }
+            pos += (size_t)bsize + 1;
+            return true;
+          }
+        }
+      }
+      if (eof) { err = "truncated header"; return false; }
+      const size_t at = comp.size();
+      comp.resize(at + ((size_t)256 << 10));
+      const size_t got = fread(comp.data() + at, 1, (size_t)256 << 10, f);
+      comp.resize(at + got);
+      if (got == 0) eof = true;
+    }
+  };
+  auto need = [&](size_t n) -> bool { while (buf.size() < n) if (!more()) return false; return true; };
+  bool ok = false;
+  do {
+    if (!need(12)) break;
+    if (memcmp(buf.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; break; }
+    int32_t l_text;
+    memcpy(&l_text, buf.data() + 4, 4);
+    if (l_text < 0) { err = "corrupt header"; break; }
+    if (!need(12 + (size_t)l_text)) break;
+    memcpy(&n_ref, buf.data() + 8 + l_text, 4);
+    if (n_ref < 0) { err = "corrupt header"; break; }
+    size_t o = 12 + (size_t)l_text;
+    bool bad = false;
+    for (int32_t i = 0; i < n_ref && !bad; ++i) {
+      if (!need(o + 4)) { bad = true; break; }
+      int32_t l_name;
+      memcpy(&l_name, buf.data() + o, 4);
+      if (l_name < 0) { err = "corrupt header"; bad = true; break; }
+      if (!need(o + 4 + (size_t)l_name + 4)) { bad = true; break; }
+      if (ref_names) {
+        std::string nm((const char*)buf.data() + o + 4, (size_t)l_name);
+        if (!nm.empty() && nm.back() == '\0') nm.pop_back();
+        ref_names->push_back(nm);
+      }
+      o += 4 + (size_t)l_name + 4;
+    }
+    if (bad) break;
+    skip = (int64_t)o;
+    ok = true;
+  } while (false);
+  fclose(f);
+  return ok;
+}
+
+
+// the kept records of one device batch, in file order: record k = bytes[off[k] + 4 ..), block_size at bytes[off[k]]
+struct SelectedBatch {
+  std::vector<uint8_t> bytes;
+  std::vector<int64_t> off;
+  uint64_t n_records = 0;       // records of the batch, kept or not
+  double stage_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, inflate_kernel_s = 0;
+};
+
+// a record's view (BamReader::RawView: the zero-copy form the host readers hand out) over bytes that hold it
+inline bool view_of_record(const uint8_t* rec, size_t avail, BamReader::RawView& v) {
+  if (avail < 36) return false;
+  int32_t block_size;
+  memcpy(&block_size, rec, 4);
+  if (block_size < 32 || (size_t)block_size + 4 > avail) return false;
+  const uint8_t* core = rec + 4;
+  v.own.reset();
+  v.p = core;
+  uint16_t n_cigar;
+  memcpy(&v.tid, core, 4);
+  memcpy(&v.pos, core + 4, 4);
+  v.l_name = core[8];
+  v.mapq = core[9];
+  memcpy(&n_cigar, core + 12, 2);
+  v.n_cigar = n_cigar;
+  memcpy(&v.flag, core + 14, 2);
+  memcpy(&v.l_seq, core + 16, 4);
+  if (v.l_seq < 0) return false;
+  const size_t head = 32 + (size_t)v.l_name + 4u * v.n_cigar + ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq;
+  if (head > (size_t)block_size) return false;
+  v.l_aux = (uint32_t)((size_t)block_size - head);
+  return true;
+}
+
+class DeviceBamSelect {
+ public:
+  // filters[d]: the filter on device d (one per GPU used); feeders: feeding threads per GPU
+  DeviceBamSelect(const std::string& path, const std::vector<svdss_bam_filter_t*>& filters, const std::vector<int>& devices, int32_t n_ref,
+                  int64_t skip, int feeders, int64_t batch_bytes)
+      : filters_(filters), devices_(devices), skip_(skip), target_(batch_bytes) {
+    BgzfScanner::Hooks hooks;
+    hooks.host_alloc = svdss_host_alloc;
+    hooks.host_free = svdss_host_free;
+    const size_t slab = (getenv("SVDSS_BAM_SLAB_KB") && atoll(getenv("SVDSS_BAM_SLAB_KB")) >= 64 ? (size_t)atoll(getenv("SVDSS_BAM_SLAB_KB")) << 10 : (size_t)16 << 20);
+    const size_t per_batch = (size_t)target_ / slab + 2;
+    feeders = std::max(1, feeders);
+    sc_.reset(new BgzfScanner(path, hooks, slab, 8, 8 + ((size_t)filters.size() * (size_t)feeders + 3) * per_batch));
+    if (!sc_->ok()) { err_ = "cannot open file"; finished_ = true; return; }
+    if (svdss_bam_stream_create(n_ref, &stream_) != SVDSS_OK) { err_ = "out of memory"; finished_ = true; return; }
+    n_feeders_ = filters_.size() * (size_t)feeders;
+    batcher_ = std::thread([this] { batch_loop(); });
+    for (size_t d = 0; d < filters_.size(); ++d)
+      for (int k = 0; k < feeders; ++k) feeders_.emplace_back([this, d] { feed_loop(d); });
+  }
+  ~DeviceBamSelect() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    if (batcher_.joinable()) batcher_.join();
+    for (std::thread& t : feeders_) t.join();
+    if (stream_) svdss_bam_stream_free(stream_);
+  }
+  DeviceBamSelect(const DeviceBamSelect&) = delete;
+  DeviceBamSelect& operator=(const DeviceBamSelect&) = delete;
+
+  // the next batch in file order; nullptr at the end of the file or on an error (error() says which)
+  std::unique_ptr<SelectedBatch> next() {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return done_.count(want_) || !err_.empty() || (finished_ && done_.empty()); });
+    if (!err_.empty()) return nullptr;
+    auto it = done_.find(want_);
+    if (it == done_.end()) return nullptr;
+    std::unique_ptr<SelectedBatch> b = std::move(it->second);
+    done_.erase(it);
+    ++want_;
+    lk.unlock();
+    cv_.notify_all();
+    return b;
+  }
+  const std::string& error() const { return err_; }
+  int64_t segments_walked_again(int64_t* n_segments) const { return stream_ ? svdss_bam_stream_rewalked(stream_, n_segments) : 0; }
+
+ private:
+  struct Job { uint64_t seq = 0; bool last = false; std::vector<std::unique_ptr<CompChunk>> chunks; };
+  void fail(const std::string& e) {
+    { std::lock_guard<std::mutex> lk(m_); if (err_.empty()) err_ = e; }
+    cv_.notify_all();
+  }
+  void batch_loop() {
+    std::unique_ptr<Job> cur(new Job);
+    int64_t acc = 0;
+    uint64_t seq = 0;
+    bool any_last = false;
+    auto push = [&](std::unique_ptr<Job> j) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return jobs_.size() < 2 || stop_ || !err_.empty(); });
+      if (stop_ || !err_.empty()) return false;
+      jobs_.push_back(std::move(j));
+      lk.unlock();
+      cv_.notify_all();
+      return true;
+    };
+    while (std::unique_ptr<CompChunk> c = sc_->next()) {
+      acc += c->inflated;
+      const bool last = c->last;
+      cur->chunks.push_back(std::move(c));
+      if (acc >= target_ || last) {
+        cur->seq = seq++;
+        cur->last = last;
+        any_last = any_last || last;
+        if (!push(std::move(cur))) return;
+        cur.reset(new Job);
+        acc = 0;
+      }
+    }
+    if (!sc_->error().empty()) { fail(sc_->error()); return; }
+    if (!any_last) { cur->seq = seq++; cur->last = true; if (!push(std::move(cur))) return; }
+    { std::lock_guard<std::mutex> lk(m_); jobs_closed_ = true; }
+    cv_.notify_all();
+  }
+  void feed_loop(size_t d) {
+    svdss_bam_batch_t* batch = nullptr;
+    std::vector<const uint8_t*> comp;
+    std::vector<int64_t> comp_bytes, n_blocks;
+    std::vector<const svdss_bgzf_block_t*> blocks;
+    std::vector<const uint32_t*> crcs;
+    for (;;) {
+      std::unique_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !jobs_.empty() || jobs_closed_ || stop_ || !err_.empty(); });
+        if (stop_ || !err_.empty() || jobs_.empty()) break;
+        job = std::move(jobs_.front());
+        jobs_.erase(jobs_.begin());
+      }
+      cv_.notify_all();
+      comp.clear(); comp_bytes.clear(); n_blocks.clear(); blocks.clear(); crcs.clear();
+      for (const std::unique_ptr<CompChunk>& c : job->chunks) {
+        comp.push_back(c->data); comp_bytes.push_back((int64_t)c->n_bytes); n_blocks.push_back((int64_t)c->blocks.size());
+        blocks.push_back(c->blocks.data()); crcs.push_back(c->crc.data());
+      }
+      const int rc = svdss_bam_select_run(stream_, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? skip_ : 0, filters_[d], (int32_t)comp.size(),
+                                          comp.data(), comp_bytes.data(), blocks.data(), crcs.data(), n_blocks.data(), &batch);
+      for (std::unique_ptr<CompChunk>& c : job->chunks) sc_->recycle(std::move(c));
+      if (rc != SVDSS_OK) {
+        std::string msg = batch ? svdss_bam_batch_error(batch) : "";
+        if (msg.empty()) msg = svdss_bam_stream_error(stream_);
+        if (msg.empty()) msg = std::string(svdss_strerror(rc)) + " " + svdss_last_hip_error();
+        fail(msg);
+        break;
+      }
+      svdss_bam_selection_t r;
+      (void)svdss_bam_batch_selection(batch, &r);
+      std::unique_ptr<SelectedBatch> out(new SelectedBatch);
+      out->n_records = (uint64_t)r.n_records;
+      out->off.assign(r.rec_off, r.rec_off + r.n_selected + 1);
+      out->bytes.assign(r.bytes, r.bytes + r.n_bytes);
+      for (int k = 0; k < 8; ++k) out->stage_s[k] = r.stage_ms[k] * 1e-3;
+      out->inflate_kernel_s = r.inflate_kernel_ms * 1e-3;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        const uint64_t sq = job->seq;
+        cv_.wait(lk, [&] { return stop_ || done_.size() < 8 || done_.begin()->first > sq; });
+        done_[sq] = std::move(out);
+      }
+      cv_.notify_all();
+    }
+    if (batch) svdss_bam_batch_free(batch);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      if (++feeders_done_ == n_feeders_) finished_ = true;
+    }
+    cv_.notify_all();
+  }
+
+  std::vector<svdss_bam_filter_t*> filters_;
+  std::vector<int> devices_;
+  int64_t skip_ = 0, target_ = 0;
+  std::unique_ptr<BgzfScanner> sc_;
+  svdss_bam_stream_t* stream_ = nullptr;
+  std::thread batcher_;
+  std::vector<std::thread> feeders_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<std::unique_ptr<Job>> jobs_;
+  bool jobs_closed_ = false, stop_ = false, finished_ = false;
+  size_t feeders_done_ = 0, n_feeders_ = 0;
+  std::map<uint64_t, std::unique_ptr<SelectedBatch>> done_;
+  uint64_t want_ = 0;
+  std::string err_;
+};

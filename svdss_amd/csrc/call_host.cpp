@@ -26,6 +26,7 @@
 #include "../../include/svdss_hip.h"
 #include "bai_index.h"
 #include "bam_reader.h"
+#include "bam_device_select.h"
 #include "gpu_inflate_hook.h"
 #include "sfs_file.h"
 #include "sv_record.h"
@@ -461,6 +462,13 @@ struct CallRun {
   std::vector<Clip> clips;               // --clipped
   // The inflated records of pass 1 are kept for pass 2 when they fit in memory (a second inflate of the whole file
   // otherwise): SVDSS_CALL_CACHE_GB, default 40 % of MemAvailable, at most 64 GiB.
+  bool dev_pass = false;                 // the BAM is read through the device path (csrc/bam_device.hip): no record cache
+  int64_t bam_skip = 0;                  // the BAM header's length in the inflated stream
+  uint64_t n_records_seen = 0;
+  static int64_t bam_batch_bytes() {
+    const char* e = getenv("SVDSS_BAM_BATCH_MB");
+    return (e && atoll(e) > 0 ? atoll(e) : 256) << 20;
+  }
   std::vector<BamReader::RawView> cache_views;
   std::vector<std::shared_ptr<BamReader::Bytes>> cache_chunks;
   size_t cache_bytes = 0, cache_limit = 0;
@@ -527,11 +535,44 @@ struct CallRun {
       if (cache_limit == 0) cache_ok = false;
     }
     {
-      BamReader bam(o.bam);
-      // (--gpus N: the chunks of pass 1 are inflated on all N GPUs in turn, as `search` does)
-      svdss_enable_gpu_inflate(bam, 0, std::max(1, std::min(o.gpus, svdss_device_count())));
-      if (!bam.ok() || !bam.read_header()) die("cannot read " + o.bam + ": " + bam.error());
-      ref_names = bam.ref_names();
+      // Records handled on the GPU (csrc/bam_device.hip, svdss_bam_select_run; the default when there is a GPU and the
+      // input is a regular file): only the primary, mapq-ok alignments of reads that HAVE SFS come back to the host --
+      // the records clusterer.cpp:108-145 keeps -- instead of every inflated byte.  No record cache then: pass 2 goes
+      // through the BAI index, or reads the file again through the same path with the cluster regions as the filter.
+      // SVDSS_BAM_DEVICE=0: the host reader (chunks inflated on the GPU or the host, records sliced here).
+      const bool dev_bam = svdss_device_count() > 0 && !(getenv("SVDSS_BAM_DEVICE") && atoi(getenv("SVDSS_BAM_DEVICE")) == 0);
+      std::unique_ptr<BamReader> bam_p;
+      std::unique_ptr<DeviceBamSelect> sel;
+      std::vector<svdss_bam_filter_t*> filters;
+      int32_t n_ref_hdr = 0;
+      if (dev_bam) {
+        std::string herr;
+        if (!bam_header_probe(o.bam, n_ref_hdr, bam_skip, herr, &ref_names)) die("cannot read " + o.bam + ": " + herr);
+        std::string names;
+        std::vector<int64_t> name_off(1, 0);
+        for (const auto& kv : C.sfs) { names += kv.first; name_off.push_back((int64_t)names.size()); }
+        const int n_dev = std::max(1, std::min(o.gpus, svdss_device_count()));
+        std::vector<int> devs;
+        for (int d = 0; d < n_dev; ++d) {
+          svdss_bam_filter_t* f = nullptr;
+          check(svdss_bam_filter_create(d, (int32_t)std::min<unsigned>(o.min_mapq, 256u), n_ref_hdr, names.data(), name_off.data(), (int64_t)name_off.size() - 1,
+                                        nullptr, nullptr, nullptr, 0, &f), "svdss_bam_filter_create");
+          filters.push_back(f);
+          devs.push_back(d);
+        }
+        sel.reset(new DeviceBamSelect(o.bam, filters, devs, n_ref_hdr, bam_skip, 3, bam_batch_bytes()));
+        cache_ok = false;
+        dev_pass = true;
+      } else {
+        bam_p.reset(new BamReader(o.bam));
+        // (--gpus N: the chunks of pass 1 are inflated on all N GPUs in turn, as `search` does)
+        svdss_enable_gpu_inflate(*bam_p, 0, std::max(1, std::min(o.gpus, svdss_device_count())));
+        if (!bam_p->ok() || !bam_p->read_header()) die("cannot read " + o.bam + ": " + bam_p->error());
+        ref_names = bam_p->ref_names();
+      }
+      // the next record pass 1 looks at: 1 = record, 0 = end of file (errors end the run)
+      std::unique_ptr<SelectedBatch> sel_cur;
+      size_t sel_k = 0;
       const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
       std::vector<std::vector<ESFS>> per_thread((size_t)T);
       std::vector<std::vector<Clip>> per_thread_clips((size_t)T);
@@ -565,6 +606,23 @@ struct CallRun {
         while ((int)batch.size() < bsize) {
           // records are located in the inflated chunks and only decoded if the read has SFS at all
           BamReader::RawView rr;
+          if (sel) {
+            while (!sel_cur || sel_k + 1 >= sel_cur->off.size()) {
+              sel_cur = sel->next();
+              sel_k = 0;
+              if (!sel_cur) break;
+              n_records_seen += sel_cur->n_records;
+            }
+            if (!sel_cur) {
+              if (!sel->error().empty()) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": " + sel->error()); }
+              eof = true;
+              break;
+            }
+            const size_t at = (size_t)sel_cur->off[sel_k], end = (size_t)sel_cur->off[sel_k + 1];
+            ++sel_k;
+            if (!view_of_record(sel_cur->bytes.data() + at, end - at, rr)) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": corrupt record"); }
+          } else {
+          BamReader& bam = *bam_p;
           const int rc = bam.next_view(rr);
           if (rc == 0) { eof = true; break; }
           if (rc < 0) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": " + bam.error()); }
@@ -579,6 +637,7 @@ struct CallRun {
                 cache_chunks.clear(); cache_chunks.shrink_to_fit();
               } else cache_chunks.push_back(cur_chunk);
             }
+          }
           }
           if (rr.flag & (4 | 2048 | 256)) continue;   // clusterer.cpp:118-122
           if ((unsigned)rr.mapq < o.min_mapq) continue;
@@ -650,6 +709,8 @@ struct CallRun {
       }
       if (worker.joinable()) worker.join();
       svdss_ref_free(dref);
+      sel.reset();
+      for (svdss_bam_filter_t* f : filters) svdss_bam_filter_free(f);
       for (int t = 0; t < T; ++t) extended.insert(extended.end(), per_thread[(size_t)t].begin(), per_thread[(size_t)t].end());
       for (int t = T; t-- > 0;)   // each thread's list goes in front of the others' (clusterer.cpp:24)
         clips.insert(clips.end(), per_thread_clips[(size_t)t].begin(), per_thread_clips[(size_t)t].end());
@@ -866,6 +927,44 @@ struct CallRun {
                               " file chunks");
           const std::string e = bam_scan_chunks(o.bam, chunks, [&](const BamReader::RawView& rr) { process(rr, qname, apply); });
           if (!e.empty()) die("error reading " + o.bam + ": " + e);
+        } else if (dev_pass) {
+          // no index: the file again through the device path, the (merged) cluster regions as the filter -- the records
+          // that overlap a cluster come back, in file order
+          std::vector<int32_t> rt, rb, re;
+          for (size_t t = 0; t < ref_names.size(); ++t) {
+            if (!tid_clusters[t]) continue;
+            int64_t cb = -1, ce = -1;
+            for (size_t ci : *tid_clusters[t]) {
+              const int64_t b0 = std::max(min_s[ci] - 1, 0), e0 = max_e[ci];
+              if (ce >= 0 && b0 <= ce) { ce = std::max(ce, e0); continue; }
+              if (ce >= 0) { rt.push_back((int32_t)t); rb.push_back((int32_t)cb); re.push_back((int32_t)ce); }
+              cb = b0; ce = e0;
+            }
+            if (ce >= 0) { rt.push_back((int32_t)t); rb.push_back((int32_t)cb); re.push_back((int32_t)ce); }
+          }
+          if (!rt.empty()) {
+            const int n_dev = std::max(1, std::min(o.gpus, svdss_device_count()));
+            std::vector<svdss_bam_filter_t*> filters;
+            std::vector<int> devs;
+            for (int d = 0; d < n_dev; ++d) {
+              svdss_bam_filter_t* f = nullptr;
+              check(svdss_bam_filter_create(d, (int32_t)std::min<unsigned>(o.min_mapq, 256u), (int32_t)ref_names.size(), nullptr, nullptr, 0, rt.data(),
+                                            rb.data(), re.data(), (int64_t)rt.size(), &f), "svdss_bam_filter_create");
+              filters.push_back(f);
+              devs.push_back(d);
+            }
+            {
+              DeviceBamSelect sel(o.bam, filters, devs, (int32_t)ref_names.size(), bam_skip, 3, bam_batch_bytes());
+              BamReader::RawView rr;
+              while (std::unique_ptr<SelectedBatch> sb = sel.next())
+                for (size_t k = 0; k + 1 < sb->off.size(); ++k) {
+                  if (!view_of_record(sb->bytes.data() + sb->off[k], (size_t)(sb->off[k + 1] - sb->off[k]), rr)) die("error reading " + o.bam + ": corrupt record");
+                  process(rr, qname, apply);
+                }
+              if (!sel.error().empty()) die("error reading " + o.bam + ": " + sel.error());
+            }
+            for (svdss_bam_filter_t* f : filters) svdss_bam_filter_free(f);
+          }
         } else {
           BamReader bam(o.bam);
           svdss_enable_gpu_inflate(bam);

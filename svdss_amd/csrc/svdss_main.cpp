@@ -35,6 +35,7 @@
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
 #include "bgzf_scanner.h"
+#include "bam_device_select.h"
 #include "gpu_inflate_hook.h"
 #include "cli_options.h"
 #include "call_host.h"
@@ -314,83 +315,6 @@ static void format_batch(const Options& o, SearchBatch& b) {
   }
 }
 
-// The BAM header read on the host (the first BGZF members, zlib / libdeflate): number of reference sequences and the
-// length of the header in the inflated stream -- where the first record begins (sam_hdr_read, ping_pong.cpp:248).
-static bool bam_header_probe(const std::string& path, int32_t& n_ref, int64_t& skip, std::string& err) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) { err = "cannot open file"; return false; }
-  std::vector<uint8_t> comp, buf;
-  size_t pos = 0;
-  bool eof = false;
-  BgzfInflater inf;
-  auto more = [&]() -> bool {        // one more member inflated onto buf
-    for (;;) {
-      if (pos + 18 <= comp.size()) {
-        const uint8_t* h = comp.data() + pos;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BAM file"; return false; }
-        uint16_t xlen;
-        memcpy(&xlen, h + 10, 2);
-        int bsize = -1;
-        if (pos + 12 + xlen <= comp.size()) {
-          for (size_t o = 0; o + 4 <= xlen;) {
-            const uint8_t* x = h + 12 + o;
-            uint16_t slen;
-            memcpy(&slen, x + 2, 2);
-            if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) { uint16_t v; memcpy(&v, x + 4, 2); bsize = v; break; }
-            o += 4u + slen;
-          }
-          if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) { err = "BGZF block without BC field"; return false; }
-          if (pos + (size_t)bsize + 1 <= comp.size()) {
-            const size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
-            uint32_t crc, isize;
-            memcpy(&crc, h + 12 + xlen + clen, 4);
-            memcpy(&isize, h + 12 + xlen + clen + 4, 4);
-            if (isize > 65536u) { err = "bad BGZF block"; return false; }
-            const size_t at = buf.size();
-            buf.resize(at + isize);
-            if (isize) if (const char* e = inf.run(h + 12 + xlen, clen, buf.data() + at, isize, crc)) { err = e; return false; }
-            pos += (size_t)bsize + 1;
-            return true;
-          }
-        }
-      }
-      if (eof) { err = "truncated header"; return false; }
-      const size_t at = comp.size();
-      comp.resize(at + ((size_t)256 << 10));
-      const size_t got = fread(comp.data() + at, 1, (size_t)256 << 10, f);
-      comp.resize(at + got);
-      if (got == 0) eof = true;
-    }
-  };
-  auto need = [&](size_t n) -> bool { while (buf.size() < n) if (!more()) return false; return true; };
-  bool ok = false;
-  do {
-    if (!need(12)) break;
-    if (memcmp(buf.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; break; }
-    int32_t l_text;
-    memcpy(&l_text, buf.data() + 4, 4);
-    if (l_text < 0) { err = "corrupt header"; break; }
-    if (!need(12 + (size_t)l_text)) break;
-    memcpy(&n_ref, buf.data() + 8 + l_text, 4);
-    if (n_ref < 0) { err = "corrupt header"; break; }
-    size_t o = 12 + (size_t)l_text;
-    bool bad = false;
-    for (int32_t i = 0; i < n_ref && !bad; ++i) {
-      if (!need(o + 4)) { bad = true; break; }
-      int32_t l_name;
-      memcpy(&l_name, buf.data() + o, 4);
-      if (l_name < 0) { err = "corrupt header"; bad = true; break; }
-      o += 4 + (size_t)l_name + 4;
-      if (!need(o)) bad = true;
-    }
-    if (bad) break;
-    skip = (int64_t)o;
-    ok = true;
-  } while (false);
-  fclose(f);
-  return ok;
-}
-
 // ---- `search --bam` with the records handled where they are inflated (csrc/bam_device.hip): the host reads the file,
 // finds the BGZF members, hands runs of them to the GPUs and gets names, tags and SFS back.  Stages: scanner (loader
 // threads) -> batcher -> feeding threads (svdss_bam_batch_run, one batch object each) -> assembler (device batches end
@@ -645,7 +569,7 @@ int main_search(const Options& o) {
   int64_t bam_skip = 0;
   if (dev_bam) {
     std::string herr;
-    if (!bam_header_probe(o.bam, bam_n_ref, bam_skip, herr)) die("cannot read " + o.bam + ": " + herr);
+    if (!bam_header_probe(o.bam, bam_n_ref, bam_skip, herr, nullptr)) die("cannot read " + o.bam + ": " + herr);
     BgzfScanner::Hooks hooks;
     hooks.host_alloc = svdss_host_alloc;
     hooks.host_free = svdss_host_free;

@@ -50,6 +50,14 @@ def test_chr20_10x_end_to_end(tmp_path):
     r_host = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4",
                              "--min-sv-length", "50"], capture_output=True, text=True, env=dict(os.environ, SVDSS_PLACE_HOST="1"))
     assert r_host.returncode == 0 and r_host.stdout == vcf
+    # (the BAM read through the device path -- the default: svdss_bam_select_run keeps the records of reads with SFS in pass 1
+    # and, without an index, those that overlap a cluster in pass 2 -- and through the host reader with its record cache)
+    r_dev = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50",
+                            "--verbose"], capture_output=True, text=True, env=dict(os.environ, SVDSS_BAM_BATCH_MB="8", SVDSS_BAM_SLAB_KB="512"))
+    assert r_dev.returncode == 0 and r_dev.stdout == vcf, r_dev.stderr[-500:]
+    r_hr = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50"],
+                          capture_output=True, text=True, env=dict(os.environ, SVDSS_BAM_DEVICE="0"))
+    assert r_hr.returncode == 0 and r_hr.stdout == vcf
     # the second BAM pass without the records of pass 1 in memory: the whole file again, or -- with a BAI index beside
     # the file, as the reference requires -- only the chunks the index names for the cluster regions (records here
     # straddle BGZF blocks, chunks start and end inside blocks): the same VCF
