@@ -260,7 +260,7 @@ class DeviceBamSelect {
       {
         std::unique_lock<std::mutex> lk(m_);
         const uint64_t sq = job->seq;
-        cv_.wait(lk, [&] { return stop_ || done_.size() < 8 || done_.begin()->first > sq; });
+        cv_.wait(lk, [&] { return stop_ || done_.size() < 64 || done_.begin()->first > sq; });   // (kept records are few: let the GPU run ahead)
         done_[sq] = std::move(out);
       }
       cv_.notify_all();

@@ -8,6 +8,8 @@
 // BAM access: the reference streams the BAM once (placement) and then issues one BAI region query
 // per cluster; here the second phase is a second sequential pass that hands every alignment to
 // the clusters it overlaps -- same alignments per cluster, same (file) order, no index needed.
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -462,6 +464,8 @@ struct CallRun {
   std::vector<Clip> clips;               // --clipped
   // The inflated records of pass 1 are kept for pass 2 when they fit in memory (a second inflate of the whole file
   // otherwise): SVDSS_CALL_CACHE_GB, default 40 % of MemAvailable, at most 64 GiB.
+  std::thread fasta_loader;              // load_chromosomes, beside the SFS file and the start of pass 1
+  void reference_ready() { if (fasta_loader.joinable()) fasta_loader.join(); }
   bool dev_pass = false;                 // the BAM is read through the device path (csrc/bam_device.hip): no record cache
   int64_t bam_skip = 0;                  // the BAM header's length in the inflated stream
   uint64_t n_records_seen = 0;
@@ -493,16 +497,20 @@ struct CallRun {
 
   // load_chromosomes + parse_sfsfile (chromosomes.cpp:9-27, sfs.cpp:5-30)
   void load_inputs() {
-    // ---- load_chromosomes (chromosomes.cpp:9-27): upper-cased, FASTA order
+    // ---- load_chromosomes (chromosomes.cpp:9-27): upper-cased, FASTA order.  On a thread of its own: the SFS file is
+    // parsed and pass 1 starts reading the BAM beside it; the first use of the chromosomes waits (reference_ready)
     {
-      FastxReader fx(o.reference);
-      if (!fx.ok()) die("cannot open " + o.reference);
-      std::string name, seq;
-      while (fx.next(name, seq)) {
-        for (char& ch : seq) ch = (char)(ch - ((ch >= 'a' && ch <= 'z') ? 32 : 0));   // toupper of chromosomes.cpp:19 (ASCII; vectorises)
-        C.chrom_names.push_back(name);
-        C.chrom_seqs[name] = seq;
-      }
+      if (FILE* f = fopen(o.reference.c_str(), "rb")) fclose(f); else die("cannot open " + o.reference);
+      fasta_loader = std::thread([this] {
+        FastxReader fx(o.reference);
+        if (!fx.ok()) die("cannot open " + o.reference);
+        std::string name, seq;
+        while (fx.next(name, seq)) {
+          for (char& ch : seq) ch = (char)(ch - ((ch >= 'a' && ch <= 'z') ? 32 : 0));   // toupper of chromosomes.cpp:19 (ASCII; vectorises)
+          C.chrom_names.push_back(name);
+          C.chrom_seqs[name] = seq;
+        }
+      });
     }
     // ---- parse_sfsfile (sfs.cpp:5-30)
     // (csrc/sfs_file.h: the file mapped and parsed by T threads; a file that cannot be opened leaves the map empty, as
@@ -576,6 +584,7 @@ struct CallRun {
       const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
       std::vector<std::vector<ESFS>> per_thread((size_t)T);
       std::vector<std::vector<Clip>> per_thread_clips((size_t)T);
+      reference_ready();
       // the chromosomes in BAM header order on the GPU, for the placement kernel (SVDSS_PLACE_HOST=1: host code instead;
       // --clipped: host code as well -- the kernel reports how many SFS stay unplaced, not next to which soft clip)
       svdss_ref_t* dref = nullptr;
@@ -908,9 +917,9 @@ struct CallRun {
             have_bai = bai.load(o.bam.substr(0, o.bam.size() - 4) + ".bai");
           if (have_bai && bai.refs.size() != ref_names.size()) have_bai = false;
         }
+        std::vector<std::pair<uint64_t, uint64_t>> chunks;
+        size_t n_regions = 0;
         if (have_bai) {
-          std::vector<std::pair<uint64_t, uint64_t>> chunks;
-          size_t n_regions = 0;
           for (size_t t = 0; t < ref_names.size(); ++t) {
             if (!tid_clusters[t]) continue;
             int64_t rb = -1, re = -1;   // current merged region
@@ -923,6 +932,20 @@ struct CallRun {
             if (re >= 0) { bai.query((int)t, rb, re, chunks); ++n_regions; }
           }
           BaiIndex::merge(chunks);
+          // The index names the file chunks around the clusters; one host thread inflates them (~0.3 GB/s).  When they are
+          // more than a few percent of the file, reading ALL of it through the device path (tens of GB/s, only the
+          // overlapping records come back) is quicker: SVDSS_CALL_PASS2 = bai | device overrides the estimate.
+          if (dev_pass) {
+            uint64_t chunk_bytes = 0;
+            for (const auto& ch : chunks) chunk_bytes += (ch.second >> 16) - (ch.first >> 16) + 65536;
+            struct stat st;
+            const uint64_t file_bytes = stat(o.bam.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
+            const char* p2 = getenv("SVDSS_CALL_PASS2");
+            if (p2 && !strcmp(p2, "device")) have_bai = false;
+            else if (!(p2 && !strcmp(p2, "bai")) && file_bytes && (double)chunk_bytes > 0.08 * (double)file_bytes) have_bai = false;
+          }
+        }
+        if (have_bai) {
           logmsg("debug", "pass 2 through the BAI index: " + std::to_string(n_regions) + " regions, " + std::to_string(chunks.size()) +
                               " file chunks");
           const std::string e = bam_scan_chunks(o.bam, chunks, [&](const BamReader::RawView& rr) { process(rr, qname, apply); });

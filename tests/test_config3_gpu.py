@@ -70,10 +70,16 @@ def test_chr20_10x_end_to_end(tmp_path):
                 fh.write(idx)
         r_p2 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4",
                                "--min-sv-length", "50", "--verbose"], capture_output=True, text=True,
-                              env=dict(os.environ, SVDSS_CALL_CACHE_GB="0"))
+                              env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai"))
         assert r_p2.returncode == 0, r_p2.stderr[-500:]
         assert ("through the BAI index" in r_p2.stderr) == with_bai
         assert r_p2.stdout == vcf
+        # (and the host reader without its cache, with and without the index; with the index present the device path may
+        # still read the whole file when the chunks the index names are a large part of it: SVDSS_CALL_PASS2=device)
+        for env in ({"SVDSS_BAM_DEVICE": "0"}, {"SVDSS_CALL_PASS2": "device"}):
+            r_p3 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50"],
+                                  capture_output=True, text=True, env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", **env))
+            assert r_p3.returncode == 0 and r_p3.stdout == vcf, (env, r_p3.stderr[-300:])
     os.remove(bam + ".bai")
     # the reads around four SVs (two heterozygous, two homozygous): the same chain on that sub-BAM, and the Python mirror
     # of the host logic (clusterer.cpp / caller.cpp restated in svdss_amd/) on the same inputs -> the same VCF bytes
