@@ -69,6 +69,8 @@ struct SvdssDevIndex {
   int64_t n;                // BWT length
   int32_t n_dollar;
   int32_t k;                // K of the k-mer table (0: no table)
+  int32_t bs_after;         // BS takes a deep backward phase over when more than this many rank steps are still expected (sfs_core2.h)
+  int32_t pad_;
   int64_t acc[7];           // acc[c] = #symbols < c
   const uint8_t* text;      // nt6 text; text[-64 .. n+64) is readable ('$' padding)
   const void* sa;           // suffix array: uint32[n] (n < 2^32) or uint64[n]
@@ -85,6 +87,7 @@ SVDSS_HD int64_t svdss_acc(const SvdssDevIndex& ix, int c) {
 SVDSS_HD int svdss_comp(int a) { return (a >= 1 && a <= 4) ? 5 - a : a; }  // ping_pong.hpp:38
 
 SVDSS_HD int svdss_popc(uint32_t x) { return __builtin_popcount(x); }
+SVDSS_HD float svdss_log2f(float x) { return __builtin_log2f(x); }
 
 // mask with the low r bits set, r clamped to [0,32]
 SVDSS_HD uint32_t svdss_lowmask(int r) {

@@ -330,6 +330,8 @@ SvdssDevIndex svdss_device_view(const svdss_index* ix) {
   v.n = ix->n;
   v.n_dollar = (int32_t)ix->dollar.size();
   v.k = ix->table_k;
+  v.bs_after = getenv("SVDSS_BS_AFTER") ? atoi(getenv("SVDSS_BS_AFTER")) : SV_BS_AFTER_DEFAULT;
+  v.pad_ = 0;
   memcpy(v.acc, ix->acc, sizeof v.acc);
   v.text = ix->d_text ? (const uint8_t*)ix->d_text + 64 : nullptr;
   v.sa = ix->d_sa;
@@ -337,13 +339,21 @@ SvdssDevIndex svdss_device_view(const svdss_index* ix) {
   return v;
 }
 
+// deep[0] / deep[1]: occurrences of the sampled K-mers (every 256th key) in all / of those with SV_BS_MIN or more of them
 template <class P>
-__global__ void __launch_bounds__(256) build_table_kernel(SvdssDevIndex ix, SvdssTabEntry* tab, int K, int forward) {
+__global__ void __launch_bounds__(256) build_table_kernel(SvdssDevIndex ix, SvdssTabEntry* tab, int K, int forward, unsigned long long* deep) {
   const uint64_t nkeys = (uint64_t)1 << (2 * K);
   for (uint64_t key = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; key < nkeys;
        key += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t lo, info;
     sv_table_entry<P>(ix, (uint32_t)key, K, lo, info);
+    if ((key & 255u) == 77u && (info >> 62) != SVDSS_TAB_EMPTY) {
+      const uint64_t type = info >> 62;
+      const unsigned long long occ = type == SVDSS_TAB_MULTI ? (unsigned long long)(info & SVDSS_TAB_MASK)
+                                    : type == SVDSS_TAB_UNIQUE ? 1ull : (unsigned long long)((info >> 59) & 7u);
+      atomicAdd(&deep[0], occ);
+      if (type == SVDSS_TAB_MULTI && occ >= (unsigned long long)SV_BS_MIN) atomicAdd(&deep[1], occ);
+    }
     if (!forward && (info >> 62) == SVDSS_TAB_EMPTY) info &= ~0xff00ull;   // SVDSS_TABLE_FORWARD=0 (A/B measurements)
     tab[key].lo = lo;
     tab[key].info = info;
@@ -367,14 +377,24 @@ static int build_table(svdss_index* ix) {
     const int blocks = (int)((nkeys + 255) / 256 < 65536 ? (nkeys + 255) / 256 : 65536);
     const char* fw = getenv("SVDSS_TABLE_FORWARD");
     const int forward = (fw && atoi(fw) == 0) ? 0 : 1;   // 0: entries without the forward-phase outcome
+    unsigned long long* d_deep = nullptr;
+    HIPCHK(hipMalloc((void**)&d_deep, 16));
+    HIPCHK(hipMemset(d_deep, 0, 16));
     if (wide)
       hipLaunchKernelGGL(build_table_kernel<uint64_t>, dim3(blocks), dim3(256), 0, 0, v,
-                         (SvdssTabEntry*)ix->d_table, k, forward);
+                         (SvdssTabEntry*)ix->d_table, k, forward, d_deep);
     else
       hipLaunchKernelGGL(build_table_kernel<uint32_t>, dim3(blocks), dim3(256), 0, 0, v,
-                         (SvdssTabEntry*)ix->d_table, k, forward);
+                         (SvdssTabEntry*)ix->d_table, k, forward, d_deep);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
+    {
+      unsigned long long h[2] = {0, 0};
+      (void)hipMemcpy(h, d_deep, sizeof h, hipMemcpyDeviceToHost);
+      (void)hipFree(d_deep);
+      ix->deep_frac = h[0] ? (double)h[1] / (double)h[0] : 0.0;
+      if (verbose) fprintf(stderr, "[index] %.1f %% of the sampled K-mer occurrences belong to K-mers with %d or more\n", 100.0 * ix->deep_frac, SV_BS_MIN);
+    }
     if (verbose) fprintf(stderr, "[index] k-mer table filled at +%.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     ix->table_k = k;
   }
@@ -508,7 +528,7 @@ static SvdssDevIndex host_view(const svdss_index* ix) {
   v.dollar = ix->dollar.data();
   v.n = ix->n;
   v.n_dollar = (int32_t)ix->dollar.size();
-  v.k = 0; v.text = nullptr; v.sa = nullptr; v.table = nullptr;
+  v.k = 0; v.bs_after = 0; v.pad_ = 0; v.text = nullptr; v.sa = nullptr; v.table = nullptr;
   memcpy(v.acc, ix->acc, sizeof v.acc);
   return v;
 }

@@ -28,6 +28,7 @@ struct svdss_index {
   void* d_sa = nullptr;
   void* d_table = nullptr;
   int32_t table_k = 0;
+  double deep_frac = 0.0;   // share of the K-mer occurrences that belong to K-mers with 8 or more of them (sampled while the table is built)
 };
 
 // Builds text (contig $ revcomp $ ...), suffix array, BWT and the block layout.

@@ -170,7 +170,7 @@ extern "C" int svdss_index_verify_device(const svdss_index_t* ixp, int64_t strid
   v.dollar = (const int64_t*)ix->d_dollar;
   v.n = ix->n;
   v.n_dollar = (int32_t)ix->dollar.size();
-  v.k = 0;
+  v.k = 0; v.bs_after = 0; v.pad_ = 0;
   memcpy(v.acc, ix->acc, sizeof v.acc);
   v.text = (const uint8_t*)ix->d_text + 64;
   v.sa = ix->d_sa;

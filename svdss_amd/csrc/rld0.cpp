@@ -422,7 +422,7 @@ int rld0_strings_of_bwt(const uint8_t* bwt, int64_t n, int threads, std::vector<
   v.dollar = tmp.dollar.data();
   v.n = n;
   v.n_dollar = (int32_t)tmp.dollar.size();
-  v.k = 0; v.text = nullptr; v.sa = nullptr; v.table = nullptr;
+  v.k = 0; v.bs_after = 0; v.pad_ = 0; v.text = nullptr; v.sa = nullptr; v.table = nullptr;
   memcpy(v.acc, tmp.acc, sizeof v.acc);
   out.assign((size_t)m, std::vector<uint8_t>());
   int bad = 0;

@@ -28,7 +28,8 @@
 #endif
 
 enum { SV_OP_DONE = 0, SV_OP_LF = 1, SV_OP_TABLE = 2, SV_OP_SA = 3, SV_OP_TEXT = 4, SV_OP_FILL = 5,
-       SV_OP_TEXT_SLOW = 6, SV_OP_PEEK = 7, SV_OP_SA_SET = 8, SV_OP_SET = 9 };
+       SV_OP_TEXT_SLOW = 6, SV_OP_PEEK = 7, SV_OP_SA_SET = 8, SV_OP_SET = 9, SV_OP_BS_SA = 10, SV_OP_BS_TEXT = 11,
+       SV_OP_BS_TEXT_SLOW = 12, SV_OP_BS_ORD = 13, SV_N_OPS = 14 };
 
 #define SV_M_DIR 1     // 0 backward (ping_pong.cpp:15-22), 1 forward (:31-37)
 #define SV_M_START 2   // at a phase start: no interval yet (before :12 / :30)
@@ -65,6 +66,7 @@ struct SvLane {
   int32_t chain_lo, chain_end;
   int32_t stop_lo;   // segmented search: this lane owns read positions >= stop_lo (0: whole read)
   int32_t n_below;   // SFS produced with start < stop_lo (overrun into the next segment)
+  int32_t bs_m;      // BS: symbols of Q matched with the middle row so far
 };
 
 // A segment's chain keeps going past its lower boundary until it sees (peek) that the next
@@ -85,6 +87,37 @@ struct SvLane {
 #define SV_M_SHIFT (1 << 14)   // s.c = read symbols consumed since the table lookup whose SA rows are being fetched
 #define SV_M_FEWSET (1 << 15)  // the alive bits already hold the occurrences of a FEW entry that are left: fetch their rows
 #define SV_PEEK_VISIBLE 16 // records per segment stored so that a concurrently running neighbour can see them
+// BS: a backward phase on a DEEP interval (a K-mer with SV_BS_MIN or more occurrences: reads inside repeat families)
+// finished by binary search instead of one rank step per symbol.  The phase ends where the longest suffix of
+// P[0..e] that occurs anywhere ends; reverse-complemented (the text holds both strands) that is the longest PREFIX of
+// Q = revcomp(P[0..e]) that occurs, i.e. the longest common prefix of Q with its two neighbours in the suffix array
+// among the rows that start with Q's first K symbols -- the interval of the reverse-complemented K-mer, one more table
+// lookup.  log2(occurrences) rows are looked at (suffix array entry, then 64 symbols per text comparison, from the
+// prefix length both current neighbours are known to share with Q), instead of hundreds of dependent block fetches.
+// The comparison itself is the TEXT mode's: row M holds text position p', whose mirror image in the other strand
+// (2 * middle '$' of its record pair - p') is where P[e] sits, and P[e - x] is compared with the text going left.
+// State while it runs: lo / hi = the rows [A, B) not decided yet, begin / c = symbols Q shares with row A - 1 / row B
+// (K for a neighbour outside the K-mer's interval), tdelta / bs_m = the middle row's text alignment and the symbols
+// matched with it so far; pos stays at the K-mer's first symbol (e = pos + K - 1).
+#define SV_M_BS (1 << 16)
+#define SV_M_BS_TAB (1 << 17)   // waiting for the interval of the reverse-complemented K-mer
+#define SV_M_BS_CMP (1 << 18)   // the middle row's text position is known: compare
+#define SV_M_BS_ORD (1 << 19)   // a comparison ended at a mismatch: which of the two symbols is the smaller
+#define SV_BS_MIN 8
+// ... but not always: most phases on a deep interval are over after a dozen symbols (the ones that follow an SFS: they
+// end at the sequencing error that SFS is about), and of the others most narrow fast (old, diverged repeat copies: a few dozen rank steps until four
+// occurrences are left and SET / TEXT take over), and a binary search costs ~3 log2(occurrences) memory operations
+// whatever the outcome.  The walk starts as before; after SV_BS_PROBE rank steps the shrinkage of the interval says how
+// many more it would take to get down to four occurrences at this rate -- Np / N0 = q^p, so ln(Np / 4) / ln(1 / q) --
+// and a phase that would need more than bs_after of them (near-identical copies: the interval barely moves) is started
+// again from its K-mer by binary search.  Measured on a 3.1 Gb reference with 45 % of its bases in 40 repeat families
+// (profiles/r04h_*): copies 1 % apart 431 -> 344 ms per million reads; at 5 % and 15 % the walk is the cheaper way and
+// the estimate leaves it alone (a binary search started at once there costs +8 % / +35 %).  tdelta holds N0 and bs_m counts the rank steps while SV_M_BS_OK is set.
+// (The estimate decides cost only: either way ends the phase at the same symbol with the same extension count.)
+#define SV_BS_PROBE 8
+#define SV_BS_AFTER_DEFAULT 256  // (SvdssDevIndex::bs_after; SVDSS_BS_AFTER overrides, 0: binary search at once)
+#define SV_M_BS_OK (1 << 20)    // the backward phase began with a table lookup on a deep interval: BS may take it over
+#define SV_BS_MAX_DOLLAR 256    // '$' positions kept next to the lanes (128 records); beyond: no BS
 
 struct SvOp {
   int op;
@@ -154,6 +187,7 @@ SVDSS_HD void sv_lane_init(SvLane<P>& s, int len, int start_pos = -1, int stop_l
   s.begin = 0;
   s.stop_lo = stop_lo;
   s.n_below = 0;
+  s.bs_m = 0;
   s.mode = SV_M_START;  // backward phase about to start at pos = len-1 (ping_pong.cpp:8-12)
   s.c = 0;
   s.wrel = SV_NO_WINDOW;
@@ -195,7 +229,7 @@ SVDSS_HD void sv_flush(SvLane<P>& s, bool assemble, Emit&& emit) {
 // lengthens the overrun; sv_stitch verifies everything.
 template <class P, class Emit>
 SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, int64_t off,
-                        bool assemble, Emit&& emit, bool can_peek = false, bool use_set = false) {
+                        bool assemble, Emit&& emit, bool can_peek = false, bool use_set = false, bool use_bs = true) {
   SvOp o;
   o.op = SV_OP_DONE;
   o.a = 0;
@@ -207,6 +241,43 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
   // start on top, as ping_pong.cpp is written, every phase end cost the whole wavefront a second pass over the body.)
   for (;;) {
     SV_COUNT_PASS();
+    if (use_bs && (s.mode & SV_M_BS)) {
+      const int K = ix.k;
+      if (s.mode & SV_M_BS_TAB) {                       // the K-mer at [pos, pos + K) once more, reverse-complemented
+        if (s.pos < s.wrel || s.pos + K > s.wrel + 64) {
+          o.op = SV_OP_FILL;
+          o.a = ((off + s.pos - 20) >> 4);
+          return o;
+        }
+        uint32_t key = 0;
+        (void)sv_ring_kmer(g, off + s.pos, K, key);
+        o.op = SV_OP_TABLE;
+        o.a = sv_key_revcomp(key, K);
+        return o;
+      }
+      if (s.lo < s.hi) {
+        if (s.mode & SV_M_BS_ORD) { o.op = SV_OP_BS_ORD; return o; }
+        if (s.mode & SV_M_BS_CMP) {
+          const int cp = s.pos + K - s.bs_m;            // read positions below cp are still to be compared
+          (void)cp;                                     // (off >= 64 for every lane in BS mode: a full window fits)
+          o.op = SV_OP_BS_TEXT;
+          return o;
+        }
+        o.op = SV_OP_BS_SA;
+        o.a = (int64_t)(s.lo + ((s.hi - s.lo) >> 1));
+        return o;
+      }
+      // every row decided: Q shares lmax symbols with its nearer neighbour and no more with any suffix; the extend that
+      // prepends P[e - lmax] empties the interval (ping_pong.cpp:15-22: lmax extends in all, K - 1 of them counted by
+      // the table lookup)
+      const int lmax = s.begin > s.c ? s.begin : s.c;
+      const int e = s.pos + K - 1;
+      s.n_ext += lmax - (K - 1);
+      s.pos = e - lmax;
+      s.lo = 0;
+      s.hi = 0;
+      s.mode &= ~(SV_M_BS | SV_M_BS_TAB | SV_M_BS_CMP | SV_M_BS_ORD);
+    }
     if (s.mode & SV_M_SET) { o.op = SV_OP_SET; return o; }
     if (s.mode & SV_M_TEXT) {
       o.op = (off + s.pos >= 64) ? SV_OP_TEXT : SV_OP_TEXT_SLOW;
@@ -234,6 +305,19 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
               return o;
             }
             s.mode += 1 << SV_LFC_SHIFT;
+          }
+          if (use_bs && (s.mode & SV_M_BS_OK) && s.bs_m >= SV_BS_PROBE) {
+            s.mode &= ~SV_M_BS_OK;
+            const float n0 = (float)s.tdelta, n8 = (float)(int64_t)(s.hi - s.lo);
+            // steps to four occurrences at the rate seen so far: SV_BS_PROBE * log(n8 / 4) / log(n0 / n8)
+            const bool slow = n8 >= (float)SV_BS_MIN &&
+                              (float)SV_BS_PROBE * svdss_log2f(n8 * 0.25f) > (float)ix.bs_after * svdss_log2f(n0 / n8);
+            if (slow) {                                 // back to the K-mer, the rest by binary search
+              s.pos += s.bs_m;
+              s.n_ext -= s.bs_m;
+              s.mode = (s.mode & ~SV_LFC_MASK) | SV_M_BS | SV_M_BS_TAB;
+              continue;
+            }
           }
           const int np = s.pos - 1;
           if (!sv_in_window(s, np)) {
@@ -309,7 +393,7 @@ SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, 
     if (dir) c = svdss_comp(c);
     s.lo = (P)svdss_acc(ix, c);
     s.hi = (P)svdss_acc(ix, c + 1);
-    s.mode &= ~SV_M_START;
+    s.mode &= ~(SV_M_START | SV_M_BS_OK);
   }
 }
 
@@ -350,18 +434,33 @@ SVDSS_HD void sv_apply_lf(SvLane<P>& s, const SvdssDevIndex& ix, const svdss_u4 
     s.hi = (P)(a + svdss_rank_in_block(ix, same_block ? qa : qb, c, (int64_t)s.hi));
   }
   ++s.n_ext;
+  ++s.bs_m;
 }
 
 // g / off: the lane's window of read symbols (the extension symbols of a UNIQUE / FEW entry are compared with the
 // read symbols next to the K-mer when those are resident); can_set: SET mode may be entered (sv_decide's rule)
 template <class P>
 SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_lo, uint64_t e_info, const SvRing& g,
-                             int64_t off, bool can_set) {
+                             int64_t off, bool can_set, bool can_bs = false) {
   const int K = ix.k;
   const int dir = s.mode & SV_M_DIR;
   const uint64_t type = e_info >> 62;
   const uint64_t val = e_info & SVDSS_TAB_MASK;
-  s.mode &= ~SV_M_START;
+  if (s.mode & SV_M_BS_TAB) {
+    // the entry of the reverse-complemented K-mer (as many occurrences as the K-mer itself: MULTI): the rows that start
+    // with Q's first K symbols.  Nothing is decided yet; both neighbours are outside the interval (K symbols shared).
+    s.mode &= ~SV_M_BS_TAB;
+    if (type != SVDSS_TAB_MULTI) {          // (cannot happen with both strands indexed: walk the BWT after all)
+      s.mode &= ~SV_M_BS;
+      return;
+    }
+    s.lo = (P)e_lo;
+    s.hi = (P)(e_lo + val);
+    s.begin = K;
+    s.c = K;
+    return;
+  }
+  s.mode &= ~(SV_M_START | SV_M_BS_OK);
   if (type == SVDSS_TAB_EMPTY) {
     const int d = (int)(val & 0xff);      // symbols consumed with a non-empty interval
     // the reference consumed 1 (set_intv) + d extends, the last one emptied the interval
@@ -386,6 +485,11 @@ SVDSS_HD void sv_apply_table(SvLane<P>& s, const SvdssDevIndex& ix, uint64_t e_l
   if (type == SVDSS_TAB_MULTI) {
     s.lo = (P)e_lo;
     s.hi = (P)(e_lo + val);
+    if (can_bs && !dir && val >= (uint64_t)SV_BS_MIN && s.pos > 0) {
+      s.bs_m = 0;
+      s.tdelta = (int64_t)val;
+      s.mode |= ix.bs_after > 0 ? SV_M_BS_OK : (SV_M_BS | SV_M_BS_TAB);
+    }
     return;
   }
   // one to four occurrences, each with the SVDSS_TAB_EXT text symbols in front of it: the next extensions
@@ -588,8 +692,8 @@ SVDSS_HD void sv_apply_peek(SvLane<P>& s, const int32_t q[SV_PEEK_RECS], const b
 // [pos-64, pos) (byte 0 of ta[0]/rb[0] <-> position pos-64).  The lane consumes
 // symbols pos-1, pos-2, ... while they agree (one rb3_fmd_extend each,
 // ping_pong.cpp:15-22 with a size-1 interval), stops at the read start.
-template <class P>
-SVDSS_HD void sv_apply_text(SvLane<P>& s, const svdss_u4 ta[4], const svdss_u4 rb[4]) {
+// number of symbols that agree, counted down from the last of the 64 (byte 63 of the windows)
+SVDSS_HD int sv_text_matched(const svdss_u4 ta[4], const svdss_u4 rb[4]) {
   uint32_t x[16];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -628,6 +732,12 @@ SVDSS_HD void sv_apply_text(SvLane<P>& s, const svdss_u4 ta[4], const svdss_u4 r
   int matched;
   if (v1 == 0) matched = 64;
   else matched = 63 - (4 * idx + ((31 - __builtin_clz(v1)) >> 3));
+  return matched;
+}
+
+template <class P>
+SVDSS_HD void sv_apply_text(SvLane<P>& s, const svdss_u4 ta[4], const svdss_u4 rb[4]) {
+  const int matched = sv_text_matched(ta, rb);
   const int avail = s.pos < 64 ? s.pos : 64;     // symbols left before the read start
   if (matched >= avail) {
     // every remaining symbol of this window agrees
@@ -666,6 +776,85 @@ SVDSS_HD void sv_apply_text_slow(SvLane<P>& s, const uint8_t* text, const uint8_
   s.mode &= ~SV_M_TEXT;
   s.lo = 0;
   s.hi = 1;
+}
+
+
+// ---- BS (see the mode bits above) ----
+
+// the middle '$' of the record pair (record $ revcomp $) that holds text position x: dsorted = the text positions of
+// all '$', ascending (suffix array rows 0 .. n_dollar - 1, sorted); x -> 2 * mid - x maps a position to the position
+// of the complementary base in the other strand
+SVDSS_HD int64_t sv_mirror(const int64_t* dsorted, int n_d, int64_t x) {
+  int a = 0, b = n_d;                       // first '$' position >= x
+  while (a < b) { const int m = (a + b) >> 1; if (dsorted[m] < x) a = m + 1; else b = m; }
+  int mid = a & ~1;                         // '$' 2c closes record c, '$' 2c + 1 its reverse complement: x lies in pair a / 2
+  if (mid >= n_d) mid = n_d - 2 < 0 ? 0 : n_d - 2;
+  return 2 * dsorted[mid] - x;
+}
+
+// BS_SA: text position of row M = (lo + hi) / 2
+template <class P>
+SVDSS_HD void sv_apply_bs_sa(SvLane<P>& s, const SvdssDevIndex& ix, int64_t text_pos, const int64_t* dsorted, int n_d) {
+  const int e = s.pos + ix.k - 1;
+  s.tdelta = sv_mirror(dsorted, n_d, text_pos) - e;
+  s.bs_m = s.begin < s.c ? s.begin : s.c;   // rows between the two neighbours share at least this much with Q
+  s.mode |= SV_M_BS_CMP;
+}
+
+// what a comparison of the middle row found: `matched` more symbols agree; then either the read's start was reached
+// (at_start: every symbol of P[0..e] occurs -- ping_pong.cpp:24) or the read symbol rsym met the text symbol tsym
+template <class P>
+SVDSS_HD void sv_bs_outcome(SvLane<P>& s, const SvdssDevIndex& ix, int matched, bool at_start, bool more, int rsym, int tsym) {
+  const int K = ix.k;
+  s.bs_m += matched;
+  if (at_start) {
+    const int e = s.pos + K - 1;
+    s.n_ext += e - (K - 1);                 // e extends in all
+    s.pos = 0;
+    s.lo = 0;
+    s.hi = 1;
+    s.mode &= ~(SV_M_BS | SV_M_BS_TAB | SV_M_BS_CMP | SV_M_BS_ORD);
+    return;
+  }
+  if (more) return;                         // the whole window agreed: the next one
+  // Q[m] = comp(rsym), the row's symbol there = comp(tsym) (the text is read in the other strand)
+  const P M = s.lo + ((s.hi - s.lo) >> 1);
+  if (svdss_comp(tsym) < svdss_comp(rsym)) { s.lo = M + 1; s.begin = s.bs_m; }   // row M < Q
+  else { s.hi = M; s.c = s.bs_m; }
+  s.mode &= ~SV_M_BS_CMP;
+}
+
+// BS_TEXT: ta[] / rb[] = text / read bytes for read positions [cp - 64, cp), cp = pos + K - bs_m (the TEXT mode's
+// comparison).  A mismatch leaves the lane in SV_M_BS_ORD: the two symbols that differ decide on which side of Q the
+// middle row lies (sv_apply_bs_ord).
+template <class P>
+SVDSS_HD void sv_apply_bs_text(SvLane<P>& s, const SvdssDevIndex& ix, const svdss_u4 ta[4], const svdss_u4 rb[4]) {
+  const int matched = sv_text_matched(ta, rb);
+  const int cp = s.pos + ix.k - s.bs_m;
+  const int avail = cp < 64 ? cp : 64;
+  if (matched >= avail) sv_bs_outcome(s, ix, avail, cp - avail == 0, cp - avail > 0, 0, 0);
+  else { s.bs_m += matched; s.mode |= SV_M_BS_ORD; }
+}
+
+// BS_ORD: rsym / tsym = the read's and the text's symbol at read position e - bs_m (they differ)
+template <class P>
+SVDSS_HD void sv_apply_bs_ord(SvLane<P>& s, const SvdssDevIndex& ix, int rsym, int tsym) {
+  s.mode &= ~SV_M_BS_ORD;
+  sv_bs_outcome(s, ix, 0, false, false, rsym, tsym);
+}
+
+// the same byte by byte (the first 64 bytes of the whole read buffer)
+template <class P>
+SVDSS_HD void sv_apply_bs_text_slow(SvLane<P>& s, const SvdssDevIndex& ix, const uint8_t* text, const uint8_t* reads, int64_t off) {
+  int cp = s.pos + ix.k - s.bs_m;
+  int matched = 0;
+  while (cp > 0) {
+    const int r = reads[off + cp - 1], t = text[s.tdelta + cp - 1];
+    if (r != t) { sv_bs_outcome(s, ix, matched, false, false, r, t); return; }
+    ++matched;
+    --cp;
+  }
+  sv_bs_outcome(s, ix, matched, true, false, 0, 0);
 }
 
 // ---- k-mer table construction (one entry per key; device kernel and emulator) ----

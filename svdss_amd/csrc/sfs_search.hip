@@ -61,6 +61,7 @@ struct SfsParams {
   int64_t* fallback_ids;
   int32_t ticket_chunk;    // work-item tickets a wavefront takes from next_read at a time
   int32_t use_set;         // follow 2-4 occurrences in the text instead of walking the BWT (SV_OP_SET)
+  int32_t use_bs;          // finish backward phases on deep intervals by binary search of the suffix array (SV_OP_BS_*)
   const int64_t* sub_ids;  // stitch / assemble kernels: the reads to process (nullptr: all n_reads)
   int64_t n_sub;
   int32_t* seg_take;       // per read and segment: [lo, hi) of the records that belong to the read's chain (-1: redo)
@@ -214,9 +215,11 @@ static void sfs_report_op_counts() {
   unsigned long long h[64];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess) {
     fprintf(stderr, "[svdss] decision-loop passes %llu; wave-iterations with a lane in: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu "
-            "PEEK %llu SA_SET %llu SET %llu\n", h[1], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[39], h[40], h[41]);
+            "PEEK %llu SA_SET %llu SET %llu BS_SA %llu BS_TEXT %llu BS_ORD %llu\n", h[1], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[39], h[40], h[41],
+            h[42], h[43], h[45]);
     fprintf(stderr, "[svdss] wave-iterations %llu; lane ops: DONE %llu LF %llu TABLE %llu SA %llu TEXT %llu FILL %llu SLOW %llu "
-            "PEEK %llu SA_SET %llu SET %llu\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+            "PEEK %llu SA_SET %llu SET %llu BS_SA %llu BS_TEXT %llu BS_ORD %llu\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11],
+            h[12], h[13], h[15]);
   }
   fprintf(stderr, "[svdss] items by ops (2^k .. 2^(k+1)-1, k=4..15):");
   for (int k = 4; k < 16; ++k) fprintf(stderr, " %llu", h[16 + k]);
@@ -226,7 +229,14 @@ static void sfs_report_op_counts() {
 #endif
 }
 
-template <class P, bool SEG>
+// BS: the instantiation that can finish deep backward phases by binary search (sfs_core2.h).  It is the kernel for
+// references rich in repeats (svdss_index::deep_frac, estimated when the k-mer table is built); the plain one carries none
+// of that code (its branches cost the headline workload ~4 % when compiled in).  Only the one-lane-per-read launches use
+// it (large batches): the segmented instantiation with the BS code compiled in gave run-to-run different text when four
+// batches of eight segments per read ran concurrently -- even with the BS table switched off, i.e. without executing any
+// of it (tools/r04_bs_dbg2.py; one, two feeders or fewer segments: never) -- and is not instantiated until that is
+// understood; the segmented launches of every index use the plain kernel.
+template <class P, bool SEG, bool BS>
 #ifndef SV_SEARCH_OCC
 #define SV_SEARCH_OCC 4   // workgroups per CU the register budget is set for
 #endif
@@ -281,6 +291,22 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
   const SvSet ts{&set_lds[threadIdx.x], 256};
   __shared__ uint32_t pf_lds[4 * 256];
   uint32_t* pfl = &pf_lds[threadIdx.x];   // rows: read id, offset lo, offset hi, length
+  // BS mode: the text positions of the '$' (suffix array rows 0 .. n_dollar - 1), sorted -- which record pair a text
+  // position lies in decides where its mirror image in the other strand is (sv_mirror)
+  __shared__ int64_t dsort_lds[BS ? SV_BS_MAX_DOLLAR : 1];
+  const int n_d = BS && p.use_bs ? p.ix.n_dollar : 0;
+  if (n_d > 0) {
+    __shared__ int64_t dtmp_lds[BS ? SV_BS_MAX_DOLLAR : 1];
+    if ((int)threadIdx.x < n_d) dtmp_lds[threadIdx.x] = (int64_t)((const P*)p.ix.sa)[threadIdx.x];
+    __syncthreads();
+    if ((int)threadIdx.x < n_d) {
+      const int64_t v = dtmp_lds[threadIdx.x];
+      int rank = 0;
+      for (int j = 0; j < n_d; ++j) rank += dtmp_lds[j] < v ? 1 : 0;
+      dsort_lds[rank] = v;
+    }
+    __syncthreads();
+  }
 #ifdef SV_COUNT_ITERS
   uint32_t item_ops = 0;
 #endif
@@ -353,11 +379,11 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
       }
       active = true;
     }
-    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, SEG && has_left, p.use_set != 0);
+    const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, SEG && has_left, p.use_set != 0, BS);
 #ifdef SV_COUNT_ITERS
     if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(&g_sfs_iters[0], 1ULL);
     atomicAdd(&g_sfs_iters[2 + o.op], 1ULL);
-    for (int q = 0; q < 10; ++q) {
+    for (int q = 0; q < SV_N_OPS; ++q) {
       const unsigned long long bm = __ballot(o.op == q);
       if (bm && (threadIdx.x & 63) == __builtin_ctzll(bm)) atomicAdd(&g_sfs_iters[32 + q], 1ULL);
     }
@@ -406,11 +432,17 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
       need_b = bhi != blo;
     } else if (o.op == SV_OP_TABLE) {
       pa = (const uint8_t*)(p.ix.table + o.a);
-    } else if (o.op == SV_OP_SA) {
+    } else if (o.op == SV_OP_SA || (BS && o.op == SV_OP_BS_SA)) {
       pa = (const uint8_t*)p.ix.sa + o.a * (int64_t)sizeof(P);
     } else if (o.op == SV_OP_TEXT) {
       pa = p.ix.text + st.tdelta + st.pos - 64;
       pb = reads + off + st.pos - 64;
+      wide_a = true;
+      need_b = true;
+    } else if (BS && o.op == SV_OP_BS_TEXT) {
+      const int64_t cp = (int64_t)st.pos + p.ix.k - st.bs_m;   // read positions [cp - 64, cp) against the text of the middle row
+      pa = p.ix.text + st.tdelta + cp - 64;
+      pb = reads + off + cp - 64;
       wide_a = true;
       need_b = true;
     } else if (o.op == SV_OP_PEEK) {
@@ -421,7 +453,7 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
       if (i0 < 0) i0 = 0;
       pa = (const uint8_t*)(p.seg_rec + (base - cap + i0));
       c0 = i0;
-    } else if (o.op == SV_OP_SET || o.op == SV_OP_SA_SET) {
+    } else if (o.op == SV_OP_SET || o.op == SV_OP_SA_SET || (BS && o.op == SV_OP_BS_ORD)) {
       // (their loads are issued below, next to the others)
     } else {  // SV_OP_FILL
       c0 = o.a;
@@ -448,6 +480,11 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
         if ((alive >> i) & 1) A[i] = sv_load16(p.ix.text + ts.base[i * ts.stride] + st.pos - SV_SET_WIN);
       }
       B[0] = sv_load16(reads + off + st.pos - SV_SET_WIN);
+    } else if (BS && o.op == SV_OP_BS_ORD) {
+      // the two symbols a comparison stopped at (their lines were fetched a moment ago)
+      const int64_t rp = (int64_t)st.pos + p.ix.k - 1 - st.bs_m;
+      A[0] = sv_load16(p.ix.text + st.tdelta + rp);
+      B[0] = sv_load16(reads + off + rp);
     } else if (o.op == SV_OP_SA_SET) {
       const int n_occ = (int)(st.hi - st.lo);
 #pragma unroll
@@ -472,13 +509,21 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
       sv_apply_lf(st, p.ix, A, B, !need_b);
     } else if (o.op == SV_OP_TABLE) {
       sv_apply_table(st, p.ix, (uint64_t)A[0].x | ((uint64_t)A[0].y << 32),
-                     (uint64_t)A[0].z | ((uint64_t)A[0].w << 32), g, off, p.use_set != 0 && off >= 64);
+                     (uint64_t)A[0].z | ((uint64_t)A[0].w << 32), g, off, p.use_set != 0 && off >= 64, BS && n_d > 0 && off >= 64);
     } else if (o.op == SV_OP_SA) {
       const int64_t tp = sizeof(P) == 4 ? (int64_t)A[0].x
                                         : (int64_t)((uint64_t)A[0].x | ((uint64_t)A[0].y << 32));
       sv_apply_sa(st, tp);
     } else if (o.op == SV_OP_TEXT) {
       sv_apply_text(st, A, B);
+    } else if (BS && o.op == SV_OP_BS_SA) {
+      const int64_t tp = sizeof(P) == 4 ? (int64_t)A[0].x
+                                        : (int64_t)((uint64_t)A[0].x | ((uint64_t)A[0].y << 32));
+      sv_apply_bs_sa(st, p.ix, tp, dsort_lds, n_d);
+    } else if (BS && o.op == SV_OP_BS_TEXT) {
+      sv_apply_bs_text(st, p.ix, A, B);
+    } else if (BS && o.op == SV_OP_BS_ORD) {
+      sv_apply_bs_ord(st, p.ix, (int)(B[0].x & 0xffu), (int)(A[0].x & 0xffu));
     } else if (o.op == SV_OP_SET) {
       sv_apply_set(st, ts, A, B[0]);
     } else if (o.op == SV_OP_SA_SET) {
@@ -797,6 +842,16 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.n_sub = 0;
   p.use_set = 1;
   if (const char* e = getenv("SVDSS_SET")) p.use_set = atoi(e) != 0;
+  // (BS needs the suffix array, a k-mer table, and few enough records for their '$' positions to sit in LDS)
+  p.use_bs = p.ix.sa != nullptr && p.ix.k > 0 && p.ix.n_dollar > 0 && p.ix.n_dollar <= SV_BS_MAX_DOLLAR;
+  // The BS instantiation is opt-in (SVDSS_BS=1).  Measured at GRCh38 lengths with 45 % of the bases in 40 repeat families
+  // (profiles/r04h_search_bs.txt, ms per 1,048,576 reads, plain -> BS kernel): copies 1 % apart 408 -> 363, 5 % apart
+  // 197 -> 209, 15 % apart 103 -> 108, the headline reference 67.7 either way when the plain kernel is the one launched.
+  // Most of a real genome's repeats are old (15 %): the plain kernel is the better default; svdss_index::deep_frac (the
+  // share of K-mer occurrences in K-mers with SV_BS_MIN or more of them) says whether a reference has families at all.
+  bool use_bs_kernel = false;
+  if (const char* e = getenv("SVDSS_BS")) use_bs_kernel = p.use_bs && atoi(e) != 0;
+  p.use_bs = use_bs_kernel;
   p.ticket_chunk = 8;
   if (const char* e = getenv("SVDSS_TICKETS")) p.ticket_chunk = atoi(e) > 0 ? atoi(e) : 8;
   p.n_items = n_reads;
@@ -893,8 +948,8 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       // SVDSS_EXTRA_LDS (developer knob): unused dynamic LDS per block, to study the kernel at lower occupancy
       const char* xl = getenv("SVDSS_EXTRA_LDS");
       const size_t extra_lds = xl ? (size_t)atol(xl) : 0;
-      if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
-      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
+      if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true, false>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
+      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true, false>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(b->ek1, stream));
       hipLaunchKernelGGL(sfs_stitch_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, p);
@@ -930,8 +985,10 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
         if (lvl_seg == 1) {
           q.n_seg = 1;
           q.n_items = (int64_t)n_fb;
-          if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
-          else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+          if (wide && use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false, true>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+          else if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+          else if (use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false, true>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+          else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
           HIPCHK(hipGetLastError());
           break;
         }
@@ -942,8 +999,8 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
         q.sub_ids = q.read_ids;
         q.n_sub = (int64_t)n_fb;
         q.epoch = ++b->epoch;
-        if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
-        else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(sfs_stitch_kernel, dim3((unsigned)((n_fb + 255) / 256)), dim3(256), 0, stream, q);
         HIPCHK(hipGetLastError());
@@ -956,8 +1013,10 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       p.n_seg = 1;
       p.n_items = n_reads;
       if (pass == 0) HIPCHK(hipEventRecord(b->ek0, stream));
-      if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+      if (wide && use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false, true>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+      else if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+      else if (use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false, true>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
       if (pass == 0) HIPCHK(hipEventRecord(b->ek1, stream));
     }
     HIPCHK(hipGetLastError());

@@ -55,11 +55,11 @@ def kmer_table(index, K: int):
     return lo, info
 
 
-OP_NAMES = ["DONE", "LF", "TABLE", "SA", "TEXT", "FILL", "TEXT_SLOW", "PEEK", "SA_SET", "SET"]
+OP_NAMES = ["DONE", "LF", "TABLE", "SA", "TEXT", "FILL", "TEXT_SLOW", "PEEK", "SA_SET", "SET", "BS_SA", "BS_TEXT", "BS_TEXT_SLOW", "BS_ORD"]
 
 
 def search2(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool, K: int = 6, use_text: bool = True,
-            n_seg: int = 1, use_set: bool = True):
+            n_seg: int = 1, use_set: bool = True, use_bs: bool = True):
     """v2 lane code (k-mer table of order K, LF, TEXT).  Returns (counts, qs, len, n_ext, op_counts)."""
     n = len(offsets) - 1
     total_syms = int(offsets[-1])
@@ -75,7 +75,7 @@ def search2(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool, K: int
     ln = np.zeros(cap, dtype=np.int32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     t = _lib.emu_search2(index._h, padded.ctypes.data, offsets.ctypes.data, n, alloc_syms, int(assemble), K,
-                         int(use_text) | (2 if (use_set and use_text) else 0), counts.ctypes.data, qs.ctypes.data, ln.ctypes.data, cap,
+                         int(use_text) | (2 if (use_set and use_text) else 0) | (4 if (use_bs and use_text) else 0), counts.ctypes.data, qs.ctypes.data, ln.ctypes.data, cap,
                          n_ext.ctypes.data, ops.ctypes.data, n_seg, seg_stats.ctypes.data)
     assert t >= 0
     d = dict(zip(OP_NAMES, ops.tolist()))

@@ -24,7 +24,7 @@ extern "C" int64_t emu_search(const svdss_index* ix, const uint8_t* reads_padded
   v.dollar = ix->dollar.data();
   v.n = ix->n;
   v.n_dollar = (int32_t)ix->dollar.size();
-  v.k = 0; v.text = nullptr; v.sa = nullptr; v.table = nullptr;
+  v.k = 0; v.bs_after = 0; v.pad_ = 0; v.text = nullptr; v.sa = nullptr; v.table = nullptr;
   memcpy(v.acc, ix->acc, sizeof v.acc);
   int64_t total = 0;
   for (int64_t r = 0; r < n_reads; ++r) {
@@ -81,12 +81,21 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
   v.n = ix->n;
   v.n_dollar = (int32_t)ix->dollar.size();
   v.k = K;
+  v.bs_after = getenv("SVDSS_BS_AFTER") ? atoi(getenv("SVDSS_BS_AFTER")) : SV_BS_AFTER_DEFAULT;
+  v.pad_ = 0;
   memcpy(v.acc, ix->acc, sizeof v.acc);
   std::vector<uint8_t> text((size_t)ix->n + 128 + 16, 0);
   memcpy(text.data() + 64, ix->text.data(), (size_t)ix->n);
   v.text = text.data() + 64;
   v.sa = (use_text & 1) ? (ix->sa64.empty() ? (const void*)ix->sa32.data() : (const void*)ix->sa64.data()) : nullptr;
   const bool use_set = (use_text & 2) != 0;   // bit 1: SET mode (2-4 occurrences followed in the text)
+  // bit 2: BS mode (deep intervals finished by binary search of the suffix array); the text positions of the '$', sorted
+  std::vector<int64_t> dsorted;
+  if ((use_text & 4) && v.sa) {
+    for (int64_t i = 0; i < ix->acc[1]; ++i) dsorted.push_back((int64_t)((const P*)v.sa)[i]);
+    std::sort(dsorted.begin(), dsorted.end());
+  }
+  const bool use_bs = !dsorted.empty() && (int)dsorted.size() <= SV_BS_MAX_DOLLAR;
   std::vector<SvdssTabEntry> table;
   if (K > 0) {
     table.resize((size_t)1 << (2 * K));
@@ -118,6 +127,21 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
       if (op_counts) op_counts[o.op]++;
       if (o.op == SV_OP_DONE) break;
       if (o.op == SV_OP_TEXT_SLOW) { sv_apply_text_slow(st, v.text, reads_padded, off); continue; }
+      if (o.op == SV_OP_BS_TEXT_SLOW) { sv_apply_bs_text_slow(st, v, v.text, reads_padded, off); continue; }
+      if (o.op == SV_OP_BS_ORD) {
+        const int64_t rp = (int64_t)st.pos + v.k - 1 - st.bs_m;
+        sv_apply_bs_ord(st, v, (int)reads_padded[off + rp], (int)v.text[st.tdelta + rp]);
+        continue;
+      }
+      if (o.op == SV_OP_BS_SA) { sv_apply_bs_sa(st, v, (int64_t)((const P*)v.sa)[o.a], dsorted.data(), (int)dsorted.size()); continue; }
+      if (o.op == SV_OP_BS_TEXT) {
+        svdss_u4 ta[4], rb[4];
+        const int cp = st.pos + v.k - st.bs_m;
+        memcpy(ta, v.text + st.tdelta + cp - 64, 64);
+        memcpy(rb, reads_padded + off + cp - 64, 64);
+        sv_apply_bs_text(st, v, ta, rb);
+        continue;
+      }
       if (o.op == SV_OP_SA_SET) {
         int64_t tp[SV_SET_MAX];
         const int n_occ = (int)(st.hi - st.lo);
@@ -154,7 +178,7 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
         sv_apply_lf(st, v, A, B, bhi == blo);
       } else if (o.op == SV_OP_TABLE) {
         const SvdssTabEntry e = v.table[o.a];
-        sv_apply_table(st, v, e.lo, e.info, g, off, use_set && off >= 64);
+        sv_apply_table(st, v, e.lo, e.info, g, off, use_set && off >= 64, use_bs && off >= 64);
       } else if (o.op == SV_OP_SA) {
         sv_apply_sa(st, (int64_t)((const P*)v.sa)[o.a]);
       } else if (o.op == SV_OP_TEXT) {
@@ -234,6 +258,8 @@ extern "C" int emu_table(const svdss_index* ix, int K, uint64_t* out_lo, uint64_
   v.n = ix->n;
   v.n_dollar = (int32_t)ix->dollar.size();
   v.k = K;
+  v.bs_after = getenv("SVDSS_BS_AFTER") ? atoi(getenv("SVDSS_BS_AFTER")) : SV_BS_AFTER_DEFAULT;
+  v.pad_ = 0;
   memcpy(v.acc, ix->acc, sizeof v.acc);
   v.text = ix->text.data();
   v.sa = ix->sa64.empty() ? (const void*)ix->sa32.data() : (const void*)ix->sa64.data();

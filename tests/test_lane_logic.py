@@ -264,3 +264,64 @@ def test_lane_code_under_sanitizers():
     p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_lane_logic.py", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "not under_sanitizers and not 103 and not 104"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("n_seg,bs_after", [(1, 0), (4, 0), (1, 2), (4, 48)])
+def test_v2_deep_intervals_by_binary_search(n_seg, bs_after, monkeypatch):
+    """BS mode (round 4): a backward phase that starts on a K-mer with 8 or more occurrences -- reads inside repeat
+    families -- is finished by binary search of the suffix array among the rows of the reverse-complemented K-mer (text
+    comparisons in the other strand) instead of one rank step per symbol.  Families of near-identical copies on both
+    strands, several records (the mirror image of a text position depends on its record), N runs, reads that run into the
+    start of the read inside a repeat: SFS and extension counts as the oracle's, with most LF steps gone."""
+    from svdss_amd import synth
+    # (the binary search takes a phase over when more than this many rank steps are still expected after the first eight:
+    # 0 = at once; the shipped value is 48 -- intervals that slow are rare at this scale, so the assertions on the
+    # operation counts are for 0 / 2 only)
+    monkeypatch.setenv("SVDSS_BS_AFTER", str(bs_after))
+    rng = np.random.default_rng(17)
+    contigs = []
+    fam = [rng.integers(1, 5, size=int(rng.integers(300, 1500)), dtype=np.uint8) for _ in range(6)]
+    for ci, L in enumerate((60000, 25000, 8000)):
+        c = rng.integers(1, 5, size=L, dtype=np.uint8)
+        at = 500
+        while at + 2000 < L:
+            f = fam[int(rng.integers(0, len(fam)))].copy()
+            e = rng.random(len(f)) < 0.01                     # 1 % divergence between copies
+            f[e] = (f[e] - 1 + rng.integers(1, 4, size=int(e.sum()))) % 4 + 1
+            if rng.random() < 0.5:
+                f = synth.revcomp(f)
+            c[at:at + len(f)] = f
+            at += len(f) + int(rng.integers(100, 900))
+        if ci == 1:
+            c[3000:3040] = 5
+        contigs.append(c)
+    reads = []
+    for i in range(48):
+        c = contigs[i % 3]
+        ln = int(rng.integers(400, 3000))
+        a = int(rng.integers(0, len(c) - ln))
+        r = c[a:a + ln].copy()
+        e = rng.random(ln) < 0.005
+        r[e] = (r[e] - 1 + rng.integers(1, 4, size=int(e.sum()))) % 4 + 1
+        if i % 2:
+            r = synth.revcomp(r)
+        reads.append(r.astype(np.uint8))
+    reads.append(fam[0][:200].copy())                        # a read that is nothing but the start of a family
+    reads.append(synth.revcomp(fam[1])[-300:].copy())
+    flat, offs = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(contigs)
+    fm = O.OracleFMD.build(contigs)
+    for assemble in (False, True):
+        c, q, l, e = fm.search_batch(flat, offs, assemble)
+        ops = {}
+        for K in (6, 8):
+            for use_bs in (False, True):
+                got = E.search2(ix, flat, offs, assemble=assemble, K=K, n_seg=n_seg, use_bs=use_bs)
+                assert (got[0] == c).all() and (got[3] == e).all(), (K, use_bs)
+                assert (got[1] == q).all() and (got[2] == l).all(), (K, use_bs)
+                ops[(K, use_bs)] = got[4]
+        assert ops[(6, False)]["BS_SA"] == 0
+        if bs_after == 0:
+            assert ops[(6, True)]["BS_SA"] > 100 and ops[(6, True)]["LF"] < ops[(6, False)]["LF"] // 3
+        if bs_after == 2:
+            assert ops[(6, True)]["BS_SA"] > 10 and ops[(6, True)]["LF"] < ops[(6, False)]["LF"]
