@@ -559,11 +559,14 @@ struct CallRun {
         std::string names;
         std::vector<int64_t> name_off(1, 0);
         for (const auto& kv : C.sfs) { names += kv.first; name_off.push_back((int64_t)names.size()); }
-        const int n_dev = std::max(1, std::min(o.gpus, svdss_device_count()));
+        // (--gpus N: the batches of the file go to whichever GPU has a feeding thread free; SVDSS_GPUS_OVERSUBSCRIBE puts the N
+        // shards on the GPUs there are -- the code path of N devices on a one-GPU box)
+        const int n_phys = std::max(1, svdss_device_count());
+        const int n_dev = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_phys));
         std::vector<int> devs;
         for (int d = 0; d < n_dev; ++d) {
           svdss_bam_filter_t* f = nullptr;
-          check(svdss_bam_filter_create(d, (int32_t)std::min<unsigned>(o.min_mapq, 256u), n_ref_hdr, names.data(), name_off.data(), (int64_t)name_off.size() - 1,
+          check(svdss_bam_filter_create(d % n_phys, (int32_t)std::min<unsigned>(o.min_mapq, 256u), n_ref_hdr, names.data(), name_off.data(), (int64_t)name_off.size() - 1,
                                         nullptr, nullptr, nullptr, 0, &f), "svdss_bam_filter_create");
           filters.push_back(f);
           devs.push_back(d);
@@ -966,12 +969,13 @@ struct CallRun {
             if (ce >= 0) { rt.push_back((int32_t)t); rb.push_back((int32_t)cb); re.push_back((int32_t)ce); }
           }
           if (!rt.empty()) {
-            const int n_dev = std::max(1, std::min(o.gpus, svdss_device_count()));
+            const int n_phys = std::max(1, svdss_device_count());
+            const int n_dev = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_phys));
             std::vector<svdss_bam_filter_t*> filters;
             std::vector<int> devs;
             for (int d = 0; d < n_dev; ++d) {
               svdss_bam_filter_t* f = nullptr;
-              check(svdss_bam_filter_create(d, (int32_t)std::min<unsigned>(o.min_mapq, 256u), (int32_t)ref_names.size(), nullptr, nullptr, 0, rt.data(),
+              check(svdss_bam_filter_create(d % n_phys, (int32_t)std::min<unsigned>(o.min_mapq, 256u), (int32_t)ref_names.size(), nullptr, nullptr, 0, rt.data(),
                                             rb.data(), re.data(), (int64_t)rt.size(), &f), "svdss_bam_filter_create");
               filters.push_back(f);
               devs.push_back(d);

@@ -520,7 +520,9 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
   });
   {
     const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 4;
-    const int n_fmt = getenv("SVDSS_FORMAT_THREADS") ? std::max(1, atoi(getenv("SVDSS_FORMAT_THREADS"))) : 5;
+    // (formatting the text costs about one core-second per million reads: five threads per GPU, as many as the cores allow)
+    const int n_fmt = getenv("SVDSS_FORMAT_THREADS") ? std::max(1, atoi(getenv("SVDSS_FORMAT_THREADS")))
+                                                     : (int)std::max<size_t>(5, std::min<size_t>(5 * replicas.size(), effective_cpus()));
     std::vector<std::thread> fmt;
     for (int k = 0; k < n_fmt; ++k) fmt.emplace_back(formatter);
     std::vector<std::thread> feeders;

@@ -58,6 +58,11 @@ def test_chr20_10x_end_to_end(tmp_path):
     r_hr = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50"],
                           capture_output=True, text=True, env=dict(os.environ, SVDSS_BAM_DEVICE="0"))
     assert r_hr.returncode == 0 and r_hr.stdout == vcf
+    # --gpus 3 (three filters / feeding groups / DP shards on the box's one GPU): the batches of the BAM go to whichever
+    # shard is free, the VCF is the same
+    r_g3 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50", "--gpus", "3"],
+                          capture_output=True, text=True, env=dict(os.environ, SVDSS_GPUS_OVERSUBSCRIBE="1", SVDSS_BAM_BATCH_MB="8", SVDSS_BAM_SLAB_KB="512"))
+    assert r_g3.returncode == 0 and r_g3.stdout == vcf, r_g3.stderr[-400:]
     # the second BAM pass without the records of pass 1 in memory: the whole file again, or -- with a BAI index beside
     # the file, as the reference requires -- only the chunks the index names for the cluster regions (records here
     # straddle BGZF blocks, chunks start and end inside blocks): the same VCF
