@@ -2,7 +2,7 @@
 // fastx_reader.h, rld0.cpp) run over one input file, for tests/test_host_io_robustness.py: built with
 // -fsanitize=address,undefined, fed valid files and damaged ones.  A reader may accept a file or refuse it with its
 // error message; it may not read outside its buffers, overflow, throw out of main or hang.  Test infrastructure.
-//   host_io_harness bam <file> | bai <file.bam> | fastx <file> | fmd <file> | sidecar <file> | sfs <file>
+//   host_io_harness bam <file> | bai <file.bam> | fastx <file> | fmd <file> | sidecar <file> | sfs <file> | scan <file.bam>
 // exit 0: read to a clean end; 1: the reader reported an error (printed); anything else: a finding.
 #include <cstdint>
 #include <cstdio>
@@ -12,6 +12,8 @@
 
 #include "../svdss_amd/csrc/bai_index.h"
 #include "../svdss_amd/csrc/bam_reader.h"
+#include "../svdss_amd/csrc/bgzf_scanner.h"
+#include "../svdss_amd/csrc/bam_device_select.h"
 #include "../svdss_amd/csrc/fastx_reader.h"
 #include "../svdss_amd/csrc/index_host.h"
 #include "../svdss_amd/csrc/rld0.h"
@@ -64,6 +66,55 @@ static int run_bam(const std::string& path) {
       ++n_rec;
     }
     printf("pass %d: %ld records\n", pass, n_rec);
+  }
+  return 0;
+}
+
+// the host side of the device path (round 4): the BAM header probe, the BGZF member scanner with a few loaders and small
+// slabs (every member located must lie inside what was read, its deflate stream inside the member), and the record view
+// over bytes that came back from a selection -- here: over the members inflated on the host
+static int run_scan(const std::string& path) {
+  int32_t n_ref = 0;
+  int64_t skip = 0;
+  std::string err;
+  std::vector<std::string> names;
+  if (!bam_header_probe(path, n_ref, skip, err, &names)) { printf("error: %s\n", err.c_str()); return 1; }
+  for (const std::string& n : names) touch(n.data(), n.size());
+  for (size_t slab : {(size_t)64 << 10, (size_t)1 << 20}) {
+    BgzfScanner sc(path, BgzfScanner::Hooks(), slab, 3, 6);
+    if (!sc.ok()) { printf("error: cannot open\n"); return 1; }
+    std::vector<uint8_t> stream;
+    BgzfInflater inf;
+    long n_members = 0;
+    while (std::unique_ptr<CompChunk> c = sc.next()) {
+      for (size_t i = 0; i < c->blocks.size(); ++i) {
+        const svdss_bgzf_block_t& b = c->blocks[i];
+        if (b.coff < 0 || b.clen < 0 || (size_t)(b.coff + b.clen) + 8 > c->n_bytes) { printf("finding: member outside the slab\n"); return 3; }
+        touch(c->data + b.coff, (size_t)b.clen);
+        const size_t at = stream.size();
+        stream.resize(at + (size_t)b.isize);
+        if (b.isize && inf.run(c->data + b.coff, (size_t)b.clen, stream.data() + at, (uint32_t)b.isize, c->crc[i])) { printf("error: inflate / crc\n"); return 1; }
+        ++n_members;
+      }
+      sc.recycle(std::move(c));
+    }
+    if (!sc.error().empty()) { printf("error: %s\n", sc.error().c_str()); return 1; }
+    // the records behind the header, as a selection would hand them over
+    long n_rec = 0;
+    size_t p = (size_t)skip;
+    while (p + 4 <= stream.size()) {
+      BamReader::RawView v;
+      int32_t bs;
+      memcpy(&bs, stream.data() + p, 4);
+      if (bs < 32 || p + 4 + (size_t)bs > stream.size()) { printf("error: truncated record\n"); return 1; }
+      if (!view_of_record(stream.data() + p, stream.size() - p, v)) { printf("error: corrupt record\n"); return 1; }
+      touch(v.name(), v.l_name);
+      touch(v.seq4(), ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq);
+      touch(v.aux(), v.l_aux);
+      p += 4 + (size_t)bs;
+      ++n_rec;
+    }
+    printf("slab %zu: %ld members, %ld records\n", slab, n_members, n_rec);
   }
   return 0;
 }
@@ -166,6 +217,7 @@ int main(int argc, char** argv) {
     else if (mode == "fmd") rc = run_fmd(path);
     else if (mode == "sidecar") rc = run_sidecar(path);
     else if (mode == "sfs") rc = run_sfs(path);
+    else if (mode == "scan") rc = run_scan(path);
   } catch (const std::exception& e) {
     printf("finding: exception out of a reader: %s\n", e.what());
     return 3;

@@ -17,7 +17,8 @@ from tests.common import ROOT
 HARNESS = os.path.join(ROOT, "tests", "_host_io_harness")
 SRC = [os.path.join(ROOT, "tests", "host_io_harness.cpp"), os.path.join(ROOT, "svdss_amd", "csrc", "rld0.cpp"),
        os.path.join(ROOT, "svdss_amd", "csrc", "index_build.cpp")]
-DEPS = SRC + [os.path.join(ROOT, "svdss_amd", "csrc", h) for h in ("bam_reader.h", "bai_index.h", "fastx_reader.h", "rld0.h", "index_host.h", "fmd_layout.h", "sfs_file.h")]
+DEPS = SRC + [os.path.join(ROOT, "svdss_amd", "csrc", h) for h in ("bam_reader.h", "bai_index.h", "fastx_reader.h", "rld0.h", "index_host.h", "fmd_layout.h", "sfs_file.h", "bgzf_scanner.h",
+                                                                   "bam_device_select.h")]
 
 
 @pytest.fixture(scope="module")
@@ -115,6 +116,71 @@ def test_bam_reader_on_damaged_files(harness, tmp_path):
         n_err += rc == 1
         n_ok += rc == 0
     assert n_err > 60 and n_ok > 5                        # both outcomes occur; the sanitizers stayed silent
+
+
+def test_device_path_host_side_on_damaged_files(harness, tmp_path):
+    """Round 4: what the device path keeps on the host -- the BAM header probe, the BGZF member scanner (several loader
+    threads, slabs of 64 KB and 1 MB so that members straddle slabs) and the record view over returned bytes -- on the valid
+    file and on the same kinds of damage as above."""
+    rng = np.random.default_rng(2)
+    refs = [("chr1", 5_000_000), ("chr2", 3_000_000)]
+    recs = _records(rng, 300)
+    good = W.bam(refs, recs)
+    path = str(tmp_path / "x.bam")
+    open(path, "wb").write(good)
+    rc, out = run(harness, "scan", path)
+    assert rc == 0 and out.count("300 records") == 2, out
+    hdr, body = _plain_bam(refs, recs)
+    plain = hdr + body
+    n_err = n_ok = 0
+    for k in range(120):
+        kind = k % 6
+        if kind == 0:
+            d = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
+            data = bytes(d)
+        elif kind == 1:
+            data = good[:int(rng.integers(0, len(good)))]
+        elif kind == 2:                                    # a BGZF header field of some member (sizes, magic, subfield)
+            d = bytearray(good)
+            blocks = []
+            pos = 0
+            while pos + 18 <= len(good):
+                blocks.append(pos)
+                pos += struct.unpack_from("<H", good, pos + 16)[0] + 1
+            at = blocks[int(rng.integers(0, len(blocks)))] + int(rng.integers(0, 18))
+            d[at] = int(rng.integers(0, 256))
+            data = bytes(d)
+        elif kind == 3:                                    # header lengths, behind a valid BGZF layer
+            d = bytearray(plain)
+            field = int(rng.choice([4, 8 + struct.unpack_from("<i", d, 4)[0], 12 + struct.unpack_from("<i", d, 4)[0]]))
+            struct.pack_into("<i", d, field, int(rng.choice([-1, -2**31, 2**31 - 1, 2**24, 0, 7])))
+            data = W.bgzf(bytes(d), block=int(rng.choice([60000, 700])))
+        elif kind == 4:                                    # record fields
+            d = bytearray(plain)
+            off = len(hdr)
+            for _ in range(int(rng.integers(0, 40))):
+                bs, = struct.unpack_from("<i", d, off)
+                off += 4 + bs
+            struct.pack_into("<i", d, off + int(rng.choice([0, 12, 16, 20])), int(rng.choice([-1, -2**31, 2**31 - 1, 0, 31, 2**20])))
+            data = W.bgzf(bytes(d), block=int(rng.choice([60000, 700, 65280])))
+        else:                                              # members of odd sizes, empty members in between
+            parts = []
+            i = 0
+            while i < len(plain):
+                n = int(rng.integers(1, 4000))
+                parts.append(W._bgzf_block(plain[i:i + n]))
+                if rng.random() < 0.1:
+                    parts.append(W._bgzf_block(b""))
+                i += n
+            parts.append(W._bgzf_block(b""))
+            data = b"".join(parts)
+        open(path, "wb").write(data)
+        rc, out = run(harness, "scan", path)
+        n_err += rc == 1
+        n_ok += rc == 0
+    assert n_err > 40 and n_ok > 15
 
 
 def test_bai_and_region_scan_on_damaged_files(harness, tmp_path):
