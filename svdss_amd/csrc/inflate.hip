@@ -34,36 +34,59 @@
 
 namespace {
 
-// the LDS ring holds the most recent output only; a match that reaches further back than NEAR reads the bytes the block
-// itself wrote to HBM earlier (they left the ring at least FLUSH + one round ago)
+// ---- sizes (macros so that tools/r04_inflate_sweep.sh can build variants)
 #ifndef INF_WIN
-#define INF_WIN 4096
+#define INF_WIN 4096        // the LDS ring of recent output, bytes
 #endif
-#ifndef INF_FRAC
-#define INF_FRAC 8
+#ifndef INF_INB
+#define INF_INB 4096        // the LDS ring of compressed input, bytes
 #endif
-constexpr int WIN = INF_WIN, WM = WIN - 1;
-constexpr int FLUSH = WIN / INF_FRAC;        // the ring is written out whenever this many bytes are waiting
-constexpr int ROUND_MAX = WIN / INF_FRAC;    // a round stops taking symbols once it has produced this many bytes (+ one match)
-// sources within this distance of a match's output position are read from the ring: everything further back has been
-// written out (FLUSH + ROUND_MAX + 258 < NEAR) and nothing closer has been overwritten (NEAR + ROUND_MAX + 258 < WIN)
-constexpr int NEAR = WIN / 2 - WIN / INF_FRAC;
-static_assert(FLUSH + ROUND_MAX + 258 + 64 < NEAR && NEAR + ROUND_MAX + 258 + 64 < WIN, "ring too small");
+#ifndef INF_SD
+#define INF_SD 9            // dwords of input per lane and pass (odd: the lanes' reads fall into different LDS banks)
+#endif
+#ifndef INF_MAXM
+#define INF_MAXM 512        // matches a pass may hold back until its literals are placed
+#endif
+#ifndef INF_MAXIT
+#define INF_MAXIT 5         // walks of a pass before it settles for the lanes that agree
+#endif
+#ifndef INF_WARM
+#define INF_WARM 0          // bits before its piece at which a lane's first, guessed walk starts: more symbols to fall in step over
+#endif
 #ifndef INF_LB
-#define INF_LB 10
+#define INF_LB 9
 #endif
 #ifndef INF_DB
 #define INF_DB 8
 #endif
+constexpr int WIN = INF_WIN, WM = WIN - 1;
+constexpr int FLUSH = WIN / 8;        // (rounds) the ring is written out whenever this many bytes are waiting
+constexpr int ROUND_MAX = WIN / 8;    // a round stops taking symbols once it has produced this many bytes (+ one match)
+// Which of a match's source bytes are read from the ring, and which from HBM, where an earlier flush put them:
+// * in a round (flushes when FLUSH bytes wait, writes at most ROUND_MAX + 258): the bytes closer than NEAR to the match's
+//   output position are in the ring -- the two static_asserts below;
+// * in a pass (flushes before it starts, then writes at most PASS_MAX bytes): the bytes from PASS_BACK before the pass's
+//   first output byte on -- PASS_BACK + PASS_MAX <= WIN keeps them in the ring until the pass is over, and everything
+//   before them is in HBM (a flush leaves fewer than 4 bytes behind).
+constexpr int NEAR = WIN / 2 - 96;
+constexpr int PASS_BACK = 64;
+constexpr int PASS_MAX = WIN - PASS_BACK - 264;
+static_assert(FLUSH + ROUND_MAX + 258 + 64 < NEAR && NEAR + ROUND_MAX + 258 + 64 < WIN, "ring too small for a round");
 constexpr int LB = INF_LB, DB = INF_DB, CB = 7;   // bits of the direct tables (literal / length, distance, code lengths)
-constexpr int INB = 1024, HALF = INB / 2;   // input ring, refilled a half at a time
-
+constexpr int INB = INF_INB, HALF = 512;          // input ring, refilled HALF bytes at a time
+constexpr int SB = 32 * INF_SD;                   // bits of input per lane and pass
+constexpr int PASS_BYTES = 64 * SB / 8 + 16;      // what a pass may read beyond its first bit
+static_assert(INB - HALF - 32 >= PASS_BYTES, "input ring too small for a pass");
+static_assert(PASS_MAX < 65536, "match records hold 16 bits of output offset");
+constexpr int MAXM = INF_MAXM;
 
 struct Lds {
   uint32_t win[WIN / 4];
-  uint16_t lit[1 << LB];
-  uint16_t dst[1 << DB];
+  uint32_t lit[1 << LB];
+  uint32_t dst[1 << DB];       // (its first 256 bytes also hold the code-length code's table while a header is read)
   uint32_t inb[INB / 4];
+  uint32_t mrec[MAXM];         // the matches a pass holds back: (length - 3) << 15 | (distance - 1) ...
+  uint16_t mpos[MAXM];         // ... and where they write, relative to the pass's first output byte
   uint8_t lens[320];
   uint16_t lsym[288];
   uint16_t dsym[32];
@@ -71,7 +94,8 @@ struct Lds {
 };
 
 #ifdef INF_COUNT
-__device__ unsigned long long g_inf_cnt[8];   // rounds, literals, matches, one-symbol steps, deflate blocks, copy bytes, overlap copies
+// rounds, literals(unused), matches of rounds, one-symbol steps, deflate blocks, passes, lanes taken, walks, walk steps, matches of passes, of them one by one
+__device__ unsigned long long g_inf_cnt[12];
 #define CNT(k, v) (cnt[k] += (v))
 #else
 #define CNT(k, v)
@@ -95,12 +119,41 @@ __device__ __forceinline__ int wave_scan_add(int x) {
   return x;
 }
 
-// Canonical Huffman code of n symbols with lengths lens[0..n): table of 2^tb 16-bit entries (symbol << 4 | length, 0 =
-// a longer code or none), per-length counts and the symbols sorted by (length, symbol) for the bit-by-bit decoder.
+// ---- table entries: everything a lane needs to know about a code, so that decoding is two lookups and a few shifts
+// literal / length code:  bits 0-3 code length (0: no code this short starts with these bits), 4-5 kind (0 literal, 1 length,
+//   2 end of block, 3 none / invalid), 6-8 number of extra bits, 9-17 the literal or the length's base
+constexpr uint32_t LIT_NONE = 3u << 4;
+struct LitEntry {
+ __device__ __forceinline__ uint32_t operator()(uint32_t s, uint32_t ml) const {
+  if (s < 256u) return ml | (s << 9);
+  if (s == 256u) return ml | (2u << 4);
+  if (s > 285u) return ml | (3u << 4);
+  const uint32_t ls = s - 257u;
+  const uint32_t lx = ls < 8u || ls == 28u ? 0u : (ls >> 2) - 1u;
+  const uint32_t lb = ls < 8u ? 3u + ls : ls == 28u ? 258u : 3u + ((4u + (ls & 3u)) << lx);
+  return ml | (1u << 4) | (lx << 6) | (lb << 9);
+ }
+};
+// distance code: bits 0-3 code length (0: none), 4-7 number of extra bits, 8-23 base
+struct DstEntry {
+ __device__ __forceinline__ uint32_t operator()(uint32_t s, uint32_t ml) const {
+  if (s > 29u) return 0u;
+  const uint32_t dx = s < 4u ? 0u : (s >> 1) - 1u;
+  const uint32_t db = s < 4u ? 1u + s : 1u + ((2u + (s & 1u)) << dx);
+  return ml | (dx << 4) | (db << 8);
+ }
+};
+struct LenEntry {
+  __device__ __forceinline__ uint16_t operator()(uint32_t s, uint32_t ml) const { return (uint16_t)((s << 4) | ml); }
+};
+
+// Canonical Huffman code of n symbols with lengths lens[0..n): table of 2^tb entries (make(symbol, length); `none` where a
+// longer code or none starts), per-length counts and the symbols sorted by (length, symbol) for the bit-by-bit decoder.
 // Returns false if the lengths over-subscribe the code space.
-__device__ bool build_table(const uint8_t* lens, int n, uint16_t* tab, int tb, uint16_t* cnt, uint16_t* sym, int lane,
-                            int n_flagged = 0) {   // entries of the symbols below n_flagged carry bit 15 (literals)
-  for (int k = lane; k < (1 << tb); k += 64) tab[k] = 0;
+template <class T, class F>
+__device__ bool build_table(const uint8_t* lens, int n, T* tab, int tb, uint16_t* cnt, uint16_t* sym, int lane, T none, F make,
+                            uint32_t* state = nullptr) {   // the bit-by-bit decoder's first << 16 | index after tb levels
+  for (int k = lane; k < (1 << tb); k += 64) tab[k] = none;
   int count[16];
 #pragma unroll
   for (int l = 0; l < 16; ++l) count[l] = 0;
@@ -124,6 +177,13 @@ __device__ bool build_table(const uint8_t* lens, int n, uint16_t* tab, int tb, u
     o += count[l];
   }
   if (over) return false;
+  if (state) {
+    int f = 0, ix = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l)
+      if (l <= tb) { ix += count[l]; f = (f + count[l]) << 1; }
+    *state = ((uint32_t)f << 16) | (uint32_t)ix;
+  }
   if (lane < 16) {
     int c = 0;
 #pragma unroll
@@ -148,13 +208,38 @@ __device__ bool build_table(const uint8_t* lens, int n, uint16_t* tab, int tb, u
       sym[base + rank] = (uint16_t)s;
       if (ml <= tb) {
         const uint32_t rev = __brev((uint32_t)(first + rank)) >> (32 - ml);
-        const uint16_t e = (uint16_t)((s << 4) | ml | (s < n_flagged ? 0x8000 : 0));
+        const T e = make((uint32_t)s, (uint32_t)ml);
         for (uint32_t k = rev; k < (1u << tb); k += (1u << ml)) tab[k] = e;
       }
     }
   }
   return true;
 }
+
+// A code longer than the direct table's tb index bits, decoded canonically from level tb + 1 on by the lane that met it:
+// bits = the stream from the code's first bit (at least 15 valid), state = the decoder's first << 16 | index after tb
+// levels.  Symbol | length << 16, or ~0 when no code of at most 15 bits starts like this.
+__device__ __forceinline__ uint32_t long_code(uint32_t bits, int tb, uint32_t state, const uint16_t* cnt, const uint16_t* sym) {
+  int code = (int)(__brev(bits) >> (32 - tb)) << 1, first = (int)(state >> 16), index = (int)(state & 0xffffu);
+  uint32_t b = bits >> tb;
+  for (int l = tb + 1; l <= 15; ++l) {
+    code |= (int)(b & 1u);
+    b >>= 1;
+    const int count = (int)cnt[l];
+    if (code - count < first) return (uint32_t)sym[index + (code - first)] | ((uint32_t)l << 16);
+    index += count; first += count; first <<= 1; code <<= 1;
+  }
+  return ~0u;
+}
+
+// what a lane finds at a bit position
+struct Sym {
+  uint32_t kind;     // 0 literal, 1 match, 2 end of block, 3 = a code longer than the table's index bits, or an invalid one
+  uint32_t nbits;    // the whole symbol: code, extra bits, distance code, extra bits
+  uint32_t outlen;   // bytes it produces
+  uint32_t val;      // the literal, or the match's length
+  uint32_t dist;
+};
 
 __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const svdss_bgzf_block_t* __restrict__ blks,
                                                          uint8_t* out, int32_t* __restrict__ status) {
@@ -167,60 +252,88 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
   uint8_t* const winb = (uint8_t*)L.win;
   if (isize == 0) { if (lane == 0) status[blockIdx.x] = ST_OK; return; }
 #ifdef INF_COUNT
-  unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 #define FAIL(code) do { status[blockIdx.x] = (code); return; } while (0)
 
   // ---- input: absolute offsets into comp; the ring holds [base, base + INB)
   uint64_t base = in_first & ~(uint64_t)(HALF - 1), in_addr = in_first;
-  auto load_half = [&](uint64_t a0) {   // HALF bytes, 8 per lane
-    static_assert(HALF == 64 * 8, "one uint2 per lane");
-    const uint2 v = *(const uint2*)(comp + a0 + (uint64_t)lane * 8);
-    *(uint2*)((uint8_t*)L.inb + ((a0 + (uint64_t)lane * 8) & (INB - 1))) = v;
+  static_assert(HALF == 64 * 8, "one uint2 per lane");
+  auto fill_from = [&](uint64_t a0, int n_half) {   // n_half (at most 8) pieces of HALF bytes from a0 on, 8 bytes per lane each
+    uint2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < n_half) v[i] = *(const uint2*)(comp + a0 + (uint64_t)(i * HALF) + (uint64_t)lane * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < n_half) *(uint2*)((uint8_t*)L.inb + ((a0 + (uint64_t)(i * HALF) + (uint64_t)lane * 8) & (INB - 1))) = v[i];
   };
-  load_half(base);
-  load_half(base + HALF);
+  auto restart_at = [&](uint64_t a) {   // the ring anew, from the piece that holds byte a
+    base = a & ~(uint64_t)(HALF - 1);
+    for (int h = 0; h < INB / HALF; h += 8) fill_from(base + (uint64_t)(h * HALF), INB / HALF - h < 8 ? INB / HALF - h : 8);
+  };
+  // the ring follows the reader: whenever the reader is HALF + 32 bytes past the ring's first byte, the piece it left is
+  // replaced by the next one not held yet (32 bytes late: the bit buffer holds up to 8 bytes that were read before
+  // in_addr, and rounds and passes read the ring at the position of the first unused bit)
+  auto catch_up = [&](uint64_t reader) {
+    while (reader - base >= (uint64_t)(HALF + 32)) {
+      const uint32_t can = (uint32_t)((reader - base - 32) / HALF);
+      const int n = (int)(can < 8u ? can : 8u);
+      fill_from(base + INB, n);
+      base += (uint64_t)(n * HALF);
+    }
+  };
+  restart_at(in_addr);
   uint64_t bb = 0;
   int bc = 0;
-  auto step_half = [&]() {
-    // (32 bytes late: the bit buffer holds up to 8 bytes that were read before in_addr, and the literal runs read the
-    // ring at the position of the first unused bit)
-    if (in_addr - base >= HALF + 32) { load_half(base + INB); base += HALF; }
+  auto align_reader = [&]() {   // single bytes until in_addr is a multiple of 4
+    for (; (in_addr & 3) != 0; ++in_addr) {
+      const uint32_t b = UNI((uint32_t)((const uint8_t*)L.inb)[in_addr & (INB - 1)]);
+      bb |= (uint64_t)b << bc;
+      bc += 8;
+    }
   };
-  for (; (in_addr & 3) != 0; ++in_addr) {
-    const uint32_t b = UNI((uint32_t)((const uint8_t*)L.inb)[in_addr & (INB - 1)]);
-    bb |= (uint64_t)b << bc;
-    bc += 8;
-  }
-  step_half();
+  align_reader();
   auto refill = [&]() {   // at least 33 bits afterwards
     if (bc <= 32) {
       const uint32_t w = UNI(L.inb[(in_addr & (INB - 1)) >> 2]);
       bb |= (uint64_t)w << bc;
       bc += 32;
       in_addr += 4;
-      step_half();
+      catch_up(in_addr);
     }
   };
   auto take = [&](int n) { const uint32_t v = (uint32_t)(bb & ((1ull << n) - 1)); bb >>= n; bc -= n; return v; };
-  auto decode = [&](const uint16_t* tab, int tb, const uint16_t* cnt, const uint16_t* sym) -> int {
+  auto reader_to_bit = [&](uint64_t P) {   // the bit buffer, from bit position P
+    in_addr = (P >> 5) << 2;
+    catch_up(in_addr);
+    const uint32_t v0 = UNI(L.inb[(in_addr & (INB - 1)) >> 2]), v1 = UNI(L.inb[((in_addr + 4) & (INB - 1)) >> 2]);
+    const int sh = (int)(P & 31);
+    bb = (((uint64_t)v1 << 32) | v0) >> sh;
+    bc = 64 - sh;
+    in_addr += 8;
+    catch_up(in_addr);
+  };
+  // one code through the bit buffer: the table's entry, or -- a code longer than the table's index bits -- the entry
+  // `make` gives the symbol that canonical decoding finds; ~0 if there is no such code
+  auto decode = [&](const auto* tab, int tb, const uint16_t* cnt, const uint16_t* sym, auto make) -> uint32_t {
     refill();
     const uint32_t e = UNI((uint32_t)tab[bb & ((1u << tb) - 1)]);
     const int len = (int)(e & 15u);
-    if (len) { bb >>= len; bc -= len; return (int)((e & 0x7fffu) >> 4); }
+    if (len) { bb >>= len; bc -= len; return e; }
     int code = 0, first = 0, index = 0;
     uint64_t b = bb;
     for (int l = 1; l <= 15; ++l) {
       code |= (int)(b & 1);
       b >>= 1;
       const int count = UNI((int)cnt[l]);
-      if (code - count < first) { bb >>= l; bc -= l; return UNI((int)sym[index + (code - first)]); }
+      if (code - count < first) { bb >>= l; bc -= l; return (uint32_t)make((uint32_t)UNI((int)sym[index + (code - first)]), (uint32_t)l); }
       index += count; first += count; first <<= 1; code <<= 1;
     }
-    return -1;
+    return ~0u;
   };
 
-  // ---- output: the ring holds the last 32 KB; [flushed, wpos) is not in HBM yet
+  // ---- output: the ring holds the most recent WIN bytes; [flushed, wpos) is not in HBM yet
   uint32_t wpos = 0, flushed = 0;
   auto flush = [&](bool final) {
     const uint32_t upto = wpos;
@@ -244,26 +357,62 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
     }
   };
 
-  // a match of ml bytes at output position o, dd bytes back.  Sources closer than NEAR are in the ring; older ones were
-  // written to HBM by an earlier flush (complete 128-byte lines by now: nothing of this block's output is read from HBM
-  // within FLUSH + ROUND_MAX + 258 of its end) and are read back from there -- with the ring this small a CU holds a dozen
-  // blocks, and that latency is what the other wavefronts are for.
-  auto copy_match = [&](uint32_t o, uint32_t ml, uint32_t dd) {
+  // a match of ml bytes at output position o, dd bytes back, copied by the whole wave.  Source bytes from position
+  // ring_lo on are in the ring; older ones were written to HBM by an earlier flush and are read back from there -- with
+  // a ring this small a CU holds several blocks, and that latency is what the other wavefronts are for.
+  auto copy_match = [&](uint32_t o, uint32_t ml, uint32_t dd, uint32_t ring_lo) {
     const uint32_t from = o - dd;
-    if (dd <= (uint32_t)NEAR && dd >= ml && ml <= 64) {   // the common one: short, from the ring, not overlapping itself
+    if (from >= ring_lo && dd >= ml && ml <= 64) {   // the common one: short, from the ring, not overlapping itself
       if ((uint32_t)lane < ml) winb[(o + (uint32_t)lane) & WM] = winb[(from + (uint32_t)lane) & WM];
       return;
     }
-    const bool far = dd > (uint32_t)NEAR;
+    const bool far = from < ring_lo;
     if (far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this block's own stores of long ago)
     uint8_t v[5];
     int nk = 0;
     for (uint32_t k = lane; k < ml; k += 64) {
       const uint32_t sp = from + (dd >= ml ? k : k % dd);   // (an overlapping match repeats its first dd bytes)
-      v[nk++] = (far && o - sp > (uint32_t)NEAR) ? __hip_atomic_load(o8 + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : winb[sp & WM];
+      v[nk++] = sp < ring_lo ? __hip_atomic_load(o8 + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : winb[sp & WM];
     }
     nk = 0;
     for (uint32_t k = lane; k < ml; k += 64) winb[(o + k) & WM] = v[nk++];
+  };
+  auto near_lo = [&](uint32_t o) { return o > (uint32_t)NEAR ? o - (uint32_t)NEAR : 0u; };   // (rounds)
+
+  uint32_t lstate = 0, dstate = 0;   // (long_code: the canonical decoders' state behind the direct tables' levels)
+  // the symbol that starts at bit position pl (modulo 2^32: the ring is indexed by the low bits), whole: a literal, or
+  // a length with its extra bits, its distance code and that one's extra bits -- at most 48 bits --, or the end-of-block code
+  auto symbol_at = [&](uint32_t pl) -> Sym {
+    const uint32_t di = pl >> 5;
+    const uint32_t w0 = L.inb[di & (INB / 4 - 1)], w1 = L.inb[(di + 1) & (INB / 4 - 1)], w2 = L.inb[(di + 2) & (INB / 4 - 1)];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, pl & 31u), hi = __builtin_amdgcn_alignbit(w2, w1, pl & 31u);
+    const uint64_t b64 = ((uint64_t)hi << 32) | lo;
+    uint32_t E = L.lit[lo & ((1u << LB) - 1)];
+    if (__ballot((E & 15u) == 0u)) {
+      if ((E & 15u) == 0u) {
+        const uint32_t r = long_code(lo, LB, lstate, L.lcnt, L.lsym);
+        if (r != ~0u) E = LitEntry()(r & 0xffffu, r >> 16);
+      }
+    }
+    const uint32_t len = E & 15u, lx = (E >> 6) & 7u;
+    Sym s;
+    s.kind = (E >> 4) & 3u;
+    s.val = ((E >> 9) & 511u) + __builtin_amdgcn_ubfe(lo, len, lx);
+    const uint32_t doff = len + lx;
+    const uint32_t dbits = (uint32_t)(b64 >> doff);
+    uint32_t D = L.dst[dbits & ((1u << DB) - 1)];
+    if (__ballot(s.kind == 1u && (D & 15u) == 0u)) {
+      if (s.kind == 1u && (D & 15u) == 0u) {
+        const uint32_t r = long_code(dbits, DB, dstate, L.dcnt, L.dsym);
+        if (r != ~0u) D = DstEntry()(r & 0xffffu, r >> 16);
+      }
+    }
+    const uint32_t dl = D & 15u, dx = (D >> 4) & 15u;
+    s.dist = (D >> 8) + __builtin_amdgcn_ubfe(dbits, dl, dx);
+    if (s.kind == 1u && dl == 0u) s.kind = 3u;
+    s.nbits = s.kind == 1u ? doff + dl + dx : len;
+    s.outlen = s.kind == 0u ? 1u : s.kind == 1u ? s.val : 0u;
+    return s;
   };
 
   for (;;) {
@@ -289,16 +438,9 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
       }
       // restart the reader behind the stored bytes
       in_addr = src + len;
-      base = in_addr & ~(uint64_t)(HALF - 1);
-      load_half(base);
-      load_half(base + HALF);
+      restart_at(in_addr);
       bb = 0; bc = 0;
-      for (; (in_addr & 3) != 0; ++in_addr) {
-        const uint32_t b = UNI((uint32_t)((const uint8_t*)L.inb)[in_addr & (INB - 1)]);
-        bb |= (uint64_t)b << bc;
-        bc += 8;
-      }
-      step_half();
+      align_reader();
     } else if (btype == 1 || btype == 2) {
       int nlen, ndist;
       if (btype == 1) {
@@ -317,13 +459,15 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
           const int ord = i < 12 ? (int)((0x022caa324e804a30ull >> (5 * i)) & 31) : (int)((0x3c2e1346cull >> (5 * (i - 12))) & 31);
           if (lane == 0) L.lens[ord] = (uint8_t)v;
         }
-        if (!build_table(L.lens, 19, L.dst, CB, L.dcnt, L.dsym, lane)) FAIL(ST_LENS);
+        uint16_t* const ctab = (uint16_t*)L.dst;
+        if (!build_table(L.lens, 19, ctab, CB, L.dcnt, L.dsym, lane, (uint16_t)0, LenEntry())) FAIL(ST_LENS);
         // the code lengths of the literal/length and distance codes, run-length coded (all lanes keep the same copy)
         uint8_t* const tmp = (uint8_t*)L.lsym;   // (free until the tables are built)
         int i = 0, prev = 0;
         while (i < nlen + ndist) {
-          const int s = decode(L.dst, CB, L.dcnt, L.dsym);
-          if (s < 0) FAIL(ST_LENS);
+          const uint32_t e = decode(ctab, CB, L.dcnt, L.dsym, LenEntry());
+          if (e == ~0u) FAIL(ST_LENS);
+          const int s = (int)(e >> 4);
           if (s < 16) { if (lane == 0) tmp[i] = (uint8_t)s; prev = s; ++i; continue; }
           refill();
           int rep, val = 0;
@@ -343,58 +487,171 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
         nlen = 288; ndist = 30;
       }
       CNT(4, 1);
-      if (!build_table(L.lens, nlen, L.lit, LB, L.lcnt, L.lsym, lane, 256)) FAIL(ST_LENS);
-      if (!build_table(L.lens + 288, ndist, L.dst, DB, L.dcnt, L.dsym, lane)) FAIL(ST_LENS);
-      // ---- symbols, a round of up to 64 bits at a time.  Lane l fetches the 32 bits that start l bits ahead (straight
-      // from the input ring) and looks them up in both tables; the scalar unit then follows the chain from offset 0 --
-      // a code's length names the lane that holds what comes next: the next code, a length's extra bits, the distance
-      // code, its extra bits -- with lane reads only, no memory in the chain.  Literals are stored together by the lanes
-      // they start at; a match is copied by all lanes as soon as the literals before it are in the window.  A code
-      // longer than the table's index bits takes the one-symbol path (bit buffer, canonical decoding).  The cursor of
-      // the rounds is the bit position P alone; errors are collected and reported after the loop.
+      if (!build_table(L.lens, nlen, L.lit, LB, L.lcnt, L.lsym, lane, LIT_NONE, LitEntry(), &lstate)) FAIL(ST_LENS);
+      if (!build_table(L.lens + 288, ndist, L.dst, DB, L.dcnt, L.dsym, lane, 0u, DstEntry(), &dstate)) FAIL(ST_LENS);
+      lstate = (uint32_t)UNI((int)lstate); dstate = (uint32_t)UNI((int)dstate);
+      // ---- symbols.  Two engines share the rings, the tables and the cursor (the bit position P, the output position):
+      //
+      // A PASS takes 64 * SB bits at once, SB bits per lane.  Every lane walks the symbols of its own piece one after
+      // the other (symbol_at: two table lookups per symbol, 64 symbols per instruction) from a start that is a guess at
+      // first -- the piece's first bit -- and notes where its walk leaves the piece.  Huffman codes resynchronise: after a
+      // few symbols a walk from a wrong start falls in step with the true chain of symbols, so most exits are right
+      // although most starts were wrong.  The walk is repeated with every lane starting where its neighbour left, until
+      // the starts stop changing (lane 0's start is true; by induction so are all that agree with their neighbour's exit:
+      // two or three walks for data that resynchronises, and the lanes that agree after INF_MAXIT walks for data that
+      // does not).  A scan over the lanes' byte and match counts places every lane's output; a last walk stores the
+      // literals in the ring and queues the matches, which are then copied 64 at a time: those whose source lies before
+      // everything the 64 write -- nearly all -- by one lane each, side by side, the others one after the other by the
+      // wave.  A pass ends early at the end-of-block code, at a code the tables cannot decode (the round below takes it),
+      // at the ring's capacity.
+      //
+      // A ROUND takes up to 64 bits: lane l decodes the symbol that would start l bits ahead, the chain of symbol starts
+      // from offset 0 is found by pointer doubling on the lanes (lane l knows where the symbol after its own starts, J,
+      // and which offsets the chain from l visits, M; six steps of "append the chain of the lane I point at" close M),
+      // literals are stored together, matches copied in order by all lanes.  A code longer than the table's index bits
+      // takes the one-symbol path (bit buffer, canonical decoding).  Rounds run between passes -- they take what ends a
+      // pass -- and instead of passes where passes do not pay: near the end of the input, and for a while after a pass that
+      // found few lanes in agreement.
       uint32_t err = 0;
       bool eob = false;
       uint64_t P = in_addr * 8 - (uint64_t)bc;
+      uint32_t skip_pass = 0;
       for (;;) {
-        if ((P >> 3) - base >= HALF + 32) { load_half(base + INB); base += HALF; }
+        catch_up(P >> 3);
+        if (skip_pass) --skip_pass;
+        else if ((P >> 3) + (uint64_t)(PASS_BYTES / 4) < in_end) {
+          CNT(5, 1);
+          flush(false);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (far sources of this pass's matches: stores of this block)
+          const uint32_t P32 = (uint32_t)P;
+          const uint32_t ring_lo = wpos > (uint32_t)PASS_BACK ? wpos - (uint32_t)PASS_BACK : 0u;
+          const uint32_t hi_bound = (uint32_t)(lane + 1) * (uint32_t)SB;
+          // ---- walks until the starts agree
+          static_assert(INF_WARM <= SB, "a guessed walk starts inside the neighbour's piece");
+          uint32_t start = lane ? (uint32_t)lane * (uint32_t)SB - (uint32_t)INF_WARM : 0u, x = 0, c = 0, m = 0, st = 0;   // st: 0 left the piece, 1 end of block, 2 stopped
+          bool walk = true;
+          uint32_t n_ok = 1;
+          for (int it = 0;; ++it) {
+            CNT(7, 1);
+            uint32_t r = walk ? start : x;
+            if (walk) { c = 0; m = 0; st = 0; }
+            bool going = walk && r < hi_bound;
+            while (__ballot(going)) {
+              CNT(8, 1);
+              const Sym s = symbol_at(P32 + r);
+              if (going) {
+                if (s.kind == 3u) { st = 2u; going = false; }
+                else {
+                  r += s.nbits;
+                  c += s.outlen;
+                  m += s.kind & 1u;
+                  if (s.kind == 2u) { st = 1u; going = false; }
+                  else going = r < hi_bound;
+                }
+              }
+            }
+            x = r;
+            const uint32_t px = (uint32_t)__shfl_up((int)x, 1), pst = (uint32_t)__shfl_up((int)st, 1);
+            const bool agrees = lane == 0 || (pst == 0u && px == start);
+            const unsigned long long ag = __ballot(agrees);
+            n_ok = ag == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ag);
+            // the first lane that disagrees walks again from its neighbour's exit -- and so do all others that disagree:
+            // most of them are right about their neighbour already
+            walk = !agrees && pst == 0u;
+            if (walk) start = px;
+            const bool again = n_ok < 64u && __builtin_amdgcn_readlane((int)walk, (int)(n_ok & 63u)) != 0;
+            // (another walk costs what every walk costs and can bring the pass to 64 lanes at most: it + 1 walks and the
+            // last one for n_ok lanes now, against one more for 64)
+            if (!again || it + 1 >= INF_MAXIT || (it >= 1 && n_ok * (uint32_t)(it + 3) >= 64u * (uint32_t)(it + 2))) break;
+          }
+          // ---- the lanes taken: in agreement, within the ring's and the queue's capacity
+          const bool mine = (uint32_t)lane < n_ok;
+          const uint32_t ic = (uint32_t)wave_scan_add((int)(mine ? c : 0u)), im = (uint32_t)wave_scan_add((int)(mine ? m : 0u));
+          const unsigned long long fits = __ballot(mine && ic <= (uint32_t)PASS_MAX && im <= (uint32_t)MAXM);
+          const uint32_t T = fits == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fits);
+          if (T == 0u) skip_pass = 4;
+          else {
+            CNT(6, T);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)ic, (int)(T - 1u));
+            const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)im, (int)(T - 1u));
+            const uint32_t adv = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(T - 1u));
+            const uint32_t lst = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)(T - 1u));
+            if (wpos + total > isize) { err = ST_OUT; break; }
+            // ---- the last walk: literals into the ring, matches into the queue
+            {
+              uint32_t r = start, o = wpos + (ic - c), q = im - m;
+              bool going = (uint32_t)lane < T && r < hi_bound;
+              bool bad = false;
+              while (__ballot(going)) {
+                const Sym s = symbol_at(P32 + r);
+                if (going) {
+                  if (s.kind >= 2u) going = false;
+                  else {
+                    if (s.kind == 0u) winb[o & WM] = (uint8_t)s.val;
+                    else {
+                      if (s.dist > o) bad = true;
+                      L.mrec[q] = ((s.val - 3u) << 15) | (s.dist - 1u);
+                      L.mpos[q] = (uint16_t)(o - wpos);
+                      ++q;
+                    }
+                    r += s.nbits;
+                    o += s.outlen;
+                    going = r < hi_bound;
+                  }
+                }
+              }
+              if (__ballot(bad)) { err = ST_DIST; break; }
+            }
+            // ---- the matches, 64 at a time in output order.  Everything below the first one's output position is
+            // complete (literals, earlier matches): a match whose source ends there depends on none of the 64.
+            CNT(9, M);
+            for (uint32_t g0 = 0; g0 < M; g0 += 64) {
+              const bool have = g0 + (uint32_t)lane < M;
+              const uint32_t rec = have ? L.mrec[g0 + (uint32_t)lane] : 0u;
+              const uint32_t o = wpos + (have ? (uint32_t)L.mpos[g0 + (uint32_t)lane] : 0u), ml = (rec >> 15) + 3u, dd = (rec & 0x7fffu) + 1u;
+              const uint32_t from = o - dd;
+              const uint32_t o_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+              const bool side = have && ml <= 32u && from + ml <= o_first;
+              for (uint32_t k0 = 0; k0 < 32u; k0 += 4u) {
+                if (!__ballot(side && k0 < ml)) break;
+                uint8_t v[4];
+#pragma unroll
+                for (uint32_t t = 0; t < 4u; ++t) {
+                  const uint32_t k = k0 + t;
+                  if (side && k < ml)
+                    v[t] = from + k < ring_lo ? __hip_atomic_load(o8 + from + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : winb[(from + k) & WM];
+                }
+#pragma unroll
+                for (uint32_t t = 0; t < 4u; ++t) {
+                  const uint32_t k = k0 + t;
+                  if (side && k < ml) winb[(o + k) & WM] = v[t];
+                }
+              }
+              unsigned long long rest = __ballot(have && !side);
+              while (rest) {
+                const int h = (int)__builtin_ctzll(rest);
+                rest &= rest - 1;
+                CNT(10, 1);
+                copy_match(__builtin_amdgcn_readlane((int)o, h), __builtin_amdgcn_readlane((int)ml, h), __builtin_amdgcn_readlane((int)dd, h), ring_lo);
+              }
+            }
+            wpos += total;
+            P += (uint64_t)adv;
+            if ((P >> 3) > in_end + 16) { err = ST_IN; break; }
+            if (lst == 1u) { eob = true; break; }
+            if (T < 8u) skip_pass = 24;     // (no resynchronisation to speak of: rounds for a while)
+            if (wpos - flushed >= (uint32_t)FLUSH) flush(false);
+            catch_up(P >> 3);
+          }
+        }
         CNT(0, 1);
-        // ---- every lane decodes the symbol that would start at its bit offset, whole: a literal, or a match with its
-        // extra bits and its distance (all inside the 64 bits that start there), or the end-of-block code -- and where
-        // the next symbol starts
-        const uint32_t pl = (uint32_t)P + (uint32_t)lane;   // (the ring is indexed modulo 2^14 bits)
-        const uint32_t di = pl >> 5;
-        const uint32_t w0 = L.inb[di & (INB / 4 - 1)], w1 = L.inb[(di + 1) & (INB / 4 - 1)], w2 = L.inb[(di + 2) & (INB / 4 - 1)];
-        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, pl & 31u), hi = __builtin_amdgcn_alignbit(w2, w1, pl & 31u);
-        const uint64_t b64 = ((uint64_t)hi << 32) | lo;
-        const uint32_t E = (uint32_t)L.lit[lo & ((1u << LB) - 1)];
-        const uint32_t len = E & 15u, sym = (E & 0x7fffu) >> 4;
-        const bool is_lit = (E & 0x8000u) != 0;
-        const uint32_t ls = umin(sym - 257u, 28u);   // (lanes that hold no length code compute on a harmless value)
-        const uint32_t lx = ls < 8 || ls == 28 ? 0 : (ls >> 2) - 1;
-        const uint32_t lb = ls < 8 ? 3u + ls : ls == 28 ? 258u : 3u + ((4u + (ls & 3u)) << lx);
-        const uint32_t mlen = lb + ((lo >> len) & ((1u << lx) - 1));
-        const uint32_t doff = len + lx;
-        const uint32_t D = (uint32_t)L.dst[(uint32_t)(b64 >> doff) & ((1u << DB) - 1)];
-        const uint32_t dl = D & 15u, ds = umin(D >> 4, 29u);
-        const uint32_t dx = ds < 4 ? 0 : (ds >> 1) - 1;
-        const uint32_t db = ds < 4 ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx);
-        const uint32_t eoff = doff + dl;
-        const uint32_t dist = db + ((uint32_t)(b64 >> eoff) & ((1u << dx) - 1));
-        // kind: 0 literal, 1 match, 2 end of block, 3 = a code longer than the table's index bits or an invalid one (the
-        // one-symbol path decodes it, or reports it)
-        const bool is_match = !is_lit && sym >= 257u;
-        uint32_t kind = is_lit ? 0u : sym == 256u ? 2u : 1u;
-        if (len == 0 || (is_match && (sym > 285u || dl == 0 || (D >> 4) > 29u))) kind = 3u;
-        const uint32_t nbits = kind == 1u ? eoff + dx : len;
-        const uint32_t outlen = kind == 0u ? 1u : kind == 1u ? mlen : 0u;
-        // ---- the chain of symbol starts from offset 0, by pointer doubling on the lanes: lane l knows where the symbol
-        // after its own starts (J) and which offsets the chain from l visits (M); six rounds of "append the chain of
-        // the lane I point at" close M over the 64 offsets (a symbol is at least one bit long), and the chain of the
-        // round is M of lane 0.  A symbol the tables cannot decode (kind 3) is on nobody's chain and ends the chains
-        // that reach it; so do the end-of-block code and a symbol that ends beyond the 64 offsets -- after being
-        // visited.  (One scalar instruction per CU and cycle: followed symbol by symbol on the scalar unit, ~14
-        // instructions each, the chain was what bound the kernel.)
-        const uint32_t nextl = (uint32_t)lane + nbits;
+        // ---- a round: every lane decodes the symbol that would start at its bit offset, and where the next one starts
+        const Sym s = symbol_at((uint32_t)P + (uint32_t)lane);
+        const uint32_t kind = s.kind, outlen = s.outlen;
+        // the chain of symbol starts from offset 0.  A symbol the tables cannot decode (kind 3) is on nobody's chain and
+        // ends the chains that reach it; so do the end-of-block code and a symbol that ends beyond the 64 offsets --
+        // after being visited.
+        const uint32_t nextl = (uint32_t)lane + s.nbits;
         uint32_t J = (kind == 3u || kind == 2u || nextl >= 64u) ? 64u : nextl;
         uint32_t Mlo = kind == 3u ? 0u : (lane < 32 ? 1u << lane : 0u), Mhi = kind == 3u ? 0u : (lane >= 32 ? 1u << (lane - 32) : 0u);
         while (__ballot(J < 64u)) {
@@ -405,8 +662,8 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
         }
         const unsigned long long chain0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)Mlo) |
                                           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)Mhi) << 32);
-        // ---- where every symbol of the chain puts its output: a scan over the chain's lanes; the round takes the
-        // symbols that start before ROUND_MAX bytes of it
+        // where every symbol of the chain puts its output: a scan over the chain's lanes; the round takes the symbols
+        // that start before ROUND_MAX bytes of it
         const bool onc0 = ((chain0 >> lane) & 1ull) != 0;
         const uint32_t x0 = onc0 ? outlen : 0u;
         const uint32_t incl = (uint32_t)wave_scan_add((int)x0);
@@ -423,16 +680,16 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
         } else slow = true;                                          // (the symbol at offset 0 itself)
         const uint32_t opos = wpos + (incl - x0);
         if (wpos + total > isize) { err = ST_OUT; break; }
-        if (__ballot(onc && kind == 1u && dist > opos)) { err = ST_DIST; break; }
-        if (onc && kind == 0u) winb[opos & WM] = (uint8_t)sym;
-        // ---- the matches, in order
+        if (__ballot(onc && kind == 1u && s.dist > opos)) { err = ST_DIST; break; }
+        if (onc && kind == 0u) winb[opos & WM] = (uint8_t)s.val;
+        // the matches, in order
         unsigned long long mm = __ballot(onc && kind == 1u);
         while (mm) {
           const int h = (int)__builtin_ctzll(mm);
           mm &= mm - 1;
           CNT(2, 1);
-          const uint32_t o = __builtin_amdgcn_readlane(opos, h), ml = __builtin_amdgcn_readlane(mlen, h), dd = __builtin_amdgcn_readlane(dist, h);
-          copy_match(o, ml, dd);
+          const uint32_t o = __builtin_amdgcn_readlane(opos, h), ml = __builtin_amdgcn_readlane(s.val, h), dd = __builtin_amdgcn_readlane(s.dist, h);
+          copy_match(o, ml, dd, near_lo(o));
         }
         wpos += total;
         P += (uint64_t)off;
@@ -442,55 +699,33 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
         if (!slow && off != 0) continue;
         // ---- one symbol through the bit buffer
         CNT(3, 1);
-        {
-          in_addr = (P >> 5) << 2;
-          const uint32_t v0 = UNI(L.inb[(in_addr & (INB - 1)) >> 2]), v1 = UNI(L.inb[((in_addr + 4) & (INB - 1)) >> 2]);
-          const int sh = (int)(P & 31);
-          bb = (((uint64_t)v1 << 32) | v0) >> sh;
-          bc = 64 - sh;
-          in_addr += 8;
-          step_half();
-        }
-        const int s = decode(L.lit, LB, L.lcnt, L.lsym);
-        if (s < 0) { err = ST_CODE; break; }
-        if (s < 256) {
+        reader_to_bit(P);
+        const uint32_t E = decode(L.lit, LB, L.lcnt, L.lsym, LitEntry());
+        const uint32_t k1 = E == ~0u ? 3u : (E >> 4) & 3u;
+        if (k1 == 3u) { err = ST_CODE; break; }
+        if (k1 == 0u) {
           if (wpos >= isize) { err = ST_OUT; break; }
-          if (lane == 0) winb[wpos & WM] = (uint8_t)s;
+          if (lane == 0) winb[wpos & WM] = (uint8_t)(E >> 9);
           ++wpos;
-        } else if (s == 256) {
+        } else if (k1 == 2u) {
           eob = true;
         } else {
-          if (s > 285) { err = ST_CODE; break; }
           refill();
-          const int ls = s - 257;
-          const int lx = ls < 8 || ls == 28 ? 0 : (ls >> 2) - 1;
-          const uint32_t lb = ls < 8 ? 3u + (uint32_t)ls : ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << lx);
-          const uint32_t len = lb + take(lx);
-          const int ds = decode(L.dst, DB, L.dcnt, L.dsym);
-          if (ds < 0 || ds > 29) { err = ST_DIST; break; }
+          const uint32_t len = ((E >> 9) & 511u) + take((int)((E >> 6) & 7u));
+          const uint32_t D = decode(L.dst, DB, L.dcnt, L.dsym, DstEntry());
+          if (D == ~0u || (D & 15u) == 0u) { err = ST_DIST; break; }
           refill();
-          const int dx = ds < 4 ? 0 : (ds >> 1) - 1;
-          const uint32_t db = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << dx);
-          const uint32_t dist = db + take(dx);
+          const uint32_t dist = (D >> 8) + take((int)((D >> 4) & 15u));
           if (dist > wpos) { err = ST_DIST; break; }
           if (wpos + len > isize) { err = ST_OUT; break; }
-          copy_match(wpos, len, dist);
+          copy_match(wpos, len, dist, near_lo(wpos));
           wpos += len;
         }
         P = in_addr * 8 - (uint64_t)bc;
         if (eob) break;
       }
       if (err) FAIL((int)err);
-      {   // the bit buffer again, behind the end-of-block code
-        in_addr = (P >> 5) << 2;
-        step_half();
-        const uint32_t v0 = UNI(L.inb[(in_addr & (INB - 1)) >> 2]), v1 = UNI(L.inb[((in_addr + 4) & (INB - 1)) >> 2]);
-        const int sh = (int)(P & 31);
-        bb = (((uint64_t)v1 << 32) | v0) >> sh;
-        bc = 64 - sh;
-        in_addr += 8;
-        step_half();
-      }
+      reader_to_bit(P);   // the bit buffer again, behind the end-of-block code
       if (wpos - flushed >= (uint32_t)FLUSH) flush(false);
     } else {
       FAIL(ST_BTYPE);
@@ -501,7 +736,7 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
   flush(true);
   if (lane == 0) status[blockIdx.x] = ST_OK;
 #ifdef INF_COUNT
-  if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_inf_cnt[k], (unsigned long long)cnt[k]);
+  if (lane == 0) for (int k = 0; k < 12; ++k) atomicAdd(&g_inf_cnt[k], (unsigned long long)cnt[k]);
 #endif
 #undef FAIL
 }
@@ -573,8 +808,8 @@ extern "C" int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8
   if (!o->st) HIPCHK(hipStreamCreateWithFlags(&o->st, hipStreamNonBlocking));
   if (n_blocks == 0) return SVDSS_OK;
   int rc;
-  // (the kernel reads the input in aligned 1 KB pieces, up to 3 KB past a block's last byte)
-  if ((rc = ensure(o->comp, (size_t)comp_bytes + 4096))) return rc;
+  // (the kernel reads the input in aligned 512-byte pieces, up to 5 KB past a block's last byte)
+  if ((rc = ensure(o->comp, (size_t)comp_bytes + 8192))) return rc;
   if ((rc = ensure(o->blks, sizeof(svdss_bgzf_block_t) * (size_t)n_blocks))) return rc;
   if ((rc = ensure(o->status, sizeof(int32_t) * (size_t)n_blocks))) return rc;
   HIPCHK(hipMemcpyAsync(o->comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, o->st));
@@ -595,11 +830,12 @@ extern "C" int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8
   }
 #ifdef INF_COUNT
   {
-    unsigned long long h[8];
+    unsigned long long h[12];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_inf_cnt), sizeof h) == hipSuccess) {
-      fprintf(stderr, "[inflate] per block: rounds %.0f literals %.0f matches %.0f (bytes %.0f, overlapping %.0f) one-symbol steps %.0f deflate blocks %.2f\n",
-              (double)h[0] / n_blocks, (double)h[1] / n_blocks, (double)h[2] / n_blocks, (double)h[5] / n_blocks, (double)h[6] / n_blocks,
-              (double)h[3] / n_blocks, (double)h[4] / n_blocks);
+      fprintf(stderr, "[inflate] per block: deflate blocks %.2f; passes %.1f (lanes taken %.1f, walks %.1f, walk steps %.0f, matches %.0f of them one by one %.0f); "
+                      "rounds %.0f (matches %.0f, one-symbol steps %.0f)\n",
+              (double)h[4] / n_blocks, (double)h[5] / n_blocks, (double)h[6] / n_blocks, (double)h[7] / n_blocks, (double)h[8] / n_blocks,
+              (double)h[9] / n_blocks, (double)h[10] / n_blocks, (double)h[0] / n_blocks, (double)h[2] / n_blocks, (double)h[3] / n_blocks);
       memset(h, 0, sizeof h);
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inf_cnt), h, sizeof h);
     }
