@@ -602,8 +602,12 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
               }
               if (__ballot(bad)) { err = ST_DIST; break; }
             }
-            // ---- the matches, 64 at a time in output order.  Everything below the first one's output position is
-            // complete (literals, earlier matches): a match whose source ends there depends on none of the 64.
+            // ---- the matches, 64 at a time in output order, each lane holding one.  Everything below the first one's output
+            // position is complete (literals, earlier matches).  Copied side by side by the lanes that hold them: the short
+            // ones whose source ends there, or begins behind the match before them (between two matches there are only
+            // literals, and those are in place; such a match may overlap its own output).  The others -- chained closely, as
+            // in low-entropy data, or long -- one after the other by the whole wave.  (Tried: further side-by-side rounds for
+            // those that become ready -- 8 rounds per 64 on binned qualities, each dearer than three single copies.)
             CNT(9, M);
             for (uint32_t g0 = 0; g0 < M; g0 += 64) {
               const bool have = g0 + (uint32_t)lane < M;
@@ -611,15 +615,19 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
               const uint32_t o = wpos + (have ? (uint32_t)L.mpos[g0 + (uint32_t)lane] : 0u), ml = (rec >> 15) + 3u, dd = (rec & 0x7fffu) + 1u;
               const uint32_t from = o - dd;
               const uint32_t o_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
-              const bool side = have && ml <= 32u && from + ml <= o_first;
+              const uint32_t pe = (uint32_t)__shfl_up((int)(o + ml), 1);
+              const bool side = have && ml <= 32u && (from + ml <= o_first || lane == 0 || from >= pe);
+              uint32_t sp = from;
               for (uint32_t k0 = 0; k0 < 32u; k0 += 4u) {
                 if (!__ballot(side && k0 < ml)) break;
                 uint8_t v[4];
 #pragma unroll
                 for (uint32_t t = 0; t < 4u; ++t) {
-                  const uint32_t k = k0 + t;
-                  if (side && k < ml)
-                    v[t] = from + k < ring_lo ? __hip_atomic_load(o8 + from + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : winb[(from + k) & WM];
+                  if (side && k0 + t < ml) {
+                    v[t] = sp < ring_lo ? __hip_atomic_load(o8 + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : winb[sp & WM];
+                    ++sp;
+                    if (sp == o) sp = from;     // (a match that overlaps its own output repeats its first dd bytes)
+                  }
                 }
 #pragma unroll
                 for (uint32_t t = 0; t < 4u; ++t) {
