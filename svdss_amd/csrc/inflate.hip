@@ -47,11 +47,14 @@ namespace {
 #ifndef INF_MAXM
 #define INF_MAXM 512        // matches a pass may hold back until its literals are placed
 #endif
-#ifndef INF_MAXIT
-#define INF_MAXIT 5         // walks of a pass before it settles for the lanes that agree
+#ifndef INF_WALKS
+#define INF_WALKS 2         // walks per pass: then it takes the lanes that agree, and the others keep theirs for the next ...
 #endif
-#ifndef INF_WARM
-#define INF_WARM 0          // bits before its piece at which a lane's first, guessed walk starts: more symbols to fall in step over
+#ifndef INF_TAKE
+#define INF_TAKE 32         // ... unless fewer than this many agree: then up to ...
+#endif
+#ifndef INF_MAXW
+#define INF_MAXW 3          // ... this many walks
 #endif
 #ifndef INF_LB
 #define INF_LB 9
@@ -496,14 +499,15 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
       // the other (symbol_at: two table lookups per symbol, 64 symbols per instruction) from a start that is a guess at
       // first -- the piece's first bit -- and notes where its walk leaves the piece.  Huffman codes resynchronise: after a
       // few symbols a walk from a wrong start falls in step with the true chain of symbols, so most exits are right
-      // although most starts were wrong.  The walk is repeated with every lane starting where its neighbour left, until
-      // the starts stop changing (lane 0's start is true; by induction so are all that agree with their neighbour's exit:
-      // two or three walks for data that resynchronises, and the lanes that agree after INF_MAXIT walks for data that
-      // does not).  A scan over the lanes' byte and match counts places every lane's output; a last walk stores the
-      // literals in the ring and queues the matches, which are then copied 64 at a time: those whose source lies before
-      // everything the 64 write -- nearly all -- by one lane each, side by side, the others one after the other by the
-      // wave.  A pass ends early at the end-of-block code, at a code the tables cannot decode (the round below takes it),
-      // at the ring's capacity.
+      // although most starts were wrong.  Then every lane walks again from where its neighbour left.  Lane 0's start is
+      // true; by induction so are all that agree with their neighbour's exit, up to the first lane that does not (its
+      // neighbour had not fallen in step by the end of its piece: one piece in twenty).  The pass takes the lanes in
+      // agreement: a scan over their byte and match counts places every lane's output, a last walk stores the literals in
+      // the ring and queues the matches, which are then copied 64 at a time.  The lanes it does not take move down and keep
+      // their walks: in the next pass they are repaired (the first of them starts where this pass ended) while the new
+      // lanes behind them guess.  INF_WALKS = 2 walks and the last one per pass, ~40 lanes taken.  A pass ends early at
+      // the end-of-block code, at a code no table entry or canonical decoding explains (the round below reports it), at
+      // the ring's or the queue's capacity.
       //
       // A ROUND takes up to 64 bits: lane l decodes the symbol that would start l bits ahead, the chain of symbol starts
       // from offset 0 is found by pointer doubling on the lanes (lane l knows where the symbol after its own starts, J,
@@ -515,9 +519,16 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
       uint32_t err = 0;
       bool eob = false;
       uint64_t P = in_addr * 8 - (uint64_t)bc;
-      uint32_t skip_pass = 0;
+      uint32_t skip_pass = 0, small = 0;
+      // what the lanes keep from pass to pass (within this deflate block): each lane's last walk -- where it started and
+      // where it left its piece, relative to P; the bytes and matches it counted; how it ended (0 left the piece, 1 end of
+      // block, 2 stopped at a code the tables cannot decode) -- and where the pieces lie: lane l's ends (l + 1) * SB - delta
+      // bits behind P.  The lanes a pass does not take move down and keep theirs.
+      uint32_t start = 0, x = 0, c = 0, m = 0, st = 0, delta = 0;
+      bool valid = false;
       for (;;) {
         catch_up(P >> 3);
+        bool round_now = true;
         if (skip_pass) --skip_pass;
         else if ((P >> 3) + (uint64_t)(PASS_BYTES / 4) < in_end) {
           CNT(5, 1);
@@ -525,16 +536,28 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (far sources of this pass's matches: stores of this block)
           const uint32_t P32 = (uint32_t)P;
           const uint32_t ring_lo = wpos > (uint32_t)PASS_BACK ? wpos - (uint32_t)PASS_BACK : 0u;
-          const uint32_t hi_bound = (uint32_t)(lane + 1) * (uint32_t)SB;
-          // ---- walks until the starts agree
-          static_assert(INF_WARM <= SB, "a guessed walk starts inside the neighbour's piece");
-          uint32_t start = lane ? (uint32_t)lane * (uint32_t)SB - (uint32_t)INF_WARM : 0u, x = 0, c = 0, m = 0, st = 0;   // st: 0 left the piece, 1 end of block, 2 stopped
-          bool walk = true;
-          uint32_t n_ok = 1;
+          const uint32_t hi_bound = (uint32_t)(lane + 1) * (uint32_t)SB - delta;
+          // ---- INF_WALKS walks: a lane that has not walked yet starts at its piece's first bit (a guess); one whose
+          // neighbour left elsewhere than it started walks again from there; the others keep what they have
+          uint32_t n_ok = 0;
           for (int it = 0;; ++it) {
+            const uint32_t px = (uint32_t)__shfl_up((int)x, 1), pst = (uint32_t)__shfl_up((int)st, 1);
+            const bool pv = __shfl_up((int)valid, 1) != 0;
+            bool walk;
+            uint32_t from_;
+            if (lane == 0) { walk = !valid || start != 0u; from_ = 0u; }
+            else if (!valid) { walk = true; from_ = (uint32_t)lane * (uint32_t)SB - delta; }
+            else { walk = pv && pst == 0u && px != start; from_ = px; }
+            // in agreement: lane 0 if it started at P, a lane whose neighbour left where it started (by induction all up
+            // to the first that is not are the true chain of symbols)
+            const bool agrees = valid && !walk && (lane == 0 || (pv && pst == 0u));
+            const unsigned long long ag = __ballot(agrees);
+            n_ok = ag == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ag);
+            // (the first lane not in agreement walks now -- unless the chain ended before it: end of block, a stop)
+            if (n_ok == 64u || !__builtin_amdgcn_readlane((int)walk, (int)n_ok) || it >= INF_MAXW || (it >= INF_WALKS && n_ok >= (uint32_t)INF_TAKE)) break;
             CNT(7, 1);
+            if (walk) { start = from_; c = 0; m = 0; st = 0; valid = true; }
             uint32_t r = walk ? start : x;
-            if (walk) { c = 0; m = 0; st = 0; }
             bool going = walk && r < hi_bound;
             while (__ballot(going)) {
               CNT(8, 1);
@@ -551,18 +574,6 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
               }
             }
             x = r;
-            const uint32_t px = (uint32_t)__shfl_up((int)x, 1), pst = (uint32_t)__shfl_up((int)st, 1);
-            const bool agrees = lane == 0 || (pst == 0u && px == start);
-            const unsigned long long ag = __ballot(agrees);
-            n_ok = ag == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ag);
-            // the first lane that disagrees walks again from its neighbour's exit -- and so do all others that disagree:
-            // most of them are right about their neighbour already
-            walk = !agrees && pst == 0u;
-            if (walk) start = px;
-            const bool again = n_ok < 64u && __builtin_amdgcn_readlane((int)walk, (int)(n_ok & 63u)) != 0;
-            // (another walk costs what every walk costs and can bring the pass to 64 lanes at most: it + 1 walks and the
-            // last one for n_ok lanes now, against one more for 64)
-            if (!again || it + 1 >= INF_MAXIT || (it >= 1 && n_ok * (uint32_t)(it + 3) >= 64u * (uint32_t)(it + 2))) break;
           }
           // ---- the lanes taken: in agreement, within the ring's and the queue's capacity
           const bool mine = (uint32_t)lane < n_ok;
@@ -579,7 +590,7 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
             if (wpos + total > isize) { err = ST_OUT; break; }
             // ---- the last walk: literals into the ring, matches into the queue
             {
-              uint32_t r = start, o = wpos + (ic - c), q = im - m;
+              uint32_t r = start, o = wpos + (ic - c), q = im - m;   // (lanes below T: c and m are those of the walk from start)
               bool going = (uint32_t)lane < T && r < hi_bound;
               bool bad = false;
               while (__ballot(going)) {
@@ -647,11 +658,27 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
             P += (uint64_t)adv;
             if ((P >> 3) > in_end + 16) { err = ST_IN; break; }
             if (lst == 1u) { eob = true; break; }
-            if (T < 8u) skip_pass = 24;     // (no resynchronisation to speak of: rounds for a while)
             if (wpos - flushed >= (uint32_t)FLUSH) flush(false);
             catch_up(P >> 3);
+            if (T < 8u && ++small >= 2u) { skip_pass = 24; small = 0; }   // (no resynchronisation to speak of: rounds for a while)
+            else if (lst == 0u && delta + adv - T * (uint32_t)SB < (uint32_t)(SB / 2)) {
+              // the next pass: the lanes not taken move down by T, their positions by what this pass consumed
+              if (T >= 8u) small = 0;
+              const int src = ((lane + (int)T) & 63) << 2;
+              start = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)start) - adv;
+              x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)x) - adv;
+              c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)c);
+              m = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m);
+              st = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)st);
+              valid = __builtin_amdgcn_ds_bpermute(src, (int)valid) != 0 && (uint32_t)lane + T < 64u;
+              delta = delta + adv - T * (uint32_t)SB;
+              round_now = false;
+            }
           }
         }
+        if (!round_now) continue;
+        valid = false;
+        delta = 0;
         CNT(0, 1);
         // ---- a round: every lane decodes the symbol that would start at its bit offset, and where the next one starts
         const Sym s = symbol_at((uint32_t)P + (uint32_t)lane);
