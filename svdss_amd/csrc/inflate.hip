@@ -2,22 +2,29 @@
 //
 // Stands where htslib's bgzf_read / inflate stand under sam_read1 (/root/reference/ping_pong.cpp:58,247-249;
 // clusterer.cpp:101; smoother.cpp:262): `SVDSS search` reads ~1.5 bytes of BAM per base, all of it deflate streams of
-// at most 64 KB, and inflating them is what bounds the binary end to end (a host core inflates ~0.3 GB/s of this kind of
-// data; a 30x human sample is ~140 GB inflated).  Every BGZF block is an independent stream, so the GPU takes one
-// wavefront per block and a few thousand blocks at a time:
-//   * the most recent 4 KB of output live in an LDS ring: literals and near matches never touch HBM, the ring is written
-//     out in aligned dwords 512 bytes at a time; a match that reaches further back (deflate allows 32 KB) reads the bytes
-//     the block itself wrote to HBM earlier -- the ring is that small so that a CU holds 18 blocks instead of 4, and
-//     the latency of those reads (and of everything else) is hidden by the other wavefronts;
-//   * the compressed bytes pass through a 1 KB LDS ring, refilled 512 bytes at a time by the whole wave;
-//   * Huffman tables (10-bit literal/length, 8-bit distance, 16-bit entries; longer codes are decoded canonically) are
+// at most 64 KB, and inflating them is the largest piece of GPU work of the binary end to end (a host core inflates
+// ~0.3 GB/s of this kind of data; a 30x human sample is ~140 GB inflated).  Every BGZF block is an independent stream, so
+// the GPU takes one wavefront per block and a few thousand blocks at a time:
+//   * the most recent 4 KB of output live in an LDS ring and leave for HBM as aligned dwords; a match that reaches
+//     further back than the ring (deflate allows 32 KB) reads the bytes the block itself wrote to HBM earlier -- the ring is
+//     that small so that a CU holds 10 blocks, and the latency of those reads is hidden by the other wavefronts;
+//   * the compressed bytes pass through a 4 KB LDS ring, refilled 512 bytes at a time by the whole wave;
+//   * Huffman tables (9-bit literal/length, 8-bit distance; 32-bit entries that hold everything a lane needs to know
+//     about a code: length, kind, extra bits, base; longer codes are decoded canonically by the lane that meets one) are
 //     built by the wave in parallel: the canonical code of a symbol is the rank of the symbol among those of its length
 //     (wave ballots), and every lane fills the table entries of its own symbols;
-//   * symbols are decoded in rounds of 64 bits: every lane decodes the whole symbol that would start at its bit offset
-//     (literal, or length + extra bits + distance code + extra bits, or end of block) from the 64 bits that start there;
-//     the scalar unit follows the chain of symbol starts with lane reads, a wave scan places the outputs, literals are
-//     stored together, matches are copied in order by all 64 lanes.
-// 8.7 KB of LDS per block.  No CRC check on this path (the caller checks the BGZF footers on the host).
+//   * symbols are decoded in PASSES over 64 x 288 bits (round 4): every lane walks the symbols of its own 288 bits one
+//     after the other -- 64 symbols per instruction instead of the ~8 that start within 64 bits --, from a guessed start
+//     first; Huffman codes resynchronise, so the walks' exits are mostly right, every lane walks again from its
+//     neighbour's exit, and the lanes whose start then equals their neighbour's exit are the true chain of symbols.  A
+//     scan places their output, a last walk stores the literals and queues the matches, the matches are copied 64 side
+//     by side.  (See the comment above the symbol loop; rounds of 64 bits -- rounds 2-3's engine, every lane decoding the
+//     symbol that would start at its bit offset, the chain found by pointer doubling -- remain for what a pass cannot
+//     take, the tail of a stream, and data that does not resynchronise.)
+// 15.4 KB of LDS per block.  No CRC check here (bam_device.hip's crc32_kernel, or the caller on the host, checks the BGZF
+// footers).  Measured on 16,384 blocks of 64 KB (tools/inflate_probe.py, GB/s of output; rounds 2-3's kernel in
+// brackets): packed bases + random qualities zlib level 1: 68 (23.7), level 6: 76 (25); binned qualities 61 (35); skewed
+// 94-value qualities 64 (27); literals only, as csrc/deflate.hip writes them: 70 (42); text 325 (335).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -334,6 +334,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
   std::mutex t_m;
   double t_gpu = 0, t_inflate_ms = 0, t_build = 0, t_format = 0, t_write = 0, t_assemble = 0;
   double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double t_wait_file = 0, t_wait_gpu = 0;       // (the batcher's alone)
   uint64_t n_seen = 0, n_batches = 0, total_sfs = 0;
 
   std::thread batcher([&] {
@@ -341,7 +342,11 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     int64_t acc = 0;
     uint64_t seq = 0;
     bool any_last = false;
-    while (std::unique_ptr<CompChunk> c = sc.next()) {
+    for (;;) {
+      const auto w0 = now();
+      std::unique_ptr<CompChunk> c = sc.next();
+      t_wait_file += secs(w0, now());           // (the loaders behind: the file is what bounds the run)
+      if (!c) break;
       acc += c->inflated;
       const bool last = c->last;
       cur->chunks.push_back(std::move(c));
@@ -349,7 +354,9 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
         cur->seq = seq++;
         cur->last = last;
         any_last = any_last || last;
+        const auto w1 = now();
         jobs.push(std::move(cur));
+        t_wait_gpu += secs(w1, now());          // (the feeding threads behind: the GPU side is)
         cur.reset(new DevJob);
         acc = 0;
       }
@@ -546,9 +553,10 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
                         " walked again); busy seconds: GPU batches " + std::to_string(t_gpu) + " (inflate kernels " + std::to_string(t_inflate_ms * 1e-3) +
                         "), result unpacking " + std::to_string(t_build) + ", re-dealing " + std::to_string(t_assemble) + ", format " + std::to_string(t_format) +
                         ", write " + std::to_string(t_write));
-    char buf[320];
+    char buf[480];
     snprintf(buf, sizeof buf, "device batches, seconds summed: upload+inflate+crc+walk %.3f, waiting for the turn %.3f, turn (carry, link) %.3f, "
-             "fields+scans %.3f, unpack %.3f, search %.3f, results down %.3f", t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5], t_stage[6]);
+             "fields+scans %.3f, unpack %.3f, search %.3f, results down %.3f; the batcher waited %.3f s for the file's loaders and %.3f s for the feeding threads",
+             t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5], t_stage[6], t_wait_file, t_wait_gpu);
     logmsg("debug", buf);
   }
   svdss_bam_stream_free(stream);
@@ -582,7 +590,8 @@ int main_search(const Options& o) {
     const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 4;
     // slabs alive at once: those the loaders read ahead + those of the batches being fed, queued and cut
     const size_t per_batch = target / slab + 2;
-    scanner.reset(new BgzfScanner(o.bam, hooks, slab, 8, 8 + ((size_t)(n_g * per_gpu) + 3) * per_batch));
+    const int loaders = getenv("SVDSS_BAM_LOADERS") ? std::max(1, atoi(getenv("SVDSS_BAM_LOADERS"))) : 8;
+    scanner.reset(new BgzfScanner(o.bam, hooks, slab, loaders, (size_t)loaders + ((size_t)(n_g * per_gpu) + 3) * per_batch));
     if (!scanner->ok()) die("cannot open " + o.bam);
     if (!getenv("SVDSS_NO_PREWARM")) bam_prewarm = std::thread([&scanner] { scanner->prewarm(); });
   } else if (bam_mode) {

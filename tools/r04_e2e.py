@@ -61,6 +61,20 @@ def main():
                 ("device path, 128 MB batches, 8 feeders", {"SVDSS_SEARCH_FEEDERS": "8", "SVDSS_BAM_BATCH_MB": "128"}),
                 ("device path, 512 MB batches", {"SVDSS_BAM_BATCH_MB": "512"}),
                 ("device path, 2 feeders", {"SVDSS_SEARCH_FEEDERS": "2"})]
+    if os.environ.get("R04_SHORT"):
+        settings = [("device path, defaults", {}), ("device path, defaults (2)", {}), ("12 loaders", {"SVDSS_BAM_LOADERS": "12"}), ("12 loaders (2)", {"SVDSS_BAM_LOADERS": "12"}),
+                    ("16 loaders, 128 MB", {"SVDSS_BAM_LOADERS": "16", "SVDSS_BAM_BATCH_MB": "128"}), ("4 loaders", {"SVDSS_BAM_LOADERS": "4"}),
+                    ("12 loaders, 3 format threads", {"SVDSS_BAM_LOADERS": "12", "SVDSS_FORMAT_THREADS": "3"}),
+                    ("device path, 128 MB batches, 8 feeders", {"SVDSS_SEARCH_FEEDERS": "8", "SVDSS_BAM_BATCH_MB": "128"}),
+                    ("device path, 128 MB batches, 8 feeders (2)", {"SVDSS_SEARCH_FEEDERS": "8", "SVDSS_BAM_BATCH_MB": "128"}),
+                    ("device path, 128 MB batches, 6 feeders", {"SVDSS_SEARCH_FEEDERS": "6", "SVDSS_BAM_BATCH_MB": "128"}),
+                    ("device path, 128 MB batches, 4 feeders", {"SVDSS_BAM_BATCH_MB": "128"}),
+                    ("device path, 64 MB batches, 8 feeders", {"SVDSS_SEARCH_FEEDERS": "8", "SVDSS_BAM_BATCH_MB": "64"}),
+                    ("device path, 3 feeders", {"SVDSS_SEARCH_FEEDERS": "3"})]
+    if os.environ.get("R04_ONE"):
+        settings = [("1 feeder, 1024 MB", {"SVDSS_SEARCH_FEEDERS": "1", "SVDSS_BAM_BATCH_MB": "1024"}), ("1 feeder, 512 MB", {"SVDSS_SEARCH_FEEDERS": "1", "SVDSS_BAM_BATCH_MB": "512"}),
+                    ("3 feeders, 1024 MB", {"SVDSS_SEARCH_FEEDERS": "3", "SVDSS_BAM_BATCH_MB": "1024"}), ("3 feeders, 512 MB", {"SVDSS_SEARCH_FEEDERS": "3", "SVDSS_BAM_BATCH_MB": "512"}),
+                    ("4 feeders, 512 MB", {"SVDSS_SEARCH_FEEDERS": "4", "SVDSS_BAM_BATCH_MB": "512"}), ("defaults", {}), ("6 feeders, 128 MB", {"SVDSS_SEARCH_FEEDERS": "6", "SVDSS_BAM_BATCH_MB": "128"})]
     if os.environ.get("R04_SMOOTHED"):
         # the BAM `SVDSS smooth` writes (literal-only dynamic Huffman from csrc/deflate.hip), as search sees it in run_svdss
         sm = os.path.join(work, "smoothed.bam")
