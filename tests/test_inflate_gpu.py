@@ -112,6 +112,89 @@ def test_random_mixtures_of_literals_runs_and_copies():
     assert o == len(out)
 
 
+def test_what_the_passes_of_288_bit_pieces_have_to_get_right():
+    """Round 4's symbol engine (csrc/inflate.hip: every lane walks its own 288 bits, starts settle by resynchronisation):
+    codes of ONE length never resynchronise (a pass yields a lane or two, the kernel falls back to rounds); runs and long
+    copies make one lane's piece larger than the 4 KB ring (capacity cuts, lane 0 alone too large); dense 3-byte copies
+    overflow the queue of 512 matches per pass; copies whose source lies right around a pass's first output byte and around
+    the ring's size are read partly from the ring and partly from HBM; several deflate blocks per stream (memLevel 1) end
+    passes at end-of-block codes after a few lanes."""
+    from svdss_amd.bgzf import gpu_inflate
+    rng = np.random.default_rng(404)
+    streams, want = [], []
+
+    def add(data, level=6, strat=zlib.Z_DEFAULT_STRATEGY, memlevel=8):
+        streams.append(_raw(bytes(data), level, strat, memlevel=memlevel)); want.append(bytes(data))
+
+    for bits in range(1, 9):                                   # 2^bits equiprobable symbols: every code `bits` long
+        add(rng.integers(0, 1 << bits, size=60000, dtype=np.uint8), 6, zlib.Z_HUFFMAN_ONLY)
+        add(rng.integers(0, 1 << bits, size=60000, dtype=np.uint8), 1)
+    add(b"\x07" * 65536); add(b"ab" * 32768); add((b"x" * 300 + b"y") * 217)          # 258-byte copies back to back
+    words = [bytes(rng.integers(0, 256, size=3, dtype=np.uint8)) for _ in range(40)]
+    add(b"".join(words[int(i)] for i in rng.integers(0, 40, size=21000)), 9)                # a 3-byte copy per ~14 bits
+    add(b"".join(words[int(i)] for i in rng.integers(0, 40, size=21000)), 1)
+    for base in (1, 40, 60, 64, 70, 200, 1800, 3700, 3830, 4000, 4096, 4200, 8192, 20000, 32768):
+        buf = bytearray(rng.integers(0, 256, size=base + 300, dtype=np.uint8).tobytes())
+        while len(buf) < 65000:                                  # literals, then a copy from `base` +- a little back
+            buf += rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+            d = max(1, min(len(buf), base + int(rng.integers(-8, 9))))
+            for _ in range(int(rng.integers(3, 70))):
+                buf.append(buf[-d])
+        add(buf, 9); add(buf, 1)
+    for ml in (1, 2, 3):                                         # deflate blocks of a few hundred symbols each
+        a = rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28], dtype=np.uint8), size=20000).tobytes()
+        add(a + rng.integers(30, 50, size=40000, dtype=np.uint8).tobytes(), 6, memlevel=ml)
+    comp, blocks = bytearray(), []
+    for s_, w in zip(streams, want):
+        comp += b"\xa5" * int(rng.integers(0, 4))
+        blocks.append((len(comp), len(s_), len(w)))
+        comp += s_
+    out = gpu_inflate(bytes(comp), blocks).tobytes()
+    o = 0
+    for i, w in enumerate(want):
+        assert out[o:o + len(w)] == w, "stream %d" % i
+        o += len(w)
+    assert o == len(out)
+
+
+def test_flipped_bits_anywhere_end_in_an_answer():
+    """A bit flipped anywhere in a stream -- headers, code lengths, deep inside the symbols where the lanes of a pass walk
+    from guessed starts -- must end in an answer: an error, or bytes (zlib's own, if zlib accepts the stream too; the BGZF
+    CRC is the caller's check).  Never a hang, never a write outside the block's output."""
+    from svdss_amd._lib import SvdssError
+    from svdss_amd.bgzf import gpu_inflate
+    rng = np.random.default_rng(77)
+    pay = _payloads(rng)
+    guard = b"\xcc" * 4096
+    n_err = n_same = n_diff = 0
+    for name in ("bam", "binned", "skew", "text", "nibbles"):
+        good = _raw(pay[name], 1 if name != "text" else 6)
+        for k in range(24):
+            t = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                t[int(rng.integers(0, len(t)))] ^= 1 << int(rng.integers(0, 8))
+            ok = _raw(guard, 0)                                  # stored blocks before and behind: their output must survive
+            comp = ok + bytes(t) + ok
+            blocks = [(0, len(ok), len(guard)), (len(ok), len(t), len(pay[name])), (len(ok) + len(t), len(ok), len(guard))]
+            try:
+                z = zlib.decompressobj(-15).decompress(bytes(t))
+            except zlib.error:
+                z = None
+            try:
+                out = gpu_inflate(comp, blocks).tobytes()
+            except SvdssError as e:
+                assert e.bad_block == 1
+                n_err += 1
+                continue
+            assert out[:len(guard)] == guard and out[-len(guard):] == guard
+            if z is not None and len(z) == len(pay[name]):
+                assert out[len(guard):-len(guard)] == z
+                n_same += 1
+            else:
+                n_diff += 1                                      # (zlib refuses, e.g. a distance beyond its window check, or another size)
+    assert n_err > 20 and n_same > 5, (n_err, n_same, n_diff)
+
+
 def test_scattered_outputs_do_not_touch_their_neighbours():
     from svdss_amd.bgzf import gpu_inflate
     rng = np.random.default_rng(5)
