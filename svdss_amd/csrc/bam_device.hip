@@ -942,7 +942,7 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   const size_t padded = (size_t)((total_syms + 15) & ~(int64_t)15) + 16;
   RCHK(ensure(b->reads, padded + 16));
   if (n_srch > 0) {
-    BCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded - 32), 0, 32, st));
+    BCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded >= 32 ? padded - 32 : 0), 0, padded >= 32 ? 32 : padded, st));
     // (the longest read decides the grid's width: the scan's inputs hold the lengths, the host does not -- bounded by
     // the largest record of the batch, i.e. by the batch itself; a second pass over the symbol offsets would cost more)
     int64_t max_len = 0;

@@ -198,7 +198,11 @@ SVDSS_HD void sv_lane_init(SvLane<P>& s, int len, int start_pos = -1, int stop_l
 template <class P>
 SVDSS_HD bool sv_in_window(const SvLane<P>& s, int p) { return p >= s.wrel && p < s.wrel + 64; }
 
-// Streaming Assembler::assemble (/root/reference/assembler.cpp:34-56), see sfs_core.h.
+// Streaming form of Assembler::assemble (/root/reference/assembler.cpp:34-56).  ping_pong_search pushes SFS with strictly
+// decreasing qs AND strictly decreasing end, so the sort at assembler.cpp:36 is a reversal and the chain rule
+// "sfs[j-1].qs + sfs[j-1].l > sfs[j].qs" can be applied as records are produced: a new SFS (q, l) joins the open chain
+// iff q + l > (qs of the previously produced SFS).  The chain's end is the end of its first-produced member (largest
+// qs), exactly sfs[j-1].qs + sfs[j-1].l at assembler.cpp:42,50.
 template <class P, class Emit>
 SVDSS_HD void sv_emit(SvLane<P>& s, int qs, int l, bool assemble, Emit&& emit) {
   if (!assemble) { emit(s.n_sfs++, qs, l); return; }

@@ -5,11 +5,11 @@
 // (/root/reference/assembler.cpp:34-56) for a whole batch of reads
 // (PingPong::process_batch, ping_pong.cpp:176-209).
 //
-// Mapping: one read per lane, persistent lanes that pull the next read from a
-// global counter when they finish (reads differ up to 2x in the number of
-// extensions they need).  Every loop iteration performs exactly one LF step
-// per active lane = one (two while the interval still spans blocks) 64-byte
-// BWT block fetch; see sfs_core.h for the flattened state machine.
+// Mapping: one work item (a read, or one of up to 8 segments of a read) per lane,
+// persistent lanes that pull the next item from per-wavefront ticket pools when
+// they finish.  Every loop iteration performs one memory operation per active
+// lane -- a k-mer table entry, a BWT block (LF step), suffix-array rows, text --
+// chosen by the flattened state machine of sfs_core2.h.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -26,7 +26,6 @@
 #include "fmd_layout.h"
 #include "hip_check.h"
 #include "index_host.h"
-#include "sfs_core.h"
 #ifdef SV_COUNT_ITERS
 // counting build: passes of sv_decide's loop, per wavefront (any lane inside)
 extern __device__ unsigned long long g_sfs_iters[64];
@@ -86,65 +85,6 @@ __host__ __device__ inline int64_t seg_region_cap(int64_t len, int cr) { return 
 // default per-read record region: (len/8 + 8) records starting at off/8 + 8 r
 __host__ __device__ inline int64_t rec_region_base(int64_t off, int64_t r) { return (off >> 3) + 8 * r; }
 __host__ __device__ inline int64_t rec_region_cap(int64_t len) { return (len >> 3) + 8; }
-
-__global__ void __launch_bounds__(256) sfs_search_kernel(SfsParams p) {
-  SvdssLane st;
-  SvdssSymWindow win;
-  SvdssReadView rv;
-  rv.chunks = p.chunks;
-  rv.max_chunk = p.max_chunk;
-  rv.off = 0;
-  int64_t r = 0, base = 0, cap = 0;
-  bool active = false;
-  const bool assemble = p.assemble != 0;
-
-  auto sym = [&](int32_t pos) -> int { return svdss_window_sym(win, rv, pos, st.dir); };
-  auto emit = [&](int32_t idx, int32_t qs, int32_t l) {
-    if (idx < cap) p.rec[base + idx] = make_uint2((uint32_t)qs, (uint32_t)l);
-  };
-
-  for (;;) {
-    if (!active) {
-      const unsigned long long t = atomicAdd(p.next_read, 1ULL);
-      if (t >= (unsigned long long)p.n_reads) break;
-      r = (int64_t)t;
-      const int64_t off = p.offsets[r];
-      const int64_t len = p.offsets[r + 1] - off;
-      rv.off = off;
-      svdss_window_reset(win);
-      base = p.rec_base ? p.rec_base[r] : rec_region_base(off, r);
-      cap = p.rec_cap ? p.rec_cap[r] : rec_region_cap(len);
-      st.dir = 0;
-      svdss_lane_init(st, p.ix, sym, (int32_t)len);
-      active = true;
-    }
-    if (!svdss_lane_resolve(st, p.ix, sym, assemble, emit)) {
-      svdss_lane_flush(st, assemble, emit);
-      p.counts[r] = st.n_sfs;
-      p.n_ext[r] = st.n_ext;
-      active = false;
-      continue;
-    }
-    // overlap the (possible) next read-chunk fetch with the BWT block fetches
-    const int32_t np = st.dir ? st.pos + 1 : st.pos - 1;
-    if (np >= 0 && np < st.len) svdss_window_prefetch(win, rv, np);
-
-    const int64_t blo = st.lo >> SVDSS_BLOCK_SHIFT, bhi = st.hi >> SVDSS_BLOCK_SHIFT;
-    svdss_u4 ql[4], qh[4];
-    const svdss_u4* Bl = p.ix.blocks + 4 * blo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ql[j] = Bl[j];
-    if (bhi != blo) {
-      const svdss_u4* Bh = p.ix.blocks + 4 * bhi;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) qh[j] = Bh[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) qh[j] = ql[j];
-    }
-    svdss_lane_step(st, p.ix, ql, qh);
-  }
-}
 
 // ---- v2: k-mer table + LF + unique-match TEXT mode (sfs_core2.h) -------------
 struct __attribute__((packed, aligned(1))) SvU4u { uint32_t x, y, z, w; };  // 16 bytes, any alignment
@@ -725,7 +665,7 @@ struct svdss_sfs_batch {
   double kernel_ms = 0.0;
   double search_ms = 0.0;   // the segmented / one-lane-per-read search kernel of pass 0 alone
   DevBuf rec, counts, n_ext, out_off, out_qs, out_len, tmp, misc, reads, offsets, base2, sum;
-  DevBuf seg_rec, seg_info, fallback, fallback2, seg_take, order, order_cnt;
+  DevBuf seg_rec, seg_info, fallback, fallback2, seg_take, order, order_cnt, tiny;
   int64_t n_fallback = 0;   // reads of the last call that were redone unsegmented
   int32_t n_seg = 1;        // segments per read used by the last call
   uint32_t epoch = 0;
@@ -756,7 +696,7 @@ extern "C" void svdss_sfs_batch_free(svdss_sfs_batch_t* b) {
   if (b->device >= 0) (void)hipSetDevice(b->device);
   for (DevBuf* d : {&b->rec, &b->counts, &b->n_ext, &b->out_off, &b->out_qs, &b->out_len, &b->tmp,
                     &b->misc, &b->reads, &b->offsets, &b->base2, &b->sum, &b->seg_rec, &b->seg_info,
-                    &b->fallback, &b->fallback2, &b->seg_take, &b->order, &b->order_cnt, &b->packed, &b->byte_off, &b->lens32})
+                    &b->fallback, &b->fallback2, &b->seg_take, &b->order, &b->order_cnt, &b->tiny, &b->packed, &b->byte_off, &b->lens32})
     release(*d);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -859,9 +799,14 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   p.fallback_ids = nullptr;
   p.epoch = ++b->epoch ? b->epoch : ++b->epoch;
 
-  // SVDSS_KERNEL=1 selects the v1 kernel (plain LF walk) for A/B measurements
-  const char* kv = getenv("SVDSS_KERNEL");
-  const bool use_v1 = (kv && atoi(kv) == 1) || total_syms < 64;
+  // (the kernel fetches a read's symbols 64 bytes at a time: a batch smaller than that is searched in a padded copy)
+  if (total_syms < 64) {
+    if ((rc = ensure(b->tiny, 96))) return rc;
+    HIPCHK(hipMemsetAsync(b->tiny.p, 0, 96, stream));
+    if (total_syms > 0) HIPCHK(hipMemcpyAsync(b->tiny.p, d_reads, (size_t)total_syms, hipMemcpyDeviceToDevice, stream));
+    p.chunks = (const svdss_u4*)b->tiny.p;
+    p.max_chunk = 3;
+  }
   int max_blocks = 0;
   if ((rc = launch_grid(ix->device, &max_blocks))) return rc;
   // Small batches cannot fill the GPU with one lane per read (256 CUs x 16 waves x 64 lanes):
@@ -876,7 +821,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     if (n_seg < 1) n_seg = 1;
     if (n_seg > 16) n_seg = 16;
     while (n_seg & (n_seg - 1)) n_seg &= n_seg - 1;   // power of two: item -> (read, segment) by shift
-    if (use_v1 || total_syms / (n_reads > 0 ? n_reads : 1) < 1024) n_seg = 1;
+    if (total_syms / (n_reads > 0 ? n_reads : 1) < 1024) n_seg = 1;
     if (n_reads * (int64_t)n_seg >= ((int64_t)1 << 31)) n_seg = 1;   // item tickets are 32-bit in the kernel
   }
   if (n_seg > 1) {
@@ -910,7 +855,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
 
   // heavy reads first (see sfs_order_kernel); SVDSS_ORDER=0 keeps the input order
   const char* ord_env = getenv("SVDSS_ORDER");
-  const bool use_order = !use_v1 && n_reads >= 1024 && p.ix.k >= 8 && !(ord_env && atoi(ord_env) == 0);
+  const bool use_order = n_reads >= 1024 && p.ix.k >= 8 && !(ord_env && atoi(ord_env) == 0);
   if (use_order) {
     if ((rc = ensure(b->order, (size_t)n_reads * sizeof(int64_t)))) return rc;
     if ((rc = ensure(b->order_cnt, (size_t)(2 * n_reads + 2) * sizeof(int64_t)))) return rc;   // flags, their scan
@@ -938,9 +883,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       HIPCHK(hipGetLastError());
       p.read_ids = (const int64_t*)b->order.p;
     }
-    if (use_v1) {
-      hipLaunchKernelGGL(sfs_search_kernel, dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
-    } else if (seg) {
+    if (seg) {
       p.n_seg = n_seg;
       p.seg_shift = __builtin_ctz((unsigned)n_seg);
       p.n_items = n_reads * n_seg;
@@ -1045,7 +988,7 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     b->kernel_ms += ms;
-    if (pass == 0 && !use_v1) {
+    if (pass == 0) {
       float ks = 0.f;
       HIPCHK(hipEventElapsedTime(&ks, b->ek0, b->ek1));
       b->search_ms = ks;
@@ -1110,7 +1053,7 @@ extern "C" int svdss_sfs_search_batch(const svdss_index_t* ix, const uint8_t* re
   if ((rc = ensure(b->reads, padded))) return rc;
   if ((rc = ensure(b->offsets, (size_t)(n_reads + 1) * sizeof(int64_t)))) return rc;
   const hipStream_t st = b->own_stream;
-  HIPCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded - 32), 0, 32, st));   // the bytes past the last read
+  HIPCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded >= 32 ? padded - 32 : 0), 0, padded >= 32 ? 32 : padded, st));   // the bytes past the last read
   if (total > 0) HIPCHK(hipMemcpyAsync(b->reads.p, reads, (size_t)total, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->offsets.p, offsets, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
   return svdss_sfs_search_batch_device(ix, (const uint8_t*)b->reads.p, (const int64_t*)b->offsets.p,
@@ -1168,7 +1111,7 @@ extern "C" int svdss_sfs_search_batch_bam(const svdss_index_t* ix, const uint8_t
   const hipStream_t st = b->own_stream;
   std::vector<int64_t> rel((size_t)n_reads + 1);
   for (int64_t i = 0; i <= n_reads; ++i) rel[(size_t)i] = byte_off[i] - byte_off[0];
-  HIPCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded - 32), 0, 32, st));
+  HIPCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded >= 32 ? padded - 32 : 0), 0, padded >= 32 ? 32 : padded, st));
   if (pbytes > 0) HIPCHK(hipMemcpyAsync(b->packed.p, seq4 + byte_off[0], (size_t)pbytes, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->byte_off.p, rel.data(), (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->offsets.p, sym_off.data(), (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));

@@ -12,35 +12,13 @@ SANITIZE = os.environ.get("SVDSS_EMU_SANITIZE") == "1"
 SO = os.path.join(HERE, "_lane_emulator_san.so" if SANITIZE else "_lane_emulator.so")
 SRC = os.path.join(HERE, "lane_emulator.cpp")
 _deps = [SRC] + [os.path.join(HERE, "..", "svdss_amd", "csrc", f)
-                 for f in ("sfs_core.h", "sfs_core2.h", "sym_window.h", "fmd_layout.h", "index_host.h")]
+                 for f in ("sfs_core2.h", "sym_window.h", "fmd_layout.h", "index_host.h")]
 if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in _deps):
     subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas"] +
                           (["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if SANITIZE else ["-O2"]) +
                           ["-o", SO, SRC])
 _lib = C.CDLL(SO)
 _p, _i64 = C.c_void_p, C.c_int64
-_lib.emu_search.restype = _i64
-_lib.emu_search.argtypes = [_p, _p, _p, _i64, _i64, C.c_int, _p, _p, _p, _i64, _p]
-
-
-def search(index, flat: np.ndarray, offsets: np.ndarray, assemble: bool):
-    """index: svdss_amd.FMDIndex.  Returns (counts, qs, len, n_ext)."""
-    n = len(offsets) - 1
-    total_syms = int(offsets[-1])
-    padded = np.zeros(((total_syms + 15) // 16) * 16 + 16, dtype=np.uint8)
-    padded[:total_syms] = flat
-    cap = total_syms + n + 1
-    counts = np.zeros(n, dtype=np.int64)
-    n_ext = np.zeros(n, dtype=np.int64)
-    qs = np.zeros(cap, dtype=np.int32)
-    ln = np.zeros(cap, dtype=np.int32)
-    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-    t = _lib.emu_search(index._h, padded.ctypes.data, offsets.ctypes.data, n, total_syms, int(assemble),
-                        counts.ctypes.data, qs.ctypes.data, ln.ctypes.data, cap, n_ext.ctypes.data)
-    assert t >= 0
-    return counts, qs[:t].copy(), ln[:t].copy(), n_ext
-
-
 _lib.emu_search2.restype = _i64
 _lib.emu_search2.argtypes = [_p, _p, _p, _i64, _i64, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _p, _p, C.c_int, _p]
 _lib.emu_table.restype = C.c_int

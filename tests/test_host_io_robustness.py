@@ -17,7 +17,7 @@ from tests.common import ROOT
 HARNESS = os.path.join(ROOT, "tests", "_host_io_harness")
 SRC = [os.path.join(ROOT, "tests", "host_io_harness.cpp"), os.path.join(ROOT, "svdss_amd", "csrc", "rld0.cpp"),
        os.path.join(ROOT, "svdss_amd", "csrc", "index_build.cpp")]
-DEPS = SRC + [os.path.join(ROOT, "svdss_amd", "csrc", h) for h in ("bam_reader.h", "bai_index.h", "fastx_reader.h", "rld0.h", "index_host.h", "fmd_layout.h", "sfs_file.h", "bgzf_scanner.h",
+DEPS = SRC + [os.path.join(ROOT, "svdss_amd", "csrc", h) for h in ("bam_reader.h", "bgzf_inflater.h", "bai_index.h", "fastx_reader.h", "rld0.h", "index_host.h", "fmd_layout.h", "sfs_file.h", "bgzf_scanner.h",
                                                                    "bam_device_select.h")]
 
 

@@ -1,4 +1,4 @@
-"""The kernel's per-lane code (sfs_core.h + sym_window.h + fmd_layout.h), run on
+"""The kernel's per-lane code (sfs_core2.h + sym_window.h + fmd_layout.h), run on
 the CPU through tests/lane_emulator.cpp, against the oracle and the golden
 vectors.  This validates the state machine, the register window over the read
 and the streaming assembler without a GPU; the -m gpu tests repeat the same
@@ -12,48 +12,39 @@ from tests import oracle_lib as O
 from tests.common import from_ascii, load_golden, small_workload, split
 
 
-def test_golden_through_lane_code():
-    for case in load_golden():
-        contigs = [from_ascii(c) for c in case["contigs"]]
-        ix = svdss_amd.FMDIndex.build(contigs, threads=2)
-        reads = [from_ascii(r["read"]) for r in case["reads"]]
-        flat, offs = svdss_amd.pack_reads(reads)
-        c, q, l, e = E.search(ix, flat, offs, assemble=False)
-        for got, rd, ne in zip(split(c, q, l), case["reads"], e.tolist()):
-            assert [list(x) for x in got] == rd["sfs"]
-            assert ne == rd["n_ext"]
-        c, q, l, e = E.search(ix, flat, offs, assemble=True)
-        for got, rd in zip(split(c, q, l), case["reads"]):
-            assert [list(x) for x in got] == rd["assembled"]
-
-
-@pytest.mark.parametrize("assemble", [False, True])
-def test_random_reads_match_oracle(assemble):
-    ref, hap, svs, flat, offs = small_workload(seed=31, n_reads=48, read_len=1200)
-    ix = svdss_amd.FMDIndex.build(ref, threads=4)
-    fm = O.OracleFMD.build(ref)
-    c, q, l, e = E.search(ix, flat, offs, assemble)
-    c2, q2, l2, e2 = fm.search_batch(flat, offs, assemble)
-    assert (c == c2).all() and (e == e2).all()
-    assert (q == q2).all() and (l == l2).all()
-    assert c.sum() > 0
-
-
 def test_unaligned_offsets_and_empty_reads():
-    # reads start at arbitrary byte offsets of the concatenated buffer; some are empty
-    ref, hap, svs, flat, offs = small_workload(seed=41, n_reads=10, read_len=300, ref_lens=(40000,))
-    reads = [flat[offs[i]:offs[i + 1]] for i in range(10)]
-    reads.insert(3, np.zeros(0, np.uint8))
-    reads.append(np.zeros(0, np.uint8))
-    reads.insert(0, ref[0][5:6])
-    flat2, offs2 = svdss_amd.pack_reads(reads)
+    # reads start at arbitrary byte offsets of the concatenated buffer; some are empty; every way of evaluating
+    for K, use_text in [(0, False), (0, True), (7, True)]:
+        ref, hap, svs, flat, offs = small_workload(seed=41, n_reads=10, read_len=300, ref_lens=(40000,))
+        reads = [flat[offs[i]:offs[i + 1]] for i in range(10)]
+        reads.insert(3, np.zeros(0, np.uint8))
+        reads.append(np.zeros(0, np.uint8))
+        reads.insert(0, ref[0][5:6])
+        flat2, offs2 = svdss_amd.pack_reads(reads)
+        ix = svdss_amd.FMDIndex.build(ref, threads=2)
+        fm = O.OracleFMD.build(ref)
+        for assemble in (False, True):
+            c, q, l, e, ops = E.search2(ix, flat2, offs2, assemble, K, use_text)
+            c2, q2, l2, e2 = fm.search_batch(flat2, offs2, assemble)
+            assert (c == c2).all() and (q == q2).all() and (l == l2).all() and (e == e2).all()
+        assert c[4] == 0 and c[-1] == 0
+
+
+def test_batches_smaller_than_one_fetch():
+    """A whole batch of fewer than 64 symbols (the kernel fetches 64 bytes of a read at a time and searches such a batch
+    in a padded copy, csrc/sfs_search.hip): one read of 1 .. 63 symbols, several tiny reads, only empty reads."""
+    ref, hap, svs, flat, offs = small_workload(seed=43, n_reads=2, read_len=300, ref_lens=(20000,))
     ix = svdss_amd.FMDIndex.build(ref, threads=2)
     fm = O.OracleFMD.build(ref)
-    for assemble in (False, True):
-        c, q, l, e = E.search(ix, flat2, offs2, assemble)
-        c2, q2, l2, e2 = fm.search_batch(flat2, offs2, assemble)
-        assert (c == c2).all() and (q == q2).all() and (l == l2).all() and (e == e2).all()
-    assert c[4] == 0 and c[-1] == 0
+    cases = [[ref[0][100:100 + n].copy()] for n in (1, 2, 15, 16, 17, 31, 47, 63)]
+    cases += [[ref[0][7:20].copy(), np.zeros(0, np.uint8), hap[0][50:61].copy(), ref[0][900:925].copy()], [np.zeros(0, np.uint8)] * 3]
+    for reads in cases:
+        flat2, offs2 = svdss_amd.pack_reads(reads)
+        for K, use_text in [(0, False), (5, True)]:
+            for assemble in (False, True):
+                c, q, l, e, ops = E.search2(ix, flat2, offs2, assemble, K, use_text)
+                c2, q2, l2, e2 = fm.search_batch(flat2, offs2, assemble)
+                assert (c == c2).all() and (q == q2).all() and (l == l2).all() and (e == e2).all()
 
 
 # ---- v2 state machine (sfs_core2.h): k-mer table + LF + unique-match TEXT mode ----
@@ -245,7 +236,7 @@ def test_v2_randomised_configurations(seed):
 
 
 def test_lane_code_under_sanitizers():
-    """The kernel's per-lane code (sfs_core.h, sfs_core2.h, sym_window.h, fmd_layout.h: the search state machine, the
+    """The kernel's per-lane code (sfs_core2.h, sym_window.h, fmd_layout.h: the search state machine, the
     k-mer table entries, SET / TEXT windows) has no GPU sanitizer to run under on this pool; its CPU emulation has:
     this module's tests again in a process with AddressSanitizer preloaded and the emulator built with
     -fsanitize=address,undefined -- an out-of-bounds window index, a shift by the word size, a signed overflow in the

@@ -242,15 +242,23 @@ def test_kmer_table_orders(monkeypatch, kmer):
     assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
 
 
-def test_v1_kernel_still_agrees(monkeypatch):
-    """SVDSS_KERNEL=1 selects the plain LF-walk kernel kept for A/B measurements."""
-    monkeypatch.setenv("SVDSS_KERNEL", "1")
-    ref, hap, svs, flat, offs = small_workload(seed=37, n_reads=100, read_len=1200)
-    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+@pytest.mark.parametrize("kmer", [0, 8])
+def test_batches_smaller_than_one_fetch(kmer, monkeypatch):
+    """A whole batch of fewer than 64 symbols: the kernel fetches 64 bytes of a read at a time, so such a batch is searched
+    in a padded copy (csrc/sfs_search.hip) -- one read of 1 .. 63 symbols, several tiny reads, only empty reads; with and
+    without the k-mer table."""
+    ref, hap, svs, flat, offs = small_workload(seed=43, n_reads=2, read_len=300, ref_lens=(20000,))
     fm = O.OracleFMD.build(ref)
-    got = _search(ix, flat, offs, False)
-    c, q, l, e = fm.search_batch(flat, offs, False)
-    assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
+    cases = [[ref[0][100:100 + n].copy()] for n in (1, 2, 15, 16, 17, 31, 47, 63)]
+    cases += [[ref[0][7:20].copy(), np.zeros(0, np.uint8), hap[0][50:61].copy(), ref[0][900:925].copy()], [np.zeros(0, np.uint8)] * 3]
+    monkeypatch.setenv("SVDSS_KMER", str(kmer))
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    for reads in cases:
+        flat2, offs2 = svdss_amd.pack_reads(reads)
+        for assemble in (False, True):
+            got = _search(ix, flat2, offs2, assemble)
+            c, q, l, e = fm.search_batch(flat2, offs2, assemble)
+            assert (got.counts == c).all() and (got.qs == q).all() and (got.len == l).all() and (got.n_ext == e).all()
 
 
 def test_device_results_alias_and_single_rank_gather():
