@@ -26,7 +26,10 @@ extern thread_local std::string g_svdss_hip_err;   // defined in index_api.hip
 // bit b stands for CU b / 8 of XCD b % 8 (tools/cu_mask_probe.hip), so a contiguous range is the same share of every
 // XCD.  What for: the search kernel and the call-side DP kernels each fill the chip with long-lived wavefronts; side by
 // side on all CUs they take turns, on disjoint CUs they run at the same time (SVDSS_SEARCH_CUS /
-// SVDSS_CALL_CUS).
+// SVDSS_CALL_CUS).  NOTE: hipExtStreamCreateWithCUMask has no flags argument -- a masked stream is a *blocking* stream
+// (it synchronises with work on the null stream: torch's default stream, a plain hipMemcpy), unlike the non-blocking
+// stream returned without the variable: the knob is a developer measurement aid, and what it measured (HISTORY.md 5a:
+// CU partitioning never wins) was measured with no null-stream work in flight.
 inline hipError_t svdss_make_stream(hipStream_t* st, const char* env) {
   int first = 0, count = 0;
   const char* e = env ? getenv(env) : nullptr;

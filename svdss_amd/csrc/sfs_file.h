@@ -46,16 +46,22 @@ namespace sfs_file_detail {
 inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
 // %d of sscanf: optional blanks, optional sign, digits; false if no digit is there
-inline bool scan_int(const char*& p, const char* e, int& v) {
+inline bool scan_int(const char*& p, const char* e, int& v, bool& overflow) {
   while (p < e && is_space(*p)) ++p;
   bool neg = false;
   if (p < e && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
   if (p >= e || *p < '0' || *p > '9') return false;
-  unsigned x = 0;
-  while (p < e && *p >= '0' && *p <= '9') { x = x * 10u + (unsigned)(*p - '0'); ++p; }
-  v = neg ? (int)(0u - x) : (int)x;
+  unsigned long long x = 0;
+  while (p < e && *p >= '0' && *p <= '9') {
+    x = x * 10u + (unsigned)(*p - '0');
+    if (x > 0x80000000ull) overflow = true;   // (beyond int: what sscanf's %d does with it is the line-by-line reader's to say)
+    ++p;
+  }
+  v = neg ? (int)(0u - (unsigned)x) : (int)x;
+  if (x > (neg ? 0x80000000ull : 0x7fffffffull)) overflow = true;
   return true;
 }
+inline bool scan_int(const char*& p, const char* e, int& v) { bool o = false; return scan_int(p, e, v, o); }
 
 struct Piece {
   std::vector<RawSFS> recs;                 // every record of the piece, in file order
@@ -77,7 +83,10 @@ inline void parse_piece(const char* b, const char* e, Piece& P) {
     while (q < le && !is_space(*q)) ++q;
     const size_t nlen = (size_t)(q - n0);
     int qs, l, ht;
-    if (nlen >= 1 && nlen <= 4095 && scan_int(q, le, qs) && scan_int(q, le, l) && scan_int(q, le, ht)) {
+    bool ovf = false;
+    if (nlen > 4095) { P.long_line = true; return; }    // (sscanf's %4095s would cut the name there: the line-by-line reader's case)
+    if (nlen >= 1 && scan_int(q, le, qs, ovf) && scan_int(q, le, l, ovf) && scan_int(q, le, ht, ovf)) {
+      if (ovf) { P.long_line = true; return; }
       if (!(nlen == 1 && *n0 == '*')) P.groups.push_back(Piece::Group{n0, (uint32_t)nlen, P.recs.size(), 0});
       if (P.groups.empty()) ++P.lead; else ++P.groups.back().count;
       P.recs.push_back(RawSFS{qs, l, ht});

@@ -154,9 +154,12 @@ static int main_index(int argc, char** argv) {
   int rc_side = SVDSS_OK;
   std::thread side;
   const bool records_side = !getenv("SVDSS_INDEX_NO_CACHE") && !getenv("SVDSS_INDEX_FULL");
+  // (an older sidecar must not outlive a failed rewrite of its .fmd: it goes first, and a failure takes the .tmp with it)
+  if (!getenv("SVDSS_INDEX_NO_CACHE")) (void)unlink((out + ".svdss").c_str());
   if (records_side) side = std::thread([&] { rc_side = svdss_index_save_records(ix, (out + ".svdss.tmp").c_str()); });
   const int rc_fmd = svdss_index_save_fmd(ix, out.c_str());
   if (side.joinable()) side.join();
+  if (rc_fmd != SVDSS_OK || rc_side != SVDSS_OK) (void)unlink((out + ".svdss.tmp").c_str());
   check(rc_fmd, "svdss_index_save_fmd");
   mark("rld0 .fmd written");
   if (records_side) {

@@ -112,8 +112,10 @@ class SfsGatherer:
             return None
         if not concat:
             return h["views"]
-        cs = torch.cat([v[0] for v in h["views"]]).to(torch.int64)
-        return cs, torch.cat([v[1] for v in h["views"]]), torch.cat([v[2] for v in h["views"]])
+        # (under gloo the peers' slots are host tensors while rank 0's own are where its input was: one device for the cat)
+        dev = h["views"][-1][0].device
+        cs = torch.cat([v[0].to(dev) for v in h["views"]]).to(torch.int64)
+        return cs, torch.cat([v[1].to(dev) for v in h["views"]]), torch.cat([v[2].to(dev) for v in h["views"]])
 
     def flush(self):
         for s in self.slots:

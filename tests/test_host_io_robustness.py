@@ -325,7 +325,7 @@ def test_sfs_file_readers_agree(harness, tmp_path):
     assert rc == 0 and "reads" in out
     odd = ["*\t1\t2\t0\t\n", "\n", "   \n", "name only\n", "r1\t5\n", "r2\t5\t6\n", "r3\t5\t6\t7\textra\tfields\n", "r4 5 6 7\n",
            "r5\t-5\t+6\t7\n", "r6\t5x\t6\t7\n", "r7\t5\t6\t7x\n", "*\t9\t9\t9\r\n", "r8\t\t5\t\t6\t\t7\n", "*\n", "* * * *\n",
-           "r9\t99999999999\t1\t1\n", "r" * 4095 + "\t1\t2\t3\n", "q" * 4096 + "\t1\t2\t3\n", "\tr10\t1\t2\t3\n", "r11\t1\t2\t3"]
+           "r9\t99999999999\t1\t1\n", "r9b\t1\t-99999999999\t1\n", "r9c\t2147483647\t-2147483648\t2147483648\n", "r" * 4095 + "\t1\t2\t3\n", "q" * 4096 + "\t1\t2\t3\n", "\tr10\t1\t2\t3\n", "r11\t1\t2\t3"]
     for trial in range(12):
         body = lines[:int(rng.integers(0, 3000))]
         for _ in range(int(rng.integers(1, 60))):
