@@ -251,20 +251,20 @@ struct Sym {
   uint32_t dist;
 };
 
-__global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const svdss_bgzf_block_t* __restrict__ blks,
-                                                         uint8_t* out, int32_t* __restrict__ status) {
-  __shared__ Lds L;
+// one BGZF member (block `member` of blks), by one wavefront
+__device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict__ comp, const svdss_bgzf_block_t* __restrict__ blks, uint8_t* out,
+                               int32_t* __restrict__ status, const int64_t member) {
   const int lane = threadIdx.x;
-  const svdss_bgzf_block_t B = blks[blockIdx.x];
+  const svdss_bgzf_block_t B = blks[member];
   const uint32_t isize = (uint32_t)B.isize;
   const uint64_t in_first = (uint64_t)B.coff, in_end = in_first + (uint64_t)(uint32_t)B.clen;
   uint8_t* const o8 = out + B.uoff;
   uint8_t* const winb = (uint8_t*)L.win;
-  if (isize == 0) { if (lane == 0) status[blockIdx.x] = ST_OK; return; }
+  if (isize == 0) { if (lane == 0) status[member] = ST_OK; return; }
 #ifdef INF_COUNT
   unsigned cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-#define FAIL(code) do { status[blockIdx.x] = (code); return; } while (0)
+#define FAIL(code) do { status[member] = (code); return; } while (0)
 
   // ---- input: absolute offsets into comp; the ring holds [base, base + INB)
   uint64_t base = in_first & ~(uint64_t)(HALF - 1), in_addr = in_first;
@@ -776,11 +776,37 @@ __global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restr
   }
   if (wpos != isize) FAIL(ST_SIZE);
   flush(true);
-  if (lane == 0) status[blockIdx.x] = ST_OK;
+  if (lane == 0) status[member] = ST_OK;
 #ifdef INF_COUNT
   if (lane == 0) for (int k = 0; k < 12; ++k) atomicAdd(&g_inf_cnt[k], (unsigned long long)cnt[k]);
 #endif
 #undef FAIL
+}
+
+// One wavefront per member when the grid is as large as the batch (the default); a smaller grid walks the members with a
+// stride: SVDSS_INFLATE_PER_CU=n launches at most n wavefronts per compute unit.  What for: ten members fit on a CU and
+// take all of its LDS, so no block of the search / CRC / record kernels of the neighbouring batches (other streams) can
+// start beside them -- in `search` end to end the kernel trace shows inflate and search kernels one after the other
+// (0.39 s + 0.13 s of a 0.58 s stream).  Measured with n = 8 (37 KB left per CU): they do overlap then (0.42 s and 0.19 s
+// in a 0.59 s stream) and each runs that much longer -- the sum of the GPU's work is what bounds the stream, not their
+// order (profiles/r04q_e2e_kernel_overlap.txt).  Not the default.
+__global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const svdss_bgzf_block_t* __restrict__ blks,
+                                                         uint8_t* out, int32_t* __restrict__ status, const int64_t n_members) {
+  __shared__ Lds L;
+  for (int64_t m = blockIdx.x; m < n_members; m += gridDim.x) inflate_member(L, comp, blks, out, status, m);
+}
+
+static unsigned inflate_grid(int64_t n_blocks) {
+  static int n_cu = 0;
+  static int per_cu = -1;
+  if (per_cu < 0) {
+    const char* e = getenv("SVDSS_INFLATE_PER_CU");
+    per_cu = e ? atoi(e) : 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  const int64_t cap = per_cu > 0 ? (int64_t)per_cu * n_cu : n_blocks;
+  return (unsigned)(n_blocks < cap ? n_blocks : cap);
 }
 
 struct DevBuf {
@@ -793,7 +819,7 @@ struct DevBuf {
 hipError_t svdss_inflate_enqueue(hipStream_t st, const uint8_t* d_comp, const svdss_bgzf_block_t* d_blocks, int64_t n_blocks,
                                  uint8_t* d_out, int32_t* d_status) {
   if (n_blocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, d_comp, d_blocks, d_out, d_status);
+  hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(inflate_grid(n_blocks)), dim3(64), 0, st, d_comp, d_blocks, d_out, d_status, n_blocks);
   return hipGetLastError();
 }
 
@@ -858,8 +884,8 @@ extern "C" int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8
   HIPCHK(hipMemcpyAsync(o->blks.p, blocks, sizeof(svdss_bgzf_block_t) * (size_t)n_blocks, hipMemcpyHostToDevice, o->st));
   if (!o->ev0) { HIPCHK(hipEventCreate(&o->ev0)); HIPCHK(hipEventCreate(&o->ev1)); }
   HIPCHK(hipEventRecord(o->ev0, o->st));
-  hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, o->st, (const uint8_t*)o->comp.p,
-                     (const svdss_bgzf_block_t*)o->blks.p, (uint8_t*)d_out, (int32_t*)o->status.p);
+  hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(inflate_grid(n_blocks)), dim3(64), 0, o->st, (const uint8_t*)o->comp.p,
+                     (const svdss_bgzf_block_t*)o->blks.p, (uint8_t*)d_out, (int32_t*)o->status.p, n_blocks);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(o->ev1, o->st));
   o->h_status.resize((size_t)n_blocks);

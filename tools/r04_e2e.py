@@ -72,9 +72,10 @@ def main():
                     ("device path, 64 MB batches, 8 feeders", {"SVDSS_SEARCH_FEEDERS": "8", "SVDSS_BAM_BATCH_MB": "64"}),
                     ("device path, 3 feeders", {"SVDSS_SEARCH_FEEDERS": "3"})]
     if os.environ.get("R04_ONE"):
-        settings = [("1 feeder", {"SVDSS_SEARCH_FEEDERS": "1"}), ("1 feeder, 16 segments", {"SVDSS_SEARCH_FEEDERS": "1", "SVDSS_SEGMENTS": "16"}),
-                    ("1 feeder, 4 segments", {"SVDSS_SEARCH_FEEDERS": "1", "SVDSS_SEGMENTS": "4"}), ("1 feeder, 2 segments", {"SVDSS_SEARCH_FEEDERS": "1", "SVDSS_SEGMENTS": "2"}),
-                    ("defaults", {}), ("16 segments", {"SVDSS_SEGMENTS": "16"}), ("4 segments", {"SVDSS_SEGMENTS": "4"}), ("defaults (2)", {}), ("16 segments (2)", {"SVDSS_SEGMENTS": "16"})]
+        settings = [("defaults (8 inflate waves per CU)", {}), ("no cap", {"SVDSS_INFLATE_PER_CU": "0"}), ("6 per CU", {"SVDSS_INFLATE_PER_CU": "6"}),
+                    ("7 per CU", {"SVDSS_INFLATE_PER_CU": "7"}), ("9 per CU", {"SVDSS_INFLATE_PER_CU": "9"}),
+                    ("defaults (2)", {}), ("no cap (2)", {"SVDSS_INFLATE_PER_CU": "0"}), ("6 per CU, 6 feeders", {"SVDSS_INFLATE_PER_CU": "6", "SVDSS_SEARCH_FEEDERS": "6"}),
+                    ("8 per CU, 6 feeders, 128 MB", {"SVDSS_SEARCH_FEEDERS": "6", "SVDSS_BAM_BATCH_MB": "128"}), ("1 feeder", {"SVDSS_SEARCH_FEEDERS": "1"})]
     if os.environ.get("R04_SMOOTHED"):
         # the BAM `SVDSS smooth` writes (literal-only dynamic Huffman from csrc/deflate.hip), as search sees it in run_svdss
         sm = os.path.join(work, "smoothed.bam")
