@@ -398,25 +398,30 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, pl & 31u), hi = __builtin_amdgcn_alignbit(w2, w1, pl & 31u);
     const uint64_t b64 = ((uint64_t)hi << 32) | lo;
     uint32_t E = L.lit[lo & ((1u << LB) - 1)];
-    if (__ballot((E & 15u) == 0u)) {
-      if ((E & 15u) == 0u) {
-        const uint32_t r = long_code(lo, LB, lstate, L.lcnt, L.lsym);
-        if (r != ~0u) E = LitEntry()(r & 0xffffu, r >> 16);
-      }
-    }
-    const uint32_t len = E & 15u, lx = (E >> 6) & 7u;
-    Sym s;
-    s.kind = (E >> 4) & 3u;
-    s.val = ((E >> 9) & 511u) + __builtin_amdgcn_ubfe(lo, len, lx);
-    const uint32_t doff = len + lx;
-    const uint32_t dbits = (uint32_t)(b64 >> doff);
+    uint32_t len = E & 15u, lx = (E >> 6) & 7u, kind = (E >> 4) & 3u;
+    uint32_t doff = len + lx;
+    uint32_t dbits = (uint32_t)(b64 >> doff);
     uint32_t D = L.dst[dbits & ((1u << DB) - 1)];
-    if (__ballot(s.kind == 1u && (D & 15u) == 0u)) {
-      if (s.kind == 1u && (D & 15u) == 0u) {
+    // (codes longer than the tables' index bits: one test for both tables, the lanes that met one finish it canonically)
+    if (__ballot(len == 0u || (kind == 1u && (D & 15u) == 0u))) {
+      if (len == 0u) {
+        const uint32_t r = long_code(lo, LB, lstate, L.lcnt, L.lsym);
+        if (r != ~0u) {
+          E = LitEntry()(r & 0xffffu, r >> 16);
+          len = E & 15u; lx = (E >> 6) & 7u; kind = (E >> 4) & 3u;
+          doff = len + lx;
+          dbits = (uint32_t)(b64 >> doff);
+          D = L.dst[dbits & ((1u << DB) - 1)];
+        }
+      }
+      if (kind == 1u && (D & 15u) == 0u) {
         const uint32_t r = long_code(dbits, DB, dstate, L.dcnt, L.dsym);
         if (r != ~0u) D = DstEntry()(r & 0xffffu, r >> 16);
       }
     }
+    Sym s;
+    s.kind = kind;
+    s.val = ((E >> 9) & 511u) + __builtin_amdgcn_ubfe(lo, len, lx);
     const uint32_t dl = D & 15u, dx = (D >> 4) & 15u;
     s.dist = (D >> 8) + __builtin_amdgcn_ubfe(dbits, dl, dx);
     if (s.kind == 1u && dl == 0u) s.kind = 3u;
