@@ -23,8 +23,8 @@
 //     take, the tail of a stream, and data that does not resynchronise.)
 // 15.4 KB of LDS per block.  No CRC check here (bam_device.hip's crc32_kernel, or the caller on the host, checks the BGZF
 // footers).  Measured on 16,384 blocks of 64 KB (tools/inflate_probe.py, GB/s of output; rounds 2-3's kernel in
-// brackets): packed bases + random qualities zlib level 1: 68 (23.7), level 6: 76 (25); binned qualities 61 (35); skewed
-// 94-value qualities 64 (27); literals only, as csrc/deflate.hip writes them: 70 (42); text 325 (335).
+// brackets): packed bases + random qualities zlib level 1: 73 (23.7), level 6: 83 (25); binned qualities 63 (35); skewed
+// 94-value qualities 66 (27); literals only, as csrc/deflate.hip writes them: 78 (42); text 330 (335).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
