@@ -23,8 +23,8 @@
 //     take, the tail of a stream, and data that does not resynchronise.)
 // 15.4 KB of LDS per block.  No CRC check here (bam_device.hip's crc32_kernel, or the caller on the host, checks the BGZF
 // footers).  Measured on 16,384 blocks of 64 KB (tools/inflate_probe.py, GB/s of output; rounds 2-3's kernel in
-// brackets): packed bases + random qualities zlib level 1: 73 (23.7), level 6: 83 (25); binned qualities 63 (35); skewed
-// 94-value qualities 66 (27); literals only, as csrc/deflate.hip writes them: 78 (42); text 330 (335).
+// brackets): packed bases + random qualities zlib level 1: 80 (23.7), level 6: 87 (25); binned qualities 67 (35); skewed
+// 94-value qualities 72 (27); literals only, as csrc/deflate.hip writes them: 82 (42); text 334 (335).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -55,13 +55,16 @@ namespace {
 #define INF_MAXM 512        // matches a pass may hold back until its literals are placed
 #endif
 #ifndef INF_WALKS
-#define INF_WALKS 2         // walks per pass: then it takes the lanes that agree, and the others keep theirs for the next ...
+#define INF_WALKS 1         // walks per pass: then it takes the lanes that agree, and the others keep theirs for the next ...
 #endif
 #ifndef INF_TAKE
-#define INF_TAKE 32         // ... unless fewer than this many agree: then up to ...
+#define INF_TAKE 24         // ... unless fewer than this many agree: then up to ...
 #endif
 #ifndef INF_MAXW
 #define INF_MAXW 3          // ... this many walks
+#endif
+#ifndef INF_GUESTS
+#define INF_GUESTS 1        // the lanes a pass does not take guess, during its last walk, for the pieces of the next pass
 #endif
 #ifndef INF_LB
 #define INF_LB 9
@@ -516,10 +519,12 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
       // neighbour had not fallen in step by the end of its piece: one piece in twenty).  The pass takes the lanes in
       // agreement: a scan over their byte and match counts places every lane's output, a last walk stores the literals in
       // the ring and queues the matches, which are then copied 64 at a time.  The lanes it does not take move down and keep
-      // their walks: in the next pass they are repaired (the first of them starts where this pass ended) while the new
-      // lanes behind them guess.  INF_WALKS = 2 walks and the last one per pass, ~40 lanes taken.  A pass ends early at
-      // the end-of-block code, at a code no table entry or canonical decoding explains (the round below reports it), at
-      // the ring's or the queue's capacity.
+      // their walks: in the next pass they are repaired (the first of them starts where this pass ended).  And they are idle
+      // during the pass's last walk: there they guess for the pieces that ENTER with the next pass (piece 64 + i by lane
+      // T + i, as far as the 3.5 KB of input ring ahead of P reach: ~30 pieces), noting the exit only -- those pieces start
+      // the next pass with their second walk.  One counting walk per pass (up to three while fewer than 24 lanes agree) and
+      // the storing walk; ~40 lanes taken.  A pass ends early at the end-of-block code, at a code no table entry or
+      // canonical decoding explains (the round below reports it), at the ring's or the queue's capacity.
       //
       // A ROUND takes up to 64 bits: lane l decodes the symbol that would start l bits ahead, the chain of symbol starts
       // from offset 0 is found by pointer doubling on the lanes (lane l knows where the symbol after its own starts, J,
@@ -553,13 +558,13 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
           // neighbour left elsewhere than it started walks again from there; the others keep what they have
           uint32_t n_ok = 0;
           for (int it = 0;; ++it) {
-            const uint32_t px = (uint32_t)__shfl_up((int)x, 1), pst = (uint32_t)__shfl_up((int)st, 1);
+            const uint32_t px = (uint32_t)__shfl_up((int)x, 1), pst = (uint32_t)__shfl_up((int)st, 1) & 3u;   // (bit 2 of st: see the last walk)
             const bool pv = __shfl_up((int)valid, 1) != 0;
             bool walk;
             uint32_t from_;
-            if (lane == 0) { walk = !valid || start != 0u; from_ = 0u; }
+            if (lane == 0) { walk = !valid || start != 0u || (st & 4u) != 0u; from_ = 0u; }
             else if (!valid) { walk = true; from_ = (uint32_t)lane * (uint32_t)SB - delta; }
-            else { walk = pv && pst == 0u && px != start; from_ = px; }
+            else { walk = pv && pst == 0u && (px != start || (st & 4u) != 0u); from_ = px; }   // (a walk that did not count, from the right bit: again)
             // in agreement: lane 0 if it started at P, a lane whose neighbour left where it started (by induction all up
             // to the first that is not are the true chain of symbols)
             const bool agrees = valid && !walk && (lane == 0 || (pv && pst == 0u));
@@ -600,29 +605,43 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
             const uint32_t adv = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(T - 1u));
             const uint32_t lst = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)(T - 1u));
             if (wpos + total > isize) { err = ST_OUT; break; }
-            // ---- the last walk: literals into the ring, matches into the queue
+            // ---- the last walk: literals into the ring, matches into the queue.  The lanes the pass does not take have
+            // nothing to do in it: they guess for the pieces that enter with the next pass (piece 64 + i by lane T + i, as
+            // far as the input ring reaches), so that those start the next pass with their second walk.
+            uint32_t gstart = 0, gx = 0, gst = 0;
+            bool gvalid = false;
             {
-              uint32_t r = start, o = wpos + (ic - c), q = im - m;   // (lanes below T: c and m are those of the walk from start)
-              bool going = (uint32_t)lane < T && r < hi_bound;
+              const bool fin = (uint32_t)lane < T;
+              gstart = (64u + ((uint32_t)lane - T)) * (uint32_t)SB - delta;
+              const uint32_t ghi = gstart + (uint32_t)SB;
+              gvalid = INF_GUESTS && !fin && lst == 0u && ghi + 128u <= (uint32_t)(INB - HALF - 32) * 8u;
+              const uint32_t hi = fin ? hi_bound : ghi;
+              uint32_t r = fin ? start : gstart, o = wpos + (ic - c), q = im - m;   // (lanes below T: c and m are those of the walk from start)
+              bool going = fin ? r < hi_bound : gvalid;
               bool bad = false;
               while (__ballot(going)) {
                 const Sym s = symbol_at(P32 + r);
                 if (going) {
-                  if (s.kind >= 2u) going = false;
-                  else {
-                    if (s.kind == 0u) winb[o & WM] = (uint8_t)s.val;
-                    else {
-                      if (s.dist > o) bad = true;
-                      L.mrec[q] = ((s.val - 3u) << 15) | (s.dist - 1u);
-                      L.mpos[q] = (uint16_t)(o - wpos);
-                      ++q;
+                  if (s.kind >= 2u) {
+                    if (!fin) { gst = s.kind == 2u ? 1u : 2u; if (s.kind == 2u) r += s.nbits; }
+                    going = false;
+                  } else {
+                    if (fin) {
+                      if (s.kind == 0u) winb[o & WM] = (uint8_t)s.val;
+                      else {
+                        if (s.dist > o) bad = true;
+                        L.mrec[q] = ((s.val - 3u) << 15) | (s.dist - 1u);
+                        L.mpos[q] = (uint16_t)(o - wpos);
+                        ++q;
+                      }
+                      o += s.outlen;
                     }
                     r += s.nbits;
-                    o += s.outlen;
-                    going = r < hi_bound;
+                    going = r < hi;
                   }
                 }
               }
+              gx = r;
               if (__ballot(bad)) { err = ST_DIST; break; }
             }
             // ---- the matches, 64 at a time in output order, each lane holding one.  Everything below the first one's output
@@ -683,6 +702,15 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
               m = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m);
               st = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)st);
               valid = __builtin_amdgcn_ds_bpermute(src, (int)valid) != 0 && (uint32_t)lane + T < 64u;
+              // (the pieces that enter: guessed in the last walk by the lane that is now lane - (64 - T))
+              const int glane = lane + 2 * (int)T - 64, gsrc = (glane & 63) << 2;
+              const uint32_t g_start = (uint32_t)__builtin_amdgcn_ds_bpermute(gsrc, (int)gstart), g_x = (uint32_t)__builtin_amdgcn_ds_bpermute(gsrc, (int)gx);
+              const uint32_t g_st = (uint32_t)__builtin_amdgcn_ds_bpermute(gsrc, (int)gst);
+              const bool g_valid = __builtin_amdgcn_ds_bpermute(gsrc, (int)gvalid) != 0;
+              if (INF_GUESTS && (uint32_t)lane + T >= 64u && glane >= (int)T && glane < 64 && g_valid) {
+                // (bit 2 of st: a walk that noted its exit only -- the lane walks again before it can agree, even from the same bit)
+                start = g_start - adv; x = g_x - adv; c = 0; m = 0; st = g_st | 4u; valid = true;
+              }
               delta = delta + adv - T * (uint32_t)SB;
               round_now = false;
             }
