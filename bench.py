@@ -744,8 +744,17 @@ def e2e_prepare(work, ref, wg):
                 f.write(b"\n")
 
 
-def _run_search(exe, fmd, bam, env=None):
-    """`SVDSS search --bam` -> (dict of timings from its --verbose log, wall seconds)"""
+def _run_search(exe, fmd, bam, env=None, repeats=1):
+    """`SVDSS search --bam` -> dict of timings from its --verbose log.  repeats > 1: that many runs of the process, the
+    one with the MEDIAN streaming time reported and every run's streaming seconds listed beside it (`streaming_s_runs`):
+    a run that starts while the driver is still clearing the memory the process before it released can wait most of a
+    second for page-locked buffers -- one in five runs on the boxes this was developed on."""
+    if repeats > 1:
+        runs = [_run_search(exe, fmd, bam, env) for _ in range(repeats)]
+        runs_sorted = sorted(runs, key=lambda r: r["streaming_s"])
+        out = dict(runs_sorted[len(runs) // 2])
+        out["streaming_s_runs"] = [r["streaming_s"] for r in runs]
+        return out
     import re
     import subprocess
     t0 = time.perf_counter()
@@ -798,10 +807,10 @@ def e2e_runs(work, n_reads, call=True):
     t0 = time.perf_counter()
     subprocess.run([exe, "index", "-d", os.path.join(work, "chr.fa"), "-o", os.path.join(work, "chr.fmd")], check=True, capture_output=True)
     t_index = time.perf_counter() - t0
-    r = _run_search(exe, os.path.join(work, "chr.fmd"), bam)
+    r = _run_search(exe, os.path.join(work, "chr.fmd"), bam, repeats=3)
     out["e2e_reads_per_s"] = r["reads_per_s_streaming"]
     r["what"] = ("SVDSS search --bam (binary): synthetic BAM, %d x 15 kb reads, %.1f GB file (%.1f GB inflated), "
-                 "chr20-length index, text to /dev/null" % (r["reads"], os.path.getsize(bam) / 1e9, raw / 1e9))
+                 "chr20-length index, text to /dev/null; the run with the median streaming time of three" % (r["reads"], os.path.getsize(bam) / 1e9, raw / 1e9))
     r["index_s"] = round(t_index, 2)
     r["host_cpu_quota_cores"] = cpu_quota()
     out["e2e"] = r
@@ -821,7 +830,7 @@ def e2e_runs(work, n_reads, call=True):
             subprocess.run([exe, "smooth", "--reference", os.path.join(work, "chr.fa"), "--bam", bam, "--threads", "16"], check=True,
                            stdout=f, stderr=subprocess.DEVNULL)
         t_smooth = time.perf_counter() - t0
-        r2 = _run_search(exe, os.path.join(work, "chr.fmd"), sm)
+        r2 = _run_search(exe, os.path.join(work, "chr.fmd"), sm, repeats=3)
         r2["what"] = ("SVDSS smooth -> SVDSS search (binaries), as run_svdss:151-165 chains them: search reads the BAM smooth wrote "
                       "(%.1f GB, deflated on the GPU); smooth: %.2f s whole process = %.0f reads/s"
                       % (os.path.getsize(sm) / 1e9, t_smooth, r["reads"] / t_smooth))
@@ -837,7 +846,7 @@ def e2e_runs(work, n_reads, call=True):
             subprocess.run([exe, "index", "-d", os.path.join(work, "wg.fa"), "-o", os.path.join(work, "wg.fmd")], check=True, capture_output=True)
             t_index = time.perf_counter() - t0
             os.remove(os.path.join(work, "wg.fa"))
-            r = _run_search(exe, os.path.join(work, "wg.fmd"), bam)
+            r = _run_search(exe, os.path.join(work, "wg.fmd"), bam, repeats=3)
             r["what"] = ("the same BAM against the index of the whole reference (24 contigs, GRCh38 primary lengths, 6.18e9 BWT "
                          "symbols): restore = records file (%.1f GB) read + index rebuilt in HBM + K = 16 table"
                          % (os.path.getsize(os.path.join(work, "wg.fmd.svdss")) / 1e9))

@@ -72,13 +72,8 @@ def main():
                     ("device path, 64 MB batches, 8 feeders", {"SVDSS_SEARCH_FEEDERS": "8", "SVDSS_BAM_BATCH_MB": "64"}),
                     ("device path, 3 feeders", {"SVDSS_SEARCH_FEEDERS": "3"})]
     if os.environ.get("R04_ONE"):
-        settings = [("defaults", {}), ("4 MB slabs, 326 MB batches (2 rounds of 2560 members)", {"SVDSS_BAM_SLAB_KB": "4096", "SVDSS_BAM_BATCH_MB": "326"}),
-                    ("4 MB slabs, 163 MB (1 round)", {"SVDSS_BAM_SLAB_KB": "4096", "SVDSS_BAM_BATCH_MB": "161"}),
-                    ("4 MB slabs, 490 MB (3 rounds)", {"SVDSS_BAM_SLAB_KB": "4096", "SVDSS_BAM_BATCH_MB": "487"}),
-                    ("4 MB slabs, 256 MB", {"SVDSS_BAM_SLAB_KB": "4096"}),
-                    ("defaults (2)", {}), ("4 MB slabs, 326 MB (2)", {"SVDSS_BAM_SLAB_KB": "4096", "SVDSS_BAM_BATCH_MB": "326"}),
-                    ("1 feeder, 4 MB slabs, 326 MB", {"SVDSS_SEARCH_FEEDERS": "1", "SVDSS_BAM_SLAB_KB": "4096", "SVDSS_BAM_BATCH_MB": "326"}),
-                    ("1 feeder", {"SVDSS_SEARCH_FEEDERS": "1"})]
+        settings = [("defaults", {}), ("defaults (2)", {}), ("defaults (3)", {}), ("6 feeders, 128 MB", {"SVDSS_SEARCH_FEEDERS": "6", "SVDSS_BAM_BATCH_MB": "128"}),
+                    ("6 feeders, 128 MB (2)", {"SVDSS_SEARCH_FEEDERS": "6", "SVDSS_BAM_BATCH_MB": "128"}), ("3 feeders", {"SVDSS_SEARCH_FEEDERS": "3"}), ("1 feeder", {"SVDSS_SEARCH_FEEDERS": "1"})]
     if os.environ.get("R04_SMOOTHED"):
         # the BAM `SVDSS smooth` writes (literal-only dynamic Huffman from csrc/deflate.hip), as search sees it in run_svdss
         sm = os.path.join(work, "smoothed.bam")
