@@ -328,7 +328,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
   svdss_bam_stream_t* stream = nullptr;
   check(svdss_bam_stream_create(n_ref, &stream), "svdss_bam_stream_create");
   const int64_t super = std::max<int64_t>(o.bsize, 32768 / o.bsize * (int64_t)o.bsize);
-  const int64_t target = (getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 256) << 20;
+  const int64_t target = (getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 192) << 20;
   struct DevJob { uint64_t seq = 0; bool last = false; std::vector<std::unique_ptr<CompChunk>> chunks; };
   struct DevOut { std::vector<Read> reads; std::vector<int32_t> qs, ln; };
   BoundedQueue<DevJob> jobs(2);
@@ -529,7 +529,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     fflush(stdout);
   });
   {
-    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 4;
+    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
     // (formatting the text costs about one core-second per million reads: five threads per GPU, as many as the cores allow)
     const int n_fmt = getenv("SVDSS_FORMAT_THREADS") ? std::max(1, atoi(getenv("SVDSS_FORMAT_THREADS")))
                                                      : (int)std::max<size_t>(5, std::min<size_t>(5 * replicas.size(), effective_cpus()));
@@ -587,10 +587,10 @@ int main_search(const Options& o) {
     hooks.host_alloc = svdss_host_alloc;
     hooks.host_free = svdss_host_free;
     const size_t slab = (getenv("SVDSS_BAM_SLAB_KB") && atoll(getenv("SVDSS_BAM_SLAB_KB")) >= 64 ? (size_t)atoll(getenv("SVDSS_BAM_SLAB_KB")) << 10 : (size_t)16 << 20);
-    const size_t target = (size_t)(getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 256) << 20;
+    const size_t target = (size_t)(getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 192) << 20;
     const int n_dev0 = std::max(1, svdss_device_count());
     const int n_g = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev0));
-    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 4;
+    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
     // slabs alive at once: those the loaders read ahead + those of the batches being fed, queued and cut
     const size_t per_batch = target / slab + 2;
     const int loaders = getenv("SVDSS_BAM_LOADERS") ? std::max(1, atoi(getenv("SVDSS_BAM_LOADERS"))) : 8;
