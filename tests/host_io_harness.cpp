@@ -144,8 +144,26 @@ static int run_fastx(const std::string& path) {
   if (!fx.ok()) { printf("error: cannot open\n"); return 1; }
   std::string name, seq;
   long n = 0;
-  while (fx.next(name, seq)) { touch(name.data(), name.size()); touch(seq.data(), seq.size()); ++n; }
+  std::vector<std::string> names, seqs;
+  while (fx.next(name, seq)) { touch(name.data(), name.size()); touch(seq.data(), seq.size()); ++n; names.push_back(name); seqs.push_back(seq); }
   printf("%ld records\n", n);
+  // the mapped, multi-threaded FASTA loader of `SVDSS call` (fastx_reader.h load_fasta_mapped): whenever it takes a file
+  // it must give exactly the records above (sequence as it is, and upper-cased)
+  for (int threads : {1, 3, 7}) {
+    std::vector<std::string> nm, sq, squ;
+    const bool took = load_fasta_mapped(path, threads, false, nm, sq);
+    if (!took) { printf("mapped loader: declined\n"); break; }
+    if (!load_fasta_mapped(path, threads, true, nm, squ)) { printf("finding: the mapped loader took the file once and not twice\n"); return 3; }
+    if (nm != names || sq != seqs) { printf("finding: the mapped loader and the line reader disagree (%d threads)\n", threads); return 3; }
+    for (size_t i = 0; i < sq.size(); ++i) {
+      if (squ[i].size() != sq[i].size()) { printf("finding: upper-cased length\n"); return 3; }
+      for (size_t k = 0; k < sq[i].size(); ++k) {
+        const char c = sq[i][k];
+        if (squ[i][k] != (char)(c - ((c >= 'a' && c <= 'z') ? 32 : 0))) { printf("finding: upper-casing\n"); return 3; }
+      }
+    }
+    if (threads == 7) printf("mapped loader: the same %zu records\n", nm.size());
+  }
   return 0;
 }
 

@@ -229,6 +229,16 @@ def test_fastx_reader_on_odd_files(harness, tmp_path):
             open(path, "wb").write(gzip.compress(c) if gz else c)
             rc, out = run(harness, "fastx", path)
             assert rc == 0
+    # the mapped loader of `SVDSS call` takes plain FASTA with '\n' line ends -- and then gives what the line reader gives
+    big = b"stray line\n>chr1 some description\n" + b"\n".join(bytes(rng.choice(np.frombuffer(b"ACGTacgtNn", dtype=np.uint8), size=int(w))) for w in rng.integers(0, 90, size=60000))
+    big += b"\n>chr2\tx\n\n\nACGT\n>empty\n>chr1\nTTTT" + b"\n>long\n" + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=20_000_000))
+    open(path, "wb").write(big)
+    rc, out = run(harness, "fastx", path)
+    assert rc == 0 and "mapped loader: the same 5 records" in out, out
+    for odd in (b">a\nAC\r\nGT\n", b"@q\nACGT\n+\nIIII\n", b">a\nAC\n@b\nGT\n", gzip.compress(b">a\nACGT\n"), b"no header at all\n"):
+        open(path, "wb").write(odd)
+        rc, out = run(harness, "fastx", path)
+        assert rc == 0 and "mapped loader: declined" in out, out
     # a gzip stream cut short / damaged
     blob = gzip.compress(b">x\n" + b"ACGT" * 100000 + b"\n")
     for cut in (10, len(blob) // 2, len(blob) - 3):
