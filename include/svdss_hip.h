@@ -321,6 +321,9 @@ void svdss_bam_batch_free(svdss_bam_batch_t* b);
  * entry keeps.  stats: SFS counted unplaced, s_unplaced, e_unplaced, unknown (clusterer.cpp:207-226,296). */
 typedef struct svdss_ref svdss_ref_t;
 int svdss_ref_upload(const uint8_t* seqs, const int64_t* off, int32_t n_chrom, int32_t device, svdss_ref_t** out);
+/* the same from one host buffer per chromosome (as load_chromosomes leaves them, chromosomes.cpp:20: a map of strings): no
+ * 3 GB copy on the host to put them back to back first */
+int svdss_ref_upload_parts(const uint8_t* const* seqs, const int64_t* lens, int32_t n_chrom, int32_t device, svdss_ref_t** out);
 void svdss_ref_free(svdss_ref_t* ref);
 int svdss_place_sfs_batch(svdss_ref_t* ref, const int32_t* tid, const int32_t* pos, const uint32_t* cigar,
                           const int64_t* cigar_off, const int32_t* sfs_qs, const int32_t* sfs_len, const int64_t* sfs_off,

@@ -105,6 +105,7 @@ SIGNATURES = {
     "svdss_bam_batch_selection": (C.c_int, [_p, _p]),
     "svdss_bam_batch_free": (None, [_p]),
     "svdss_ref_upload": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
+    "svdss_ref_upload_parts": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(_p)]),
     "svdss_ref_free": (None, [_p]),
     "svdss_place_sfs_batch": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
     "svdss_smooth_batch": (C.c_int, [_p] * 11 + [_i64] + [_p] * 7),

@@ -603,16 +603,16 @@ struct CallRun {
       svdss_ref_t* dref = nullptr;
       std::vector<int32_t> tid_map(ref_names.size(), -1);
       if (!getenv("SVDSS_PLACE_HOST") && !o.clipped) {
-        std::string all;
-        std::vector<int64_t> off(1, 0);
+        std::vector<const uint8_t*> parts;
+        std::vector<int64_t> lens;
         for (size_t t = 0; t < ref_names.size(); ++t) {
           auto it = C.chrom_seqs.find(ref_names[t]);
           if (it == C.chrom_seqs.end()) continue;
-          tid_map[t] = (int32_t)off.size() - 1;
-          all += it->second;
-          off.push_back((int64_t)all.size());
+          tid_map[t] = (int32_t)parts.size();
+          parts.push_back((const uint8_t*)it->second.data());
+          lens.push_back((int64_t)it->second.size());
         }
-        check(svdss_ref_upload((const uint8_t*)all.data(), off.data(), (int32_t)off.size() - 1, 0, &dref), "svdss_ref_upload");
+        check(svdss_ref_upload_parts(parts.data(), lens.data(), (int32_t)parts.size(), 0, &dref), "svdss_ref_upload_parts");
       }
       // two batches: the next one is read (inflate + slicing, this thread) while the T slices of the previous one run
       std::vector<BamRecord> batches[2];

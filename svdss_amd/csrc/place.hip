@@ -253,6 +253,33 @@ extern "C" int svdss_ref_upload(const uint8_t* seqs, const int64_t* off, int32_t
   return SVDSS_OK;
 }
 
+extern "C" int svdss_ref_upload_parts(const uint8_t* const* seqs, const int64_t* lens, int32_t n_chrom, int32_t device, svdss_ref_t** out) {
+  if (!out || n_chrom < 0 || device < 0 || (n_chrom > 0 && (!seqs || !lens))) return SVDSS_EINVAL;
+  std::vector<int64_t> off((size_t)n_chrom + 1, 0);
+  for (int32_t i = 0; i < n_chrom; ++i) {
+    if (lens[i] < 0 || (lens[i] > 0 && !seqs[i])) return SVDSS_EINVAL;
+    off[(size_t)i + 1] = off[(size_t)i] + lens[i];
+  }
+  HIPCHK5(hipSetDevice(device));
+  svdss_ref* r = new (std::nothrow) svdss_ref();
+  if (!r) return SVDSS_ENOMEM;
+  r->device = device;
+  r->n_chrom = n_chrom;
+  const int64_t total = off[(size_t)n_chrom];
+  auto fail = [&](int code) { svdss_ref_free(r); return code; };
+  if (hipMalloc(&r->d_ref, (size_t)total + 16) != hipSuccess || hipMalloc(&r->d_off, sizeof(int64_t) * (size_t)(n_chrom + 1)) != hipSuccess)
+    return fail(SVDSS_ENOMEM);
+  if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return fail(SVDSS_EHIP);
+  for (int32_t i = 0; i < n_chrom; ++i)
+    if (lens[i] > 0 && hipMemcpyAsync((uint8_t*)r->d_ref + off[(size_t)i], seqs[i], (size_t)lens[i], hipMemcpyHostToDevice, r->stream) != hipSuccess)
+      return fail(SVDSS_EHIP);
+  if (hipMemcpyAsync(r->d_off, off.data(), sizeof(int64_t) * (size_t)(n_chrom + 1), hipMemcpyHostToDevice, r->stream) != hipSuccess ||
+      hipStreamSynchronize(r->stream) != hipSuccess)
+    return fail(SVDSS_EHIP);
+  *out = r;
+  return SVDSS_OK;
+}
+
 extern "C" void svdss_ref_free(svdss_ref_t* r) {
   if (!r) return;
   if (r->device >= 0) (void)hipSetDevice(r->device);

@@ -16,12 +16,22 @@ pytestmark = pytest.mark.gpu
 OPS = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "=": 7, "X": 8}
 
 
+_PARTS = [False]      # alternates: the chromosomes back to back in one buffer / one buffer each (svdss_ref_upload_parts)
+
+
 def _place(chrom_seqs, alns, sfs_lists):
     seqs = np.frombuffer("".join(chrom_seqs).encode(), np.uint8)
     off = np.zeros(len(chrom_seqs) + 1, np.int64)
     off[1:] = np.cumsum([len(s) for s in chrom_seqs])
     h = C.c_void_p()
-    check(lib.svdss_ref_upload(seqs.ctypes.data, off.ctypes.data, len(chrom_seqs), 0, C.byref(h)), "svdss_ref_upload")
+    _PARTS[0] = not _PARTS[0]
+    if _PARTS[0]:
+        bufs = [np.frombuffer(s.encode(), np.uint8) if len(s) else np.zeros(0, np.uint8) for s in chrom_seqs]
+        ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data if len(b) else None for b in bufs])
+        lens = np.array([len(b) for b in bufs], np.int64)
+        check(lib.svdss_ref_upload_parts(ptrs, lens.ctypes.data, len(bufs), 0, C.byref(h)), "svdss_ref_upload_parts")
+    else:
+        check(lib.svdss_ref_upload(seqs.ctypes.data, off.ctypes.data, len(chrom_seqs), 0, C.byref(h)), "svdss_ref_upload")
     try:
         tid = np.array([a.tid for a in alns], np.int32)
         pos = np.array([a.pos for a in alns], np.int32)
