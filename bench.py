@@ -803,6 +803,8 @@ def e2e_runs(work, n_reads, call=True):
     ref0 = np.load(os.path.join(work, "ref0.npy"))
     bam = os.path.join(work, "reads.bam")
     raw = E.write_bam(bam, "chrS", ref0, unit, 15000, repeat=repeat)
+    os.sync()   # (15 GB of freshly written pages: the kernel's write-back otherwise lands in the middle of one of the timed runs
+                #  and its loaders wait ~0.5-0.9 s for the file -- tools/r04_backtoback.sh)
     del ref0
     t0 = time.perf_counter()
     subprocess.run([exe, "index", "-d", os.path.join(work, "chr.fa"), "-o", os.path.join(work, "chr.fmd")], check=True, capture_output=True)
