@@ -747,8 +747,8 @@ def e2e_prepare(work, ref, wg):
 def _run_search(exe, fmd, bam, env=None, repeats=1):
     """`SVDSS search --bam` -> dict of timings from its --verbose log.  repeats > 1: that many runs of the process, the
     one with the MEDIAN streaming time reported and every run's streaming seconds listed beside it (`streaming_s_runs`):
-    a run that starts while the driver is still clearing the memory the process before it released can wait most of a
-    second for page-locked buffers -- one in five runs on the boxes this was developed on."""
+    a run during which the kernel writes a freshly generated input file back to disk waits most of a second for the
+    file's loaders (profiles/r04y_consecutive_runs.txt; e2e_runs syncs after writing its BAM for that reason)."""
     if repeats > 1:
         runs = [_run_search(exe, fmd, bam, env) for _ in range(repeats)]
         runs_sorted = sorted(runs, key=lambda r: r["streaming_s"])
