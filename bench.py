@@ -747,8 +747,8 @@ def e2e_prepare(work, ref, wg):
 def _run_search(exe, fmd, bam, env=None, repeats=1):
     """`SVDSS search --bam` -> dict of timings from its --verbose log.  repeats > 1: that many runs of the process, the
     one with the MEDIAN streaming time reported and every run's streaming seconds listed beside it (`streaming_s_runs`):
-    a run during which the kernel writes a freshly generated input file back to disk waits most of a second for the
-    file's loaders (profiles/r04y_consecutive_runs.txt; e2e_runs syncs after writing its BAM for that reason)."""
+    the second run over a freshly generated input file waits most of a second for the file's loaders (the page cache, not
+    this code: runs 1, 3, 4, 5 do not, nor does any run a second apart; profiles/r04y_consecutive_runs.txt)."""
     if repeats > 1:
         runs = [_run_search(exe, fmd, bam, env) for _ in range(repeats)]
         runs_sorted = sorted(runs, key=lambda r: r["streaming_s"])
@@ -803,8 +803,8 @@ def e2e_runs(work, n_reads, call=True):
     ref0 = np.load(os.path.join(work, "ref0.npy"))
     bam = os.path.join(work, "reads.bam")
     raw = E.write_bam(bam, "chrS", ref0, unit, 15000, repeat=repeat)
-    os.sync()   # (15 GB of freshly written pages: the kernel's write-back otherwise lands in the middle of one of the timed runs
-                #  and its loaders wait ~0.5-0.9 s for the file -- tools/r04_backtoback.sh)
+    os.sync()   # (15 GB of freshly written pages.  It does not cure what it was added for: the SECOND run over a new file
+                #  waits 0.4-0.9 s for the file's loaders, with or without it -- tools/r04_backtoback.sh -- hence the medians)
     del ref0
     t0 = time.perf_counter()
     subprocess.run([exe, "index", "-d", os.path.join(work, "chr.fa"), "-o", os.path.join(work, "chr.fmd")], check=True, capture_output=True)
