@@ -23,8 +23,8 @@
 //     take, the tail of a stream, and data that does not resynchronise.)
 // 15.4 KB of LDS per block.  No CRC check here (bam_device.hip's crc32_kernel, or the caller on the host, checks the BGZF
 // footers).  Measured on 16,384 blocks of 64 KB (tools/inflate_probe.py, GB/s of output; rounds 2-3's kernel in
-// brackets): packed bases + random qualities zlib level 1: 80 (23.7), level 6: 87 (25); binned qualities 67 (35); skewed
-// 94-value qualities 72 (27); literals only, as csrc/deflate.hip writes them: 82 (42); text 334 (335).
+// brackets): packed bases + random qualities zlib level 1: 82 (23.7), level 6: 88 (25); binned qualities 75 (35); skewed
+// 94-value qualities 79 (27); literals only, as csrc/deflate.hip writes them: 81 (42); text 333 (335).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -373,6 +373,7 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
   // a match of ml bytes at output position o, dd bytes back, copied by the whole wave.  Source bytes from position
   // ring_lo on are in the ring; older ones were written to HBM by an earlier flush and are read back from there -- with
   // a ring this small a CU holds several blocks, and that latency is what the other wavefronts are for.
+  const uint32_t inv_lane = lane ? 65536u / (uint32_t)lane + 1u : 0u;   // (k mod d for d < 64, k < 512: k - ((k * inv_d) >> 16) * d; lane d keeps inv_d)
   auto copy_match = [&](uint32_t o, uint32_t ml, uint32_t dd, uint32_t ring_lo) {
     const uint32_t from = o - dd;
     if (from >= ring_lo && dd >= ml && ml <= 64) {   // the common one: short, from the ring, not overlapping itself
@@ -383,8 +384,10 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
     if (far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this block's own stores of long ago)
     uint8_t v[5];
     int nk = 0;
+    const uint32_t inv = dd < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)inv_lane, (int)(dd & 63u)) : 0u;
     for (uint32_t k = lane; k < ml; k += 64) {
-      const uint32_t sp = from + (dd >= ml ? k : k % dd);   // (an overlapping match repeats its first dd bytes)
+      // (an overlapping match repeats its first dd bytes: k mod dd, without a division for the distances runs have)
+      const uint32_t sp = from + (dd >= ml ? k : dd < 64u ? k - ((k * inv) >> 16) * dd : k % dd);
       v[nk++] = sp < ring_lo ? __hip_atomic_load(o8 + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : winb[sp & WM];
     }
     nk = 0;
@@ -677,12 +680,31 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
                   if (side && k < ml) winb[(o + k) & WM] = v[t];
                 }
               }
+              // the others, in order, by the whole wave.  What a chain of such copies costs is instructions (the scalar side
+              // fetches each match from the lane that holds it), so the lanes prepare two words per match: position, length
+              // and "short, from the ring, not overlapping itself" in one, the source position in the other
               unsigned long long rest = __ballot(have && !side);
+              // (bit 31: source and output apart; bit 30: the match overlaps its own output, distance below 64 -- a run: lane k
+              // reads byte k mod distance of the source, by a multiplication with 65536 / distance + 1, which lane `distance`
+              // keeps)
+              const uint32_t near_short = from >= ring_lo && ml <= 64u;
+              const uint32_t pa = (o & 0xffffu) | (ml << 16) | ((near_short && dd >= ml) ? 0x80000000u : 0u) | ((near_short && dd < ml && dd < 64u) ? 0x40000000u : 0u);
               while (rest) {
                 const int h = (int)__builtin_ctzll(rest);
                 rest &= rest - 1;
                 CNT(10, 1);
-                copy_match(__builtin_amdgcn_readlane((int)o, h), __builtin_amdgcn_readlane((int)ml, h), __builtin_amdgcn_readlane((int)dd, h), ring_lo);
+                const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)pa, h), Bf = (uint32_t)__builtin_amdgcn_readlane((int)from, h);
+                if (A & 0x80000000u) {
+                  if ((uint32_t)lane < ((A >> 16) & 0x1ffu)) winb[((A & 0xffffu) + (uint32_t)lane) & WM] = winb[(Bf + (uint32_t)lane) & WM];
+                } else if (A & 0x40000000u) {
+                  const uint32_t o1 = A & 0xffffu, d1 = o1 - Bf;
+                  const uint32_t inv = (uint32_t)__builtin_amdgcn_readlane((int)inv_lane, (int)d1);
+                  const uint32_t k = (uint32_t)lane, r = k - ((k * inv) >> 16) * d1;
+                  if (k < ((A >> 16) & 0x1ffu)) winb[(o1 + k) & WM] = winb[(Bf + r) & WM];
+                } else {
+                  const uint32_t o1 = A & 0xffffu;
+                  copy_match(o1, (A >> 16) & 0x1ffu, o1 - Bf, ring_lo);
+                }
               }
             }
             wpos += total;
