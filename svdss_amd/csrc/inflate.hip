@@ -63,6 +63,9 @@ namespace {
 #ifndef INF_MAXW
 #define INF_MAXW 3          // ... this many walks
 #endif
+#ifndef INF_SIDE_MAX
+#define INF_SIDE_MAX 32     // longest match (a multiple of 4) copied side by side by the lane that holds it
+#endif
 #ifndef INF_GUESTS
 #define INF_GUESTS 1        // the lanes a pass does not take guess, during its last walk, for the pieces of the next pass
 #endif
@@ -661,9 +664,9 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
               const uint32_t from = o - dd;
               const uint32_t o_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
               const uint32_t pe = (uint32_t)__shfl_up((int)(o + ml), 1);
-              const bool side = have && ml <= 32u && (from + ml <= o_first || lane == 0 || from >= pe);
+              const bool side = have && ml <= (uint32_t)INF_SIDE_MAX && (from + ml <= o_first || lane == 0 || from >= pe);
               uint32_t sp = from;
-              for (uint32_t k0 = 0; k0 < 32u; k0 += 4u) {
+              for (uint32_t k0 = 0; k0 < (uint32_t)INF_SIDE_MAX; k0 += 4u) {
                 if (!__ballot(side && k0 < ml)) break;
                 uint8_t v[4];
 #pragma unroll
