@@ -195,6 +195,40 @@ def test_flipped_bits_anywhere_end_in_an_answer():
     assert n_err > 20 and n_same > 5, (n_err, n_same, n_diff)
 
 
+def test_a_capped_grid_walks_the_members_with_a_stride():
+    """SVDSS_INFLATE_PER_CU=n launches at most n wavefronts per compute unit and lets each inflate several members one
+    after the other (csrc/inflate.hip: rings, tables and the lanes' walks start over per member).  In a process of its
+    own: the library reads the variable once."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import zlib, numpy as np
+from svdss_amd.bgzf import gpu_inflate
+rng = np.random.default_rng(5)
+streams, want = [], []
+for k in range(1500):                       # more members than 1 x 256 wavefronts: every wavefront takes five or six
+    n = int(rng.integers(1, 20000))
+    kind = k % 4
+    if kind == 0: d = rng.integers(0, 40, size=n, dtype=np.uint8).tobytes()
+    elif kind == 1: d = bytes(rng.choice(np.array([2, 10, 20, 30, 40, 93], dtype=np.uint8), p=[.02, .03, .05, .1, .3, .5], size=n))
+    elif kind == 2: d = (b"run " * n)[:n]
+    else: d = b""
+    c = zlib.compressobj(int(rng.choice([0, 1, 6])), zlib.DEFLATED, -15)
+    streams.append(c.compress(d) + c.flush()); want.append(d)
+comp, blocks = bytearray(), []
+for s_, w in zip(streams, want):
+    blocks.append((len(comp), len(s_), len(w))); comp += s_
+out = gpu_inflate(bytes(comp), blocks).tobytes()
+assert out == b"".join(want)
+print("ok", len(want))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root,
+                       env=dict(os.environ, SVDSS_INFLATE_PER_CU="1", PYTHONPATH=root))
+    assert p.returncode == 0 and "ok 1500" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
 def test_scattered_outputs_do_not_touch_their_neighbours():
     from svdss_amd.bgzf import gpu_inflate
     rng = np.random.default_rng(5)
