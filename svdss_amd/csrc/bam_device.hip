@@ -12,8 +12,8 @@
 // record that straddles two blocks is contiguous.  The record that straddles two BATCHES is carried: the bytes behind the
 // last complete record of batch b are copied in front of batch b + 1's data (head room).  Per batch:
 //   inflate     csrc/inflate.hip, one wavefront per block; crc32_kernel checks the BGZF footers (one wavefront per block:
-//               64 slices through a 4 x 256-entry table in LDS, combined with x^(8 n) mod P products -- the arithmetic of
-//               zlib's crc32_combine);
+//               lane l takes the words l, l + 64, ... with a <- a x^2048 + w through 4 x 256-entry tables in LDS, the lanes'
+//               sums combined with x^(32 (64 - l)) -- the arithmetic of zlib's crc32_combine);
 //   walk        the records form a chain (offset += 4 + block_size): ~23,000 dependent loads per batch if one lane
 //               follows it.  walk_kernel cuts the batch into segments, one wavefront each: the 64 lanes look for the
 //               first plausible record start in the segment (64 candidates per step; plausible = every field in range
