@@ -1,0 +1,766 @@
+// poa_quad_core.h -- POA consensus with SEVERAL SUB-CLUSTERS PER WAVEFRONT (device code of poa_quad.hip).
+//
+// Same specification as poa_wave.hip / poa.hip / oracle/svdss_oracle_poa.c, bit for bit (caller.cpp:257-308).
+//
+// Why: poa_wave.hip gives every sub-cluster a whole wavefront and one DP row per step.  A banded row is 35-80
+// columns, so the row's arithmetic is a few dozen vector instructions -- and around them ~100 scalar instructions
+// of per-row bookkeeping (band, descriptors, ring slots, branches), three 6-step DPP scans and a scalar round trip
+// for the row maximum: ~290 wave-instructions per row all told (profiles/r03j_what_bounds_a_step.txt), 45 % of them
+// scalar.  The kernel is bound by instruction issue, not by memory, so the way to make it faster is fewer
+// instructions per row.
+//
+// Here a wavefront is G = 64 / GW groups of GW lanes (GW = 16: one group per DPP row), one sub-cluster per group,
+// C consecutive band columns per lane (GW * C >= the widest row).  The groups walk their graphs in lock-step -- row r
+// of every group in the same step -- so
+//   * all per-row bookkeeping is vector code shared by the G groups (a group's "scalars" are values that happen to
+//     be equal in its GW lanes); the scalar unit only counts rows;
+//   * the F prefix maxima and the row maximum are 4-step DPP scans / rotations inside a 16-lane DPP row, the
+//     per-lane part of a row is C independent cells (instruction-level parallelism for a lone wavefront);
+//   * every row is written to an LDS ring of four rows per group (tagged H, E1, E2; cells outside the band and four
+//     guard cells on each side hold "no path", so a successor reads its predecessor unchecked at any small band
+//     shift); a predecessor further back than the ring comes from a copy in HBM (rows flagged in advance);
+//   * direction words go to HBM relative to the row's first column, the C words of a lane side by side.
+// Values are the tagged scores of poa_wave.hip's chain rows (TGB + score * 16 + tag), generalised to any number of
+// predecessors: a candidate through predecessor slot k carries tag 15 - k (match), 15 - k / 7 - k (gap opened from H /
+// extended from E of slot k), so one maximum picks the score and, among equal scores, the source the specification
+// tries first; the direction nibbles are the inverted tags.
+// Traceback, graph update and topological re-ordering are the algorithms of poa_wave.hip with a group's GW lanes in the
+// place of the wavefront's 64 and vector state in the place of scalars.
+// What does not fit (a row wider than GW * C, more than 7 predecessors, a predecessor more than 254 rows back, a band
+// that loses the sink, a graph beyond its allocation) ends that group with status 3 | reason << 8 exactly like
+// poa_wave.hip; the host hands those sub-clusters to poa_wave.hip's rounds.
+//
+// The file is compiled twice: by hipcc for gfx950 (poa_quad.hip), and by g++ with POAQ_EMU for the CPU wave emulator
+// of the tests (tests/native/poa_quad_emu.cpp, tests/native/wave_emu.h), where the cross-lane primitives below are
+// meetings of 64 fibres.  Everything else is the same source.
+#pragma once
+#include <cstdint>
+
+#include "poa_task.h"
+
+#define PQ_NEG (-0x20000000)
+#define PQ_TGB 0x20000000
+#define PQ_O1 4
+#define PQ_E1 2
+#define PQ_O2 24
+#define PQ_E2 1
+#define PQ_MATCH 2
+#define PQ_MISMATCH 4
+#define PQ_COL_SINK 0x7FFFFFFE
+#define PQ_COL_NEW 0x7FFFFFFF
+#define PQ_RING 4     // LDS ring rows per group; a predecessor 1..3 rows back is read from the ring
+#define PQ_GD 4       // "no path" guard cells on each side of a ring row
+#define PQ_INT_MIN (-0x7fffffff - 1)
+
+#ifdef POAQ_EMU
+// ------------------------------------------------------------------------------------------ emulator back end
+#include "../../tests/native/wave_emu.h"
+#define PQ_DEV static inline
+namespace pq {
+inline int lane_id() { return wemu::lane_id(); }
+#define PQ_SITE __LINE__
+template <int GW>
+struct Grp {
+  static int g() { return wemu::lane_id() / GW; }
+  static int l() { return wemu::lane_id() % GW; }
+  static int shr1(int x, int fill, int site) {
+    const uint64_t* d = wemu::meet((uint32_t)x, site);
+    return l() == 0 ? fill : (int)(uint32_t)d[wemu::lane_id() - 1];
+  }
+  static int shl1(int x, int fill, int site) {
+    const uint64_t* d = wemu::meet((uint32_t)x, site);
+    return l() == GW - 1 ? fill : (int)(uint32_t)d[wemu::lane_id() + 1];
+  }
+  static int scan_max(int x, int site) {
+    const uint64_t* d = wemu::meet((uint32_t)x, site);
+    int m = PQ_INT_MIN;
+    for (int i = g() * GW; i <= wemu::lane_id(); ++i) { const int v = (int)(uint32_t)d[i]; if (v > m) m = v; }
+    return m;
+  }
+  static int scan_add(int x, int site) {
+    const uint64_t* d = wemu::meet((uint32_t)x, site);
+    int s = 0;
+    for (int i = g() * GW; i <= wemu::lane_id(); ++i) s += (int)(uint32_t)d[i];
+    return s;
+  }
+  static int all_max(int x, int site) {
+    const uint64_t* d = wemu::meet((uint32_t)x, site);
+    int m = PQ_INT_MIN;
+    for (int i = g() * GW; i < g() * GW + GW; ++i) { const int v = (int)(uint32_t)d[i]; if (v > m) m = v; }
+    return m;
+  }
+  static int all_min(int x, int site) {
+    const uint64_t* d = wemu::meet((uint32_t)x, site);
+    int m = 0x7fffffff;
+    for (int i = g() * GW; i < g() * GW + GW; ++i) { const int v = (int)(uint32_t)d[i]; if (v < m) m = v; }
+    return m;
+  }
+  static int last(int x, int site) {
+    const uint64_t* d = wemu::meet((uint32_t)x, site);
+    return (int)(uint32_t)d[g() * GW + GW - 1];
+  }
+  static int from(int x, int src_l, int site) {
+    const uint64_t* d = wemu::meet((uint32_t)x, site);
+    return (int)(uint32_t)d[g() * GW + (src_l & (GW - 1))];
+  }
+  static uint64_t bits(bool p, int site) {
+    const uint64_t* d = wemu::meet(p ? 1 : 0, site);
+    uint64_t m = 0;
+    for (int i = 0; i < GW; ++i) if (d[g() * GW + i]) m |= 1ull << i;
+    return m;
+  }
+};
+inline bool wave_any(bool p, int site) {
+  const uint64_t* d = wemu::meet(p ? 1 : 0, site);
+  for (int i = 0; i < 64; ++i) if (d[i]) return true;
+  return false;
+}
+inline void lds_sync(int site) { (void)wemu::meet(0, site); }
+inline void mem_sync(int site) { (void)wemu::meet(0, site); }
+inline int atomic_add(int32_t* p, int v) { const int o = *p; *p = o + v; return o; }
+inline void atomic_max(int32_t* p, int v) { if (v > *p) *p = v; }
+inline void atomic_add64(unsigned long long* p, unsigned long long v) { *p += v; }
+inline int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
+inline uint64_t load_u64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
+}  // namespace pq
+#else
+// ------------------------------------------------------------------------------------------ gfx950 back end
+#include <hip/hip_runtime.h>
+#define PQ_DEV __device__ __forceinline__
+#define PQ_SITE 0
+namespace pq {
+PQ_DEV int lane_id() { return (int)threadIdx.x; }
+template <int CTRL, int RMASK>
+PQ_DEV int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, RMASK, 0xf, false); }
+PQ_DEV int imax_(int a, int b) { return a > b ? a : b; }
+PQ_DEV int imin_(int a, int b) { return a < b ? a : b; }
+// DPP controls (gfx9): row_shl:n 0x100+n, row_shr:n 0x110+n, row_ror:n 0x120+n, wave_shl:1 0x130, wave_shr:1 0x138,
+// row_bcast:15 0x142, row_bcast:31 0x143.  A lane whose source lies outside its 16-lane row keeps `old`.
+template <int GW>
+struct Grp {
+  static_assert(GW == 16 || GW == 32 || GW == 64, "group width");
+  PQ_DEV static int g() { return (int)threadIdx.x / GW; }
+  PQ_DEV static int l() { return (int)threadIdx.x % GW; }
+  PQ_DEV static int shr1(int x, int fill, int) {
+    if (GW == 16) return dpp<0x111, 0xf>(fill, x);
+    const int r = dpp<0x138, 0xf>(fill, x);
+    return GW == 64 ? r : (l() == 0 ? fill : r);
+  }
+  PQ_DEV static int shl1(int x, int fill, int) {
+    if (GW == 16) return dpp<0x101, 0xf>(fill, x);
+    const int r = dpp<0x130, 0xf>(fill, x);
+    return GW == 64 ? r : (l() == GW - 1 ? fill : r);
+  }
+  PQ_DEV static int scan_max(int x, int) {
+    x = imax_(x, dpp<0x111, 0xf>(PQ_INT_MIN, x));
+    x = imax_(x, dpp<0x112, 0xf>(PQ_INT_MIN, x));
+    x = imax_(x, dpp<0x114, 0xf>(PQ_INT_MIN, x));
+    x = imax_(x, dpp<0x118, 0xf>(PQ_INT_MIN, x));
+    if (GW >= 32) x = imax_(x, dpp<0x142, 0xa>(PQ_INT_MIN, x));
+    if (GW >= 64) x = imax_(x, dpp<0x143, 0xc>(PQ_INT_MIN, x));
+    return x;
+  }
+  PQ_DEV static int scan_add(int x, int) {
+    x += dpp<0x111, 0xf>(0, x);
+    x += dpp<0x112, 0xf>(0, x);
+    x += dpp<0x114, 0xf>(0, x);
+    x += dpp<0x118, 0xf>(0, x);
+    if (GW >= 32) x += dpp<0x142, 0xa>(0, x);
+    if (GW >= 64) x += dpp<0x143, 0xc>(0, x);
+    return x;
+  }
+  PQ_DEV static int last(int x, int) {
+    if (GW == 64) return __builtin_amdgcn_readlane(x, 63);
+    if (GW == 32) { const int a = __builtin_amdgcn_readlane(x, 31), b = __builtin_amdgcn_readlane(x, 63); return g() ? b : a; }
+    return __builtin_amdgcn_ds_bpermute((int)(threadIdx.x | 15u) << 2, x);
+  }
+  PQ_DEV static int all_max(int x, int s) {
+    if (GW == 16) {   // rotations inside the DPP row: every lane ends with the maximum of the 16
+      x = imax_(x, dpp<0x128, 0xf>(x, x));
+      x = imax_(x, dpp<0x124, 0xf>(x, x));
+      x = imax_(x, dpp<0x122, 0xf>(x, x));
+      x = imax_(x, dpp<0x121, 0xf>(x, x));
+      return x;
+    }
+    return last(scan_max(x, s), s);
+  }
+  PQ_DEV static int all_min(int x, int s) {
+    if (GW == 16) {
+      x = imin_(x, dpp<0x128, 0xf>(x, x));
+      x = imin_(x, dpp<0x124, 0xf>(x, x));
+      x = imin_(x, dpp<0x122, 0xf>(x, x));
+      x = imin_(x, dpp<0x121, 0xf>(x, x));
+      return x;
+    }
+    return -all_max(-x, s);   // (callers pass values far from INT_MIN)
+  }
+  PQ_DEV static int from(int x, int src_l, int) {
+    return __builtin_amdgcn_ds_bpermute((g() * GW + (src_l & (GW - 1))) << 2, x);
+  }
+  PQ_DEV static uint64_t bits(bool p, int) {
+    const uint64_t m = __ballot(p);
+    if (GW == 64) return m;
+    return (m >> (g() * GW)) & ((1ull << GW) - 1ull);
+  }
+};
+PQ_DEV bool wave_any(bool p, int) { return __ballot(p) != 0ull; }
+// LDS accesses of one wavefront are served in program order: nothing to wait for, the compiler must only keep the order
+PQ_DEV void lds_sync(int) { __builtin_amdgcn_wave_barrier(); }
+// global memory written by other lanes of this wavefront: the stores have to have left the wavefront's queue
+PQ_DEV void mem_sync(int) { __syncthreads(); }
+PQ_DEV int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
+PQ_DEV void atomic_max(int32_t* p, int v) { atomicMax(p, v); }
+PQ_DEV void atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+PQ_DEV int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
+PQ_DEV uint64_t load_u64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
+}  // namespace pq
+#endif
+
+namespace pq {
+
+PQ_DEV int imax(int a, int b) { return a > b ? a : b; }
+PQ_DEV int imin(int a, int b) { return a < b ? a : b; }
+PQ_DEV int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
+PQ_DEV int tg_down(int x) { return x <= PQ_TGB / 2 ? PQ_NEG : (x - PQ_TGB) >> 4; }
+
+// LDS the kernel needs for one wavefront (bytes)
+template <int GW, int C>
+struct Geom {
+  static constexpr int G = 64 / GW;
+  static constexpr int WSR = GW * C;                 // columns of a row (HBM stride of the row pools, T.ws)
+  static constexpr int RW = WSR + 2 * PQ_GD;         // cells of a ring row
+  static constexpr int ROW3 = 3 * RW;                // H, E1, E2 of one ring row
+  static constexpr int RING_INTS = G * PQ_RING * ROW3;
+  static constexpr int NULL_OFF = RING_INTS;         // a row of "no path" (predecessor slots a group does not have)
+  static constexpr int CNT_OFF = NULL_OFF + ROW3;    // per group: edge counter
+  static constexpr int LDS_INTS = CNT_OFF + 16;
+};
+
+// direction word: bits 0-3 source of H (0-6 match through predecessor slot k, 8 E1, 9 E2, 10 F1, 11 F2), bits 4-7 source
+// of H' (0-6, 8, 9), bits 8-11 E1 (0-6 opened from H of slot k, 8-14 extended from E1 of slot k - 8), bits 12-15 E2
+// likewise, bit 16 F1 opened from H'(v, j - 1) (else extended), bit 17 F2 likewise  [= poa_wave.hip's]
+// row descriptor dA[r]: bits 0-2 base, 3-6 number of predecessors (0-7), bit 7 the row is read again after it left the
+// ring (keep a copy in HBM), bits 8-15 / 16-23 / 24-31 row deltas of predecessor slots 0-2; dB[r]: slots 3-6
+
+template <int GW, int C>
+PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs, const int64_t* seq_off, int32_t* ws32,
+                     int32_t* cons_len, int32_t* status, unsigned long long* cells, int32_t* lds, int block) {
+  typedef Geom<GW, C> GE;
+  typedef Grp<GW> GR;
+  static_assert(C >= 1 && C <= 7, "the read window of a lane is 8 bytes");
+  constexpr int G = GE::G, WSR = GE::WSR, RW = GE::RW, GD = PQ_GD;
+  const int lane = lane_id();
+  const int g = lane / GW, l = lane % GW;
+  const int ti = block * G + g;
+  const bool has = ti < n_tasks;
+  const PoaWaveTask T = tasks[has ? ti : 0];
+  const int n = has ? (int)T.n_seqs : 0;
+  const int nc = T.nc, ec = T.ec;
+  const int opcap = nc + T.max_len + 4;
+  // ---- HBM arrays of the sub-cluster (ws_layout of poa_wave.hip with ws = WSR), as 32-bit offsets into ws32
+  const uint32_t W0 = (uint32_t)T.ws_off;
+  const uint32_t a_out_head = W0, a_in_head = W0 + (uint32_t)nc, a_order = W0 + 2u * nc, a_index = W0 + 3u * nc,
+                 a_col = W0 + 4u * nc, a_base = W0 + 5u * nc, a_row_beg = W0 + 6u * nc, a_row_end = W0 + 7u * nc,
+                 a_hl = W0 + 8u * nc, a_dB = W0 + 9u * nc, a_row_mpl = W0 + 11u * nc, a_row_mpr = W0 + 12u * nc,
+                 a_aln = W0 + 13u * nc, a_scr = W0 + 18u * nc, a_dA = W0 + 19u * nc + 64u, a_keepf = W0 + 20u * nc + 128u;
+  const uint32_t E0 = W0 + 21u * nc + 192u;
+  const uint32_t a_e_from = E0, a_e_to = E0 + (uint32_t)ec, a_e_w = E0 + 2u * ec, a_e_next_out = E0 + 3u * ec, a_e_next_in = E0 + 4u * ec;
+  const uint32_t OP0 = E0 + 5u * ec;
+  const uint32_t a_op_node = OP0, a_op_q = OP0 + (uint32_t)opcap, a_path_use = OP0 + 2u * opcap, a_path_aux = OP0 + 3u * opcap;
+  const uint32_t P0 = OP0 + 4u * opcap;
+  const uint32_t a_gdir = P0, a_gH = P0 + (uint32_t)nc * WSR, a_gE1 = P0 + 2u * nc * WSR, a_gE2 = P0 + 3u * nc * WSR;
+#define WS(off) ws32[(uint32_t)(off)]
+  // ---- LDS
+  const int ring_g = g * (PQ_RING * GE::ROW3);        // the group's ring
+  int32_t* const cnt = lds + GE::CNT_OFF + g;         // edge counter
+  for (int x = lane; x < GE::CNT_OFF; x += 64) lds[x] = 0;   // ring cells, guards, null row: "no path"
+  unsigned long long my_cells = 0;
+  bool alive = n > 0;
+  int fail_code = 0;
+#define PQ_FAIL(cond, code) do { if (alive && (cond)) { alive = false; fail_code = 3 | ((code) << 8); } } while (0)
+#define PQ_GLOOP(var, bound, pred) for (int var = l; wave_any((pred) && var < (bound), PQ_SITE); var += GW) if ((pred) && var < (bound))
+  int N = 0, ncols = 0;
+  // ------------------------------------------------------------------ graph of the first read
+  {
+    const int64_t so = alive ? seq_off[T.seq_first] : 0;
+    const int L0 = alive ? (int)(seq_off[T.seq_first + 1] - so) : 0;
+    PQ_FAIL(L0 + 2 > nc || L0 + 1 > ec, 1);
+    const uint8_t* q0 = seqs + so;
+    PQ_GLOOP(v, L0 + 2, alive) {
+      const int b = v < 2 ? 4 : q0[v - 2];
+      WS(a_base + v) = b;
+      WS(a_out_head + v) = v == 1 ? -1 : (v == 0 ? 0 : v - 1);
+      WS(a_in_head + v) = v == 0 ? -1 : (v == 1 ? L0 : v - 2);
+      for (int x = 0; x < 5; ++x) WS(a_aln + 5 * v + x) = -1;
+      if (v >= 2) WS(a_aln + 5 * v + b) = v;
+      const int idx = v == 0 ? 0 : v == 1 ? L0 + 1 : v - 1;
+      WS(a_col + v) = v == 1 ? PQ_COL_SINK : idx;
+      WS(a_index + v) = idx;
+      WS(a_order + idx) = v;
+    }
+    PQ_GLOOP(e, L0 + 1, alive) {
+      WS(a_e_from + e) = e == 0 ? 0 : e + 1;
+      WS(a_e_to + e) = e == L0 ? 1 : e + 2;
+      WS(a_e_w + e) = 1;
+      WS(a_e_next_out + e) = -1; WS(a_e_next_in + e) = -1;
+    }
+    N = L0 + 2; ncols = L0 + 1;
+    if (l == 0) *cnt = L0 + 1;
+    mem_sync(PQ_SITE);
+  }
+  for (int i = 1; wave_any(alive && i < n, PQ_SITE); ++i) {
+    bool act = alive && i < n;
+    const int64_t so = act ? seq_off[T.seq_first + i] : 0;
+    const int L = act ? (int)(seq_off[T.seq_first + i + 1] - so) : 0;
+    const uint8_t* q = seqs + so;
+    PQ_FAIL(act && L > T.max_len, 6);
+    act = act && alive;
+    const int w = 10 + (int)(0.01 * L);
+    // ---------------------------------------------------------- row descriptors
+    {
+      bool bad = false;
+      PQ_GLOOP(r, N, act) {
+        const int v = WS(a_order + r);
+        uint32_t dA = (uint32_t)WS(a_base + v) & 7u, dB = 0;
+        int np = 0;
+        for (int e = WS(a_in_head + v); e >= 0; e = WS(a_e_next_in + e)) {
+          const int d = r - WS(a_index + WS(a_e_from + e));
+          if (d < 1 || d > 254) bad = true;
+          if (np < 3) dA |= (uint32_t)(d & 255) << (8 + 8 * np);
+          else if (np < 7) dB |= (uint32_t)(d & 255) << (8 * (np - 3));
+          ++np;
+        }
+        if (np > 7) { bad = true; np = 7; }
+        dA |= (uint32_t)np << 3;
+        WS(a_dA + r) = (int32_t)dA;
+        WS(a_dB + r) = (int32_t)dB;
+        WS(a_hl + r) = PQ_NEG;
+        WS(a_keepf + r) = 0;
+      }
+      const bool gbad = GR::bits(bad, PQ_SITE) != 0;
+      PQ_FAIL(act && gbad, 2);
+      act = act && alive;
+      mem_sync(PQ_SITE);
+      // rows that are read again after they left the ring keep a copy of H / E1 / E2 in HBM
+      PQ_GLOOP(r, N - 1, act) {
+        const uint32_t dA = (uint32_t)WS(a_dA + r), dB = (uint32_t)WS(a_dB + r);
+        const int np = (int)((dA >> 3) & 15u);
+        for (int k = 0; k < np; ++k) {
+          const int d = (int)((k < 3 ? dA >> (8 + 8 * k) : dB >> (8 * (k - 3))) & 255u);
+          if (d >= PQ_RING) WS(a_keepf + (r - d)) = 1;
+        }
+      }
+      mem_sync(PQ_SITE);
+    }
+    // ------------------------------------------------------------ forward (the sink is order[N-1])
+    {
+      int pb1 = 0, pl1 = 0, pr1 = 0, pb2 = 0, pl2 = 0, pr2 = 0, pb3 = 0, pl3 = 0, pr3 = 0;   // beg / mpl / mpr of rows r-1..r-3
+      uint64_t qwin = 0;
+      int qwin_jb = -(1 << 20);
+      uint32_t ri_next = act ? ((uint32_t)WS(a_dA) | (WS(a_keepf) ? 0x80u : 0u)) : 0u;
+      for (int r = 0; wave_any(act && r < N - 1, PQ_SITE); ++r) {
+        bool fw = act && r < N - 1;
+        const uint32_t ri = ri_next;
+        if (act && r + 1 < N - 1) ri_next = (uint32_t)WS(a_dA + r + 1) | (WS(a_keepf + r + 1) ? 0x80u : 0u);
+        const int bv = (int)(ri & 7u), np = (int)((ri >> 3) & 15u);
+        const bool keep = ((ri >> 7) & 1u) != 0;
+        uint32_t riB = 0;
+        if (wave_any(fw && np > 3, PQ_SITE)) { if (fw && np > 3) riB = (uint32_t)WS(a_dB + r); }
+        // ---- band: around the row maxima of the predecessors
+        int lo = 1 << 30, hi = -1;
+        for (int k = 0; wave_any(fw && k < np, PQ_SITE); ++k) {
+          const bool on = fw && k < np;
+          const int d = (int)((k < 3 ? ri >> (8 + 8 * k) : riB >> (8 * (k - 3))) & 255u);
+          int ml = d == 1 ? pl1 : d == 2 ? pl2 : pl3, mr = d == 1 ? pr1 : d == 2 ? pr2 : pr3;
+          if (wave_any(on && d >= PQ_RING, PQ_SITE)) {
+            if (on && d >= PQ_RING) { ml = WS(a_row_mpl + (r - d)); mr = WS(a_row_mpr + (r - d)); }
+          }
+          if (on) { lo = imin(lo, ml); hi = imax(hi, mr); }
+        }
+        int beg, end;
+        if (r == 0) { beg = 0; end = w < L ? w : L; }
+        else {
+          beg = lo + 1 - w; if (beg < 0) beg = 0;
+          end = hi + 1 + w; if (end > L) end = L;
+          if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
+        }
+        const int width = end - beg + 1;
+        PQ_FAIL(fw && width > WSR, 3);
+        fw = fw && alive; act = act && alive;
+        const int jb = beg + l * C;
+        // ---- read symbols q[j - 1] of the lane's columns: an 8-byte window that follows the band
+        uint64_t qcur;
+        {
+          const int dlt = jb - qwin_jb;
+          const bool okw = dlt >= 0 && dlt + C <= 8;
+          uint64_t qnew = 0;
+          if (fw) {
+            const int a = jb - 1;
+            const uint64_t x = load_u64(q + (a < 0 ? 0 : a));
+            qnew = a < 0 ? ((x << 8) | 4ull) : x;      // q[-1] = N: column 0 has no match score
+          }
+          if (wave_any(fw && !okw, PQ_SITE)) qcur = okw ? (qwin >> (8 * (dlt & 7))) : qnew;
+          else qcur = qwin >> (8 * (dlt & 7));
+          qwin = qnew; qwin_jb = jb;
+        }
+        // ---- M, E1, E2 over the predecessors
+        int32_t m[C], e1[C], e2[C];
+        const int s_mat = bv < 4 ? PQ_MATCH * 16 : 0, s_mis = bv < 4 ? -PQ_MISMATCH * 16 : 0;
+        int sc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int qc = (int)((qcur >> (8 * c)) & 0xffu);
+          sc[c] = qc >= 4 ? 0 : (qc == bv ? s_mat : s_mis);
+          m[c] = (r == 0 && jb + c == 0) ? (PQ_TGB + 15) : 0;
+          e1[c] = 0; e2[c] = 0;
+        }
+        for (int k = 0; wave_any(fw && k < np, PQ_SITE); ++k) {
+          const bool on = fw && k < np;
+          const int d = (int)((k < 3 ? ri >> (8 + 8 * k) : riB >> (8 * (k - 3))) & 255u);
+          const int ur = r - d;
+          const int pbeg = d == 1 ? pb1 : d == 2 ? pb2 : pb3;
+          const bool near = d < PQ_RING;
+          const int delta = beg - pbeg;
+          int32_t hv[C + 1], x1[C], x2[C];
+          if (wave_any(on && (!near || delta < 1 - GD || delta > GD), PQ_SITE)) {
+            // the general way (rare): far predecessors from their HBM copy, near ones with clamped ring indices
+            int fb = 0, fe = -1;
+            if (on && !near) { fb = WS(a_row_beg + ur); fe = WS(a_row_end + ur); }
+            const int rb = ring_g + (ur & (PQ_RING - 1)) * GE::ROW3;
+#pragma unroll
+            for (int t = 0; t <= C; ++t) {
+              const int jj = jb - 1 + t;
+              int32_t vh = 0, v1 = 0, v2 = 0;
+              if (on && near) {
+                int idx = jj - pbeg + GD;
+                idx = idx < 0 ? 0 : (idx > RW - 1 ? RW - 1 : idx);
+                vh = lds[rb + idx]; v1 = lds[rb + RW + idx]; v2 = lds[rb + 2 * RW + idx];
+              } else if (on && jj >= fb && jj <= fe) {
+                const uint32_t o = (uint32_t)ur * WSR + (uint32_t)(jj - fb);
+                vh = WS(a_gH + o); v1 = WS(a_gE1 + o); v2 = WS(a_gE2 + o);
+              }
+              hv[t] = vh;
+              if (t >= 1) { x1[t - 1] = v1; x2[t - 1] = v2; }
+            }
+          } else {
+            // ring row read unchecked: its cells outside the band and the guards hold "no path"
+            const int a0 = on ? ring_g + (ur & (PQ_RING - 1)) * GE::ROW3 + (jb - 1 - pbeg + GD) : GE::NULL_OFF;
+#pragma unroll
+            for (int t = 0; t <= C; ++t) hv[t] = lds[a0 + t];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { x1[c] = lds[a0 + RW + 1 + c]; x2[c] = lds[a0 + 2 * RW + 1 + c]; }
+          }
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int32_t mk = hv[c] + sc[c] - k;                                   // tag 15 - k
+            const int32_t a1 = hv[c + 1] - ((PQ_O1 + PQ_E1) * 16 + k);              // tag 15 - k: opened from H of slot k
+            const int32_t b1 = x1[c] - (PQ_E1 * 16 + k);                            // tag 7 - k: extended from E1 of slot k
+            const int32_t a2 = hv[c + 1] - ((PQ_O2 + PQ_E2) * 16 + k);
+            const int32_t b2 = x2[c] - (PQ_E2 * 16 + k);                            // (E2 is stored with tag 6: 6 - k, see below)
+            if (k == 0) { m[c] = mk; e1[c] = imax(a1, b1); e2[c] = imax(a2, b2); }
+            else { m[c] = imax(m[c], mk); e1[c] = imax3(e1[c], a1, b1); e2[c] = imax3(e2[c], a2, b2); }
+          }
+        }
+        // ---- H' = max(M, E1, E2); the lane-serial half of the F prefix maxima; the row maximum
+        int32_t hp[C], hq[C], t1[C], t2[C], p1[C], p2[C], e1c[C], e2c[C];
+        uint32_t dw[C];
+        bool valid[C];
+        int32_t lmax = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int j = jb + c;
+          valid[c] = fw && j <= end;
+          // the source nibbles of E1 / E2 are the inverted tags; as candidates for H' (and as stored values) they carry
+          // the tags of their state: E1 7, E2 6.  (E2 values are stored with tag 6, so "extended from slot k" arrives with
+          // tag 6 - k and "opened" with 15 - k: the nibble of an extension is 9 + k, put right below.)
+          const uint32_t n1 = ~(uint32_t)e1[c] & 15u;
+          uint32_t n2 = ~(uint32_t)e2[c] & 15u;
+          n2 = n2 >= 8u ? n2 - 1u : n2;
+          dw[c] = (n1 << 8) | (n2 << 12);
+          e1c[c] = (int32_t)(((uint32_t)e1[c] & ~15u) | 7u);
+          e2c[c] = (int32_t)(((uint32_t)e2[c] & ~15u) | 6u);
+          hp[c] = valid[c] ? imax3(m[c], e1c[c], e2c[c]) : 0;
+          hq[c] = hp[c] | 15;
+          t1[c] = hq[c] + j * (PQ_E1 * 16); t2[c] = hq[c] + j * (PQ_E2 * 16);
+          p1[c] = c ? imax(p1[c - 1], t1[c]) : t1[c];
+          p2[c] = c ? imax(p2[c - 1], t2[c]) : t2[c];
+          lmax = c ? imax(lmax, hq[c]) : hq[c];
+        }
+        const int32_t s1 = GR::scan_max(p1[C - 1], PQ_SITE), s2 = GR::scan_max(p2[C - 1], PQ_SITE);
+        // (a group's first lane has nothing to its left: prefix maximum 0 = "no path", and a t that equals no x)
+        const int32_t X1 = GR::shr1(s1, 0, PQ_SITE), X2 = GR::shr1(s2, 0, PQ_SITE);
+        const int32_t t1_prev = GR::shr1(t1[C - 1], -1, PQ_SITE), t2_prev = GR::shr1(t2[C - 1], -1, PQ_SITE);
+        // the row maximum of H is the maximum of H', attained where H' attains it (F(j) < max H' -- poa_wave.hip)
+        const int32_t wmx = GR::all_max(lmax, PQ_SITE);
+        int lc = 1 << 20, rc = -1;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          if (hq[c] == wmx) { lc = imin(lc, l * C + c); rc = l * C + c; }
+        }
+        int mpl = GR::all_min(lc, PQ_SITE) + beg, mpr = GR::all_max(rc, PQ_SITE) + beg;
+        if (wmx <= PQ_TGB / 2) { mpl = beg; mpr = end; }
+        // ---- F, H, direction words, the row into the ring
+        const int slot_off = ring_g + (r & (PQ_RING - 1)) * GE::ROW3 + GD + l * C;
+        const uint32_t rowo = (uint32_t)r * WSR + (uint32_t)(l * C);
+        int32_t sH[C], sE1[C], sE2[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int j = jb + c;
+          const int32_t x1 = c ? imax(X1, p1[c - 1]) : X1, x2 = c ? imax(X2, p2[c - 1]) : X2;
+          const int32_t f1 = x1 - (PQ_O1 * 16 + 10) - j * (PQ_E1 * 16);      // tag 15 -> 5
+          const int32_t f2 = x2 - (PQ_O2 * 16 + 11) - j * (PQ_E2 * 16);      // tag 15 -> 4
+          const int32_t h = imax3(hp[c], f1, f2);
+          const uint32_t dH = ~(uint32_t)h & 15u;
+          uint32_t dHp = ~(uint32_t)hp[c] & 15u;
+          // (tags of H': 15 - k match, 7 E1, 6 E2 -> nibbles k, 8, 9.  Tags of H add 5 F1, 4 F2 -> 10, 11)
+          const uint32_t o1 = (c ? t1[c - 1] : t1_prev) == x1 ? 0x10000u : 0u;
+          const uint32_t o2 = (c ? t2[c - 1] : t2_prev) == x2 ? 0x20000u : 0u;
+          dw[c] |= dH | (dHp << 4) | o1 | o2;
+          sH[c] = valid[c] ? (h | 15) : 0; sE1[c] = valid[c] ? e1c[c] : 0; sE2[c] = valid[c] ? e2c[c] : 0;
+          if (valid[c] && j == L) WS(a_hl + r) = tg_down(h);
+        }
+        if (fw) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            WS(a_gdir + rowo + c) = (int32_t)dw[c];
+            lds[slot_off + c] = sH[c]; lds[slot_off + RW + c] = sE1[c]; lds[slot_off + 2 * RW + c] = sE2[c];
+          }
+          if (l == 0) { WS(a_row_beg + r) = beg; my_cells += (unsigned long long)width; }
+        }
+        if (wave_any(fw && keep, PQ_SITE)) {
+          if (fw && keep) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { WS(a_gH + rowo + c) = sH[c]; WS(a_gE1 + rowo + c) = sE1[c]; WS(a_gE2 + rowo + c) = sE2[c]; }
+            if (l == 0) { WS(a_row_end + r) = end; WS(a_row_mpl + r) = mpl; WS(a_row_mpr + r) = mpr; }
+          }
+        }
+        pb3 = pb2; pl3 = pl2; pr3 = pr2; pb2 = pb1; pl2 = pl1; pr2 = pr1; pb1 = beg; pl1 = mpl; pr1 = mpr;
+        lds_sync(PQ_SITE);
+      }
+    }
+    mem_sync(PQ_SITE);   // direction words, row origins and end cells are in HBM
+    // --------------------------------------------------------- traceback
+    int nops = -1;
+    {
+      int bu = -1; int32_t bsc = PQ_NEG;
+      for (int e = act ? WS(a_in_head + 1) : -1; wave_any(e >= 0, PQ_SITE); e = e >= 0 ? WS(a_e_next_in + e) : -1) {
+        if (e >= 0) {
+          const int ur = WS(a_index + WS(a_e_from + e));
+          const int32_t h = WS(a_hl + ur);
+          if (h > bsc) { bsc = h; bu = ur; }
+        }
+      }
+      bool walking = act && bu >= 0 && bsc > PQ_NEG / 2;
+      if (walking) nops = 0;
+      int tr = bu, tj = L, st = 0;   // 0 H, 1 E1, 2 E2, 3 F1, 4 F2, 5 H'
+      int r0 = -(1 << 28), j0 = 0;
+      uint32_t W0_ = 0, W1_ = 0, W2_ = 0, W3_ = 0, PA = 0, PB = 0;
+      for (;;) {
+        bool walk = walking && (tr != 0 || tj > 0);
+        if (!wave_any(walk, PQ_SITE)) break;
+        if (walk && (nops + tj + 2 > opcap || tj < 0 || tr < 0)) { walking = false; walk = false; nops = -1; }   // cannot happen on a valid path
+        if (wave_any(walk && tr == 0, PQ_SITE)) {   // only inserted bases remain
+          const bool s0 = walk && tr == 0;
+          PQ_GLOOP(t, tj, s0) { WS(a_op_node + nops + t) = -1; WS(a_op_q + nops + t) = tj - 1 - t; }
+          if (s0) { nops += tj; tj = 0; walk = false; }
+        }
+        int k = r0 - tr, d = k - (j0 - tj);
+        const bool need = walk && (k < 0 || k >= GW || d < 0 || d > 3);
+        if (wave_any(need, PQ_SITE)) {
+          if (need) {
+            r0 = tr; j0 = tj; k = 0; d = 0;
+            const int rr = r0 - l;
+            W0_ = W1_ = W2_ = W3_ = 0; PA = 0; PB = 0;
+            if (rr >= 0) {
+              const int cc = j0 - l - WS(a_row_beg + rr);
+              const uint32_t bp = a_gdir + (uint32_t)rr * WSR;
+              if ((unsigned)cc < (unsigned)WSR) W0_ = (uint32_t)WS(bp + cc);
+              if ((unsigned)(cc + 1) < (unsigned)WSR) W1_ = (uint32_t)WS(bp + cc + 1);
+              if ((unsigned)(cc + 2) < (unsigned)WSR) W2_ = (uint32_t)WS(bp + cc + 2);
+              if ((unsigned)(cc + 3) < (unsigned)WSR) W3_ = (uint32_t)WS(bp + cc + 3);
+              PA = (uint32_t)WS(a_dA + rr); PB = (uint32_t)WS(a_dB + rr);
+            }
+          }
+        }
+        const uint32_t wsel = d == 0 ? W0_ : d == 1 ? W1_ : d == 2 ? W2_ : W3_;
+        // a run of plain diagonal steps -- a match through predecessor slot 0, which is the row above -- all at once
+        const bool diag = (wsel & 15u) == 0u && ((PA >> 8) & 255u) == 1u && r0 - l >= 1;
+        const uint64_t gm = GR::bits(diag, PQ_SITE);
+        const int kk = k & (GW - 1);
+        int run = ctz64(~(gm >> kk));
+        if (run > tj) run = tj;
+        const uint32_t dwk = (uint32_t)GR::from((int)wsel, kk, PQ_SITE), pak = (uint32_t)GR::from((int)PA, kk, PQ_SITE),
+                       pbk = (uint32_t)GR::from((int)PB, kk, PQ_SITE);
+        if (walk && st == 0 && run > 0) {
+          if (l < run) { WS(a_op_node + nops + l) = tr - l; WS(a_op_q + nops + l) = tj - 1 - l; }
+          nops += run; tr -= run; tj -= run;
+        } else if (walk) {
+          int s = -1;   // predecessor slot to follow
+          if (st == 0 || st == 5) {
+            const uint32_t dd = st == 0 ? (dwk & 15u) : ((dwk >> 4) & 15u);
+            if (dd < 8) {
+              if (l == 0) { WS(a_op_node + nops) = tr; WS(a_op_q + nops) = tj - 1; }
+              ++nops; --tj; st = 0; s = (int)dd;
+            } else st = (int)dd - 7;   // 8 -> E1, 9 -> E2, 10 -> F1, 11 -> F2
+          } else if (st == 1 || st == 2) {
+            const uint32_t dd = st == 1 ? ((dwk >> 8) & 15u) : ((dwk >> 12) & 15u);
+            if (l == 0) { WS(a_op_node + nops) = tr; WS(a_op_q + nops) = -1; }
+            ++nops; s = (int)(dd & 7u);
+            if (dd < 8) st = 0;
+          } else {
+            const uint32_t open = st == 3 ? ((dwk >> 16) & 1u) : ((dwk >> 17) & 1u);
+            if (l == 0) { WS(a_op_node + nops) = -1; WS(a_op_q + nops) = tj - 1; }
+            ++nops;
+            if (open) st = 5;
+            --tj;
+          }
+          if (s >= 0) tr -= (int)((s < 3 ? pak >> (8 + 8 * s) : pbk >> (8 * (s - 3))) & 255u);
+        }
+      }
+    }
+    PQ_FAIL(act && nops < 0, 4);
+    PQ_FAIL(act && nops > 32000, 5);   // (path positions are packed into 15 bits of a scan key)
+    act = act && alive;
+    mem_sync(PQ_SITE);
+    // ------------------------------------------------------- graph update
+    const int n_old = N;
+    PQ_GLOOP(c, ncols, act) WS(a_scr + c) = 0;
+    mem_sync(PQ_SITE);
+    int carry_c = 0, carry_n = 0, carry_key = 0;
+    for (int p0 = 0; wave_any(act && p0 < nops, PQ_SITE); p0 += GW) {
+      const int p = p0 + l;
+      const bool valid = act && p < nops;
+      int row = -1, j = -1;
+      if (valid) { row = WS(a_op_node + nops - 1 - p); j = WS(a_op_q + nops - 1 - p); }
+      const bool ali = valid && row >= 0 && j >= 0, ins = valid && row < 0;
+      const int v = ali ? WS(a_order + row) : -1;
+      const int qb = (ali || ins) ? (int)q[j] : 0;
+      int use = -1;
+      bool isnew = ins;
+      if (ali) {
+        if (WS(a_base + v) == qb) use = v;
+        else { const int a = WS(a_aln + 5 * v + qb); if (a >= 0) use = a; else isnew = true; }
+      }
+      const int inc_c = GR::scan_add((ali || ins) ? 1 : 0, PQ_SITE), inc_n = GR::scan_add(isnew ? 1 : 0, PQ_SITE);
+      const int cidx = carry_c + inc_c - ((ali || ins) ? 1 : 0);
+      const int nrank = carry_n + inc_n - (isnew ? 1 : 0);
+      const int key = ali ? (((cidx + 1) << 16) | WS(a_col + v)) : 0;     // (columns and path positions < 65536)
+      const int inc_k = GR::scan_max(key, PQ_SITE);
+      const int ikey = imax(carry_key, inc_k);
+      carry_c += GR::last(inc_c, PQ_SITE);
+      carry_n += GR::last(inc_n, PQ_SITE);
+      carry_key = imax(carry_key, GR::last(inc_k, PQ_SITE));
+      uint32_t aux = 0xFFFFFFFFu;
+      if (isnew && n_old + nrank < nc) {   // (capacity is checked after the loop)
+        const int nid = n_old + nrank;
+        use = nid;
+        WS(a_base + nid) = qb;
+        WS(a_out_head + nid) = -1; WS(a_in_head + nid) = -1;
+        if (ali) {   // a new base at the column of v: joins v's aligned group
+          for (int b = 0; b < 5; ++b) {
+            const int sib = WS(a_aln + 5 * v + b);
+            WS(a_aln + 5 * nid + b) = sib;
+            if (sib >= 0) WS(a_aln + 5 * sib + qb) = nid;
+          }
+          WS(a_aln + 5 * nid + qb) = nid;
+          WS(a_col + nid) = WS(a_col + v);
+        } else {     // an inserted base: a new column, the t-th after its anchor's
+          for (int b = 0; b < 5; ++b) WS(a_aln + 5 * nid + b) = b == qb ? nid : -1;
+          WS(a_col + nid) = PQ_COL_NEW;
+          const int ac = ikey & 0xffff, t = (cidx + 1) - (ikey >> 16);
+          atomic_max(&WS(a_scr + ac), t);
+          aux = (uint32_t)ac | ((uint32_t)t << 16);
+        }
+      }
+      if (ali || ins) { WS(a_path_use + cidx) = use; WS(a_path_aux + cidx) = (int32_t)aux; }
+    }
+    const int PC = carry_c, n_new = n_old + carry_n;
+    // the graph outgrew its allocation: this sub-cluster goes to the roomier rounds of poa_wave.hip
+    PQ_FAIL(act && (n_new > nc || ncols + carry_n > nc || ncols + carry_n > 65000 || PC > 65000), 5);
+    act = act && alive;
+    mem_sync(PQ_SITE);
+    // one edge per path step; no other lane touches the out-list of u or the in-list of v
+    for (int t = l; wave_any(act && t <= PC, PQ_SITE); t += GW) {
+      if (!(act && t <= PC)) continue;
+      const int u = t == 0 ? 0 : WS(a_path_use + t - 1), v = t == PC ? 1 : WS(a_path_use + t);
+      int tail = -1, e = WS(a_out_head + u);
+      bool found = false;
+      for (; e >= 0; e = WS(a_e_next_out + e)) {
+        if (WS(a_e_to + e) == v) { WS(a_e_w + e) += 1; found = true; break; }
+        tail = e;
+      }
+      if (found) continue;
+      const int ne = atomic_add(cnt, 1);
+      if (ne >= ec) continue;   // out of edge slots: the counter above ec gives the sub-cluster up below
+      WS(a_e_from + ne) = u; WS(a_e_to + ne) = v; WS(a_e_w + ne) = 1;
+      WS(a_e_next_out + ne) = -1; WS(a_e_next_in + ne) = -1;
+      if (tail < 0) WS(a_out_head + u) = ne; else WS(a_e_next_out + tail) = ne;
+      int ie = WS(a_in_head + v);
+      if (ie < 0) WS(a_in_head + v) = ne;
+      else {
+        while (WS(a_e_next_in + ie) >= 0) ie = WS(a_e_next_in + ie);
+        WS(a_e_next_in + ie) = ne;
+      }
+    }
+    mem_sync(PQ_SITE);
+    PQ_FAIL(act && *cnt > ec, 5);
+    act = act && alive;
+    // column ranks: every column moves right by the number of columns inserted before it
+    int carry = 0;
+    for (int c0 = 0; wave_any(act && c0 < ncols, PQ_SITE); c0 += GW) {
+      const int c = c0 + l;
+      const int x = (act && c < ncols) ? WS(a_scr + c) : 0;
+      const int inc = GR::scan_add(x, PQ_SITE);
+      if (act && c < ncols) WS(a_scr + c) = carry + inc - x;
+      carry += GR::last(inc, PQ_SITE);
+    }
+    mem_sync(PQ_SITE);
+    PQ_GLOOP(v, n_new, act) {
+      const int cv = WS(a_col + v);
+      if (cv < PQ_COL_SINK) WS(a_col + v) = cv + WS(a_scr + cv);
+    }
+    mem_sync(PQ_SITE);
+    PQ_GLOOP(t, PC, act) {
+      const uint32_t aux = (uint32_t)WS(a_path_aux + t);
+      if (aux != 0xFFFFFFFFu) { const int ac = (int)(aux & 0xffffu); WS(a_col + WS(a_path_use + t)) = ac + WS(a_scr + ac) + (int)(aux >> 16); }
+    }
+    const int ncols_new = ncols + carry;
+    mem_sync(PQ_SITE);
+    // counting sort of the nodes by column = a topological order; the sink goes last
+    PQ_GLOOP(c, ncols_new, act) WS(a_scr + c) = 0;
+    mem_sync(PQ_SITE);
+    PQ_GLOOP(v, n_new, act) { if (v != 1) (void)atomic_add(&WS(a_scr + WS(a_col + v)), 1); }
+    mem_sync(PQ_SITE);
+    carry = 0;
+    for (int c0 = 0; wave_any(act && c0 < ncols_new, PQ_SITE); c0 += GW) {
+      const int c = c0 + l;
+      const int x = (act && c < ncols_new) ? WS(a_scr + c) : 0;
+      const int inc = GR::scan_add(x, PQ_SITE);
+      if (act && c < ncols_new) WS(a_scr + c) = carry + inc - x;
+      carry += GR::last(inc, PQ_SITE);
+    }
+    mem_sync(PQ_SITE);
+    PQ_GLOOP(v, n_new, act) {
+      if (v != 1) {
+        const int pos = atomic_add(&WS(a_scr + WS(a_col + v)), 1);
+        WS(a_order + pos) = v; WS(a_index + v) = pos;
+      }
+    }
+    if (act) {
+      if (l == 0) { WS(a_order + n_new - 1) = 1; WS(a_index + 1) = n_new - 1; }
+      N = n_new; ncols = ncols_new;
+    }
+    mem_sync(PQ_SITE);
+  }
+  // the heaviest-bundle consensus is poa_bundle_kernel's job: hand over the number of graph rows
+  if (has && l == 0) {
+    if (n <= 0) { cons_len[ti] = 0; status[ti] = 0; }
+    else if (!alive) status[ti] = fail_code;
+    else { cons_len[ti] = N; status[ti] = 0; atomic_add64(cells, my_cells); }
+  }
+#undef WS
+#undef PQ_FAIL
+#undef PQ_GLOOP
+}
+
+}  // namespace pq
