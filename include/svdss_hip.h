@@ -389,6 +389,14 @@ double svdss_poa_batch_kernel_ms(const svdss_poa_batch_t* b);
 /* sub-clusters the LDS-resident kernel handed to the HBM kernel (graph too large for LDS, a node with
  * more than 8 predecessors, or the full-matrix fallback of the band) */
 int64_t svdss_poa_batch_hbm(const svdss_poa_batch_t* b);
+/* sub-clusters the first stage (several sub-clusters per wavefront, csrc/poa_quad.hip) handed on to the
+ * one-wavefront-per-sub-cluster rounds: a row wider than its lanes, a node with more than 7 predecessors, a band that
+ * lost the sink, a graph beyond its first allocation */
+int64_t svdss_poa_batch_quad_back(const svdss_poa_batch_t* b);
+/* developer check of the cross-lane primitives of csrc/poa_quad_core.h (DPP shifts / scans / rotations, permutes,
+ * ballots) on the device: in = 64 values, out = 3 x 64 x 12 values (group widths 16, 32, 64); tests/test_poa_quad_gpu.py
+ * holds them against the definitions the CPU wave emulator of the tests uses */
+int svdss_poa_quad_selftest(const int32_t* in, int32_t* out, int32_t device);
 int svdss_poa_batch_fetch(const svdss_poa_batch_t* b, int64_t* cons_len, uint8_t* cons);
 void svdss_poa_batch_free(svdss_poa_batch_t* b);
 

@@ -123,6 +123,8 @@ SIGNATURES = {
     "svdss_poa_batch_cells": (_i64, [_p]),
     "svdss_poa_batch_kernel_ms": (C.c_double, [_p]),
     "svdss_poa_batch_hbm": (_i64, [_p]),
+    "svdss_poa_batch_quad_back": (_i64, [_p]),
+    "svdss_poa_quad_selftest": (C.c_int, [_p, _p, C.c_int32]),
     "svdss_poa_batch_fetch": (C.c_int, [_p, _p, _p]),
     "svdss_poa_batch_free": (None, [_p]),
     "svdss_indel_ratio_batch": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),

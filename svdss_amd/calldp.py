@@ -103,7 +103,8 @@ def run_poa(clusters: Sequence[Sequence], device: int = 0):
         cons = np.zeros(lib.svdss_poa_batch_total(h), dtype=np.uint8)
         check(lib.svdss_poa_batch_fetch(h, lens.ctypes.data, cons.ctypes.data), "svdss_poa_batch_fetch")
         stats = {"cells": lib.svdss_poa_batch_cells(h), "kernel_ms": lib.svdss_poa_batch_kernel_ms(h),
-                 "hbm": lib.svdss_poa_batch_hbm(h)}
+                 "hbm": lib.svdss_poa_batch_hbm(h),
+                 "quad_back": lib.svdss_poa_batch_quad_back(h)}
     finally:
         if h:
             lib.svdss_poa_batch_free(h)

@@ -30,6 +30,7 @@
 #include "dev_arena.h"
 #include "hip_check.h"
 #include "poa_wave.h"
+#include "poa_quad.h"
 
 extern thread_local std::string g_svdss_hip_err;
 
@@ -409,6 +410,7 @@ struct DevMem3 {
 struct svdss_poa_batch {
   int64_t n_clusters = 0;
   int64_t n_hbm = 0;   // clusters the LDS kernel handed to the HBM kernel
+  int64_t n_quad_back = 0;   // clusters poa_quad.hip handed to poa_wave.hip's rounds
   int64_t cells = 0;
   double kernel_ms = 0.0;
   std::vector<int64_t> cons_len;
@@ -434,6 +436,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   b->n_clusters = n_clusters;
   b->cells = 0;
   b->n_hbm = 0;
+  b->n_quad_back = 0;
   b->kernel_ms = 0.0;
   b->cons_len.assign((size_t)n_clusters, 0);
   b->cons.clear();
@@ -494,8 +497,20 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     if (ws_budget < ((size_t)1 << 30)) ws_budget = (size_t)1 << 30;
   }
   const int n_rounds = 3;
-  for (int round = 0; round < n_rounds && !cur.empty(); ++round) {
-    struct Cand { int64_t c; size_t lds; int cols; PoaWaveTask t; };
+  // round -1 (poa_quad.hip): several sub-clusters per wavefront -- the band as it is in practice, a graph of ~1.5 x the
+  // longest read, at most 7 predecessors per node; whatever it hands back starts round 0 (SVDSS_POA_QUAD=0: skip it)
+  const bool use_quad = use_lds && !(getenv("SVDSS_POA_QUAD") && atoi(getenv("SVDSS_POA_QUAD")) == 0);
+  const int64_t quad_short = getenv("SVDSS_POA_QUAD_SHORT") ? atoll(getenv("SVDSS_POA_QUAD_SHORT")) : 0;
+  const int64_t quad_minwork_pct = getenv("SVDSS_POA_QUAD_MINWORK") ? atoll(getenv("SVDSS_POA_QUAD_MINWORK")) : 0;
+  int64_t batch_max_work = 1;
+  for (int64_t c = 0; c < n_clusters; ++c) {
+    int64_t maxl = 0;
+    for (int64_t s = cluster_off[c]; s < cluster_off[c + 1]; ++s) maxl = std::max(maxl, seq_off[s + 1] - seq_off[s]);
+    batch_max_work = std::max(batch_max_work, (cluster_off[c + 1] - cluster_off[c]) * maxl);
+  }
+  for (int round = use_quad ? -1 : 0; round < n_rounds && !cur.empty(); ++round) {
+    const bool quad = round < 0;
+    struct Cand { int64_t c; size_t lds; int cols; int gw; PoaWaveTask t; };
     std::vector<Cand> cands;
     const size_t LDS_MAX = 160 * 1024 - 512;
     for (int64_t c : cur) {
@@ -511,10 +526,10 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
       }
       // the graph rarely grows beyond ~1.5 x the longest read (later rounds: 3 x); a cluster that outgrows its
       // allocation is redone.  SVDSS_POA_NC scales the first estimate (percent).
-      const int nc_pct = round ? 300 : getenv("SVDSS_POA_NC") ? std::max(atoi(getenv("SVDSS_POA_NC")), 100) : 150;
+      const int nc_pct = round > 0 ? 300 : getenv("SVDSS_POA_NC") ? std::max(atoi(getenv("SVDSS_POA_NC")), 100) : 150;
       int64_t nc = std::min<int64_t>(tot + 2, maxl * nc_pct / 100 + 8 * t.n_seqs + 64);
       if (nc > 65000) nc = 65000;
-      const int64_t ecap = std::min<int64_t>(nc + nc / (round ? 2 : 4) + t.n_seqs + 64, 100000);
+      const int64_t ecap = std::min<int64_t>(nc + nc / (round > 0 ? 2 : 4) + t.n_seqs + 64, 100000);
       // widest row the ring holds: the band as it is in practice (round 0), as wide as the specification lets it
       // get (round 1), the full matrix (round 2, after the band lost the sink)
       const int64_t w_band = 10 + (int64_t)(0.01 * (double)maxl);
@@ -522,7 +537,27 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
       // leaves at least 8 of slack, so that a row is one column per lane: the C = 1 instantiation)
       const int64_t w2 = 2 * w_band + 1;
       const int64_t wcap0 = w2 + 8 <= 64 ? 64 : w2 + 32;
-      const int64_t wcap = std::min<int64_t>(round == 0 ? wcap0 : round == 1 ? 2 * w_band + 129 : maxl + 1, maxl + 1);
+      const int64_t wcap = std::min<int64_t>(round <= 0 ? wcap0 : round == 1 ? 2 * w_band + 129 : maxl + 1, maxl + 1);
+      if (quad) {
+        // group width x columns per lane >= 2w + 1 columns plus 8 of slack for the spread of the predecessors' maxima
+        // (SVDSS_POA_QUAD_GW: 16 -- four sub-clusters per wavefront --, 32 or 64)
+        // Group width: four short sub-clusters share a wavefront (a quarter of the wavefront slots for the latency-bound
+        // traceback / graph-update phases); a long one gets the wavefront to itself -- the longest chains of a batch
+        // decide when it ends, and a row of C = 2 columns per lane is the quickest there is.
+        const int gw = getenv("SVDSS_POA_QUAD_GW") ? atoi(getenv("SVDSS_POA_QUAD_GW")) : (maxl <= quad_short ? 16 : 64);
+        // SVDSS_POA_QUAD_MINWORK (percent of the batch's largest reads x length): only the long chains take this stage
+        if (t.n_seqs * maxl * 100 < quad_minwork_pct * batch_max_work) { retry.push_back(c); continue; }
+        const int64_t need = std::min<int64_t>(w2 + 8, maxl + 1);
+        const int qc = (int)std::max<int64_t>((need + gw - 1) / gw, gw == 16 ? 3 : gw == 32 ? 2 : 1);
+        if ((gw != 16 && gw != 32 && gw != 64) || !poa_quad_supported(gw, qc) || t.n_seqs <= 0 || t.n_seqs > 8191 ||
+            poa_bundle_lds_bytes((int)nc) > LDS_MAX || poa_quad_lds_bytes(gw, qc, (int)maxl) > LDS_MAX) {
+          retry.push_back(c);
+          continue;
+        }
+        t.nc = (int32_t)nc; t.ec = (int32_t)ecap; t.max_len = (int32_t)maxl; t.ws = gw * qc; t.rs = 0; t.ring = 0;
+        cands.push_back(Cand{c, poa_quad_lds_bytes(gw, qc, (int)maxl), qc, gw, t});
+        continue;
+      }
       int64_t ws = 64;
       while (ws < wcap) ws <<= 1;
       const int64_t rs = (wcap + 3) & ~(int64_t)3;
@@ -536,14 +571,14 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         if (t.n_seqs > 0) ++b->n_hbm;
         continue;
       }
-      cands.push_back(Cand{c, lds, cols, t});
+      cands.push_back(Cand{c, lds, cols, 0, t});
     }
     // launches are grouped by instantiation and by LDS size class, so that small clusters are not charged the
     // LDS of the largest one (LDS decides how many sub-clusters a CU keeps in flight); the groups run
     // concurrently on their own streams (one sub-cluster is a chain of dependent steps: the machine is
     // filled by running many of them, whichever launch they came from)
     struct Group {
-      int cols = 0;
+      int cols = 0, gw = 0, max_len = 0;   // gw != 0: a launch of poa_quad.hip
       size_t lds = 0, bundle_lds = 0;
       std::vector<PoaWaveTask> tasks;
       std::vector<int64_t> ids;
@@ -568,7 +603,34 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         cd.t.prio = wk * 2 > wmax ? 3 : wk * 4 > wmax ? 2 : wk * 8 > wmax ? 1 : 0;
       }
     }
-    for (int ci = 0; ci < kPoaWaveNCols; ++ci) {
+    if (quad) {
+      // wavefronts of sub-clusters that are alike (the groups of a wavefront walk in lock-step: it lasts as long as its
+      // longest), the longest first; one launch per variant
+      std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) {
+        if (x.gw != y.gw) return x.gw > y.gw;
+        if (x.cols != y.cols) return x.cols > y.cols;
+        const int64_t wx = x.t.n_seqs * (int64_t)x.t.max_len, wy = y.t.n_seqs * (int64_t)y.t.max_len;
+        if (wx != wy) return wx > wy;
+        return x.c < y.c;
+      });
+      Group* g = nullptr;
+      for (Cand& cd : cands) {
+        PoaWaveTask t = cd.t;
+        const int64_t need = poa_wave_ws_ints(t.nc, t.ec, t.max_len, t.ws);
+        if (!g || g->gw != cd.gw || g->cols != cd.cols || g->w32 + need > group_budget32) {
+          groups.emplace_back(new Group);
+          g = groups.back().get();
+          g->cols = cd.cols; g->gw = cd.gw; g->lds = cd.lds;
+        }
+        g->max_len = std::max(g->max_len, (int)t.max_len);
+        t.ws_off = g->w32; g->w32 += need;
+        t.cons_off = g->w8; g->w8 += t.nc;
+        g->bundle_lds = std::max(g->bundle_lds, poa_bundle_lds_bytes(t.nc));
+        g->tasks.push_back(t);
+        g->ids.push_back(cd.c);
+      }
+    }
+    for (int ci = 0; ci < kPoaWaveNCols && !quad; ++ci) {
       Group* g = nullptr;
       size_t fill = 0;   // sub-clusters that fill the machine at the group's LDS size
       for (Cand& cd : cands) {
@@ -611,10 +673,17 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
       const auto t0 = std::chrono::steady_clock::now();
       for (size_t gi = gpos; gi < gend; ++gi) {
         Group& g = *groups[gi];
+        const hipStream_t gs = b->streams[(gi - gpos) % b->streams.size()];
+        if (g.gw) {
+          HIPCHK3(poa_quad_launch(g.gw, g.cols, (const PoaWaveTask*)g.d_tasks, (int)g.tasks.size(), g.max_len, (const uint8_t*)d_seqs.p,
+                                  (const int64_t*)d_off.p, (int32_t*)g.d32, (int32_t*)g.d_len, (int32_t*)g.d_st,
+                                  (unsigned long long*)d_cells.p, gs));
+          HIPCHK3(poa_bundle_launch((const PoaWaveTask*)g.d_tasks, (int)g.tasks.size(), g.bundle_lds, (int32_t*)g.d32, (uint8_t*)g.d8,
+                                    (int32_t*)g.d_len, (const int32_t*)g.d_st, gs));
+        } else
         HIPCHK3(poa_wave_launch(g.cols, (const PoaWaveTask*)g.d_tasks, (int)g.tasks.size(), g.lds, g.bundle_lds,
                                 (const uint8_t*)d_seqs.p, (const int64_t*)d_off.p, (int32_t*)g.d32, (uint8_t*)g.d8,
-                                (int32_t*)g.d_len, (int32_t*)g.d_st, (unsigned long long*)d_cells.p,
-                                b->streams[(gi - gpos) % b->streams.size()]));
+                                (int32_t*)g.d_len, (int32_t*)g.d_st, (unsigned long long*)d_cells.p, gs));
       }
       for (size_t k = 0; k < std::min(gend - gpos, b->streams.size()); ++k) HIPCHK3(hipStreamSynchronize(b->streams[k]));
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -637,21 +706,24 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
             results[(size_t)g.ids[(size_t)k]].assign(src, src + lens[(size_t)k]);
           } else {
             const int reason = (st[(size_t)k] >> 8) & 7;
-            if (round + 1 < n_rounds && (reason == 3 || reason == 4 || reason == 5)) retry.push_back(g.ids[(size_t)k]);
+            if (quad) retry.push_back(g.ids[(size_t)k]);
+            else if (round + 1 < n_rounds && (reason == 3 || reason == 4 || reason == 5)) retry.push_back(g.ids[(size_t)k]);
             else { todo.push_back(g.ids[(size_t)k]); ++b->n_hbm; }
             ++why[reason];
+            if (quad) ++b->n_quad_back;
           }
         }
         groups[gi].reset();
       }
-      if (getenv("SVDSS_DEBUG")) poa_wave_debug_report();
+      if (getenv("SVDSS_DEBUG")) { if (quad) poa_quad_debug_report(); else poa_wave_debug_report(); }
       if (getenv("SVDSS_DEBUG"))
-        fprintf(stderr, "[poa] wave round %d: %lld clusters in %zu launches, %.3f ms, not done: first-read %d preds %d width %d band %d capacity %d other %d\n",
-                round, (long long)n_run, gend - gpos, ms, why[1], why[2], why[3], why[4], why[5], why[0] + why[6] + why[7]);
+        fprintf(stderr, "[poa] %s round %d: %lld clusters in %zu launches, %.3f ms, not done: first-read %d preds %d width %d band %d capacity %d other %d\n",
+                quad ? "quad" : "wave", round, (long long)n_run, gend - gpos, ms, why[1], why[2], why[3], why[4], why[5], why[0] + why[6] + why[7]);
       gpos = gend;
     }
     cur.swap(retry);
     retry.clear();
+    if (quad) std::sort(cur.begin(), cur.end());
   }
   std::sort(todo.begin(), todo.end());
   for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
@@ -750,6 +822,7 @@ extern "C" int64_t svdss_poa_batch_total(const svdss_poa_batch_t* b) { return b 
 extern "C" int64_t svdss_poa_batch_cells(const svdss_poa_batch_t* b) { return b ? b->cells : -1; }
 extern "C" double svdss_poa_batch_kernel_ms(const svdss_poa_batch_t* b) { return b ? b->kernel_ms : -1.0; }
 extern "C" int64_t svdss_poa_batch_hbm(const svdss_poa_batch_t* b) { return b ? b->n_hbm : -1; }
+extern "C" int64_t svdss_poa_batch_quad_back(const svdss_poa_batch_t* b) { return b ? b->n_quad_back : -1; }
 extern "C" int svdss_poa_batch_fetch(const svdss_poa_batch_t* b, int64_t* cons_len, uint8_t* cons) {
   if (!b) return SVDSS_EINVAL;
   if (cons_len) memcpy(cons_len, b->cons_len.data(), sizeof(int64_t) * b->cons_len.size());

@@ -71,6 +71,8 @@ struct Grp {
     const uint64_t* d = wemu::meet((uint32_t)x, site);
     return l() == GW - 1 ? fill : (int)(uint32_t)d[wemu::lane_id() + 1];
   }
+  static int shr1z(int x, int site) { return shr1(x, 0, site); }
+  static int shl1z(int x, int site) { return shl1(x, 0, site); }
   static int scan_max(int x, int site) {
     const uint64_t* d = wemu::meet((uint32_t)x, site);
     int m = PQ_INT_MIN;
@@ -109,12 +111,31 @@ struct Grp {
     for (int i = 0; i < GW; ++i) if (d[g() * GW + i]) m |= 1ull << i;
     return m;
   }
+  // first / last lane of the group with p (1 << 20 / -1 if none)
+  static void first_last(bool p, int& first, int& last, int site) {
+    const uint64_t m = bits(p, site);
+    first = m ? __builtin_ctzll(m) : (1 << 20);
+    last = m ? 63 - __builtin_clzll(m) : -1;
+  }
 };
 inline bool wave_any(bool p, int site) {
   const uint64_t* d = wemu::meet(p ? 1 : 0, site);
   for (int i = 0; i < 64; ++i) if (d[i]) return true;
   return false;
 }
+// maximum over the wavefront of a value that is uniform within every group -> a wave-uniform value
+template <int GW>
+inline int wave_gmax(int x, int site) {
+  const uint64_t* d = wemu::meet((uint32_t)x, site);
+  int m = PQ_INT_MIN;
+  for (int i = 0; i < 64; ++i) { const int v = (int)(uint32_t)d[i]; if (v > m) m = v; }
+  return m;
+}
+inline void force_ready(uint32_t&) {}
+inline void force_ready_i(int32_t&) {}
+inline void vm_drain() {}
+inline unsigned long long prof_clock() { return 0; }
+inline void prof_out(const unsigned long long*) {}
 inline void lds_sync(int site) { (void)wemu::meet(0, site); }
 inline void mem_sync(int site) { (void)wemu::meet(0, site); }
 inline int atomic_add(int32_t* p, int v) { const int o = *p; *p = o + v; return o; }
@@ -122,6 +143,10 @@ inline void atomic_max(int32_t* p, int v) { if (v > *p) *p = v; }
 inline void atomic_add64(unsigned long long* p, unsigned long long v) { *p += v; }
 inline int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
 inline uint64_t load_u64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
+// the low bytes of four values side by side
+inline uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return (a & 255u) | ((b & 255u) << 8) | ((c & 255u) << 16) | ((d & 255u) << 24); }
+// signed 3-bit field of x at bit `at`
+inline int sbfe3(uint32_t x, uint32_t at) { return (int)((int32_t)(x << (29u - (at & 31u))) >> 29); }
 }  // namespace pq
 #else
 // ------------------------------------------------------------------------------------------ gfx950 back end
@@ -150,6 +175,17 @@ struct Grp {
     if (GW == 16) return dpp<0x101, 0xf>(fill, x);
     const int r = dpp<0x130, 0xf>(fill, x);
     return GW == 64 ? r : (l() == GW - 1 ? fill : r);
+  }
+  // the same with 0 for the lane that has no neighbour: one instruction (bound_ctrl), no register to preload with the fill
+  PQ_DEV static int shr1z(int x, int) {
+    if (GW == 16) return __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+    const int r = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);
+    return GW == 64 ? r : (l() == 0 ? 0 : r);
+  }
+  PQ_DEV static int shl1z(int x, int) {
+    if (GW == 16) return __builtin_amdgcn_update_dpp(0, x, 0x101, 0xf, 0xf, true);
+    const int r = __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true);
+    return GW == 64 ? r : (l() == GW - 1 ? 0 : r);
   }
   PQ_DEV static int scan_max(int x, int) {
     x = imax_(x, dpp<0x111, 0xf>(PQ_INT_MIN, x));
@@ -195,6 +231,8 @@ struct Grp {
     return -all_max(-x, s);   // (callers pass values far from INT_MIN)
   }
   PQ_DEV static int from(int x, int src_l, int) {
+    // (one group = the wavefront: what is uniform in the group is uniform, and a scalar lane select does it)
+    if (GW == 64) return __builtin_amdgcn_readlane(x, __builtin_amdgcn_readfirstlane(src_l) & 63);
     return __builtin_amdgcn_ds_bpermute((g() * GW + (src_l & (GW - 1))) << 2, x);
   }
   PQ_DEV static uint64_t bits(bool p, int) {
@@ -202,8 +240,30 @@ struct Grp {
     if (GW == 64) return m;
     return (m >> (g() * GW)) & ((1ull << GW) - 1ull);
   }
+  // first / last lane of the group with p (1 << 20 / -1 if none)
+  PQ_DEV static void first_last(bool p, int& first, int& last, int s) {
+    const uint64_t m = bits(p, s);
+    first = m ? (int)__builtin_ctzll(m) : (1 << 20);
+    last = m ? 63 - (int)__builtin_clzll(m) : -1;
+  }
 };
 PQ_DEV bool wave_any(bool p, int) { return __ballot(p) != 0ull; }
+template <int GW>
+PQ_DEV int wave_gmax(int x, int) {
+  int m = __builtin_amdgcn_readlane(x, 0);
+#pragma unroll
+  for (int i = GW; i < 64; i += GW) m = imax_(m, __builtin_amdgcn_readlane(x, i));
+  return m;
+}
+// the value of a load is needed HERE (the compiler would otherwise wait for it at its first use, inside the row loop)
+PQ_DEV void force_ready(uint32_t& x) { asm volatile("" : "+v"(x)); }
+PQ_DEV void force_ready_i(int32_t& x) { asm volatile("" : "+v"(x)); }
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt left alone) as an instruction the compiler's wait-count pass sees: behind it no
+// vector-memory result is pending, so code after the join of a rare branch that loads is not made to wait
+PQ_DEV void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+PQ_DEV unsigned long long prof_clock() { return wall_clock64(); }
+__device__ unsigned long long g_poaq_prof[8];   // SVDSS_DEBUG: 100 MHz ticks in prepare, forward, traceback, update; steps, general steps
+PQ_DEV void prof_out(const unsigned long long* p) { if (threadIdx.x == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_poaq_prof[k], p[k]); }
 // LDS accesses of one wavefront are served in program order: nothing to wait for, the compiler must only keep the order
 PQ_DEV void lds_sync(int) { __builtin_amdgcn_wave_barrier(); }
 // global memory written by other lanes of this wavefront: the stores have to have left the wavefront's queue
@@ -213,6 +273,12 @@ PQ_DEV void atomic_max(int32_t* p, int v) { atomicMax(p, v); }
 PQ_DEV void atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 PQ_DEV int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
 PQ_DEV uint64_t load_u64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
+// the low bytes of four values side by side: two byte permutes and an or
+PQ_DEV uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  return __builtin_amdgcn_perm(b, a, 0x0c0c0400u) | __builtin_amdgcn_perm(d, c, 0x04000c0cu);
+}
+// signed 3-bit field of x at bit `at` (v_bfe_i32)
+PQ_DEV int sbfe3(uint32_t x, uint32_t at) { return __builtin_amdgcn_sbfe(x, at, 3u); }
 }  // namespace pq
 #endif
 
@@ -233,18 +299,23 @@ struct Geom {
   static constexpr int RING_INTS = G * PQ_RING * ROW3;
   static constexpr int NULL_OFF = RING_INTS;         // a row of "no path" (predecessor slots a group does not have)
   static constexpr int CNT_OFF = NULL_OFF + ROW3;    // per group: edge counter
-  static constexpr int LDS_INTS = CNT_OFF + 16;
+  static constexpr int LDS_INTS = CNT_OFF + 16;             // behind them: the G reads, qcap bytes each
+  // bytes of a group's read buffer: the read at byte 4, and the lanes past the band's end read (and ignore) up to WSR
+  // symbols behind it
+  static constexpr int qcap(int max_len) { return (max_len + WSR + 24 + 15) & ~15; }
+  static constexpr size_t lds_bytes(int max_len) { return sizeof(int32_t) * (size_t)LDS_INTS + (size_t)G * (size_t)qcap(max_len); }
 };
 
-// direction word: bits 0-3 source of H (0-6 match through predecessor slot k, 8 E1, 9 E2, 10 F1, 11 F2), bits 4-7 source
-// of H' (0-6, 8, 9), bits 8-11 E1 (0-6 opened from H of slot k, 8-14 extended from E1 of slot k - 8), bits 12-15 E2
-// likewise, bit 16 F1 opened from H'(v, j - 1) (else extended), bit 17 F2 likewise  [= poa_wave.hip's]
+// direction word: the low nibbles of its four bytes are the INVERTED source codes of H, H', E1, E2 (the tags of the values
+// that won, as they are): H 0-6 match through predecessor slot k, 8 E1, 9 E2, 10 F1, 11 F2; H' 0-6, 8, 9; E1 0-6 opened
+// from H of slot k, 8-14 extended from E1 of slot k - 8; E2 likewise.  Bit 4: F1 opened from H'(v, j - 1) (else
+// extended), bit 5: F2 likewise.  (poa_wave.hip's codes, laid out for two byte permutes instead of a dozen shifts)
 // row descriptor dA[r]: bits 0-2 base, 3-6 number of predecessors (0-7), bit 7 the row is read again after it left the
 // ring (keep a copy in HBM), bits 8-15 / 16-23 / 24-31 row deltas of predecessor slots 0-2; dB[r]: slots 3-6
 
 template <int GW, int C>
 PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs, const int64_t* seq_off, int32_t* ws32,
-                     int32_t* cons_len, int32_t* status, unsigned long long* cells, int32_t* lds, int block) {
+                     int32_t* cons_len, int32_t* status, unsigned long long* cells, int32_t* lds, int block, int qcap) {
   typedef Geom<GW, C> GE;
   typedef Grp<GW> GR;
   static_assert(C >= 1 && C <= 7, "the read window of a lane is 8 bytes");
@@ -273,8 +344,11 @@ PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs,
   // ---- LDS
   const int ring_g = g * (PQ_RING * GE::ROW3);        // the group's ring
   int32_t* const cnt = lds + GE::CNT_OFF + g;         // edge counter
+  uint8_t* const qb = (uint8_t*)(lds + GE::LDS_INTS) + (size_t)g * (size_t)qcap;   // the read being aligned
   for (int x = lane; x < GE::CNT_OFF; x += 64) lds[x] = 0;   // ring cells, guards, null row: "no path"
   unsigned long long my_cells = 0;
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = 0;
+#define PQ_PROF(k) do { const unsigned long long t_ = prof_clock(); prof[k] += t_ - prof_t; prof_t = t_; } while (0)
   bool alive = n > 0;
   int fail_code = 0;
 #define PQ_FAIL(cond, code) do { if (alive && (cond)) { alive = false; fail_code = 3 | ((code) << 8); } } while (0)
@@ -316,6 +390,7 @@ PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs,
     PQ_FAIL(act && L > T.max_len, 6);
     act = act && alive;
     const int w = 10 + (int)(0.01 * L);
+    prof_t = prof_clock();
     // ---------------------------------------------------------- row descriptors
     {
       bool bad = false;
@@ -352,193 +427,313 @@ PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs,
       }
       mem_sync(PQ_SITE);
     }
+    // ------------------------------------------------------------ the read into LDS: 3 * q[j] at byte 4 + j (the bit offset of
+    // the symbol's field in the row's score word), q[-1] = N (column 0 has no match score), zeros behind the end
+    {
+      uint32_t* qw32 = (uint32_t*)qb;
+      for (int x = l; wave_any(act && 4 * x < L + 24 && 4 * x < qcap, PQ_SITE); x += GW) {
+        if (!(act && 4 * x < L + 24 && 4 * x < qcap)) continue;
+        uint32_t wv = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int idx = 4 * x + b - 4;
+          const uint32_t sym = idx == -1 ? 4u : (idx >= 0 && idx < L) ? (uint32_t)q[idx] : 0u;
+          wv |= (3u * (sym > 4u ? 4u : sym)) << (8 * b);
+        }
+        qw32[x] = wv;
+      }
+      lds_sync(PQ_SITE);
+    }
+    PQ_PROF(0);
     // ------------------------------------------------------------ forward (the sink is order[N-1])
     {
       int pb1 = 0, pl1 = 0, pr1 = 0, pb2 = 0, pl2 = 0, pr2 = 0, pb3 = 0, pl3 = 0, pr3 = 0;   // beg / mpl / mpr of rows r-1..r-3
-      uint64_t qwin = 0;
-      int qwin_jb = -(1 << 20);
-      uint32_t ri_next = act ? ((uint32_t)WS(a_dA) | (WS(a_keepf) ? 0x80u : 0u)) : 0u;
-      for (int r = 0; wave_any(act && r < N - 1, PQ_SITE); ++r) {
-        bool fw = act && r < N - 1;
-        const uint32_t ri = ri_next;
-        if (act && r + 1 < N - 1) ri_next = (uint32_t)WS(a_dA + r + 1) | (WS(a_keepf + r + 1) ? 0x80u : 0u);
+      int32_t pH[C], pE1[C], pE2[C];   // the row computed last, as it went into the ring
+#pragma unroll
+      for (int c = 0; c < C; ++c) { pH[c] = 0; pE1[c] = 0; pE2[c] = 0; }
+      uint64_t qcur = 0;               // read symbols q[j - 1] of the lane's columns, one byte each
+      uint32_t qpre = 0;               // the symbol the group's last lane takes in if the next row is a chain row
+      int failed = 0;                  // a row wider than the lanes (reported after the pass: the row loop has no per-group exits)
+      unsigned cells_read = 0;
+      // F(j) = max_{k<j} (H'(k) + k e) - o - j e: any origin of k and j does, so the lane's own column offsets (constants)
+      // stand in for the columns
+      int32_t LO1[C], LO2[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) { LO1[c] = (l * C + c) * (PQ_E1 * 16); LO2[c] = (l * C + c) * (PQ_E2 * 16); }
+      const int nrows = act ? N - 1 : 0;
+      const int maxN1 = wave_gmax<GW>(nrows, PQ_SITE);
+      // descriptors of GW rows at a time, one per lane of the group, waited for where they are loaded: the row loop itself
+      // issues no vector loads on its common path, so it never waits for its own direction-word stores (vmcnt counts loads
+      // and stores alike)
+      uint32_t ri_blk = 0;
+      int blk0 = 0;
+      if (act && l < N) ri_blk = (uint32_t)WS(a_dA + l) | (WS(a_keepf + l) ? 0x80u : 0u);
+      force_ready(ri_blk);
+      uint32_t ri = (uint32_t)GR::from((int)ri_blk, 0, PQ_SITE);
+      for (int r = 0; r < maxN1; ++r) {
+        const bool fw = r < nrows;
+        if (r + 1 - blk0 >= GW) {
+          blk0 = r + 1;
+          ri_blk = 0;
+          if (act && r + 1 + l < N) ri_blk = (uint32_t)WS(a_dA + r + 1 + l) | (WS(a_keepf + r + 1 + l) ? 0x80u : 0u);
+          force_ready(ri_blk);
+        }
+        const uint32_t ri_nx = (uint32_t)GR::from((int)ri_blk, r + 1 - blk0, PQ_SITE);   // (a permute whose latency the row hides)
         const int bv = (int)(ri & 7u), np = (int)((ri >> 3) & 15u);
         const bool keep = ((ri >> 7) & 1u) != 0;
-        uint32_t riB = 0;
-        if (wave_any(fw && np > 3, PQ_SITE)) { if (fw && np > 3) riB = (uint32_t)WS(a_dB + r); }
-        // ---- band: around the row maxima of the predecessors
-        int lo = 1 << 30, hi = -1;
-        for (int k = 0; wave_any(fw && k < np, PQ_SITE); ++k) {
-          const bool on = fw && k < np;
-          const int d = (int)((k < 3 ? ri >> (8 + 8 * k) : riB >> (8 * (k - 3))) & 255u);
-          int ml = d == 1 ? pl1 : d == 2 ? pl2 : pl3, mr = d == 1 ? pr1 : d == 2 ? pr2 : pr3;
-          if (wave_any(on && d >= PQ_RING, PQ_SITE)) {
-            if (on && d >= PQ_RING) { ml = WS(a_row_mpl + (r - d)); mr = WS(a_row_mpr + (r - d)); }
-          }
-          if (on) { lo = imin(lo, ml); hi = imax(hi, mr); }
-        }
-        int beg, end;
-        if (r == 0) { beg = 0; end = w < L ? w : L; }
-        else {
-          beg = lo + 1 - w; if (beg < 0) beg = 0;
-          end = hi + 1 + w; if (end > L) end = L;
-          if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
-        }
-        const int width = end - beg + 1;
-        PQ_FAIL(fw && width > WSR, 3);
-        fw = fw && alive; act = act && alive;
-        const int jb = beg + l * C;
-        // ---- read symbols q[j - 1] of the lane's columns: an 8-byte window that follows the band
-        uint64_t qcur;
-        {
-          const int dlt = jb - qwin_jb;
-          const bool okw = dlt >= 0 && dlt + C <= 8;
-          uint64_t qnew = 0;
-          if (fw) {
-            const int a = jb - 1;
-            const uint64_t x = load_u64(q + (a < 0 ? 0 : a));
-            qnew = a < 0 ? ((x << 8) | 4ull) : x;      // q[-1] = N: column 0 has no match score
-          }
-          if (wave_any(fw && !okw, PQ_SITE)) qcur = okw ? (qwin >> (8 * (dlt & 7))) : qnew;
-          else qcur = qwin >> (8 * (dlt & 7));
-          qwin = qnew; qwin_jb = jb;
-        }
-        // ---- M, E1, E2 over the predecessors
+        const int d0 = (int)((ri >> 8) & 255u), d1 = (int)((ri >> 16) & 255u);
+        // ---- chain rows (9 in 10): one predecessor, the previous row, whose band starts one column before this one's,
+        // nothing kept in HBM.  The previous row is still in the lane's registers.
+        int beg = imax(pl1 + 1 - w, 0), end = imin(pr1 + 1 + w, L);
+        if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
+        const bool chain = (ri & 0xFFF8u) == ((1u << 3) | (1u << 8)) && beg == pb1 + 1 && end - beg < WSR;
+        const bool general = r == 0 || wave_any(fw && !chain, PQ_SITE);
+        ++prof[4]; if (general) ++prof[5];
         int32_t m[C], e1[C], e2[C];
-        const int s_mat = bv < 4 ? PQ_MATCH * 16 : 0, s_mis = bv < 4 ? -PQ_MISMATCH * 16 : 0;
         int sc[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const int qc = (int)((qcur >> (8 * c)) & 0xffu);
-          sc[c] = qc >= 4 ? 0 : (qc == bv ? s_mat : s_mis);
-          m[c] = (r == 0 && jb + c == 0) ? (PQ_TGB + 15) : 0;
-          e1[c] = 0; e2[c] = 0;
-        }
-        for (int k = 0; wave_any(fw && k < np, PQ_SITE); ++k) {
-          const bool on = fw && k < np;
-          const int d = (int)((k < 3 ? ri >> (8 + 8 * k) : riB >> (8 * (k - 3))) & 255u);
-          const int ur = r - d;
-          const int pbeg = d == 1 ? pb1 : d == 2 ? pb2 : pb3;
-          const bool near = d < PQ_RING;
-          const int delta = beg - pbeg;
-          int32_t hv[C + 1], x1[C], x2[C];
-          if (wave_any(on && (!near || delta < 1 - GD || delta > GD), PQ_SITE)) {
-            // the general way (rare): far predecessors from their HBM copy, near ones with clamped ring indices
-            int fb = 0, fe = -1;
-            if (on && !near) { fb = WS(a_row_beg + ur); fe = WS(a_row_end + ur); }
-            const int rb = ring_g + (ur & (PQ_RING - 1)) * GE::ROW3;
-#pragma unroll
-            for (int t = 0; t <= C; ++t) {
-              const int jj = jb - 1 + t;
-              int32_t vh = 0, v1 = 0, v2 = 0;
-              if (on && near) {
-                int idx = jj - pbeg + GD;
-                idx = idx < 0 ? 0 : (idx > RW - 1 ? RW - 1 : idx);
-                vh = lds[rb + idx]; v1 = lds[rb + RW + idx]; v2 = lds[rb + 2 * RW + idx];
-              } else if (on && jj >= fb && jj <= fe) {
-                const uint32_t o = (uint32_t)ur * WSR + (uint32_t)(jj - fb);
-                vh = WS(a_gH + o); v1 = WS(a_gE1 + o); v2 = WS(a_gE2 + o);
-              }
-              hv[t] = vh;
-              if (t >= 1) { x1[t - 1] = v1; x2[t - 1] = v2; }
-            }
-          } else {
-            // ring row read unchecked: its cells outside the band and the guards hold "no path"
-            const int a0 = on ? ring_g + (ur & (PQ_RING - 1)) * GE::ROW3 + (jb - 1 - pbeg + GD) : GE::NULL_OFF;
-#pragma unroll
-            for (int t = 0; t <= C; ++t) hv[t] = lds[a0 + t];
-#pragma unroll
-            for (int c = 0; c < C; ++c) { x1[c] = lds[a0 + RW + 1 + c]; x2[c] = lds[a0 + 2 * RW + 1 + c]; }
+        // match + 1, mismatch - 2, N 0 (x 32) as signed 3-bit fields by read symbol: 110 110 110 110 with the base's own 001
+        const uint32_t tab = bv < 4 ? (0xDB6u ^ (7u << (3 * bv))) : 0u;
+        int jb;
+        if (!general) {
+          jb = beg + l * C;
+          // the lane's symbols move down one place; the new one is the next lane's first (the last lane's was fetched a row ago)
+          {
+            const uint32_t nx = (uint32_t)GR::shl1z((int)(uint32_t)qcur, PQ_SITE);
+            const uint32_t nb = (l == GW - 1 ? qpre : nx) & 0xffu;
+            qcur = (qcur >> 8) | ((uint64_t)nb << (8 * (C - 1)));
           }
+          const int32_t nH = GR::shl1z(pH[0], PQ_SITE), n1 = GR::shl1z(pE1[0], PQ_SITE), n2 = GR::shl1z(pE2[0], PQ_SITE);
 #pragma unroll
           for (int c = 0; c < C; ++c) {
-            const int32_t mk = hv[c] + sc[c] - k;                                   // tag 15 - k
-            const int32_t a1 = hv[c + 1] - ((PQ_O1 + PQ_E1) * 16 + k);              // tag 15 - k: opened from H of slot k
-            const int32_t b1 = x1[c] - (PQ_E1 * 16 + k);                            // tag 7 - k: extended from E1 of slot k
-            const int32_t a2 = hv[c + 1] - ((PQ_O2 + PQ_E2) * 16 + k);
-            const int32_t b2 = x2[c] - (PQ_E2 * 16 + k);                            // (E2 is stored with tag 6: 6 - k, see below)
-            if (k == 0) { m[c] = mk; e1[c] = imax(a1, b1); e2[c] = imax(a2, b2); }
-            else { m[c] = imax(m[c], mk); e1[c] = imax3(e1[c], a1, b1); e2[c] = imax3(e2[c], a2, b2); }
+            sc[c] = sbfe3(tab, (uint32_t)(qcur >> (8 * c)) & 0xffu) * 32;
+            const int32_t hB = c + 1 < C ? pH[c + 1] : nH, xa = c + 1 < C ? pE1[c + 1] : n1, xb = c + 1 < C ? pE2[c + 1] : n2;
+            m[c] = pH[c] + sc[c];
+            e1[c] = imax(hB - (PQ_O1 + PQ_E1) * 16, xa - PQ_E1 * 16);
+            e2[c] = imax(hB - (PQ_O2 + PQ_E2) * 16, xb - PQ_E2 * 16);
+          }
+        } else {
+          // ---- band around the row maxima of the predecessors: the first two slots from the registers of the last three rows
+          int lo = d0 == 1 ? pl1 : d0 == 2 ? pl2 : pl3, hi = d0 == 1 ? pr1 : d0 == 2 ? pr2 : pr3;
+          if (np == 2) { lo = imin(lo, d1 == 1 ? pl1 : d1 == 2 ? pl2 : pl3); hi = imax(hi, d1 == 1 ? pr1 : d1 == 2 ? pr2 : pr3); }
+          if (r == 0) { beg = 0; end = w < L ? w : L; }
+          else {
+            beg = lo + 1 - w; if (beg < 0) beg = 0;
+            end = hi + 1 + w; if (end > L) end = L;
+            if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
+          }
+          const int pbeg0 = d0 == 1 ? pb1 : d0 == 2 ? pb2 : pb3, pbeg1 = d1 == 1 ? pb1 : d1 == 2 ? pb2 : pb3;
+          // one or two predecessors inside the ring whose stored row (with its guards) covers every column this row reads,
+          // nothing to keep in HBM: read unchecked.  Anything else sends the whole wavefront's step the long way.
+          const bool rare = fw && (np > 2 || d0 >= PQ_RING || beg - pbeg0 < 1 - GD || beg - pbeg0 > GD || keep || end - beg + 1 > WSR ||
+                                   (np == 2 && (d1 >= PQ_RING || beg - pbeg1 < 1 - GD || beg - pbeg1 > GD)));
+          const bool any_rare = r == 0 || wave_any(rare, PQ_SITE);
+          uint32_t riB = 0;
+          if (any_rare && r > 0) {
+            if (wave_any(fw && np > 3, PQ_SITE)) { if (fw && np > 3) riB = (uint32_t)WS(a_dB + r); }
+            lo = 1 << 30; hi = -1;
+            for (int k = 0; wave_any(fw && k < np, PQ_SITE); ++k) {
+              const bool on = fw && k < np;
+              const int d = (int)((k < 3 ? ri >> (8 + 8 * k) : riB >> (8 * (k - 3))) & 255u);
+              int ml = d == 1 ? pl1 : d == 2 ? pl2 : pl3, mr = d == 1 ? pr1 : d == 2 ? pr2 : pr3;
+              if (wave_any(on && d >= PQ_RING, PQ_SITE)) {
+                if (on && d >= PQ_RING) { ml = WS(a_row_mpl + (r - d)); mr = WS(a_row_mpr + (r - d)); }
+              }
+              if (on) { lo = imin(lo, ml); hi = imax(hi, mr); }
+            }
+            if (fw) {
+              beg = lo + 1 - w; if (beg < 0) beg = 0;
+              end = hi + 1 + w; if (end > L) end = L;
+              if (end - beg + 1 > 2 * w + 129) end = beg + 2 * w + 128;
+            }
+            vm_drain();   // (see the end of the long way below)
+          }
+          if (fw && end - beg + 1 > WSR) failed = 1;
+          jb = beg + l * C;
+          // ---- read symbols q[j - 1] of the lane's columns (bytes 3 + jb .. of the group's copy in LDS)
+          {
+            const int a = 3 + jb;
+            const uint32_t* qw32 = (const uint32_t*)qb + (a >> 2);
+            const uint32_t w0 = qw32[0], w1 = qw32[1];
+            const int sh = 8 * (a & 3);
+            qcur = (((uint64_t)w1 << 32) | w0) >> sh;
+            if (C > 5) { const uint32_t w2 = qw32[2]; qcur |= sh ? ((uint64_t)w2 << (64 - sh)) : 0ull; }
+          }
+#pragma unroll
+          for (int c = 0; c < C; ++c) sc[c] = sbfe3(tab, (uint32_t)(qcur >> (8 * c)) & 0xffu) * 32;
+          if (!any_rare) {
+            {
+              const int a0 = fw ? ring_g + ((r - d0) & (PQ_RING - 1)) * GE::ROW3 + (jb - 1 - pbeg0 + GD) : GE::NULL_OFF;
+              int32_t hv[C + 1], x1[C], x2[C];
+#pragma unroll
+              for (int t = 0; t <= C; ++t) hv[t] = lds[a0 + t];
+#pragma unroll
+              for (int c = 0; c < C; ++c) { x1[c] = lds[a0 + RW + 1 + c]; x2[c] = lds[a0 + 2 * RW + 1 + c]; }
+#pragma unroll
+              for (int c = 0; c < C; ++c) {
+                m[c] = hv[c] + sc[c];
+                e1[c] = imax(hv[c + 1] - (PQ_O1 + PQ_E1) * 16, x1[c] - PQ_E1 * 16);
+                e2[c] = imax(hv[c + 1] - (PQ_O2 + PQ_E2) * 16, x2[c] - PQ_E2 * 16);
+              }
+            }
+            if (wave_any(fw && np == 2, PQ_SITE)) {
+              const int a1 = (fw && np == 2) ? ring_g + ((r - d1) & (PQ_RING - 1)) * GE::ROW3 + (jb - 1 - pbeg1 + GD) : GE::NULL_OFF;
+              int32_t hv[C + 1], x1[C], x2[C];
+#pragma unroll
+              for (int t = 0; t <= C; ++t) hv[t] = lds[a1 + t];
+#pragma unroll
+              for (int c = 0; c < C; ++c) { x1[c] = lds[a1 + RW + 1 + c]; x2[c] = lds[a1 + 2 * RW + 1 + c]; }
+#pragma unroll
+              for (int c = 0; c < C; ++c) {
+                m[c] = imax(m[c], hv[c] + sc[c] - 1);
+                e1[c] = imax3(e1[c], hv[c + 1] - ((PQ_O1 + PQ_E1) * 16 + 1), x1[c] - (PQ_E1 * 16 + 1));
+                e2[c] = imax3(e2[c], hv[c + 1] - ((PQ_O2 + PQ_E2) * 16 + 1), x2[c] - (PQ_E2 * 16 + 1));
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { m[c] = (r == 0 && jb + c == 0) ? (PQ_TGB + 15) : 0; e1[c] = 0; e2[c] = 0; }
+            for (int k = 0; wave_any(fw && k < np, PQ_SITE); ++k) {
+              const bool on = fw && k < np;
+              const int d = (int)((k < 3 ? ri >> (8 + 8 * k) : riB >> (8 * (k - 3))) & 255u);
+              const int ur = r - d;
+              const int pbeg = d == 1 ? pb1 : d == 2 ? pb2 : pb3;
+              const bool near = d < PQ_RING;
+              // far predecessors from their HBM copy, near ones with clamped ring indices
+              int fb = 0, fe = -1;
+              if (wave_any(on && !near, PQ_SITE)) {
+                mem_sync(PQ_SITE);   // (the copy was stored by this wavefront, some rows ago)
+                if (on && !near) { fb = WS(a_row_beg + ur); fe = WS(a_row_end + ur); }
+              }
+              const int rb = ring_g + (ur & (PQ_RING - 1)) * GE::ROW3;
+              int32_t hv[C + 1], x1[C], x2[C];
+#pragma unroll
+              for (int t = 0; t <= C; ++t) {
+                const int jj = jb - 1 + t;
+                int32_t vh = 0, v1 = 0, v2 = 0;
+                if (on && near) {
+                  int idx = jj - pbeg + GD;
+                  idx = idx < 0 ? 0 : (idx > RW - 1 ? RW - 1 : idx);
+                  vh = lds[rb + idx]; v1 = lds[rb + RW + idx]; v2 = lds[rb + 2 * RW + idx];
+                } else if (on && jj >= fb && jj <= fe) {
+                  const uint32_t o = (uint32_t)ur * WSR + (uint32_t)(jj - fb);
+                  vh = WS(a_gH + o); v1 = WS(a_gE1 + o); v2 = WS(a_gE2 + o);
+                }
+                hv[t] = vh;
+                if (t >= 1) { x1[t - 1] = v1; x2[t - 1] = v2; }
+              }
+#pragma unroll
+              for (int c = 0; c < C; ++c) {
+                const int32_t mk = hv[c] + sc[c] - k;                                   // tag 15 - k
+                const int32_t a1 = hv[c + 1] - ((PQ_O1 + PQ_E1) * 16 + k);              // tag 15 - k: opened from H of slot k
+                const int32_t b1 = x1[c] - (PQ_E1 * 16 + k);                            // tag 7 - k: extended from E1 of slot k
+                const int32_t a2 = hv[c + 1] - ((PQ_O2 + PQ_E2) * 16 + k);
+                const int32_t b2 = x2[c] - (PQ_E2 * 16 + k);                            // tag 7 - k (E2 is stored with tag 7 too)
+                if (k == 0) { m[c] = mk; e1[c] = imax(a1, b1); e2[c] = imax(a2, b2); }
+                else { m[c] = imax(m[c], mk); e1[c] = imax3(e1[c], a1, b1); e2[c] = imax3(e2[c], a2, b2); }
+              }
+            }
+            // (the loads of this path end here: a wait at their first use -- or at the next write of a register one of them
+            // was loaded into --, behind the join, would be a wait for the direction-word stores in every row)
+#pragma unroll
+            for (int c = 0; c < C; ++c) { force_ready_i(m[c]); force_ready_i(e1[c]); force_ready_i(e2[c]); }
+            vm_drain();
           }
         }
+        // the symbol the group's last lane needs if the next row is a chain row: q[jb + C - 1]
+        qpre = (uint32_t)qb[4 + jb + C - 1];
         // ---- H' = max(M, E1, E2); the lane-serial half of the F prefix maxima; the row maximum
-        int32_t hp[C], hq[C], t1[C], t2[C], p1[C], p2[C], e1c[C], e2c[C];
-        uint32_t dw[C];
-        bool valid[C];
+        // Tags: match through slot k 15 - k; E1 7; E2 6 as a candidate (stored with 7: its own sources are told apart like
+        // E1's); F1 5; F2 4.  The direction nibbles are the inverted tags.
+        int32_t hp[C], hq[C], t1[C], t2[C], p1[C], p2[C], e1s[C], e2s[C], nm[C];
         int32_t lmax = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const int j = jb + c;
-          valid[c] = fw && j <= end;
-          // the source nibbles of E1 / E2 are the inverted tags; as candidates for H' (and as stored values) they carry
-          // the tags of their state: E1 7, E2 6.  (E2 values are stored with tag 6, so "extended from slot k" arrives with
-          // tag 6 - k and "opened" with 15 - k: the nibble of an extension is 9 + k, put right below.)
-          const uint32_t n1 = ~(uint32_t)e1[c] & 15u;
-          uint32_t n2 = ~(uint32_t)e2[c] & 15u;
-          n2 = n2 >= 8u ? n2 - 1u : n2;
-          dw[c] = (n1 << 8) | (n2 << 12);
-          e1c[c] = (int32_t)(((uint32_t)e1[c] & ~15u) | 7u);
-          e2c[c] = (int32_t)(((uint32_t)e2[c] & ~15u) | 6u);
-          hp[c] = valid[c] ? imax3(m[c], e1c[c], e2c[c]) : 0;
+          nm[c] = ~((end - j) >> 31);     // all ones inside the band, 0 behind its end
+          e1s[c] = (int32_t)(((uint32_t)e1[c] & ~15u) | 7u);
+          e2s[c] = (int32_t)(((uint32_t)e2[c] & ~15u) | 7u);
+          hp[c] = imax3(m[c], e1s[c], e2s[c] - 1) & nm[c];
           hq[c] = hp[c] | 15;
-          t1[c] = hq[c] + j * (PQ_E1 * 16); t2[c] = hq[c] + j * (PQ_E2 * 16);
+          t1[c] = hq[c] + LO1[c]; t2[c] = hq[c] + LO2[c];
           p1[c] = c ? imax(p1[c - 1], t1[c]) : t1[c];
           p2[c] = c ? imax(p2[c - 1], t2[c]) : t2[c];
           lmax = c ? imax(lmax, hq[c]) : hq[c];
         }
         const int32_t s1 = GR::scan_max(p1[C - 1], PQ_SITE), s2 = GR::scan_max(p2[C - 1], PQ_SITE);
-        // (a group's first lane has nothing to its left: prefix maximum 0 = "no path", and a t that equals no x)
-        const int32_t X1 = GR::shr1(s1, 0, PQ_SITE), X2 = GR::shr1(s2, 0, PQ_SITE);
-        const int32_t t1_prev = GR::shr1(t1[C - 1], -1, PQ_SITE), t2_prev = GR::shr1(t2[C - 1], -1, PQ_SITE);
+        // (a group's first lane has nothing to its left: prefix maximum 0 = "no path"; its "opened here" bits come out set,
+        // and are never read: F is no path there)
+        const int32_t X1 = GR::shr1z(s1, PQ_SITE), X2 = GR::shr1z(s2, PQ_SITE);
+        const int32_t t1_prev = GR::shr1z(t1[C - 1], PQ_SITE), t2_prev = GR::shr1z(t2[C - 1], PQ_SITE);
         // the row maximum of H is the maximum of H', attained where H' attains it (F(j) < max H' -- poa_wave.hip)
         const int32_t wmx = GR::all_max(lmax, PQ_SITE);
-        int lc = 1 << 20, rc = -1;
+        int mpl, mpr;
+        if (GW == 64) {
+          // one group = the wavefront: first / last lane of each column's ballot, on the scalar unit
+          int lcl = C, rcl = -1;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          if (hq[c] == wmx) { lc = imin(lc, l * C + c); rc = l * C + c; }
+          for (int c = C - 1; c >= 0; --c) { if (hq[c] == wmx) { lcl = c; if (rcl < 0) rcl = c; } }
+          int fl, ll;
+          GR::first_last(rcl >= 0, fl, ll, PQ_SITE);   // (some lane holds the maximum)
+          mpl = beg + fl * C + GR::from(lcl, fl, PQ_SITE); mpr = beg + ll * C + GR::from(rcl, ll, PQ_SITE);
+        } else {
+          int lc = 1 << 20, rc = -1;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            if (hq[c] == wmx) { lc = imin(lc, l * C + c); rc = l * C + c; }
+          }
+          mpl = GR::all_min(lc, PQ_SITE) + beg; mpr = GR::all_max(rc, PQ_SITE) + beg;
         }
-        int mpl = GR::all_min(lc, PQ_SITE) + beg, mpr = GR::all_max(rc, PQ_SITE) + beg;
         if (wmx <= PQ_TGB / 2) { mpl = beg; mpr = end; }
         // ---- F, H, direction words, the row into the ring
         const int slot_off = ring_g + (r & (PQ_RING - 1)) * GE::ROW3 + GD + l * C;
         const uint32_t rowo = (uint32_t)r * WSR + (uint32_t)(l * C);
-        int32_t sH[C], sE1[C], sE2[C];
+        uint32_t dw[C];
+        int32_t hfull[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          const int j = jb + c;
           const int32_t x1 = c ? imax(X1, p1[c - 1]) : X1, x2 = c ? imax(X2, p2[c - 1]) : X2;
-          const int32_t f1 = x1 - (PQ_O1 * 16 + 10) - j * (PQ_E1 * 16);      // tag 15 -> 5
-          const int32_t f2 = x2 - (PQ_O2 * 16 + 11) - j * (PQ_E2 * 16);      // tag 15 -> 4
+          const int32_t f1 = x1 - (PQ_O1 * 16 + 10) - LO1[c];      // tag 15 -> 5
+          const int32_t f2 = x2 - (PQ_O2 * 16 + 11) - LO2[c];      // tag 15 -> 4
           const int32_t h = imax3(hp[c], f1, f2);
-          const uint32_t dH = ~(uint32_t)h & 15u;
-          uint32_t dHp = ~(uint32_t)hp[c] & 15u;
-          // (tags of H': 15 - k match, 7 E1, 6 E2 -> nibbles k, 8, 9.  Tags of H add 5 F1, 4 F2 -> 10, 11)
-          const uint32_t o1 = (c ? t1[c - 1] : t1_prev) == x1 ? 0x10000u : 0u;
-          const uint32_t o2 = (c ? t2[c - 1] : t2_prev) == x2 ? 0x20000u : 0u;
-          dw[c] |= dH | (dHp << 4) | o1 | o2;
-          sH[c] = valid[c] ? (h | 15) : 0; sE1[c] = valid[c] ? e1c[c] : 0; sE2[c] = valid[c] ? e2c[c] : 0;
-          if (valid[c] && j == L) WS(a_hl + r) = tg_down(h);
+          hfull[c] = h;
+          // the tags of H, H', E1, E2 (the winners' sources, inverted) in the low nibbles of the word's four bytes;
+          // bit 4 / 5: F1 / F2 opened from H'(v, j - 1)
+          const uint32_t o1 = (c ? t1[c - 1] : t1_prev) == x1 ? 0x10u : 0u;
+          const uint32_t o2 = (c ? t2[c - 1] : t2_prev) == x2 ? 0x20u : 0u;
+          dw[c] = (pack4((uint32_t)h, (uint32_t)hp[c], (uint32_t)e1[c], (uint32_t)e2[c]) & 0x0F0F0F0Fu) | o1 | o2;
+          pH[c] = (h | 15) & nm[c]; pE1[c] = e1s[c] & nm[c]; pE2[c] = e2s[c] & nm[c];
         }
         if (fw) {
+          int32_t* const dp = &WS(a_gdir + rowo);
+          int32_t* const rp = lds + slot_off;
 #pragma unroll
           for (int c = 0; c < C; ++c) {
-            WS(a_gdir + rowo + c) = (int32_t)dw[c];
-            lds[slot_off + c] = sH[c]; lds[slot_off + RW + c] = sE1[c]; lds[slot_off + 2 * RW + c] = sE2[c];
+            dp[c] = (int32_t)dw[c];
+            rp[c] = pH[c]; rp[RW + c] = pE1[c]; rp[2 * RW + c] = pE2[c];
           }
-          if (l == 0) { WS(a_row_beg + r) = beg; my_cells += (unsigned long long)width; }
+          if (end == L) {   // the row reaches the read's end: its last cell is a candidate for the sink
+#pragma unroll
+            for (int c = 0; c < C; ++c) if (jb + c == L) WS(a_hl + r) = tg_down(hfull[c]);
+          }
+          if (l == 0) { WS(a_row_beg + r) = beg; cells_read += (unsigned)(end - beg + 1); }
         }
-        if (wave_any(fw && keep, PQ_SITE)) {
+        if (general && wave_any(fw && keep, PQ_SITE)) {
           if (fw && keep) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) { WS(a_gH + rowo + c) = sH[c]; WS(a_gE1 + rowo + c) = sE1[c]; WS(a_gE2 + rowo + c) = sE2[c]; }
+            for (int c = 0; c < C; ++c) { WS(a_gH + rowo + c) = pH[c]; WS(a_gE1 + rowo + c) = pE1[c]; WS(a_gE2 + rowo + c) = pE2[c]; }
             if (l == 0) { WS(a_row_end + r) = end; WS(a_row_mpl + r) = mpl; WS(a_row_mpr + r) = mpr; }
           }
         }
         pb3 = pb2; pl3 = pl2; pr3 = pr2; pb2 = pb1; pl2 = pl1; pr2 = pr1; pb1 = beg; pl1 = mpl; pr1 = mpr;
+        ri = ri_nx;
         lds_sync(PQ_SITE);
       }
+      my_cells += cells_read;
+      PQ_FAIL(act && failed, 3);
+      act = act && alive;
     }
     mem_sync(PQ_SITE);   // direction words, row origins and end cells are in HBM
+    PQ_PROF(1);
     // --------------------------------------------------------- traceback
     int nops = -1;
     {
@@ -584,7 +779,7 @@ PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs,
         }
         const uint32_t wsel = d == 0 ? W0_ : d == 1 ? W1_ : d == 2 ? W2_ : W3_;
         // a run of plain diagonal steps -- a match through predecessor slot 0, which is the row above -- all at once
-        const bool diag = (wsel & 15u) == 0u && ((PA >> 8) & 255u) == 1u && r0 - l >= 1;
+        const bool diag = (wsel & 15u) == 15u && ((PA >> 8) & 255u) == 1u && r0 - l >= 1;
         const uint64_t gm = GR::bits(diag, PQ_SITE);
         const int kk = k & (GW - 1);
         int run = ctz64(~(gm >> kk));
@@ -597,18 +792,18 @@ PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs,
         } else if (walk) {
           int s = -1;   // predecessor slot to follow
           if (st == 0 || st == 5) {
-            const uint32_t dd = st == 0 ? (dwk & 15u) : ((dwk >> 4) & 15u);
+            const uint32_t dd = ~(st == 0 ? dwk : (dwk >> 8)) & 15u;
             if (dd < 8) {
               if (l == 0) { WS(a_op_node + nops) = tr; WS(a_op_q + nops) = tj - 1; }
               ++nops; --tj; st = 0; s = (int)dd;
             } else st = (int)dd - 7;   // 8 -> E1, 9 -> E2, 10 -> F1, 11 -> F2
           } else if (st == 1 || st == 2) {
-            const uint32_t dd = st == 1 ? ((dwk >> 8) & 15u) : ((dwk >> 12) & 15u);
+            const uint32_t dd = ~(st == 1 ? (dwk >> 16) : (dwk >> 24)) & 15u;
             if (l == 0) { WS(a_op_node + nops) = tr; WS(a_op_q + nops) = -1; }
             ++nops; s = (int)(dd & 7u);
             if (dd < 8) st = 0;
           } else {
-            const uint32_t open = st == 3 ? ((dwk >> 16) & 1u) : ((dwk >> 17) & 1u);
+            const uint32_t open = st == 3 ? ((dwk >> 4) & 1u) : ((dwk >> 5) & 1u);
             if (l == 0) { WS(a_op_node + nops) = -1; WS(a_op_q + nops) = tj - 1; }
             ++nops;
             if (open) st = 5;
@@ -618,6 +813,7 @@ PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs,
         }
       }
     }
+    PQ_PROF(2);
     PQ_FAIL(act && nops < 0, 4);
     PQ_FAIL(act && nops > 32000, 5);   // (path positions are packed into 15 bits of a scan key)
     act = act && alive;
@@ -751,7 +947,9 @@ PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs,
       N = n_new; ncols = ncols_new;
     }
     mem_sync(PQ_SITE);
+    PQ_PROF(3);
   }
+  prof_out(prof);
   // the heaviest-bundle consensus is poa_bundle_kernel's job: hand over the number of graph rows
   if (has && l == 0) {
     if (n <= 0) { cons_len[ti] = 0; status[ti] = 0; }
@@ -761,6 +959,7 @@ PQ_DEV void poaq_run(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs,
 #undef WS
 #undef PQ_FAIL
 #undef PQ_GLOOP
+#undef PQ_PROF
 }
 
 }  // namespace pq

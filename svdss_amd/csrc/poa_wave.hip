@@ -1206,10 +1206,14 @@ hipError_t poa_wave_launch(int cols, const PoaWaveTask* d_tasks, int n_tasks, si
   else if (cols == 5) e = launch_c<5>(d_tasks, n_tasks, lds_bytes, d_seqs, d_seq_off, ws32, ws8, d_len, d_status, d_cells, stream);
   else return hipErrorInvalidValue;
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)poa_bundle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bundle_lds_bytes);
+  return poa_bundle_launch(d_tasks, n_tasks, bundle_lds_bytes, ws32, ws8, d_len, (const int32_t*)d_status, stream);
+}
+
+hipError_t poa_bundle_launch(const PoaWaveTask* d_tasks, int n_tasks, size_t bundle_lds_bytes, int32_t* ws32, uint8_t* ws8, int32_t* d_len,
+                             const int32_t* d_status, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute((const void*)poa_bundle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bundle_lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(poa_bundle_kernel, dim3((unsigned)n_tasks), dim3(64), bundle_lds_bytes, stream, d_tasks, ws32, ws8, d_len,
-                     (const int32_t*)d_status);
+  hipLaunchKernelGGL(poa_bundle_kernel, dim3((unsigned)n_tasks), dim3(64), bundle_lds_bytes, stream, d_tasks, ws32, ws8, d_len, d_status);
   return hipGetLastError();
 }
 

@@ -17,20 +17,20 @@ namespace {
 
 struct Args {
   const PoaWaveTask* tasks; int n_tasks; const uint8_t* seqs; const int64_t* seq_off; int32_t* ws32; int32_t* cons_len;
-  int32_t* status; unsigned long long* cells; int gw, c;
+  int32_t* status; unsigned long long* cells; int gw, c, max_len;
 };
 
 template <int GW, int C>
 void body(void* p) {
   const Args* a = (const Args*)p;
   pq::poaq_run<GW, C>(a->tasks, a->n_tasks, a->seqs, a->seq_off, a->ws32, a->cons_len, a->status, a->cells,
-                      (int32_t*)wemu::lds_base(), wemu::block_id());
+                      (int32_t*)wemu::lds_base(), wemu::block_id(), pq::Geom<GW, C>::qcap(a->max_len));
 }
 
 template <int GW, int C>
 void run_blocks(Args& a) {
   const int G = 64 / GW;
-  for (int b = 0; b * G < a.n_tasks; ++b) wemu::run_block(b, sizeof(int32_t) * pq::Geom<GW, C>::LDS_INTS, &body<GW, C>, &a);
+  for (int b = 0; b * G < a.n_tasks; ++b) wemu::run_block(b, pq::Geom<GW, C>::lds_bytes(a.max_len), &body<GW, C>, &a);
 }
 
 int64_t ws_ints(int nc, int ec, int max_len, int ws) {
@@ -71,7 +71,9 @@ extern "C" int poaq_emu_consensus(const uint8_t* seqs_in, const int64_t* seq_off
   }
   std::vector<int32_t> ws((size_t)w32 + 64, 0x5A5A5A5A), len((size_t)n_clusters, -7), st((size_t)n_clusters, -1);
   *cells = 0;
-  Args a{tasks.data(), (int)tasks.size(), seqs.data(), seq_off, ws.data(), len.data(), st.data(), cells, gw, c};
+  int max_len = 0;
+  for (const PoaWaveTask& t : tasks) max_len = std::max(max_len, (int)t.max_len);
+  Args a{tasks.data(), (int)tasks.size(), seqs.data(), seq_off, ws.data(), len.data(), st.data(), cells, gw, c, max_len};
   if (n_clusters > 0) {
     if (gw == 16 && c == 3) run_blocks<16, 3>(a);
     else if (gw == 16 && c == 4) run_blocks<16, 4>(a);
