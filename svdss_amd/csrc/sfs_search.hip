@@ -171,11 +171,9 @@ static void sfs_report_op_counts() {
 
 // BS: the instantiation that can finish deep backward phases by binary search (sfs_core2.h).  It is the kernel for
 // references rich in repeats (svdss_index::deep_frac, estimated when the k-mer table is built); the plain one carries none
-// of that code (its branches cost the headline workload ~4 % when compiled in).  Only the one-lane-per-read launches use
-// it (large batches): the segmented instantiation with the BS code compiled in gave run-to-run different text when four
-// batches of eight segments per read ran concurrently -- even with the BS table switched off, i.e. without executing any
-// of it (tools/r04_bs_dbg2.py; one, two feeders or fewer segments: never) -- and is not instantiated until that is
-// understood; the segmented launches of every index use the plain kernel.
+// of that code (its branches cost the headline workload ~4 % when compiled in).  Both the one-lane-per-read and the
+// segmented launches have it since round 5 (round 4 left the segmented one out because its text differed from run to
+// run: a hardware hazard behind the inline-asm store of emit(), see there -- not the BS code, which never ran).
 template <class P, bool SEG, bool BS>
 #ifndef SV_SEARCH_OCC
 #define SV_SEARCH_OCC 4   // workgroups per CU the register budget is set for
@@ -205,8 +203,20 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
           // the first records of a segment are the ones its right neighbour peeks at (it synchronises on the first
           // SFS below the boundary): one 16-byte agent-scope (write-through) store, visible to lanes on other XCDs
           // (a torn or late view only lengthens the neighbour's overrun or sends the read to the exact fallback)
+          // The two wait states behind the store are part of it.  A vector-memory store of more than 8 bytes reads its
+          // data registers AFTER it has issued; a vector instruction that writes one of them has to keep two wait states
+          // (gfx940 and later; one before) behind it.  For its own instructions the compiler's hazard recogniser does
+          // that -- it cannot see inside this asm.  Round 4's "segmented kernel with the BS code compiled in gives
+          // run-to-run different text" was this: in that instantiation the register allocation puts `v_mov_b32 v3, 1`
+          // one instruction (an exec restore) behind the store of v[2:5], so the record's length went to memory as 1 or
+          // as itself depending on how long the memory pipeline took to fetch the data -- i.e. on load, hence four
+          // concurrent launches.  In the plain instantiation the next writers of v[2:5] happened to be far away.
           const sv_u32x4 v = {(uint32_t)qs, (uint32_t)l, ext_at_begin, p.epoch};
+#ifndef SV_NO_STORE_NOP   // (developer build `make hazard`: the store as round 4 had it, for tools/seg_stress.py to show the difference)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p.seg_rec + (base + idx)), "v"(v) : "memory");
+#else
           asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p.seg_rec + (base + idx)), "v"(v) : "memory");
+#endif
         } else if ((((base + idx) & 1) == 0)) {
           // the rest is only read after the launch (stitch / assemble).  A 16-byte record written on its own is one
           // 32-byte memory transaction (the line leaves L2 long before the lane's next record): records wait in LDS
@@ -891,7 +901,9 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       // SVDSS_EXTRA_LDS (developer knob): unused dynamic LDS per block, to study the kernel at lower occupancy
       const char* xl = getenv("SVDSS_EXTRA_LDS");
       const size_t extra_lds = xl ? (size_t)atol(xl) : 0;
-      if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true, false>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
+      if (wide && use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true, true>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
+      else if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true, false>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
+      else if (use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true, true>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
       else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true, false>), dim3(blocks_for(p.n_items)), dim3(256), extra_lds, stream, p);
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(b->ek1, stream));
@@ -942,7 +954,9 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
         q.sub_ids = q.read_ids;
         q.n_sub = (int64_t)n_fb;
         q.epoch = ++b->epoch;
-        if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        if (wide && use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true, true>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        else if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, true, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
+        else if (use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true, true>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
         else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, true, false>), dim3(blocks_for(q.n_items)), dim3(256), 0, stream, q);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(sfs_stitch_kernel, dim3((unsigned)((n_fb + 255) / 256)), dim3(256), 0, stream, q);
