@@ -303,6 +303,49 @@ typedef struct svdss_bam_selection {
   double stage_ms[8];
 } svdss_bam_selection_t;
 int svdss_bam_batch_selection(const svdss_bam_batch_t* b, svdss_bam_selection_t* out);
+/* `SVDSS smooth` on the same front end (csrc/bam_smooth.inc): BGZF blocks in, BGZF blocks out; the inflated records never
+ * leave the device.  Stands where smoother.cpp:349-571 stand (loader :498-571 with the filters of :509-537, smooth_read
+ * :84-232, rebuild_bam_entry :50-82, the writer :441-494).  A svdss_bam_smooth_t names the reference (svdss_ref_upload:
+ * upper-case ASCII), tid_map[t] = chromosome of BAM reference t in it or -1 (records on it are dropped, like every record
+ * that is unmapped, secondary, supplementary, below min_mapq or shorter than 2 bases).
+ * svdss_bam_smooth_measure: a batch like svdss_bam_batch_run; the kept records' matches / mismatches over their M
+ * operations and whether their CIGAR fits read and contig come down (compute_maxaccuracy, smoother.cpp:259-346).
+ * svdss_bam_smooth_run: every kept record rewritten (XF 0: smoothed -- equal to the reference except at indels longer than
+ * 20 and clips --, 1: mismatch rate above max_mismatch_rate, 2: nothing interesting, 3: CIGAR does not fit; 1-3 keep bases
+ * and CIGAR), in file order, as the bytes of a BAM stream cut into BGZF blocks of 0xff00 bytes wherever the batches end:
+ * batches take a second turn in file order at which the bytes behind a batch's last full block go to the next one
+ * (svdss_bam_stream_set_output_prefix: what precedes batch 0 -- the BAM header of the output).  The blocks of a batch
+ * (deflated by csrc/deflate.hip, CRC32 / ISIZE filled in) are in svdss_bam_smoothed_t::bgzf -- in host_out when it is
+ * given and large enough (page-locked memory of the caller's, svdss_host_alloc: the writer then needs no copy), else in
+ * memory of the batch object; the batch with is_last also holds the stream's short last block; the 28-byte EOF marker is
+ * the caller's. */
+typedef struct svdss_ref svdss_ref_t;
+typedef struct svdss_bam_smooth svdss_bam_smooth_t;
+int svdss_bam_smooth_create(const svdss_ref_t* ref, const int32_t* tid_map, int32_t n_ref, int32_t min_mapq,
+                            svdss_bam_smooth_t** out);
+void svdss_bam_smooth_free(svdss_bam_smooth_t* s);
+int svdss_bam_stream_set_output_prefix(svdss_bam_stream_t* s, const uint8_t* bytes, int64_t n);
+int svdss_bam_smooth_measure(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_smooth_t* sm,
+                             int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                             const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                             svdss_bam_batch_t** out);
+int svdss_bam_smooth_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_smooth_t* sm,
+                         double max_mismatch_rate, uint8_t* host_out, int64_t host_cap, int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                         const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                         svdss_bam_batch_t** out);
+typedef struct svdss_bam_smoothed {
+  int64_t n_records;              /* records of the batch */
+  int64_t n_kept;                 /* of them kept */
+  const int64_t* match_mismatch;  /* measure: 2 per kept record */
+  const uint8_t* fits;            /* measure: 1 per kept record */
+  int64_t out_bytes;              /* run: bytes of the batch's records in the output stream */
+  const uint8_t* bgzf;            /* run: the batch's BGZF members, back to back (host memory of the batch object) */
+  int64_t bgzf_bytes;
+  int64_t n_xf[4];                /* run: records by XF value */
+  double inflate_kernel_ms;
+  double stage_ms[8];             /* 0-2 as svdss_bam_result_t, 3 filters + CIGAR walk, 4 sizes + records, 5 the output turn, 6 deflate + down */
+} svdss_bam_smoothed_t;
+int svdss_bam_batch_smoothed(const svdss_bam_batch_t* b, svdss_bam_smoothed_t* out);
 const char* svdss_bam_batch_error(const svdss_bam_batch_t* b);
 void svdss_bam_batch_free(svdss_bam_batch_t* b);
 

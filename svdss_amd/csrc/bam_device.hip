@@ -47,6 +47,8 @@
 #include "hip_check.h"
 #include "index_host.h"
 #include "inflate_dev.h"
+#include "deflate_dev.h"
+#include "ref_dev.h"
 
 namespace {
 
@@ -118,7 +120,9 @@ __global__ void __launch_bounds__(64) crc32_kernel(const uint8_t* __restrict__ d
   if (J > 0) {
     uint32_t a = 0;
     for (int j = 0; j < J; ++j) {
-      uint32_t w = ld32(p, (int64_t)(j * 64 + lane) * 4);
+      // (the block's first byte is wherever the blocks before it end: the aligned-words-and-shift of ld32 on the offset
+      // from the buffer's -- aligned -- start, not on a pointer that is not)
+      uint32_t w = ld32(data, b.uoff + (int64_t)(j * 64 + lane) * 4);
       if (j == 0 && lane == 0) w ^= 0xFFFFFFFFu;
       a = T[1][a & 0xff] ^ T[2][(a >> 8) & 0xff] ^ T[3][(a >> 16) & 0xff] ^ T[4][a >> 24] ^ w;
     }
@@ -585,6 +589,10 @@ struct svdss_bam_stream {
   std::string err;
   std::vector<uint8_t> carry;      // the bytes behind the last complete record of the batch that had its turn last
   int64_t n_rewalked = 0, n_segments = 0;
+  // smoothing (bam_smooth.inc): the output stream's turn, and the bytes behind its last full BGZF block (at first: the
+  // BAM header of the output)
+  int64_t next_out = 0;
+  std::vector<uint8_t> out_tail;
 };
 
 struct svdss_bam_filter {
@@ -608,6 +616,12 @@ struct svdss_bam_batch {
   std::vector<int64_t> h_sel_off;
   int64_t n_selected = 0, sel_bytes = 0;
   std::vector<int32_t> h_status;
+  // svdss_bam_smooth_run / _measure (bam_smooth.inc)
+  DevBuf sm_rec, sm_out, sm_scratch, sm_members, sm_dense, sm_len;
+  int64_t sm_kept = 0, sm_out_bytes = 0, sm_bgzf_bytes = 0, sm_in0 = 0, sm_xf[4] = {0, 0, 0, 0};
+  const uint8_t* sm_bgzf = nullptr;   // where the last run's BGZF members are (the caller's buffer or h_sel)
+  std::vector<int64_t> sm_nmx;
+  std::vector<uint8_t> sm_fits;
   svdss_sfs_batch_t* sfs = nullptr;
   // results of the last run (host side)
   std::vector<int32_t> name_off, hp, sidx, qs, len;
@@ -665,7 +679,7 @@ extern "C" void svdss_bam_batch_free(svdss_bam_batch_t* b) {
     if (d->p) (void)hipFree(d->p);
   if (b->h_pin) (void)hipHostFree(b->h_pin);
   if (b->h_sel) (void)hipHostFree(b->h_sel);
-  for (DevBuf* d : {&b->sel_out, &b->sel_off})
+  for (DevBuf* d : {&b->sel_out, &b->sel_off, &b->sm_rec, &b->sm_out, &b->sm_scratch, &b->sm_members, &b->sm_dense, &b->sm_len})
     if (d->p) (void)hipFree(d->p);
   if (b->sfs) svdss_sfs_batch_free(b->sfs);
   if (b->e0) (void)hipEventDestroy(b->e0);
@@ -1183,6 +1197,8 @@ extern "C" int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_resu
 }
 
 extern "C" const char* svdss_bam_batch_error(const svdss_bam_batch_t* b) { return b ? b->err.c_str() : ""; }
+
+#include "bam_smooth.inc"
 
 #undef BCHK
 #undef RCHK

@@ -4,6 +4,7 @@
 // output; the caller sees plain record bytes.
 #pragma once
 #include <condition_variable>
+#include <functional>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -102,9 +103,16 @@ inline bool bam_header_probe(const std::string& path, int32_t& n_ref, int64_t& s
 
 // the kept records of one device batch, in file order: record k = bytes[off[k] + 4 ..), block_size at bytes[off[k]]
 struct SelectedBatch {
-  std::vector<uint8_t> bytes;
+  std::vector<uint8_t> bytes;   // (smoothing: the batch's BGZF members)
   std::vector<int64_t> off;
   uint64_t n_records = 0;       // records of the batch, kept or not
+  // smoothing (svdss_bam_smooth_run / _measure): kept records, by XF value; matches / mismatches and "CIGAR fits" per kept record
+  uint64_t n_kept = 0, n_xf[4] = {0, 0, 0, 0};
+  std::vector<int64_t> match_mismatch;
+  std::vector<uint8_t> fits;
+  const uint8_t* ext = nullptr;   // smoothing: the BGZF members in a page-locked buffer of the caller's pool (ext_n bytes) ...
+  size_t ext_n = 0;
+  int ext_slot = -1;              // ... and which one, for its return
   double stage_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, inflate_kernel_s = 0;
 };
 
@@ -135,10 +143,18 @@ inline bool view_of_record(const uint8_t* rec, size_t avail, BamReader::RawView&
 
 class DeviceBamSelect {
  public:
+  // what a feeding thread does with a batch (default: svdss_bam_select_run with the device's filter) and how its result
+  // becomes a SelectedBatch -- `SVDSS smooth` runs svdss_bam_smooth_run / _measure through the same scanner, batcher,
+  // feeders and ordered hand-over
+  typedef std::function<int(svdss_bam_stream_t*, int64_t seq, int32_t is_last, int64_t skip, size_t dev, int32_t n_chunks, const uint8_t* const* comp,
+                            const int64_t* comp_bytes, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                            svdss_bam_batch_t** batch)> RunFn;
+  typedef std::function<void(const svdss_bam_batch_t*, SelectedBatch&)> CollectFn;
   // filters[d]: the filter on device d (one per GPU used); feeders: feeding threads per GPU
   DeviceBamSelect(const std::string& path, const std::vector<svdss_bam_filter_t*>& filters, const std::vector<int>& devices, int32_t n_ref,
-                  int64_t skip, int feeders, int64_t batch_bytes)
-      : filters_(filters), devices_(devices), skip_(skip), target_(batch_bytes) {
+                  int64_t skip, int feeders, int64_t batch_bytes, RunFn run = RunFn(), CollectFn collect = CollectFn(),
+                  svdss_bam_stream_t* prepared_stream = nullptr)
+      : filters_(filters), devices_(devices), skip_(skip), target_(batch_bytes), run_(run), collect_(collect), stream_(prepared_stream) {
     BgzfScanner::Hooks hooks;
     hooks.host_alloc = svdss_host_alloc;
     hooks.host_free = svdss_host_free;
@@ -147,7 +163,7 @@ class DeviceBamSelect {
     feeders = std::max(1, feeders);
     sc_.reset(new BgzfScanner(path, hooks, slab, 8, 8 + ((size_t)filters.size() * (size_t)feeders + 3) * per_batch));
     if (!sc_->ok()) { err_ = "cannot open file"; finished_ = true; return; }
-    if (svdss_bam_stream_create(n_ref, &stream_) != SVDSS_OK) { err_ = "out of memory"; finished_ = true; return; }
+    if (!stream_ && svdss_bam_stream_create(n_ref, &stream_) != SVDSS_OK) { err_ = "out of memory"; finished_ = true; return; }
     n_feeders_ = filters_.size() * (size_t)feeders;
     batcher_ = std::thread([this] { batch_loop(); });
     for (size_t d = 0; d < filters_.size(); ++d)
@@ -239,8 +255,10 @@ class DeviceBamSelect {
         comp.push_back(c->data); comp_bytes.push_back((int64_t)c->n_bytes); n_blocks.push_back((int64_t)c->blocks.size());
         blocks.push_back(c->blocks.data()); crcs.push_back(c->crc.data());
       }
-      const int rc = svdss_bam_select_run(stream_, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? skip_ : 0, filters_[d], (int32_t)comp.size(),
-                                          comp.data(), comp_bytes.data(), blocks.data(), crcs.data(), n_blocks.data(), &batch);
+      const int rc = run_ ? run_(stream_, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? skip_ : 0, d, (int32_t)comp.size(), comp.data(),
+                                 comp_bytes.data(), blocks.data(), crcs.data(), n_blocks.data(), &batch)
+                          : svdss_bam_select_run(stream_, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? skip_ : 0, filters_[d], (int32_t)comp.size(),
+                                                 comp.data(), comp_bytes.data(), blocks.data(), crcs.data(), n_blocks.data(), &batch);
       for (std::unique_ptr<CompChunk>& c : job->chunks) sc_->recycle(std::move(c));
       if (rc != SVDSS_OK) {
         std::string msg = batch ? svdss_bam_batch_error(batch) : "";
@@ -249,14 +267,17 @@ class DeviceBamSelect {
         fail(msg);
         break;
       }
-      svdss_bam_selection_t r;
-      (void)svdss_bam_batch_selection(batch, &r);
       std::unique_ptr<SelectedBatch> out(new SelectedBatch);
-      out->n_records = (uint64_t)r.n_records;
-      out->off.assign(r.rec_off, r.rec_off + r.n_selected + 1);
-      out->bytes.assign(r.bytes, r.bytes + r.n_bytes);
-      for (int k = 0; k < 8; ++k) out->stage_s[k] = r.stage_ms[k] * 1e-3;
-      out->inflate_kernel_s = r.inflate_kernel_ms * 1e-3;
+      if (collect_) collect_(batch, *out);
+      else {
+        svdss_bam_selection_t r;
+        (void)svdss_bam_batch_selection(batch, &r);
+        out->n_records = (uint64_t)r.n_records;
+        out->off.assign(r.rec_off, r.rec_off + r.n_selected + 1);
+        out->bytes.assign(r.bytes, r.bytes + r.n_bytes);
+        for (int k = 0; k < 8; ++k) out->stage_s[k] = r.stage_ms[k] * 1e-3;
+        out->inflate_kernel_s = r.inflate_kernel_ms * 1e-3;
+      }
       {
         std::unique_lock<std::mutex> lk(m_);
         const uint64_t sq = job->seq;
@@ -276,6 +297,8 @@ class DeviceBamSelect {
   std::vector<svdss_bam_filter_t*> filters_;
   std::vector<int> devices_;
   int64_t skip_ = 0, target_ = 0;
+  RunFn run_;
+  CollectFn collect_;
   std::unique_ptr<BgzfScanner> sc_;
   svdss_bam_stream_t* stream_ = nullptr;
   std::thread batcher_;

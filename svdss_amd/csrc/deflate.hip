@@ -33,6 +33,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "hip_check.h"
+#include "deflate_dev.h"
 
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 
@@ -301,6 +302,23 @@ __global__ void __launch_bounds__(256) deflate_compact_kernel(const uint8_t* str
 }
 
 }  // namespace
+
+int64_t svdss_deflate_stride(int32_t block_bytes) { return ((int64_t)block_bytes + 26 + 6 * SUBS + 4 + 63) & ~(int64_t)63; }
+
+hipError_t svdss_deflate_enqueue(hipStream_t st, const uint8_t* d_in, int64_t in_bytes, int32_t block_bytes, uint8_t* d_out,
+                                 int64_t stride, int32_t* d_len) {
+  if (in_bytes <= 0 || block_bytes <= 0 || block_bytes > MAX_IN || stride < svdss_deflate_stride(block_bytes)) return hipErrorInvalidValue;
+  const int64_t nb = (in_bytes + block_bytes - 1) / block_bytes;
+  hipLaunchKernelGGL(bgzf_deflate_kernel, dim3((unsigned)nb), dim3(64), 0, st, d_in, in_bytes, block_bytes, d_out, stride, d_len);
+  return hipGetLastError();
+}
+
+hipError_t svdss_deflate_compact_enqueue(hipStream_t st, const uint8_t* d_strided, int64_t stride, const int32_t* d_len, int64_t nb,
+                                         int64_t* d_off, uint8_t* d_dense) {
+  hipLaunchKernelGGL(deflate_offsets_kernel, dim3(1), dim3(64), 0, st, d_len, nb, d_off);
+  hipLaunchKernelGGL(deflate_compact_kernel, dim3((unsigned)nb), dim3(256), 0, st, d_strided, stride, d_len, (const int64_t*)d_off, d_dense);
+  return hipGetLastError();
+}
 
 struct svdss_deflate {
   int device = -1;

@@ -22,6 +22,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "dev_arena.h"
+#include "ref_dev.h"
 
 extern thread_local std::string g_svdss_hip_err;
 
@@ -233,6 +234,12 @@ struct svdss_ref {
   DevArena arena;                // per-call buffers, reused
   hipStream_t stream = nullptr;
 };
+
+SvdssRefView svdss_ref_view(const svdss_ref_t* ref) {
+  SvdssRefView v;
+  if (ref) { v.device = ref->device; v.d_seq = (const uint8_t*)ref->d_ref; v.d_off = (const int64_t*)ref->d_off; v.n_chrom = ref->n_chrom; }
+  return v;
+}
 
 extern "C" int svdss_ref_upload(const uint8_t* seqs, const int64_t* off, int32_t n_chrom, int32_t device, svdss_ref_t** out) {
   if (!out || n_chrom < 0 || device < 0 || (n_chrom > 0 && (!seqs || !off))) return SVDSS_EINVAL;

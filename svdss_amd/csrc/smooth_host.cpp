@@ -15,6 +15,7 @@
 #include <chrono>
 #include <string>
 
+#include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
 #include <unordered_map>
@@ -22,6 +23,7 @@
 
 #include "../../include/svdss_hip.h"
 #include "bam_reader.h"
+#include "bam_device_select.h"
 #include "gpu_deflate_hook.h"
 #include "gpu_inflate_hook.h"
 #include "bam_writer.h"
@@ -193,6 +195,254 @@ int main_smooth(const CallOptions& o) {
   auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
   const bool dbg = getenv("SVDSS_DEBUG") != nullptr;
   double t_read = 0, t_proc = 0, t_write = 0;
+  // ---- the device path (csrc/bam_smooth.inc): compressed blocks up, compressed blocks down; the records are filtered,
+  // measured, smoothed, rebuilt and deflated in HBM.  SVDSS_BAM_DEVICE=0 (or SVDSS_SMOOTH_HOST=1): the host pipeline below,
+  // which writes the same bytes.
+  // (SVDSS_GPU_DEFLATE=0 asks for the host's deflate: that is the host pipeline's writer)
+  if (!getenv("SVDSS_SMOOTH_HOST") && svdss_device_count() > 0 && !(getenv("SVDSS_BAM_DEVICE") && atoi(getenv("SVDSS_BAM_DEVICE")) == 0) &&
+      !(getenv("SVDSS_GPU_DEFLATE") && atoi(getenv("SVDSS_GPU_DEFLATE")) == 0)) {
+    std::string header_text;
+    std::vector<std::string> names;
+    std::vector<int32_t> lens;
+    {
+      BamReader hb(o.bam);
+      if (!hb.ok() || !hb.read_header()) die("cannot read " + o.bam + ": " + hb.error());
+      header_text = hb.header_text(); names = hb.ref_names(); lens = hb.ref_lens();
+    }
+    int32_t n_ref = 0;
+    int64_t skip = 0;
+    std::string perr;
+    if (!bam_header_probe(o.bam, n_ref, skip, perr, nullptr)) die("cannot read " + o.bam + ": " + perr);
+    if ((size_t)n_ref != names.size()) die("cannot read " + o.bam + ": inconsistent header");
+    const int64_t target = (getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 64) << 20;
+    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
+    const std::vector<svdss_bam_filter_t*> one(1, nullptr);
+    const std::vector<int> dev0(1, 0);
+    svdss_bam_smooth_t* sm = nullptr;
+    double al_accuracy = 0.0;
+    // The reader of the smoothing pass starts FIRST: its loaders page-lock their slabs and read ahead while the reference
+    // goes up and the accuracy pass runs; its feeding threads wait at this gate for the threshold.
+    struct Gate { std::mutex m; std::condition_variable cv; bool open = false; } gate;
+    // the output's header goes in front of the first batch's records
+    svdss_bam_stream_t* stream = nullptr;
+    if (svdss_bam_stream_create(n_ref, &stream) != SVDSS_OK) die("out of memory");
+    {
+      struct Sink { std::vector<uint8_t> v; void write(const void* p, size_t n) { v.insert(v.end(), (const uint8_t*)p, (const uint8_t*)p + n); } } hs;
+      hs.write("BAM\1", 4);
+      const int32_t lt = (int32_t)header_text.size(), nr = (int32_t)names.size();
+      hs.write(&lt, 4);
+      hs.write(header_text.data(), header_text.size());
+      hs.write(&nr, 4);
+      for (size_t i = 0; i < names.size(); ++i) {
+        const int32_t ln = (int32_t)names[i].size() + 1;
+        hs.write(&ln, 4);
+        hs.write(names[i].c_str(), (size_t)ln);
+        hs.write(&lens[i], 4);
+      }
+      if (svdss_bam_stream_set_output_prefix(stream, hs.v.data(), (int64_t)hs.v.size()) != SVDSS_OK) die("out of memory");
+    }
+    // The BGZF members of a batch come down into a page-locked buffer of this pool and are written from it: no copy on
+    // the way.  When stdout is a regular file the batches are written side by side (pwrite at the offsets the ordered
+    // hand-over gives them: one thread copying into the page cache is slower than the GPU side); a pipe gets them in order.
+    struct Pool {
+      std::mutex m; std::condition_variable cv;
+      std::vector<uint8_t*> buf; std::vector<int> free_;
+      size_t cap = 0;
+      int max_n = 0, n_made = 0;
+      bool broken = false;
+      // a free buffer; while fewer than max_n exist a new one is made instead of waiting (by the feeding thread that needs
+      // it: page-locking a tenth of a gigabyte takes tens of milliseconds, and the feeders start one after the other)
+      int take() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          if (!free_.empty()) { const int k = free_.back(); free_.pop_back(); return k; }
+          if (broken) return -1;
+          if (n_made < max_n) {
+            const int k = n_made++;
+            lk.unlock();
+            void* q = nullptr;
+            const bool ok = svdss_host_alloc((int64_t)cap, &q) == SVDSS_OK && q;
+            lk.lock();
+            if (!ok) { broken = true; cv.notify_all(); return -1; }
+            buf[(size_t)k] = (uint8_t*)q;
+            return k;
+          }
+          cv.wait(lk);
+        }
+      }
+      void give(int k) { { std::lock_guard<std::mutex> lk(m); free_.push_back(k); } cv.notify_all(); }
+    } pool;
+    pool.cap = (size_t)target + (size_t)target / 8 + ((size_t)32 << 20);   // (literals-only members: at most ~1.001 x the records, which grow by 4 bytes each)
+    pool.max_n = per_gpu + 6;
+    pool.buf.assign((size_t)pool.max_n, nullptr);
+    static thread_local int tl_slot = -1;
+    DeviceBamSelect::RunFn run = [&](svdss_bam_stream_t* st, int64_t seq, int32_t last, int64_t sk, size_t, int32_t nc, const uint8_t* const* comp,
+                                    const int64_t* cb, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* nb,
+                                    svdss_bam_batch_t** batch) {
+      { std::unique_lock<std::mutex> lk(gate.m); gate.cv.wait(lk, [&] { return gate.open; }); }
+      tl_slot = pool.take();
+      const int rc = svdss_bam_smooth_run(st, seq, last, sk, sm, al_accuracy, tl_slot >= 0 ? pool.buf[(size_t)tl_slot] : nullptr,
+                                          tl_slot >= 0 ? (int64_t)pool.cap : 0, nc, comp, cb, blocks, crc, nb, batch);
+      if (rc != SVDSS_OK && tl_slot >= 0) { pool.give(tl_slot); tl_slot = -1; }
+      return rc;
+    };
+    DeviceBamSelect::CollectFn collect = [&](const svdss_bam_batch_t* b, SelectedBatch& out) {
+      svdss_bam_smoothed_t r;
+      (void)svdss_bam_batch_smoothed(b, &r);
+      out.n_records = (uint64_t)r.n_records; out.n_kept = (uint64_t)r.n_kept;
+      for (int k = 0; k < 4; ++k) out.n_xf[k] = (uint64_t)r.n_xf[k];
+      if (tl_slot >= 0 && r.bgzf == pool.buf[(size_t)tl_slot]) { out.ext = r.bgzf; out.ext_n = (size_t)r.bgzf_bytes; out.ext_slot = tl_slot; }
+      else {
+        out.bytes.assign(r.bgzf, r.bgzf + r.bgzf_bytes);
+        if (tl_slot >= 0) pool.give(tl_slot);
+      }
+      tl_slot = -1;
+      for (int k = 0; k < 8; ++k) out.stage_s[k] = r.stage_ms[k] * 1e-3;
+      out.inflate_kernel_s = r.inflate_kernel_ms * 1e-3;
+    };
+    std::unique_ptr<DeviceBamSelect> rd(new DeviceBamSelect(o.bam, one, dev0, n_ref, skip, per_gpu, target, run, collect, stream));
+    // the chromosomes the BAM names, in its order, one device buffer (svdss_ref_upload_parts: no concatenation on the host)
+    std::vector<int32_t> tid_map(names.size(), -1);
+    std::vector<const uint8_t*> parts;
+    std::vector<int64_t> plen;
+    for (size_t t = 0; t < names.size(); ++t) {
+      auto it = chrom.find(names[t]);
+      if (it == chrom.end()) continue;
+      tid_map[t] = (int32_t)parts.size();
+      parts.push_back((const uint8_t*)it->second.data());
+      plen.push_back((int64_t)it->second.size());
+    }
+    svdss_ref_t* dref = nullptr;
+    if (svdss_ref_upload_parts(parts.data(), plen.data(), (int32_t)parts.size(), 0, &dref) != SVDSS_OK)
+      die(std::string("svdss_ref_upload_parts: ") + svdss_last_hip_error());
+    if (svdss_bam_smooth_create(dref, tid_map.data(), (int32_t)tid_map.size(), (int32_t)o.min_mapq, &sm) != SVDSS_OK)
+      die(std::string("svdss_bam_smooth_create: ") + svdss_last_hip_error());
+    if (dbg) fprintf(stderr, "[smooth] reference on the device at +%.3f s\n", since());
+    // compute_maxaccuracy (smoother.cpp:259-346): the mismatch rates of the first 10,000 records that fit, their percentile
+    {
+      std::vector<double> acc;
+      DeviceBamSelect::RunFn mrun = [&](svdss_bam_stream_t* st, int64_t seq, int32_t last, int64_t sk, size_t, int32_t nc, const uint8_t* const* comp,
+                                       const int64_t* cb, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* nb,
+                                       svdss_bam_batch_t** batch) {
+        return svdss_bam_smooth_measure(st, seq, last, sk, sm, nc, comp, cb, blocks, crc, nb, batch);
+      };
+      DeviceBamSelect::CollectFn mcollect = [](const svdss_bam_batch_t* b, SelectedBatch& out) {
+        svdss_bam_smoothed_t r;
+        (void)svdss_bam_batch_smoothed(b, &r);
+        out.n_records = (uint64_t)r.n_records; out.n_kept = (uint64_t)r.n_kept;
+        out.match_mismatch.assign(r.match_mismatch, r.match_mismatch + 2 * r.n_kept);
+        out.fits.assign(r.fits, r.fits + r.n_kept);
+      };
+      // (10,000 records are a few tens of megabytes: small batches, two feeders, and the reader is dropped as soon as it has them)
+      DeviceBamSelect pre(o.bam, one, dev0, n_ref, skip, 2, std::min<int64_t>(target, (int64_t)48 << 20), mrun, mcollect);
+      while (acc.size() < 10000) {
+        std::unique_ptr<SelectedBatch> b = pre.next();
+        if (!b) { if (!pre.error().empty()) die("error reading " + o.bam + ": " + pre.error()); break; }
+        for (size_t k = 0; k < b->fits.size() && acc.size() < 10000; ++k) {
+          if (!b->fits[k]) continue;
+          acc.push_back((double)b->match_mismatch[2 * k + 1] / (double)b->match_mismatch[2 * k]);
+        }
+      }
+      if (!acc.empty()) {
+        std::sort(acc.begin(), acc.end());
+        const double id = (double)(acc.size() - 1) * (double)o.accp;   // percentile(), smoother.cpp:246-255
+        const double lo = floor(id), hi = ceil(id), h = id - lo;
+        al_accuracy = (1.0 - h) * acc[(size_t)lo] + h * acc[(size_t)hi];
+      }
+    }
+    if (dbg) fprintf(stderr, "[smooth] accuracy threshold %.6g at +%.3f s\n", al_accuracy, since());
+    { std::lock_guard<std::mutex> lk(gate.m); gate.open = true; }
+    gate.cv.notify_all();
+    uint64_t n_rec = 0, n_kept = 0, n_xf[4] = {0, 0, 0, 0}, out_bytes = 0;
+    bool write_ok = true;
+    {
+      // side-by-side writers for a regular file
+      fflush(stdout);
+      const off_t pos0 = lseek(STDOUT_FILENO, 0, SEEK_CUR);
+      struct stat sb;
+      const bool seekable = pos0 >= 0 && fstat(STDOUT_FILENO, &sb) == 0 && S_ISREG(sb.st_mode) && !getenv("SVDSS_SMOOTH_SERIAL_WRITE");
+      struct WJob { std::unique_ptr<SelectedBatch> b; off_t at; };
+      std::mutex wm; std::condition_variable wcv;
+      std::deque<WJob> wq;
+      bool wclosed = false;
+      std::vector<std::thread> writers;
+      auto put = [&](const uint8_t* p, size_t n, off_t at) {
+        while (n) {
+          const ssize_t w = pwrite(STDOUT_FILENO, p, n, at);
+          if (w <= 0) { write_ok = false; return; }
+          p += w; n -= (size_t)w; at += w;
+        }
+      };
+      if (seekable)
+        for (int t = 0; t < (getenv("SVDSS_SMOOTH_WRITERS") ? std::max(1, atoi(getenv("SVDSS_SMOOTH_WRITERS"))) : 4); ++t)
+          writers.emplace_back([&] {
+            for (;;) {
+              WJob j;
+              {
+                std::unique_lock<std::mutex> lk(wm);
+                wcv.wait(lk, [&] { return !wq.empty() || wclosed; });
+                if (wq.empty()) return;
+                j = std::move(wq.front());
+                wq.pop_front();
+              }
+              wcv.notify_all();
+              if (j.b->ext) { put(j.b->ext, j.b->ext_n, j.at); pool.give(j.b->ext_slot); }
+              else put(j.b->bytes.data(), j.b->bytes.size(), j.at);
+            }
+          });
+      if (dbg) fprintf(stderr, "[smooth] streaming from +%.3f s\n", since());
+      double st_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, inf_s = 0;
+      off_t at = pos0 < 0 ? 0 : pos0;
+      while (std::unique_ptr<SelectedBatch> b = rd->next()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t nb = b->ext ? b->ext_n : b->bytes.size();
+        n_rec += b->n_records; n_kept += b->n_kept; out_bytes += nb;
+        for (int k = 0; k < 4; ++k) n_xf[k] += b->n_xf[k];
+        for (int k = 0; k < 8; ++k) st_s[k] += b->stage_s[k];
+        inf_s += b->inflate_kernel_s;
+        if (seekable) {
+          {
+            std::unique_lock<std::mutex> lk(wm);
+            wcv.wait(lk, [&] { return wq.size() < 4; });
+            wq.push_back(WJob{std::move(b), at});
+          }
+          wcv.notify_all();
+        } else {
+          const uint8_t* p = b->ext ? b->ext : b->bytes.data();
+          if (nb && fwrite(p, 1, nb, stdout) != nb) write_ok = false;
+          if (b->ext) pool.give(b->ext_slot);
+        }
+        at += (off_t)nb;
+        t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      }
+      { std::lock_guard<std::mutex> lk(wm); wclosed = true; }
+      wcv.notify_all();
+      for (std::thread& t : writers) t.join();
+      if (seekable && lseek(STDOUT_FILENO, at, SEEK_SET) < 0) write_ok = false;   // (the EOF marker goes behind the last batch)
+      const std::string rerr = rd->error();
+      rd.reset();
+      for (uint8_t* q : pool.buf) if (q) svdss_host_free(q);
+      if (!rerr.empty()) die("error reading " + o.bam + ": " + rerr);
+      if (dbg)
+        fprintf(stderr, "[smooth] device path: %llu records, %llu kept (XF 0/1/2/3: %llu %llu %llu %llu), %llu BGZF bytes; feeder seconds: front %.3f "
+                "turn wait %.3f turn %.3f walk %.3f rebuild %.3f output turn %.3f deflate + down %.3f (inflate kernels %.3f); writing %.3f\n",
+                (unsigned long long)n_rec, (unsigned long long)n_kept, (unsigned long long)n_xf[0], (unsigned long long)n_xf[1],
+                (unsigned long long)n_xf[2], (unsigned long long)n_xf[3], (unsigned long long)out_bytes, st_s[0], st_s[1], st_s[2], st_s[3],
+                st_s[4], st_s[5], st_s[6], inf_s, t_write);
+    }
+    static const uint8_t eof_marker[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fwrite(eof_marker, 1, 28, stdout) != 28 || fflush(stdout) != 0) write_ok = false;
+    svdss_bam_smooth_free(sm);
+    svdss_ref_free(dref);
+    if (!write_ok) die("error writing the BAM to stdout");
+    if (dbg) fprintf(stderr, "[smooth] done at +%.3f s\n", since());
+    if (!getenv("SVDSS_CLEAN_EXIT")) {
+      fprintf(stderr, "[smooth] [info] All done!\n");
+      fflush(stderr);
+      _exit(0);
+    }
+    return 0;
+  }
   // compute_maxaccuracy (smoother.cpp:259-346)
   double al_accuracy;
   {
