@@ -280,7 +280,8 @@ int svdss_bam_batch_result(const svdss_bam_batch_t* b, svdss_bam_result_t* out);
  * fill_clusters those that overlap a cluster (sam_itr_querys per cluster, :495-545).  A filter names what is kept: records
  * without flags 4 / 256 / 2048, with mapq >= min_mapq, and -- when names and / or regions are given -- whose read name is
  * in `names` (name i = names[name_off[i] .. name_off[i + 1])) or whose alignment [pos, bam_endpos) overlaps one of the
- * regions [reg_beg, reg_end) of its reference (sorted by (tid, beg)).  Names are compared by a 64-bit hash: a kept record
+ * regions [reg_beg, reg_end) of its reference (sorted by (tid, beg)); names = NULL: no name test, names given with
+ * n_names = 0: the empty set (no record passes by name).  Names are compared by a 64-bit hash: a kept record
  * may rarely be one nobody asked for (the caller looks at the name anyway), a wanted one is never dropped.
  * svdss_bam_select_run takes a batch like svdss_bam_batch_run; the kept records (block_size field first, as in the file)
  * come back in file order at 4-aligned offsets of one page-locked buffer. */

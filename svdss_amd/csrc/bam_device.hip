@@ -733,7 +733,11 @@ static int batch_front(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int6
       if (wait_turn(s, seq)) done_turn(s, code, msg);   // (a stream that already failed has let everybody through)
       had_turn = true;
     }
-    if (*out) (*out)->err = msg;
+    if (*out) {
+      (*out)->err = msg;
+      // the caller recycles its page-locked slabs as soon as this returns: no copy out of them may still be under way
+      if ((*out)->st) (void)hipStreamSynchronize((*out)->st);
+    }
     return code;
   };
   if (n_chunks > 0 && (!comp || !comp_bytes || !blocks || !crc || !n_blocks)) return fail(SVDSS_EINVAL, "bad argument");
@@ -919,7 +923,7 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   int32_t* seg_base = F.seg_base;
   const int64_t* hdr = F.hdr;
   const int64_t total_inf = F.total_inf, HEAD = F.HEAD;
-  auto fail = [&](int code, const std::string& msg) { b->err = msg; return code; };
+  auto fail = [&](int code, const std::string& msg) { b->err = msg; (void)hipStreamSynchronize(st); return code; };
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](int k) {
     const auto t = std::chrono::steady_clock::now();
@@ -1054,7 +1058,9 @@ extern "C" int svdss_bam_filter_create(int32_t device, int32_t min_mapq, int32_t
   f->device = device; f->min_mapq = min_mapq; f->n_ref = n_ref;
   auto bail = [&](int code) { svdss_bam_filter_free(f); return code; };
   try {
-    if (n_names > 0) {
+    // (a name array that is given but EMPTY is the empty set: nothing is named, so nothing passes by name -- `call` on an
+    // empty SFS file does not have every record of the BAM exported to look at; no array at all: no name test)
+    if (n_names > 0 || (names && name_off)) {
       uint64_t size = 64;
       while (size < 2 * (uint64_t)n_names) size <<= 1;
       std::vector<uint64_t> tab((size_t)size, 0);
@@ -1116,7 +1122,7 @@ extern "C" int svdss_bam_select_run(svdss_bam_stream_t* s, int64_t seq, int32_t 
   svdss_bam_batch* b = *out;
   const hipStream_t st = b->st;
   const WalkP& W = F.W;
-  auto fail = [&](int code, const std::string& msg) { b->err = msg; return code; };
+  auto fail = [&](int code, const std::string& msg) { b->err = msg; (void)hipStreamSynchronize(st); return code; };
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](int k) {
     const auto t = std::chrono::steady_clock::now();

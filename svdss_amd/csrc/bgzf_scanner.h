@@ -67,7 +67,9 @@ class BgzfScanner {
   // the pool's buffers, allocated ahead of the first read (a page-locked allocation of a slab takes tens of
   // milliseconds: a caller with something else to do first -- `search` restores its index -- runs this beside it)
   void prewarm() {
-    const size_t want = std::min(std::min(pool_chunks_, n_tickets_), (size_t)96);
+    size_t tickets;
+    { std::lock_guard<std::mutex> lk(m_); tickets = n_tickets_; }   // (the loaders may be shortening it: the file's last slab)
+    const size_t want = std::min(std::min(pool_chunks_, tickets), (size_t)96);
     std::vector<std::thread> th;
     for (int t = 0; t < 8; ++t)
       th.emplace_back([this, t, want] {
