@@ -4,6 +4,10 @@ lengths, ~3,400 implanted SVs (INS / DEL alternating, every other one heterozygo
 (run_svdss:142-178).  Runs on the GPU box; the generator uses every core it gets.
 
   python tools/e2e_call_wg.py [reads] [n_svs] [workdir] [scale]      scale < 1 shrinks every contig (trial runs)
+  python tools/e2e_call_wg.py chain [reads] [n_svs] [workdir] [scale]
+      the chain a user of run_svdss runs (run_svdss:136-178): the reads carry 0.5 % substitution errors and
+      no XF tag; `SVDSS index` -> `SVDSS smooth` -> `SVDSS search` (putative: the reads smooth tagged XF != 0 are skipped) on the
+      smoothed BAM -> `SVDSS call` on it; per-stage seconds, one search_plus_call_reads_per_s, truth recovery.
 """
 import json
 import multiprocessing as mp
@@ -50,7 +54,7 @@ def reg2bin(beg, end):
 def _contig(args):
     """one contig: reference, SVs, two haplotypes, reads, records, BGZF members.  Returns what the parent needs for the
     FASTA, the BAM and the BAI."""
-    tid, ref_len, n_svs, n_reads, seed, work = args
+    tid, ref_len, n_svs, n_reads, seed, work, err = args
     rng = np.random.default_rng(seed)
     ref = rng.integers(1, 5, size=ref_len, dtype=np.uint8)
     with open(os.path.join(work, "c%02d.fa" % tid), "wb") as f:
@@ -125,11 +129,18 @@ def _contig(args):
                     continue
                 end = last_r
             c = code[a:b]
+            if err > 0:                                      # substitution errors of a HiFi read (codes 1, 2, 4, 8 rotate)
+                e = np.nonzero(rng.random(L) < err)[0]
+                if len(e):
+                    c = c.copy()
+                    rot = rng.integers(1, 4, size=len(e))
+                    idx = np.array([0, 0, 1, 0, 2, 0, 0, 0, 3], dtype=np.int64)[c[e]]
+                    c[e] = np.array([1, 2, 4, 8], dtype=np.uint8)[(idx + rot) & 3]
             packed = ((c[0::2] << 4) | c[1::2]).tobytes()
             name = b"r%02d_%d_%07d\0" % (tid, hi, r)
             cig = b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in cigar)
             core = struct.pack("<iiBBHHHiiii", tid, pos, len(name), 60, reg2bin(pos, end), len(cigar), 0, L, -1, -1, 0)
-            body = core + name + cig + packed + qual + b"XFC\0"
+            body = core + name + cig + packed + qual + (b"XFC\0" if err <= 0 else b"")
             recs.append((pos, end, struct.pack("<i", len(body)) + body))
     recs.sort(key=lambda x: x[0])
     # BGZF members of this contig's records + where every record begins / ends (member, offset in member)
@@ -159,7 +170,7 @@ def _contig(args):
             "member_sizes": sizes, "svs": [(tid, p, k, ln, het) for p, k, ln, _, het in svs]}
 
 
-def write_dataset(work, n_reads, n_svs, scale=1.0):
+def write_dataset(work, n_reads, n_svs, scale=1.0, err=0.0):
     os.makedirs(work, exist_ok=True)
     lens = [max(200000, int(x * scale)) for x in GRCH38_PRIMARY]
     total = sum(lens)
@@ -171,7 +182,7 @@ def write_dataset(work, n_reads, n_svs, scale=1.0):
         nr = rd_left if last else round(n_reads * ln / total)
         sv_left -= ns
         rd_left -= nr
-        jobs.append((tid, ln, ns, nr, 1000 + tid, work))
+        jobs.append((tid, ln, ns, nr, 1000 + tid, work, err))
     # (largest contigs first; as many workers as memory allows: a worker holds ~4 bytes per base of its contig)
     with mp.Pool(min(12, os.cpu_count() or 1)) as pool:
         res = pool.map(_contig, sorted(jobs, key=lambda j: -j[1]), chunksize=1)
@@ -286,7 +297,71 @@ def run(work, n_reads, n_svs, scale=1.0, threads=16):
     return out
 
 
+def _vcf_hits(vcf_text, svs):
+    called = []
+    for line in vcf_text.splitlines():
+        if line.startswith("#"):
+            continue
+        f = line.split("\t")
+        kv = dict(x.split("=", 1) for x in f[7].split(";") if "=" in x)
+        called.append((f[0], int(f[1]), kv["SVTYPE"], abs(int(kv["SVLEN"]))))
+    truth = [("c%d" % (t + 1), p, k, ln) for t, p, k, ln, het in svs]
+    by = {}
+    for ch, p, k, ln in called:
+        by.setdefault((ch, k), []).append((p, ln))
+    # (smoothed reads leave the SV's length exact; reads the accuracy filter left unsmoothed can move it by a base or two)
+    hit = sum(1 for ch, p, k, ln in truth if any(abs(cp - p) <= 12 and abs(cl - ln) <= max(2, ln // 50) for cp, cl in by.get((ch, k), [])))
+    return len(called), hit
+
+
+def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005):
+    """index -> smooth -> search (putative) -> call, as run_svdss:136-178 chains them, on reads WITH errors."""
+    exe = os.path.join(ROOT, "svdss_amd", "SVDSS")
+    out = {}
+    t0 = time.perf_counter()
+    fa, bam, svs, n, lens = write_dataset(work, n_reads, n_svs, scale, err=err)
+    out["generate_s"] = round(time.perf_counter() - t0, 1)
+    out.update({"reads": n, "svs": len(svs), "read_error_rate": err, "reference_bp": sum(lens), "bam_bytes": os.path.getsize(bam)})
+    fmd = os.path.join(work, "ref.fmd")
+    t0 = time.perf_counter()
+    subprocess.run([exe, "index", "-d", fa, "-o", fmd], check=True, capture_output=True)
+    out["index_s"] = round(time.perf_counter() - t0, 2)
+    sm = os.path.join(work, "smoothed.bam")
+    t0 = time.perf_counter()
+    with open(sm, "wb") as f:
+        r = subprocess.run([exe, "smooth", "--reference", fa, "--bam", bam, "--threads", str(threads)], check=True, stdout=f, stderr=subprocess.PIPE,
+                           text=True, env=dict(os.environ, SVDSS_DEBUG="1"))
+    out["smooth_s"] = round(time.perf_counter() - t0, 3)
+    out["smooth_log"] = [ln for ln in r.stderr.splitlines() if "device path" in ln or "accuracy" in ln][-3:]
+    out["smoothed_bam_bytes"] = os.path.getsize(sm)
+    sfs = os.path.join(work, "specifics.txt")
+    t0 = time.perf_counter()
+    with open(sfs, "wb") as f:
+        r = subprocess.run([exe, "search", "--index", fmd, "--bam", sm, "--verbose"], check=True, stdout=f, stderr=subprocess.PIPE, text=True)
+    out["search_s"] = round(time.perf_counter() - t0, 3)
+    m = re.search(r"on the device at \+([0-9.]+) s", r.stderr)
+    out["search_index_resident_s"] = float(m.group(1)) if m else None
+    out["sfs_bytes"] = os.path.getsize(sfs)
+    out["search_log"] = [ln for ln in r.stderr.splitlines() if "debug" in ln][-6:]
+    t0 = time.perf_counter()
+    c = subprocess.run([exe, "call", "--reference", fa, "--bam", sm, "--sfs", sfs, "--threads", str(threads), "--min-sv-length", "50", "--verbose"],
+                       check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    out["call_s"] = round(time.perf_counter() - t0, 3)
+    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "[time]" in ln][-20:]
+    n_called, hit = _vcf_hits(c.stdout.decode(), svs)
+    chain = out["smooth_s"] + out["search_s"] + out["call_s"]
+    out.update({"svs_called": n_called, "truth_recovered": hit, "smooth_reads_per_s": n / out["smooth_s"],
+                "search_plus_call_reads_per_s": n / (out["search_s"] + out["call_s"]), "chain_reads_per_s": n / chain,
+                "chain_s": round(chain, 3)})
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "chain":
+        a = sys.argv[2:]
+        print(json.dumps(run_chain(a[2] if len(a) > 2 else "/tmp/svdss_e2e_chain_wg", int(a[0]) if a else 1030000, int(a[1]) if len(a) > 1 else 3400,
+                                   float(a[3]) if len(a) > 3 else 1.0), indent=1))
+        sys.exit(0)
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1030000
     n_svs = int(sys.argv[2]) if len(sys.argv) > 2 else 3400
     work = sys.argv[3] if len(sys.argv) > 3 else "/tmp/svdss_e2e_call_wg"
