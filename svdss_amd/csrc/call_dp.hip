@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
@@ -49,44 +50,66 @@ __device__ __forceinline__ int dp_gap(int l, const GapModel& g) {
 
 struct AlnPair {
   int64_t q_off, t_off;   // into the concatenated query / target symbol buffers
-  int64_t bnd_off;        // int32 workspace: 2 x 3 arrays of (ql + 64): H, E, E2 of a stripe's last row (in / out)
+  int64_t bnd_off;        // int32 workspace: (waves + 1) x 3 arrays of (ql + 64): H, E, E2 of a stripe's last row
   int64_t dir_off;        // (tl+ql)*tl direction bytes, diagonal-major: cell (i, j) at (i+j)*tl + i
   int64_t cig_off;        // uint32 ops in backtrack order, capacity tl + ql + 2
   int32_t ql, tl;
   int32_t slot;           // index of the pair in the caller's order (results are written there)
-  int32_t pad_;
+  int32_t waves;          // wavefronts that share the pair's stripes (1, or the kernel's W for the longest pairs)
 };
 
 __device__ __forceinline__ int dp_shr1(int x) {   // value of the lane below (lane 0: unchanged, it is overwritten)
   return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false);
 }
 
-// One wavefront per pair.  Cell (i, j): i indexes the target, j the query.
+// One wavefront per pair -- or, for the longest pairs of a batch, W wavefronts (round 5): a pair is a chain of
+// (tl / 64) x (ql + 63) dependent steps, so a launch lasts as long as its longest pair (26 ms of a bench step's
+// realignment, all of it the 2.6 kb x 2.6 kb pairs, while the whole batch is 8 ms of work).  The stripes of a pair only
+// depend on each other through the boundary row, column by column: stripe s + 1 can run three blocks of 64 columns behind
+// stripe s.  Wavefront v of the pair's workgroup takes stripes v, v + W, ...; the boundary rows go through W + 1 buffers
+// in HBM (workgroup-scope release / loads: producer and consumer sit on the same CU and share its L1), progress through one LDS word per buffer, (stripe + 1) << 20 | columns done -- the stripe number in
+// it, so that what an earlier stripe left in the word reads as "not yet".  Nobody waits for a stripe with a higher number,
+// the lowest unfinished stripe never waits: no deadlock; a wait that does not end all the same (1 << 22 polls) raises
+// *abort_flag and the host runs the batch again with one wavefront per pair.
+// Cell (i, j): i indexes the target, j the query.
 // Recurrences and tie rules are those of ksw2's extd2 (left-aligned), see the oracle
 // (oracle/svdss_oracle_call.c, orc_ksw_extd2_global) which this kernel must match bit for bit.
-__global__ void __launch_bounds__(64) align_wave_kernel(
+template <int W>
+__global__ void __launch_bounds__(64 * W) align_wave_kernel(
     const AlnPair* pairs, const uint8_t* qsyms, const uint8_t* tsyms, int m, const int8_t* mat_g,
-    GapModel gm, int32_t* ws, uint8_t* dirs, uint32_t* cigars, int32_t* scores, int32_t* n_cigar) {
+    GapModel gm, int32_t* ws, uint8_t* dirs, uint32_t* cigars, int32_t* scores, int32_t* n_cigar, int32_t* abort_flag) {
   const AlnPair P = pairs[blockIdx.x];
   const int ql = P.ql, tl = P.tl;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Wp = W > 1 ? P.waves : 1, NB = Wp + 1;
+  if (wave >= Wp) return;
   if (ql <= 0 || tl <= 0) {   // ksw2 returns before touching ez: score 0, no CIGAR
     if (lane == 0) { scores[P.slot] = 0; n_cigar[P.slot] = 0; }
     return;
   }
+  __shared__ volatile int32_t prog[W + 1];
+  __shared__ int32_t s_score;
   const uint8_t* q = qsyms + P.q_off;
   const uint8_t* t = tsyms + P.t_off;
   uint8_t* dir = dirs + P.dir_off;
   const int bstride = ql + 64;
   int32_t* bnd = ws + P.bnd_off;
-  // boundary above row 0: H(-1, j) = -gap(j + 1), no gap state
-  for (int j = lane; j < ql; j += 64) { bnd[j] = -dp_gap(j + 1, gm); bnd[bstride + j] = DP_NEG; bnd[2 * bstride + j] = DP_NEG; }
+  // boundary above row 0 ("stripe -1", buffer NB - 1): H(-1, j) = -gap(j + 1), no gap state
+  {
+    int32_t* b0 = bnd + (int64_t)(NB - 1) * 3 * bstride;
+    for (int j = threadIdx.x; j < ql; j += 64 * Wp) { b0[j] = -dp_gap(j + 1, gm); b0[bstride + j] = DP_NEG; b0[2 * bstride + j] = DP_NEG; }
+    if ((int)threadIdx.x < NB) prog[threadIdx.x] = (int)threadIdx.x == NB - 1 ? ql : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
   __syncthreads();
   const int n_stripes = (tl + 63) >> 6;
   int32_t final_score = 0;
-  for (int s = 0; s < n_stripes; ++s) {
-    const int32_t* bin = bnd + (s & 1) * 3 * bstride;
-    int32_t* bout = bnd + ((s & 1) ^ 1) * 3 * bstride;
+  bool aborted = false;
+  for (int s = wave; s < n_stripes && !aborted; s += Wp) {
+    const int in_slot = (s + NB - 1) % NB, out_slot = s % NB;
+    const int32_t* bin = bnd + (int64_t)in_slot * 3 * bstride;
+    int32_t* bout = bnd + (int64_t)out_slot * 3 * bstride;
+    if (W > 1 && lane == 0) prog[out_slot] = (s + 1) << 20;
     const int i = (s << 6) + lane;
     const bool row_ok = i < tl;
     const int rows = tl - (s << 6) < 64 ? tl - (s << 6) : 64;
@@ -109,11 +132,27 @@ __global__ void __launch_bounds__(64) align_wave_kernel(
       const int jj = tau0 + lane;
       const bool in = jj < ql;
       nq = in ? q[jj] : 0;
-      nH = in ? bin[jj] : 0; nE = in ? bin[bstride + jj] : 0; nE2 = in ? bin[2 * bstride + jj] : 0;
+      if (W > 1 && Wp > 1) {
+        // columns tau0 .. tau0 + 63 of the stripe above: wait until its wavefront has them in memory
+        const int need = tau0 + 64 < ql ? tau0 + 64 : ql;
+        int polls = 0;
+        for (;;) {
+          const int32_t v = prog[in_slot];
+          if ((v >> 20) == s && (v & 0xFFFFF) >= need) break;
+          if (++polls > (1 << 22)) { aborted = true; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (aborted) { nH = 0; nE = 0; nE2 = 0; return; }
+        nH = in ? __hip_atomic_load(&bin[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+        nE = in ? __hip_atomic_load(&bin[bstride + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+        nE2 = in ? __hip_atomic_load(&bin[2 * bstride + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+      } else {
+        nH = in ? bin[jj] : 0; nE = in ? bin[bstride + jj] : 0; nE2 = in ? bin[2 * bstride + jj] : 0;
+      }
     };
     fetch(0);
     uint8_t* dcell = dir + (int64_t)(s << 6) * tl + i;   // cell (i, j) at (i + j) * tl + i: + tl per step
-    for (int tau0 = 0; tau0 < n_steps; tau0 += 64) {
+    for (int tau0 = 0; tau0 < n_steps && !aborted; tau0 += 64) {
       // wait for the block here, once, so that the 64 steps below never wait on memory (their direction-byte stores
       // stay in flight: vmcnt counts stores too)
       asm volatile("" : "+v"(nq), "+v"(nH), "+v"(nE), "+v"(nE2));
@@ -155,15 +194,28 @@ __global__ void __launch_bounds__(64) align_wave_kernel(
         Hd = Hu;
         dcell += tl;
       }
+      if (W > 1 && Wp > 1 && s + 1 < n_stripes) {
+        // lane 63 has finished columns 0 .. tau0 + kmax - 64 of the boundary row: in memory, then announced
+        // (workgroup scope: the stores have reached the L2 of this XCD, which the reader's CU -- the same one -- reads
+        // through the L1 it shares with the writer.  An agent-scope fence writes the whole L2 back on this multi-die part:
+        // the first version of this kernel spent more time in it than it saved)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const int done = tau0 + kmax - 63;
+        if (lane == 63) prog[out_slot] = ((s + 1) << 20) | (done < 0 ? 0 : done > ql ? ql : done);
+      }
     }
-    __syncthreads();   // the boundary row is in memory before the next stripe reads it
+    if (W == 1 || Wp == 1) __syncthreads();   // (one wavefront: the boundary row is in memory before the next stripe reads it)
+    else if (s + 1 < n_stripes) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 63) prog[out_slot] = ((s + 1) << 20) | ql; }
+    if (s == n_stripes - 1) {   // the lane that owned (tl-1, ql-1) has the score
+      const int owner = (tl - 1) & 63;
+      final_score = __builtin_amdgcn_readlane(final_score, owner);
+      if (lane == 0) s_score = final_score;
+    }
   }
-  // the lane that owned (tl-1, ql-1) has the score
-  {
-    const int owner = (tl - 1) & 63;
-    final_score = __builtin_amdgcn_readlane(final_score, owner);
-  }
-  __syncthreads();   // the direction bytes are in HBM
+  if (aborted && lane == 0) atomicExch(abort_flag, 1);
+  __syncthreads();   // the direction bytes are in HBM, the score in LDS
+  if (wave != 0) return;
+  final_score = s_score;
   {
     // ksw_backtrack from (tl-1, ql-1); ops are left in backtrack order, the host reverses
     // them.  A register window holds the direction bytes of 64 rows x 4 columns along the current diagonal (one HBM
@@ -416,9 +468,22 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
   std::vector<std::pair<int64_t, int64_t>> cig_at((size_t)n_pairs);   // (chunk-local offset, chunk index)
   std::vector<std::vector<uint32_t>> chunk_cigs;
   int64_t start = 0;
+  // the longest pairs of the batch get ALN_W wavefronts each (align_wave_kernel): within a factor of four of the largest
+  // matrix (SVDSS_ALIGN_FRAC, default eight), or every pair of a batch too small to fill the GPU with one wavefront per pair.
+  // SVDSS_ALIGN_WAVES=1: never; =8: eight.  Measured on a bench step (5,093 pairs): 26.5 -> 16.5 ms.
+  const int ALN_W = getenv("SVDSS_ALIGN_WAVES") && atoi(getenv("SVDSS_ALIGN_WAVES")) == 8 ? 8 : 4;
+  const int64_t aln_frac = getenv("SVDSS_ALIGN_FRAC") && atoll(getenv("SVDSS_ALIGN_FRAC")) > 0 ? atoll(getenv("SVDSS_ALIGN_FRAC")) : 8;
+  int64_t max_cells = 0;
+  for (int64_t i = 0; i < n_pairs; ++i) max_cells = std::max(max_cells, (q_off[i + 1] - q_off[i]) * (t_off[i + 1] - t_off[i]));
+  bool multi = !(getenv("SVDSS_ALIGN_WAVES") && atoi(getenv("SVDSS_ALIGN_WAVES")) <= 1);
+  auto waves_of = [&](int64_t ql, int64_t tl) {
+    if (!multi || tl < 8 * 64 || ql >= (1 << 20)) return 1;
+    return (ql * tl * aln_frac >= max_cells || n_pairs < 2048) ? ALN_W : 1;
+  };
   while (start < n_pairs) {
     std::vector<AlnPair> hp;
     int64_t ws = 0, dirb = 0, cig = 0, end = start;
+    bool any_multi = false;
     while (end < n_pairs) {
       const int64_t ql = q_off[end + 1] - q_off[end], tl = t_off[end + 1] - t_off[end];
       const int64_t need = (ql + tl) * tl;   // direction bytes, one row of tl per anti-diagonal
@@ -433,9 +498,11 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
       a.ql = (int32_t)ql;
       a.tl = (int32_t)tl;
       a.slot = (int32_t)(end - start);
+      a.waves = waves_of(ql, tl);
+      any_multi = any_multi || a.waves > 1;
       hp.push_back(a);
       cig_at[(size_t)end] = {cig, (int64_t)chunk_cigs.size()};
-      ws += 6 * (ql + 64);
+      ws += 3 * (a.waves + 1) * (ql + 64);
       dirb += need;
       cig += ql + tl + 2;
       b->cells += ql * tl;
@@ -450,7 +517,7 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
     const size_t need_bytes = DevArena::padded((size_t)qtot) + DevArena::padded((size_t)ttot) + DevArena::padded(64) +
                               DevArena::padded(sizeof(AlnPair) * (size_t)np) + DevArena::padded(sizeof(int32_t) * (size_t)ws) +
                               DevArena::padded((size_t)dirb) + DevArena::padded(sizeof(uint32_t) * (size_t)cig) +
-                              2 * DevArena::padded(sizeof(int32_t) * (size_t)np);
+                              2 * DevArena::padded(sizeof(int32_t) * (size_t)np) + DevArena::padded(64);
     HIPCHK2(b->arena.reserve(need_bytes));
     void* d_q = b->arena.take((size_t)qtot);
     void* d_t = b->arena.take((size_t)ttot);
@@ -461,16 +528,39 @@ extern "C" int svdss_align_global_batch(const uint8_t* queries, const int64_t* q
     void* d_cig = b->arena.take(sizeof(uint32_t) * (size_t)cig);
     void* d_sc = b->arena.take(sizeof(int32_t) * (size_t)np);
     void* d_nc = b->arena.take(sizeof(int32_t) * (size_t)np);
+    void* d_abort = b->arena.take(64);
     if (qtot) HIPCHK2(hipMemcpyAsync(d_q, queries + q_off[0], (size_t)qtot, hipMemcpyHostToDevice, st));
     if (ttot) HIPCHK2(hipMemcpyAsync(d_t, targets + t_off[0], (size_t)ttot, hipMemcpyHostToDevice, st));
     HIPCHK2(hipMemcpyAsync(d_mat, mat, (size_t)(m * m), hipMemcpyHostToDevice, st));
     HIPCHK2(hipMemcpyAsync(d_pairs, hp.data(), sizeof(AlnPair) * (size_t)np, hipMemcpyHostToDevice, st));
+    HIPCHK2(hipMemsetAsync(d_abort, 0, 64, st));
     HIPCHK2(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(align_wave_kernel, dim3((unsigned)np), dim3(64), 0, st, (const AlnPair*)d_pairs,
-                       (const uint8_t*)d_q, (const uint8_t*)d_t, (int)m, (const int8_t*)d_mat, gm, (int32_t*)d_ws,
-                       (uint8_t*)d_dir, (uint32_t*)d_cig, (int32_t*)d_sc, (int32_t*)d_nc);
+    if (any_multi && ALN_W == 8)
+      hipLaunchKernelGGL(align_wave_kernel<8>, dim3((unsigned)np), dim3(64 * 8), 0, st, (const AlnPair*)d_pairs,
+                         (const uint8_t*)d_q, (const uint8_t*)d_t, (int)m, (const int8_t*)d_mat, gm, (int32_t*)d_ws,
+                         (uint8_t*)d_dir, (uint32_t*)d_cig, (int32_t*)d_sc, (int32_t*)d_nc, (int32_t*)d_abort);
+    else if (any_multi)
+      hipLaunchKernelGGL(align_wave_kernel<4>, dim3((unsigned)np), dim3(64 * 4), 0, st, (const AlnPair*)d_pairs,
+                         (const uint8_t*)d_q, (const uint8_t*)d_t, (int)m, (const int8_t*)d_mat, gm, (int32_t*)d_ws,
+                         (uint8_t*)d_dir, (uint32_t*)d_cig, (int32_t*)d_sc, (int32_t*)d_nc, (int32_t*)d_abort);
+    else
+      hipLaunchKernelGGL(align_wave_kernel<1>, dim3((unsigned)np), dim3(64), 0, st, (const AlnPair*)d_pairs,
+                         (const uint8_t*)d_q, (const uint8_t*)d_t, (int)m, (const int8_t*)d_mat, gm, (int32_t*)d_ws,
+                         (uint8_t*)d_dir, (uint32_t*)d_cig, (int32_t*)d_sc, (int32_t*)d_nc, (int32_t*)d_abort);
     HIPCHK2(hipGetLastError());
     HIPCHK2(hipEventRecord(ev1, st));
+    if (any_multi) {
+      int32_t ab = 0;
+      HIPCHK2(hipMemcpyAsync(&ab, d_abort, sizeof ab, hipMemcpyDeviceToHost, st));
+      HIPCHK2(hipStreamSynchronize(st));
+      if (ab) {   // a wavefront gave up waiting for its neighbour (never seen): the chunk again, one wavefront per pair
+        fprintf(stderr, "[svdss] realignment: a multi-wavefront pair did not finish; the batch runs again with one wavefront per pair\n");
+        multi = false;
+        b->cells -= [&] { int64_t c = 0; for (const AlnPair& a : hp) c += (int64_t)a.ql * a.tl; return c; }();
+        for (int64_t k = start; k < end; ++k) cig_at[(size_t)k] = {0, 0};
+        continue;   // (same `start`: the chunk is laid out again with waves = 1)
+      }
+    }
     chunk_cigs.emplace_back((size_t)cig);
     HIPCHK2(hipMemcpyAsync(&b->scores[(size_t)start], d_sc, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
     HIPCHK2(hipMemcpyAsync(&h_nc[(size_t)start], d_nc, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
