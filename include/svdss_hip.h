@@ -249,6 +249,17 @@ typedef struct svdss_bam_batch svdss_bam_batch_t;
 int svdss_bam_stream_create(int32_t n_ref, svdss_bam_stream_t** out);
 void svdss_bam_stream_free(svdss_bam_stream_t* s);
 const char* svdss_bam_stream_error(const svdss_bam_stream_t* s);
+/* A stream over a REGION of the file (`SVDSS search --gpus N` gives every GPU its own range of BGZF blocks -- north_star:
+ * "BAM regions partition across the GPUs"; the per-shard loop of ping_pong.cpp:53-128).  Call before batch 0.
+ * open_start: the region begins inside a record nobody has located yet: batch 0 starts the chain at the first record its
+ *   segments guess (plausible fields, a plausible record behind it) and keeps the bytes in front of it (svdss_bam_stream_head).
+ *   The guess is proved by the caller: the previous region's tail + this head must be a chain of whole records -- run
+ *   them as a one-batch stream of their own; if they are not, run the region again with open_start = 0 and carry = the
+ *   previous region's tail (the incomplete record in front of batch 0).
+ * open_end: the last batch may end inside a record; svdss_bam_stream_tail are its bytes (no "truncated record"). */
+int svdss_bam_stream_region(svdss_bam_stream_t* s, int32_t open_start, int32_t open_end, const uint8_t* carry, int64_t n_carry);
+int64_t svdss_bam_stream_head(const svdss_bam_stream_t* s, const uint8_t** bytes);   /* after batch 0 */
+int64_t svdss_bam_stream_tail(const svdss_bam_stream_t* s, const uint8_t** bytes);   /* after the last batch */
 /* segments whose guessed first record the chain did not arrive at (walked again, exactly), of *n_segments in all */
 int64_t svdss_bam_stream_rewalked(const svdss_bam_stream_t* s, int64_t* n_segments);
 int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_index_t* ix,

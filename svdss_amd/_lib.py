@@ -96,6 +96,9 @@ SIGNATURES = {
     "svdss_bam_stream_free": (None, [_p]),
     "svdss_bam_stream_error": (C.c_char_p, [_p]),
     "svdss_bam_stream_rewalked": (_i64, [_p, _pi64]),
+    "svdss_bam_stream_region": (C.c_int, [_p, _i32, _i32, _p, _i64]),
+    "svdss_bam_stream_head": (_i64, [_p, C.POINTER(_p)]),
+    "svdss_bam_stream_tail": (_i64, [_p, C.POINTER(_p)]),
     "svdss_bam_batch_run": (C.c_int, [_p, _i64, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p, _i32, C.POINTER(_p)]),
     "svdss_bam_batch_result": (C.c_int, [_p, _p]),
     "svdss_bam_smooth_create": (C.c_int, [_p, _p, C.c_int32, C.c_int32, _p]),

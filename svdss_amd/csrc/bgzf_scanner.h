@@ -41,13 +41,17 @@ class BgzfScanner {
   };
   static constexpr size_t kOverlap = (size_t)128 << 10;   // a member that starts inside a slab ends within this
 
-  BgzfScanner(const std::string& path, Hooks hooks, size_t slab, int loaders, size_t pool_chunks)
+  // [begin, end): the members of a region of the file (both at member starts, see member_start_near; end = 0: the file's)
+  BgzfScanner(const std::string& path, Hooks hooks, size_t slab, int loaders, size_t pool_chunks, size_t begin = 0, size_t end = 0)
       : hooks_(hooks), slab_(slab), pool_chunks_(pool_chunks < 2 ? 2 : pool_chunks) {
     f_ = fopen(path.c_str(), "rb");
     struct stat st;
-    if (f_ && fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode)) size_ = (size_t)st.st_size;
+    if (f_ && fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode)) fsize_ = (size_t)st.st_size;
     else if (f_) { fclose(f_); f_ = nullptr; }
-    n_tickets_ = size_ ? (size_ + slab_ - 1) / slab_ : 0;
+    size_ = end && end < fsize_ ? end : fsize_;
+    begin_ = begin < size_ ? begin : size_;
+    next_off_ = begin_;
+    n_tickets_ = size_ > begin_ ? (size_ - begin_ + slab_ - 1) / slab_ : 0;
     if (f_) for (int i = 0; i < (loaders < 1 ? 1 : loaders); ++i) th_.emplace_back([this] { loader(); });
   }
   ~BgzfScanner() {
@@ -61,7 +65,72 @@ class BgzfScanner {
   BgzfScanner(const BgzfScanner&) = delete;
   BgzfScanner& operator=(const BgzfScanner&) = delete;
   bool ok() const { return f_ != nullptr; }
-  size_t file_size() const { return size_; }
+  size_t file_size() const { return fsize_; }
+  size_t range_bytes() const { return size_ - begin_; }
+
+  // One BGZF member header at h (avail bytes visible): its length in the file, where its deflate stream is and how long.
+  // 0 = not a member header, -1 = more bytes needed.
+  static int parse_member(const uint8_t* h, size_t avail, size_t& total, size_t& data_off, size_t& data_len) {
+    if (avail < 18) return -1;
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return 0;
+    uint16_t xlen;
+    memcpy(&xlen, h + 10, 2);
+    if ((size_t)12 + xlen > avail) return -1;
+    int bsize = -1;
+    for (size_t o = 0; o + 4 <= xlen;) {
+      const uint8_t* x = h + 12 + o;
+      uint16_t slen;
+      memcpy(&slen, x + 2, 2);
+      if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) { uint16_t v; memcpy(&v, x + 4, 2); bsize = v; break; }
+      o += 4u + slen;
+    }
+    if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) return 0;
+    total = (size_t)bsize + 1;
+    data_off = (size_t)12 + xlen;
+    data_len = total - 12 - xlen - 8;
+    return 1;
+  }
+  // The first member that starts at or behind `approx`: a header whose chain of BSIZE fields leads through kChain more
+  // headers (or exactly to the end of the file).  Compressed bytes can imitate one header, hardly a chain; a region cut
+  // at an imitation fails its first inflate and the caller falls back to one region.  file size = none found.
+  static size_t member_start_near(const std::string& path, size_t approx) {
+    constexpr int kChain = 6;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return 0;
+    struct stat st;
+    size_t fsize = 0;
+    if (fstat(fileno(f), &st) == 0) fsize = (size_t)st.st_size;
+    size_t found = fsize;
+    if (approx < fsize) {
+      const size_t want = std::min(fsize - approx, (size_t)(kChain + 2) << 16);
+      std::vector<uint8_t> w(want);
+      size_t got = 0;
+      while (got < want) {
+        const ssize_t k = pread(fileno(f), w.data() + got, want - got, (off_t)(approx + got));
+        if (k <= 0) break;
+        got += (size_t)k;
+      }
+      for (size_t p = 0; p + 18 <= got && p < ((size_t)1 << 16) + 18; ++p) {
+        if (w[p] != 31 || w[p + 1] != 139) continue;
+        size_t q = p;
+        int n = 0;
+        bool good = true;
+        while (n <= kChain) {
+          if (approx + q == fsize) break;                 // the chain ends with the file
+          size_t tot, doff, dlen;
+          const int r = parse_member(w.data() + q, got - q, tot, doff, dlen);
+          if (r < 0) { good = approx + got < fsize && n >= 2; break; }   // (ran out of the window: long enough a chain)
+          if (r == 0) { good = false; break; }
+          q += tot;
+          ++n;
+          if (q > got) { good = approx + q <= fsize && n >= 2; break; }
+        }
+        if (good) { found = approx + p; break; }
+      }
+    }
+    fclose(f);
+    return found;
+  }
   const std::string& error() const { return err_; }
 
   // the pool's buffers, allocated ahead of the first read (a page-locked allocation of a slab takes tens of
@@ -141,8 +210,8 @@ class BgzfScanner {
         if (!free_.empty()) { c = std::move(free_.back()); free_.pop_back(); }
       }
       if (!c) { c.reset(new CompChunk); if (!alloc(*c)) { fail("out of memory while loading a BAM chunk"); return; } }
-      const size_t base = t * slab_;
-      const size_t want = std::min(slab_ + kOverlap, size_ - base);
+      const size_t base = begin_ + t * slab_;
+      const size_t want = std::min(slab_ + kOverlap, fsize_ - base);
       size_t got = 0;
       while (got < want) {
         const ssize_t k = pread(fileno(f_), c->data + got, want - got, (off_t)(base + got));
@@ -173,16 +242,16 @@ class BgzfScanner {
     if (next_off_ >= size_) return;
     if (next_off_ < base || next_off_ > base + slab_ + kOverlap) { err = "BGZF block chain lost"; return; }
     const uint8_t* src = c.data;
-    const size_t avail = c.n_bytes, scan_end = std::min(slab_, c.n_bytes);
+    const size_t avail = c.n_bytes, scan_end = std::min(std::min(slab_, c.n_bytes), size_ - base);   // (a region ends at size_)
     size_t pos = next_off_ - base;
     if (pos >= scan_end && base + c.n_bytes < size_ && c.n_bytes < slab_ + kOverlap) { err = "short read"; return; }
     while (pos < scan_end) {
-      if (pos + 18 > avail) { if (base + avail >= size_) err = "truncated BGZF block"; break; }
+      if (pos + 18 > avail) { if (base + avail >= fsize_) err = "truncated BGZF block"; break; }
       const uint8_t* h = src + pos;
       if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "bad BGZF block"; return; }
       uint16_t xlen;
       memcpy(&xlen, h + 10, 2);
-      if (pos + 12 + xlen > avail) { if (base + avail >= size_) err = "truncated BGZF block"; break; }
+      if (pos + 12 + xlen > avail) { if (base + avail >= fsize_) err = "truncated BGZF block"; break; }
       int bsize = -1;
       for (size_t o = 0; o + 4 <= xlen;) {
         const uint8_t* x = h + 12 + o;
@@ -192,7 +261,8 @@ class BgzfScanner {
         o += 4u + slen;
       }
       if (bsize < 0 || (size_t)bsize + 1 < 12u + xlen + 8u) { err = "BGZF block without BC field"; return; }
-      if (pos + (size_t)bsize + 1 > avail) { if (base + avail >= size_) err = "truncated BGZF block"; break; }
+      if (pos + (size_t)bsize + 1 > avail) { if (base + avail >= fsize_) err = "truncated BGZF block"; break; }
+      if (base + pos + (size_t)bsize + 1 > size_ && size_ < fsize_) { err = "BGZF block chain lost"; return; }   // (a region's end is a member's start)
       const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
       svdss_bgzf_block_t b;
       b.coff = (int64_t)(pos + 12 + xlen); b.clen = (int32_t)cdata; b.uoff = 0;
@@ -211,7 +281,7 @@ class BgzfScanner {
 
   Hooks hooks_;
   FILE* f_ = nullptr;
-  size_t size_ = 0, slab_, pool_chunks_;
+  size_t size_ = 0, fsize_ = 0, begin_ = 0, slab_, pool_chunks_;   // the scanner's range is [begin_, size_) of fsize_ bytes
   std::vector<std::thread> th_;
   std::mutex m_;
   std::condition_variable cv_;

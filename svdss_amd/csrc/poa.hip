@@ -464,7 +464,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   // wait for those streams: calls on different batch objects (threads) and a search running beside them overlap
   // (few streams: the runtime multiplexes streams onto a handful of hardware queues, and streams that share one run
   // in order)
-  while (b->streams.size() < 2) {
+  while (b->streams.size() < 6) {   // (the launches of a round run side by side: one stream each while they last)
     hipStream_t st;
     HIPCHK3(svdss_make_stream(&st, "SVDSS_CALL_CUS"));
     b->streams.push_back(st);
@@ -502,6 +502,8 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
   const bool use_quad = use_lds && !(getenv("SVDSS_POA_QUAD") && atoi(getenv("SVDSS_POA_QUAD")) == 0);
   const int64_t quad_short = getenv("SVDSS_POA_QUAD_SHORT") ? atoll(getenv("SVDSS_POA_QUAD_SHORT")) : 0;
   const int64_t quad_minwork_pct = getenv("SVDSS_POA_QUAD_MINWORK") ? atoll(getenv("SVDSS_POA_QUAD_MINWORK")) : 0;
+  const int64_t quad_rows16 = getenv("SVDSS_POA_QUAD_ROWS16") ? atoll(getenv("SVDSS_POA_QUAD_ROWS16")) : 0;
+  const int64_t quad_rows32 = getenv("SVDSS_POA_QUAD_ROWS32") ? atoll(getenv("SVDSS_POA_QUAD_ROWS32")) : 0;
   int64_t batch_max_work = 1;
   for (int64_t c = 0; c < n_clusters; ++c) {
     int64_t maxl = 0;
@@ -544,7 +546,11 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         // Group width: four short sub-clusters share a wavefront (a quarter of the wavefront slots for the latency-bound
         // traceback / graph-update phases); a long one gets the wavefront to itself -- the longest chains of a batch
         // decide when it ends, and a row of C = 2 columns per lane is the quickest there is.
-        const int gw = getenv("SVDSS_POA_QUAD_GW") ? atoi(getenv("SVDSS_POA_QUAD_GW")) : (maxl <= quad_short ? 16 : 64);
+        // (SVDSS_POA_QUAD_ROWS16 / _ROWS32: a sub-cluster of at most that many reads x length shares its wavefront with three /
+        // one other: its chain is short enough not to become the batch's tail at the slower lock-step pace)
+        const int64_t chain = t.n_seqs * maxl;
+        const int gw = getenv("SVDSS_POA_QUAD_GW") ? atoi(getenv("SVDSS_POA_QUAD_GW"))
+                       : (maxl <= quad_short || chain <= quad_rows16) ? 16 : chain <= quad_rows32 ? 32 : 64;
         // SVDSS_POA_QUAD_MINWORK (percent of the batch's largest reads x length): only the long chains take this stage
         if (t.n_seqs * maxl * 100 < quad_minwork_pct * batch_max_work) { retry.push_back(c); continue; }
         const int64_t need = std::min<int64_t>(w2 + 8, maxl + 1);

@@ -11,8 +11,11 @@
 #include "poa_quad_core.h"
 
 // (launch bounds: one wavefront per block; the LDS ring, not the registers, decides how many stay on a CU)
+#ifndef PQ_MIN_WAVES
+#define PQ_MIN_WAVES 1
+#endif
 template <int GW, int C>
-__global__ void __launch_bounds__(64) poa_quad_kernel(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs, const int64_t* seq_off,
+__global__ void __launch_bounds__(64, PQ_MIN_WAVES) poa_quad_kernel(const PoaWaveTask* tasks, int n_tasks, const uint8_t* seqs, const int64_t* seq_off,
                                                       int32_t* ws32, int32_t* cons_len, int32_t* status, unsigned long long* cells, int qcap) {
   extern __shared__ __align__(16) int32_t poaq_lds[];
   pq::poaq_run<GW, C>(tasks, n_tasks, seqs, seq_off, ws32, cons_len, status, cells, poaq_lds, (int)blockIdx.x, qcap);

@@ -970,10 +970,12 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       p.n_seg = 1;
       p.n_items = n_reads;
       if (pass == 0) HIPCHK(hipEventRecord(b->ek0, stream));
-      if (wide && use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false, true>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
-      else if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
-      else if (use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false, true>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false, false>), dim3(blocks_for(n_reads)), dim3(256), 0, stream, p);
+      const char* xl1 = getenv("SVDSS_EXTRA_LDS");   // (developer knob, as above)
+      const size_t xlds = xl1 ? (size_t)atol(xl1) : 0;
+      if (wide && use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false, true>), dim3(blocks_for(n_reads)), dim3(256), xlds, stream, p);
+      else if (wide) hipLaunchKernelGGL((sfs_search2_kernel<uint64_t, false, false>), dim3(blocks_for(n_reads)), dim3(256), xlds, stream, p);
+      else if (use_bs_kernel) hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false, true>), dim3(blocks_for(n_reads)), dim3(256), xlds, stream, p);
+      else hipLaunchKernelGGL((sfs_search2_kernel<uint32_t, false, false>), dim3(blocks_for(n_reads)), dim3(256), xlds, stream, p);
       if (pass == 0) HIPCHK(hipEventRecord(b->ek1, stream));
     }
     HIPCHK(hipGetLastError());

@@ -319,36 +319,120 @@ static void format_batch(const Options& o, SearchBatch& b) {
 }
 
 // ---- `search --bam` with the records handled where they are inflated (csrc/bam_device.hip): the host reads the file,
-// finds the BGZF members, hands runs of them to the GPUs and gets names, tags and SFS back.  Stages: scanner (loader
-// threads) -> batcher -> feeding threads (svdss_bam_batch_run, one batch object each) -> assembler (device batches end
-// where a BGZF member ends; the text is defined on batches of --bsize reads, ping_pong.cpp:213-236: the reads are dealt
-// again into units of whole reference batches) -> formatting threads -> writer.  The same bytes as the host path.
-static void search_bam_device(const Options& o, const std::vector<svdss_index_t*>& replicas, BgzfScanner& sc, int32_t n_ref,
-                              int64_t skip, const std::function<std::string()>& since) {
+// finds the BGZF members, hands runs of them to the GPUs and gets names, tags and SFS back.  Stages, PER REGION of the
+// file: scanner (loader threads) -> batcher -> feeding threads (svdss_bam_batch_run, one batch object each); then, once
+// for the file: assembler (device batches end where a BGZF member ends; the text is defined on batches of --bsize reads,
+// ping_pong.cpp:213-236: the reads are dealt again into units of whole reference batches) -> formatting threads ->
+// writer.  The same bytes as the host path.
+//
+// --gpus N (north_star: "BAM regions partition across the GPUs"; the per-shard loop of ping_pong.cpp:53-128): the file is
+// cut at BGZF members into N regions of about equal size, every GPU reads, inflates, walks and searches its own region
+// with its own scanner, batcher and feeders -- nothing is shared on the way in.  A region that does not begin the file
+// begins inside a record: its first batch starts the record chain at the first record its segments guess
+// (svdss_bam_stream_region) and sets the bytes in front aside; when the region before it has ended, what that one left
+// over and those bytes go through the device as a batch of their own (the SEAM: normally one record): if they are a
+// chain of whole records the guess is proved, if not -- or if the region failed in any way -- the region runs again from
+// the known carry.  The reads of a region are dealt into units when everything before it has been (the unit a read
+// belongs to depends on the reads in front of it), so the later regions' results wait in memory (~0.6 KB per read).
+struct DevJob { uint64_t seq = 0; bool last = false; std::vector<std::unique_ptr<CompChunk>> chunks; };
+struct DevOut { std::vector<Read> reads; std::vector<int32_t> qs, ln; int64_t n_short = 0; };
+struct BamRegion {
+  size_t begin = 0, end = 0;                 // file range (member starts)
+  std::unique_ptr<BgzfScanner> sc;
+  std::vector<svdss_index_t*> gpus;          // the replicas whose feeders take this region's batches
   svdss_bam_stream_t* stream = nullptr;
-  check(svdss_bam_stream_create(n_ref, &stream), "svdss_bam_stream_create");
+  int64_t skip = 0;                          // inflated bytes of BAM header in front (the file's first region)
+  bool open_start = false, open_end = false;
+  std::unique_ptr<BoundedQueue<DevJob>> jobs;
+  std::vector<std::thread> threads;          // batcher + feeders
+  // under dev_m:
+  std::map<uint64_t, std::unique_ptr<DevOut>> done;
+  bool finished = false;                     // its threads have ended
+  bool head_known = false;                   // batch 0 had its turn (svdss_bam_stream_head is final)
+  std::string error;                         // open_start only: why the run failed (the region runs again)
+};
+
+// where `n` regions of a file begin (member starts; [0] = 0, back() = file size): fewer than n for a small file
+static std::vector<size_t> plan_bam_regions(const std::string& path, int n, int64_t header_inflated) {
+  struct stat st;
+  std::vector<size_t> cuts{0};
+  if (stat(path.c_str(), &st) != 0 || st.st_size <= 0) return {0, 0};
+  const size_t fsize = (size_t)st.st_size;
+  const size_t min_bytes = getenv("SVDSS_REGION_MIN_KB") && atoll(getenv("SVDSS_REGION_MIN_KB")) > 0 ? (size_t)atoll(getenv("SVDSS_REGION_MIN_KB")) << 10
+                                                                                                         : (size_t)64 << 20;
+  // (the first region holds the whole BAM header)
+  const size_t first_min = (size_t)header_inflated + ((size_t)header_inflated >> 6) + ((size_t)128 << 10);
+  if (getenv("SVDSS_REGION_SHARDS") && atoi(getenv("SVDSS_REGION_SHARDS")) == 0) n = 1;
+  n = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, fsize / min_bytes));
+  for (int g = 1; g < n; ++g) {
+    const size_t approx = std::max(first_min, (size_t)((unsigned __int128)fsize * (unsigned)g / (unsigned)n));
+    if (approx >= fsize) break;
+    const size_t c = BgzfScanner::member_start_near(path, approx);
+    if (c > cuts.back() && c < fsize) cuts.push_back(c);
+  }
+  cuts.push_back(fsize);
+  return cuts;
+}
+
+static void search_bam_device(const Options& o, const std::vector<svdss_index_t*>& replicas, std::vector<BamRegion>& regions,
+                              const BgzfScanner::Hooks& hooks, size_t slab, int loaders, size_t pool_chunks, int32_t n_ref,
+                              const std::function<std::string()>& since) {
   const int64_t super = std::max<int64_t>(o.bsize, 32768 / o.bsize * (int64_t)o.bsize);
   const int64_t target = (getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 192) << 20;
-  struct DevJob { uint64_t seq = 0; bool last = false; std::vector<std::unique_ptr<CompChunk>> chunks; };
-  struct DevOut { std::vector<Read> reads; std::vector<int32_t> qs, ln; };
-  BoundedQueue<DevJob> jobs(2);
+  const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   std::mutex t_m;
   double t_gpu = 0, t_inflate_ms = 0, t_build = 0, t_format = 0, t_write = 0, t_assemble = 0;
   double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  double t_wait_file = 0, t_wait_gpu = 0;       // (the batcher's alone)
+  double t_wait_file = 0, t_wait_gpu = 0;       // (the batchers')
   uint64_t n_seen = 0, n_batches = 0, total_sfs = 0;
+  int64_t n_seg_all = 0, n_rewalk_all = 0, n_seams = 0, n_reruns = 0;
+  const int32_t flags = (o.assemble ? SVDSS_SFS_ASSEMBLE : 0) | (o.putative ? SVDSS_BAM_PUTATIVE : 0);
 
-  std::thread batcher([&] {
+  // device batches in file order, region after region
+  std::mutex dev_m;
+  std::condition_variable dev_cv;
+  size_t cursor = 0;            // the region the assembler is taking batches from (under dev_m)
+
+  // what a batch object holds after its run -> reads with their SFS
+  auto collect = [&](svdss_bam_batch_t* batch, double gpu_s, std::chrono::steady_clock::time_point t1) {
+    svdss_bam_result_t r;
+    check(svdss_bam_batch_result(batch, &r), "svdss_bam_batch_result");
+    std::unique_ptr<DevOut> out(new DevOut);
+    out->n_short = r.n_short;
+    out->reads.resize((size_t)r.n_slots);
+    out->qs.assign(r.qs, r.qs + r.total_sfs);
+    out->ln.assign(r.len, r.len + r.total_sfs);
+    {
+      // (searched reads are numbered in slot order, so their SFS follow each other in slot order too)
+      int64_t acc = 0;
+      for (int64_t i = 0; i < r.n_slots; ++i) {
+        Read& rd = out->reads[(size_t)i];
+        rd.name.assign(r.names + r.name_off[i], (size_t)(r.name_off[i + 1] - r.name_off[i]));
+        rd.hp = r.hp[i];
+        if (r.sidx[i] < 0) { rd.count = -1; rd.first = acc; }
+        else { rd.first = acc; rd.count = r.counts[r.sidx[i]]; acc += rd.count; }
+      }
+    }
+    std::lock_guard<std::mutex> lk(t_m);
+    t_gpu += gpu_s; t_build += secs(t1, now()); t_inflate_ms += r.inflate_kernel_ms;
+    n_seen += (uint64_t)r.n_records; ++n_batches;
+    for (int k = 0; k < 8; ++k) t_stage[k] += r.stage_ms[k] * 1e-3;
+    return out;
+  };
+
+  auto batcher = [&](BamRegion& R) {
+    BgzfScanner& sc = *R.sc;
     std::unique_ptr<DevJob> cur(new DevJob);
     int64_t acc = 0;
     uint64_t seq = 0;
     bool any_last = false;
+    double w_file = 0, w_gpu = 0;
     for (;;) {
       const auto w0 = now();
       std::unique_ptr<CompChunk> c = sc.next();
-      t_wait_file += secs(w0, now());           // (the loaders behind: the file is what bounds the run)
+      w_file += secs(w0, now());           // (the loaders behind: the file is what bounds the run)
       if (!c) break;
       acc += c->inflated;
       const bool last = c->last;
@@ -358,84 +442,131 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
         cur->last = last;
         any_last = any_last || last;
         const auto w1 = now();
-        jobs.push(std::move(cur));
-        t_wait_gpu += secs(w1, now());          // (the feeding threads behind: the GPU side is)
+        R.jobs->push(std::move(cur));
+        w_gpu += secs(w1, now());          // (the feeding threads behind: the GPU side is)
         cur.reset(new DevJob);
         acc = 0;
       }
     }
-    if (!sc.error().empty()) die("error reading " + o.bam + ": " + sc.error());
-    if (!any_last) {            // (cannot happen with a readable file: the scanner marks the final slab)
+    if (!sc.error().empty()) {
+      if (!R.open_start) die("error reading " + o.bam + ": " + sc.error());
+      std::lock_guard<std::mutex> lk(dev_m);
+      if (R.error.empty()) R.error = sc.error();
+    } else if (!any_last) {            // (an empty region; cannot happen otherwise: the scanner marks the final slab)
       cur->seq = seq++;
       cur->last = true;
-      jobs.push(std::move(cur));
+      R.jobs->push(std::move(cur));
     }
-    jobs.close();
-  });
+    R.jobs->close();
+    std::lock_guard<std::mutex> lk(t_m);
+    t_wait_file += w_file; t_wait_gpu += w_gpu;
+  };
 
-  // device batches in file order
-  std::mutex dev_m;
-  std::condition_variable dev_cv;
-  std::map<uint64_t, std::unique_ptr<DevOut>> dev_done;
-  bool feeders_finished = false;
-  const int32_t flags = (o.assemble ? SVDSS_SFS_ASSEMBLE : 0) | (o.putative ? SVDSS_BAM_PUTATIVE : 0);
-  auto feeder = [&](svdss_index_t* ix) {
+  auto feeder = [&](BamRegion& R, size_t g, svdss_index_t* ix) {
     svdss_bam_batch_t* batch = nullptr;
     std::vector<const uint8_t*> comp;
     std::vector<int64_t> comp_bytes, n_blocks;
     std::vector<const svdss_bgzf_block_t*> blocks;
     std::vector<const uint32_t*> crcs;
-    while (std::unique_ptr<DevJob> job = jobs.pop()) {
+    while (std::unique_ptr<DevJob> job = R.jobs->pop()) {
       const auto t0 = now();
       comp.clear(); comp_bytes.clear(); n_blocks.clear(); blocks.clear(); crcs.clear();
       for (const std::unique_ptr<CompChunk>& c : job->chunks) {
         comp.push_back(c->data); comp_bytes.push_back((int64_t)c->n_bytes); n_blocks.push_back((int64_t)c->blocks.size());
         blocks.push_back(c->blocks.data()); crcs.push_back(c->crc.data());
       }
-      const int rc = svdss_bam_batch_run(stream, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? skip : 0, ix, (int32_t)comp.size(),
+      const int rc = svdss_bam_batch_run(R.stream, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? R.skip : 0, ix, (int32_t)comp.size(),
                                          comp.data(), comp_bytes.data(), blocks.data(), crcs.data(), n_blocks.data(), flags, &batch);
-      for (std::unique_ptr<CompChunk>& c : job->chunks) sc.recycle(std::move(c));
+      for (std::unique_ptr<CompChunk>& c : job->chunks) R.sc->recycle(std::move(c));
       if (rc != SVDSS_OK) {
         std::string msg = batch ? svdss_bam_batch_error(batch) : "";
-        if (msg.empty()) msg = svdss_bam_stream_error(stream);
+        if (msg.empty()) msg = svdss_bam_stream_error(R.stream);
+        if (R.open_start) {
+          // (a guess that was not a record can end in any of the messages below: the region runs again from the known
+          // carry and says then what a reader of the whole file would have said)
+          { std::lock_guard<std::mutex> lk(dev_m); if (R.error.empty()) R.error = msg.empty() ? svdss_strerror(rc) : msg; R.head_known = true; }
+          dev_cv.notify_all();
+          continue;   // (the stream has failed: the batches left return at once; the queue drains)
+        }
         if (msg.find("core.tid") != std::string::npos) die(msg);                       // ping_pong.cpp:76-79
         if (rc == SVDSS_EIO) die("error reading " + o.bam + ": " + msg);
         die(std::string("svdss_bam_batch_run: ") + svdss_strerror(rc) + " " + msg + " " + svdss_last_hip_error());
       }
       const auto t1 = now();
-      svdss_bam_result_t r;
-      check(svdss_bam_batch_result(batch, &r), "svdss_bam_batch_result");
-      for (int64_t k = 0; k < r.n_short; ++k) logmsg("warning", "Alignment filtered due to l_qseq. Why are we here? Please check");   // :70-75
-      std::unique_ptr<DevOut> out(new DevOut);
-      out->reads.resize((size_t)r.n_slots);
-      out->qs.assign(r.qs, r.qs + r.total_sfs);
-      out->ln.assign(r.len, r.len + r.total_sfs);
-      {
-        // (searched reads are numbered in slot order, so their SFS follow each other in slot order too)
-        int64_t acc = 0;
-        for (int64_t i = 0; i < r.n_slots; ++i) {
-          Read& rd = out->reads[(size_t)i];
-          rd.name.assign(r.names + r.name_off[i], (size_t)(r.name_off[i + 1] - r.name_off[i]));
-          rd.hp = r.hp[i];
-          if (r.sidx[i] < 0) { rd.count = -1; rd.first = acc; }
-          else { rd.first = acc; rd.count = r.counts[r.sidx[i]]; acc += rd.count; }
-        }
-      }
-      {
-        std::lock_guard<std::mutex> lk(t_m);
-        t_gpu += secs(t0, t1); t_build += secs(t1, now()); t_inflate_ms += r.inflate_kernel_ms;
-        n_seen += (uint64_t)r.n_records; ++n_batches;
-        for (int k = 0; k < 8; ++k) t_stage[k] += r.stage_ms[k] * 1e-3;
-      }
+      std::unique_ptr<DevOut> out = collect(batch, secs(t0, t1), t1);
       {
         std::unique_lock<std::mutex> lk(dev_m);
         const uint64_t sq = job->seq;
-        dev_cv.wait(lk, [&] { return dev_done.size() < 8 || dev_done.begin()->first > sq; });
-        dev_done[sq] = std::move(out);
+        // (only the region the assembler is at holds its feeders back; the others' results wait for their turn)
+        dev_cv.wait(lk, [&] { return cursor != g || R.done.size() < 8 || R.done.begin()->first > sq; });
+        R.done[sq] = std::move(out);
+        R.head_known = true;
       }
       dev_cv.notify_all();
     }
     svdss_bam_batch_free(batch);
+  };
+
+  auto launch = [&](BamRegion& R, size_t g, const uint8_t* carry, int64_t n_carry) {
+    if (!R.sc) R.sc.reset(new BgzfScanner(o.bam, hooks, slab, loaders, pool_chunks, R.begin, R.end));
+    if (!R.sc->ok()) die("cannot open " + o.bam);
+    check(svdss_bam_stream_create(n_ref, &R.stream), "svdss_bam_stream_create");
+    check(svdss_bam_stream_region(R.stream, R.open_start ? 1 : 0, R.open_end ? 1 : 0, carry, n_carry), "svdss_bam_stream_region");
+    R.jobs.reset(new BoundedQueue<DevJob>(2));
+    R.threads.emplace_back(batcher, std::ref(R));
+    for (svdss_index_t* ix : R.gpus)
+      for (int k = 0; k < per_gpu; ++k) R.threads.emplace_back(feeder, std::ref(R), g, ix);
+  };
+  auto join_region = [&](BamRegion& R) {
+    for (std::thread& th : R.threads) th.join();
+    R.threads.clear();
+    int64_t n_seg = 0;
+    const int64_t rew = svdss_bam_stream_rewalked(R.stream, &n_seg);
+    { std::lock_guard<std::mutex> lk(t_m); n_seg_all += n_seg; n_rewalk_all += rew; }
+    { std::lock_guard<std::mutex> lk(dev_m); R.finished = true; }
+    dev_cv.notify_all();
+  };
+
+  // the seam in front of region g: `tail` (what the region before left) + `head` (what region g set aside) as a stream of
+  // its own -- stored deflate blocks, the same entry point.  false: not a chain of whole records (the guess was wrong).
+  auto run_seam = [&](const uint8_t* tail, int64_t n_tail, const uint8_t* head, int64_t n_head, svdss_index_t* ix, std::unique_ptr<DevOut>& out) {
+    std::vector<uint8_t> bytes((size_t)(n_tail + n_head));
+    if (n_tail) memcpy(bytes.data(), tail, (size_t)n_tail);
+    if (n_head) memcpy(bytes.data() + n_tail, head, (size_t)n_head);
+    std::vector<uint8_t> comp;
+    std::vector<svdss_bgzf_block_t> blk;
+    std::vector<uint32_t> crc;
+    for (size_t off = 0; off < bytes.size(); off += 0xff00) {
+      const size_t len = std::min<size_t>(0xff00, bytes.size() - off);
+      while (comp.size() & 15) comp.push_back(0);
+      svdss_bgzf_block_t b;
+      b.coff = (int64_t)comp.size(); b.clen = (int32_t)(5 + len); b.isize = (int32_t)len; b.uoff = 0;
+      comp.push_back(1);   // BFINAL, stored
+      comp.push_back((uint8_t)(len & 0xff)); comp.push_back((uint8_t)(len >> 8));
+      comp.push_back((uint8_t)(~len & 0xff)); comp.push_back((uint8_t)((~len >> 8) & 0xff));
+      comp.insert(comp.end(), bytes.begin() + (long)off, bytes.begin() + (long)(off + len));
+      blk.push_back(b);
+      crc.push_back((uint32_t)crc32(crc32(0L, Z_NULL, 0), bytes.data() + off, (uInt)len));
+    }
+    comp.resize(comp.size() + 64);
+    svdss_bam_stream_t* st = nullptr;
+    check(svdss_bam_stream_create(n_ref, &st), "svdss_bam_stream_create");
+    svdss_bam_batch_t* batch = nullptr;
+    const uint8_t* cp = comp.data();
+    const int64_t cb = (int64_t)comp.size(), nb = (int64_t)blk.size();
+    const svdss_bgzf_block_t* bp = blk.data();
+    const uint32_t* rp = crc.data();
+    const auto t0 = now();
+    const int rc = svdss_bam_batch_run(st, 0, 1, 0, ix, 1, &cp, &cb, &bp, &rp, &nb, flags, &batch);
+    bool ok = rc == SVDSS_OK;
+    if (ok) { const auto t1 = now(); out = collect(batch, secs(t0, t1), t1); }
+    else {
+      const std::string msg = batch ? svdss_bam_batch_error(batch) : "";
+      if (rc != SVDSS_EIO) die(std::string("svdss_bam_batch_run (seam): ") + svdss_strerror(rc) + " " + msg + " " + svdss_last_hip_error());
+    }
+    svdss_bam_batch_free(batch);
+    svdss_bam_stream_free(st);
+    return ok;
   };
 
   // units of whole reference batches, formatted by a few threads, written in order
@@ -457,27 +588,18 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     return b;
   };
   std::thread assembler([&] {
-    uint64_t want = 0, unit_seq = 0;
+    uint64_t unit_seq = 0;
     std::unique_ptr<SearchBatch> unit = new_unit();
-    for (;;) {
-      std::unique_ptr<DevOut> d;
-      {
-        std::unique_lock<std::mutex> lk(dev_m);
-        dev_cv.wait(lk, [&] { return dev_done.count(want) || (feeders_finished && dev_done.empty()); });
-        auto it = dev_done.find(want);
-        if (it == dev_done.end()) break;
-        d = std::move(it->second);
-        dev_done.erase(it);
-        ++want;
-      }
-      dev_cv.notify_all();
+    auto deal = [&](DevOut& d) {
       const auto ta = now();
-      for (Read& r : d->reads) {
+      // (said when the batch is dealt, not when it was read: a region that runs twice says it once)
+      for (int64_t k = 0; k < d.n_short; ++k) logmsg("warning", "Alignment filtered due to l_qseq. Why are we here? Please check");   // :70-75
+      for (Read& r : d.reads) {
         const int64_t first = r.first;
         r.first = (int64_t)unit->qs.size();
         if (r.count > 0) {
-          unit->qs.insert(unit->qs.end(), d->qs.begin() + first, d->qs.begin() + first + r.count);
-          unit->ln.insert(unit->ln.end(), d->ln.begin() + first, d->ln.begin() + first + r.count);
+          unit->qs.insert(unit->qs.end(), d.qs.begin() + first, d.qs.begin() + first + r.count);
+          unit->ln.insert(unit->ln.end(), d.ln.begin() + first, d.ln.begin() + first + r.count);
         }
         unit->reads.push_back(std::move(r));
         if ((int64_t)unit->reads.size() == super) {
@@ -487,6 +609,62 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
         }
       }
       t_assemble += secs(ta, now());
+    };
+    for (size_t g = 0; g < regions.size(); ++g) {
+      BamRegion& R = regions[g];
+      std::thread rerun_joiner;
+      if (g > 0) {
+        // the region in front has ended and is dealt: its tail is final.  This region's head: after its first batch.
+        BamRegion& P = regions[g - 1];
+        const uint8_t *tail = nullptr, *head = nullptr;
+        const int64_t n_tail = svdss_bam_stream_tail(P.stream, &tail);
+        bool good;
+        {
+          std::unique_lock<std::mutex> lk(dev_m);
+          dev_cv.wait(lk, [&] { return R.head_known || R.finished; });
+          good = R.error.empty();
+        }
+        std::unique_ptr<DevOut> seam;
+        if (good) {
+          const int64_t n_head = svdss_bam_stream_head(R.stream, &head);
+          if (n_tail + n_head > 0) { good = run_seam(tail, n_tail, head, n_head, R.gpus[0], seam); ++n_seams; }
+        }
+        if (!good) {
+          // not proved (or the region failed): once more, from the record the region before ended in
+          if (o.verbose) logmsg("debug", "region " + std::to_string(g) + " runs again from the end of region " + std::to_string(g - 1) +
+                                             (R.error.empty() ? std::string(" (its first record was not where the chain arrives)") : " (" + R.error + ")"));
+          {
+            std::unique_lock<std::mutex> lk(dev_m);
+            dev_cv.wait(lk, [&] { return R.finished; });   // (its first run: what is left of it ends at once, the stream has failed)
+            R.done.clear(); R.error.clear(); R.finished = false; R.head_known = false; R.open_start = false;
+          }
+          svdss_bam_stream_free(R.stream);
+          R.stream = nullptr;
+          R.sc.reset();
+          ++n_reruns;
+          launch(R, g, tail, n_tail);
+          rerun_joiner = std::thread([&join_region, &R] { join_region(R); });
+        } else if (seam) deal(*seam);
+        svdss_bam_stream_free(P.stream);
+        P.stream = nullptr;
+      }
+      { std::lock_guard<std::mutex> lk(dev_m); cursor = g; }
+      dev_cv.notify_all();
+      for (uint64_t want = 0;; ++want) {
+        std::unique_ptr<DevOut> d;
+        {
+          std::unique_lock<std::mutex> lk(dev_m);
+          dev_cv.wait(lk, [&] { return R.done.count(want) || !R.error.empty() || (R.finished && R.done.empty()); });
+          if (!R.error.empty()) die(R.error.find("core.tid") != std::string::npos ? R.error : "error reading " + o.bam + ": " + R.error);   // (after the proof: the file's own fault)
+          auto it = R.done.find(want);
+          if (it == R.done.end()) break;
+          d = std::move(it->second);
+          R.done.erase(it);
+        }
+        dev_cv.notify_all();
+        deal(*d);
+      }
+      if (rerun_joiner.joinable()) rerun_joiner.join();
     }
     if (!unit->reads.empty()) { unit->seq = unit_seq++; units.push(std::move(unit)); }
     units.close();
@@ -529,19 +707,15 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     fflush(stdout);
   });
   {
-    const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
     // (formatting the text costs about one core-second per million reads: five threads per GPU, as many as the cores allow)
     const int n_fmt = getenv("SVDSS_FORMAT_THREADS") ? std::max(1, atoi(getenv("SVDSS_FORMAT_THREADS")))
                                                      : (int)std::max<size_t>(5, std::min<size_t>(5 * replicas.size(), effective_cpus()));
     std::vector<std::thread> fmt;
     for (int k = 0; k < n_fmt; ++k) fmt.emplace_back(formatter);
-    std::vector<std::thread> feeders;
-    for (size_t d = 0; d < replicas.size(); ++d)
-      for (int k = 0; k < per_gpu; ++k) feeders.emplace_back(feeder, replicas[d]);
-    for (std::thread& th : feeders) th.join();
-    { std::lock_guard<std::mutex> lk(dev_m); feeders_finished = true; }
-    dev_cv.notify_all();
-    batcher.join();
+    for (size_t g = 0; g < regions.size(); ++g) launch(regions[g], g, nullptr, 0);
+    std::vector<std::thread> joiners;
+    for (BamRegion& R : regions) joiners.emplace_back([&join_region, &R] { join_region(R); });
+    for (std::thread& th : joiners) th.join();
     assembler.join();
     for (std::thread& th : fmt) th.join();
     { std::lock_guard<std::mutex> lk(done_m); format_finished = true; }
@@ -549,20 +723,21 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     writer.join();
   }
   if (o.verbose) {
-    int64_t n_seg = 0;
-    const int64_t rew = svdss_bam_stream_rewalked(stream, &n_seg);
     logmsg("debug", std::to_string(n_seen) + " records read, " + std::to_string(total_sfs) + " SFS written at +" + since() + " s");
-    logmsg("debug", "device path: " + std::to_string(n_batches) + " batches, " + std::to_string(n_seg) + " segments (" + std::to_string(rew) +
+    if (regions.size() > 1)
+      logmsg("debug", std::to_string(regions.size()) + " regions of the file, one per GPU: " + std::to_string(n_seams) + " seam(s) run, " +
+                          std::to_string(n_reruns) + " region(s) run again");
+    logmsg("debug", "device path: " + std::to_string(n_batches) + " batches, " + std::to_string(n_seg_all) + " segments (" + std::to_string(n_rewalk_all) +
                         " walked again); busy seconds: GPU batches " + std::to_string(t_gpu) + " (inflate kernels " + std::to_string(t_inflate_ms * 1e-3) +
                         "), result unpacking " + std::to_string(t_build) + ", re-dealing " + std::to_string(t_assemble) + ", format " + std::to_string(t_format) +
                         ", write " + std::to_string(t_write));
     char buf[480];
     snprintf(buf, sizeof buf, "device batches, seconds summed: upload+inflate+crc+walk %.3f, waiting for the turn %.3f, turn (carry, link) %.3f, "
-             "fields+scans %.3f, unpack %.3f, search %.3f, results down %.3f; the batcher waited %.3f s for the file's loaders and %.3f s for the feeding threads",
+             "fields+scans %.3f, unpack %.3f, search %.3f, results down %.3f; the batchers waited %.3f s for the file's loaders and %.3f s for the feeding threads",
              t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5], t_stage[6], t_wait_file, t_wait_gpu);
     logmsg("debug", buf);
   }
-  svdss_bam_stream_free(stream);
+  for (BamRegion& R : regions) if (R.stream) { svdss_bam_stream_free(R.stream); R.stream = nullptr; }
 }
 
 int main_search(const Options& o) {
@@ -577,7 +752,10 @@ int main_search(const Options& o) {
   // SVDSS_BAM_DEVICE=0: the host path below (BamReader: chunks inflated on the GPU or by the host pool, records sliced
   // on the host, packed bases uploaded) -- the tested fallback, and what a reader of stdin-like inputs needs.
   const bool dev_bam = bam_mode && svdss_device_count() > 0 && !(getenv("SVDSS_BAM_DEVICE") && atoi(getenv("SVDSS_BAM_DEVICE")) == 0);
-  std::unique_ptr<BgzfScanner> scanner;
+  std::vector<BamRegion> bam_regions;
+  BgzfScanner::Hooks bam_hooks;
+  size_t bam_slab = 0, bam_pool_chunks = 0;
+  int bam_loaders = 0;
   int32_t bam_n_ref = 0;
   int64_t bam_skip = 0;
   if (dev_bam) {
@@ -594,9 +772,28 @@ int main_search(const Options& o) {
     // slabs alive at once: those the loaders read ahead + those of the batches being fed, queued and cut
     const size_t per_batch = target / slab + 2;
     const int loaders = getenv("SVDSS_BAM_LOADERS") ? std::max(1, atoi(getenv("SVDSS_BAM_LOADERS"))) : 8;
-    scanner.reset(new BgzfScanner(o.bam, hooks, slab, loaders, (size_t)loaders + ((size_t)(n_g * per_gpu) + 3) * per_batch));
-    if (!scanner->ok()) die("cannot open " + o.bam);
-    if (!getenv("SVDSS_NO_PREWARM")) bam_prewarm = std::thread([&scanner] { scanner->prewarm(); });
+    // the file's regions, one per GPU (one region for a small file, or SVDSS_REGION_SHARDS=0: every GPU's feeders take its batches)
+    const std::vector<size_t> cuts = plan_bam_regions(o.bam, n_g, bam_skip);
+    bam_regions.resize(cuts.size() - 1);
+    bam_hooks = hooks; bam_slab = slab;
+    bam_loaders = bam_regions.size() > 1 ? std::max(2, std::min(loaders, (int)effective_cpus() / (int)bam_regions.size())) : loaders;
+    const size_t feeders_per_region = bam_regions.size() > 1 ? (size_t)per_gpu : (size_t)(n_g * per_gpu);
+    bam_pool_chunks = (size_t)bam_loaders + (feeders_per_region + 3) * per_batch;
+    for (size_t g = 0; g < bam_regions.size(); ++g) {
+      BamRegion& R = bam_regions[g];
+      R.begin = cuts[g]; R.end = cuts[g + 1];
+      R.skip = g == 0 ? bam_skip : 0;
+      R.open_start = g > 0;
+      R.open_end = g + 1 < bam_regions.size();
+      R.sc.reset(new BgzfScanner(o.bam, hooks, slab, bam_loaders, bam_pool_chunks, R.begin, R.end));
+      if (!R.sc->ok()) die("cannot open " + o.bam);
+    }
+    if (!getenv("SVDSS_NO_PREWARM"))
+      bam_prewarm = std::thread([&bam_regions] {
+        std::vector<std::thread> th;
+        for (BamRegion& R : bam_regions) th.emplace_back([&R] { R.sc->prewarm(); });
+        for (std::thread& t : th) t.join();
+      });
   } else if (bam_mode) {
     // the reader's page-locked chunk buffers are allocated while the index is restored (BamReader::prewarm)
     bam = new BamReader(o.bam, o.io_threads);
@@ -658,14 +855,24 @@ int main_search(const Options& o) {
     if (bam_prewarm.joinable()) bam_prewarm.join();
     if (o.bsize <= 0) die("batch size smaller than the number of threads");
     logmsg("info", "Extracting SFS strings on the GPU (output order as with " + std::to_string(o.threads) + " threads)..");
-    search_bam_device(o, replicas, *scanner, bam_n_ref, bam_skip, since);
+    // region g on GPU g (one region: every GPU's feeders take its batches)
+    for (size_t g = 0; g < bam_regions.size(); ++g) {
+      if (bam_regions.size() == 1) bam_regions[g].gpus = replicas;
+      else bam_regions[g].gpus = {replicas[g % replicas.size()]};
+    }
+    if (o.verbose && bam_regions.size() > 1) {
+      std::string m = "file regions (bytes):";
+      for (const BamRegion& R : bam_regions) m += " " + std::to_string(R.end - R.begin);
+      logmsg("debug", m);
+    }
+    search_bam_device(o, replicas, bam_regions, bam_hooks, bam_slab, bam_loaders, bam_pool_chunks, bam_n_ref, since);
     if (!getenv("SVDSS_CLEAN_EXIT")) {
       logmsg("info", "All done! Runtime: " + std::to_string((long)(time(nullptr) - g_t0)) + " seconds");
       fflush(stdout);
       fflush(stderr);
       _exit(0);
     }
-    scanner.reset();
+    bam_regions.clear();
     for (svdss_index_t* r : replicas) svdss_index_free(r);
     return 0;
   }

@@ -2,7 +2,7 @@
 // fastx_reader.h, rld0.cpp) run over one input file, for tests/test_host_io_robustness.py: built with
 // -fsanitize=address,undefined, fed valid files and damaged ones.  A reader may accept a file or refuse it with its
 // error message; it may not read outside its buffers, overflow, throw out of main or hang.  Test infrastructure.
-//   host_io_harness bam <file> | bai <file.bam> | fastx <file> | fmd <file> | sidecar <file> | sfs <file> | scan <file.bam>
+//   host_io_harness bam <file> | bai <file.bam> | fastx <file> | fmd <file> | sidecar <file> | sfs <file> | scan <file.bam> | regions <file.bam>
 // exit 0: read to a clean end; 1: the reader reported an error (printed); anything else: a finding.
 #include <cstdint>
 #include <cstdio>
@@ -115,6 +115,52 @@ static int run_scan(const std::string& path) {
       ++n_rec;
     }
     printf("slab %zu: %ld members, %ld records\n", slab, n_members, n_rec);
+  }
+  return 0;
+}
+
+// round 5: the file cut into regions at BGZF members (BgzfScanner::member_start_near) and every region scanned on its own
+// (`SVDSS search --gpus N`): the members of the regions, in order, are the members of the file
+static int run_regions(const std::string& path) {
+  auto scan = [&](size_t begin, size_t end, std::vector<uint8_t>& stream, long& n_members) -> std::string {
+    BgzfScanner sc(path, BgzfScanner::Hooks(), (size_t)64 << 10, 3, 6, begin, end);
+    if (!sc.ok()) return "cannot open";
+    BgzfInflater inf;
+    while (std::unique_ptr<CompChunk> c = sc.next()) {
+      for (size_t i = 0; i < c->blocks.size(); ++i) {
+        const svdss_bgzf_block_t& b = c->blocks[i];
+        if (b.coff < 0 || b.clen < 0 || (size_t)(b.coff + b.clen) + 8 > c->n_bytes) return "finding: member outside the slab";
+        const size_t at = stream.size();
+        stream.resize(at + (size_t)b.isize);
+        if (b.isize && inf.run(c->data + b.coff, (size_t)b.clen, stream.data() + at, (uint32_t)b.isize, c->crc[i])) return "inflate / crc";
+        ++n_members;
+      }
+      sc.recycle(std::move(c));
+    }
+    return sc.error();
+  };
+  std::vector<uint8_t> whole;
+  long n_whole = 0;
+  const std::string e0 = scan(0, 0, whole, n_whole);
+  if (!e0.empty()) { printf("error: %s\n", e0.c_str()); return e0.rfind("finding", 0) == 0 ? 3 : 1; }
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) return 1;
+  const size_t fsize = (size_t)st.st_size;
+  for (int n : {2, 3, 7}) {
+    std::vector<size_t> cuts{0};
+    for (int g = 1; g < n; ++g) {
+      const size_t c = BgzfScanner::member_start_near(path, fsize * (size_t)g / (size_t)n);
+      if (c > cuts.back() && c < fsize) cuts.push_back(c);
+    }
+    cuts.push_back(fsize);
+    std::vector<uint8_t> joined;
+    long n_joined = 0;
+    for (size_t g = 0; g + 1 < cuts.size(); ++g) {
+      const std::string e = scan(cuts[g], cuts[g + 1], joined, n_joined);
+      if (!e.empty()) { printf("finding: region [%zu, %zu): %s\n", cuts[g], cuts[g + 1], e.c_str()); return 3; }
+    }
+    if (n_joined != n_whole || joined != whole) { printf("finding: %d regions hold %ld members, the file %ld\n", n, n_joined, n_whole); return 3; }
+    printf("%zu regions: %ld members, the file's\n", cuts.size() - 1, n_joined);
   }
   return 0;
 }
@@ -236,6 +282,7 @@ int main(int argc, char** argv) {
     else if (mode == "sidecar") rc = run_sidecar(path);
     else if (mode == "sfs") rc = run_sfs(path);
     else if (mode == "scan") rc = run_scan(path);
+    else if (mode == "regions") rc = run_regions(path);
   } catch (const std::exception& e) {
     printf("finding: exception out of a reader: %s\n", e.what());
     return 3;

@@ -253,6 +253,26 @@ def test_binary_device_path_writes_the_host_paths_bytes(case, tmp_path):
         assert dev2.stdout == host.stdout
         big = run({}, *extra)          # the default sizes: one batch
         assert big.stdout == host.stdout
+        # round 5: --gpus N cuts the file into N regions, each with its own scanner / batcher / feeders; a region's first
+        # record is guessed and proved at the seam.  SVDSS_REGION_TEST: 1 = every guess is no record (the regions fail
+        # and run again from the region before), 2 = the seams do not fit (the regions run again)
+        import re
+        for n, knob in ((4, None), (3, "1"), (2, "2"), (7, None)):
+            env = {"SVDSS_BAM_SLAB_KB": "64", "SVDSS_BAM_BATCH_MB": "1", "SVDSS_GPUS_OVERSUBSCRIBE": "1", "SVDSS_SEARCH_FEEDERS": "2",
+                   "SVDSS_REGION_MIN_KB": "128"}
+            if knob:
+                env["SVDSS_REGION_TEST"] = knob
+            sh = run(env, "--gpus", str(n), *extra)
+            m = re.search(r"(\d+) regions of the file, one per GPU: (\d+) seam\(s\) run, (\d+) region\(s\) run again", sh.stderr)
+            assert m and int(m.group(1)) == n, sh.stderr[-2000:]
+            assert sh.stdout == host.stdout, (n, knob)
+            assert sh.stderr.count("Alignment filtered due to l_qseq") == 8
+            if knob is None:
+                assert int(m.group(2)) >= n - 2 and m.group(3) == "0", [l for l in sh.stderr.splitlines() if "region" in l]
+            elif knob == "1":
+                assert m.group(3) == str(n - 1)
+            else:
+                assert int(m.group(3)) >= 1
     # damage through the binary: message + exit 1
     data = bytearray(bam.read_bytes())
     data[len(data) // 2] ^= 0x40

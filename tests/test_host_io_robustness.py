@@ -130,6 +130,21 @@ def test_device_path_host_side_on_damaged_files(harness, tmp_path):
     open(path, "wb").write(good)
     rc, out = run(harness, "scan", path)
     assert rc == 0 and out.count("300 records") == 2, out
+    # round 5: the same file as regions cut at BGZF members (`search --gpus N`): blocks of every size, one that is empty
+    rc, out = run(harness, "regions", path)
+    assert rc == 0 and out.count("the file's") == 3, out
+    odd = str(tmp_path / "odd.bam")
+    hdr0, body0 = _plain_bam(refs, recs)
+    parts, i, plain0 = [], 0, hdr0 + body0
+    while i < len(plain0):
+        n = int(rng.integers(1, 9000))
+        parts.append(W._bgzf_block(plain0[i:i + n]))
+        if rng.random() < 0.05:
+            parts.append(W._bgzf_block(b""))
+        i += n
+    open(odd, "wb").write(b"".join(parts) + W._bgzf_block(b""))
+    rc, out = run(harness, "regions", odd)
+    assert rc == 0 and out.count("the file's") == 3, out
     hdr, body = _plain_bam(refs, recs)
     plain = hdr + body
     n_err = n_ok = 0
@@ -180,6 +195,7 @@ def test_device_path_host_side_on_damaged_files(harness, tmp_path):
         rc, out = run(harness, "scan", path)
         n_err += rc == 1
         n_ok += rc == 0
+        run(harness, "regions", path)                      # (an error or the file's members; never something else)
     assert n_err > 40 and n_ok > 15
 
 
