@@ -585,6 +585,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     // filled by running many of them, whichever launch they came from)
     struct Group {
       int cols = 0, gw = 0, max_len = 0;   // gw != 0: a launch of poa_quad.hip
+      int wave = 0;                        // groups of one wave of launches run together
       size_t lds = 0, bundle_lds = 0;
       std::vector<PoaWaveTask> tasks;
       std::vector<int64_t> ids;
@@ -612,7 +613,30 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     if (quad) {
       // wavefronts of sub-clusters that are alike (the groups of a wavefront walk in lock-step: it lasts as long as its
       // longest), the longest first; one launch per variant
-      std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) {
+      // A batch beyond the workspace budget (a whole genome's sub-clusters at once) runs in several waves of launches, and
+      // every wave lasts at least as long as its longest chain: the sub-clusters are dealt to the waves longest first, one
+      // each in turn, so that every wave has its share of long chains and of short ones to fill the machine beside them
+      // (rounds 2-4 cut the sorted list into consecutive pieces: the first wave was all long chains, the last all short).
+      std::vector<int> wave_of(cands.size(), 0);
+      {
+        size_t total = 0;
+        for (const Cand& cd : cands) total += sizeof(int32_t) * (size_t)poa_wave_ws_ints(cd.t.nc, cd.t.ec, cd.t.max_len, cd.t.ws) + (size_t)cd.t.nc + 256;
+        const size_t n_waves = std::max<size_t>(1, (total + ws_budget - ws_budget / 8 - 1) / (ws_budget - ws_budget / 8));
+        if (n_waves > 1 && !getenv("SVDSS_POA_NO_MIX")) {
+          std::vector<size_t> by_work(cands.size());
+          for (size_t i = 0; i < by_work.size(); ++i) by_work[i] = i;
+          std::sort(by_work.begin(), by_work.end(), [&](size_t x, size_t y) {
+            const int64_t wx = cands[x].t.n_seqs * (int64_t)cands[x].t.max_len, wy = cands[y].t.n_seqs * (int64_t)cands[y].t.max_len;
+            return wx != wy ? wx > wy : cands[x].c < cands[y].c;
+          });
+          for (size_t k = 0; k < by_work.size(); ++k) wave_of[by_work[k]] = (int)(k % n_waves);
+        }
+      }
+      std::vector<size_t> order(cands.size());
+      for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](size_t xi, size_t yi) {
+        const Cand &x = cands[xi], &y = cands[yi];
+        if (wave_of[xi] != wave_of[yi]) return wave_of[xi] < wave_of[yi];
         if (x.gw != y.gw) return x.gw > y.gw;
         if (x.cols != y.cols) return x.cols > y.cols;
         const int64_t wx = x.t.n_seqs * (int64_t)x.t.max_len, wy = y.t.n_seqs * (int64_t)y.t.max_len;
@@ -620,13 +644,14 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
         return x.c < y.c;
       });
       Group* g = nullptr;
-      for (Cand& cd : cands) {
+      for (size_t oi : order) {
+        Cand& cd = cands[oi];
         PoaWaveTask t = cd.t;
         const int64_t need = poa_wave_ws_ints(t.nc, t.ec, t.max_len, t.ws);
-        if (!g || g->gw != cd.gw || g->cols != cd.cols || g->w32 + need > group_budget32) {
+        if (!g || g->wave != wave_of[oi] || g->gw != cd.gw || g->cols != cd.cols || g->w32 + need > group_budget32) {
           groups.emplace_back(new Group);
           g = groups.back().get();
-          g->cols = cd.cols; g->gw = cd.gw; g->lds = cd.lds;
+          g->cols = cd.cols; g->gw = cd.gw; g->lds = cd.lds; g->wave = wave_of[oi];
         }
         g->max_len = std::max(g->max_len, (int)t.max_len);
         t.ws_off = g->w32; g->w32 += need;
@@ -662,7 +687,8 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     size_t gpos = 0;
     while (gpos < groups.size()) {
       size_t gend = gpos, tot_bytes = 0;
-      while (gend < groups.size() && (gend == gpos || tot_bytes + groups[gend]->bytes() <= ws_budget)) tot_bytes += groups[gend++]->bytes();
+      while (gend < groups.size() && (gend == gpos || (groups[gend]->wave == groups[gpos]->wave && tot_bytes + groups[gend]->bytes() <= ws_budget)))
+        tot_bytes += groups[gend++]->bytes();
       HIPCHK3(b->ws_arena.reserve(tot_bytes));
       for (size_t gi = gpos; gi < gend; ++gi) {
         Group& g = *groups[gi];
