@@ -89,6 +89,11 @@ int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out);
 int64_t svdss_index_device_bytes(const svdss_index_t* ix);
 /* order K of the k-mer table built by svdss_index_to_device (0 before / without it) */
 int32_t svdss_index_kmer(const svdss_index_t* ix);
+/* share of the k-mer occurrences (sampled while the table is built) that belong to k-mers with 8 or more of them: a
+ * reference rich in young repeat families has >= 0.35, and the search then finishes backward phases on deep intervals by
+ * binary search of the suffix array (the BS instantiation of the kernel; SVDSS_BS=0|1 overrides, SVDSS_BS_DEEP moves the
+ * threshold).  Results never depend on it. */
+double svdss_index_deep_frac(const svdss_index_t* ix);
 /* copy the index into the HBM of `device` (replicated per GPU): BWT blocks,
  * text, suffix array, and the 4^K k-mer table (K = floor(log4 n)+1, env SVDSS_KMER overrides) */
 int svdss_index_to_device(svdss_index_t* ix, int32_t device);
@@ -208,6 +213,7 @@ int64_t svdss_sfs_batch_total_ext(const svdss_sfs_batch_t* b);   /* sum of n_ext
  * how many reads had to be redone unsegmented because their chains could not be stitched. */
 int32_t svdss_sfs_batch_segments(const svdss_sfs_batch_t* b);
 int64_t svdss_sfs_batch_fallbacks(const svdss_sfs_batch_t* b);
+int32_t svdss_sfs_batch_used_bs(const svdss_sfs_batch_t* b);   /* 1: the last call launched the BS instantiation */
 /* duration of the search kernel(s) of the last call, from HIP events on its stream */
 double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b);
 /* HIP-event time of the search kernel alone (first pass; without ordering, stitching, assembling, gather) */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "svdss_index_bwt": (C.c_int, [_p, _p]),
     "svdss_index_device_bytes": (_i64, [_p]),
     "svdss_index_kmer": (_i32, [_p]),
+    "svdss_index_deep_frac": (C.c_double, [_p]),
     "svdss_index_to_device": (C.c_int, [_p, _i32]),
     "svdss_index_count": (_i64, [_p, _p, _i64]),
     "svdss_index_verify_device": (C.c_int, [_p, _i64, _p]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "svdss_sfs_batch_search_kernel_ms": (C.c_double, [_p]),
     "svdss_sfs_batch_segments": (_i32, [_p]),
     "svdss_sfs_batch_fallbacks": (_i64, [_p]),
+    "svdss_sfs_batch_used_bs": (_i32, [_p]),
     "svdss_sfs_batch_fetch": (C.c_int, [_p, _p, _p, _p, _p]),
     "svdss_sfs_batch_device_ptrs": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "svdss_sfs_batch_free": (None, [_p]),

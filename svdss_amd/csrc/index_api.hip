@@ -322,6 +322,7 @@ extern "C" int64_t svdss_index_device_bytes(const svdss_index_t* ix) {
 }
 
 extern "C" int32_t svdss_index_kmer(const svdss_index_t* ix) { return ix ? ix->table_k : -1; }
+extern "C" double svdss_index_deep_frac(const svdss_index_t* ix) { return ix ? ix->deep_frac : -1.0; }
 
 SvdssDevIndex svdss_device_view(const svdss_index* ix) {
   SvdssDevIndex v;

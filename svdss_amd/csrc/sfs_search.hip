@@ -678,6 +678,7 @@ struct svdss_sfs_batch {
   DevBuf seg_rec, seg_info, fallback, fallback2, seg_take, order, order_cnt, tiny;
   int64_t n_fallback = 0;   // reads of the last call that were redone unsegmented
   int32_t n_seg = 1;        // segments per read used by the last call
+  int32_t used_bs = 0;      // the last call launched the BS instantiation
   uint32_t epoch = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ek0 = nullptr, ek1 = nullptr;
   // host-buffer entry points: the batch object's own non-blocking stream (copies in, kernels, copies out), so that
@@ -723,6 +724,7 @@ extern "C" double svdss_sfs_batch_kernel_ms(const svdss_sfs_batch_t* b) { return
 extern "C" double svdss_sfs_batch_search_kernel_ms(const svdss_sfs_batch_t* b) { return b ? b->search_ms : -1.0; }
 extern "C" int32_t svdss_sfs_batch_segments(const svdss_sfs_batch_t* b) { return b ? b->n_seg : -1; }
 extern "C" int64_t svdss_sfs_batch_fallbacks(const svdss_sfs_batch_t* b) { return b ? b->n_fallback : -1; }
+extern "C" int32_t svdss_sfs_batch_used_bs(const svdss_sfs_batch_t* b) { return b ? b->used_bs : -1; }
 
 static int launch_grid(int device, int* blocks_out) {
   hipDeviceProp_t prop;
@@ -794,14 +796,18 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
   if (const char* e = getenv("SVDSS_SET")) p.use_set = atoi(e) != 0;
   // (BS needs the suffix array, a k-mer table, and few enough records for their '$' positions to sit in LDS)
   p.use_bs = p.ix.sa != nullptr && p.ix.k > 0 && p.ix.n_dollar > 0 && p.ix.n_dollar <= SV_BS_MAX_DOLLAR;
-  // The BS instantiation is opt-in (SVDSS_BS=1).  Measured at GRCh38 lengths with 45 % of the bases in 40 repeat families
-  // (profiles/r04h_search_bs.txt, ms per 1,048,576 reads, plain -> BS kernel): copies 1 % apart 408 -> 363, 5 % apart
-  // 197 -> 209, 15 % apart 103 -> 108, the headline reference 67.7 either way when the plain kernel is the one launched.
-  // Most of a real genome's repeats are old (15 %): the plain kernel is the better default; svdss_index::deep_frac (the
-  // share of K-mer occurrences in K-mers with SV_BS_MIN or more of them) says whether a reference has families at all.
-  bool use_bs_kernel = false;
-  if (const char* e = getenv("SVDSS_BS")) use_bs_kernel = p.use_bs && atoi(e) != 0;
+  // The BS instantiation is chosen by the reference (round 5; rounds 3-4: opt-in).  Measured at GRCh38 lengths with 45 % of
+  // the bases in 40 repeat families (profiles/r04h_search_bs.txt, ms per 1,048,576 reads, plain -> BS kernel): copies 1 %
+  // apart 408 -> 363, 5 % apart 197 -> 209, 15 % apart 103 -> 108, the headline reference 67.7 either way when the plain
+  // kernel is the one launched.  svdss_index::deep_frac (the share of K-mer occurrences in K-mers with SV_BS_MIN or more
+  // of them, sampled while the table is built) was 0.001 / 0.206 / 0.329 / 0.371 on the four: from 0.35 on the copies are
+  // young enough for the binary search to pay.  Most of a real genome's repeats are old: it keeps the plain kernel.
+  // SVDSS_BS=0|1 overrides, SVDSS_BS_DEEP moves the threshold.  Either kernel gives the same SFS and extension counts.
+  const double bs_deep = getenv("SVDSS_BS_DEEP") ? atof(getenv("SVDSS_BS_DEEP")) : 0.35;
+  bool use_bs_kernel = p.use_bs && ix->deep_frac >= bs_deep;
+  if (const char* e = getenv("SVDSS_BS")) if (*e == '0' || *e == '1') use_bs_kernel = p.use_bs && *e == '1';
   p.use_bs = use_bs_kernel;
+  b->used_bs = use_bs_kernel ? 1 : 0;
   p.ticket_chunk = 8;
   if (const char* e = getenv("SVDSS_TICKETS")) p.ticket_chunk = atoi(e) > 0 ? atoi(e) : 8;
   p.n_items = n_reads;

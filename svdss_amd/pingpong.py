@@ -125,6 +125,10 @@ class FMDIndex:
     def kmer_k(self) -> int:
         return lib.svdss_index_kmer(self._h)
 
+    @property
+    def deep_frac(self) -> float:
+        return lib.svdss_index_deep_frac(self._h)
+
     def bwt(self) -> np.ndarray:
         b = np.empty(self.size, dtype=np.uint8)
         check(lib.svdss_index_bwt(self._h, b.ctypes.data), "svdss_index_bwt")
@@ -254,6 +258,10 @@ class PingPong:
     @property
     def last_fallbacks(self) -> int:
         return lib.svdss_sfs_batch_fallbacks(self._batch)
+
+    @property
+    def last_used_bs(self) -> bool:
+        return lib.svdss_sfs_batch_used_bs(self._batch) == 1
 
     @property
     def last_kernel_ms(self) -> float:

@@ -380,6 +380,45 @@ def test_low_copy_repeats_with_n_runs(monkeypatch, wide):
         pp.close()
 
 
+def test_binary_search_kernel_is_chosen_by_the_reference(monkeypatch):
+    """Round 5: the BS instantiation (deep backward phases finished by binary search of the suffix array) is launched when the
+    reference is rich in young repeat families (svdss_index_deep_frac >= 0.35), not for an iid one; SVDSS_BS=0|1 overrides;
+    every choice, on one-lane-per-read and segmented launches, gives the oracle's SFS and extension counts."""
+    fam = synth.make_family_reference([400000, 200000], seed=7, repeat_frac=0.6, divergence=0.01, n_families=6)
+    iid = synth.make_reference([300000], seed=8)
+    rng = np.random.default_rng(9)
+    for ref, expect_bs in ((fam, True), (iid, False)):
+        reads = []
+        for i in range(600):
+            c = ref[int(rng.integers(0, len(ref)))]
+            ln = int(rng.integers(1500, 6000))
+            a = int(rng.integers(0, len(c) - ln))
+            r = c[a:a + ln].copy()
+            e = rng.random(ln) < 0.005
+            r[e] = (r[e] - 1 + rng.integers(1, 4, size=int(e.sum()))) % 4 + 1
+            reads.append(r.astype(np.uint8))
+        flat, offs = svdss_amd.pack_reads(reads)
+        monkeypatch.setenv("SVDSS_KMER", "10")     # (a table order at which the small reference has deep k-mers at all)
+        ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+        assert (ix.deep_frac >= 0.35) == expect_bs, ix.deep_frac
+        fm = O.OracleFMD.build(ref)
+        c, q, l, e = fm.search_batch(flat, offs, False)
+        for bs_env, segs in ((None, "1"), (None, "8"), ("0", "8"), ("1", "1"), ("1", "8")):
+            if bs_env is None:
+                monkeypatch.delenv("SVDSS_BS", raising=False)
+            else:
+                monkeypatch.setenv("SVDSS_BS", bs_env)
+            monkeypatch.setenv("SVDSS_SEGMENTS", segs)
+            pp = svdss_amd.PingPong(ix, assemble=False)
+            got = pp.ping_pong_search(flat, offs)
+            assert pp.last_used_bs == (expect_bs if bs_env is None else bs_env == "1")
+            assert pp.last_segments == int(segs)
+            assert (got.counts == c).all() and (got.n_ext == e).all()
+            assert (got.qs == q).all() and (got.len == l).all()
+            pp.close()
+        del ix
+
+
 def test_gpu_suffix_sorter_builds_the_same_index(monkeypatch, tmp_path):
     """`SVDSS index` sorts suffixes on the GPU when there is one (csrc/index_gpu.hip); the index file must be the one
     the host builder writes (the suffix array of a text is unique), including long repeats, N runs and several contigs."""
