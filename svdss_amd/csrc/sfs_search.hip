@@ -33,6 +33,19 @@ extern __device__ unsigned long long g_sfs_iters[64];
 #endif
 #include "sfs_core2.h"
 #include "sym_window.h"
+// profiling build (make searchprof -> libsvdss_hip_searchprof.so): shader-clock cycles per section of the main loop, summed over
+// the wavefronts -- [0] tickets + item start, [1] sv_decide, [2] addresses + loads issued, [3..] the apply of each operation
+// (which is where the wait for the loads lands), [15] passes
+#ifdef SV_PROF
+__device__ unsigned long long g_sfs_prof[16];
+#define SV_PROF_DECL unsigned long long pr_t = __builtin_readcyclecounter(), pr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SV_PROF_LAP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); pr_acc[k] += t_ - pr_t; pr_t = t_; } while (0)
+#define SV_PROF_OUT() do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 16; ++k_) atomicAdd(&g_sfs_prof[k_], pr_acc[k_]); } while (0)
+#else
+#define SV_PROF_DECL
+#define SV_PROF_LAP(k)
+#define SV_PROF_OUT()
+#endif
 
 // ---------------------------------------------------------------- kernels
 
@@ -151,6 +164,20 @@ __device__ unsigned long long g_sfs_iters[64];   // [0] wave iterations, [1] pas
 // counting build (make count -> libsvdss_hip_count.so, SVDSS_LIB selects it): lane operations of the launches since
 // the last report, by type -- what `useful_bytes` in profiles/traffic.json is computed from
 static void sfs_report_op_counts() {
+#ifdef SV_PROF
+  {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_prof), sizeof h) == hipSuccess) {
+      double tot = 0;
+      for (int k = 0; k < 15; ++k) tot += (double)h[k];
+      fprintf(stderr, "[svdss] search kernel, cycles per pass of a wavefront (%llu passes, %.0f cycles each): tickets/start %.0f decide %.0f addresses+issue %.0f | apply LF %.0f TABLE %.0f "
+              "SA %.0f TEXT %.0f SET %.0f SA_SET %.0f FILL %.0f | loop edge %.0f\n", h[15], tot / (double)h[15], (double)h[0] / h[15], (double)h[1] / h[15], (double)h[2] / h[15],
+              (double)h[3] / h[15], (double)h[4] / h[15], (double)h[5] / h[15], (double)h[6] / h[15], (double)h[7] / h[15], (double)h[8] / h[15], (double)h[9] / h[15], (double)h[14] / h[15]);
+    }
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sfs_prof), h, sizeof h);
+  }
+#endif
 #ifdef SV_COUNT_ITERS
   unsigned long long h[64];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sfs_iters), sizeof h) == hipSuccess) {
@@ -274,7 +301,12 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
   // Tickets come from a per-wavefront pool refilled ticket_chunk at a time: one atomic on the global counter per
   // chunk instead of one per item (2 M items serialise on that one address for ~20 ms otherwise).
   uint32_t pool_next = 0, pool_end = 0;   // wave-uniform
+  SV_PROF_DECL;
   for (;;) {
+    SV_PROF_LAP(14);
+#ifdef SV_PROF
+    pr_acc[15] += 1;
+#endif
     {
       const int lane = threadIdx.x & 63;
       const bool want = pf == 0 && (!active || st.pos - st.stop_lo < 256);   // idle, or close to the end of its item
@@ -329,7 +361,9 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
       }
       active = true;
     }
+    SV_PROF_LAP(0);
     const SvOp o = sv_decide(st, p.ix, g, off, assemble, emit, SEG && has_left, p.use_set != 0, BS);
+    SV_PROF_LAP(1);
 #ifdef SV_COUNT_ITERS
     if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(&g_sfs_iters[0], 1ULL);
     atomicAdd(&g_sfs_iters[2 + o.op], 1ULL);
@@ -455,17 +489,22 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
       B[2] = sv_load16(pb + 32);
       B[3] = sv_load16(pb + 48);
     }
+    SV_PROF_LAP(2);
     if (o.op == SV_OP_LF) {
       sv_apply_lf(st, p.ix, A, B, !need_b);
+      SV_PROF_LAP(3);
     } else if (o.op == SV_OP_TABLE) {
       sv_apply_table(st, p.ix, (uint64_t)A[0].x | ((uint64_t)A[0].y << 32),
                      (uint64_t)A[0].z | ((uint64_t)A[0].w << 32), g, off, p.use_set != 0 && off >= 64, BS && n_d > 0 && off >= 64);
+      SV_PROF_LAP(4);
     } else if (o.op == SV_OP_SA) {
       const int64_t tp = sizeof(P) == 4 ? (int64_t)A[0].x
                                         : (int64_t)((uint64_t)A[0].x | ((uint64_t)A[0].y << 32));
       sv_apply_sa(st, tp);
+      SV_PROF_LAP(5);
     } else if (o.op == SV_OP_TEXT) {
       sv_apply_text(st, A, B);
+      SV_PROF_LAP(6);
     } else if (BS && o.op == SV_OP_BS_SA) {
       const int64_t tp = sizeof(P) == 4 ? (int64_t)A[0].x
                                         : (int64_t)((uint64_t)A[0].x | ((uint64_t)A[0].y << 32));
@@ -476,11 +515,13 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
       sv_apply_bs_ord(st, p.ix, (int)(B[0].x & 0xffu), (int)(A[0].x & 0xffu));
     } else if (o.op == SV_OP_SET) {
       sv_apply_set(st, ts, A, B[0]);
+      SV_PROF_LAP(7);
     } else if (o.op == SV_OP_SA_SET) {
       int64_t tp[SV_SET_MAX];
 #pragma unroll
       for (int i = 0; i < SV_SET_MAX; ++i) tp[i] = (int64_t)((uint64_t)A[i].x | ((uint64_t)A[i].y << 32));
       sv_apply_sa_set(st, ts, tp);
+      SV_PROF_LAP(8);
     } else if (o.op == SV_OP_PEEK) {
       int32_t q[SV_PEEK_RECS];
       bool written[SV_PEEK_RECS];
@@ -497,8 +538,10 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
     } else {
       sv_ring_fill(g, c0, B);
       st.wrel = (int32_t)(16 * c0 - off);
+      SV_PROF_LAP(9);
     }
   }
+  SV_PROF_OUT();
 }
 
 // One lane per read: stitch the chains of its segments (sv_stitch), run the streaming
