@@ -1,4 +1,4 @@
-// bai_index.h -- BAI index and region-restricted reading of a BAM file.
+// bai_index.h -- BAI / CSI index and region-restricted reading of a BAM file.
 // Stands where htslib's sam_index_load / sam_itr_querys / sam_itr_next stand in /root/reference/clusterer.cpp:495-527
 // (fill_clusters queries "chrom:start-end" per cluster).  Here the regions of all clusters are turned into one sorted,
 // merged list of file chunks (virtual offsets) and read once, in file order: the same records in the same relative
@@ -18,15 +18,36 @@
 struct BaiIndex {
   struct Ref {
     std::vector<std::pair<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins;   // sorted by bin number
-    std::vector<uint64_t> linear;                                                          // 16 kb windows
+    std::vector<uint64_t> linear;                                                          // BAI: 16 kb windows
+    std::vector<std::pair<uint32_t, uint64_t>> loff;                                       // CSI: per bin, sorted like bins
   };
   std::vector<Ref> refs;
+  // the binning scheme: BAI is fixed at 14 / 5; a CSI index names its own (SAM specification 5.3, CSIv1: for references
+  // beyond 2^29 bases, or a finer / coarser smallest bin)
+  int min_shift = 14, depth = 5;
+  bool csi = false;
 
+  // .bai as written (BAI\1 ...) or .csi (BGZF-compressed, CSI\1 ...): what htslib's sam_index_load accepts for a BAM
   bool load(const std::string& path) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    bool ok = read_all(f);
-    fclose(f);
+    refs.clear();
+    std::vector<uint8_t> raw;
+    {
+      FILE* f = fopen(path.c_str(), "rb");
+      if (!f) return false;
+      uint8_t buf[1 << 16];
+      size_t k;
+      while ((k = fread(buf, 1, sizeof buf, f)) > 0) {
+        if (raw.size() + k > ((size_t)4 << 30)) { fclose(f); return false; }   // (an index, not a data file)
+        raw.insert(raw.end(), buf, buf + k);
+      }
+      fclose(f);
+    }
+    bool ok = false;
+    if (raw.size() >= 4 && memcmp(raw.data(), "BAI\1", 4) == 0) ok = parse(raw.data(), raw.size(), false);
+    else if (raw.size() >= 18 && raw[0] == 31 && raw[1] == 139) {
+      std::vector<uint8_t> plain;
+      if (inflate_all(raw, plain) && plain.size() >= 4 && memcmp(plain.data(), "CSI\1", 4) == 0) ok = parse(plain.data(), plain.size(), true);
+    }
     if (!ok) refs.clear();
     return ok;
   }
@@ -35,25 +56,37 @@ struct BaiIndex {
   void query(int tid, int64_t beg, int64_t end, std::vector<std::pair<uint64_t, uint64_t>>& out) const {
     if (tid < 0 || tid >= (int)refs.size() || end <= beg) return;
     if (beg < 0) beg = 0;
+    const int64_t span = (int64_t)1 << (min_shift + 3 * depth);   // positions the scheme can bin
+    if (beg >= span) return;
     const Ref& r = refs[(size_t)tid];
+    const int64_t e = std::min(end, span) - 1;
     uint64_t min_off = 0;
-    if (!r.linear.empty()) {
-      const size_t w = (size_t)(beg >> 14);
-      min_off = w < r.linear.size() ? r.linear[w] : r.linear.back();
+    if (!csi) {
+      if (!r.linear.empty()) {
+        const size_t w = (size_t)(beg >> 14);
+        min_off = w < r.linear.size() ? r.linear[w] : r.linear.back();
+      }
+    } else {
+      // the smallest bin that holds beg and is in the index says where the records that reach it begin; without one
+      // its parents do (their value is the smaller)
+      uint32_t bin = (uint32_t)(first_bin(depth) + (beg >> min_shift));
+      for (;;) {
+        auto it = std::lower_bound(r.loff.begin(), r.loff.end(), bin, [](const auto& a, uint32_t b) { return a.first < b; });
+        if (it != r.loff.end() && it->first == bin) { min_off = it->second; break; }
+        if (bin == 0) break;
+        bin = (bin - 1) >> 3;
+      }
     }
-    const int64_t e = end - 1;
     auto take = [&](uint32_t bin) {
       auto it = std::lower_bound(r.bins.begin(), r.bins.end(), bin, [](const auto& a, uint32_t b) { return a.first < b; });
       if (it == r.bins.end() || it->first != bin) return;
       for (const auto& c : it->second)
         if (c.second > min_off) out.emplace_back(std::max(c.first, min_off), c.second);
     };
-    take(0);
-    for (int64_t k = 1 + (beg >> 26); k <= 1 + (e >> 26); ++k) take((uint32_t)k);
-    for (int64_t k = 9 + (beg >> 23); k <= 9 + (e >> 23); ++k) take((uint32_t)k);
-    for (int64_t k = 73 + (beg >> 20); k <= 73 + (e >> 20); ++k) take((uint32_t)k);
-    for (int64_t k = 585 + (beg >> 17); k <= 585 + (e >> 17); ++k) take((uint32_t)k);
-    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (e >> 14); ++k) take((uint32_t)k);
+    for (int l = 0; l <= depth; ++l) {
+      const int sh = min_shift + 3 * (depth - l);
+      for (int64_t k = beg >> sh; k <= e >> sh; ++k) take((uint32_t)(first_bin(l) + k));
+    }
   }
 
   // sorted, overlapping / touching chunks merged
@@ -68,40 +101,84 @@ struct BaiIndex {
   }
 
  private:
-  bool read_all(FILE* f) {
-    char magic[4];
-    int32_t n_ref;
-    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "BAI\1", 4) != 0 || fread(&n_ref, 4, 1, f) != 1 || n_ref < 0) return false;
-    // a count in the file is believed only as far as the file has bytes for what it counts: a damaged index is
-    // refused, not answered with an allocation of gigabytes
-    uint64_t left = 0;
-    {
-      const off_t here = ftello(f);
-      if (here < 0 || fseeko(f, 0, SEEK_END) != 0) return false;
-      const off_t end = ftello(f);
-      if (end < here || fseeko(f, here, SEEK_SET) != 0) return false;
-      left = (uint64_t)(end - here);
+  static int64_t first_bin(int level) { return (((int64_t)1 << (3 * level)) - 1) / 7; }
+
+  static bool inflate_all(const std::vector<uint8_t>& raw, std::vector<uint8_t>& out) {
+    BgzfInflater inf;
+    size_t pos = 0;
+    while (pos < raw.size()) {
+      if (pos + 18 > raw.size()) return false;
+      const uint8_t* h = raw.data() + pos;
+      uint16_t xlen, bsize;
+      memcpy(&xlen, h + 10, 2);
+      if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4) || xlen != 6 || h[12] != 'B' || h[13] != 'C') return false;
+      memcpy(&bsize, h + 16, 2);
+      if ((size_t)bsize + 1 < 18u + 8u || pos + (size_t)bsize + 1 > raw.size()) return false;
+      const size_t clen = (size_t)bsize + 1 - 18 - 8;
+      uint32_t crc, isize;
+      memcpy(&crc, h + 18 + clen, 4);
+      memcpy(&isize, h + 18 + clen + 4, 4);
+      if (isize > 65536u || out.size() + isize > ((size_t)4 << 30)) return false;
+      const size_t at = out.size();
+      out.resize(at + isize);
+      if (isize && inf.run(h + 18, clen, out.data() + at, isize, crc)) return false;
+      pos += (size_t)bsize + 1;
     }
-    auto fits = [&](uint64_t count, uint64_t bytes_each) { return count <= left / bytes_each; };
-    if (!fits((uint64_t)n_ref, 8)) return false;
+    return true;
+  }
+
+  // a count in the file is believed only as far as the file has bytes for what it counts: a damaged index is
+  // refused, not answered with an allocation of gigabytes
+  struct Cur {
+    const uint8_t* p;
+    size_t left;
+    bool get(void* dst, size_t n) {
+      if (n > left) return false;
+      memcpy(dst, p, n);
+      p += n; left -= n;
+      return true;
+    }
+    bool skip(size_t n) { if (n > left) return false; p += n; left -= n; return true; }
+    bool fits(uint64_t count, uint64_t bytes_each) const { return count <= left / bytes_each; }
+  };
+
+  bool parse(const uint8_t* data, size_t size, bool is_csi) {
+    Cur c{data + 4, size - 4};
+    csi = is_csi;
+    min_shift = 14; depth = 5;
+    if (is_csi) {
+      int32_t ms, dp, l_aux;
+      if (!c.get(&ms, 4) || !c.get(&dp, 4) || !c.get(&l_aux, 4) || l_aux < 0 || !c.skip((size_t)l_aux)) return false;
+      if (ms < 1 || ms > 40 || dp < 0 || dp > 10 || ms + 3 * dp > 62) return false;   // (bin numbers stay below 2^31)
+      min_shift = ms; depth = dp;
+    }
+    int32_t n_ref;
+    if (!c.get(&n_ref, 4) || n_ref < 0 || !c.fits((uint64_t)n_ref, is_csi ? 4 : 8)) return false;
+    const uint32_t meta_bin = (uint32_t)(first_bin(depth + 1) + 1);   // htslib's metadata pseudo-bin (37450 for BAI)
     refs.resize((size_t)n_ref);
     for (Ref& r : refs) {
       int32_t n_bin;
-      if (fread(&n_bin, 4, 1, f) != 1 || n_bin < 0 || !fits((uint64_t)n_bin, 8)) return false;
+      if (!c.get(&n_bin, 4) || n_bin < 0 || !c.fits((uint64_t)n_bin, is_csi ? 16 : 8)) return false;
       for (int32_t b = 0; b < n_bin; ++b) {
         uint32_t bin;
+        uint64_t lo = 0;
         int32_t n_chunk;
-        if (fread(&bin, 4, 1, f) != 1 || fread(&n_chunk, 4, 1, f) != 1 || n_chunk < 0 || !fits((uint64_t)n_chunk, 16)) return false;
+        if (!c.get(&bin, 4) || (is_csi && !c.get(&lo, 8)) || !c.get(&n_chunk, 4) || n_chunk < 0 || !c.fits((uint64_t)n_chunk, 16)) return false;
         std::vector<std::pair<uint64_t, uint64_t>> ch((size_t)n_chunk);
-        for (auto& c : ch)
-          if (fread(&c.first, 8, 1, f) != 1 || fread(&c.second, 8, 1, f) != 1) return false;
-        if (bin != 37450) r.bins.emplace_back(bin, std::move(ch));   // (37450: htslib's metadata pseudo-bin)
+        for (auto& k : ch)
+          if (!c.get(&k.first, 8) || !c.get(&k.second, 8)) return false;
+        if (bin == meta_bin) continue;
+        r.bins.emplace_back(bin, std::move(ch));
+        if (is_csi) r.loff.emplace_back(bin, lo);
       }
       std::sort(r.bins.begin(), r.bins.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-      int32_t n_intv;
-      if (fread(&n_intv, 4, 1, f) != 1 || n_intv < 0 || !fits((uint64_t)n_intv, 8)) return false;
-      r.linear.resize((size_t)n_intv);
-      if (n_intv && fread(r.linear.data(), 8, (size_t)n_intv, f) != (size_t)n_intv) return false;
+      std::sort(r.loff.begin(), r.loff.end());
+      if (!is_csi) {
+        int32_t n_intv;
+        if (!c.get(&n_intv, 4) || n_intv < 0 || !c.fits((uint64_t)n_intv, 8)) return false;
+        r.linear.resize((size_t)n_intv);
+        if (n_intv && !c.get(r.linear.data(), 8 * (size_t)n_intv)) return false;
+      }
     }
     return true;
   }

@@ -925,9 +925,10 @@ struct CallRun {
         BaiIndex bai;
         bool have_bai = false;
         if (!getenv("SVDSS_CALL_NO_BAI")) {
-          have_bai = bai.load(o.bam + ".bai");
-          if (!have_bai && o.bam.size() > 4 && o.bam.compare(o.bam.size() - 4, 4, ".bam") == 0)
-            have_bai = bai.load(o.bam.substr(0, o.bam.size() - 4) + ".bai");
+          // (x.bam.bai, x.bai, x.bam.csi, x.csi: the names htslib's sam_index_load looks for)
+          const std::string stem = o.bam.size() > 4 && o.bam.compare(o.bam.size() - 4, 4, ".bam") == 0 ? o.bam.substr(0, o.bam.size() - 4) : std::string();
+          have_bai = bai.load(o.bam + ".bai") || (!stem.empty() && bai.load(stem + ".bai")) || bai.load(o.bam + ".csi") ||
+                     (!stem.empty() && bai.load(stem + ".csi"));
           if (have_bai && bai.refs.size() != ref_names.size()) have_bai = false;
         }
         std::vector<std::pair<uint64_t, uint64_t>> chunks;
@@ -959,7 +960,7 @@ struct CallRun {
           }
         }
         if (have_bai) {
-          logmsg("debug", "pass 2 through the BAI index: " + std::to_string(n_regions) + " regions, " + std::to_string(chunks.size()) +
+          logmsg("debug", std::string("pass 2 through the ") + (bai.csi ? "CSI" : "BAI") + " index: " + std::to_string(n_regions) + " regions, " + std::to_string(chunks.size()) +
                               " file chunks");
           const std::string e = bam_scan_chunks(o.bam, chunks, [&](const BamReader::RawView& rr) { process(rr, qname, apply); });
           if (!e.empty()) die("error reading " + o.bam + ": " + e);

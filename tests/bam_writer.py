@@ -65,6 +65,82 @@ def reg2bin(beg: int, end: int) -> int:
     return 0
 
 
+def reg2bin_csi(beg: int, end: int, min_shift: int, depth: int) -> int:
+    """SAM specification, section 5.3, the general scheme of CSI (0-based half-open [beg, end))"""
+    end -= 1
+    s, t = min_shift, ((1 << (depth * 3)) - 1) // 7
+    for l in range(depth, 0, -1):
+        if beg >> s == end >> s:
+            return t + (beg >> s)
+        s += 3
+        t -= 1 << ((l - 1) * 3)
+    return 0
+
+
+def csi(bam_bytes: bytes, min_shift: int = 14, depth: int = 5) -> bytes:
+    """A CSI index (CSIv1) of a coordinate-sorted BAM: the bins of the (min_shift, depth) scheme with their chunks and,
+    per bin, loffset = the smallest virtual offset of a record that reaches into the bin's range; BGZF-compressed as
+    `samtools index -c` writes it."""
+    import zlib
+    blocks, data, pos = [], bytearray(), 0
+    while pos + 18 <= len(bam_bytes):
+        bsize = struct.unpack_from("<H", bam_bytes, pos + 16)[0] + 1
+        raw = zlib.decompress(bam_bytes[pos + 18:pos + bsize - 8], -15)
+        blocks.append((pos, len(data), len(raw)))
+        data += raw
+        pos += bsize
+    import bisect
+    nonempty = [b for b in blocks if b[2] > 0]
+    starts = [b[1] for b in nonempty]
+
+    def voff(u):
+        k = max(bisect.bisect_left(starts, u) - 1, 0)
+        c, s, n = nonempty[k]
+        return (c << 16) | (u - s)
+
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    n_ref = struct.unpack_from("<i", data, 8 + l_text)[0]
+    p = 12 + l_text
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", data, p)[0]
+        p += 8 + l_name
+    bins = [dict() for _ in range(n_ref)]
+    loff = [dict() for _ in range(n_ref)]
+    while p + 4 <= len(data):
+        bs = struct.unpack_from("<i", data, p)[0]
+        tid, start = struct.unpack_from("<ii", data, p + 4)
+        l_name = data[p + 12]
+        n_cig = struct.unpack_from("<H", data, p + 16)[0]
+        ref_len = 0
+        for k in range(n_cig):
+            c = struct.unpack_from("<I", data, p + 36 + l_name + 4 * k)[0]
+            if (c & 15) in (0, 2, 3, 7, 8):
+                ref_len += c >> 4
+        end = start + max(ref_len, 1)
+        v0, v1 = voff(p), voff(p + 4 + bs)
+        if tid >= 0:
+            ch = bins[tid].setdefault(reg2bin_csi(start, end, min_shift, depth), [])
+            if ch and ch[-1][1] == v0:
+                ch[-1][1] = v1
+            else:
+                ch.append([v0, v1])
+            # every bin of every level the record reaches into
+            for l in range(depth + 1):
+                sh = min_shift + 3 * (depth - l)
+                t = ((1 << (3 * l)) - 1) // 7
+                for k in range(start >> sh, ((end - 1) >> sh) + 1):
+                    loff[tid].setdefault(t + k, v0)
+        p += 4 + bs
+    out = bytearray(b"CSI\1" + struct.pack("<iii", min_shift, depth, 0) + struct.pack("<i", n_ref))
+    for t in range(n_ref):
+        out += struct.pack("<i", len(bins[t]))
+        for b in sorted(bins[t]):
+            out += struct.pack("<IQi", b, loff[t][b], len(bins[t][b]))
+            for v0, v1 in bins[t][b]:
+                out += struct.pack("<QQ", v0, v1)
+    return bgzf(bytes(out))
+
+
 def bai(bam_bytes: bytes) -> bytes:
     """A BAI index of a coordinate-sorted BAM as `samtools index` writes it (SAM specification 5.2): bins with their
     chunks (virtual offsets, adjacent chunks of a bin merged), the 16 kb linear index, without the metadata pseudo-bin.

@@ -52,8 +52,8 @@ def test_regions_through_the_index_are_the_overlapping_records_of_a_sequential_r
     seq_read = _lines(subprocess.run([exe, str(bam), "-"], capture_output=True, text=True, check=True).stdout)
     assert seq_read == [(n, str(t), str(p)) for n, t, p, e in meta]
 
-    def through_index(regions):
-        r = subprocess.run([exe, str(bam), str(bai)] + [f"{t}:{b}-{e}" for t, b, e in regions], capture_output=True, text=True)
+    def through_index(regions, index=None):
+        r = subprocess.run([exe, str(bam), str(index or bai)] + [f"{t}:{b}-{e}" for t, b, e in regions], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         return _lines(r.stdout)
 
@@ -75,6 +75,37 @@ def test_regions_through_the_index_are_the_overlapping_records_of_a_sequential_r
         assert len(set(got)) == len(got), regions
     # the index is worth having: a small region reads a small part of the file
     assert len(through_index([(0, 1_000_000, 1_000_001)])) < len(meta) // 10
+    # round 5: CSI indexes (what `samtools index -c` writes; htslib's sam_index_load takes either): the BAI scheme and
+    # three others -- a deeper tree, finer and coarser smallest bins
+    for ms, dp in ((14, 5), (14, 6), (12, 5), (16, 3)):
+        csi = tmp_path / f"x.{ms}.{dp}.csi"
+        csi.write_bytes(bam_writer.csi(data, ms, dp))
+        for regions in cases:
+            got = through_index(regions, csi)
+            want = overlapping(regions)
+            assert [g for g in got if g in set(want)] == want, (ms, dp, regions)
+            assert len(set(got)) == len(got), (ms, dp, regions)
+        assert len(through_index([(0, 1_000_000, 1_000_001)], csi)) < len(meta) // 10
+    # a damaged CSI is refused or answers with chunks of the file; it is never believed beyond its bytes
+    good = bam_writer.csi(data, 14, 5)
+    import zlib
+    plain = bytearray()
+    pos = 0
+    while pos + 18 <= len(good):
+        bsize = int.from_bytes(good[pos + 16:pos + 18], "little") + 1
+        plain += zlib.decompress(good[pos + 18:pos + bsize - 8], -15)
+        pos += bsize
+    for k in range(60):
+        d = bytearray(plain)
+        if k % 3 == 0:
+            d = d[:int(rng.integers(0, len(d)))]
+        else:
+            at = int(rng.integers(4, min(len(d), 400)))
+            d[at:at + 4] = int(rng.choice([-1, 2**31 - 1, 2**30, 0, 7])).to_bytes(4, "little", signed=True)
+        bad = tmp_path / "bad.csi"
+        bad.write_bytes(bam_writer.bgzf(bytes(d)))
+        r = subprocess.run([exe, str(bam), str(bad), "0:0-3000000"], capture_output=True, text=True, timeout=60)
+        assert r.returncode in (0, 1), r.stderr[-300:]
 
 
 def test_corrupt_block_headers_are_reported_not_followed(tmp_path, exe):

@@ -66,18 +66,21 @@ def test_chr20_10x_end_to_end(tmp_path):
     # the second BAM pass without the records of pass 1 in memory: the whole file again, or -- with a BAI index beside
     # the file, as the reference requires -- only the chunks the index names for the cluster regions (records here
     # straddle BGZF blocks, chunks start and end inside blocks): the same VCF
-    for with_bai in (False, True):
+    for with_bai in (False, "csi", True):
         if with_bai:
             from tests import bam_writer
             with open(bam, "rb") as fh:
-                idx = bam_writer.bai(fh.read())
-            with open(bam + ".bai", "wb") as fh:
+                idx = bam_writer.csi(fh.read(), 14, 6) if with_bai == "csi" else bam_writer.bai(fh.read())
+            if with_bai is True:
+                os.remove(bam + ".csi")
+            with open(bam + (".csi" if with_bai == "csi" else ".bai"), "wb") as fh:
                 fh.write(idx)
         r_p2 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4",
                                "--min-sv-length", "50", "--verbose"], capture_output=True, text=True,
                               env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai"))
         assert r_p2.returncode == 0, r_p2.stderr[-500:]
-        assert ("through the BAI index" in r_p2.stderr) == with_bai
+        assert ("through the BAI index" in r_p2.stderr) == (with_bai is True)
+        assert ("through the CSI index" in r_p2.stderr) == (with_bai == "csi")
         assert r_p2.stdout == vcf
         # (and the host reader without its cache, with and without the index; with the index present the device path may
         # still read the whole file when the chunks the index names are a large part of it: SVDSS_CALL_PASS2=device)
