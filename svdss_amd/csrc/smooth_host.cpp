@@ -176,15 +176,25 @@ void write_record(ByteSink& w, const BamRecord& r, const std::vector<uint32_t>& 
 
 int main_smooth(const CallOptions& o) {
   std::unordered_map<std::string, std::string> chrom;
+  const auto t_fasta0 = std::chrono::steady_clock::now();
   {
-    FastxReader fx(o.reference);
-    if (!fx.ok()) die("cannot open " + o.reference);
-    std::string name, seq;
-    while (fx.next(name, seq)) {
-      for (char& c : seq) c = (char)(c - ((c >= 'a' && c <= 'z') ? 32 : 0));   // toupper (ASCII; vectorises)
-      chrom[name] = seq;
+    // load_chromosomes (chromosomes.cpp:9-27).  A plain FASTA with '\n' line ends is mapped and read by several threads
+    // (fastx_reader.h, as `SVDSS call` does: GRCh38 in ~0.3 s instead of ~2 s, which was half of a smooth run of a million
+    // reads); anything else -- gzip, CRLF, FASTQ-like headers -- line by line.
+    std::vector<std::string> nm, sq;
+    if (!getenv("SVDSS_FASTA_SERIAL") && load_fasta_mapped(o.reference, std::max(1, std::min((int)o.threads, 8)), true, nm, sq)) {
+      for (size_t i = 0; i < nm.size(); ++i) chrom[nm[i]] = std::move(sq[i]);   // (a name that occurs twice: the later record wins, as below)
+    } else {
+      FastxReader fx(o.reference);
+      if (!fx.ok()) die("cannot open " + o.reference);
+      std::string name, seq;
+      while (fx.next(name, seq)) {
+        for (char& c : seq) c = (char)(c - ((c >= 'a' && c <= 'z') ? 32 : 0));   // toupper (ASCII; vectorises)
+        chrom[name].swap(seq);
+      }
     }
   }
+  const double fasta_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fasta0).count();
   auto eligible = [&](const BamRecord& r, const std::vector<std::string>& names) {
     if (r.flag & (4 | 2048 | 256)) return false;
     if ((unsigned)r.mapq < o.min_mapq || r.l_seq < 2) return false;
@@ -317,7 +327,7 @@ int main_smooth(const CallOptions& o) {
       die(std::string("svdss_ref_upload_parts: ") + svdss_last_hip_error());
     if (svdss_bam_smooth_create(dref, tid_map.data(), (int32_t)tid_map.size(), (int32_t)o.min_mapq, &sm) != SVDSS_OK)
       die(std::string("svdss_bam_smooth_create: ") + svdss_last_hip_error());
-    if (dbg) fprintf(stderr, "[smooth] reference on the device at +%.3f s\n", since());
+    if (dbg) fprintf(stderr, "[smooth] reference read in %.3f s, on the device at +%.3f s\n", fasta_s, since());
     // compute_maxaccuracy (smoother.cpp:259-346): the mismatch rates of the first 10,000 records that fit, their percentile
     {
       std::vector<double> acc;

@@ -173,3 +173,55 @@ def test_inconsistent_records_pass_through_with_xf3(tmp_path):
     assert by["over"].tags["XF"] == 3 and by["over"].seq == over and by["over"].cigar == [(152, 0)]
     assert by["short"].tags["XF"] == 3 and by["short"].seq == short and by["short"].cigar == [(120, 0)]
     assert by["good"].tags["XF"] == 0 and by["good"].cigar == [(70, 0), (30, 2), (80, 0)]
+
+
+def test_smooth_output_does_not_depend_on_how_the_fasta_is_written(tmp_path):
+    """load_chromosomes (chromosomes.cpp:9-27) upper-cases and joins lines whatever the file looks like.  `smooth` reads a
+    plain FASTA through a mapping with several threads (fastx_reader.h load_fasta_mapped) and everything else -- gzip,
+    CRLF line ends -- line by line: one line per chromosome, 60-column lines in mixed case, the same with CRLF, gzipped,
+    and the line reader forced (SVDSS_FASTA_SERIAL) must all give the same bytes."""
+    import gzip
+    ref, svs, reads = simulate(ref_lens=(50000, 20011), n_svs=3, coverage=4, read_len=2500, seed=21)
+    rng = np.random.default_rng(5)
+    names = ["chrA", "chrB"]
+    recs = []
+    for k, (n, tid, pos, cig, seq, hp) in enumerate(reads):
+        s2, c2 = add_errors(seq, cig, rng, 0.01)
+        recs.append(bam_writer.record(n, 16 if k % 2 else 0, tid, pos, 60, c2, s2, [], bytes(rng.integers(1, 60, size=len(s2)).astype(np.uint8))))
+    bam = tmp_path / "in.bam"
+    bam.write_bytes(bam_writer.bam([(n, len(c)) for n, c in zip(names, ref)], recs))
+    texts = [synth.to_ascii(c) for c in ref]
+
+    def mixed(s, k):
+        return "".join(ch.lower() if (i * 7 + k) % 3 == 0 else ch for i, ch in enumerate(s))
+
+    def body(width, eol, case):
+        out = []
+        for k, (n, t) in enumerate(zip(names, texts)):
+            out.append(f">{n} some description{eol}")
+            t = mixed(t, k) if case else t
+            if width:
+                out.extend(t[i:i + width] + eol for i in range(0, len(t), width))
+            else:
+                out.append(t + eol)
+        return "".join(out).encode()
+
+    forms = {"one_line.fa": body(0, "\n", False), "wrapped_mixed.fa": body(60, "\n", True), "crlf.fa": body(60, "\r\n", True),
+             "odd_width.fa": body(61, "\n", True)}
+    outs = {}
+    for name, data in forms.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        for env in ({}, {"SVDSS_FASTA_SERIAL": "1"}):
+            r = subprocess.run([BIN, "smooth", "--reference", str(p), "--bam", str(bam), "--threads", "5"], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr.decode()
+            outs[(name, bool(env))] = r.stdout
+    gz = tmp_path / "wrapped.fa.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(forms["wrapped_mixed.fa"])
+    r = subprocess.run([BIN, "smooth", "--reference", str(gz), "--bam", str(bam), "--threads", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    outs[("gz", False)] = r.stdout
+    first = outs[("one_line.fa", False)]
+    assert len(first) > 10000 and all(v == first for v in outs.values())
