@@ -473,6 +473,10 @@ struct CallRun {
     const char* e = getenv("SVDSS_BAM_BATCH_MB");
     return (e && atoll(e) > 0 ? atoll(e) : 256) << 20;
   }
+  static int bam_feeders() {             // feeding threads (device batches in flight) per GPU of the two BAM passes
+    const char* e = getenv("SVDSS_CALL_FEEDERS");
+    return e && atoi(e) > 0 ? atoi(e) : 3;
+  }
   std::vector<BamReader::RawView> cache_views;
   std::vector<std::shared_ptr<BamReader::Bytes>> cache_chunks;
   size_t cache_bytes = 0, cache_limit = 0;
@@ -581,7 +585,7 @@ struct CallRun {
           filters.push_back(f);
           devs.push_back(d);
         }
-        sel.reset(new DeviceBamSelect(o.bam, filters, devs, n_ref_hdr, bam_skip, 3, bam_batch_bytes()));
+        sel.reset(new DeviceBamSelect(o.bam, filters, devs, n_ref_hdr, bam_skip, bam_feeders(), bam_batch_bytes()));
         cache_ok = false;
         dev_pass = true;
       } else {
@@ -992,7 +996,7 @@ struct CallRun {
               devs.push_back(d);
             }
             {
-              DeviceBamSelect sel(o.bam, filters, devs, (int32_t)ref_names.size(), bam_skip, 3, bam_batch_bytes());
+              DeviceBamSelect sel(o.bam, filters, devs, (int32_t)ref_names.size(), bam_skip, bam_feeders(), bam_batch_bytes());
               BamReader::RawView rr;
               while (std::unique_ptr<SelectedBatch> sb = sel.next())
                 for (size_t k = 0; k + 1 < sb->off.size(); ++k) {

@@ -7,16 +7,25 @@
 //
 // One wavefront per BGZF block.  The encoder is a level-1-class one made for this data: packed bases and quality
 // bytes hold almost no repeats inside a 32 KB window, what compresses them is their symbol statistics -- so a block is
-// coded with literals only, no LZ77 matches, under dynamic Huffman codes rebuilt four times per block (the statistics
-// of bases, qualities, names and tags differ; zlib re-derives its trees every ~16 K symbols for the same reason):
+// coded with literals under dynamic Huffman codes rebuilt four times per block (the statistics of bases, qualities,
+// names and tags differ; zlib re-derives its trees every ~16 K symbols for the same reason) and with ONE kind of match:
+// RUNS (length 4-258 at distance 1; second session of round 5).  Quality strings are where a BAM has them -- absent
+// qualities are 15,000 x 0xff per read, HiFi qualities sit at their top value for long stretches -- and as literals a
+// run is a bit per byte at best: the smoothed BAM of the chain bench was 1.8 x its input, and this repo's own inflater
+// (csrc/inflate.hip) reads a stream of one-bit codes at a quarter of its rate (a 288-bit piece then decodes to more
+// bytes than the output ring holds, it falls back to rounds).  A run costs a length code, its extra bits and one bit
+// for the distance; a lane finds the runs of its own slice alone (a byte equal to the one before it, even across the
+// slice's start), so the three passes over a slice (count, size, pack) see the same tokens without storing them.
+// No general LZ77: BGZF members are independent 64 KB streams, and bases and qualities do not repeat inside one.
 //   * the quarter block is staged in LDS (coalesced loads), every lane counts the bytes of its 1/64 of it (LDS atomics);
-//   * the 257 symbols (literals + end of block) are ranked by (count, symbol) -- every lane ranks its symbols against
+//   * the 286 symbols (literals, end of block, length codes) are ranked by (count, symbol) -- every lane ranks its symbols against
 //     all others with broadcast LDS reads --, one lane runs the two-queue Huffman merge over the sorted leaves, turns
 //     node depths into counts per length, folds lengths above 15 back the way zlib's gen_bitlen does, and hands the
 //     lengths out longest-first to the rarest symbols; canonical codes, bit-reversed for deflate's LSB-first stream;
-//   * the header is the plainest valid one: HLIT = 257, one distance code of zero bits (RFC 1951: "the data is all
-//     literals"), the code-length alphabet with 4 bits for each of 0..15 (a complete code), every length sent as
-//     itself: 1,106 bits per quarter block;
+//   * the header is the plainest valid one: HLIT = 286, two distance codes of one bit each (only distance 1 is ever
+//     used; two codes make the distance code complete, which is what zlib itself always writes and every inflater
+//     accepts), the code-length alphabet with 4 bits for each of 0..15 (a complete code), every length sent as
+//     itself: 1,226 bits per quarter block;
 //   * the bit offset of every lane's first symbol is a wave scan over the lanes' code lengths; a lane packs its symbols
 //     into 32-bit words and stores them -- the first and the last word, which it shares with its neighbours, with an
 //     atomic OR on the zeroed output --; a quarter block that Huffman coding would not shrink is stored (BTYPE 00).
@@ -42,20 +51,69 @@ namespace {
 constexpr int SUBS = 4;                    // deflate blocks per BGZF block
 constexpr int MAX_IN = 0xff00;             // BGZF's block size (htslib BGZF_BLOCK_SIZE)
 constexpr int MAX_SUB = (MAX_IN + SUBS - 1) / SUBS;
-constexpr int NSYM = 257;                  // literals + end of block
-constexpr int HDR_BITS = 3 + 5 + 5 + 4 + 19 * 3 + (NSYM + 1) * 4;   // 1,106
+constexpr int NSYM = 286;                  // literals, end of block, the 29 length codes
+constexpr int NDIST = 2;                   // distance codes 0 (distance 1: the runs) and 1 (never used), one bit each
+constexpr int HDR_BITS = 3 + 5 + 5 + 4 + 19 * 3 + (NSYM + NDIST) * 4;   // 1,226
+constexpr int MIN_RUN = 4;                 // shorter runs stay literals (a match costs a length code + the distance bit)
+constexpr int MAX_RUN = 258;
 
 struct Lds {
   uint32_t in[MAX_SUB / 4 + 8];
-  uint32_t freq[NSYM + 7];
-  uint32_t enc[NSYM + 7];      // reversed code | length << 16
-  uint16_t order[NSYM + 7];    // symbols with a non-zero count, rarest first
-  uint32_t weight[2 * NSYM];
+  uint32_t freq[NSYM + 6];
+  uint16_t order[NSYM + 6];    // symbols with a non-zero count, rarest first
+  union {                      // (the codes are written when the merge's weights are dead: seven blocks per CU stay)
+    uint32_t weight[2 * NSYM];
+    uint32_t enc[NSYM + 6];    // reversed code | length << 16
+  };
   uint16_t parent[2 * NSYM];
   uint8_t depth[2 * NSYM];
-  uint8_t len[NSYM + 7];
+  uint8_t len[NSYM + 6];
   int32_t n_used;
 };
+
+// length 3..258 -> its length symbol (257..285), the number of extra bits and their value (RFC 1951 3.2.5)
+__device__ __forceinline__ int len_symbol(int len, int& ebits, int& eval) {
+  ebits = 0; eval = 0;
+  if (len == MAX_RUN) return 285;
+  const int l = len - 3;
+  if (l < 8) return 257 + l;
+  const int e = (31 - __builtin_clz((unsigned)l)) - 2;
+  ebits = e;
+  eval = l & ((1 << e) - 1);
+  return 261 + 4 * e + ((l >> e) & 3);
+}
+
+// The tokens of the slice [c0, c1) of the staged bytes: f(true, run length) for a run of MIN_RUN..MAX_RUN bytes equal to
+// the byte in front of them, f(false, byte) for a literal.  prev = the byte in front of the slice (-1: none -- the first
+// byte of the member).  A function of the slice's bytes and prev alone: every pass over the slice sees the same tokens.
+// One pass of the loop per byte in every lane (the lanes' slices have the same length): a lane inside a run only counts,
+// so lanes in runs and lanes in literals do not take turns (the first version scanned a run in an inner loop and the
+// wavefront paid for both paths: 2.2 x the literal-only kernel's time).  The bytes come a dword at a time, the next
+// dword loaded while this one is looked at (c0 is a multiple of 4): a byte load per step put the LDS latency into the
+// loop-carried chain (p, rl).  One call site for literals and one for runs keeps the three passes' code small: the
+// pending bytes of a run that stayed short and the byte that ended it go through the same short loop, and the slice's
+// end is one more step with a byte that equals nothing.
+template <class F>
+__device__ __forceinline__ void for_tokens(const uint32_t* in, int c0, int c1, int prev, F&& f) {
+  if (c0 >= c1) return;
+  int p = prev, rl = 0;                       // rl bytes equal to p are pending behind it
+  int w = c0 >> 2;
+  uint32_t cur = 0, nxt = in[w];
+  for (int i = c0; i <= c1; ++i) {
+    int b = -2;
+    if (i < c1) {
+      if ((i & 3) == 0) { cur = nxt; nxt = in[++w]; }   // (in[] has words to spare behind the quarter block)
+      b = (int)(cur & 0xffu);
+      cur >>= 8;
+    }
+    if (b == p && rl < MAX_RUN) { ++rl; continue; }
+    if (rl >= MIN_RUN) { f(true, rl); rl = 0; }
+    const int n_l = rl + ((b != p && b >= 0) ? 1 : 0);
+    for (int k = 0; k < n_l; ++k) f(false, k < rl ? p : b);
+    if (b == p) rl = 1;                       // (a run longer than MAX_RUN goes on as the next match)
+    else { p = b; rl = 0; }
+  }
+}
 
 template <int CTRL, int RMASK>
 __device__ __forceinline__ int dpp_add(int x) { return x + __builtin_amdgcn_update_dpp(0, x, CTRL, RMASK, 0xf, false); }
@@ -150,6 +208,7 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
   uint32_t* const ow = (uint32_t*)ob;          // (out and out_stride are multiples of 4; the region is zeroed)
   int64_t bitpos = 18 * 8;                       // the deflate stream starts behind the 18-byte BGZF header
   const int base = (n + SUBS - 1) / SUBS;
+  int prev_last = -1;                            // the byte in front of the quarter block (runs go on across quarters)
   for (int s0 = 0; s0 < n; s0 += base) {
     const int m = UNI(n - s0 < base ? n - s0 : base);
     const bool final_sub = s0 + m >= n;
@@ -160,12 +219,16 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
       __builtin_memcpy(&v, src + 4 * w, 4);      // (the input buffer has 16 bytes of slack behind its end)
       S.in[w] = v;
     }
-    for (int t = lane; t < NSYM + 7; t += 64) S.freq[t] = 0;
+    for (int t = lane; t < NSYM + 6; t += 64) S.freq[t] = 0;
     __syncthreads();
     const uint8_t* sb = (const uint8_t*)S.in;
-    const int cl = (m + 63) / 64;                // bytes per lane
+    const int cl = ((m + 63) / 64 + 3) & ~3;     // bytes per lane (whole dwords: for_tokens reads its slice by dwords)
     const int c0 = lane * cl, c1 = c0 + cl < m ? c0 + cl : m;
-    for (int i = c0; i < c1; ++i) atomicAdd(&S.freq[sb[i]], 1u);
+    const int prev = c0 > 0 ? (c0 <= m ? (int)sb[c0 - 1] : -1) : prev_last;
+    for_tokens(S.in, c0, c1, prev, [&](bool run, int v) {
+      int eb, ev;
+      atomicAdd(&S.freq[run ? len_symbol(v, eb, ev) : v], 1u);
+    });
     if (lane == 0) S.freq[256] = 1;
     __syncthreads();
     // ---- symbols ranked by (count, symbol), zero counts left out
@@ -191,7 +254,11 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
     __syncthreads();
     // ---- sizes
     int my_bits = 0;
-    for (int i = c0; i < c1; ++i) my_bits += (int)(S.enc[sb[i]] >> 16);
+    for_tokens(S.in, c0, c1, prev, [&](bool run, int v) {
+      int eb = 0, ev = 0;
+      const int sym = run ? len_symbol(v, eb, ev) : v;
+      my_bits += (int)(S.enc[sym] >> 16) + (run ? eb + 1 : 0);   // (+ the one-bit distance code)
+    });
     const int incl = wave_scan_add(my_bits);
     const int body_bits = __builtin_amdgcn_readlane(incl, 63);
     const int eob = (int)S.enc[256];
@@ -211,14 +278,14 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
       if (lane == 0) {
         int64_t p = bitpos;
         put_bits_atomic(ow, p, (final_sub ? 1u : 0u) | (2u << 1), 3); p += 3;
-        put_bits_atomic(ow, p, 0u, 5); p += 5;                      // HLIT: 257 codes
-        put_bits_atomic(ow, p, 0u, 5); p += 5;                      // HDIST: 1 code
+        put_bits_atomic(ow, p, (uint32_t)(NSYM - 257), 5); p += 5;  // HLIT: 286 codes
+        put_bits_atomic(ow, p, (uint32_t)(NDIST - 1), 5); p += 5;   // HDIST: 2 codes
         put_bits_atomic(ow, p, 15u, 4); p += 4;                     // HCLEN: 19 code-length codes
         // order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15: the three run-length codes unused, 4 bits for 0..15
         for (int k = 0; k < 19; ++k) { put_bits_atomic(ow, p, k < 3 ? 0u : 4u, 3); p += 3; }
         // every length sent as itself: code-length symbol v has the 4-bit code v, packed most significant bit first
-        for (int t = 0; t <= NSYM; ++t) {
-          const uint32_t v = t < NSYM ? S.len[t] : 0u;               // (the one distance code: zero bits)
+        for (int t = 0; t < NSYM + NDIST; ++t) {
+          const uint32_t v = t < NSYM ? S.len[t] : 1u;               // (the two distance codes: one bit each)
           put_bits_atomic(ow, p, __builtin_bitreverse32(v) >> 28, 4);
           p += 4;
         }
@@ -237,12 +304,18 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
           first = false;
           acc >>= 32; have -= 32; ++w;
         };
-        for (int i = c0; i < c1; ++i) {
-          const uint32_t e = S.enc[sb[i]];
+        for_tokens(S.in, c0, c1, prev, [&](bool run, int v) {
+          int eb = 0, ev = 0;
+          const uint32_t e = S.enc[run ? len_symbol(v, eb, ev) : v];
           acc |= (uint64_t)(e & 0xffffu) << have;
           have += (int)(e >> 16);
           if (have >= 32) flush(false);
-        }
+          if (run) {                                // the length's extra bits, then distance code 0 (one bit, 0)
+            acc |= (uint64_t)(uint32_t)ev << have;
+            have += eb + 1;
+            if (have >= 32) flush(false);
+          }
+        });
         if (lane == 63) {                         // end of block, behind the last lane's symbols (lane 63 may hold none)
           acc |= (uint64_t)((uint32_t)eob & 0xffffu) << have;
           have += eob >> 16;
@@ -252,6 +325,7 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
       }
       bitpos += total_bits;
     }
+    prev_last = (int)sb[m - 1];
     __syncthreads();
   }
   if (lane == 0) {

@@ -374,6 +374,14 @@ __global__ void __launch_bounds__(256, SV_SEARCH_OCC) sfs_search2_kernel(SfsPara
     ++item_ops;
     if (o.op == SV_OP_DONE) { atomicAdd(&g_sfs_iters[16 + (31 - __builtin_clz(item_ops | 1))], 1ULL); item_ops = 0; }
 #endif
+    if (SEG && o.op != SV_OP_DONE && st.n_sfs > (int32_t)cap) {
+      // More SFS than the segment's region holds: the stitcher sends the whole read to the next level whatever this
+      // lane does from here on (sv_stitch: n_rec > cap), so it stops now.  A read with a long novel insertion has an
+      // SFS at every base of it -- the lane that owns that stretch used to walk all of it, 1,900 dependent SFS for
+      // nothing, and the launch lasted as long as that lane (8.8 ms per batch of `SVDSS search` in the chain bench).
+      st.mode |= SV_M_PARTIAL;
+      continue;
+    }
     if (o.op == SV_OP_DONE) {
       if (SEG) {
         {   // a record still waiting for its pair
@@ -979,8 +987,11 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
       // reads whose chains could not be stitched are searched again with a quarter of the segments (their
       // boundaries fall elsewhere), at the end one lane per read
       int lvl_seg = n_seg;
+      // (a handful of reads: one lane each at once -- a launch of so few lanes lasts as long as its longest read either
+      // way, and an intermediate level that fails again costs that time twice; SVDSS_FALLBACK_DIRECT moves the limit)
+      const unsigned long long direct = getenv("SVDSS_FALLBACK_DIRECT") ? (unsigned long long)atoll(getenv("SVDSS_FALLBACK_DIRECT")) : 64ull;
       while (n_fb > 0) {
-        lvl_seg = lvl_seg / 4 < 1 ? 1 : lvl_seg / 4;
+        lvl_seg = lvl_seg / 4 < 1 || n_fb <= direct ? 1 : lvl_seg / 4;
         if ((rc = ensure(b->fallback2, (size_t)n_fb * sizeof(int64_t)))) return rc;
         HIPCHK(hipMemcpyAsync(b->fallback2.p, p.fallback_ids, (size_t)n_fb * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
         SfsParams q = p;

@@ -182,7 +182,7 @@ int main_smooth(const CallOptions& o) {
     // (fastx_reader.h, as `SVDSS call` does: GRCh38 in ~0.3 s instead of ~2 s, which was half of a smooth run of a million
     // reads); anything else -- gzip, CRLF, FASTQ-like headers -- line by line.
     std::vector<std::string> nm, sq;
-    if (!getenv("SVDSS_FASTA_SERIAL") && load_fasta_mapped(o.reference, std::max(1, std::min((int)o.threads, 8)), true, nm, sq)) {
+    if (!getenv("SVDSS_FASTA_SERIAL") && load_fasta_mapped(o.reference, std::max(1, std::min((int)o.threads, 16)), true, nm, sq)) {
       for (size_t i = 0; i < nm.size(); ++i) chrom[nm[i]] = std::move(sq[i]);   // (a name that occurs twice: the later record wins, as below)
     } else {
       FastxReader fx(o.reference);

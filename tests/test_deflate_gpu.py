@@ -122,6 +122,51 @@ def test_every_kind_of_block_inflates_with_zlib():
         check_roundtrip(bytes(rng.integers(60, 70, size=n, dtype=np.uint8)))
 
 
+def test_runs_become_matches_at_distance_one():
+    """Second session of round 5: runs of 4-258 equal bytes are coded as matches at distance 1 (absent qualities are
+    15,000 x 0xff per read; as literals a run costs a bit per byte and this repo's own inflater reads one-bit codes at a
+    quarter of its rate).  Every inflater must give the bytes back; runs of every length around the thresholds (3, 4,
+    258, 259, 261, 262), runs that begin or end at a lane's slice (255 bytes) or a quarter block (16,320 bytes), a run
+    as the whole member, runs of several values, and records as the chain bench writes them."""
+    rng = np.random.default_rng(11)
+    # run lengths 1..600 of a changing byte, separated by one different byte: every remainder modulo 258 and every
+    # position relative to the lanes' slices
+    parts = []
+    for r in list(range(1, 300)) + [515, 516, 517, 518, 519, 520, 600]:
+        parts.append(bytes([65 + r % 7]) * r + bytes([200 + r % 5]))
+    data = b"".join(parts)
+    for off in (0, 1, 254, 255):                       # shifted against the slices
+        check_roundtrip((b"x" * off + data)[:0xff00])
+    check_roundtrip(bytes([0xff]) * 0xff00)
+    check_roundtrip(bytes([0xff]) * (4 * 16320 - 1))
+    check_roundtrip(b"a" + bytes([7]) * 16319 + bytes([7]) * 5 + b"b" * 16315 + b"b" * 16320 + b"c" * 3)   # runs across the quarters
+    for n in (1, 2, 3, 4, 5, 257, 258, 259, 260, 261, 262, 263, 516, 517, 1000):
+        check_roundtrip(bytes([1]) * n)
+        check_roundtrip(b"q" + bytes([1]) * n + b"r")
+    # the chain bench's records: random packed bases, qualities absent (0xff), a tag
+    rec = []
+    for k in range(40):
+        l = int(rng.integers(9000, 16000))
+        rec.append(b"read%07d\0" % k + bytes(rng.choice([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88],
+                                                         size=l // 2).astype(np.uint8)) + b"\xff" * l + b"XFC\x02")
+    data = b"".join(rec)
+    stream, ms = check_roundtrip(data)
+    z1 = sum(len(zlib.compress(data[i:i + 0xff00], 1)) for i in range(0, len(data), 0xff00))
+    assert len(stream) < 1.05 * z1 and len(stream) < 0.2 * len(data), (len(stream), z1, len(data))
+    blocks = bgzf_blocks(stream)
+    assert bytes(gpu_inflate(stream, [(c, l, i) for c, l, i, _ in blocks])) == data
+    # binned qualities with stretches at the top value (HiFi-like): runs and literals mixed
+    q = np.array([3, 10, 17, 22, 27, 33, 40, 93], np.uint8)[rng.integers(0, 8, size=200000)]
+    at = rng.integers(0, len(q) - 400, size=300)
+    for a in at:
+        q[a:a + int(rng.integers(4, 400))] = 93
+    stream, ms = check_roundtrip(bytes(q))
+    blocks = bgzf_blocks(stream)
+    assert bytes(gpu_inflate(stream, [(c, l, i) for c, l, i, _ in blocks])) == bytes(q)
+    # two bytes alternating: no runs, nothing may be taken for one
+    check_roundtrip(b"ab" * 30000)
+
+
 def test_many_blocks_short_tail_and_the_gpu_inflater_reads_them():
     rng = np.random.default_rng(8)
     # BAM-like: records of packed bases + qualities + names, 300 blocks and a tail of 777 bytes
