@@ -9,13 +9,14 @@
 // bytes hold almost no repeats inside a 32 KB window, what compresses them is their symbol statistics -- so a block is
 // coded with literals under dynamic Huffman codes rebuilt four times per block (the statistics of bases, qualities,
 // names and tags differ; zlib re-derives its trees every ~16 K symbols for the same reason) and with ONE kind of match:
-// RUNS (length 4-258 at distance 1; second session of round 5).  Quality strings are where a BAM has them -- absent
+// RUNS (4, 8, ... 256 equal bytes, at distance 1; second session of round 5).  Quality strings are where a BAM has them -- absent
 // qualities are 15,000 x 0xff per read, HiFi qualities sit at their top value for long stretches -- and as literals a
 // run is a bit per byte at best: the smoothed BAM of the chain bench was 1.8 x its input, and this repo's own inflater
 // (csrc/inflate.hip) reads a stream of one-bit codes at a quarter of its rate (a 288-bit piece then decodes to more
 // bytes than the output ring holds, it falls back to rounds).  A run costs a length code, its extra bits and one bit
-// for the distance; a lane finds the runs of its own slice alone (a byte equal to the one before it, even across the
-// slice's start), so the three passes over a slice (count, size, pack) see the same tokens without storing them.
+// for the distance; a lane finds the runs of its own slice alone (dwords whose bytes equal the byte in front of them,
+// even across the slice's start), so the three passes over a slice (count, size, pack) see the same tokens without
+// storing them.
 // No general LZ77: BGZF members are independent 64 KB streams, and bases and qualities do not repeat inside one.
 //   * the quarter block is staged in LDS (coalesced loads), every lane counts the bytes of its 1/64 of it (LDS atomics);
 //   * the 286 symbols (literals, end of block, length codes) are ranked by (count, symbol) -- every lane ranks its symbols against
@@ -54,8 +55,7 @@ constexpr int MAX_SUB = (MAX_IN + SUBS - 1) / SUBS;
 constexpr int NSYM = 286;                  // literals, end of block, the 29 length codes
 constexpr int NDIST = 2;                   // distance codes 0 (distance 1: the runs) and 1 (never used), one bit each
 constexpr int HDR_BITS = 3 + 5 + 5 + 4 + 19 * 3 + (NSYM + NDIST) * 4;   // 1,226
-constexpr int MIN_RUN = 4;                 // shorter runs stay literals (a match costs a length code + the distance bit)
-constexpr int MAX_RUN = 258;
+constexpr int MAX_RUN = 256;               // runs are found a dword at a time: 4, 8, ... 256 bytes (deflate allows 258)
 
 struct Lds {
   uint32_t in[MAX_SUB / 4 + 8];
@@ -74,8 +74,7 @@ struct Lds {
 // length 3..258 -> its length symbol (257..285), the number of extra bits and their value (RFC 1951 3.2.5)
 __device__ __forceinline__ int len_symbol(int len, int& ebits, int& eval) {
   ebits = 0; eval = 0;
-  if (len == MAX_RUN) return 285;
-  const int l = len - 3;
+  const int l = len - 3;                      // (lengths here are 4 .. 256: symbol 285, length 258, is never needed)
   if (l < 8) return 257 + l;
   const int e = (31 - __builtin_clz((unsigned)l)) - 2;
   ebits = e;
@@ -83,36 +82,36 @@ __device__ __forceinline__ int len_symbol(int len, int& ebits, int& eval) {
   return 261 + 4 * e + ((l >> e) & 3);
 }
 
-// The tokens of the slice [c0, c1) of the staged bytes: f(true, run length) for a run of MIN_RUN..MAX_RUN bytes equal to
-// the byte in front of them, f(false, byte) for a literal.  prev = the byte in front of the slice (-1: none -- the first
-// byte of the member).  A function of the slice's bytes and prev alone: every pass over the slice sees the same tokens.
-// One pass of the loop per byte in every lane (the lanes' slices have the same length): a lane inside a run only counts,
-// so lanes in runs and lanes in literals do not take turns (the first version scanned a run in an inner loop and the
-// wavefront paid for both paths: 2.2 x the literal-only kernel's time).  The bytes come a dword at a time, the next
-// dword loaded while this one is looked at (c0 is a multiple of 4): a byte load per step put the LDS latency into the
-// loop-carried chain (p, rl).  One call site for literals and one for runs keeps the three passes' code small: the
-// pending bytes of a run that stayed short and the byte that ended it go through the same short loop, and the slice's
-// end is one more step with a byte that equals nothing.
-template <class F>
-__device__ __forceinline__ void for_tokens(const uint32_t* in, int c0, int c1, int prev, F&& f) {
+// The tokens of the slice [c0, c1) of the staged bytes (c0 a multiple of 4), found a DWORD at a time: a dword whose four
+// bytes all equal the byte in front of it continues a run -- runs are 4, 8, ... 256 bytes long, match(length) --, any
+// other dword is four literals, lit(dword, 4); the last bytes of the quarter block that do not fill a dword are literals
+// (lit(dword, 1..3)).  prev = the byte in front of the slice (-1: none -- the first byte of the member).  A function of
+// the slice's bytes and prev alone: every pass over the slice sees the same tokens, and a lane finds its own without its
+// neighbours (a run goes on across slices: the next lane's first dword equals this lane's last byte).  What a run loses
+// at its ends (up to three bytes each, coded as literals) does not matter for runs worth coding.  Two byte-wise versions
+// came first: a state machine over the bytes costs several divergent branches per byte, 2.3 x the literal-only kernel's
+// time on data without a single run (profiles/r05w_deflate_runs_ab.txt); per dword the kernel is where it was.
+template <class FL, class FM>
+__device__ __forceinline__ void for_tokens(const uint32_t* in, int c0, int c1, int prev, FL&& lit, FM&& match) {
   if (c0 >= c1) return;
-  int p = prev, rl = 0;                       // rl bytes equal to p are pending behind it
-  int w = c0 >> 2;
-  uint32_t cur = 0, nxt = in[w];
-  for (int i = c0; i <= c1; ++i) {
-    int b = -2;
-    if (i < c1) {
-      if ((i & 3) == 0) { cur = nxt; nxt = in[++w]; }   // (in[] has words to spare behind the quarter block)
-      b = (int)(cur & 0xffu);
-      cur >>= 8;
-    }
-    if (b == p && rl < MAX_RUN) { ++rl; continue; }
-    if (rl >= MIN_RUN) { f(true, rl); rl = 0; }
-    const int n_l = rl + ((b != p && b >= 0) ? 1 : 0);
-    for (int k = 0; k < n_l; ++k) f(false, k < rl ? p : b);
-    if (b == p) rl = 1;                       // (a run longer than MAX_RUN goes on as the next match)
-    else { p = b; rl = 0; }
+  const int nw = (c1 - c0) >> 2;
+  int w = c0 >> 2, rl = 0;
+  bool have_prev = prev >= 0;
+  uint32_t sp = have_prev ? (uint32_t)prev * 0x01010101u : 0u;   // the byte in front, four times
+  uint32_t nxt = in[w];
+  for (int j = 0; j < nw; ++j) {
+    const uint32_t cur = nxt;
+    nxt = in[++w];                              // (in[] has words to spare behind the quarter block)
+    const bool same = have_prev && cur == sp;
+    if (same && rl < MAX_RUN) { rl += 4; continue; }
+    if (rl) { match(rl); rl = 0; }
+    if (same) { rl = 4; continue; }             // (a run longer than MAX_RUN goes on as the next match)
+    lit(cur, 4);
+    sp = (cur >> 24) * 0x01010101u;
+    have_prev = true;
   }
+  if (rl) match(rl);
+  if ((c1 - c0) & 3) lit(nxt, (c1 - c0) & 3);
 }
 
 template <int CTRL, int RMASK>
@@ -225,10 +224,14 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
     const int cl = ((m + 63) / 64 + 3) & ~3;     // bytes per lane (whole dwords: for_tokens reads its slice by dwords)
     const int c0 = lane * cl, c1 = c0 + cl < m ? c0 + cl : m;
     const int prev = c0 > 0 ? (c0 <= m ? (int)sb[c0 - 1] : -1) : prev_last;
-    for_tokens(S.in, c0, c1, prev, [&](bool run, int v) {
-      int eb, ev;
-      atomicAdd(&S.freq[run ? len_symbol(v, eb, ev) : v], 1u);
-    });
+    for_tokens(S.in, c0, c1, prev,
+               [&](uint32_t v, int nb) {
+                 for (int k = 0; k < nb; ++k) atomicAdd(&S.freq[(v >> (8 * k)) & 0xffu], 1u);
+               },
+               [&](int len) {
+                 int eb, ev;
+                 atomicAdd(&S.freq[len_symbol(len, eb, ev)], 1u);
+               });
     if (lane == 0) S.freq[256] = 1;
     __syncthreads();
     // ---- symbols ranked by (count, symbol), zero counts left out
@@ -254,11 +257,14 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
     __syncthreads();
     // ---- sizes
     int my_bits = 0;
-    for_tokens(S.in, c0, c1, prev, [&](bool run, int v) {
-      int eb = 0, ev = 0;
-      const int sym = run ? len_symbol(v, eb, ev) : v;
-      my_bits += (int)(S.enc[sym] >> 16) + (run ? eb + 1 : 0);   // (+ the one-bit distance code)
-    });
+    for_tokens(S.in, c0, c1, prev,
+               [&](uint32_t v, int nb) {
+                 for (int k = 0; k < nb; ++k) my_bits += (int)(S.enc[(v >> (8 * k)) & 0xffu] >> 16);
+               },
+               [&](int len) {
+                 int eb, ev;
+                 my_bits += (int)(S.enc[len_symbol(len, eb, ev)] >> 16) + eb + 1;   // (+ the one-bit distance code)
+               });
     const int incl = wave_scan_add(my_bits);
     const int body_bits = __builtin_amdgcn_readlane(incl, 63);
     const int eob = (int)S.enc[256];
@@ -304,18 +310,25 @@ __global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t* in, int
           first = false;
           acc >>= 32; have -= 32; ++w;
         };
-        for_tokens(S.in, c0, c1, prev, [&](bool run, int v) {
-          int eb = 0, ev = 0;
-          const uint32_t e = S.enc[run ? len_symbol(v, eb, ev) : v];
-          acc |= (uint64_t)(e & 0xffffu) << have;
-          have += (int)(e >> 16);
-          if (have >= 32) flush(false);
-          if (run) {                                // the length's extra bits, then distance code 0 (one bit, 0)
-            acc |= (uint64_t)(uint32_t)ev << have;
-            have += eb + 1;
-            if (have >= 32) flush(false);
-          }
-        });
+        for_tokens(S.in, c0, c1, prev,
+                   [&](uint32_t v, int nb) {
+                     for (int k = 0; k < nb; ++k) {
+                       const uint32_t e = S.enc[(v >> (8 * k)) & 0xffu];
+                       acc |= (uint64_t)(e & 0xffffu) << have;
+                       have += (int)(e >> 16);
+                       if (have >= 32) flush(false);
+                     }
+                   },
+                   [&](int len) {
+                     int eb, ev;
+                     const uint32_t e = S.enc[len_symbol(len, eb, ev)];
+                     acc |= (uint64_t)(e & 0xffffu) << have;
+                     have += (int)(e >> 16);
+                     if (have >= 32) flush(false);
+                     acc |= (uint64_t)(uint32_t)ev << have;   // the length's extra bits, then distance code 0 (one bit, 0)
+                     have += eb + 1;
+                     if (have >= 32) flush(false);
+                   });
         if (lane == 63) {                         // end of block, behind the last lane's symbols (lane 63 may hold none)
           acc |= (uint64_t)((uint32_t)eob & 0xffffu) << have;
           have += eob >> 16;

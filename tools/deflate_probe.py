@@ -1,5 +1,5 @@
 """Developer probe: the GPU deflate encoder (csrc/deflate.hip) on BAM-like data -- kernel time, ratio against zlib.
-  python tools/deflate_probe.py [n_blocks] [binned]"""
+  python tools/deflate_probe.py [n_blocks] [binned | ff | hifi]     (ff: qualities absent, 0xff; hifi: binned with stretches at the top value)"""
 import os
 import sys
 import time
@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from svdss_amd.bgzf import gpu_deflate  # noqa: E402
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-binned = len(sys.argv) > 2 and sys.argv[2] == "binned"
+kind = sys.argv[2] if len(sys.argv) > 2 else "random"
+binned = kind == "binned"
 rng = np.random.default_rng(1)
 parts = []
 total = nb * 0xff00
@@ -20,8 +21,15 @@ while sum(len(p) for p in parts) < total:
     parts.append(b"read%07d\0" % len(parts))
     parts.append(rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88], np.uint8),
                             size=l // 2).tobytes())
-    q = (np.array([3, 10, 17, 22, 27, 33, 40], np.uint8)[rng.integers(0, 7, size=l)] if binned
-         else rng.integers(20, 60, size=l, dtype=np.uint8))
+    if kind == "ff":
+        q = np.full(l, 0xff, np.uint8)
+    elif kind == "hifi":
+        q = np.array([3, 10, 17, 22, 27, 33, 40, 93], np.uint8)[rng.integers(0, 8, size=l)]
+        for a in rng.integers(0, l - 300, size=25):
+            q[a:a + int(rng.integers(4, 300))] = 93
+    else:
+        q = (np.array([3, 10, 17, 22, 27, 33, 40], np.uint8)[rng.integers(0, 7, size=l)] if binned
+             else rng.integers(20, 60, size=l, dtype=np.uint8))
     parts.append(q.tobytes())
 data = b"".join(parts)[:total]
 for rep in range(3):
