@@ -601,23 +601,32 @@ struct CallRun {
       const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
       std::vector<std::vector<ESFS>> per_thread((size_t)T);
       std::vector<std::vector<Clip>> per_thread_clips((size_t)T);
-      reference_ready();
       // the chromosomes in BAM header order on the GPU, for the placement kernel (SVDSS_PLACE_HOST=1: host code instead;
-      // --clipped: host code as well -- the kernel reports how many SFS stay unplaced, not next to which soft clip)
+      // --clipped: host code as well -- the kernel reports how many SFS stay unplaced, not next to which soft clip).
+      // Waiting for the FASTA's thread and the upload happen where the first batch is placed (the worker below, one at a
+      // time): until then this thread goes on taking the records the device path selects -- a pass over a million reads
+      // keeps a dozen thousand of them, and its feeders used to stand still behind a full queue while the reference
+      // was read (0.7 s of a 1.2 s pass at GRCh38 lengths).
       svdss_ref_t* dref = nullptr;
       std::vector<int32_t> tid_map(ref_names.size(), -1);
-      if (!getenv("SVDSS_PLACE_HOST") && !o.clipped) {
-        std::vector<const uint8_t*> parts;
-        std::vector<int64_t> lens;
-        for (size_t t = 0; t < ref_names.size(); ++t) {
-          auto it = C.chrom_seqs.find(ref_names[t]);
-          if (it == C.chrom_seqs.end()) continue;
-          tid_map[t] = (int32_t)parts.size();
-          parts.push_back((const uint8_t*)it->second.data());
-          lens.push_back((int64_t)it->second.size());
+      bool ref_set_up = false;
+      auto set_up_reference = [this, &dref, &tid_map, &ref_set_up]() {
+        if (ref_set_up) return;
+        ref_set_up = true;
+        reference_ready();
+        if (!getenv("SVDSS_PLACE_HOST") && !o.clipped) {
+          std::vector<const uint8_t*> parts;
+          std::vector<int64_t> lens;
+          for (size_t t = 0; t < ref_names.size(); ++t) {
+            auto it = C.chrom_seqs.find(ref_names[t]);
+            if (it == C.chrom_seqs.end()) continue;
+            tid_map[t] = (int32_t)parts.size();
+            parts.push_back((const uint8_t*)it->second.data());
+            lens.push_back((int64_t)it->second.size());
+          }
+          check(svdss_ref_upload_parts(parts.data(), lens.data(), (int32_t)parts.size(), 0, &dref), "svdss_ref_upload_parts");
         }
-        check(svdss_ref_upload_parts(parts.data(), lens.data(), (int32_t)parts.size(), 0, &dref), "svdss_ref_upload_parts");
-      }
+      };
       // two batches: the next one is read (inflate + slicing, this thread) while the T slices of the previous one run
       std::vector<BamRecord> batches[2];
       std::thread worker;
@@ -677,7 +686,8 @@ struct CallRun {
         if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
         // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
         // the same order per slice
-        worker = std::thread([this, &per_thread, &per_thread_clips, &batch, dref, &tid_map]() {
+        worker = std::thread([this, &per_thread, &per_thread_clips, &batch, &dref, &tid_map, &set_up_reference]() {
+          set_up_reference();
           if (dref) {
             // placement on the GPU (csrc/place.hip: one lane per alignment); the results go to the T per-thread lists in
             // the order the reference's slices would have produced them (record n belongs to slice n % T)
@@ -734,6 +744,7 @@ struct CallRun {
         cur ^= 1;
       }
       if (worker.joinable()) worker.join();
+      set_up_reference();   // (an input without a single batch: the later stages still want the chromosomes)
       svdss_ref_free(dref);
       sel.reset();
       for (svdss_bam_filter_t* f : filters) svdss_bam_filter_free(f);

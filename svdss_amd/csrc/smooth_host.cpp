@@ -177,6 +177,11 @@ void write_record(ByteSink& w, const BamRecord& r, const std::vector<uint32_t>& 
 int main_smooth(const CallOptions& o) {
   std::unordered_map<std::string, std::string> chrom;
   const auto t_fasta0 = std::chrono::steady_clock::now();
+  // the HIP runtime and the device's context come up (a few tenths of a second) while the FASTA is read
+  std::thread gpu_warm([] {
+    void* q = nullptr;
+    if (svdss_device_count() > 0 && svdss_host_alloc(1 << 20, &q) == SVDSS_OK && q) svdss_host_free(q);
+  });
   {
     // load_chromosomes (chromosomes.cpp:9-27).  A plain FASTA with '\n' line ends is mapped and read by several threads
     // (fastx_reader.h, as `SVDSS call` does: GRCh38 in ~0.3 s instead of ~2 s, which was half of a smooth run of a million
@@ -194,6 +199,7 @@ int main_smooth(const CallOptions& o) {
       }
     }
   }
+  gpu_warm.join();
   const double fasta_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fasta0).count();
   auto eligible = [&](const BamRecord& r, const std::vector<std::string>& names) {
     if (r.flag & (4 | 2048 | 256)) return false;
