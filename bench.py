@@ -176,6 +176,23 @@ class CallWorkload:
         c.last = {}
         return c
 
+    def tiled(self, g):
+        """The sub-clusters of g consecutive steps as ONE batch (the same packed workload g times, its own batch
+        objects): what the call side is handed when it takes several steps' clusters at once (--call-group)."""
+        import copy
+        c = copy.copy(self)
+        n_seq, n_sym, n_ref = len(self.seq_off) - 1, int(self.seq_off[-1]), int(self.ref_off[-1])
+        c.seqs = np.ascontiguousarray(np.tile(self.seqs, g))
+        c.refs = np.ascontiguousarray(np.tile(self.refs, g))
+        c.seq_off = np.concatenate([self.seq_off[:-1] + k * n_sym for k in range(g)] + [[g * n_sym]]).astype(np.int64)
+        c.cluster_off = np.concatenate([self.cluster_off[:-1] + k * n_seq for k in range(g)] + [[g * n_seq]]).astype(np.int64)
+        c.ref_off = np.concatenate([self.ref_off[:-1] + k * n_ref for k in range(g)] + [[g * n_ref]]).astype(np.int64)
+        c.n_clusters, c.n_sub, c.kinds = self.n_clusters * g, self.n_sub * g, self.kinds * g
+        # (the SAME batch objects as the step's workload: a call thread runs one batch at a time, and a POA batch object
+        # holds up to 32 GB of workspace)
+        c.last = {}
+        return c
+
     def run(self, lib, check, device):
         """POA -> consensus to the host -> realignment against the reference windows -> ratio of adjacent consensus
         pairs; returns nothing, leaves timings / results in self.last."""
@@ -260,7 +277,14 @@ def main():
     ap.add_argument("--call-threads", type=int, default=3,
                     help="steps whose call-side DP may be in flight at once (0: no pipelining, search and call of a "
                          "step run back to back)")
+    ap.add_argument("--call-group", type=int, default=1,
+                    help="the call side takes the sub-clusters of this many consecutive steps as one batch (`SVDSS call` "
+                         "is handed a whole genome's at once: a single step's 5,093 leave the chip waiting for their "
+                         "longest chains); every step's sub-clusters are processed inside the timed region either way; "
+                         "steps that do not fill a group go one by one; 1 (default) = a batch per step.  Measured: the step does not "
+                         "move with it (profiles/r05x_call_group.txt) -- in the pipeline the search fills the tails already")
     args = ap.parse_args()
+    args.call_group = max(1, args.call_group)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -348,6 +372,10 @@ def main():
     total_syms = n_reads * L
     del ref_t
     torch.cuda.synchronize()
+    # the read simulator's temporaries sit in torch's caching allocator: hand them back, the call side sizes its POA
+    # workspace (a few MB per sub-cluster) by what the device has free
+    torch.cuda.empty_cache()
+    hbm_free_after_reads = torch.cuda.mem_get_info(device)[0]
 
     # ---- call-side work of one step's reads ------
     cw = None
@@ -398,7 +426,7 @@ def main():
     searchers = [(pp, sstream)] + [(svdss_amd.PingPong(ix, assemble=True), search_stream())
                                    for _ in range(max(0, (1 if gather else args.search_threads) - 1))]
 
-    stats = {"kernel_ms": [], "pipeline_ms": [], "poa_ms": [], "aln_ms": [], "call_wall_ms": []}
+    stats = {"kernel_ms": [], "pipeline_ms": [], "poa_ms": [], "aln_ms": [], "call_wall_ms": [], "call_steps": []}
 
     def run_steps(n_steps, record):
         """n_steps steps: step i = search(i), then call(i).  With --call-threads T > 0 the steps are software-pipelined:
@@ -407,16 +435,24 @@ def main():
         steps: a single step's POA batch leaves most of the chip idle while its longest chains finish)."""
         import queue
         import threading
+        G = args.call_group
+        n_grouped = (n_steps // G) * G if G > 1 else 0     # steps whose sub-clusters go G steps at a time
         if cw is None or args.call_threads <= 0:
-            for _ in range(n_steps):
+            for i in range(n_steps):
                 search()
                 if record:
                     stats["kernel_ms"].append(pp.last_search_kernel_ms)
                     stats["pipeline_ms"].append(pp.last_kernel_ms)
                 if cw is not None:
-                    cw.run(lib, check, local_rank)
-                    if record:
-                        note_call(cw)
+                    if i < n_grouped:
+                        if (i + 1) % G == 0:
+                            workers[0][1].run(lib, check, local_rank)
+                            if record:
+                                note_call(workers[0][1], G)
+                    else:
+                        cw.run(lib, check, local_rank)
+                        if record:
+                            note_call(cw, 1)
             return
         todo = queue.Queue()
         errors = []
@@ -425,12 +461,13 @@ def main():
             torch.cuda.set_device(local_rank)
             try:
                 while True:
-                    i = todo.get()
-                    if i is None:
+                    n = todo.get()
+                    if n is None:
                         return
-                    w.run(lib, check, local_rank)
+                    b = w[1] if n > 1 else w[0]      # the batch of G steps' sub-clusters / of one step's
+                    b.run(lib, check, local_rank)
                     if record:
-                        note_call(w)
+                        note_call(b, n)
             except BaseException as e:   # noqa: BLE001  (re-raised in the main thread)
                 errors.append(e)
 
@@ -440,6 +477,7 @@ def main():
         steps_q = queue.Queue()
         for i in range(n_steps):
             steps_q.put(i)
+        searched = [0]
 
         def searcher(spp, sst):
             torch.cuda.set_device(local_rank)
@@ -454,7 +492,13 @@ def main():
                         with lock:
                             stats["kernel_ms"].append(spp.last_search_kernel_ms)   # HIP events on the search stream
                             stats["pipeline_ms"].append(spp.last_kernel_ms)
-                    todo.put(i)
+                    with lock:       # the call side is handed the steps whose search is done, G at a time
+                        searched[0] += 1
+                        k = searched[0]
+                    if k > n_grouped:
+                        todo.put(1)
+                    elif k % G == 0:
+                        todo.put(G)
             except BaseException as e:   # noqa: BLE001
                 errors.append(e)
 
@@ -475,13 +519,20 @@ def main():
 
     lock = __import__("threading").Lock()
 
-    def note_call(w):
+    def note_call(w, n):
         with lock:
             stats["poa_ms"].append(w.last["poa_kernel_ms"])
             stats["aln_ms"].append(w.last["realign_kernel_ms"])
             stats["call_wall_ms"].append(w.last["poa_wall_ms"] + w.last["realign_wall_ms"] + w.last["ratio_wall_ms"])
+            stats["call_steps"].append(n)
 
-    workers = [cw] + [cw.clone() for _ in range(max(0, args.call_threads - 1))] if cw is not None else []
+    # per call thread: a batch object for one step's sub-clusters and one for a group's
+    workers = []
+    if cw is not None:
+        for t in range(max(1, args.call_threads)):
+            one = cw if t == 0 else cw.clone()
+            workers.append((one, one.tiled(args.call_group) if args.call_group > 1 else None))
+    gw = workers[0][1] if workers else None
 
     # raw (unassembled) SFS count: the N_sfs of SURVEY 8(d)'s reference-model bytes; and the search kernel on an
     # otherwise idle GPU
@@ -494,9 +545,21 @@ def main():
     call_alone = None
     if cw is not None:
         for w in workers:       # first call of every batch object: allocates its device arena
-            w.run(lib, check, local_rank)
+            for b in w:
+                if b is not None:
+                    b.run(lib, check, local_rank)
         cw.run(lib, check, local_rank)
         call_alone = dict(cw.last)
+        group_alone = None
+        if gw is not None:
+            gw.run(lib, check, local_rank)
+            group_alone = dict(gw.last)
+            # the group is the step's workload G times: G times the step's results
+            for key in ("cons_len", "n_cig", "scores"):
+                if not np.array_equal(gw.last[key], np.tile(cw.last[key], args.call_group)):
+                    raise SystemExit(f"CALL GROUP MISMATCH: {key} of the batch of {args.call_group} steps is not {args.call_group} x the step's")
+            if not np.array_equal(gw.last["cig"], np.tile(cw.last["cig"], args.call_group)):
+                raise SystemExit("CALL GROUP MISMATCH: CIGARs")
     run_steps(args.warmup, record=False)
     finish_gathers()
     torch.cuda.synchronize()
@@ -552,7 +615,7 @@ def main():
                              + (f" + call DP for the {cw.n_clusters} clusters / {cw.n_sub} sub-clusters those reads imply "
                                 f"(20,000 SVs per 30x: POA of {int(cw.cluster_off[-1])} sub-reads, realignment, chain-filter "
                                 "ratio; sub-reads handed over as host buffers)" if cw is not None else "")),
-                "reads_per_gpu": n_reads, "read_len": L, "index_bytes": ix.device_bytes,
+                "reads_per_gpu": n_reads, "read_len": L, "index_bytes": ix.device_bytes, "hbm_free_before_the_steps": hbm_free_after_reads,
                 "parallelism": (f"contigs dealt to {world} GPU(s) by LPT, reads drawn from each rank's contigs, index "
                                 "replicated (built per rank in HBM), "
                                 + ("assembled SFS gathered on rank 0 over RCCL every step" if gather
@@ -564,7 +627,7 @@ def main():
                 "search_ms_per_step": float(np.mean(pipeline_ms)),
                 "search_kernel_ms_on_idle_gpu": float(np.mean(alone_ms)),
                 "pipelining": (f"{args.call_threads} call thread(s): the call-side DP of up to {args.call_threads} earlier "
-                               "steps runs beside the search of the current one" if cw is not None and args.call_threads > 0
+                               f"call batches (of {args.call_group} step(s) each) runs beside the search of the current step" if cw is not None and args.call_threads > 0
                                else "none: search and call of a step back to back"),
             },
         }
@@ -574,16 +637,28 @@ def main():
                                           tag=(f"_families{args.divergence:g}" if families else ""))
         if cw is not None:
             okc, n_alt = cw.svs_recovered()
-            poa_k, aln_k = float(np.mean(poa_ms)), float(np.mean(aln_ms))
+            # per STEP: the batches of the timed region covered call_steps steps each
+            n_call_steps = float(sum(stats["call_steps"]))
+            poa_k, aln_k = float(np.sum(poa_ms)) / n_call_steps, float(np.sum(aln_ms)) / n_call_steps
             out["config"]["call_dp"] = {
                 "clusters": cw.n_clusters, "subclusters": cw.n_sub, "subreads": int(cw.cluster_off[-1]),
-                "call_wall_ms_per_step": float(np.mean(call_wall_ms)),
+                "call_group_steps": args.call_group,
+                "call_batches_in_the_timed_region": {str(g): stats["call_steps"].count(g) for g in sorted(set(stats["call_steps"]))},
+                "what_a_call_batch_is": (f"the sub-clusters of {args.call_group} consecutive steps ({gw.n_sub} sub-clusters) as one batch, handed over "
+                                         f"when the last of their searches is done; steps that do not fill a group one by one; every step's "
+                                         "sub-clusters are processed inside the timed region" if gw is not None else "one step's sub-clusters"),
+                "group_call_on_idle_gpu": ({"subclusters": gw.n_sub, "poa_kernel_ms": round(group_alone["poa_kernel_ms"], 3),
+                                            "realign_kernel_ms": round(group_alone["realign_kernel_ms"], 3),
+                                            "poa_gcups": group_alone["poa_cells"] / (group_alone["poa_kernel_ms"] * 1e-3) / 1e9,
+                                            "wall_ms": round(group_alone["poa_wall_ms"] + group_alone["realign_wall_ms"] + group_alone["ratio_wall_ms"], 3)}
+                                           if group_alone is not None else None),
+                "call_wall_ms_per_step": float(np.sum(call_wall_ms)) / n_call_steps,
                 "one_call_on_idle_gpu": {"poa_kernel_ms": round(call_alone["poa_kernel_ms"], 3),
                                          "realign_kernel_ms": round(call_alone["realign_kernel_ms"], 3),
                                          "ratio_wall_ms": round(call_alone["ratio_wall_ms"], 3),
                                          "wall_ms": round(call_alone["poa_wall_ms"] + call_alone["realign_wall_ms"]
                                                           + call_alone["ratio_wall_ms"], 3)},
-                "poa_kernel_ms": round(poa_k, 3), "poa_cells": cw.last["poa_cells"],
+                "poa_kernel_ms": round(poa_k, 3), "poa_kernel_ms_is": "per step (kernel time of the timed region's call batches / steps they covered)", "poa_cells": cw.last["poa_cells"],
                 "poa_gcups": cw.last["poa_cells"] / (poa_k * 1e-3) / 1e9, "poa_subclusters_on_hbm_kernel": cw.last["poa_hbm"],
                 "realign_kernel_ms": round(aln_k, 3), "realign_cells": cw.last["realign_cells"],
                 "realign_gcups": cw.last["realign_cells"] / (aln_k * 1e-3) / 1e9,
@@ -604,11 +679,12 @@ def main():
             # reads and the call-side arenas first
             for sp, _ in searchers:
                 sp.close()
-            for w in workers:
+            for w, _g in workers:      # (a pair shares its batch objects)
                 for h, free in ((w._poa, lib.svdss_poa_batch_free), (w._aln, lib.svdss_aln_batch_free)):
                     if h:
                         free(h)
-                w._poa, w._aln = C.c_void_p(), C.c_void_p()
+                w._poa.value = None
+                w._aln.value = None
             ix.close()
             del d_reads, d_offs
             torch.cuda.empty_cache()
