@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/svdss_hip.h"
@@ -402,6 +403,15 @@ static int build_table(svdss_index* ix) {
   return SVDSS_OK;
 }
 
+// the k-mer table of an index just built with defer_host_blocks, the host copy of its rank blocks coming down meanwhile
+static int table_and_blocks(svdss_index* ix) {
+  int frc = SVDSS_OK;
+  std::thread fetch([&] { frc = svdss_index_fetch_blocks(ix); });
+  const int rc = build_table(ix);
+  fetch.join();
+  return rc != SVDSS_OK ? rc : frc;
+}
+
 extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
   if (!ix || device < 0) return SVDSS_EINVAL;
   HIPCHK(hipSetDevice(device));
@@ -411,8 +421,8 @@ extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
     // restored from a records file: the index is built where it is going to live (GRCh38 lengths: seconds; the host
     // builder + upload only when the device cannot)
     int rc = getenv("SVDSS_INDEX_CPU") ? -1 : svdss_index_build_gpu(ix->records.data(), ix->rec_lens.data(),
-                                                                    (int32_t)ix->rec_lens.size(), device, ix);
-    if (rc == SVDSS_OK) return build_table(ix);
+                                                                    (int32_t)ix->rec_lens.size(), device, ix, true);
+    if (rc == SVDSS_OK) return table_and_blocks(ix);
     if (rc > 0) return rc;
     free_device_side(ix);
     rc = materialize(ix);
@@ -479,8 +489,8 @@ extern "C" int svdss_index_replicate(const svdss_index_t* src, int32_t device, s
     // array through the host)
     svdss_index* ix = new (std::nothrow) svdss_index();
     if (!ix) return SVDSS_ENOMEM;
-    int rc = svdss_index_build_gpu(src->records.data(), src->rec_lens.data(), (int32_t)src->rec_lens.size(), device, ix);
-    if (rc == SVDSS_OK) rc = build_table(ix);
+    int rc = svdss_index_build_gpu(src->records.data(), src->rec_lens.data(), (int32_t)src->rec_lens.size(), device, ix, true);
+    if (rc == SVDSS_OK) rc = table_and_blocks(ix);
     if (rc == SVDSS_OK) { *out = ix; return SVDSS_OK; }
     free_device_side(ix);
     delete ix;

@@ -504,7 +504,7 @@ int suffix_sort(const uint8_t* text, int64_t n, uint64_t* sa, uint64_t* rank, si
 // 0 = done; -1 = not possible here (no GPU / memory / degenerate text): use the host builder;
 // SVDSS_EINVAL / SVDSS_ERANGE as the host builder reports them.
 int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
-                          svdss_index* ix) {
+                          svdss_index* ix, bool defer_host_blocks) {
   if (!contigs || !lens || n_contigs <= 0 || !ix) return SVDSS_EINVAL;
   const bool verbose = getenv("SVDSS_INDEX_VERBOSE") != nullptr;
   int ndev = 0;
@@ -636,12 +636,13 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
     P.release(d_tmp); P.release(d_tmp3); P.release(d_tot);
   }
   P.release(d_cntb); P.release(d_nd);
-  // host side: blocks, '$' list, acc
+  // host side: blocks, '$' list, acc.  (defer_host_blocks: the caller brings the rank blocks down beside the k-mer table's
+  // build, svdss_index_fetch_blocks -- 3.1 GB into ordinary memory are 0.7 s of a restore at GRCh38 lengths)
   try {
-    ix->blocks.resize((size_t)(4 * nb));
+    if (!defer_host_blocks) ix->blocks.resize((size_t)(4 * nb));
     ix->dollar.resize((size_t)n_dollar);
   } catch (...) { return SVDSS_ENOMEM; }
-  GCHK(hipMemcpy(ix->blocks.data(), d_blocks, (size_t)nb * 64, hipMemcpyDeviceToHost));
+  if (!defer_host_blocks) GCHK(hipMemcpy(ix->blocks.data(), d_blocks, (size_t)nb * 64, hipMemcpyDeviceToHost));
   GCHK(hipMemcpy(ix->dollar.data(), d_dollar + n_dollar + 1, (size_t)n_dollar * 8, hipMemcpyDeviceToHost));
   int64_t* d_dollar_final;
   PALLOC(P, d_dollar_final, (size_t)(n_dollar + 1) * 8);
@@ -665,6 +666,23 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
   ix->table_k = 0;
   mark("counters, blocks to the host");
   return 0;
+}
+
+// the rank blocks of an index built with defer_host_blocks -> host vector, on a stream of its own (the caller's thread
+// runs beside build_table's kernel)
+int svdss_index_fetch_blocks(svdss_index* ix) {
+  if (!ix || ix->device < 0 || !ix->d_blocks) return SVDSS_EINVAL;
+  const int64_t nb = ix->n / SVDSS_BLOCK_SYMS + 1;
+  if ((int64_t)ix->blocks.size() == 4 * nb) return SVDSS_OK;
+  if (hipSetDevice(ix->device) != hipSuccess) { (void)hipGetLastError(); return SVDSS_EHIP; }
+  try { ix->blocks.resize((size_t)(4 * nb)); } catch (...) { return SVDSS_ENOMEM; }
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ix->blocks.clear(); return SVDSS_EHIP; }
+  const bool ok = hipMemcpyAsync(ix->blocks.data(), ix->d_blocks, (size_t)nb * 64, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                  hipStreamSynchronize(st) == hipSuccess;
+  (void)hipStreamDestroy(st);
+  if (!ok) { (void)hipGetLastError(); ix->blocks.clear(); return SVDSS_EHIP; }
+  return SVDSS_OK;
 }
 
 // the text of a device-built index -> host vector (no-op when it is there already)

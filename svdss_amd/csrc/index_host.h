@@ -1,9 +1,26 @@
 // index_host.h -- host-side index object behind the opaque svdss_index_t.
 #pragma once
 #include <stdint.h>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 #include "fmd_layout.h"
+
+// std::allocator whose construct() leaves trivially constructible elements alone: resize() of a vector that is about to
+// be filled from a file does not write the zeros first (3.1 GB of records: 0.3 s on one core, and every page touched by
+// that core instead of by the threads that read into it)
+template <class T>
+struct SvdssNoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = SvdssNoInitAlloc<U>; };
+  SvdssNoInitAlloc() = default;
+  template <class U> SvdssNoInitAlloc(const SvdssNoInitAlloc<U>&) {}
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
 
 struct svdss_index {
   int64_t n = 0;              // BWT length = sum over contigs of 2*(len+1)
@@ -18,7 +35,7 @@ struct svdss_index {
   // The records the index stands for (nt6, concatenated) -- all an index restored from a records file holds until it
   // is made resident or a host-side accessor needs the layout (svdss_index_materialize): rebuilding GRCh38 lengths in
   // HBM takes seconds, reading the 58 GB of text + suffix array from a file takes longer on any disk.
-  std::vector<uint8_t> records;
+  std::vector<uint8_t, SvdssNoInitAlloc<uint8_t>> records;
   std::vector<int64_t> rec_lens;
   // device residency (filled by svdss_index_to_device)
   int device = -1;
@@ -47,7 +64,10 @@ void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt);
 // not copied to the host: svdss_index_fetch_host does that on demand).  0 = done, -1 = not possible here (use the
 // host builder), SVDSS_EINVAL / SVDSS_ERANGE as svdss_index_build_host reports them.
 int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
-                          svdss_index* out);
+                          svdss_index* out, bool defer_host_blocks = false);
+// defer_host_blocks: the host copy of the rank blocks is left out; svdss_index_fetch_blocks brings it down (the restore
+// paths run it on a thread beside the k-mer table's build)
+int svdss_index_fetch_blocks(svdss_index* ix);
 int svdss_index_fetch_host(svdss_index* ix);
 int svdss_index_fetch_text(svdss_index* ix);   // the text alone (n bytes, not the 4-8 n of the suffix array)
 // the kernels' view of a resident index (index_api.hip)

@@ -312,6 +312,44 @@ def test_segmented_search_is_exact(monkeypatch, segments):
         pp.close()
 
 
+@pytest.mark.parametrize("n_reads,direct", [(24, None), (150, None), (150, "0"), (24, "1000000")])
+def test_reads_with_long_novel_insertions_in_segmented_launches(monkeypatch, n_reads, direct):
+    """What `SVDSS search` sees after `SVDSS smooth`: reads that equal the reference except for one long insertion of
+    novel sequence -- an SFS at nearly every base of it.  The segment that owns the insertion overflows its record
+    region: it stops at once (second session of round 5; it used to walk the whole stretch for nothing), the read goes
+    to the next level -- at most SVDSS_FALLBACK_DIRECT (64) such reads straight to one lane each, more through a level
+    with a quarter of the segments first.  Whatever the route: the oracle's SFS, order and extension counts."""
+    monkeypatch.setenv("SVDSS_SEGMENTS", "8")
+    if direct is not None:
+        monkeypatch.setenv("SVDSS_FALLBACK_DIRECT", direct)
+    rng = np.random.default_rng(77)
+    ref = synth.make_reference([500000], seed=5)
+    reads = []
+    for k in range(n_reads):
+        a = int(rng.integers(0, 500000 - 9000))
+        r = ref[0][a:a + 8000].copy()
+        ins = rng.integers(1, 5, size=int(rng.integers(300, 2001))).astype(np.uint8)
+        cut = int(rng.integers(500, 7500))
+        r = np.concatenate([r[:cut], ins, r[cut:]]) if k % 5 else r            # (every fifth read: a plain copy)
+        if k % 7 == 3:
+            r = synth.revcomp(r)
+        reads.append(r)
+    flat, offs = svdss_amd.pack_reads(reads)
+    ix = svdss_amd.FMDIndex.build(ref).to_device(0)
+    fm = O.OracleFMD.build(ref)
+    for assemble in (False, True):
+        pp = svdss_amd.PingPong(ix, assemble=assemble)
+        got = pp.ping_pong_search(flat, offs)
+        assert pp.last_segments == 8
+        assert pp.last_fallbacks >= n_reads // 2           # the reads with an insertion overflow a segment's region
+        c, q, l, e = fm.search_batch(flat, offs, assemble)
+        assert (got.counts == c).all() and (got.n_ext == e).all()
+        assert (got.qs == q).all() and (got.len == l).all()
+        if not assemble:
+            assert int(c.max()) > 300                       # an SFS per base of the longest insertions
+        pp.close()
+
+
 @pytest.mark.parametrize("env", [
     {"SVDSS_ORDER": "0"},
     {"SVDSS_ORDER": "1", "SVDSS_TICKETS": "1"},

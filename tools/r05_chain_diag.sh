@@ -22,7 +22,7 @@ for k in 1 2; do
 done
 cmp $W/sm2.bam $SM && echo "smoothed BAM identical to the chain's" >> "$OUT/files.txt"
 for k in 1 2; do
-  tm "search" $EXE search --index $FMD --bam $SM --verbose > $W/sfs2.txt 2> "$OUT/search_$k.log"
+  tm "search" env SVDSS_INDEX_VERBOSE=1 $EXE search --index $FMD --bam $SM --verbose > $W/sfs2.txt 2> "$OUT/search_$k.log"
 done
 cmp $W/sfs2.txt $SFS && echo "SFS identical to the chain's" >> "$OUT/files.txt"
 tm "call" $EXE call --reference $FA --bam $SM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls.vcf 2> "$OUT/call_1.log"
