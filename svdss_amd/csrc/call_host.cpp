@@ -473,6 +473,12 @@ struct CallRun {
     const char* e = getenv("SVDSS_BAM_BATCH_MB");
     return (e && atoll(e) > 0 ? atoll(e) : 256) << 20;
   }
+  // host threads that scan the file chunks an index names for pass 2 (SVDSS_CALL_PASS2_THREADS; 1: the single scan)
+  size_t pass2_threads(size_t n_chunks) const {
+    const char* e = getenv("SVDSS_CALL_PASS2_THREADS");
+    const size_t want = e && atoi(e) > 0 ? (size_t)atoi(e) : std::min<size_t>((size_t)effective_cpus(), 32);
+    return std::max<size_t>(1, std::min(want, n_chunks / 4 + 1));
+  }
   static int bam_feeders() {             // feeding threads (device batches in flight) per GPU of the two BAM passes
     const char* e = getenv("SVDSS_CALL_FEEDERS");
     return e && atoi(e) > 0 ? atoi(e) : 3;
@@ -961,24 +967,66 @@ struct CallRun {
             if (re >= 0) { bai.query((int)t, rb, re, chunks); ++n_regions; }
           }
           BaiIndex::merge(chunks);
-          // The index names the file chunks around the clusters; one host thread inflates them (~0.3 GB/s).  When they are
-          // more than a few percent of the file, reading ALL of it through the device path (tens of GB/s, only the
-          // overlapping records come back) is quicker: SVDSS_CALL_PASS2 = bai | device overrides the estimate.
+          // The index names the file chunks around the clusters; host threads inflate them (~0.3 GB/s each; second session
+          // of round 5: all of them, until then one).  When the chunks are a large part of the file, reading ALL of it
+          // through the device path (tens of GB/s, only the overlapping records come back) is quicker: beyond 8 % of the
+          // file per thread that scans.  SVDSS_CALL_PASS2 = bai | device overrides the estimate.
           if (dev_pass) {
             uint64_t chunk_bytes = 0;
             for (const auto& ch : chunks) chunk_bytes += (ch.second >> 16) - (ch.first >> 16) + 65536;
             struct stat st;
             const uint64_t file_bytes = stat(o.bam.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
             const char* p2 = getenv("SVDSS_CALL_PASS2");
+            const double share = std::min(0.6, 0.08 * (double)pass2_threads(chunks.size()));
             if (p2 && !strcmp(p2, "device")) have_bai = false;
-            else if (!(p2 && !strcmp(p2, "bai")) && file_bytes && (double)chunk_bytes > 0.08 * (double)file_bytes) have_bai = false;
+            else if (!(p2 && !strcmp(p2, "bai")) && file_bytes && (double)chunk_bytes > share * (double)file_bytes) have_bai = false;
           }
         }
         if (have_bai) {
           logmsg("debug", std::string("pass 2 through the ") + (bai.csi ? "CSI" : "BAI") + " index: " + std::to_string(n_regions) + " regions, " + std::to_string(chunks.size()) +
                               " file chunks");
-          const std::string e = bam_scan_chunks(o.bam, chunks, [&](const BamReader::RawView& rr) { process(rr, qname, apply); });
-          if (!e.empty()) die("error reading " + o.bam + ": " + e);
+          const size_t Wt = pass2_threads(chunks.size());
+          if (Wt <= 1) {
+            const std::string e = bam_scan_chunks(o.bam, chunks, [&](const BamReader::RawView& rr) { process(rr, qname, apply); });
+            if (!e.empty()) die("error reading " + o.bam + ": " + e);
+          } else {
+            // Runs of consecutive chunks of about the same size in the file, a few per thread, taken in turn: every run is
+            // scanned by one thread with a file handle and an inflater of its own (bam_scan_chunks), what its records do
+            // to the clusters is collected and applied run after run -- the order of the single scan.
+            std::vector<std::pair<size_t, size_t>> runs;
+            {
+              uint64_t total = 0;
+              for (const auto& ch : chunks) total += (ch.second >> 16) - (ch.first >> 16) + 65536;
+              const uint64_t per = std::max<uint64_t>(1, total / (4 * Wt));
+              size_t a = 0;
+              uint64_t acc = 0;
+              for (size_t k = 0; k < chunks.size(); ++k) {
+                acc += (chunks[k].second >> 16) - (chunks[k].first >> 16) + 65536;
+                if (acc >= per || k + 1 == chunks.size()) { runs.emplace_back(a, k + 1); a = k + 1; acc = 0; }
+              }
+            }
+            std::vector<std::vector<Ev>> evs(runs.size());
+            std::vector<std::string> errs(runs.size());
+            std::atomic<size_t> next(0);
+            auto work = [&]() {
+              std::string nm;
+              for (;;) {
+                const size_t g = next.fetch_add(1);
+                if (g >= runs.size()) return;
+                const std::vector<std::pair<uint64_t, uint64_t>> sub(chunks.begin() + (ptrdiff_t)runs[g].first, chunks.begin() + (ptrdiff_t)runs[g].second);
+                auto sink = [&](Ev& e) { evs[g].push_back(std::move(e)); };
+                errs[g] = bam_scan_chunks(o.bam, sub, [&](const BamReader::RawView& rr) { process(rr, nm, sink); });
+              }
+            };
+            std::vector<std::thread> pool;
+            for (size_t w = 1; w < Wt; ++w) pool.emplace_back(work);
+            work();
+            for (std::thread& th : pool) th.join();
+            for (size_t g = 0; g < runs.size(); ++g) {
+              if (!errs[g].empty()) die("error reading " + o.bam + ": " + errs[g]);
+              for (Ev& e : evs[g]) apply(e);
+            }
+          }
         } else if (dev_pass) {
           // no index: the file again through the device path, the (merged) cluster regions as the filter -- the records
           // that overlap a cluster come back, in file order

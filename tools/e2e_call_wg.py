@@ -344,10 +344,12 @@ def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005):
     out["sfs_bytes"] = os.path.getsize(sfs)
     out["search_log"] = [ln for ln in r.stderr.splitlines() if "debug" in ln][-6:]
     t0 = time.perf_counter()
-    c = subprocess.run([exe, "call", "--reference", fa, "--bam", sm, "--sfs", sfs, "--threads", str(threads), "--min-sv-length", "50", "--verbose"],
+    # (run_svdss:167-176 hands `call` the ORIGINAL BAM -- the one with an index beside it -- and the SFS of the smoothed reads)
+    c = subprocess.run([exe, "call", "--reference", fa, "--bam", bam, "--sfs", sfs, "--threads", str(threads), "--min-sv-length", "50", "--verbose"],
                        check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     out["call_s"] = round(time.perf_counter() - t0, 3)
-    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "[time]" in ln][-20:]
+    out["call_bam"] = "the original BAM (its .bai beside it), as run_svdss does; until the second session of round 5: the smoothed BAM (no index)"
+    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "[time]" in ln or "pass 2 through" in ln][-20:]
     n_called, hit = _vcf_hits(c.stdout.decode(), svs)
     chain = out["smooth_s"] + out["search_s"] + out["call_s"]
     out.update({"svs_called": n_called, "truth_recovered": hit, "smooth_reads_per_s": n / out["smooth_s"],

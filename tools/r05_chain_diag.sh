@@ -25,7 +25,12 @@ for k in 1 2; do
   tm "search" env SVDSS_INDEX_VERBOSE=1 $EXE search --index $FMD --bam $SM --verbose > $W/sfs2.txt 2> "$OUT/search_$k.log"
 done
 cmp $W/sfs2.txt $SFS && echo "SFS identical to the chain's" >> "$OUT/files.txt"
-tm "call" $EXE call --reference $FA --bam $SM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls.vcf 2> "$OUT/call_1.log"
+tm "call (smoothed BAM, no index)" $EXE call --reference $FA --bam $SM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls.vcf 2> "$OUT/call_1.log"
+for cfg in "SVDSS_X=1" "SVDSS_CALL_PASS2=bai" "SVDSS_CALL_PASS2=bai SVDSS_CALL_PASS2_THREADS=1" "SVDSS_CALL_PASS2=device"; do
+  tm "call (original BAM + BAI) $cfg" env $cfg $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls_o.vcf 2> "$OUT/call_orig.log"
+  echo "== $cfg: $(cmp $W/calls_o.vcf $W/calls.vcf && echo "VCF identical to the smoothed BAM's")" >> $OUT/call_orig_all.txt
+  grep "pass 1\|pass 2" "$OUT/call_orig.log" >> $OUT/call_orig_all.txt
+done
 # kernel traces (the binaries end with _exit unless SVDSS_CLEAN_EXIT is set: rocprofv3 writes its files at exit)
 export TMPDIR=/tmp
 for st in search smooth call; do
@@ -37,12 +42,5 @@ for st in search smooth call; do
   ( cd /tmp && SVDSS_DEBUG=1 SVDSS_CLEAN_EXIT=1 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/prof_$st -- $CMD > /dev/null 2> $ROOT/$OUT/${st}_prof.log )
   f=$(find /tmp/prof_$st -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $ROOT/$OUT/${st}_kernel_stats.csv
   python3 tools/trace_summary.py /tmp/prof_$st $([ $st = call ] || echo inflate) > $ROOT/$OUT/${st}_trace_summary.txt 2>&1
-done
-# call: feeding threads / batch size of its two BAM passes
-for cfg in "SVDSS_CALL_FEEDERS=3" "SVDSS_CALL_FEEDERS=5" "SVDSS_CALL_FEEDERS=6 SVDSS_BAM_BATCH_MB=128" "SVDSS_CALL_FEEDERS=6 SVDSS_BAM_BATCH_MB=192" "SVDSS_REF_UPLOAD_THREADS=1"; do
-  echo "== $cfg" >> $OUT/call_sweep.txt
-  t0=$(date +%s%N)
-  env $cfg $EXE call --reference $FA --bam $SM --sfs $SFS --threads 16 --min-sv-length 50 --verbose 2>&1 > $W/calls2.vcf | grep "pass 1\|pass 2" >> $OUT/call_sweep.txt
-  t1=$(date +%s%N); echo "wall $(( (t1 - t0) / 1000000 )) ms; vcf $(cmp $W/calls2.vcf $W/calls.vcf && echo identical)" >> $OUT/call_sweep.txt
 done
 du -sh "$OUT" >> "$OUT/files.txt"
