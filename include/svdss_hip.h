@@ -184,8 +184,8 @@ void svdss_inflate_free(svdss_inflate_t* obj);
  * sam_write1 in `SVDSS smooth` (/root/reference/smoother.cpp:441-494).  `in` (host memory) is cut into blocks of
  * block_bytes (<= 0xff00; the last one may be short); block i becomes a BGZF member at out + i * out_stride (host
  * memory; out_stride >= block_bytes + 64, a multiple of 4): 18-byte header with BSIZE, a deflate stream of dynamic-
- * Huffman coded literals (no matches: a level-1-class encoder for packed bases and qualities; incompressible quarters
- * are stored), and 8 bytes LEFT FOR THE CALLER to fill with CRC32 and ISIZE; out_len[i] = the member's length with
+ * Huffman coded literals and runs (4, 8, ... 256 equal bytes as one match at distance 1; no other matches: a
+ * level-1-class encoder for packed bases and qualities; incompressible quarters are stored), and 8 bytes LEFT FOR THE CALLER to fill with CRC32 and ISIZE; out_len[i] = the member's length with
  * those 8 bytes.  out_stride 0: the members are written back to back instead (out needs in_bytes + 64 per block).
  * Any inflater reads the result; it is not the byte stream zlib would write.  Returns when done (the
  * object's own stream: calls on different objects overlap). */

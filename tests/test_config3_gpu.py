@@ -82,6 +82,14 @@ def test_chr20_10x_end_to_end(tmp_path):
         assert ("through the BAI index" in r_p2.stderr) == (with_bai is True)
         assert ("through the CSI index" in r_p2.stderr) == (with_bai == "csi")
         assert r_p2.stdout == vcf
+        if with_bai:
+            # the chunks the index names scanned by one host thread and by seven (runs of consecutive chunks taken in turn,
+            # applied in file order): the same VCF
+            for thr in ("1", "7"):
+                r_t = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50"],
+                                     capture_output=True, text=True,
+                                     env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai", SVDSS_CALL_PASS2_THREADS=thr))
+                assert r_t.returncode == 0 and r_t.stdout == vcf, (thr, r_t.stderr[-300:])
         # (and the host reader without its cache, with and without the index; with the index present the device path may
         # still read the whole file when the chunks the index names are a large part of it: SVDSS_CALL_PASS2=device)
         for env in ({"SVDSS_BAM_DEVICE": "0"}, {"SVDSS_CALL_PASS2": "device"}):
