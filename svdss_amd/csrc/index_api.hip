@@ -403,13 +403,11 @@ static int build_table(svdss_index* ix) {
   return SVDSS_OK;
 }
 
-// the k-mer table of an index just built with defer_host_blocks, the host copy of its rank blocks coming down meanwhile
+// the host copy of the rank blocks of an index just built with defer_host_blocks (four threads: index_gpu.hip), then
+// its k-mer table
 static int table_and_blocks(svdss_index* ix) {
-  int frc = SVDSS_OK;
-  std::thread fetch([&] { frc = svdss_index_fetch_blocks(ix); });
-  const int rc = build_table(ix);
-  fetch.join();
-  return rc != SVDSS_OK ? rc : frc;
+  const int rc = svdss_index_fetch_blocks(ix);
+  return rc != SVDSS_OK ? rc : build_table(ix);
 }
 
 extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {

@@ -355,7 +355,8 @@ int svdss_index_load_records_host(const char* path, svdss_index* ix) {
     const int64_t piece = (int64_t)32 << 20, n_pieces = (h.total + piece - 1) / piece;
     bool good = true;
     uint8_t* dst = ix->records.data();
-#pragma omp parallel for reduction(&& : good) schedule(dynamic, 1)
+    // (at most 32 threads: the page cache does not give more, and a box may show far more cores than its quota grants)
+#pragma omp parallel for reduction(&& : good) schedule(dynamic, 1) num_threads(getenv("SVDSS_INDEX_SERIAL_READ") ? 1 : std::min(omp_get_max_threads(), 32))
     for (int64_t k = 0; k < n_pieces; ++k) {
       const int64_t a = k * piece, b = std::min(h.total, a + piece);
       int64_t got = a;

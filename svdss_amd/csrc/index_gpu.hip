@@ -28,6 +28,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
+#include <thread>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -668,20 +671,36 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
   return 0;
 }
 
-// the rank blocks of an index built with defer_host_blocks -> host vector, on a stream of its own (the caller's thread
-// runs beside build_table's kernel)
+// the rank blocks of an index built with defer_host_blocks -> host vector
 int svdss_index_fetch_blocks(svdss_index* ix) {
   if (!ix || ix->device < 0 || !ix->d_blocks) return SVDSS_EINVAL;
   const int64_t nb = ix->n / SVDSS_BLOCK_SYMS + 1;
   if ((int64_t)ix->blocks.size() == 4 * nb) return SVDSS_OK;
   if (hipSetDevice(ix->device) != hipSuccess) { (void)hipGetLastError(); return SVDSS_EHIP; }
   try { ix->blocks.resize((size_t)(4 * nb)); } catch (...) { return SVDSS_ENOMEM; }
-  hipStream_t st = nullptr;
-  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ix->blocks.clear(); return SVDSS_EHIP; }
-  const bool ok = hipMemcpyAsync(ix->blocks.data(), ix->d_blocks, (size_t)nb * 64, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                  hipStreamSynchronize(st) == hipSuccess;
-  (void)hipStreamDestroy(st);
-  if (!ok) { (void)hipGetLastError(); ix->blocks.clear(); return SVDSS_EHIP; }
+  // Plain blocking copies into ordinary memory, a quarter of the blocks per thread (the copy of ordinary memory is staged
+  // by the calling thread: one thread 0.4 s, and the vector's zero fill before it 0.3 s -- gone with the allocator of
+  // index_host.h).  Two asynchronous versions came first (one copy on a stream of its own beside the k-mer table's
+  // build; the same through page-locked bounce buffers): both took the copy off the critical path and BOTH left every
+  // later host <-> device copy of the process slower -- `SVDSS search` streamed 0.58 -> 0.63 s on the chain bench's BAM,
+  // 0.58 -> 0.80 s on the bench's 15 GB one (tools/r05_restore_ab.sh, profiles/r05z_restore_ab.txt) -- so the copy stays
+  // where it was, in front of the table's build, and is merely quicker.
+  const size_t total = (size_t)nb * 64;
+  const int T = 4;
+  std::atomic<int> bad(0);
+  uint8_t* dst = (uint8_t*)ix->blocks.data();
+  const int dev = ix->device;
+  const void* src = ix->d_blocks;
+  auto part = [&](int t) {
+    if (hipSetDevice(dev) != hipSuccess) { bad = 1; return; }
+    const size_t a = total * (size_t)t / T & ~(size_t)63, b = t + 1 == T ? total : (total * (size_t)(t + 1) / T & ~(size_t)63);
+    if (b > a && hipMemcpy(dst + a, (const uint8_t*)src + a, b - a, hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(part, t);
+  part(0);
+  for (std::thread& x : th) x.join();
+  if (bad.load()) { (void)hipGetLastError(); ix->blocks.clear(); return SVDSS_EHIP; }
   return SVDSS_OK;
 }
 

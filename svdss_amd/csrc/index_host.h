@@ -26,7 +26,7 @@ struct svdss_index {
   int64_t n = 0;              // BWT length = sum over contigs of 2*(len+1)
   int64_t acc[7] = {0};
   int32_t n_contigs = 0;
-  std::vector<svdss_u4> blocks;   // 4 * (n/128 + 1) quarters
+  std::vector<svdss_u4, SvdssNoInitAlloc<svdss_u4>> blocks;   // 4 * (n/128 + 1) quarters (resize() leaves the new elements alone)
   std::vector<int64_t> dollar;    // sorted BWT positions of '$'
   std::vector<uint8_t> text;      // nt6 text (contig $ revcomp $ ...), n symbols
   std::vector<uint32_t> sa32;     // suffix array when n < 2^32 ...
