@@ -182,6 +182,16 @@ int main_smooth(const CallOptions& o) {
     void* q = nullptr;
     if (svdss_device_count() > 0 && svdss_host_alloc(1 << 20, &q) == SVDSS_OK && q) svdss_host_free(q);
   });
+  // ... and so is the BAM's header (0.3 s through the host reader: its workers, its first chunks), for the device path below
+  struct HeaderPre { std::string text, err; std::vector<std::string> names; std::vector<int32_t> lens; int32_t n_ref = 0; int64_t skip = 0; } hp;
+  std::thread header_pre([&hp, &o] {
+    BamReader hb(o.bam);
+    if (!hb.ok() || !hb.read_header()) { hp.err = "cannot read " + o.bam + ": " + hb.error(); return; }
+    hp.text = hb.header_text(); hp.names = hb.ref_names(); hp.lens = hb.ref_lens();
+    std::string perr;
+    if (!bam_header_probe(o.bam, hp.n_ref, hp.skip, perr, nullptr)) { hp.err = "cannot read " + o.bam + ": " + perr; return; }
+    if ((size_t)hp.n_ref != hp.names.size()) hp.err = "cannot read " + o.bam + ": inconsistent header";
+  });
   {
     // load_chromosomes (chromosomes.cpp:9-27).  A plain FASTA with '\n' line ends is mapped and read by several threads
     // (fastx_reader.h, as `SVDSS call` does: GRCh38 in ~0.3 s instead of ~2 s, which was half of a smooth run of a million
@@ -200,6 +210,7 @@ int main_smooth(const CallOptions& o) {
     }
   }
   gpu_warm.join();
+  header_pre.join();
   const double fasta_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fasta0).count();
   auto eligible = [&](const BamRecord& r, const std::vector<std::string>& names) {
     if (r.flag & (4 | 2048 | 256)) return false;
@@ -217,19 +228,12 @@ int main_smooth(const CallOptions& o) {
   // (SVDSS_GPU_DEFLATE=0 asks for the host's deflate: that is the host pipeline's writer)
   if (!getenv("SVDSS_SMOOTH_HOST") && svdss_device_count() > 0 && !(getenv("SVDSS_BAM_DEVICE") && atoi(getenv("SVDSS_BAM_DEVICE")) == 0) &&
       !(getenv("SVDSS_GPU_DEFLATE") && atoi(getenv("SVDSS_GPU_DEFLATE")) == 0)) {
-    std::string header_text;
-    std::vector<std::string> names;
-    std::vector<int32_t> lens;
-    {
-      BamReader hb(o.bam);
-      if (!hb.ok() || !hb.read_header()) die("cannot read " + o.bam + ": " + hb.error());
-      header_text = hb.header_text(); names = hb.ref_names(); lens = hb.ref_lens();
-    }
-    int32_t n_ref = 0;
-    int64_t skip = 0;
-    std::string perr;
-    if (!bam_header_probe(o.bam, n_ref, skip, perr, nullptr)) die("cannot read " + o.bam + ": " + perr);
-    if ((size_t)n_ref != names.size()) die("cannot read " + o.bam + ": inconsistent header");
+    if (!hp.err.empty()) die(hp.err);
+    const std::string& header_text = hp.text;
+    const std::vector<std::string>& names = hp.names;
+    const std::vector<int32_t>& lens = hp.lens;
+    const int32_t n_ref = hp.n_ref;
+    const int64_t skip = hp.skip;
     const int64_t target = (getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 64) << 20;
     const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
     const std::vector<svdss_bam_filter_t*> one(1, nullptr);
@@ -316,7 +320,9 @@ int main_smooth(const CallOptions& o) {
       for (int k = 0; k < 8; ++k) out.stage_s[k] = r.stage_ms[k] * 1e-3;
       out.inflate_kernel_s = r.inflate_kernel_ms * 1e-3;
     };
+    if (dbg) fprintf(stderr, "[smooth] BAM header read, output prefix set at +%.3f s\n", since());
     std::unique_ptr<DeviceBamSelect> rd(new DeviceBamSelect(o.bam, one, dev0, n_ref, skip, per_gpu, target, run, collect, stream));
+    if (dbg) fprintf(stderr, "[smooth] reader of the smoothing pass started at +%.3f s\n", since());
     // the chromosomes the BAM names, in its order, one device buffer (svdss_ref_upload_parts: no concatenation on the host)
     std::vector<int32_t> tid_map(names.size(), -1);
     std::vector<const uint8_t*> parts;
@@ -331,6 +337,7 @@ int main_smooth(const CallOptions& o) {
     svdss_ref_t* dref = nullptr;
     if (svdss_ref_upload_parts(parts.data(), plen.data(), (int32_t)parts.size(), 0, &dref) != SVDSS_OK)
       die(std::string("svdss_ref_upload_parts: ") + svdss_last_hip_error());
+    if (dbg) fprintf(stderr, "[smooth] chromosomes uploaded at +%.3f s\n", since());
     if (svdss_bam_smooth_create(dref, tid_map.data(), (int32_t)tid_map.size(), (int32_t)o.min_mapq, &sm) != SVDSS_OK)
       die(std::string("svdss_bam_smooth_create: ") + svdss_last_hip_error());
     if (dbg) fprintf(stderr, "[smooth] reference read in %.3f s, on the device at +%.3f s\n", fasta_s, since());
