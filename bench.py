@@ -820,13 +820,21 @@ def e2e_prepare(work, ref, wg):
                 f.write(b"\n")
 
 
-def _run_search(exe, fmd, bam, env=None, repeats=1):
+def _run_search(exe, fmd, bam, env=None, repeats=1, pause_s=0.0):
     """`SVDSS search --bam` -> dict of timings from its --verbose log.  repeats > 1: that many runs of the process, the
     one with the MEDIAN streaming time reported and every run's streaming seconds listed beside it (`streaming_s_runs`):
     the second run over a freshly generated input file waits most of a second for the file's loaders (the page cache, not
     this code: runs 1, 3, 4, 5 do not, nor does any run a second apart; profiles/r04y_consecutive_runs.txt)."""
     if repeats > 1:
-        runs = [_run_search(exe, fmd, bam, env) for _ in range(repeats)]
+        # pause_s: seconds between the end of one process and the start of the next.  A process that ends hands ~190 GB of
+        # HBM back (whole-genome index) and the driver clears them at 30-50 GB/s: the next process either waits for clean
+        # memory while it restores its index or, when enough is clean already, streams beside the clearing -- 0.56 s
+        # becomes 0.79 s (profiles/r05z_e2e_lib_ab.txt, section 3).  Back-to-back runs are this bench's doing, not a user's.
+        runs = []
+        for _ in range(repeats):
+            if pause_s > 0:
+                time.sleep(pause_s)
+            runs.append(_run_search(exe, fmd, bam, env))
         runs_sorted = sorted(runs, key=lambda r: r["streaming_s"])
         out = dict(runs_sorted[len(runs) // 2])
         out["streaming_s_runs"] = [r["streaming_s"] for r in runs]
@@ -924,9 +932,10 @@ def e2e_runs(work, n_reads, call=True):
             subprocess.run([exe, "index", "-d", os.path.join(work, "wg.fa"), "-o", os.path.join(work, "wg.fmd")], check=True, capture_output=True)
             t_index = time.perf_counter() - t0
             os.remove(os.path.join(work, "wg.fa"))
-            r = _run_search(exe, os.path.join(work, "wg.fmd"), bam, repeats=3)
+            r = _run_search(exe, os.path.join(work, "wg.fmd"), bam, repeats=3, pause_s=5.0)
             r["what"] = ("the same BAM against the index of the whole reference (24 contigs, GRCh38 primary lengths, 6.18e9 BWT "
-                         "symbols): restore = records file (%.1f GB) read + index rebuilt in HBM + K = 16 table"
+                         "symbols), every run 5 s after the process before ended (the driver clears the HBM a process hands back; "
+                         "back to back the next one streams beside that): restore = records file (%.1f GB) read + index rebuilt in HBM + K = 16 table"
                          % (os.path.getsize(os.path.join(work, "wg.fmd.svdss")) / 1e9))
             r["index_s"] = round(t_index, 2)
             r["fmd_bytes"] = os.path.getsize(os.path.join(work, "wg.fmd"))

@@ -680,11 +680,10 @@ int svdss_index_fetch_blocks(svdss_index* ix) {
   try { ix->blocks.resize((size_t)(4 * nb)); } catch (...) { return SVDSS_ENOMEM; }
   // Plain blocking copies into ordinary memory, a quarter of the blocks per thread (the copy of ordinary memory is staged
   // by the calling thread: one thread 0.4 s, and the vector's zero fill before it 0.3 s -- gone with the allocator of
-  // index_host.h).  Two asynchronous versions came first (one copy on a stream of its own beside the k-mer table's
-  // build; the same through page-locked bounce buffers): both took the copy off the critical path and BOTH left every
-  // later host <-> device copy of the process slower -- `SVDSS search` streamed 0.58 -> 0.63 s on the chain bench's BAM,
-  // 0.58 -> 0.80 s on the bench's 15 GB one (tools/r05_restore_ab.sh, profiles/r05z_restore_ab.txt) -- so the copy stays
-  // where it was, in front of the table's build, and is merely quicker.
+  // index_host.h).  Two asynchronous versions beside the k-mer table's build took the copy off the critical path
+  // altogether; they were dropped when `SVDSS search` seemed to stream slower behind them (profiles/r05z_restore_ab.txt)
+  // -- which turned out to be the driver clearing the HBM of the process before while the stream runs instead of while
+  // the restore waits (profiles/r05z_e2e_lib_ab.txt, section 3); this version is simple and costs 0.2 s.
   const size_t total = (size_t)nb * 64;
   const int T = 4;
   std::atomic<int> bad(0);
