@@ -688,6 +688,7 @@ def main():
             ix.close()
             del d_reads, d_offs
             torch.cuda.empty_cache()
+            time.sleep(6.0)   # (the driver clears the ~190 GB this process just handed back; see _run_search)
             try:
                 out.update(e2e_runs(e2e_dir, args.e2e_reads, call=not args.no_e2e_call))
             except Exception as e:   # noqa: BLE001
