@@ -119,13 +119,21 @@ static int materialize(const svdss_index* cix) {
 }
 
 static int build_table(svdss_index* ix);
+static size_t table_bytes_for(int64_t n);
 
 extern "C" int svdss_index_build_device(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs,
                                         int32_t threads, int32_t device, svdss_index_t** out) {
   if (!out || device < 0) return SVDSS_EINVAL;
   svdss_index* ix = new (std::nothrow) svdss_index();
   if (!ix) return SVDSS_ENOMEM;
-  int rc = getenv("SVDSS_INDEX_CPU") ? -1 : svdss_index_build_gpu(contigs, lens, n_contigs, device, ix);
+  // (the table's memory lent to the suffix sort, as the restore paths do: index_gpu.hip)
+  size_t tb = 0;
+  if (contigs && lens && n_contigs > 0) {
+    int64_t n = 0;
+    for (int32_t i = 0; i < n_contigs; ++i) n += 2 * (lens[i] + 1);
+    tb = table_bytes_for(n);
+  }
+  int rc = getenv("SVDSS_INDEX_CPU") ? -1 : svdss_index_build_gpu(contigs, lens, n_contigs, device, ix, false, tb);
   if (rc == SVDSS_OK) {
     rc = build_table(ix);
   } else if (rc < 0) {   // no GPU / no room / degenerate text: host builder, then upload
@@ -362,16 +370,34 @@ __global__ void __launch_bounds__(256) build_table_kernel(SvdssDevIndex ix, Svds
   }
 }
 
+// bytes of the k-mer table an index of n symbols gets (0: none) -- the restore paths allocate it ahead of the suffix sort
+static size_t table_bytes_for(int64_t n) {
+  if (getenv("SVDSS_INDEX_NO_ARENA")) return 0;   // (developer knob: the sort's buffers and the table allocated one after the other, as until round 5)
+  const int k = auto_kmer(n);
+  return k > 0 ? (size_t)16 << (2 * k) : 0;
+}
+
 // the 4^K k-mer table of an index whose blocks, text and suffix array are resident
 static int build_table(svdss_index* ix) {
-  if (ix->d_table) { (void)hipFree(ix->d_table); ix->d_table = nullptr; ix->table_k = 0; }
   const bool wide = ix->sa_wide;
-  const int k = auto_kmer(ix->n);
+  int k = auto_kmer(ix->n);
+  // Memory allocated ahead for this table (and lent to the suffix sort meanwhile, index_gpu.hip) was sized for the order
+  // chosen THEN, with the device still empty: that order stands (asked again now, with the table's own bytes counted as
+  // used, auto_kmer answers one less -- a 16 GiB table in a 64 GiB allocation and a search kernel 2.5 x slower).
+  if (ix->d_table && ix->table_k == 0 && ix->d_table_cap >= 64) {
+    int kc = 0;
+    while (kc < 16 && ((size_t)16 << (2 * (kc + 1))) <= ix->d_table_cap) ++kc;
+    k = kc;
+  }
+  const bool ahead = ix->d_table && ix->table_k == 0 && k > 0 && ix->d_table_cap >= ((size_t)16 << (2 * k));
+  if (ix->d_table && !ahead) { (void)hipFree(ix->d_table); ix->d_table = nullptr; }
+  ix->table_k = 0;
+  if (!ahead) ix->d_table_cap = 0;
   if (k > 0 && ix->d_text && ix->d_sa) {
     const size_t tbytes = (size_t)16 << (2 * k);
     const bool verbose = getenv("SVDSS_INDEX_VERBOSE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(hipMalloc(&ix->d_table, tbytes));
+    if (!ahead) HIPCHK(hipMalloc(&ix->d_table, tbytes));
     if (verbose) fprintf(stderr, "[index] k-mer table of order %d: %.1f GiB allocated in %.3f s\n", k, (double)tbytes / (1 << 30),
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     SvdssDevIndex v = svdss_device_view(ix);
@@ -414,12 +440,12 @@ extern "C" int svdss_index_to_device(svdss_index_t* ix, int32_t device) {
   if (!ix || device < 0) return SVDSS_EINVAL;
   HIPCHK(hipSetDevice(device));
   if (ix->device == device && ix->d_blocks && ix->d_text && ix->d_sa)   // built there (svdss_index_build_device)
-    return ix->d_table ? SVDSS_OK : build_table(ix);
+    return ix->d_table && ix->table_k > 0 ? SVDSS_OK : build_table(ix);
   if (svdss_index_is_lazy(ix)) {
     // restored from a records file: the index is built where it is going to live (GRCh38 lengths: seconds; the host
     // builder + upload only when the device cannot)
     int rc = getenv("SVDSS_INDEX_CPU") ? -1 : svdss_index_build_gpu(ix->records.data(), ix->rec_lens.data(),
-                                                                    (int32_t)ix->rec_lens.size(), device, ix, true);
+                                                                    (int32_t)ix->rec_lens.size(), device, ix, true, table_bytes_for(ix->n));
     if (rc == SVDSS_OK) return table_and_blocks(ix);
     if (rc > 0) return rc;
     free_device_side(ix);
@@ -487,7 +513,7 @@ extern "C" int svdss_index_replicate(const svdss_index_t* src, int32_t device, s
     // array through the host)
     svdss_index* ix = new (std::nothrow) svdss_index();
     if (!ix) return SVDSS_ENOMEM;
-    int rc = svdss_index_build_gpu(src->records.data(), src->rec_lens.data(), (int32_t)src->rec_lens.size(), device, ix, true);
+    int rc = svdss_index_build_gpu(src->records.data(), src->rec_lens.data(), (int32_t)src->rec_lens.size(), device, ix, true, table_bytes_for(src->n));
     if (rc == SVDSS_OK) rc = table_and_blocks(ix);
     if (rc == SVDSS_OK) { *out = ix; return SVDSS_OK; }
     free_device_side(ix);

@@ -64,6 +64,15 @@ constexpr int SVDSS_GPU_NO = -1;   // "not possible on this device / with this t
 // device allocations released when the builder leaves, unless handed over with take()
 struct Pool {
   std::vector<void*> v;
+  // an arena some of the big scratch buffers are carved from (alloc_big) instead of being allocated and freed: the memory
+  // that becomes the k-mer table afterwards (svdss_index_build_gpu).  Not owned: release() of a pointer inside it does nothing.
+  uint8_t* arena = nullptr;
+  size_t arena_cap = 0, arena_at = 0;
+  int alloc_big(void** out, size_t bytes) {
+    const size_t a = (arena_at + 255) & ~(size_t)255;
+    if (arena && a + bytes <= arena_cap) { *out = arena + a; arena_at = a + bytes; return 0; }
+    return alloc(out, bytes);
+  }
   ~Pool() { for (void* p : v) if (p) (void)hipFree(p); }
   int alloc(void** out, size_t bytes) {
     void* p = nullptr;
@@ -73,6 +82,7 @@ struct Pool {
     return 0;
   }
   void release(void* p) {
+    if (arena && (uint8_t*)p >= arena && (uint8_t*)p < arena + arena_cap) return;   // (carved from the arena -- its first piece has the arena's own address)
     for (void*& q : v) if (q == p && p) { (void)hipFree(p); q = nullptr; }
   }
   void* take(void* p) {
@@ -81,6 +91,7 @@ struct Pool {
   }
 };
 #define PALLOC(pool, ptr, bytes) do { if ((pool).alloc((void**)&(ptr), (bytes))) return SVDSS_GPU_NO; } while (0)
+#define PALLOC_BIG(pool, ptr, bytes) do { if ((pool).alloc_big((void**)&(ptr), (bytes))) return SVDSS_GPU_NO; } while (0)
 
 constexpr int KEY_SYMS = 21;
 constexpr int BUCKET_BITS = 12;              // first 4 symbols
@@ -328,8 +339,10 @@ __global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* in, int64_t
 inline unsigned grid_for(int64_t items) { return (unsigned)((items + 255) / 256); }
 
 // suffix array of text[0, n) (device, followed by >= 64 zero bytes) into sa (device, uint64[n]); rank = scratch uint64[n]
-int suffix_sort(const uint8_t* text, int64_t n, uint64_t* sa, uint64_t* rank, size_t free_bytes, bool verbose) {
+int suffix_sort(const uint8_t* text, int64_t n, uint64_t* sa, uint64_t* rank, size_t free_bytes, bool verbose,
+                uint8_t* arena = nullptr, size_t arena_bytes = 0) {
   Pool P;
+  P.arena = arena; P.arena_cap = arena_bytes;
   // piece size: the sort buffers of a piece cost ~56 B per suffix
   int64_t M = (int64_t)1 << 29;
   while (M > ((int64_t)1 << 20) && (size_t)M * 64 > free_bytes / 2) M >>= 1;
@@ -340,8 +353,8 @@ int suffix_sort(const uint8_t* text, int64_t n, uint64_t* sa, uint64_t* rank, si
   uint32_t *hs, *unres;
   uint8_t* nh;
   ull* d_cnt;
-  PALLOC(P, k0, (size_t)cap * 8); PALLOC(P, k1, (size_t)cap * 8);
-  PALLOC(P, v0, (size_t)cap * 8); PALLOC(P, v1, (size_t)cap * 8);
+  PALLOC_BIG(P, k0, (size_t)cap * 8); PALLOC_BIG(P, k1, (size_t)cap * 8);
+  PALLOC_BIG(P, v0, (size_t)cap * 8); PALLOC_BIG(P, v1, (size_t)cap * 8);
   PALLOC(P, hs, (size_t)cap * 4); PALLOC(P, unres, (size_t)cap * 4 + 8);
   PALLOC(P, nh, (size_t)cap + 8);
   PALLOC(P, d_cnt, (N_BUCKETS + 8) * sizeof(ull));
@@ -507,7 +520,7 @@ int suffix_sort(const uint8_t* text, int64_t n, uint64_t* sa, uint64_t* rank, si
 // 0 = done; -1 = not possible here (no GPU / memory / degenerate text): use the host builder;
 // SVDSS_EINVAL / SVDSS_ERANGE as the host builder reports them.
 int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
-                          svdss_index* ix, bool defer_host_blocks) {
+                          svdss_index* ix, bool defer_host_blocks, size_t table_bytes) {
   if (!contigs || !lens || n_contigs <= 0 || !ix) return SVDSS_EINVAL;
   const bool verbose = getenv("SVDSS_INDEX_VERBOSE") != nullptr;
   int ndev = 0;
@@ -560,10 +573,22 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
   mark("records up, text laid down");
   uint64_t *d_sa64, *d_rank;
   PALLOC(P, d_sa64, N * 8 + 16);
-  PALLOC(P, d_rank, N * 8);
+  // table_bytes > 0 (the restore paths): the memory of the k-mer table is allocated HERE and lent to the sort -- the rank
+  // array (8 N bytes) and the sort's four key / value buffers are carved from it -- instead of ~70 GB being allocated,
+  // released after the sort and 64 GiB allocated again for the table.  The driver clears what it hands out and what it
+  // gets back (30-50 GB/s, and host <-> device copies crawl meanwhile): at GRCh38 lengths that was ~140 GB of clearing
+  // per restore, part of it beside the stream that follows (profiles/r05z_e2e_lib_ab.txt, section 3).
+  uint8_t* d_arena = nullptr;
+  if (table_bytes > 0 && P.alloc((void**)&d_arena, table_bytes) == 0) { P.arena = d_arena; P.arena_cap = table_bytes; }
+  else d_arena = nullptr;
+  PALLOC_BIG(P, d_rank, N * 8);
   GCHK(hipMemGetInfo(&free_b, &total_b));
   mark("suffix array + rank buffers");
-  if (suffix_sort(d_text, n, d_sa64, d_rank, free_b, verbose)) return SVDSS_GPU_NO;
+  {
+    const size_t used = (P.arena_at + 255) & ~(size_t)255;
+    uint8_t* rest = P.arena && used < P.arena_cap ? P.arena + used : nullptr;
+    if (suffix_sort(d_text, n, d_sa64, d_rank, free_b, verbose, rest, rest ? P.arena_cap - used : 0)) return SVDSS_GPU_NO;
+  }
   mark("suffixes sorted");
   P.release(d_rank);
   void* d_sa = d_sa64;
@@ -665,7 +690,8 @@ int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n
   ix->d_sa = P.take(d_sa);
   ix->d_blocks = P.take(d_blocks);
   ix->d_dollar = P.take(d_dollar_final);
-  ix->d_table = nullptr;
+  ix->d_table = d_arena ? P.take(d_arena) : nullptr;   // (not a table yet: table_k = 0; build_table fills it if it is large enough)
+  ix->d_table_cap = d_arena ? table_bytes : 0;
   ix->table_k = 0;
   mark("counters, blocks to the host");
   return 0;

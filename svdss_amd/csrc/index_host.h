@@ -44,6 +44,7 @@ struct svdss_index {
   void* d_text = nullptr;         // allocation start; text begins 64 bytes in
   void* d_sa = nullptr;
   void* d_table = nullptr;
+  size_t d_table_cap = 0;         // bytes behind d_table when it was allocated ahead of the table's build (index_gpu.hip)
   int32_t table_k = 0;
   double deep_frac = 0.0;   // share of the K-mer occurrences that belong to K-mers with 8 or more of them (sampled while the table is built)
 };
@@ -64,7 +65,7 @@ void svdss_index_decode_bwt(const svdss_index* ix, uint8_t* bwt);
 // not copied to the host: svdss_index_fetch_host does that on demand).  0 = done, -1 = not possible here (use the
 // host builder), SVDSS_EINVAL / SVDSS_ERANGE as svdss_index_build_host reports them.
 int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
-                          svdss_index* out, bool defer_host_blocks = false);
+                          svdss_index* out, bool defer_host_blocks = false, size_t table_bytes = 0);
 // defer_host_blocks: the host copy of the rank blocks is left out; svdss_index_fetch_blocks brings it down (the restore
 // paths run it on a thread beside the k-mer table's build)
 int svdss_index_fetch_blocks(svdss_index* ix);
