@@ -827,10 +827,10 @@ def _run_search(exe, fmd, bam, env=None, repeats=1, pause_s=0.0):
     the second run over a freshly generated input file waits most of a second for the file's loaders (the page cache, not
     this code: runs 1, 3, 4, 5 do not, nor does any run a second apart; profiles/r04y_consecutive_runs.txt)."""
     if repeats > 1:
-        # pause_s: seconds between the end of one process and the start of the next.  A process that ends hands ~190 GB of
-        # HBM back (whole-genome index) and the driver clears them at 30-50 GB/s: the next process either waits for clean
-        # memory while it restores its index or, when enough is clean already, streams beside the clearing -- 0.56 s
-        # becomes 0.79 s (profiles/r05z_e2e_lib_ab.txt, section 3).  Back-to-back runs are this bench's doing, not a user's.
+        # pause_s: seconds between the end of one process and the start of the next.  A process that ends hands ~130 GB of
+        # HBM back (whole-genome index) and the driver clears them at 30-50 GB/s: a process started right behind it waits
+        # for clean memory in its first allocations (profiles/r05z_e2e_lib_ab.txt).  Back-to-back runs are this bench's
+        # doing, not a user's.
         runs = []
         for _ in range(repeats):
             if pause_s > 0:

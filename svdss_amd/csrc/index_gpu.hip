@@ -708,8 +708,8 @@ int svdss_index_fetch_blocks(svdss_index* ix) {
   // by the calling thread: one thread 0.4 s, and the vector's zero fill before it 0.3 s -- gone with the allocator of
   // index_host.h).  Two asynchronous versions beside the k-mer table's build took the copy off the critical path
   // altogether; they were dropped when `SVDSS search` seemed to stream slower behind them (profiles/r05z_restore_ab.txt)
-  // -- which turned out to be the driver clearing the HBM of the process before while the stream runs instead of while
-  // the restore waits (profiles/r05z_e2e_lib_ab.txt, section 3); this version is simple and costs 0.2 s.
+  // -- which turned out to be the driver clearing the sort's released buffers beside the stream (profiles/r05z_e2e_lib_ab.txt,
+  // sections 3-4: fixed by lending the table's memory to the sort); this version is simple and costs 0.2 s.
   const size_t total = (size_t)nb * 64;
   const int T = 4;
   std::atomic<int> bad(0);
