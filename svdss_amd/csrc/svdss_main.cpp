@@ -129,16 +129,41 @@ static int main_index(int argc, char** argv) {
   auto mark = [&](const char* what) {
     if (dbg) fprintf(stderr, "[index] %-28s at +%.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
   };
-  FastxReader fx(fasta);
-  if (!fx.ok()) die("cannot open " + fasta);
   std::vector<uint8_t> cat;
   std::vector<int64_t> lens;
-  std::string name, seq;
-  while (fx.next(name, seq)) {
-    const size_t o = cat.size();
-    cat.resize(o + seq.size());
-    check(svdss_nt6_encode(seq.data(), (int64_t)seq.size(), cat.data() + o), "svdss_nt6_encode");
-    lens.push_back((int64_t)seq.size());
+  {
+    // a plain FASTA is mapped and read by several threads (fastx_reader.h, as `call` and `smooth` do), the records encoded
+    // side by side into one buffer sized once; gzip / CRLF / FASTQ-like files go through the line reader as before
+    std::vector<std::string> nm, sq;
+    if (!getenv("SVDSS_FASTA_SERIAL") && load_fasta_mapped(fasta, std::max(1, std::min(threads < 8 ? 8 : threads, 16)), false, nm, sq)) {
+      std::vector<size_t> at(sq.size() + 1, 0);
+      for (size_t i = 0; i < sq.size(); ++i) { at[i + 1] = at[i] + sq[i].size(); lens.push_back((int64_t)sq[i].size()); }
+      cat.resize(at.back());
+      std::vector<std::thread> th;
+      std::atomic<size_t> next(0);
+      std::atomic<int> bad(0);
+      for (int t = 0; t < (int)std::min<size_t>(sq.size(), 8); ++t)
+        th.emplace_back([&] {
+          for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= sq.size()) return;
+            if (svdss_nt6_encode(sq[i].data(), (int64_t)sq[i].size(), cat.data() + at[i]) != SVDSS_OK) bad = 1;
+            std::string().swap(sq[i]);
+          }
+        });
+      for (std::thread& x : th) x.join();
+      if (bad.load()) die("svdss_nt6_encode failed");
+    } else {
+      FastxReader fx(fasta);
+      if (!fx.ok()) die("cannot open " + fasta);
+      std::string name, seq;
+      while (fx.next(name, seq)) {
+        const size_t o = cat.size();
+        cat.resize(o + seq.size());
+        check(svdss_nt6_encode(seq.data(), (int64_t)seq.size(), cat.data() + o), "svdss_nt6_encode");
+        lens.push_back((int64_t)seq.size());
+      }
+    }
   }
   if (lens.empty()) die("no sequence in " + fasta);
   mark("FASTA read + nt6");
