@@ -514,7 +514,7 @@ struct CallRun {
       fasta_loader = std::thread([this] {
         {   // a plain FASTA with '\n' line ends: mapped and read by several threads (fastx_reader.h)
           std::vector<std::string> nm, sq;
-          if (!getenv("SVDSS_FASTA_SERIAL") && load_fasta_mapped(o.reference, std::max(1, std::min(T, 8)), true, nm, sq)) {
+          if (!getenv("SVDSS_FASTA_SERIAL") && load_fasta_mapped(o.reference, std::max(1, std::min(T, 16)), true, nm, sq)) {
             for (size_t i = 0; i < nm.size(); ++i) {
               C.chrom_names.push_back(nm[i]);
               C.chrom_seqs[nm[i]] = std::move(sq[i]);   // (a name that occurs twice: the later record wins, as below)
