@@ -77,15 +77,15 @@ struct BaiIndex {
         bin = (bin - 1) >> 3;
       }
     }
-    auto take = [&](uint32_t bin) {
-      auto it = std::lower_bound(r.bins.begin(), r.bins.end(), bin, [](const auto& a, uint32_t b) { return a.first < b; });
-      if (it == r.bins.end() || it->first != bin) return;
-      for (const auto& c : it->second)
-        if (c.second > min_off) out.emplace_back(std::max(c.first, min_off), c.second);
-    };
+    // per level, the bins PRESENT in [first_bin(l) + lo, first_bin(l) + hi] -- not every possible bin number (a .csi with
+    // a small min_shift makes that ~1e8 lookups for a chromosome-wide query: ADVICE r5)
     for (int l = 0; l <= depth; ++l) {
       const int sh = min_shift + 3 * (depth - l);
-      for (int64_t k = beg >> sh; k <= e >> sh; ++k) take((uint32_t)(first_bin(l) + k));
+      const int64_t lo = first_bin(l) + (beg >> sh), hi = first_bin(l) + (e >> sh);
+      auto it = std::lower_bound(r.bins.begin(), r.bins.end(), lo, [](const auto& a, int64_t b) { return (int64_t)a.first < b; });
+      for (; it != r.bins.end() && (int64_t)it->first <= hi; ++it)
+        for (const auto& c : it->second)
+          if (c.second > min_off) out.emplace_back(std::max(c.first, min_off), c.second);
     }
   }
 

@@ -143,6 +143,9 @@ __global__ void __launch_bounds__(64 * W) align_wave_kernel(
           __builtin_amdgcn_s_sleep(2);
         }
         if (aborted) { nH = 0; nE = 0; nE2 = 0; return; }
+        // acquire side of the producer's workgroup-scope release: the boundary row is read after the progress word
+        // whatever the CU mode (relaxed loads alone are only ordered while both waves share one L1)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         nH = in ? __hip_atomic_load(&bin[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
         nE = in ? __hip_atomic_load(&bin[bstride + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
         nE2 = in ? __hip_atomic_load(&bin[2 * bstride + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;

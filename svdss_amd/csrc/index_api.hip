@@ -131,6 +131,8 @@ extern "C" int svdss_index_build_device(const uint8_t* contigs, const int64_t* l
   if (contigs && lens && n_contigs > 0) {
     int64_t n = 0;
     for (int32_t i = 0; i < n_contigs; ++i) n += 2 * (lens[i] + 1);
+    // (the order is chosen from the free memory of the device the index goes to, not of the calling thread's current one)
+    if (!getenv("SVDSS_INDEX_CPU")) (void)hipSetDevice(device);
     tb = table_bytes_for(n);
   }
   int rc = getenv("SVDSS_INDEX_CPU") ? -1 : svdss_index_build_gpu(contigs, lens, n_contigs, device, ix, false, tb);
@@ -511,9 +513,13 @@ extern "C" int svdss_index_replicate(const svdss_index_t* src, int32_t device, s
   if (!src->rec_lens.empty() && !getenv("SVDSS_INDEX_CPU")) {
     // the source came from a records file: the replica is built in the HBM of its own device (no 4-8 n bytes of suffix
     // array through the host)
+    // a fresh thread's current device is 0, which may already hold an index and its table: the replica's order (and the
+    // arena lent to its sort) must come from the free memory of ITS device
+    HIPCHK(hipSetDevice(device));
     svdss_index* ix = new (std::nothrow) svdss_index();
     if (!ix) return SVDSS_ENOMEM;
-    int rc = svdss_index_build_gpu(src->records.data(), src->rec_lens.data(), (int32_t)src->rec_lens.size(), device, ix, true, table_bytes_for(src->n));
+    const size_t tb = table_bytes_for(src->n);
+    int rc = svdss_index_build_gpu(src->records.data(), src->rec_lens.data(), (int32_t)src->rec_lens.size(), device, ix, true, tb);
     if (rc == SVDSS_OK) rc = table_and_blocks(ix);
     if (rc == SVDSS_OK) { *out = ix; return SVDSS_OK; }
     free_device_side(ix);

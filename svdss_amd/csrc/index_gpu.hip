@@ -519,7 +519,23 @@ int suffix_sort(const uint8_t* text, int64_t n, uint64_t* sa, uint64_t* rank, si
 // suffix array stay on the device until svdss_index_fetch_host() is called (save, another device).
 // 0 = done; -1 = not possible here (no GPU / memory / degenerate text): use the host builder;
 // SVDSS_EINVAL / SVDSS_ERANGE as the host builder reports them.
+static int build_gpu_once(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
+                          svdss_index* ix, bool defer_host_blocks, size_t table_bytes);
+
 int svdss_index_build_gpu(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
+                          svdss_index* ix, bool defer_host_blocks, size_t table_bytes) {
+  int rc = build_gpu_once(contigs, lens, n_contigs, device, ix, defer_host_blocks, table_bytes);
+  // The table's memory, taken ahead of the sort, sits on top of the suffix array, the text and the sort's other buffers:
+  // where the build only just fits it is the arena that made an allocation fail.  Everything of the failed attempt has
+  // been released (Pool); once more without it before the caller drops to the host builder, which takes minutes.
+  if (rc == SVDSS_GPU_NO && table_bytes > 0) {
+    if (getenv("SVDSS_INDEX_VERBOSE")) fprintf(stderr, "[index_gpu] no room with the table's %zu bytes taken ahead: again without\n", table_bytes);
+    rc = build_gpu_once(contigs, lens, n_contigs, device, ix, defer_host_blocks, 0);
+  }
+  return rc;
+}
+
+static int build_gpu_once(const uint8_t* contigs, const int64_t* lens, int32_t n_contigs, int32_t device,
                           svdss_index* ix, bool defer_host_blocks, size_t table_bytes) {
   if (!contigs || !lens || n_contigs <= 0 || !ix) return SVDSS_EINVAL;
   const bool verbose = getenv("SVDSS_INDEX_VERBOSE") != nullptr;

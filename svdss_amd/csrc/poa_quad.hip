@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "poa_quad.h"
+#include "poa_quad_gfx950.h"
 #include "poa_quad_core.h"
 
 // (launch bounds: one wavefront per block; the LDS ring, not the registers, decides how many stay on a CU)

@@ -30,256 +30,21 @@
 // that loses the sink, a graph beyond its allocation) ends that group with status 3 | reason << 8 exactly like
 // poa_wave.hip; the host hands those sub-clusters to poa_wave.hip's rounds.
 //
-// The file is compiled twice: by hipcc for gfx950 (poa_quad.hip), and by g++ with POAQ_EMU for the CPU wave emulator
-// of the tests (tests/native/poa_quad_emu.cpp, tests/native/wave_emu.h), where the cross-lane primitives below are
-// meetings of 64 fibres.  Everything else is the same source.
+// The file is compiled twice: by hipcc for gfx950 (poa_quad.hip, behind poa_quad_gfx950.h), and by g++ for the CPU wave
+// emulator of the tests (behind their own back end), where the cross-lane primitives are meetings of 64 fibres.
+// Everything else is the same source.
 #pragma once
 #include <cstdint>
 
 #include "poa_task.h"
 
-#define PQ_NEG (-0x20000000)
-#define PQ_TGB 0x20000000
-#define PQ_O1 4
-#define PQ_E1 2
-#define PQ_O2 24
-#define PQ_E2 1
-#define PQ_MATCH 2
-#define PQ_MISMATCH 4
-#define PQ_COL_SINK 0x7FFFFFFE
-#define PQ_COL_NEW 0x7FFFFFFF
-#define PQ_RING 4     // LDS ring rows per group; a predecessor 1..3 rows back is read from the ring
-#define PQ_GD 4       // "no path" guard cells on each side of a ring row
-#define PQ_INT_MIN (-0x7fffffff - 1)
+#include "poa_quad_defs.h"
 
-#ifdef POAQ_EMU
-// ------------------------------------------------------------------------------------------ emulator back end
-#include "../../tests/native/wave_emu.h"
-#define PQ_DEV static inline
-namespace pq {
-inline int lane_id() { return wemu::lane_id(); }
-#define PQ_SITE __LINE__
-template <int GW>
-struct Grp {
-  static int g() { return wemu::lane_id() / GW; }
-  static int l() { return wemu::lane_id() % GW; }
-  static int shr1(int x, int fill, int site) {
-    const uint64_t* d = wemu::meet((uint32_t)x, site);
-    return l() == 0 ? fill : (int)(uint32_t)d[wemu::lane_id() - 1];
-  }
-  static int shl1(int x, int fill, int site) {
-    const uint64_t* d = wemu::meet((uint32_t)x, site);
-    return l() == GW - 1 ? fill : (int)(uint32_t)d[wemu::lane_id() + 1];
-  }
-  static int shr1z(int x, int site) { return shr1(x, 0, site); }
-  static int shl1z(int x, int site) { return shl1(x, 0, site); }
-  static int scan_max(int x, int site) {
-    const uint64_t* d = wemu::meet((uint32_t)x, site);
-    int m = PQ_INT_MIN;
-    for (int i = g() * GW; i <= wemu::lane_id(); ++i) { const int v = (int)(uint32_t)d[i]; if (v > m) m = v; }
-    return m;
-  }
-  static int scan_add(int x, int site) {
-    const uint64_t* d = wemu::meet((uint32_t)x, site);
-    int s = 0;
-    for (int i = g() * GW; i <= wemu::lane_id(); ++i) s += (int)(uint32_t)d[i];
-    return s;
-  }
-  static int all_max(int x, int site) {
-    const uint64_t* d = wemu::meet((uint32_t)x, site);
-    int m = PQ_INT_MIN;
-    for (int i = g() * GW; i < g() * GW + GW; ++i) { const int v = (int)(uint32_t)d[i]; if (v > m) m = v; }
-    return m;
-  }
-  static int all_min(int x, int site) {
-    const uint64_t* d = wemu::meet((uint32_t)x, site);
-    int m = 0x7fffffff;
-    for (int i = g() * GW; i < g() * GW + GW; ++i) { const int v = (int)(uint32_t)d[i]; if (v < m) m = v; }
-    return m;
-  }
-  static int last(int x, int site) {
-    const uint64_t* d = wemu::meet((uint32_t)x, site);
-    return (int)(uint32_t)d[g() * GW + GW - 1];
-  }
-  static int from(int x, int src_l, int site) {
-    const uint64_t* d = wemu::meet((uint32_t)x, site);
-    return (int)(uint32_t)d[g() * GW + (src_l & (GW - 1))];
-  }
-  static uint64_t bits(bool p, int site) {
-    const uint64_t* d = wemu::meet(p ? 1 : 0, site);
-    uint64_t m = 0;
-    for (int i = 0; i < GW; ++i) if (d[g() * GW + i]) m |= 1ull << i;
-    return m;
-  }
-  // first / last lane of the group with p (1 << 20 / -1 if none)
-  static void first_last(bool p, int& first, int& last, int site) {
-    const uint64_t m = bits(p, site);
-    first = m ? __builtin_ctzll(m) : (1 << 20);
-    last = m ? 63 - __builtin_clzll(m) : -1;
-  }
-};
-inline bool wave_any(bool p, int site) {
-  const uint64_t* d = wemu::meet(p ? 1 : 0, site);
-  for (int i = 0; i < 64; ++i) if (d[i]) return true;
-  return false;
-}
-// maximum over the wavefront of a value that is uniform within every group -> a wave-uniform value
-template <int GW>
-inline int wave_gmax(int x, int site) {
-  const uint64_t* d = wemu::meet((uint32_t)x, site);
-  int m = PQ_INT_MIN;
-  for (int i = 0; i < 64; ++i) { const int v = (int)(uint32_t)d[i]; if (v > m) m = v; }
-  return m;
-}
-inline void force_ready(uint32_t&) {}
-inline void force_ready_i(int32_t&) {}
-inline void vm_drain() {}
-inline unsigned long long prof_clock() { return 0; }
-inline void prof_out(const unsigned long long*) {}
-inline void lds_sync(int site) { (void)wemu::meet(0, site); }
-inline void mem_sync(int site) { (void)wemu::meet(0, site); }
-inline int atomic_add(int32_t* p, int v) { const int o = *p; *p = o + v; return o; }
-inline void atomic_max(int32_t* p, int v) { if (v > *p) *p = v; }
-inline void atomic_add64(unsigned long long* p, unsigned long long v) { *p += v; }
-inline int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
-inline uint64_t load_u64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
-// the low bytes of four values side by side
-inline uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return (a & 255u) | ((b & 255u) << 8) | ((c & 255u) << 16) | ((d & 255u) << 24); }
-// signed 3-bit field of x at bit `at`
-inline int sbfe3(uint32_t x, uint32_t at) { return (int)((int32_t)(x << (29u - (at & 31u))) >> 29); }
-}  // namespace pq
-#else
-// ------------------------------------------------------------------------------------------ gfx950 back end
-#include <hip/hip_runtime.h>
-#define PQ_DEV __device__ __forceinline__
-#define PQ_SITE 0
-namespace pq {
-PQ_DEV int lane_id() { return (int)threadIdx.x; }
-template <int CTRL, int RMASK>
-PQ_DEV int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, RMASK, 0xf, false); }
-PQ_DEV int imax_(int a, int b) { return a > b ? a : b; }
-PQ_DEV int imin_(int a, int b) { return a < b ? a : b; }
-// DPP controls (gfx9): row_shl:n 0x100+n, row_shr:n 0x110+n, row_ror:n 0x120+n, wave_shl:1 0x130, wave_shr:1 0x138,
-// row_bcast:15 0x142, row_bcast:31 0x143.  A lane whose source lies outside its 16-lane row keeps `old`.
-template <int GW>
-struct Grp {
-  static_assert(GW == 16 || GW == 32 || GW == 64, "group width");
-  PQ_DEV static int g() { return (int)threadIdx.x / GW; }
-  PQ_DEV static int l() { return (int)threadIdx.x % GW; }
-  PQ_DEV static int shr1(int x, int fill, int) {
-    if (GW == 16) return dpp<0x111, 0xf>(fill, x);
-    const int r = dpp<0x138, 0xf>(fill, x);
-    return GW == 64 ? r : (l() == 0 ? fill : r);
-  }
-  PQ_DEV static int shl1(int x, int fill, int) {
-    if (GW == 16) return dpp<0x101, 0xf>(fill, x);
-    const int r = dpp<0x130, 0xf>(fill, x);
-    return GW == 64 ? r : (l() == GW - 1 ? fill : r);
-  }
-  // the same with 0 for the lane that has no neighbour: one instruction (bound_ctrl), no register to preload with the fill
-  PQ_DEV static int shr1z(int x, int) {
-    if (GW == 16) return __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
-    const int r = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);
-    return GW == 64 ? r : (l() == 0 ? 0 : r);
-  }
-  PQ_DEV static int shl1z(int x, int) {
-    if (GW == 16) return __builtin_amdgcn_update_dpp(0, x, 0x101, 0xf, 0xf, true);
-    const int r = __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true);
-    return GW == 64 ? r : (l() == GW - 1 ? 0 : r);
-  }
-  PQ_DEV static int scan_max(int x, int) {
-    x = imax_(x, dpp<0x111, 0xf>(PQ_INT_MIN, x));
-    x = imax_(x, dpp<0x112, 0xf>(PQ_INT_MIN, x));
-    x = imax_(x, dpp<0x114, 0xf>(PQ_INT_MIN, x));
-    x = imax_(x, dpp<0x118, 0xf>(PQ_INT_MIN, x));
-    if (GW >= 32) x = imax_(x, dpp<0x142, 0xa>(PQ_INT_MIN, x));
-    if (GW >= 64) x = imax_(x, dpp<0x143, 0xc>(PQ_INT_MIN, x));
-    return x;
-  }
-  PQ_DEV static int scan_add(int x, int) {
-    x += dpp<0x111, 0xf>(0, x);
-    x += dpp<0x112, 0xf>(0, x);
-    x += dpp<0x114, 0xf>(0, x);
-    x += dpp<0x118, 0xf>(0, x);
-    if (GW >= 32) x += dpp<0x142, 0xa>(0, x);
-    if (GW >= 64) x += dpp<0x143, 0xc>(0, x);
-    return x;
-  }
-  PQ_DEV static int last(int x, int) {
-    if (GW == 64) return __builtin_amdgcn_readlane(x, 63);
-    if (GW == 32) { const int a = __builtin_amdgcn_readlane(x, 31), b = __builtin_amdgcn_readlane(x, 63); return g() ? b : a; }
-    return __builtin_amdgcn_ds_bpermute((int)(threadIdx.x | 15u) << 2, x);
-  }
-  PQ_DEV static int all_max(int x, int s) {
-    if (GW == 16) {   // rotations inside the DPP row: every lane ends with the maximum of the 16
-      x = imax_(x, dpp<0x128, 0xf>(x, x));
-      x = imax_(x, dpp<0x124, 0xf>(x, x));
-      x = imax_(x, dpp<0x122, 0xf>(x, x));
-      x = imax_(x, dpp<0x121, 0xf>(x, x));
-      return x;
-    }
-    return last(scan_max(x, s), s);
-  }
-  PQ_DEV static int all_min(int x, int s) {
-    if (GW == 16) {
-      x = imin_(x, dpp<0x128, 0xf>(x, x));
-      x = imin_(x, dpp<0x124, 0xf>(x, x));
-      x = imin_(x, dpp<0x122, 0xf>(x, x));
-      x = imin_(x, dpp<0x121, 0xf>(x, x));
-      return x;
-    }
-    return -all_max(-x, s);   // (callers pass values far from INT_MIN)
-  }
-  PQ_DEV static int from(int x, int src_l, int) {
-    // (one group = the wavefront: what is uniform in the group is uniform, and a scalar lane select does it)
-    if (GW == 64) return __builtin_amdgcn_readlane(x, __builtin_amdgcn_readfirstlane(src_l) & 63);
-    return __builtin_amdgcn_ds_bpermute((g() * GW + (src_l & (GW - 1))) << 2, x);
-  }
-  PQ_DEV static uint64_t bits(bool p, int) {
-    const uint64_t m = __ballot(p);
-    if (GW == 64) return m;
-    return (m >> (g() * GW)) & ((1ull << GW) - 1ull);
-  }
-  // first / last lane of the group with p (1 << 20 / -1 if none)
-  PQ_DEV static void first_last(bool p, int& first, int& last, int s) {
-    const uint64_t m = bits(p, s);
-    first = m ? (int)__builtin_ctzll(m) : (1 << 20);
-    last = m ? 63 - (int)__builtin_clzll(m) : -1;
-  }
-};
-PQ_DEV bool wave_any(bool p, int) { return __ballot(p) != 0ull; }
-template <int GW>
-PQ_DEV int wave_gmax(int x, int) {
-  int m = __builtin_amdgcn_readlane(x, 0);
-#pragma unroll
-  for (int i = GW; i < 64; i += GW) m = imax_(m, __builtin_amdgcn_readlane(x, i));
-  return m;
-}
-// the value of a load is needed HERE (the compiler would otherwise wait for it at its first use, inside the row loop)
-PQ_DEV void force_ready(uint32_t& x) { asm volatile("" : "+v"(x)); }
-PQ_DEV void force_ready_i(int32_t& x) { asm volatile("" : "+v"(x)); }
-// s_waitcnt vmcnt(0) (expcnt / lgkmcnt left alone) as an instruction the compiler's wait-count pass sees: behind it no
-// vector-memory result is pending, so code after the join of a rare branch that loads is not made to wait
-PQ_DEV void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
-PQ_DEV unsigned long long prof_clock() { return wall_clock64(); }
-__device__ unsigned long long g_poaq_prof[8];   // SVDSS_DEBUG: 100 MHz ticks in prepare, forward, traceback, update; steps, general steps
-PQ_DEV void prof_out(const unsigned long long* p) { if (threadIdx.x == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_poaq_prof[k], p[k]); }
-// LDS accesses of one wavefront are served in program order: nothing to wait for, the compiler must only keep the order
-PQ_DEV void lds_sync(int) { __builtin_amdgcn_wave_barrier(); }
-// global memory written by other lanes of this wavefront: the stores have to have left the wavefront's queue
-PQ_DEV void mem_sync(int) { __syncthreads(); }
-PQ_DEV int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
-PQ_DEV void atomic_max(int32_t* p, int v) { atomicMax(p, v); }
-PQ_DEV void atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
-PQ_DEV int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
-PQ_DEV uint64_t load_u64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
-// the low bytes of four values side by side: two byte permutes and an or
-PQ_DEV uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-  return __builtin_amdgcn_perm(b, a, 0x0c0c0400u) | __builtin_amdgcn_perm(d, c, 0x04000c0cu);
-}
-// signed 3-bit field of x at bit `at` (v_bfe_i32)
-PQ_DEV int sbfe3(uint32_t x, uint32_t at) { return __builtin_amdgcn_sbfe(x, at, 3u); }
-}  // namespace pq
+// The cross-lane back end (pq::Grp<GW>, pq::lane_id, PQ_DEV, PQ_SITE, the LDS / memory helpers) comes from the file that
+// includes this one: poa_quad_gfx950.h for the GPU, the tests' own emulator back end for the CPU -- the product does not
+// know where the tests live.
+#ifndef PQ_BACKEND
+#error "include a back end (poa_quad_gfx950.h) before poa_quad_core.h"
 #endif
 
 namespace pq {

@@ -4,6 +4,7 @@
 // other records are dropped; output order == input order; BAM on stdout.  A CIGAR walk with
 // copies from the reference -- the reference has no alignment DP here.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,7 @@
 #include <chrono>
 #include <string>
 
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
@@ -377,13 +379,17 @@ int main_smooth(const CallOptions& o) {
     { std::lock_guard<std::mutex> lk(gate.m); gate.open = true; }
     gate.cv.notify_all();
     uint64_t n_rec = 0, n_kept = 0, n_xf[4] = {0, 0, 0, 0}, out_bytes = 0;
-    bool write_ok = true;
+    std::atomic<bool> write_ok{true};   // (set by several writer threads)
     {
       // side-by-side writers for a regular file
       fflush(stdout);
       const off_t pos0 = lseek(STDOUT_FILENO, 0, SEEK_CUR);
       struct stat sb;
-      const bool seekable = pos0 >= 0 && fstat(STDOUT_FILENO, &sb) == 0 && S_ISREG(sb.st_mode) && !getenv("SVDSS_SMOOTH_SERIAL_WRITE");
+      // (pwrite ignores its offset on an O_APPEND descriptor -- `SVDSS smooth ... >> out.bam` -- and the batches would land in
+      // completion order: such a stdout takes the ordered path)
+      const int fl = fcntl(STDOUT_FILENO, F_GETFL);
+      const bool seekable = pos0 >= 0 && fstat(STDOUT_FILENO, &sb) == 0 && S_ISREG(sb.st_mode) && fl >= 0 && !(fl & O_APPEND) &&
+                            !getenv("SVDSS_SMOOTH_SERIAL_WRITE");
       struct WJob { std::unique_ptr<SelectedBatch> b; off_t at; };
       std::mutex wm; std::condition_variable wcv;
       std::deque<WJob> wq;

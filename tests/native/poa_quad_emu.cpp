@@ -4,13 +4,13 @@
 // CPU wave emulator (wave_emu.h), so that its row loop, traceback and graph update can be held against the oracle in
 // this GPU-less container.  Task sizing mirrors poa.hip's first round; the heaviest-bundle step (poa_bundle_kernel on
 // the GPU) is a plain loop over the graph the emulated kernel leaves in its workspace.
-#define POAQ_EMU 1
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <vector>
 
+#include "poa_quad_backend_emu.h"
 #include "../../svdss_amd/csrc/poa_quad_core.h"
 
 namespace {

@@ -9,7 +9,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(ROOT, "tests", "native", "_poa_quad_emu.so")
 _SRC = [os.path.join(ROOT, "tests", "native", "poa_quad_emu.cpp"), os.path.join(ROOT, "tests", "native", "wave_emu.h"),
-        os.path.join(ROOT, "svdss_amd", "csrc", "poa_quad_core.h"), os.path.join(ROOT, "svdss_amd", "csrc", "poa_task.h")]
+        os.path.join(ROOT, "tests", "native", "poa_quad_backend_emu.h"),
+        os.path.join(ROOT, "svdss_amd", "csrc", "poa_quad_core.h"), os.path.join(ROOT, "svdss_amd", "csrc", "poa_quad_defs.h"),
+        os.path.join(ROOT, "svdss_amd", "csrc", "poa_task.h")]
 
 
 def _build():
