@@ -255,6 +255,38 @@ def write_dataset(work, n_reads, n_svs, scale=1.0, err=0.0):
     return fa, bam, svs, sum(r["n"] for r in res), lens
 
 
+GEN_SRC = os.path.join(ROOT, "tools", "chain_dataset.cpp")
+GEN_EXE = os.path.join(ROOT, "tools", "chain_dataset")
+
+
+def build_generator():
+    """tools/chain_dataset (C++; the Python generator above writes ~50 k reads/s with substitutions only)"""
+    if not os.path.exists(GEN_EXE) or os.path.getmtime(GEN_EXE) < os.path.getmtime(GEN_SRC):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", GEN_EXE, GEN_SRC, "-lz", "-ldl"], check=True)
+    return GEN_EXE
+
+
+def write_dataset_cxx(work, n_reads, n_svs, scale=1.0, err=0.005, threads=None, codec=None, keep_ref=False):
+    """The same data set by tools/chain_dataset.cpp, with errors sub:ins:del = 2:1.5:1.5 and the indels in the
+    truth CIGARs.  Returns (fa, bam, svs, n, lens, info)."""
+    os.makedirs(work, exist_ok=True)
+    exe = build_generator()
+    threads = threads or min(32, os.cpu_count() or 1)
+    if codec is None:   # what htslib writes when it is built with libdeflate (level 6); zlib level 1 where that library is absent
+        import ctypes.util
+        codec = "libdeflate6" if ctypes.util.find_library("deflate") else "zlib1"
+    r = subprocess.run([exe, work, str(n_reads), str(n_svs), repr(scale), repr(err), str(threads), codec, "1" if keep_ref else "0"],
+                       check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    svs = []
+    with open(os.path.join(work, "truth.tsv")) as f:
+        for line in f:
+            t, p, k, ln, het = line.split()
+            svs.append((int(t), int(p), k, int(ln), het == "1"))
+    lens = [max(200000, int(x * scale)) for x in GRCH38_PRIMARY]
+    return os.path.join(work, "ref.fa"), os.path.join(work, "reads.bam"), svs, info["reads"], lens, info
+
+
 def run(work, n_reads, n_svs, scale=1.0, threads=16):
     exe = os.path.join(ROOT, "svdss_amd", "SVDSS")
     out = {}
@@ -314,30 +346,41 @@ def _vcf_hits(vcf_text, svs):
     return len(called), hit
 
 
-def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005):
-    """index -> smooth -> search (putative) -> call, as run_svdss:136-178 chains them, on reads WITH errors."""
+def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005, generator="cxx", keep_ref=False, keep=False, stage_env=None):
+    """index -> smooth -> search (putative) -> call, as run_svdss:136-178 chains them, on reads WITH errors.
+    generator "cxx": tools/chain_dataset.cpp, errors sub:ins:del = 2:1.5:1.5 with the indels in the CIGARs (round 6);
+    "py": the Python generator above (substitutions only; rounds 4-5).  keep_ref: ref.fa / ref.fmd already in `work`
+    (the same seeds give the same reference whatever the number of reads) are used as they are."""
     exe = os.path.join(ROOT, "svdss_amd", "SVDSS")
     out = {}
     t0 = time.perf_counter()
-    fa, bam, svs, n, lens = write_dataset(work, n_reads, n_svs, scale, err=err)
+    if generator == "cxx":
+        fa, bam, svs, n, lens, info = write_dataset_cxx(work, n_reads, n_svs, scale, err=err, keep_ref=keep_ref)
+        out["generator"] = "tools/chain_dataset.cpp: errors sub:ins:del = 2:1.5:1.5, %.1f CIGAR operations per read, BGZF by %s" % (info["cigar_ops_per_read"], info["codec"])
+    else:
+        fa, bam, svs, n, lens = write_dataset(work, n_reads, n_svs, scale, err=err)
+        out["generator"] = "tools/e2e_call_wg.py: substitution errors only, BGZF by zlib level 1"
     out["generate_s"] = round(time.perf_counter() - t0, 1)
-    out.update({"reads": n, "svs": len(svs), "read_error_rate": err, "reference_bp": sum(lens), "bam_bytes": os.path.getsize(bam)})
+    out.update({"reads": n, "svs": len(svs), "read_error_rate": err, "reference_bp": sum(lens), "coverage": round(n * L / sum(lens), 2),
+                "bam_bytes": os.path.getsize(bam)})
     fmd = os.path.join(work, "ref.fmd")
-    t0 = time.perf_counter()
-    subprocess.run([exe, "index", "-d", fa, "-o", fmd], check=True, capture_output=True)
-    out["index_s"] = round(time.perf_counter() - t0, 2)
+    env = dict(os.environ, **(stage_env or {}))
+    if not (keep_ref and os.path.exists(fmd)):
+        t0 = time.perf_counter()
+        subprocess.run([exe, "index", "-d", fa, "-o", fmd], check=True, capture_output=True, env=env)
+        out["index_s"] = round(time.perf_counter() - t0, 2)
     sm = os.path.join(work, "smoothed.bam")
     t0 = time.perf_counter()
     with open(sm, "wb") as f:
         r = subprocess.run([exe, "smooth", "--reference", fa, "--bam", bam, "--threads", str(threads)], check=True, stdout=f, stderr=subprocess.PIPE,
-                           text=True, env=dict(os.environ, SVDSS_DEBUG="1"))
+                           text=True, env=dict(env, SVDSS_DEBUG="1"))
     out["smooth_s"] = round(time.perf_counter() - t0, 3)
     out["smooth_log"] = [ln for ln in r.stderr.splitlines() if "device path" in ln or "accuracy" in ln][-3:]
     out["smoothed_bam_bytes"] = os.path.getsize(sm)
     sfs = os.path.join(work, "specifics.txt")
     t0 = time.perf_counter()
     with open(sfs, "wb") as f:
-        r = subprocess.run([exe, "search", "--index", fmd, "--bam", sm, "--verbose"], check=True, stdout=f, stderr=subprocess.PIPE, text=True)
+        r = subprocess.run([exe, "search", "--index", fmd, "--bam", sm, "--verbose"], check=True, stdout=f, stderr=subprocess.PIPE, text=True, env=env)
     out["search_s"] = round(time.perf_counter() - t0, 3)
     m = re.search(r"on the device at \+([0-9.]+) s", r.stderr)
     out["search_index_resident_s"] = float(m.group(1)) if m else None
@@ -346,15 +389,19 @@ def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005):
     t0 = time.perf_counter()
     # (run_svdss:167-176 hands `call` the ORIGINAL BAM -- the one with an index beside it -- and the SFS of the smoothed reads)
     c = subprocess.run([exe, "call", "--reference", fa, "--bam", bam, "--sfs", sfs, "--threads", str(threads), "--min-sv-length", "50", "--verbose"],
-                       check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                       check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     out["call_s"] = round(time.perf_counter() - t0, 3)
-    out["call_bam"] = "the original BAM (its .bai beside it), as run_svdss does; until the second session of round 5: the smoothed BAM (no index)"
-    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "[time]" in ln or "pass 2 through" in ln][-20:]
+    out["call_bam"] = "the original BAM (its .bai beside it), as run_svdss does"
+    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "[time]" in ln or "pass 2 through" in ln or "pass 1" in ln][-24:]
     n_called, hit = _vcf_hits(c.stdout.decode(), svs)
     chain = out["smooth_s"] + out["search_s"] + out["call_s"]
     out.update({"svs_called": n_called, "truth_recovered": hit, "smooth_reads_per_s": n / out["smooth_s"],
+                "search_plus_call_s": round(out["search_s"] + out["call_s"], 3),
                 "search_plus_call_reads_per_s": n / (out["search_s"] + out["call_s"]), "chain_reads_per_s": n / chain,
                 "chain_s": round(chain, 3)})
+    if keep:
+        with open(os.path.join(work, "calls.vcf"), "wb") as f:
+            f.write(c.stdout)
     return out
 
 
@@ -362,7 +409,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "chain":
         a = sys.argv[2:]
         print(json.dumps(run_chain(a[2] if len(a) > 2 else "/tmp/svdss_e2e_chain_wg", int(a[0]) if a else 1030000, int(a[1]) if len(a) > 1 else 3400,
-                                   float(a[3]) if len(a) > 3 else 1.0), indent=1))
+                                   float(a[3]) if len(a) > 3 else 1.0, generator=os.environ.get("CHAIN_GENERATOR", "cxx"), keep=True,
+                                   keep_ref=bool(os.environ.get("CHAIN_KEEP_REF"))), indent=1))
         sys.exit(0)
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1030000
     n_svs = int(sys.argv[2]) if len(sys.argv) > 2 else 3400

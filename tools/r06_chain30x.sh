@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 6: the chain (index -> smooth -> search -> call, run_svdss:136-178) at the metric's own scale: GRCh38 lengths,
+# 6,176,540 x 15 kb reads (30x) with 0.5 % errors sub:ins:del = 2:1.5:1.5, 20,000 SVs -- and, first, the 1.03 M-read (4.9x) chain
+# of rounds 4-5 on the same generator.  Output: gpurun_out/$TAG/.
+set -u
+TAG=${TAG:-r06a}
+OUT=gpurun_out/$TAG
+W=${W:-/tmp/svdss_chain30x}
+cd "$(dirname "$0")/.."
+mkdir -p "$OUT" "$W"
+{ nproc; free -g; df -h /tmp; cat /sys/fs/cgroup/cpu.max 2>/dev/null; } > "$OUT/box.txt" 2>&1
+if [ -z "${SKIP_SMALL:-}" ]; then
+  python tools/e2e_call_wg.py chain ${READS_SMALL:-1030000} ${SVS_SMALL:-3400} "$W" 1.0 > "$OUT/chain_4.9x.json" 2> "$OUT/chain_4.9x.err"
+  rm -f $W/reads.bam $W/reads.bam.bai $W/smoothed.bam
+fi
+CHAIN_KEEP_REF=1 python tools/e2e_call_wg.py chain ${READS:-6176540} ${SVS:-20000} "$W" 1.0 > "$OUT/chain_30x.json" 2> "$OUT/chain_30x.err"
+ls -l "$W" > "$OUT/files.txt"; df -h /tmp >> "$OUT/box.txt"; free -g >> "$OUT/box.txt"
+if [ -n "${DIAG:-}" ]; then
+  EXE=$PWD/svdss_amd/SVDSS
+  FA=$W/ref.fa; BAM=$W/reads.bam; SM=$W/smoothed.bam; FMD=$W/ref.fmd; SFS=$W/specifics.txt
+  SVDSS_DEBUG=1 $EXE smooth --reference $FA --bam $BAM --threads 16 2> "$OUT/smooth_null.log" > /dev/null
+  SVDSS_INDEX_VERBOSE=1 SVDSS_DEBUG=1 $EXE search --index $FMD --bam $SM --verbose > /dev/null 2> "$OUT/search.log"
+  SVDSS_DEBUG=1 $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls2.vcf 2> "$OUT/call.log"
+  cmp $W/calls2.vcf $W/calls.vcf && echo "VCF of the second call identical" >> "$OUT/files.txt"
+  SVDSS_CALL_PASS2=device $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls3.vcf 2> "$OUT/call_pass2_device.log"
+  cmp $W/calls3.vcf $W/calls.vcf && echo "VCF with pass 2 on the device identical (the generator's BAI agrees with the file)" >> "$OUT/files.txt"
+fi
+rm -rf "$W"
