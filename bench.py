@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--e2e-reads", type=int, default=1032000, help="reads in the BAM of the end-to-end run")
     ap.add_argument("--no-e2e-wg", action="store_true", help="skip the end-to-end run against the whole-genome index")
     ap.add_argument("--no-e2e-call", action="store_true", help="skip the end-to-end run of `SVDSS call`")
+    ap.add_argument("--no-e2e-30x", action="store_true", help="skip the chain of the binaries at the metric's own scale (e2e_chain_30x)")
+    ap.add_argument("--chain-reads", type=int, default=READS_30X_WG, help="reads of e2e_chain_30x (default: the 30x set, 6,176,540)")
     ap.add_argument("--no-call-dp", action="store_true", help="search only (value is then NOT the headline metric)")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: leave the SFS on the ranks")
     ap.add_argument("--search-threads", type=int, default=1,
@@ -631,6 +633,7 @@ def main():
                                else "none: search and call of a step back to back"),
             },
         }
+        oracle_fm = None
         out["index_verified_rows"] = iv["rows"]
         out["roofline"] = search_roofline(ref_total, n_reads, L, ix.kmer_k, k_ms, n_ext, total_syms, n_sfs_raw,
                                           float(np.mean(pipeline_ms)), float(np.mean(alone_ms)),
@@ -670,7 +673,7 @@ def main():
                                            call_alone["realign_kernel_ms"]),
             }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["verified_reads"], out["verified_subclusters"] = cpu_baseline_and_verify(
+            out["cpu_baseline"], out["verified_reads"], out["verified_subclusters"], oracle_fm = cpu_baseline_and_verify(
                 ix, pp, d_reads, L, n_reads, args.cpu_seconds, cw)
         if e2e_error:
             out["e2e_error"] = e2e_error
@@ -690,7 +693,16 @@ def main():
             torch.cuda.empty_cache()
             time.sleep(6.0)   # (the driver clears the ~190 GB this process just handed back; see _run_search)
             try:
-                out.update(e2e_runs(e2e_dir, args.e2e_reads, call=not args.no_e2e_call))
+                out.update(e2e_runs(e2e_dir, args.e2e_reads, call=not args.no_e2e_call,
+                                    chain_reads=0 if args.no_e2e_30x else args.chain_reads, oracle_fm=oracle_fm,
+                                    cpu_call=(out.get("cpu_baseline") or {}).get("call")))
+                if "e2e_chain_30x" in out:
+                    c30 = out["e2e_chain_30x"]
+                    out["binaries"] = {
+                        "what": "files in, files out: SVDSS smooth -> search -> call on the metric's own configuration (e2e_chain_30x); "
+                                "`value` above is the kernels on reads resident in HBM",
+                        "search_plus_call_reads_per_s": c30["search_plus_call_reads_per_s"], "chain_reads_per_s": c30["chain_reads_per_s"],
+                        "reads": c30["reads"], "coverage": c30["coverage"]}
             except Exception as e:   # noqa: BLE001
                 out["e2e_error"] = f"{type(e).__name__}: {str(e)[-400:]}"
             finally:
@@ -839,6 +851,7 @@ def _run_search(exe, fmd, bam, env=None, repeats=1, pause_s=0.0):
         runs_sorted = sorted(runs, key=lambda r: r["streaming_s"])
         out = dict(runs_sorted[len(runs) // 2])
         out["streaming_s_runs"] = [r["streaming_s"] for r in runs]
+        out["streaming_s_min_median_max"] = [runs_sorted[0]["streaming_s"], out["streaming_s"], runs_sorted[-1]["streaming_s"]]
         return out
     import re
     import subprocess
@@ -867,7 +880,7 @@ def _run_search(exe, fmd, bam, env=None, repeats=1, pause_s=0.0):
     return out
 
 
-def e2e_runs(work, n_reads, call=True):
+def e2e_runs(work, n_reads, call=True, chain_reads=0, oracle_fm=None, cpu_call=None):
     """The binaries as a user of run_svdss sees them (file- and PCIe-inclusive, never `value`), on the GPU the main
     measurement has just let go of.
       e2e       `SVDSS search --bam`: a synthetic BAM of 15 kb reads against a chr20-length index -- BGZF inflate (GPU),
@@ -894,10 +907,10 @@ def e2e_runs(work, n_reads, call=True):
     t0 = time.perf_counter()
     subprocess.run([exe, "index", "-d", os.path.join(work, "chr.fa"), "-o", os.path.join(work, "chr.fmd")], check=True, capture_output=True)
     t_index = time.perf_counter() - t0
-    r = _run_search(exe, os.path.join(work, "chr.fmd"), bam, repeats=3)
+    r = _run_search(exe, os.path.join(work, "chr.fmd"), bam, repeats=3, pause_s=5.0)
     out["e2e_reads_per_s"] = r["reads_per_s_streaming"]
     r["what"] = ("SVDSS search --bam (binary): synthetic BAM, %d x 15 kb reads, %.1f GB file (%.1f GB inflated), "
-                 "chr20-length index, text to /dev/null; the run with the median streaming time of three" % (r["reads"], os.path.getsize(bam) / 1e9, raw / 1e9))
+                 "chr20-length index, text to /dev/null; the run with the median streaming time of three, 5 s apart (min / median / max beside it)" % (r["reads"], os.path.getsize(bam) / 1e9, raw / 1e9))
     r["index_s"] = round(t_index, 2)
     r["host_cpu_quota_cores"] = cpu_quota()
     out["e2e"] = r
@@ -917,7 +930,7 @@ def e2e_runs(work, n_reads, call=True):
             subprocess.run([exe, "smooth", "--reference", os.path.join(work, "chr.fa"), "--bam", bam, "--threads", "16"], check=True,
                            stdout=f, stderr=subprocess.DEVNULL)
         t_smooth = time.perf_counter() - t0
-        r2 = _run_search(exe, os.path.join(work, "chr.fmd"), sm, repeats=3)
+        r2 = _run_search(exe, os.path.join(work, "chr.fmd"), sm, repeats=3, pause_s=5.0)
         r2["what"] = ("SVDSS smooth -> SVDSS search (binaries), as run_svdss:151-165 chains them: search reads the BAM smooth wrote "
                       "(%.1f GB, deflated on the GPU); smooth: %.2f s whole process = %.0f reads/s"
                       % (os.path.getsize(sm) / 1e9, t_smooth, r["reads"] / t_smooth))
@@ -932,7 +945,6 @@ def e2e_runs(work, n_reads, call=True):
             t0 = time.perf_counter()
             subprocess.run([exe, "index", "-d", os.path.join(work, "wg.fa"), "-o", os.path.join(work, "wg.fmd")], check=True, capture_output=True)
             t_index = time.perf_counter() - t0
-            os.remove(os.path.join(work, "wg.fa"))
             r = _run_search(exe, os.path.join(work, "wg.fmd"), bam, repeats=3, pause_s=5.0)
             r["what"] = ("the same BAM against the index of the whole reference (24 contigs, GRCh38 primary lengths, 6.18e9 BWT "
                          "symbols), every run 5 s after the process before ended (the driver clears the HBM a process hands back; "
@@ -941,8 +953,6 @@ def e2e_runs(work, n_reads, call=True):
             r["index_s"] = round(t_index, 2)
             r["fmd_bytes"] = os.path.getsize(os.path.join(work, "wg.fmd"))
             out["e2e_wg"] = r
-            for f in ("wg.fmd", "wg.fmd.svdss"):
-                os.remove(os.path.join(work, f))
         except Exception as e:   # noqa: BLE001
             out["e2e_wg_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
     os.remove(bam)
@@ -974,30 +984,168 @@ def e2e_runs(work, n_reads, call=True):
                                "svs_called": len(called), "svs_truth": len(truth), "truth_recovered": hit}
         except Exception as e:   # noqa: BLE001
             out["e2e_call_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
+        shutil_rm = __import__("shutil").rmtree
+        shutil_rm(os.path.join(work, "call"), ignore_errors=True)
+        have_wg = os.path.exists(os.path.join(work, "wg.fa")) and os.path.exists(os.path.join(work, "wg.fmd"))
+        from tools import e2e_call_wg as W
+
+        def chain_dir():
+            # the chains run on THIS run's reference (wg.fa, the contigs the headline index was built from) and on the index
+            # `SVDSS index` made of it for e2e_wg: ref.fa / ref.fmd are links, tools/chain_dataset.cpp reads the FASTA
+            d = os.path.join(work, "chainwg")
+            os.makedirs(d, exist_ok=True)
+            for link, target in (("ref.fa", "wg.fa"), ("ref.fmd", "wg.fmd"), ("ref.fmd.svdss", "wg.fmd.svdss")):
+                if have_wg and not os.path.lexists(os.path.join(d, link)):
+                    os.symlink(os.path.join(work, target), os.path.join(d, link))
+            return d
+
         try:
-            # the same chain at the metric's scale: GRCh38 primary lengths, 3,400 implanted SVs, 1.03 M
-            # error-free 15 kb reads (4.9x) with truth alignments and a BAI, per-stage seconds of `call`
-            import shutil
-            # ONE dataset at the metric's scale serves both keys: the chain a user of run_svdss runs (run_svdss:136-178; VERDICT
-            # r4 item 6) -- reads WITH errors, smooth first --, and, as its last two stages, what `e2e_call_wg` has reported since
-            # round 4 (search + call on smoothed reads)
-            from tools import e2e_call_wg as W
-            shutil.rmtree(os.path.join(work, "call"), ignore_errors=True)
-            r = W.run_chain(os.path.join(work, "chainwg"), 1_030_000, 3400)
-            r["what"] = ("SVDSS index -> smooth -> search (putative) -> call (binaries) at whole-genome scale: 24 contigs with the GRCh38 "
-                         "primary lengths, 3,400 implanted SVs (every other one heterozygous: at 4.9x many of those stay below "
-                         "--min-cluster-weight), 1,030,000 x 15 kb reads (4.9x) with 0.5 % substitution errors and truth alignments; smooth "
-                         "rewrites them to the reference, search reads the smoothed BAM and skips what smooth tagged XF != 0, call reads it "
-                         "again (no BAI: the device path); whole-process wall times, the index restore of search included")
+            # the chain a user of run_svdss runs (run_svdss:136-178) on 1.03 M reads (5x), and as its last two
+            # stages what `e2e_call_wg` has reported since round 4.  Round 6: the reads carry errors sub:ins:del = 2:1.5:1.5
+            # with the indels in their CIGARs (tools/chain_dataset.cpp; rounds 4-5: substitutions only)
+            d = chain_dir()
+            r = W.run_chain(d, 1_030_000, 3400, ref_from_fasta=have_wg)
+            r["what"] = ("SVDSS index -> smooth -> search (putative) -> call (binaries) at whole-genome lengths: 24 contigs with the GRCh38 "
+                         "primary lengths, 3,400 implanted SVs (every other one heterozygous: at 5x many of those stay below "
+                         "--min-cluster-weight), 1,030,000 x 15 kb reads (5x) with 0.5 % errors sub:ins:del = 2:1.5:1.5 and truth alignments; "
+                         "smooth rewrites them to the reference, search reads the smoothed BAM and skips what smooth tagged XF != 0, call "
+                         "reads the ORIGINAL BAM through its .bai (run_svdss:167-176); whole-process wall times, the index restore of search included")
             out["e2e_chain_wg"] = r
             out["e2e_call_wg"] = {k: r.get(k) for k in ("reads", "svs", "reference_bp", "index_s", "search_s", "search_index_resident_s", "call_s",
                                                         "svs_called", "truth_recovered", "search_plus_call_reads_per_s", "call_log", "search_log")}
             out["e2e_call_wg"]["call_reads_per_s"] = r["reads"] / r["call_s"]
             out["e2e_call_wg"]["what"] = "the search and call stages of e2e_chain_wg (since round 5 the reads reach them through SVDSS smooth)"
-            shutil.rmtree(os.path.join(work, "chainwg"), ignore_errors=True)
+            for f in ("reads.bam", "reads.bam.bai", "smoothed.bam", "specifics.txt"):
+                if os.path.exists(os.path.join(d, f)):
+                    os.remove(os.path.join(d, f))
         except Exception as e:   # noqa: BLE001
             out["e2e_chain_wg_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
+        if chain_reads > 0:
+            try:
+                # THE METRIC'S OWN CONFIGURATION through the binaries (BASELINE.json config 4): 30x = 6,176,540
+                # reads, 20,000 SVs, run_svdss's order.  ~50 GB of /tmp while it runs.
+                d = chain_dir()
+                n_svs = max(1, round(SVS_30X_WG * chain_reads / READS_30X_WG))
+                r = W.run_chain(d, chain_reads, n_svs, ref_from_fasta=have_wg, keep=True)
+                r["what"] = ("BASELINE.json config 4 through the binaries, as run_svdss:136-178 chains them: 24 contigs with the GRCh38 primary "
+                             "lengths, %d x 15 kb reads (%.1fx) with 0.5 %% errors sub:ins:del = 2:1.5:1.5 and truth alignments in a sorted, "
+                             "indexed BAM, %d implanted SVs (INS / DEL, 50-2000 bp, every other pair heterozygous); SVDSS smooth -> SVDSS search "
+                             "(putative, on the smoothed BAM) -> SVDSS call (original BAM + .bai); whole-process wall times of each binary, "
+                             "files in and out (page cache warm: the generator has just written them), search includes its index restore"
+                             % (r["reads"], r["coverage"], r["svs"]))
+                try:
+                    r["cpu_baseline"] = cpu_chain_baseline(d, r, oracle_fm, cpu_call)
+                except Exception as e:   # noqa: BLE001
+                    r["cpu_baseline_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
+                out["e2e_chain_30x"] = r
+            except Exception as e:   # noqa: BLE001
+                out["e2e_chain_30x_error"] = f"{type(e).__name__}: {str(e)[-300:]}"
+        shutil_rm(os.path.join(work, "chainwg"), ignore_errors=True)
     return out
+
+
+def cpu_chain_baseline(work, chain, fm, cpu_call, max_file_bytes=256 << 20, max_reads=4096):
+    """The CPU cost of the SAME chain on the SAME files, from measured pieces on a bounded sample (VERDICT r5 missing #5):
+      * BGZF: zlib inflate of the first members of the chain's BAMs and zlib level-6 deflate of what they hold (what htslib
+        does around every stage), single-thread rates scaled to the files' sizes and divided by the cores;
+      * search: the reads `SVDSS smooth` tagged XF:0 among the first records of the smoothed BAM -- the ones `search`
+        (putative) looks at -- through the oracle's ping-pong search + assemble on all cores, scaled to the XF:0 reads of the file;
+      * call: the oracle's POA + realignment + ratio rate on the step's sub-clusters (cpu_baseline.call), times the clusters
+        `call` reported.
+    Smoothing's CIGAR walk, placement and clustering are left out (cheap next to these): the figure is a LOWER bound of the
+    CPU time, the GPU / CPU ratio conservative.  Test infrastructure timed as a baseline; never on the product path."""
+    import re
+    import struct
+    import zlib
+    from tests import oracle_lib as O
+    threads = min(O.max_threads(), cpu_quota())
+    sm = os.path.join(work, "smoothed.bam")
+    data = open(sm, "rb").read(max_file_bytes)
+    # members
+    t_inf, raw_parts, comp_bytes, o = 0.0, [], 0, 0
+    while o + 18 <= len(data):
+        bsize = struct.unpack_from("<H", data, o + 16)[0] + 1
+        if o + bsize > len(data):
+            break
+        t0 = time.perf_counter()
+        raw_parts.append(zlib.decompress(data[o + 18:o + bsize - 8], -15))
+        t_inf += time.perf_counter() - t0
+        comp_bytes += bsize
+        o += bsize
+    raw = b"".join(raw_parts)
+    inflate_bps = len(raw) / max(t_inf, 1e-9)
+    t0 = time.perf_counter()
+    defl_sample = raw[:64 << 20]
+    zc = zlib.compressobj(6, zlib.DEFLATED, -15)
+    zc.compress(defl_sample)
+    zc.flush()
+    deflate_bps = len(defl_sample) / max(time.perf_counter() - t0, 1e-9)
+    # records: XF:0 reads -> nt6
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        p += 4 + struct.unpack_from("<i", raw, p)[0] + 4
+    lut = np.full(16, 5, dtype=np.uint8)
+    lut[[1, 2, 4, 8]] = [1, 2, 3, 4]
+    reads, n_rec, p_first = [], 0, p
+    while p + 4 <= len(raw) and len(reads) < max_reads:
+        bs = struct.unpack_from("<i", raw, p)[0]
+        if p + 4 + bs > len(raw):
+            break
+        l_name, n_cig, l_seq = raw[p + 12], struct.unpack_from("<H", raw, p + 16)[0], struct.unpack_from("<i", raw, p + 20)[0]
+        q = p + 36 + l_name + 4 * n_cig
+        aux = q + (l_seq + 1) // 2 + l_seq
+        end = p + 4 + bs
+        xf = None
+        while aux + 3 <= end:      # (smooth writes XF as a one-byte integer; other tags of these files: none)
+            tag, ty = raw[aux:aux + 2], chr(raw[aux + 2])
+            size = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}.get(ty)
+            if size is None:
+                break
+            if tag == b"XF":
+                xf = int.from_bytes(raw[aux + 3:aux + 3 + size], "little")
+            aux += 3 + size
+        n_rec += 1
+        if xf == 0:
+            packed = np.frombuffer(raw, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q)
+            b = np.empty(2 * len(packed), dtype=np.uint8)
+            b[0::2] = lut[packed >> 4]
+            b[1::2] = lut[packed & 15]
+            reads.append(b[:l_seq])
+        p = end
+    if fm is None or not reads:
+        raise RuntimeError("no oracle index / no XF:0 reads in the sample")
+    offs = np.zeros(len(reads) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(x) for x in reads])
+    flat = np.ascontiguousarray(np.concatenate(reads))
+    t0 = time.perf_counter()
+    c, _, _, _ = fm.search_batch(flat, offs, True, threads)
+    t_search = time.perf_counter() - t0
+    search_rate = len(reads) / t_search
+    m = re.search(r"XF 0/1/2/3: (\d+) ", " ".join(chain.get("smooth_log", [])))
+    n_xf0 = int(m.group(1)) if m else int(chain["reads"] * len(reads) / max(n_rec, 1))
+    n_sub = max(chain.get("svs_called", 0), chain.get("svs", 0))
+    sub_rate = (cpu_call or {}).get("value")
+    # inflated sizes: ~ reads x (32 + name + cigar + 7.5 kb of bases + 15 kb of qualities)
+    inflated_per_read = (p - p_first) / max(n_rec, 1)
+    inflated = chain["reads"] * inflated_per_read
+    smooth_s = (inflated / inflate_bps + inflated / deflate_bps) / threads
+    search_s = inflated / inflate_bps / threads + n_xf0 / search_rate
+    call_s = 1.3 * inflated / inflate_bps / threads + (n_sub / sub_rate if sub_rate else 0.0)
+    total = smooth_s + search_s + call_s
+    return {"kind": "port", "cores": threads, "unit": "reads/s",
+            "chain_reads_per_s": chain["reads"] / total, "search_plus_call_reads_per_s": chain["reads"] / (search_s + call_s),
+            "seconds": {"smooth": round(smooth_s, 1), "search": round(search_s, 1), "call": round(call_s, 1)},
+            "measured": {"zlib_inflate_MBps_per_core": round(inflate_bps / 1e6, 1), "zlib6_deflate_MBps_per_core": round(deflate_bps / 1e6, 1),
+                         "oracle_search_reads_per_s": round(search_rate, 1), "oracle_call_subclusters_per_s": sub_rate,
+                         "sample_records": n_rec, "sample_xf0_reads": len(reads), "sample_sfs": int(c.sum()), "search_sample_s": round(t_search, 2)},
+            "scaled_to": {"reads": chain["reads"], "xf0_reads": n_xf0, "subclusters": n_sub, "inflated_bytes_per_bam": int(inflated)},
+            "sample": (f"first {comp_bytes >> 20} MB of the chain's smoothed BAM: zlib inflate / level-6 deflate single-thread rates; its "
+                       f"{len(reads)} XF:0 reads through oracle/svdss_oracle.c on {threads} threads; call DP at cpu_baseline.call's rate; "
+                       "per-stage seconds = BGZF bytes / rate / cores + searched reads / rate + sub-clusters / rate (smoothing's CIGAR "
+                       "walk, placement, clustering not counted: a lower bound of the CPU time)")}
 
 
 def cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads, target_s, cw):
@@ -1064,7 +1212,7 @@ def cpu_baseline_and_verify(ix, pp, d_reads, L, n_reads, target_s, cw):
         base["sample"] += (f"; call: first {m2} of the step's {cw.n_sub} sub-clusters, {t2c:.1f} s, oracle POA + extd2 + ratio "
                            f"(oracle/svdss_oracle_callbatch.c) with {threads} OpenMP threads; value = reads of a step / (their "
                            "search time + the call time of the sub-clusters they imply)")
-    return base, k2, m2
+    return base, k2, m2, fm
 
 
 if __name__ == "__main__":

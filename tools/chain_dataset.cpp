@@ -4,7 +4,9 @@
 // the implanted SVs (truth.tsv).  The C++ successor of tools/e2e_call_wg.py::write_dataset (a Python loop per read: 22 s
 // per 1.03 M substitution-only reads; a 30x set is 6.18 M reads with ~45 indels each in the CIGAR).
 //
-//   chain_dataset <workdir> <n_reads> <n_svs> [scale=1] [err=0.005] [threads=16] [codec=zlib1|zlib6|libdeflate1|libdeflate6] [keep_ref=0]
+//   chain_dataset <workdir> <n_reads> <n_svs> [scale=1] [err=0.005] [threads=16] [codec=zlib1|zlib6|libdeflate1|libdeflate6] [ref=0]
+//       ref: 0 = generate the reference and write <workdir>/ref.fa; 1 = generate it, leave an existing ref.fa alone (same seeds,
+//       same file); 2 = READ <workdir>/ref.fa (any FASTA; the contigs and their order are the file's)
 //
 // Per contig c (GRCh38 primary lengths x scale): iid ACGT reference (seeded), n_svs * len / total SVs -- one per stretch,
 // INS / DEL alternating, length U[50, 2000], every other pair heterozygous --, two haplotypes (all SVs / homozygous ones
@@ -218,7 +220,8 @@ int main(int argc, char** argv) {
   const double scale = argc > 4 ? atof(argv[4]) : 1.0, err = argc > 5 ? atof(argv[5]) : 0.005;
   const int threads = std::max(1, argc > 6 ? atoi(argv[6]) : 16);
   const std::string codec = argc > 7 ? argv[7] : "zlib1";
-  const bool keep_ref = argc > 8 && atoi(argv[8]) != 0;
+  const int ref_mode = argc > 8 ? atoi(argv[8]) : 0;
+  const bool keep_ref = ref_mode != 0;
   g_codec.level = codec.back() - '0';
   if (codec.rfind("libdeflate", 0) == 0) {
     void* h = dlopen("libdeflate.so.0", RTLD_NOW);
@@ -232,10 +235,33 @@ int main(int argc, char** argv) {
   }
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
-  std::vector<int64_t> lens(24);
-  int64_t total = 0;
-  for (int i = 0; i < 24; ++i) { lens[i] = std::max<int64_t>(200000, (int64_t)(GRCH38_PRIMARY[i] * scale)); total += lens[i]; }
   const std::string fa_path = work + "/ref.fa", bam_path = work + "/reads.bam";
+  std::vector<int64_t> lens;
+  std::vector<std::vector<uint8_t>> given;       // ref = 2: the contigs of the FASTA, nt 1..5
+  std::vector<std::string> names;
+  int64_t total = 0;
+  if (ref_mode == 2) {
+    FILE* f = fopen(fa_path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "cannot read %s\n", fa_path.c_str()); return 1; }
+    uint8_t map[256]; memset(map, 5, sizeof map);
+    map[(int)'A'] = map[(int)'a'] = 1; map[(int)'C'] = map[(int)'c'] = 2; map[(int)'G'] = map[(int)'g'] = 3; map[(int)'T'] = map[(int)'t'] = 4;
+    std::vector<char> buf(1 << 24);
+    bool in_header = false;
+    std::string hdr;
+    for (size_t n; (n = fread(buf.data(), 1, buf.size(), f)) > 0;)
+      for (size_t k = 0; k < n; ++k) {
+        const char c = buf[k];
+        if (in_header) { if (c == '\n') { in_header = false; names.push_back(hdr.substr(0, hdr.find_first_of(" \t"))); given.emplace_back(); } else hdr += c; }
+        else if (c == '>') { in_header = true; hdr.clear(); }
+        else if (c != '\n' && c != '\r' && !given.empty()) given.back().push_back(map[(uint8_t)c]);
+      }
+    fclose(f);
+    for (auto& g : given) { lens.push_back((int64_t)g.size()); total += (int64_t)g.size(); }
+    if (lens.empty()) { fprintf(stderr, "no contigs in %s\n", fa_path.c_str()); return 1; }
+  } else {
+    for (int i = 0; i < 24; ++i) { lens.push_back(std::max<int64_t>(200000, (int64_t)(GRCH38_PRIMARY[i] * scale))); total += lens.back(); names.push_back("c" + std::to_string(i + 1)); }
+  }
+  const int nctg = (int)lens.size();
   const bool write_fa = !(keep_ref && access(fa_path.c_str(), R_OK) == 0);
   FILE* fa = write_fa ? fopen(fa_path.c_str(), "wb") : nullptr;
   FILE* bam = fopen(bam_path.c_str(), "wb");
@@ -244,11 +270,11 @@ int main(int argc, char** argv) {
   // BAM header
   {
     std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
-    for (int i = 0; i < 24; ++i) text += "@SQ\tSN:c" + std::to_string(i + 1) + "\tLN:" + std::to_string(lens[i]) + "\n";
+    for (int i = 0; i < nctg; ++i) text += "@SQ\tSN:" + names[i] + "\tLN:" + std::to_string(lens[i]) + "\n";
     std::vector<uint8_t> hdr = {'B', 'A', 'M', 1};
     auto put32 = [&](int32_t v) { const uint8_t* b = (const uint8_t*)&v; hdr.insert(hdr.end(), b, b + 4); };
-    put32((int32_t)text.size()); hdr.insert(hdr.end(), text.begin(), text.end()); put32(24);
-    for (int i = 0; i < 24; ++i) { const std::string nm = "c" + std::to_string(i + 1); put32((int32_t)nm.size() + 1); hdr.insert(hdr.end(), nm.begin(), nm.end()); hdr.push_back(0); put32((int32_t)lens[i]); }
+    put32((int32_t)text.size()); hdr.insert(hdr.end(), text.begin(), text.end()); put32(nctg);
+    for (int i = 0; i < nctg; ++i) { const std::string nm = names[i]; put32((int32_t)nm.size() + 1); hdr.insert(hdr.end(), nm.begin(), nm.end()); hdr.push_back(0); put32((int32_t)lens[i]); }
     Deflater d; std::vector<uint8_t> m; bgzf_member(d, hdr.data(), hdr.size(), m);
     fwrite(m.data(), 1, m.size(), bam);
   }
@@ -256,18 +282,20 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> bai = {'B', 'A', 'I', 1};
   auto bai32 = [&](int32_t v) { const uint8_t* b = (const uint8_t*)&v; bai.insert(bai.end(), b, b + 4); };
   auto bai64 = [&](uint64_t v) { const uint8_t* b = (const uint8_t*)&v; bai.insert(bai.end(), b, b + 8); };
-  bai32(24);
+  bai32(nctg);
   std::vector<Sv> svs;
   int64_t sv_left = n_svs, rd_left = n_reads, n_written = 0, n_cigar_ops = 0;
   static const char LUT[6] = {'N', 'A', 'C', 'G', 'T', 'N'};
-  for (int tid = 0; tid < 24; ++tid) {
+  for (int tid = 0; tid < nctg; ++tid) {
     const int64_t ref_len = lens[tid];
-    const int64_t ns = tid == 23 ? sv_left : llround((double)n_svs * ref_len / total), nr = tid == 23 ? rd_left : llround((double)n_reads * ref_len / total);
+    const int64_t ns = tid == nctg - 1 ? sv_left : llround((double)n_svs * ref_len / total), nr = tid == nctg - 1 ? rd_left : llround((double)n_reads * ref_len / total);
     sv_left -= ns; rd_left -= nr;
     const uint64_t seed = 1000 + (uint64_t)tid;
     // ---- reference (blocks of 1 M bases, seeded per block)
-    std::vector<uint8_t> ref((size_t)ref_len);
-    {
+    std::vector<uint8_t> ref;
+    if (ref_mode == 2) ref.swap(given[(size_t)tid]);
+    else {
+      ref.resize((size_t)ref_len);
       std::atomic<int64_t> nextb{0};
       const int64_t nb = (ref_len + (1 << 20) - 1) >> 20;
       std::vector<std::thread> th;
@@ -281,7 +309,7 @@ int main(int argc, char** argv) {
       for (auto& t : th) t.join();
     }
     if (fa) {
-      fprintf(fa, ">c%d\n", tid + 1);
+      fprintf(fa, ">%s\n", names[(size_t)tid].c_str());
       std::vector<char> line(1 << 22);
       for (int64_t k = 0; k < ref_len; k += (int64_t)line.size()) { const size_t n = (size_t)std::min<int64_t>((int64_t)line.size(), ref_len - k); for (size_t q = 0; q < n; ++q) line[q] = LUT[ref[(size_t)k + q]]; fwrite(line.data(), 1, n, fa); }
       fputc('\n', fa);
@@ -398,7 +426,7 @@ int main(int argc, char** argv) {
     bai32((int32_t)lin.size());
     uint64_t lastv = 0;
     for (auto v : lin) { if (v) lastv = v; bai64(lastv); }
-    fprintf(stderr, "[chain_dataset] c%d: %lld reads at +%.1f s\n", tid + 1, (long long)ds.size(), since());
+    fprintf(stderr, "[chain_dataset] %s: %lld reads at +%.1f s\n", names[(size_t)tid].c_str(), (long long)ds.size(), since());
   }
   { Deflater d; std::vector<uint8_t> m; bgzf_member(d, (const uint8_t*)"", 0, m); fwrite(m.data(), 1, m.size(), bam); }
   if (fclose(bam) != 0 || (fa && fclose(fa) != 0)) { fprintf(stderr, "write error\n"); return 1; }

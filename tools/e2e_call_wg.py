@@ -266,7 +266,7 @@ def build_generator():
     return GEN_EXE
 
 
-def write_dataset_cxx(work, n_reads, n_svs, scale=1.0, err=0.005, threads=None, codec=None, keep_ref=False):
+def write_dataset_cxx(work, n_reads, n_svs, scale=1.0, err=0.005, threads=None, codec=None, keep_ref=False, ref_from_fasta=False):
     """The same data set by tools/chain_dataset.cpp, with errors sub:ins:del = 2:1.5:1.5 and the indels in the
     truth CIGARs.  Returns (fa, bam, svs, n, lens, info)."""
     os.makedirs(work, exist_ok=True)
@@ -275,7 +275,7 @@ def write_dataset_cxx(work, n_reads, n_svs, scale=1.0, err=0.005, threads=None, 
     if codec is None:   # what htslib writes when it is built with libdeflate (level 6); zlib level 1 where that library is absent
         import ctypes.util
         codec = "libdeflate6" if ctypes.util.find_library("deflate") else "zlib1"
-    r = subprocess.run([exe, work, str(n_reads), str(n_svs), repr(scale), repr(err), str(threads), codec, "1" if keep_ref else "0"],
+    r = subprocess.run([exe, work, str(n_reads), str(n_svs), repr(scale), repr(err), str(threads), codec, "2" if ref_from_fasta else "1" if keep_ref else "0"],
                        check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     info = json.loads(r.stdout.strip().splitlines()[-1])
     svs = []
@@ -283,7 +283,7 @@ def write_dataset_cxx(work, n_reads, n_svs, scale=1.0, err=0.005, threads=None, 
         for line in f:
             t, p, k, ln, het = line.split()
             svs.append((int(t), int(p), k, int(ln), het == "1"))
-    lens = [max(200000, int(x * scale)) for x in GRCH38_PRIMARY]
+    lens = [info["reference_bp"]] if ref_from_fasta else [max(200000, int(x * scale)) for x in GRCH38_PRIMARY]
     return os.path.join(work, "ref.fa"), os.path.join(work, "reads.bam"), svs, info["reads"], lens, info
 
 
@@ -346,16 +346,18 @@ def _vcf_hits(vcf_text, svs):
     return len(called), hit
 
 
-def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005, generator="cxx", keep_ref=False, keep=False, stage_env=None):
+def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005, generator="cxx", keep_ref=False, keep=False, stage_env=None,
+              ref_from_fasta=False):
     """index -> smooth -> search (putative) -> call, as run_svdss:136-178 chains them, on reads WITH errors.
     generator "cxx": tools/chain_dataset.cpp, errors sub:ins:del = 2:1.5:1.5 with the indels in the CIGARs (round 6);
     "py": the Python generator above (substitutions only; rounds 4-5).  keep_ref: ref.fa / ref.fmd already in `work`
-    (the same seeds give the same reference whatever the number of reads) are used as they are."""
+    (the same seeds give the same reference whatever the number of reads) are used as they are.  ref_from_fasta: the reads
+    are drawn from the contigs of `work`/ref.fa (somebody else's reference: bench.py's), ref.fmd beside it is used if there."""
     exe = os.path.join(ROOT, "svdss_amd", "SVDSS")
     out = {}
     t0 = time.perf_counter()
     if generator == "cxx":
-        fa, bam, svs, n, lens, info = write_dataset_cxx(work, n_reads, n_svs, scale, err=err, keep_ref=keep_ref)
+        fa, bam, svs, n, lens, info = write_dataset_cxx(work, n_reads, n_svs, scale, err=err, keep_ref=keep_ref, ref_from_fasta=ref_from_fasta)
         out["generator"] = "tools/chain_dataset.cpp: errors sub:ins:del = 2:1.5:1.5, %.1f CIGAR operations per read, BGZF by %s" % (info["cigar_ops_per_read"], info["codec"])
     else:
         fa, bam, svs, n, lens = write_dataset(work, n_reads, n_svs, scale, err=err)
@@ -365,7 +367,7 @@ def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005, generator=
                 "bam_bytes": os.path.getsize(bam)})
     fmd = os.path.join(work, "ref.fmd")
     env = dict(os.environ, **(stage_env or {}))
-    if not (keep_ref and os.path.exists(fmd)):
+    if not ((keep_ref or ref_from_fasta) and os.path.exists(fmd)):
         t0 = time.perf_counter()
         subprocess.run([exe, "index", "-d", fa, "-o", fmd], check=True, capture_output=True, env=env)
         out["index_s"] = round(time.perf_counter() - t0, 2)
