@@ -89,6 +89,12 @@ int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out);
 int64_t svdss_index_device_bytes(const svdss_index_t* ix);
 /* order K of the k-mer table built by svdss_index_to_device (0 before / without it) */
 int32_t svdss_index_kmer(const svdss_index_t* ix);
+/* An upper limit for the order of tables built FROM NOW ON (process-wide; 0 = none; an explicit SVDSS_KMER wins).  The
+ * table's build time quarters per step down, the search kernel slows down by about a factor of two per step: a process that
+ * restores the index for one input may learn, while the suffix array is still being sorted, that it has few reads to search
+ * (`SVDSS search` on a smoothed BAM: the putative filter of ping_pong.cpp:202-203 skips most of them) -- the limit is read
+ * when the table's build begins.  Results never depend on K. */
+void svdss_index_kmer_limit(int32_t k);
 /* share of the k-mer occurrences (sampled while the table is built) that belong to k-mers with 8 or more of them: a
  * reference rich in young repeat families has >= 0.35, and the search then finishes backward phases on deep intervals by
  * binary search of the suffix array (the BS instantiation of the kernel; SVDSS_BS=0|1 overrides, SVDSS_BS_DEEP moves the
@@ -272,6 +278,35 @@ int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int
                         int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
                         const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
                         int32_t flags, svdss_bam_batch_t** out);
+/* The two halves of svdss_bam_batch_run, and a PARK for the reads of batches whose front half runs while no index is
+ * resident yet: PingPong::run loads the index (ping_pong.cpp:245, seconds for a human genome) and only then starts reading
+ * the BAM (:329-363); here the BAM front end (inflate, CRC, record chain, filters, 4-bit -> nt6) runs beside the index
+ * restore, the unpacked reads wait in HBM, and are searched in large launches -- one lane per read -- when the index is there.
+ *   svdss_bam_batch_front   everything of svdss_bam_batch_run up to the search.  park = NULL, or no room in it, or closed:
+ *                           the reads stay in the batch object and svdss_bam_batch_search(b, ix) finishes the batch.
+ *                           Else they go into the park (svdss_bam_batch_parked: group >= 0, index of the batch's first
+ *                           searched read in the group) and the batch object is free for the next batch; names / tags /
+ *                           slots of the batch are on the host either way (svdss_bam_batch_result: counts / qs / len empty).
+ *                           group = -2: the batch has no read to search.
+ *   svdss_bam_park_create   read_bytes of nt6 symbols + max_reads offsets in the HBM of `device` -- allocate it BEFORE the
+ *                           index restore starts so that nothing is handed back to the driver mid-stream.
+ *   svdss_bam_park_close    no more reservations (the index is resident); the open group is closed.
+ *   svdss_bam_park_search   group g (closed, all its batches unpacked: waits for that) as ONE svdss_sfs_search_batch_device
+ *                           launch; results with svdss_sfs_batch_fetch, reads in the order of their reservations.
+ * A group closes at SVDSS_PARK_GROUP_READS reads (262,144) or SVDSS_PARK_GROUP_MB of symbols (4,096). */
+typedef struct svdss_bam_park svdss_bam_park_t;
+int svdss_bam_park_create(int32_t device, int64_t read_bytes, int64_t max_reads, svdss_bam_park_t** out);
+void svdss_bam_park_free(svdss_bam_park_t* p);
+int svdss_bam_park_close(svdss_bam_park_t* p);
+int64_t svdss_bam_park_groups(svdss_bam_park_t* p);
+int svdss_bam_park_group(svdss_bam_park_t* p, int64_t g, int64_t* n_batches, int64_t* n_reads, int64_t* n_syms);
+int svdss_bam_park_search(svdss_bam_park_t* p, int64_t g, const svdss_index_t* ix, int32_t flags, svdss_sfs_batch_t** sfs);
+int svdss_bam_batch_front(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, int32_t device, svdss_bam_park_t* park,
+                          int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                          const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                          int32_t flags, svdss_bam_batch_t** out);
+int svdss_bam_batch_parked(const svdss_bam_batch_t* b, int64_t* group, int64_t* first, int64_t* n_reads);
+int svdss_bam_batch_search(svdss_bam_batch_t* b, const svdss_index_t* ix);
 /* What the last run of a batch object left on the host (valid until its next run / svdss_bam_batch_free).  A "slot" is a
  * record that passed the filters of ping_pong.cpp:66-75, in file order -- what load_batch_bam deals to the threads. */
 typedef struct svdss_bam_result {

@@ -60,6 +60,7 @@ SIGNATURES = {
     "svdss_index_bwt": (C.c_int, [_p, _p]),
     "svdss_index_device_bytes": (_i64, [_p]),
     "svdss_index_kmer": (_i32, [_p]),
+    "svdss_index_kmer_limit": (None, [_i32]),
     "svdss_index_deep_frac": (C.c_double, [_p]),
     "svdss_index_to_device": (C.c_int, [_p, _i32]),
     "svdss_index_count": (_i64, [_p, _p, _i64]),
@@ -102,6 +103,15 @@ SIGNATURES = {
     "svdss_bam_stream_head": (_i64, [_p, C.POINTER(_p)]),
     "svdss_bam_stream_tail": (_i64, [_p, C.POINTER(_p)]),
     "svdss_bam_batch_run": (C.c_int, [_p, _i64, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p, _i32, C.POINTER(_p)]),
+    "svdss_bam_batch_front": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _i32, _p, _p, _p, _p, _p, _i32, C.POINTER(_p)]),
+    "svdss_bam_batch_parked": (C.c_int, [_p, _pi64, _pi64, _pi64]),
+    "svdss_bam_batch_search": (C.c_int, [_p, _p]),
+    "svdss_bam_park_create": (C.c_int, [_i32, _i64, _i64, C.POINTER(_p)]),
+    "svdss_bam_park_free": (None, [_p]),
+    "svdss_bam_park_close": (C.c_int, [_p]),
+    "svdss_bam_park_groups": (_i64, [_p]),
+    "svdss_bam_park_group": (C.c_int, [_p, _i64, _pi64, _pi64, _pi64]),
+    "svdss_bam_park_search": (C.c_int, [_p, _i64, _p, _i32, C.POINTER(_p)]),
     "svdss_bam_batch_result": (C.c_int, [_p, _p]),
     "svdss_bam_smooth_create": (C.c_int, [_p, _p, C.c_int32, C.c_int32, _p]),
     "svdss_bam_smooth_free": (None, [_p]),

@@ -629,9 +629,46 @@ struct svdss_bam_filter {
   int32_t *d_reg_beg = nullptr, *d_reg_runmax = nullptr;
 };
 
+// Reads unpacked while no index is resident yet (`SVDSS search` restores its index for seconds; the BAM front end runs
+// meanwhile): an arena of nt6 bytes + one of offsets, cut into GROUPS of consecutive reservations that are searched as one
+// large launch each (one lane per read) once the index is there.  A group's reads are contiguous from a 16-byte aligned
+// start, its offsets relative to that start.
+struct ParkGroup {
+  int32_t arena = 0;
+  int64_t sym0 = 0, n_syms = 0;      // where its reads begin in its arena (16-aligned), symbols so far
+  int64_t off0 = 0, n_reads = 0;     // where its offsets begin, reads so far (offsets: n_reads + 1 entries)
+  int32_t n_batches = 0, pending = 0;
+  bool closed = false;
+};
+// (arenas are allocated one at a time, the first before the index restore starts: a process that searches 1 % of its reads --
+// `SVDSS search` on a smoothed BAM -- never needs a second one, and memory the driver hands out is cleared first, 30-50 GB/s)
+struct ParkArena {
+  uint8_t* d_reads = nullptr;
+  int64_t* d_off = nullptr;
+  int64_t cap_bytes = 0, cap_off = 0;
+};
+struct svdss_bam_park {
+  int device = -1;
+  std::vector<ParkArena> arenas;
+  int64_t arena_bytes = (int64_t)8 << 30, max_bytes = 0, reads_per_arena = 0;
+  int64_t group_reads = 262144, group_bytes = (int64_t)4 << 30;
+  hipStream_t st = nullptr;
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<ParkGroup> groups;
+  bool closed = false;
+};
+
 struct svdss_bam_batch {
   int device = -1;
   hipStream_t st = nullptr;
+  // what the front half left for the search half (svdss_bam_batch_front / _search)
+  const uint8_t* cur_reads = nullptr;
+  const int64_t* cur_off = nullptr;
+  int64_t cur_syms = 0, name_bytes = 0;
+  int32_t cur_flags = 0;
+  bool front_done = false;
+  int64_t park_group = -1, park_first = 0;   // -1: not parked (reads in this object), -2: nothing to search, >= 0: group
   DevBuf comp, blks, crcb, status, buf, seg, lists, pre, hdr, rpos, flags, scans, d_hp, tmp, o_small, d_names, sym_off, seq_src, reads, totals;
   uint8_t* h_pin = nullptr;        // page-locked staging: block tables up, small results down
   size_t h_pin_cap = 0;
@@ -962,15 +999,157 @@ static int batch_front(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int6
   return SVDSS_OK;
 }
 
-extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_index_t* ix,
-                                   int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
-                                   const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
-                                   int32_t flags, svdss_bam_batch_t** out) {
-  if (!s || !ix || !out || seq < 0 || skip < 0 || n_chunks < 0) return SVDSS_EINVAL;
-  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;   // (the caller's mistake: the stream's turn is not taken)
+__global__ void __launch_bounds__(256) rebase_offsets_kernel(const int64_t* __restrict__ in, int64_t n, int64_t base, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] + base;
+}
+
+// ---- the park (see struct svdss_bam_park)
+static hipError_t park_new_arena(svdss_bam_park* p) {
+  ParkArena A;
+  A.cap_bytes = std::min(p->arena_bytes, p->max_bytes - (int64_t)p->arenas.size() * p->arena_bytes);
+  if (A.cap_bytes < 4096) return hipErrorOutOfMemory;
+  A.cap_off = p->reads_per_arena + 64;
+  hipError_t e = hipMalloc((void**)&A.d_reads, (size_t)A.cap_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&A.d_off, sizeof(int64_t) * (size_t)A.cap_off);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (A.d_reads) (void)hipFree(A.d_reads);
+    return e;
+  }
+  p->arenas.push_back(A);
+  return hipSuccess;
+}
+
+extern "C" int svdss_bam_park_create(int32_t device, int64_t read_bytes, int64_t max_reads, svdss_bam_park_t** out) {
+  if (!out || device < 0 || read_bytes < 4096 || max_reads < 1) return SVDSS_EINVAL;
+  HIPCHK(hipSetDevice(device));
+  svdss_bam_park* p = new (std::nothrow) svdss_bam_park();
+  if (!p) return SVDSS_ENOMEM;
+  p->device = device;
+  if (const char* e = getenv("SVDSS_PARK_GROUP_READS")) if (atoll(e) > 0) p->group_reads = atoll(e);
+  if (const char* e = getenv("SVDSS_PARK_GROUP_MB")) if (atoll(e) > 0) p->group_bytes = atoll(e) << 20;
+  if (const char* e = getenv("SVDSS_PARK_ARENA_MB")) if (atoll(e) > 0) p->arena_bytes = atoll(e) << 20;
+  p->max_bytes = read_bytes;
+  p->arena_bytes = std::min(p->arena_bytes, read_bytes);
+  p->group_bytes = std::min(p->group_bytes, p->arena_bytes / 2);
+  p->reads_per_arena = std::max<int64_t>(1024, (int64_t)((double)max_reads * (double)p->arena_bytes / (double)read_bytes) + 1);
+  hipError_t e = park_new_arena(p);
+  if (e == hipSuccess) e = svdss_make_stream(&p->st, "SVDSS_SEARCH_CUS");
+  if (e != hipSuccess) {
+    g_svdss_hip_err = std::string("svdss_bam_park_create: ") + hipGetErrorString(e);
+    svdss_bam_park_free(p);
+    return e == hipErrorOutOfMemory ? SVDSS_ENOMEM : SVDSS_EHIP;
+  }
+  *out = p;
+  return SVDSS_OK;
+}
+
+extern "C" void svdss_bam_park_free(svdss_bam_park_t* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->st) (void)hipStreamDestroy(p->st);
+  for (ParkArena& A : p->arenas) { if (A.d_reads) (void)hipFree(A.d_reads); if (A.d_off) (void)hipFree(A.d_off); }
+  delete p;
+}
+
+// no more reservations: the open group is closed (the index is resident; batches go straight to the search from here on)
+extern "C" int svdss_bam_park_close(svdss_bam_park_t* p) {
+  if (!p) return SVDSS_EINVAL;
+  { std::lock_guard<std::mutex> lk(p->m); p->closed = true; if (!p->groups.empty()) p->groups.back().closed = true; }
+  p->cv.notify_all();
+  return SVDSS_OK;
+}
+
+extern "C" int64_t svdss_bam_park_groups(svdss_bam_park_t* p) {
+  if (!p) return -1;
+  std::lock_guard<std::mutex> lk(p->m);
+  return (int64_t)p->groups.size();
+}
+
+extern "C" int svdss_bam_park_group(svdss_bam_park_t* p, int64_t g, int64_t* n_batches, int64_t* n_reads, int64_t* n_syms) {
+  if (!p || g < 0) return SVDSS_EINVAL;
+  std::lock_guard<std::mutex> lk(p->m);
+  if (g >= (int64_t)p->groups.size()) return SVDSS_EINVAL;
+  const ParkGroup& G = p->groups[(size_t)g];
+  if (n_batches) *n_batches = G.n_batches;
+  if (n_reads) *n_reads = G.n_reads;
+  if (n_syms) *n_syms = G.n_syms;
+  return SVDSS_OK;
+}
+
+// room for n reads / syms symbols: group, index of the first read and symbol offset inside it; false = not parked
+static bool park_reserve(svdss_bam_park* p, int64_t n, int64_t syms, int64_t& g, int64_t& first, int64_t& sym_first) {
+  std::lock_guard<std::mutex> lk(p->m);
+  if (p->closed) return false;
+  auto fits = [&](const ParkGroup& G) {
+    const ParkArena& A = p->arenas[(size_t)G.arena];
+    return G.sym0 + G.n_syms + syms + 64 <= A.cap_bytes && G.off0 + G.n_reads + n + 2 <= A.cap_off;
+  };
+  if (!p->groups.empty() && !p->groups.back().closed && !fits(p->groups.back())) p->groups.back().closed = true;
+  if (p->groups.empty() || p->groups.back().closed) {
+    ParkGroup G;
+    if (!p->groups.empty()) {
+      const ParkGroup& L = p->groups.back();
+      G.arena = L.arena;
+      G.sym0 = ((L.sym0 + L.n_syms + 15) & ~(int64_t)15) + 32;
+      G.off0 = L.off0 + L.n_reads + 1;
+    }
+    if (!fits(G)) {
+      // the next arena (what is parked stays where it is); none to be had: the rest of the file waits for the index
+      if (syms + 64 > p->arena_bytes || n + 2 > p->reads_per_arena || park_new_arena(p) != hipSuccess) { p->closed = true; return false; }
+      G.arena = (int32_t)p->arenas.size() - 1; G.sym0 = 0; G.off0 = 0;
+      if (!fits(G)) { p->closed = true; return false; }
+    }
+    p->groups.push_back(G);
+  }
+  ParkGroup& G = p->groups.back();
+  g = (int64_t)p->groups.size() - 1;
+  first = G.n_reads; sym_first = G.n_syms;
+  G.n_reads += n; G.n_syms += syms; ++G.n_batches; ++G.pending;
+  if (G.n_reads >= p->group_reads || G.n_syms >= p->group_bytes) G.closed = true;
+  return true;
+}
+static void park_done(svdss_bam_park* p, int64_t g) {
+  { std::lock_guard<std::mutex> lk(p->m); --p->groups[(size_t)g].pending; }
+  p->cv.notify_all();
+}
+
+// One group searched as ONE launch (one lane per read: the large-batch regime).  Waits until the group is closed and all
+// its batches have unpacked; results with svdss_sfs_batch_fetch (reads in reservation order).
+extern "C" int svdss_bam_park_search(svdss_bam_park_t* p, int64_t g, const svdss_index_t* ix, int32_t flags, svdss_sfs_batch_t** sfs) {
+  if (!p || !ix || !sfs || g < 0) return SVDSS_EINVAL;
+  if (ix->device != p->device || !ix->d_blocks) return SVDSS_ENODEV;
+  ParkGroup G;
+  {
+    std::unique_lock<std::mutex> lk(p->m);
+    if (g >= (int64_t)p->groups.size()) return SVDSS_EINVAL;
+    p->cv.wait(lk, [&] { return p->groups[(size_t)g].closed && p->groups[(size_t)g].pending == 0; });
+    G = p->groups[(size_t)g];
+  }
+  HIPCHK(hipSetDevice(p->device));
+  // (the bytes behind the last read up to the end of its 16-byte chunk and one chunk more: what a batch's own buffer has zeroed)
+  const ParkArena A = [&] { std::lock_guard<std::mutex> lk(p->m); return p->arenas[(size_t)G.arena]; }();
+  HIPCHK(hipMemsetAsync(A.d_reads + G.sym0 + G.n_syms, 0, (size_t)((((G.n_syms + 15) & ~(int64_t)15) + 16) - G.n_syms), p->st));
+  const int rc = svdss_sfs_search_batch_device(ix, A.d_reads + G.sym0, A.d_off + G.off0, G.n_reads, G.n_syms, flags & SVDSS_SFS_ASSEMBLE, (void*)p->st, sfs);
+  if (rc != SVDSS_OK) return rc;
+  HIPCHK(hipStreamSynchronize(p->st));
+  return SVDSS_OK;
+}
+
+// The front half of svdss_bam_batch_run: inflate, CRC, record chain, the turn, fields / filters / tags, bases unpacked --
+// into `park` when one is given and has room (svdss_bam_batch_parked says where), else into the batch object.  Names, tags
+// and slots of the batch are on the host when it returns (svdss_bam_batch_result; counts / SFS after the search).
+extern "C" int svdss_bam_batch_front(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, int32_t device, svdss_bam_park_t* park,
+                                     int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                                     const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                                     int32_t flags, svdss_bam_batch_t** out) {
+  if (!s || !out || seq < 0 || skip < 0 || n_chunks < 0 || device < 0) return SVDSS_EINVAL;
+  if (park && park->device != device) return SVDSS_EINVAL;
+  if (*out) (*out)->front_done = false;
   Front F;
   {
-    const int rc = batch_front(s, seq, is_last, skip, ix->device, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, out, F);
+    const int rc = batch_front(s, seq, is_last, skip, device, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, out, F);
     if (rc != SVDSS_OK) return rc;
   }
   svdss_bam_batch* b = *out;
@@ -979,7 +1158,10 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   int32_t* seg_base = F.seg_base;
   const int64_t* hdr = F.hdr;
   const int64_t total_inf = F.total_inf, HEAD = F.HEAD;
-  auto fail = [&](int code, const std::string& msg) { b->err = msg; (void)hipStreamSynchronize(st); return code; };
+  int64_t pg = -1, pfirst = 0, psym = 0;      // the park's group this batch reserved room in (-1: none)
+  auto unpark = [&]() { if (pg >= 0) { park_done(park, pg); pg = -1; } };
+  // (a failure must not leave the group waiting for this batch)
+  auto fail = [&](int code, const std::string& msg) { b->err = msg; (void)hipStreamSynchronize(st); unpark(); return code; };
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](int k) {
     const auto t = std::chrono::steady_clock::now();
@@ -1039,9 +1221,26 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
 
   // ---- bases, search
   const size_t padded = (size_t)((total_syms + 15) & ~(int64_t)15) + 16;
-  RCHK(ensure(b->reads, padded + 16));
+  b->park_group = n_srch > 0 ? -1 : -2;
+  b->park_first = 0;
+  uint8_t* reads_out = nullptr;
+  const int64_t* off_out = (const int64_t*)S.sym_off;
+  if (n_srch > 0 && park && park_reserve(park, n_srch, total_syms, pg, pfirst, psym)) {
+    // the reads go behind those of the batches that reserved before this one; the offsets are the group's
+    ParkArena A;
+    const ParkGroup G = [&] { std::lock_guard<std::mutex> lk(park->m); A = park->arenas[(size_t)park->groups[(size_t)pg].arena]; return park->groups[(size_t)pg]; }();
+    reads_out = A.d_reads + G.sym0;
+    int64_t* po = A.d_off + G.off0 + pfirst;
+    hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((n_srch + 1 + 255) / 256)), dim3(256), 0, st, (const int64_t*)S.sym_off, n_srch + 1, psym, po);
+    off_out = po;
+    b->park_group = pg; b->park_first = pfirst;
+    BCHK(hipGetLastError());
+  } else {
+    RCHK(ensure(b->reads, padded + 16));
+    reads_out = (uint8_t*)b->reads.p;
+  }
   if (n_srch > 0) {
-    BCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded >= 32 ? padded - 32 : 0), 0, padded >= 32 ? 32 : padded, st));
+    if (b->park_group < 0) BCHK(hipMemsetAsync((uint8_t*)b->reads.p + (padded >= 32 ? padded - 32 : 0), 0, padded >= 32 ? 32 : padded, st));
     // (the longest read decides the grid's width: the scan's inputs hold the lengths, the host does not -- bounded by
     // the largest record of the batch, i.e. by the batch itself; a second pass over the symbol offsets would cost more)
     int64_t max_len = 0;
@@ -1063,32 +1262,67 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
       const unsigned gx = (unsigned)((max_len + 15 + 256 * 16 - 1) / (256 * 16) + 1);
       for (int64_t y0 = 0; y0 < n_srch; y0 += 65535) {
         const unsigned gy = (unsigned)std::min<int64_t>(65535, n_srch - y0);
-        hipLaunchKernelGGL(unpack_kernel, dim3(gx, gy), dim3(256), 0, st, W.buf, (const int64_t*)S.seq_src, (const int64_t*)S.sym_off, y0, n_srch,
-                           (uint8_t*)b->reads.p);
+        hipLaunchKernelGGL(unpack_kernel, dim3(gx, gy), dim3(256), 0, st, W.buf, (const int64_t*)S.seq_src, off_out, y0, n_srch, reads_out);
       }
       BCHK(hipGetLastError());
     }
   }
-  BCHK(hipStreamSynchronize(st));
-  lap(4);   // unpack
+  // ---- what the host needs of the slots: names and tags
+  b->name_bytes = name_bytes;
+  try {
+    b->name_off.resize((size_t)n_slots + 1); b->hp.resize((size_t)n_slots); b->sidx.resize((size_t)n_slots);
+    b->names.resize((size_t)name_bytes + 1); b->counts.clear(); b->qs.clear(); b->len.clear();
+  } catch (...) { unpark(); return fail(SVDSS_ENOMEM, "out of memory"); }
   {
-    const int rc = svdss_sfs_search_batch_device(ix, (const uint8_t*)b->reads.p, (const int64_t*)S.sym_off, n_srch, total_syms,
+    hipError_t e = hipMemcpyAsync(b->name_off.data(), S.o_name_off, sizeof(int32_t) * (size_t)(n_slots + 1), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && n_slots > 0) e = hipMemcpyAsync(b->hp.data(), S.o_hp, sizeof(int32_t) * (size_t)n_slots, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && n_slots > 0) e = hipMemcpyAsync(b->sidx.data(), S.o_sidx, sizeof(int32_t) * (size_t)n_slots, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && name_bytes > 0) e = hipMemcpyAsync(b->names.data(), S.o_names, (size_t)name_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    unpark();     // (the unpack has run: the group may be searched)
+    if (e != hipSuccess) { g_svdss_hip_err = std::string("bam batch front: ") + hipGetErrorString(e); return fail(e == hipErrorOutOfMemory ? SVDSS_ENOMEM : SVDSS_EHIP, g_svdss_hip_err); }
+  }
+  lap(4);   // unpack; names and tags down
+  b->cur_reads = reads_out; b->cur_off = off_out; b->cur_syms = total_syms; b->cur_flags = flags;
+  b->stage_ms[5] = b->stage_ms[6] = 0;
+  b->front_done = true;
+  return SVDSS_OK;
+}
+
+extern "C" int svdss_bam_batch_parked(const svdss_bam_batch_t* b, int64_t* group, int64_t* first, int64_t* n_reads) {
+  if (!b || !b->front_done) return SVDSS_EINVAL;
+  if (group) *group = b->park_group;
+  if (first) *first = b->park_first;
+  if (n_reads) *n_reads = b->n_searched;
+  return SVDSS_OK;
+}
+
+// The search half, for a batch whose front half left the reads in the batch object (not parked): search, counts and SFS down.
+extern "C" int svdss_bam_batch_search(svdss_bam_batch_t* b, const svdss_index_t* ix) {
+  if (!b || !ix || !b->front_done || b->park_group >= 0) return SVDSS_EINVAL;
+  if (ix->device != b->device || !ix->d_blocks) return SVDSS_ENODEV;
+  const hipStream_t st = b->st;
+  const int32_t flags = b->cur_flags;
+  const int64_t n_srch = b->n_searched, total_syms = b->cur_syms;
+  auto fail = [&](int code, const std::string& msg) { b->err = msg; (void)hipStreamSynchronize(st); return code; };
+  BCHK(hipSetDevice(b->device));
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](int k) {
+    const auto t = std::chrono::steady_clock::now();
+    b->stage_ms[k] = std::chrono::duration<double, std::milli>(t - t_prev).count();
+    t_prev = t;
+  };
+  b->front_done = false;
+  {
+    const int rc = svdss_sfs_search_batch_device(ix, b->cur_reads, b->cur_off, n_srch, total_syms,
                                                  (flags & SVDSS_SFS_ASSEMBLE), (void*)st, &b->sfs);
     if (rc != SVDSS_OK) return fail(rc, std::string("search: ") + svdss_last_hip_error());
   }
   lap(5);   // search
-  // ---- what the host needs: names and tags of the slots, counts and SFS of the searched reads
   b->total_sfs = svdss_sfs_batch_total(b->sfs);
   try {
-    b->name_off.resize((size_t)n_slots + 1); b->hp.resize((size_t)n_slots); b->sidx.resize((size_t)n_slots);
-    b->names.resize((size_t)name_bytes + 1); b->counts.resize((size_t)n_srch); b->qs.resize((size_t)b->total_sfs); b->len.resize((size_t)b->total_sfs);
+    b->counts.resize((size_t)n_srch); b->qs.resize((size_t)b->total_sfs); b->len.resize((size_t)b->total_sfs);
   } catch (...) { return fail(SVDSS_ENOMEM, "out of memory"); }
-  BCHK(hipMemcpyAsync(b->name_off.data(), S.o_name_off, sizeof(int32_t) * (size_t)(n_slots + 1), hipMemcpyDeviceToHost, st));
-  if (n_slots > 0) {
-    BCHK(hipMemcpyAsync(b->hp.data(), S.o_hp, sizeof(int32_t) * (size_t)n_slots, hipMemcpyDeviceToHost, st));
-    BCHK(hipMemcpyAsync(b->sidx.data(), S.o_sidx, sizeof(int32_t) * (size_t)n_slots, hipMemcpyDeviceToHost, st));
-  }
-  if (name_bytes > 0) BCHK(hipMemcpyAsync(b->names.data(), S.o_names, (size_t)name_bytes, hipMemcpyDeviceToHost, st));
   if (n_srch > 0) {
     void *d_counts = nullptr, *d_qs = nullptr, *d_len = nullptr;
     RCHK(svdss_sfs_batch_device_ptrs(b->sfs, &d_counts, &d_qs, &d_len, nullptr));
@@ -1101,6 +1335,17 @@ extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t i
   BCHK(hipStreamSynchronize(st));
   lap(6);   // results down
   return SVDSS_OK;
+}
+
+extern "C" int svdss_bam_batch_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_index_t* ix,
+                                   int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                                   const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                                   int32_t flags, svdss_bam_batch_t** out) {
+  if (!s || !ix || !out || seq < 0 || skip < 0 || n_chunks < 0) return SVDSS_EINVAL;
+  if (ix->device < 0 || !ix->d_blocks) return SVDSS_ENODEV;   // (the caller's mistake: the stream's turn is not taken)
+  const int rc = svdss_bam_batch_front(s, seq, is_last, skip, ix->device, nullptr, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, flags, out);
+  if (rc != SVDSS_OK) return rc;
+  return svdss_bam_batch_search(*out, ix);
 }
 
 extern "C" int svdss_bam_filter_create(int32_t device, int32_t min_mapq, int32_t n_ref, const char* names, const int64_t* name_off,

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <new>
@@ -307,6 +308,9 @@ extern "C" int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out) {
   return SVDSS_OK;
 }
 
+static std::atomic<int> g_kmer_limit{0};
+extern "C" void svdss_index_kmer_limit(int32_t k) { g_kmer_limit.store(k < 0 ? 0 : k > 16 ? 16 : k); }
+
 static int auto_kmer(int64_t n) {
   // K = floor(log4 n) + 3, at most 16: nearly every K-mer of the text is then unique and
   // nearly every other K-mer absent, so ONE lookup resolves a phase start (unique -> TEXT
@@ -391,6 +395,8 @@ static int build_table(svdss_index* ix) {
     while (kc < 16 && ((size_t)16 << (2 * (kc + 1))) <= ix->d_table_cap) ++kc;
     k = kc;
   }
+  // (a caller that has learnt meanwhile how little there is to search: svdss_index_kmer_limit)
+  if (const int lim = g_kmer_limit.load(); lim > 0 && k > lim && !getenv("SVDSS_KMER")) k = lim;
   const bool ahead = ix->d_table && ix->table_k == 0 && k > 0 && ix->d_table_cap >= ((size_t)16 << (2 * k));
   if (ix->d_table && !ahead) { (void)hipFree(ix->d_table); ix->d_table = nullptr; }
   ix->table_k = 0;

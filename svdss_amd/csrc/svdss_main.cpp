@@ -360,7 +360,24 @@ static void format_batch(const Options& o, SearchBatch& b) {
 // the known carry.  The reads of a region are dealt into units when everything before it has been (the unit a read
 // belongs to depends on the reads in front of it), so the later regions' results wait in memory (~0.6 KB per read).
 struct DevJob { uint64_t seq = 0; bool last = false; std::vector<std::unique_ptr<CompChunk>> chunks; };
-struct DevOut { std::vector<Read> reads; std::vector<int32_t> qs, ln; int64_t n_short = 0; };
+struct DevOut { std::vector<Read> reads; std::vector<int32_t> qs, ln; int64_t n_short = 0; std::vector<int32_t> sidx; };
+struct BamRegion;
+// `SVDSS search` with the BAM front end started BEFORE the index is resident (include/svdss_hip.h, svdss_bam_park_*): while
+// `ix` is null the feeders run the front half of their batches and park the unpacked reads in HBM; when the index is there the
+// parked groups are searched one large launch each, and the feeders go on with whole batches.
+struct EarlySearch {
+  svdss_bam_park_t* park = nullptr;
+  std::mutex m;
+  std::condition_variable cv;
+  svdss_index_t* ix = nullptr;      // set once, with `ready`
+  bool ready = false;
+  struct Pending { BamRegion* R; uint64_t seq; std::unique_ptr<DevOut> out; int64_t first, n; };
+  std::map<int64_t, std::vector<Pending>> by_group;     // under m
+  // what the front end has seen so far (the order of the k-mer table is chosen from it: svdss_index_kmer_limit)
+  std::atomic<int64_t> records{0}, searched{0}, comp_bytes{0}, index_n{0};
+  int64_t file_bytes = 0;
+  int kmer_limit = 0;               // the last limit given (under m)
+};
 struct BamRegion {
   size_t begin = 0, end = 0;                 // file range (member starts)
   std::unique_ptr<BgzfScanner> sc;
@@ -401,7 +418,7 @@ static std::vector<size_t> plan_bam_regions(const std::string& path, int n, int6
 
 static void search_bam_device(const Options& o, const std::vector<svdss_index_t*>& replicas, std::vector<BamRegion>& regions,
                               const BgzfScanner::Hooks& hooks, size_t slab, int loaders, size_t pool_chunks, int32_t n_ref,
-                              const std::function<std::string()>& since) {
+                              const std::function<std::string()>& since, EarlySearch* early = nullptr) {
   const int64_t super = std::max<int64_t>(o.bsize, 32768 / o.bsize * (int64_t)o.bsize);
   const int64_t target = (getenv("SVDSS_BAM_BATCH_MB") && atoll(getenv("SVDSS_BAM_BATCH_MB")) > 0 ? atoll(getenv("SVDSS_BAM_BATCH_MB")) : 192) << 20;
   const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
@@ -421,12 +438,22 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
   size_t cursor = 0;            // the region the assembler is taking batches from (under dev_m)
 
   // what a batch object holds after its run -> reads with their SFS
-  auto collect = [&](svdss_bam_batch_t* batch, double gpu_s, std::chrono::steady_clock::time_point t1) {
+  auto collect = [&](svdss_bam_batch_t* batch, double gpu_s, std::chrono::steady_clock::time_point t1, bool searched = true) {
     svdss_bam_result_t r;
     check(svdss_bam_batch_result(batch, &r), "svdss_bam_batch_result");
     std::unique_ptr<DevOut> out(new DevOut);
     out->n_short = r.n_short;
     out->reads.resize((size_t)r.n_slots);
+    if (!searched) {
+      // the front half only: names and tags; counts and SFS follow when the batch's group has been searched (fill_parked)
+      out->sidx.assign(r.sidx, r.sidx + r.n_slots);
+      for (int64_t i = 0; i < r.n_slots; ++i) {
+        Read& rd = out->reads[(size_t)i];
+        rd.name.assign(r.names + r.name_off[i], (size_t)(r.name_off[i + 1] - r.name_off[i]));
+        rd.hp = r.hp[i];
+        rd.count = r.sidx[i] < 0 ? -1 : 0; rd.first = 0;
+      }
+    } else {
     out->qs.assign(r.qs, r.qs + r.total_sfs);
     out->ln.assign(r.len, r.len + r.total_sfs);
     {
@@ -439,6 +466,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
         if (r.sidx[i] < 0) { rd.count = -1; rd.first = acc; }
         else { rd.first = acc; rd.count = r.counts[r.sidx[i]]; acc += rd.count; }
       }
+    }
     }
     std::lock_guard<std::mutex> lk(t_m);
     t_gpu += gpu_s; t_build += secs(t1, now()); t_inflate_ms += r.inflate_kernel_ms;
@@ -500,9 +528,55 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
         comp.push_back(c->data); comp_bytes.push_back((int64_t)c->n_bytes); n_blocks.push_back((int64_t)c->blocks.size());
         blocks.push_back(c->blocks.data()); crcs.push_back(c->crc.data());
       }
-      const int rc = svdss_bam_batch_run(R.stream, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? R.skip : 0, ix, (int32_t)comp.size(),
+      // (early: while the index is being restored the front half of the batch runs and its reads are parked)
+      bool front_only = false;
+      if (early) {
+        std::lock_guard<std::mutex> lk(early->m);
+        if (early->ready) ix = early->ix; else front_only = true;
+      }
+      int64_t job_comp = 0;
+      for (const std::unique_ptr<CompChunk>& c : job->chunks) job_comp += (int64_t)c->n_bytes;
+      int rc = front_only
+                   ? svdss_bam_batch_front(R.stream, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? R.skip : 0, 0, early->park, (int32_t)comp.size(),
+                                           comp.data(), comp_bytes.data(), blocks.data(), crcs.data(), n_blocks.data(), flags, &batch)
+                   : svdss_bam_batch_run(R.stream, (int64_t)job->seq, job->last ? 1 : 0, job->seq == 0 ? R.skip : 0, ix, (int32_t)comp.size(),
                                          comp.data(), comp_bytes.data(), blocks.data(), crcs.data(), n_blocks.data(), flags, &batch);
       for (std::unique_ptr<CompChunk>& c : job->chunks) R.sc->recycle(std::move(c));
+      if (rc == SVDSS_OK && front_only) {
+        int64_t grp = -1, first = 0, n_srch = 0;
+        check(svdss_bam_batch_parked(batch, &grp, &first, &n_srch), "svdss_bam_batch_parked");
+        {
+          // how much there will be to search, from what has been seen: the order of the k-mer table (its build begins when the
+          // suffix array is sorted; the limit is read then)
+          svdss_bam_result_t r0;
+          check(svdss_bam_batch_result(batch, &r0), "svdss_bam_batch_result");
+          const int64_t recs = (early->records += r0.n_records), srch = (early->searched += r0.n_searched), cb = (early->comp_bytes += job_comp);
+          const int64_t n_ix = early->index_n.load();
+          if (n_ix >= ((int64_t)1 << 31) && recs >= 50000 && cb > 0 && !getenv("SVDSS_KMER") && !getenv("SVDSS_NO_KMER_LIMIT")) {
+            const double est = (double)srch / (double)recs * ((double)recs * (double)early->file_bytes / (double)cb);
+            // build: 1.6 s at K = 16, a quarter of that per step down; kernel: 16 M reads/s at K = 16, half of that per step down
+            // (profiles/r05i_restore_by_table_order.txt); its seconds count double, as in main_search
+            auto cost = [&](int k) { return 1.6 * std::pow(4.0, k - 16) + 2 * est / 16e6 * std::pow(2.2, 16 - k); };
+            int best = 16;
+            for (int k = 15; k >= 12; --k) if (cost(k) < cost(best)) best = k;
+            if (cost(best) > 0.8 * cost(16)) best = 16;     // (a clear gain or none)
+            std::lock_guard<std::mutex> lk(early->m);
+            if (best != early->kmer_limit) { early->kmer_limit = best; svdss_index_kmer_limit(best == 16 ? 0 : best); }
+          }
+        }
+        if (grp >= 0) {
+          const auto t1 = now();
+          std::unique_ptr<DevOut> out = collect(batch, secs(t0, t1), t1, false);
+          { std::lock_guard<std::mutex> lk(early->m); early->by_group[grp].push_back(EarlySearch::Pending{&R, job->seq, std::move(out), first, n_srch}); }
+          early->cv.notify_all();
+          continue;
+        }
+        if (grp == -1) {
+          // no room in the park (or it has just been closed): this batch waits here for the index
+          { std::unique_lock<std::mutex> lk(early->m); early->cv.wait(lk, [&] { return early->ready; }); ix = early->ix; }
+          rc = svdss_bam_batch_search(batch, ix);
+        }   // (grp == -2: nothing to search in this batch, its results are complete)
+      }
       if (rc != SVDSS_OK) {
         std::string msg = batch ? svdss_bam_batch_error(batch) : "";
         if (msg.empty()) msg = svdss_bam_stream_error(R.stream);
@@ -738,9 +812,65 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     std::vector<std::thread> fmt;
     for (int k = 0; k < n_fmt; ++k) fmt.emplace_back(formatter);
     for (size_t g = 0; g < regions.size(); ++g) launch(regions[g], g, nullptr, 0);
+    // early: once the index is resident, the parked groups -- ONE launch each, one lane per read -- and their batches' results
+    std::thread drain;
+    if (early) drain = std::thread([&] {
+      svdss_index_t* ix = nullptr;
+      { std::unique_lock<std::mutex> lk(early->m); early->cv.wait(lk, [&] { return early->ready; }); ix = early->ix; }
+      check(svdss_bam_park_close(early->park), "svdss_bam_park_close");
+      const int64_t n_groups = svdss_bam_park_groups(early->park);
+      svdss_sfs_batch_t* sfs = nullptr;
+      std::vector<int64_t> counts, prefix;
+      std::vector<int32_t> qs, ln;
+      int64_t n_parked = 0, n_parked_batches = 0;
+      double t_search = 0;
+      for (int64_t g = 0; g < n_groups; ++g) {
+        int64_t nb = 0, nr = 0, ns = 0;
+        check(svdss_bam_park_group(early->park, g, &nb, &nr, &ns), "svdss_bam_park_group");
+        const auto t0 = now();
+        check(svdss_bam_park_search(early->park, g, ix, flags, &sfs), "svdss_bam_park_search");
+        const int64_t total = svdss_sfs_batch_total(sfs);
+        counts.resize((size_t)nr); qs.resize((size_t)total); ln.resize((size_t)total);
+        check(svdss_sfs_batch_fetch(sfs, counts.data(), qs.data(), ln.data(), nullptr), "svdss_sfs_batch_fetch");
+        t_search += secs(t0, now());
+        prefix.assign((size_t)nr + 1, 0);
+        for (int64_t i = 0; i < nr; ++i) prefix[(size_t)i + 1] = prefix[(size_t)i] + counts[(size_t)i];
+        std::vector<EarlySearch::Pending> pend;
+        {
+          std::unique_lock<std::mutex> lk(early->m);
+          early->cv.wait(lk, [&] { return (int64_t)early->by_group[g].size() == nb; });
+          pend.swap(early->by_group[g]);
+        }
+        for (EarlySearch::Pending& P : pend) {
+          DevOut& d = *P.out;
+          int64_t acc = 0;
+          for (size_t i = 0; i < d.reads.size(); ++i) {
+            Read& rd = d.reads[i];
+            rd.first = acc;
+            if (d.sidx[i] < 0) { rd.count = -1; continue; }
+            const size_t k = (size_t)(P.first + d.sidx[i]);
+            rd.count = counts[k];
+            d.qs.insert(d.qs.end(), qs.begin() + prefix[k], qs.begin() + prefix[k + 1]);
+            d.ln.insert(d.ln.end(), ln.begin() + prefix[k], ln.begin() + prefix[k + 1]);
+            acc += rd.count;
+          }
+          d.sidx.clear();
+          { std::lock_guard<std::mutex> lk(dev_m); P.R->done[P.seq] = std::move(P.out); P.R->head_known = true; }
+          dev_cv.notify_all();
+        }
+        n_parked += nr; n_parked_batches += nb;
+      }
+      if (sfs) svdss_sfs_batch_free(sfs);
+      { std::lock_guard<std::mutex> lk(t_m); t_stage[5] += t_search; }
+      if (o.verbose)
+        logmsg("debug", "front end beside the index restore: " + std::to_string(n_parked_batches) + " batches (" + std::to_string(early->records.load()) +
+                            " records) had been read when the index was resident; their " + std::to_string(n_parked) + " reads searched in " +
+                            std::to_string(n_groups) + " launch(es), " + std::to_string(t_search) + " s, done at +" + since() + " s");
+    });
     std::vector<std::thread> joiners;
     for (BamRegion& R : regions) joiners.emplace_back([&join_region, &R] { join_region(R); });
     for (std::thread& th : joiners) th.join();
+    if (drain.joinable()) drain.join();
     assembler.join();
     for (std::thread& th : fmt) th.join();
     { std::lock_guard<std::mutex> lk(done_m); format_finished = true; }
@@ -827,7 +957,29 @@ int main_search(const Options& o) {
     svdss_enable_gpu_inflate(*bam, 0, std::min(std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_dev0)), n_dev0));
     if (bam->ok() && !getenv("SVDSS_NO_PREWARM")) bam_prewarm = std::thread([bam] { bam->prewarm(); });
   }
+  // One GPU, one region: the BAM front end starts NOW, beside the index restore (EarlySearch; SVDSS_SEARCH_EARLY=0: the index
+  // first, as PingPong::run does, ping_pong.cpp:245,329).  The park's first arena is allocated before the restore begins.
+  std::unique_ptr<EarlySearch> early;
+  std::thread early_stream;
+  if (dev_bam && bam_regions.size() == 1 && std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, std::max(1, svdss_device_count()))) == 1 &&
+      !(getenv("SVDSS_SEARCH_EARLY") && atoi(getenv("SVDSS_SEARCH_EARLY")) == 0)) {
+    if (o.bsize <= 0) die("batch size smaller than the number of threads");
+    early.reset(new EarlySearch);
+    struct stat stb;
+    early->file_bytes = stat(o.bam.c_str(), &stb) == 0 ? (int64_t)stb.st_size : 0;
+    // (SVDSS_PARK_GB: what may be parked at most, in arenas allocated as they are needed; SVDSS_PARK_MB: the same in MB, for tests)
+    const int64_t park_b = getenv("SVDSS_PARK_MB") && atoll(getenv("SVDSS_PARK_MB")) > 0 ? atoll(getenv("SVDSS_PARK_MB")) << 20
+                           : (getenv("SVDSS_PARK_GB") && atoll(getenv("SVDSS_PARK_GB")) > 0 ? atoll(getenv("SVDSS_PARK_GB")) : 32) << 30;
+    check(svdss_bam_park_create(0, park_b, park_b / 512 + 4096, &early->park), "svdss_bam_park_create");
+    if (bam_prewarm.joinable()) bam_prewarm.join();
+    bam_regions[0].gpus = {nullptr};
+    early_stream = std::thread([&] {
+      const std::vector<svdss_index_t*> none(1, nullptr);
+      search_bam_device(o, none, bam_regions, bam_hooks, bam_slab, bam_loaders, bam_pool_chunks, bam_n_ref, since, early.get());
+    });
+  }
   check(svdss_index_load(o.index.c_str(), &ix), "svdss_index_load");
+  if (early) early->index_n.store(svdss_index_size(ix));
   if (o.verbose) logmsg("debug", "index file read at +" + since() + " s");
   if (!getenv("SVDSS_KMER")) {
     // The order K of the k-mer table trades its build time (4^K entries: 1.6 s at K = 16, a quarter of that per step
@@ -858,7 +1010,27 @@ int main_search(const Options& o) {
     }
   }
   check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
-  if (o.verbose) logmsg("debug", "index and k-mer table on the device at +" + since() + " s");
+  if (o.verbose) logmsg("debug", "index and k-mer table on the device at +" + since() + " s" +
+                                     (early && svdss_index_kmer(ix) < 16 ? " (table of order " + std::to_string(svdss_index_kmer(ix)) + ": few reads to search)" : ""));
+  if (early) {
+    logmsg("info", "Extracting SFS strings on the GPU (output order as with " + std::to_string(o.threads) + " threads)..");
+    // (SVDSS_EARLY_HOLD_MS, for the tests: the index is held back that long, as if its restore had taken seconds)
+    if (const char* e = getenv("SVDSS_EARLY_HOLD_MS")) if (atoi(e) > 0) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e)));
+    { std::lock_guard<std::mutex> lk(early->m); early->ix = ix; early->ready = true; }
+    early->cv.notify_all();
+    early_stream.join();
+    if (!getenv("SVDSS_CLEAN_EXIT")) {
+      logmsg("info", "All done! Runtime: " + std::to_string((long)(time(nullptr) - g_t0)) + " seconds");
+      fflush(stdout);
+      fflush(stderr);
+      _exit(0);
+    }
+    svdss_bam_park_free(early->park);
+    bam_regions.clear();
+    svdss_index_free(ix);
+    logmsg("info", "All done! Runtime: " + std::to_string((long)(time(nullptr) - g_t0)) + " seconds");
+    return 0;
+  }
   // --gpus N: one replica of the index per GPU; the batches of reads go to whichever GPU is free, the
   // text is written in input order whatever GPU searched a batch -- the same bytes as with one GPU
   // (SVDSS_GPUS_OVERSUBSCRIBE: more replicas than GPUs, replica d on GPU d % count -- exercises the path on a one-GPU box)

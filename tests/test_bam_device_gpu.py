@@ -223,6 +223,7 @@ def test_binary_device_path_writes_the_host_paths_bytes(case, tmp_path):
     host) -- the same stdout byte for byte, with slabs / batches so small that the file is dozens of batches, with
     several feeding threads per GPU and two (oversubscribed) GPUs, for two --threads / --bsize settings (the text order
     depends on them, ping_pong.cpp:213-236: device batches never end where reference batches do)."""
+    import re
     import subprocess
     from tests.common import BIN
     ref, ix, fm, reads, names = case
@@ -253,6 +254,25 @@ def test_binary_device_path_writes_the_host_paths_bytes(case, tmp_path):
         assert dev2.stdout == host.stdout
         big = run({}, *extra)          # the default sizes: one batch
         assert big.stdout == host.stdout
+        # round 6: the front end runs beside the index restore (one GPU: the default) -- the batches read before the index
+        # is resident park their unpacked reads in HBM and are searched one large launch per group.  The index of this
+        # test is resident in milliseconds, so it is held back (SVDSS_EARLY_HOLD_MS): dozens of batches get parked, in
+        # groups of a few hundred reads, in arenas of 1 MB (several), with a park too small for all of them (the rest
+        # waits for the index), and against the index-first order (SVDSS_SEARCH_EARLY=0)
+        first = run({"SVDSS_SEARCH_EARLY": "0", "SVDSS_BAM_SLAB_KB": "64", "SVDSS_BAM_BATCH_MB": "1"}, *extra)
+        assert first.stdout == host.stdout and "front end beside the index restore" not in first.stderr
+        for env in ({"SVDSS_PARK_GROUP_READS": "300", "SVDSS_PARK_ARENA_MB": "1"},
+                    {"SVDSS_PARK_GROUP_READS": "100000"},
+                    {"SVDSS_PARK_MB": "2", "SVDSS_PARK_ARENA_MB": "1", "SVDSS_PARK_GROUP_READS": "200"},
+                    {"SVDSS_PARK_GROUP_READS": "7", "SVDSS_SEARCH_FEEDERS": "2"}):
+            ev = dict(env, SVDSS_EARLY_HOLD_MS="1500", SVDSS_BAM_SLAB_KB="64", SVDSS_BAM_BATCH_MB="1")
+            early = run(ev, *extra)
+            m = re.search(r"front end beside the index restore: (\d+) batches \((\d+) records\) .* their (\d+) reads searched in (\d+) launch", early.stderr)
+            assert m and int(m.group(1)) >= 3 and int(m.group(4)) >= 1, early.stderr[-1500:]
+            if "SVDSS_PARK_MB" in env:
+                assert int(m.group(3)) < 3000          # (the park was full: not every read fitted)
+            assert early.stdout == host.stdout, env
+            assert early.stderr.count("Alignment filtered due to l_qseq") == 8
         # round 5: --gpus N cuts the file into N regions, each with its own scanner / batcher / feeders; a region's first
         # record is guessed and proved at the seam.  SVDSS_REGION_TEST: 1 = every guess is no record (the regions fail
         # and run again from the region before), 2 = the seams do not fit (the regions run again)
