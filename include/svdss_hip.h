@@ -354,8 +354,27 @@ typedef struct svdss_bam_selection {
   const uint8_t* bytes;
   double inflate_kernel_ms;
   double stage_ms[8];
+  int32_t slim;             /* 1: the records are slim ones (svdss_bam_store_select) */
 } svdss_bam_selection_t;
 int svdss_bam_batch_selection(const svdss_bam_batch_t* b, svdss_bam_selection_t* out);
+/* ONE pass over the file for `SVDSS call`.  Clusterer::run reads the BAM twice: align_and_extend places the SFS of the reads
+ * that have any (clusterer.cpp:56-156), fill_clusters fetches, per cluster, the alignments that overlap it (sam_itr_querys,
+ * :477-610).  What the second pass looks at of a record is its core, name, CIGAR, bases and HP tag; a svdss_bam_store_t keeps
+ * exactly that ("slim" record: block_size | core | name | CIGAR | packed bases | HP as one int32 tag when the record had an
+ * integer one -- no qualities, no other tags; ~1/3 of the record) of EVERY record that passes the flag / mapq filters, in
+ * HBM, while the first pass runs (svdss_bam_select_store_run = svdss_bam_select_run + the store); the second pass is then a
+ * kernel over resident records (svdss_bam_store_select, per stored batch: the slim records that overlap a region of the
+ * filter come down, in file order).  A store that would exceed max_bytes stays incomplete (svdss_bam_store_batches):
+ * the caller reads the file again, through its index or the device path, as before. */
+typedef struct svdss_bam_store svdss_bam_store_t;
+int svdss_bam_store_create(int32_t device, int64_t max_bytes, svdss_bam_store_t** out);
+void svdss_bam_store_free(svdss_bam_store_t* t);
+int64_t svdss_bam_store_batches(svdss_bam_store_t* t, int32_t* complete, int64_t* n_records, int64_t* n_bytes);
+int svdss_bam_select_store_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_filter_t* f,
+                               svdss_bam_store_t* store, int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                               const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                               svdss_bam_batch_t** out);
+int svdss_bam_store_select(svdss_bam_store_t* t, int64_t seq, const svdss_bam_filter_t* f, svdss_bam_batch_t** out);
 /* `SVDSS smooth` on the same front end (csrc/bam_smooth.inc): BGZF blocks in, BGZF blocks out; the inflated records never
  * leave the device.  Stands where smoother.cpp:349-571 stand (loader :498-571 with the filters of :509-537, smooth_read
  * :84-232, rebuild_bam_entry :50-82, the writer :441-494).  A svdss_bam_smooth_t names the reference (svdss_ref_upload:

@@ -122,7 +122,8 @@ def search_bam(index, data, assemble=True, putative=False, batch_bytes=256 << 20
 
 class BamSelection(C.Structure):
     _fields_ = [("n_records", C.c_int64), ("n_selected", C.c_int64), ("n_bytes", C.c_int64), ("rec_off", C.POINTER(C.c_int64)),
-                ("bytes", C.POINTER(C.c_uint8)), ("inflate_kernel_ms", C.c_double), ("stage_ms", C.c_double * 8)]
+                ("bytes", C.POINTER(C.c_uint8)), ("inflate_kernel_ms", C.c_double), ("stage_ms", C.c_double * 8),
+                ("slim", C.c_int32)]
 
 
 def select_bam(data, names=None, regions=None, min_mapq=0, batch_bytes=256 << 20, device=0):
@@ -188,3 +189,91 @@ def select_bam(data, names=None, regions=None, min_mapq=0, batch_bytes=256 << 20
         lib.svdss_bam_stream_free(stream)
         lib.svdss_bam_filter_free(flt)
     return out, stats
+
+
+def select_bam_store(data, names, regions, min_mapq=0, batch_bytes=256 << 20, device=0, max_store_bytes=1 << 34):
+    """`SVDSS call`'s ONE pass: svdss_bam_select_store_run over a whole BAM file with `names` as the filter (the first pass'
+    records come back whole) and every record that passes the flag / mapq filters kept, slim, in a svdss_bam_store_t; then
+    svdss_bam_store_select of every stored batch with `regions` [(tid, beg, end)] sorted by (tid, beg).
+    Returns (named records, slim records that overlap a region -- both without the block_size field --, counters)."""
+    blocks = bgzf.bgzf_blocks(data)
+    n_ref, skip = bam_header(data, blocks)
+    comp = np.frombuffer(bytes(data), dtype=np.uint8)
+    nm = b"".join(n.encode() if isinstance(n, str) else n for n in names)
+    nm_off = np.zeros(len(names) + 1, dtype=np.int64)
+    nm_off[1:] = np.cumsum([len(n) for n in names])
+    rt = np.array([r[0] for r in regions], dtype=np.int32)
+    rb = np.array([r[1] for r in regions], dtype=np.int32)
+    re_ = np.array([r[2] for r in regions], dtype=np.int32)
+    f_names, f_regions, store = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    rc = lib.svdss_bam_filter_create(device, min_mapq, n_ref, nm, nm_off.ctypes.data, len(names), None, None, None, 0, C.byref(f_names))
+    if rc:
+        raise SvdssError(rc, "svdss_bam_filter_create")
+    rc = lib.svdss_bam_filter_create(device, min_mapq, n_ref, None, None, 0, rt.ctypes.data if regions else None, rb.ctypes.data if regions else None,
+                                     re_.ctypes.data if regions else None, len(regions), C.byref(f_regions))
+    if rc:
+        raise SvdssError(rc, "svdss_bam_filter_create")
+    rc = lib.svdss_bam_store_create(device, max_store_bytes, C.byref(store))
+    if rc:
+        raise SvdssError(rc, "svdss_bam_store_create")
+    stream = C.c_void_p()
+    lib.svdss_bam_stream_create(n_ref, C.byref(stream))
+    batch = C.c_void_p()
+    named, slim, stats = [], [], {"records": 0, "batches": 0}
+
+    def take(r, into):
+        if r.n_selected:
+            off = np.ctypeslib.as_array(r.rec_off, shape=(r.n_selected + 1,))
+            raw = C.string_at(r.bytes, r.n_bytes)
+            for k in range(r.n_selected):
+                o = int(off[k])
+                bs = struct.unpack_from("<i", raw, o)[0]
+                into.append(raw[o + 4:o + 4 + bs])
+    try:
+        groups, cur, acc = [], [], 0
+        for b in blocks:
+            cur.append(b)
+            acc += b[2]
+            if acc >= batch_bytes:
+                groups.append(cur)
+                cur, acc = [], 0
+        groups.append(cur)
+        for seq, g in enumerate(groups):
+            rec = np.zeros(max(1, len(g)), dtype=[("coff", "<i8"), ("clen", "<i4"), ("isize", "<i4"), ("uoff", "<i8")])
+            crc = np.zeros(max(1, len(g)), dtype=np.uint32)
+            for i, b in enumerate(g):
+                rec[i] = (b[0], b[1], b[2], 0)
+                crc[i] = b[3]
+            rc = lib.svdss_bam_select_store_run(stream, seq, 1 if seq == len(groups) - 1 else 0, skip if seq == 0 else 0, f_names, store, 1,
+                                                (C.c_void_p * 1)(comp.ctypes.data), (C.c_int64 * 1)(len(comp)), (C.c_void_p * 1)(rec.ctypes.data),
+                                                (C.c_void_p * 1)(crc.ctypes.data), (C.c_int64 * 1)(len(g)), C.byref(batch))
+            if rc:
+                e = SvdssError(rc, "svdss_bam_select_store_run")
+                e.detail = (lib.svdss_bam_batch_error(batch) or b"").decode() if batch else ""
+                raise e
+            r = BamSelection()
+            lib.svdss_bam_batch_selection(batch, C.byref(r))
+            assert r.slim == 0
+            stats["records"] += r.n_records
+            stats["batches"] += 1
+            take(r, named)
+        complete, n_rec, n_bytes = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        n_b = lib.svdss_bam_store_batches(store, C.byref(complete), C.byref(n_rec), C.byref(n_bytes))
+        stats.update({"stored_batches": n_b, "complete": complete.value, "stored_records": n_rec.value, "stored_bytes": n_bytes.value})
+        if complete.value:
+            for seq in range(n_b):
+                rc = lib.svdss_bam_store_select(store, seq, f_regions, C.byref(batch))
+                if rc:
+                    raise SvdssError(rc, "svdss_bam_store_select")
+                r = BamSelection()
+                lib.svdss_bam_batch_selection(batch, C.byref(r))
+                assert r.slim == 1
+                take(r, slim)
+    finally:
+        if batch:
+            lib.svdss_bam_batch_free(batch)
+        lib.svdss_bam_stream_free(stream)
+        lib.svdss_bam_filter_free(f_names)
+        lib.svdss_bam_filter_free(f_regions)
+        lib.svdss_bam_store_free(store)
+    return named, slim, stats

@@ -38,6 +38,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -512,7 +513,11 @@ struct SelP {
   uint32_t* rpos;
   int64_t *f_sel, *f_bytes;       // n_rec + 1 each
   int64_t* hdr;
+  // the record store of `SVDSS call` (svdss_bam_store_t): every record that passes the flag / mapq filters, named or not, in
+  // its slim form -- f_keep / f_kbytes (n_rec + 1 each; nullptr: no store), hpv: its HP tag (kNoHp: none)
+  int64_t *f_keep, *f_kbytes, *hpv;
 };
+constexpr int64_t kNoHp = (int64_t)1 << 40;
 
 // block s < n_seg: the records of segment s; block n_seg: those that begin in the carried bytes.  A record is kept if it
 // passes the flag / mapq filters of clusterer.cpp:118-122 (= :535-540) and, when names and / or regions are given, is
@@ -532,9 +537,17 @@ __global__ void __launch_bounds__(64) select_kernel(SelP M) {
     const uint32_t l_name = w3 & 0xffu, mapq = (w3 >> 8) & 0xffu, n_cig = w4 & 0xffffu, flag = w4 >> 16;
     const int64_t head = 32 + (int64_t)l_name + 4 * (int64_t)n_cig + ((int64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (l_seq < 0 ? 0 : l_seq);
     bool keep = false;
+    if (M.f_keep) { M.f_keep[gi] = 0; M.f_kbytes[gi] = 0; }
     if (l_seq < 0 || head > (int64_t)bs) atomicOr((unsigned long long*)&M.hdr[H_ERR], (unsigned long long)E_CORRUPT);
     else {
       keep = !(flag & (4u | 2048u | 256u)) && (int32_t)mapq >= M.min_mapq;
+      if (keep && M.f_keep) {
+        int64_t hp = 0;
+        const bool have = aux_int(M.buf + p + 4 + head, M.buf + p + 4 + bs, 'H', 'P', hp);
+        M.hpv[gi] = have ? hp : kNoHp;
+        M.f_keep[gi] = 1;
+        M.f_kbytes[gi] = (4 + head - l_seq + (have ? 7 : 0) + 3) & ~(int64_t)3;    // block_size + core .. bases + "HPi" + value
+      }
       if (keep && (M.hash || M.reg_off)) {
         bool hit = false;
         if (M.hash) {
@@ -569,7 +582,96 @@ __global__ void __launch_bounds__(64) select_kernel(SelP M) {
     M.f_sel[gi] = keep ? 1 : 0;
     M.f_bytes[gi] = keep ? (((int64_t)bs + 4 + 3) & ~(int64_t)3) : 0;
   }
-  if (s == 0 && threadIdx.x == 0) { M.f_sel[M.n_rec] = 0; M.f_bytes[M.n_rec] = 0; }
+  if (s == 0 && threadIdx.x == 0) { M.f_sel[M.n_rec] = 0; M.f_bytes[M.n_rec] = 0; if (M.f_keep) { M.f_keep[M.n_rec] = 0; M.f_kbytes[M.n_rec] = 0; } }
+}
+
+// one wavefront per stored record: block_size' | core | name | CIGAR | packed bases | HP as an int32 tag if the record had
+// an integer one -- no qualities, no other tags (`call` reads neither: clusterer.cpp:56-156, 477-610)
+__global__ void __launch_bounds__(64) slim_export_kernel(const uint8_t* __restrict__ buf, int64_t n_rec, const uint32_t* __restrict__ rpos,
+                                                         const int64_t* __restrict__ f_keep, const int64_t* __restrict__ s_keep,
+                                                         const int64_t* __restrict__ s_bytes, const int64_t* __restrict__ hpv,
+                                                         uint8_t* out, int64_t* out_off, int64_t* totals) {
+  const int64_t gi = blockIdx.x;
+  if (gi == n_rec) {
+    if (threadIdx.x == 0) { out_off[s_keep[gi]] = s_bytes[gi]; totals[2] = s_keep[gi]; totals[3] = s_bytes[gi]; }
+    return;
+  }
+  if (!f_keep[gi]) return;
+  const int64_t p = rpos[gi], o = s_bytes[gi];
+  const uint32_t w3 = ld32(buf, p + 12), w4 = ld32(buf, p + 16);
+  const int32_t l_seq = (int32_t)ld32(buf, p + 20);
+  const uint32_t l_name = w3 & 0xffu, n_cig = w4 & 0xffffu;
+  const uint32_t n1 = 36u + l_name + 4u * n_cig + ((uint32_t)l_seq + 1u) / 2u;       // bytes taken over (block_size field included)
+  const int64_t hp = hpv[gi];
+  const uint32_t total = n1 + (hp != kNoHp ? 7u : 0u);
+  if (threadIdx.x == 0) out_off[s_keep[gi]] = o;
+  uint32_t* dst = (uint32_t*)(out + o);
+  for (uint32_t k = threadIdx.x; k < n1 / 4; k += 64) {
+    uint32_t w = ld32(buf, p + 4 * (int64_t)k);
+    if (k == 0) w = total - 4u;                       // the slim record's block_size
+    dst[k] = w;
+  }
+  if (threadIdx.x == 0) {
+    uint8_t* q = out + o;
+    for (uint32_t k = n1 & ~3u; k < n1; ++k) q[k] = buf[p + k];
+    if (hp != kNoHp) {
+      const bool neg_ok = hp >= -2147483648ll && hp <= 2147483647ll;
+      q[n1] = 'H'; q[n1 + 1] = 'P'; q[n1 + 2] = neg_ok ? 'i' : 'I';
+      const uint32_t v = (uint32_t)hp;
+      q[n1 + 3] = (uint8_t)v; q[n1 + 4] = (uint8_t)(v >> 8); q[n1 + 5] = (uint8_t)(v >> 16); q[n1 + 6] = (uint8_t)(v >> 24);
+    }
+  }
+}
+
+// the second pass of `SVDSS call` over a stored batch: one lane per slim record, kept if its alignment overlaps a region
+struct StoreSelP {
+  const uint8_t* recs; const int64_t* off; int64_t n;
+  int32_t n_ref;
+  const int64_t* reg_off; const int32_t* reg_beg; const int32_t* reg_runmax;
+  int64_t *f_sel, *f_bytes;
+};
+__global__ void __launch_bounds__(256) store_select_kernel(StoreSelP M) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > M.n) return;
+  if (k == M.n) { M.f_sel[k] = 0; M.f_bytes[k] = 0; return; }
+  const int64_t p = M.off[k];
+  const int32_t tid = (int32_t)ld32(M.recs, p + 4), pos = (int32_t)ld32(M.recs, p + 8);
+  const uint32_t w3 = ld32(M.recs, p + 12), w4 = ld32(M.recs, p + 16);
+  const uint32_t l_name = w3 & 0xffu, n_cig = w4 & 0xffffu;
+  bool hit = false;
+  if (M.reg_off && tid >= 0 && tid < M.n_ref) {
+    const int64_t lo = M.reg_off[tid], hi = M.reg_off[tid + 1];
+    if (hi > lo) {
+      int64_t ref_len = 0;
+      const int64_t cg = p + 36 + l_name;
+      for (uint32_t i = 0; i < n_cig; ++i) {
+        const uint32_t c = ld32(M.recs, cg + 4 * (int64_t)i), op = c & 15u;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+      }
+      const int64_t a_beg = pos, a_end = (int64_t)pos + (ref_len ? ref_len : 1);      // bam_endpos
+      int64_t a = lo, b = hi;
+      while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)M.reg_runmax[m] > a_beg) b = m; else a = m + 1; }
+      hit = a < hi && (int64_t)M.reg_beg[a] < a_end;
+    }
+  }
+  M.f_sel[k] = hit ? 1 : 0;
+  M.f_bytes[k] = hit ? M.off[k + 1] - p : 0;
+}
+__global__ void __launch_bounds__(64) store_export_kernel(const uint8_t* __restrict__ recs, const int64_t* __restrict__ off, int64_t n,
+                                                          const int64_t* __restrict__ f_sel, const int64_t* __restrict__ s_sel,
+                                                          const int64_t* __restrict__ s_bytes, uint8_t* out, int64_t* out_off, int64_t* totals) {
+  const int64_t k = blockIdx.x;
+  if (k == n) {
+    if (threadIdx.x == 0) { out_off[s_sel[k]] = s_bytes[k]; totals[0] = s_sel[k]; totals[1] = s_bytes[k]; }
+    return;
+  }
+  if (!f_sel[k]) return;
+  const int64_t p = off[k], o = s_bytes[k];
+  const uint32_t n4 = (uint32_t)((off[k + 1] - p) / 4);
+  if (threadIdx.x == 0) out_off[s_sel[k]] = o;
+  const uint32_t* src = (const uint32_t*)(recs + p);
+  uint32_t* dst = (uint32_t*)(out + o);
+  for (uint32_t i = threadIdx.x; i < n4; i += 64) dst[i] = src[i];
 }
 
 // one wavefront per kept record: its bytes (block_size field included) to a 4-aligned place of the output
@@ -618,6 +720,20 @@ struct svdss_bam_stream {
   // BAM header of the output)
   int64_t next_out = 0;
   std::vector<uint8_t> out_tail;
+};
+
+// What `SVDSS call` keeps of its first pass over the BAM for the second one (svdss_bam_store_t): the slim records of every
+// batch, in HBM, batch by batch in arenas allocated as they are needed.
+struct StoreBatch { int arena = -1; int64_t at = 0, bytes = 0, n = 0, off_at = 0; };
+struct StoreArena { uint8_t* p = nullptr; int64_t cap = 0, used = 0; };
+struct svdss_bam_store {
+  int device = -1;
+  int64_t max_bytes = 0, arena_bytes = (int64_t)2 << 30, allocated = 0;
+  std::mutex m;
+  std::vector<StoreArena> arenas;
+  std::map<int64_t, StoreBatch> batches;
+  bool complete = true;          // false: a batch did not fit (the caller reads the file again)
+  int64_t n_records = 0, n_bytes = 0;
 };
 
 struct svdss_bam_filter {
@@ -677,6 +793,7 @@ struct svdss_bam_batch {
   size_t h_sel_cap = 0;
   std::vector<int64_t> h_sel_off;
   int64_t n_selected = 0, sel_bytes = 0;
+  bool sel_slim = false;           // the kept records are slim ones (svdss_bam_store_select)
   std::vector<int32_t> h_status;
   // svdss_bam_smooth_run / _measure (bam_smooth.inc)
   DevBuf sm_rec, sm_out, sm_scratch, sm_members, sm_dense, sm_len;
@@ -1410,11 +1527,66 @@ extern "C" void svdss_bam_filter_free(svdss_bam_filter_t* f) {
   delete f;
 }
 
+extern "C" int svdss_bam_store_create(int32_t device, int64_t max_bytes, svdss_bam_store_t** out) {
+  if (!out || device < 0 || max_bytes < 0) return SVDSS_EINVAL;
+  svdss_bam_store* t = new (std::nothrow) svdss_bam_store();
+  if (!t) return SVDSS_ENOMEM;
+  t->device = device;
+  t->max_bytes = max_bytes;
+  if (const char* e = getenv("SVDSS_STORE_ARENA_MB")) if (atoll(e) > 0) t->arena_bytes = atoll(e) << 20;
+  *out = t;
+  return SVDSS_OK;
+}
+extern "C" void svdss_bam_store_free(svdss_bam_store_t* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  for (StoreArena& A : t->arenas) if (A.p) (void)hipFree(A.p);
+  delete t;
+}
+extern "C" int64_t svdss_bam_store_batches(svdss_bam_store_t* t, int32_t* complete, int64_t* n_records, int64_t* n_bytes) {
+  if (!t) return -1;
+  std::lock_guard<std::mutex> lk(t->m);
+  if (complete) *complete = t->complete ? 1 : 0;
+  if (n_records) *n_records = t->n_records;
+  if (n_bytes) *n_bytes = t->n_bytes;
+  return (int64_t)t->batches.size();
+}
+// room for a batch's slim records (+ their n + 1 offsets); false: the store is over its limit (and stays incomplete)
+static bool store_reserve(svdss_bam_store* t, int64_t seq, int64_t bytes, int64_t n, StoreBatch& B, uint8_t*& base) {
+  const int64_t need = ((bytes + 255) & ~(int64_t)255) + (((n + 1) * 8 + 255) & ~(int64_t)255);
+  std::lock_guard<std::mutex> lk(t->m);
+  if (!t->complete) return false;
+  if (t->arenas.empty() || t->arenas.back().used + need > t->arenas.back().cap) {
+    StoreArena A;
+    A.cap = std::max(t->arena_bytes, need);
+    if (t->allocated + A.cap > t->max_bytes || hipMalloc((void**)&A.p, (size_t)A.cap) != hipSuccess) { (void)hipGetLastError(); t->complete = false; return false; }
+    t->allocated += A.cap;
+    t->arenas.push_back(A);
+  }
+  StoreArena& A = t->arenas.back();
+  B.arena = (int)t->arenas.size() - 1; B.at = A.used; B.bytes = bytes; B.n = n;
+  B.off_at = A.used + ((bytes + 255) & ~(int64_t)255);
+  A.used += need;
+  base = A.p;
+  t->batches[seq] = B;
+  t->n_records += n; t->n_bytes += bytes;
+  return true;
+}
+
 extern "C" int svdss_bam_select_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_filter_t* f,
                                     int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
                                     const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
                                     svdss_bam_batch_t** out) {
+  return svdss_bam_select_store_run(s, seq, is_last, skip, f, nullptr, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, out);
+}
+
+extern "C" int svdss_bam_select_store_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_filter_t* f,
+                                          svdss_bam_store_t* store, int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
+                                          const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                                          svdss_bam_batch_t** out) {
   if (!s || !f || !out || seq < 0 || skip < 0 || n_chunks < 0) return SVDSS_EINVAL;
+  if (store && store->device != f->device) return SVDSS_EINVAL;
+  if (store) { std::lock_guard<std::mutex> lk(store->m); if (!store->complete) store = nullptr; }
   Front F;
   {
     const int rc = batch_front(s, seq, is_last, skip, f->device, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, out, F);
@@ -1432,16 +1604,17 @@ extern "C" int svdss_bam_select_run(svdss_bam_stream_t* s, int64_t seq, int32_t 
   };
   const int64_t n_rec = F.hdr[H_NREC];
   b->n_records = n_rec;
-  b->n_selected = 0; b->sel_bytes = 0;
+  b->n_selected = 0; b->sel_bytes = 0; b->sel_slim = false;
   RCHK(ensure(b->rpos, sizeof(uint32_t) * (size_t)(n_rec + 1)));
-  RCHK(ensure(b->flags, sizeof(int64_t) * 2 * (size_t)(n_rec + 1)));
-  RCHK(ensure(b->scans, sizeof(int64_t) * 2 * (size_t)(n_rec + 1)));
+  RCHK(ensure(b->flags, sizeof(int64_t) * 5 * (size_t)(n_rec + 1)));
+  RCHK(ensure(b->scans, sizeof(int64_t) * 4 * (size_t)(n_rec + 1)));
   SelP M;
   M.buf = W.buf; M.lists = W.lists; M.list_cap = W.list_cap; M.seg_cnt = W.seg_cnt; M.seg_base = F.seg_base; M.pre = (const uint32_t*)b->pre.p;
   M.n_seg = W.n_seg; M.min_mapq = f->min_mapq; M.n_ref = f->n_ref; M.n_rec = n_rec;
   M.hash = f->d_hash; M.hash_mask = f->hash_mask; M.reg_off = f->d_reg_off; M.reg_beg = f->d_reg_beg; M.reg_runmax = f->d_reg_runmax;
   M.rpos = (uint32_t*)b->rpos.p;
   M.f_sel = (int64_t*)b->flags.p; M.f_bytes = M.f_sel + (n_rec + 1);
+  M.f_keep = store ? M.f_bytes + (n_rec + 1) : nullptr; M.f_kbytes = store ? M.f_keep + (n_rec + 1) : nullptr; M.hpv = store ? M.f_kbytes + (n_rec + 1) : nullptr;
   M.hdr = (int64_t*)b->hdr.p;
   hipLaunchKernelGGL(select_kernel, dim3((unsigned)W.n_seg + 1), dim3(64), 0, st, M);
   BCHK(hipGetLastError());
@@ -1450,7 +1623,7 @@ extern "C" int svdss_bam_select_run(svdss_bam_stream_t* s, int64_t seq, int32_t 
     size_t tb = 0;
     BCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, M.f_sel, sc, (int)(n_rec + 1), st));
     RCHK(ensure(b->tmp, tb + 256));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < (store ? 4 : 2); ++k) {
       size_t t2 = b->tmp.cap;
       BCHK(hipcub::DeviceScan::ExclusiveSum(b->tmp.p, t2, M.f_sel + (int64_t)k * (n_rec + 1), sc + (int64_t)k * (n_rec + 1), (int)(n_rec + 1), st));
     }
@@ -1464,9 +1637,24 @@ extern "C" int svdss_bam_select_run(svdss_bam_stream_t* s, int64_t seq, int32_t 
   int64_t totals[2] = {0, 0}, hdr2[H_N] = {0};
   BCHK(hipMemcpyAsync(totals, b->totals.p, sizeof totals, hipMemcpyDeviceToHost, st));
   BCHK(hipMemcpyAsync(hdr2, b->hdr.p, sizeof hdr2, hipMemcpyDeviceToHost, st));
+  int64_t kept[2] = {0, 0};       // the store's share: records, bytes (the last entries of the third and fourth scan)
+  if (store) {
+    BCHK(hipMemcpyAsync(&kept[0], sc + 2 * (n_rec + 1) + n_rec, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    BCHK(hipMemcpyAsync(&kept[1], sc + 3 * (n_rec + 1) + n_rec, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  }
   BCHK(hipStreamSynchronize(st));
   lap(3);
   if (hdr2[H_ERR] & E_CORRUPT) return fail(SVDSS_EIO, "corrupt record");
+  if (store) {
+    StoreBatch B;
+    uint8_t* base = nullptr;
+    if (store_reserve(store, seq, kept[1], kept[0], B, base)) {
+      hipLaunchKernelGGL(slim_export_kernel, dim3((unsigned)(n_rec + 1)), dim3(64), 0, st, W.buf, n_rec, (const uint32_t*)M.rpos, (const int64_t*)M.f_keep,
+                         (const int64_t*)(sc + 2 * (n_rec + 1)), (const int64_t*)(sc + 3 * (n_rec + 1)), (const int64_t*)M.hpv, base + B.at,
+                         (int64_t*)(base + B.off_at), (int64_t*)b->totals.p);
+      BCHK(hipGetLastError());
+    }
+  }
   b->n_selected = totals[0];
   b->sel_bytes = totals[1];
   if ((size_t)totals[1] + 64 > b->h_sel_cap || !b->h_sel) {
@@ -1483,10 +1671,85 @@ extern "C" int svdss_bam_select_run(svdss_bam_stream_t* s, int64_t seq, int32_t 
   return SVDSS_OK;
 }
 
+// The second pass over ONE stored batch: its slim records whose alignment overlaps a region of `f`, in file order, on the host
+// (svdss_bam_batch_selection, slim = 1).  Any batch object of the store's device (or none yet) may be used; calls on different
+// batch objects overlap.
+extern "C" int svdss_bam_store_select(svdss_bam_store_t* t, int64_t seq, const svdss_bam_filter_t* f, svdss_bam_batch_t** out) {
+  if (!t || !f || !out || seq < 0 || f->device != t->device) return SVDSS_EINVAL;
+  StoreBatch B;
+  const uint8_t* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(t->m);
+    auto it = t->batches.find(seq);
+    if (it == t->batches.end()) return SVDSS_EINVAL;
+    B = it->second;
+    base = t->arenas[(size_t)B.arena].p;
+  }
+  HIPCHK(hipSetDevice(t->device));
+  svdss_bam_batch* b = *out;
+  if (!b) {
+    b = new (std::nothrow) svdss_bam_batch();
+    if (!b) return SVDSS_ENOMEM;
+    b->device = t->device;
+    *out = b;
+  }
+  if (b->device != t->device) return SVDSS_EINVAL;
+  auto fail = [&](int code, const std::string& msg) { b->err = msg; if (b->st) (void)hipStreamSynchronize(b->st); return code; };
+  if (!b->st) BCHK(svdss_make_stream(&b->st, "SVDSS_SEARCH_CUS"));
+  const hipStream_t st = b->st;
+  b->err.clear();
+  const int64_t n = B.n;
+  b->n_records = n; b->n_selected = 0; b->sel_bytes = 0; b->sel_slim = true; b->inflate_ms = 0;
+  for (int k = 0; k < 8; ++k) b->stage_ms[k] = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  RCHK(ensure(b->flags, sizeof(int64_t) * 2 * (size_t)(n + 1)));
+  RCHK(ensure(b->scans, sizeof(int64_t) * 2 * (size_t)(n + 1)));
+  RCHK(ensure(b->totals, 64));
+  StoreSelP M;
+  M.recs = base + B.at; M.off = (const int64_t*)(base + B.off_at); M.n = n; M.n_ref = f->n_ref;
+  M.reg_off = f->d_reg_off; M.reg_beg = f->d_reg_beg; M.reg_runmax = f->d_reg_runmax;
+  M.f_sel = (int64_t*)b->flags.p; M.f_bytes = M.f_sel + (n + 1);
+  hipLaunchKernelGGL(store_select_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, M);
+  BCHK(hipGetLastError());
+  int64_t* sc = (int64_t*)b->scans.p;
+  {
+    size_t tb = 0;
+    BCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, M.f_sel, sc, (int)(n + 1), st));
+    RCHK(ensure(b->tmp, tb + 256));
+    for (int k = 0; k < 2; ++k) {
+      size_t t2 = b->tmp.cap;
+      BCHK(hipcub::DeviceScan::ExclusiveSum(b->tmp.p, t2, M.f_sel + (int64_t)k * (n + 1), sc + (int64_t)k * (n + 1), (int)(n + 1), st));
+    }
+  }
+  RCHK(ensure(b->sel_out, (size_t)B.bytes + 64));
+  RCHK(ensure(b->sel_off, sizeof(int64_t) * (size_t)(n + 2)));
+  hipLaunchKernelGGL(store_export_kernel, dim3((unsigned)(n + 1)), dim3(64), 0, st, M.recs, M.off, n, (const int64_t*)M.f_sel, (const int64_t*)sc,
+                     (const int64_t*)(sc + (n + 1)), (uint8_t*)b->sel_out.p, (int64_t*)b->sel_off.p, (int64_t*)b->totals.p);
+  BCHK(hipGetLastError());
+  int64_t totals[2] = {0, 0};
+  BCHK(hipMemcpyAsync(totals, b->totals.p, sizeof totals, hipMemcpyDeviceToHost, st));
+  BCHK(hipStreamSynchronize(st));
+  b->n_selected = totals[0];
+  b->sel_bytes = totals[1];
+  if ((size_t)totals[1] + 64 > b->h_sel_cap || !b->h_sel) {
+    if (b->h_sel) { (void)hipHostFree(b->h_sel); b->h_sel = nullptr; b->h_sel_cap = 0; }
+    const size_t want = (size_t)totals[1] + ((size_t)totals[1] >> 2) + ((size_t)1 << 20);
+    BCHK(hipHostMalloc((void**)&b->h_sel, want, hipHostMallocDefault));
+    b->h_sel_cap = want;
+  }
+  try { b->h_sel_off.resize((size_t)totals[0] + 1); } catch (...) { return fail(SVDSS_ENOMEM, "out of memory"); }
+  BCHK(hipMemcpyAsync(b->h_sel_off.data(), b->sel_off.p, sizeof(int64_t) * (size_t)(totals[0] + 1), hipMemcpyDeviceToHost, st));
+  if (totals[1] > 0) BCHK(hipMemcpyAsync(b->h_sel, b->sel_out.p, (size_t)totals[1], hipMemcpyDeviceToHost, st));
+  BCHK(hipStreamSynchronize(st));
+  b->stage_ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return SVDSS_OK;
+}
+
 extern "C" int svdss_bam_batch_selection(const svdss_bam_batch_t* b, svdss_bam_selection_t* r) {
   if (!b || !r) return SVDSS_EINVAL;
   r->n_records = b->n_records; r->n_selected = b->n_selected; r->n_bytes = b->sel_bytes;
   r->rec_off = b->h_sel_off.data(); r->bytes = b->h_sel;
+  r->slim = b->sel_slim ? 1 : 0;
   r->inflate_kernel_ms = b->inflate_ms;
   for (int k = 0; k < 8; ++k) r->stage_ms[k] = b->stage_ms[k];
   return SVDSS_OK;

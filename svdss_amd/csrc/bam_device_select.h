@@ -117,7 +117,7 @@ struct SelectedBatch {
 };
 
 // a record's view (BamReader::RawView: the zero-copy form the host readers hand out) over bytes that hold it
-inline bool view_of_record(const uint8_t* rec, size_t avail, BamReader::RawView& v) {
+inline bool view_of_record(const uint8_t* rec, size_t avail, BamReader::RawView& v, bool slim = false) {
   if (avail < 36) return false;
   int32_t block_size;
   memcpy(&block_size, rec, 4);
@@ -135,8 +135,9 @@ inline bool view_of_record(const uint8_t* rec, size_t avail, BamReader::RawView&
   memcpy(&v.flag, core + 14, 2);
   memcpy(&v.l_seq, core + 16, 4);
   if (v.l_seq < 0) return false;
-  const size_t head = 32 + (size_t)v.l_name + 4u * v.n_cigar + ((size_t)v.l_seq + 1) / 2 + (size_t)v.l_seq;
+  const size_t head = 32 + (size_t)v.l_name + 4u * v.n_cigar + ((size_t)v.l_seq + 1) / 2 + (slim ? 0 : (size_t)v.l_seq);
   if (head > (size_t)block_size) return false;
+  v.noqual = slim;
   v.l_aux = (uint32_t)((size_t)block_size - head);
   return true;
 }

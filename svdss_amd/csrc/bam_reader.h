@@ -367,9 +367,10 @@ class BamReader {
     int32_t tid = -1, pos = 0, l_seq = 0;
     uint16_t flag = 0;
     uint8_t mapq = 0;
+    bool noqual = false;            // a slim record (svdss_bam_store_select): the tags follow the bases
     const uint8_t* name() const { return p + 32; }
     const uint8_t* seq4() const { return p + 32 + l_name + 4u * n_cigar; }
-    const uint8_t* aux() const { return seq4() + ((size_t)l_seq + 1) / 2 + (size_t)l_seq; }
+    const uint8_t* aux() const { return seq4() + ((size_t)l_seq + 1) / 2 + (noqual ? 0 : (size_t)l_seq); }
   };
   std::shared_ptr<Bytes> chunk() const { return chunk_; }
   uint64_t chunk_id() const { return chunk_id_; }
@@ -381,6 +382,7 @@ class BamReader {
     if (got == 0) return err_.empty() ? 0 : -1;
     if (got != 4 || block_size < 32) { err_ = "truncated record"; return -1; }
     v.own.reset();
+    v.noqual = false;
     if (chunk_->size() - upos_ >= (size_t)block_size) {   // whole record inside the current chunk
       v.p = chunk_->data() + upos_;
       upos_ += (size_t)block_size;

@@ -465,6 +465,8 @@ struct CallRun {
   // The inflated records of pass 1 are kept for pass 2 when they fit in memory (a second inflate of the whole file
   // otherwise): SVDSS_CALL_CACHE_GB, default 40 % of MemAvailable, at most 64 GiB.
   std::thread fasta_loader;              // load_chromosomes, beside the SFS file and the start of pass 1
+  // ONE pass over the BAM (round 6): what pass 2 needs of every record stays in HBM while pass 1 runs (svdss_bam_store_t)
+  svdss_bam_store_t* store = nullptr;
   void reference_ready() { if (fasta_loader.joinable()) fasta_loader.join(); }
   bool dev_pass = false;                 // the BAM is read through the device path (csrc/bam_device.hip): no record cache
   int64_t bam_skip = 0;                  // the BAM header's length in the inflated stream
@@ -591,7 +593,23 @@ struct CallRun {
           filters.push_back(f);
           devs.push_back(d);
         }
-        sel.reset(new DeviceBamSelect(o.bam, filters, devs, n_ref_hdr, bam_skip, bam_feeders(), bam_batch_bytes()));
+        // One GPU: the slim form of every record that passes the flag / mapq filters stays in its HBM for pass 2 (up to
+        // SVDSS_CALL_STORE_GB, default 160: a 30x human sample is ~50 GB; more than fits: the file is read again, as before).
+        // SVDSS_CALL_STORE=0: two passes over the file.
+        DeviceBamSelect::RunFn run;
+        if (n_dev == 1 && !(getenv("SVDSS_CALL_STORE") && atoi(getenv("SVDSS_CALL_STORE")) == 0)) {
+          const int64_t gb = getenv("SVDSS_CALL_STORE_GB") && atoll(getenv("SVDSS_CALL_STORE_GB")) > 0 ? atoll(getenv("SVDSS_CALL_STORE_GB")) : 160;
+          const int64_t cap = getenv("SVDSS_CALL_STORE_MB") && atoll(getenv("SVDSS_CALL_STORE_MB")) > 0 ? atoll(getenv("SVDSS_CALL_STORE_MB")) << 20 : gb << 30;
+          check(svdss_bam_store_create(0, cap, &store), "svdss_bam_store_create");
+          svdss_bam_filter_t* f0 = filters[0];
+          svdss_bam_store_t* st0 = store;
+          run = [f0, st0](svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, size_t, int32_t n_chunks, const uint8_t* const* comp,
+                          const int64_t* comp_bytes, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                          svdss_bam_batch_t** batch) {
+            return svdss_bam_select_store_run(s, seq, is_last, skip, f0, st0, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, batch);
+          };
+        }
+        sel.reset(new DeviceBamSelect(o.bam, filters, devs, n_ref_hdr, bam_skip, bam_feeders(), bam_batch_bytes(), run));
         cache_ok = false;
         dev_pass = true;
       } else {
@@ -602,6 +620,8 @@ struct CallRun {
         ref_names = bam_p->ref_names();
       }
       // the next record pass 1 looks at: 1 = record, 0 = end of file (errors end the run)
+      double pass1_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint64_t pass1_batches = 0;
       std::unique_ptr<SelectedBatch> sel_cur;
       size_t sel_k = 0;
       const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
@@ -653,6 +673,8 @@ struct CallRun {
               sel_k = 0;
               if (!sel_cur) break;
               n_records_seen += sel_cur->n_records;
+              for (int k = 0; k < 8; ++k) pass1_stage[k] += sel_cur->stage_s[k];
+              pass1_stage[7] += sel_cur->inflate_kernel_s; ++pass1_batches;
             }
             if (!sel_cur) {
               if (!sel->error().empty()) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": " + sel->error()); }
@@ -751,6 +773,13 @@ struct CallRun {
       }
       if (worker.joinable()) worker.join();
       set_up_reference();   // (an input without a single batch: the later stages still want the chromosomes)
+      if (sel && pass1_batches) {
+        char buf[320];
+        snprintf(buf, sizeof buf, "pass 1 on the device: %llu batches, %llu records; feeder seconds summed: upload+inflate+crc+walk %.3f, turn wait %.3f, turn %.3f, "
+                 "select+scans%s %.3f, records down %.3f (inflate kernels %.3f)", (unsigned long long)pass1_batches, (unsigned long long)n_records_seen, pass1_stage[0],
+                 pass1_stage[1], pass1_stage[2], store ? "+store" : "", pass1_stage[3], pass1_stage[6], pass1_stage[7]);
+        logmsg("debug", buf);
+      }
       svdss_ref_free(dref);
       sel.reset();
       for (svdss_bam_filter_t* f : filters) svdss_bam_filter_free(f);
@@ -918,7 +947,81 @@ struct CallRun {
           sink(ev);
         }
       };
-      if (cache_ok) {
+      bool from_store = false;
+      if (store) {
+        // Round 6: the records are in HBM since pass 1 (svdss_bam_store_t).  Per stored batch a kernel keeps those that overlap
+        // a (merged) cluster region; they come down slim, in file order, and go through `process` on a few threads, what
+        // they do to the clusters applied batch after batch -- the order of the single scan.
+        int32_t complete = 0;
+        int64_t n_rec_st = 0, n_bytes_st = 0;
+        const int64_t n_b = svdss_bam_store_batches(store, &complete, &n_rec_st, &n_bytes_st);
+        if (complete && n_b >= 0) {
+          from_store = true;
+          std::vector<int32_t> rt, rb, re;
+          for (size_t t = 0; t < ref_names.size(); ++t) {
+            if (!tid_clusters[t]) continue;
+            int64_t cb = -1, ce = -1;
+            for (size_t ci : *tid_clusters[t]) {
+              const int64_t b0 = std::max(min_s[ci] - 1, 0), e0 = max_e[ci];
+              if (ce >= 0 && b0 <= ce) { ce = std::max(ce, e0); continue; }
+              if (ce >= 0) { rt.push_back((int32_t)t); rb.push_back((int32_t)cb); re.push_back((int32_t)ce); }
+              cb = b0; ce = e0;
+            }
+            if (ce >= 0) { rt.push_back((int32_t)t); rb.push_back((int32_t)cb); re.push_back((int32_t)ce); }
+          }
+          uint64_t n_down = 0, bytes_down = 0;
+          if (!rt.empty() && n_b > 0) {
+            svdss_bam_filter_t* f = nullptr;
+            check(svdss_bam_filter_create(0, (int32_t)std::min<unsigned>(o.min_mapq, 256u), (int32_t)ref_names.size(), nullptr, nullptr, 0, rt.data(), rb.data(),
+                                          re.data(), (int64_t)rt.size(), &f), "svdss_bam_filter_create");
+            std::vector<std::vector<Ev>> evs((size_t)n_b);
+            std::atomic<int64_t> next(0);
+            std::atomic<uint64_t> a_down(0), a_bytes(0);
+            std::mutex err_m;
+            std::string err;
+            auto work = [&]() {
+              svdss_bam_batch_t* batch = nullptr;
+              std::string nm;
+              BamReader::RawView rr;
+              for (;;) {
+                const int64_t k = next.fetch_add(1);
+                if (k >= n_b) break;
+                const int rc = svdss_bam_store_select(store, k, f, &batch);
+                if (rc != SVDSS_OK) { std::lock_guard<std::mutex> lk(err_m); if (err.empty()) err = std::string(svdss_strerror(rc)) + " " + svdss_last_hip_error(); break; }
+                svdss_bam_selection_t r;
+                (void)svdss_bam_batch_selection(batch, &r);
+                auto sink = [&](Ev& e) { evs[(size_t)k].push_back(std::move(e)); };
+                for (int64_t i = 0; i < r.n_selected; ++i) {
+                  if (!view_of_record(r.bytes + r.rec_off[i], (size_t)(r.rec_off[i + 1] - r.rec_off[i]), rr, true)) {
+                    std::lock_guard<std::mutex> lk(err_m); if (err.empty()) err = "corrupt record in the store"; break;
+                  }
+                  process(rr, nm, sink);
+                }
+                a_down += (uint64_t)r.n_selected; a_bytes += (uint64_t)r.n_bytes;
+              }
+              if (batch) svdss_bam_batch_free(batch);
+            };
+            const size_t Wt = (size_t)std::max<int64_t>(1, std::min<int64_t>({(int64_t)effective_cpus(), (int64_t)8, n_b}));
+            std::vector<std::thread> pool;
+            for (size_t w = 1; w < Wt; ++w) pool.emplace_back(work);
+            work();
+            for (std::thread& th : pool) th.join();
+            svdss_bam_filter_free(f);
+            if (!err.empty()) die("pass 2 from the record store: " + err);
+            for (int64_t k = 0; k < n_b; ++k)
+              for (Ev& e : evs[(size_t)k]) apply(e);
+            n_down = a_down.load(); bytes_down = a_bytes.load();
+          }
+          logmsg("debug", "pass 2 from the records kept in HBM: " + std::to_string(n_rec_st) + " records (" + std::to_string(n_bytes_st >> 20) + " MB) in " +
+                              std::to_string(n_b) + " batches, " + std::to_string(rt.size()) + " regions, " + std::to_string(n_down) + " records (" +
+                              std::to_string(bytes_down >> 20) + " MB) came down");
+        } else
+          logmsg("debug", "the record store is incomplete (" + std::to_string(n_bytes_st >> 20) + " MB kept): pass 2 reads the file again");
+        // (tens of GB of HBM stay allocated until the run ends: memory handed back is cleared by the driver beside whatever
+        // runs next -- here the POA batches -- and `call` has room to spare: it holds no index)
+      }
+      if (from_store) {
+      } else if (cache_ok) {
         stage("pass 2: setup");
         const size_t n = cache_views.size();
         const size_t W = std::max<size_t>(1, std::min<size_t>({(size_t)effective_cpus(), (size_t)32, n / 4096 + 1}));
@@ -1389,6 +1492,7 @@ struct CallRun {
     logmsg("info", "Writing " + std::to_string(svs.size()) + " SVs.");
     stage("vcf");
     if (cache_release.joinable()) cache_release.join();
+    if (store && getenv("SVDSS_CLEAN_EXIT")) { svdss_bam_store_free(store); store = nullptr; }   // (otherwise the process ends with _exit)
     // ---- write_sam (caller.cpp:65-75): rows in the order of the reference's per-thread lists, each inserted at the
     // front of the global one (caller.cpp:18-22)
     if (!o.poa.empty()) {

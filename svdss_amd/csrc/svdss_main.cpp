@@ -622,6 +622,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     int64_t n_seg = 0;
     const int64_t rew = svdss_bam_stream_rewalked(R.stream, &n_seg);
     { std::lock_guard<std::mutex> lk(t_m); n_seg_all += n_seg; n_rewalk_all += rew; }
+    if (early) return;      // (its parked batches are still to come: finished when they have been searched and handed over)
     { std::lock_guard<std::mutex> lk(dev_m); R.finished = true; }
     dev_cv.notify_all();
   };
@@ -870,7 +871,11 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     std::vector<std::thread> joiners;
     for (BamRegion& R : regions) joiners.emplace_back([&join_region, &R] { join_region(R); });
     for (std::thread& th : joiners) th.join();
-    if (drain.joinable()) drain.join();
+    if (drain.joinable()) {
+      drain.join();
+      { std::lock_guard<std::mutex> lk(dev_m); for (BamRegion& R : regions) R.finished = true; }
+      dev_cv.notify_all();
+    }
     assembler.join();
     for (std::thread& th : fmt) th.join();
     { std::lock_guard<std::mutex> lk(done_m); format_finished = true; }
@@ -970,10 +975,11 @@ int main_search(const Options& o) {
     // (SVDSS_PARK_GB: what may be parked at most, in arenas allocated as they are needed; SVDSS_PARK_MB: the same in MB, for tests)
     const int64_t park_b = getenv("SVDSS_PARK_MB") && atoll(getenv("SVDSS_PARK_MB")) > 0 ? atoll(getenv("SVDSS_PARK_MB")) << 20
                            : (getenv("SVDSS_PARK_GB") && atoll(getenv("SVDSS_PARK_GB")) > 0 ? atoll(getenv("SVDSS_PARK_GB")) : 32) << 30;
-    check(svdss_bam_park_create(0, park_b, park_b / 512 + 4096, &early->park), "svdss_bam_park_create");
-    if (bam_prewarm.joinable()) bam_prewarm.join();
     bam_regions[0].gpus = {nullptr};
-    early_stream = std::thread([&] {
+    // (on a thread of its own from the first moment: this one goes straight to the index file)
+    early_stream = std::thread([&, park_b] {
+      check(svdss_bam_park_create(0, park_b, park_b / 512 + 4096, &early->park), "svdss_bam_park_create");
+      if (bam_prewarm.joinable()) bam_prewarm.join();
       const std::vector<svdss_index_t*> none(1, nullptr);
       search_bam_device(o, none, bam_regions, bam_hooks, bam_slab, bam_loaders, bam_pool_chunks, bam_n_ref, since, early.get());
     });

@@ -55,6 +55,16 @@ def test_chr20_10x_end_to_end(tmp_path):
     r_dev = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50",
                             "--verbose"], capture_output=True, text=True, env=dict(os.environ, SVDSS_BAM_BATCH_MB="8", SVDSS_BAM_SLAB_KB="512"))
     assert r_dev.returncode == 0 and r_dev.stdout == vcf, r_dev.stderr[-500:]
+    # round 6: ONE pass over the file -- what pass 2 needs of every record stays in HBM while pass 1 runs (svdss_bam_store_t);
+    # in arenas of 1 MB (dozens); with a store too small for the file (pass 2 reads the file again); switched off
+    assert "pass 2 from the records kept in HBM" in r_dev.stderr
+    for env, what in (({"SVDSS_STORE_ARENA_MB": "1", "SVDSS_BAM_BATCH_MB": "2", "SVDSS_BAM_SLAB_KB": "256"}, "pass 2 from the records kept in HBM"),
+                      ({"SVDSS_CALL_STORE_MB": "3", "SVDSS_STORE_ARENA_MB": "1", "SVDSS_BAM_BATCH_MB": "2", "SVDSS_BAM_SLAB_KB": "256"}, "the record store is incomplete"),
+                      ({"SVDSS_CALL_STORE": "0"}, None)):
+        r_st = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50", "--verbose"],
+                              capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r_st.returncode == 0 and r_st.stdout == vcf, (env, r_st.stderr[-500:])
+        assert (what in r_st.stderr) if what else ("record store" not in r_st.stderr and "kept in HBM" not in r_st.stderr), (env, r_st.stderr[-800:])
     r_hr = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50"],
                           capture_output=True, text=True, env=dict(os.environ, SVDSS_BAM_DEVICE="0"))
     assert r_hr.returncode == 0 and r_hr.stdout == vcf
@@ -77,7 +87,7 @@ def test_chr20_10x_end_to_end(tmp_path):
                 fh.write(idx)
         r_p2 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4",
                                "--min-sv-length", "50", "--verbose"], capture_output=True, text=True,
-                              env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai"))
+                              env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai", SVDSS_CALL_STORE="0"))
         assert r_p2.returncode == 0, r_p2.stderr[-500:]
         assert ("through the BAI index" in r_p2.stderr) == (with_bai is True)
         assert ("through the CSI index" in r_p2.stderr) == (with_bai == "csi")
@@ -88,13 +98,13 @@ def test_chr20_10x_end_to_end(tmp_path):
             for thr in ("1", "7"):
                 r_t = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50"],
                                      capture_output=True, text=True,
-                                     env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai", SVDSS_CALL_PASS2_THREADS=thr))
+                                     env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai", SVDSS_CALL_PASS2_THREADS=thr, SVDSS_CALL_STORE="0"))
                 assert r_t.returncode == 0 and r_t.stdout == vcf, (thr, r_t.stderr[-300:])
         # (and the host reader without its cache, with and without the index; with the index present the device path may
         # still read the whole file when the chunks the index names are a large part of it: SVDSS_CALL_PASS2=device)
         for env in ({"SVDSS_BAM_DEVICE": "0"}, {"SVDSS_CALL_PASS2": "device"}):
             r_p3 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50"],
-                                  capture_output=True, text=True, env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", **env))
+                                  capture_output=True, text=True, env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_STORE="0", **env))
             assert r_p3.returncode == 0 and r_p3.stdout == vcf, (env, r_p3.stderr[-300:])
     os.remove(bam + ".bai")
     # the reads around four SVs (two heterozygous, two homozygous): the same chain on that sub-BAM, and the Python mirror

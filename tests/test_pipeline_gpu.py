@@ -75,7 +75,7 @@ def test_index_search_call_recovers_implanted_svs(tmp_path, het):
             (tmp_path / "smoothed.bam.bai").write_bytes(bam_writer.bai(bam.read_bytes()))
         r2 = subprocess.run([BIN, "call", "--reference", str(fa), "--bam", str(bam), "--sfs", str(sfs_path), "--threads", "4",
                              "--min-sv-length", "50", "--clusters", str(tmp_path / "clusters2.txt"), "--verbose"],
-                            capture_output=True, text=True, env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai"))
+                            capture_output=True, text=True, env=dict(os.environ, SVDSS_CALL_CACHE_GB="0", SVDSS_CALL_PASS2="bai", SVDSS_CALL_STORE="0"))
         assert r2.returncode == 0, r2.stderr
         # (SVDSS_CALL_PASS2=bai: with an index present the device path would otherwise weigh the chunks it names against
         # reading the whole file, tests/test_config3_gpu.py)

@@ -394,7 +394,7 @@ def run_chain(work, n_reads, n_svs, scale=1.0, threads=16, err=0.005, generator=
                        check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     out["call_s"] = round(time.perf_counter() - t0, 3)
     out["call_bam"] = "the original BAM (its .bai beside it), as run_svdss does"
-    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "[time]" in ln or "pass 2 through" in ln or "pass 1" in ln][-24:]
+    out["call_log"] = [ln for ln in c.stderr.decode().splitlines() if "[time]" in ln or "pass 2 " in ln or "pass 1" in ln or "record store" in ln][-26:]
     n_called, hit = _vcf_hits(c.stdout.decode(), svs)
     chain = out["smooth_s"] + out["search_s"] + out["call_s"]
     out.update({"svs_called": n_called, "truth_recovered": hit, "smooth_reads_per_s": n / out["smooth_s"],
