@@ -364,10 +364,12 @@ int svdss_bam_batch_selection(const svdss_bam_batch_t* b, svdss_bam_selection_t*
  * integer one -- no qualities, no other tags; ~1/3 of the record) of EVERY record that passes the flag / mapq filters, in
  * HBM, while the first pass runs (svdss_bam_select_store_run = svdss_bam_select_run + the store); the second pass is then a
  * kernel over resident records (svdss_bam_store_select, per stored batch: the slim records that overlap a region of the
- * filter come down, in file order).  A store that would exceed max_bytes stays incomplete (svdss_bam_store_batches):
- * the caller reads the file again, through its index or the device path, as before. */
+ * filter come down, in file order).  With a store the records of the first pass come down slim as well (slim = 1).  A store
+ * that would exceed max_bytes stays incomplete (svdss_bam_store_batches): the caller reads the file again, through its
+ * index or the device path, as before.  initial_bytes: allocated at once (what the caller expects the store to need: an
+ * allocation in the middle of the stream stalls it); the rest in arenas of SVDSS_STORE_ARENA_MB (2,048). */
 typedef struct svdss_bam_store svdss_bam_store_t;
-int svdss_bam_store_create(int32_t device, int64_t max_bytes, svdss_bam_store_t** out);
+int svdss_bam_store_create(int32_t device, int64_t max_bytes, int64_t initial_bytes, svdss_bam_store_t** out);
 void svdss_bam_store_free(svdss_bam_store_t* t);
 int64_t svdss_bam_store_batches(svdss_bam_store_t* t, int32_t* complete, int64_t* n_records, int64_t* n_bytes);
 int svdss_bam_select_store_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_filter_t* f,

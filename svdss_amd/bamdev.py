@@ -213,7 +213,7 @@ def select_bam_store(data, names, regions, min_mapq=0, batch_bytes=256 << 20, de
                                      re_.ctypes.data if regions else None, len(regions), C.byref(f_regions))
     if rc:
         raise SvdssError(rc, "svdss_bam_filter_create")
-    rc = lib.svdss_bam_store_create(device, max_store_bytes, C.byref(store))
+    rc = lib.svdss_bam_store_create(device, max_store_bytes, min(max_store_bytes, 1 << 20), C.byref(store))
     if rc:
         raise SvdssError(rc, "svdss_bam_store_create")
     stream = C.c_void_p()
@@ -253,9 +253,10 @@ def select_bam_store(data, names, regions, min_mapq=0, batch_bytes=256 << 20, de
                 raise e
             r = BamSelection()
             lib.svdss_bam_batch_selection(batch, C.byref(r))
-            assert r.slim == 0
+            # (with a store the first pass' records are slim too; once it is over its limit the batches behind come whole)
             stats["records"] += r.n_records
             stats["batches"] += 1
+            stats.setdefault("named_slim", []).extend([int(r.slim)] * int(r.n_selected))
             take(r, named)
         complete, n_rec, n_bytes = C.c_int32(0), C.c_int64(0), C.c_int64(0)
         n_b = lib.svdss_bam_store_batches(store, C.byref(complete), C.byref(n_rec), C.byref(n_bytes))

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -580,7 +581,7 @@ __global__ void __launch_bounds__(64) select_kernel(SelP M) {
     }
     M.rpos[gi] = (uint32_t)p;
     M.f_sel[gi] = keep ? 1 : 0;
-    M.f_bytes[gi] = keep ? (((int64_t)bs + 4 + 3) & ~(int64_t)3) : 0;
+    M.f_bytes[gi] = !keep ? 0 : M.f_keep ? M.f_kbytes[gi] : (((int64_t)bs + 4 + 3) & ~(int64_t)3);   // (with a store: slim, like the stored ones)
   }
   if (s == 0 && threadIdx.x == 0) { M.f_sel[M.n_rec] = 0; M.f_bytes[M.n_rec] = 0; if (M.f_keep) { M.f_keep[M.n_rec] = 0; M.f_kbytes[M.n_rec] = 0; } }
 }
@@ -593,7 +594,7 @@ __global__ void __launch_bounds__(64) slim_export_kernel(const uint8_t* __restri
                                                          uint8_t* out, int64_t* out_off, int64_t* totals) {
   const int64_t gi = blockIdx.x;
   if (gi == n_rec) {
-    if (threadIdx.x == 0) { out_off[s_keep[gi]] = s_bytes[gi]; totals[2] = s_keep[gi]; totals[3] = s_bytes[gi]; }
+    if (threadIdx.x == 0) { out_off[s_keep[gi]] = s_bytes[gi]; totals[0] = s_keep[gi]; totals[1] = s_bytes[gi]; }
     return;
   }
   if (!f_keep[gi]) return;
@@ -729,6 +730,12 @@ struct StoreArena { uint8_t* p = nullptr; int64_t cap = 0, used = 0; };
 struct svdss_bam_store {
   int device = -1;
   int64_t max_bytes = 0, arena_bytes = (int64_t)2 << 30, allocated = 0;
+  // arenas taken AHEAD of the batches by a thread of the store (see svdss_bam_store_create): next_use = the first arena no
+  // batch has been placed in yet
+  std::thread ahead;
+  std::condition_variable cv;
+  bool ahead_running = false, stop = false;
+  size_t cur = 0;                // the arena batches are being placed in
   std::mutex m;
   std::vector<StoreArena> arenas;
   std::map<int64_t, StoreBatch> batches;
@@ -1527,18 +1534,45 @@ extern "C" void svdss_bam_filter_free(svdss_bam_filter_t* f) {
   delete f;
 }
 
-extern "C" int svdss_bam_store_create(int32_t device, int64_t max_bytes, svdss_bam_store_t** out) {
-  if (!out || device < 0 || max_bytes < 0) return SVDSS_EINVAL;
+extern "C" int svdss_bam_store_create(int32_t device, int64_t max_bytes, int64_t initial_bytes, svdss_bam_store_t** out) {
+  if (!out || device < 0 || max_bytes < 0 || initial_bytes < 0) return SVDSS_EINVAL;
   svdss_bam_store* t = new (std::nothrow) svdss_bam_store();
   if (!t) return SVDSS_ENOMEM;
   t->device = device;
   t->max_bytes = max_bytes;
   if (const char* e = getenv("SVDSS_STORE_ARENA_MB")) if (atoll(e) > 0) t->arena_bytes = atoll(e) << 20;
+  // initial_bytes of arenas are taken by a thread of the store, one after the other, AHEAD of the batches: a hipMalloc by a
+  // feeding thread in the middle of the stream waits for the device (24 arenas of 2 GB on demand cost `SVDSS call` 2.5 s of a
+  // 3.3 s pass at 30x), and memory that another process has just handed back is cleared by the driver before it is handed
+  // out again -- 4 s for 50 GB right behind a `SVDSS search` that held 190 GB, taken in one piece before the stream began.
+  // Taken ahead, piece by piece, the clearing runs beside the stream; a batch only waits when it has caught up with it.
+  initial_bytes = std::min(initial_bytes, max_bytes);
+  if (initial_bytes > 0) {
+    t->ahead_running = true;
+    t->ahead = std::thread([t, initial_bytes] {
+      (void)hipSetDevice(t->device);
+      int64_t left = initial_bytes;
+      while (left > 0) {
+        { std::lock_guard<std::mutex> lk(t->m); if (t->stop) break; }
+        StoreArena A;
+        A.cap = std::min(left, t->arena_bytes);
+        if (A.cap < ((int64_t)1 << 20) && left != initial_bytes) break;
+        if (hipMalloc((void**)&A.p, (size_t)A.cap) != hipSuccess) { (void)hipGetLastError(); break; }
+        { std::lock_guard<std::mutex> lk(t->m); t->allocated += A.cap; t->arenas.push_back(A); }
+        t->cv.notify_all();
+        left -= A.cap;
+      }
+      { std::lock_guard<std::mutex> lk(t->m); t->ahead_running = false; }
+      t->cv.notify_all();
+    });
+  }
   *out = t;
   return SVDSS_OK;
 }
 extern "C" void svdss_bam_store_free(svdss_bam_store_t* t) {
   if (!t) return;
+  { std::lock_guard<std::mutex> lk(t->m); t->stop = true; }
+  if (t->ahead.joinable()) t->ahead.join();
   (void)hipSetDevice(t->device);
   for (StoreArena& A : t->arenas) if (A.p) (void)hipFree(A.p);
   delete t;
@@ -1554,17 +1588,21 @@ extern "C" int64_t svdss_bam_store_batches(svdss_bam_store_t* t, int32_t* comple
 // room for a batch's slim records (+ their n + 1 offsets); false: the store is over its limit (and stays incomplete)
 static bool store_reserve(svdss_bam_store* t, int64_t seq, int64_t bytes, int64_t n, StoreBatch& B, uint8_t*& base) {
   const int64_t need = ((bytes + 255) & ~(int64_t)255) + (((n + 1) * 8 + 255) & ~(int64_t)255);
-  std::lock_guard<std::mutex> lk(t->m);
+  std::unique_lock<std::mutex> lk(t->m);
   if (!t->complete) return false;
-  if (t->arenas.empty() || t->arenas.back().used + need > t->arenas.back().cap) {
+  for (;;) {
+    // the arena in use, then those taken ahead that nothing has been placed in yet
+    while (t->cur < t->arenas.size() && t->arenas[t->cur].used + need > t->arenas[t->cur].cap) ++t->cur;
+    if (t->cur < t->arenas.size()) break;
+    if (t->ahead_running) { t->cv.wait(lk); continue; }      // (the thread that takes arenas ahead has not got this far yet)
     StoreArena A;
     A.cap = std::max(t->arena_bytes, need);
     if (t->allocated + A.cap > t->max_bytes || hipMalloc((void**)&A.p, (size_t)A.cap) != hipSuccess) { (void)hipGetLastError(); t->complete = false; return false; }
     t->allocated += A.cap;
     t->arenas.push_back(A);
   }
-  StoreArena& A = t->arenas.back();
-  B.arena = (int)t->arenas.size() - 1; B.at = A.used; B.bytes = bytes; B.n = n;
+  StoreArena& A = t->arenas[t->cur];
+  B.arena = (int)t->cur; B.at = A.used; B.bytes = bytes; B.n = n;
   B.off_at = A.used + ((bytes + 255) & ~(int64_t)255);
   A.used += need;
   base = A.p;
@@ -1631,9 +1669,15 @@ extern "C" int svdss_bam_select_store_run(svdss_bam_stream_t* s, int64_t seq, in
   // (how much is kept is only known on the device: bounded by the batch itself)
   RCHK(ensure(b->sel_out, (size_t)(F.total_inf + F.HEAD) + 4 * (size_t)(n_rec + 1) + 64));
   RCHK(ensure(b->sel_off, sizeof(int64_t) * (size_t)(n_rec + 2)));
-  hipLaunchKernelGGL(export_kernel, dim3((unsigned)(n_rec + 1)), dim3(64), 0, st, W.buf, n_rec, (const uint32_t*)M.rpos, (const int64_t*)M.f_sel,
-                     (const int64_t*)sc, (const int64_t*)(sc + (n_rec + 1)), (uint8_t*)b->sel_out.p, (int64_t*)b->sel_off.p, (int64_t*)b->totals.p);
+  if (store)
+    hipLaunchKernelGGL(slim_export_kernel, dim3((unsigned)(n_rec + 1)), dim3(64), 0, st, W.buf, n_rec, (const uint32_t*)M.rpos, (const int64_t*)M.f_sel,
+                       (const int64_t*)sc, (const int64_t*)(sc + (n_rec + 1)), (const int64_t*)M.hpv, (uint8_t*)b->sel_out.p, (int64_t*)b->sel_off.p,
+                       (int64_t*)b->totals.p);
+  else
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)(n_rec + 1)), dim3(64), 0, st, W.buf, n_rec, (const uint32_t*)M.rpos, (const int64_t*)M.f_sel,
+                       (const int64_t*)sc, (const int64_t*)(sc + (n_rec + 1)), (uint8_t*)b->sel_out.p, (int64_t*)b->sel_off.p, (int64_t*)b->totals.p);
   BCHK(hipGetLastError());
+  b->sel_slim = store != nullptr;
   int64_t totals[2] = {0, 0}, hdr2[H_N] = {0};
   BCHK(hipMemcpyAsync(totals, b->totals.p, sizeof totals, hipMemcpyDeviceToHost, st));
   BCHK(hipMemcpyAsync(hdr2, b->hdr.p, sizeof hdr2, hipMemcpyDeviceToHost, st));
@@ -1651,7 +1695,7 @@ extern "C" int svdss_bam_select_store_run(svdss_bam_stream_t* s, int64_t seq, in
     if (store_reserve(store, seq, kept[1], kept[0], B, base)) {
       hipLaunchKernelGGL(slim_export_kernel, dim3((unsigned)(n_rec + 1)), dim3(64), 0, st, W.buf, n_rec, (const uint32_t*)M.rpos, (const int64_t*)M.f_keep,
                          (const int64_t*)(sc + 2 * (n_rec + 1)), (const int64_t*)(sc + 3 * (n_rec + 1)), (const int64_t*)M.hpv, base + B.at,
-                         (int64_t*)(base + B.off_at), (int64_t*)b->totals.p);
+                         (int64_t*)(base + B.off_at), (int64_t*)b->totals.p + 2);
       BCHK(hipGetLastError());
     }
   }

@@ -3,6 +3,7 @@
 // a svdss_bam_filter_t keeps.  Scanner (loader threads) -> batcher -> feeding threads (one batch object each) -> ordered
 // output; the caller sees plain record bytes.
 #pragma once
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <cstdint>
@@ -106,6 +107,7 @@ struct SelectedBatch {
   std::vector<uint8_t> bytes;   // (smoothing: the batch's BGZF members)
   std::vector<int64_t> off;
   uint64_t n_records = 0;       // records of the batch, kept or not
+  bool slim = false;            // the kept records are slim ones (svdss_bam_selection_t::slim)
   // smoothing (svdss_bam_smooth_run / _measure): kept records, by XF value; matches / mismatches and "CIGAR fits" per kept record
   uint64_t n_kept = 0, n_xf[4] = {0, 0, 0, 0};
   std::vector<int64_t> match_mismatch;
@@ -195,6 +197,9 @@ class DeviceBamSelect {
     return b;
   }
   const std::string& error() const { return err_; }
+  // seconds the batcher waited for the file's loaders / for a feeding thread to take a batch (valid once the file has ended)
+  double waited_for_file() const { return wait_file_s_; }
+  double waited_for_feeders() const { return wait_feed_s_; }
   int64_t segments_walked_again(int64_t* n_segments) const { return stream_ ? svdss_bam_stream_rewalked(stream_, n_segments) : 0; }
 
  private:
@@ -217,7 +222,11 @@ class DeviceBamSelect {
       cv_.notify_all();
       return true;
     };
-    while (std::unique_ptr<CompChunk> c = sc_->next()) {
+    for (;;) {
+      const auto w0 = std::chrono::steady_clock::now();
+      std::unique_ptr<CompChunk> c = sc_->next();
+      wait_file_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+      if (!c) break;
       acc += c->inflated;
       const bool last = c->last;
       cur->chunks.push_back(std::move(c));
@@ -225,7 +234,9 @@ class DeviceBamSelect {
         cur->seq = seq++;
         cur->last = last;
         any_last = any_last || last;
+        const auto w1 = std::chrono::steady_clock::now();
         if (!push(std::move(cur))) return;
+        wait_feed_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - w1).count();
         cur.reset(new Job);
         acc = 0;
       }
@@ -274,6 +285,7 @@ class DeviceBamSelect {
         svdss_bam_selection_t r;
         (void)svdss_bam_batch_selection(batch, &r);
         out->n_records = (uint64_t)r.n_records;
+        out->slim = r.slim != 0;
         out->off.assign(r.rec_off, r.rec_off + r.n_selected + 1);
         out->bytes.assign(r.bytes, r.bytes + r.n_bytes);
         for (int k = 0; k < 8; ++k) out->stage_s[k] = r.stage_ms[k] * 1e-3;
@@ -298,6 +310,7 @@ class DeviceBamSelect {
   std::vector<svdss_bam_filter_t*> filters_;
   std::vector<int> devices_;
   int64_t skip_ = 0, target_ = 0;
+  double wait_file_s_ = 0, wait_feed_s_ = 0;
   RunFn run_;
   CollectFn collect_;
   std::unique_ptr<BgzfScanner> sc_;

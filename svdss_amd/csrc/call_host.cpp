@@ -467,6 +467,8 @@ struct CallRun {
   std::thread fasta_loader;              // load_chromosomes, beside the SFS file and the start of pass 1
   // ONE pass over the BAM (round 6): what pass 2 needs of every record stays in HBM while pass 1 runs (svdss_bam_store_t)
   svdss_bam_store_t* store = nullptr;
+  std::thread store_alloc;
+  double store_alloc_s = 0;
   void reference_ready() { if (fasta_loader.joinable()) fasta_loader.join(); }
   bool dev_pass = false;                 // the BAM is read through the device path (csrc/bam_device.hip): no record cache
   int64_t bam_skip = 0;                  // the BAM header's length in the inflated stream
@@ -534,6 +536,27 @@ struct CallRun {
         }
       });
     }
+    // the record store of the ONE pass over the BAM (round 6, align_and_extend / fill_clusters below): its memory is taken NOW,
+    // on a thread of its own, beside the FASTA and the SFS file -- tens of GB that the driver clears before it hands them out
+    {
+      const int n_phys = std::max(1, svdss_device_count());
+      const int n_dev = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_phys));
+      const bool dev_bam = svdss_device_count() > 0 && !(getenv("SVDSS_BAM_DEVICE") && atoi(getenv("SVDSS_BAM_DEVICE")) == 0);
+      if (dev_bam && n_dev == 1 && !(getenv("SVDSS_CALL_STORE") && atoi(getenv("SVDSS_CALL_STORE")) == 0)) {
+        // (up to SVDSS_CALL_STORE_GB, default 160: a 30x human sample is ~50 GB; more than fits: the file is read again, as
+        // before.  Expected size: the bases of the file, two per byte, + names and CIGARs -- at most ~2.5 x a well-compressed BAM)
+        const int64_t gb = getenv("SVDSS_CALL_STORE_GB") && atoll(getenv("SVDSS_CALL_STORE_GB")) > 0 ? atoll(getenv("SVDSS_CALL_STORE_GB")) : 160;
+        const int64_t cap = getenv("SVDSS_CALL_STORE_MB") && atoll(getenv("SVDSS_CALL_STORE_MB")) > 0 ? atoll(getenv("SVDSS_CALL_STORE_MB")) << 20 : gb << 30;
+        struct stat stb;
+        const int64_t fsz = stat(o.bam.c_str(), &stb) == 0 ? (int64_t)stb.st_size : 0;
+        const int64_t initial = getenv("SVDSS_CALL_STORE_INITIAL_MB") ? atoll(getenv("SVDSS_CALL_STORE_INITIAL_MB")) << 20 : std::min(cap, fsz * 5 / 2 + ((int64_t)256 << 20));
+        store_alloc = std::thread([this, cap, initial] {
+          const auto t0 = std::chrono::steady_clock::now();
+          if (svdss_bam_store_create(0, cap, initial, &store) != SVDSS_OK) store = nullptr;
+          store_alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+      }
+    }
     // ---- parse_sfsfile (sfs.cpp:5-30)
     // (csrc/sfs_file.h: the file mapped and parsed by T threads; a file that cannot be opened leaves the map empty, as
     // the reference's ifstream does)
@@ -593,14 +616,11 @@ struct CallRun {
           filters.push_back(f);
           devs.push_back(d);
         }
-        // One GPU: the slim form of every record that passes the flag / mapq filters stays in its HBM for pass 2 (up to
-        // SVDSS_CALL_STORE_GB, default 160: a 30x human sample is ~50 GB; more than fits: the file is read again, as before).
-        // SVDSS_CALL_STORE=0: two passes over the file.
+        // One GPU: the slim form of every record that passes the flag / mapq filters stays in its HBM for pass 2
+        // (load_inputs took the memory).  SVDSS_CALL_STORE=0: two passes over the file.
         DeviceBamSelect::RunFn run;
-        if (n_dev == 1 && !(getenv("SVDSS_CALL_STORE") && atoi(getenv("SVDSS_CALL_STORE")) == 0)) {
-          const int64_t gb = getenv("SVDSS_CALL_STORE_GB") && atoll(getenv("SVDSS_CALL_STORE_GB")) > 0 ? atoll(getenv("SVDSS_CALL_STORE_GB")) : 160;
-          const int64_t cap = getenv("SVDSS_CALL_STORE_MB") && atoll(getenv("SVDSS_CALL_STORE_MB")) > 0 ? atoll(getenv("SVDSS_CALL_STORE_MB")) << 20 : gb << 30;
-          check(svdss_bam_store_create(0, cap, &store), "svdss_bam_store_create");
+        if (store_alloc.joinable()) store_alloc.join();
+        if (store) {
           svdss_bam_filter_t* f0 = filters[0];
           svdss_bam_store_t* st0 = store;
           run = [f0, st0](svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, size_t, int32_t n_chunks, const uint8_t* const* comp,
@@ -620,8 +640,9 @@ struct CallRun {
         ref_names = bam_p->ref_names();
       }
       // the next record pass 1 looks at: 1 = record, 0 = end of file (errors end the run)
-      double pass1_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      double pass1_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pass1_wait_s = 0, pass1_join_s = 0;
       uint64_t pass1_batches = 0;
+      const auto pass1_t0 = std::chrono::steady_clock::now();
       std::unique_ptr<SelectedBatch> sel_cur;
       size_t sel_k = 0;
       const int bsize = std::max(T, (10000 / T) * T);   // config.hpp:69, config.cpp:106
@@ -669,7 +690,9 @@ struct CallRun {
           BamReader::RawView rr;
           if (sel) {
             while (!sel_cur || sel_k + 1 >= sel_cur->off.size()) {
+              const auto tw0 = std::chrono::steady_clock::now();
               sel_cur = sel->next();
+              pass1_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
               sel_k = 0;
               if (!sel_cur) break;
               n_records_seen += sel_cur->n_records;
@@ -683,7 +706,7 @@ struct CallRun {
             }
             const size_t at = (size_t)sel_cur->off[sel_k], end = (size_t)sel_cur->off[sel_k + 1];
             ++sel_k;
-            if (!view_of_record(sel_cur->bytes.data() + at, end - at, rr)) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": corrupt record"); }
+            if (!view_of_record(sel_cur->bytes.data() + at, end - at, rr, sel_cur->slim)) { if (worker.joinable()) worker.join(); die("error reading " + o.bam + ": corrupt record"); }
           } else {
           BamReader& bam = *bam_p;
           const int rc = bam.next_view(rr);
@@ -711,7 +734,11 @@ struct CallRun {
           BamReader::materialize(rr, r);
           batch.push_back(std::move(r));
         }
-        if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
+        {
+          const auto tj0 = std::chrono::steady_clock::now();
+          if (worker.joinable()) worker.join();   // batches are extended in order (per-thread output order, clusterer.cpp:129-141)
+          pass1_join_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tj0).count();
+        }
         // the T slices of the reference's OpenMP loop (clusterer.cpp:129-141), one worker each: the same records in
         // the same order per slice
         worker = std::thread([this, &per_thread, &per_thread_clips, &batch, &dref, &tid_map, &set_up_reference]() {
@@ -774,10 +801,14 @@ struct CallRun {
       if (worker.joinable()) worker.join();
       set_up_reference();   // (an input without a single batch: the later stages still want the chromosomes)
       if (sel && pass1_batches) {
-        char buf[320];
+        char buf[480];
         snprintf(buf, sizeof buf, "pass 1 on the device: %llu batches, %llu records; feeder seconds summed: upload+inflate+crc+walk %.3f, turn wait %.3f, turn %.3f, "
                  "select+scans%s %.3f, records down %.3f (inflate kernels %.3f)", (unsigned long long)pass1_batches, (unsigned long long)n_records_seen, pass1_stage[0],
                  pass1_stage[1], pass1_stage[2], store ? "+store" : "", pass1_stage[3], pass1_stage[6], pass1_stage[7]);
+        logmsg("debug", buf);
+        snprintf(buf, sizeof buf, "pass 1, this thread: %.3f s in all, %.3f s waiting for the device's batches, %.3f s waiting for the placement of the batch before; "
+                 "the record store's memory took %.3f s; the batcher waited %.3f s for the file's loaders, %.3f s for the feeding threads",
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - pass1_t0).count(), pass1_wait_s, pass1_join_s, store_alloc_s, sel->waited_for_file(), sel->waited_for_feeders());
         logmsg("debug", buf);
       }
       svdss_ref_free(dref);

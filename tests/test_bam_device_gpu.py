@@ -401,8 +401,13 @@ def test_one_pass_for_call_the_store_keeps_slim_records_for_the_second_pass(case
             del os.environ["SVDSS_STORE_ARENA_MB"]
         ok = [not (m[1] & (4 | 256 | 2048)) and m[2] >= min_mapq for m in metas]
         assert st["complete"] == 1 and st["stored_batches"] == st["batches"] > 5 and st["stored_records"] == sum(ok)
-        assert named == [b for b, m, k in zip(bodies, metas, ok) if k and m[0] in set(wanted)]
+        assert named == [sl for sl, m, k in zip(slims, metas, ok) if k and m[0] in set(wanted)] and all(st["named_slim"])
         want = [sl for sl, m, k in zip(slims, metas, ok) if k and any(m[3] < e and m[4] > s_ for _, s_, e in regions)]
         assert slim == want and 0 < len(want) < 300
     named, slim, st = bamdev.select_bam_store(data, wanted, regions, min_mapq=0, batch_bytes=40 << 10, max_store_bytes=1 << 16)
-    assert st["complete"] == 0 and slim == [] and len(named) > 0
+    assert st["complete"] == 0 and slim == []
+    # (the batches behind the one that did not fit come whole)
+    assert named == [(sl if f else b) for sl, b, m, f in zip([x for x, m in zip(slims, metas) if not (m[1] & (4 | 256 | 2048)) and m[0] in set(wanted)],
+                                                            [x for x, m in zip(bodies, metas) if not (m[1] & (4 | 256 | 2048)) and m[0] in set(wanted)],
+                                                            [m for m in metas if not (m[1] & (4 | 256 | 2048)) and m[0] in set(wanted)], st["named_slim"])]
+    assert 0 in st["named_slim"]

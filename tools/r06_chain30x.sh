@@ -22,7 +22,15 @@ if [ -n "${DIAG:-}" ]; then
   SVDSS_INDEX_VERBOSE=1 SVDSS_DEBUG=1 $EXE search --index $FMD --bam $SM --verbose > /dev/null 2> "$OUT/search.log"
   SVDSS_DEBUG=1 $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls2.vcf 2> "$OUT/call.log"
   cmp $W/calls2.vcf $W/calls.vcf && echo "VCF of the second call identical" >> "$OUT/files.txt"
-  SVDSS_CALL_PASS2=device $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls3.vcf 2> "$OUT/call_pass2_device.log"
+  for cfg in "SVDSS_CALL_STORE=0" "SVDSS_CALL_STORE_INITIAL_MB=2048" "SVDSS_X=1"; do
+    sleep 3
+    t0=$(date +%s%N)
+    env $cfg $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls4.vcf 2> "$OUT/call_cfg.log"
+    t1=$(date +%s%N)
+    echo "== $cfg: $(( (t1 - t0) / 1000000 )) ms wall; $(cmp $W/calls4.vcf $W/calls.vcf && echo same VCF)" >> "$OUT/call_cfgs.txt"
+    grep "pass 1\|pass 2\|record store" "$OUT/call_cfg.log" | cut -c1-400 >> "$OUT/call_cfgs.txt"
+  done
+  SVDSS_CALL_PASS2=device SVDSS_CALL_STORE=0 $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls3.vcf 2> "$OUT/call_pass2_device.log"
   cmp $W/calls3.vcf $W/calls.vcf && echo "VCF with pass 2 on the device identical (the generator's BAI agrees with the file)" >> "$OUT/files.txt"
 fi
 rm -rf "$W"
