@@ -372,6 +372,7 @@ typedef struct svdss_bam_store svdss_bam_store_t;
 int svdss_bam_store_create(int32_t device, int64_t max_bytes, int64_t initial_bytes, svdss_bam_store_t** out);
 void svdss_bam_store_free(svdss_bam_store_t* t);
 int64_t svdss_bam_store_batches(svdss_bam_store_t* t, int32_t* complete, int64_t* n_records, int64_t* n_bytes);
+int svdss_bam_store_reset(svdss_bam_store_t* t);   /* forget what is stored, keep the memory (a file region that runs again) */
 int svdss_bam_select_store_run(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, const svdss_bam_filter_t* f,
                                svdss_bam_store_t* store, int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,
                                const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,

@@ -105,6 +105,7 @@ SIGNATURES = {
     "svdss_bam_batch_run": (C.c_int, [_p, _i64, _i32, _i64, _p, _i32, _p, _p, _p, _p, _p, _i32, C.POINTER(_p)]),
     "svdss_bam_store_create": (C.c_int, [_i32, _i64, _i64, C.POINTER(_p)]),
     "svdss_bam_store_free": (None, [_p]),
+    "svdss_bam_store_reset": (C.c_int, [_p]),
     "svdss_bam_store_batches": (_i64, [_p, _p, _pi64, _pi64]),
     "svdss_bam_select_store_run": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _i32, _p, _p, _p, _p, _p, C.POINTER(_p)]),
     "svdss_bam_store_select": (C.c_int, [_p, _i64, _p, C.POINTER(_p)]),

@@ -1577,6 +1577,17 @@ extern "C" void svdss_bam_store_free(svdss_bam_store_t* t) {
   for (StoreArena& A : t->arenas) if (A.p) (void)hipFree(A.p);
   delete t;
 }
+// forget what is stored (the arenas stay): a region of the file that runs again (ShardedBamSelect, bam_device_select.h)
+extern "C" int svdss_bam_store_reset(svdss_bam_store_t* t) {
+  if (!t) return SVDSS_EINVAL;
+  std::lock_guard<std::mutex> lk(t->m);
+  t->batches.clear();
+  for (StoreArena& A : t->arenas) A.used = 0;
+  t->cur = 0;
+  t->n_records = 0; t->n_bytes = 0;
+  t->complete = true;
+  return SVDSS_OK;
+}
 extern "C" int64_t svdss_bam_store_batches(svdss_bam_store_t* t, int32_t* complete, int64_t* n_records, int64_t* n_bytes) {
   if (!t) return -1;
   std::lock_guard<std::mutex> lk(t->m);
@@ -1596,7 +1607,7 @@ static bool store_reserve(svdss_bam_store* t, int64_t seq, int64_t bytes, int64_
     if (t->cur < t->arenas.size()) break;
     if (t->ahead_running) { t->cv.wait(lk); continue; }      // (the thread that takes arenas ahead has not got this far yet)
     StoreArena A;
-    A.cap = std::max(t->arena_bytes, need);
+    A.cap = std::max(std::min(t->arena_bytes, t->max_bytes - t->allocated), need);     // (a small store -- a seam's -- takes small arenas)
     if (t->allocated + A.cap > t->max_bytes || hipMalloc((void**)&A.p, (size_t)A.cap) != hipSuccess) { (void)hipGetLastError(); t->complete = false; return false; }
     t->allocated += A.cap;
     t->arenas.push_back(A);

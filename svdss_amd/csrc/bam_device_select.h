@@ -3,6 +3,9 @@
 // a svdss_bam_filter_t keeps.  Scanner (loader threads) -> batcher -> feeding threads (one batch object each) -> ordered
 // output; the caller sees plain record bytes.
 #pragma once
+#include <sys/stat.h>
+
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -144,6 +147,8 @@ inline bool view_of_record(const uint8_t* rec, size_t avail, BamReader::RawView&
   return true;
 }
 
+struct BamSelectRegion { size_t begin = 0, end = 0; bool open_start = false, open_end = false; std::vector<uint8_t> carry; int loaders = 8; size_t pending = 64; };
+
 class DeviceBamSelect {
  public:
   // what a feeding thread does with a batch (default: svdss_bam_select_run with the device's filter) and how its result
@@ -154,19 +159,30 @@ class DeviceBamSelect {
                             svdss_bam_batch_t** batch)> RunFn;
   typedef std::function<void(const svdss_bam_batch_t*, SelectedBatch&)> CollectFn;
   // filters[d]: the filter on device d (one per GPU used); feeders: feeding threads per GPU
+  // A region of the file (ShardedBamSelect below): [begin, end) at member starts (end = 0: the file's end); open_start: the
+  // region begins inside a record nobody has located (svdss_bam_stream_region: the chain starts at a guess, to be proved at
+  // the seam); open_end: it may end inside one; carry: the incomplete record in front of it when the region runs from a known
+  // start; pending: batches that may wait for the caller (a later region's wait until the regions in front are done)
+  typedef BamSelectRegion Region;
   DeviceBamSelect(const std::string& path, const std::vector<svdss_bam_filter_t*>& filters, const std::vector<int>& devices, int32_t n_ref,
                   int64_t skip, int feeders, int64_t batch_bytes, RunFn run = RunFn(), CollectFn collect = CollectFn(),
-                  svdss_bam_stream_t* prepared_stream = nullptr)
-      : filters_(filters), devices_(devices), skip_(skip), target_(batch_bytes), run_(run), collect_(collect), stream_(prepared_stream) {
+                  svdss_bam_stream_t* prepared_stream = nullptr, const Region& region = Region())
+      : filters_(filters), devices_(devices), skip_(skip), target_(batch_bytes), run_(run), collect_(collect), stream_(prepared_stream),
+        max_pending_(region.pending) {
     BgzfScanner::Hooks hooks;
     hooks.host_alloc = svdss_host_alloc;
     hooks.host_free = svdss_host_free;
     const size_t slab = (getenv("SVDSS_BAM_SLAB_KB") && atoll(getenv("SVDSS_BAM_SLAB_KB")) >= 64 ? (size_t)atoll(getenv("SVDSS_BAM_SLAB_KB")) << 10 : (size_t)16 << 20);
     const size_t per_batch = (size_t)target_ / slab + 2;
     feeders = std::max(1, feeders);
-    sc_.reset(new BgzfScanner(path, hooks, slab, 8, 8 + ((size_t)filters.size() * (size_t)feeders + 3) * per_batch));
+    sc_.reset(new BgzfScanner(path, hooks, slab, region.loaders, (size_t)region.loaders + ((size_t)filters.size() * (size_t)feeders + 3) * per_batch, region.begin,
+                              region.end));
     if (!sc_->ok()) { err_ = "cannot open file"; finished_ = true; return; }
     if (!stream_ && svdss_bam_stream_create(n_ref, &stream_) != SVDSS_OK) { err_ = "out of memory"; finished_ = true; return; }
+    if (region.open_start || region.open_end || !region.carry.empty())
+      if (svdss_bam_stream_region(stream_, region.open_start ? 1 : 0, region.open_end ? 1 : 0, region.carry.data(), (int64_t)region.carry.size()) != SVDSS_OK) {
+        err_ = "out of memory"; finished_ = true; return;
+      }
     n_feeders_ = filters_.size() * (size_t)feeders;
     batcher_ = std::thread([this] { batch_loop(); });
     for (size_t d = 0; d < filters_.size(); ++d)
@@ -197,6 +213,17 @@ class DeviceBamSelect {
     return b;
   }
   const std::string& error() const { return err_; }
+  // blocks until batch 0 has had its turn (svdss_bam_stream_head is final), the file has ended or the run has failed
+  void wait_first() {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return want_ > 0 || done_.count(0) || !err_.empty() || finished_; });
+  }
+  // blocks until every feeding thread has ended (the stream's tail is final)
+  void wait_finished() {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return finished_; });
+  }
+  svdss_bam_stream_t* stream() const { return stream_; }
   // seconds the batcher waited for the file's loaders / for a feeding thread to take a batch (valid once the file has ended)
   double waited_for_file() const { return wait_file_s_; }
   double waited_for_feeders() const { return wait_feed_s_; }
@@ -294,7 +321,7 @@ class DeviceBamSelect {
       {
         std::unique_lock<std::mutex> lk(m_);
         const uint64_t sq = job->seq;
-        cv_.wait(lk, [&] { return stop_ || done_.size() < 64 || done_.begin()->first > sq; });   // (kept records are few: let the GPU run ahead)
+        cv_.wait(lk, [&] { return stop_ || done_.size() < max_pending_ || done_.begin()->first > sq; });   // (kept records are few: let the GPU run ahead)
         done_[sq] = std::move(out);
       }
       cv_.notify_all();
@@ -311,6 +338,7 @@ class DeviceBamSelect {
   std::vector<int> devices_;
   int64_t skip_ = 0, target_ = 0;
   double wait_file_s_ = 0, wait_feed_s_ = 0;
+  size_t max_pending_ = 64;
   RunFn run_;
   CollectFn collect_;
   std::unique_ptr<BgzfScanner> sc_;
@@ -324,5 +352,198 @@ class DeviceBamSelect {
   size_t feeders_done_ = 0, n_feeders_ = 0;
   std::map<uint64_t, std::unique_ptr<SelectedBatch>> done_;
   uint64_t want_ = 0;
+  std::string err_;
+};
+
+
+// where `n` regions of a file begin (member starts; [0] = 0, back() = file size): fewer than n for a small file
+// (SVDSS_REGION_MIN_KB, default 64 MB per region; SVDSS_REGION_SHARDS=0: one region)
+inline std::vector<size_t> plan_bam_regions(const std::string& path, int n, int64_t header_inflated) {
+  struct stat st;
+  std::vector<size_t> cuts{0};
+  if (stat(path.c_str(), &st) != 0 || st.st_size <= 0) return {0, 0};
+  const size_t fsize = (size_t)st.st_size;
+  const size_t min_bytes = getenv("SVDSS_REGION_MIN_KB") && atoll(getenv("SVDSS_REGION_MIN_KB")) > 0 ? (size_t)atoll(getenv("SVDSS_REGION_MIN_KB")) << 10
+                                                                                                         : (size_t)64 << 20;
+  // (the first region holds the whole BAM header)
+  const size_t first_min = (size_t)header_inflated + ((size_t)header_inflated >> 6) + ((size_t)128 << 10);
+  if (getenv("SVDSS_REGION_SHARDS") && atoi(getenv("SVDSS_REGION_SHARDS")) == 0) n = 1;
+  n = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, fsize / min_bytes));
+  for (int g = 1; g < n; ++g) {
+    const size_t approx = std::max(first_min, (size_t)((unsigned __int128)fsize * (unsigned)g / (unsigned)n));
+    if (approx >= fsize) break;
+    const size_t c = BgzfScanner::member_start_near(path, approx);
+    if (c > cuts.back() && c < fsize) cuts.push_back(c);
+  }
+  cuts.push_back(fsize);
+  return cuts;
+}
+
+// `SVDSS call --gpus N` (round 6; SURVEY 8(e): the BAM's regions partition across the GPUs): the file is cut at BGZF members
+// into one region per GPU, and every region has its own scanner (loader threads), batcher, feeding threads, record stream,
+// filter and -- when the caller keeps one -- record store: nothing is shared on the way in, as in `SVDSS search --gpus N`
+// (svdss_main.cpp).  A region that does not begin the file begins inside a record: its chain starts at a guess
+// (svdss_bam_stream_region) that is PROVED when the region in front has been handed out -- its leftover + the bytes this
+// region set aside must be a chain of whole records (the seam: a batch of its own through the same entry point); if they
+// are not, or the region failed in any way, it runs again from the known carry.  The caller sees the batches of the file in
+// file order, as from one DeviceBamSelect.
+class ShardedBamSelect {
+ public:
+  struct Shard { svdss_bam_filter_t* filter = nullptr; int device = 0; svdss_bam_store_t* store = nullptr; svdss_bam_store_t* seam_store = nullptr; };
+  ShardedBamSelect(const std::string& path, const std::vector<Shard>& shards, int32_t n_ref, int64_t skip, int feeders, int64_t batch_bytes,
+                   const std::vector<size_t>& cuts)
+      : path_(path), shards_(shards), n_ref_(n_ref), skip_(skip), feeders_(feeders), batch_bytes_(batch_bytes) {
+    const size_t n = cuts.size() - 1;
+    regions_.resize(n);
+    for (size_t g = 0; g < n; ++g) {
+      regions_[g].begin = cuts[g]; regions_[g].end = g + 1 < n ? cuts[g + 1] : 0;
+      launch(g, g > 0, std::vector<uint8_t>());
+    }
+  }
+  size_t n_regions() const { return regions_.size(); }
+  int64_t seams_run() const { return n_seams_; }
+  int64_t regions_run_again() const { return n_reruns_; }
+  // the store keys of the file's batches in file order: (shard, seam?) per region: the seam's store holds key 0
+  bool region_has_seam(size_t g) const { return regions_[g].seam_stored; }
+  int64_t region_batches(size_t g) const { return regions_[g].n_batches; }
+
+  std::unique_ptr<SelectedBatch> next() {
+    for (;;) {
+      if (cur_ >= regions_.size()) return nullptr;
+      Reg& R = regions_[cur_];
+      if (!R.entered) {
+        R.entered = true;
+        if (cur_ > 0 && !enter(cur_)) return nullptr;
+        if (R.seam) { std::unique_ptr<SelectedBatch> b = std::move(R.seam); return b; }
+      }
+      std::unique_ptr<SelectedBatch> b = R.sel->next();
+      if (b) { ++R.n_batches; return b; }
+      if (!R.sel->error().empty()) { err_ = R.sel->error(); return nullptr; }
+      ++cur_;
+    }
+  }
+  const std::string& error() const { return err_; }
+  double waited_for_file() const { double s = 0; for (const Reg& R : regions_) if (R.sel) s += R.sel->waited_for_file(); return s; }
+  double waited_for_feeders() const { double s = 0; for (const Reg& R : regions_) if (R.sel) s += R.sel->waited_for_feeders(); return s; }
+
+ private:
+  struct Reg {
+    size_t begin = 0, end = 0;
+    std::unique_ptr<DeviceBamSelect> sel;
+    std::unique_ptr<SelectedBatch> seam;
+    bool entered = false, seam_stored = false;
+    int64_t n_batches = 0;
+  };
+  DeviceBamSelect::RunFn run_fn(size_t g, svdss_bam_store_t* store) const {
+    svdss_bam_filter_t* f = shards_[g % shards_.size()].filter;
+    return [f, store](svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, size_t, int32_t n_chunks, const uint8_t* const* comp,
+                      const int64_t* comp_bytes, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
+                      svdss_bam_batch_t** batch) {
+      return svdss_bam_select_store_run(s, seq, is_last, skip, f, store, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, batch);
+    };
+  }
+  void launch(size_t g, bool open_start, const std::vector<uint8_t>& carry) {
+    const Shard& S = shards_[g % shards_.size()];
+    DeviceBamSelect::Region rg;
+    rg.begin = regions_[g].begin; rg.end = regions_[g].end;
+    rg.open_start = open_start; rg.open_end = g + 1 < regions_.size();
+    rg.carry = carry;
+    rg.loaders = regions_.size() > 1 ? std::max(2, 8 / (int)std::min<size_t>(regions_.size(), 4)) : 8;
+    rg.pending = g == 0 ? 64 : (size_t)1 << 30;       // (a later region's results wait in memory until the regions in front are handed out)
+    const std::vector<svdss_bam_filter_t*> one(1, S.filter);
+    const std::vector<int> dev(1, S.device);
+    regions_[g].sel.reset(new DeviceBamSelect(path_, one, dev, n_ref_, g == 0 ? skip_ : 0, feeders_, batch_bytes_, run_fn(g, S.store), DeviceBamSelect::CollectFn(),
+                                              nullptr, rg));
+  }
+  // the seam in front of region g, proved; false = the run has failed (err_)
+  bool enter(size_t g) {
+    Reg& P = regions_[g - 1];
+    Reg& R = regions_[g];
+    const Shard& S = shards_[g % shards_.size()];
+    P.sel->wait_finished();
+    const uint8_t *tail = nullptr, *head = nullptr;
+    const int64_t n_tail = svdss_bam_stream_tail(P.sel->stream(), &tail);
+    const std::vector<uint8_t> carry(tail, tail + (n_tail > 0 ? n_tail : 0));
+    R.sel->wait_first();
+    bool good = R.sel->error().empty();
+    if (good) {
+      const int64_t n_head = svdss_bam_stream_head(R.sel->stream(), &head);
+      if ((int64_t)carry.size() + n_head > 0) { good = run_seam(g, carry, head, n_head, S); ++n_seams_; }
+    }
+    if (!good) {
+      if (!err_.empty()) return false;
+      // not proved (or the region failed): once more, from the record the region in front ended in
+      R.sel->wait_finished();
+      R.sel.reset();
+      R.seam.reset();
+      if (S.store) svdss_bam_store_reset(S.store);
+      ++n_reruns_;
+      launch(g, false, carry);
+    }
+    P.sel.reset();       // (its stream's tail has been copied)
+    return true;
+  }
+  bool run_seam(size_t g, const std::vector<uint8_t>& tail, const uint8_t* head, int64_t n_head, const Shard& S) {
+    std::vector<uint8_t> bytes(tail);
+    if (n_head > 0) bytes.insert(bytes.end(), head, head + n_head);
+    std::vector<uint8_t> comp;
+    std::vector<svdss_bgzf_block_t> blk;
+    std::vector<uint32_t> crc;
+    for (size_t off = 0; off < bytes.size(); off += 0xff00) {
+      const size_t len = std::min<size_t>(0xff00, bytes.size() - off);
+      while (comp.size() & 15) comp.push_back(0);
+      svdss_bgzf_block_t b;
+      b.coff = (int64_t)comp.size(); b.clen = (int32_t)(5 + len); b.isize = (int32_t)len; b.uoff = 0;
+      comp.push_back(1);   // BFINAL, stored
+      comp.push_back((uint8_t)(len & 0xff)); comp.push_back((uint8_t)(len >> 8));
+      comp.push_back((uint8_t)(~len & 0xff)); comp.push_back((uint8_t)((~len >> 8) & 0xff));
+      comp.insert(comp.end(), bytes.begin() + (long)off, bytes.begin() + (long)(off + len));
+      blk.push_back(b);
+      crc.push_back(bgzf_crc32(bytes.data() + off, len));
+    }
+    comp.resize(comp.size() + 64);
+    svdss_bam_stream_t* st = nullptr;
+    if (svdss_bam_stream_create(n_ref_, &st) != SVDSS_OK) { err_ = "out of memory"; return false; }
+    svdss_bam_batch_t* batch = nullptr;
+    const uint8_t* cp = comp.data();
+    const int64_t cb = (int64_t)comp.size(), nb = (int64_t)blk.size();
+    const svdss_bgzf_block_t* bp = blk.data();
+    const uint32_t* rp = crc.data();
+    if (S.seam_store) svdss_bam_store_reset(S.seam_store);
+    const int rc = svdss_bam_select_store_run(st, 0, 1, 0, S.filter, S.seam_store, 1, &cp, &cb, &bp, &rp, &nb, &batch);
+    bool ok = rc == SVDSS_OK;
+    if (ok) {
+      std::unique_ptr<SelectedBatch> out(new SelectedBatch);
+      svdss_bam_selection_t r;
+      (void)svdss_bam_batch_selection(batch, &r);
+      out->n_records = (uint64_t)r.n_records;
+      out->slim = r.slim != 0;
+      out->off.assign(r.rec_off, r.rec_off + r.n_selected + 1);
+      out->bytes.assign(r.bytes, r.bytes + r.n_bytes);
+      regions_[g].seam = std::move(out);
+      regions_[g].seam_stored = S.seam_store != nullptr;
+    } else if (rc != SVDSS_EIO) {
+      err_ = std::string("seam: ") + svdss_strerror(rc) + " " + (batch ? svdss_bam_batch_error(batch) : "") + " " + svdss_last_hip_error();
+    }
+    if (batch) svdss_bam_batch_free(batch);
+    svdss_bam_stream_free(st);
+    return ok;
+  }
+  static uint32_t bgzf_crc32(const uint8_t* p, size_t n) {
+    static const std::vector<uint32_t> tab = [] { std::vector<uint32_t> t(256); for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u))); t[i] = c; } return t; }();
+    uint32_t c = 0xffffffffu;
+    for (size_t i = 0; i < n; ++i) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    return c ^ 0xffffffffu;
+  }
+
+  std::string path_;
+  std::vector<Shard> shards_;
+  int32_t n_ref_ = 0;
+  int64_t skip_ = 0;
+  int feeders_ = 3;
+  int64_t batch_bytes_ = 0;
+  std::vector<Reg> regions_;
+  size_t cur_ = 0;
+  int64_t n_seams_ = 0, n_reruns_ = 0;
   std::string err_;
 };

@@ -466,7 +466,13 @@ struct CallRun {
   // otherwise): SVDSS_CALL_CACHE_GB, default 40 % of MemAvailable, at most 64 GiB.
   std::thread fasta_loader;              // load_chromosomes, beside the SFS file and the start of pass 1
   // ONE pass over the BAM (round 6): what pass 2 needs of every record stays in HBM while pass 1 runs (svdss_bam_store_t)
-  svdss_bam_store_t* store = nullptr;
+  // (--gpus N: the file's regions, one per GPU, each with a store of its own in that GPU's HBM -- and a small one for the
+  // records of the seam in front of it; ShardedBamSelect, bam_device_select.h)
+  std::vector<svdss_bam_store_t*> stores, seam_stores;
+  std::vector<size_t> bam_cuts;            // where the regions begin (plan_bam_regions); one region: {0, file size}
+  std::vector<int64_t> region_batches;     // after pass 1: batches per region, and whether a seam batch precedes it
+  std::vector<char> region_seam;
+  int32_t n_ref_hdr = 0;
   std::thread store_alloc;
   double store_alloc_s = 0;
   void reference_ready() { if (fasta_loader.joinable()) fasta_loader.join(); }
@@ -536,23 +542,33 @@ struct CallRun {
         }
       });
     }
-    // the record store of the ONE pass over the BAM (round 6, align_and_extend / fill_clusters below): its memory is taken NOW,
-    // on a thread of its own, beside the FASTA and the SFS file -- tens of GB that the driver clears before it hands them out
+    // the record store(s) of the ONE pass over the BAM (round 6, align_and_extend / fill_clusters below): the memory is taken
+    // NOW, on a thread of its own, beside the FASTA and the SFS file -- tens of GB that the driver clears before it hands them out
     {
       const int n_phys = std::max(1, svdss_device_count());
       const int n_dev = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_phys));
       const bool dev_bam = svdss_device_count() > 0 && !(getenv("SVDSS_BAM_DEVICE") && atoi(getenv("SVDSS_BAM_DEVICE")) == 0);
-      if (dev_bam && n_dev == 1 && !(getenv("SVDSS_CALL_STORE") && atoi(getenv("SVDSS_CALL_STORE")) == 0)) {
-        // (up to SVDSS_CALL_STORE_GB, default 160: a 30x human sample is ~50 GB; more than fits: the file is read again, as
-        // before.  Expected size: the bases of the file, two per byte, + names and CIGARs -- at most ~2.5 x a well-compressed BAM)
+      if (dev_bam) {
+        std::string herr;
+        if (!bam_header_probe(o.bam, n_ref_hdr, bam_skip, herr, &ref_names)) die("cannot read " + o.bam + ": " + herr);
+        bam_cuts = plan_bam_regions(o.bam, n_dev, bam_skip);
+      }
+      if (dev_bam && !(getenv("SVDSS_CALL_STORE") && atoi(getenv("SVDSS_CALL_STORE")) == 0)) {
+        // (up to SVDSS_CALL_STORE_GB per GPU, default 160: a 30x human sample is ~50 GB; more than fits: the file is read again,
+        // as before.  Expected size: the bases of the file, two per byte, + names and CIGARs -- at most ~2.5 x a well-compressed BAM)
         const int64_t gb = getenv("SVDSS_CALL_STORE_GB") && atoll(getenv("SVDSS_CALL_STORE_GB")) > 0 ? atoll(getenv("SVDSS_CALL_STORE_GB")) : 160;
         const int64_t cap = getenv("SVDSS_CALL_STORE_MB") && atoll(getenv("SVDSS_CALL_STORE_MB")) > 0 ? atoll(getenv("SVDSS_CALL_STORE_MB")) << 20 : gb << 30;
-        struct stat stb;
-        const int64_t fsz = stat(o.bam.c_str(), &stb) == 0 ? (int64_t)stb.st_size : 0;
-        const int64_t initial = getenv("SVDSS_CALL_STORE_INITIAL_MB") ? atoll(getenv("SVDSS_CALL_STORE_INITIAL_MB")) << 20 : std::min(cap, fsz * 5 / 2 + ((int64_t)256 << 20));
-        store_alloc = std::thread([this, cap, initial] {
+        const size_t n_reg = bam_cuts.size() - 1;
+        stores.assign(n_reg, nullptr);
+        seam_stores.assign(n_reg, nullptr);
+        store_alloc = std::thread([this, cap, n_reg, n_phys] {
           const auto t0 = std::chrono::steady_clock::now();
-          if (svdss_bam_store_create(0, cap, initial, &store) != SVDSS_OK) store = nullptr;
+          for (size_t g = 0; g < n_reg; ++g) {
+            const int64_t rsz = (int64_t)(bam_cuts[g + 1] - bam_cuts[g]);
+            const int64_t initial = getenv("SVDSS_CALL_STORE_INITIAL_MB") ? atoll(getenv("SVDSS_CALL_STORE_INITIAL_MB")) << 20 : std::min(cap, rsz * 5 / 2 + ((int64_t)256 << 20));
+            if (svdss_bam_store_create((int32_t)(g % (size_t)n_phys), cap, initial, &stores[g]) != SVDSS_OK) stores[g] = nullptr;
+            if (g > 0 && svdss_bam_store_create((int32_t)(g % (size_t)n_phys), (int64_t)64 << 20, 0, &seam_stores[g]) != SVDSS_OK) seam_stores[g] = nullptr;
+          }
           store_alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         });
       }
@@ -595,41 +611,45 @@ struct CallRun {
       // SVDSS_BAM_DEVICE=0: the host reader (chunks inflated on the GPU or the host, records sliced here).
       const bool dev_bam = svdss_device_count() > 0 && !(getenv("SVDSS_BAM_DEVICE") && atoi(getenv("SVDSS_BAM_DEVICE")) == 0);
       std::unique_ptr<BamReader> bam_p;
-      std::unique_ptr<DeviceBamSelect> sel;
+      std::unique_ptr<ShardedBamSelect> sel;
       std::vector<svdss_bam_filter_t*> filters;
-      int32_t n_ref_hdr = 0;
       if (dev_bam) {
-        std::string herr;
-        if (!bam_header_probe(o.bam, n_ref_hdr, bam_skip, herr, &ref_names)) die("cannot read " + o.bam + ": " + herr);
+        if (bam_cuts.empty()) {      // (load_inputs probes the header; a caller that skipped it)
+          std::string herr;
+          if (!bam_header_probe(o.bam, n_ref_hdr, bam_skip, herr, &ref_names)) die("cannot read " + o.bam + ": " + herr);
+          bam_cuts = plan_bam_regions(o.bam, 1, bam_skip);
+        }
         std::string names;
         std::vector<int64_t> name_off(1, 0);
         for (const auto& kv : C.sfs) { names += kv.first; name_off.push_back((int64_t)names.size()); }
-        // (--gpus N: the batches of the file go to whichever GPU has a feeding thread free; SVDSS_GPUS_OVERSUBSCRIBE puts the N
-        // shards on the GPUs there are -- the code path of N devices on a one-GPU box)
-        const int n_phys = std::max(1, svdss_device_count());
-        const int n_dev = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_phys));
-        std::vector<int> devs;
-        for (int d = 0; d < n_dev; ++d) {
-          svdss_bam_filter_t* f = nullptr;
-          check(svdss_bam_filter_create(d % n_phys, (int32_t)std::min<unsigned>(o.min_mapq, 256u), n_ref_hdr, names.data(), name_off.data(), (int64_t)name_off.size() - 1,
-                                        nullptr, nullptr, nullptr, 0, &f), "svdss_bam_filter_create");
-          filters.push_back(f);
-          devs.push_back(d);
-        }
-        // One GPU: the slim form of every record that passes the flag / mapq filters stays in its HBM for pass 2
+        // --gpus N: the file's regions, one per GPU (SVDSS_GPUS_OVERSUBSCRIBE puts the N shards on the GPUs there are -- the code
+        // path of N devices on a one-GPU box): every region has its own scanner, batcher, feeding threads, record stream and
+        // filter; the slim form of every record that passes the flag / mapq filters stays in that GPU's HBM for pass 2
         // (load_inputs took the memory).  SVDSS_CALL_STORE=0: two passes over the file.
-        DeviceBamSelect::RunFn run;
+        const int n_phys = std::max(1, svdss_device_count());
+        const size_t n_reg = bam_cuts.size() - 1;
         if (store_alloc.joinable()) store_alloc.join();
-        if (store) {
-          svdss_bam_filter_t* f0 = filters[0];
-          svdss_bam_store_t* st0 = store;
-          run = [f0, st0](svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, size_t, int32_t n_chunks, const uint8_t* const* comp,
-                          const int64_t* comp_bytes, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
-                          svdss_bam_batch_t** batch) {
-            return svdss_bam_select_store_run(s, seq, is_last, skip, f0, st0, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, batch);
-          };
+        bool all_stores = !stores.empty();
+        for (svdss_bam_store_t* st : stores) all_stores = all_stores && st != nullptr;
+        for (size_t g = 1; g < seam_stores.size(); ++g) all_stores = all_stores && seam_stores[g] != nullptr;
+        if (!all_stores) {
+          for (svdss_bam_store_t* st : stores) svdss_bam_store_free(st);
+          for (svdss_bam_store_t* st : seam_stores) svdss_bam_store_free(st);
+          stores.clear(); seam_stores.clear();
         }
-        sel.reset(new DeviceBamSelect(o.bam, filters, devs, n_ref_hdr, bam_skip, bam_feeders(), bam_batch_bytes(), run));
+        std::vector<ShardedBamSelect::Shard> shards;
+        for (size_t g = 0; g < n_reg; ++g) {
+          svdss_bam_filter_t* f = nullptr;
+          check(svdss_bam_filter_create((int32_t)(g % (size_t)n_phys), (int32_t)std::min<unsigned>(o.min_mapq, 256u), n_ref_hdr, names.data(), name_off.data(),
+                                        (int64_t)name_off.size() - 1, nullptr, nullptr, nullptr, 0, &f), "svdss_bam_filter_create");
+          filters.push_back(f);
+          ShardedBamSelect::Shard sh;
+          sh.filter = f; sh.device = (int)(g % (size_t)n_phys);
+          sh.store = stores.empty() ? nullptr : stores[g];
+          sh.seam_store = seam_stores.empty() ? nullptr : seam_stores[g];
+          shards.push_back(sh);
+        }
+        sel.reset(new ShardedBamSelect(o.bam, shards, n_ref_hdr, bam_skip, bam_feeders(), bam_batch_bytes(), bam_cuts));
         cache_ok = false;
         dev_pass = true;
       } else {
@@ -800,11 +820,18 @@ struct CallRun {
       }
       if (worker.joinable()) worker.join();
       set_up_reference();   // (an input without a single batch: the later stages still want the chromosomes)
+      if (sel) {
+        region_batches.clear(); region_seam.clear();
+        for (size_t g = 0; g < sel->n_regions(); ++g) { region_batches.push_back(sel->region_batches(g)); region_seam.push_back(sel->region_has_seam(g) ? 1 : 0); }
+        if (sel->n_regions() > 1)
+          logmsg("debug", std::to_string(sel->n_regions()) + " regions of the file, one per GPU: " + std::to_string(sel->seams_run()) + " seam(s) run, " +
+                              std::to_string(sel->regions_run_again()) + " region(s) run again");
+      }
       if (sel && pass1_batches) {
         char buf[480];
         snprintf(buf, sizeof buf, "pass 1 on the device: %llu batches, %llu records; feeder seconds summed: upload+inflate+crc+walk %.3f, turn wait %.3f, turn %.3f, "
                  "select+scans%s %.3f, records down %.3f (inflate kernels %.3f)", (unsigned long long)pass1_batches, (unsigned long long)n_records_seen, pass1_stage[0],
-                 pass1_stage[1], pass1_stage[2], store ? "+store" : "", pass1_stage[3], pass1_stage[6], pass1_stage[7]);
+                 pass1_stage[1], pass1_stage[2], !stores.empty() ? "+store" : "", pass1_stage[3], pass1_stage[6], pass1_stage[7]);
         logmsg("debug", buf);
         snprintf(buf, sizeof buf, "pass 1, this thread: %.3f s in all, %.3f s waiting for the device's batches, %.3f s waiting for the placement of the batch before; "
                  "the record store's memory took %.3f s; the batcher waited %.3f s for the file's loaders, %.3f s for the feeding threads",
@@ -979,14 +1006,31 @@ struct CallRun {
         }
       };
       bool from_store = false;
-      if (store) {
-        // Round 6: the records are in HBM since pass 1 (svdss_bam_store_t).  Per stored batch a kernel keeps those that overlap
-        // a (merged) cluster region; they come down slim, in file order, and go through `process` on a few threads, what
-        // they do to the clusters applied batch after batch -- the order of the single scan.
-        int32_t complete = 0;
+      if (!stores.empty()) {
+        // Round 6: the records are in HBM since pass 1 (svdss_bam_store_t; --gpus N: the store of every region in its GPU's).
+        // Per stored batch a kernel keeps those that overlap a (merged) cluster region; they come down slim, in file order,
+        // and go through `process` on a few threads, what they do to the clusters applied batch after batch -- the order
+        // of the single scan.
+        struct Item { svdss_bam_store_t* st; int64_t key; size_t dev; };
+        std::vector<Item> items;
+        bool complete_all = true;
         int64_t n_rec_st = 0, n_bytes_st = 0;
-        const int64_t n_b = svdss_bam_store_batches(store, &complete, &n_rec_st, &n_bytes_st);
-        if (complete && n_b >= 0) {
+        const int n_phys = std::max(1, svdss_device_count());
+        for (size_t g = 0; g < stores.size(); ++g) {
+          int32_t complete = 0;
+          int64_t nr = 0, nb = 0;
+          if (g > 0 && g < region_seam.size() && region_seam[g]) {
+            (void)svdss_bam_store_batches(seam_stores[g], &complete, &nr, &nb);
+            complete_all = complete_all && complete;
+            n_rec_st += nr; n_bytes_st += nb;
+            items.push_back(Item{seam_stores[g], 0, g % (size_t)n_phys});
+          }
+          const int64_t n_b = svdss_bam_store_batches(stores[g], &complete, &nr, &nb);
+          complete_all = complete_all && complete && n_b == (g < region_batches.size() ? region_batches[g] : -1);
+          n_rec_st += nr; n_bytes_st += nb;
+          for (int64_t k = 0; k < n_b; ++k) items.push_back(Item{stores[g], k, g % (size_t)n_phys});
+        }
+        if (complete_all) {
           from_store = true;
           std::vector<int32_t> rt, rb, re;
           for (size_t t = 0; t < ref_names.size(); ++t) {
@@ -1001,27 +1045,29 @@ struct CallRun {
             if (ce >= 0) { rt.push_back((int32_t)t); rb.push_back((int32_t)cb); re.push_back((int32_t)ce); }
           }
           uint64_t n_down = 0, bytes_down = 0;
-          if (!rt.empty() && n_b > 0) {
-            svdss_bam_filter_t* f = nullptr;
-            check(svdss_bam_filter_create(0, (int32_t)std::min<unsigned>(o.min_mapq, 256u), (int32_t)ref_names.size(), nullptr, nullptr, 0, rt.data(), rb.data(),
-                                          re.data(), (int64_t)rt.size(), &f), "svdss_bam_filter_create");
-            std::vector<std::vector<Ev>> evs((size_t)n_b);
-            std::atomic<int64_t> next(0);
+          if (!rt.empty() && !items.empty()) {
+            std::vector<svdss_bam_filter_t*> rf((size_t)std::min<size_t>((size_t)n_phys, stores.size()), nullptr);   // the regions, on every GPU that holds a store
+            for (size_t d = 0; d < rf.size(); ++d)
+              check(svdss_bam_filter_create((int32_t)d, (int32_t)std::min<unsigned>(o.min_mapq, 256u), (int32_t)ref_names.size(), nullptr, nullptr, 0, rt.data(), rb.data(),
+                                            re.data(), (int64_t)rt.size(), &rf[d]), "svdss_bam_filter_create");
+            std::vector<std::vector<Ev>> evs(items.size());
+            std::atomic<size_t> next(0);
             std::atomic<uint64_t> a_down(0), a_bytes(0);
             std::mutex err_m;
             std::string err;
             auto work = [&]() {
-              svdss_bam_batch_t* batch = nullptr;
+              std::vector<svdss_bam_batch_t*> batch(rf.size(), nullptr);      // (a batch object belongs to one device)
               std::string nm;
               BamReader::RawView rr;
               for (;;) {
-                const int64_t k = next.fetch_add(1);
-                if (k >= n_b) break;
-                const int rc = svdss_bam_store_select(store, k, f, &batch);
+                const size_t k = next.fetch_add(1);
+                if (k >= items.size()) break;
+                const Item& it = items[k];
+                const int rc = svdss_bam_store_select(it.st, it.key, rf[it.dev], &batch[it.dev]);
                 if (rc != SVDSS_OK) { std::lock_guard<std::mutex> lk(err_m); if (err.empty()) err = std::string(svdss_strerror(rc)) + " " + svdss_last_hip_error(); break; }
                 svdss_bam_selection_t r;
-                (void)svdss_bam_batch_selection(batch, &r);
-                auto sink = [&](Ev& e) { evs[(size_t)k].push_back(std::move(e)); };
+                (void)svdss_bam_batch_selection(batch[it.dev], &r);
+                auto sink = [&](Ev& e) { evs[k].push_back(std::move(e)); };
                 for (int64_t i = 0; i < r.n_selected; ++i) {
                   if (!view_of_record(r.bytes + r.rec_off[i], (size_t)(r.rec_off[i + 1] - r.rec_off[i]), rr, true)) {
                     std::lock_guard<std::mutex> lk(err_m); if (err.empty()) err = "corrupt record in the store"; break;
@@ -1030,22 +1076,22 @@ struct CallRun {
                 }
                 a_down += (uint64_t)r.n_selected; a_bytes += (uint64_t)r.n_bytes;
               }
-              if (batch) svdss_bam_batch_free(batch);
+              for (svdss_bam_batch_t* b : batch) if (b) svdss_bam_batch_free(b);
             };
-            const size_t Wt = (size_t)std::max<int64_t>(1, std::min<int64_t>({(int64_t)effective_cpus(), (int64_t)8, n_b}));
+            const size_t Wt = std::max<size_t>(1, std::min<size_t>({(size_t)effective_cpus(), (size_t)8, items.size()}));
             std::vector<std::thread> pool;
             for (size_t w = 1; w < Wt; ++w) pool.emplace_back(work);
             work();
             for (std::thread& th : pool) th.join();
-            svdss_bam_filter_free(f);
+            for (svdss_bam_filter_t* f : rf) svdss_bam_filter_free(f);
             if (!err.empty()) die("pass 2 from the record store: " + err);
-            for (int64_t k = 0; k < n_b; ++k)
-              for (Ev& e : evs[(size_t)k]) apply(e);
+            for (size_t k = 0; k < items.size(); ++k)
+              for (Ev& e : evs[k]) apply(e);
             n_down = a_down.load(); bytes_down = a_bytes.load();
           }
           logmsg("debug", "pass 2 from the records kept in HBM: " + std::to_string(n_rec_st) + " records (" + std::to_string(n_bytes_st >> 20) + " MB) in " +
-                              std::to_string(n_b) + " batches, " + std::to_string(rt.size()) + " regions, " + std::to_string(n_down) + " records (" +
-                              std::to_string(bytes_down >> 20) + " MB) came down");
+                              std::to_string(items.size()) + " batches" + (stores.size() > 1 ? " of " + std::to_string(stores.size()) + " stores" : "") + ", " +
+                              std::to_string(rt.size()) + " regions, " + std::to_string(n_down) + " records (" + std::to_string(bytes_down >> 20) + " MB) came down");
         } else
           logmsg("debug", "the record store is incomplete (" + std::to_string(n_bytes_st >> 20) + " MB kept): pass 2 reads the file again");
         // (tens of GB of HBM stay allocated until the run ends: memory handed back is cleared by the driver beside whatever
@@ -1178,22 +1224,24 @@ struct CallRun {
           }
           if (!rt.empty()) {
             const int n_phys = std::max(1, svdss_device_count());
-            const int n_dev = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_phys));
+            if (bam_cuts.empty()) bam_cuts = plan_bam_regions(o.bam, 1, bam_skip);
             std::vector<svdss_bam_filter_t*> filters;
-            std::vector<int> devs;
-            for (int d = 0; d < n_dev; ++d) {
+            std::vector<ShardedBamSelect::Shard> shards;
+            for (size_t g = 0; g + 1 < bam_cuts.size(); ++g) {
               svdss_bam_filter_t* f = nullptr;
-              check(svdss_bam_filter_create(d % n_phys, (int32_t)std::min<unsigned>(o.min_mapq, 256u), (int32_t)ref_names.size(), nullptr, nullptr, 0, rt.data(),
-                                            rb.data(), re.data(), (int64_t)rt.size(), &f), "svdss_bam_filter_create");
+              check(svdss_bam_filter_create((int32_t)(g % (size_t)n_phys), (int32_t)std::min<unsigned>(o.min_mapq, 256u), (int32_t)ref_names.size(), nullptr, nullptr, 0,
+                                            rt.data(), rb.data(), re.data(), (int64_t)rt.size(), &f), "svdss_bam_filter_create");
               filters.push_back(f);
-              devs.push_back(d);
+              ShardedBamSelect::Shard sh;
+              sh.filter = f; sh.device = (int)(g % (size_t)n_phys);
+              shards.push_back(sh);
             }
             {
-              DeviceBamSelect sel(o.bam, filters, devs, (int32_t)ref_names.size(), bam_skip, bam_feeders(), bam_batch_bytes());
+              ShardedBamSelect sel(o.bam, shards, (int32_t)ref_names.size(), bam_skip, bam_feeders(), bam_batch_bytes(), bam_cuts);
               BamReader::RawView rr;
               while (std::unique_ptr<SelectedBatch> sb = sel.next())
                 for (size_t k = 0; k + 1 < sb->off.size(); ++k) {
-                  if (!view_of_record(sb->bytes.data() + sb->off[k], (size_t)(sb->off[k + 1] - sb->off[k]), rr)) die("error reading " + o.bam + ": corrupt record");
+                  if (!view_of_record(sb->bytes.data() + sb->off[k], (size_t)(sb->off[k + 1] - sb->off[k]), rr, sb->slim)) die("error reading " + o.bam + ": corrupt record");
                   process(rr, qname, apply);
                 }
               if (!sel.error().empty()) die("error reading " + o.bam + ": " + sel.error());
@@ -1523,7 +1571,11 @@ struct CallRun {
     logmsg("info", "Writing " + std::to_string(svs.size()) + " SVs.");
     stage("vcf");
     if (cache_release.joinable()) cache_release.join();
-    if (store && getenv("SVDSS_CLEAN_EXIT")) { svdss_bam_store_free(store); store = nullptr; }   // (otherwise the process ends with _exit)
+    if (getenv("SVDSS_CLEAN_EXIT")) {   // (otherwise the process ends with _exit)
+      for (svdss_bam_store_t* st : stores) svdss_bam_store_free(st);
+      for (svdss_bam_store_t* st : seam_stores) svdss_bam_store_free(st);
+      stores.clear(); seam_stores.clear();
+    }
     // ---- write_sam (caller.cpp:65-75): rows in the order of the reference's per-thread lists, each inserted at the
     // front of the global one (caller.cpp:18-22)
     if (!o.poa.empty()) {

@@ -394,27 +394,7 @@ struct BamRegion {
   std::string error;                         // open_start only: why the run failed (the region runs again)
 };
 
-// where `n` regions of a file begin (member starts; [0] = 0, back() = file size): fewer than n for a small file
-static std::vector<size_t> plan_bam_regions(const std::string& path, int n, int64_t header_inflated) {
-  struct stat st;
-  std::vector<size_t> cuts{0};
-  if (stat(path.c_str(), &st) != 0 || st.st_size <= 0) return {0, 0};
-  const size_t fsize = (size_t)st.st_size;
-  const size_t min_bytes = getenv("SVDSS_REGION_MIN_KB") && atoll(getenv("SVDSS_REGION_MIN_KB")) > 0 ? (size_t)atoll(getenv("SVDSS_REGION_MIN_KB")) << 10
-                                                                                                         : (size_t)64 << 20;
-  // (the first region holds the whole BAM header)
-  const size_t first_min = (size_t)header_inflated + ((size_t)header_inflated >> 6) + ((size_t)128 << 10);
-  if (getenv("SVDSS_REGION_SHARDS") && atoi(getenv("SVDSS_REGION_SHARDS")) == 0) n = 1;
-  n = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, fsize / min_bytes));
-  for (int g = 1; g < n; ++g) {
-    const size_t approx = std::max(first_min, (size_t)((unsigned __int128)fsize * (unsigned)g / (unsigned)n));
-    if (approx >= fsize) break;
-    const size_t c = BgzfScanner::member_start_near(path, approx);
-    if (c > cuts.back() && c < fsize) cuts.push_back(c);
-  }
-  cuts.push_back(fsize);
-  return cuts;
-}
+// (plan_bam_regions: bam_device_select.h -- where the regions of a file begin, shared with `SVDSS call --gpus N`)
 
 static void search_bam_device(const Options& o, const std::vector<svdss_index_t*>& replicas, std::vector<BamRegion>& regions,
                               const BgzfScanner::Hooks& hooks, size_t slab, int loaders, size_t pool_chunks, int32_t n_ref,

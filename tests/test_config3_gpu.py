@@ -73,6 +73,32 @@ def test_chr20_10x_end_to_end(tmp_path):
     r_g3 = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50", "--gpus", "3"],
                           capture_output=True, text=True, env=dict(os.environ, SVDSS_GPUS_OVERSUBSCRIBE="1", SVDSS_BAM_BATCH_MB="8", SVDSS_BAM_SLAB_KB="512"))
     assert r_g3.returncode == 0 and r_g3.stdout == vcf, r_g3.stderr[-400:]
+    # round 6: --gpus N cuts the file into N regions, each with its own scanner / batcher / feeders / record stream / filter /
+    # record store (ShardedBamSelect); a region's first record is guessed and proved at the seam.  SVDSS_REGION_TEST: 1 =
+    # every guess is no record (the regions fail and run again from the region before), 2 = the seams do not fit (the
+    # regions run again); with the stores (one pass) and without (two passes, both sharded)
+    import re
+    size_kb = os.path.getsize(bam) >> 10
+    for n, knob, store in ((3, None, True), (4, "1", True), (2, "2", True), (7, None, True), (3, None, False), (4, "1", False)):
+        env = {"SVDSS_GPUS_OVERSUBSCRIBE": "1", "SVDSS_BAM_BATCH_MB": "2", "SVDSS_BAM_SLAB_KB": "256", "SVDSS_REGION_MIN_KB": str(max(64, size_kb // 8)),
+               "SVDSS_STORE_ARENA_MB": "4", "SVDSS_CALL_STORE_INITIAL_MB": "4"}
+        if knob:
+            env["SVDSS_REGION_TEST"] = knob
+        if not store:
+            env["SVDSS_CALL_STORE"] = "0"
+            env["SVDSS_CALL_PASS2"] = "device"
+        r_sh = subprocess.run([BIN, "call", "--reference", fa, "--bam", bam, "--sfs", bam + ".sfs", "--threads", "4", "--min-sv-length", "50", "--gpus", str(n),
+                               "--verbose"], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r_sh.returncode == 0 and r_sh.stdout == vcf, (n, knob, store, r_sh.stderr[-600:])
+        m = re.search(r"(\d+) regions of the file, one per GPU: (\d+) seam\(s\) run, (\d+) region\(s\) run again", r_sh.stderr)
+        assert m and int(m.group(1)) == n, (n, knob, r_sh.stderr[-800:])
+        if knob is None:
+            assert m.group(3) == "0"
+        elif knob == "1":
+            assert m.group(3) == str(n - 1)
+        else:
+            assert int(m.group(3)) >= 1
+        assert ("pass 2 from the records kept in HBM" in r_sh.stderr) == store
     # the second BAM pass without the records of pass 1 in memory: the whole file again, or -- with a BAI index beside
     # the file, as the reference requires -- only the chunks the index names for the cluster regions (records here
     # straddle BGZF blocks, chunks start and end inside blocks): the same VCF

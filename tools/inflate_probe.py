@@ -1,5 +1,5 @@
 """Developer probe: throughput of the GPU BGZF inflate (svdss_bgzf_inflate) on BAM-like blocks.
-  python tools/inflate_probe.py [n_blocks] [level] [kind]     kind: bam (packed bases + random qualities) | binned | skew | text"""
+  python tools/inflate_probe.py [n_blocks] [level] [kind]     kind: bam (packed bases + random qualities) | binned | skew | absent | hifi | text"""
 import ctypes as C
 import sys
 import time
@@ -30,6 +30,22 @@ for i in range(uniq):
         pq = np.r_[np.full(93, 0.35 / 93) * np.linspace(0.05, 1.95, 93), 0.65]
         b = rng.choice(np.arange(94, dtype=np.uint8), p=pq / pq.sum(), size=43520)
         raw = np.concatenate([a, b]).tobytes()
+    elif kind in ("absent", "hifi"):
+        # whole BAM records as tools/chain_dataset.cpp writes them: core + name + ~90 CIGAR operations, 7,500 bytes of packed
+        # bases, then 15,000 qualities -- absent (0xff: what the chain's data set has) or HiFi-like (stretches at the top
+        # value, dips of a few bases): RUNS, which a deflate writer codes as matches of up to 258 bytes at distance 1
+        parts = []
+        while sum(len(p) for p in parts) < 65280:
+            hdr = rng.integers(0, 256, size=36 + 18 + 360, dtype=np.uint8)
+            a = rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88], dtype=np.uint8), size=7500)
+            if kind == "absent":
+                q = np.full(15000, 0xff, dtype=np.uint8)
+            else:
+                q = np.full(15000, 93, dtype=np.uint8)
+                for at in rng.integers(0, 14990, size=60):
+                    q[at:at + int(rng.integers(1, 9))] = rng.integers(5, 60, size=1, dtype=np.uint8)[0]
+            parts += [hdr, a, q]
+        raw = np.concatenate(parts).tobytes()[:65280]
     else:
         raw = (b"the quick brown fox jumps over the lazy dog %d. " % i * 1500)[:65280]
     c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
