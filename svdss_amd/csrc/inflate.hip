@@ -110,7 +110,7 @@ struct Lds {
 };
 
 #ifdef INF_COUNT
-// rounds, literals(unused), matches of rounds, one-symbol steps, deflate blocks, passes, lanes taken, walks, walk steps, matches of passes, of them one by one
+// rounds, literals(unused), matches of rounds, one-symbol steps, deflate blocks, passes, lanes taken, walks, walk steps, matches of passes, of them one by one, run fills of rounds
 __device__ unsigned long long g_inf_cnt[12];
 #define CNT(k, v) (cnt[k] += (v))
 #else
@@ -767,8 +767,35 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
         const bool onc0 = ((chain0 >> lane) & 1ull) != 0;
         const uint32_t x0 = onc0 ? outlen : 0u;
         const uint32_t incl = (uint32_t)wave_scan_add((int)x0);
-        const bool onc = onc0 && incl - x0 < (uint32_t)ROUND_MAX;
-        const unsigned long long chain = __ballot(onc);
+        bool onc = onc0 && incl - x0 < (uint32_t)ROUND_MAX;
+        unsigned long long chain = __ballot(onc);
+        // RUNS (round 6).  A stretch of equal bytes -- absent qualities are 15,000 x 0xff per record, HiFi qualities sit at
+        // their top value -- is a chain of matches of up to 258 bytes at distance 1, four or five bits each: a 288-bit piece
+        // of them decodes to more than the ring holds, so they always come here, where ROUND_MAX let a round take two or
+        // three of the ~14 that its 64 bit offsets hold, each copied by the wave through the ring (profiles/r06j_*: 89
+        // rounds per member of a BAM without qualities).  Now the round also takes the distance-1 matches that FOLLOW what it
+        // takes, as far as they go, and the run at its end -- those and the distance-1 matches it took anyway -- is written
+        // as ONE fill: everything in front of it goes to HBM, the bytes of the fill straight to HBM as 16-byte stores,
+        // and the ring gets its last WIN bytes.
+        const unsigned long long runm = __ballot(onc0 && kind == 1u && s.dist == 1u);
+        unsigned long long fillm = 0;
+        if (chain) {
+          const unsigned long long after = chain0 & ~chain;            // on the chain, beyond what the round takes (all above it)
+          const unsigned long long stop = after & ~runm;                // the first of them that is no run ends the extension
+          const unsigned long long ext = stop ? after & ((stop & (0ull - stop)) - 1ull) : after;
+          const unsigned long long taken = chain | ext;
+          const unsigned long long nonrun = taken & ~runm;
+          const unsigned long long suffix = nonrun ? ((63 - (int)__builtin_clzll(nonrun)) == 63 ? 0ull : taken & ~((2ull << (63 - (int)__builtin_clzll(nonrun))) - 1ull)) : taken;
+          if (suffix) {
+            const int g0 = (int)__builtin_ctzll(suffix), g1 = 63 - (int)__builtin_clzll(suffix);
+            const uint32_t flen = (uint32_t)__builtin_amdgcn_readlane((int)incl, g1) - ((uint32_t)__builtin_amdgcn_readlane((int)incl, g0) - (uint32_t)__builtin_amdgcn_readlane((int)x0, g0));
+            if (ext || flen >= 2u * 258u) {     // (a short run that the round takes anyway: the ring's way)
+              fillm = suffix;
+              chain = taken;
+              onc = ((taken >> lane) & 1ull) != 0;
+            }
+          }
+        }
         uint32_t off = 0, total = 0;
         bool slow = false;
         if (chain) {
@@ -783,13 +810,52 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
         if (__ballot(onc && kind == 1u && s.dist > opos)) { err = ST_DIST; break; }
         if (onc && kind == 0u) winb[opos & WM] = (uint8_t)s.val;
         // the matches, in order
-        unsigned long long mm = __ballot(onc && kind == 1u);
+        unsigned long long mm = __ballot(onc && kind == 1u) & ~fillm;
         while (mm) {
           const int h = (int)__builtin_ctzll(mm);
           mm &= mm - 1;
           CNT(2, 1);
           const uint32_t o = __builtin_amdgcn_readlane(opos, h), ml = __builtin_amdgcn_readlane(s.val, h), dd = __builtin_amdgcn_readlane(s.dist, h);
           copy_match(o, ml, dd, near_lo(o));
+        }
+        if (fillm) {
+          // the run at the round's end: [fo, wpos + total) all equal the byte in front of it
+          CNT(11, 1);
+          const uint32_t fo = (uint32_t)__builtin_amdgcn_readlane((int)opos, (int)__builtin_ctzll(fillm)), fend = wpos + total, flen = fend - fo;
+          const uint32_t v = winb[(fo - 1u) & WM];
+          const uint32_t v4 = v * 0x01010101u;
+          // everything in front of it to HBM (a flush leaves fewer than four bytes behind: those as bytes)
+          const uint32_t wkeep = wpos;
+          wpos = fo;
+          flush(false);
+          if ((uint32_t)lane < fo - flushed) o8[flushed + (uint32_t)lane] = winb[(flushed + (uint32_t)lane) & WM];
+          wpos = wkeep;
+          // the fill, straight to HBM: bytes up to a 16-byte boundary, 16-byte stores, bytes
+          {
+            uint8_t* const d = o8 + fo;
+            uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)d & 15u)) & 15u);
+            if (head > flen) head = flen;
+            if ((uint32_t)lane < head) d[lane] = (uint8_t)v;
+            const uint32_t n16 = (flen - head) >> 4;
+            uint4* const d16 = (uint4*)(d + head);
+            const uint4 vv = make_uint4(v4, v4, v4, v4);
+            for (uint32_t i = (uint32_t)lane; i < n16; i += 64u) d16[i] = vv;
+            const uint32_t done = head + (n16 << 4);
+            if ((uint32_t)lane < flen - done) d[done + (uint32_t)lane] = (uint8_t)v;
+          }
+          // the ring: the last min(flen, WIN) bytes of the fill
+          {
+            const uint32_t keep = flen < (uint32_t)WIN ? flen : (uint32_t)WIN;
+            const uint32_t r0 = fend - keep;
+            uint32_t head = (4u - (r0 & 3u)) & 3u;
+            if (head > keep) head = keep;
+            if ((uint32_t)lane < head) winb[(r0 + (uint32_t)lane) & WM] = (uint8_t)v;
+            const uint32_t n4 = (keep - head) >> 2;
+            for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) L.win[((r0 + head + 4u * i) & WM) >> 2] = v4;
+            const uint32_t done = head + (n4 << 2);
+            if ((uint32_t)lane < keep - done) winb[(r0 + done + (uint32_t)lane) & WM] = (uint8_t)v;
+          }
+          flushed = fend;
         }
         wpos += total;
         P += (uint64_t)off;
@@ -959,9 +1025,9 @@ extern "C" int svdss_bgzf_inflate(svdss_inflate_t** obj, int device, const uint8
     unsigned long long h[12];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_inf_cnt), sizeof h) == hipSuccess) {
       fprintf(stderr, "[inflate] per block: deflate blocks %.2f; passes %.1f (lanes taken %.1f, walks %.1f, walk steps %.0f, matches %.0f of them one by one %.0f); "
-                      "rounds %.0f (matches %.0f, one-symbol steps %.0f)\n",
+                      "rounds %.0f (matches %.0f, run fills %.1f, one-symbol steps %.0f)\n",
               (double)h[4] / n_blocks, (double)h[5] / n_blocks, (double)h[6] / n_blocks, (double)h[7] / n_blocks, (double)h[8] / n_blocks,
-              (double)h[9] / n_blocks, (double)h[10] / n_blocks, (double)h[0] / n_blocks, (double)h[2] / n_blocks, (double)h[3] / n_blocks);
+              (double)h[9] / n_blocks, (double)h[10] / n_blocks, (double)h[0] / n_blocks, (double)h[2] / n_blocks, (double)h[11] / n_blocks, (double)h[3] / n_blocks);
       memset(h, 0, sizeof h);
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inf_cnt), h, sizeof h);
     }

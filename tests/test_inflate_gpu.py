@@ -38,6 +38,28 @@ def _payloads(rng):
         rec += rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x48, 0x84, 0x88], dtype=np.uint8), size=l // 2).tobytes()
         rec += rng.integers(20, 60, size=l, dtype=np.uint8).tobytes()
     p["bam"] = bytes(rec)
+    # round 6: runs written as ONE fill by the round engine (csrc/inflate.hip): run lengths around every boundary of the
+    # path (2 x 258, the round's 512 bytes, the 4 KB ring, many rings), literals of 0 .. 40 bytes between them, runs at
+    # the stream's start and end, a run that ends exactly at the member's size; and BAM records without qualities
+    mixed = bytearray()
+    for k, n in enumerate([1, 2, 3, 257, 258, 259, 515, 516, 517, 600, 769, 770, 1000, 2047, 4093, 4094, 4095, 4096, 4097, 4098, 4099, 5000,
+                           8191, 8192, 8193, 12000]):
+        mixed += bytes([int(rng.integers(0, 256))]) * n
+        mixed += rng.integers(0, 256, size=int(rng.integers(0, 41)), dtype=np.uint8).tobytes()
+    p["runs_mixed"] = bytes(mixed[:65536])
+    p["run_start_end"] = b"\xff" * 20000 + rng.integers(0, 256, size=25000, dtype=np.uint8).tobytes() + b"\x07" * 20536
+    rec = bytearray()
+    for i in range(2):
+        l = 15000
+        rec += struct.pack("<iiiBBHHHiiii", 32 + 8 + 4 + l // 2 + l, 0, 1000 * i, 8, 60, 4680, 1, 0, l, -1, -1, 0)
+        rec += b"read%03d\0" % i + struct.pack("<I", l << 4)
+        rec += rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x48, 0x84, 0x88], dtype=np.uint8), size=l // 2).tobytes()
+        rec += b"\xff" * l
+    p["bam_absent_quals"] = bytes(rec)
+    q = np.full(60000, 93, dtype=np.uint8)
+    for at in rng.integers(0, 59990, size=300):
+        q[at:at + int(rng.integers(1, 9))] = int(rng.integers(5, 60))
+    p["hifi_quals"] = q.tobytes()
     return p
 
 
