@@ -805,6 +805,28 @@ __device__ __forceinline__ void inflate_member(Lds& L, const uint8_t* __restrict
           if (__builtin_amdgcn_readlane(kind, h) == 2u) eob = true;
           else if (off < 64u && total < (uint32_t)ROUND_MAX) slow = __builtin_amdgcn_readlane(kind, off) == 3u;
         } else slow = true;                                          // (the symbol at offset 0 itself)
+        // ... and the run goes on behind the round's 64 bit offsets: its symbols are all the SAME bits (one length code, one
+        // distance code, no extra bits that differ), so the lanes compare the nb bits at Q, Q + nb, Q + 2 nb, ... with the
+        // round's last symbol -- 64 symbols (16 KB of output) at once; a prefix code makes "the same bits" the same symbol
+        if (fillm && !eob && chain) {
+          const int h = 63 - (int)__builtin_clzll(chain);
+          const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)s.nbits, h), lh = (uint32_t)__builtin_amdgcn_readlane((int)s.val, h);
+          if (((fillm >> h) & 1ull) && nb <= 16u && lh > 0u) {
+            auto peek32 = [&](uint32_t pl) -> uint32_t {
+              const uint32_t di = pl >> 5;
+              return __builtin_amdgcn_alignbit(L.inb[(di + 1) & (INB / 4 - 1)], L.inb[di & (INB / 4 - 1)], pl & 31u);
+            };
+            const uint32_t mask = (1u << nb) - 1u;
+            const uint32_t pat = peek32((uint32_t)P + (uint32_t)h) & mask;
+            const bool same = (peek32((uint32_t)P + off + (uint32_t)lane * nb) & mask) == pat;
+            const unsigned long long diff = ~__ballot(same);
+            uint32_t rep = diff ? (uint32_t)__builtin_ctzll(diff) : 64u;
+            const uint32_t room = wpos + total <= isize ? (isize - (wpos + total)) / lh : 0u;
+            if (rep > room) rep = room;
+            total += rep * lh;
+            off += rep * nb;
+          }
+        }
         const uint32_t opos = wpos + (incl - x0);
         if (wpos + total > isize) { err = ST_OUT; break; }
         if (__ballot(onc && kind == 1u && s.dist > opos)) { err = ST_DIST; break; }
