@@ -876,6 +876,8 @@ def _run_search(exe, fmd, bam, env=None, repeats=1, pause_s=0.0):
     k = re.search(r"table of order (\d+): few reads to search", r.stderr)
     if k:
         out["kmer_table_order"] = int(k.group(1))
+    if "rank blocks alone" in r.stderr:
+        out["index_mode"] = "the rank blocks alone (few reads to search): no text, suffix array or k-mer table"
     if d:   # records handled on the GPU (csrc/bam_device.hip): only compressed bytes went up
         out.update({"path": "device (BAM records walked, filtered and unpacked on the GPU)", "device_batches": int(d.group(1)),
                     "record_chain_segments": int(d.group(2)), "segments_walked_again": int(d.group(3)),
@@ -902,7 +904,7 @@ def _search_leg(exe, fmd, bam, pause_s=5.0):
     r["whole_process_s"] = d[0]["whole_process_s"]
     r["whole_process_s_runs"] = [x["whole_process_s"] for x in d]
     r["whole_process_reads_per_s"] = d[0]["whole_process_reads_per_s"]
-    r["default_run"] = {k: d[0].get(k) for k in ("index_restore_s", "end_of_output_s", "whole_process_s", "front_end_beside_restore", "kmer_table_order")}
+    r["default_run"] = {k: d[0].get(k) for k in ("index_restore_s", "end_of_output_s", "whole_process_s", "front_end_beside_restore", "kmer_table_order", "index_mode")}
     r["streaming_is"] = "SVDSS_SEARCH_EARLY=0 (index first, then the file); whole_process_s is the default run (front end beside the index restore)"
     return r
 

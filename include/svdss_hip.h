@@ -89,6 +89,15 @@ int svdss_index_bwt(const svdss_index_t* ix, uint8_t* bwt_out);
 int64_t svdss_index_device_bytes(const svdss_index_t* ix);
 /* order K of the k-mer table built by svdss_index_to_device (0 before / without it) */
 int32_t svdss_index_kmer(const svdss_index_t* ix);
+/* The index as a rank structure alone.  `SVDSS index` leaves the rank blocks and '$' rows behind the records of its
+ * sidecar; svdss_index_attach_blocks (before svdss_index_to_device, on a handle svdss_index_load gave for the same path)
+ * makes them the handle's host side and drops the records: svdss_index_to_device then uploads ~n/2 bytes instead of
+ * rebuilding text, suffix array and k-mer table (rb3_fmi_restore, ping_pong.cpp:245, restores exactly this much: the
+ * reference searches with rank steps alone).  The search is then one rank step per rb3_fmd_extend -- about a million reads
+ * per second at GRCh38 lengths instead of 8 - 24 M, results identical -- which pays when few reads are searched.
+ * SVDSS_EINVAL: the file has no such section (restore as before). */
+int svdss_index_attach_blocks(svdss_index_t* ix, const char* path);
+int svdss_index_append_blocks(const svdss_index_t* ix, const char* path);   /* behind the records svdss_index_save_records wrote at `path` */
 /* An upper limit for the order of tables built FROM NOW ON (process-wide; 0 = none; an explicit SVDSS_KMER wins).  The
  * table's build time quarters per step down, the search kernel slows down by about a factor of two per step: a process that
  * restores the index for one input may learn, while the suffix array is still being sorted, that it has few reads to search

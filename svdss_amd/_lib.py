@@ -61,6 +61,8 @@ SIGNATURES = {
     "svdss_index_device_bytes": (_i64, [_p]),
     "svdss_index_kmer": (_i32, [_p]),
     "svdss_index_kmer_limit": (None, [_i32]),
+    "svdss_index_attach_blocks": (C.c_int, [_p, C.c_char_p]),
+    "svdss_index_append_blocks": (C.c_int, [_p, C.c_char_p]),
     "svdss_index_deep_frac": (C.c_double, [_p]),
     "svdss_index_to_device": (C.c_int, [_p, _i32]),
     "svdss_index_count": (_i64, [_p, _p, _i64]),

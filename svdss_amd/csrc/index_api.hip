@@ -168,6 +168,43 @@ extern "C" int svdss_index_save_records(const svdss_index_t* ix, const char* pat
   return svdss_index_save_records_host(ix, path);
 }
 
+// The index as a rank structure ALONE (round 6): the rank blocks and '$' rows that `SVDSS index` leaves behind the records
+// of its sidecar become this handle's host side, the records are dropped, and svdss_index_to_device then uploads 3 GB
+// instead of sorting six billion suffixes -- no text, no suffix array, no k-mer table: every extension is one rank step
+// (the reference's own cost, ~1 M reads/s at GRCh38 lengths against 8 - 24 M with the table), which is what a `search`
+// with few reads to search wants (svdss_main.cpp).  path: the index as svdss_index_load takes it (an .fmd: its sidecar).
+// SVDSS_EINVAL: no such section there (an older sidecar, a full-layout file, an imported .fmd): restore as before.
+extern "C" int svdss_index_append_blocks(const svdss_index_t* ix, const char* path) {
+  if (!ix || !path) return SVDSS_EINVAL;
+  { const int rc = materialize(ix); if (rc != SVDSS_OK) return rc; }      // (an index that holds records only: built first)
+  return svdss_index_append_blocks_host(ix, path);
+}
+
+extern "C" int svdss_index_attach_blocks(svdss_index_t* ix, const char* path) {
+  if (!ix || !path) return SVDSS_EINVAL;
+  if (ix->device >= 0) return SVDSS_EINVAL;          // (already resident)
+  std::string file = path;
+  if (rld0_is_fmd(path)) {
+    file += ".svdss";
+    struct stat a, c;
+    if (getenv("SVDSS_INDEX_NO_CACHE") || stat(path, &a) != 0 || stat(file.c_str(), &c) != 0 || c.st_mtime < a.st_mtime) return SVDSS_EINVAL;
+  }
+  svdss_index tmp;
+  const int rc = svdss_index_load_blocks_host(file.c_str(), &tmp);
+  if (rc != SVDSS_OK) return rc;
+  if (ix->n != 0 && (tmp.n != ix->n || memcmp(tmp.acc, ix->acc, sizeof tmp.acc) != 0)) return SVDSS_EINVAL;   // (not this index's)
+  ix->n = tmp.n;
+  memcpy(ix->acc, tmp.acc, sizeof ix->acc);
+  ix->n_contigs = tmp.n_contigs;
+  ix->sa_wide = tmp.sa_wide;
+  ix->blocks.swap(tmp.blocks);
+  ix->dollar.swap(tmp.dollar);
+  decltype(ix->records)().swap(ix->records);
+  ix->rec_lens.clear();
+  ix->text.clear(); ix->sa32.clear(); ix->sa64.clear();
+  return SVDSS_OK;
+}
+
 extern "C" int svdss_index_save_fmd(const svdss_index_t* ix, const char* path) {
   if (!ix || !path) return SVDSS_EINVAL;
   { const int rc = materialize(ix); if (rc != SVDSS_OK) return rc; }
@@ -385,6 +422,15 @@ static size_t table_bytes_for(int64_t n) {
 
 // the 4^K k-mer table of an index whose blocks, text and suffix array are resident
 static int build_table(svdss_index* ix) {
+  // (SVDSS_LF_ONLY=1, a measurement knob: the index as a rank structure alone -- no text, no suffix array, no table; every
+  // extension is one rank step, the reference's own cost model)
+  if (getenv("SVDSS_LF_ONLY")) {
+    if (ix->d_text) { (void)hipFree(ix->d_text); ix->d_text = nullptr; }
+    if (ix->d_sa) { (void)hipFree(ix->d_sa); ix->d_sa = nullptr; }
+    if (ix->d_table) { (void)hipFree(ix->d_table); ix->d_table = nullptr; ix->d_table_cap = 0; }
+    ix->table_k = 0;
+    return SVDSS_OK;
+  }
   const bool wide = ix->sa_wide;
   int k = auto_kmer(ix->n);
   // Memory allocated ahead for this table (and lent to the suffix sort meanwhile, index_gpu.hip) was sized for the order

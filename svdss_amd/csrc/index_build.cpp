@@ -281,6 +281,8 @@ struct RecHeader {
 };
 }  // namespace
 
+static bool file_holds(FILE* f, uint64_t bytes);
+
 int svdss_index_save_records_host(const svdss_index* ix, const char* path) {
   RecHeader h;
   memset(&h, 0, sizeof h);
@@ -319,6 +321,73 @@ int svdss_index_save_records_host(const svdss_index* ix, const char* path) {
   ok = ok && (h.total == 0 || fwrite(rec, 1, (size_t)h.total, f) == (size_t)h.total);
   ok = (fclose(f) == 0) && ok;
   return ok ? SVDSS_OK : SVDSS_EIO;
+}
+
+// Round 6: behind the records of a file svdss_index_save_records_host wrote, the rank blocks and the '$' rows -- the index
+// as a rank structure alone ("SVDSSBK1": n_blocks, n_dollar, blocks, rows).  A `search` that has few reads to search (a
+// smoothed BAM: the putative filter leaves 1 - 7 % of them) makes THAT resident in a second instead of sorting six
+// billion suffixes for a text, a suffix array and a k-mer table it would hardly use (svdss_index_attach_blocks).  Older
+// readers stop at the records; a file without the section restores as before.
+int svdss_index_append_blocks_host(const svdss_index* ix, const char* path) {
+  if (ix->blocks.empty() || (int64_t)ix->blocks.size() != 4 * (ix->n / SVDSS_BLOCK_SYMS + 1)) return SVDSS_EINVAL;
+  FILE* f = fopen(path, "ab");
+  if (!f) return SVDSS_EIO;
+  const int64_t nb = ix->n / SVDSS_BLOCK_SYMS + 1, nd = (int64_t)ix->dollar.size();
+  bool ok = fwrite("SVDSSBK1", 1, 8, f) == 8 && fwrite(&nb, 8, 1, f) == 1 && fwrite(&nd, 8, 1, f) == 1;
+  ok = ok && fwrite(ix->blocks.data(), sizeof(svdss_u4), ix->blocks.size(), f) == ix->blocks.size();
+  ok = ok && (nd == 0 || fwrite(ix->dollar.data(), 8, (size_t)nd, f) == (size_t)nd);
+  ok = (fclose(f) == 0) && ok;
+  return ok ? SVDSS_OK : SVDSS_EIO;
+}
+
+// the "SVDSSBK1" section of a records file into ix->blocks / ix->dollar (ix->n, acc, n_contigs as the records' header has
+// them); SVDSS_EINVAL: the file has no such section
+int svdss_index_load_blocks_host(const char* path, svdss_index* ix) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return SVDSS_EIO;
+  RecHeader h;
+  if (fread(&h, sizeof h, 1, f) != 1) { fclose(f); return SVDSS_EIO; }
+  if (memcmp(h.magic, "SVDSSRC1", 8) != 0) { fclose(f); return SVDSS_EINVAL; }       // (another layout: no such section)
+  if (h.n < 0 || h.total < 0 || h.n_contigs <= 0 || h.total > ((int64_t)1 << 46) || h.n != 2 * (h.total + h.n_contigs)) { fclose(f); return SVDSS_EIO; }
+  const off_t sec = (off_t)sizeof h + (off_t)h.n_contigs * 8 + (off_t)h.total;
+  char magic[8];
+  int64_t nb = 0, nd = 0;
+  if (fseeko(f, sec, SEEK_SET) != 0 || fread(magic, 1, 8, f) != 8 || memcmp(magic, "SVDSSBK1", 8) != 0 || fread(&nb, 8, 1, f) != 1 || fread(&nd, 8, 1, f) != 1) {
+    fclose(f);
+    return SVDSS_EINVAL;
+  }
+  if (nb != h.n / SVDSS_BLOCK_SYMS + 1 || nd < 0 || nd > h.n || !file_holds(f, (uint64_t)nb * 64 + (uint64_t)nd * 8)) { fclose(f); return SVDSS_EIO; }
+  try {
+    ix->blocks.resize((size_t)(4 * nb));
+    ix->dollar.resize((size_t)nd);
+  } catch (...) { fclose(f); return SVDSS_ENOMEM; }
+  const off_t at = ftello(f);
+  const int fd = fileno(f);
+  const int64_t total = nb * 64, piece = (int64_t)32 << 20, n_pieces = (total + piece - 1) / piece;
+  bool good = at >= 0;
+  uint8_t* dst = (uint8_t*)ix->blocks.data();
+#pragma omp parallel for reduction(&& : good) schedule(dynamic, 1) num_threads(std::min(omp_get_max_threads(), 32))
+  for (int64_t k = 0; k < n_pieces; ++k) {
+    const int64_t a = k * piece, b = std::min(total, a + piece);
+    int64_t got = a;
+    while (got < b) {
+      const ssize_t r = pread(fd, dst + got, (size_t)(b - got), at + (off_t)got);
+      if (r <= 0) break;
+      got += r;
+    }
+    good = good && got == b;
+  }
+  if (good && nd > 0) good = pread(fd, ix->dollar.data(), (size_t)nd * 8, at + (off_t)total) == (ssize_t)(nd * 8);
+  fclose(f);
+  if (!good) { ix->blocks.clear(); ix->dollar.clear(); return SVDSS_EIO; }
+  for (int64_t i = 0; i < nd; ++i) if (ix->dollar[(size_t)i] < 0 || ix->dollar[(size_t)i] >= h.n || (i > 0 && ix->dollar[(size_t)i] <= ix->dollar[(size_t)i - 1])) {
+    ix->blocks.clear(); ix->dollar.clear(); return SVDSS_EIO;
+  }
+  ix->n = h.n;
+  memcpy(ix->acc, h.acc, sizeof h.acc);
+  ix->n_contigs = h.n_contigs;
+  ix->sa_wide = h.n >= (int64_t)0x7fffffff;
+  return SVDSS_OK;
 }
 
 // true if the file has at least `bytes` more bytes: a header's sizes are believed only as far as the file goes

@@ -57,6 +57,9 @@ int svdss_index_save_host(const svdss_index* ix, const char* path);
 // the records file ("SVDSSRC1": n, acc, record lengths, nt6 records): what `SVDSS index` leaves beside the .fmd
 int svdss_index_save_records_host(const svdss_index* ix, const char* path);
 int svdss_index_load_records_host(const char* path, svdss_index* ix);
+// the rank blocks and '$' rows a records file may carry behind the records (round 6): the index as a rank structure alone
+int svdss_index_append_blocks_host(const svdss_index* ix, const char* path);
+int svdss_index_load_blocks_host(const char* path, svdss_index* ix);
 // true when *ix holds records only (restored from a records file, nothing built yet)
 inline bool svdss_index_is_lazy(const svdss_index* ix) { return ix->blocks.empty() && !ix->rec_lens.empty(); }
 int svdss_index_load_host(const char* path, svdss_index* ix);

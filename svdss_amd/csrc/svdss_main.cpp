@@ -181,7 +181,12 @@ static int main_index(int argc, char** argv) {
   const bool records_side = !getenv("SVDSS_INDEX_NO_CACHE") && !getenv("SVDSS_INDEX_FULL");
   // (an older sidecar must not outlive a failed rewrite of its .fmd: it goes first, and a failure takes the .tmp with it)
   if (!getenv("SVDSS_INDEX_NO_CACHE")) (void)unlink((out + ".svdss").c_str());
-  if (records_side) side = std::thread([&] { rc_side = svdss_index_save_records(ix, (out + ".svdss.tmp").c_str()); });
+  // (round 6: behind the records the rank blocks -- the index as a rank structure alone, what a `search` with few reads to
+  // search makes resident instead of rebuilding everything: svdss_index_attach_blocks; SVDSS_INDEX_NO_BLOCKS=1: records only)
+  if (records_side) side = std::thread([&] {
+    rc_side = svdss_index_save_records(ix, (out + ".svdss.tmp").c_str());
+    if (rc_side == SVDSS_OK && !getenv("SVDSS_INDEX_NO_BLOCKS")) rc_side = svdss_index_append_blocks(ix, (out + ".svdss.tmp").c_str());
+  });
   const int rc_fmd = svdss_index_save_fmd(ix, out.c_str());
   if (side.joinable()) side.join();
   if (rc_fmd != SVDSS_OK || rc_side != SVDSS_OK) (void)unlink((out + ".svdss.tmp").c_str());
@@ -375,6 +380,9 @@ struct EarlySearch {
   std::map<int64_t, std::vector<Pending>> by_group;     // under m
   // what the front end has seen so far (the order of the k-mer table is chosen from it: svdss_index_kmer_limit)
   std::atomic<int64_t> records{0}, searched{0}, comp_bytes{0}, index_n{0};
+  // (under m) every feeding thread has ended / a batch did not fit into the park: an index that is made resident early --
+  // the rank structure alone -- is held back until one of the two, so that the parked reads go in large launches
+  bool front_done = false, park_full = false;
   int64_t file_bytes = 0;
   int kmer_limit = 0;               // the last limit given (under m)
 };
@@ -553,7 +561,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
         }
         if (grp == -1) {
           // no room in the park (or it has just been closed): this batch waits here for the index
-          { std::unique_lock<std::mutex> lk(early->m); early->cv.wait(lk, [&] { return early->ready; }); ix = early->ix; }
+          { std::unique_lock<std::mutex> lk(early->m); early->park_full = true; early->cv.notify_all(); early->cv.wait(lk, [&] { return early->ready; }); ix = early->ix; }
           rc = svdss_bam_batch_search(batch, ix);
         }   // (grp == -2: nothing to search in this batch, its results are complete)
       }
@@ -851,6 +859,7 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     std::vector<std::thread> joiners;
     for (BamRegion& R : regions) joiners.emplace_back([&join_region, &R] { join_region(R); });
     for (std::thread& th : joiners) th.join();
+    if (early) { { std::lock_guard<std::mutex> lk(early->m); early->front_done = true; } early->cv.notify_all(); }
     if (drain.joinable()) {
       drain.join();
       { std::lock_guard<std::mutex> lk(dev_m); for (BamRegion& R : regions) R.finished = true; }
@@ -995,9 +1004,42 @@ int main_search(const Options& o) {
       }
     }
   }
+  // Few reads to search (the front end has seen enough to say: `search` on a smoothed BAM skips what `smooth` tagged XF != 0)
+  // and the sidecar carries the rank blocks: the index as a rank structure ALONE -- 3 GB uploaded instead of six billion
+  // suffixes sorted for a text, a suffix array and a k-mer table; ~1 M reads/s instead of 8 - 24 M, results identical
+  // (svdss_index_attach_blocks).  SVDSS_SEARCH_LF=0|1 forces the choice, SVDSS_SEARCH_LF_MAX moves the threshold (reads).
+  bool lf_only = false;
+  if (early && !getenv("SVDSS_KMER") && !(getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) == 0)) {
+    const bool forced = getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) != 0;
+    const auto w0 = std::chrono::steady_clock::now();
+    for (;;) {
+      bool done;
+      { std::lock_guard<std::mutex> lk(early->m); done = early->front_done; }
+      if (forced || done || early->records.load() >= 50000 || std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 1.5) break;
+      std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+    const int64_t recs = early->records.load(), srch = early->searched.load(), cb = early->comp_bytes.load();
+    double est = -1;
+    if (recs > 0 && cb > 0) est = (double)srch / (double)recs * ((double)recs * (double)early->file_bytes / (double)cb);
+    const double lf_max = getenv("SVDSS_SEARCH_LF_MAX") ? atof(getenv("SVDSS_SEARCH_LF_MAX")) : 2e6;
+    if (forced || (est >= 0 && est <= lf_max)) {
+      const int rc = svdss_index_attach_blocks(ix, o.index.c_str());
+      if (rc == SVDSS_OK) {
+        lf_only = true;
+        if (o.verbose) logmsg("debug", "~" + std::to_string((long long)std::max(0.0, est)) + " reads to search: the index as a rank structure alone (blocks read at +" + since() + " s)");
+      } else if (rc != SVDSS_EINVAL) check(rc, "svdss_index_attach_blocks");
+    }
+  }
   check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
   if (o.verbose) logmsg("debug", "index and k-mer table on the device at +" + since() + " s" +
-                                     (early && svdss_index_kmer(ix) < 16 ? " (table of order " + std::to_string(svdss_index_kmer(ix)) + ": few reads to search)" : ""));
+                                     (lf_only ? " (rank blocks alone: few reads to search)"
+                                      : early && svdss_index_kmer(ix) < 16 ? " (table of order " + std::to_string(svdss_index_kmer(ix)) + ": few reads to search)" : ""));
+  if (early && lf_only) {
+    // (resident long before the file has been read: held back until the front end is through -- or the park is full -- so
+    // that what is parked goes in large launches, one lane per read, instead of a small segmented launch per batch)
+    std::unique_lock<std::mutex> lk(early->m);
+    early->cv.wait(lk, [&] { return early->front_done || early->park_full; });
+  }
   if (early) {
     logmsg("info", "Extracting SFS strings on the GPU (output order as with " + std::to_string(o.threads) + " threads)..");
     // (SVDSS_EARLY_HOLD_MS, for the tests: the index is held back that long, as if its restore had taken seconds)

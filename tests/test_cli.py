@@ -200,8 +200,12 @@ def test_index_writes_an_rld0_fmd_and_the_records_beside_it(tmp_path):
     r = run("index", "-t", "2", "-d", str(fa), "-o", str(fmd))
     assert r.returncode == 0, r.stderr
     assert fmd.read_bytes()[:4] == b"RLD\x03"
-    assert (tmp_path / "ref.fa.fmd.svdss").read_bytes()[:8] == b"SVDSSRC1"
-    assert os.path.getsize(tmp_path / "ref.fa.fmd.svdss") < 24000                  # ~1 byte per base, not 19
+    side = (tmp_path / "ref.fa.fmd.svdss").read_bytes()
+    assert side[:8] == b"SVDSSRC1"
+    # ~1 byte per base, not 19 -- and, since round 6, the rank blocks behind the records (64 bytes per 128 BWT symbols:
+    # another byte per base): the index as a rank structure alone, for a `search` with few reads to search
+    n_rec = 88 + 8 * 2 + 23000          # header, two record lengths, the records
+    assert side[n_rec:n_rec + 8] == b"SVDSSBK1" and len(side) < 2 * 24000 + 1000
     r = run("index", "-t", "2", "-d", str(fa), "-o", str(tmp_path / "full.fmd"), env=dict(os.environ, SVDSS_INDEX_FULL="1"))
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "full.fmd.svdss").read_bytes()[:8] == b"SVDSSFM2"
@@ -216,9 +220,22 @@ def test_index_writes_an_rld0_fmd_and_the_records_beside_it(tmp_path):
     assert (lazy.bwt() == want.bwt()).all() and lazy.count(ref[0][50:90]) == want.count(ref[0][50:90])
     assert (svdss_amd.FMDIndex.load(str(tmp_path / "full.fmd")).bwt() == want.bwt()).all()
     lazy.save_records(str(tmp_path / "again.rc"))
-    assert (tmp_path / "again.rc").read_bytes() == (tmp_path / "ref.fa.fmd.svdss").read_bytes()
+    assert (tmp_path / "again.rc").read_bytes() == side[:n_rec]
     want.save_records(str(tmp_path / "fromtext.rc"))                               # records out of the text
-    assert (tmp_path / "fromtext.rc").read_bytes() == (tmp_path / "ref.fa.fmd.svdss").read_bytes()
+    assert (tmp_path / "fromtext.rc").read_bytes() == side[:n_rec]
+    # the blocks section alone restores the rank structure: same BWT
+    from svdss_amd._lib import check
+    h = C.c_void_p()
+    check(lib.svdss_index_load(str(fmd).encode(), C.byref(h)), "load")
+    check(lib.svdss_index_attach_blocks(h, str(fmd).encode()), "attach")
+    got2 = np.zeros(want.size, np.uint8)
+    check(lib.svdss_index_bwt(h, got2.ctypes.data), "bwt")
+    assert (got2 == want.bwt()).all()
+    lib.svdss_index_free(h)
+    h = C.c_void_p()
+    check(lib.svdss_index_load(str(tmp_path / "full.fmd").encode(), C.byref(h)), "load")
+    assert lib.svdss_index_attach_blocks(h, str(tmp_path / "full.fmd").encode()) == 1      # SVDSS_EINVAL: a full layout has no such section
+    lib.svdss_index_free(h)
     os.remove(tmp_path / "ref.fa.fmd.svdss")
     back = svdss_amd.FMDIndex.load(str(fmd))                                       # through the rld0 import
     assert back.size == want.size and (back.acc == want.acc).all()
@@ -277,6 +294,45 @@ def test_search_bam_inflated_on_the_gpu_or_the_host_same_bytes(tmp_path):
         env = dict(os.environ, SVDSS_GPU_INFLATE=mode, SVDSS_BAM_DEVICE="0") if mode != "device" else dict(os.environ)
         r = run("search", "--index", str(fmd), "--bam", str(tmp_path / "bad.bam"), "--noputative", env=env)
         assert r.returncode == 1 and ("CRC" in r.stderr or "inflate" in r.stderr), (mode, r.stderr[-300:])
+
+
+@pytest.mark.gpu
+def test_search_with_the_rank_blocks_alone_writes_the_same_text(tmp_path):
+    """Round 6: a `search` that expects few reads to search makes the index resident as a rank structure alone
+    (svdss_index_attach_blocks: the blocks `SVDSS index` leaves behind the records; no text, suffix array or k-mer table).
+    Forced here both ways (SVDSS_SEARCH_LF=1 / 0) and left to the binary on a BAM in which one read in ten is to be
+    searched: the same text as the full index gives, putative and not; an index without the section (SVDSS_INDEX_NO_BLOCKS)
+    restores as before."""
+    ref, hap, svs, flat, offs = small_workload(seed=85, n_reads=600, read_len=3000, ref_lens=(150000, 40000))
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as fh:
+        for i, c in enumerate(ref):
+            fh.write(f">chr{i + 1}\n{synth.to_ascii(c)}\n")
+    fmd, fmd0 = tmp_path / "ref.fmd", tmp_path / "ref0.fmd"
+    assert run("index", "-d", str(fa), "-o", str(fmd)).returncode == 0
+    assert run("index", "-d", str(fa), "-o", str(fmd0), env=dict(os.environ, SVDSS_INDEX_NO_BLOCKS="1")).returncode == 0
+    assert os.path.getsize(str(fmd0) + ".svdss") < os.path.getsize(str(fmd) + ".svdss")
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(600):
+        rd = flat[offs[i]:offs[i + 1]]
+        recs.append(bam_writer.record(f"r{i:04d}", 0, 0, 100 + i, 60, [("M", len(rd))], synth.to_ascii(rd), [("XF", "C", 0 if i % 10 == 0 else 1)]))
+    bam = tmp_path / "reads.bam"
+    bam.write_bytes(bam_writer.bam([("chr1", 150000), ("chr2", 40000)], recs))
+    for extra in ((), ("--noputative",)):
+        base = run("search", "--index", str(fmd), "--bam", str(bam), "--threads", "4", "--bsize", "64", "--verbose", *extra,
+                   env=dict(os.environ, SVDSS_SEARCH_LF="0"))
+        assert base.returncode == 0 and "rank blocks alone" not in base.stderr and base.stdout.count("\n") > 50
+        for env in ({"SVDSS_SEARCH_LF": "1"}, {"SVDSS_SEARCH_LF": "1", "SVDSS_BAM_SLAB_KB": "64", "SVDSS_BAM_BATCH_MB": "1", "SVDSS_PARK_GROUP_READS": "50"},
+                    {"SVDSS_SEARCH_LF": "1", "SVDSS_BAM_SLAB_KB": "64", "SVDSS_BAM_BATCH_MB": "1", "SVDSS_PARK_MB": "1", "SVDSS_PARK_ARENA_MB": "1"}, {}):
+            r = run("search", "--index", str(fmd), "--bam", str(bam), "--threads", "4", "--bsize", "64", "--verbose", *extra, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-600:]
+            assert r.stdout == base.stdout, (extra, env)
+            if env:
+                assert "rank blocks alone" in r.stderr, r.stderr[-800:]
+        r0 = run("search", "--index", str(fmd0), "--bam", str(bam), "--threads", "4", "--bsize", "64", "--verbose", *extra,
+                 env=dict(os.environ, SVDSS_SEARCH_LF="1"))
+        assert r0.returncode == 0 and "rank blocks alone" not in r0.stderr and r0.stdout == base.stdout
 
 
 def test_fastx_reader_line_shapes(tmp_path, monkeypatch):

@@ -38,7 +38,7 @@ if [ -n "${DIAG2:-}" ]; then
   FA=$W/ref.fa; BAM=$W/reads.bam; SM=$W/smoothed.bam; FMD=$W/ref.fmd; SFS=$W/specifics.txt
   MD5=$(md5sum < $SM); rm -f $SM $W/calls2.vcf $W/calls3.vcf      # (/tmp is 79 GB: one smoothed BAM at a time)
   tm() { local what=$1; shift; sleep 3; local t0=$(date +%s%N); "$@"; local t1=$(date +%s%N); echo "$what: $(( (t1 - t0) / 1000000 )) ms wall" >> "$OUT/walls2.txt"; }
-  for cfg in "SVDSS_X=1" "SVDSS_SEARCH_FEEDERS=9" "SVDSS_SEARCH_FEEDERS=12" "SVDSS_BAM_BATCH_MB=128" "SVDSS_BAM_BATCH_MB=192 SVDSS_SEARCH_FEEDERS=8" "SVDSS_SMOOTH_WRITERS=8"; do
+  [ -n "${NO_SMOOTH_CFGS:-}" ] || for cfg in "SVDSS_X=1" "SVDSS_SEARCH_FEEDERS=9" "SVDSS_SEARCH_FEEDERS=12" "SVDSS_BAM_BATCH_MB=128" "SVDSS_BAM_BATCH_MB=192 SVDSS_SEARCH_FEEDERS=8" "SVDSS_SMOOTH_WRITERS=8"; do
     tm "smooth to a file [$cfg]" env SVDSS_DEBUG=1 $cfg $EXE smooth --reference $FA --bam $BAM --threads 16 > $W/sm2.bam 2> "$OUT/smooth_cfg.log"
     grep "device path" "$OUT/smooth_cfg.log" | cut -c1-400 >> "$OUT/walls2.txt"
   done
@@ -46,11 +46,12 @@ if [ -n "${DIAG2:-}" ]; then
   rm -f $W/sm2.bam
   tm "smooth to /dev/null" env SVDSS_DEBUG=1 $EXE smooth --reference $FA --bam $BAM --threads 16 2> "$OUT/smooth_null2.log" > /dev/null
   grep "device path" "$OUT/smooth_null2.log" | cut -c1-400 >> "$OUT/walls2.txt"
-  for cfg in "SVDSS_X=1" "SVDSS_CALL_FEEDERS=6" "SVDSS_CALL_FEEDERS=6 SVDSS_BAM_BATCH_MB=128" "SVDSS_CALL_FEEDERS=8 SVDSS_BAM_BATCH_MB=192"; do
+  for cfg in "SVDSS_X=1" "SVDSS_CALL_FEEDERS=4" "SVDSS_CALL_FEEDERS=6" "SVDSS_CALL_FEEDERS=6 SVDSS_BAM_BATCH_MB=128" "SVDSS_CALL_FEEDERS=5 SVDSS_BAM_BATCH_MB=192"; do
     tm "call [$cfg]" env $cfg $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls5.vcf 2> "$OUT/call_cfg2.log"
     echo "   $(cmp $W/calls5.vcf $W/calls.vcf && echo same VCF)" >> "$OUT/walls2.txt"
     grep "pass 1\|pass 2 " "$OUT/call_cfg2.log" | cut -c1-330 >> "$OUT/walls2.txt"
   done
+  [ -n "${NO_SMOOTH_CFGS:-}" ] && { rm -rf "$W"; exit 0; }
   export TMPDIR=/tmp
   ( cd /tmp && SVDSS_DEBUG=1 SVDSS_CLEAN_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_smooth -- $EXE smooth --reference $FA --bam $BAM --threads 16 > /dev/null 2> $OLDPWD/$OUT/smooth_prof.log )
   f=$(find /tmp/prof_smooth -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/smooth_kernel_stats.csv

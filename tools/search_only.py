@@ -32,7 +32,8 @@ ix = svdss_amd.FMDIndex.build(ref, device=0)
 starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
 ref_t = torch.from_numpy(ref[0] if len(ref) == 1 else np.concatenate(ref)).to(dev)
 del ref
-d_reads, d_offs = bench.simulate_reads_gpu(ref_t, [(int(s), int(l)) for s, l in zip(starts, lens)], n_reads, L, 0.005,
+err = float(os.environ.get("SEARCH_ONLY_ERR", "0.005"))
+d_reads, d_offs = bench.simulate_reads_gpu(ref_t, [(int(s), int(l)) for s, l in zip(starts, lens)], n_reads, L, err,
                                            seed=13, device=dev)
 del ref_t
 torch.cuda.synchronize()
