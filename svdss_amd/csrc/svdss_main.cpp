@@ -976,6 +976,7 @@ int main_search(const Options& o) {
   check(svdss_index_load(o.index.c_str(), &ix), "svdss_index_load");
   if (early) early->index_n.store(svdss_index_size(ix));
   if (o.verbose) logmsg("debug", "index file read at +" + since() + " s");
+  const bool user_kmer = getenv("SVDSS_KMER") != nullptr;      // (the block below may set the variable itself)
   if (!getenv("SVDSS_KMER")) {
     // The order K of the k-mer table trades its build time (4^K entries: 1.6 s at K = 16, a quarter of that per step
     // down) against the search kernel's speed (about a third slower per step down).  The library's own choice (K = 16
@@ -1009,7 +1010,7 @@ int main_search(const Options& o) {
   // suffixes sorted for a text, a suffix array and a k-mer table; ~1 M reads/s instead of 8 - 24 M, results identical
   // (svdss_index_attach_blocks).  SVDSS_SEARCH_LF=0|1 forces the choice, SVDSS_SEARCH_LF_MAX moves the threshold (reads).
   bool lf_only = false;
-  if (early && !getenv("SVDSS_KMER") && !(getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) == 0)) {
+  if (early && !user_kmer && !(getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) == 0)) {
     const bool forced = getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) != 0;
     const auto w0 = std::chrono::steady_clock::now();
     for (;;) {
