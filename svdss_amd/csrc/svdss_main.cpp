@@ -1020,14 +1020,18 @@ int main_search(const Options& o) {
       std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
     const int64_t recs = early->records.load(), srch = early->searched.load(), cb = early->comp_bytes.load();
+    const std::string t_est = since();
     double est = -1;
     if (recs > 0 && cb > 0) est = (double)srch / (double)recs * ((double)recs * (double)early->file_bytes / (double)cb);
-    const double lf_max = getenv("SVDSS_SEARCH_LF_MAX") ? atof(getenv("SVDSS_SEARCH_LF_MAX")) : 2e6;
+    // (what the rank structure alone saves is the rest of the restore -- ~4.5 s at GRCh38 lengths, in proportion for a
+    // smaller reference --, what it costs is the search at ~1 M reads/s instead of 8 - 24 M: worth it below ~2 M reads
+    // per 6.2e9 BWT symbols; profiles/r06q_*)
+    const double lf_max = getenv("SVDSS_SEARCH_LF_MAX") ? atof(getenv("SVDSS_SEARCH_LF_MAX")) : 2e6 * (double)svdss_index_size(ix) / 6.18e9;
     if (forced || (est >= 0 && est <= lf_max)) {
       const int rc = svdss_index_attach_blocks(ix, o.index.c_str());
       if (rc == SVDSS_OK) {
         lf_only = true;
-        if (o.verbose) logmsg("debug", "~" + std::to_string((long long)std::max(0.0, est)) + " reads to search: the index as a rank structure alone (blocks read at +" + since() + " s)");
+        if (o.verbose) logmsg("debug", "~" + std::to_string((long long)std::max(0.0, est)) + " reads to search (known at +" + t_est + " s): the index as a rank structure alone (blocks read at +" + since() + " s)");
       } else if (rc != SVDSS_EINVAL) check(rc, "svdss_index_attach_blocks");
     }
   }
