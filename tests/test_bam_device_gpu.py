@@ -265,7 +265,7 @@ def test_binary_device_path_writes_the_host_paths_bytes(case, tmp_path):
                     {"SVDSS_PARK_GROUP_READS": "100000"},
                     {"SVDSS_PARK_MB": "2", "SVDSS_PARK_ARENA_MB": "1", "SVDSS_PARK_GROUP_READS": "200"},
                     {"SVDSS_PARK_GROUP_READS": "7", "SVDSS_SEARCH_FEEDERS": "2"}):
-            ev = dict(env, SVDSS_EARLY_HOLD_MS="1500", SVDSS_BAM_SLAB_KB="64", SVDSS_BAM_BATCH_MB="1")
+            ev = dict(env, SVDSS_SEARCH_EARLY="1", SVDSS_EARLY_HOLD_MS="1500", SVDSS_BAM_SLAB_KB="64", SVDSS_BAM_BATCH_MB="1")
             early = run(ev, *extra)
             m = re.search(r"front end beside the index restore: (\d+) batches \((\d+) records\) .* their (\d+) reads searched in (\d+) launch", early.stderr)
             assert m and int(m.group(1)) >= 2 and int(m.group(4)) >= 1, early.stderr[-1500:]

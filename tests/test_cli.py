@@ -321,17 +321,17 @@ def test_search_with_the_rank_blocks_alone_writes_the_same_text(tmp_path):
     bam.write_bytes(bam_writer.bam([("chr1", 150000), ("chr2", 40000)], recs))
     for extra in ((), ("--noputative",)):
         base = run("search", "--index", str(fmd), "--bam", str(bam), "--threads", "4", "--bsize", "64", "--verbose", *extra,
-                   env=dict(os.environ, SVDSS_SEARCH_LF="0"))
+                   env=dict(os.environ, SVDSS_SEARCH_LF="0", SVDSS_SEARCH_EARLY="1"))
         assert base.returncode == 0 and "rank blocks alone" not in base.stderr and base.stdout.count("\n") > 50
         for env in ({"SVDSS_SEARCH_LF": "1"}, {"SVDSS_SEARCH_LF": "1", "SVDSS_BAM_SLAB_KB": "64", "SVDSS_BAM_BATCH_MB": "1", "SVDSS_PARK_GROUP_READS": "50"},
                     {"SVDSS_SEARCH_LF": "1", "SVDSS_BAM_SLAB_KB": "64", "SVDSS_BAM_BATCH_MB": "1", "SVDSS_PARK_MB": "1", "SVDSS_PARK_ARENA_MB": "1"}, {}):
-            r = run("search", "--index", str(fmd), "--bam", str(bam), "--threads", "4", "--bsize", "64", "--verbose", *extra, env=dict(os.environ, **env))
+            r = run("search", "--index", str(fmd), "--bam", str(bam), "--threads", "4", "--bsize", "64", "--verbose", *extra, env=dict(os.environ, SVDSS_SEARCH_EARLY="1", **env))
             assert r.returncode == 0, r.stderr[-600:]
             assert r.stdout == base.stdout, (extra, env)
             if env:
                 assert "rank blocks alone" in r.stderr, r.stderr[-800:]
         r0 = run("search", "--index", str(fmd0), "--bam", str(bam), "--threads", "4", "--bsize", "64", "--verbose", *extra,
-                 env=dict(os.environ, SVDSS_SEARCH_LF="1"))
+                 env=dict(os.environ, SVDSS_SEARCH_LF="1", SVDSS_SEARCH_EARLY="1"))
         assert r0.returncode == 0 and "rank blocks alone" not in r0.stderr and r0.stdout == base.stdout
 
 
