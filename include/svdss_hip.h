@@ -97,6 +97,7 @@ int32_t svdss_index_kmer(const svdss_index_t* ix);
  * per second at GRCh38 lengths instead of 8 - 24 M, results identical -- which pays when few reads are searched.
  * SVDSS_EINVAL: the file has no such section (restore as before). */
 int svdss_index_attach_blocks(svdss_index_t* ix, const char* path);
+int svdss_index_load_blocks(const char* path, svdss_index_t** out);       /* the same as a handle of its own: the records are never read */
 int svdss_index_append_blocks(const svdss_index_t* ix, const char* path);   /* behind the records svdss_index_save_records wrote at `path` */
 /* An upper limit for the order of tables built FROM NOW ON (process-wide; 0 = none; an explicit SVDSS_KMER wins).  The
  * table's build time quarters per step down, the search kernel slows down by about a factor of two per step: a process that
@@ -309,6 +310,7 @@ void svdss_bam_park_free(svdss_bam_park_t* p);
 int svdss_bam_park_close(svdss_bam_park_t* p);
 int64_t svdss_bam_park_groups(svdss_bam_park_t* p);
 int svdss_bam_park_group(svdss_bam_park_t* p, int64_t g, int64_t* n_batches, int64_t* n_reads, int64_t* n_syms);
+int32_t svdss_bam_park_group_ready(svdss_bam_park_t* p, int64_t g);   /* 1: closed and unpacked -- may be searched while later groups still fill */
 int svdss_bam_park_search(svdss_bam_park_t* p, int64_t g, const svdss_index_t* ix, int32_t flags, svdss_sfs_batch_t** sfs);
 int svdss_bam_batch_front(svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, int32_t device, svdss_bam_park_t* park,
                           int32_t n_chunks, const uint8_t* const* comp, const int64_t* comp_bytes,

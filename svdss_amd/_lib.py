@@ -62,6 +62,7 @@ SIGNATURES = {
     "svdss_index_kmer": (_i32, [_p]),
     "svdss_index_kmer_limit": (None, [_i32]),
     "svdss_index_attach_blocks": (C.c_int, [_p, C.c_char_p]),
+    "svdss_index_load_blocks": (C.c_int, [C.c_char_p, C.POINTER(_p)]),
     "svdss_index_append_blocks": (C.c_int, [_p, C.c_char_p]),
     "svdss_index_deep_frac": (C.c_double, [_p]),
     "svdss_index_to_device": (C.c_int, [_p, _i32]),
@@ -119,6 +120,7 @@ SIGNATURES = {
     "svdss_bam_park_close": (C.c_int, [_p]),
     "svdss_bam_park_groups": (_i64, [_p]),
     "svdss_bam_park_group": (C.c_int, [_p, _i64, _pi64, _pi64, _pi64]),
+    "svdss_bam_park_group_ready": (_i32, [_p, _i64]),
     "svdss_bam_park_search": (C.c_int, [_p, _i64, _p, _i32, C.POINTER(_p)]),
     "svdss_bam_batch_result": (C.c_int, [_p, _p]),
     "svdss_bam_smooth_create": (C.c_int, [_p, _p, C.c_int32, C.c_int32, _p]),

@@ -1191,6 +1191,13 @@ extern "C" int64_t svdss_bam_park_groups(svdss_bam_park_t* p) {
   return (int64_t)p->groups.size();
 }
 
+// 1: group g is closed and all its batches have unpacked (svdss_bam_park_search would not wait); 0: not yet, or no such group
+extern "C" int32_t svdss_bam_park_group_ready(svdss_bam_park_t* p, int64_t g) {
+  if (!p || g < 0) return 0;
+  std::lock_guard<std::mutex> lk(p->m);
+  return g < (int64_t)p->groups.size() && p->groups[(size_t)g].closed && p->groups[(size_t)g].pending == 0 ? 1 : 0;
+}
+
 extern "C" int svdss_bam_park_group(svdss_bam_park_t* p, int64_t g, int64_t* n_batches, int64_t* n_reads, int64_t* n_syms) {
   if (!p || g < 0) return SVDSS_EINVAL;
   std::lock_guard<std::mutex> lk(p->m);

@@ -205,6 +205,17 @@ extern "C" int svdss_index_attach_blocks(svdss_index_t* ix, const char* path) {
   return SVDSS_OK;
 }
 
+// the same as a handle of its own (svdss_index_load + svdss_index_attach_blocks without reading the records first)
+extern "C" int svdss_index_load_blocks(const char* path, svdss_index_t** out) {
+  if (!path || !out) return SVDSS_EINVAL;
+  svdss_index* ix = new (std::nothrow) svdss_index();
+  if (!ix) return SVDSS_ENOMEM;
+  const int rc = svdss_index_attach_blocks(ix, path);
+  if (rc != SVDSS_OK) { delete ix; return rc; }
+  *out = ix;
+  return SVDSS_OK;
+}
+
 extern "C" int svdss_index_save_fmd(const svdss_index_t* ix, const char* path) {
   if (!ix || !path) return SVDSS_EINVAL;
   { const int rc = materialize(ix); if (rc != SVDSS_OK) return rc; }

@@ -374,8 +374,10 @@ struct EarlySearch {
   svdss_bam_park_t* park = nullptr;
   std::mutex m;
   std::condition_variable cv;
-  svdss_index_t* ix = nullptr;      // set once, with `ready`
+  svdss_index_t* ix = nullptr;      // set once, with `ready` -- or before it, with `ix_avail`
   bool ready = false;
+  bool ix_avail = false;            // the index is resident but held back from the feeders (the rank blocks alone): the drain
+                                    // thread may search the groups that have closed while the later ones still fill
   struct Pending { BamRegion* R; uint64_t seq; std::unique_ptr<DevOut> out; int64_t first, n; };
   std::map<int64_t, std::vector<Pending>> by_group;     // under m
   // what the front end has seen so far (the order of the k-mer table is chosen from it: svdss_index_kmer_limit)
@@ -805,15 +807,28 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
     std::thread drain;
     if (early) drain = std::thread([&] {
       svdss_index_t* ix = nullptr;
-      { std::unique_lock<std::mutex> lk(early->m); early->cv.wait(lk, [&] { return early->ready; }); ix = early->ix; }
-      check(svdss_bam_park_close(early->park), "svdss_bam_park_close");
-      const int64_t n_groups = svdss_bam_park_groups(early->park);
+      { std::unique_lock<std::mutex> lk(early->m); early->cv.wait(lk, [&] { return early->ready || early->ix_avail; }); ix = early->ix; }
       svdss_sfs_batch_t* sfs = nullptr;
       std::vector<int64_t> counts, prefix;
       std::vector<int32_t> qs, ln;
-      int64_t n_parked = 0, n_parked_batches = 0;
+      int64_t n_parked = 0, n_parked_batches = 0, n_groups = 0, n_early_groups = 0;
       double t_search = 0;
-      for (int64_t g = 0; g < n_groups; ++g) {
+      bool closed = false;
+      for (int64_t g = 0;; ++g) {
+        // the next group: one that has closed while the index is held back from the feeders, or -- once the feeders have the
+        // index and the park is closed -- whatever is left
+        for (;;) {
+          if (!closed) {
+            bool rdy;
+            { std::lock_guard<std::mutex> lk(early->m); rdy = early->ready; }
+            if (rdy) { check(svdss_bam_park_close(early->park), "svdss_bam_park_close"); closed = true; n_groups = svdss_bam_park_groups(early->park); }
+          }
+          if (closed || svdss_bam_park_group_ready(early->park, g)) break;
+          std::unique_lock<std::mutex> lk(early->m);
+          early->cv.wait_for(lk, std::chrono::milliseconds(2));
+        }
+        if (closed && g >= n_groups) break;
+        if (!closed) ++n_early_groups;
         int64_t nb = 0, nr = 0, ns = 0;
         check(svdss_bam_park_group(early->park, g, &nb, &nr, &ns), "svdss_bam_park_group");
         const auto t0 = now();
@@ -854,7 +869,8 @@ static void search_bam_device(const Options& o, const std::vector<svdss_index_t*
       if (o.verbose)
         logmsg("debug", "front end beside the index restore: " + std::to_string(n_parked_batches) + " batches (" + std::to_string(early->records.load()) +
                             " records) had been read when the index was resident; their " + std::to_string(n_parked) + " reads searched in " +
-                            std::to_string(n_groups) + " launch(es), " + std::to_string(t_search) + " s, done at +" + since() + " s");
+                            std::to_string(n_groups) + " launch(es), " + std::to_string(t_search) + " s" +
+                            (n_early_groups ? " (" + std::to_string(n_early_groups) + " of them while the file was still being read)" : "") + ", done at +" + since() + " s");
     });
     std::vector<std::thread> joiners;
     for (BamRegion& R : regions) joiners.emplace_back([&join_region, &R] { join_region(R); });
@@ -983,6 +999,15 @@ int main_search(const Options& o) {
       search_bam_device(o, none, bam_regions, bam_hooks, bam_slab, bam_loaders, bam_pool_chunks, bam_n_ref, since, early.get());
     });
   }
+  // (the rank blocks of the sidecar are read beside the records, on a thread of their own, when the run may want them: the
+  // choice falls ~0.8 s into the process, and 3 GB from the page cache are 0.3 - 0.5 s that would otherwise follow it)
+  svdss_index_t* ix_blocks = nullptr;
+  int rc_blocks = SVDSS_EINVAL;
+  std::thread blocks_reader;
+  const bool user_kmer0 = getenv("SVDSS_KMER") != nullptr;
+  const bool lf_possible = early && !user_kmer0 && !(getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) == 0);
+  if (lf_possible && (o.putative || (getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) != 0) || early->file_bytes < ((int64_t)40 << 30)))
+    blocks_reader = std::thread([&] { rc_blocks = svdss_index_load_blocks(o.index.c_str(), &ix_blocks); });
   check(svdss_index_load(o.index.c_str(), &ix), "svdss_index_load");
   if (early) early->index_n.store(svdss_index_size(ix));
   if (o.verbose) logmsg("debug", "index file read at +" + since() + " s");
@@ -1038,13 +1063,18 @@ int main_search(const Options& o) {
     // per 6.2e9 BWT symbols; profiles/r06q_*)
     const double lf_max = getenv("SVDSS_SEARCH_LF_MAX") ? atof(getenv("SVDSS_SEARCH_LF_MAX")) : 2e6 * (double)svdss_index_size(ix) / 6.18e9;
     if (forced || (est >= 0 && est <= lf_max)) {
-      const int rc = svdss_index_attach_blocks(ix, o.index.c_str());
+      if (blocks_reader.joinable()) blocks_reader.join();
+      int rc = rc_blocks;
+      if (rc == SVDSS_OK && ix_blocks) { svdss_index_free(ix); ix = ix_blocks; ix_blocks = nullptr; }     // (read beside the records)
+      else rc = svdss_index_attach_blocks(ix, o.index.c_str());
       if (rc == SVDSS_OK) {
         lf_only = true;
         if (o.verbose) logmsg("debug", "~" + std::to_string((long long)std::max(0.0, est)) + " reads to search (known at +" + t_est + " s): the index as a rank structure alone (blocks read at +" + since() + " s)");
       } else if (rc != SVDSS_EINVAL) check(rc, "svdss_index_attach_blocks");
     }
   }
+  if (blocks_reader.joinable()) blocks_reader.join();
+  if (ix_blocks) { svdss_index_free(ix_blocks); ix_blocks = nullptr; }
   check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
   if (o.verbose) logmsg("debug", "index and k-mer table on the device at +" + since() + " s" +
                                      (lf_only ? " (rank blocks alone: few reads to search)"
@@ -1053,6 +1083,8 @@ int main_search(const Options& o) {
     // (resident long before the file has been read: held back until the front end is through -- or the park is full -- so
     // that what is parked goes in large launches, one lane per read, instead of a small segmented launch per batch)
     std::unique_lock<std::mutex> lk(early->m);
+    early->ix = ix; early->ix_avail = true;      // (the drain thread has it at once and searches the groups as they close)
+    early->cv.notify_all();
     early->cv.wait(lk, [&] { return early->front_done || early->park_full; });
   }
   if (early) {

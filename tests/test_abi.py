@@ -67,7 +67,7 @@ def test_null_arguments_are_refused_not_dereferenced():
     code = r'''
 import ctypes as C, sys
 from svdss_amd import _lib
-ok_zero = {"svdss_indel_ratio_batch", "svdss_nt6_encode", "svdss_stream_destroy", "svdss_device_count"}
+ok_zero = {"svdss_indel_ratio_batch", "svdss_nt6_encode", "svdss_stream_destroy", "svdss_device_count", "svdss_bam_park_group_ready"}
 for n in sorted(_lib.SIGNATURES):
     restype, argtypes = _lib.SIGNATURES[n]
     args = [a(0) if a in (C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_double) else None for a in argtypes]
