@@ -999,15 +999,9 @@ int main_search(const Options& o) {
       search_bam_device(o, none, bam_regions, bam_hooks, bam_slab, bam_loaders, bam_pool_chunks, bam_n_ref, since, early.get());
     });
   }
-  // (the rank blocks of the sidecar are read beside the records, on a thread of their own, when the run may want them: the
-  // choice falls ~0.8 s into the process, and 3 GB from the page cache are 0.3 - 0.5 s that would otherwise follow it)
-  svdss_index_t* ix_blocks = nullptr;
-  int rc_blocks = SVDSS_EINVAL;
-  std::thread blocks_reader;
-  const bool user_kmer0 = getenv("SVDSS_KMER") != nullptr;
-  const bool lf_possible = early && !user_kmer0 && !(getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) == 0);
-  if (lf_possible && (o.putative || (getenv("SVDSS_SEARCH_LF") && atoi(getenv("SVDSS_SEARCH_LF")) != 0) || early->file_bytes < ((int64_t)40 << 30)))
-    blocks_reader = std::thread([&] { rc_blocks = svdss_index_load_blocks(o.index.c_str(), &ix_blocks); });
+  // (Tried: the rank blocks of the sidecar read beside the records, on a thread of their own, so that they are in memory when
+  // the choice falls.  Two 3 GB reads and the front end's start share the process's cores: the front end's estimate came
+  // 0.4 s later and the blocks no sooner -- 5x `search` 2.4 -> 2.7 s.  They are read when they are wanted.)
   check(svdss_index_load(o.index.c_str(), &ix), "svdss_index_load");
   if (early) early->index_n.store(svdss_index_size(ix));
   if (o.verbose) logmsg("debug", "index file read at +" + since() + " s");
@@ -1063,18 +1057,13 @@ int main_search(const Options& o) {
     // per 6.2e9 BWT symbols; profiles/r06q_*)
     const double lf_max = getenv("SVDSS_SEARCH_LF_MAX") ? atof(getenv("SVDSS_SEARCH_LF_MAX")) : 2e6 * (double)svdss_index_size(ix) / 6.18e9;
     if (forced || (est >= 0 && est <= lf_max)) {
-      if (blocks_reader.joinable()) blocks_reader.join();
-      int rc = rc_blocks;
-      if (rc == SVDSS_OK && ix_blocks) { svdss_index_free(ix); ix = ix_blocks; ix_blocks = nullptr; }     // (read beside the records)
-      else rc = svdss_index_attach_blocks(ix, o.index.c_str());
+      const int rc = svdss_index_attach_blocks(ix, o.index.c_str());
       if (rc == SVDSS_OK) {
         lf_only = true;
         if (o.verbose) logmsg("debug", "~" + std::to_string((long long)std::max(0.0, est)) + " reads to search (known at +" + t_est + " s): the index as a rank structure alone (blocks read at +" + since() + " s)");
       } else if (rc != SVDSS_EINVAL) check(rc, "svdss_index_attach_blocks");
     }
   }
-  if (blocks_reader.joinable()) blocks_reader.join();
-  if (ix_blocks) { svdss_index_free(ix_blocks); ix_blocks = nullptr; }
   check(svdss_index_to_device(ix, 0), "svdss_index_to_device");
   if (o.verbose) logmsg("debug", "index and k-mer table on the device at +" + since() + " s" +
                                      (lf_only ? " (rank blocks alone: few reads to search)"
