@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6: is `smooth`'s output file slow because of where the bytes come from?  (page-locked coherent / non-coherent memory, writers)
+# NOTE: SVDSS_PIN_NONCOHERENT was a knob of the experiment's build (hipHostMallocNonCoherent in svdss_host_alloc); it made no difference and is gone.
 set -u
 TAG=${TAG:-r06v}; OUT=gpurun_out/$TAG; W=/tmp/svdss_sw
 cd "$(dirname "$0")/.."; mkdir -p $OUT $W
