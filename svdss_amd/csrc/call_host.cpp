@@ -751,7 +751,7 @@ struct CallRun {
           qname.assign((const char*)rr.name(), rr.l_name ? rr.l_name - 1 : 0);
           if (C.sfs.find(qname) == C.sfs.end()) continue;
           BamRecord r;
-          BamReader::materialize(rr, r);
+          BamReader::materialize(rr, r, false);   // (placement reads position, CIGAR and name: not the bases)
           batch.push_back(std::move(r));
         }
         {
