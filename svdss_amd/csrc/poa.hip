@@ -490,7 +490,9 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
   }
-  size_t ws_budget = (size_t)32 << 30;   // bytes of workspace per wave of launches
+  // bytes of workspace per wave of launches (SVDSS_POA_WS_GB, default 32: a whole genome's 21,500 sub-clusters want ~64 GB and
+  // run in two waves of ~75 ms; one wave needs an allocation that large on a device other processes have just left)
+  size_t ws_budget = (size_t)(getenv("SVDSS_POA_WS_GB") && atoll(getenv("SVDSS_POA_WS_GB")) > 0 ? atoll(getenv("SVDSS_POA_WS_GB")) : 32) << 30;
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws_budget = std::min(ws_budget, (free_b + b->ws_arena.cap) / 2);

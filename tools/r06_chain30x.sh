@@ -46,10 +46,10 @@ if [ -n "${DIAG2:-}" ]; then
   rm -f $W/sm2.bam
   tm "smooth to /dev/null" env SVDSS_DEBUG=1 $EXE smooth --reference $FA --bam $BAM --threads 16 2> "$OUT/smooth_null2.log" > /dev/null
   grep "device path" "$OUT/smooth_null2.log" | cut -c1-400 >> "$OUT/walls2.txt"
-  for cfg in "SVDSS_X=1" "SVDSS_CALL_FEEDERS=4" "SVDSS_CALL_FEEDERS=6" "SVDSS_CALL_FEEDERS=6 SVDSS_BAM_BATCH_MB=128" "SVDSS_CALL_FEEDERS=5 SVDSS_BAM_BATCH_MB=192"; do
+  for cfg in ${CALL_CFGS:-"SVDSS_X=1" "SVDSS_CALL_FEEDERS=4" "SVDSS_CALL_FEEDERS=6" "SVDSS_CALL_FEEDERS=6 SVDSS_BAM_BATCH_MB=128" "SVDSS_CALL_FEEDERS=5 SVDSS_BAM_BATCH_MB=192"}; do
     tm "call [$cfg]" env $cfg $EXE call --reference $FA --bam $BAM --sfs $SFS --threads 16 --min-sv-length 50 --verbose > $W/calls5.vcf 2> "$OUT/call_cfg2.log"
     echo "   $(cmp $W/calls5.vcf $W/calls.vcf && echo same VCF)" >> "$OUT/walls2.txt"
-    grep "pass 1\|pass 2 " "$OUT/call_cfg2.log" | cut -c1-330 >> "$OUT/walls2.txt"
+    grep "pass 1\|pass 2 \|POA\|poa\]" "$OUT/call_cfg2.log" | cut -c1-330 >> "$OUT/walls2.txt"
   done
   [ -n "${NO_SMOOTH_CFGS:-}" ] && { rm -rf "$W"; exit 0; }
   export TMPDIR=/tmp
