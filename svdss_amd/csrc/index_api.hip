@@ -440,10 +440,21 @@ static int build_table(svdss_index* ix) {
     if (ix->d_sa) { (void)hipFree(ix->d_sa); ix->d_sa = nullptr; }
     if (ix->d_table) { (void)hipFree(ix->d_table); ix->d_table = nullptr; ix->d_table_cap = 0; }
     ix->table_k = 0;
-    return SVDSS_OK;
   }
   const bool wide = ix->sa_wide;
+  // The rank structure alone (no text, no suffix array: svdss_index_attach_blocks) still gets a SMALL k-mer table: its
+  // entries need rank steps only (sv_table_entry: every K-mer that occurs becomes an interval, every absent one its fail
+  // depth), it is built in a few hundredths of a second (K = 13: 67 M keys x 13 steps) and takes the first K rank steps of
+  // every phase -- of ~18 at GRCh38 lengths -- off the search.  SVDSS_LF_KMER (0: none).
+  const bool rank_only = !ix->d_text || !ix->d_sa;
   int k = auto_kmer(ix->n);
+  if (rank_only) {
+    int lk = getenv("SVDSS_LF_KMER") ? atoi(getenv("SVDSS_LF_KMER")) : 13;
+    if (lk > 14) lk = 14;
+    while (lk > 0 && ((int64_t)1 << (2 * lk)) > ix->n) --lk;       // (not more keys than symbols)
+    k = lk < 0 ? 0 : lk;
+    if (ix->d_table) { (void)hipFree(ix->d_table); ix->d_table = nullptr; ix->d_table_cap = 0; }
+  }
   // Memory allocated ahead for this table (and lent to the suffix sort meanwhile, index_gpu.hip) was sized for the order
   // chosen THEN, with the device still empty: that order stands (asked again now, with the table's own bytes counted as
   // used, auto_kmer answers one less -- a 16 GiB table in a 64 GiB allocation and a search kernel 2.5 x slower).
@@ -453,12 +464,12 @@ static int build_table(svdss_index* ix) {
     k = kc;
   }
   // (a caller that has learnt meanwhile how little there is to search: svdss_index_kmer_limit)
-  if (const int lim = g_kmer_limit.load(); lim > 0 && k > lim && !getenv("SVDSS_KMER")) k = lim;
+  if (const int lim = g_kmer_limit.load(); lim > 0 && k > lim && !getenv("SVDSS_KMER") && !rank_only) k = lim;
   const bool ahead = ix->d_table && ix->table_k == 0 && k > 0 && ix->d_table_cap >= ((size_t)16 << (2 * k));
   if (ix->d_table && !ahead) { (void)hipFree(ix->d_table); ix->d_table = nullptr; }
   ix->table_k = 0;
   if (!ahead) ix->d_table_cap = 0;
-  if (k > 0 && ix->d_text && ix->d_sa) {
+  if (k > 0 && ((ix->d_text && ix->d_sa) || rank_only)) {
     const size_t tbytes = (size_t)16 << (2 * k);
     const bool verbose = getenv("SVDSS_INDEX_VERBOSE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
