@@ -972,13 +972,13 @@ int main_search(const Options& o) {
   std::unique_ptr<EarlySearch> early;
   std::thread early_stream;
   // (It pays when the restore takes seconds: an index of a chr20-length reference is resident in 0.4 s, and sharing the GPU
-  // with the front end meanwhile only delays it -- 1.87 against 1.55 s per 1.03 M reads, profiles/r06t_*.  The records of the
-  // sidecar are half the BWT's length: from 400 MB on -- ~0.8 G symbols, a restore of ~0.7 s -- the front end starts first;
+  // with the front end meanwhile only delays it -- 1.87 against 1.55 s per 1.03 M reads, profiles/r06t_*.  The sidecar holds
+  // a byte per BWT symbol (records + rank blocks): from 800 MB on -- ~0.8 G symbols, a restore of ~0.7 s -- the front end starts first;
   // SVDSS_SEARCH_EARLY=1 forces it, SVDSS_EARLY_MIN_MB moves the threshold.)
   bool early_pays = getenv("SVDSS_SEARCH_EARLY") && atoi(getenv("SVDSS_SEARCH_EARLY")) != 0;
   if (!early_pays) {
     struct stat sti;
-    const int64_t min_mb = getenv("SVDSS_EARLY_MIN_MB") ? atoll(getenv("SVDSS_EARLY_MIN_MB")) : 400;
+    const int64_t min_mb = getenv("SVDSS_EARLY_MIN_MB") ? atoll(getenv("SVDSS_EARLY_MIN_MB")) : 800;   // (records + rank blocks: a byte per BWT symbol)
     if (stat((o.index + ".svdss").c_str(), &sti) == 0 || stat(o.index.c_str(), &sti) == 0) early_pays = (int64_t)sti.st_size >= (min_mb << 20);
   }
   if (dev_bam && early_pays && bam_regions.size() == 1 && std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, std::max(1, svdss_device_count()))) == 1 &&
