@@ -24,8 +24,9 @@ $EXE index -d $W/ref.fa -o $W/ref.fmd > /dev/null 2>&1
 $EXE smooth --reference $W/ref.fa --bam $W/reads.bam --threads 16 > $W/smoothed.bam 2> /dev/null
 $EXE search --index $W/ref.fmd --bam $W/smoothed.bam > $W/specifics.txt 2> /dev/null
 cd /tmp
-for st in search call; do
+for st in smooth search call; do
   case $st in
+    smooth) CMD="$EXE smooth --reference $W/ref.fa --bam $W/reads.bam --threads 16" ;;
     search) CMD="$EXE search --index $W/ref.fmd --bam $W/smoothed.bam --verbose" ;;
     call) CMD="$EXE call --reference $W/ref.fa --bam $W/reads.bam --sfs $W/specifics.txt --threads 16 --min-sv-length 50 --verbose" ;;
   esac
