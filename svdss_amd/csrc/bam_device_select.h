@@ -338,11 +338,11 @@ class DeviceBamSelect {
   std::vector<int> devices_;
   int64_t skip_ = 0, target_ = 0;
   double wait_file_s_ = 0, wait_feed_s_ = 0;
-  size_t max_pending_ = 64;
   RunFn run_;
   CollectFn collect_;
   std::unique_ptr<BgzfScanner> sc_;
   svdss_bam_stream_t* stream_ = nullptr;
+  size_t max_pending_ = 64;
   std::thread batcher_;
   std::vector<std::thread> feeders_;
   std::mutex m_;
@@ -390,15 +390,40 @@ inline std::vector<size_t> plan_bam_regions(const std::string& path, int n, int6
 class ShardedBamSelect {
  public:
   struct Shard { svdss_bam_filter_t* filter = nullptr; int device = 0; svdss_bam_store_t* store = nullptr; svdss_bam_store_t* seam_store = nullptr; };
+  // What a region's batches go through (the select / store entry point below; `SVDSS smooth --gpus N`: svdss_bam_smooth_run).
+  // run(g, seam) / collect(g, seam): for the feeding threads of region g, or (seam = true) for the one batch of the seam in
+  // front of it, run on the caller's thread with is_last = 1; stream(g): a prepared record stream for region g's run (nullptr
+  // or no hook: a plain one) -- asked again if the region runs again; again(g): the region runs again (forget what its first
+  // run left); seam_kept(g): the seam's batch stays somewhere the caller looks for it (region_has_seam)
+  struct Hooks {
+    std::function<DeviceBamSelect::RunFn(size_t g, bool seam)> run;
+    std::function<DeviceBamSelect::CollectFn(size_t g, bool seam)> collect;
+    std::function<svdss_bam_stream_t*(size_t g)> stream;
+    std::function<void(size_t g)> again;
+    std::function<bool(size_t g)> seam_kept;
+    std::function<int(size_t g)> device;
+  };
   ShardedBamSelect(const std::string& path, const std::vector<Shard>& shards, int32_t n_ref, int64_t skip, int feeders, int64_t batch_bytes,
                    const std::vector<size_t>& cuts)
-      : path_(path), shards_(shards), n_ref_(n_ref), skip_(skip), feeders_(feeders), batch_bytes_(batch_bytes) {
-    const size_t n = cuts.size() - 1;
-    regions_.resize(n);
-    for (size_t g = 0; g < n; ++g) {
-      regions_[g].begin = cuts[g]; regions_[g].end = g + 1 < n ? cuts[g + 1] : 0;
-      launch(g, g > 0, std::vector<uint8_t>());
-    }
+      : path_(path), n_ref_(n_ref), skip_(skip), feeders_(feeders), batch_bytes_(batch_bytes) {
+    hooks_.run = [shards](size_t g, bool seam) {
+      const Shard S = shards[g % shards.size()];
+      svdss_bam_store_t* store = seam ? S.seam_store : S.store;
+      return DeviceBamSelect::RunFn([S, store, seam](svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, size_t, int32_t n_chunks,
+                                                     const uint8_t* const* comp, const int64_t* comp_bytes, const svdss_bgzf_block_t* const* blocks,
+                                                     const uint32_t* const* crc, const int64_t* n_blocks, svdss_bam_batch_t** batch) {
+        if (seam && store) svdss_bam_store_reset(store);
+        return svdss_bam_select_store_run(s, seq, is_last, skip, S.filter, store, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, batch);
+      });
+    };
+    hooks_.again = [shards](size_t g) { if (shards[g % shards.size()].store) svdss_bam_store_reset(shards[g % shards.size()].store); };
+    hooks_.seam_kept = [shards](size_t g) { return shards[g % shards.size()].seam_store != nullptr; };
+    hooks_.device = [shards](size_t g) { return shards[g % shards.size()].device; };
+    start(cuts);
+  }
+  ShardedBamSelect(const std::string& path, const Hooks& hooks, int32_t n_ref, int64_t skip, int feeders, int64_t batch_bytes, const std::vector<size_t>& cuts)
+      : path_(path), hooks_(hooks), n_ref_(n_ref), skip_(skip), feeders_(feeders), batch_bytes_(batch_bytes) {
+    start(cuts);
   }
   size_t n_regions() const { return regions_.size(); }
   int64_t seams_run() const { return n_seams_; }
@@ -434,32 +459,31 @@ class ShardedBamSelect {
     bool entered = false, seam_stored = false;
     int64_t n_batches = 0;
   };
-  DeviceBamSelect::RunFn run_fn(size_t g, svdss_bam_store_t* store) const {
-    svdss_bam_filter_t* f = shards_[g % shards_.size()].filter;
-    return [f, store](svdss_bam_stream_t* s, int64_t seq, int32_t is_last, int64_t skip, size_t, int32_t n_chunks, const uint8_t* const* comp,
-                      const int64_t* comp_bytes, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* n_blocks,
-                      svdss_bam_batch_t** batch) {
-      return svdss_bam_select_store_run(s, seq, is_last, skip, f, store, n_chunks, comp, comp_bytes, blocks, crc, n_blocks, batch);
-    };
+  void start(const std::vector<size_t>& cuts) {
+    const size_t n = cuts.size() - 1;
+    regions_.resize(n);
+    for (size_t g = 0; g < n; ++g) {
+      regions_[g].begin = cuts[g]; regions_[g].end = g + 1 < n ? cuts[g + 1] : 0;
+      launch(g, g > 0, std::vector<uint8_t>());
+    }
   }
   void launch(size_t g, bool open_start, const std::vector<uint8_t>& carry) {
-    const Shard& S = shards_[g % shards_.size()];
     DeviceBamSelect::Region rg;
     rg.begin = regions_[g].begin; rg.end = regions_[g].end;
     rg.open_start = open_start; rg.open_end = g + 1 < regions_.size();
     rg.carry = carry;
     rg.loaders = regions_.size() > 1 ? std::max(2, 8 / (int)std::min<size_t>(regions_.size(), 4)) : 8;
     rg.pending = g == 0 ? 64 : (size_t)1 << 30;       // (a later region's results wait in memory until the regions in front are handed out)
-    const std::vector<svdss_bam_filter_t*> one(1, S.filter);
-    const std::vector<int> dev(1, S.device);
-    regions_[g].sel.reset(new DeviceBamSelect(path_, one, dev, n_ref_, g == 0 ? skip_ : 0, feeders_, batch_bytes_, run_fn(g, S.store), DeviceBamSelect::CollectFn(),
-                                              nullptr, rg));
+    const std::vector<svdss_bam_filter_t*> one(1, nullptr);
+    const std::vector<int> dev(1, hooks_.device ? hooks_.device(g) : 0);
+    regions_[g].sel.reset(new DeviceBamSelect(path_, one, dev, n_ref_, g == 0 ? skip_ : 0, feeders_, batch_bytes_, hooks_.run(g, false),
+                                              hooks_.collect ? hooks_.collect(g, false) : DeviceBamSelect::CollectFn(),
+                                              hooks_.stream ? hooks_.stream(g) : nullptr, rg));
   }
   // the seam in front of region g, proved; false = the run has failed (err_)
   bool enter(size_t g) {
     Reg& P = regions_[g - 1];
     Reg& R = regions_[g];
-    const Shard& S = shards_[g % shards_.size()];
     P.sel->wait_finished();
     const uint8_t *tail = nullptr, *head = nullptr;
     const int64_t n_tail = svdss_bam_stream_tail(P.sel->stream(), &tail);
@@ -468,7 +492,7 @@ class ShardedBamSelect {
     bool good = R.sel->error().empty();
     if (good) {
       const int64_t n_head = svdss_bam_stream_head(R.sel->stream(), &head);
-      if ((int64_t)carry.size() + n_head > 0) { good = run_seam(g, carry, head, n_head, S); ++n_seams_; }
+      if ((int64_t)carry.size() + n_head > 0) { good = run_seam(g, carry, head, n_head); ++n_seams_; }
     }
     if (!good) {
       if (!err_.empty()) return false;
@@ -476,14 +500,14 @@ class ShardedBamSelect {
       R.sel->wait_finished();
       R.sel.reset();
       R.seam.reset();
-      if (S.store) svdss_bam_store_reset(S.store);
+      if (hooks_.again) hooks_.again(g);
       ++n_reruns_;
       launch(g, false, carry);
     }
     P.sel.reset();       // (its stream's tail has been copied)
     return true;
   }
-  bool run_seam(size_t g, const std::vector<uint8_t>& tail, const uint8_t* head, int64_t n_head, const Shard& S) {
+  bool run_seam(size_t g, const std::vector<uint8_t>& tail, const uint8_t* head, int64_t n_head) {
     std::vector<uint8_t> bytes(tail);
     if (n_head > 0) bytes.insert(bytes.end(), head, head + n_head);
     std::vector<uint8_t> comp;
@@ -509,19 +533,21 @@ class ShardedBamSelect {
     const int64_t cb = (int64_t)comp.size(), nb = (int64_t)blk.size();
     const svdss_bgzf_block_t* bp = blk.data();
     const uint32_t* rp = crc.data();
-    if (S.seam_store) svdss_bam_store_reset(S.seam_store);
-    const int rc = svdss_bam_select_store_run(st, 0, 1, 0, S.filter, S.seam_store, 1, &cp, &cb, &bp, &rp, &nb, &batch);
+    const int rc = hooks_.run(g, true)(st, 0, 1, 0, 0, 1, &cp, &cb, &bp, &rp, &nb, &batch);
     bool ok = rc == SVDSS_OK;
     if (ok) {
       std::unique_ptr<SelectedBatch> out(new SelectedBatch);
-      svdss_bam_selection_t r;
-      (void)svdss_bam_batch_selection(batch, &r);
-      out->n_records = (uint64_t)r.n_records;
-      out->slim = r.slim != 0;
-      out->off.assign(r.rec_off, r.rec_off + r.n_selected + 1);
-      out->bytes.assign(r.bytes, r.bytes + r.n_bytes);
+      if (hooks_.collect && hooks_.collect(g, true)) hooks_.collect(g, true)(batch, *out);
+      else {
+        svdss_bam_selection_t r;
+        (void)svdss_bam_batch_selection(batch, &r);
+        out->n_records = (uint64_t)r.n_records;
+        out->slim = r.slim != 0;
+        out->off.assign(r.rec_off, r.rec_off + r.n_selected + 1);
+        out->bytes.assign(r.bytes, r.bytes + r.n_bytes);
+      }
       regions_[g].seam = std::move(out);
-      regions_[g].seam_stored = S.seam_store != nullptr;
+      regions_[g].seam_stored = hooks_.seam_kept && hooks_.seam_kept(g);
     } else if (rc != SVDSS_EIO) {
       err_ = std::string("seam: ") + svdss_strerror(rc) + " " + (batch ? svdss_bam_batch_error(batch) : "") + " " + svdss_last_hip_error();
     }
@@ -537,7 +563,7 @@ class ShardedBamSelect {
   }
 
   std::string path_;
-  std::vector<Shard> shards_;
+  Hooks hooks_;
   int32_t n_ref_ = 0;
   int64_t skip_ = 0;
   int feeders_ = 3;

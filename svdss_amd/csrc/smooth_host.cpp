@@ -240,7 +240,19 @@ int main_smooth(const CallOptions& o) {
     const int per_gpu = getenv("SVDSS_SEARCH_FEEDERS") ? std::max(1, atoi(getenv("SVDSS_SEARCH_FEEDERS"))) : 6;
     const std::vector<svdss_bam_filter_t*> one(1, nullptr);
     const std::vector<int> dev0(1, 0);
-    svdss_bam_smooth_t* sm = nullptr;
+    // --gpus N (round 6): the file's regions, one per GPU (ShardedBamSelect, bam_device_select.h: the machinery of `SVDSS call
+    // --gpus N`) -- every region has its own loaders, feeding threads and record stream, and every GPU its copy of the
+    // chromosomes; SVDSS_GPUS_OVERSUBSCRIBE puts the N regions on the GPUs there are.  The records and their order are those
+    // of one GPU's run; the BGZF members are not cut at the same bytes: a region ends with a short member where one GPU's
+    // stream would have gone on filling it, and the record a seam completes is a member of its own (`gzip -dc` of the two
+    // files is the same).
+    const int n_phys = std::max(1, svdss_device_count());
+    const int n_g = std::max(1, getenv("SVDSS_GPUS_OVERSUBSCRIBE") ? o.gpus : std::min(o.gpus, n_phys));
+    const std::vector<size_t> cuts = n_g > 1 ? plan_bam_regions(o.bam, n_g, skip) : std::vector<size_t>{0, 0};
+    const size_t n_regions = cuts.size() - 1;
+    const size_t n_sm = std::min<size_t>(n_regions, (size_t)n_phys);
+    std::vector<svdss_bam_smooth_t*> sms(n_sm, nullptr);
+    std::vector<svdss_ref_t*> drefs(n_sm, nullptr);
     double al_accuracy = 0.0;
     // The reader of the smoothing pass starts FIRST: its loaders page-lock their slabs and read ahead while the reference
     // goes up and the accuracy pass runs; its feeding threads wait at this gate for the threshold.
@@ -298,15 +310,19 @@ int main_smooth(const CallOptions& o) {
     pool.max_n = per_gpu + 6;
     pool.buf.assign((size_t)pool.max_n, nullptr);
     static thread_local int tl_slot = -1;
-    DeviceBamSelect::RunFn run = [&](svdss_bam_stream_t* st, int64_t seq, int32_t last, int64_t sk, size_t, int32_t nc, const uint8_t* const* comp,
-                                    const int64_t* cb, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* nb,
-                                    svdss_bam_batch_t** batch) {
-      { std::unique_lock<std::mutex> lk(gate.m); gate.cv.wait(lk, [&] { return gate.open; }); }
-      tl_slot = pool.take();
-      const int rc = svdss_bam_smooth_run(st, seq, last, sk, sm, al_accuracy, tl_slot >= 0 ? pool.buf[(size_t)tl_slot] : nullptr,
-                                          tl_slot >= 0 ? (int64_t)pool.cap : 0, nc, comp, cb, blocks, crc, nb, batch);
-      if (rc != SVDSS_OK && tl_slot >= 0) { pool.give(tl_slot); tl_slot = -1; }
-      return rc;
+    // (the pool is the first region's: a later region's members wait in plain memory until the regions in front are written,
+    // and would hold every buffer of the pool while the first region's feeders wait for one)
+    auto run_for = [&](size_t g, bool use_pool) {
+      return DeviceBamSelect::RunFn([&, g, use_pool](svdss_bam_stream_t* st, int64_t seq, int32_t last, int64_t sk, size_t, int32_t nc, const uint8_t* const* comp,
+                                                     const int64_t* cb, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* nb,
+                                                     svdss_bam_batch_t** batch) {
+        { std::unique_lock<std::mutex> lk(gate.m); gate.cv.wait(lk, [&] { return gate.open; }); }
+        tl_slot = use_pool ? pool.take() : -1;
+        const int rc = svdss_bam_smooth_run(st, seq, last, sk, sms[g % sms.size()], al_accuracy, tl_slot >= 0 ? pool.buf[(size_t)tl_slot] : nullptr,
+                                            tl_slot >= 0 ? (int64_t)pool.cap : 0, nc, comp, cb, blocks, crc, nb, batch);
+        if (rc != SVDSS_OK && tl_slot >= 0) { pool.give(tl_slot); tl_slot = -1; }
+        return rc;
+      });
     };
     DeviceBamSelect::CollectFn collect = [&](const svdss_bam_batch_t* b, SelectedBatch& out) {
       svdss_bam_smoothed_t r;
@@ -323,7 +339,18 @@ int main_smooth(const CallOptions& o) {
       out.inflate_kernel_s = r.inflate_kernel_ms * 1e-3;
     };
     if (dbg) fprintf(stderr, "[smooth] BAM header read, output prefix set at +%.3f s\n", since());
-    std::unique_ptr<DeviceBamSelect> rd(new DeviceBamSelect(o.bam, one, dev0, n_ref, skip, per_gpu, target, run, collect, stream));
+    std::unique_ptr<DeviceBamSelect> rd;
+    std::unique_ptr<ShardedBamSelect> rds;
+    if (n_regions == 1) rd.reset(new DeviceBamSelect(o.bam, one, dev0, n_ref, skip, per_gpu, target, run_for(0, true), collect, stream));
+    else {
+      ShardedBamSelect::Hooks hk;
+      hk.run = [&](size_t g, bool seam) { return run_for(g, g == 0 && !seam); };
+      hk.collect = [&](size_t, bool) { return collect; };
+      // (the output's header is in front of the first region's stream; the first region never runs again)
+      hk.stream = [&](size_t g) { svdss_bam_stream_t* st = g == 0 ? stream : nullptr; if (g == 0) stream = nullptr; return st; };
+      hk.device = [&](size_t g) { return (int)(g % (size_t)n_phys); };
+      rds.reset(new ShardedBamSelect(o.bam, hk, n_ref, skip, per_gpu, target, cuts));
+    }
     if (dbg) fprintf(stderr, "[smooth] reader of the smoothing pass started at +%.3f s\n", since());
     // the chromosomes the BAM names, in its order, one device buffer (svdss_ref_upload_parts: no concatenation on the host)
     std::vector<int32_t> tid_map(names.size(), -1);
@@ -336,12 +363,20 @@ int main_smooth(const CallOptions& o) {
       parts.push_back((const uint8_t*)it->second.data());
       plen.push_back((int64_t)it->second.size());
     }
-    svdss_ref_t* dref = nullptr;
-    if (svdss_ref_upload_parts(parts.data(), plen.data(), (int32_t)parts.size(), 0, &dref) != SVDSS_OK)
-      die(std::string("svdss_ref_upload_parts: ") + svdss_last_hip_error());
-    if (dbg) fprintf(stderr, "[smooth] chromosomes uploaded at +%.3f s\n", since());
-    if (svdss_bam_smooth_create(dref, tid_map.data(), (int32_t)tid_map.size(), (int32_t)o.min_mapq, &sm) != SVDSS_OK)
-      die(std::string("svdss_bam_smooth_create: ") + svdss_last_hip_error());
+    {
+      std::vector<int> rcs(n_sm, SVDSS_OK);
+      std::vector<std::thread> up;
+      auto upload = [&](size_t d) {
+        rcs[d] = svdss_ref_upload_parts(parts.data(), plen.data(), (int32_t)parts.size(), (int)d, &drefs[d]);
+        if (rcs[d] == SVDSS_OK) rcs[d] = svdss_bam_smooth_create(drefs[d], tid_map.data(), (int32_t)tid_map.size(), (int32_t)o.min_mapq, &sms[d]);
+      };
+      for (size_t d = 1; d < n_sm; ++d) up.emplace_back(upload, d);
+      upload(0);
+      for (std::thread& t : up) t.join();
+      for (size_t d = 0; d < n_sm; ++d)
+        if (rcs[d] != SVDSS_OK) die(std::string("chromosomes to GPU ") + std::to_string(d) + ": " + svdss_strerror(rcs[d]) + " " + svdss_last_hip_error());
+    }
+    if (dbg) fprintf(stderr, "[smooth] chromosomes uploaded at +%.3f s (%zu GPU(s), %zu region(s))\n", since(), n_sm, n_regions);
     if (dbg) fprintf(stderr, "[smooth] reference read in %.3f s, on the device at +%.3f s\n", fasta_s, since());
     // compute_maxaccuracy (smoother.cpp:259-346): the mismatch rates of the first 10,000 records that fit, their percentile
     {
@@ -349,7 +384,7 @@ int main_smooth(const CallOptions& o) {
       DeviceBamSelect::RunFn mrun = [&](svdss_bam_stream_t* st, int64_t seq, int32_t last, int64_t sk, size_t, int32_t nc, const uint8_t* const* comp,
                                        const int64_t* cb, const svdss_bgzf_block_t* const* blocks, const uint32_t* const* crc, const int64_t* nb,
                                        svdss_bam_batch_t** batch) {
-        return svdss_bam_smooth_measure(st, seq, last, sk, sm, nc, comp, cb, blocks, crc, nb, batch);
+        return svdss_bam_smooth_measure(st, seq, last, sk, sms[0], nc, comp, cb, blocks, crc, nb, batch);
       };
       DeviceBamSelect::CollectFn mcollect = [](const svdss_bam_batch_t* b, SelectedBatch& out) {
         svdss_bam_smoothed_t r;
@@ -422,7 +457,7 @@ int main_smooth(const CallOptions& o) {
       if (dbg) fprintf(stderr, "[smooth] streaming from +%.3f s\n", since());
       double st_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, inf_s = 0;
       off_t at = pos0 < 0 ? 0 : pos0;
-      while (std::unique_ptr<SelectedBatch> b = rd->next()) {
+      while (std::unique_ptr<SelectedBatch> b = rd ? rd->next() : rds->next()) {
         const auto t0 = std::chrono::steady_clock::now();
         const size_t nb = b->ext ? b->ext_n : b->bytes.size();
         n_rec += b->n_records; n_kept += b->n_kept; out_bytes += nb;
@@ -448,8 +483,12 @@ int main_smooth(const CallOptions& o) {
       wcv.notify_all();
       for (std::thread& t : writers) t.join();
       if (seekable && lseek(STDOUT_FILENO, at, SEEK_SET) < 0) write_ok = false;   // (the EOF marker goes behind the last batch)
-      const std::string rerr = rd->error();
+      const std::string rerr = rd ? rd->error() : rds->error();
+      if (rds && dbg)
+        fprintf(stderr, "[smooth] %zu regions on %zu GPU(s): %lld seam(s) proved, %lld region(s) run again\n", rds->n_regions(), n_sm, (long long)rds->seams_run(),
+                (long long)rds->regions_run_again());
       rd.reset();
+      rds.reset();
       for (uint8_t* q : pool.buf) if (q) svdss_host_free(q);
       if (!rerr.empty()) die("error reading " + o.bam + ": " + rerr);
       if (dbg)
@@ -461,8 +500,8 @@ int main_smooth(const CallOptions& o) {
     }
     static const uint8_t eof_marker[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (fwrite(eof_marker, 1, 28, stdout) != 28 || fflush(stdout) != 0) write_ok = false;
-    svdss_bam_smooth_free(sm);
-    svdss_ref_free(dref);
+    for (svdss_bam_smooth_t* q : sms) svdss_bam_smooth_free(q);
+    for (svdss_ref_t* q : drefs) svdss_ref_free(q);
     if (!write_ok) die("error writing the BAM to stdout");
     if (dbg) fprintf(stderr, "[smooth] done at +%.3f s\n", since());
     if (!getenv("SVDSS_CLEAN_EXIT")) {

@@ -9,7 +9,7 @@
 //   SVDSS --version                                     (main.cpp:45-47)
 // SFS text goes to stdout exactly as PingPong::output_batch prints it
 // (ping_pong.cpp:213-236), logs to stderr, fatal conditions exit(1).
-// Additions of this program: --gpus N (search, call), --io-threads N, --verbose stage timings.
+// Additions of this program: --gpus N (search, call, smooth), --io-threads N, --verbose stage timings.
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -1431,7 +1431,7 @@ int main(int argc, char** argv) {
     } else if (!strcmp(argv[1], "smooth")) {
       if (o.reference.empty() || o.bam.empty()) { fputs(SMOOTH_USAGE, stderr); return EXIT_FAILURE; }   // main.cpp:73-76
       CallOptions c;
-      c.reference = o.reference; c.bam = o.bam; c.threads = o.threads; c.min_mapq = o.min_mapq; c.accp = o.accp;
+      c.reference = o.reference; c.bam = o.bam; c.threads = o.threads; c.min_mapq = o.min_mapq; c.accp = o.accp; c.gpus = o.gpus;
       main_smooth(c);
     } else {
       fputs(MAIN_USAGE, stderr);

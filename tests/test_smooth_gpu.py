@@ -95,3 +95,26 @@ def test_device_path_writes_the_bytes_of_the_host_paths(tmp_path):
     assert len(outs["host"]) > 100000
     for tag in outs:
         assert outs[tag] == outs["host"], tag
+    # --gpus N (round 6): the file's regions, one per GPU (two or three of them on the one GPU of this box).  The records and
+    # their order are the single GPU's; the BGZF members are not cut at the same bytes (a region ends with a short member, a
+    # seam's record is a member of its own): the inflated streams are compared.  SVDSS_REGION_TEST makes the guesses at the
+    # regions' starts fail (1: no record there; 2: a head one byte short): those regions run again from the known carry.
+    import gzip
+    import re
+    want = gzip.decompress(outs["host"])
+    small = {"SVDSS_GPUS_OVERSUBSCRIBE": "1", "SVDSS_REGION_MIN_KB": "256", "SVDSS_BAM_BATCH_MB": "1", "SVDSS_BAM_SLAB_KB": "64", "SVDSS_DEBUG": "1"}
+    for gpus, env, reruns in (("2", {}, 0), ("3", {"SVDSS_SEARCH_FEEDERS": "2"}, 0), ("4", {"SVDSS_REGION_TEST": "1"}, 3),
+                              ("2", {"SVDSS_REGION_TEST": "2"}, 1)):
+        r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam), "--threads", "4", "--min-mapq", "20", "--gpus", gpus],
+                           capture_output=True, timeout=900, env=dict(os.environ, **small, **env))
+        assert r.returncode == 0, r.stderr.decode()
+        m = re.search(rb"(\d+) regions on 1 GPU\(s\): (\d+) seam\(s\) proved, (\d+) region\(s\) run again", r.stderr)
+        assert m and int(m.group(1)) == int(gpus) and int(m.group(3)) == reruns, r.stderr.decode()[-800:]
+        assert r.stdout[-28:] == outs["host"][-28:] and gzip.decompress(r.stdout) == want, (gpus, env)
+    # ... and into a regular file (the side-by-side writers)
+    out = tmp_path / "sharded.bam"
+    with open(out, "wb") as fh:
+        r = subprocess.run([BIN, "smooth", "--reference", str(fa), "--bam", str(bam), "--threads", "4", "--min-mapq", "20", "--gpus", "3"],
+                           stdout=fh, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, **small))
+    assert r.returncode == 0, r.stderr.decode()
+    assert gzip.decompress(out.read_bytes()) == want
