@@ -223,6 +223,136 @@ SVDSS_HD void sv_flush(SvLane<P>& s, bool assemble, Emit&& emit) {
   }
 }
 
+// sv_decide without its branches (round 6; the kernels that carry no BS code).  A wavefront executes the union of the
+// paths its 64 lanes take, and nearly every pass has a lane on every path: as a tree of early returns sv_decide cost ~650
+// instructions per pass, two thirds of them exec-mask bookkeeping and the copies that merge (op, a) at every join
+// (profiles/r06af_*).  Here every lane computes the predicates of all paths and the results are selected; the branches
+// left are the one around the record store of a forward phase's end and the rare single-symbol phase start.  Same decisions,
+// same state, same order of the LFC increment and the window checks as sv_decide below -- tests/lane_emulator.cpp runs
+// this form whenever BS is off.
+template <class P, class Emit>
+SVDSS_HD SvOp sv_decide_flat(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, int64_t off, bool assemble, Emit&& emit,
+                             bool can_peek, bool use_set) {
+  const int K = ix.k;
+  const bool has_sa = ix.sa != nullptr;
+  int op = SV_OP_DONE;
+  int64_t a = 0;
+  for (;;) {
+    const int mode = s.mode;
+    const bool usable = s.len > 0 && !(mode & SV_M_PARTIAL);
+    const bool peeking = usable && (mode & SV_M_PEEK);
+    const bool live = usable && !(mode & SV_M_PEEK);
+    const bool tmode = (mode & (SV_M_SET | SV_M_TEXT)) != 0;
+    const bool dir = (mode & SV_M_DIR) != 0;
+    const bool nonempty = s.hi > s.lo;
+    const bool body = live && !tmode;
+    const bool mid = body && !(mode & SV_M_START);          // inside a phase: an interval to look at
+    const bool walk = mid && nonempty && (dir || s.pos > 0);
+    const bool bend = mid && !nonempty && !dir;             // backward phase over (ping_pong.cpp:28)
+    const bool fend = mid && !nonempty && dir;              // forward phase over (:38-47)
+    op = peeking ? SV_OP_PEEK : SV_OP_DONE;                 // (mid && nonempty && !dir && pos == 0 stays DONE, :24)
+    if (live && tmode) op = (mode & SV_M_SET) ? SV_OP_SET : ((off + s.pos >= 64) ? SV_OP_TEXT : SV_OP_TEXT_SLOW);
+    // -- inside a phase, interval not empty: the next extension (:15-22 / :31-37)
+    {
+      const uint64_t sz = (uint64_t)(s.hi - s.lo);
+      const bool few = (mode & SV_M_FEWSET) != 0;
+      const bool one = sz == 1 && has_sa;
+      const bool small = use_set && sz <= (uint64_t)SV_SET_MAX && has_sa && off >= 64;
+      const bool ripe = ((mode & SV_LFC_MASK) >> SV_LFC_SHIFT) >= SV_SET_AFTER;
+      const bool bw = walk && !dir;
+      const bool w_saset = bw && (few || (!one && small && ripe));
+      const bool w_sa = bw && !few && one;
+      const bool w_inc = bw && !few && !one && small && !ripe;
+      const bool w_lf = walk && !w_saset && !w_sa;
+      const int np = dir ? s.pos + 1 : s.pos - 1;
+      const bool np_in = np >= s.wrel && np < s.wrel + 64;
+      const bool w_fill = w_lf && !np_in && (!dir || np < s.len);
+      const bool w_do = w_lf && !w_fill;
+      const int sym = sv_ring_sym(g, off + np);
+      const int cnew = dir ? svdss_comp(np < s.len ? sym : 0) : sym;
+      if (w_inc) s.mode = mode + (1 << SV_LFC_SHIFT);
+      if (w_do) { s.pos = np; s.c = cnew; }
+      if (w_saset) op = SV_OP_SA_SET;
+      if (w_sa) op = SV_OP_SA;
+      if (w_fill) op = SV_OP_FILL;
+      if (w_do) op = SV_OP_LF;
+      if (w_saset || w_sa) a = (int64_t)s.lo;
+      if (w_fill) a = (off + np - (dir ? 24 : 40)) >> 4;
+    }
+    // -- a phase is over
+    bool go = body && (mode & SV_M_START);
+    if (bend) {
+      s.begin = s.pos;
+      s.mode = (mode & ~SV_LFC_MASK) | SV_M_DIR | SV_M_START;
+      go = true;
+    }
+    {
+      // the SFS [begin, pos] (:38-41) through the streaming assembler (sv_emit), as selects around ONE record store
+      const int qs = s.begin, l = s.pos - s.begin + 1;
+      const bool chain = (mode & SV_M_CHAIN) != 0;
+      const bool joins = assemble && chain && qs + l > s.chain_lo;
+      const bool store = fend && (!assemble || (chain && !joins));
+      if (store) emit(s.n_sfs, assemble ? s.chain_lo : qs, assemble ? s.chain_end - s.chain_lo : l);
+      if (store) ++s.n_sfs;
+      const bool open = fend && assemble && !joins;         // a new chain opens with this SFS
+      if (fend && assemble) s.chain_lo = qs;
+      if (open) s.chain_end = qs + l;
+      int m2 = open ? (mode | SV_M_CHAIN) : mode;
+      const bool below = fend && qs != 0 && qs < s.stop_lo;
+      const bool peek = below && can_peek;                  // ask the neighbour before going on
+      const bool count = below && !can_peek;
+      const int nb = s.n_below + 1;
+      const bool partial = count && nb >= SV_OVERRUN;       // segment finished; the stitcher takes over
+      const bool next = fend && qs != 0 && !peek && !partial;   // (qs == 0: :42 -> DONE)
+      if (count) s.n_below = nb;
+      if (peek) { m2 |= SV_M_PEEK; s.c = 0; op = SV_OP_PEEK; }
+      if (partial) m2 |= SV_M_PARTIAL;
+      if (next) {
+        s.pos = s.pos - 1;                                  // :47
+        m2 = (m2 & ~(SV_M_DIR | SV_LFC_MASK)) | SV_M_START;
+        go = true;
+      }
+      if (fend) s.mode = m2;
+    }
+    // -- a phase starts (backward :12, forward :30): its first K symbols through the table
+    bool single = false;
+    {
+      const bool dir2 = (s.mode & SV_M_DIR) != 0;
+      const int st = s.pos;
+      const int first = dir2 ? st : st - K + 1;             // lowest read position of the K-mer
+      const bool ok = K > 0 && first >= 0 && first + K <= s.len;
+      const bool kin = first >= s.wrel && first + K <= s.wrel + 64;   // the K symbols are resident
+      uint32_t key = 0;
+      const bool good = sv_ring_kmer(g, off + first, K, key);
+      const bool tab = go && ok && kin && good;
+      const bool kfill = go && ok && !kin;
+      single = go && !tab && !kfill;
+      if (tab) { op = SV_OP_TABLE; a = (int64_t)(dir2 ? sv_key_revcomp(key, K) : key); }
+      if (kfill) { op = SV_OP_FILL; a = (off + first - 20) >> 4; }
+    }
+    if (!single) break;
+    // fewer than K symbols left in this direction, or an N among them: start from the single symbol like the
+    // reference does (rb3_fmd_set_intv, :12 / :30), then once more through the body
+    {
+      const int st = s.pos;
+      if (!sv_in_window(s, st)) {
+        op = SV_OP_FILL;
+        a = (off + st - 24) >> 4;
+        break;
+      }
+      int c = sv_ring_sym(g, off + st);
+      if (s.mode & SV_M_DIR) c = svdss_comp(c);
+      s.lo = (P)svdss_acc(ix, c);
+      s.hi = (P)svdss_acc(ix, c + 1);
+      s.mode &= ~(SV_M_START | SV_M_BS_OK);
+    }
+  }
+  SvOp o;
+  o.op = op;
+  o.a = a;
+  return o;
+}
+
 // Decide the one memory operation of this iteration.  `off` = absolute buffer
 // position of the read's first symbol.  ALU + ring (LDS) reads only.
 //
@@ -234,6 +364,9 @@ SVDSS_HD void sv_flush(SvLane<P>& s, bool assemble, Emit&& emit) {
 template <class P, class Emit>
 SVDSS_HD SvOp sv_decide(SvLane<P>& s, const SvdssDevIndex& ix, const SvRing& g, int64_t off,
                         bool assemble, Emit&& emit, bool can_peek = false, bool use_set = false, bool use_bs = true) {
+#ifndef SV_DECIDE_TREE   // (developer build: the tree of early returns everywhere, for an A/B)
+  if (!use_bs) return sv_decide_flat(s, ix, g, off, assemble, emit, can_peek, use_set);
+#endif
   SvOp o;
   o.op = SV_OP_DONE;
   o.a = 0;

@@ -74,7 +74,7 @@ int64_t emu2_run(const svdss_index* ix, const uint8_t* reads_padded, const int64
     sv_lane_init(st, (int32_t)l, start_pos, stop_lo);
     for (int64_t guard = 0;; ++guard) {
       if (guard > 400 * l + 10000) { fprintf(stderr, "emu2: no termination off=%ld l=%ld start=%d stop=%d pos=%d begin=%d mode=%d lo=%ld hi=%ld wrel=%d nsfs=%d\n", (long)off, (long)l, start_pos, stop_lo, st.pos, st.begin, st.mode, (long)st.lo, (long)st.hi, st.wrel, st.n_sfs); abort(); }
-      SvOp o = sv_decide(st, v, g, off, asm_, emit, left != nullptr, use_set);
+      SvOp o = sv_decide(st, v, g, off, asm_, emit, left != nullptr, use_set, use_bs);   // (BS off: sv_decide_flat)
       if (op_counts) op_counts[o.op]++;
       if (o.op == SV_OP_DONE) break;
       if (o.op == SV_OP_TEXT_SLOW) { sv_apply_text_slow(st, v.text, reads_padded, off); continue; }
