@@ -512,6 +512,10 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
     for (int64_t s = cluster_off[c]; s < cluster_off[c + 1]; ++s) maxl = std::max(maxl, seq_off[s + 1] - seq_off[s]);
     batch_max_work = std::max(batch_max_work, (cluster_off[c + 1] - cluster_off[c]) * maxl);
   }
+  // A sub-cluster the first stage hands back because a row got wider than its lanes hold goes straight to the round that has
+  // wider rows when round 0's rows are no wider than the first stage's were (`call` at 30x: one such sub-cluster of 21,500
+  // cost a round of 39 ms that could only fail the same way)
+  std::vector<uint8_t> round0_no_wider((size_t)n_clusters, 0), skip_round0((size_t)n_clusters, 0);
   for (int round = use_quad ? -1 : 0; round < n_rounds && !cur.empty(); ++round) {
     const bool quad = round < 0;
     struct Cand { int64_t c; size_t lds; int cols; int gw; PoaWaveTask t; };
@@ -563,9 +567,11 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
           continue;
         }
         t.nc = (int32_t)nc; t.ec = (int32_t)ecap; t.max_len = (int32_t)maxl; t.ws = gw * qc; t.rs = 0; t.ring = 0;
+        round0_no_wider[(size_t)c] = wcap0 <= (int64_t)gw * qc ? 1 : 0;
         cands.push_back(Cand{c, poa_quad_lds_bytes(gw, qc, (int)maxl), qc, gw, t});
         continue;
       }
+      if (round == 0 && skip_round0[(size_t)c] && n_rounds > 1) { retry.push_back(c); continue; }
       int64_t ws = 64;
       while (ws < wcap) ws <<= 1;
       const int64_t rs = (wcap + 3) & ~(int64_t)3;
@@ -740,7 +746,7 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
             results[(size_t)g.ids[(size_t)k]].assign(src, src + lens[(size_t)k]);
           } else {
             const int reason = (st[(size_t)k] >> 8) & 7;
-            if (quad) retry.push_back(g.ids[(size_t)k]);
+            if (quad) { retry.push_back(g.ids[(size_t)k]); if (reason == 3 && round0_no_wider[(size_t)g.ids[(size_t)k]]) skip_round0[(size_t)g.ids[(size_t)k]] = 1; }
             else if (round + 1 < n_rounds && (reason == 3 || reason == 4 || reason == 5)) retry.push_back(g.ids[(size_t)k]);
             else { todo.push_back(g.ids[(size_t)k]); ++b->n_hbm; }
             ++why[reason];
