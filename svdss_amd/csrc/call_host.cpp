@@ -1313,7 +1313,8 @@ struct CallRun {
         }
         cl_off.push_back((int64_t)seq_off.size() - 1);
       }
-      std::vector<uint8_t> flat((size_t)seq_off.back());
+      // (not a vector: its zero-fill of ~1 GB on one thread was a fifth of this stage at 30x; the threads below write every byte)
+      struct Flat { std::unique_ptr<uint8_t[]> p; uint8_t* data() const { return p.get(); } uint8_t* begin() const { return p.get(); } } flat{std::unique_ptr<uint8_t[]>(new uint8_t[(size_t)seq_off.back() + 1])};
       {
         uint8_t lut[256];
         for (int c = 0; c < 256; ++c) lut[c] = enc26((char)c);
@@ -1350,13 +1351,19 @@ struct CallRun {
             co.push_back((int64_t)so.size() - 1);
           }
           svdss_poa_batch_t* pb = nullptr;
+          const auto tp0 = std::chrono::steady_clock::now();
           check(svdss_poa_consensus_batch(G == 1 ? flat.data() : f.data(), G == 1 ? seq_off.data() : so.data(),
                                           G == 1 ? cl_off.data() : co.data(), (int64_t)co.size() - 1, g % n_dev, &pb),
                 "svdss_poa_consensus_batch");
+          const auto tp1 = std::chrono::steady_clock::now();
           part_lens[(size_t)g].resize(co.size() - 1);
           part_cons[(size_t)g].resize((size_t)svdss_poa_batch_total(pb));
           check(svdss_poa_batch_fetch(pb, part_lens[(size_t)g].data(), part_cons[(size_t)g].data()), "svdss_poa_batch_fetch");
+          const auto tp2 = std::chrono::steady_clock::now();
           svdss_poa_batch_free(pb);
+          if (o.verbose && getenv("SVDSS_DEBUG"))
+            fprintf(stderr, "[call] [debug] POA shard %d: batch %.3f s, fetch %.3f s, free %.3f s\n", g, std::chrono::duration<double>(tp1 - tp0).count(),
+                    std::chrono::duration<double>(tp2 - tp1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count());
         };
         for (int g = 1; g < G; ++g) pool.emplace_back(run, g);
         run(0);

@@ -697,7 +697,12 @@ extern "C" int svdss_poa_consensus_batch(const uint8_t* seqs, const int64_t* seq
       size_t gend = gpos, tot_bytes = 0;
       while (gend < groups.size() && (gend == gpos || (groups[gend]->wave == groups[gpos]->wave && tot_bytes + groups[gend]->bytes() <= ws_budget)))
         tot_bytes += groups[gend++]->bytes();
-      HIPCHK3(b->ws_arena.reserve(tot_bytes));
+      {
+        const auto ta = std::chrono::steady_clock::now();
+        HIPCHK3(b->ws_arena.reserve(tot_bytes));
+        const double as = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+        if (getenv("SVDSS_DEBUG") && as > 0.005) fprintf(stderr, "[poa] workspace of %.1f GB taken in %.3f s\n", (double)tot_bytes / 1073741824.0, as);
+      }
       for (size_t gi = gpos; gi < gend; ++gi) {
         Group& g = *groups[gi];
         const size_t nt = g.tasks.size();
