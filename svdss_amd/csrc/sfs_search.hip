@@ -884,6 +884,11 @@ extern "C" int svdss_sfs_search_batch_device(const svdss_index_t* ix, const uint
     const int64_t want = 4 * lanes / (n_reads > 0 ? n_reads : 1);   // ~4 items per resident lane: short items bound the tail
     n_seg = (int)(want < 4 ? 1 : (want > 8 ? 8 : want));   // large batches fill the GPU with one lane per read; beyond 8
                                                               // the odd unstitchable read costs more than it saves
+    // On the rank blocks alone (no text, no suffix array: svdss_index_attach_blocks) a read is thousands of dependent rank steps
+    // whatever its segments do, and the reads such a search gets -- smoothed ones -- have too few SFS for their segments to be
+    // stitched at (27 % searched again at 30x): from half a lane-load of reads on, one lane per read (`search` at 30x: the two
+    // launches 0.44 -> 0.29 s, profiles/r06av_*)
+    if ((!ix->d_text || !ix->d_sa) && 2 * n_reads >= lanes) n_seg = 1;
     if (const char* e = getenv("SVDSS_SEGMENTS")) n_seg = atoi(e);
     if (n_seg < 1) n_seg = 1;
     if (n_seg > 16) n_seg = 16;
